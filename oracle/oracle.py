@@ -1,0 +1,162 @@
+"""ctypes loader for the two CPU checkers (svdf_oracle.h API).
+
+TEST INFRASTRUCTURE, NOT PRODUCT.  Import only from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  ``kind="port"`` loads oracle/libsvdf_oracle.so (the plain-C
+restatement), ``kind="reference"`` loads oracle/_ref/libsvdf_ref.so (the reference's own classes,
+compiled from /root/reference by oracle/Makefile).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_SO = os.path.join(HERE, "libsvdf_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libsvdf_ref.so")
+
+VIEW = {"u_bias": 0, "W_user": 1, "i_bias": 2, "W_item": 3, "g_bias": 4, "ufeedback_bias": 5, "W_ufeedback": 6}
+
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+
+
+def build(force=False):
+    """Compile the checkers (building the checker is not using it)."""
+    if force or not os.path.exists(PORT_SO) or (
+            os.path.exists("/root/reference/apex_svd.h") and not os.path.exists(REF_SO)):
+        subprocess.check_call(["make", "-C", HERE], stdout=subprocess.DEVNULL)
+
+
+def have_reference():
+    return os.path.exists(REF_SO)
+
+
+_libs = {}
+
+
+def _load(kind):
+    if kind in _libs:
+        return _libs[kind]
+    path = PORT_SO if kind == "port" else REF_SO
+    if not os.path.exists(path):
+        build()
+    lib = C.CDLL(path, mode=C.RTLD_LOCAL)
+    P = C.c_void_p
+    lib.svdo_create.restype = P
+    lib.svdo_create.argtypes = [C.c_int] * 4
+    lib.svdo_destroy.argtypes = [P]
+    lib.svdo_set_param.argtypes = [P, C.c_char_p, C.c_char_p]
+    lib.svdo_seed.argtypes = [C.c_uint]
+    for f in ("svdo_init_model", "svdo_init_trainer", "svdo_finish_round"):
+        getattr(lib, f).argtypes = [P]
+    lib.svdo_set_round.argtypes = [P, C.c_int]
+    lib.svdo_save_model_path.argtypes = [P, C.c_char_p, C.c_int]
+    lib.svdo_load_model_path.argtypes = [P, C.c_char_p, C.c_int]
+    lib.svdo_update_csr.argtypes = [P, C.c_float, C.c_int, C.c_int, C.c_int, _u32p, _f32p]
+    lib.svdo_predict_csr.argtypes = lib.svdo_update_csr.argtypes
+    lib.svdo_predict_csr.restype = C.c_float
+    lib.svdo_update_csr_batch.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p]
+    lib.svdo_predict_csr_batch.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p]
+    lib.svdo_update_block.argtypes = [P, C.c_int, C.c_int, _u32p, _f32p, C.c_int, _f32p, _i32p, _u32p, _f32p]
+    lib.svdo_predict_block.argtypes = lib.svdo_update_block.argtypes + [_f32p]
+    lib.svdo_get_view.argtypes = [P, C.c_int, _f32p, C.c_long]
+    lib.svdo_get_view.restype = C.c_long
+    lib.svdo_view_shape.argtypes = [P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.svdo_kind.restype = C.c_int
+    _libs[kind] = lib
+    return lib
+
+
+def _pad(a, dtype):
+    """ctypes ndpointer rejects zero-length views of some arrays; always hand over >=1 element."""
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a if a.size else np.zeros(1, dtype=dtype)
+
+
+class OracleTrainer:
+    """ISVDTrainer-shaped handle on one of the CPU checkers (apex_svd.h:33-107)."""
+
+    def __init__(self, kind="port", format_type=0, active_type=0, extend_type=0, variant_type=0, params=None):
+        self.kind = kind
+        self.lib = _load(kind)
+        self.h = self.lib.svdo_create(format_type, active_type, extend_type, variant_type)
+        for k, v in (params or {}).items():
+            self.set_param(k, v)
+
+    def close(self):
+        if self.h:
+            self.lib.svdo_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_param(self, name, val):
+        self.lib.svdo_set_param(self.h, str(name).encode(), str(val).encode())
+
+    def seed(self, s):
+        self.lib.svdo_seed(int(s))
+
+    def init_model(self):
+        self.lib.svdo_init_model(self.h)
+
+    def init_trainer(self):
+        self.lib.svdo_init_trainer(self.h)
+
+    def set_round(self, r):
+        self.lib.svdo_set_round(self.h, int(r))
+
+    def finish_round(self):
+        self.lib.svdo_finish_round(self.h)
+
+    def save_model(self, path, with_type_header=True):
+        assert self.lib.svdo_save_model_path(self.h, str(path).encode(), int(with_type_header)) == 0
+
+    def load_model(self, path, with_type_header=True):
+        assert self.lib.svdo_load_model_path(self.h, str(path).encode(), int(with_type_header)) == 0
+
+    def update_csr(self, label, ng, nu, ni, index, value):
+        self.lib.svdo_update_csr(self.h, float(label), ng, nu, ni, _pad(index, np.uint32), _pad(value, np.float32))
+
+    def predict_csr(self, label, ng, nu, ni, index, value):
+        return self.lib.svdo_predict_csr(self.h, float(label), ng, nu, ni, _pad(index, np.uint32), _pad(value, np.float32))
+
+    def update_batch(self, d):
+        self.lib.svdo_update_csr_batch(self.h, d.num_row, _pad(d.row_label, np.float32), _pad(d.row_ptr, np.int32),
+                                       _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32))
+
+    def predict_batch(self, d):
+        out = np.zeros(max(d.num_row, 1), dtype=np.float32)
+        self.lib.svdo_predict_csr_batch(self.h, d.num_row, _pad(d.row_label, np.float32), _pad(d.row_ptr, np.int32),
+                                        _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32), out)
+        return out[:d.num_row]
+
+    def update_block(self, b):
+        d = b.data
+        self.lib.svdo_update_block(self.h, b.num_ufeedback, b.extend_tag, _pad(b.index_ufeedback, np.uint32),
+                                   _pad(b.value_ufeedback, np.float32), d.num_row, _pad(d.row_label, np.float32),
+                                   _pad(d.row_ptr, np.int32), _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32))
+
+    def predict_block(self, b):
+        d = b.data
+        out = np.zeros(max(d.num_row, 1), dtype=np.float32)
+        self.lib.svdo_predict_block(self.h, b.num_ufeedback, b.extend_tag, _pad(b.index_ufeedback, np.uint32),
+                                    _pad(b.value_ufeedback, np.float32), d.num_row, _pad(d.row_label, np.float32),
+                                    _pad(d.row_ptr, np.int32), _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32), out)
+        return out[:d.num_row]
+
+    def view(self, name):
+        rows, cols = C.c_int(), C.c_int()
+        self.lib.svdo_view_shape(self.h, VIEW[name], C.byref(rows), C.byref(cols))
+        if rows.value < 0:
+            return None
+        out = np.zeros(max(rows.value * cols.value, 1), dtype=np.float32)
+        n = self.lib.svdo_get_view(self.h, VIEW[name], out, out.size)
+        assert n == rows.value * cols.value
+        out = out[:n]
+        return out.reshape(rows.value, cols.value) if cols.value > 1 or name.startswith("W_") else out

@@ -1,0 +1,197 @@
+/*
+ * ref_shim.cpp -- C wrapper (svdf_oracle.h API) around the REFERENCE's own solver classes.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  This file contains no reference code: it #includes the
+ * reference's public header from /root/reference (apex_svd.h) and is linked, by oracle/Makefile,
+ * against the reference's own translation units compiled where they lie
+ * (solvers/base-solver/apex_svd_base.cpp = the factory, apex_svd_data.cpp = data iterators).
+ * The result, oracle/_ref/libsvdf_ref.so, is git-ignored and is used only to validate the C
+ * restatement (svdf_oracle.c), to generate tests/golden/ and as bench.py's cpu_baseline
+ * (kind "reference").
+ *
+ * Objects are obtained exactly the way svd_feature.cpp:198-216 obtains them:
+ * apex_svd::create_svd_trainer(SVDTypeParam) and then only ISVDTrainer virtual calls.
+ */
+#define _GNU_SOURCE 1
+#include "apex_svd.h" /* -I/root/reference */
+#include "apex-tensor/apex_random.h"
+
+#include <unistd.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "svdf_oracle.h"
+
+using namespace apex_svd;
+
+struct svdo_trainer {
+    SVDTypeParam mtype;
+    ISVDTrainer *tr;
+};
+
+extern "C" {
+
+int svdo_kind(void) { return 2; }
+
+svdo_trainer *svdo_create(int format_type, int active_type, int extend_type, int variant_type) {
+    svdo_trainer *t = new svdo_trainer();
+    t->mtype.format_type = (uint8_t)format_type;
+    t->mtype.active_type = (uint8_t)active_type;
+    t->mtype.extend_type = (uint8_t)extend_type;
+    t->mtype.variant_type = (uint8_t)variant_type;
+    t->tr = create_svd_trainer(t->mtype);
+    return t;
+}
+void svdo_destroy(svdo_trainer *t) {
+    if (!t) return;
+    delete t->tr;
+    delete t;
+}
+void svdo_set_param(svdo_trainer *t, const char *name, const char *val) { t->tr->set_param(name, val); }
+void svdo_seed(unsigned seed) { apex_random::seed(seed); }
+void svdo_init_model(svdo_trainer *t) { t->tr->init_model(); }
+void svdo_init_trainer(svdo_trainer *t) { t->tr->init_trainer(); }
+void svdo_set_round(svdo_trainer *t, int nround) { t->tr->set_round(nround); }
+void svdo_finish_round(svdo_trainer *t) { t->tr->finish_round(); }
+
+int svdo_save_model_path(svdo_trainer *t, const char *path, int with_type_header) {
+    FILE *fo = fopen(path, "wb");
+    if (!fo) return -1;
+    if (with_type_header) fwrite(&t->mtype, sizeof(SVDTypeParam), 1, fo);
+    t->tr->save_model(fo);
+    fclose(fo);
+    return 0;
+}
+int svdo_load_model_path(svdo_trainer *t, const char *path, int with_type_header) {
+    FILE *fi = fopen(path, "rb");
+    if (!fi) return -1;
+    if (with_type_header) {
+        SVDTypeParam mt;
+        if (fread(&mt, sizeof(SVDTypeParam), 1, fi) != 1) { fclose(fi); return -1; }
+    }
+    /* this fork's load_from_file drops u_bias.txt etc. into the CWD (apex_svd_model.h:586-621);
+     * run it inside a scratch directory so the caller's CWD stays clean */
+    char cwd[4096];
+    char tmpl[] = "/tmp/svdf_ref_XXXXXX";
+    char *scratch = mkdtemp(tmpl);
+    bool moved = scratch && getcwd(cwd, sizeof(cwd)) && chdir(scratch) == 0;
+    t->tr->load_model(fi);
+    if (moved) {
+        const char *junk[] = {"u_bias.txt", "i_bias.txt", "w_user.txt", "w_item.txt"};
+        for (int i = 0; i < 4; i++) unlink(junk[i]);
+        if (chdir(cwd) != 0) { /* nothing sensible to do */ }
+        rmdir(scratch);
+    }
+    fclose(fi);
+    return 0;
+}
+
+static SVDFeatureCSR::Elem make_elem(float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
+    SVDFeatureCSR::Elem e;
+    e.label = label;
+    e.num_global = ng; e.num_ufactor = nu; e.num_ifactor = ni;
+    e.set_space(const_cast<unsigned *>(index), const_cast<float *>(value));
+    return e;
+}
+static SVDFeatureCSR make_csr(int num_row, const float *row_label, const int *row_ptr,
+                              const unsigned *feat_index, const float *feat_value) {
+    SVDFeatureCSR m;
+    m.num_row = num_row;
+    m.num_val = row_ptr[3 * num_row] - row_ptr[0];
+    m.row_label = const_cast<float *>(row_label);
+    m.row_ptr = const_cast<int *>(row_ptr);
+    m.feat_index = const_cast<unsigned *>(feat_index);
+    m.feat_value = const_cast<float *>(feat_value);
+    return m;
+}
+
+void svdo_update_csr(svdo_trainer *t, float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
+    t->tr->update(make_elem(label, ng, nu, ni, index, value));
+}
+float svdo_predict_csr(svdo_trainer *t, float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
+    return t->tr->predict(make_elem(label, ng, nu, ni, index, value));
+}
+void svdo_update_csr_batch(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                           const unsigned *feat_index, const float *feat_value) {
+    SVDFeatureCSR m = make_csr(num_row, row_label, row_ptr, feat_index, feat_value);
+    for (int r = 0; r < num_row; r++) t->tr->update(m[r]);
+}
+void svdo_predict_csr_batch(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                            const unsigned *feat_index, const float *feat_value, float *out) {
+    SVDFeatureCSR m = make_csr(num_row, row_label, row_ptr, feat_index, feat_value);
+    for (int r = 0; r < num_row; r++) out[r] = t->tr->predict(m[r]);
+}
+static SVDPlusBlock make_block(int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb,
+                               int num_row, const float *row_label, const int *row_ptr,
+                               const unsigned *feat_index, const float *feat_value) {
+    SVDPlusBlock b;
+    b.num_ufeedback = nfb;
+    b.extend_tag = extend_tag;
+    b.index_ufeedback = const_cast<unsigned *>(idx_fb);
+    b.value_ufeedback = const_cast<float *>(val_fb);
+    b.data = make_csr(num_row, row_label, row_ptr, feat_index, feat_value);
+    return b;
+}
+void svdo_update_block(svdo_trainer *t, int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb,
+                       int num_row, const float *row_label, const int *row_ptr,
+                       const unsigned *feat_index, const float *feat_value) {
+    t->tr->update(make_block(nfb, extend_tag, idx_fb, val_fb, num_row, row_label, row_ptr, feat_index, feat_value));
+}
+void svdo_predict_block(svdo_trainer *t, int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb,
+                        int num_row, const float *row_label, const int *row_ptr,
+                        const unsigned *feat_index, const float *feat_value, float *out) {
+    std::vector<float> p;
+    t->tr->predict(p, make_block(nfb, extend_tag, idx_fb, val_fb, num_row, row_label, row_ptr, feat_index, feat_value));
+    for (size_t i = 0; i < p.size(); i++) out[i] = p[i];
+}
+
+/* views are recovered from the bytes ISVDTrainer::save_model writes (layout: SURVEY.md section 5) */
+static bool dump_model(svdo_trainer *t, std::vector<char> &buf) {
+    char *mem = NULL;
+    size_t len = 0;
+    FILE *fo = open_memstream(&mem, &len);
+    if (!fo) return false;
+    t->tr->save_model(fo);
+    fclose(fo);
+    buf.assign(mem, mem + len);
+    free(mem);
+    return true;
+}
+struct view_pos { long off; int rows, cols; };
+static bool locate(svdo_trainer *t, const std::vector<char> &buf, int which, view_pos &vp) {
+    const int *hdr = reinterpret_cast<const int *>(buf.data());
+    const int common_latent = hdr[12], common_fb = hdr[14];
+    if (common_latent != 0) return false; /* not needed by the tests */
+    long off = 1056;
+    for (int v = 0; v <= 6; v++) {
+        if (v >= 5 && !(t->mtype.format_type == 1 && common_fb == 0)) return false;
+        if (off >= (long)buf.size()) return false;
+        const int *h = reinterpret_cast<const int *>(buf.data() + off);
+        int rows, cols;
+        long start;
+        if (v == 1 || v == 3 || v == 6) { cols = h[0]; rows = h[1]; start = off + 8; }
+        else { cols = 1; rows = h[0]; start = off + 4; }
+        if (v == which) { vp.off = start; vp.rows = rows; vp.cols = cols; return true; }
+        off = start + 4L * rows * cols;
+    }
+    return false;
+}
+void svdo_view_shape(svdo_trainer *t, int which, int *rows, int *cols) {
+    std::vector<char> buf;
+    view_pos vp;
+    *rows = -1; *cols = 0;
+    if (dump_model(t, buf) && locate(t, buf, which, vp)) { *rows = vp.rows; *cols = vp.cols; }
+}
+long svdo_get_view(svdo_trainer *t, int which, float *out, long capacity) {
+    std::vector<char> buf;
+    view_pos vp;
+    if (!dump_model(t, buf) || !locate(t, buf, which, vp)) return -1;
+    long n = (long)vp.rows * vp.cols;
+    if (n > capacity) return -1;
+    memcpy(out, buf.data() + vp.off, sizeof(float) * (size_t)n);
+    return n;
+}
+
+} /* extern "C" */

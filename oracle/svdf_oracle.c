@@ -1,0 +1,880 @@
+/*
+ * svdf_oracle.c -- plain-C, single-threaded restatement of the reference's apex_svd SGD hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Loaded only by tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg (kind "port").  The product path never links or calls this file.
+ *
+ * Parity status: PINNED.  tests/test_oracle_vs_reference.py compares this file, byte for byte on
+ * model files and bit for bit on predictions, against the compiled reference
+ * (oracle/_ref/libsvdf_ref.so, built by oracle/Makefile from /root/reference) and against the
+ * golden vectors under tests/golden/ that were generated from that compiled reference.
+ *
+ * Every function cites the reference file:line it follows (paths relative to /root/reference).
+ * Arithmetic rules that matter for bit parity:
+ *   - fp32 everywhere, no FMA contraction (compile with -ffp-contract=off), products and sums
+ *     are separate roundings (apex-tensor/apex_tensor_sse.h:261-272: _mm_mul_ps then _mm_add_ps)
+ *   - tensor-times-scalar expressions carry the scalar as a double and cast it to float at
+ *     evaluation (apex-tensor/apex_exp_template.h:485-502, apex_tensor_func_decl_common.h:239-245)
+ *   - multiply-by-scalar is skipped when |s-1| <= 1e-6 (apex_tensor_sse.h:231-242)
+ *   - the dot product keeps 4 lane accumulators (lane l sums j = l mod 4 in index order),
+ *     reduces (l0+l2)+(l1+l3) and then adds the k%4 tail (apex_tensor_sse.h:88-97,289-317)
+ *   - bias sum and final score accumulate in double (solvers/base-solver/apex_svd_base.h:317,446)
+ */
+#define _GNU_SOURCE
+#include "svdf_oracle.h"
+
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ---- apex_svd_model.h:373-435 SVDModelParam: 1056-byte on-disk header ---- */
+typedef struct {
+    int num_user, num_item, num_factor, num_global;
+    float u_init_sigma, i_init_sigma, base_score;
+    int no_user_bias, num_ufeedback;
+    float ufeedback_init_sigma;
+    int num_randinit_ufactor, num_randinit_ifactor;
+    int common_latent_space, user_nonnegative, common_feedback_space, extend_flag, item_nonnegative;
+    int reserved[247];
+} model_param;
+
+/* ---- apex_svd_model.h:291-344 SVDTrainParam ---- */
+typedef struct {
+    float learning_rate;
+    int decay_learning_rate;
+    float decay_rate, min_learning_rate;
+    float wd_user, wd_item, wd_user_bias, wd_item_bias;
+    int reg_method;
+    float wd_global;
+    int reg_global;
+    unsigned num_regfree_global;
+    float scale_lr_ufeedback, wd_ufeedback_user, wd_ufeedback, wd_ufeedback_bias;
+} train_param;
+
+/* ---- solvers/base-solver/apex_svd_base.h:33-75 ParameterSet ---- */
+typedef struct {
+    float *wd; unsigned *bound; int nwd, nbound;
+    const char *prefix_a, *prefix_b;
+} param_set;
+
+/* ---- apex-utils/apex_utils.h:140-196 SparseFeatureArray<float> ---- */
+typedef struct { unsigned index; float value; } sf_entry;
+typedef struct { unsigned num_row; unsigned *row_ptr; sf_entry *data; size_t ndata; } sparse_feat;
+
+struct svdo_trainer {
+    uint8_t mtype[4]; /* format_type, active_type, extend_type, variant_type */
+    model_param mp;
+    train_param tp;
+    int space_allocated, init_end, round_counter;
+    /* W_uiset / ui_bias with views (apex_svd_model.h:511-556) */
+    int pitch;          /* floats per row: ceil(4k/16)*16 bytes (apex_tensor_sse.h:26-27) */
+    int n_uiset;
+    float *ui_bias, *W_uiset, *g_bias;
+    float *u_bias, *W_user, *i_bias, *W_item, *ufb_bias, *W_ufb;
+    /* scratch (apex_svd_base.h:85, 486-488) */
+    float *tmp_u, *tmp_i, *tmp_fb, *old_fb;
+    float norm_fb, tmp_fb_bias, old_fb_bias;
+    sparse_feat feat_user, feat_item;
+    char name_feat_user[256], name_feat_item[256];
+    unsigned sample_counter;
+    unsigned *ref_user, *ref_item, *ref_global;
+    param_set u_param, i_param, g_param;
+};
+
+static void die(const char *msg) { /* apex-utils/apex_utils.h:47-50 */
+    fprintf(stderr, "%s\n", msg);
+    exit(-1);
+}
+static void assert_true(int ok, const char *msg) { if (!ok) die(msg); }
+
+int svdo_kind(void) { return 1; }
+
+/* ================= tensor micro-ops ================= */
+
+/* apex_tensor_sse.h:231-242 ScalarOptimizer<ST,Mul>: multiply skipped when |s-1|<=1e-6 */
+static int scalar_is_one(float s) { return !(fabs((double)fabsf(s - 1.0f)) > 1e-6); }
+
+/* K1: dst += src*s  (apex_tensor_sse.h:261-272 with Store<AddTo>, :161-166) */
+static void axpy(float *dst, const float *src, float s, int n) {
+    if (scalar_is_one(s)) { for (int j = 0; j < n; j++) dst[j] = dst[j] + src[j]; return; }
+    for (int j = 0; j < n; j++) { float m = src[j] * s; dst[j] = dst[j] + m; }
+}
+/* K2: dst *= s  (same routine with Store<SaveTo>) */
+static void scale(float *dst, float s, int n) {
+    if (scalar_is_one(s)) return;
+    for (int j = 0; j < n; j++) dst[j] = dst[j] * s;
+}
+/* K3: apex_tensor_sse.h:289-317 sdot + :88-97 sum_all */
+static float sdot(const float *a, const float *b, int n) {
+    int len = (n >> 2) << 2;
+    float l0 = 0.0f, l1 = 0.0f, l2 = 0.0f, l3 = 0.0f;
+    for (int j = 0; j < len; j += 4) {
+        float m0 = a[j] * b[j], m1 = a[j + 1] * b[j + 1], m2 = a[j + 2] * b[j + 2], m3 = a[j + 3] * b[j + 3];
+        l0 = l0 + m0; l1 = l1 + m1; l2 = l2 + m2; l3 = l3 + m3;
+    }
+    float h02 = l0 + l2, h13 = l1 + l3; /* movehl add, then shuffle add_ss */
+    float sum = h02 + h13;
+    for (int j = len; j < n; j++) { float m = a[j] * b[j]; sum = sum + m; }
+    return sum;
+}
+/* K6: apex_tensor_cpu_inline_common.h:168-175 */
+static void regularize_l1(float *w, float eps, int n) {
+    for (int j = 0; j < n; j++) {
+        if (w[j] > eps) w[j] -= eps;
+        else if (w[j] < -eps) w[j] += eps;
+        else w[j] = 0.0f;
+    }
+}
+/* apex_svd_base.h:175-180 */
+static void reg_l1_scalar(float *w, float wd) {
+    if (*w > wd) *w -= wd;
+    else if (*w < -wd) *w += wd;
+    else *w = 0.0f;
+}
+/* apex_svd_base.h:181-186 */
+static void project(float *w, float B, int n) {
+    float sum = sdot(w, w, n);
+    if (sum > B) scale(w, sqrtf(B / sum), n);
+}
+
+/* ================= loss / link (apex_svd_model.h:90-156, 220-237) ================= */
+static float smooth_hinge_grad(float z) {
+    if (z > 1.0f) return 0.0f;
+    if (z < 0.0f) return 1.0f;
+    return 1.0f - z;
+}
+static float map_active(float sum, int type) {
+    switch (type) {
+    case 0: return sum;
+    case 1: case 2: return 1.0f / (1.0f + expf(-sum));
+    case 3: case 5: case 6: case 7: return sum;
+    default: die("unkown active type"); return 0.0f;
+    }
+}
+static float cal_grad(float r, float pred, int type) {
+    switch (type) {
+    case 0: return r - pred;
+    case 1: return (r - pred) * pred * (1 - pred);
+    case 2: return r - pred;
+    case 7: case 3: return r - 1.0f / (1.0f + expf(-pred));
+    case 5:
+        if (r > 0.5f) return smooth_hinge_grad(pred - 0.5f);
+        else return -smooth_hinge_grad(0.5f - pred);
+    case 6:
+        if (r > 0.5f) { if (pred > 1.0f) return 0.0f; else return r - pred; }
+        else { if (pred < 0.0f) return 0.0f; else return r - pred; }
+    default: die("unkown active type"); return 0.0f;
+    }
+}
+static float calc_base_score(float base_score, int type) {
+    switch (type) {
+    case 0: case 6: case 5: return base_score;
+    case 1: case 2: case 3: case 7:
+        assert_true(base_score > 0.0f && base_score < 1.0f, "sigmoid range constrain");
+        return -logf(1.0f / base_score - 1.0f);
+    default: die("unkown active type"); return 0.0f;
+    }
+}
+
+/* ================= PRNG (apex-tensor/apex_random.h:42-77) ================= */
+void svdo_seed(unsigned seed) { srand(seed); }
+static double next_double2(void) { return ((double)rand() + 1.0) / ((double)RAND_MAX + 2.0); }
+static double sample_normal(void) {
+    double x, y, s;
+    do {
+        x = 2 * next_double2() - 1.0;
+        y = 2 * next_double2() - 1.0;
+        s = x * x + y * y;
+    } while (s >= 1.0 || s == 0.0);
+    return x * sqrt(-2.0 * log(s) / s);
+}
+/* apex_tensor_cpu_inline_common.h:249-253 on a row-major sub-matrix */
+static void sample_gaussian(float *w, int rows, int cols, int pitch, float sd) {
+    for (int y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++)
+            w[(size_t)y * pitch + x] = (float)sample_normal() * sd;
+}
+
+/* ================= ParameterSet (apex_svd_base.h:33-75) ================= */
+static void pset_set_param(param_set *p, const char *name, const char *val) {
+    size_t la = strlen(p->prefix_a), lb = strlen(p->prefix_b);
+    if (!strncmp(name, p->prefix_a, la)) name += la;
+    else if (!strncmp(name, p->prefix_b, lb)) name += lb;
+    else return;
+    if (!strcmp("bound", name)) {
+        unsigned bd = (unsigned)atoi(val);
+        assert_true(bd > 0, "can't give 0 as bound");
+        assert_true(p->nbound == 0 || p->bound[p->nbound - 1] < bd, "bound must be given in order");
+        assert_true(p->nbound + 1 == p->nwd, "must specifiy wd in each range");
+        p->bound = (unsigned *)realloc(p->bound, sizeof(unsigned) * (p->nbound + 1));
+        p->bound[p->nbound++] = bd - 1;
+    }
+    if (!strcmp("wd", name)) {
+        assert_true(p->nwd == p->nbound, "setting must be exactly");
+        p->wd = (float *)realloc(p->wd, sizeof(float) * (p->nwd + 1));
+        p->wd[p->nwd++] = (float)atof(val);
+    }
+}
+static float pset_get_wd(const param_set *p, unsigned gid, float wd_default) {
+    if (p->nbound == 0) return wd_default;
+    int lo = 0, hi = p->nbound; /* std::lower_bound */
+    while (lo < hi) { int mid = (lo + hi) / 2; if (p->bound[mid] < gid) lo = mid + 1; else hi = mid; }
+    assert_true(lo < p->nbound, "bound set err");
+    return p->wd[lo];
+}
+
+/* ================= SparseFeatureArray (apex-utils/apex_utils.h:172-195) ================= */
+static void sf_load(sparse_feat *f, const char *fname) {
+    free(f->row_ptr); free(f->data);
+    memset(f, 0, sizeof(*f));
+    size_t cap_r = 16, cap_d = 16;
+    f->row_ptr = (unsigned *)malloc(sizeof(unsigned) * cap_r);
+    f->data = (sf_entry *)malloc(sizeof(sf_entry) * cap_d);
+    f->row_ptr[0] = 0;
+    FILE *fi = fopen(fname, "r");
+    if (!fi) { fprintf(stderr, "can not open file \"%s\"\n", fname); exit(-1); }
+    int n;
+    while (fscanf(fi, "%d", &n) == 1) {
+        if (f->num_row + 2 > cap_r) { cap_r *= 2; f->row_ptr = (unsigned *)realloc(f->row_ptr, sizeof(unsigned) * cap_r); }
+        f->row_ptr[f->num_row + 1] = f->row_ptr[f->num_row] + (unsigned)n;
+        f->num_row++;
+        for (int i = 0; i < n; i++) {
+            sf_entry e;
+            assert_true(fscanf(fi, "%u:%f", &e.index, &e.value) == 2, "load sparse feature");
+            if (f->ndata + 1 > cap_d) { cap_d *= 2; f->data = (sf_entry *)realloc(f->data, sizeof(sf_entry) * cap_d); }
+            f->data[f->ndata++] = e;
+        }
+    }
+    fclose(fi);
+}
+static int sf_get(const sparse_feat *f, unsigned idx, const sf_entry **out) {
+    if (idx < f->num_row) { *out = f->data + f->row_ptr[idx]; return (int)(f->row_ptr[idx + 1] - f->row_ptr[idx]); }
+    *out = NULL;
+    return 0;
+}
+
+/* ================= param parsing ================= */
+/* apex_svd_model.h:350-368 */
+static void tp_set_param(train_param *p, const char *name, const char *val) {
+    if (!strcmp("learning_rate", name)) p->learning_rate = (float)atof(val);
+    if (!strcmp("wd_user", name)) p->wd_user = (float)atof(val);
+    if (!strcmp("wd_item", name)) p->wd_item = (float)atof(val);
+    if (!strcmp("wd_uiset", name)) p->wd_user = p->wd_item = (float)atof(val);
+    if (!strcmp("wd_user_bias", name)) p->wd_user_bias = (float)atof(val);
+    if (!strcmp("wd_item_bias", name)) p->wd_item_bias = (float)atof(val);
+    if (!strcmp("wd_uiset_bias", name)) p->wd_user_bias = p->wd_item_bias = (float)atof(val);
+    if (!strcmp("wd_global", name)) p->wd_global = (float)atof(val);
+    if (!strcmp("reg_method", name)) p->reg_method = atoi(val);
+    if (!strcmp("reg_global", name)) p->reg_global = atoi(val);
+    if (!strcmp("num_regfree_global", name)) p->num_regfree_global = (unsigned)atoi(val);
+    if (!strcmp("decay_learning_rate", name)) p->decay_learning_rate = atoi(val);
+    if (!strcmp("min_learning_rate", name)) p->min_learning_rate = (float)atof(val);
+    if (!strcmp("decay_rate", name)) p->decay_rate = (float)atof(val);
+    if (!strcmp("scale_lr_ufeedback", name)) p->scale_lr_ufeedback = (float)atof(val);
+    if (!strcmp("wd_ufeedback", name)) p->wd_ufeedback = (float)atof(val);
+    if (!strcmp("wd_ufeedback_bias", name)) p->wd_ufeedback_bias = (float)atof(val);
+}
+/* apex_svd_model.h:456-476 */
+static void mp_set_param(model_param *p, const char *name, const char *val) {
+    if (!strcmp("num_user", name)) p->num_user = atoi(val);
+    if (!strcmp("num_item", name)) p->num_item = atoi(val);
+    if (!strcmp("num_uiset", name)) p->num_user = p->num_item = atoi(val);
+    if (!strcmp("num_global", name)) p->num_global = atoi(val);
+    if (!strcmp("num_factor", name)) p->num_factor = atoi(val);
+    if (!strcmp("u_init_sigma", name)) p->u_init_sigma = (float)atof(val);
+    if (!strcmp("i_init_sigma", name)) p->i_init_sigma = (float)atof(val);
+    if (!strcmp("ui_init_sigma", name)) p->u_init_sigma = p->i_init_sigma = (float)atof(val);
+    if (!strcmp("base_score", name)) p->base_score = (float)atof(val);
+    if (!strcmp("no_user_bias", name)) p->no_user_bias = atoi(val);
+    if (!strcmp("num_ufeedback", name)) p->num_ufeedback = atoi(val);
+    if (!strcmp("num_randinit_ufactor", name)) p->num_randinit_ufactor = atoi(val);
+    if (!strcmp("num_randinit_ifactor", name)) p->num_randinit_ifactor = atoi(val);
+    if (!strcmp("num_randinit_uifactor", name)) p->num_randinit_ifactor = p->num_randinit_ufactor = atoi(val);
+    if (!strcmp("ufeedback_init_sigma", name)) p->ufeedback_init_sigma = (float)atof(val);
+    if (!strcmp("common_latent_space", name)) p->common_latent_space = atoi(val);
+    if (!strcmp("common_feedback_space", name)) p->common_feedback_space = atoi(val);
+    if (!strcmp("user_nonnegative", name)) p->user_nonnegative = atoi(val);
+    if (!strcmp("item_nonnegative", name)) p->item_nonnegative = atoi(val);
+}
+
+/* ================= lifecycle ================= */
+svdo_trainer *svdo_create(int format_type, int active_type, int extend_type, int variant_type) {
+    svdo_trainer *t = (svdo_trainer *)calloc(1, sizeof(*t));
+    t->mtype[0] = (uint8_t)format_type; t->mtype[1] = (uint8_t)active_type;
+    t->mtype[2] = (uint8_t)extend_type; t->mtype[3] = (uint8_t)variant_type;
+    /* SVDModelParam() apex_svd_model.h:436-450 */
+    t->mp.u_init_sigma = t->mp.i_init_sigma = 0.01f;
+    t->mp.base_score = 0.5f;
+    /* SVDTrainParam() apex_svd_model.h:334-344 */
+    t->tp.learning_rate = 0.01f;
+    t->tp.decay_rate = 1.0f;
+    t->tp.scale_lr_ufeedback = 1.0f;
+    /* SVDFeature() apex_svd_base.h:102-109 */
+    t->u_param.prefix_a = "up:"; t->u_param.prefix_b = "uip:";
+    t->i_param.prefix_a = "ip:"; t->i_param.prefix_b = "uip:";
+    t->g_param.prefix_a = "gp:"; t->g_param.prefix_b = "gp:";
+    strcpy(t->name_feat_user, "NULL");
+    strcpy(t->name_feat_item, "NULL");
+    return t;
+}
+
+static void free_model(svdo_trainer *t) {
+    if (!t->space_allocated) return;
+    free(t->ui_bias); free(t->W_uiset); free(t->g_bias);
+    t->ui_bias = t->W_uiset = t->g_bias = NULL;
+    t->space_allocated = 0;
+}
+
+void svdo_destroy(svdo_trainer *t) {
+    if (!t) return;
+    free_model(t);
+    free(t->tmp_u); free(t->tmp_i); free(t->tmp_fb); free(t->old_fb);
+    free(t->ref_user); if (t->ref_item != t->ref_user) free(t->ref_item); free(t->ref_global);
+    free(t->feat_user.row_ptr); free(t->feat_user.data);
+    free(t->feat_item.row_ptr); free(t->feat_item.data);
+    free(t->u_param.wd); free(t->u_param.bound);
+    free(t->i_param.wd); free(t->i_param.bound);
+    free(t->g_param.wd); free(t->g_param.bound);
+    free(t);
+}
+
+/* apex_svd_base.h:126-136 */
+void svdo_set_param(svdo_trainer *t, const char *name, const char *val) {
+    if (!strcmp(name, "feature_user")) strcpy(t->name_feat_user, val);
+    if (!strcmp(name, "feature_item")) strcpy(t->name_feat_item, val);
+    tp_set_param(&t->tp, name, val);
+    pset_set_param(&t->u_param, name, val);
+    pset_set_param(&t->i_param, name, val);
+    pset_set_param(&t->g_param, name, val);
+    if (t->space_allocated == 0) mp_set_param(&t->mp, name, val);
+}
+
+/* apex_svd_model.h:511-556 SVDModel::alloc_space */
+static void alloc_space(svdo_trainer *t) {
+    model_param *p = &t->mp;
+    const int user_group = (t->mtype[0] == 1);
+    const int ustart = (p->common_feedback_space == 0 && user_group) ? p->num_ufeedback : 0;
+    int n;
+    if (p->common_latent_space == 0) n = ustart + p->num_user + p->num_item;
+    else {
+        assert_true(p->num_user == p->num_item, "num_user and num_item must be the same to use common latent space");
+        assert_true(p->common_feedback_space != 0, "common latent space must enforce common feedback space");
+        n = p->num_item;
+    }
+    t->n_uiset = n;
+    t->pitch = ((p->num_factor * 4 + 15) >> 4) << 2; /* floats */
+    t->ui_bias = (float *)calloc((size_t)n + 4, sizeof(float));
+    t->W_uiset = (float *)calloc((size_t)n * t->pitch + 4, sizeof(float));
+    t->g_bias = (float *)calloc((size_t)p->num_global + 4, sizeof(float));
+    if (p->common_latent_space == 0) {
+        t->u_bias = t->ui_bias + ustart;
+        t->W_user = t->W_uiset + (size_t)ustart * t->pitch;
+        t->i_bias = t->ui_bias + ustart + p->num_user;
+        t->W_item = t->W_uiset + (size_t)(ustart + p->num_user) * t->pitch;
+    } else {
+        t->W_user = t->W_uiset + (size_t)ustart * t->pitch;
+        t->u_bias = t->ui_bias + ustart;
+        t->W_item = t->W_user;
+        t->i_bias = t->u_bias;
+    }
+    t->ufb_bias = NULL; t->W_ufb = NULL;
+    if (user_group) {
+        if (p->common_feedback_space == 0) { t->ufb_bias = t->ui_bias; t->W_ufb = t->W_uiset; }
+        else { t->ufb_bias = t->u_bias; t->W_ufb = t->W_user; }
+    }
+    t->space_allocated = 1;
+}
+
+/* apex_svd_model.h:665-705 SVDModel::rand_init */
+static void rand_init(svdo_trainer *t) {
+    model_param *p = &t->mp;
+    /* ui_bias = 0, g_bias = 0 : calloc */
+    memset(t->ui_bias, 0, sizeof(float) * (size_t)t->n_uiset);
+    memset(t->g_bias, 0, sizeof(float) * (size_t)p->num_global);
+    p->base_score = calc_base_score(p->base_score, t->mtype[1]);
+    {
+        int rows = p->num_randinit_ufactor != 0 ? p->num_randinit_ufactor : p->num_user;
+        sample_gaussian(t->W_user, rows, p->num_factor, t->pitch, p->u_init_sigma);
+        if (p->user_nonnegative)
+            for (int y = 0; y < p->num_user; y++)
+                for (int x = 0; x < p->num_factor; x++) {
+                    float *w = &t->W_user[(size_t)y * t->pitch + x];
+                    *w = fabsf(*w);
+                }
+    }
+    if (p->common_latent_space == 0) {
+        int rows = p->num_randinit_ifactor != 0 ? p->num_randinit_ifactor : p->num_item;
+        sample_gaussian(t->W_item, rows, p->num_factor, t->pitch, p->i_init_sigma);
+        if (p->item_nonnegative)
+            for (int y = 0; y < rows; y++)
+                for (int x = 0; x < p->num_factor; x++) {
+                    float *w = &t->W_item[(size_t)y * t->pitch + x];
+                    *w = fabsf(*w);
+                }
+    }
+    if (t->mtype[0] == 1) {
+        /* note: draws are consumed even when ufeedback_init_sigma == 0 (apex_svd_model.h:702-704) */
+        int rows = p->common_feedback_space == 0 ? p->num_ufeedback : p->num_user;
+        sample_gaussian(t->W_ufb, rows, p->num_factor, t->pitch, p->ufeedback_init_sigma);
+    }
+}
+
+void svdo_init_model(svdo_trainer *t) { /* apex_svd_base.h:146-149 */
+    alloc_space(t);
+    rand_init(t);
+}
+
+/* apex_svd_base.h:151-173 (+ :499-503 for the user-group trainer) */
+void svdo_init_trainer(svdo_trainer *t) {
+    if (strcmp(t->name_feat_user, "NULL")) sf_load(&t->feat_user, t->name_feat_user);
+    if (strcmp(t->name_feat_item, "NULL")) sf_load(&t->feat_item, t->name_feat_item);
+    size_t nb = sizeof(float) * (size_t)(t->pitch + 4);
+    t->tmp_u = (float *)calloc(1, nb); t->tmp_i = (float *)calloc(1, nb);
+    t->tmp_fb = (float *)calloc(1, nb); t->old_fb = (float *)calloc(1, nb);
+    t->sample_counter = 0;
+    if (t->tp.reg_global >= 4) t->ref_global = (unsigned *)calloc((size_t)t->mp.num_global + 1, sizeof(unsigned));
+    if (t->tp.reg_method >= 4) {
+        t->ref_user = (unsigned *)calloc((size_t)t->mp.num_user + 1, sizeof(unsigned));
+        if (t->mp.common_latent_space == 0) t->ref_item = (unsigned *)calloc((size_t)t->mp.num_item + 1, sizeof(unsigned));
+        else t->ref_item = t->ref_user;
+    }
+    t->init_end = 1;
+}
+
+void svdo_set_round(svdo_trainer *t, int nround) { /* apex_svd_base.h:470-478 */
+    if (t->tp.decay_learning_rate != 0) {
+        assert_true(t->round_counter <= nround, "round counter restriction");
+        while (t->round_counter < nround) {
+            t->tp.learning_rate *= t->tp.decay_rate;
+            t->round_counter++;
+        }
+    }
+}
+void svdo_finish_round(svdo_trainer *t) { (void)t; } /* apex_svd.h:78 default no-op */
+
+/* ================= model file (apex_svd_model.h:570-660, tensor serialisation
+ * apex_tensor_cpu_inline_common.h:72-87: int header x_max[,y_max] then unpadded rows) ======== */
+static void save_1d(FILE *fo, const float *v, int n) {
+    fwrite(&n, sizeof(int), 1, fo);
+    fwrite(v, sizeof(float), (size_t)n, fo);
+}
+static void save_2d(FILE *fo, const float *w, int rows, int cols, int pitch) {
+    int hdr[2] = { cols, rows };
+    fwrite(hdr, sizeof(int), 2, fo);
+    for (int y = 0; y < rows; y++) fwrite(w + (size_t)y * pitch, sizeof(float), (size_t)cols, fo);
+}
+static void load_1d(FILE *fi, float *v, int n) {
+    int x;
+    assert_true(fread(&x, sizeof(int), 1, fi) > 0, "tensor::load_from_file");
+    assert_true(x == n, "tensor shape mismatch");
+    if (n > 0) assert_true(fread(v, sizeof(float), (size_t)n, fi) > 0, "tensor::load_from_file");
+}
+static void load_2d(FILE *fi, float *w, int rows, int cols, int pitch) {
+    int hdr[2];
+    assert_true(fread(hdr, sizeof(int), 2, fi) > 0, "tensor::load_from_file");
+    assert_true(hdr[0] == cols && hdr[1] == rows, "tensor shape mismatch");
+    for (int y = 0; y < rows; y++)
+        if (cols > 0) assert_true(fread(w + (size_t)y * pitch, sizeof(float), (size_t)cols, fi) > 0, "tensor::load_from_file");
+}
+static void save_model(svdo_trainer *t, FILE *fo) {
+    model_param *p = &t->mp;
+    fwrite(p, sizeof(model_param), 1, fo);
+    if (p->common_latent_space == 0) {
+        save_1d(fo, t->u_bias, p->num_user);
+        save_2d(fo, t->W_user, p->num_user, p->num_factor, t->pitch);
+        save_1d(fo, t->i_bias, p->num_item);
+        save_2d(fo, t->W_item, p->num_item, p->num_factor, t->pitch);
+    } else {
+        save_1d(fo, t->ui_bias, t->n_uiset);
+        save_2d(fo, t->W_uiset, t->n_uiset, p->num_factor, t->pitch);
+    }
+    save_1d(fo, t->g_bias, p->num_global);
+    if (t->mtype[0] == 1 && p->common_feedback_space == 0) {
+        save_1d(fo, t->ufb_bias, p->num_ufeedback);
+        save_2d(fo, t->W_ufb, p->num_ufeedback, p->num_factor, t->pitch);
+    }
+}
+static void load_model(svdo_trainer *t, FILE *fi) {
+    if (fread(&t->mp, sizeof(model_param), 1, fi) == 0) die("error loading CF SVD model");
+    if (t->space_allocated) free_model(t);
+    alloc_space(t);
+    model_param *p = &t->mp;
+    if (p->common_latent_space == 0) {
+        load_1d(fi, t->u_bias, p->num_user);
+        load_2d(fi, t->W_user, p->num_user, p->num_factor, t->pitch);
+        load_1d(fi, t->i_bias, p->num_item);
+        load_2d(fi, t->W_item, p->num_item, p->num_factor, t->pitch);
+    } else {
+        load_1d(fi, t->ui_bias, t->n_uiset);
+        load_2d(fi, t->W_uiset, t->n_uiset, p->num_factor, t->pitch);
+    }
+    load_1d(fi, t->g_bias, p->num_global);
+    if (t->mtype[0] == 1 && p->common_feedback_space == 0) {
+        load_1d(fi, t->ufb_bias, p->num_ufeedback);
+        load_2d(fi, t->W_ufb, p->num_ufeedback, p->num_factor, t->pitch);
+    }
+}
+int svdo_save_model_path(svdo_trainer *t, const char *path, int with_type_header) {
+    FILE *fo = fopen(path, "wb");
+    if (!fo) return -1;
+    if (with_type_header) fwrite(t->mtype, 1, 4, fo);
+    save_model(t, fo);
+    fclose(fo);
+    return 0;
+}
+int svdo_load_model_path(svdo_trainer *t, const char *path, int with_type_header) {
+    FILE *fi = fopen(path, "rb");
+    if (!fi) return -1;
+    if (with_type_header) assert_true(fread(t->mtype, 1, 4, fi) == 4, "loading model");
+    load_model(t, fi);
+    fclose(fi);
+    return 0;
+}
+
+/* ================= the hot path ================= */
+typedef struct {
+    float label;
+    int ng, nu, ni;
+    const unsigned *ig, *iu, *ii;
+    const float *vg, *vu, *vi;
+} elem; /* SVDFeatureCSR::Elem apex_svd_data.h:38-107 */
+
+static elem make_elem(float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
+    elem e; /* Elem::set_space apex_svd_data.h:71-78 */
+    e.label = label; e.ng = ng; e.nu = nu; e.ni = ni;
+    e.ig = index; e.iu = index + ng; e.ii = index + ng + nu;
+    e.vg = value; e.vu = value + ng; e.vi = value + ng + nu;
+    return e;
+}
+
+/* apex_svd_base.h:188-210 */
+static void reg_global(svdo_trainer *t, unsigned gid) {
+    float lambda = t->tp.learning_rate * pset_get_wd(&t->g_param, gid, t->tp.wd_global);
+    if (gid >= t->tp.num_regfree_global) {
+        switch (t->tp.reg_global) {
+        case 0: t->g_bias[gid] *= (1.0f - lambda); break;
+        case 1: reg_l1_scalar(&t->g_bias[gid], lambda); break;
+        case 4: {
+            float k = (float)(t->ref_global[gid] - t->sample_counter);
+            t->g_bias[gid] *= expf(logf(1.0f - lambda) * k);
+            t->ref_global[gid] = t->sample_counter;
+            break;
+        }
+        case 5: {
+            float k = (float)(t->ref_global[gid] - t->sample_counter);
+            reg_l1_scalar(&t->g_bias[gid], lambda * k);
+            t->ref_global[gid] = t->sample_counter;
+            break;
+        }
+        default: die("unknown global decay method");
+        }
+    }
+}
+/* apex_svd_base.h:211-250 */
+static void reg_user(svdo_trainer *t, unsigned uid) {
+    const int k = t->mp.num_factor;
+    float *w = t->W_user + (size_t)uid * t->pitch;
+    float wd = pset_get_wd(&t->u_param, uid, t->tp.wd_user);
+    float lambda = t->tp.learning_rate * wd;
+    switch (t->tp.reg_method) {
+    case 0: scale(w, (float)(double)(1.0f - lambda), k); break;
+    case 3: case 1: regularize_l1(w, lambda, k); break;
+    case 2: project(w, wd, k); break;
+    case 4: {
+        float kk = (float)(t->ref_user[uid] - t->sample_counter);
+        scale(w, (float)(double)expf(logf(1.0f - lambda) * kk), k);
+        t->ref_user[uid] = t->sample_counter;
+        break;
+    }
+    case 5: {
+        float kk = (float)(t->ref_user[uid] - t->sample_counter);
+        regularize_l1(w, lambda * kk, k);
+        t->ref_user[uid] = t->sample_counter;
+        break;
+    }
+    default: die("unknown reg_method");
+    }
+    if (t->mp.user_nonnegative) /* K7 apex_tensor_cpu_inline_common.h:177-181 */
+        for (int j = 0; j < k; j++) if (w[j] <= 0.0f) w[j] = 0.0f;
+    if (t->mp.no_user_bias == 0)
+        t->u_bias[uid] *= (1.0f - t->tp.learning_rate * t->tp.wd_user_bias);
+}
+/* apex_svd_base.h:251-283 */
+static void reg_item(svdo_trainer *t, unsigned iid) {
+    const int k = t->mp.num_factor;
+    float *w = t->W_item + (size_t)iid * t->pitch;
+    float wd = pset_get_wd(&t->i_param, iid, t->tp.wd_item);
+    float lambda = t->tp.learning_rate * wd;
+    switch (t->tp.reg_method) {
+    case 3: case 0: scale(w, (float)(double)(1.0f - lambda), k); break;
+    case 1: regularize_l1(w, lambda, k); break;
+    case 2: project(w, wd, k); break;
+    case 4: {
+        float kk = (float)(t->ref_item[iid] - t->sample_counter);
+        scale(w, (float)(double)expf(logf(1.0f - lambda) * kk), k);
+        t->ref_item[iid] = t->sample_counter;
+        break;
+    }
+    case 5: {
+        float kk = (float)(t->ref_item[iid] - t->sample_counter);
+        regularize_l1(w, lambda * kk, k);
+        t->ref_item[iid] = t->sample_counter;
+        break;
+    }
+    default: die("unknown reg_method");
+    }
+    t->i_bias[iid] *= (1.0f - t->tp.learning_rate * t->tp.wd_item_bias);
+}
+/* apex_svd_base.h:286-311 */
+static void regularize(svdo_trainer *t, const elem *f, int is_after_update) {
+    const sf_entry *vec;
+    if ((is_after_update && t->tp.reg_global < 4) || (!is_after_update && t->tp.reg_global >= 4))
+        for (int i = 0; i < f->ng; i++) reg_global(t, f->ig[i]);
+    if ((is_after_update && t->tp.reg_method < 4) || (!is_after_update && t->tp.reg_method >= 4)) {
+        for (int i = 0; i < f->nu; i++) {
+            reg_user(t, f->iu[i]);
+            int n = sf_get(&t->feat_user, f->iu[i], &vec);
+            for (int j = 0; j < n; j++) reg_user(t, vec[j].index);
+        }
+        for (int i = 0; i < f->ni; i++) {
+            reg_item(t, f->ii[i]);
+            int n = sf_get(&t->feat_item, f->ii[i], &vec);
+            for (int j = 0; j < n; j++) reg_item(t, vec[j].index);
+        }
+    }
+}
+static int is_user_group(const svdo_trainer *t) { return t->mtype[0] == 1; }
+
+/* apex_svd_base.h:313-353 */
+static double calc_bias(svdo_trainer *t, const elem *f) {
+    const sf_entry *vec;
+    double sum = 0.0f;
+    for (int i = 0; i < f->ng; i++) {
+        unsigned gid = f->ig[i];
+        assert_true(gid < (unsigned)t->mp.num_global, "global feature index exceed setting");
+        sum += f->vg[i] * t->g_bias[gid];
+    }
+    if (t->mp.no_user_bias == 0) {
+        for (int i = 0; i < f->nu; i++) {
+            unsigned uid = f->iu[i];
+            assert_true(uid < (unsigned)t->mp.num_user, "user feature index exceed bound");
+            sum += f->vu[i] * t->u_bias[uid];
+            int n = sf_get(&t->feat_user, uid, &vec);
+            for (int j = 0; j < n; j++) sum += t->u_bias[vec[j].index] * vec[j].value;
+        }
+        sum += is_user_group(t) ? t->tmp_fb_bias : 0.0f; /* get_bias_svdpp :433-435,509-511 */
+    }
+    sum += 0.0f; /* get_bias_plugin :436-438 */
+    for (int i = 0; i < f->ni; i++) {
+        unsigned iid = f->ii[i];
+        float ival = f->vi[i];
+        assert_true(iid < (unsigned)t->mp.num_item, "item feature index exceed bound");
+        sum += ival * t->i_bias[iid];
+        int n = sf_get(&t->feat_item, iid, &vec);
+        for (int j = 0; j < n; j++) sum += t->i_bias[vec[j].index] * vec[j].value * ival;
+    }
+    return sum;
+}
+/* apex_svd_base.h:354-381 */
+static void prepare_tmp(svdo_trainer *t, const elem *f) {
+    const int k = t->mp.num_factor;
+    const sf_entry *vec;
+    if (is_user_group(t)) memcpy(t->tmp_u, t->tmp_fb, sizeof(float) * (size_t)k); /* :506-508 */
+    else for (int j = 0; j < k; j++) t->tmp_u[j] = 0.0f;                          /* :430-432 */
+    for (int j = 0; j < k; j++) t->tmp_i[j] = 0.0f;
+    for (int i = 0; i < f->nu; i++) {
+        unsigned uid = f->iu[i];
+        assert_true(uid < (unsigned)t->mp.num_user, "user feature index exceed bound");
+        axpy(t->tmp_u, t->W_user + (size_t)uid * t->pitch, (float)(double)f->vu[i], k);
+        int n = sf_get(&t->feat_user, uid, &vec);
+        for (int j = 0; j < n; j++)
+            axpy(t->tmp_u, t->W_user + (size_t)vec[j].index * t->pitch, (float)(double)vec[j].value, k);
+    }
+    for (int i = 0; i < f->ni; i++) {
+        unsigned iid = f->ii[i];
+        float ival = f->vi[i];
+        axpy(t->tmp_i, t->W_item + (size_t)iid * t->pitch, (float)(double)ival, k);
+        int n = sf_get(&t->feat_item, iid, &vec);
+        for (int j = 0; j < n; j++) /* scalar product formed in double: apex_exp_template.h:500-502 */
+            axpy(t->tmp_i, t->W_item + (size_t)vec[j].index * t->pitch, (float)((double)vec[j].value * (double)ival), k);
+    }
+}
+/* apex_svd_base.h:445-454 */
+static float pred(svdo_trainer *t, const elem *f) {
+    double sum = t->mp.base_score + calc_bias(t, f);
+    prepare_tmp(t, f);
+    sum += sdot(t->tmp_u, t->tmp_i, t->mp.num_factor);
+    return map_active((float)sum, t->mtype[1]);
+}
+/* apex_svd_base.h:512-520 */
+static void update_svdpp(svdo_trainer *t, float err) {
+    const int k = t->mp.num_factor;
+    float lr = t->tp.learning_rate * t->tp.scale_lr_ufeedback;
+    axpy(t->tmp_fb, t->tmp_i, (float)(double)(lr * err * t->norm_fb), k);
+    scale(t->tmp_fb, (float)(double)(1.0f - lr * t->tp.wd_ufeedback), k);
+    if (t->mp.no_user_bias == 0) {
+        t->tmp_fb_bias += lr * err * t->norm_fb;
+        t->tmp_fb_bias *= (1.0f - lr * t->tp.wd_ufeedback_bias);
+    }
+}
+/* apex_svd_base.h:383-427 */
+static void update_no_decay(svdo_trainer *t, float err, const elem *f) {
+    const int k = t->mp.num_factor;
+    const float lr = t->tp.learning_rate;
+    const sf_entry *vec;
+    for (int i = 0; i < f->ng; i++) t->g_bias[f->ig[i]] += lr * err * f->vg[i];
+    for (int i = 0; i < f->nu; i++) {
+        unsigned uid = f->iu[i];
+        float sc = lr * err * f->vu[i];
+        axpy(t->W_user + (size_t)uid * t->pitch, t->tmp_i, sc, k);
+        if (t->mp.no_user_bias == 0) t->u_bias[uid] += sc;
+        int n = sf_get(&t->feat_user, uid, &vec);
+        for (int j = 0; j < n; j++) {
+            float s2 = lr * err * vec[j].value;
+            axpy(t->W_user + (size_t)vec[j].index * t->pitch, t->tmp_i, s2, k);
+            if (t->mp.no_user_bias == 0) t->u_bias[vec[j].index] += s2;
+        }
+    }
+    for (int i = 0; i < f->ni; i++) {
+        unsigned iid = f->ii[i];
+        float ival = f->vi[i];
+        float sc = lr * err * ival;
+        axpy(t->W_item + (size_t)iid * t->pitch, t->tmp_u, sc, k);
+        t->i_bias[iid] += sc;
+        int n = sf_get(&t->feat_item, iid, &vec);
+        for (int j = 0; j < n; j++) {
+            float s2 = lr * err * vec[j].value * ival;
+            t->i_bias[vec[j].index] += s2;
+            axpy(t->W_item + (size_t)vec[j].index * t->pitch, t->tmp_u, s2, k);
+        }
+    }
+    if (is_user_group(t)) update_svdpp(t, err);
+    /* update_bias_plugin :439-440 no-op */
+}
+/* apex_svd_base.h:456-462 */
+static void update_inner(svdo_trainer *t, const elem *f) {
+    regularize(t, f, 0);
+    float err = cal_grad(f->label, pred(t, f), t->mtype[1]) * 1.0f;
+    update_no_decay(t, err, f);
+    t->sample_counter++;
+    regularize(t, f, 1);
+}
+
+void svdo_update_csr(svdo_trainer *t, float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
+    elem e = make_elem(label, ng, nu, ni, index, value);
+    update_inner(t, &e);
+}
+float svdo_predict_csr(svdo_trainer *t, float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
+    elem e = make_elem(label, ng, nu, ni, index, value);
+    return pred(t, &e);
+}
+/* SVDFeatureCSR::operator[] apex_svd_data.h:129-142 */
+static elem csr_row(int r, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value) {
+    elem e;
+    e.label = row_label[r];
+    e.ng = row_ptr[r * 3 + 1] - row_ptr[r * 3 + 0];
+    e.nu = row_ptr[r * 3 + 2] - row_ptr[r * 3 + 1];
+    e.ni = row_ptr[r * 3 + 3] - row_ptr[r * 3 + 2];
+    e.ig = feat_index + row_ptr[r * 3 + 0]; e.iu = feat_index + row_ptr[r * 3 + 1]; e.ii = feat_index + row_ptr[r * 3 + 2];
+    e.vg = feat_value + row_ptr[r * 3 + 0]; e.vu = feat_value + row_ptr[r * 3 + 1]; e.vi = feat_value + row_ptr[r * 3 + 2];
+    return e;
+}
+void svdo_update_csr_batch(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                           const unsigned *feat_index, const float *feat_value) {
+    for (int r = 0; r < num_row; r++) {
+        elem e = csr_row(r, row_label, row_ptr, feat_index, feat_value);
+        update_inner(t, &e);
+    }
+}
+void svdo_predict_csr_batch(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                            const unsigned *feat_index, const float *feat_value, float *out) {
+    for (int r = 0; r < num_row; r++) {
+        elem e = csr_row(r, row_label, row_ptr, feat_index, feat_value);
+        out[r] = pred(t, &e);
+    }
+}
+
+/* ---- SVD++ user-group path, apex_svd_base.h:523-591 ---- */
+static void prepare_ufeedback(svdo_trainer *t, int nfb, const unsigned *idx, const float *val) {
+    const int k = t->mp.num_factor;
+    t->norm_fb = 0.0f;
+    for (int j = 0; j < k; j++) t->tmp_fb[j] = 0.0f;
+    t->tmp_fb_bias = 0.0f;
+    for (int i = 0; i < nfb; i++) {
+        unsigned fid = idx[i];
+        float v = val[i];
+        assert_true(fid < (unsigned)t->mp.num_ufeedback, "ufeedback id exceed bound");
+        axpy(t->tmp_fb, t->W_ufb + (size_t)fid * t->pitch, (float)(double)v, k);
+        t->norm_fb += v * v;
+        if (t->mp.no_user_bias == 0) t->tmp_fb_bias += t->ufb_bias[fid] * v;
+    }
+}
+static void update_ufeedback(svdo_trainer *t, int nfb, const unsigned *idx, const float *val) {
+    const int k = t->mp.num_factor;
+    if (nfb == 0) return;
+    for (int j = 0; j < k; j++) t->tmp_fb[j] = t->tmp_fb[j] - t->old_fb[j]; /* K5 */
+    t->tmp_fb_bias -= t->old_fb_bias;
+    scale(t->tmp_fb, (float)(double)(1.0f / t->norm_fb), k);
+    t->tmp_fb_bias *= 1.0f / t->norm_fb;
+    for (int i = 0; i < nfb; i++) {
+        unsigned fid = idx[i];
+        float v = val[i];
+        axpy(t->W_ufb + (size_t)fid * t->pitch, t->tmp_fb, (float)(double)v, k);
+        if (t->mp.no_user_bias == 0) t->ufb_bias[fid] += t->tmp_fb_bias * v;
+    }
+}
+void svdo_update_block(svdo_trainer *t, int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb,
+                       int num_row, const float *row_label, const int *row_ptr,
+                       const unsigned *feat_index, const float *feat_value) {
+    if (extend_tag == 0 || extend_tag == 1) { /* DEFAULT or START_TAG */
+        prepare_ufeedback(t, nfb, idx_fb, val_fb);
+        t->old_fb_bias = t->tmp_fb_bias;
+        memcpy(t->old_fb, t->tmp_fb, sizeof(float) * (size_t)t->mp.num_factor);
+    }
+    svdo_update_csr_batch(t, num_row, row_label, row_ptr, feat_index, feat_value); /* update_each :560-565 */
+    if (extend_tag == 0 || extend_tag == 2) update_ufeedback(t, nfb, idx_fb, val_fb); /* DEFAULT or END_TAG */
+}
+void svdo_predict_block(svdo_trainer *t, int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb,
+                        int num_row, const float *row_label, const int *row_ptr,
+                        const unsigned *feat_index, const float *feat_value, float *out) {
+    if (extend_tag == 0 || extend_tag == 1) prepare_ufeedback(t, nfb, idx_fb, val_fb);
+    svdo_predict_csr_batch(t, num_row, row_label, row_ptr, feat_index, feat_value, out);
+}
+
+/* ================= views ================= */
+void svdo_view_shape(svdo_trainer *t, int which, int *rows, int *cols) {
+    const model_param *p = &t->mp;
+    int nfb = p->common_feedback_space == 0 ? p->num_ufeedback : p->num_user;
+    *rows = -1; *cols = 0;
+    switch (which) {
+    case 0: *rows = p->num_user; *cols = 1; break;
+    case 1: *rows = p->num_user; *cols = p->num_factor; break;
+    case 2: *rows = p->num_item; *cols = 1; break;
+    case 3: *rows = p->num_item; *cols = p->num_factor; break;
+    case 4: *rows = p->num_global; *cols = 1; break;
+    case 5: if (t->mtype[0] == 1) { *rows = nfb; *cols = 1; } break;
+    case 6: if (t->mtype[0] == 1) { *rows = nfb; *cols = p->num_factor; } break;
+    default: break;
+    }
+}
+long svdo_get_view(svdo_trainer *t, int which, float *out, long capacity) {
+    int rows, cols;
+    svdo_view_shape(t, which, &rows, &cols);
+    if (rows < 0) return -1;
+    long n = (long)rows * cols;
+    if (n > capacity) return -1;
+    const float *vec = NULL, *mat = NULL;
+    switch (which) {
+    case 0: vec = t->u_bias; break;
+    case 1: mat = t->W_user; break;
+    case 2: vec = t->i_bias; break;
+    case 3: mat = t->W_item; break;
+    case 4: vec = t->g_bias; break;
+    case 5: vec = t->ufb_bias; break;
+    case 6: mat = t->W_ufb; break;
+    }
+    if (vec) memcpy(out, vec, sizeof(float) * (size_t)n);
+    else for (int y = 0; y < rows; y++) memcpy(out + (size_t)y * cols, mat + (size_t)y * t->pitch, sizeof(float) * (size_t)cols);
+    return n;
+}

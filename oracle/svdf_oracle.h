@@ -1,0 +1,77 @@
+/*
+ * svdf_oracle.h -- C API shared by the two CPU checkers of the apex_svd SGD hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Two shared libraries export exactly this API:
+ *
+ *   oracle/libsvdf_oracle.so     plain-C restatement of the reference algorithm (svdf_oracle.c)
+ *   oracle/_ref/libsvdf_ref.so   the reference's own C++ classes (SVDFeature / SVDPPFeature),
+ *                                compiled from /root/reference where they lie and wrapped by
+ *                                ref_shim.cpp
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load either
+ * library; the product (svdfeature_amd/) never does.
+ *
+ * The API mirrors the reference's ISVDTrainer virtual surface (apex_svd.h:33-107) flattened to C.
+ */
+#ifndef SVDF_ORACLE_H_
+#define SVDF_ORACLE_H_
+
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svdo_trainer svdo_trainer;
+
+/* create_svd_trainer(SVDTypeParam) (apex_svd.h:212); the four bytes of SVDTypeParam */
+svdo_trainer *svdo_create(int format_type, int active_type, int extend_type, int variant_type);
+void svdo_destroy(svdo_trainer *t);
+
+/* ISVDTrainer::set_param / init_model / init_trainer / set_round / finish_round */
+void svdo_set_param(svdo_trainer *t, const char *name, const char *val);
+void svdo_seed(unsigned seed);          /* apex_random::seed -> srand (apex_random.h:42-44) */
+void svdo_init_model(svdo_trainer *t);  /* alloc_space + rand_init, consumes libc rand() */
+void svdo_init_trainer(svdo_trainer *t);
+void svdo_set_round(svdo_trainer *t, int nround);
+void svdo_finish_round(svdo_trainer *t);
+
+/* model file = 4-byte SVDTypeParam (written by the caller in the reference, svd_feature.cpp:184-191)
+ * followed by SVDModel::save_to_file.  with_type_header != 0 reads/writes the 4 type bytes too. */
+int svdo_save_model_path(svdo_trainer *t, const char *path, int with_type_header);
+int svdo_load_model_path(svdo_trainer *t, const char *path, int with_type_header);
+
+/* ISVDTrainer::update(const SVDFeatureCSR::Elem&) / predict(const Elem&) */
+void svdo_update_csr(svdo_trainer *t, float label, int num_global, int num_ufactor, int num_ifactor,
+                     const unsigned *index, const float *value);
+float svdo_predict_csr(svdo_trainer *t, float label, int num_global, int num_ufactor, int num_ifactor,
+                       const unsigned *index, const float *value);
+
+/* the same over a whole SVDFeatureCSR block (apex_svd_data.h:34-231), rows in order */
+void svdo_update_csr_batch(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                           const unsigned *feat_index, const float *feat_value);
+void svdo_predict_csr_batch(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                            const unsigned *feat_index, const float *feat_value, float *out);
+
+/* ISVDTrainer::update(const SVDPlusBlock&) / predict(vector<float>&, const SVDPlusBlock&) */
+void svdo_update_block(svdo_trainer *t, int num_ufeedback, int extend_tag,
+                       const unsigned *index_ufeedback, const float *value_ufeedback,
+                       int num_row, const float *row_label, const int *row_ptr,
+                       const unsigned *feat_index, const float *feat_value);
+void svdo_predict_block(svdo_trainer *t, int num_ufeedback, int extend_tag,
+                        const unsigned *index_ufeedback, const float *value_ufeedback,
+                        int num_row, const float *row_label, const int *row_ptr,
+                        const unsigned *feat_index, const float *feat_value, float *out);
+
+/* raw views for bit-exact comparison.  which: 0 u_bias 1 W_user 2 i_bias 3 W_item 4 g_bias
+ * 5 ufeedback_bias 6 W_ufeedback.  Copies rows unpadded into out (rows*cols floats);
+ * returns rows*cols, or -1 when the view does not exist. */
+long svdo_get_view(svdo_trainer *t, int which, float *out, long capacity);
+void svdo_view_shape(svdo_trainer *t, int which, int *rows, int *cols);
+/* 1 for the plain-C restatement, 2 for the compiled reference */
+int svdo_kind(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

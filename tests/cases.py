@@ -1,0 +1,116 @@
+"""Seeded synthetic workloads shared by the CPU (oracle) and GPU parity tests.
+
+Every case is (config pairs, training data, test data[, side-feature tables]) built from a
+numpy Generator with a fixed seed, so the oracle, the compiled reference and the HIP path all
+see identical bytes.
+"""
+import os
+
+import numpy as np
+
+from svdfeature_amd.data import CSRData, PlusBlock, TAG_DEFAULT, TAG_END, TAG_MIDDLE, TAG_START
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+BASICMF_CONF = [  # demo/basicMF/basicMF.conf:4-23
+    ("base_score", "3"), ("learning_rate", "0.005"), ("wd_item", "0.004"), ("wd_user", "0.004"),
+    ("num_item", "1682"), ("num_user", "943"), ("num_global", "0"), ("num_factor", "64"), ("active_type", "0"),
+]
+
+
+def conf_with(base, **kw):
+    out = [(k, v) for k, v in base if k not in kw]
+    out += [(k, str(v)) for k, v in kw.items()]
+    return out
+
+
+def ml100k():
+    """ML-100K ua.base (shuffled order of demo/basicMF/ua.base.basicfeature) and ua.test as
+    0-based (user, item, rating) arrays; fixture written by tests/golden/make_golden.py."""
+    z = np.load(os.path.join(GOLDEN, "ml100k_ua.npz"))
+    base = CSRData.from_triples(z["base_u"], z["base_i"], z["base_r"])
+    test = CSRData.from_triples(z["test_u"], z["test_i"], z["test_r"])
+    return base, test
+
+
+def planted_triples(n, num_user, num_item, seed, rank=8, noise=0.3, zipf=False):
+    """(u, i, r) with r in 1..5 from a planted low-rank model."""
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, num_user, n, dtype=np.int64)
+    if zipf:
+        w = 1.0 / np.arange(1, num_item + 1) ** 0.8
+        i = rng.choice(num_item, size=n, p=w / w.sum())
+    else:
+        i = rng.integers(0, num_item, n, dtype=np.int64)
+    pu = rng.standard_normal((num_user, rank)).astype(np.float32)
+    qi = rng.standard_normal((num_item, rank)).astype(np.float32)
+    score = 3.0 + 0.6 * np.einsum("nk,nk->n", pu[u], qi[i]) / np.sqrt(rank) + noise * rng.standard_normal(n)
+    r = np.clip(np.rint(score), 1, 5).astype(np.float32)
+    return u.astype(np.uint32), i.astype(np.uint32), r
+
+
+def sparse_feature_rows(n, num_user, num_item, num_global, seed, max_g=3, max_u=3, max_i=3,
+                        binary_label=False, allow_dup=True):
+    """Ragged instances: 0..max_g globals, 1..max_u user ids, 1..max_i item ids with real-valued
+    weights; some rows have empty sections and (allow_dup) a repeated id inside one section."""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for r in range(n):
+        ng = int(rng.integers(0, max_g + 1)) if num_global else 0
+        nu = int(rng.integers(0 if r % 17 == 5 else 1, max_u + 1))
+        ni = int(rng.integers(0 if r % 19 == 7 else 1, max_i + 1))
+        g = [(int(rng.integers(0, num_global)), float(np.float32(rng.uniform(-1, 1)))) for _ in range(ng)]
+        u = [(int(rng.integers(0, num_user)), float(np.float32(rng.choice([1.0, 0.5, 0.25, rng.uniform(0.1, 1.5)])))) for _ in range(nu)]
+        i = [(int(rng.integers(0, num_item)), float(np.float32(rng.choice([1.0, -1.0, 0.5, rng.uniform(-1, 1)])))) for _ in range(ni)]
+        if allow_dup and r % 23 == 3 and nu >= 2:
+            u[1] = (u[0][0], u[1][1])
+        if allow_dup and r % 29 == 4 and ni >= 2:
+            i[1] = (i[0][0], i[1][1])
+        label = float(rng.integers(0, 2)) if binary_label else float(rng.integers(1, 6))
+        rows.append((label, g, u, i))
+    return CSRData.from_rows(rows)
+
+
+def write_side_table(path, num_rows, num_ids, seed, max_children=2):
+    """feature_user / feature_item text table (apex-utils/apex_utils.h:172-195): per id
+    ``n idx:val ...``.  Children point into the same id space."""
+    rng = np.random.default_rng(seed)
+    with open(path, "w") as f:
+        for _ in range(num_rows):
+            n = int(rng.integers(0, max_children + 1))
+            ent = " ".join("%d:%g" % (int(rng.integers(0, num_ids)), float(np.float32(rng.uniform(0.1, 1.0)))) for _ in range(n))
+            f.write(("%d %s" % (n, ent)).strip() + "\n")
+
+
+def user_blocks(num_user_blocks, num_user, num_item, num_ufeedback, seed, max_rows=6, max_fb=5, split_every=0,
+                binary_label=False):
+    """User-grouped SVD++ blocks: each block = one user's rows + that user's feedback set with
+    value n^-1/2 (demo/implicitFeedback/mkimplicitfeedbackfeature.py:46-55).  split_every>0
+    splits every split_every'th user into START/MIDDLE/END pieces; some users have no feedback."""
+    rng = np.random.default_rng(seed)
+    blocks = []
+    users = rng.permutation(num_user)[:num_user_blocks]
+    for b, uid in enumerate(users):
+        nrow = int(rng.integers(1, max_rows + 1))
+        nfb = 0 if b % 7 == 3 else int(rng.integers(1, max_fb + 1))
+        fb_idx = np.sort(rng.choice(num_ufeedback, size=nfb, replace=False)).astype(np.uint32)
+        fb_val = np.full(nfb, 1.0 / np.sqrt(max(nfb, 1)), np.float32)
+        rows = []
+        for _ in range(nrow):
+            label = float(rng.integers(0, 2)) if binary_label else float(rng.integers(1, 6))
+            rows.append((label, [], [(int(uid), 1.0)], [(int(rng.integers(0, num_item)), 1.0)]))
+        data = CSRData.from_rows(rows)
+        if split_every and b % split_every == 1 and nrow >= 3:
+            cut1, cut2 = 1, nrow - 1
+            e = np.zeros(0, np.uint32), np.zeros(0, np.float32)
+            blocks.append(PlusBlock(fb_idx, fb_val, data.slice_rows(0, cut1), TAG_START))
+            blocks.append(PlusBlock(e[0], e[1], data.slice_rows(cut1, cut2), TAG_MIDDLE))
+            blocks.append(PlusBlock(fb_idx, fb_val, data.slice_rows(cut2, nrow), TAG_END))
+        else:
+            blocks.append(PlusBlock(fb_idx, fb_val, data, TAG_DEFAULT))
+    return blocks
+
+
+def rmse(pred, label):
+    d = pred.astype(np.float64) - label.astype(np.float64)
+    return float(np.sqrt(np.mean(d * d)))
