@@ -1,0 +1,153 @@
+/*
+ * svdfeature_amd.h -- C ABI of the MI355X-native apex_svd SGD engine (libsvdfeature_amd.so).
+ *
+ * This is the drop-in boundary for ONE path of Gnnng/SVDFeature: the SGD training/prediction step
+ * behind `class apex_svd::ISVDTrainer` (reference apex_svd.h:33-107), as implemented by the
+ * reference's base solver (solvers/base-solver/apex_svd_base.h: SVDFeature :79-479, SVDPPFeature
+ * :484-592).  The reference has no FFI layer of its own -- solvers are swapped at link time by
+ * providing `apex_svd::create_svd_trainer` (apex_svd.h:212, solvers/base-solver/Makefile:17-23) --
+ * so every entry point below is one ISVDTrainer virtual flattened to C: plain pointers and
+ * sizes, no C++ or torch types.  `svdfeature_amd/csrc/apex_svd_shim.{h,cpp}` is the C++ class
+ * with the reference's vtable order that forwards to these functions (INTEGRATION.md shows the
+ * reference-side link line).
+ *
+ * Error behaviour follows the reference (apex-utils/apex_utils.h:47-58: message on stderr, then
+ * exit(-1)) unless svdf_set_error_mode(1) was called, in which case a failing call returns a
+ * negative status / NULL and svdf_last_error() holds the message.  Index-bound violations
+ * ("user feature index exceed bound", apex_svd_base.h:320,327,343,360,530) are detected when
+ * instances are staged, before anything reaches the GPU.
+ *
+ * Threading: like the reference a handle is driven from one thread at a time.
+ * Borrowed pointers (instances, blocks) are copied before the call returns.
+ */
+#ifndef SVDFEATURE_AMD_H_
+#define SVDFEATURE_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct svdf_trainer svdf_trainer; /* opaque: one ISVDTrainer instance */
+typedef struct svdf_dataset svdf_dataset; /* opaque: a scheduled, HBM-resident training set */
+
+/* ---- library ---- */
+const char *svdf_version(void);
+/* 0 (default): reference behaviour, errors print and exit(-1).  1: errors return status codes. */
+void svdf_set_error_mode(int mode);
+const char *svdf_last_error(void);
+/* number of visible HIP devices (0 when there is no GPU; the library still loads). */
+int svdf_device_count(void);
+
+/* ---- lifecycle: apex_svd::create_svd_trainer(SVDTypeParam) (apex_svd.h:212; the four bytes are
+ * SVDTypeParam, apex_svd_model.h:242-261) and the virtual destructor (apex_svd.h:106).
+ * device < 0 selects the current HIP device. */
+svdf_trainer *svdf_create(uint8_t format_type, uint8_t active_type, uint8_t extend_type, uint8_t variant_type,
+                          int device);
+void svdf_destroy(svdf_trainer *t);
+
+/* ISVDTrainer::set_param (apex_svd.h:42; keys: apex_svd_base.h:126-136, apex_svd_model.h:350-368
+ * and :456-476, ParameterSet prefixes up:/ip:/uip:/gp: apex_svd_base.h:48-67).  Unknown keys are
+ * ignored, model-shape keys are ignored once the model is allocated. */
+int svdf_set_param(svdf_trainer *t, const char *name, const char *val);
+/* apex_random::seed (apex-tensor/apex_random.h:42-44) -> srand; process-global like the reference. */
+void svdf_seed(unsigned seed);
+/* ISVDTrainer::init_model (apex_svd.h:58; apex_svd_base.h:146-149): alloc + rand_init with libc
+ * rand(), bit-identical starting point, then upload to HBM. */
+int svdf_init_model(svdf_trainer *t);
+/* ISVDTrainer::load_model / save_model (apex_svd.h:47,52): byte-compatible with
+ * SVDModel::load_from_file / save_to_file (apex_svd_model.h:570-660).  The caller owns the FILE*
+ * and reads/writes the leading 4-byte SVDTypeParam itself (svd_feature.cpp:165-190). */
+int svdf_load_model(svdf_trainer *t, FILE *fi);
+int svdf_save_model(svdf_trainer *t, FILE *fo);
+/* ISVDTrainer::init_trainer (apex_svd.h:64; apex_svd_base.h:151-173, 499-503) */
+int svdf_init_trainer(svdf_trainer *t);
+/* ISVDTrainer::set_round / finish_round (apex_svd.h:72,77).  finish_round flushes staged work. */
+int svdf_set_round(svdf_trainer *t, int nround);
+int svdf_finish_round(svdf_trainer *t);
+
+/* ---- random-order input: ISVDTrainer::update(const SVDFeatureCSR::Elem&) / predict(const Elem&)
+ * (apex_svd.h:83,89).  index/value hold the global, user and item sections back to back exactly
+ * like Elem::set_space (apex_svd_data.h:71-78).  update stages the instance; the sequential
+ * result is materialised at the next flush point (finish_round, predict, save_model, set_round,
+ * destroy, or when the staging window fills). */
+int svdf_update_csr(svdf_trainer *t, float label, int num_global, int num_ufactor, int num_ifactor,
+                    const unsigned *index, const float *value);
+float svdf_predict_csr(svdf_trainer *t, float label, int num_global, int num_ufactor, int num_ifactor,
+                       const unsigned *index, const float *value);
+/* bulk forms over one SVDFeatureCSR block (apex_svd_data.h:109-127 member layout): equivalent to
+ * calling update/predict on rows 0..num_row-1 in order. */
+int svdf_update_csr_batch(svdf_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                          const unsigned *feat_index, const float *feat_value);
+int svdf_predict_csr_batch(svdf_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                           const unsigned *feat_index, const float *feat_value, float *out);
+
+/* ---- user-grouped input: ISVDTrainer::update(const SVDPlusBlock&) /
+ * predict(std::vector<float>&, const SVDPlusBlock&) (apex_svd.h:97,104); fields of SVDPlusBlock
+ * (apex_svd_data.h:376-393) passed flat.  out must hold num_row floats. */
+int svdf_update_block(svdf_trainer *t, int num_ufeedback, int extend_tag,
+                      const unsigned *index_ufeedback, const float *value_ufeedback,
+                      int num_row, const float *row_label, const int *row_ptr,
+                      const unsigned *feat_index, const float *feat_value);
+int svdf_predict_block(svdf_trainer *t, int num_ufeedback, int extend_tag,
+                       const unsigned *index_ufeedback, const float *value_ufeedback,
+                       int num_row, const float *row_label, const int *row_ptr,
+                       const unsigned *feat_index, const float *feat_value, float *out);
+
+/* ---- HBM-resident training sets (removes the per-instance virtual call).
+ * A dataset is the instance stream of one pass of svd_feature.cpp:220-248's inner loop, scheduled
+ * once and kept in HBM; svdf_train_dataset(t, ds) == update(x) for every x in file order.
+ * svdf_dataset_from_triples is the three-column form of SVDBasicLoader (apex_svd_data.cpp:32-67):
+ * no global feature, one user id and one item id with value 1. */
+svdf_dataset *svdf_dataset_from_csr(svdf_trainer *t, long num_row, const float *row_label, const int64_t *row_ptr,
+                                    const unsigned *feat_index, const float *feat_value);
+svdf_dataset *svdf_dataset_from_triples(svdf_trainer *t, long n, const unsigned *user, const unsigned *item,
+                                        const float *label);
+void svdf_dataset_destroy(svdf_dataset *ds);
+int svdf_train_dataset(svdf_trainer *t, svdf_dataset *ds);       /* one pass, asynchronous on the trainer's stream */
+int svdf_predict_dataset(svdf_trainer *t, svdf_dataset *ds, float *out); /* out[num_row], file order */
+/* dataset facts: 0 num_row, 1 number of conflict-free batches, 2 largest batch, 3 kernel kind
+ * (0 = basicMF fused kernel, 1 = general sparse kernel), 4 algorithmic bytes per pass */
+int64_t svdf_dataset_info(const svdf_dataset *ds, int what);
+
+/* ---- multi-GPU support: item-side parameters are replicated, each rank trains its
+ * user shard, and the item-side deltas of a window are summed across ranks by the caller's
+ * collective (RCCL all-reduce on the returned device buffer).
+ *   svdf_item_delta_begin   snapshot item-side parameters (W_item, i_bias [, g_bias])
+ *   svdf_item_delta_buffer  delta = current - snapshot, returned as ONE contiguous fp32 device
+ *                           buffer of *count floats (caller all-reduces it in place)
+ *   svdf_item_delta_apply   current = snapshot + (all-reduced) delta */
+int svdf_item_delta_begin(svdf_trainer *t);
+void *svdf_item_delta_buffer(svdf_trainer *t, int64_t *count);
+int svdf_item_delta_apply(svdf_trainer *t);
+
+/* ---- introspection used by tests, bench.py and the harness ---- */
+/* raw copies of parameter views: 0 u_bias 1 W_user 2 i_bias 3 W_item 4 g_bias 5 ufeedback_bias
+ * 6 W_ufeedback; rows are returned unpadded.  Returns number of floats or -1. */
+int64_t svdf_get_view(svdf_trainer *t, int which, float *out, int64_t capacity);
+int svdf_view_shape(svdf_trainer *t, int which, int *rows, int *cols);
+/* the HIP stream (hipStream_t) all of this trainer's work is enqueued on; timing code records
+ * HIP events on it. */
+void *svdf_stream(svdf_trainer *t);
+int svdf_synchronize(svdf_trainer *t);
+/* counters: 0 instances trained, 1 kernels launched, 2 conflict-free batches executed,
+ * 3 staged-window flushes */
+int64_t svdf_counter(svdf_trainer *t, int what);
+/* tuning knobs (not part of the reference surface): "stage_window" (instances staged before an
+ * automatic flush), "groups_per_wave".  Returns 0 if the knob exists. */
+int svdf_set_knob(svdf_trainer *t, const char *name, long value);
+
+/* ---- host-side conflict-free batch scheduler, exposed so it can be tested without a GPU.
+ * Unit r touches resources res[res_ptr[r] .. res_ptr[r+1]) out of num_res.  Writes the batch-sorted
+ * (stable) unit order and level_ptr[0..nlevels]; returns the number of batches, -2 if level_cap
+ * (capacity of level_ptr_out) is too small. */
+int svdf_schedule_resources(long n, const int64_t *res_ptr, const unsigned *res, long num_res, int *order_out,
+                            int64_t *level_ptr_out, long level_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVDFEATURE_AMD_H_ */

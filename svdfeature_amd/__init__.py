@@ -1,0 +1,312 @@
+"""svdfeature_amd -- MI355X-native engine for the apex_svd SGD hot path of Gnnng/SVDFeature.
+
+The product is ``libsvdfeature_amd.so`` (hand-written gfx950 HIP kernels + C++ host engine behind
+the C ABI of ``include/svdfeature_amd.h``).  This module is only the ctypes binding the tests and
+bench.py use; ``Trainer`` mirrors the reference's ``ISVDTrainer`` surface (apex_svd.h:33-107)
+method for method.  There is no CPU fallback: if the shared library is missing or no GPU is
+visible, construction fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from .data import CSRData, PlusBlock  # noqa: F401
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libsvdfeature_amd.so")
+HEADER_PATH = os.path.join(os.path.dirname(HERE), "include", "svdfeature_amd.h")
+
+VIEW = {"u_bias": 0, "W_user": 1, "i_bias": 2, "W_item": 3, "g_bias": 4, "ufeedback_bias": 5, "W_ufeedback": 6}
+
+_u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
+_i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+_i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
+_f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
+
+_lib = None
+_libc = C.CDLL(None)
+_libc.fopen.restype = C.c_void_p
+_libc.fopen.argtypes = [C.c_char_p, C.c_char_p]
+_libc.fclose.argtypes = [C.c_void_p]
+
+
+class SvdfError(RuntimeError):
+    pass
+
+
+def load_library():
+    """dlopen libsvdfeature_amd.so and declare every prototype of include/svdfeature_amd.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SvdfError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                        "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    P = C.c_void_p
+    lib.svdf_version.restype = C.c_char_p
+    lib.svdf_last_error.restype = C.c_char_p
+    lib.svdf_set_error_mode.argtypes = [C.c_int]
+    lib.svdf_device_count.restype = C.c_int
+    lib.svdf_create.restype = P
+    lib.svdf_create.argtypes = [C.c_uint8] * 4 + [C.c_int]
+    lib.svdf_destroy.argtypes = [P]
+    lib.svdf_set_param.argtypes = [P, C.c_char_p, C.c_char_p]
+    lib.svdf_seed.argtypes = [C.c_uint]
+    for f in ("svdf_init_model", "svdf_init_trainer", "svdf_finish_round", "svdf_synchronize",
+              "svdf_item_delta_begin", "svdf_item_delta_apply"):
+        getattr(lib, f).argtypes = [P]
+    lib.svdf_set_round.argtypes = [P, C.c_int]
+    lib.svdf_load_model.argtypes = [P, C.c_void_p]
+    lib.svdf_save_model.argtypes = [P, C.c_void_p]
+    lib.svdf_update_csr.argtypes = [P, C.c_float, C.c_int, C.c_int, C.c_int, _u32p, _f32p]
+    lib.svdf_predict_csr.argtypes = lib.svdf_update_csr.argtypes
+    lib.svdf_predict_csr.restype = C.c_float
+    lib.svdf_update_csr_batch.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p]
+    lib.svdf_predict_csr_batch.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p]
+    lib.svdf_update_block.argtypes = [P, C.c_int, C.c_int, _u32p, _f32p, C.c_int, _f32p, _i32p, _u32p, _f32p]
+    lib.svdf_predict_block.argtypes = lib.svdf_update_block.argtypes + [_f32p]
+    lib.svdf_dataset_from_csr.restype = P
+    lib.svdf_dataset_from_csr.argtypes = [P, C.c_long, _f32p, _i64p, _u32p, _f32p]
+    lib.svdf_dataset_from_triples.restype = P
+    lib.svdf_dataset_from_triples.argtypes = [P, C.c_long, _u32p, _u32p, _f32p]
+    lib.svdf_dataset_destroy.argtypes = [P]
+    lib.svdf_train_dataset.argtypes = [P, P]
+    lib.svdf_predict_dataset.argtypes = [P, P, _f32p]
+    lib.svdf_dataset_info.restype = C.c_int64
+    lib.svdf_dataset_info.argtypes = [P, C.c_int]
+    lib.svdf_item_delta_buffer.restype = P
+    lib.svdf_item_delta_buffer.argtypes = [P, C.POINTER(C.c_int64)]
+    lib.svdf_get_view.restype = C.c_int64
+    lib.svdf_get_view.argtypes = [P, C.c_int, _f32p, C.c_int64]
+    lib.svdf_view_shape.argtypes = [P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.svdf_stream.restype = P
+    lib.svdf_stream.argtypes = [P]
+    lib.svdf_counter.restype = C.c_int64
+    lib.svdf_counter.argtypes = [P, C.c_int]
+    lib.svdf_set_knob.argtypes = [P, C.c_char_p, C.c_long]
+    lib.svdf_schedule_resources.argtypes = [C.c_long, _i64p, _u32p, C.c_long, _i32p, _i64p, C.c_long]
+    lib.svdf_set_error_mode(1)   # python callers get exceptions instead of exit(-1)
+    _lib = lib
+    return lib
+
+
+def device_count():
+    return load_library().svdf_device_count()
+
+
+def _pad(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a if a.size else np.zeros(1, dtype=dtype)
+
+
+def schedule_resources(res_ptr, res, num_res):
+    """Host scheduler (no GPU needed): returns (order, level_ptr)."""
+    lib = load_library()
+    n = len(res_ptr) - 1
+    order = np.zeros(max(n, 1), np.int32)
+    level_ptr = np.zeros(n + 2, np.int64)
+    nl = lib.svdf_schedule_resources(n, _pad(res_ptr, np.int64), _pad(res, np.uint32), int(num_res), order, level_ptr, n + 2)
+    if nl < 0:
+        raise SvdfError(lib.svdf_last_error().decode())
+    return order[:n], level_ptr[:nl + 1]
+
+
+class Dataset:
+    """A scheduled, HBM-resident training set (svdf_dataset)."""
+
+    def __init__(self, trainer, handle):
+        self.trainer, self.h = trainer, handle
+
+    def info(self, what):
+        return int(self.trainer.lib.svdf_dataset_info(self.h, what))
+
+    num_row = property(lambda s: s.info(0))
+    num_batches = property(lambda s: s.info(1))
+    max_batch = property(lambda s: s.info(2))
+    kind = property(lambda s: s.info(3))
+    algorithmic_bytes = property(lambda s: s.info(4))
+
+    def close(self):
+        if self.h:
+            self.trainer.lib.svdf_dataset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Trainer:
+    """ISVDTrainer over the HIP engine.  device=-1: current GPU (required); device=-2: host-only
+    handle for config / model-file / staging logic (compute calls raise)."""
+
+    def __init__(self, format_type=0, active_type=0, extend_type=0, variant_type=0, params=None, device=-1):
+        self.lib = load_library()
+        self.h = self.lib.svdf_create(format_type, active_type, extend_type, variant_type, device)
+        if not self.h:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        self.mtype = bytes([format_type, active_type, extend_type, variant_type])
+        for k, v in (params or {}).items():
+            self.set_param(k, v)
+
+    # -- plumbing
+    def _ok(self, rc):
+        if rc != 0:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.svdf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- ISVDTrainer
+    def set_param(self, name, val):
+        self._ok(self.lib.svdf_set_param(self.h, str(name).encode(), str(val).encode()))
+
+    def seed(self, s):
+        self.lib.svdf_seed(int(s))
+
+    def init_model(self):
+        self._ok(self.lib.svdf_init_model(self.h))
+
+    def init_trainer(self):
+        self._ok(self.lib.svdf_init_trainer(self.h))
+
+    def set_round(self, r):
+        self._ok(self.lib.svdf_set_round(self.h, int(r)))
+
+    def finish_round(self):
+        self._ok(self.lib.svdf_finish_round(self.h))
+
+    def save_model(self, path, with_type_header=True):
+        """Caller-side protocol of svd_feature.cpp:184-191: fopen, 4-byte SVDTypeParam, save_model(fo)."""
+        fo = _libc.fopen(str(path).encode(), b"wb")
+        if not fo:
+            raise SvdfError("can not open file \"%s\"" % path)
+        try:
+            if with_type_header:
+                hdr = (C.c_char * 4).from_buffer_copy(self.mtype)
+                _libc.fwrite(hdr, 1, 4, C.c_void_p(fo))
+            self._ok(self.lib.svdf_save_model(self.h, fo))
+        finally:
+            _libc.fclose(fo)
+
+    def load_model(self, path, with_type_header=True):
+        fi = _libc.fopen(str(path).encode(), b"rb")
+        if not fi:
+            raise SvdfError("can not open file \"%s\"" % path)
+        try:
+            if with_type_header:
+                buf = (C.c_char * 4)()
+                _libc.fread(buf, 1, 4, C.c_void_p(fi))
+            self._ok(self.lib.svdf_load_model(self.h, fi))
+        finally:
+            _libc.fclose(fi)
+
+    def update_csr(self, label, ng, nu, ni, index, value):
+        self._ok(self.lib.svdf_update_csr(self.h, float(label), ng, nu, ni, _pad(index, np.uint32), _pad(value, np.float32)))
+
+    def predict_csr(self, label, ng, nu, ni, index, value):
+        self.lib.svdf_last_error()
+        return self.lib.svdf_predict_csr(self.h, float(label), ng, nu, ni, _pad(index, np.uint32), _pad(value, np.float32))
+
+    def update_batch(self, d):
+        self._ok(self.lib.svdf_update_csr_batch(self.h, d.num_row, _pad(d.row_label, np.float32), _pad(d.row_ptr, np.int32),
+                                                _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32)))
+
+    def predict_batch(self, d):
+        out = np.zeros(max(d.num_row, 1), dtype=np.float32)
+        self._ok(self.lib.svdf_predict_csr_batch(self.h, d.num_row, _pad(d.row_label, np.float32), _pad(d.row_ptr, np.int32),
+                                                 _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32), out))
+        return out[:d.num_row]
+
+    def update_block(self, b):
+        d = b.data
+        self._ok(self.lib.svdf_update_block(self.h, b.num_ufeedback, b.extend_tag, _pad(b.index_ufeedback, np.uint32),
+                                            _pad(b.value_ufeedback, np.float32), d.num_row, _pad(d.row_label, np.float32),
+                                            _pad(d.row_ptr, np.int32), _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32)))
+
+    def predict_block(self, b):
+        d = b.data
+        out = np.zeros(max(d.num_row, 1), dtype=np.float32)
+        self._ok(self.lib.svdf_predict_block(self.h, b.num_ufeedback, b.extend_tag, _pad(b.index_ufeedback, np.uint32),
+                                             _pad(b.value_ufeedback, np.float32), d.num_row, _pad(d.row_label, np.float32),
+                                             _pad(d.row_ptr, np.int32), _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32), out))
+        return out[:d.num_row]
+
+    # -- resident datasets
+    def dataset_from_csr(self, d):
+        h = self.lib.svdf_dataset_from_csr(self.h, d.num_row, _pad(d.row_label, np.float32), _pad(d.row_ptr, np.int64),
+                                           _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32))
+        if not h:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return Dataset(self, h)
+
+    def dataset_from_triples(self, user, item, label):
+        n = len(label)
+        h = self.lib.svdf_dataset_from_triples(self.h, n, _pad(user, np.uint32), _pad(item, np.uint32), _pad(label, np.float32))
+        if not h:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return Dataset(self, h)
+
+    def train_dataset(self, ds):
+        self._ok(self.lib.svdf_train_dataset(self.h, ds.h))
+
+    def predict_dataset(self, ds):
+        out = np.zeros(max(ds.num_row, 1), dtype=np.float32)
+        self._ok(self.lib.svdf_predict_dataset(self.h, ds.h, out))
+        return out[:ds.num_row]
+
+    # -- multi-GPU item-side delta
+    def item_delta_begin(self):
+        self._ok(self.lib.svdf_item_delta_begin(self.h))
+
+    def item_delta_buffer(self):
+        """(device pointer, float count) of the packed item-side delta."""
+        n = C.c_int64()
+        p = self.lib.svdf_item_delta_buffer(self.h, C.byref(n))
+        if not p:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return p, n.value
+
+    def item_delta_apply(self):
+        self._ok(self.lib.svdf_item_delta_apply(self.h))
+
+    # -- introspection
+    def view(self, name):
+        rows, cols = C.c_int(), C.c_int()
+        self._ok(self.lib.svdf_view_shape(self.h, VIEW[name], C.byref(rows), C.byref(cols)))
+        if rows.value < 0:
+            return None
+        out = np.zeros(max(rows.value * cols.value, 1), dtype=np.float32)
+        n = self.lib.svdf_get_view(self.h, VIEW[name], out, out.size)
+        if n < 0:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        out = out[:n]
+        return out.reshape(rows.value, cols.value) if name.startswith("W_") else out
+
+    def synchronize(self):
+        self._ok(self.lib.svdf_synchronize(self.h))
+
+    def stream(self):
+        return self.lib.svdf_stream(self.h)
+
+    def counter(self, what):
+        return int(self.lib.svdf_counter(self.h, what))
+
+    def set_knob(self, name, value):
+        self._ok(self.lib.svdf_set_knob(self.h, name.encode(), int(value)))
+
+
+_libc.fwrite.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+_libc.fread.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]

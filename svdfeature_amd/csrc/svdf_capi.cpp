@@ -1,0 +1,156 @@
+// svdf_capi.cpp -- extern "C" surface of include/svdfeature_amd.h over svdf::Engine.
+#include <svdfeature_amd.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "svdf_engine.h"
+#include "svdf_kernels.h"
+
+namespace svdf {
+void set_error_mode(int m);
+const char *last_error();
+void note_error(const std::string &m);
+}  // namespace svdf
+
+struct svdf_trainer { svdf::Engine *e; };
+struct svdf_dataset { svdf::Dataset *d; };
+
+// In error mode 0 svdf::fail() has already printed and exited (reference behaviour); in mode 1 it
+// throws and the wrapper turns that into a status code.
+#define SVDF_GUARD(retval, ...)                                 \
+    try { __VA_ARGS__; }                                        \
+    catch (const std::exception &ex) { svdf::note_error(ex.what()); return retval; } \
+    catch (...) { svdf::note_error("unknown error"); return retval; }
+
+extern "C" {
+
+const char *svdf_version(void) { return "svdfeature_amd 0.1 (gfx950)"; }
+void svdf_set_error_mode(int mode) { svdf::set_error_mode(mode); }
+const char *svdf_last_error(void) { return svdf::last_error(); }
+int svdf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+svdf_trainer *svdf_create(uint8_t format_type, uint8_t active_type, uint8_t extend_type, uint8_t variant_type, int device) {
+    SVDF_GUARD(nullptr, {
+        svdf::TypeParam tp{format_type, active_type, extend_type, variant_type};
+        svdf_trainer *t = new svdf_trainer();
+        t->e = nullptr;
+        try { t->e = new svdf::Engine(tp, device); } catch (...) { delete t; throw; }
+        return t;
+    })
+}
+void svdf_destroy(svdf_trainer *t) {
+    if (!t) return;
+    try { delete t->e; } catch (...) {}
+    delete t;
+}
+int svdf_set_param(svdf_trainer *t, const char *name, const char *val) { SVDF_GUARD(-1, { t->e->set_param(name, val); return 0; }) }
+void svdf_seed(unsigned seed) { srand(seed); }
+int svdf_init_model(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->init_model(); return 0; }) }
+int svdf_load_model(svdf_trainer *t, FILE *fi) { SVDF_GUARD(-1, { t->e->load_model(fi); return 0; }) }
+int svdf_save_model(svdf_trainer *t, FILE *fo) { SVDF_GUARD(-1, { t->e->save_model(fo); return 0; }) }
+int svdf_init_trainer(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->init_trainer(); return 0; }) }
+int svdf_set_round(svdf_trainer *t, int nround) { SVDF_GUARD(-1, { t->e->set_round(nround); return 0; }) }
+int svdf_finish_round(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->finish_round(); return 0; }) }
+
+int svdf_update_csr(svdf_trainer *t, float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
+    SVDF_GUARD(-1, { t->e->update_csr(label, ng, nu, ni, index, value); return 0; })
+}
+float svdf_predict_csr(svdf_trainer *t, float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
+    SVDF_GUARD(0.0f, { return t->e->predict_csr(label, ng, nu, ni, index, value); })
+}
+int svdf_update_csr_batch(svdf_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                          const unsigned *feat_index, const float *feat_value) {
+    SVDF_GUARD(-1, { t->e->update_csr_batch(num_row, row_label, row_ptr, feat_index, feat_value); return 0; })
+}
+int svdf_predict_csr_batch(svdf_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                           const unsigned *feat_index, const float *feat_value, float *out) {
+    SVDF_GUARD(-1, { t->e->predict_csr_batch(num_row, row_label, row_ptr, feat_index, feat_value, out); return 0; })
+}
+int svdf_update_block(svdf_trainer *t, int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row,
+                      const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value) {
+    SVDF_GUARD(-1, { t->e->update_block(nfb, tag, ifb, vfb, num_row, row_label, row_ptr, feat_index, feat_value); return 0; })
+}
+int svdf_predict_block(svdf_trainer *t, int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row,
+                       const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value, float *out) {
+    SVDF_GUARD(-1, { t->e->predict_block(nfb, tag, ifb, vfb, num_row, row_label, row_ptr, feat_index, feat_value, out); return 0; })
+}
+
+svdf_dataset *svdf_dataset_from_csr(svdf_trainer *t, long num_row, const float *row_label, const int64_t *row_ptr,
+                                    const unsigned *feat_index, const float *feat_value) {
+    SVDF_GUARD(nullptr, {
+        svdf::Dataset *d = t->e->dataset_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);
+        svdf_dataset *h = new svdf_dataset();
+        h->d = d;
+        return h;
+    })
+}
+svdf_dataset *svdf_dataset_from_triples(svdf_trainer *t, long n, const unsigned *user, const unsigned *item, const float *label) {
+    SVDF_GUARD(nullptr, {
+        svdf::Dataset *d = t->e->dataset_from_triples(n, user, item, label);
+        svdf_dataset *h = new svdf_dataset();
+        h->d = d;
+        return h;
+    })
+}
+void svdf_dataset_destroy(svdf_dataset *ds) {
+    if (!ds) return;
+    try { if (ds->d && ds->d->owner) ds->d->owner->synchronize(); } catch (...) {}
+    delete ds->d;
+    delete ds;
+}
+int svdf_train_dataset(svdf_trainer *t, svdf_dataset *ds) { SVDF_GUARD(-1, { t->e->train_dataset(ds->d); return 0; }) }
+int svdf_predict_dataset(svdf_trainer *t, svdf_dataset *ds, float *out) { SVDF_GUARD(-1, { t->e->predict_dataset(ds->d, out); return 0; }) }
+int64_t svdf_dataset_info(const svdf_dataset *ds, int what) {
+    if (!ds || !ds->d) return -1;
+    switch (what) {
+    case 0: return ds->d->num_row;
+    case 1: return (int64_t)ds->d->sched.num_levels();
+    case 2: return ds->d->sched.max_level_size;
+    case 3: return ds->d->kind;
+    case 4: return ds->d->algorithmic_bytes;
+    default: return -1;
+    }
+}
+
+int svdf_item_delta_begin(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->item_delta_begin(); return 0; }) }
+void *svdf_item_delta_buffer(svdf_trainer *t, int64_t *count) { SVDF_GUARD(nullptr, { return t->e->item_delta_buffer(count); }) }
+int svdf_item_delta_apply(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->item_delta_apply(); return 0; }) }
+
+int64_t svdf_get_view(svdf_trainer *t, int which, float *out, int64_t capacity) { SVDF_GUARD(-1, { return t->e->get_view(which, out, capacity); }) }
+int svdf_view_shape(svdf_trainer *t, int which, int *rows, int *cols) { SVDF_GUARD(-1, { t->e->view_shape(which, rows, cols); return 0; }) }
+void *svdf_stream(svdf_trainer *t) { return (void *)t->e->stream(); }
+int svdf_synchronize(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->synchronize(); return 0; }) }
+int64_t svdf_counter(svdf_trainer *t, int what) { return t->e->counter(what); }
+int svdf_set_knob(svdf_trainer *t, const char *name, long value) { SVDF_GUARD(-1, { return t->e->set_knob(name, value); }) }
+
+// host-side scheduler exposed for CPU tests (tests/test_scheduler.py): levels for a CSR stream over
+// `num_res` resources where instance r touches resources res[res_ptr[r]..res_ptr[r+1]).
+int svdf_schedule_resources(long n, const int64_t *res_ptr, const unsigned *res, long num_res, int *order_out,
+                            int64_t *level_ptr_out, long level_cap) {
+    SVDF_GUARD(-1, {
+        std::vector<int> last((size_t)num_res, 0), levels((size_t)n);
+        for (long r = 0; r < n; r++) {
+            int l = 0;
+            for (int64_t j = res_ptr[r]; j < res_ptr[r + 1]; j++) l = std::max(l, last[res[j]]);
+            l += 1;
+            for (int64_t j = res_ptr[r]; j < res_ptr[r + 1]; j++) last[res[j]] = l;
+            levels[(size_t)r] = l;
+        }
+        svdf::Schedule s;
+        svdf::build_schedule(levels, 0, s);
+        if ((long)s.num_levels() + 1 > level_cap) return -2;
+        for (long r = 0; r < n; r++) order_out[r] = s.order[(size_t)r];
+        for (size_t l = 0; l <= s.num_levels(); l++) level_ptr_out[l] = s.level_ptr[l];
+        return (int)s.num_levels();
+    })
+}
+
+}  // extern "C"

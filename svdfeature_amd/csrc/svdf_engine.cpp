@@ -1,0 +1,1104 @@
+// svdf_engine.cpp -- see svdf_engine.h.  Reference citations are relative to /root/reference.
+#include "svdf_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <thread>
+
+#include "svdf_kernels.h"
+
+namespace svdf {
+
+// =============================================================================== errors
+static int g_error_mode = 0;
+static thread_local std::string g_last_error;
+void set_error_mode(int m) { g_error_mode = m; }
+const char *last_error() { return g_last_error.c_str(); }
+void note_error(const std::string &m) { g_last_error = m; }
+
+[[noreturn]] void fail(const std::string &msg) {
+    g_last_error = msg;
+    if (g_error_mode == 0) {  // apex-utils/apex_utils.h:47-50
+        fprintf(stderr, "%s\n", msg.c_str());
+        exit(-1);
+    }
+    throw Error(msg);
+}
+static inline void check(bool ok, const char *msg) { if (!ok) fail(msg); }
+#define HIPCHECK(call)                                                                           \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) fail(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #call); \
+    } while (0)
+
+// =============================================================================== DevBuf
+template <typename T>
+void DevBuf<T>::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+template <typename T>
+void DevBuf<T>::reserve(size_t n) {
+    if (n <= cap && p) return;
+    release();
+    size_t want = n ? n : 1;
+    HIPCHECK(hipMalloc((void **)&p, want * sizeof(T)));
+    cap = want;
+}
+template <typename T>
+void DevBuf<T>::upload(const T *src, size_t n, hipStream_t st) {
+    reserve(n);
+    if (n) HIPCHECK(hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, st));
+}
+template struct DevBuf<float>;
+template struct DevBuf<int>;
+template struct DevBuf<unsigned>;
+template struct DevBuf<DevUnit>;
+
+// =============================================================================== scheduler
+void build_schedule(const std::vector<int> &levels, int base, Schedule &out) {
+    const long n = (long)levels.size();
+    int maxl = base;
+    for (long t = 0; t < n; t++) maxl = std::max(maxl, levels[(size_t)t]);
+    const int nl = maxl - base;                 // number of batches; batch j holds level base+1+j
+    std::vector<long> cnt((size_t)nl + 1, 0);
+    for (long t = 0; t < n; t++) cnt[(size_t)(levels[(size_t)t] - base)]++;
+    out.level_ptr.assign((size_t)nl + 1, 0);
+    out.max_level_size = 0;
+    long acc = 0;
+    for (int j = 0; j < nl; j++) {
+        out.level_ptr[(size_t)j] = acc;
+        acc += cnt[(size_t)j + 1];
+        out.max_level_size = std::max(out.max_level_size, cnt[(size_t)j + 1]);
+    }
+    out.level_ptr[(size_t)nl] = acc;
+    std::vector<long> cursor(out.level_ptr.begin(), out.level_ptr.end());
+    out.order.resize((size_t)n);
+    for (long t = 0; t < n; t++) out.order[(size_t)cursor[(size_t)(levels[(size_t)t] - base - 1)]++] = (int)t;   // counting sort: stable
+}
+
+// =============================================================================== small parsers
+void ParamSet::set_param(const char *name, const char *val) {  // apex_svd_base.h:48-68
+    if (!strncmp(name, prefix_a.c_str(), prefix_a.size())) name += prefix_a.size();
+    else if (!strncmp(name, prefix_b.c_str(), prefix_b.size())) name += prefix_b.size();
+    else return;
+    if (!strcmp("bound", name)) {
+        unsigned bd = (unsigned)atoi(val);
+        check(bd > 0, "can't give 0 as bound");
+        check(bound.empty() || bound.back() < bd, "bound must be given in order");
+        check(bound.size() + 1 == wd.size(), "must specifiy wd in each range");
+        bound.push_back(bd - 1);
+    }
+    if (!strcmp("wd", name)) {
+        check(wd.size() == bound.size(), "setting must be exactly");
+        wd.push_back((float)atof(val));
+    }
+}
+void SideTable::load(const char *fname) {  // apex-utils/apex_utils.h:172-195
+    row_ptr.assign(1, 0);
+    index.clear();
+    value.clear();
+    FILE *fi = fopen(fname, "r");
+    if (!fi) fail(std::string("can not open file \"") + fname + "\"");
+    int n;
+    while (fscanf(fi, "%d", &n) == 1) {
+        row_ptr.push_back(row_ptr.back() + (unsigned)n);
+        for (int i = 0; i < n; i++) {
+            unsigned idx;
+            float v;
+            if (fscanf(fi, "%u:%f", &idx, &v) != 2) { fclose(fi); fail("load sparse feature"); }
+            index.push_back(idx);
+            value.push_back(v);
+        }
+    }
+    fclose(fi);
+}
+static void tp_set_param(TrainParam &p, const char *name, const char *val) {  // apex_svd_model.h:350-368
+    if (!strcmp("learning_rate", name)) p.learning_rate = (float)atof(val);
+    if (!strcmp("wd_user", name)) p.wd_user = (float)atof(val);
+    if (!strcmp("wd_item", name)) p.wd_item = (float)atof(val);
+    if (!strcmp("wd_uiset", name)) p.wd_user = p.wd_item = (float)atof(val);
+    if (!strcmp("wd_user_bias", name)) p.wd_user_bias = (float)atof(val);
+    if (!strcmp("wd_item_bias", name)) p.wd_item_bias = (float)atof(val);
+    if (!strcmp("wd_uiset_bias", name)) p.wd_user_bias = p.wd_item_bias = (float)atof(val);
+    if (!strcmp("wd_global", name)) p.wd_global = (float)atof(val);
+    if (!strcmp("reg_method", name)) p.reg_method = atoi(val);
+    if (!strcmp("reg_global", name)) p.reg_global = atoi(val);
+    if (!strcmp("num_regfree_global", name)) p.num_regfree_global = (unsigned)atoi(val);
+    if (!strcmp("decay_learning_rate", name)) p.decay_learning_rate = atoi(val);
+    if (!strcmp("min_learning_rate", name)) p.min_learning_rate = (float)atof(val);
+    if (!strcmp("decay_rate", name)) p.decay_rate = (float)atof(val);
+    if (!strcmp("scale_lr_ufeedback", name)) p.scale_lr_ufeedback = (float)atof(val);
+    if (!strcmp("wd_ufeedback", name)) p.wd_ufeedback = (float)atof(val);
+    if (!strcmp("wd_ufeedback_bias", name)) p.wd_ufeedback_bias = (float)atof(val);
+}
+static void mp_set_param(ModelParam &p, const char *name, const char *val) {  // apex_svd_model.h:456-476
+    if (!strcmp("num_user", name)) p.num_user = atoi(val);
+    if (!strcmp("num_item", name)) p.num_item = atoi(val);
+    if (!strcmp("num_uiset", name)) p.num_user = p.num_item = atoi(val);
+    if (!strcmp("num_global", name)) p.num_global = atoi(val);
+    if (!strcmp("num_factor", name)) p.num_factor = atoi(val);
+    if (!strcmp("u_init_sigma", name)) p.u_init_sigma = (float)atof(val);
+    if (!strcmp("i_init_sigma", name)) p.i_init_sigma = (float)atof(val);
+    if (!strcmp("ui_init_sigma", name)) p.u_init_sigma = p.i_init_sigma = (float)atof(val);
+    if (!strcmp("base_score", name)) p.base_score = (float)atof(val);
+    if (!strcmp("no_user_bias", name)) p.no_user_bias = atoi(val);
+    if (!strcmp("num_ufeedback", name)) p.num_ufeedback = atoi(val);
+    if (!strcmp("num_randinit_ufactor", name)) p.num_randinit_ufactor = atoi(val);
+    if (!strcmp("num_randinit_ifactor", name)) p.num_randinit_ifactor = atoi(val);
+    if (!strcmp("num_randinit_uifactor", name)) p.num_randinit_ifactor = p.num_randinit_ufactor = atoi(val);
+    if (!strcmp("ufeedback_init_sigma", name)) p.ufeedback_init_sigma = (float)atof(val);
+    if (!strcmp("common_latent_space", name)) p.common_latent_space = atoi(val);
+    if (!strcmp("common_feedback_space", name)) p.common_feedback_space = atoi(val);
+    if (!strcmp("user_nonnegative", name)) p.user_nonnegative = atoi(val);
+    if (!strcmp("item_nonnegative", name)) p.item_nonnegative = atoi(val);
+}
+
+// =============================================================================== lifecycle
+Engine::Engine(TypeParam mtype, int device) : mtype_(mtype) {
+    memset(&mp_, 0, sizeof(mp_));
+    mp_.u_init_sigma = mp_.i_init_sigma = 0.01f;   // SVDModelParam() apex_svd_model.h:436-450
+    mp_.base_score = 0.5f;
+    memset(&tp_, 0, sizeof(tp_));
+    tp_.learning_rate = 0.01f;                     // SVDTrainParam() apex_svd_model.h:334-344
+    tp_.decay_rate = 1.0f;
+    tp_.scale_lr_ufeedback = 1.0f;
+    u_param_.prefix_a = "up:"; u_param_.prefix_b = "uip:";   // apex_svd_base.h:103
+    i_param_.prefix_a = "ip:"; i_param_.prefix_b = "uip:";
+    g_param_.prefix_a = "gp:"; g_param_.prefix_b = "gp:";
+    memset(&dev_params_, 0, sizeof(dev_params_));
+    if (device == -2) {   // host-only handle: config / model file / scheduler logic, no compute
+        host_only_ = true;
+        return;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        fail("svdfeature_amd: no HIP device visible -- this engine has no CPU fallback");
+    if (device >= 0) HIPCHECK(hipSetDevice(device));
+    HIPCHECK(hipGetDevice(&device_));
+    HIPCHECK(hipStreamCreate(&stream_));
+}
+
+Engine::~Engine() {
+    if (!host_only_ && stream_) {
+        try { flush(); } catch (...) {}
+        (void)hipStreamSynchronize(stream_);
+        (void)hipStreamDestroy(stream_);
+    }
+}
+
+void Engine::need_device(const char *what) {
+    if (host_only_) fail(std::string("svdfeature_amd: ") + what + " needs a GPU (handle was created host-only)");
+    HIPCHECK(hipSetDevice(device_));
+}
+
+void Engine::set_param(const char *name, const char *val) {  // apex_svd_base.h:126-136
+    if (trainer_ready_ && !host_only_) flush();   // staged instances were issued under the old parameters
+    if (!strcmp(name, "feature_user")) name_feat_user_ = val;
+    if (!strcmp(name, "feature_item")) name_feat_item_ = val;
+    tp_set_param(tp_, name, val);
+    u_param_.set_param(name, val);
+    i_param_.set_param(name, val);
+    g_param_.set_param(name, val);
+    if (!space_allocated_) mp_set_param(mp_, name, val);
+    params_dirty_ = true;
+}
+
+void Engine::compute_geometry() {  // SVDModel::alloc_space apex_svd_model.h:511-556
+    const int ustart = (mp_.common_feedback_space == 0 && user_group()) ? mp_.num_ufeedback : 0;
+    if (mp_.common_latent_space == 0) {
+        n_uiset_ = (long)ustart + mp_.num_user + mp_.num_item;
+        user_off_ = (unsigned)ustart;
+        item_off_ = (unsigned)(ustart + mp_.num_user);
+    } else {
+        check(mp_.num_user == mp_.num_item, "num_user and num_item must be the same to use common latent space");
+        check(mp_.common_feedback_space != 0, "common latent space must enforce common feedback space");
+        n_uiset_ = mp_.num_item;
+        user_off_ = item_off_ = (unsigned)ustart;
+    }
+    fb_off_ = mp_.common_feedback_space == 0 ? 0u : user_off_;
+    pitch_ = ((mp_.num_factor + 3) / 4) * 4;   // ceil(4k/16)*16 bytes (apex_tensor_sse.h:26-27)
+    space_allocated_ = true;
+}
+void Engine::alloc_host_model() {
+    compute_geometry();
+    hW_.assign((size_t)n_uiset_ * pitch_, 0.0f);
+    hbias_.assign((size_t)n_uiset_, 0.0f);
+    hg_.assign((size_t)mp_.num_global, 0.0f);
+    host_model_valid_ = true;
+}
+
+// ---- PRNG: apex-tensor/apex_random.h:42-77 over libc rand(), so the starting point is bit-identical
+static inline double next_double2() { return ((double)rand() + 1.0) / ((double)RAND_MAX + 2.0); }
+static inline double sample_normal() {
+    double x, y, s;
+    do {
+        x = 2 * next_double2() - 1.0;
+        y = 2 * next_double2() - 1.0;
+        s = x * x + y * y;
+    } while (s >= 1.0 || s == 0.0);
+    return x * sqrt(-2.0 * log(s) / s);
+}
+static void sample_gaussian(float *w, long rows, int cols, int pitch, float sd) {  // apex_tensor_cpu_inline_common.h:249-253
+    for (long y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) w[(size_t)y * pitch + x] = (float)sample_normal() * sd;
+}
+static float calc_base_score(float base_score, int type) {  // apex_svd_model.h:220-237
+    switch (type) {
+    case ACT_LINEAR: case ACT_HINGE_L2: case ACT_HINGE_SMOOTH: return base_score;
+    case ACT_SIGMOID_L2: case ACT_SIGMOID_LIKELIHOOD: case ACT_SIGMOID_RANK: case ACT_SIGMOID_QSGRAD:
+        check(base_score > 0.0f && base_score < 1.0f, "sigmoid range constrain");
+        return -logf(1.0f / base_score - 1.0f);
+    default: fail("unkown active type");
+    }
+}
+void Engine::rand_init() {  // SVDModel::rand_init apex_svd_model.h:665-705
+    mp_.base_score = calc_base_score(mp_.base_score, mtype_.active_type);
+    const int k = mp_.num_factor;
+    float *Wu = hW_.data() + (size_t)user_off_ * pitch_;
+    float *Wi = hW_.data() + (size_t)item_off_ * pitch_;
+    {
+        long rows = mp_.num_randinit_ufactor != 0 ? mp_.num_randinit_ufactor : mp_.num_user;
+        sample_gaussian(Wu, rows, k, pitch_, mp_.u_init_sigma);
+        if (mp_.user_nonnegative)
+            for (long y = 0; y < mp_.num_user; y++)
+                for (int x = 0; x < k; x++) Wu[(size_t)y * pitch_ + x] = fabsf(Wu[(size_t)y * pitch_ + x]);
+    }
+    if (mp_.common_latent_space == 0) {
+        long rows = mp_.num_randinit_ifactor != 0 ? mp_.num_randinit_ifactor : mp_.num_item;
+        sample_gaussian(Wi, rows, k, pitch_, mp_.i_init_sigma);
+        if (mp_.item_nonnegative)
+            for (long y = 0; y < rows; y++)
+                for (int x = 0; x < k; x++) Wi[(size_t)y * pitch_ + x] = fabsf(Wi[(size_t)y * pitch_ + x]);
+    }
+    if (user_group())  // draws are consumed even when sigma == 0 (apex_svd_model.h:702-704)
+        sample_gaussian(hW_.data() + (size_t)fb_off_ * pitch_, num_fb_rows(), k, pitch_, mp_.ufeedback_init_sigma);
+}
+
+void Engine::init_model() {  // apex_svd_base.h:146-149
+    alloc_host_model();
+    rand_init();
+    if (device_model_) upload_model();
+}
+
+// ---- model file: apex_svd_model.h:570-660; tensors: int header x_max[,y_max] + unpadded rows
+static void save_1d(FILE *fo, const float *v, int n) {
+    fwrite(&n, sizeof(int), 1, fo);
+    fwrite(v, sizeof(float), (size_t)n, fo);
+}
+static void save_2d(FILE *fo, const float *w, int rows, int cols, int pitch) {
+    int hdr[2] = {cols, rows};
+    fwrite(hdr, sizeof(int), 2, fo);
+    for (int y = 0; y < rows; y++) fwrite(w + (size_t)y * pitch, sizeof(float), (size_t)cols, fo);
+}
+static void load_1d(FILE *fi, float *v, int n) {
+    int x;
+    check(fread(&x, sizeof(int), 1, fi) > 0, "tensor::load_from_file");
+    check(x == n, "tensor::load_from_file: shape does not match the model header");
+    if (n > 0) check(fread(v, sizeof(float), (size_t)n, fi) > 0, "tensor::load_from_file");
+}
+static void load_2d(FILE *fi, float *w, int rows, int cols, int pitch) {
+    int hdr[2];
+    check(fread(hdr, sizeof(int), 2, fi) > 0, "tensor::load_from_file");
+    check(hdr[0] == cols && hdr[1] == rows, "tensor::load_from_file: shape does not match the model header");
+    for (int y = 0; y < rows; y++)
+        if (cols > 0) check(fread(w + (size_t)y * pitch, sizeof(float), (size_t)cols, fi) > 0, "tensor::load_from_file");
+}
+void Engine::write_model(FILE *fo) {
+    const int k = mp_.num_factor;
+    fwrite(&mp_, sizeof(ModelParam), 1, fo);
+    if (mp_.common_latent_space == 0) {
+        save_1d(fo, hbias_.data() + user_off_, mp_.num_user);
+        save_2d(fo, hW_.data() + (size_t)user_off_ * pitch_, mp_.num_user, k, pitch_);
+        save_1d(fo, hbias_.data() + item_off_, mp_.num_item);
+        save_2d(fo, hW_.data() + (size_t)item_off_ * pitch_, mp_.num_item, k, pitch_);
+    } else {
+        save_1d(fo, hbias_.data(), (int)n_uiset_);
+        save_2d(fo, hW_.data(), (int)n_uiset_, k, pitch_);
+    }
+    save_1d(fo, hg_.data(), mp_.num_global);
+    if (user_group() && mp_.common_feedback_space == 0) {
+        save_1d(fo, hbias_.data(), mp_.num_ufeedback);
+        save_2d(fo, hW_.data(), mp_.num_ufeedback, k, pitch_);
+    }
+}
+void Engine::read_model(FILE *fi) {
+    if (fread(&mp_, sizeof(ModelParam), 1, fi) == 0) fail("error loading CF SVD model");
+    alloc_host_model();
+    const int k = mp_.num_factor;
+    if (mp_.common_latent_space == 0) {
+        load_1d(fi, hbias_.data() + user_off_, mp_.num_user);
+        load_2d(fi, hW_.data() + (size_t)user_off_ * pitch_, mp_.num_user, k, pitch_);
+        load_1d(fi, hbias_.data() + item_off_, mp_.num_item);
+        load_2d(fi, hW_.data() + (size_t)item_off_ * pitch_, mp_.num_item, k, pitch_);
+    } else {
+        load_1d(fi, hbias_.data(), (int)n_uiset_);
+        load_2d(fi, hW_.data(), (int)n_uiset_, k, pitch_);
+    }
+    load_1d(fi, hg_.data(), mp_.num_global);
+    if (user_group() && mp_.common_feedback_space == 0) {
+        load_1d(fi, hbias_.data(), mp_.num_ufeedback);
+        load_2d(fi, hW_.data(), mp_.num_ufeedback, k, pitch_);
+    }
+}
+void Engine::load_model(FILE *fi) {  // apex_svd_base.h:138-140
+    if (trainer_ready_ && !host_only_) flush();
+    read_model(fi);
+    params_dirty_ = true;
+    if (device_model_) upload_model();
+}
+void Engine::save_model(FILE *fo) {  // apex_svd_base.h:142-144
+    check(space_allocated_, "save_model: model is not initialised");
+    if (device_model_) { flush(); download_model(); }
+    check(host_model_valid_, "save_model: no model");
+    write_model(fo);
+    if (device_model_) { hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hg_.clear(); host_model_valid_ = false; }
+}
+
+void Engine::upload_model() {
+    need_device("uploading the model");
+    check(host_model_valid_, "upload_model: no host model");
+    dW_.upload(hW_.data(), hW_.size(), stream_);
+    dbias_.upload(hbias_.data(), hbias_.size(), stream_);
+    dg_.upload(hg_.data(), hg_.size(), stream_);
+    std::vector<float> zero((size_t)2 * pitch_ + 4, 0.0f);
+    dstate_.upload(zero.data(), zero.size(), stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    device_model_ = true;
+    params_dirty_ = true;
+    hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hbias_.shrink_to_fit(); hg_.clear();
+    host_model_valid_ = false;
+}
+void Engine::download_model() {
+    need_device("downloading the model");
+    hW_.resize((size_t)n_uiset_ * pitch_);
+    hbias_.resize((size_t)n_uiset_);
+    hg_.resize((size_t)mp_.num_global);
+    if (!hW_.empty()) HIPCHECK(hipMemcpyAsync(hW_.data(), dW_.p, hW_.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (!hbias_.empty()) HIPCHECK(hipMemcpyAsync(hbias_.data(), dbias_.p, hbias_.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (!hg_.empty()) HIPCHECK(hipMemcpyAsync(hg_.data(), dg_.p, hg_.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    HIPCHECK(hipStreamSynchronize(stream_));
+    host_model_valid_ = true;
+}
+
+void Engine::init_trainer() {  // apex_svd_base.h:151-173, 499-503
+    check(space_allocated_, "init_trainer: call init_model or load_model first");
+    if (name_feat_user_ != "NULL") feat_user_.load(name_feat_user_.c_str());
+    if (name_feat_item_ != "NULL") feat_item_.load(name_feat_item_.c_str());
+    // the reference indexes children unchecked; validate once here instead
+    for (unsigned c : feat_user_.index) check(c < (unsigned)mp_.num_user, "feature_user: child index exceed bound");
+    for (unsigned c : feat_item_.index) check(c < (unsigned)mp_.num_item, "feature_item: child index exceed bound");
+    if (tp_.reg_method >= 4 || tp_.reg_global >= 4)
+        fail("svdfeature_amd: lazy decay (reg_method/reg_global >= 4) is not supported (see DESIGN.md, out of scope)");
+    check(tp_.reg_method >= 0 && tp_.reg_method <= 3, "unknown reg_method");
+    check(tp_.reg_global == 0 || tp_.reg_global == 1, "unknown global decay method");
+    trainer_ready_ = true;
+    if (host_only_) return;
+    if (mp_.num_factor > max_supported_factor())
+        fail("svdfeature_amd: num_factor > 256 is not supported by the gfx950 kernels yet");
+    if (!device_model_) upload_model();
+    tracker_.resize(num_resources() + 1);
+    params_dirty_ = true;
+}
+
+void Engine::set_round(int nround) {  // apex_svd_base.h:470-478
+    if (tp_.decay_learning_rate != 0) {
+        check(round_counter_ <= nround, "round counter restriction");
+        if (round_counter_ < nround && trainer_ready_ && !host_only_) flush();
+        while (round_counter_ < nround) {
+            tp_.learning_rate *= tp_.decay_rate;
+            round_counter_++;
+        }
+        params_dirty_ = true;
+    }
+}
+void Engine::finish_round() {
+    if (trainer_ready_ && !host_only_) flush();
+}
+
+const DevParams &Engine::params() {
+    if (!params_dirty_) return dev_params_;
+    need_device("building kernel parameters");
+    DevParams &P = dev_params_;
+    memset(&P, 0, sizeof(P));
+    P.W = dW_.p; P.bias = dbias_.p; P.g_bias = dg_.p; P.svdpp_state = dstate_.p;
+    P.pitch = pitch_; P.k = mp_.num_factor;
+    P.user_off = user_off_; P.item_off = item_off_; P.fb_off = fb_off_;
+    P.num_user = mp_.num_user; P.num_item = mp_.num_item; P.num_global = mp_.num_global; P.num_ufeedback = mp_.num_ufeedback;
+    P.base_score = mp_.base_score;
+    P.active_type = mtype_.active_type; P.no_user_bias = mp_.no_user_bias; P.user_nonnegative = mp_.user_nonnegative;
+    P.user_group = user_group() ? 1 : 0;
+    P.lr = tp_.learning_rate; P.wd_user = tp_.wd_user; P.wd_item = tp_.wd_item;
+    P.wd_user_bias = tp_.wd_user_bias; P.wd_item_bias = tp_.wd_item_bias; P.wd_global = tp_.wd_global;
+    P.reg_method = tp_.reg_method; P.reg_global = tp_.reg_global; P.num_regfree_global = tp_.num_regfree_global;
+    P.scale_lr_ufeedback = tp_.scale_lr_ufeedback; P.wd_ufeedback = tp_.wd_ufeedback; P.wd_ufeedback_bias = tp_.wd_ufeedback_bias;
+    auto up_ranges = [&](const ParamSet &ps, DevBuf<unsigned> &db, DevBuf<float> &dw, DevRanges &out, unsigned max_id) {
+        out.n = 0; out.bound = nullptr; out.wd = nullptr;
+        if (ps.bound.empty()) return;
+        // ParameterSet::get_wd asserts idx < bound.size() for every id it is asked about
+        if (max_id > 0) check(ps.bound.back() >= max_id - 1, "bound set err");
+        db.upload(ps.bound.data(), ps.bound.size(), stream_);
+        dw.upload(ps.wd.data(), ps.bound.size(), stream_);
+        out.n = (int)ps.bound.size(); out.bound = db.p; out.wd = dw.p;
+    };
+    up_ranges(u_param_, d_ubound_, d_uwd_, P.u_rng, (unsigned)mp_.num_user);
+    up_ranges(i_param_, d_ibound_, d_iwd_, P.i_rng, (unsigned)mp_.num_item);
+    up_ranges(g_param_, d_gbound_, d_gwd_, P.g_rng, (unsigned)mp_.num_global);
+    auto up_table = [&](const SideTable &t, DevBuf<unsigned> &dp, DevBuf<unsigned> &di, DevBuf<float> &dv, DevSideTable &out) {
+        out.num_row = 0; out.row_ptr = nullptr; out.index = nullptr; out.value = nullptr;
+        if (t.num_row() == 0) return;
+        dp.upload(t.row_ptr.data(), t.row_ptr.size(), stream_);
+        di.upload(t.index.data(), t.index.size(), stream_);
+        dv.upload(t.value.data(), t.value.size(), stream_);
+        out.num_row = t.num_row(); out.row_ptr = dp.p; out.index = di.p; out.value = dv.p;
+    };
+    up_table(feat_user_, d_fu_ptr_, d_fu_idx_, d_fu_val_, P.feat_user);
+    up_table(feat_item_, d_fi_ptr_, d_fi_idx_, d_fi_val_, P.feat_item);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    params_dirty_ = false;
+    return dev_params_;
+}
+
+// =============================================================================== staging
+void Engine::check_row(int ng, int nu, int ni, const unsigned *index) {  // asserts of apex_svd_base.h:320,327,343,360
+    for (int j = 0; j < ng; j++) check(index[j] < (unsigned)mp_.num_global, "global feature index exceed setting");
+    for (int j = 0; j < nu; j++) check(index[ng + j] < (unsigned)mp_.num_user, "user feature index exceed bound");
+    for (int j = 0; j < ni; j++) check(index[ng + nu + j] < (unsigned)mp_.num_item, "item feature index exceed bound");
+}
+void Engine::stage_rows(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value) {
+    for (int r = 0; r < num_row; r++) {
+        const int p0 = row_ptr[3 * r], p1 = row_ptr[3 * r + 1], p2 = row_ptr[3 * r + 2], p3 = row_ptr[3 * r + 3];
+        check(p0 <= p1 && p1 <= p2 && p2 <= p3, "CSR row_ptr must be non-decreasing");
+        check_row(p1 - p0, p2 - p1, p3 - p2, feat_index + p0);
+        const int base = staged_.row_ptr.back() - p0;
+        staged_.row_label.push_back(row_label[r]);
+        staged_.row_ptr.push_back(p1 + base);
+        staged_.row_ptr.push_back(p2 + base);
+        staged_.row_ptr.push_back(p3 + base);
+        staged_.feat_index.insert(staged_.feat_index.end(), feat_index + p0, feat_index + p3);
+        staged_.feat_value.insert(staged_.feat_value.end(), feat_value + p0, feat_value + p3);
+    }
+}
+bool Engine::basic_fast_path_allowed() const {
+    return !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
+}
+
+void Engine::update_csr(float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
+    const int ptr[4] = {0, ng, ng + nu, ng + nu + ni};
+    update_csr_batch(1, &label, ptr, index, value);
+}
+void Engine::update_csr_batch(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value) {
+    check(trainer_ready_, "update: init_trainer has not been called");
+    need_device("update");
+    if (user_group()) {
+        // SVDPPFeature inherits update(Elem) (apex_svd_base.h:464-466): rows run against the current
+        // implicit-feedback state without prepare/scatter
+        const int h = (int)staged_.num_row();
+        stage_rows(num_row, row_label, row_ptr, feat_index, feat_value);
+        if (!staged_units_.empty() && !(staged_units_.back().flags & (UNIT_START | UNIT_END)) && staged_units_.back().row_end == h)
+            staged_units_.back().row_end = h + num_row;
+        else
+            staged_units_.push_back(HostUnit{0, 0, h, h + num_row, UNIT_LOAD | UNIT_SAVE});
+    } else {
+        stage_rows(num_row, row_label, row_ptr, feat_index, feat_value);
+    }
+    if (staged_.num_row() >= stage_window_) flush();
+}
+
+void Engine::update_block(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label,
+                          const int *row_ptr, const unsigned *feat_index, const float *feat_value) {
+    check(trainer_ready_, "update: init_trainer has not been called");
+    need_device("update");
+    check(user_group(), "not implemented");   // SVDFeature has no update(SVDPlusBlock) (apex_svd.h:97)
+    for (int j = 0; j < nfb; j++) check(ifb[j] < (unsigned)mp_.num_ufeedback, "ufeedback id exceed bound");
+    const int h = (int)staged_.num_row();
+    stage_rows(num_row, row_label, row_ptr, feat_index, feat_value);
+    const bool starts = (tag == TAG_DEFAULT || tag == TAG_START);
+    const bool ends = (tag == TAG_DEFAULT || tag == TAG_END);
+    auto push_fb = [&](int &b, int &e) {
+        b = (int)staged_fb_index_.size();
+        staged_fb_index_.insert(staged_fb_index_.end(), ifb, ifb + nfb);
+        staged_fb_value_.insert(staged_fb_value_.end(), vfb, vfb + nfb);
+        e = (int)staged_fb_index_.size();
+    };
+    HostUnit *u = nullptr;
+    // a MIDDLE/END block continues the unit staged just before it, if that unit is still open here
+    if (!starts && !staged_units_.empty() && unit_open_ && !unit_open_on_device_ && staged_units_.back().row_end == h &&
+        !(staged_units_.back().flags & UNIT_END)) {
+        u = &staged_units_.back();
+        u->row_end = h + num_row;
+    } else {
+        HostUnit nu{0, 0, h, h + num_row, 0};
+        if (starts) { push_fb(nu.fb_begin, nu.fb_end); nu.flags |= UNIT_START; }
+        else nu.flags |= UNIT_LOAD;
+        staged_units_.push_back(nu);
+        u = &staged_units_.back();
+    }
+    if (ends) {
+        // update_ufeedback scatters through the END block's own feedback list (apex_svd_base.h:579-581).
+        // It is kept next to the prepare list: [fb_begin,fb_end) prepare, the scatter list is appended and
+        // recorded by re-pointing fb_* when the unit did not start here.
+        if (!(u->flags & UNIT_START)) push_fb(u->fb_begin, u->fb_end);
+        else if (tag == TAG_END) {
+            // START and END merged in one flush: the scatter list must equal the prepare list
+            bool same = (u->fb_end - u->fb_begin) == nfb;
+            for (int j = 0; same && j < nfb; j++)
+                same = staged_fb_index_[(size_t)u->fb_begin + j] == ifb[j] && staged_fb_value_[(size_t)u->fb_begin + j] == vfb[j];
+            check(same, "svdfeature_amd: START and END blocks of one user must carry the same feedback list");
+        }
+        u->flags |= UNIT_END;
+        unit_open_ = false;
+        unit_open_on_device_ = false;
+    } else {
+        unit_open_ = true;
+    }
+    if (staged_.num_row() >= stage_window_) flush();
+}
+
+// =============================================================================== scheduling helpers
+int Engine::level_of_row(const unsigned *ig, int ng, const unsigned *iu, int nu, const unsigned *ii, int ni, int lvl) {
+    const int *last = tracker_.last.data();
+    const size_t goff = (size_t)n_uiset_;
+    for (int j = 0; j < ng; j++) lvl = std::max(lvl, last[goff + ig[j]]);
+    for (int j = 0; j < nu; j++) {
+        const unsigned uid = iu[j];
+        lvl = std::max(lvl, last[user_off_ + uid]);
+        if (uid < feat_user_.num_row())
+            for (unsigned c = feat_user_.row_ptr[uid]; c < feat_user_.row_ptr[uid + 1]; c++) lvl = std::max(lvl, last[user_off_ + feat_user_.index[c]]);
+    }
+    for (int j = 0; j < ni; j++) {
+        const unsigned iid = ii[j];
+        lvl = std::max(lvl, last[item_off_ + iid]);
+        if (iid < feat_item_.num_row())
+            for (unsigned c = feat_item_.row_ptr[iid]; c < feat_item_.row_ptr[iid + 1]; c++) lvl = std::max(lvl, last[item_off_ + feat_item_.index[c]]);
+    }
+    return lvl;
+}
+void Engine::touch_row(const unsigned *ig, int ng, const unsigned *iu, int nu, const unsigned *ii, int ni, int lvl) {
+    int *last = tracker_.last.data();
+    const size_t goff = (size_t)n_uiset_;
+    for (int j = 0; j < ng; j++) last[goff + ig[j]] = lvl;
+    for (int j = 0; j < nu; j++) {
+        const unsigned uid = iu[j];
+        last[user_off_ + uid] = lvl;
+        if (uid < feat_user_.num_row())
+            for (unsigned c = feat_user_.row_ptr[uid]; c < feat_user_.row_ptr[uid + 1]; c++) last[user_off_ + feat_user_.index[c]] = lvl;
+    }
+    for (int j = 0; j < ni; j++) {
+        const unsigned iid = ii[j];
+        last[item_off_ + iid] = lvl;
+        if (iid < feat_item_.num_row())
+            for (unsigned c = feat_item_.row_ptr[iid]; c < feat_item_.row_ptr[iid + 1]; c++) last[item_off_ + feat_item_.index[c]] = lvl;
+    }
+}
+
+template <typename T>
+static void parallel_gather(T *dst, const T *src, const int *order, long n, long stride, long offset) {
+    // dst[s] = src[order[s]*stride + offset]
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (n < (1 << 20) || hw == 1) {
+        for (long s = 0; s < n; s++) dst[s] = src[(long)order[s] * stride + offset];
+        return;
+    }
+    std::vector<std::thread> th;
+    const long chunk = (n + hw - 1) / hw;
+    for (unsigned t = 0; t < hw; t++) {
+        const long a = t * chunk, b = std::min(n, a + chunk);
+        if (a >= b) break;
+        th.emplace_back([=]() { for (long s = a; s < b; s++) dst[s] = src[(long)order[s] * stride + offset]; });
+    }
+    for (auto &x : th) x.join();
+}
+
+// =============================================================================== flush
+void Engine::flush() {
+    if (host_only_ || !trainer_ready_) return;
+    if (user_group()) flush_units();
+    else flush_csr();
+}
+
+void Engine::flush_csr() {
+    const long n = staged_.num_row();
+    if (n == 0) return;
+    need_device("update");
+    const DevParams &P = params();
+    tracker_.resize(num_resources() + 1);
+    const int base = tracker_.base;
+    std::vector<int> levels((size_t)n);
+    bool basic = basic_fast_path_allowed();
+    if (basic) {
+        for (long r = 0; r < n && basic; r++) {
+            const int *p = &staged_.row_ptr[(size_t)3 * r];
+            basic = (p[1] == p[0]) && (p[2] == p[1] + 1) && (p[3] == p[2] + 1);
+        }
+    }
+    int *last = tracker_.last.data();
+    for (long r = 0; r < n; r++) {
+        const int *p = &staged_.row_ptr[(size_t)3 * r];
+        const unsigned *idx = staged_.feat_index.data();
+        int lvl = level_of_row(idx + p[0], p[1] - p[0], idx + p[1], p[2] - p[1], idx + p[2], p[3] - p[2], base) + 1;
+        touch_row(idx + p[0], p[1] - p[0], idx + p[1], p[2] - p[1], idx + p[2], p[3] - p[2], lvl);
+        levels[(size_t)r] = lvl;
+    }
+    (void)last;
+    Schedule sched;
+    build_schedule(levels, base, sched);
+    tracker_.base = base + (int)sched.num_levels();
+    if (basic) {
+        std::vector<unsigned> su((size_t)n), si((size_t)n);
+        std::vector<float> sl((size_t)n), sua((size_t)n), sia((size_t)n);
+        bool unit = true;
+        for (long s = 0; s < n; s++) {
+            const long r = sched.order[(size_t)s];
+            su[(size_t)s] = staged_.feat_index[(size_t)2 * r];
+            si[(size_t)s] = staged_.feat_index[(size_t)2 * r + 1];
+            sl[(size_t)s] = staged_.row_label[(size_t)r];
+            sua[(size_t)s] = staged_.feat_value[(size_t)2 * r];
+            sia[(size_t)s] = staged_.feat_value[(size_t)2 * r + 1];
+            unit = unit && sua[(size_t)s] == 1.0f && sia[(size_t)s] == 1.0f;
+        }
+        w_user_.upload(su.data(), (size_t)n, stream_);
+        w_item_.upload(si.data(), (size_t)n, stream_);
+        w_label_.upload(sl.data(), (size_t)n, stream_);
+        BasicSchedule S{w_user_.p, w_item_.p, w_label_.p, nullptr, nullptr};
+        if (!unit) {
+            w_uval_.upload(sua.data(), (size_t)n, stream_);
+            w_ival_.upload(sia.data(), (size_t)n, stream_);
+            S.uval = w_uval_.p; S.ival = w_ival_.p;
+        }
+        HIPCHECK(hipStreamSynchronize(stream_));
+        for (size_t l = 0; l < sched.num_levels(); l++) {
+            launch_basicmf(P, S, sched.level_ptr[l], sched.level_ptr[l + 1], groups_per_wave_, stream_);
+            n_launches_++;
+        }
+    } else {
+        w_label_.upload(staged_.row_label.data(), (size_t)n, stream_);
+        w_ptr_.upload(staged_.row_ptr.data(), staged_.row_ptr.size(), stream_);
+        w_index_.upload(staged_.feat_index.data(), staged_.feat_index.size(), stream_);
+        w_value_.upload(staged_.feat_value.data(), staged_.feat_value.size(), stream_);
+        w_order_.upload(sched.order.data(), (size_t)n, stream_);
+        HIPCHECK(hipStreamSynchronize(stream_));
+        DevCSR D{w_label_.p, w_ptr_.p, w_index_.p, w_value_.p};
+        for (size_t l = 0; l < sched.num_levels(); l++) {
+            launch_general(P, D, w_order_.p, sched.level_ptr[l], sched.level_ptr[l + 1], stream_);
+            n_launches_++;
+        }
+    }
+    HIPCHECK(hipGetLastError());
+    n_batches_ += (int64_t)sched.num_levels();
+    n_instances_ += n;
+    n_flushes_++;
+    staged_.clear();
+}
+
+void Engine::flush_units() {
+    const long nu = (long)staged_units_.size();
+    if (nu == 0) { staged_.clear(); return; }
+    need_device("update");
+    const DevParams &P = params();
+    tracker_.resize(num_resources() + 1);
+    const size_t state_res = num_resources();
+    const int base = tracker_.base;
+    // the last unit always leaves its implicit-feedback registers in the device state slot, the way the
+    // reference leaves them in the trainer's members
+    staged_units_.back().flags |= UNIT_SAVE;
+    std::vector<int> levels((size_t)nu);
+    std::vector<DevUnit> du((size_t)nu);
+    int *last = tracker_.last.data();
+    const unsigned *idx = staged_.feat_index.data();
+    for (long t = 0; t < nu; t++) {
+        const HostUnit &u = staged_units_[(size_t)t];
+        int lvl = base;
+        for (int r = u.row_begin; r < u.row_end; r++) {
+            const int *p = &staged_.row_ptr[(size_t)3 * r];
+            lvl = level_of_row(idx + p[0], p[1] - p[0], idx + p[1], p[2] - p[1], idx + p[2], p[3] - p[2], lvl);
+        }
+        for (int j = u.fb_begin; j < u.fb_end; j++) lvl = std::max(lvl, last[fb_off_ + staged_fb_index_[(size_t)j]]);
+        if (u.flags & (UNIT_LOAD | UNIT_SAVE)) lvl = std::max(lvl, last[state_res]);
+        lvl += 1;
+        for (int r = u.row_begin; r < u.row_end; r++) {
+            const int *p = &staged_.row_ptr[(size_t)3 * r];
+            touch_row(idx + p[0], p[1] - p[0], idx + p[1], p[2] - p[1], idx + p[2], p[3] - p[2], lvl);
+        }
+        for (int j = u.fb_begin; j < u.fb_end; j++) last[fb_off_ + staged_fb_index_[(size_t)j]] = lvl;
+        if (u.flags & (UNIT_LOAD | UNIT_SAVE)) last[state_res] = lvl;
+        levels[(size_t)t] = lvl;
+        du[(size_t)t] = DevUnit{u.fb_begin, u.fb_end, u.row_begin, u.row_end, u.flags};
+    }
+    Schedule sched;
+    build_schedule(levels, base, sched);
+    tracker_.base = base + (int)sched.num_levels();
+    const long n = staged_.num_row();
+    w_label_.upload(staged_.row_label.data(), (size_t)n, stream_);
+    w_ptr_.upload(staged_.row_ptr.data(), staged_.row_ptr.size(), stream_);
+    w_index_.upload(staged_.feat_index.data(), staged_.feat_index.size(), stream_);
+    w_value_.upload(staged_.feat_value.data(), staged_.feat_value.size(), stream_);
+    w_fbidx_.upload(staged_fb_index_.data(), staged_fb_index_.size(), stream_);
+    w_fbval_.upload(staged_fb_value_.data(), staged_fb_value_.size(), stream_);
+    w_units_.upload(du.data(), du.size(), stream_);
+    w_order_.upload(sched.order.data(), (size_t)nu, stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    DevCSR D{w_label_.p, w_ptr_.p, w_index_.p, w_value_.p};
+    for (size_t l = 0; l < sched.num_levels(); l++) {
+        launch_svdpp(P, D, w_units_.p, w_fbidx_.p, w_fbval_.p, w_order_.p, sched.level_ptr[l], sched.level_ptr[l + 1], stream_);
+        n_launches_++;
+    }
+    HIPCHECK(hipGetLastError());
+    n_batches_ += (int64_t)sched.num_levels();
+    n_instances_ += n;
+    n_flushes_++;
+    if (unit_open_) unit_open_on_device_ = true;
+    staged_.clear();
+    staged_units_.clear();
+    staged_fb_index_.clear();
+    staged_fb_value_.clear();
+}
+
+// =============================================================================== predict
+float Engine::predict_csr(float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
+    const int ptr[4] = {0, ng, ng + nu, ng + nu + ni};
+    float out = 0.0f;
+    predict_csr_batch(1, &label, ptr, index, value, &out);
+    return out;
+}
+void Engine::predict_csr_batch(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index,
+                               const float *feat_value, float *out) {
+    check(trainer_ready_, "predict: init_trainer has not been called");
+    need_device("predict");
+    if (num_row <= 0) return;
+    if (user_group()) {  // SVDFeature::predict(Elem) against the current implicit-feedback state
+        predict_block(0, TAG_MIDDLE, nullptr, nullptr, num_row, row_label, row_ptr, feat_index, feat_value, out);
+        return;
+    }
+    flush();
+    const DevParams &P = params();
+    HostCSR tmp;
+    tmp.row_label.reserve((size_t)num_row);
+    std::swap(tmp, staged_);
+    stage_rows(num_row, row_label, row_ptr, feat_index, feat_value);
+    std::swap(tmp, staged_);
+    w_label_.upload(tmp.row_label.data(), tmp.row_label.size(), stream_);
+    w_ptr_.upload(tmp.row_ptr.data(), tmp.row_ptr.size(), stream_);
+    w_index_.upload(tmp.feat_index.data(), tmp.feat_index.size(), stream_);
+    w_value_.upload(tmp.feat_value.data(), tmp.feat_value.size(), stream_);
+    w_out_.reserve((size_t)num_row);
+    DevCSR D{w_label_.p, w_ptr_.p, w_index_.p, w_value_.p};
+    launch_predict(P, D, num_row, w_out_.p, stream_);
+    n_launches_++;
+    HIPCHECK(hipMemcpyAsync(out, w_out_.p, (size_t)num_row * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    HIPCHECK(hipStreamSynchronize(stream_));
+}
+void Engine::predict_block(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label,
+                           const int *row_ptr, const unsigned *feat_index, const float *feat_value, float *out) {
+    check(trainer_ready_, "predict: init_trainer has not been called");
+    need_device("predict");
+    check(user_group(), "not implemented");
+    for (int j = 0; j < nfb; j++) check(ifb[j] < (unsigned)mp_.num_ufeedback, "ufeedback id exceed bound");
+    flush();
+    const DevParams &P = params();
+    HostCSR tmp;
+    std::swap(tmp, staged_);
+    stage_rows(num_row, row_label, row_ptr, feat_index, feat_value);
+    std::swap(tmp, staged_);
+    const bool starts = (tag == TAG_DEFAULT || tag == TAG_START);
+    DevUnit u{0, starts ? nfb : 0, 0, num_row, (starts ? UNIT_START : UNIT_LOAD) | UNIT_SAVE};
+    w_label_.upload(tmp.row_label.data(), tmp.row_label.size(), stream_);
+    w_ptr_.upload(tmp.row_ptr.data(), tmp.row_ptr.size(), stream_);
+    w_index_.upload(tmp.feat_index.data(), tmp.feat_index.size(), stream_);
+    w_value_.upload(tmp.feat_value.data(), tmp.feat_value.size(), stream_);
+    w_fbidx_.upload(ifb, starts ? (size_t)nfb : 0, stream_);
+    w_fbval_.upload(vfb, starts ? (size_t)nfb : 0, stream_);
+    w_units_.upload(&u, 1, stream_);
+    w_out_.reserve((size_t)std::max(num_row, 1));
+    DevCSR D{w_label_.p, w_ptr_.p, w_index_.p, w_value_.p};
+    launch_svdpp_predict(P, D, w_units_.p, w_fbidx_.p, w_fbval_.p, 1, w_out_.p, stream_);
+    n_launches_++;
+    if (num_row > 0) HIPCHECK(hipMemcpyAsync(out, w_out_.p, (size_t)num_row * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    HIPCHECK(hipStreamSynchronize(stream_));
+}
+
+// =============================================================================== datasets
+Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
+    check(trainer_ready_, "dataset: init_trainer has not been called");
+    need_device("dataset");
+    if (!basic_fast_path_allowed()) {
+        // fall back to the general representation (side tables / shared latent space / user-group trainer)
+        std::vector<int64_t> ptr((size_t)3 * n + 1);
+        std::vector<unsigned> idx((size_t)2 * n);
+        std::vector<float> val((size_t)2 * n, 1.0f);
+        for (long r = 0; r < n; r++) {
+            ptr[(size_t)3 * r] = 2 * r; ptr[(size_t)3 * r + 1] = 2 * r; ptr[(size_t)3 * r + 2] = 2 * r + 1;
+            idx[(size_t)2 * r] = user[r]; idx[(size_t)2 * r + 1] = item[r];
+        }
+        ptr[(size_t)3 * n] = 2 * n;
+        return dataset_from_csr(n, label, ptr.data(), idx.data(), val.data());
+    }
+    for (long r = 0; r < n; r++) {
+        if (user[r] >= (unsigned)mp_.num_user) fail("user feature index exceed bound");
+        if (item[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound");
+    }
+    std::unique_ptr<Dataset> ds(new Dataset());
+    ds->owner = this; ds->num_row = n; ds->kind = 0;
+    // levels relative to an empty tracker: a dataset pass is always preceded by a flush and all launches
+    // are stream ordered, so it only has to be conflict-free within itself
+    std::vector<int> lastu((size_t)mp_.num_user, 0), lasti((size_t)mp_.num_item, 0), levels((size_t)n);
+    for (long r = 0; r < n; r++) {
+        const int l = std::max(lastu[user[r]], lasti[item[r]]) + 1;
+        lastu[user[r]] = l; lasti[item[r]] = l;
+        levels[(size_t)r] = l;
+    }
+    build_schedule(levels, 0, ds->sched);
+    { std::vector<int>().swap(levels); }
+    std::vector<unsigned> tmp((size_t)n);
+    const int *order = ds->sched.order.data();
+    parallel_gather(tmp.data(), user, order, n, 1, 0);
+    ds->user.upload(tmp.data(), (size_t)n, stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    parallel_gather(tmp.data(), item, order, n, 1, 0);
+    ds->item.upload(tmp.data(), (size_t)n, stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    parallel_gather(reinterpret_cast<float *>(tmp.data()), label, order, n, 1, 0);
+    ds->label.upload(reinterpret_cast<float *>(tmp.data()), (size_t)n, stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    ds->unit_values = true;
+    // 8k*(rows) + 8*(biases) + 16 + 8*nnz per instance
+    const long nb = mp_.no_user_bias ? 1 : 2;
+    ds->algorithmic_bytes = n * (8L * mp_.num_factor * 2 + 8 * nb + 16 + 8 * 2);
+    return ds.release();
+}
+
+Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) {
+    check(trainer_ready_, "dataset: init_trainer has not been called");
+    need_device("dataset");
+    check(!user_group(), "svdfeature_amd: resident datasets are for random-order (format_type 0) trainers");
+    const long n = num_row;
+    const int64_t p00 = row_ptr[0];
+    check(row_ptr[3 * n] - p00 < (int64_t)2147483647, "dataset: more than 2^31-1 feature entries");
+    bool basic = basic_fast_path_allowed();
+    bool unit = true;
+    for (long r = 0; r < n; r++) {
+        const int64_t *p = row_ptr + 3 * r;
+        check(p[0] <= p[1] && p[1] <= p[2] && p[2] <= p[3], "CSR row_ptr must be non-decreasing");
+        check_row((int)(p[1] - p[0]), (int)(p[2] - p[1]), (int)(p[3] - p[2]), feat_index + p[0]);
+        if (basic) basic = (p[1] == p[0]) && (p[2] == p[1] + 1) && (p[3] == p[2] + 1);
+    }
+    if (basic) {
+        for (long r = 0; r < n && unit; r++) unit = feat_value[row_ptr[3 * r]] == 1.0f && feat_value[row_ptr[3 * r] + 1] == 1.0f;
+        if (unit) {
+            std::vector<unsigned> u((size_t)n), it((size_t)n);
+            for (long r = 0; r < n; r++) { u[(size_t)r] = feat_index[row_ptr[3 * r]]; it[(size_t)r] = feat_index[row_ptr[3 * r] + 1]; }
+            return dataset_from_triples(n, u.data(), it.data(), row_label);
+        }
+    }
+    std::unique_ptr<Dataset> ds(new Dataset());
+    ds->owner = this; ds->num_row = n;
+    std::vector<int> levels((size_t)n);
+    LevelTracker saved;
+    std::swap(saved, tracker_);   // schedule against an empty tracker (see dataset_from_triples)
+    tracker_.resize(num_resources() + 1);
+    long nnz = 0, nrows_touched = 0, nbias = 0, ng_total = 0;
+    for (long r = 0; r < n; r++) {
+        const int64_t *p = row_ptr + 3 * r;
+        const unsigned *ig = feat_index + p[0], *iu = feat_index + p[1], *ii = feat_index + p[2];
+        const int ng = (int)(p[1] - p[0]), nu = (int)(p[2] - p[1]), ni = (int)(p[3] - p[2]);
+        const int lvl = level_of_row(ig, ng, iu, nu, ii, ni, 0) + 1;
+        touch_row(ig, ng, iu, nu, ii, ni, lvl);
+        levels[(size_t)r] = lvl;
+        long nc_u = 0, nc_i = 0;
+        for (int j = 0; j < nu; j++) if (iu[j] < feat_user_.num_row()) nc_u += feat_user_.row_ptr[iu[j] + 1] - feat_user_.row_ptr[iu[j]];
+        for (int j = 0; j < ni; j++) if (ii[j] < feat_item_.num_row()) nc_i += feat_item_.row_ptr[ii[j] + 1] - feat_item_.row_ptr[ii[j]];
+        nnz += ng + nu + ni; ng_total += ng;
+        nrows_touched += nu + ni + nc_u + nc_i;
+        nbias += (mp_.no_user_bias ? 0 : nu + nc_u) + ni + nc_i;
+    }
+    std::swap(saved, tracker_);
+    build_schedule(levels, 0, ds->sched);
+    ds->algorithmic_bytes = 8L * mp_.num_factor * nrows_touched + 8 * nbias + 8 * ng_total + 16 * n + 8 * nnz;
+    if (basic) {   // basic structure with non-unit feature values
+        ds->kind = 0; ds->unit_values = false;
+        const int *order = ds->sched.order.data();
+        std::vector<unsigned> tu((size_t)n), ti((size_t)n);
+        std::vector<float> tl((size_t)n), tva((size_t)n), tvb((size_t)n);
+        for (long s = 0; s < n; s++) {
+            const int64_t p = row_ptr[3 * (long)order[s]];
+            tu[(size_t)s] = feat_index[p]; ti[(size_t)s] = feat_index[p + 1];
+            tva[(size_t)s] = feat_value[p]; tvb[(size_t)s] = feat_value[p + 1];
+            tl[(size_t)s] = row_label[order[s]];
+        }
+        ds->user.upload(tu.data(), (size_t)n, stream_); ds->item.upload(ti.data(), (size_t)n, stream_);
+        ds->label.upload(tl.data(), (size_t)n, stream_);
+        ds->uval.upload(tva.data(), (size_t)n, stream_); ds->ival.upload(tvb.data(), (size_t)n, stream_);
+        HIPCHECK(hipStreamSynchronize(stream_));
+        return ds.release();
+    }
+    ds->kind = 1;
+    std::vector<int> ptr32((size_t)3 * n + 1);
+    for (long j = 0; j <= 3 * n; j++) ptr32[(size_t)j] = (int)(row_ptr[j] - p00);
+    ds->row_label.upload(row_label, (size_t)n, stream_);
+    ds->row_ptr.upload(ptr32.data(), ptr32.size(), stream_);
+    ds->feat_index.upload(feat_index + p00, (size_t)ptr32.back(), stream_);
+    ds->feat_value.upload(feat_value + p00, (size_t)ptr32.back(), stream_);
+    ds->order.upload(ds->sched.order.data(), (size_t)n, stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    return ds.release();
+}
+
+void Engine::train_dataset(Dataset *ds) {
+    check(ds && ds->owner == this, "train_dataset: dataset belongs to another trainer");
+    flush();
+    const DevParams &P = params();
+    const Schedule &sc = ds->sched;
+    if (ds->kind == 0) {
+        BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
+        for (size_t l = 0; l < sc.num_levels(); l++) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, stream_);
+    } else {
+        DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
+        for (size_t l = 0; l < sc.num_levels(); l++) launch_general(P, D, ds->order.p, sc.level_ptr[l], sc.level_ptr[l + 1], stream_);
+    }
+    HIPCHECK(hipGetLastError());
+    n_launches_ += (int64_t)sc.num_levels();
+    n_batches_ += (int64_t)sc.num_levels();
+    n_instances_ += ds->num_row;
+}
+
+void Engine::predict_dataset(Dataset *ds, float *out) {
+    check(ds && ds->owner == this, "predict_dataset: dataset belongs to another trainer");
+    flush();
+    const DevParams &P = params();
+    const long n = ds->num_row;
+    if (n == 0) return;
+    w_out_.reserve((size_t)n);
+    if (ds->kind == 0) {
+        BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
+        launch_predict_basic(P, S, n, w_out_.p, stream_);
+        std::vector<float> tmp((size_t)n);
+        HIPCHECK(hipMemcpyAsync(tmp.data(), w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
+        const int *order = ds->sched.order.data();
+        for (long s = 0; s < n; s++) out[order[s]] = tmp[(size_t)s];
+    } else {
+        DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
+        launch_predict(P, D, n, w_out_.p, stream_);
+        HIPCHECK(hipMemcpyAsync(out, w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
+    }
+    n_launches_++;
+}
+
+// =============================================================================== item-side delta (multi-GPU)
+std::vector<Engine::Range> Engine::shared_ranges() {
+    check(mp_.common_latent_space == 0, "svdfeature_amd: user sharding needs separate user and item spaces");
+    std::vector<Range> r;
+    if (user_off_ > 0) r.push_back({dW_.p, (long)user_off_ * pitch_});
+    r.push_back({dW_.p + (size_t)item_off_ * pitch_, (long)(n_uiset_ - item_off_) * pitch_});
+    if (user_off_ > 0) r.push_back({dbias_.p, (long)user_off_});
+    r.push_back({dbias_.p + item_off_, (long)(n_uiset_ - item_off_)});
+    if (mp_.num_global > 0) r.push_back({dg_.p, (long)mp_.num_global});
+    return r;
+}
+void Engine::item_delta_begin() {
+    check(trainer_ready_, "item_delta: init_trainer has not been called");
+    need_device("item_delta");
+    flush();
+    auto rg = shared_ranges();
+    long total = 0;
+    for (auto &x : rg) total += x.n;
+    d_snap_.reserve((size_t)total);
+    d_delta_.reserve((size_t)total);
+    long off = 0;
+    for (auto &x : rg) {
+        HIPCHECK(hipMemcpyAsync(d_snap_.p + off, x.base, (size_t)x.n * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+        off += x.n;
+    }
+}
+void *Engine::item_delta_buffer(int64_t *count) {
+    need_device("item_delta");
+    flush();
+    auto rg = shared_ranges();
+    long off = 0;
+    for (auto &x : rg) {
+        launch_delta_sub(x.base, d_snap_.p + off, d_delta_.p + off, x.n, stream_);
+        off += x.n;
+    }
+    HIPCHECK(hipGetLastError());
+    if (count) *count = off;
+    return d_delta_.p;
+}
+void Engine::item_delta_apply() {
+    need_device("item_delta");
+    auto rg = shared_ranges();
+    long off = 0;
+    for (auto &x : rg) {
+        launch_delta_add(x.base, d_snap_.p + off, d_delta_.p + off, x.n, stream_);
+        off += x.n;
+    }
+    HIPCHECK(hipGetLastError());
+}
+
+// =============================================================================== introspection
+void Engine::view_shape(int which, int *rows, int *cols) {
+    *rows = -1; *cols = 0;
+    if (!space_allocated_) return;
+    switch (which) {
+    case 0: *rows = mp_.num_user; *cols = 1; break;
+    case 1: *rows = mp_.num_user; *cols = mp_.num_factor; break;
+    case 2: *rows = mp_.num_item; *cols = 1; break;
+    case 3: *rows = mp_.num_item; *cols = mp_.num_factor; break;
+    case 4: *rows = mp_.num_global; *cols = 1; break;
+    case 5: if (user_group()) { *rows = num_fb_rows(); *cols = 1; } break;
+    case 6: if (user_group()) { *rows = num_fb_rows(); *cols = mp_.num_factor; } break;
+    default: break;
+    }
+}
+int64_t Engine::get_view(int which, float *out, int64_t capacity) {
+    int rows, cols;
+    view_shape(which, &rows, &cols);
+    if (rows < 0) return -1;
+    const int64_t n = (int64_t)rows * cols;
+    if (n > capacity) return -1;
+    if (n == 0) return 0;
+    const bool matrix = (which == 1 || which == 3 || which == 6);
+    const unsigned off = (which <= 1) ? user_off_ : (which <= 3) ? item_off_ : fb_off_;
+    if (device_model_) {
+        flush();
+        if (which == 4) HIPCHECK(hipMemcpyAsync(out, dg_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        else if (!matrix) HIPCHECK(hipMemcpyAsync(out, dbias_.p + off, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        else HIPCHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(float), dW_.p + (size_t)off * pitch_, (size_t)pitch_ * sizeof(float),
+                                       (size_t)cols * sizeof(float), (size_t)rows, hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
+    } else {
+        check(host_model_valid_, "get_view: no model");
+        if (which == 4) memcpy(out, hg_.data(), (size_t)n * sizeof(float));
+        else if (!matrix) memcpy(out, hbias_.data() + off, (size_t)n * sizeof(float));
+        else for (int y = 0; y < rows; y++) memcpy(out + (size_t)y * cols, hW_.data() + ((size_t)off + y) * pitch_, (size_t)cols * sizeof(float));
+    }
+    return n;
+}
+void Engine::synchronize() {
+    if (host_only_) return;
+    HIPCHECK(hipStreamSynchronize(stream_));
+}
+int64_t Engine::counter(int what) const {
+    switch (what) {
+    case 0: return n_instances_;
+    case 1: return n_launches_;
+    case 2: return n_batches_;
+    case 3: return n_flushes_;
+    default: return -1;
+    }
+}
+int Engine::set_knob(const char *name, long value) {
+    if (!strcmp(name, "stage_window")) { check(value >= 1, "stage_window must be >= 1"); stage_window_ = value; return 0; }
+    if (!strcmp(name, "groups_per_wave")) {
+        check(value == 1 || value == 2 || value == 4 || value == 8, "groups_per_wave must be 1, 2, 4 or 8");
+        groups_per_wave_ = (int)value;
+        return 0;
+    }
+    return -1;
+}
+
+}  // namespace svdf

@@ -1,0 +1,219 @@
+// svdf_engine.h -- host side of the MI355X apex_svd engine (one instance == one ISVDTrainer).
+//
+// Mirrors the call protocol of the reference's base solver (solvers/base-solver/apex_svd_base.h)
+// behind the C ABI of include/svdfeature_amd.h.  The host does: config parsing, model file I/O,
+// rand_init (libc rand(), bit-identical start), staging of borrowed instances, and the
+// CONFLICT-FREE BATCH SCHEDULER that turns the reference's strictly sequential SGD into
+// dependency-respecting parallel launches.  All arithmetic on parameters
+// happens in the HIP kernels (svdf_kernels.hip); there is no CPU compute fallback.
+#ifndef SVDF_ENGINE_H_
+#define SVDF_ENGINE_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "svdf_types.h"
+
+namespace svdf {
+
+struct Error : std::runtime_error {
+    explicit Error(const std::string &m) : std::runtime_error(m) {}
+};
+[[noreturn]] void fail(const std::string &msg);
+
+// --------------------------------------------------------------------------- device memory
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release();
+    void reserve(size_t n);            // grow-only, contents not preserved
+    void upload(const T *src, size_t n, hipStream_t st);
+};
+
+// --------------------------------------------------------------------------- scheduler (pure host)
+// Assigns every unit (instance or SVD++ user) the earliest batch in which none of its parameter
+// rows is touched by an earlier unit of the same or a later batch:
+//   level(t) = 1 + max(last[r] for r in resources(t)),  last[r] = level(t)
+// Units of one level share no resource, units that share a resource keep their file order, so
+// executing levels in increasing order reproduces the sequential result exactly.
+struct LevelTracker {
+    std::vector<int> last;   // per resource: level of the most recent unit touching it
+    int base = 0;            // levels <= base belong to work already enqueued
+    void resize(size_t nres) { if (last.size() < nres) last.resize(nres, 0); }
+};
+struct Schedule {
+    std::vector<int> order;        // unit ids sorted by level, stable
+    std::vector<long> level_ptr;   // level l occupies order[level_ptr[l] .. level_ptr[l+1])
+    long max_level_size = 0;
+    size_t num_levels() const { return level_ptr.empty() ? 0 : level_ptr.size() - 1; }
+};
+// levels[t] must already hold each unit's level (> tracker.base); builds order/level_ptr.
+void build_schedule(const std::vector<int> &levels, int base, Schedule &out);
+
+struct SideTable {   // SparseFeatureArray<float> (apex-utils/apex_utils.h:140-196)
+    std::vector<unsigned> row_ptr{0};
+    std::vector<unsigned> index;
+    std::vector<float> value;
+    unsigned num_row() const { return (unsigned)row_ptr.size() - 1; }
+    void load(const char *fname);
+};
+struct ParamSet {    // ParameterSet (apex_svd_base.h:33-75)
+    std::vector<float> wd;
+    std::vector<unsigned> bound;
+    std::string prefix_a, prefix_b;
+    void set_param(const char *name, const char *val);
+};
+
+struct HostCSR {     // staged SVDFeatureCSR rows (apex_svd_data.h:109-127)
+    std::vector<float> row_label;
+    std::vector<int> row_ptr{0};
+    std::vector<unsigned> feat_index;
+    std::vector<float> feat_value;
+    long num_row() const { return (long)row_label.size(); }
+    void clear() { row_label.clear(); row_ptr.assign(1, 0); feat_index.clear(); feat_value.clear(); }
+};
+
+class Engine;
+
+// HBM-resident scheduled training set
+struct Dataset {
+    Engine *owner = nullptr;
+    long num_row = 0;
+    int kind = 0;                 // 0 basicMF fused kernel, 1 general sparse kernel
+    Schedule sched;               // order kept on the host for predict un-permutation
+    // kind 0: level-sorted compact records
+    DevBuf<unsigned> user, item;
+    DevBuf<float> label, uval, ival;
+    bool unit_values = true;
+    // kind 1: CSR stream + order
+    DevBuf<float> row_label, feat_value;
+    DevBuf<int> row_ptr, order;
+    DevBuf<unsigned> feat_index;
+    long algorithmic_bytes = 0;
+};
+
+class Engine {
+  public:
+    Engine(TypeParam mtype, int device);
+    ~Engine();
+
+    // ISVDTrainer surface
+    void set_param(const char *name, const char *val);
+    void init_model();
+    void load_model(FILE *fi);
+    void save_model(FILE *fo);
+    void init_trainer();
+    void set_round(int nround);
+    void finish_round();
+    void update_csr(float label, int ng, int nu, int ni, const unsigned *index, const float *value);
+    float predict_csr(float label, int ng, int nu, int ni, const unsigned *index, const float *value);
+    void update_csr_batch(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value);
+    void predict_csr_batch(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value, float *out);
+    void update_block(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label,
+                      const int *row_ptr, const unsigned *feat_index, const float *feat_value);
+    void predict_block(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label,
+                       const int *row_ptr, const unsigned *feat_index, const float *feat_value, float *out);
+
+    // resident datasets
+    Dataset *dataset_from_csr(long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
+    Dataset *dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
+    void train_dataset(Dataset *ds);
+    void predict_dataset(Dataset *ds, float *out);
+
+    // multi-GPU item-side delta
+    void item_delta_begin();
+    void *item_delta_buffer(int64_t *count);
+    void item_delta_apply();
+
+    // introspection
+    int64_t get_view(int which, float *out, int64_t capacity);
+    void view_shape(int which, int *rows, int *cols);
+    hipStream_t stream() const { return stream_; }
+    void synchronize();
+    int64_t counter(int what) const;
+    int set_knob(const char *name, long value);
+    void flush();
+
+  private:
+    // ---- configuration
+    TypeParam mtype_;
+    ModelParam mp_;
+    TrainParam tp_;
+    ParamSet u_param_, i_param_, g_param_;
+    std::string name_feat_user_ = "NULL", name_feat_item_ = "NULL";
+    SideTable feat_user_, feat_item_;
+    int round_counter_ = 0;
+    bool space_allocated_ = false, trainer_ready_ = false;
+    // ---- geometry (SVDModel::alloc_space, apex_svd_model.h:511-556)
+    int pitch_ = 0;
+    long n_uiset_ = 0;
+    unsigned user_off_ = 0, item_off_ = 0, fb_off_ = 0;
+    int num_fb_rows() const { return mp_.common_feedback_space == 0 ? mp_.num_ufeedback : mp_.num_user; }
+    bool user_group() const { return mtype_.format_type == 1; }
+    void compute_geometry();
+    // ---- host model (only between init/load and upload, or transiently for save/get_view)
+    std::vector<float> hW_, hbias_, hg_;
+    bool host_model_valid_ = false;
+    void alloc_host_model();
+    void rand_init();
+    void upload_model();
+    void download_model();
+    void read_model(FILE *fi);
+    void write_model(FILE *fo);
+    // ---- device
+    int device_ = -1;
+    bool host_only_ = false;
+    hipStream_t stream_ = nullptr;
+    DevBuf<float> dW_, dbias_, dg_, dstate_;
+    bool device_model_ = false;
+    DevBuf<unsigned> d_ubound_, d_ibound_, d_gbound_, d_fu_ptr_, d_fu_idx_, d_fi_ptr_, d_fi_idx_;
+    DevBuf<float> d_uwd_, d_iwd_, d_gwd_, d_fu_val_, d_fi_val_;
+    DevParams dev_params_;
+    bool params_dirty_ = true;
+    const DevParams &params();
+    void need_device(const char *what);
+    // ---- staging + scheduling
+    HostCSR staged_;
+    struct HostUnit { int fb_begin, fb_end, row_begin, row_end, flags; };
+    std::vector<HostUnit> staged_units_;
+    std::vector<unsigned> staged_fb_index_;
+    std::vector<float> staged_fb_value_;
+    bool unit_open_ = false;          // a START block was staged and its END has not arrived
+    bool unit_open_on_device_ = false;  // ... and its first part was already flushed (state saved on device)
+    long stage_window_ = 1 << 22;
+    int groups_per_wave_ = 4;
+    LevelTracker tracker_;
+    void stage_rows(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value);
+    void check_row(int ng, int nu, int ni, const unsigned *index);
+    bool basic_fast_path_allowed() const;
+    size_t num_resources() const { return (size_t)n_uiset_ + (size_t)mp_.num_global; }
+    // per-unit level assignment
+    int level_of_row(const unsigned *ig, int ng, const unsigned *iu, int nu, const unsigned *ii, int ni, int lvl0);
+    void touch_row(const unsigned *ig, int ng, const unsigned *iu, int nu, const unsigned *ii, int ni, int lvl);
+    void flush_csr();
+    void flush_units();
+    // reusable device staging buffers
+    DevBuf<float> w_label_, w_value_, w_uval_, w_ival_, w_fbval_, w_out_;
+    DevBuf<int> w_ptr_, w_order_;
+    DevBuf<unsigned> w_index_, w_user_, w_item_, w_fbidx_;
+    DevBuf<DevUnit> w_units_;
+    // ---- item delta
+    DevBuf<float> d_snap_, d_delta_;
+    struct Range { float *base; long n; };
+    std::vector<Range> shared_ranges();
+    // ---- counters
+    int64_t n_instances_ = 0, n_launches_ = 0, n_batches_ = 0, n_flushes_ = 0;
+    friend struct Dataset;
+};
+
+}  // namespace svdf
+#endif

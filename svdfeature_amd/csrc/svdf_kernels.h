@@ -1,0 +1,32 @@
+// svdf_kernels.h -- launch wrappers of the gfx950 kernels (svdf_kernels.hip)
+#ifndef SVDF_KERNELS_H_
+#define SVDF_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+
+#include <type_traits>
+
+#include "svdf_types.h"
+
+namespace svdf {
+
+// lanes of a wave that own one factor row (one float4 each): next power of two >= ceil(k/4)
+int lanes_per_instance(int k);
+int max_supported_factor();
+
+// every launch below processes ONE conflict-free batch [begin,end) on stream st
+void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long end, int groups_per_wave, hipStream_t st);
+void launch_general(const DevParams &P, const DevCSR &D, const int *order, long begin, long end, hipStream_t st);
+void launch_svdpp(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
+                  const int *order, long begin, long end, hipStream_t st);
+// read-only scoring
+void launch_predict(const DevParams &P, const DevCSR &D, long n, float *out, hipStream_t st);
+void launch_predict_basic(const DevParams &P, const BasicSchedule &S, long n, float *out, hipStream_t st);
+void launch_svdpp_predict(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
+                          long nunit, float *out, hipStream_t st);
+// multi-GPU item-side delta over n floats
+void launch_delta_sub(const float *cur, const float *snap, float *delta, long n, hipStream_t st);
+void launch_delta_add(float *cur, const float *snap, const float *delta, long n, hipStream_t st);
+
+}  // namespace svdf
+#endif

@@ -1,0 +1,675 @@
+// svdf_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the apex_svd SGD hot path.
+//
+// What is computed, and in which order, follows the reference's base solver
+// (solvers/base-solver/apex_svd_base.h: pred :445-454, calc_bias :313-353, prepare_tmp :354-381,
+// update_no_decay :383-427, regularize :188-311, SVD++ hooks :506-554) and its SSE2 tensor ops
+// (apex-tensor/apex_tensor_sse.h: scalar_map :261-272 with the |s-1|<=1e-6 skip :231-242,
+// sdot :289-317 + sum_all :88-97).  HOW it is computed is CDNA4-first:
+//
+//  * a factor row (k fp32, pitch ceil(k/4)*4) is owned by a LANE GROUP of LPI lanes, one float4
+//    per lane, so a wave issues one 16 B/lane load per row set: 64/LPI rows x (LPI*16) bytes,
+//    e.g. 4 rows x 256 B per instruction at k=64 -- fully coalesced gathers, no LDS round trip;
+//  * the dot product reproduces the reference's 4-lane SSE accumulation order bit for bit with a
+//    DPP scan: lane m of the group holds chunk m's four products, and
+//    acc[m] = acc[m-1] + prod[m] is applied LPI-1 times through row_shr:1 / wave_shr:1 DPP adds
+//    (no LDS, no bpermute); lanes < step index are already final and are recomputed to the
+//    same value, so no select is needed;
+//  * instances of one launch are CONFLICT-FREE (no shared parameter row; the host scheduler
+//    builds such batches in file order), so every read-modify-write is a plain load/store and
+//    the result equals the reference's one-instance-at-a-time SGD exactly;
+//  * each wave keeps G independent row sets in flight (G*2 KiB of gathers per wave at k=64)
+//    to cover HBM latency without relying on occupancy alone.
+//
+// Arithmetic contract: fp32, unfused (-ffp-contract=off and the pragma below), correctly rounded
+// divide/sqrt, fp64 bias/score accumulation.  Only expf (sigmoid links) differs from glibc by
+// ulps; everything else is bit-exact against oracle/svdf_oracle.c.
+#include <hip/hip_runtime.h>
+
+#include "svdf_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace svdf {
+
+// ------------------------------------------------------------------ small helpers
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+
+// apex_tensor_sse.h:231-242: multiply is skipped when |s-1| <= 1e-6 (test done in double)
+__device__ __forceinline__ bool scalar_is_one(float s) { return !((double)fabsf(s - 1.0f) > 1e-6); }
+
+// K1: dst += src*s (separate mul and add)
+__device__ __forceinline__ void axpy4(float4 &d, const float4 s, float a) {
+    if (scalar_is_one(a)) {
+        d.x = d.x + s.x; d.y = d.y + s.y; d.z = d.z + s.z; d.w = d.w + s.w;
+    } else {
+        float mx = s.x * a, my = s.y * a, mz = s.z * a, mw = s.w * a;
+        d.x = d.x + mx; d.y = d.y + my; d.z = d.z + mz; d.w = d.w + mw;
+    }
+}
+// K2: dst *= s
+__device__ __forceinline__ void scale4(float4 &d, float a) {
+    if (!scalar_is_one(a)) { d.x = d.x * a; d.y = d.y * a; d.z = d.z * a; d.w = d.w * a; }
+}
+__device__ __forceinline__ float l1(float w, float eps) {  // K6
+    if (w > eps) return w - eps;
+    if (w < -eps) return w + eps;
+    return 0.0f;
+}
+
+// previous lane's value inside the lane group (0 for the group's first lane)
+template <int LPI>
+__device__ __forceinline__ float prev_lane(float v, int L) {
+    int iv = __float_as_int(v);
+    int r;
+    if constexpr (LPI <= 16) {
+        r = __builtin_amdgcn_update_dpp(0, iv, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+        if constexpr (LPI < 16) r = (L == 0) ? 0 : r;
+    } else {
+        r = __builtin_amdgcn_update_dpp(0, iv, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+        if constexpr (LPI < 64) r = (L == 0) ? 0 : r;
+    }
+    return __int_as_float(r);
+}
+template <int LPI>
+__device__ __forceinline__ float group_bcast(float v, int src_L) {
+    if constexpr (LPI == 1) return v;
+    const int lane = (int)(threadIdx.x & 63);
+    return __shfl(v, (lane & ~(LPI - 1)) + src_L, 64);
+}
+
+// K3: apex_tensor_sse.h:289-317.  a,b: this lane's chunk (lane L holds elements 4L..4L+3; pad and
+// out-of-range chunks are 0).  Returns the dot product, identical on every lane of the group.
+template <int LPI>
+__device__ __forceinline__ float group_dot(const float4 a, const float4 b, int L, int k) {
+    const int nfull = k >> 2;
+    const int ntail = k & 3;
+    float m0 = a.x * b.x, m1 = a.y * b.y, m2 = a.z * b.z, m3 = a.w * b.w;
+    const bool full = L < nfull;
+    // lanes beyond the full chunks feed +0 so the running sums just travel on to the last lane
+    float c0 = full ? m0 : 0.0f, c1 = full ? m1 : 0.0f, c2 = full ? m2 : 0.0f, c3 = full ? m3 : 0.0f;
+    float a0 = 0.0f + c0, a1 = 0.0f + c1, a2 = 0.0f + c2, a3 = 0.0f + c3;
+#pragma unroll
+    for (int s = 1; s < LPI; s++) {
+        a0 = prev_lane<LPI>(a0, L) + c0;
+        a1 = prev_lane<LPI>(a1, L) + c1;
+        a2 = prev_lane<LPI>(a2, L) + c2;
+        a3 = prev_lane<LPI>(a3, L) + c3;
+    }
+    float h = (a0 + a2) + (a1 + a3);  // sum_all: movehl add, then shuffle add_ss
+    float sum = group_bcast<LPI>(h, LPI - 1);
+    if (ntail) {  // scalar tail, in index order
+        float t0 = group_bcast<LPI>(m0, nfull);
+        sum = sum + t0;
+        if (ntail > 1) { float t1 = group_bcast<LPI>(m1, nfull); sum = sum + t1; }
+        if (ntail > 2) { float t2 = group_bcast<LPI>(m2, nfull); sum = sum + t2; }
+    }
+    return sum;
+}
+
+// apex_svd_model.h:112-123
+__device__ __forceinline__ float map_active(float sum, int type) {
+    if (type == ACT_SIGMOID_L2 || type == ACT_SIGMOID_LIKELIHOOD) return 1.0f / (1.0f + expf(-sum));
+    return sum;
+}
+__device__ __forceinline__ float smooth_hinge_grad(float z) {
+    if (z > 1.0f) return 0.0f;
+    if (z < 0.0f) return 1.0f;
+    return 1.0f - z;
+}
+// apex_svd_model.h:132-156
+__device__ __forceinline__ float cal_grad(float r, float pred, int type) {
+    switch (type) {
+    case ACT_LINEAR: return r - pred;
+    case ACT_SIGMOID_L2: return (r - pred) * pred * (1 - pred);
+    case ACT_SIGMOID_LIKELIHOOD: return r - pred;
+    case ACT_SIGMOID_QSGRAD:
+    case ACT_SIGMOID_RANK: return r - 1.0f / (1.0f + expf(-pred));
+    case ACT_HINGE_SMOOTH:
+        if (r > 0.5f) return smooth_hinge_grad(pred - 0.5f);
+        return -smooth_hinge_grad(0.5f - pred);
+    case ACT_HINGE_L2:
+        if (r > 0.5f) { if (pred > 1.0f) return 0.0f; return r - pred; }
+        if (pred < 0.0f) return 0.0f;
+        return r - pred;
+    default: return 0.0f;
+    }
+}
+// ParameterSet::get_wd (apex_svd_base.h:69-74); ranges are validated on the host
+__device__ __forceinline__ float get_wd(const DevRanges &rg, unsigned id, float dflt) {
+    if (rg.n == 0) return dflt;
+    int lo = 0, hi = rg.n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (rg.bound[mid] < id) lo = mid + 1; else hi = mid; }
+    return rg.wd[lo < rg.n ? lo : rg.n - 1];
+}
+
+// factor-row regularisation (reg_user / reg_item, apex_svd_base.h:211-283) on a row held in
+// registers.  is_item selects the item flavour of reg_method 3 (L2) and skips the nonneg clamp.
+template <int LPI>
+__device__ __forceinline__ void reg_row(const DevParams &P, float4 &w, float wd, bool is_item, int L) {
+    const float lambda = P.lr * wd;
+    int method = P.reg_method;
+    if (method == 3) method = is_item ? 0 : 1;
+    if (method == 0) {
+        scale4(w, 1.0f - lambda);
+    } else if (method == 1) {
+        w.x = l1(w.x, lambda); w.y = l1(w.y, lambda); w.z = l1(w.z, lambda); w.w = l1(w.w, lambda);
+    } else if (method == 2) {  // project(): ||w||^2 <= wd
+        float sum = group_dot<LPI>(w, w, L, P.k);
+        if (sum > wd) scale4(w, sqrtf(wd / sum));
+    }
+    if (!is_item && P.user_nonnegative) {  // K7 smaller_then_fill(w, 0)
+        if (w.x <= 0.0f) w.x = 0.0f;
+        if (w.y <= 0.0f) w.y = 0.0f;
+        if (w.z <= 0.0f) w.z = 0.0f;
+        if (w.w <= 0.0f) w.w = 0.0f;
+    }
+}
+__device__ __forceinline__ float reg_gbias(const DevParams &P, unsigned gid, float g) {  // :188-210
+    float lambda = P.lr * get_wd(P.g_rng, gid, P.wd_global);
+    if (gid >= P.num_regfree_global) {
+        if (P.reg_global == 0) g = g * (1.0f - lambda);
+        else g = l1(g, lambda);
+    }
+    return g;
+}
+
+template <int LPI>
+__device__ __forceinline__ float4 load_row(const float *W, size_t row, int pitch, int L, int k) {
+    if (LPI * 4 > k && L * 4 >= k) return f4zero();
+    return *reinterpret_cast<const float4 *>(W + row * (size_t)pitch + (size_t)L * 4);
+}
+template <int LPI>
+__device__ __forceinline__ void store_row(float *W, size_t row, int pitch, int L, int k, const float4 v) {
+    if (LPI * 4 > k && L * 4 >= k) return;
+    *reinterpret_cast<float4 *>(W + row * (size_t)pitch + (size_t)L * 4) = v;
+}
+
+// =====================================================================================
+// Kernel 1: basicMF fused SGD step -- no global feature, one user id, one item id, no side
+// tables, distinct user/item rows.  One lane group per instance, G groups per wave in flight.
+// Traffic per instance (k=64): 2 x 256 B row reads + 2 x 256 B row writes + 2 bias RMW +
+// 12..20 B of schedule = the 1072 B/instance algorithmic figure of SURVEY.md 8(d4).
+// =====================================================================================
+template <int LPI, int G, bool UNITVAL>
+__global__ __launch_bounds__(256) void k_basicmf(const DevParams P, const BasicSchedule S, long begin, long end) {
+    constexpr int IPW = 64 / LPI;  // instances per wave per group slot
+    const int lane = threadIdx.x & 63;
+    const int L = lane & (LPI - 1);
+    const int gslot = lane / LPI;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long w0 = begin + wave * (long)(G * IPW);
+    const int k = P.k, pitch = P.pitch;
+    const bool use_ubias = P.no_user_bias == 0;
+
+    bool valid[G];
+    unsigned ur[G], ir[G];
+    float label[G], ua[G], ia[G], bu[G], bi[G];
+    float4 p[G], q[G];
+
+    // ---- stage 1: schedule records (coalesced, one address per lane group)
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const long s = w0 + (long)g * IPW + gslot;
+        valid[g] = s < end;
+        const long sc = valid[g] ? s : begin;
+        ur[g] = P.user_off + S.user[sc];
+        ir[g] = P.item_off + S.item[sc];
+        label[g] = S.label[sc];
+        ua[g] = UNITVAL ? 1.0f : S.uval[sc];
+        ia[g] = UNITVAL ? 1.0f : S.ival[sc];
+    }
+    // ---- stage 2: all row gathers of the wave issued back to back
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        p[g] = f4zero(); q[g] = f4zero(); bu[g] = 0.0f; bi[g] = 0.0f;
+        if (valid[g]) {
+            p[g] = load_row<LPI>(P.W, ur[g], pitch, L, k);
+            q[g] = load_row<LPI>(P.W, ir[g], pitch, L, k);
+            if (use_ubias) bu[g] = P.bias[ur[g]];
+            bi[g] = P.bias[ir[g]];
+        }
+    }
+    // ---- stage 3: score, gradient, fused update + decay, scatter
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        // calc_bias (:313-353) in double; "+ 0.0" terms are the svdpp / plugin hooks returning 0.0f
+        double bs = 0.0;
+        if (use_ubias) { bs += (double)(ua[g] * bu[g]); bs += 0.0; }
+        bs += 0.0;
+        bs += (double)(ia[g] * bi[g]);
+        double sum = (double)P.base_score + bs;
+        // prepare_tmp (:354-381): tmp = 0 + row*val
+        float4 tu = f4zero(), ti = f4zero();
+        axpy4(tu, p[g], ua[g]);
+        axpy4(ti, q[g], ia[g]);
+        sum += (double)group_dot<LPI>(tu, ti, L, k);
+        const float pred = map_active((float)sum, P.active_type);
+        const float err = cal_grad(label[g], pred, P.active_type) * 1.0f;
+        // update_no_decay (:383-427): both rows use the pre-update snapshots
+        const float su = P.lr * err * ua[g];
+        const float si = P.lr * err * ia[g];
+        float4 wu = p[g], wi = q[g];
+        axpy4(wu, ti, su);
+        axpy4(wi, tu, si);
+        float nbu = bu[g] + su, nbi = bi[g] + si;
+        // regularize(feature, true) (:286-311)
+        reg_row<LPI>(P, wu, get_wd(P.u_rng, ur[g] - P.user_off, P.wd_user), false, L);
+        nbu = nbu * (1.0f - P.lr * P.wd_user_bias);
+        reg_row<LPI>(P, wi, get_wd(P.i_rng, ir[g] - P.item_off, P.wd_item), true, L);
+        nbi = nbi * (1.0f - P.lr * P.wd_item_bias);
+        if (valid[g]) {
+            store_row<LPI>(P.W, ur[g], pitch, L, k, wu);
+            store_row<LPI>(P.W, ir[g], pitch, L, k, wi);
+            if (L == 0) {
+                if (use_ubias) P.bias[ur[g]] = nbu;
+                P.bias[ir[g]] = nbi;
+            }
+        }
+    }
+}
+
+// read-only scoring of a basicMF schedule (out[s] in schedule order)
+template <int LPI, bool UNITVAL>
+__global__ __launch_bounds__(256) void k_predict_basic(const DevParams P, const BasicSchedule S, long n, float *out) {
+    constexpr int IPW = 64 / LPI;
+    const int lane = threadIdx.x & 63;
+    const int L = lane & (LPI - 1);
+    const long gidx = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * IPW + lane / LPI;
+    const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
+    for (long s = gidx; s < n; s += stride) {
+        const unsigned ur = P.user_off + S.user[s], ir = P.item_off + S.item[s];
+        const float ua = UNITVAL ? 1.0f : S.uval[s], ia = UNITVAL ? 1.0f : S.ival[s];
+        double bs = 0.0;
+        if (P.no_user_bias == 0) bs += (double)(ua * P.bias[ur]);
+        bs += (double)(ia * P.bias[ir]);
+        double sum = (double)P.base_score + bs;
+        float4 tu = f4zero(), ti = f4zero();
+        axpy4(tu, load_row<LPI>(P.W, ur, P.pitch, L, P.k), ua);
+        axpy4(ti, load_row<LPI>(P.W, ir, P.pitch, L, P.k), ia);
+        sum += (double)group_dot<LPI>(tu, ti, L, P.k);
+        if (L == 0) out[s] = map_active((float)sum, P.active_type);
+    }
+}
+
+// =====================================================================================
+// General sparse instance (any number of global / user / item features, side-feature children,
+// every regulariser).  Rows are read-modify-written through memory in the reference's order, so
+// an id that appears twice in one instance is updated and decayed twice like the reference does.
+// =====================================================================================
+struct SvdppRegs {   // SVDPPFeature members (apex_svd_base.h:486-488) held in registers
+    float4 tmp_fb, old_fb;
+    float norm, tmp_bias, old_bias;
+};
+
+// pred() (:445-454): fills tmp_u / tmp_i, returns the score before the link function (double)
+template <int LPI>
+__device__ __forceinline__ double instance_score(const DevParams &P, int ng, int nu, int ni, const unsigned *idx,
+                                                 const float *val, int L, const SvdppRegs *pp, float4 &tu, float4 &ti) {
+    const int k = P.k, pitch = P.pitch;
+    const unsigned *ig = idx, *iu = idx + ng, *ii = idx + ng + nu;
+    const float *vg = val, *vu = val + ng, *vi = val + ng + nu;
+    double bs = 0.0;
+    for (int j = 0; j < ng; j++) bs += (double)(vg[j] * P.g_bias[ig[j]]);
+    if (P.no_user_bias == 0) {
+        for (int j = 0; j < nu; j++) {
+            const unsigned uid = iu[j];
+            bs += (double)(vu[j] * P.bias[P.user_off + uid]);
+            if (uid < P.feat_user.num_row)
+                for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++)
+                    bs += (double)(P.bias[P.user_off + P.feat_user.index[c]] * P.feat_user.value[c]);
+        }
+        bs += (double)(pp ? pp->tmp_bias : 0.0f);
+    }
+    bs += 0.0;
+    for (int j = 0; j < ni; j++) {
+        const unsigned iid = ii[j];
+        const float ival = vi[j];
+        bs += (double)(ival * P.bias[P.item_off + iid]);
+        if (iid < P.feat_item.num_row)
+            for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++)
+                bs += (double)(P.bias[P.item_off + P.feat_item.index[c]] * P.feat_item.value[c] * ival);
+    }
+    double sum = (double)P.base_score + bs;
+    tu = pp ? pp->tmp_fb : f4zero();
+    ti = f4zero();
+    for (int j = 0; j < nu; j++) {
+        const unsigned uid = iu[j];
+        axpy4(tu, load_row<LPI>(P.W, P.user_off + uid, pitch, L, k), vu[j]);
+        if (uid < P.feat_user.num_row)
+            for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++)
+                axpy4(tu, load_row<LPI>(P.W, P.user_off + P.feat_user.index[c], pitch, L, k), P.feat_user.value[c]);
+    }
+    for (int j = 0; j < ni; j++) {
+        const unsigned iid = ii[j];
+        const float ival = vi[j];
+        axpy4(ti, load_row<LPI>(P.W, P.item_off + iid, pitch, L, k), ival);
+        if (iid < P.feat_item.num_row)
+            for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++)  // scalar formed in double
+                axpy4(ti, load_row<LPI>(P.W, P.item_off + P.feat_item.index[c], pitch, L, k),
+                      (float)((double)P.feat_item.value[c] * (double)ival));
+    }
+    sum += (double)group_dot<LPI>(tu, ti, L, k);
+    return sum;
+}
+
+// W[row] += tmp*sc ; bias[row] += sc   (every lane of the group stores the same bias value so
+// each thread later reads back its own write)
+template <int LPI>
+__device__ __forceinline__ void rmw_row(const DevParams &P, unsigned row, const float4 tmp, float sc, bool with_bias, int L) {
+    float4 w = load_row<LPI>(P.W, row, P.pitch, L, P.k);
+    axpy4(w, tmp, sc);
+    store_row<LPI>(P.W, row, P.pitch, L, P.k, w);
+    if (with_bias) { float b = P.bias[row]; b = b + sc; P.bias[row] = b; }
+}
+template <int LPI>
+__device__ __forceinline__ void reg_user(const DevParams &P, unsigned uid, int L) {  // :211-250
+    const unsigned row = P.user_off + uid;
+    float4 w = load_row<LPI>(P.W, row, P.pitch, L, P.k);
+    reg_row<LPI>(P, w, get_wd(P.u_rng, uid, P.wd_user), false, L);
+    store_row<LPI>(P.W, row, P.pitch, L, P.k, w);
+    if (P.no_user_bias == 0) { float b = P.bias[row]; b = b * (1.0f - P.lr * P.wd_user_bias); P.bias[row] = b; }
+}
+template <int LPI>
+__device__ __forceinline__ void reg_item(const DevParams &P, unsigned iid, int L) {  // :251-283
+    const unsigned row = P.item_off + iid;
+    float4 w = load_row<LPI>(P.W, row, P.pitch, L, P.k);
+    reg_row<LPI>(P, w, get_wd(P.i_rng, iid, P.wd_item), true, L);
+    store_row<LPI>(P.W, row, P.pitch, L, P.k, w);
+    float b = P.bias[row]; b = b * (1.0f - P.lr * P.wd_item_bias); P.bias[row] = b;
+}
+
+// update_inner (:456-462) for reg modes 0..3 (lazy modes 4/5 are rejected on the host)
+template <int LPI>
+__device__ __forceinline__ void instance_update(const DevParams &P, float label, int ng, int nu, int ni,
+                                                const unsigned *idx, const float *val, int L, SvdppRegs *pp) {
+    const unsigned *ig = idx, *iu = idx + ng, *ii = idx + ng + nu;
+    const float *vg = val, *vu = val + ng, *vi = val + ng + nu;
+    float4 tu, ti;
+    const double sum = instance_score<LPI>(P, ng, nu, ni, idx, val, L, pp, tu, ti);
+    const float pred = map_active((float)sum, P.active_type);
+    const float err = cal_grad(label, pred, P.active_type) * 1.0f;
+    const float lr = P.lr;
+    const bool ub = P.no_user_bias == 0;
+    // ---- update_no_decay (:383-427)
+    for (int j = 0; j < ng; j++) { float g = P.g_bias[ig[j]]; g = g + lr * err * vg[j]; P.g_bias[ig[j]] = g; }
+    for (int j = 0; j < nu; j++) {
+        const unsigned uid = iu[j];
+        rmw_row<LPI>(P, P.user_off + uid, ti, lr * err * vu[j], ub, L);
+        if (uid < P.feat_user.num_row)
+            for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++)
+                rmw_row<LPI>(P, P.user_off + P.feat_user.index[c], ti, lr * err * P.feat_user.value[c], ub, L);
+    }
+    for (int j = 0; j < ni; j++) {
+        const unsigned iid = ii[j];
+        const float ival = vi[j];
+        rmw_row<LPI>(P, P.item_off + iid, tu, lr * err * ival, true, L);
+        if (iid < P.feat_item.num_row)
+            for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++)
+                rmw_row<LPI>(P, P.item_off + P.feat_item.index[c], tu, lr * err * P.feat_item.value[c] * ival, true, L);
+    }
+    if (pp) {  // update_svdpp (:512-520)
+        const float lr2 = lr * P.scale_lr_ufeedback;
+        axpy4(pp->tmp_fb, ti, lr2 * err * pp->norm);
+        scale4(pp->tmp_fb, 1.0f - lr2 * P.wd_ufeedback);
+        if (ub) {
+            pp->tmp_bias = pp->tmp_bias + lr2 * err * pp->norm;
+            pp->tmp_bias = pp->tmp_bias * (1.0f - lr2 * P.wd_ufeedback_bias);
+        }
+    }
+    // ---- regularize(feature, true) (:286-311)
+    for (int j = 0; j < ng; j++) { const unsigned gid = ig[j]; float g = reg_gbias(P, gid, P.g_bias[gid]); P.g_bias[gid] = g; }
+    for (int j = 0; j < nu; j++) {
+        const unsigned uid = iu[j];
+        reg_user<LPI>(P, uid, L);
+        if (uid < P.feat_user.num_row)
+            for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++) reg_user<LPI>(P, P.feat_user.index[c], L);
+    }
+    for (int j = 0; j < ni; j++) {
+        const unsigned iid = ii[j];
+        reg_item<LPI>(P, iid, L);
+        if (iid < P.feat_item.num_row)
+            for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++) reg_item<LPI>(P, P.feat_item.index[c], L);
+    }
+}
+
+// Kernel 2: one conflict-free batch of general instances; order[] lists instance ids of the batch.
+template <int LPI>
+__global__ __launch_bounds__(256) void k_general(const DevParams P, const DevCSR D, const int *order, long begin, long end) {
+    constexpr int IPW = 64 / LPI;
+    const int lane = threadIdx.x & 63;
+    const int L = lane & (LPI - 1);
+    const long gidx = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * IPW + lane / LPI;
+    const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
+    for (long s = begin + gidx; s < end; s += stride) {
+        const int r = order ? order[s] : (int)s;
+        const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
+        instance_update<LPI>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, nullptr);
+    }
+}
+
+// Kernel 3: predictions for a CSR stream (read-only, every instance independent)
+template <int LPI>
+__global__ __launch_bounds__(256) void k_predict(const DevParams P, const DevCSR D, long n, float *out) {
+    constexpr int IPW = 64 / LPI;
+    const int lane = threadIdx.x & 63;
+    const int L = lane & (LPI - 1);
+    const long gidx = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * IPW + lane / LPI;
+    const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
+    for (long r = gidx; r < n; r += stride) {
+        const int p0 = D.row_ptr[3 * r], p1 = D.row_ptr[3 * r + 1], p2 = D.row_ptr[3 * r + 2], p3 = D.row_ptr[3 * r + 3];
+        float4 tu, ti;
+        const double sum = instance_score<LPI>(P, p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, nullptr, tu, ti);
+        if (L == 0) out[r] = map_active((float)sum, P.active_type);
+    }
+}
+
+// ---- SVD++ user units (SVDPPFeature, apex_svd_base.h:484-592) --------------------------------
+template <int LPI>
+__device__ __forceinline__ void svdpp_load_state(const DevParams &P, SvdppRegs &pp, int L) {
+    const float *st = P.svdpp_state;
+    pp.tmp_fb = load_row<LPI>(st, 0, P.pitch, L, P.k);
+    pp.old_fb = load_row<LPI>(st, 1, P.pitch, L, P.k);
+    pp.norm = st[2 * P.pitch]; pp.tmp_bias = st[2 * P.pitch + 1]; pp.old_bias = st[2 * P.pitch + 2];
+}
+template <int LPI>
+__device__ __forceinline__ void svdpp_save_state(const DevParams &P, const SvdppRegs &pp, int L) {
+    float *st = P.svdpp_state;
+    store_row<LPI>(st, 0, P.pitch, L, P.k, pp.tmp_fb);
+    store_row<LPI>(st, 1, P.pitch, L, P.k, pp.old_fb);
+    if (L == 0) { st[2 * P.pitch] = pp.norm; st[2 * P.pitch + 1] = pp.tmp_bias; st[2 * P.pitch + 2] = pp.old_bias; }
+}
+// prepare_ufeedback (:523-538)
+template <int LPI>
+__device__ __forceinline__ void svdpp_prepare(const DevParams &P, SvdppRegs &pp, const unsigned *fidx, const float *fval, int nfb, int L) {
+    pp.norm = 0.0f; pp.tmp_fb = f4zero(); pp.tmp_bias = 0.0f;
+    for (int j = 0; j < nfb; j++) {
+        const unsigned row = P.fb_off + fidx[j];
+        const float v = fval[j];
+        axpy4(pp.tmp_fb, load_row<LPI>(P.W, row, P.pitch, L, P.k), v);
+        pp.norm = pp.norm + v * v;
+        if (P.no_user_bias == 0) pp.tmp_bias = pp.tmp_bias + P.bias[row] * v;
+    }
+}
+// update_ufeedback (:539-554)
+template <int LPI>
+__device__ __forceinline__ void svdpp_scatter(const DevParams &P, SvdppRegs &pp, const unsigned *fidx, const float *fval, int nfb, int L) {
+    if (nfb == 0) return;
+    float4 d = pp.tmp_fb;
+    d.x = d.x - pp.old_fb.x; d.y = d.y - pp.old_fb.y; d.z = d.z - pp.old_fb.z; d.w = d.w - pp.old_fb.w;  // K5
+    float db = pp.tmp_bias - pp.old_bias;
+    const float inv = 1.0f / pp.norm;
+    scale4(d, inv);
+    db = db * inv;
+    pp.tmp_fb = d; pp.tmp_bias = db;  // the reference leaves the scaled delta in tmp_ufeedback
+    for (int j = 0; j < nfb; j++) {
+        const unsigned row = P.fb_off + fidx[j];
+        const float v = fval[j];
+        float4 w = load_row<LPI>(P.W, row, P.pitch, L, P.k);
+        axpy4(w, d, v);
+        store_row<LPI>(P.W, row, P.pitch, L, P.k, w);
+        if (P.no_user_bias == 0) { float b = P.bias[row]; b = b + db * v; P.bias[row] = b; }
+    }
+}
+
+// Kernel 4: one conflict-free batch of user units; one lane group walks one user's rows in order
+template <int LPI>
+__global__ __launch_bounds__(256) void k_svdpp(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
+                                               const float *fb_value, const int *order, long begin, long end) {
+    constexpr int IPW = 64 / LPI;
+    const int lane = threadIdx.x & 63;
+    const int L = lane & (LPI - 1);
+    const long gidx = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * IPW + lane / LPI;
+    const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
+    for (long s = begin + gidx; s < end; s += stride) {
+        const DevUnit u = units[order ? order[s] : (int)s];
+        SvdppRegs pp;
+        if (u.flags & UNIT_LOAD) svdpp_load_state<LPI>(P, pp, L);
+        if (u.flags & UNIT_START) {
+            svdpp_prepare<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
+            pp.old_bias = pp.tmp_bias;
+            pp.old_fb = pp.tmp_fb;
+        }
+        for (int r = u.row_begin; r < u.row_end; r++) {
+            const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
+            instance_update<LPI>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp);
+        }
+        if (u.flags & UNIT_END) svdpp_scatter<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
+        if (u.flags & UNIT_SAVE) svdpp_save_state<LPI>(P, pp, L);
+    }
+}
+// Kernel 5: predictions for user units (predict(vector<float>&, SVDPlusBlock), :583-591)
+template <int LPI>
+__global__ __launch_bounds__(256) void k_svdpp_predict(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
+                                                       const float *fb_value, long nunit, float *out) {
+    constexpr int IPW = 64 / LPI;
+    const int lane = threadIdx.x & 63;
+    const int L = lane & (LPI - 1);
+    const long gidx = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * IPW + lane / LPI;
+    const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
+    for (long s = gidx; s < nunit; s += stride) {
+        const DevUnit u = units[s];
+        SvdppRegs pp;
+        if (u.flags & UNIT_LOAD) svdpp_load_state<LPI>(P, pp, L);
+        if (u.flags & UNIT_START) svdpp_prepare<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
+        for (int r = u.row_begin; r < u.row_end; r++) {
+            const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
+            float4 tu, ti;
+            const double sum = instance_score<LPI>(P, p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp, tu, ti);
+            if (L == 0) out[r] = map_active((float)sum, P.active_type);
+        }
+        if (u.flags & UNIT_SAVE) svdpp_save_state<LPI>(P, pp, L);
+    }
+}
+
+// ---- multi-GPU item-side delta exchange -------------------------------------
+__global__ void k_delta_sub(const float *cur, const float *snap, float *delta, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = i; j < n; j += stride) delta[j] = cur[j] - snap[j];
+}
+__global__ void k_delta_add(float *cur, const float *snap, const float *delta, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = i; j < n; j += stride) cur[j] = snap[j] + delta[j];
+}
+
+// =====================================================================================
+// launchers
+// =====================================================================================
+int lanes_per_instance(int k) {
+    int chunks = (k + 3) / 4;
+    int lpi = 1;
+    while (lpi < chunks) lpi <<= 1;
+    return lpi;
+}
+int max_supported_factor() { return 256; }
+
+static inline int grid_for(long groups, int lpi, int cap) {
+    const long per_block = 4L * (64 / lpi);
+    long g = (groups + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+template <int LPI>
+static void launch_basicmf_lpi(const DevParams &P, const BasicSchedule &S, long begin, long end, int G, hipStream_t st) {
+    const long n = end - begin;
+    const bool unit = S.uval == nullptr;
+    auto go = [&](auto gtag) {
+        constexpr int GG = decltype(gtag)::value;
+        const long per_block = 4L * GG * (64 / LPI);
+        const int grid = (int)((n + per_block - 1) / per_block);
+        if (unit) hipLaunchKernelGGL((k_basicmf<LPI, GG, true>), dim3(grid), dim3(256), 0, st, P, S, begin, end);
+        else hipLaunchKernelGGL((k_basicmf<LPI, GG, false>), dim3(grid), dim3(256), 0, st, P, S, begin, end);
+    };
+    switch (G) {
+    case 1: go(std::integral_constant<int, 1>()); break;
+    case 2: go(std::integral_constant<int, 2>()); break;
+    case 8: go(std::integral_constant<int, 8>()); break;
+    default: go(std::integral_constant<int, 4>()); break;
+    }
+}
+
+#define SVDF_DISPATCH_LPI(lpi, CALL)                  \
+    switch (lpi) {                                    \
+    case 1: { constexpr int LPI = 1; CALL; } break;   \
+    case 2: { constexpr int LPI = 2; CALL; } break;   \
+    case 4: { constexpr int LPI = 4; CALL; } break;   \
+    case 8: { constexpr int LPI = 8; CALL; } break;   \
+    case 16: { constexpr int LPI = 16; CALL; } break; \
+    case 32: { constexpr int LPI = 32; CALL; } break; \
+    default: { constexpr int LPI = 64; CALL; } break; \
+    }
+
+void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long end, int groups_per_wave, hipStream_t st) {
+    if (end <= begin) return;
+    SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_basicmf_lpi<LPI>(P, S, begin, end, groups_per_wave, st));
+}
+void launch_general(const DevParams &P, const DevCSR &D, const int *order, long begin, long end, hipStream_t st) {
+    if (end <= begin) return;
+    const int lpi = lanes_per_instance(P.k);
+    const int grid = grid_for(end - begin, lpi, 256 * 8);
+    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_general<LPI>), dim3(grid), dim3(256), 0, st, P, D, order, begin, end));
+}
+void launch_predict(const DevParams &P, const DevCSR &D, long n, float *out, hipStream_t st) {
+    if (n <= 0) return;
+    const int lpi = lanes_per_instance(P.k);
+    const int grid = grid_for(n, lpi, 256 * 8);
+    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_predict<LPI>), dim3(grid), dim3(256), 0, st, P, D, n, out));
+}
+void launch_predict_basic(const DevParams &P, const BasicSchedule &S, long n, float *out, hipStream_t st) {
+    if (n <= 0) return;
+    const int lpi = lanes_per_instance(P.k);
+    const int grid = grid_for(n, lpi, 256 * 8);
+    if (S.uval == nullptr) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_predict_basic<LPI, true>), dim3(grid), dim3(256), 0, st, P, S, n, out)); }
+    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_predict_basic<LPI, false>), dim3(grid), dim3(256), 0, st, P, S, n, out)); }
+}
+void launch_svdpp(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
+                  const int *order, long begin, long end, hipStream_t st) {
+    if (end <= begin) return;
+    const int lpi = lanes_per_instance(P.k);
+    const int grid = grid_for(end - begin, lpi, 256 * 8);
+    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_svdpp<LPI>), dim3(grid), dim3(256), 0, st, P, D, units, fb_index, fb_value, order, begin, end));
+}
+void launch_svdpp_predict(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
+                          long nunit, float *out, hipStream_t st) {
+    if (nunit <= 0) return;
+    const int lpi = lanes_per_instance(P.k);
+    const int grid = grid_for(nunit, lpi, 256 * 8);
+    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_svdpp_predict<LPI>), dim3(grid), dim3(256), 0, st, P, D, units, fb_index, fb_value, nunit, out));
+}
+void launch_delta_sub(const float *cur, const float *snap, float *delta, long n, hipStream_t st) {
+    if (n <= 0) return;
+    long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_delta_sub, dim3((int)grid), dim3(256), 0, st, cur, snap, delta, n);
+}
+void launch_delta_add(float *cur, const float *snap, const float *delta, long n, hipStream_t st) {
+    if (n <= 0) return;
+    long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_delta_add, dim3((int)grid), dim3(256), 0, st, cur, snap, delta, n);
+}
+
+}  // namespace svdf

@@ -1,0 +1,115 @@
+// svdf_types.h -- PODs shared by the host engine and the HIP kernels.
+//
+// On-disk layouts restate the reference's structs byte for byte (no reference code is included):
+//   ModelParam  = SVDModelParam  (apex_svd_model.h:373-435), 1056 bytes
+//   TypeParam   = SVDTypeParam   (apex_svd_model.h:242-261), 4 bytes
+// TrainParam restates SVDTrainParam (apex_svd_model.h:291-344).
+#ifndef SVDF_TYPES_H_
+#define SVDF_TYPES_H_
+
+#include <stdint.h>
+
+namespace svdf {
+
+struct TypeParam {
+    uint8_t format_type, active_type, extend_type, variant_type;
+};
+static_assert(sizeof(TypeParam) == 4, "SVDTypeParam is 4 bytes");
+
+struct ModelParam {
+    int num_user, num_item, num_factor, num_global;
+    float u_init_sigma, i_init_sigma, base_score;
+    int no_user_bias, num_ufeedback;
+    float ufeedback_init_sigma;
+    int num_randinit_ufactor, num_randinit_ifactor;
+    int common_latent_space, user_nonnegative, common_feedback_space, extend_flag, item_nonnegative;
+    int reserved[247];
+};
+static_assert(sizeof(ModelParam) == 1056, "SVDModelParam is 1056 bytes on disk");
+
+struct TrainParam {
+    float learning_rate;
+    int decay_learning_rate;
+    float decay_rate, min_learning_rate;
+    float wd_user, wd_item, wd_user_bias, wd_item_bias;
+    int reg_method;
+    float wd_global;
+    int reg_global;
+    unsigned num_regfree_global;
+    float scale_lr_ufeedback, wd_ufeedback_user, wd_ufeedback, wd_ufeedback_bias;
+};
+
+// active_type constants (apex_svd_model.h:61-79)
+enum { ACT_LINEAR = 0, ACT_SIGMOID_L2 = 1, ACT_SIGMOID_LIKELIHOOD = 2, ACT_SIGMOID_RANK = 3,
+       ACT_HINGE_SMOOTH = 5, ACT_HINGE_L2 = 6, ACT_SIGMOID_QSGRAD = 7 };
+// svdpp_tag (apex_svd_data.h:353-371)
+enum { TAG_DEFAULT = 0, TAG_START = 1, TAG_END = 2, TAG_MIDDLE = 3 };
+
+// ---- device views -------------------------------------------------------------------------
+// ParameterSet (apex_svd_base.h:33-75) flattened: wd[j] applies to ids <= bound[j].
+struct DevRanges {
+    const unsigned *bound;
+    const float *wd;
+    int n;
+};
+// SparseFeatureArray<float> (apex-utils/apex_utils.h:140-196) as CSR in HBM.
+struct DevSideTable {
+    const unsigned *row_ptr;
+    const unsigned *index;
+    const float *value;
+    unsigned num_row;
+};
+
+// Everything a kernel needs, passed by value in the kernarg segment.
+// HBM layout of the model: ONE row-major matrix W[n_uiset][pitch] holding
+// W_ufeedback | W_user | W_item back to back exactly like the reference's W_uiset
+// (apex_svd_model.h:511-556), pitch = ceil(k/4)*4 floats so every row is float4 aligned, pad
+// floats kept at 0; ONE bias vector bias[n_uiset] with the same row numbering; g_bias[num_global].
+struct DevParams {
+    float *W;
+    float *bias;
+    float *g_bias;
+    float *svdpp_state;       // 2*pitch + 4 floats: tmp_fb, old_fb, norm, tmp_bias, old_bias
+    int pitch, k;
+    unsigned user_off, item_off, fb_off;   // first row of W_user / W_item / W_ufeedback in W
+    int num_user, num_item, num_global, num_ufeedback;
+    float base_score;
+    int active_type, no_user_bias, user_nonnegative, user_group;
+    // SVDTrainParam
+    float lr, wd_user, wd_item, wd_user_bias, wd_item_bias, wd_global;
+    int reg_method, reg_global;
+    unsigned num_regfree_global;
+    float scale_lr_ufeedback, wd_ufeedback, wd_ufeedback_bias;
+    DevRanges u_rng, i_rng, g_rng;
+    DevSideTable feat_user, feat_item;
+};
+
+// One conflict-free batch of the basicMF schedule: instance s of the batch is
+// (user[s], item[s], label[s]) with optional feature values.
+struct BasicSchedule {
+    const unsigned *user;
+    const unsigned *item;
+    const float *label;
+    const float *uval;   // nullptr when every value is 1.0f
+    const float *ival;
+};
+
+// Instance stream in SVDFeatureCSR layout (apex_svd_data.h:109-127) resident in HBM.
+struct DevCSR {
+    const float *row_label;
+    const int *row_ptr;        // 3*num_row+1
+    const unsigned *feat_index;
+    const float *feat_value;
+};
+
+// One SVD++ unit = all rows of one user (START..END blocks concatenated).
+struct DevUnit {
+    int fb_begin, fb_end;      // range in fb_index / fb_value
+    int row_begin, row_end;    // range of rows in the DevCSR
+    int flags;                 // bit0: starts here (prepare_ufeedback), bit1: ends here (update_ufeedback),
+                               // bit2: save state at exit, bit3: load state at entry
+};
+enum { UNIT_START = 1, UNIT_END = 2, UNIT_SAVE = 4, UNIT_LOAD = 8 };
+
+}  // namespace svdf
+#endif

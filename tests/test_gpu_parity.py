@@ -1,0 +1,234 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP engine, driven through the C ABI, against
+the golden vectors generated from the compiled reference and against the C oracle on the same
+seeded inputs.
+
+Bar (stated per test):
+  * everything that does not call expf: BIT-EXACT -- model files byte-identical to the reference's,
+    predictions bit-identical;
+  * sigmoid links (active_type 1,2,3,7): expf on gfx950 differs from glibc by ulps, so parameters
+    and predictions are compared with rtol=2e-5 / atol=2e-6 (fp32, hundreds of dependent updates).
+"""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import scenarios
+import svdfeature_amd as sa
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(cases.GOLDEN, "scenarios.npz"))
+USES_EXPF = {"binary_example", "sparse_sigmoid_l2", "sparse_logistic", "sparse_rank", "sparse_qsgrad"}
+RTOL, ATOL = 2e-5, 2e-6
+
+
+def hip(f, a):
+    return sa.Trainer(f, a)
+
+
+def port(f, a):
+    return oracle.OracleTrainer("port", f, a)
+
+
+def _params(model_bytes):
+    return np.frombuffer(model_bytes[4 + 1056:], dtype=np.float32)
+
+
+@pytest.mark.parametrize("name", list(scenarios.SCENARIOS))
+def test_scenarios_match_reference_golden(name):
+    res = scenarios.run_scenario(name, hip)
+    dg = scenarios.digest(res)
+    assert dg["model0_md5"] == str(GOLD[name + "/model0_md5"])
+    assert dg["model_len"] == int(GOLD[name + "/model_len"])
+    if name in USES_EXPF:
+        np.testing.assert_allclose(dg["model_sample"], GOLD[name + "/model_sample"], rtol=RTOL, atol=ATOL)
+        np.testing.assert_allclose(dg["pred"], GOLD[name + "/pred"], rtol=RTOL, atol=ATOL)
+        assert abs(dg["rmse"] - float(GOLD[name + "/rmse"])) < 1e-5
+    else:
+        np.testing.assert_array_equal(dg["model_sample"].view(np.uint32), GOLD[name + "/model_sample"].view(np.uint32))
+        assert dg["model_md5"] == str(GOLD[name + "/model_md5"]), "model file is not byte-identical to the reference's"
+        assert dg["pred_md5"] == str(GOLD[name + "/pred_md5"])
+        assert dg["rmse"] == float(GOLD[name + "/rmse"])
+
+
+@pytest.mark.parametrize("name", ["sparse_side_tables", "svdpp_random", "basicmf_ml100k_k16", "sparse_reg_project"])
+@pytest.mark.parametrize("chunk,window", [(7, 1 << 22), (64, 50), (1, 3)])
+def test_staging_boundaries_do_not_change_the_result(name, chunk, window):
+    """Feeding rows in small update() chunks and flushing every `window` staged instances must give the
+    bytes of one big batch (sequential semantics are kept across flushes)."""
+    if name == "basicmf_ml100k_k16" and chunk == 1:
+        pytest.skip("90k single-row calls: covered by the smaller scenarios")
+
+    def mk(f, a):
+        t = sa.Trainer(f, a)
+        t.set_knob("stage_window", window)
+        return t
+    res = scenarios.run_scenario(name, mk, chunk=chunk)
+    assert hashlib.md5(res["model"]).hexdigest() == str(GOLD[name + "/model_md5"])
+    assert hashlib.md5(res["pred"].tobytes()).hexdigest() == str(GOLD[name + "/pred_md5"])
+
+
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8, 10, 16, 17, 31, 32, 33, 64, 100, 128, 200, 256])
+def test_every_factor_width_basic_and_general(k):
+    """All lane-group shapes (1..64 lanes per row, ragged tails) on both kernels, bit-exact vs the oracle."""
+    nu, ni, ng = 60, 45, 5
+    u, i, r = cases.planted_triples(3000, nu, ni, seed=k)
+    basic = sa.CSRData.from_triples(u, i, r)
+    general = cases.sparse_feature_rows(400, nu, ni, ng, seed=100 + k)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=k, wd_global=0.003,
+                           wd_user_bias=0.001, learning_rate=0.01)
+    outs = []
+    for mk in (hip, port):
+        t = mk(0, 0)
+        t.seed(7)
+        for kk, v in conf:
+            t.set_param(kk, v)
+        t.init_model()
+        t.init_trainer()
+        t.update_batch(basic)
+        t.update_batch(general)
+        t.update_batch(basic)
+        t.finish_round()
+        outs.append([t.view(v).copy() for v in ("W_user", "W_item", "u_bias", "i_bias", "g_bias")] + [t.predict_batch(general), t.predict_batch(basic)])
+    for a, b in zip(*outs):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_single_instance_calls_interleaved_with_predict():
+    """update(Elem) / predict(Elem) one instance at a time, like svd_feature.cpp's loop does."""
+    d = cases.sparse_feature_rows(150, 20, 15, 5, 9)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=20, num_item=15, num_global=5, num_factor=7, wd_global=0.01)
+    trs = []
+    for mk in (hip, port):
+        t = mk(0, 0)
+        t.seed(3)
+        for k, v in conf:
+            t.set_param(k, v)
+        t.init_model()
+        t.init_trainer()
+        trs.append(t)
+    for r in range(d.num_row):
+        row = d.row(r)
+        if r % 3 == 0:
+            pa, pb = trs[0].predict_csr(*row), trs[1].predict_csr(*row)
+            assert np.float32(pa).view(np.uint32) == np.float32(pb).view(np.uint32)
+        for t in trs:
+            t.update_csr(*row)
+    for name in ("u_bias", "W_user", "i_bias", "W_item", "g_bias"):
+        np.testing.assert_array_equal(trs[0].view(name).view(np.uint32), trs[1].view(name).view(np.uint32))
+    assert trs[0].counter(0) == d.num_row
+
+
+@pytest.mark.parametrize("gpw", [1, 2, 4, 8])
+def test_resident_dataset_basicmf_two_million_ratings(gpw):
+    """svdf_dataset_from_triples + svdf_train_dataset (the bench path) on 2M ratings, 50k x 5k, k=64,
+    two passes: byte-identical parameters vs the sequential oracle, for every groups_per_wave."""
+    nu, ni, n = 50000, 5000, 2_000_000 if gpw == 4 else 300_000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=42)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
+    t = hip(0, 0)
+    t.set_knob("groups_per_wave", gpw)
+    o = port(0, 0)
+    for x in (t, o):
+        x.seed(10)
+        for k, v in conf:
+            x.set_param(k, v)
+        x.init_model()
+        x.init_trainer()
+    ds = t.dataset_from_triples(u, i, r)
+    assert ds.num_row == n and ds.kind == 0 and ds.algorithmic_bytes == n * 1072
+    d = sa.CSRData.from_triples(u, i, r)
+    for _ in range(2):
+        t.train_dataset(ds)
+        o.update_batch(d)
+    for name in ("W_user", "W_item", "u_bias", "i_bias"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+    np.testing.assert_array_equal(t.predict_dataset(ds).view(np.uint32), o.predict_batch(d).view(np.uint32))
+    ds.close()
+
+
+def test_resident_dataset_general_and_nonunit_basic():
+    nu, ni, ng = 300, 200, 12
+    gen = cases.sparse_feature_rows(5000, nu, ni, ng, 5)
+    u, i, r = cases.planted_triples(5000, nu, ni, seed=6)
+    nonunit = sa.CSRData.from_triples(u, i, r)
+    nonunit.feat_value[:] = np.random.default_rng(1).choice([1.0, 0.5, -1.0, 0.75], size=nonunit.feat_value.size).astype(np.float32)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=24, wd_global=0.002)
+    t, o = hip(0, 0), port(0, 0)
+    for x in (t, o):
+        x.seed(11)
+        for k, v in conf:
+            x.set_param(k, v)
+        x.init_model()
+        x.init_trainer()
+    dg, dn = t.dataset_from_csr(gen), t.dataset_from_csr(nonunit)
+    assert dg.kind == 1 and dn.kind == 0
+    for _ in range(2):
+        t.train_dataset(dg)
+        t.train_dataset(dn)
+        o.update_batch(gen)
+        o.update_batch(nonunit)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "g_bias"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+    np.testing.assert_array_equal(t.predict_dataset(dg).view(np.uint32), o.predict_batch(gen).view(np.uint32))
+    np.testing.assert_array_equal(t.predict_dataset(dn).view(np.uint32), o.predict_batch(nonunit).view(np.uint32))
+
+
+def test_edge_cases_empty_and_degenerate_inputs():
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=10, num_item=10, num_global=3, num_factor=6)
+    t, o = hip(0, 0), port(0, 0)
+    for x in (t, o):
+        x.seed(2)
+        for k, v in conf:
+            x.set_param(k, v)
+        x.init_model()
+        x.init_trainer()
+    empty = sa.CSRData.empty()
+    t.update_batch(empty)
+    t.finish_round()
+    assert t.predict_batch(empty).size == 0
+    # rows with no user / no item / nothing at all, and the same id on both ends of one row
+    rows = [(3.0, [], [], [(1, 1.0)]), (2.0, [(0, 1.0)], [(1, 1.0)], []), (4.0, [], [], []),
+            (5.0, [(2, 0.5), (2, 0.5)], [(3, 1.0), (3, 1.0)], [(4, 2.0), (4, -1.0)])]
+    d = sa.CSRData.from_rows(rows)
+    for x in (t, o):
+        x.update_batch(d)
+        x.update_batch(d)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "g_bias"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+    # out-of-range ids are rejected when staged, with the reference's messages
+    with pytest.raises(sa.SvdfError, match="user feature index exceed bound"):
+        t.update_batch(sa.CSRData.from_triples([10], [0], [1.0]))
+    with pytest.raises(sa.SvdfError, match="item feature index exceed bound"):
+        t.update_batch(sa.CSRData.from_triples([0], [10], [1.0]))
+    with pytest.raises(sa.SvdfError, match="global feature index exceed setting"):
+        t.update_batch(sa.CSRData.from_rows([(1.0, [(3, 1.0)], [(0, 1.0)], [(0, 1.0)])]))
+
+
+def test_item_delta_roundtrip():
+    """begin -> train -> buffer gives (current - snapshot); apply restores snapshot + delta (single rank:
+    parameters unchanged by the round trip, bit for bit)."""
+    nu, ni = 500, 300
+    u, i, r = cases.planted_triples(20000, nu, ni, seed=3)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=32)
+    t = hip(0, 0)
+    t.seed(10)
+    for k, v in conf:
+        t.set_param(k, v)
+    t.init_model()
+    t.init_trainer()
+    w0, b0 = t.view("W_item").copy(), t.view("i_bias").copy()
+    t.item_delta_begin()
+    t.update_batch(sa.CSRData.from_triples(u, i, r))
+    ptr, n = t.item_delta_buffer()
+    assert n == ni * 32 + ni
+    w1, b1 = t.view("W_item").copy(), t.view("i_bias").copy()
+    t.item_delta_apply()
+    t.synchronize()
+    w2, b2 = t.view("W_item"), t.view("i_bias")
+    np.testing.assert_allclose(w2, w0 + (w1 - w0), rtol=0, atol=0)
+    np.testing.assert_allclose(b2, b0 + (b1 - b0), rtol=0, atol=0)
