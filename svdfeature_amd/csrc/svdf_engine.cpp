@@ -534,7 +534,7 @@ void Engine::update_block(int nfb, int tag, const unsigned *ifb, const float *vf
     } else {
         HostUnit nu{0, 0, h, h + num_row, 0};
         if (starts) { push_fb(nu.fb_begin, nu.fb_end); nu.flags |= UNIT_START; }
-        else nu.flags |= UNIT_LOAD;
+        else { nu.flags |= UNIT_LOAD; unit_open_on_device_ = false; }   // the open user continues in this window
         staged_units_.push_back(nu);
         u = &staged_units_.back();
     }
