@@ -123,6 +123,10 @@ int64_t svdf_dataset_info(const svdf_dataset *ds, int what);
 int svdf_item_delta_begin(svdf_trainer *t);
 void *svdf_item_delta_buffer(svdf_trainer *t, int64_t *count);
 int svdf_item_delta_apply(svdf_trainer *t);
+/* copy the packed delta to / from a caller-owned DEVICE buffer (e.g. a torch tensor the collective
+ * runs on); both enqueue on the trainer's stream and return after it has drained. */
+int svdf_item_delta_export(svdf_trainer *t, float *device_dst);
+int svdf_item_delta_import(svdf_trainer *t, const float *device_src);
 
 /* ---- introspection used by tests, bench.py and the harness ---- */
 /* raw copies of parameter views: 0 u_bias 1 W_user 2 i_bias 3 W_item 4 g_bias 5 ufeedback_bias

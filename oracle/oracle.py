@@ -64,6 +64,8 @@ def _load(kind):
     lib.svdo_get_view.argtypes = [P, C.c_int, _f32p, C.c_long]
     lib.svdo_get_view.restype = C.c_long
     lib.svdo_view_shape.argtypes = [P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.svdo_set_view.argtypes = [P, C.c_int, _f32p, C.c_long]
+    lib.svdo_set_view.restype = C.c_long
     lib.svdo_kind.restype = C.c_int
     _libs[kind] = lib
     return lib
@@ -160,3 +162,7 @@ class OracleTrainer:
         assert n == rows.value * cols.value
         out = out[:n]
         return out.reshape(rows.value, cols.value) if cols.value > 1 or name.startswith("W_") else out
+
+    def set_view(self, name, arr):
+        a = np.ascontiguousarray(arr, dtype=np.float32).ravel()
+        assert self.lib.svdo_set_view(self.h, VIEW[name], _pad(a, np.float32), a.size) == a.size

@@ -194,4 +194,6 @@ long svdo_get_view(svdo_trainer *t, int which, float *out, long capacity) {
     return n;
 }
 
+long svdo_set_view(svdo_trainer *, int, const float *, long) { return -1; }
+
 } /* extern "C" */

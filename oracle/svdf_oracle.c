@@ -878,3 +878,22 @@ long svdo_get_view(svdo_trainer *t, int which, float *out, long capacity) {
     else for (int y = 0; y < rows; y++) memcpy(out + (size_t)y * cols, mat + (size_t)y * t->pitch, sizeof(float) * (size_t)cols);
     return n;
 }
+
+long svdo_set_view(svdo_trainer *t, int which, const float *in, long count) {
+    int rows, cols;
+    svdo_view_shape(t, which, &rows, &cols);
+    if (rows < 0 || (long)rows * cols != count) return -1;
+    float *vec = NULL, *mat = NULL;
+    switch (which) {
+    case 0: vec = t->u_bias; break;
+    case 1: mat = t->W_user; break;
+    case 2: vec = t->i_bias; break;
+    case 3: mat = t->W_item; break;
+    case 4: vec = t->g_bias; break;
+    case 5: vec = t->ufb_bias; break;
+    case 6: mat = t->W_ufb; break;
+    }
+    if (vec) memcpy(vec, in, sizeof(float) * (size_t)count);
+    else for (int y = 0; y < rows; y++) memcpy(mat + (size_t)y * t->pitch, in + (size_t)y * cols, sizeof(float) * (size_t)cols);
+    return count;
+}

@@ -68,6 +68,9 @@ void svdo_predict_block(svdo_trainer *t, int num_ufeedback, int extend_tag,
  * returns rows*cols, or -1 when the view does not exist. */
 long svdo_get_view(svdo_trainer *t, int which, float *out, long capacity);
 void svdo_view_shape(svdo_trainer *t, int which, int *rows, int *cols);
+/* overwrite a view from rows*cols unpadded floats (test plumbing for the multi-rank exchange tests;
+ * returns -1 where unsupported, i.e. in the compiled-reference shim) */
+long svdo_set_view(svdo_trainer *t, int which, const float *in, long count);
 /* 1 for the plain-C restatement, 2 for the compiled reference */
 int svdo_kind(void);
 

@@ -78,6 +78,8 @@ def load_library():
     lib.svdf_dataset_info.argtypes = [P, C.c_int]
     lib.svdf_item_delta_buffer.restype = P
     lib.svdf_item_delta_buffer.argtypes = [P, C.POINTER(C.c_int64)]
+    lib.svdf_item_delta_export.argtypes = [P, P]
+    lib.svdf_item_delta_import.argtypes = [P, P]
     lib.svdf_get_view.restype = C.c_int64
     lib.svdf_get_view.argtypes = [P, C.c_int, _f32p, C.c_int64]
     lib.svdf_view_shape.argtypes = [P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -281,6 +283,12 @@ class Trainer:
 
     def item_delta_apply(self):
         self._ok(self.lib.svdf_item_delta_apply(self.h))
+
+    def item_delta_export(self, device_ptr):
+        self._ok(self.lib.svdf_item_delta_export(self.h, C.c_void_p(device_ptr)))
+
+    def item_delta_import(self, device_ptr):
+        self._ok(self.lib.svdf_item_delta_import(self.h, C.c_void_p(device_ptr)))
 
     # -- introspection
     def view(self, name):

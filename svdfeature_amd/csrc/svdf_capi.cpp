@@ -123,6 +123,8 @@ int64_t svdf_dataset_info(const svdf_dataset *ds, int what) {
 int svdf_item_delta_begin(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->item_delta_begin(); return 0; }) }
 void *svdf_item_delta_buffer(svdf_trainer *t, int64_t *count) { SVDF_GUARD(nullptr, { return t->e->item_delta_buffer(count); }) }
 int svdf_item_delta_apply(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->item_delta_apply(); return 0; }) }
+int svdf_item_delta_export(svdf_trainer *t, float *dst) { SVDF_GUARD(-1, { t->e->item_delta_copy(dst, nullptr); return 0; }) }
+int svdf_item_delta_import(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->item_delta_copy(nullptr, src); return 0; }) }
 
 int64_t svdf_get_view(svdf_trainer *t, int which, float *out, int64_t capacity) { SVDF_GUARD(-1, { return t->e->get_view(which, out, capacity); }) }
 int svdf_view_shape(svdf_trainer *t, int which, int *rows, int *cols) { SVDF_GUARD(-1, { t->e->view_shape(which, rows, cols); return 0; }) }

@@ -1039,6 +1039,16 @@ void Engine::item_delta_apply() {
     HIPCHECK(hipGetLastError());
 }
 
+void Engine::item_delta_copy(float *device_dst, const float *device_src) {
+    need_device("item_delta");
+    long total = 0;
+    for (auto &x : shared_ranges()) total += x.n;
+    check(d_delta_.p != nullptr && (long)d_delta_.cap >= total, "item_delta: call item_delta_begin / item_delta_buffer first");
+    if (device_dst) HIPCHECK(hipMemcpyAsync(device_dst, d_delta_.p, (size_t)total * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+    if (device_src) HIPCHECK(hipMemcpyAsync(d_delta_.p, device_src, (size_t)total * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+    HIPCHECK(hipStreamSynchronize(stream_));
+}
+
 // =============================================================================== introspection
 void Engine::view_shape(int which, int *rows, int *cols) {
     *rows = -1; *cols = 0;

@@ -133,6 +133,7 @@ class Engine {
     void item_delta_begin();
     void *item_delta_buffer(int64_t *count);
     void item_delta_apply();
+    void item_delta_copy(float *device_dst, const float *device_src);
 
     // introspection
     int64_t get_view(int which, float *out, int64_t capacity);
