@@ -43,6 +43,13 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise SvdfError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                         "(hipcc --offload-arch=gfx950); there is no CPU fallback" % LIB_PATH)
+    # PyTorch-ROCm bundles its own libamdhip64; a process must hold ONE HIP runtime, so when torch is
+    # installed it is imported first and libsvdfeature_amd.so binds to the runtime torch loaded
+    # (otherwise torch.cuda reports "no GPUs" after /opt/rocm's copy has been initialised).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     P = C.c_void_p
     lib.svdf_version.restype = C.c_char_p

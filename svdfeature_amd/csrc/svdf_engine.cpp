@@ -672,7 +672,7 @@ void Engine::flush_csr() {
         }
         HIPCHECK(hipStreamSynchronize(stream_));
         for (size_t l = 0; l < sched.num_levels(); l++) {
-            launch_basicmf(P, S, sched.level_ptr[l], sched.level_ptr[l + 1], groups_per_wave_, stream_);
+            launch_basicmf(P, S, sched.level_ptr[l], sched.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
             n_launches_++;
         }
     } else {
@@ -954,7 +954,8 @@ void Engine::train_dataset(Dataset *ds) {
     const Schedule &sc = ds->sched;
     if (ds->kind == 0) {
         BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
-        for (size_t l = 0; l < sc.num_levels(); l++) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, stream_);
+        const size_t m = (size_t)std::max(1, debug_merge_);
+        for (size_t l = 0; l < sc.num_levels(); l += m) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[std::min(l + m, sc.num_levels())], groups_per_wave_, block_threads_, stream_);
     } else {
         DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
         for (size_t l = 0; l < sc.num_levels(); l++) launch_general(P, D, ds->order.p, sc.level_ptr[l], sc.level_ptr[l + 1], stream_);
@@ -1106,6 +1107,12 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "groups_per_wave")) {
         check(value == 1 || value == 2 || value == 4 || value == 8, "groups_per_wave must be 1, 2, 4 or 8");
         groups_per_wave_ = (int)value;
+        return 0;
+    }
+    if (!strcmp(name, "debug_merge")) { debug_merge_ = (int)value; return 0; }
+    if (!strcmp(name, "block_threads")) {
+        check(value == 64 || value == 128 || value == 256, "block_threads must be 64, 128 or 256");
+        block_threads_ = (int)value;
         return 0;
     }
     return -1;

@@ -15,7 +15,7 @@ int lanes_per_instance(int k);
 int max_supported_factor();
 
 // every launch below processes ONE conflict-free batch [begin,end) on stream st
-void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long end, int groups_per_wave, hipStream_t st);
+void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long end, int groups_per_wave, int block_threads, hipStream_t st);
 void launch_general(const DevParams &P, const DevCSR &D, const int *order, long begin, long end, hipStream_t st);
 void launch_svdpp(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
                   const int *order, long begin, long end, hipStream_t st);

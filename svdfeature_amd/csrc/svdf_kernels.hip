@@ -593,15 +593,15 @@ static inline int grid_for(long groups, int lpi, int cap) {
 }
 
 template <int LPI>
-static void launch_basicmf_lpi(const DevParams &P, const BasicSchedule &S, long begin, long end, int G, hipStream_t st) {
+static void launch_basicmf_lpi(const DevParams &P, const BasicSchedule &S, long begin, long end, int G, int block_threads, hipStream_t st) {
     const long n = end - begin;
     const bool unit = S.uval == nullptr;
     auto go = [&](auto gtag) {
         constexpr int GG = decltype(gtag)::value;
-        const long per_block = 4L * GG * (64 / LPI);
+        const long per_block = (long)(block_threads / 64) * GG * (64 / LPI);
         const int grid = (int)((n + per_block - 1) / per_block);
-        if (unit) hipLaunchKernelGGL((k_basicmf<LPI, GG, true>), dim3(grid), dim3(256), 0, st, P, S, begin, end);
-        else hipLaunchKernelGGL((k_basicmf<LPI, GG, false>), dim3(grid), dim3(256), 0, st, P, S, begin, end);
+        if (unit) hipLaunchKernelGGL((k_basicmf<LPI, GG, true>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
+        else hipLaunchKernelGGL((k_basicmf<LPI, GG, false>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
     };
     switch (G) {
     case 1: go(std::integral_constant<int, 1>()); break;
@@ -622,9 +622,9 @@ static void launch_basicmf_lpi(const DevParams &P, const BasicSchedule &S, long 
     default: { constexpr int LPI = 64; CALL; } break; \
     }
 
-void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long end, int groups_per_wave, hipStream_t st) {
+void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long end, int groups_per_wave, int block_threads, hipStream_t st) {
     if (end <= begin) return;
-    SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_basicmf_lpi<LPI>(P, S, begin, end, groups_per_wave, st));
+    SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_basicmf_lpi<LPI>(P, S, begin, end, groups_per_wave, block_threads, st));
 }
 void launch_general(const DevParams &P, const DevCSR &D, const int *order, long begin, long end, hipStream_t st) {
     if (end <= begin) return;

@@ -232,3 +232,76 @@ def test_item_delta_roundtrip():
     w2, b2 = t.view("W_item"), t.view("i_bias")
     np.testing.assert_allclose(w2, w0 + (w1 - w0), rtol=0, atol=0)
     np.testing.assert_allclose(b2, b0 + (b1 - b0), rtol=0, atol=0)
+
+
+def test_two_simulated_ranks_on_one_gpu_match_the_oracle_simulation():
+    """The MI355X side of the multi-GPU exchange (HipShard: item_delta begin/export/import/apply on torch
+    device tensors) driven by ShardedTrainer with a fake all-reduce that sums the two ranks' tensors;
+    must equal the oracle-backed single-process simulation bit for bit."""
+    import torch
+    from multi_rank_utils import simulate
+    from svdfeature_amd.multi_gpu import HipShard, ShardedTrainer, shard_windows
+    nu, ni, n = 3000, 400, 40000
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=16)
+    u, i, r = cases.planted_triples(n, nu, ni, seed=9)
+    world, windows, passes = 2, 4, 2
+    dev = torch.device("cuda", 0)
+    shards = []
+    for rk in range(world):
+        t = hip(0, 0)
+        t.seed(10)
+        for k, v in conf:
+            t.set_param(k, v)
+        t.init_model()
+        t.init_trainer()
+        a = HipShard(t, torch, dev)
+        shards.append((a, a.make_windows(shard_windows(u, i, r, rk, world, windows))))
+    # lock-step emulation of ShardedTrainer.train_pass over both ranks with an explicit sum
+    for _ in range(passes):
+        for w in range(windows):
+            ds = []
+            for a, wins in shards:
+                a.delta_begin()
+                a.train(wins[w])
+                ds.append(a.delta_get().clone())
+            total = ds[0] + ds[1]
+            for a, _ in shards:
+                a.delta_set(total.clone())
+    sim = simulate(conf, u, i, r, world, windows, passes)
+    for rk in range(world):
+        for name in ("W_item", "i_bias", "W_user", "u_bias"):
+            np.testing.assert_array_equal(shards[rk][0].t.view(name).view(np.uint32), sim[rk].t.view(name).view(np.uint32))
+
+
+def test_sharded_trainer_world_one_with_nccl_process_group():
+    """torch.distributed backend "nccl" (RCCL) initialises on this box and all-reduces a delta tensor in
+    place; with one rank the sum is the identity, so forcing the exchange must reproduce
+    snapshot + (current - snapshot)."""
+    import torch
+    import torch.distributed as dist
+    from svdfeature_amd.multi_gpu import HipShard
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29611")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        nu, ni = 2000, 300
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
+        u, i, r = cases.planted_triples(30000, nu, ni, seed=2)
+        t = hip(0, 0)
+        t.seed(10)
+        for k, v in conf:
+            t.set_param(k, v)
+        t.init_model()
+        t.init_trainer()
+        a = HipShard(t, torch, torch.device("cuda", 0))
+        ds = a.make_windows([(u, i, r)])[0]
+        w0 = t.view("W_item").copy()
+        a.delta_begin()
+        a.train(ds)
+        w1 = t.view("W_item").copy()
+        d = a.delta_get()
+        dist.all_reduce(d)
+        a.delta_set(d)
+        np.testing.assert_array_equal(t.view("W_item"), w0 + (w1 - w0))
+    finally:
+        dist.destroy_process_group()
