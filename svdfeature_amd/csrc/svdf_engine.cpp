@@ -159,6 +159,15 @@ static void mp_set_param(ModelParam &p, const char *name, const char *val) {  //
 }
 
 // =============================================================================== lifecycle
+namespace {
+struct RandStateGuard {
+    char scratch[256];
+    char *old;
+    RandStateGuard() { old = initstate(1u, scratch, sizeof(scratch)); }
+    ~RandStateGuard() { if (old) setstate(old); }
+};
+}  // namespace
+
 Engine::Engine(TypeParam mtype, int device) : mtype_(mtype) {
     memset(&mp_, 0, sizeof(mp_));
     mp_.u_init_sigma = mp_.i_init_sigma = 0.01f;   // SVDModelParam() apex_svd_model.h:436-450
@@ -175,12 +184,22 @@ Engine::Engine(TypeParam mtype, int device) : mtype_(mtype) {
         host_only_ = true;
         return;
     }
+    // The first real HIP call initialises the ROCm runtime, which disturbs libc's rand() state (measured:
+    // tools/dbg_rand.cpp).  The reference seeds once in main() (svd_feature.cpp:293) and then relies on the
+    // rand() stream for rand_init and for pairwise sampling, so runtime start-up is run on a scratch PRNG
+    // state and the caller's state is put back exactly (initstate/setstate save and restore the position).
+    RandStateGuard keep_callers_rand_stream;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         fail("svdfeature_amd: no HIP device visible -- this engine has no CPU fallback");
     if (device >= 0) HIPCHECK(hipSetDevice(device));
     HIPCHECK(hipGetDevice(&device_));
     HIPCHECK(hipStreamCreate(&stream_));
+    void *warm = nullptr;
+    HIPCHECK(hipMalloc(&warm, 256));
+    HIPCHECK(hipMemsetAsync(warm, 0, 256, stream_));
+    HIPCHECK(hipStreamSynchronize(stream_));
+    HIPCHECK(hipFree(warm));
 }
 
 Engine::~Engine() {

@@ -1,0 +1,85 @@
+"""Drop-in test at the reference's own boundary: the reference's trainer CLI (svd_feature.cpp) with its
+config parser, binary-buffer iterators, loader thread and pairwise-rank generator, LINKED against
+integration/apex_svd_amd.cpp + libsvdfeature_amd.so (oracle/_ref/svd_feature_amd, built by
+oracle/Makefile in the build container), must write the same NNNN.model files as the unmodified
+reference binary (oracle/_ref/svd_feature) on the same config and buffers."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+from svdfeature_amd import data as D
+
+pytestmark = pytest.mark.gpu
+
+REFDIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+REF_CLI = os.path.join(REFDIR, "svd_feature")
+AMD_CLI = os.path.join(REFDIR, "svd_feature_amd")
+need_cli = pytest.mark.skipif(not (os.path.exists(REF_CLI) and os.path.exists(AMD_CLI)),
+                              reason="oracle/_ref CLIs are built in the build container only")
+
+
+def _write_conf(path, pairs):
+    with open(path, "w") as f:
+        for k, v in pairs:
+            f.write('%s = %s\n' % (k, ('"%s"' % v) if k in ("buffer_feature", "model_out_folder") else v))
+
+
+def _run_both(tmp_path, conf, make_buffer, rounds, extra=()):
+    outs = []
+    for name, cli in (("ref", REF_CLI), ("amd", AMD_CLI)):
+        d = tmp_path / name
+        d.mkdir()
+        make_buffer(str(d / "train.buffer"))
+        _write_conf(str(d / "run.conf"), conf + [("buffer_feature", "train.buffer"), ("model_out_folder", "./")])
+        p = subprocess.run([cli, "run.conf", "num_round=%d" % rounds, "silent=1"] + list(extra), cwd=str(d),
+                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()
+        outs.append([open(str(d / ("%04d.model" % r)), "rb").read() for r in range(rounds + 1)])
+    return outs
+
+
+@need_cli
+def test_cli_basicmf_ml100k(tmp_path):
+    """demo/basicMF/run-ml100K.sh shape: CSR buffer, k=64, three rounds, per-instance update(Elem)."""
+    base, _ = cases.ml100k()
+    ref, amd = _run_both(tmp_path, cases.BASICMF_CONF, lambda p: D.write_csr_buffer(p, base), 3)
+    for r, (a, b) in enumerate(zip(ref, amd)):
+        assert a == b, "round %d model differs" % r
+
+
+@need_cli
+def test_cli_neighborhood_with_globals(tmp_path):
+    d = cases.sparse_feature_rows(3000, 943, 1682, 6, 17)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_global=6, wd_global=0.001, num_factor=20)
+    ref, amd = _run_both(tmp_path, conf, lambda p: D.write_csr_buffer(p, d, batch_size=256), 4)
+    assert ref == amd
+
+
+@need_cli
+def test_cli_implicit_feedback_user_groups(tmp_path):
+    """demo/implicitFeedback: format_type=1, user-group buffer, update(SVDPlusBlock) incl. split users."""
+    blocks = cases.user_blocks(300, 943, 1682, 1682, 5, max_rows=9, max_fb=12, split_every=5)
+    conf = cases.conf_with(cases.BASICMF_CONF, format_type=1, num_ufeedback=1682, wd_ufeedback=0.004, num_factor=32)
+    ref, amd = _run_both(tmp_path, conf, lambda p: D.write_ugroup_buffer(p, blocks), 4)
+    assert ref == amd
+
+
+@need_cli
+def test_cli_pairwise_rank_generator(tmp_path):
+    """demo/pairwiseRank: input_type=2 wraps the buffer in the reference's PairwiseRankGenerator (host, libc
+    rand()) and trains with active_type=3.  The AMD trainer consumes rand() exactly like the reference's
+    rand_init, so the sampled pairs are the same; the sigmoid uses expf, so parameters are compared with
+    the tolerance of tests/test_gpu_parity.py instead of bytes."""
+    blocks = cases.user_blocks(200, 943, 1682, 1682, 8, max_rows=10, max_fb=4, binary_label=True)
+    for b in blocks:   # the demo's feedback file carries no implicit feedback
+        b.index_ufeedback = np.zeros(0, np.uint32)
+        b.value_ufeedback = np.zeros(0, np.float32)
+    conf = [(k, v) for k, v in cases.conf_with(cases.BASICMF_CONF, format_type=1, num_ufeedback=1682, wd_ufeedback=0.004,
+                                               active_type=3, no_user_bias=1, input_type=2, num_factor=16) if k != "base_score"]
+    ref, amd = _run_both(tmp_path, conf, lambda p: D.write_ugroup_buffer(p, blocks), 3)
+    for a, b in zip(ref, amd):
+        assert len(a) == len(b) and a[:4 + 1056] == b[:4 + 1056]
+        np.testing.assert_allclose(np.frombuffer(a[4 + 1056:], np.float32), np.frombuffer(b[4 + 1056:], np.float32), rtol=2e-5, atol=2e-6)
