@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--groups-per-wave", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="debug: run the item-delta exchange path even with one rank (exercises the N>1 code on one GPU)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -162,9 +164,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or a.force_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     t0 = time.time()
@@ -192,7 +195,7 @@ def main():
     # ---- schedule the instance stream once and keep it in HBM
     t0 = time.time()
     adaptor = HipShard(tr, torch, torch.device("cuda", local_rank))
-    nwin = 1 if world == 1 else a.windows
+    nwin = 1 if (world == 1 and not a.force_exchange) else a.windows
     wins = adaptor.make_windows(shard_windows(u, i, r, rank, world, nwin))
     sched_s = time.time() - t0
     n_batches = sum(w.num_batches for w in wins)
@@ -200,7 +203,7 @@ def main():
     my_n = sum(w.num_row for w in wins)
     log("scheduled %d instances into %d conflict-free batches (largest %d) in %.1fs"
         % (my_n, n_batches, max(w.max_batch for w in wins), sched_s))
-    st = ShardedTrainer(adaptor, wins, world, dist)
+    st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange)
 
     def sync_all():
         tr.synchronize()

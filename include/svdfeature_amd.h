@@ -106,11 +106,21 @@ svdf_dataset *svdf_dataset_from_csr(svdf_trainer *t, long num_row, const float *
                                     const unsigned *feat_index, const float *feat_value);
 svdf_dataset *svdf_dataset_from_triples(svdf_trainer *t, long n, const unsigned *user, const unsigned *item,
                                         const float *label);
+/* user-group form: equivalent to update(SVDPlusBlock b) for b = 0..num_block-1 in order (the content of a
+ * user-group buffer file, apex_svd_data.cpp:558-595).  Block b has extend_tag[b], feedback entries
+ * fb_index/fb_value[fb_ptr[b] .. fb_ptr[b+1]) and rows block_row_ptr[b] .. block_row_ptr[b+1] of the CSR
+ * arrays (row_ptr has 3*num_row+1 entries over all rows).  Every START must be closed by its END. */
+svdf_dataset *svdf_dataset_from_blocks(svdf_trainer *t, long num_block, const int *extend_tag, const int64_t *fb_ptr,
+                                       const unsigned *fb_index, const float *fb_value, const int64_t *block_row_ptr,
+                                       const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
+                                       const float *feat_value);
 void svdf_dataset_destroy(svdf_dataset *ds);
 int svdf_train_dataset(svdf_trainer *t, svdf_dataset *ds);       /* one pass, asynchronous on the trainer's stream */
 int svdf_predict_dataset(svdf_trainer *t, svdf_dataset *ds, float *out); /* out[num_row], file order */
 /* dataset facts: 0 num_row, 1 number of conflict-free batches, 2 largest batch, 3 kernel kind
- * (0 = basicMF fused kernel, 1 = general sparse kernel), 4 algorithmic bytes per pass */
+ * (0 = basicMF fused kernel, 1 = general sparse kernel, 2 = few-row fused kernel, 3 = SVD++ user units),
+ * 4 algorithmic bytes per pass, 5 number of user units, 6 units on the register-resident
+ * fast path */
 int64_t svdf_dataset_info(const svdf_dataset *ds, int what);
 
 /* ---- multi-GPU support: item-side parameters are replicated, each rank trains its
@@ -138,10 +148,11 @@ int svdf_view_shape(svdf_trainer *t, int which, int *rows, int *cols);
 void *svdf_stream(svdf_trainer *t);
 int svdf_synchronize(svdf_trainer *t);
 /* counters: 0 instances trained, 1 kernels launched, 2 conflict-free batches executed,
- * 3 staged-window flushes */
+ * 3 staged-window flushes, 4/5/6 launches of the basicMF / general / few-row fused kernel */
 int64_t svdf_counter(svdf_trainer *t, int what);
 /* tuning knobs (not part of the reference surface): "stage_window" (instances staged before an
- * automatic flush), "groups_per_wave".  Returns 0 if the knob exists. */
+ * automatic flush), "groups_per_wave", "block_threads", "use_fused" (0 routes few-row instances through the general
+ * kernel).  Returns 0 if the knob exists. */
 int svdf_set_knob(svdf_trainer *t, const char *name, long value);
 
 /* ---- host-side conflict-free batch scheduler, exposed so it can be tested without a GPU.

@@ -78,6 +78,8 @@ def load_library():
     lib.svdf_dataset_from_csr.argtypes = [P, C.c_long, _f32p, _i64p, _u32p, _f32p]
     lib.svdf_dataset_from_triples.restype = P
     lib.svdf_dataset_from_triples.argtypes = [P, C.c_long, _u32p, _u32p, _f32p]
+    lib.svdf_dataset_from_blocks.restype = P
+    lib.svdf_dataset_from_blocks.argtypes = [P, C.c_long, _i32p, _i64p, _u32p, _f32p, _i64p, _f32p, _i64p, _u32p, _f32p]
     lib.svdf_dataset_destroy.argtypes = [P]
     lib.svdf_train_dataset.argtypes = [P, P]
     lib.svdf_predict_dataset.argtypes = [P, P, _f32p]
@@ -136,6 +138,8 @@ class Dataset:
     max_batch = property(lambda s: s.info(2))
     kind = property(lambda s: s.info(3))
     algorithmic_bytes = property(lambda s: s.info(4))
+    num_units = property(lambda s: s.info(5))
+    num_simple_units = property(lambda s: s.info(6))
 
     def close(self):
         if self.h:
@@ -264,6 +268,24 @@ class Trainer:
     def dataset_from_triples(self, user, item, label):
         n = len(label)
         h = self.lib.svdf_dataset_from_triples(self.h, n, _pad(user, np.uint32), _pad(item, np.uint32), _pad(label, np.float32))
+        if not h:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return Dataset(self, h)
+
+    def dataset_from_blocks(self, blocks):
+        """blocks: list of PlusBlock in file order (one pass of a user-group buffer)."""
+        tags = np.array([b.extend_tag for b in blocks], np.int32)
+        fb_ptr = np.zeros(len(blocks) + 1, np.int64)
+        brp = np.zeros(len(blocks) + 1, np.int64)
+        for j, b in enumerate(blocks):
+            fb_ptr[j + 1] = fb_ptr[j] + b.num_ufeedback
+            brp[j + 1] = brp[j] + b.data.num_row
+        cat = CSRData.concat([b.data for b in blocks])
+        fbi = np.concatenate([b.index_ufeedback for b in blocks]) if blocks else np.zeros(0, np.uint32)
+        fbv = np.concatenate([b.value_ufeedback for b in blocks]) if blocks else np.zeros(0, np.float32)
+        h = self.lib.svdf_dataset_from_blocks(self.h, len(blocks), _pad(tags, np.int32), fb_ptr, _pad(fbi, np.uint32), _pad(fbv, np.float32),
+                                              brp, _pad(cat.row_label, np.float32), _pad(cat.row_ptr, np.int64), _pad(cat.feat_index, np.uint32),
+                                              _pad(cat.feat_value, np.float32))
         if not h:
             raise SvdfError(self.lib.svdf_last_error().decode())
         return Dataset(self, h)

@@ -100,6 +100,18 @@ svdf_dataset *svdf_dataset_from_triples(svdf_trainer *t, long n, const unsigned 
         return h;
     })
 }
+svdf_dataset *svdf_dataset_from_blocks(svdf_trainer *t, long num_block, const int *extend_tag, const int64_t *fb_ptr,
+                                       const unsigned *fb_index, const float *fb_value, const int64_t *block_row_ptr,
+                                       const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
+                                       const float *feat_value) {
+    SVDF_GUARD(nullptr, {
+        svdf::Dataset *d = t->e->dataset_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr,
+                                                     feat_index, feat_value);
+        svdf_dataset *h = new svdf_dataset();
+        h->d = d;
+        return h;
+    })
+}
 void svdf_dataset_destroy(svdf_dataset *ds) {
     if (!ds) return;
     try { if (ds->d && ds->d->owner) ds->d->owner->synchronize(); } catch (...) {}
@@ -116,6 +128,8 @@ int64_t svdf_dataset_info(const svdf_dataset *ds, int what) {
     case 2: return ds->d->sched.max_level_size;
     case 3: return ds->d->kind;
     case 4: return ds->d->algorithmic_bytes;
+    case 5: return ds->d->num_units;
+    case 6: return ds->d->num_simple_units;
     default: return -1;
     }
 }

@@ -692,7 +692,17 @@ void Engine::flush_csr() {
         HIPCHECK(hipStreamSynchronize(stream_));
         for (size_t l = 0; l < sched.num_levels(); l++) {
             launch_basicmf(P, S, sched.level_ptr[l], sched.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
-            n_launches_++;
+            n_launches_++; n_kind_[0]++;
+        }
+    } else if (fused_allowed() && fused_shape_ok(n, staged_.row_ptr.data(), staged_.feat_index.data(), w_fused_host_)) {
+        fill_fused(n, staged_.row_label.data(), staged_.row_ptr.data(), staged_.feat_index.data(), staged_.feat_value.data(),
+                   sched.order.data(), w_fused_host_);
+        w_fused_.upload(w_fused_host_, stream_);
+        HIPCHECK(hipStreamSynchronize(stream_));
+        const FusedSchedule S = w_fused_.view();
+        for (size_t l = 0; l < sched.num_levels(); l++) {
+            launch_fused(P, S, w_fused_.max_nu, w_fused_.max_ni, sched.level_ptr[l], sched.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
+            n_launches_++; n_kind_[2]++;
         }
     } else {
         w_label_.upload(staged_.row_label.data(), (size_t)n, stream_);
@@ -704,7 +714,7 @@ void Engine::flush_csr() {
         DevCSR D{w_label_.p, w_ptr_.p, w_index_.p, w_value_.p};
         for (size_t l = 0; l < sched.num_levels(); l++) {
             launch_general(P, D, w_order_.p, sched.level_ptr[l], sched.level_ptr[l + 1], stream_);
-            n_launches_++;
+            n_launches_++; n_kind_[1]++;
         }
     }
     HIPCHECK(hipGetLastError());
@@ -714,29 +724,113 @@ void Engine::flush_csr() {
     staged_.clear();
 }
 
-void Engine::flush_units() {
+// ---- few-row fused path -------------------------------------------------------------------------
+bool Engine::fused_allowed() const {
+    return use_fused_ && !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
+}
+// every instance has <= 2 user ids, <= 2 item ids and no id twice in a section (ptr is int or int64)
+template <typename PtrT>
+bool Engine::fused_shape_ok(long n, const PtrT *row_ptr, const unsigned *idx, FusedHost &out) {
+    int mu = 1, mi = 1;
+    bool has_g = false;
+    for (long r = 0; r < n; r++) {
+        const PtrT *p = row_ptr + 3 * r;
+        const int ng = (int)(p[1] - p[0]), nu = (int)(p[2] - p[1]), ni = (int)(p[3] - p[2]);
+        if (nu > 2 || ni > 2) return false;
+        if (nu == 2 && idx[p[1]] == idx[p[1] + 1]) return false;
+        if (ni == 2 && idx[p[2]] == idx[p[2] + 1]) return false;
+        if (ng > 0) has_g = true;   // global ids may repeat: the kernel walks them through memory in order
+        mu = std::max(mu, nu);
+        mi = std::max(mi, ni);
+    }
+    out.max_nu = mu; out.max_ni = mi; out.has_g = has_g;
+    return true;
+}
+template <typename PtrT>
+void Engine::fill_fused(long n, const float *row_label, const PtrT *row_ptr, const unsigned *idx, const float *val, const int *order,
+                        FusedHost &out) {
+    out.label.resize((size_t)n);
+    for (int a = 0; a < 2; a++) {
+        const bool on_u = a < out.max_nu, on_i = a < out.max_ni;
+        out.uidx[a].assign(on_u ? (size_t)n : 0, SLOT_ABSENT); out.uval[a].assign(on_u ? (size_t)n : 0, 0.0f);
+        out.iidx[a].assign(on_i ? (size_t)n : 0, SLOT_ABSENT); out.ival[a].assign(on_i ? (size_t)n : 0, 0.0f);
+    }
+    out.gptr.clear(); out.gidx.clear(); out.gval.clear();
+    if (out.has_g) out.gptr.assign((size_t)n + 1, 0);
+    for (long s = 0; s < n; s++) {
+        const long r = order[s];
+        const PtrT *p = row_ptr + 3 * r;
+        out.label[(size_t)s] = row_label[r];
+        for (PtrT j = p[1]; j < p[2]; j++) { out.uidx[j - p[1]][(size_t)s] = idx[j]; out.uval[j - p[1]][(size_t)s] = val[j]; }
+        for (PtrT j = p[2]; j < p[3]; j++) { out.iidx[j - p[2]][(size_t)s] = idx[j]; out.ival[j - p[2]][(size_t)s] = val[j]; }
+        if (out.has_g) {
+            for (PtrT j = p[0]; j < p[1]; j++) { out.gidx.push_back(idx[j]); out.gval.push_back(val[j]); }
+            out.gptr[(size_t)s + 1] = (int)out.gidx.size();
+        }
+    }
+}
+void FusedDev::upload(const FusedHost &h, hipStream_t st) {
+    max_nu = h.max_nu; max_ni = h.max_ni; has_g = h.has_g;
+    label.upload(h.label.data(), h.label.size(), st);
+    for (int a = 0; a < 2; a++) {
+        uidx[a].upload(h.uidx[a].data(), h.uidx[a].size(), st); uval[a].upload(h.uval[a].data(), h.uval[a].size(), st);
+        iidx[a].upload(h.iidx[a].data(), h.iidx[a].size(), st); ival[a].upload(h.ival[a].data(), h.ival[a].size(), st);
+    }
+    if (has_g) {
+        gptr.upload(h.gptr.data(), h.gptr.size(), st);
+        gidx.upload(h.gidx.data(), h.gidx.size(), st);
+        gval.upload(h.gval.data(), h.gval.size(), st);
+    }
+}
+FusedSchedule FusedDev::view() const {
+    FusedSchedule S;
+    S.label = label.p;
+    for (int a = 0; a < 2; a++) {
+        // unused slots alias slot 0 so that the kernel never dereferences a null pointer for NU/NI = 2 variants
+        S.uidx[a] = a < max_nu ? uidx[a].p : uidx[0].p; S.uval[a] = a < max_nu ? uval[a].p : uval[0].p;
+        S.iidx[a] = a < max_ni ? iidx[a].p : iidx[0].p; S.ival[a] = a < max_ni ? ival[a].p : ival[0].p;
+    }
+    S.gptr = has_g ? gptr.p : nullptr;
+    S.gidx = has_g ? gidx.p : nullptr;
+    S.gval = has_g ? gval.p : nullptr;
+    return S;
+}
+
+void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du) {
     const long nu = (long)staged_units_.size();
-    if (nu == 0) { staged_.clear(); return; }
-    need_device("update");
-    const DevParams &P = params();
     tracker_.resize(num_resources() + 1);
     const size_t state_res = num_resources();
-    const int base = tracker_.base;
-    // the last unit always leaves its implicit-feedback registers in the device state slot, the way the
-    // reference leaves them in the trainer's members
-    staged_units_.back().flags |= UNIT_SAVE;
     std::vector<int> levels((size_t)nu);
-    std::vector<DevUnit> du((size_t)nu);
+    du.resize((size_t)nu);
     int *last = tracker_.last.data();
     const unsigned *idx = staged_.feat_index.data();
+    const bool simple_ok = feat_user_.num_row() == 0 && feat_item_.num_row() == 0 && mp_.common_latent_space == 0 && mp_.common_feedback_space == 0;
+    if (simple_ok && stamp_.size() < (size_t)n_uiset_) stamp_.assign((size_t)n_uiset_, -1);
     for (long t = 0; t < nu; t++) {
         const HostUnit &u = staged_units_[(size_t)t];
         int lvl = base;
+        bool simple = simple_ok && u.row_end > u.row_begin;
+        const unsigned uid0 = simple ? idx[staged_.row_ptr[(size_t)3 * u.row_begin]] : 0;
         for (int r = u.row_begin; r < u.row_end; r++) {
             const int *p = &staged_.row_ptr[(size_t)3 * r];
             lvl = level_of_row(idx + p[0], p[1] - p[0], idx + p[1], p[2] - p[1], idx + p[2], p[3] - p[2], lvl);
+            if (simple) {
+                simple = (p[1] == p[0]) && (p[2] == p[1] + 1) && (p[3] == p[2] + 1) && idx[p[1]] == uid0;
+                if (simple) {
+                    const unsigned row = item_off_ + idx[p[2]];
+                    if (stamp_[row] == (int)t) simple = false;   // the same item twice in one user's rows
+                    stamp_[row] = (int)t;
+                }
+            }
         }
-        for (int j = u.fb_begin; j < u.fb_end; j++) lvl = std::max(lvl, last[fb_off_ + staged_fb_index_[(size_t)j]]);
+        for (int j = u.fb_begin; j < u.fb_end; j++) {
+            const unsigned row = fb_off_ + staged_fb_index_[(size_t)j];
+            lvl = std::max(lvl, last[row]);
+            if (simple) {
+                if (stamp_[row] == (int)t) simple = false;       // a feedback id listed twice
+                stamp_[row] = (int)t;
+            }
+        }
         if (u.flags & (UNIT_LOAD | UNIT_SAVE)) lvl = std::max(lvl, last[state_res]);
         lvl += 1;
         for (int r = u.row_begin; r < u.row_end; r++) {
@@ -746,24 +840,41 @@ void Engine::flush_units() {
         for (int j = u.fb_begin; j < u.fb_end; j++) last[fb_off_ + staged_fb_index_[(size_t)j]] = lvl;
         if (u.flags & (UNIT_LOAD | UNIT_SAVE)) last[state_res] = lvl;
         levels[(size_t)t] = lvl;
-        du[(size_t)t] = DevUnit{u.fb_begin, u.fb_end, u.row_begin, u.row_end, u.flags};
+        du[(size_t)t] = DevUnit{u.fb_begin, u.fb_end, u.row_begin, u.row_end, u.flags | (simple && use_simple_units_ ? UNIT_SIMPLE : 0)};
     }
-    Schedule sched;
     build_schedule(levels, base, sched);
+}
+void Engine::upload_units(UnitDev &d, const Schedule &sched, const std::vector<DevUnit> &du) {
+    d.label.upload(staged_.row_label.data(), staged_.row_label.size(), stream_);
+    d.ptr.upload(staged_.row_ptr.data(), staged_.row_ptr.size(), stream_);
+    d.index.upload(staged_.feat_index.data(), staged_.feat_index.size(), stream_);
+    d.value.upload(staged_.feat_value.data(), staged_.feat_value.size(), stream_);
+    d.fbidx.upload(staged_fb_index_.data(), staged_fb_index_.size(), stream_);
+    d.fbval.upload(staged_fb_value_.data(), staged_fb_value_.size(), stream_);
+    d.units.upload(du.data(), du.size(), stream_);
+    d.order.upload(sched.order.data(), sched.order.size(), stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+}
+
+void Engine::flush_units() {
+    const long nu = (long)staged_units_.size();
+    if (nu == 0) { staged_.clear(); return; }
+    need_device("update");
+    const DevParams &P = params();
+    const int base = tracker_.base;
+    // the last unit always leaves its implicit-feedback registers in the device state slot, the way the
+    // reference leaves them in the trainer's members
+    staged_units_.back().flags |= UNIT_SAVE;
+    Schedule sched;
+    std::vector<DevUnit> du;
+    schedule_units(base, sched, du);
     tracker_.base = base + (int)sched.num_levels();
     const long n = staged_.num_row();
-    w_label_.upload(staged_.row_label.data(), (size_t)n, stream_);
-    w_ptr_.upload(staged_.row_ptr.data(), staged_.row_ptr.size(), stream_);
-    w_index_.upload(staged_.feat_index.data(), staged_.feat_index.size(), stream_);
-    w_value_.upload(staged_.feat_value.data(), staged_.feat_value.size(), stream_);
-    w_fbidx_.upload(staged_fb_index_.data(), staged_fb_index_.size(), stream_);
-    w_fbval_.upload(staged_fb_value_.data(), staged_fb_value_.size(), stream_);
-    w_units_.upload(du.data(), du.size(), stream_);
-    w_order_.upload(sched.order.data(), (size_t)nu, stream_);
-    HIPCHECK(hipStreamSynchronize(stream_));
-    DevCSR D{w_label_.p, w_ptr_.p, w_index_.p, w_value_.p};
+    UnitDev &d = w_unitdev_;
+    upload_units(d, sched, du);
+    DevCSR D{d.label.p, d.ptr.p, d.index.p, d.value.p};
     for (size_t l = 0; l < sched.num_levels(); l++) {
-        launch_svdpp(P, D, w_units_.p, w_fbidx_.p, w_fbval_.p, w_order_.p, sched.level_ptr[l], sched.level_ptr[l + 1], stream_);
+        launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sched.level_ptr[l], sched.level_ptr[l + 1], stream_);
         n_launches_++;
     }
     HIPCHECK(hipGetLastError());
@@ -775,6 +886,46 @@ void Engine::flush_units() {
     staged_units_.clear();
     staged_fb_index_.clear();
     staged_fb_value_.clear();
+}
+
+Dataset *Engine::dataset_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
+                                     const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
+                                     const float *feat_value) {
+    check(trainer_ready_, "dataset: init_trainer has not been called");
+    need_device("dataset");
+    check(user_group(), "svdfeature_amd: block datasets are for user-group (format_type 1) trainers");
+    flush();
+    check(!unit_open_, "dataset_from_blocks: a START block is pending in the trainer");
+    const long saved_window = stage_window_;
+    stage_window_ = (long)1 << 60;
+    std::vector<int> ptr32;
+    for (long b = 0; b < num_block; b++) {
+        const int64_t r0 = block_row_ptr[b], r1 = block_row_ptr[b + 1];
+        const int64_t e0 = row_ptr[3 * r0];
+        ptr32.resize((size_t)(3 * (r1 - r0) + 1));
+        for (int64_t j = 0; j <= 3 * (r1 - r0); j++) ptr32[(size_t)j] = (int)(row_ptr[3 * r0 + j] - e0);
+        update_block((int)(fb_ptr[b + 1] - fb_ptr[b]), extend_tag[b], fb_index + fb_ptr[b], fb_value + fb_ptr[b], (int)(r1 - r0),
+                     row_label + r0, ptr32.data(), feat_index + e0, feat_value + e0);
+    }
+    stage_window_ = saved_window;
+    auto drop = [&]() { staged_.clear(); staged_units_.clear(); staged_fb_index_.clear(); staged_fb_value_.clear(); unit_open_ = false; unit_open_on_device_ = false; };
+    if (unit_open_) { drop(); fail("dataset_from_blocks: the last user's END block is missing"); }
+    std::unique_ptr<Dataset> ds(new Dataset());
+    ds->owner = this; ds->kind = 3; ds->num_row = staged_.num_row();
+    if (!staged_units_.empty()) staged_units_.back().flags |= UNIT_SAVE;
+    LevelTracker saved;
+    std::swap(saved, tracker_);   // a dataset pass is preceded by a flush: schedule against an empty tracker
+    std::vector<DevUnit> du;
+    schedule_units(0, ds->sched, du);
+    std::swap(saved, tracker_);
+    upload_units(ds->unitdev, ds->sched, du);
+    long nfb = (long)staged_fb_index_.size();
+    const long nb = mp_.no_user_bias ? 1 : 2;
+    ds->algorithmic_bytes = ds->num_row * (8L * mp_.num_factor * 2 + 8 * nb + 16 + 16) + nfb * (12L * mp_.num_factor + 20);
+    ds->num_units = (long)du.size();
+    for (auto &x : du) ds->num_simple_units += (x.flags & UNIT_SIMPLE) ? 1 : 0;
+    drop();
+    return ds.release();
 }
 
 // =============================================================================== predict
@@ -954,6 +1105,16 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
         HIPCHECK(hipStreamSynchronize(stream_));
         return ds.release();
     }
+    {
+        FusedHost fh;
+        if (fused_allowed() && fused_shape_ok(n, row_ptr, feat_index, fh)) {
+            ds->kind = 2;
+            fill_fused(n, row_label, row_ptr, feat_index, feat_value, ds->sched.order.data(), fh);
+            ds->fused.upload(fh, stream_);
+            HIPCHECK(hipStreamSynchronize(stream_));
+            return ds.release();
+        }
+    }
     ds->kind = 1;
     std::vector<int> ptr32((size_t)3 * n + 1);
     for (long j = 0; j <= 3 * n; j++) ptr32[(size_t)j] = (int)(row_ptr[j] - p00);
@@ -975,12 +1136,22 @@ void Engine::train_dataset(Dataset *ds) {
         BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
         const size_t m = (size_t)std::max(1, debug_merge_);
         for (size_t l = 0; l < sc.num_levels(); l += m) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[std::min(l + m, sc.num_levels())], groups_per_wave_, block_threads_, stream_);
+    } else if (ds->kind == 3) {
+        const UnitDev &d = ds->unitdev;
+        DevCSR D{d.label.p, d.ptr.p, d.index.p, d.value.p};
+        for (size_t l = 0; l < sc.num_levels(); l++)
+            launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_ptr[l], sc.level_ptr[l + 1], stream_);
+    } else if (ds->kind == 2) {
+        const FusedSchedule S = ds->fused.view();
+        for (size_t l = 0; l < sc.num_levels(); l++)
+            launch_fused(P, S, ds->fused.max_nu, ds->fused.max_ni, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
     } else {
         DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
         for (size_t l = 0; l < sc.num_levels(); l++) launch_general(P, D, ds->order.p, sc.level_ptr[l], sc.level_ptr[l + 1], stream_);
     }
     HIPCHECK(hipGetLastError());
     n_launches_ += (int64_t)sc.num_levels();
+    if (ds->kind < 3) n_kind_[ds->kind] += (int64_t)sc.num_levels();
     n_batches_ += (int64_t)sc.num_levels();
     n_instances_ += ds->num_row;
 }
@@ -992,9 +1163,19 @@ void Engine::predict_dataset(Dataset *ds, float *out) {
     const long n = ds->num_row;
     if (n == 0) return;
     w_out_.reserve((size_t)n);
-    if (ds->kind == 0) {
-        BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
-        launch_predict_basic(P, S, n, w_out_.p, stream_);
+    if (ds->kind == 3) {
+        const UnitDev &d = ds->unitdev;
+        DevCSR D{d.label.p, d.ptr.p, d.index.p, d.value.p};
+        launch_svdpp_predict(P, D, d.units.p, d.fbidx.p, d.fbval.p, ds->num_units, w_out_.p, stream_);
+        HIPCHECK(hipMemcpyAsync(out, w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
+    } else if (ds->kind == 0 || ds->kind == 2) {
+        if (ds->kind == 0) {
+            BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
+            launch_predict_basic(P, S, n, w_out_.p, stream_);
+        } else {
+            launch_predict_fused(P, ds->fused.view(), ds->fused.max_nu, ds->fused.max_ni, n, w_out_.p, stream_);
+        }
         std::vector<float> tmp((size_t)n);
         HIPCHECK(hipMemcpyAsync(tmp.data(), w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
         HIPCHECK(hipStreamSynchronize(stream_));
@@ -1118,6 +1299,9 @@ int64_t Engine::counter(int what) const {
     case 1: return n_launches_;
     case 2: return n_batches_;
     case 3: return n_flushes_;
+    case 4: return n_kind_[0];
+    case 5: return n_kind_[1];
+    case 6: return n_kind_[2];
     default: return -1;
     }
 }
@@ -1129,6 +1313,8 @@ int Engine::set_knob(const char *name, long value) {
         return 0;
     }
     if (!strcmp(name, "debug_merge")) { debug_merge_ = (int)value; return 0; }
+    if (!strcmp(name, "use_fused")) { use_fused_ = value != 0; return 0; }
+    if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "block_threads")) {
         check(value == 64 || value == 128 || value == 256, "block_threads must be 64, 128 or 256");
         block_threads_ = (int)value;

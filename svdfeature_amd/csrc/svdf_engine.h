@@ -82,13 +82,41 @@ struct HostCSR {     // staged SVDFeatureCSR rows (apex_svd_data.h:109-127)
     void clear() { row_label.clear(); row_ptr.assign(1, 0); feat_index.clear(); feat_value.clear(); }
 };
 
+// level-sorted SoA form of few-row instances (FusedSchedule) on the host and in HBM
+struct FusedHost {
+    std::vector<float> label, uval[2], ival[2], gval;
+    std::vector<unsigned> uidx[2], iidx[2], gidx;
+    std::vector<int> gptr;
+    int max_nu = 1, max_ni = 1;
+    bool has_g = false;
+};
+struct FusedDev {
+    DevBuf<float> label, uval[2], ival[2], gval;
+    DevBuf<unsigned> uidx[2], iidx[2], gidx;
+    DevBuf<int> gptr;
+    int max_nu = 1, max_ni = 1;
+    bool has_g = false;
+    void upload(const FusedHost &h, hipStream_t st);
+    FusedSchedule view() const;
+};
+
+// user-group (SVD++) stream in HBM: CSR rows + feedback lists + unit records + batch order
+struct UnitDev {
+    DevBuf<float> label, value, fbval;
+    DevBuf<int> ptr, order;
+    DevBuf<unsigned> index, fbidx;
+    DevBuf<DevUnit> units;
+};
+
 class Engine;
 
 // HBM-resident scheduled training set
 struct Dataset {
     Engine *owner = nullptr;
     long num_row = 0;
-    int kind = 0;                 // 0 basicMF fused kernel, 1 general sparse kernel
+    int kind = 0;                 // 0 basicMF fused kernel, 1 general sparse kernel, 2 few-row fused kernel
+    FusedDev fused;               // kind 2
+    UnitDev unitdev;              // kind 3: user-group (SVD++) units
     Schedule sched;               // order kept on the host for predict un-permutation
     // kind 0: level-sorted compact records
     DevBuf<unsigned> user, item;
@@ -99,6 +127,7 @@ struct Dataset {
     DevBuf<int> row_ptr, order;
     DevBuf<unsigned> feat_index;
     long algorithmic_bytes = 0;
+    long num_units = 0, num_simple_units = 0;
 };
 
 class Engine {
@@ -126,6 +155,9 @@ class Engine {
     // resident datasets
     Dataset *dataset_from_csr(long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
     Dataset *dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
+    Dataset *dataset_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
+                                 const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
+                                 const float *feat_value);
     void train_dataset(Dataset *ds);
     void predict_dataset(Dataset *ds, float *out);
 
@@ -196,23 +228,36 @@ class Engine {
     void stage_rows(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value);
     void check_row(int ng, int nu, int ni, const unsigned *index);
     bool basic_fast_path_allowed() const;
+    bool fused_allowed() const;
+    template <typename PtrT> bool fused_shape_ok(long n, const PtrT *row_ptr, const unsigned *idx, FusedHost &out);
+    template <typename PtrT> void fill_fused(long n, const float *row_label, const PtrT *row_ptr, const unsigned *idx, const float *val,
+                                             const int *order, FusedHost &out);
+    FusedHost w_fused_host_;
+    FusedDev w_fused_;
+    bool use_fused_ = true, use_simple_units_ = true;
     size_t num_resources() const { return (size_t)n_uiset_ + (size_t)mp_.num_global; }
     // per-unit level assignment
     int level_of_row(const unsigned *ig, int ng, const unsigned *iu, int nu, const unsigned *ii, int ni, int lvl0);
     void touch_row(const unsigned *ig, int ng, const unsigned *iu, int nu, const unsigned *ii, int ni, int lvl);
     void flush_csr();
     void flush_units();
+    // levels + DevUnit records for the staged units (marks UNIT_SIMPLE); returns the schedule
+    void schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du);
+    void upload_units(UnitDev &dst, const Schedule &sched, const std::vector<DevUnit> &du);
+    std::vector<int> stamp_;   // scratch for per-unit distinctness checks
     // reusable device staging buffers
     DevBuf<float> w_label_, w_value_, w_uval_, w_ival_, w_fbval_, w_out_;
     DevBuf<int> w_ptr_, w_order_;
     DevBuf<unsigned> w_index_, w_user_, w_item_, w_fbidx_;
     DevBuf<DevUnit> w_units_;
+    UnitDev w_unitdev_;
     // ---- item delta
     DevBuf<float> d_snap_, d_delta_;
     struct Range { float *base; long n; };
     std::vector<Range> shared_ranges();
     // ---- counters
     int64_t n_instances_ = 0, n_launches_ = 0, n_batches_ = 0, n_flushes_ = 0;
+    int64_t n_kind_[3] = {0, 0, 0};   // launches of k_basicmf / k_general / k_fused
     friend struct Dataset;
 };
 

@@ -16,6 +16,10 @@ int max_supported_factor();
 
 // every launch below processes ONE conflict-free batch [begin,end) on stream st
 void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long end, int groups_per_wave, int block_threads, hipStream_t st);
+// few-row fused kernel: instances with <= max_nu (1|2) user ids and <= max_ni (1|2) item ids
+void launch_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int groups_per_wave,
+                  int block_threads, hipStream_t st);
+void launch_predict_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long n, float *out, hipStream_t st);
 void launch_general(const DevParams &P, const DevCSR &D, const int *order, long begin, long end, hipStream_t st);
 void launch_svdpp(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
                   const int *order, long begin, long end, hipStream_t st);

@@ -268,6 +268,154 @@ __global__ __launch_bounds__(256) void k_basicmf(const DevParams P, const BasicS
     }
 }
 
+// =====================================================================================
+// Kernel 1b: fused step for "few-row" instances (<= NU user ids, <= NI item ids, any number of global
+// features, no id repeated inside an instance, no side tables).  Same structure as k_basicmf: every row
+// of the wave's G instances is gathered up front, the update and all regularisers are applied in
+// registers, rows are written once.  Because the ids of an instance are distinct, "update every row,
+// then regularise every row" (apex_svd_base.h:456-462) equals "update+regularise row by row".
+// =====================================================================================
+template <int LPI, int NU, int NI, int G>
+__global__ __launch_bounds__(256) void k_fused(const DevParams P, const FusedSchedule S, long begin, long end) {
+    constexpr int IPW = 64 / LPI;
+    const int lane = threadIdx.x & 63;
+    const int L = lane & (LPI - 1);
+    const int gslot = lane / LPI;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long w0 = begin + wave * (long)(G * IPW);
+    const int k = P.k, pitch = P.pitch;
+    const bool use_ubias = P.no_user_bias == 0;
+
+    bool valid[G];
+    unsigned ur[G][NU], ir[G][NI];
+    float label[G], ua[G][NU], ia[G][NI], bu[G][NU], bi[G][NI];
+    int g0[G], g1[G];
+    float4 p[G][NU], q[G][NI];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const long s = w0 + (long)g * IPW + gslot;
+        valid[g] = s < end;
+        const long sc = valid[g] ? s : begin;
+        label[g] = S.label[sc];
+#pragma unroll
+        for (int a = 0; a < NU; a++) { ur[g][a] = valid[g] ? S.uidx[a][sc] : (unsigned)SLOT_ABSENT; ua[g][a] = S.uval[a][sc]; }
+#pragma unroll
+        for (int b = 0; b < NI; b++) { ir[g][b] = valid[g] ? S.iidx[b][sc] : (unsigned)SLOT_ABSENT; ia[g][b] = S.ival[b][sc]; }
+        g0[g] = 0; g1[g] = 0;
+        if (S.gptr && valid[g]) { g0[g] = S.gptr[sc]; g1[g] = S.gptr[sc + 1]; }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+#pragma unroll
+        for (int a = 0; a < NU; a++) {
+            p[g][a] = f4zero(); bu[g][a] = 0.0f;
+            if (ur[g][a] != SLOT_ABSENT) {
+                p[g][a] = load_row<LPI>(P.W, P.user_off + ur[g][a], pitch, L, k);
+                if (use_ubias) bu[g][a] = P.bias[P.user_off + ur[g][a]];
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NI; b++) {
+            q[g][b] = f4zero(); bi[g][b] = 0.0f;
+            if (ir[g][b] != SLOT_ABSENT) {
+                q[g][b] = load_row<LPI>(P.W, P.item_off + ir[g][b], pitch, L, k);
+                bi[g][b] = P.bias[P.item_off + ir[g][b]];
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        double bs = 0.0;
+        for (int j = g0[g]; j < g1[g]; j++) bs += (double)(S.gval[j] * P.g_bias[S.gidx[j]]);
+        if (use_ubias) {
+#pragma unroll
+            for (int a = 0; a < NU; a++) if (ur[g][a] != SLOT_ABSENT) bs += (double)(ua[g][a] * bu[g][a]);
+        }
+#pragma unroll
+        for (int b = 0; b < NI; b++) if (ir[g][b] != SLOT_ABSENT) bs += (double)(ia[g][b] * bi[g][b]);
+        double sum = (double)P.base_score + bs;
+        float4 tu = f4zero(), ti = f4zero();
+#pragma unroll
+        for (int a = 0; a < NU; a++) if (ur[g][a] != SLOT_ABSENT) axpy4(tu, p[g][a], ua[g][a]);
+#pragma unroll
+        for (int b = 0; b < NI; b++) if (ir[g][b] != SLOT_ABSENT) axpy4(ti, q[g][b], ia[g][b]);
+        sum += (double)group_dot<LPI>(tu, ti, L, k);
+        const float pred = map_active((float)sum, P.active_type);
+        const float err = cal_grad(label[g], pred, P.active_type) * 1.0f;
+        const float lr = P.lr;
+        // global biases go through memory in the reference's order (all updates, then all decays), so a
+        // global id listed twice behaves like the reference; every lane stores the same value
+        for (int j = g0[g]; j < g1[g]; j++) {
+            const unsigned gid = S.gidx[j];
+            float gb = P.g_bias[gid];
+            gb = gb + lr * err * S.gval[j];
+            P.g_bias[gid] = gb;
+        }
+        for (int j = g0[g]; j < g1[g]; j++) {
+            const unsigned gid = S.gidx[j];
+            P.g_bias[gid] = reg_gbias(P, gid, P.g_bias[gid]);
+        }
+#pragma unroll
+        for (int a = 0; a < NU; a++) {
+            if (ur[g][a] == SLOT_ABSENT) continue;
+            const float su = lr * err * ua[g][a];
+            float4 w = p[g][a];
+            axpy4(w, ti, su);
+            float nb = bu[g][a] + su;
+            reg_row<LPI>(P, w, get_wd(P.u_rng, ur[g][a], P.wd_user), false, L);
+            nb = nb * (1.0f - lr * P.wd_user_bias);
+            store_row<LPI>(P.W, P.user_off + ur[g][a], pitch, L, k, w);
+            if (use_ubias && L == 0) P.bias[P.user_off + ur[g][a]] = nb;
+        }
+#pragma unroll
+        for (int b = 0; b < NI; b++) {
+            if (ir[g][b] == SLOT_ABSENT) continue;
+            const float si = lr * err * ia[g][b];
+            float4 w = q[g][b];
+            axpy4(w, tu, si);
+            float nb = bi[g][b] + si;
+            reg_row<LPI>(P, w, get_wd(P.i_rng, ir[g][b], P.wd_item), true, L);
+            nb = nb * (1.0f - lr * P.wd_item_bias);
+            store_row<LPI>(P.W, P.item_off + ir[g][b], pitch, L, k, w);
+            if (L == 0) P.bias[P.item_off + ir[g][b]] = nb;
+        }
+    }
+}
+
+// read-only scoring of a fused schedule (out[s] in schedule order)
+template <int LPI, int NU, int NI>
+__global__ __launch_bounds__(256) void k_predict_fused(const DevParams P, const FusedSchedule S, long n, float *out) {
+    constexpr int IPW = 64 / LPI;
+    const int lane = threadIdx.x & 63;
+    const int L = lane & (LPI - 1);
+    const long gidx = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * IPW + lane / LPI;
+    const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
+    for (long s = gidx; s < n; s += stride) {
+        double bs = 0.0;
+        if (S.gptr) for (int j = S.gptr[s]; j < S.gptr[s + 1]; j++) bs += (double)(S.gval[j] * P.g_bias[S.gidx[j]]);
+        float4 tu = f4zero(), ti = f4zero();
+#pragma unroll
+        for (int a = 0; a < NU; a++) {
+            const unsigned u = S.uidx[a][s];
+            if (u == SLOT_ABSENT) continue;
+            const float v = S.uval[a][s];
+            if (P.no_user_bias == 0) bs += (double)(v * P.bias[P.user_off + u]);
+            axpy4(tu, load_row<LPI>(P.W, P.user_off + u, P.pitch, L, P.k), v);
+        }
+#pragma unroll
+        for (int b = 0; b < NI; b++) {
+            const unsigned i = S.iidx[b][s];
+            if (i == SLOT_ABSENT) continue;
+            const float v = S.ival[b][s];
+            bs += (double)(v * P.bias[P.item_off + i]);
+            axpy4(ti, load_row<LPI>(P.W, P.item_off + i, P.pitch, L, P.k), v);
+        }
+        double sum = (double)P.base_score + bs;
+        sum += (double)group_dot<LPI>(tu, ti, L, P.k);
+        if (L == 0) out[s] = map_active((float)sum, P.active_type);
+    }
+}
+
 // read-only scoring of a basicMF schedule (out[s] in schedule order)
 template <int LPI, bool UNITVAL>
 __global__ __launch_bounds__(256) void k_predict_basic(const DevParams P, const BasicSchedule S, long n, float *out) {
@@ -511,6 +659,156 @@ __device__ __forceinline__ void svdpp_scatter(const DevParams &P, SvdppRegs &pp,
     }
 }
 
+// ---- fast path for "simple" units (host-verified, UNIT_SIMPLE): every row is (no global, ONE user id --
+// the same for the whole unit --, one item id), the unit's item ids are pairwise distinct, its feedback
+// ids are pairwise distinct, no side tables, separate feedback/user/item row spaces.  Then
+//   * the user's factor row and bias live in registers for the whole unit (the reference re-reads
+//     and re-writes them every row; the values are identical),
+//   * item rows of the next PF rows are gathered while the current rows are computed (distinct
+//     ids => nothing in flight is modified), item rows are written once, fire and forget,
+//   * feedback rows are gathered / scattered PF at a time (accumulation order unchanged).
+// What remains sequential is the true recurrence p_u, tmp_ufeedback -> err -> p_u, tmp_ufeedback.
+constexpr int SVDPP_PF = 4;   // measured: 8 spills (167 VGPR + scratch) and is slower
+
+template <int LPI>
+__device__ __forceinline__ void svdpp_prepare_batched(const DevParams &P, SvdppRegs &pp, const unsigned *fidx, const float *fval, int nfb, int L) {
+    pp.norm = 0.0f; pp.tmp_fb = f4zero(); pp.tmp_bias = 0.0f;
+    const bool ub = P.no_user_bias == 0;
+    for (int j0 = 0; j0 < nfb; j0 += SVDPP_PF) {
+        float4 w[SVDPP_PF]; float v[SVDPP_PF], b[SVDPP_PF];
+#pragma unroll
+        for (int c = 0; c < SVDPP_PF; c++) {
+            w[c] = f4zero(); v[c] = 0.0f; b[c] = 0.0f;
+            if (j0 + c < nfb) {
+                const unsigned row = P.fb_off + fidx[j0 + c];
+                v[c] = fval[j0 + c];
+                w[c] = load_row<LPI>(P.W, row, P.pitch, L, P.k);
+                if (ub) b[c] = P.bias[row];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < SVDPP_PF; c++) {
+            if (j0 + c < nfb) {
+                axpy4(pp.tmp_fb, w[c], v[c]);
+                pp.norm = pp.norm + v[c] * v[c];
+                if (ub) pp.tmp_bias = pp.tmp_bias + b[c] * v[c];
+            }
+        }
+    }
+}
+template <int LPI>
+__device__ __forceinline__ void svdpp_scatter_batched(const DevParams &P, SvdppRegs &pp, const unsigned *fidx, const float *fval, int nfb, int L) {
+    if (nfb == 0) return;
+    float4 d = pp.tmp_fb;
+    d.x = d.x - pp.old_fb.x; d.y = d.y - pp.old_fb.y; d.z = d.z - pp.old_fb.z; d.w = d.w - pp.old_fb.w;
+    float db = pp.tmp_bias - pp.old_bias;
+    const float inv = 1.0f / pp.norm;
+    scale4(d, inv);
+    db = db * inv;
+    pp.tmp_fb = d; pp.tmp_bias = db;
+    const bool ub = P.no_user_bias == 0;
+    for (int j0 = 0; j0 < nfb; j0 += SVDPP_PF) {
+        float4 w[SVDPP_PF]; float v[SVDPP_PF], b[SVDPP_PF]; unsigned row[SVDPP_PF];
+#pragma unroll
+        for (int c = 0; c < SVDPP_PF; c++) {
+            w[c] = f4zero(); v[c] = 0.0f; b[c] = 0.0f; row[c] = 0;
+            if (j0 + c < nfb) {
+                row[c] = P.fb_off + fidx[j0 + c];
+                v[c] = fval[j0 + c];
+                w[c] = load_row<LPI>(P.W, row[c], P.pitch, L, P.k);
+                if (ub) b[c] = P.bias[row[c]];
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < SVDPP_PF; c++) {
+            if (j0 + c < nfb) {
+                axpy4(w[c], d, v[c]);
+                store_row<LPI>(P.W, row[c], P.pitch, L, P.k, w[c]);
+                if (ub && L == 0) P.bias[row[c]] = b[c] + db * v[c];
+            }
+        }
+    }
+}
+struct SvdppRowPF {   // one prefetched row of a simple unit
+    float4 q;
+    float bi, label, uv, iv;
+    unsigned irow;
+};
+template <int LPI>
+__device__ __forceinline__ void svdpp_fetch_row(const DevParams &P, const DevCSR &D, int r, int e, bool on, int L, SvdppRowPF &o) {
+    o.q = f4zero(); o.bi = 0.0f; o.label = 0.0f; o.uv = 0.0f; o.iv = 0.0f; o.irow = 0;
+    if (on) {
+        o.label = D.row_label[r];
+        o.uv = D.feat_value[e];
+        o.iv = D.feat_value[e + 1];
+        o.irow = P.item_off + D.feat_index[e + 1];
+        o.q = load_row<LPI>(P.W, o.irow, P.pitch, L, P.k);
+        o.bi = P.bias[o.irow];
+    }
+}
+template <int LPI>
+__device__ __forceinline__ void svdpp_rows_simple(const DevParams &P, const DevCSR &D, const DevUnit &u, SvdppRegs &pp, int L) {
+    const int nrow = u.row_end - u.row_begin;
+    if (nrow <= 0) return;
+    const int e0 = D.row_ptr[3 * (long)u.row_begin];   // rows are (0,1,1): entries of row j start at e0 + 2j
+    const bool ub = P.no_user_bias == 0;
+    const unsigned urow = P.user_off + D.feat_index[e0];
+    float4 p = load_row<LPI>(P.W, urow, P.pitch, L, P.k);
+    float bu = ub ? P.bias[urow] : 0.0f;
+    const float wd_u = get_wd(P.u_rng, urow - P.user_off, P.wd_user);
+    const float lr = P.lr;
+    SvdppRowPF cur[SVDPP_PF], nxt[SVDPP_PF];
+#pragma unroll
+    for (int c = 0; c < SVDPP_PF; c++) svdpp_fetch_row<LPI>(P, D, u.row_begin + c, e0 + 2 * c, c < nrow, L, cur[c]);
+    for (int j0 = 0; j0 < nrow; j0 += SVDPP_PF) {
+#pragma unroll
+        for (int c = 0; c < SVDPP_PF; c++) {
+            const int j = j0 + SVDPP_PF + c;
+            svdpp_fetch_row<LPI>(P, D, u.row_begin + j, e0 + 2 * j, j < nrow, L, nxt[c]);
+        }
+#pragma unroll
+        for (int c = 0; c < SVDPP_PF; c++) {
+            if (j0 + c < nrow) {
+                const SvdppRowPF &x = cur[c];
+                double bs = 0.0;                                   // calc_bias (:313-353)
+                if (ub) { bs += (double)(x.uv * bu); bs += (double)pp.tmp_bias; }
+                bs += (double)(x.iv * x.bi);
+                double sum = (double)P.base_score + bs;
+                float4 tu = pp.tmp_fb, ti = f4zero();              // prepare_tmp (:354-381, :506-508)
+                axpy4(tu, p, x.uv);
+                axpy4(ti, x.q, x.iv);
+                sum += (double)group_dot<LPI>(tu, ti, L, P.k);
+                const float pred = map_active((float)sum, P.active_type);
+                const float err = cal_grad(x.label, pred, P.active_type) * 1.0f;
+                const float su = lr * err * x.uv;                  // update_no_decay (:383-427)
+                axpy4(p, ti, su);
+                if (ub) bu = bu + su;
+                const float si = lr * err * x.iv;
+                float4 w = x.q;
+                axpy4(w, tu, si);
+                float nbi = x.bi + si;
+                const float lr2 = lr * P.scale_lr_ufeedback;       // update_svdpp (:512-520)
+                axpy4(pp.tmp_fb, ti, lr2 * err * pp.norm);
+                scale4(pp.tmp_fb, 1.0f - lr2 * P.wd_ufeedback);
+                if (ub) {
+                    pp.tmp_bias = pp.tmp_bias + lr2 * err * pp.norm;
+                    pp.tmp_bias = pp.tmp_bias * (1.0f - lr2 * P.wd_ufeedback_bias);
+                }
+                reg_row<LPI>(P, p, wd_u, false, L);                // regularize(feature, true) (:286-311)
+                if (ub) bu = bu * (1.0f - lr * P.wd_user_bias);
+                reg_row<LPI>(P, w, get_wd(P.i_rng, x.irow - P.item_off, P.wd_item), true, L);
+                nbi = nbi * (1.0f - lr * P.wd_item_bias);
+                store_row<LPI>(P.W, x.irow, P.pitch, L, P.k, w);
+                if (L == 0) P.bias[x.irow] = nbi;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < SVDPP_PF; c++) cur[c] = nxt[c];
+    }
+    store_row<LPI>(P.W, urow, P.pitch, L, P.k, p);
+    if (ub && L == 0) P.bias[urow] = bu;
+}
+
 // Kernel 4: one conflict-free batch of user units; one lane group walks one user's rows in order
 template <int LPI>
 __global__ __launch_bounds__(256) void k_svdpp(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
@@ -522,18 +820,27 @@ __global__ __launch_bounds__(256) void k_svdpp(const DevParams P, const DevCSR D
     const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
     for (long s = begin + gidx; s < end; s += stride) {
         const DevUnit u = units[order ? order[s] : (int)s];
+        const bool simple = (u.flags & UNIT_SIMPLE) != 0;
         SvdppRegs pp;
         if (u.flags & UNIT_LOAD) svdpp_load_state<LPI>(P, pp, L);
         if (u.flags & UNIT_START) {
-            svdpp_prepare<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
+            if (simple) svdpp_prepare_batched<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
+            else svdpp_prepare<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
             pp.old_bias = pp.tmp_bias;
             pp.old_fb = pp.tmp_fb;
         }
-        for (int r = u.row_begin; r < u.row_end; r++) {
-            const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
-            instance_update<LPI>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp);
+        if (simple) {
+            svdpp_rows_simple<LPI>(P, D, u, pp, L);
+        } else {
+            for (int r = u.row_begin; r < u.row_end; r++) {
+                const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
+                instance_update<LPI>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp);
+            }
         }
-        if (u.flags & UNIT_END) svdpp_scatter<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
+        if (u.flags & UNIT_END) {
+            if (simple) svdpp_scatter_batched<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
+            else svdpp_scatter<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
+        }
         if (u.flags & UNIT_SAVE) svdpp_save_state<LPI>(P, pp, L);
     }
 }
@@ -625,6 +932,42 @@ static void launch_basicmf_lpi(const DevParams &P, const BasicSchedule &S, long 
 void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long end, int groups_per_wave, int block_threads, hipStream_t st) {
     if (end <= begin) return;
     SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_basicmf_lpi<LPI>(P, S, begin, end, groups_per_wave, block_threads, st));
+}
+template <int LPI, int NU, int NI>
+static void launch_fused_shape(const DevParams &P, const FusedSchedule &S, long begin, long end, int G, int block_threads, hipStream_t st) {
+    const long n = end - begin;
+    if (G >= 2 && NU + NI <= 3) {
+        const long per_block = (long)(block_threads / 64) * 2 * (64 / LPI);
+        hipLaunchKernelGGL((k_fused<LPI, NU, NI, 2>), dim3((int)((n + per_block - 1) / per_block)), dim3(block_threads), 0, st, P, S, begin, end);
+    } else {
+        const long per_block = (long)(block_threads / 64) * (64 / LPI);
+        hipLaunchKernelGGL((k_fused<LPI, NU, NI, 1>), dim3((int)((n + per_block - 1) / per_block)), dim3(block_threads), 0, st, P, S, begin, end);
+    }
+}
+template <int LPI>
+static void launch_fused_lpi(const DevParams &P, const FusedSchedule &S, int nu, int ni, long begin, long end, int G, int bt, hipStream_t st) {
+    if (nu <= 1 && ni <= 1) launch_fused_shape<LPI, 1, 1>(P, S, begin, end, G, bt, st);
+    else if (nu <= 1) launch_fused_shape<LPI, 1, 2>(P, S, begin, end, G, bt, st);
+    else if (ni <= 1) launch_fused_shape<LPI, 2, 1>(P, S, begin, end, G, bt, st);
+    else launch_fused_shape<LPI, 2, 2>(P, S, begin, end, G, bt, st);
+}
+void launch_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int groups_per_wave,
+                  int block_threads, hipStream_t st) {
+    if (end <= begin) return;
+    SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_fused_lpi<LPI>(P, S, max_nu, max_ni, begin, end, groups_per_wave, block_threads, st));
+}
+template <int LPI>
+static void launch_predict_fused_lpi(const DevParams &P, const FusedSchedule &S, int nu, int ni, long n, float *out, int grid, hipStream_t st) {
+    if (nu <= 1 && ni <= 1) hipLaunchKernelGGL((k_predict_fused<LPI, 1, 1>), dim3(grid), dim3(256), 0, st, P, S, n, out);
+    else if (nu <= 1) hipLaunchKernelGGL((k_predict_fused<LPI, 1, 2>), dim3(grid), dim3(256), 0, st, P, S, n, out);
+    else if (ni <= 1) hipLaunchKernelGGL((k_predict_fused<LPI, 2, 1>), dim3(grid), dim3(256), 0, st, P, S, n, out);
+    else hipLaunchKernelGGL((k_predict_fused<LPI, 2, 2>), dim3(grid), dim3(256), 0, st, P, S, n, out);
+}
+void launch_predict_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long n, float *out, hipStream_t st) {
+    if (n <= 0) return;
+    const int lpi = lanes_per_instance(P.k);
+    const int grid = grid_for(n, lpi, 256 * 8);
+    SVDF_DISPATCH_LPI(lpi, launch_predict_fused_lpi<LPI>(P, S, max_nu, max_ni, n, out, grid, st));
 }
 void launch_general(const DevParams &P, const DevCSR &D, const int *order, long begin, long end, hipStream_t st) {
     if (end <= begin) return;

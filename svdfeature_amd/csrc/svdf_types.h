@@ -94,6 +94,22 @@ struct BasicSchedule {
     const float *ival;
 };
 
+// One conflict-free batch of "few-row" instances for the fused kernel: at most 2 user ids and 2 item ids
+// per instance (slot value 0xFFFFFFFF = absent), any number of global features (CSR over the batch order),
+// no id repeated inside an instance.  Covers pairwise-rank pairs (nu=1, ni=2), neighbourhood rows
+// (globals + 1 + 1) and basicMF with side ids.
+struct FusedSchedule {
+    const float *label;
+    const unsigned *uidx[2];
+    const float *uval[2];
+    const unsigned *iidx[2];
+    const float *ival[2];
+    const int *gptr;          // [n+1], nullptr when the data set has no global feature
+    const unsigned *gidx;
+    const float *gval;
+};
+enum { SLOT_ABSENT = 0xFFFFFFFFu };
+
 // Instance stream in SVDFeatureCSR layout (apex_svd_data.h:109-127) resident in HBM.
 struct DevCSR {
     const float *row_label;
@@ -107,9 +123,10 @@ struct DevUnit {
     int fb_begin, fb_end;      // range in fb_index / fb_value
     int row_begin, row_end;    // range of rows in the DevCSR
     int flags;                 // bit0: starts here (prepare_ufeedback), bit1: ends here (update_ufeedback),
-                               // bit2: save state at exit, bit3: load state at entry
+                               // bit2: save state at exit, bit3: load state at entry, bit4: UNIT_SIMPLE fast path
 };
-enum { UNIT_START = 1, UNIT_END = 2, UNIT_SAVE = 4, UNIT_LOAD = 8 };
+enum { UNIT_START = 1, UNIT_END = 2, UNIT_SAVE = 4, UNIT_LOAD = 8,
+       UNIT_SIMPLE = 16 };   // host-verified: rows are (0,1,1) with one user id, distinct item ids, distinct feedback ids
 
 }  // namespace svdf
 #endif

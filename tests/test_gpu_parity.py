@@ -305,3 +305,108 @@ def test_sharded_trainer_world_one_with_nccl_process_group():
         np.testing.assert_array_equal(t.view("W_item"), w0 + (w1 - w0))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("shape", ["pairwise", "globals_two_by_two", "mixed_absent"])
+@pytest.mark.parametrize("k", [10, 64, 128])
+def test_few_row_fused_kernel_matches_oracle_and_general_kernel(shape, k):
+    """k_fused (<=2 user ids, <=2 item ids, distinct ids, any number of globals) vs the oracle, bit for bit,
+    through the staged path and the resident-dataset path; use_fused=0 routes the same data through
+    k_general and must give the same bytes."""
+    nu, ni, ng = 400, 150, 40
+    rng = np.random.default_rng(k)
+    if shape == "pairwise":   # BPR pairs: one user, two items with +1/-1, label 1, no user bias
+        n = 6000
+        rows = []
+        for _ in range(n):
+            a, b = rng.choice(ni, 2, replace=False)
+            lo, hi = min(a, b), max(a, b)
+            rows.append((1.0, [], [(int(rng.integers(0, nu)), 1.0)], [(int(lo), 1.0 if lo == a else -1.0), (int(hi), 1.0 if hi == a else -1.0)]))
+        d = sa.CSRData.from_rows(rows)
+        active, extra = 0, dict(no_user_bias=1)
+    else:
+        d = cases.sparse_feature_rows(5000, nu, ni, ng, seed=k + 1, max_g=4 if shape != "mixed_absent" else 1, max_u=2, max_i=2, allow_dup=False)
+        # sparse_feature_rows may repeat an id by chance: drop those rows so the data is fused-eligible
+        keep = []
+        for r in range(d.num_row):
+            _, g, u_, i_, idx, _v = d.row(r)
+            if len(set(idx[g:g + u_])) == u_ and len(set(idx[g + u_:])) == i_:   # global ids MAY repeat
+                keep.append(r)
+        d = sa.CSRData.concat([d.slice_rows(r, r + 1) for r in keep])
+        active, extra = 0, {}
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=k, wd_global=0.004,
+                           wd_user_bias=0.002, wd_item_bias=0.001, learning_rate=0.01, **extra)
+
+    def make(mk):
+        t = mk(0, active)
+        t.seed(12)
+        for kk, v in conf:
+            t.set_param(kk, v)
+        t.init_model()
+        t.init_trainer()
+        return t
+    o = make(port)
+    t_staged, t_ds, t_gen = make(hip), make(hip), make(hip)
+    t_gen.set_knob("use_fused", 0)
+    ds = t_ds.dataset_from_csr(d)
+    assert ds.kind == 2
+    for _ in range(2):
+        o.update_batch(d)
+        t_staged.update_batch(d)
+        t_staged.finish_round()
+        t_ds.train_dataset(ds)
+        t_gen.update_batch(d)
+        t_gen.finish_round()
+    assert t_staged.counter(6) > 0 and t_staged.counter(5) == 0
+    assert t_gen.counter(6) == 0 and t_gen.counter(5) > 0
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "g_bias"):
+        ref = o.view(name).view(np.uint32)
+        for t in (t_staged, t_ds, t_gen):
+            np.testing.assert_array_equal(t.view(name).view(np.uint32), ref)
+    np.testing.assert_array_equal(t_ds.predict_dataset(ds).view(np.uint32), o.predict_batch(d).view(np.uint32))
+
+
+@pytest.mark.parametrize("k", [16, 64, 128])
+@pytest.mark.parametrize("nobias", [0, 1])
+def test_svdpp_simple_unit_fast_path_and_block_dataset(k, nobias):
+    """User-group data as a resident dataset (svdf_dataset_from_blocks): register-resident fast path
+    (UNIT_SIMPLE: one user id, distinct items, distinct feedback ids) and the generic path
+    (use_simple_units=0) both byte-identical to the oracle; split users (START/MIDDLE/END) and users
+    with a repeated item (not simple) included."""
+    nu, ni = 600, 500
+    blocks = cases.user_blocks(400, nu, ni, ni, seed=k + nobias, max_rows=40, max_fb=30, split_every=6)
+    # make every 9th user rate one item twice -> that unit must take the generic path
+    for b in blocks[::9]:
+        if b.data.num_row >= 2 and b.extend_tag == 0:
+            b.data.feat_index[3] = b.data.feat_index[1]
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni, wd_ufeedback=0.004,
+                           wd_ufeedback_bias=0.002, scale_lr_ufeedback=0.7, ufeedback_init_sigma=0.01, learning_rate=0.01,
+                           no_user_bias=nobias, wd_user_bias=0.001)
+
+    def make(mk):
+        t = mk(1, 0)
+        t.seed(21)
+        for kk, v in conf:
+            t.set_param(kk, v)
+        t.init_model()
+        t.init_trainer()
+        return t
+    o, t_ds, t_gen, t_staged = make(port), make(hip), make(hip), make(hip)
+    t_gen.set_knob("use_simple_units", 0)
+    ds, ds_gen = t_ds.dataset_from_blocks(blocks), t_gen.dataset_from_blocks(blocks)
+    assert ds.kind == 3 and 0 < ds.num_simple_units < ds.num_units and ds_gen.num_simple_units == 0
+    for _ in range(2):
+        for b in blocks:
+            o.update_block(b)
+            t_staged.update_block(b)
+        t_staged.finish_round()
+        t_ds.train_dataset(ds)
+        t_gen.train_dataset(ds_gen)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "W_ufeedback", "ufeedback_bias"):
+        ref = o.view(name).view(np.uint32)
+        for t in (t_ds, t_gen, t_staged):
+            np.testing.assert_array_equal(t.view(name).view(np.uint32), ref)
+    want = np.concatenate([o.predict_block(b) for b in blocks if b.extend_tag == 0])
+    got = t_ds.predict_dataset(ds)
+    rows = np.concatenate([np.full(b.data.num_row, b.extend_tag == 0) for b in blocks])
+    np.testing.assert_array_equal(got[rows].view(np.uint32), want.view(np.uint32))
