@@ -137,6 +137,11 @@ int svdf_item_delta_apply(svdf_trainer *t);
  * runs on); both enqueue on the trainer's stream and return after it has drained. */
 int svdf_item_delta_export(svdf_trainer *t, float *device_dst);
 int svdf_item_delta_import(svdf_trainer *t, const float *device_src);
+/* stream-ordered forms without host synchronisation: write (current - snapshot) straight into a caller-owned
+ * device buffer / set current = snapshot + caller's buffer.  Both only enqueue on the trainer's stream; use
+ * svdf_set_stream so the collective and these kernels share one stream order. */
+int svdf_item_delta_into(svdf_trainer *t, float *device_dst, int64_t *count);
+int svdf_item_delta_apply_from(svdf_trainer *t, const float *device_src);
 
 /* ---- introspection used by tests, bench.py and the harness ---- */
 /* raw copies of parameter views: 0 u_bias 1 W_user 2 i_bias 3 W_item 4 g_bias 5 ufeedback_bias
@@ -146,6 +151,9 @@ int svdf_view_shape(svdf_trainer *t, int which, int *rows, int *cols);
 /* the HIP stream (hipStream_t) all of this trainer's work is enqueued on; timing code records
  * HIP events on it. */
 void *svdf_stream(svdf_trainer *t);
+/* adopt a caller-owned HIP stream (e.g. the stream a torch process group orders its collectives against);
+ * pending work on the old stream is drained first.  The trainer never destroys an adopted stream. */
+int svdf_set_stream(svdf_trainer *t, void *hip_stream);
 int svdf_synchronize(svdf_trainer *t);
 /* counters: 0 instances trained, 1 kernels launched, 2 conflict-free batches executed,
  * 3 staged-window flushes, 4/5/6 launches of the basicMF / general / few-row fused kernel */

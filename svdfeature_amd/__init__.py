@@ -89,6 +89,9 @@ def load_library():
     lib.svdf_item_delta_buffer.argtypes = [P, C.POINTER(C.c_int64)]
     lib.svdf_item_delta_export.argtypes = [P, P]
     lib.svdf_item_delta_import.argtypes = [P, P]
+    lib.svdf_item_delta_into.argtypes = [P, P, C.POINTER(C.c_int64)]
+    lib.svdf_item_delta_apply_from.argtypes = [P, P]
+    lib.svdf_set_stream.argtypes = [P, P]
     lib.svdf_get_view.restype = C.c_int64
     lib.svdf_get_view.argtypes = [P, C.c_int, _f32p, C.c_int64]
     lib.svdf_view_shape.argtypes = [P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -315,6 +318,26 @@ class Trainer:
 
     def item_delta_export(self, device_ptr):
         self._ok(self.lib.svdf_item_delta_export(self.h, C.c_void_p(device_ptr)))
+
+    def item_delta_count(self):
+        """number of floats of the packed item-side delta"""
+        rows, cols = C.c_int(), C.c_int()
+        n = 0
+        for v in (3, 2, 4):   # W_item, i_bias, g_bias
+            self._ok(self.lib.svdf_view_shape(self.h, v, C.byref(rows), C.byref(cols)))
+            n += max(rows.value, 0) * max(cols.value, 1) if rows.value > 0 else 0
+        return n
+
+    def item_delta_into(self, device_ptr):
+        n = C.c_int64()
+        self._ok(self.lib.svdf_item_delta_into(self.h, C.c_void_p(device_ptr), C.byref(n)))
+        return n.value
+
+    def item_delta_apply_from(self, device_ptr):
+        self._ok(self.lib.svdf_item_delta_apply_from(self.h, C.c_void_p(device_ptr)))
+
+    def set_stream(self, hip_stream):
+        self._ok(self.lib.svdf_set_stream(self.h, C.c_void_p(hip_stream)))
 
     def item_delta_import(self, device_ptr):
         self._ok(self.lib.svdf_item_delta_import(self.h, C.c_void_p(device_ptr)))

@@ -140,6 +140,10 @@ int svdf_item_delta_apply(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->item_delta_a
 int svdf_item_delta_export(svdf_trainer *t, float *dst) { SVDF_GUARD(-1, { t->e->item_delta_copy(dst, nullptr); return 0; }) }
 int svdf_item_delta_import(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->item_delta_copy(nullptr, src); return 0; }) }
 
+int svdf_item_delta_into(svdf_trainer *t, float *dst, int64_t *count) { SVDF_GUARD(-1, { t->e->item_delta_into(dst, count); return 0; }) }
+int svdf_item_delta_apply_from(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->item_delta_apply_from(src); return 0; }) }
+int svdf_set_stream(svdf_trainer *t, void *hip_stream) { SVDF_GUARD(-1, { t->e->set_stream((hipStream_t)hip_stream); return 0; }) }
+
 int64_t svdf_get_view(svdf_trainer *t, int which, float *out, int64_t capacity) { SVDF_GUARD(-1, { return t->e->get_view(which, out, capacity); }) }
 int svdf_view_shape(svdf_trainer *t, int which, int *rows, int *cols) { SVDF_GUARD(-1, { t->e->view_shape(which, rows, cols); return 0; }) }
 void *svdf_stream(svdf_trainer *t) { return (void *)t->e->stream(); }

@@ -206,7 +206,7 @@ Engine::~Engine() {
     if (!host_only_ && stream_) {
         try { flush(); } catch (...) {}
         (void)hipStreamSynchronize(stream_);
-        (void)hipStreamDestroy(stream_);
+        if (owns_stream_) (void)hipStreamDestroy(stream_);
     }
 }
 
@@ -1240,6 +1240,34 @@ void Engine::item_delta_apply() {
     HIPCHECK(hipGetLastError());
 }
 
+void Engine::item_delta_into(float *device_dst, int64_t *count) {
+    need_device("item_delta");
+    flush();
+    long off = 0;
+    for (auto &x : shared_ranges()) {
+        launch_delta_sub(x.base, d_snap_.p + off, device_dst + off, x.n, stream_);
+        off += x.n;
+    }
+    HIPCHECK(hipGetLastError());
+    if (count) *count = off;
+}
+void Engine::item_delta_apply_from(const float *device_src) {
+    need_device("item_delta");
+    long off = 0;
+    for (auto &x : shared_ranges()) {
+        launch_delta_add(x.base, d_snap_.p + off, device_src + off, x.n, stream_);
+        off += x.n;
+    }
+    HIPCHECK(hipGetLastError());
+}
+void Engine::set_stream(hipStream_t s) {
+    need_device("set_stream");
+    flush();
+    HIPCHECK(hipStreamSynchronize(stream_));
+    if (owns_stream_ && stream_) (void)hipStreamDestroy(stream_);
+    stream_ = s;
+    owns_stream_ = false;
+}
 void Engine::item_delta_copy(float *device_dst, const float *device_src) {
     need_device("item_delta");
     long total = 0;

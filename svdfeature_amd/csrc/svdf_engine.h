@@ -166,6 +166,9 @@ class Engine {
     void *item_delta_buffer(int64_t *count);
     void item_delta_apply();
     void item_delta_copy(float *device_dst, const float *device_src);
+    void item_delta_into(float *device_dst, int64_t *count);
+    void item_delta_apply_from(const float *device_src);
+    void set_stream(hipStream_t s);
 
     // introspection
     int64_t get_view(int which, float *out, int64_t capacity);
@@ -206,6 +209,7 @@ class Engine {
     int device_ = -1;
     bool host_only_ = false;
     hipStream_t stream_ = nullptr;
+    bool owns_stream_ = true;
     DevBuf<float> dW_, dbias_, dg_, dstate_;
     bool device_model_ = false;
     DevBuf<unsigned> d_ubound_, d_ibound_, d_gbound_, d_fu_ptr_, d_fu_idx_, d_fi_ptr_, d_fi_idx_;

@@ -68,16 +68,23 @@ class ShardedTrainer:
             self.a.delta_begin()
             self.a.train(w)
             d = self.a.delta_get()
-            self.dist.all_reduce(d)   # SUM
+            if hasattr(self.a, "all_reduce"):
+                self.a.all_reduce(self.dist, d)   # SUM, ordered on the adaptor's stream
+            else:
+                self.dist.all_reduce(d)
             self.a.delta_set(d)
 
 
 class HipShard:
-    """Adaptor over svdfeature_amd.Trainer: windows are HBM-resident scheduled datasets, the delta lives
-    in a torch tensor so torch.distributed (backend nccl == RCCL) can all-reduce it in place."""
+    """Adaptor over svdfeature_amd.Trainer: windows are HBM-resident scheduled datasets; the delta is written
+    straight into a torch tensor and everything (SGD kernels, delta kernels, the RCCL all-reduce issued by
+    torch.distributed backend nccl) is ordered on ONE torch-owned HIP stream, so a pass needs no host
+    synchronisation at all."""
 
     def __init__(self, trainer, torch, device):
         self.t, self.torch, self.device = trainer, torch, device
+        self.stream = torch.cuda.Stream(device=device)
+        trainer.set_stream(self.stream.cuda_stream)
         self.buf = None
 
     def make_windows(self, shards):
@@ -90,13 +97,15 @@ class HipShard:
         self.t.item_delta_begin()
 
     def delta_get(self):
-        _, n = self.t.item_delta_buffer()
-        if self.buf is None or self.buf.numel() != n:
-            self.buf = self.torch.empty(n, dtype=self.torch.float32, device=self.device)
-        self.t.item_delta_export(self.buf.data_ptr())   # returns after the trainer's stream has drained
+        if self.buf is None:
+            with self.torch.cuda.stream(self.stream):
+                self.buf = self.torch.empty(self.t.item_delta_count(), dtype=self.torch.float32, device=self.device)
+        self.t.item_delta_into(self.buf.data_ptr())
         return self.buf
 
+    def all_reduce(self, dist, d):
+        with self.torch.cuda.stream(self.stream):   # the collective is ordered after the delta kernel on our stream
+            dist.all_reduce(d)
+
     def delta_set(self, d):
-        self.torch.cuda.synchronize(self.device)         # the collective ran on torch's stream
-        self.t.item_delta_import(d.data_ptr())
-        self.t.item_delta_apply()
+        self.t.item_delta_apply_from(d.data_ptr())

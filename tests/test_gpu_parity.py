@@ -263,10 +263,13 @@ def test_two_simulated_ranks_on_one_gpu_match_the_oracle_simulation():
             for a, wins in shards:
                 a.delta_begin()
                 a.train(wins[w])
-                ds.append(a.delta_get().clone())
+                d = a.delta_get()          # enqueued on the adaptor's own stream
+                a.stream.synchronize()
+                ds.append(d.clone())
             total = ds[0] + ds[1]
+            torch.cuda.synchronize()
             for a, _ in shards:
-                a.delta_set(total.clone())
+                a.delta_set(total)
     sim = simulate(conf, u, i, r, world, windows, passes)
     for rk in range(world):
         for name in ("W_item", "i_bias", "W_user", "u_bias"):
@@ -300,7 +303,7 @@ def test_sharded_trainer_world_one_with_nccl_process_group():
         a.train(ds)
         w1 = t.view("W_item").copy()
         d = a.delta_get()
-        dist.all_reduce(d)
+        a.all_reduce(dist, d)
         a.delta_set(d)
         np.testing.assert_array_equal(t.view("W_item"), w0 + (w1 - w0))
     finally:
