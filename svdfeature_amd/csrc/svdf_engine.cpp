@@ -2,6 +2,7 @@
 #include "svdf_engine.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -202,7 +203,19 @@ Engine::Engine(TypeParam mtype, int device) : mtype_(mtype) {
     HIPCHECK(hipFree(warm));
 }
 
+namespace {
+struct ScopedNs {
+    int64_t &acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit ScopedNs(int64_t &a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~ScopedNs() { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); }
+};
+}  // namespace
+
 Engine::~Engine() {
+    if (getenv("SVDF_PROFILE"))
+        fprintf(stderr, "[svdfeature_amd] host time: flush (schedule+upload+launch) %.3fs  model save/load %.3fs  instances %ld flushes %ld\n",
+                ns_flush_ * 1e-9, ns_model_ * 1e-9, (long)n_instances_, (long)n_flushes_);
     if (!host_only_ && stream_) {
         try { flush(); } catch (...) {}
         (void)hipStreamSynchronize(stream_);
@@ -371,6 +384,7 @@ void Engine::load_model(FILE *fi) {  // apex_svd_base.h:138-140
     if (device_model_) upload_model();
 }
 void Engine::save_model(FILE *fo) {  // apex_svd_base.h:142-144
+    ScopedNs timer(ns_model_);
     check(space_allocated_, "save_model: model is not initialised");
     if (device_model_) { flush(); download_model(); }
     check(host_model_valid_, "save_model: no model");
@@ -507,12 +521,26 @@ bool Engine::basic_fast_path_allowed() const {
 }
 
 void Engine::update_csr(float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
+    if (!user_group() && trainer_ready_ && !host_only_) {   // one instance per call: append in place
+        check(ng >= 0 && nu >= 0 && ni >= 0, "negative feature count");
+        check_row(ng, nu, ni, index);
+        const int nv = ng + nu + ni;
+        const int b = staged_.row_ptr.back();
+        staged_.row_label.push_back(label);
+        staged_.row_ptr.push_back(b + ng);
+        staged_.row_ptr.push_back(b + ng + nu);
+        staged_.row_ptr.push_back(b + nv);
+        for (int j = 0; j < nv; j++) { staged_.feat_index.push_back(index[j]); staged_.feat_value.push_back(value[j]); }
+        if (staged_.num_row() >= stage_window_) flush();
+        return;
+    }
     const int ptr[4] = {0, ng, ng + nu, ng + nu + ni};
     update_csr_batch(1, &label, ptr, index, value);
 }
 void Engine::update_csr_batch(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value) {
+    // hot when the reference's CLI feeds one instance per call: no HIP API call and no timer in here
     check(trainer_ready_, "update: init_trainer has not been called");
-    need_device("update");
+    if (host_only_) need_device("update");
     if (user_group()) {
         // SVDPPFeature inherits update(Elem) (apex_svd_base.h:464-466): rows run against the current
         // implicit-feedback state without prepare/scatter
@@ -531,7 +559,7 @@ void Engine::update_csr_batch(int num_row, const float *row_label, const int *ro
 void Engine::update_block(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label,
                           const int *row_ptr, const unsigned *feat_index, const float *feat_value) {
     check(trainer_ready_, "update: init_trainer has not been called");
-    need_device("update");
+    if (host_only_) need_device("update");
     check(user_group(), "not implemented");   // SVDFeature has no update(SVDPlusBlock) (apex_svd.h:97)
     for (int j = 0; j < nfb; j++) check(ifb[j] < (unsigned)mp_.num_ufeedback, "ufeedback id exceed bound");
     const int h = (int)staged_.num_row();
@@ -636,6 +664,7 @@ static void parallel_gather(T *dst, const T *src, const int *order, long n, long
 // =============================================================================== flush
 void Engine::flush() {
     if (host_only_ || !trainer_ready_) return;
+    ScopedNs timer(ns_flush_);
     if (user_group()) flush_units();
     else flush_csr();
 }

@@ -261,6 +261,7 @@ class Engine {
     std::vector<Range> shared_ranges();
     // ---- counters
     int64_t n_instances_ = 0, n_launches_ = 0, n_batches_ = 0, n_flushes_ = 0;
+    int64_t ns_flush_ = 0, ns_model_ = 0;   // host-side time accounting (SVDF_PROFILE=1 prints it)
     int64_t n_kind_[3] = {0, 0, 0};   // launches of k_basicmf / k_general / k_fused
     friend struct Dataset;
 };
