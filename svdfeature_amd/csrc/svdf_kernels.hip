@@ -184,6 +184,22 @@ __device__ __forceinline__ void store_row(float *W, size_t row, int pitch, int L
     *reinterpret_cast<float4 *>(W + row * (size_t)pitch + (size_t)L * 4) = v;
 }
 
+// row store with a cache policy: 0 plain (line stays dirty in the XCD's L2 until the kernel ends),
+// 1 nontemporal hint, 2 sc1 write-through (the line leaves L2 as soon as it is written)
+typedef float svdf_f4 __attribute__((ext_vector_type(4)));
+template <int LPI>
+__device__ __forceinline__ void store_row_policy(float *W, size_t row, int pitch, int L, int k, const float4 v, int mode) {
+    if (LPI * 4 > k && L * 4 >= k) return;
+    float *ptr = W + row * (size_t)pitch + (size_t)L * 4;
+    if (mode == 0) {
+        *reinterpret_cast<float4 *>(ptr) = v;
+    } else {
+        svdf_f4 x = {v.x, v.y, v.z, v.w};
+        if (mode == 1) __builtin_nontemporal_store(x, reinterpret_cast<svdf_f4 *>(ptr));
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(x) : "memory");
+    }
+}
+
 // =====================================================================================
 // Kernel 1: basicMF fused SGD step -- no global feature, one user id, one item id, no side
 // tables, distinct user/item rows.  One lane group per instance, G groups per wave in flight.
@@ -258,8 +274,8 @@ __global__ __launch_bounds__(256) void k_basicmf(const DevParams P, const BasicS
         reg_row<LPI>(P, wi, get_wd(P.i_rng, ir[g] - P.item_off, P.wd_item), true, L);
         nbi = nbi * (1.0f - P.lr * P.wd_item_bias);
         if (valid[g]) {
-            store_row<LPI>(P.W, ur[g], pitch, L, k, wu);
-            store_row<LPI>(P.W, ir[g], pitch, L, k, wi);
+            store_row_policy<LPI>(P.W, ur[g], pitch, L, k, wu, P.store_mode);
+            store_row_policy<LPI>(P.W, ir[g], pitch, L, k, wi, P.store_mode);
             if (L == 0) {
                 if (use_ubias) P.bias[ur[g]] = nbu;
                 P.bias[ir[g]] = nbi;

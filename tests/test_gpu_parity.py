@@ -413,3 +413,71 @@ def test_svdpp_simple_unit_fast_path_and_block_dataset(k, nobias):
     got = t_ds.predict_dataset(ds)
     rows = np.concatenate([np.full(b.data.num_row, b.extend_tag == 0) for b in blocks])
     np.testing.assert_array_equal(got[rows].view(np.uint32), want.view(np.uint32))
+
+
+def test_ten_million_ratings_match_the_oracle():
+    """BASELINE configs[1] shape (1M x 100K, k=64) on a 10M-rating prefix, one pass: every parameter
+    byte-identical to the sequential C oracle (about 3 s of CPU work)."""
+    import bench
+    nu, ni, n = 1_000_000, 100_000, 10_000_000
+    u, i, r = bench.synth_triples(n, nu, ni)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
+    t, o = hip(0, 0), port(0, 0)
+    for x in (t, o):
+        x.seed(10)
+        for k, v in conf:
+            x.set_param(k, v)
+        x.init_model()
+        x.init_trainer()
+    ds = t.dataset_from_triples(u, i, r)
+    t.train_dataset(ds)
+    o.update_batch(sa.CSRData.from_triples(u, i, r))
+    for name in ("W_user", "W_item", "u_bias", "i_bias"):
+        assert np.array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32)), name
+
+
+def test_full_size_properties_100m_ratings():
+    """BASELINE configs[1] at FULL size (100M ratings), where the CPU oracle would take minutes: size-
+    independent properties instead --
+      * learning_rate = 0, wd = 0: a full pass leaves every parameter byte-identical (every instance is
+        read, scored and written back; nothing may be corrupted or dropped),
+      * composition: pass over the first 60M then over the last 40M == one pass over all 100M (the schedule
+        of a prefix composes with the schedule of the rest),
+      * determinism: the same pass on two trainers gives identical bytes,
+      * the schedule is a permutation: counters report exactly 100M instances in <= 100K-instance batches."""
+    import bench
+    nu, ni, n = 1_000_000, 100_000, 100_000_000
+    u, i, r = bench.synth_triples(n, nu, ni)
+
+    def make(**kw):
+        t = hip(0, 0)
+        t.seed(10)
+        for k, v in cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64, **kw):
+            t.set_param(k, v)
+        t.init_model()
+        t.init_trainer()
+        return t
+    z = make(learning_rate=0, wd_user=0, wd_item=0)
+    before = [z.view(v).copy() for v in ("W_user", "W_item", "u_bias", "i_bias")]
+    dz = z.dataset_from_triples(u, i, r)
+    assert dz.num_row == n and dz.max_batch <= ni and dz.algorithmic_bytes == n * 1072
+    z.train_dataset(dz)
+    assert z.counter(0) == n
+    for a, name in zip(before, ("W_user", "W_item", "u_bias", "i_bias")):
+        assert np.array_equal(a.view(np.uint32), z.view(name).view(np.uint32)), "lr=0 pass changed " + name
+    dz.close()
+    z.close()
+    a, b = make(), make()
+    da = a.dataset_from_triples(u, i, r)
+    cut = 60_000_000
+    db1, db2 = b.dataset_from_triples(u[:cut], i[:cut], r[:cut]), b.dataset_from_triples(u[cut:], i[cut:], r[cut:])
+    a.train_dataset(da)
+    b.train_dataset(db1)
+    b.train_dataset(db2)
+    for name in ("W_item", "i_bias", "u_bias", "W_user"):
+        assert np.array_equal(a.view(name).view(np.uint32), b.view(name).view(np.uint32)), "composition broke " + name
+    c = make()
+    dc = c.dataset_from_triples(u, i, r)
+    c.train_dataset(dc)
+    assert np.array_equal(a.view("W_item").view(np.uint32), c.view("W_item").view(np.uint32))
+    assert np.array_equal(a.view("W_user").view(np.uint32), c.view("W_user").view(np.uint32))

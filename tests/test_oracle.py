@@ -150,3 +150,52 @@ def test_baseline_config1_rmse():
     """BASELINE config 1: demo/basicMF on ML-100K, k=16, one epoch: test RMSE 1.265035 -> 1.047025."""
     res = scenarios.run_scenario("basicmf_ml100k_k16", port)
     assert abs(res["rmse"] - 1.047025) < 5e-7
+
+
+REFDIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REFDIR, "make_ugroup_buffer")), reason="reference tools (oracle/_ref) not present")
+def test_buffer_writers_match_the_reference_tools_byte_for_byte(tmp_path):
+    """svdfeature_amd.data writes the binary buffer formats the reference's own tools write
+    (tools/make_feature_buffer.cpp, tools/make_ugroup_buffer.cpp -> apex_svd_data.cpp:118-195, 558-595):
+    same text input -> identical bytes, including split users (block_max_line) and empty feedback lists."""
+    import subprocess
+    rng = np.random.default_rng(3)
+    # --- random-order CSR buffer with ragged rows
+    d = cases.sparse_feature_rows(2500, 50, 40, 7, 21)
+    txt = tmp_path / "feat.txt"
+    with open(txt, "w") as f:
+        for r in range(d.num_row):
+            label, ng, nu, ni, idx, val = d.row(r)
+            f.write("%g %d %d %d %s\n" % (label, ng, nu, ni, " ".join("%d:%.9g" % (a, b) for a, b in zip(idx, val))))
+    subprocess.check_call([os.path.join(REFDIR, "make_feature_buffer"), str(txt), str(tmp_path / "ref.buffer"), "-batch_size", "700"],
+                          stdout=subprocess.DEVNULL)
+    D.write_csr_buffer(str(tmp_path / "mine.buffer"), D.read_text_features(str(txt)), batch_size=700)
+    assert open(tmp_path / "ref.buffer", "rb").read() == open(tmp_path / "mine.buffer", "rb").read()
+    back = D.read_csr_buffer(str(tmp_path / "ref.buffer"))
+    np.testing.assert_array_equal(back.feat_index, d.feat_index)
+    np.testing.assert_array_equal(back.feat_value.view(np.uint32), d.feat_value.view(np.uint32))
+    # --- user-group buffer: users with 1..25 rows, block_max_line 10 splits the long ones
+    rows, fb = [], []
+    for uid in range(60):
+        nrow = int(rng.integers(1, 26))
+        nfb = 0 if uid % 6 == 0 else int(rng.integers(1, 5))
+        fb.append((nrow, sorted(rng.choice(40, nfb, replace=False).tolist())))
+        for _ in range(nrow):
+            rows.append((int(rng.integers(1, 6)), uid, int(rng.integers(0, 40))))
+    gtxt, ftxt = tmp_path / "group.txt", tmp_path / "fb.txt"
+    with open(gtxt, "w") as f:
+        for lab, uid, iid in rows:
+            f.write("%d 0 1 1 %d:1 %d:1\n" % (lab, uid, iid))
+    with open(ftxt, "w") as f:
+        for nrow, ids in fb:
+            f.write("%d %d %s\n" % (nrow, len(ids), " ".join("%d:0.5" % x for x in ids)))
+    subprocess.check_call([os.path.join(REFDIR, "make_ugroup_buffer"), str(gtxt), str(tmp_path / "ref.ug"), "-fd", str(ftxt), "-max_block", "10"],
+                          stdout=subprocess.DEVNULL)
+    blocks = D.make_user_blocks(D.read_text_features(str(gtxt), sort_sections=True), D.read_feedback_file(str(ftxt)), block_max_line=10)
+    D.write_ugroup_buffer(str(tmp_path / "mine.ug"), blocks)
+    assert open(tmp_path / "ref.ug", "rb").read() == open(tmp_path / "mine.ug", "rb").read()
+    back = D.read_ugroup_buffer(str(tmp_path / "ref.ug"))
+    assert [b.extend_tag for b in back] == [b.extend_tag for b in blocks]
+    assert sum(b.data.num_row for b in back) == len(rows)

@@ -24,13 +24,11 @@ ds = tr.dataset_from_triples(u, i, r)
 print("batches", ds.num_batches, "max", ds.max_batch, flush=True)
 tr.train_dataset(ds); tr.synchronize()
 res = []
-for rep in range(1):
-    for gpw, bt, mg in ((4,128,1),(4,128,2),(4,128,4),(4,128,16),(4,128,2000),(2,256,2000),(1,256,2000),(4,256,1)):
-        if True:
-            tr.set_knob("groups_per_wave", gpw); tr.set_knob("block_threads", bt); tr.set_knob("debug_merge", mg); print("merge",mg,end=" ")
-            tr.synchronize(); t0 = time.perf_counter()
-            for _ in range(a.passes):
-                tr.train_dataset(ds)
-            tr.synchronize(); dt = (time.perf_counter() - t0) / a.passes
-            res.append((gpw, bt, dt))
-            print("gpw %d block %3d : %.2f ms/pass  %.3f G inst/s  %.1f%% of 8 TB/s" % (gpw, bt, dt * 1e3, a.ratings / dt / 1e9, ds.algorithmic_bytes / dt / 8e12 * 100), flush=True)
+for rep in range(2):
+    for sm in (0, 1, 2):
+        tr.set_knob("store_mode", sm)
+        tr.synchronize(); t0 = time.perf_counter()
+        for _ in range(a.passes):
+            tr.train_dataset(ds)
+        tr.synchronize(); dt = (time.perf_counter() - t0) / a.passes
+        print("store_mode %d : %.2f ms/pass  %.3f G inst/s  %.1f%% of 8 TB/s" % (sm, dt * 1e3, a.ratings / dt / 1e9, ds.algorithmic_bytes / dt / 8e12 * 100), flush=True)
