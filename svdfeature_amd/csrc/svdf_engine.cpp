@@ -325,6 +325,7 @@ static void save_1d(FILE *fo, const float *v, int n) {
 static void save_2d(FILE *fo, const float *w, int rows, int cols, int pitch) {
     int hdr[2] = {cols, rows};
     fwrite(hdr, sizeof(int), 2, fo);
+    if (cols == pitch) { fwrite(w, sizeof(float), (size_t)rows * cols, fo); return; }   // k % 4 == 0: rows are contiguous
     for (int y = 0; y < rows; y++) fwrite(w + (size_t)y * pitch, sizeof(float), (size_t)cols, fo);
 }
 static void load_1d(FILE *fi, float *v, int n) {
@@ -337,6 +338,10 @@ static void load_2d(FILE *fi, float *w, int rows, int cols, int pitch) {
     int hdr[2];
     check(fread(hdr, sizeof(int), 2, fi) > 0, "tensor::load_from_file");
     check(hdr[0] == cols && hdr[1] == rows, "tensor::load_from_file: shape does not match the model header");
+    if (cols == pitch && rows > 0 && cols > 0) {
+        check(fread(w, sizeof(float), (size_t)rows * cols, fi) == (size_t)rows * cols, "tensor::load_from_file");
+        return;
+    }
     for (int y = 0; y < rows; y++)
         if (cols > 0) check(fread(w + (size_t)y * pitch, sizeof(float), (size_t)cols, fi) > 0, "tensor::load_from_file");
 }
@@ -1164,8 +1169,7 @@ void Engine::train_dataset(Dataset *ds) {
     const Schedule &sc = ds->sched;
     if (ds->kind == 0) {
         BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
-        const size_t m = (size_t)std::max(1, debug_merge_);
-        for (size_t l = 0; l < sc.num_levels(); l += m) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[std::min(l + m, sc.num_levels())], groups_per_wave_, block_threads_, stream_);
+        for (size_t l = 0; l < sc.num_levels(); l++) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
     } else if (ds->kind == 3) {
         const UnitDev &d = ds->unitdev;
         DevCSR D{d.label.p, d.ptr.p, d.index.p, d.value.p};
@@ -1370,7 +1374,6 @@ int Engine::set_knob(const char *name, long value) {
         groups_per_wave_ = (int)value;
         return 0;
     }
-    if (!strcmp(name, "debug_merge")) { debug_merge_ = (int)value; return 0; }
     if (!strcmp(name, "store_mode")) { check(value >= 0 && value <= 2, "store_mode must be 0, 1 or 2"); store_mode_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "use_fused")) { use_fused_ = value != 0; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""End-to-end throughput of the reference's trainer CLI: unmodified (oracle/_ref/svd_feature) vs linked
+"""(not collected by pytest; lives under tests/ because it executes the reference binaries in oracle/_ref)
+End-to-end throughput of the reference's trainer CLI: unmodified (oracle/_ref/svd_feature) vs linked
 against the MI355X engine (oracle/_ref/svd_feature_amd).  Same config, same binary buffer, wall clock of
 whole rounds including the reference's loader thread, per-instance update() calls and model saves."""
 import os, subprocess, sys, tempfile, time, json

@@ -129,19 +129,3 @@ if "svdpp" in which:
         timed(t, lambda: t.train_dataset(ds), nn, ds.algorithmic_bytes, "svdpp user blocks k=%d resident dataset, simple_units=%d" % (k, simple),
               "%d users, %d on fast path, %d batches, dataset build %.1fs" % (ds.num_units, ds.num_simple_units, ds.num_batches, build_s))
         ds.close(); t.close()
-    # the reference CPU path on the same blocks (python-fed, one ctypes call per user)
-    from oracle import oracle
-    if oracle.have_reference():
-        c = oracle.OracleTrainer("reference", 1, 0)
-        c.seed(10)
-        for kk, v in [("learning_rate", "0.005"), ("wd_item", "0.004"), ("wd_user", "0.004"), ("num_item", a.items), ("num_user", a.users),
-                      ("num_factor", a.factor), ("base_score", "3"), ("num_global", "0"), ("num_ufeedback", a.items), ("wd_ufeedback", "0.004")]:
-            c.set_param(kk, v)
-        c.init_model(); c.init_trainer()
-        sub = blocks[:4000]
-        t0 = time.perf_counter()
-        for b in sub:
-            c.update_block(b)
-        dt = time.perf_counter() - t0
-        ninst = sum(b.data.num_row for b in sub)
-        print(json.dumps({"case": "svdpp reference CPU, 1 thread", "instances": ninst, "inst_per_s": ninst / dt}), flush=True)

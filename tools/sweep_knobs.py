@@ -23,12 +23,14 @@ tr.init_model(); tr.init_trainer()
 ds = tr.dataset_from_triples(u, i, r)
 print("batches", ds.num_batches, "max", ds.max_batch, flush=True)
 tr.train_dataset(ds); tr.synchronize()
-res = []
 for rep in range(2):
-    for sm in (0, 1, 2):
-        tr.set_knob("store_mode", sm)
-        tr.synchronize(); t0 = time.perf_counter()
-        for _ in range(a.passes):
-            tr.train_dataset(ds)
-        tr.synchronize(); dt = (time.perf_counter() - t0) / a.passes
-        print("store_mode %d : %.2f ms/pass  %.3f G inst/s  %.1f%% of 8 TB/s" % (sm, dt * 1e3, a.ratings / dt / 1e9, ds.algorithmic_bytes / dt / 8e12 * 100), flush=True)
+    for gpw in (1, 2, 4, 8):
+        for bt in (64, 128, 256):
+            for sm in ((0, 1, 2) if (gpw, bt) == (4, 128) else (0,)):
+                tr.set_knob("groups_per_wave", gpw); tr.set_knob("block_threads", bt); tr.set_knob("store_mode", sm)
+                tr.synchronize(); t0 = time.perf_counter()
+                for _ in range(a.passes):
+                    tr.train_dataset(ds)
+                tr.synchronize(); dt = (time.perf_counter() - t0) / a.passes
+                print("gpw %d block %3d store_mode %d : %.2f ms/pass  %.3f G inst/s  %.1f%% of 8 TB/s"
+                      % (gpw, bt, sm, dt * 1e3, a.ratings / dt / 1e9, ds.algorithmic_bytes / dt / 8e12 * 100), flush=True)
