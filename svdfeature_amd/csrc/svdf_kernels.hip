@@ -684,26 +684,31 @@ __device__ __forceinline__ void svdpp_scatter(const DevParams &P, SvdppRegs &pp,
 //     ids => nothing in flight is modified), item rows are written once, fire and forget,
 //   * feedback rows are gathered / scattered PF at a time (accumulation order unchanged).
 // What remains sequential is the true recurrence p_u, tmp_ufeedback -> err -> p_u, tmp_ufeedback.
-constexpr int SVDPP_PF = 4;   // measured: 8 spills (167 VGPR + scratch) and is slower
+constexpr int SVDPP_PF = 4;   // rows in flight; measured: 8 spills (167 VGPR + scratch) and is slower
+constexpr int SVDPP_FB = 8;   // feedback rows gathered / scattered per batch
 
+// NOTE on control flow: the gathers below are issued with CLAMPED indices and no per-element branch, so the
+// compiler can put all index loads, then all row loads of a batch back to back (a branch per element makes
+// every load wait for the previous one: s_waitcnt vmcnt(1) chains).  Only the arithmetic / stores are predicated.
 template <int LPI>
 __device__ __forceinline__ void svdpp_prepare_batched(const DevParams &P, SvdppRegs &pp, const unsigned *fidx, const float *fval, int nfb, int L) {
     pp.norm = 0.0f; pp.tmp_fb = f4zero(); pp.tmp_bias = 0.0f;
     const bool ub = P.no_user_bias == 0;
-    for (int j0 = 0; j0 < nfb; j0 += SVDPP_PF) {
-        float4 w[SVDPP_PF]; float v[SVDPP_PF], b[SVDPP_PF];
+    for (int j0 = 0; j0 < nfb; j0 += SVDPP_FB) {
+        float4 w[SVDPP_FB]; float v[SVDPP_FB], b[SVDPP_FB]; unsigned row[SVDPP_FB];
 #pragma unroll
-        for (int c = 0; c < SVDPP_PF; c++) {
-            w[c] = f4zero(); v[c] = 0.0f; b[c] = 0.0f;
-            if (j0 + c < nfb) {
-                const unsigned row = P.fb_off + fidx[j0 + c];
-                v[c] = fval[j0 + c];
-                w[c] = load_row<LPI>(P.W, row, P.pitch, L, P.k);
-                if (ub) b[c] = P.bias[row];
-            }
+        for (int c = 0; c < SVDPP_FB; c++) {
+            const int j = min(j0 + c, nfb - 1);
+            row[c] = P.fb_off + fidx[j];
+            v[c] = fval[j];
         }
 #pragma unroll
-        for (int c = 0; c < SVDPP_PF; c++) {
+        for (int c = 0; c < SVDPP_FB; c++) {
+            w[c] = load_row<LPI>(P.W, row[c], P.pitch, L, P.k);
+            b[c] = ub ? P.bias[row[c]] : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < SVDPP_FB; c++) {
             if (j0 + c < nfb) {
                 axpy4(pp.tmp_fb, w[c], v[c]);
                 pp.norm = pp.norm + v[c] * v[c];
@@ -723,20 +728,21 @@ __device__ __forceinline__ void svdpp_scatter_batched(const DevParams &P, SvdppR
     db = db * inv;
     pp.tmp_fb = d; pp.tmp_bias = db;
     const bool ub = P.no_user_bias == 0;
-    for (int j0 = 0; j0 < nfb; j0 += SVDPP_PF) {
-        float4 w[SVDPP_PF]; float v[SVDPP_PF], b[SVDPP_PF]; unsigned row[SVDPP_PF];
+    for (int j0 = 0; j0 < nfb; j0 += SVDPP_FB) {
+        float4 w[SVDPP_FB]; float v[SVDPP_FB], b[SVDPP_FB]; unsigned row[SVDPP_FB];
 #pragma unroll
-        for (int c = 0; c < SVDPP_PF; c++) {
-            w[c] = f4zero(); v[c] = 0.0f; b[c] = 0.0f; row[c] = 0;
-            if (j0 + c < nfb) {
-                row[c] = P.fb_off + fidx[j0 + c];
-                v[c] = fval[j0 + c];
-                w[c] = load_row<LPI>(P.W, row[c], P.pitch, L, P.k);
-                if (ub) b[c] = P.bias[row[c]];
-            }
+        for (int c = 0; c < SVDPP_FB; c++) {
+            const int j = min(j0 + c, nfb - 1);
+            row[c] = P.fb_off + fidx[j];
+            v[c] = fval[j];
         }
 #pragma unroll
-        for (int c = 0; c < SVDPP_PF; c++) {
+        for (int c = 0; c < SVDPP_FB; c++) {
+            w[c] = load_row<LPI>(P.W, row[c], P.pitch, L, P.k);
+            b[c] = ub ? P.bias[row[c]] : 0.0f;
+        }
+#pragma unroll
+        for (int c = 0; c < SVDPP_FB; c++) {
             if (j0 + c < nfb) {
                 axpy4(w[c], d, v[c]);
                 store_row<LPI>(P.W, row[c], P.pitch, L, P.k, w[c]);
@@ -750,16 +756,22 @@ struct SvdppRowPF {   // one prefetched row of a simple unit
     float bi, label, uv, iv;
     unsigned irow;
 };
+// rows beyond the unit's end re-fetch its last row (results unused, nothing stored)
 template <int LPI>
-__device__ __forceinline__ void svdpp_fetch_row(const DevParams &P, const DevCSR &D, int r, int e, bool on, int L, SvdppRowPF &o) {
-    o.q = f4zero(); o.bi = 0.0f; o.label = 0.0f; o.uv = 0.0f; o.iv = 0.0f; o.irow = 0;
-    if (on) {
-        o.label = D.row_label[r];
-        o.uv = D.feat_value[e];
-        o.iv = D.feat_value[e + 1];
-        o.irow = P.item_off + D.feat_index[e + 1];
-        o.q = load_row<LPI>(P.W, o.irow, P.pitch, L, P.k);
-        o.bi = P.bias[o.irow];
+__device__ __forceinline__ void svdpp_fetch_rows(const DevParams &P, const DevCSR &D, int row_begin, int e0, int j0, int nrow, int L,
+                                                 SvdppRowPF (&o)[SVDPP_PF]) {
+#pragma unroll
+    for (int c = 0; c < SVDPP_PF; c++) {
+        const int j = min(j0 + c, nrow - 1);
+        o[c].label = D.row_label[row_begin + j];
+        o[c].uv = D.feat_value[e0 + 2 * j];
+        o[c].iv = D.feat_value[e0 + 2 * j + 1];
+        o[c].irow = P.item_off + D.feat_index[e0 + 2 * j + 1];
+    }
+#pragma unroll
+    for (int c = 0; c < SVDPP_PF; c++) {
+        o[c].q = load_row<LPI>(P.W, o[c].irow, P.pitch, L, P.k);
+        o[c].bi = P.bias[o[c].irow];
     }
 }
 template <int LPI>
@@ -774,14 +786,9 @@ __device__ __forceinline__ void svdpp_rows_simple(const DevParams &P, const DevC
     const float wd_u = get_wd(P.u_rng, urow - P.user_off, P.wd_user);
     const float lr = P.lr;
     SvdppRowPF cur[SVDPP_PF], nxt[SVDPP_PF];
-#pragma unroll
-    for (int c = 0; c < SVDPP_PF; c++) svdpp_fetch_row<LPI>(P, D, u.row_begin + c, e0 + 2 * c, c < nrow, L, cur[c]);
+    svdpp_fetch_rows<LPI>(P, D, u.row_begin, e0, 0, nrow, L, cur);
     for (int j0 = 0; j0 < nrow; j0 += SVDPP_PF) {
-#pragma unroll
-        for (int c = 0; c < SVDPP_PF; c++) {
-            const int j = j0 + SVDPP_PF + c;
-            svdpp_fetch_row<LPI>(P, D, u.row_begin + j, e0 + 2 * j, j < nrow, L, nxt[c]);
-        }
+        svdpp_fetch_rows<LPI>(P, D, u.row_begin, e0, j0 + SVDPP_PF, nrow, L, nxt);
 #pragma unroll
         for (int c = 0; c < SVDPP_PF; c++) {
             if (j0 + c < nrow) {
@@ -793,6 +800,8 @@ __device__ __forceinline__ void svdpp_rows_simple(const DevParams &P, const DevC
                 float4 tu = pp.tmp_fb, ti = f4zero();              // prepare_tmp (:354-381, :506-508)
                 axpy4(tu, p, x.uv);
                 axpy4(ti, x.q, x.iv);
+                // (an LDS-staged variant of the dot -- every lane sums all chunks itself from shared memory -- was
+                // measured 1.6-1.9x SLOWER per row here than the DPP scan: 32 dependent-latency ds_read_b128)
                 sum += (double)group_dot<LPI>(tu, ti, L, P.k);
                 const float pred = map_active((float)sum, P.active_type);
                 const float err = cal_grad(x.label, pred, P.active_type) * 1.0f;
