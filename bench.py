@@ -232,8 +232,17 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    final_rmse = rmse(tr.predict_batch(sa.CSRData.from_triples(test[0][:200000], test[1][:200000], test[2][:200000])),
-                      test[2][:200000]) if world == 1 else None
+    # held-out RMSE after the run; with N ranks every rank scores the test rows of the users it owns
+    tu, ti, tl = test[0][:200000], test[1][:200000], test[2][:200000]
+    mine = (tu % world) == rank
+    pred = tr.predict_batch(sa.CSRData.from_triples(tu[mine], ti[mine], tl[mine]))
+    sse = float(np.sum((pred.astype(np.float64) - tl[mine].astype(np.float64)) ** 2))
+    cnt = float(mine.sum())
+    if dist is not None:
+        acc = torch.tensor([sse, cnt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(acc)
+        sse, cnt = float(acc[0].item()), float(acc[1].item())
+    final_rmse = float(np.sqrt(sse / max(cnt, 1.0)))
 
     if rank == 0:
         value = a.steps * n / elapsed

@@ -186,7 +186,7 @@ Engine::Engine(TypeParam mtype, int device) : mtype_(mtype) {
         return;
     }
     // The first real HIP call initialises the ROCm runtime, which disturbs libc's rand() state (measured:
-    // tools/dbg_rand.cpp).  The reference seeds once in main() (svd_feature.cpp:293) and then relies on the
+    // tools/check_hip_init_rand.cpp).  The reference seeds once in main() (svd_feature.cpp:293) and then relies on the
     // rand() stream for rand_init and for pairwise sampling, so runtime start-up is run on a scratch PRNG
     // state and the caller's state is put back exactly (initstate/setstate save and restore the position).
     RandStateGuard keep_callers_rand_stream;
