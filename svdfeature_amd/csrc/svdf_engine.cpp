@@ -513,6 +513,7 @@ void Engine::stage_rows(int num_row, const float *row_label, const int *row_ptr,
         const int p0 = row_ptr[3 * r], p1 = row_ptr[3 * r + 1], p2 = row_ptr[3 * r + 2], p3 = row_ptr[3 * r + 3];
         check(p0 <= p1 && p1 <= p2 && p2 <= p3, "CSR row_ptr must be non-decreasing");
         check_row(p1 - p0, p2 - p1, p3 - p2, feat_index + p0);
+        check((long)staged_.row_ptr.back() + (long)(p3 - p0) < 2147483647L, "svdfeature_amd: more than 2^31-1 feature entries in one window");
         const int base = staged_.row_ptr.back() - p0;
         staged_.row_label.push_back(row_label[r]);
         staged_.row_ptr.push_back(p1 + base);
