@@ -1169,6 +1169,15 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
         FusedHost fh;
         if (fused_allowed() && fused_shape_ok(n, row_ptr, feat_index, fh)) {
             ds->kind = 2;
+            if (sort_batches_ != 0) {   // batch-internal order is free: walk the item (or user) table in id order
+                std::vector<unsigned> key((size_t)n, 0u);
+                for (long r = 0; r < n; r++) {
+                    const int64_t *p = row_ptr + 3 * r;
+                    if (sort_batches_ == 1 && p[3] > p[2]) key[(size_t)r] = feat_index[p[2]];
+                    else if (sort_batches_ == 2 && p[2] > p[1]) key[(size_t)r] = feat_index[p[1]];
+                }
+                sort_batches(ds->sched, key.data());
+            }
             fill_fused(n, row_label, row_ptr, feat_index, feat_value, ds->sched.order.data(), fh);
             ds->fused.upload(fh, stream_);
             HIPCHECK(hipStreamSynchronize(stream_));
@@ -1395,7 +1404,7 @@ int64_t Engine::counter(int what) const {
 int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "stage_window")) { check(value >= 1, "stage_window must be >= 1"); stage_window_ = value; return 0; }
     if (!strcmp(name, "groups_per_wave")) {
-        check(value == 1 || value == 2 || value == 4 || value == 8, "groups_per_wave must be 1, 2, 4 or 8");
+        check(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "groups_per_wave must be 0 (auto), 1, 2, 4 or 8");
         groups_per_wave_ = (int)value;
         return 0;
     }
@@ -1404,7 +1413,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "use_fused")) { use_fused_ = value != 0; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "block_threads")) {
-        check(value == 64 || value == 128 || value == 256, "block_threads must be 64, 128 or 256");
+        check(value == 0 || value == 64 || value == 128 || value == 256, "block_threads must be 0 (auto), 64, 128 or 256");
         block_threads_ = (int)value;
         return 0;
     }

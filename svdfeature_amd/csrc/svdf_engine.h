@@ -227,7 +227,7 @@ class Engine {
     bool unit_open_ = false;          // a START block was staged and its END has not arrived
     bool unit_open_on_device_ = false;  // ... and its first part was already flushed (state saved on device)
     long stage_window_ = 1 << 22;
-    int groups_per_wave_ = 4, block_threads_ = 128, store_mode_ = 0, sort_batches_ = 1;
+    int groups_per_wave_ = 0, block_threads_ = 0, store_mode_ = 0, sort_batches_ = 1;   // 0 = tuned per factor width
     LevelTracker tracker_;
     void stage_rows(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value);
     void check_row(int ng, int nu, int ni, const unsigned *index);

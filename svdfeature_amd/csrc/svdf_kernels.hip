@@ -956,6 +956,11 @@ static void launch_basicmf_lpi(const DevParams &P, const BasicSchedule &S, long 
 
 void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long end, int groups_per_wave, int block_threads, hipStream_t st) {
     if (end <= begin) return;
+    // 0 = tuned default (tools/sweep_knobs.py on MI355X): k=64 (16 lanes per row) wants 4 row sets in flight per
+    // wave and 128-thread blocks; every other width measured best with 1 row set per wave and 256-thread blocks
+    const int lpi_ = lanes_per_instance(P.k);
+    if (groups_per_wave <= 0) groups_per_wave = lpi_ == 16 ? 4 : 1;
+    if (block_threads <= 0) block_threads = lpi_ == 16 ? 128 : 256;
     SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_basicmf_lpi<LPI>(P, S, begin, end, groups_per_wave, block_threads, st));
 }
 template <int LPI, int NU, int NI>
@@ -979,6 +984,9 @@ static void launch_fused_lpi(const DevParams &P, const FusedSchedule &S, int nu,
 void launch_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int groups_per_wave,
                   int block_threads, hipStream_t st) {
     if (end <= begin) return;
+    const int lpi_ = lanes_per_instance(P.k);
+    if (groups_per_wave <= 0) groups_per_wave = lpi_ == 16 ? 2 : 1;
+    if (block_threads <= 0) block_threads = lpi_ == 16 ? 128 : 256;
     SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_fused_lpi<LPI>(P, S, max_nu, max_ni, begin, end, groups_per_wave, block_threads, st));
 }
 template <int LPI>
