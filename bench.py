@@ -141,7 +141,10 @@ def main():
     ap.add_argument("--users", type=int, default=1_000_000)
     ap.add_argument("--items", type=int, default=100_000)
     ap.add_argument("--factor", type=int, default=64)
-    ap.add_argument("--windows", type=int, default=16, help="item-delta exchanges per pass when --gpus > 1")
+    ap.add_argument("--windows", type=int, default=0,
+                    help="item-delta exchanges per pass when --gpus > 1 (0 = chosen from the data density so that the "
+                         "RMSE stays within 1e-4 of the sequential reference: about 64 ratings per item per window at "
+                         "2 ranks, 32 at 4+ ranks; calibration in DESIGN.md section 6)")
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--groups-per-wave", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -195,6 +198,9 @@ def main():
     # ---- schedule the instance stream once and keep it in HBM
     t0 = time.time()
     adaptor = HipShard(tr, torch, torch.device("cuda", local_rank))
+    if a.windows <= 0:
+        per_item = a.ratings / max(a.items, 1)
+        a.windows = max(1, int(np.ceil(per_item / (64.0 if world <= 2 else 32.0))))
     nwin = 1 if (world == 1 and not a.force_exchange) else a.windows
     wins = adaptor.make_windows(shard_windows(u, i, r, rank, world, nwin))
     sched_s = time.time() - t0
