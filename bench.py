@@ -145,6 +145,8 @@ def main():
                     help="item-delta exchanges per pass when --gpus > 1 (0 = chosen from the data density so that the "
                          "RMSE stays within 1e-4 of the sequential reference: about 64 ratings per item per window at "
                          "2 ranks, 32 at 4+ ranks; calibration in DESIGN.md section 6)")
+    ap.add_argument("--delta-dtype", choices=["fp16", "fp32"], default="fp16",
+                    help="wire format of the item-side window deltas when --gpus > 1 (parameters stay fp32)")
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--groups-per-wave", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -209,7 +211,7 @@ def main():
     my_n = sum(w.num_row for w in wins)
     log("scheduled %d instances into %d conflict-free batches (largest %d) in %.1fs"
         % (my_n, n_batches, max(w.max_batch for w in wins), sched_s))
-    st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange)
+    st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange, half_delta=(a.delta_dtype == "fp16"))
 
     def sync_all():
         tr.synchronize()
@@ -273,7 +275,7 @@ def main():
             "config": {"workload": "basicMF synthetic %dx%d, %d ratings, k=%d fp32 (BASELINE configs[%d])"
                                    % (a.users, a.items, n, a.factor, 1 if world == 1 else 2),
                        "order": "uniform random (file order preserved: result == sequential SGD)" if world == 1 else
-                                "user-sharded, item-delta all-reduce every 1/%d pass" % nwin,
+                                "user-sharded, item-delta all-reduce (%s on the wire) every 1/%d pass" % (a.delta_dtype, nwin),
                        "conflict_free_batches_per_pass": n_batches, "schedule_build_s": round(sched_s, 2),
                        "parallelism": "1 GPU" if world == 1 else "dp%d user shards + RCCL all-reduce" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -306,6 +306,15 @@ def test_sharded_trainer_world_one_with_nccl_process_group():
         a.all_reduce(dist, d)
         a.delta_set(d)
         np.testing.assert_array_equal(t.view("W_item"), w0 + (w1 - w0))
+        # fp16 wire format: same protocol, deltas rounded to half precision
+        w2 = t.view("W_item").copy()
+        a.delta_begin()
+        a.train(ds)
+        w3 = t.view("W_item").copy()
+        d = a.delta_get()
+        a.all_reduce(dist, d, half=True)
+        a.delta_set(d)
+        np.testing.assert_array_equal(t.view("W_item"), w2 + (w3 - w2).astype(np.float16).astype(np.float32))
     finally:
         dist.destroy_process_group()
 

@@ -103,3 +103,31 @@ def test_rmse_contract_of_the_exchange(world, windows):
     ref = cases.rmse(merged_predict(simulate(conf, u, i, r, 1, 1, 5), 1, tu, ti, tr), tr)
     got = cases.rmse(merged_predict(simulate(conf, u, i, r, world, windows, 5), world, tu, ti, tr), tr)
     assert abs(got - ref) <= 1e-4
+
+
+def test_fp16_wire_format_keeps_the_rmse_contract():
+    """ShardedTrainer(half_delta=True) semantics (deltas rounded to fp16, summed in fp16 like RCCL does) in the
+    single-process simulation: still within 1e-4 of the sequential reference."""
+    from svdfeature_amd.multi_gpu import shard_windows as sw
+    nu, ni, n = 20000, 2000, 1_000_000
+    u, i, r = cases.planted_triples(n + 100_000, nu, ni, seed=5)
+    tu, ti, tr = u[n:], i[n:], r[n:]
+    u, i, r = u[:n], i[:n], r[:n]
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=16)
+    world, windows, passes = 8, 16, 5
+    ranks = [OracleShard(make_oracle(conf)) for _ in range(world)]
+    wins = [a.make_windows(sw(u, i, r, rk, world, windows)) for rk, a in enumerate(ranks)]
+    for _ in range(passes):
+        for w in range(windows):
+            for rk, a in enumerate(ranks):
+                a.delta_begin()
+                a.train(wins[rk][w])
+            total = None
+            for a in ranks:
+                d = a.delta_get().astype(np.float16)
+                total = d if total is None else (total + d).astype(np.float16)
+            for a in ranks:
+                a.delta_set(total.astype(np.float32))
+    ref = cases.rmse(merged_predict(simulate(conf, u, i, r, 1, 1, passes), 1, tu, ti, tr), tr)
+    got = cases.rmse(merged_predict(ranks, world, tu, ti, tr), tr)
+    assert abs(got - ref) <= 1e-4
