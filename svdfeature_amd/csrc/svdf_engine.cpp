@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "svdf_kernels.h"
@@ -218,6 +219,11 @@ Engine::~Engine() {
                 ns_flush_ * 1e-9, ns_model_ * 1e-9, (long)n_instances_, (long)n_flushes_);
     if (!host_only_ && stream_) {
         try { flush(); } catch (...) {}
+        if (worker_.joinable()) {
+            { std::lock_guard<std::mutex> g(mu_); worker_stop_ = true; }
+            cv_.notify_all();
+            worker_.join();
+        }
         (void)hipStreamSynchronize(stream_);
         if (owns_stream_) (void)hipStreamDestroy(stream_);
     }
@@ -538,7 +544,7 @@ void Engine::update_csr(float label, int ng, int nu, int ni, const unsigned *ind
         staged_.row_ptr.push_back(b + ng + nu);
         staged_.row_ptr.push_back(b + nv);
         for (int j = 0; j < nv; j++) { staged_.feat_index.push_back(index[j]); staged_.feat_value.push_back(value[j]); }
-        if (staged_.num_row() >= stage_window_) flush();
+        if (staged_.num_row() >= stage_window_) submit_window();
         return;
     }
     const int ptr[4] = {0, ng, ng + nu, ng + nu + ni};
@@ -560,7 +566,7 @@ void Engine::update_csr_batch(int num_row, const float *row_label, const int *ro
     } else {
         stage_rows(num_row, row_label, row_ptr, feat_index, feat_value);
     }
-    if (staged_.num_row() >= stage_window_) flush();
+    if (staged_.num_row() >= stage_window_) submit_window();
 }
 
 void Engine::update_block(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label,
@@ -693,13 +699,62 @@ static void parallel_gather(T *dst, const T *src, const int *order, long n, long
 // =============================================================================== flush
 void Engine::flush() {
     if (host_only_ || !trainer_ready_) return;
+    wait_worker();   // a window handed to the background thread earlier must land first
     ScopedNs timer(ns_flush_);
     if (user_group()) flush_units();
-    else flush_csr();
+    else flush_csr(staged_);
 }
 
-void Engine::flush_csr() {
-    const long n = staged_.num_row();
+// ---- background window flush -----------------------------------------------------------------------
+// While the caller keeps staging instances of window w+1 (the reference's CLI hands them over one virtual
+// call at a time), a worker thread schedules, uploads and launches window w.  Windows are processed
+// strictly in order on one HIP stream; every synchronisation point goes through flush(), which first
+// waits for the worker, so the observable semantics are those of the synchronous path.
+void Engine::wait_worker() {
+    if (!worker_.joinable()) return;
+    std::unique_lock<std::mutex> lk(mu_);
+    cv_.wait(lk, [&] { return !worker_busy_; });
+    if (!worker_error_.empty()) {
+        std::string m;
+        m.swap(worker_error_);
+        lk.unlock();
+        fail(m);
+    }
+}
+void Engine::worker_main() {
+    (void)hipSetDevice(device_);
+    std::unique_lock<std::mutex> lk(mu_);
+    for (;;) {
+        cv_.wait(lk, [&] { return worker_busy_ || worker_stop_; });
+        if (worker_stop_) return;
+        lk.unlock();
+        try {
+            ScopedNs timer(ns_flush_);
+            flush_csr(job_);
+        } catch (const std::exception &ex) {
+            std::lock_guard<std::mutex> g(mu_);
+            worker_error_ = ex.what();
+        }
+        job_.clear();
+        lk.lock();
+        worker_busy_ = false;
+        cv_.notify_all();
+    }
+}
+void Engine::submit_window() {
+    if (!async_flush_ || user_group()) { flush(); return; }
+    if (!worker_.joinable()) worker_ = std::thread([this] { worker_main(); });
+    wait_worker();
+    {
+        std::lock_guard<std::mutex> g(mu_);
+        std::swap(job_, staged_);   // job_ was cleared by the worker; staged_ starts empty again
+        worker_busy_ = true;
+    }
+    cv_.notify_all();
+}
+
+void Engine::flush_csr(HostCSR &src) {
+    const long n = src.num_row();
     if (n == 0) return;
     need_device("update");
     const DevParams &P = params();
@@ -709,14 +764,14 @@ void Engine::flush_csr() {
     bool basic = basic_fast_path_allowed();
     if (basic) {
         for (long r = 0; r < n && basic; r++) {
-            const int *p = &staged_.row_ptr[(size_t)3 * r];
+            const int *p = &src.row_ptr[(size_t)3 * r];
             basic = (p[1] == p[0]) && (p[2] == p[1] + 1) && (p[3] == p[2] + 1);
         }
     }
     int *last = tracker_.last.data();
     for (long r = 0; r < n; r++) {
-        const int *p = &staged_.row_ptr[(size_t)3 * r];
-        const unsigned *idx = staged_.feat_index.data();
+        const int *p = &src.row_ptr[(size_t)3 * r];
+        const unsigned *idx = src.feat_index.data();
         int lvl = level_of_row(idx + p[0], p[1] - p[0], idx + p[1], p[2] - p[1], idx + p[2], p[3] - p[2], base) + 1;
         touch_row(idx + p[0], p[1] - p[0], idx + p[1], p[2] - p[1], idx + p[2], p[3] - p[2], lvl);
         levels[(size_t)r] = lvl;
@@ -731,11 +786,11 @@ void Engine::flush_csr() {
         bool unit = true;
         for (long s = 0; s < n; s++) {
             const long r = sched.order[(size_t)s];
-            su[(size_t)s] = staged_.feat_index[(size_t)2 * r];
-            si[(size_t)s] = staged_.feat_index[(size_t)2 * r + 1];
-            sl[(size_t)s] = staged_.row_label[(size_t)r];
-            sua[(size_t)s] = staged_.feat_value[(size_t)2 * r];
-            sia[(size_t)s] = staged_.feat_value[(size_t)2 * r + 1];
+            su[(size_t)s] = src.feat_index[(size_t)2 * r];
+            si[(size_t)s] = src.feat_index[(size_t)2 * r + 1];
+            sl[(size_t)s] = src.row_label[(size_t)r];
+            sua[(size_t)s] = src.feat_value[(size_t)2 * r];
+            sia[(size_t)s] = src.feat_value[(size_t)2 * r + 1];
             unit = unit && sua[(size_t)s] == 1.0f && sia[(size_t)s] == 1.0f;
         }
         w_user_.upload(su.data(), (size_t)n, stream_);
@@ -752,8 +807,8 @@ void Engine::flush_csr() {
             launch_basicmf(P, S, sched.level_ptr[l], sched.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
             n_launches_++; n_kind_[0]++;
         }
-    } else if (fused_allowed() && fused_shape_ok(n, staged_.row_ptr.data(), staged_.feat_index.data(), w_fused_host_)) {
-        fill_fused(n, staged_.row_label.data(), staged_.row_ptr.data(), staged_.feat_index.data(), staged_.feat_value.data(),
+    } else if (fused_allowed() && fused_shape_ok(n, src.row_ptr.data(), src.feat_index.data(), w_fused_host_)) {
+        fill_fused(n, src.row_label.data(), src.row_ptr.data(), src.feat_index.data(), src.feat_value.data(),
                    sched.order.data(), w_fused_host_);
         w_fused_.upload(w_fused_host_, stream_);
         HIPCHECK(hipStreamSynchronize(stream_));
@@ -763,10 +818,10 @@ void Engine::flush_csr() {
             n_launches_++; n_kind_[2]++;
         }
     } else {
-        w_label_.upload(staged_.row_label.data(), (size_t)n, stream_);
-        w_ptr_.upload(staged_.row_ptr.data(), staged_.row_ptr.size(), stream_);
-        w_index_.upload(staged_.feat_index.data(), staged_.feat_index.size(), stream_);
-        w_value_.upload(staged_.feat_value.data(), staged_.feat_value.size(), stream_);
+        w_label_.upload(src.row_label.data(), (size_t)n, stream_);
+        w_ptr_.upload(src.row_ptr.data(), src.row_ptr.size(), stream_);
+        w_index_.upload(src.feat_index.data(), src.feat_index.size(), stream_);
+        w_value_.upload(src.feat_value.data(), src.feat_value.size(), stream_);
         w_order_.upload(sched.order.data(), (size_t)n, stream_);
         HIPCHECK(hipStreamSynchronize(stream_));
         DevCSR D{w_label_.p, w_ptr_.p, w_index_.p, w_value_.p};
@@ -779,7 +834,7 @@ void Engine::flush_csr() {
     n_batches_ += (int64_t)sched.num_levels();
     n_instances_ += n;
     n_flushes_++;
-    staged_.clear();
+    src.clear();
 }
 
 // ---- few-row fused path -------------------------------------------------------------------------
@@ -1410,6 +1465,7 @@ int Engine::set_knob(const char *name, long value) {
     }
     if (!strcmp(name, "store_mode")) { check(value >= 0 && value <= 2, "store_mode must be 0, 1 or 2"); store_mode_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "sort_batches")) { check(value >= 0 && value <= 2, "sort_batches must be 0, 1 (by item) or 2 (by user)"); sort_batches_ = (int)value; return 0; }
+    if (!strcmp(name, "async_flush")) { flush(); async_flush_ = value != 0; return 0; }
     if (!strcmp(name, "use_fused")) { use_fused_ = value != 0; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "block_threads")) {

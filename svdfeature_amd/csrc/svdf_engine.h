@@ -11,8 +11,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdio>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -243,8 +246,18 @@ class Engine {
     // per-unit level assignment
     int level_of_row(const unsigned *ig, int ng, const unsigned *iu, int nu, const unsigned *ii, int ni, int lvl0);
     void touch_row(const unsigned *ig, int ng, const unsigned *iu, int nu, const unsigned *ii, int ni, int lvl);
-    void flush_csr();
+    void flush_csr(HostCSR &src);
     void flush_units();
+    // background flush of full windows (random-order trainers only)
+    void submit_window();
+    void wait_worker();
+    void worker_main();
+    std::thread worker_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    HostCSR job_;
+    bool worker_busy_ = false, worker_stop_ = false, async_flush_ = true;
+    std::string worker_error_;
     // levels + DevUnit records for the staged units (marks UNIT_SIMPLE); returns the schedule
     void schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du);
     void upload_units(UnitDev &dst, const Schedule &sched, const std::vector<DevUnit> &du);
