@@ -88,12 +88,36 @@ __device__ __forceinline__ float group_dot(const float4 a, const float4 b, int L
     // lanes beyond the full chunks feed +0 so the running sums just travel on to the last lane
     float c0 = full ? m0 : 0.0f, c1 = full ? m1 : 0.0f, c2 = full ? m2 : 0.0f, c3 = full ? m3 : 0.0f;
     float a0 = 0.0f + c0, a1 = 0.0f + c1, a2 = 0.0f + c2, a3 = 0.0f + c3;
+    if constexpr (LPI <= 16 || LPI == 64) {   // 64: wave_shr:1 needs no select (lane 0 reads 0), measured faster than row scans
 #pragma unroll
-    for (int s = 1; s < LPI; s++) {
-        a0 = prev_lane<LPI>(a0, L) + c0;
-        a1 = prev_lane<LPI>(a1, L) + c1;
-        a2 = prev_lane<LPI>(a2, L) + c2;
-        a3 = prev_lane<LPI>(a3, L) + c3;
+        for (int s = 1; s < LPI; s++) {
+            a0 = prev_lane<LPI>(a0, L) + c0;
+            a1 = prev_lane<LPI>(a1, L) + c1;
+            a2 = prev_lane<LPI>(a2, L) + c2;
+            a3 = prev_lane<LPI>(a3, L) + c3;
+        }
+    } else {
+        // LPI == 32, two 16-lane DPP rows per group: scan one row at a time with the cheap fused
+        // v_add_f32_dpp row_shr:1 (a row's first lane reads 0), and carry the finished sum of row r-1 into
+        // row r by FOLDING it into the addend of that row's first lane: a[16r] = 0 + (carry + c[16r]).
+        // Same additions in the same order as the chain a[m] = a[m-1] + c[m]; no per-step select
+        // (measured 23 ns per step with wave_shr + select vs 8 ns per step for a plain row_shr add).
+#pragma unroll
+        for (int s = 1; s < 16; s++) {
+            a0 = prev_lane<16>(a0, L) + c0; a1 = prev_lane<16>(a1, L) + c1;
+            a2 = prev_lane<16>(a2, L) + c2; a3 = prev_lane<16>(a3, L) + c3;
+        }
+#pragma unroll
+        for (int r = 1; r < LPI / 16; r++) {
+            const float s0 = group_bcast<LPI>(a0, 16 * r - 1), s1 = group_bcast<LPI>(a1, 16 * r - 1);
+            const float s2 = group_bcast<LPI>(a2, 16 * r - 1), s3 = group_bcast<LPI>(a3, 16 * r - 1);
+            if (L == 16 * r) { c0 = s0 + c0; c1 = s1 + c1; c2 = s2 + c2; c3 = s3 + c3; }
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                a0 = prev_lane<16>(a0, L) + c0; a1 = prev_lane<16>(a1, L) + c1;
+                a2 = prev_lane<16>(a2, L) + c2; a3 = prev_lane<16>(a3, L) + c3;
+            }
+        }
     }
     float h = (a0 + a2) + (a1 + a3);  // sum_all: movehl add, then shuffle add_ss
     float sum = group_bcast<LPI>(h, LPI - 1);

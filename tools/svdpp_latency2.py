@@ -5,8 +5,8 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import svdfeature_amd as sa
 from svdfeature_amd.data import CSRData, PlusBlock
-for K in (64, 128):
-    for rows, nfb in ((100, 100), (100, 1), (1, 100), (400, 1), (1, 400), (1, 1)):
+for K in (16, 32, 64, 128, 256):
+    for rows, nfb in ((400, 1), (1, 400)):
         ni = max(rows, nfb) + 8
         t = sa.Trainer(1, 0)
         t.seed(10)
