@@ -114,6 +114,12 @@ svdf_dataset *svdf_dataset_from_blocks(svdf_trainer *t, long num_block, const in
                                        const unsigned *fb_index, const float *fb_value, const int64_t *block_row_ptr,
                                        const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
                                        const float *feat_value);
+/* The same, straight from the reference's binary buffer files: user_group_format 0 = the CSR buffer written by
+ * tools/make_feature_buffer (SVDFeatureCSRFactory::create_buffer, apex_svd_data.cpp:118-195; block layout
+ * apex_svd_data.h:200-230), 1 = the user-group buffer written by tools/make_ugroup_buffer (SVDPlusBlock
+ * save/load, apex_svd_data.h:419-450; apex_svd_data.cpp:558-595).  Replaces the loader thread + one virtual
+ * update() per instance of svd_feature.cpp:220-248 for callers that train whole passes. */
+svdf_dataset *svdf_dataset_from_buffer_file(svdf_trainer *t, const char *path, int user_group_format);
 void svdf_dataset_destroy(svdf_dataset *ds);
 int svdf_train_dataset(svdf_trainer *t, svdf_dataset *ds);       /* one pass, asynchronous on the trainer's stream */
 int svdf_predict_dataset(svdf_trainer *t, svdf_dataset *ds, float *out); /* out[num_row], file order */

@@ -78,6 +78,8 @@ def load_library():
     lib.svdf_dataset_from_csr.argtypes = [P, C.c_long, _f32p, _i64p, _u32p, _f32p]
     lib.svdf_dataset_from_triples.restype = P
     lib.svdf_dataset_from_triples.argtypes = [P, C.c_long, _u32p, _u32p, _f32p]
+    lib.svdf_dataset_from_buffer_file.restype = P
+    lib.svdf_dataset_from_buffer_file.argtypes = [P, C.c_char_p, C.c_int]
     lib.svdf_dataset_from_blocks.restype = P
     lib.svdf_dataset_from_blocks.argtypes = [P, C.c_long, _i32p, _i64p, _u32p, _f32p, _i64p, _f32p, _i64p, _u32p, _f32p]
     lib.svdf_dataset_destroy.argtypes = [P]
@@ -289,6 +291,13 @@ class Trainer:
         h = self.lib.svdf_dataset_from_blocks(self.h, len(blocks), _pad(tags, np.int32), fb_ptr, _pad(fbi, np.uint32), _pad(fbv, np.float32),
                                               brp, _pad(cat.row_label, np.float32), _pad(cat.row_ptr, np.int64), _pad(cat.feat_index, np.uint32),
                                               _pad(cat.feat_value, np.float32))
+        if not h:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return Dataset(self, h)
+
+    def dataset_from_buffer_file(self, path, user_group=False):
+        """Resident dataset straight from a reference buffer file (make_feature_buffer / make_ugroup_buffer output)."""
+        h = self.lib.svdf_dataset_from_buffer_file(self.h, str(path).encode(), 1 if user_group else 0)
         if not h:
             raise SvdfError(self.lib.svdf_last_error().decode())
         return Dataset(self, h)

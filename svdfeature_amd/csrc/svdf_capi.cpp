@@ -112,6 +112,14 @@ svdf_dataset *svdf_dataset_from_blocks(svdf_trainer *t, long num_block, const in
         return h;
     })
 }
+svdf_dataset *svdf_dataset_from_buffer_file(svdf_trainer *t, const char *path, int user_group_format) {
+    SVDF_GUARD(nullptr, {
+        svdf::Dataset *d = t->e->dataset_from_buffer_file(path, user_group_format);
+        svdf_dataset *h = new svdf_dataset();
+        h->d = d;
+        return h;
+    })
+}
 void svdf_dataset_destroy(svdf_dataset *ds) {
     if (!ds) return;
     try { if (ds->d && ds->d->owner) ds->d->owner->synchronize(); } catch (...) {}

@@ -477,6 +477,7 @@ const DevParams &Engine::params() {
     P.active_type = mtype_.active_type; P.no_user_bias = mp_.no_user_bias; P.user_nonnegative = mp_.user_nonnegative;
     P.user_group = user_group() ? 1 : 0;
     P.store_mode = store_mode_;
+    P.xcd_remap = xcd_remap_;
     P.lr = tp_.learning_rate; P.wd_user = tp_.wd_user; P.wd_item = tp_.wd_item;
     P.wd_user_bias = tp_.wd_user_bias; P.wd_item_bias = tp_.wd_item_bias; P.wd_global = tp_.wd_global;
     P.reg_method = tp_.reg_method; P.reg_global = tp_.reg_global; P.num_regfree_global = tp_.num_regfree_global;
@@ -1463,6 +1464,7 @@ int Engine::set_knob(const char *name, long value) {
         groups_per_wave_ = (int)value;
         return 0;
     }
+    if (!strcmp(name, "xcd_remap")) { xcd_remap_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "store_mode")) { check(value >= 0 && value <= 2, "store_mode must be 0, 1 or 2"); store_mode_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "sort_batches")) { check(value >= 0 && value <= 2, "sort_batches must be 0, 1 (by item) or 2 (by user)"); sort_batches_ = (int)value; return 0; }
     if (!strcmp(name, "async_flush")) { flush(); async_flush_ = value != 0; return 0; }

@@ -161,6 +161,8 @@ class Engine {
     Dataset *dataset_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
                                  const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
                                  const float *feat_value);
+    // the reference's binary buffer files, read natively (svdf_buffer.cpp): CSR buffer or user-group buffer
+    Dataset *dataset_from_buffer_file(const char *path, int user_group_format);
     void train_dataset(Dataset *ds);
     void predict_dataset(Dataset *ds, float *out);
 
@@ -230,7 +232,7 @@ class Engine {
     bool unit_open_ = false;          // a START block was staged and its END has not arrived
     bool unit_open_on_device_ = false;  // ... and its first part was already flushed (state saved on device)
     long stage_window_ = 1 << 22;
-    int groups_per_wave_ = 0, block_threads_ = 0, store_mode_ = 0, sort_batches_ = 1;   // 0 = tuned per factor width
+    int groups_per_wave_ = 0, block_threads_ = 0, store_mode_ = 0, sort_batches_ = 1, xcd_remap_ = 1;   // 0 = tuned per factor width
     LevelTracker tracker_;
     void stage_rows(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value);
     void check_row(int ng, int nu, int ni, const unsigned *index);

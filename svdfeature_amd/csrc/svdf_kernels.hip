@@ -236,7 +236,12 @@ __global__ __launch_bounds__(256) void k_basicmf(const DevParams P, const BasicS
     const int lane = threadIdx.x & 63;
     const int L = lane & (LPI - 1);
     const int gslot = lane / LPI;
-    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    // Hardware deals workgroups to the 8 XCDs round-robin (blockIdx % 8).  With xcd_remap the grid is a multiple
+    // of 8 and XCD x works on the x-th contiguous eighth of the batch, so (the batch being sorted by item id)
+    // neighbouring item rows / bias sectors meet in ONE XCD's L2 instead of eight.
+    long tile = blockIdx.x;
+    if (P.xcd_remap) tile = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long wave = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long w0 = begin + wave * (long)(G * IPW);
     const int k = P.k, pitch = P.pitch;
     const bool use_ubias = P.no_user_bias == 0;
@@ -321,7 +326,9 @@ __global__ __launch_bounds__(256) void k_fused(const DevParams P, const FusedSch
     const int lane = threadIdx.x & 63;
     const int L = lane & (LPI - 1);
     const int gslot = lane / LPI;
-    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    long tile = blockIdx.x;   // XCD-aware tile mapping, see k_basicmf
+    if (P.xcd_remap) tile = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long wave = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long w0 = begin + wave * (long)(G * IPW);
     const int k = P.k, pitch = P.pitch;
     const bool use_ubias = P.no_user_bias == 0;
@@ -955,7 +962,8 @@ static void launch_basicmf_lpi(const DevParams &P, const BasicSchedule &S, long 
     auto go = [&](auto gtag) {
         constexpr int GG = decltype(gtag)::value;
         const long per_block = (long)(block_threads / 64) * GG * (64 / LPI);
-        const int grid = (int)((n + per_block - 1) / per_block);
+        int grid = (int)((n + per_block - 1) / per_block);
+        if (P.xcd_remap) grid = (grid + 7) & ~7;
         if (unit) hipLaunchKernelGGL((k_basicmf<LPI, GG, true>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
         else hipLaunchKernelGGL((k_basicmf<LPI, GG, false>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
     };
@@ -992,10 +1000,14 @@ static void launch_fused_shape(const DevParams &P, const FusedSchedule &S, long 
     const long n = end - begin;
     if (G >= 2 && NU + NI <= 3) {
         const long per_block = (long)(block_threads / 64) * 2 * (64 / LPI);
-        hipLaunchKernelGGL((k_fused<LPI, NU, NI, 2>), dim3((int)((n + per_block - 1) / per_block)), dim3(block_threads), 0, st, P, S, begin, end);
+        int grid = (int)((n + per_block - 1) / per_block);
+        if (P.xcd_remap) grid = (grid + 7) & ~7;
+        hipLaunchKernelGGL((k_fused<LPI, NU, NI, 2>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
     } else {
         const long per_block = (long)(block_threads / 64) * (64 / LPI);
-        hipLaunchKernelGGL((k_fused<LPI, NU, NI, 1>), dim3((int)((n + per_block - 1) / per_block)), dim3(block_threads), 0, st, P, S, begin, end);
+        int grid = (int)((n + per_block - 1) / per_block);
+        if (P.xcd_remap) grid = (grid + 7) & ~7;
+        hipLaunchKernelGGL((k_fused<LPI, NU, NI, 1>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
     }
 }
 template <int LPI>

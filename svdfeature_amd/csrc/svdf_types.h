@@ -75,6 +75,7 @@ struct DevParams {
     int num_user, num_item, num_global, num_ufeedback;
     float base_score;
     int active_type, no_user_bias, user_nonnegative, user_group;
+    int xcd_remap;            // 1: consecutive tiles of a batch go to the same XCD (blockIdx%8), see k_basicmf
     int store_mode;           // row-store cache policy of k_basicmf: 0 plain, 1 nontemporal, 2 sc1 write-through
     // SVDTrainParam
     float lr, wd_user, wd_item, wd_user_bias, wd_item_bias, wd_global;

@@ -490,3 +490,104 @@ def test_full_size_properties_100m_ratings():
     c.train_dataset(dc)
     assert np.array_equal(a.view("W_item").view(np.uint32), c.view("W_item").view(np.uint32))
     assert np.array_equal(a.view("W_user").view(np.uint32), c.view("W_user").view(np.uint32))
+
+
+def _ready(mk, fmt, conf, seed=21):
+    t = mk(fmt, 0)
+    t.seed(seed)
+    for kk, v in conf:
+        t.set_param(kk, v)
+    t.init_model()
+    t.init_trainer()
+    return t
+
+
+def test_buffer_file_datasets_csr(tmp_path):
+    """svdf_dataset_from_buffer_file on CSR buffers: ML-100K in the reference's 1000-row batches
+    (basicMF kernel), sparse multi-feature rows in ragged 7-row batches (general kernel), and the buffer bytes
+    the reference's own tool wrote (tests/golden/fixtures/ua.base.buffer): same parameters, bit for bit, as
+    the oracle fed instance by instance."""
+    tr, _ = cases.ml100k()
+    p1 = str(tmp_path / "ua.base.buffer")
+    sa.data.write_csr_buffer(p1, tr, 1000)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_factor=64)
+    o, t = _ready(port, 0, conf), _ready(hip, 0, conf)
+    ds = t.dataset_from_buffer_file(p1)
+    assert ds.num_row == tr.num_row and ds.kind == 0
+    for _ in range(2):
+        o.update_batch(tr)
+        t.train_dataset(ds)
+    for name in ("W_user", "W_item", "u_bias", "i_bias"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+
+    nu, ni, ng = 300, 200, 50
+    rows = cases.sparse_feature_rows(5000, nu, ni, ng, seed=3)
+    p2 = str(tmp_path / "sparse.buffer")
+    sa.data.write_csr_buffer(p2, rows, 7)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=10, wd_global=0.001)
+    o, t = _ready(port, 0, conf), _ready(hip, 0, conf)
+    ds = t.dataset_from_buffer_file(p2)
+    assert ds.num_row == rows.num_row and ds.kind in (1, 2)
+    o.update_batch(rows)
+    t.train_dataset(ds)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "g_bias"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+    np.testing.assert_array_equal(t.predict_dataset(ds).view(np.uint32), o.predict_batch(rows).view(np.uint32))
+
+    fx = os.path.join(cases.GOLDEN, "fixtures", "ua.base.buffer")
+    want = sa.data.read_csr_buffer(fx)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_factor=8)
+    o, t = _ready(port, 0, conf), _ready(hip, 0, conf)
+    ds = t.dataset_from_buffer_file(fx)
+    assert ds.num_row == want.num_row > 0
+    o.update_batch(want)
+    t.train_dataset(ds)
+    np.testing.assert_array_equal(t.view("W_item").view(np.uint32), o.view("W_item").view(np.uint32))
+
+
+def test_buffer_file_datasets_user_group(tmp_path):
+    """User-group buffer (make_ugroup_buffer format, incl. START/MIDDLE/END split users whose blocks carry the
+    bit-31 tag word): native reader + SVD++ unit schedule == oracle update(block) in file order."""
+    nu, ni = 400, 300
+    blocks = cases.user_blocks(250, nu, ni, ni, seed=8, max_rows=30, max_fb=20, split_every=5)
+    path = str(tmp_path / "ug.buffer")
+    sa.data.write_ugroup_buffer(path, blocks)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=32, num_ufeedback=ni, wd_ufeedback=0.004,
+                           ufeedback_init_sigma=0.01, learning_rate=0.01)
+    o, t = _ready(port, 1, conf), _ready(hip, 1, conf)
+    ds = t.dataset_from_buffer_file(path, user_group=True)
+    assert ds.kind == 3 and ds.num_row == sum(b.data.num_row for b in blocks)
+    for _ in range(2):
+        for b in blocks:
+            o.update_block(b)
+        t.train_dataset(ds)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "W_ufeedback"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+
+
+def test_buffer_file_errors(tmp_path):
+    conf = cases.conf_with(cases.BASICMF_CONF, num_factor=8)
+    t = _ready(hip, 0, conf)
+    with pytest.raises(sa.SvdfError, match="can not open"):
+        t.dataset_from_buffer_file(str(tmp_path / "missing.buffer"))
+    tr, _ = cases.ml100k()
+    good = str(tmp_path / "good.buffer")
+    sa.data.write_csr_buffer(good, tr.slice_rows(0, 2500), 1000)
+    raw = open(good, "rb").read()
+    cut = str(tmp_path / "cut.buffer")
+    open(cut, "wb").write(raw[: len(raw) - 10])
+    with pytest.raises(sa.SvdfError, match="truncated"):
+        t.dataset_from_buffer_file(cut)
+    empty = str(tmp_path / "empty.buffer")
+    np.array([0, 1000, 0], np.int32).tofile(empty)
+    ds = t.dataset_from_buffer_file(empty)
+    assert ds.num_row == 0
+    t.train_dataset(ds)
+    # an index beyond num_user is the reference's bound error, raised when the buffer is scheduled
+    bad = bytearray(raw)
+    first_index = 12 + 8 + 4 * (3 * 1000 + 1) + 4 * 1000
+    bad[first_index:first_index + 4] = np.array([10 ** 6], np.uint32).tobytes()
+    badp = str(tmp_path / "bad.buffer")
+    open(badp, "wb").write(bytes(bad))
+    with pytest.raises(sa.SvdfError, match="user feature index exceed bound"):
+        t.dataset_from_buffer_file(badp)

@@ -188,3 +188,24 @@ def test_scheduler_edge_cases():
     # no instance shares anything: a single batch
     order, level_ptr = sa.schedule_resources(np.arange(n + 1, dtype=np.int64), np.arange(n, dtype=np.uint32), n)
     assert list(level_ptr) == [0, n]
+
+
+def test_buffer_file_reader_rejects_bad_files_before_touching_a_device(tmp_path):
+    """svdf_dataset_from_buffer_file parses on the host first: missing / truncated files are reported with a
+    host-only handle too (the parsed stream then needs a GPU: 'no silent fallback')."""
+    t = sa.Trainer(0, 0, device=-2)
+    for k, v in cases.conf_with(cases.BASICMF_CONF, num_factor=4):
+        t.set_param(k, v)
+    t.init_model()
+    t.init_trainer()
+    with pytest.raises(sa.SvdfError, match="can not open"):
+        t.dataset_from_buffer_file(str(tmp_path / "nope.buffer"))
+    tr, _ = cases.ml100k()
+    good = str(tmp_path / "good.buffer")
+    sa.data.write_csr_buffer(good, tr.slice_rows(0, 1500), 1000)
+    raw = open(good, "rb").read()
+    open(str(tmp_path / "cut.buffer"), "wb").write(raw[:-3])
+    with pytest.raises(sa.SvdfError, match="truncated"):
+        t.dataset_from_buffer_file(str(tmp_path / "cut.buffer"))
+    with pytest.raises(sa.SvdfError):   # well-formed file, but this handle has no device to put it on
+        t.dataset_from_buffer_file(good)
