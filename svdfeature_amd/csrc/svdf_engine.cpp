@@ -436,16 +436,16 @@ void Engine::init_trainer() {  // apex_svd_base.h:151-173, 499-503
     // the reference indexes children unchecked; validate once here instead
     for (unsigned c : feat_user_.index) check(c < (unsigned)mp_.num_user, "feature_user: child index exceed bound");
     for (unsigned c : feat_item_.index) check(c < (unsigned)mp_.num_item, "feature_item: child index exceed bound");
-    if (tp_.reg_method >= 4 || tp_.reg_global >= 4)
-        fail("svdfeature_amd: lazy decay (reg_method/reg_global >= 4) is not supported (see DESIGN.md, out of scope)");
-    check(tp_.reg_method >= 0 && tp_.reg_method <= 3, "unknown reg_method");
-    check(tp_.reg_global == 0 || tp_.reg_global == 1, "unknown global decay method");
+    check(tp_.reg_method >= 0 && tp_.reg_method <= 5, "unknown reg_method");
+    check(tp_.reg_global == 0 || tp_.reg_global == 1 || tp_.reg_global == 4 || tp_.reg_global == 5, "unknown global decay method");
     trainer_ready_ = true;
+    sample_counter_ = 0;   // :157
     if (host_only_) return;
     if (mp_.num_factor > max_supported_factor())
         fail("svdfeature_amd: num_factor > 256 is not supported by the gfx950 kernels yet");
     if (!device_model_) upload_model();
     tracker_.resize(num_resources() + 1);
+    d_ref_ui_.release(); d_ref_global_.release();   // ref_user/ref_item/ref_global start at 0 (:159-170)
     params_dirty_ = true;
 }
 
@@ -481,6 +481,17 @@ const DevParams &Engine::params() {
     P.lr = tp_.learning_rate; P.wd_user = tp_.wd_user; P.wd_item = tp_.wd_item;
     P.wd_user_bias = tp_.wd_user_bias; P.wd_item_bias = tp_.wd_item_bias; P.wd_global = tp_.wd_global;
     P.reg_method = tp_.reg_method; P.reg_global = tp_.reg_global; P.num_regfree_global = tp_.num_regfree_global;
+    check(tp_.reg_method >= 0 && tp_.reg_method <= 5, "unknown reg_method");
+    check(tp_.reg_global == 0 || tp_.reg_global == 1 || tp_.reg_global == 4 || tp_.reg_global == 5, "unknown global decay method");
+    if (tp_.reg_method >= 4 && !d_ref_ui_.p) {        // one word per W_uiset row: with common_latent_space users and items
+        d_ref_ui_.reserve((size_t)n_uiset_ + 1);        // share rows and therefore refs, like ref_item = ref_user (:167)
+        HIPCHECK(hipMemsetAsync(d_ref_ui_.p, 0, ((size_t)n_uiset_ + 1) * sizeof(unsigned), stream_));
+    }
+    if (tp_.reg_global >= 4 && !d_ref_global_.p) {
+        d_ref_global_.reserve((size_t)mp_.num_global + 1);
+        HIPCHECK(hipMemsetAsync(d_ref_global_.p, 0, ((size_t)mp_.num_global + 1) * sizeof(unsigned), stream_));
+    }
+    P.ref_ui = d_ref_ui_.p; P.ref_global = d_ref_global_.p;
     P.scale_lr_ufeedback = tp_.scale_lr_ufeedback; P.wd_ufeedback = tp_.wd_ufeedback; P.wd_ufeedback_bias = tp_.wd_ufeedback_bias;
     auto up_ranges = [&](const ParamSet &ps, DevBuf<unsigned> &db, DevBuf<float> &dw, DevRanges &out, unsigned max_id) {
         out.n = 0; out.bound = nullptr; out.wd = nullptr;
@@ -531,7 +542,7 @@ void Engine::stage_rows(int num_row, const float *row_label, const int *row_ptr,
     }
 }
 bool Engine::basic_fast_path_allowed() const {
-    return !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
+    return !lazy_decay() && !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
 }
 
 void Engine::update_csr(float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
@@ -827,20 +838,21 @@ void Engine::flush_csr(HostCSR &src) {
         HIPCHECK(hipStreamSynchronize(stream_));
         DevCSR D{w_label_.p, w_ptr_.p, w_index_.p, w_value_.p};
         for (size_t l = 0; l < sched.num_levels(); l++) {
-            launch_general(P, D, w_order_.p, sched.level_ptr[l], sched.level_ptr[l + 1], stream_);
+            launch_general(P, D, w_order_.p, sched.level_ptr[l], sched.level_ptr[l + 1], sample_counter_, stream_);
             n_launches_++; n_kind_[1]++;
         }
     }
     HIPCHECK(hipGetLastError());
     n_batches_ += (int64_t)sched.num_levels();
     n_instances_ += n;
+    sample_counter_ += (unsigned)n;
     n_flushes_++;
     src.clear();
 }
 
 // ---- few-row fused path -------------------------------------------------------------------------
 bool Engine::fused_allowed() const {
-    return use_fused_ && !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
+    return use_fused_ && !lazy_decay() && !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
 }
 // every instance has <= 2 user ids, <= 2 item ids and no id twice in a section (ptr is int or int64)
 template <typename PtrT>
@@ -954,7 +966,7 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
         for (int j = u.fb_begin; j < u.fb_end; j++) last[fb_off_ + staged_fb_index_[(size_t)j]] = lvl;
         if (u.flags & (UNIT_LOAD | UNIT_SAVE)) last[state_res] = lvl;
         levels[(size_t)t] = lvl;
-        du[(size_t)t] = DevUnit{u.fb_begin, u.fb_end, u.row_begin, u.row_end, u.flags | (simple && use_simple_units_ ? UNIT_SIMPLE : 0)};
+        du[(size_t)t] = DevUnit{u.fb_begin, u.fb_end, u.row_begin, u.row_end, u.flags | (simple && use_simple_units_ && !lazy_decay() ? UNIT_SIMPLE : 0)};
     }
     build_schedule(levels, base, sched);
 }
@@ -988,12 +1000,13 @@ void Engine::flush_units() {
     upload_units(d, sched, du);
     DevCSR D{d.label.p, d.ptr.p, d.index.p, d.value.p};
     for (size_t l = 0; l < sched.num_levels(); l++) {
-        launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sched.level_ptr[l], sched.level_ptr[l + 1], stream_);
+        launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sched.level_ptr[l], sched.level_ptr[l + 1], sample_counter_, stream_);
         n_launches_++;
     }
     HIPCHECK(hipGetLastError());
     n_batches_ += (int64_t)sched.num_levels();
     n_instances_ += n;
+    sample_counter_ += (unsigned)n;
     n_flushes_++;
     if (unit_open_) unit_open_on_device_ = true;
     staged_.clear();
@@ -1257,6 +1270,7 @@ void Engine::train_dataset(Dataset *ds) {
     flush();
     const DevParams &P = params();
     const Schedule &sc = ds->sched;
+    check(!lazy_decay() || ds->kind == 1 || (ds->kind == 3 && ds->num_simple_units == 0), "train_dataset: the dataset was scheduled before lazy decay (reg_method/reg_global >= 4) was selected");
     if (ds->kind == 0) {
         BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
         for (size_t l = 0; l < sc.num_levels(); l++) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
@@ -1264,20 +1278,21 @@ void Engine::train_dataset(Dataset *ds) {
         const UnitDev &d = ds->unitdev;
         DevCSR D{d.label.p, d.ptr.p, d.index.p, d.value.p};
         for (size_t l = 0; l < sc.num_levels(); l++)
-            launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_ptr[l], sc.level_ptr[l + 1], stream_);
+            launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_ptr[l], sc.level_ptr[l + 1], sample_counter_, stream_);
     } else if (ds->kind == 2) {
         const FusedSchedule S = ds->fused.view();
         for (size_t l = 0; l < sc.num_levels(); l++)
             launch_fused(P, S, ds->fused.max_nu, ds->fused.max_ni, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
     } else {
         DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
-        for (size_t l = 0; l < sc.num_levels(); l++) launch_general(P, D, ds->order.p, sc.level_ptr[l], sc.level_ptr[l + 1], stream_);
+        for (size_t l = 0; l < sc.num_levels(); l++) launch_general(P, D, ds->order.p, sc.level_ptr[l], sc.level_ptr[l + 1], sample_counter_, stream_);
     }
     HIPCHECK(hipGetLastError());
     n_launches_ += (int64_t)sc.num_levels();
     if (ds->kind < 3) n_kind_[ds->kind] += (int64_t)sc.num_levels();
     n_batches_ += (int64_t)sc.num_levels();
     n_instances_ += ds->num_row;
+    sample_counter_ += (unsigned)ds->num_row;
 }
 
 void Engine::predict_dataset(Dataset *ds, float *out) {

@@ -232,6 +232,10 @@ class Engine {
     bool unit_open_ = false;          // a START block was staged and its END has not arrived
     bool unit_open_on_device_ = false;  // ... and its first part was already flushed (state saved on device)
     long stage_window_ = 1 << 22;
+    // lazy decay modes (apex_svd_base.h:95-97,157-170): the reference's sample_counter and per-id ref words
+    unsigned sample_counter_ = 0;
+    DevBuf<unsigned> d_ref_ui_, d_ref_global_;
+    bool lazy_decay() const { return tp_.reg_method >= 4 || tp_.reg_global >= 4; }
     int groups_per_wave_ = 0, block_threads_ = 0, store_mode_ = 0, sort_batches_ = 1, xcd_remap_ = 1;   // 0 = tuned per factor width
     LevelTracker tracker_;
     void stage_rows(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value);

@@ -20,9 +20,11 @@ void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long
 void launch_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int groups_per_wave,
                   int block_threads, hipStream_t st);
 void launch_predict_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long n, float *out, hipStream_t st);
-void launch_general(const DevParams &P, const DevCSR &D, const int *order, long begin, long end, hipStream_t st);
+// counter_base: the reference's sample_counter at the first instance of D (row r runs with counter_base + r); only the
+// lazy decay modes read it
+void launch_general(const DevParams &P, const DevCSR &D, const int *order, long begin, long end, unsigned counter_base, hipStream_t st);
 void launch_svdpp(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
-                  const int *order, long begin, long end, hipStream_t st);
+                  const int *order, long begin, long end, unsigned counter_base, hipStream_t st);
 // read-only scoring
 void launch_predict(const DevParams &P, const DevCSR &D, long n, float *out, hipStream_t st);
 void launch_predict_basic(const DevParams &P, const BasicSchedule &S, long n, float *out, hipStream_t st);

@@ -168,8 +168,10 @@ __device__ __forceinline__ float get_wd(const DevRanges &rg, unsigned id, float 
 
 // factor-row regularisation (reg_user / reg_item, apex_svd_base.h:211-283) on a row held in
 // registers.  is_item selects the item flavour of reg_method 3 (L2) and skips the nonneg clamp.
+// Lazy modes 4/5 (:225-238, :265-278) take kk = (float)(ref[id] - sample_counter): the reference subtracts two
+// UNSIGNED counters, so kk is 0 for an id touched in this very instance and about 4.29e9 otherwise; restated as is.
 template <int LPI>
-__device__ __forceinline__ void reg_row(const DevParams &P, float4 &w, float wd, bool is_item, int L) {
+__device__ __forceinline__ void reg_row(const DevParams &P, float4 &w, float wd, bool is_item, int L, float kk = 0.0f) {
     const float lambda = P.lr * wd;
     int method = P.reg_method;
     if (method == 3) method = is_item ? 0 : 1;
@@ -180,6 +182,11 @@ __device__ __forceinline__ void reg_row(const DevParams &P, float4 &w, float wd,
     } else if (method == 2) {  // project(): ||w||^2 <= wd
         float sum = group_dot<LPI>(w, w, L, P.k);
         if (sum > wd) scale4(w, sqrtf(wd / sum));
+    } else if (method == 4) {  // lazy L2
+        scale4(w, expf(logf(1.0f - lambda) * kk));
+    } else if (method == 5) {  // lazy L1
+        const float th = lambda * kk;
+        w.x = l1(w.x, th); w.y = l1(w.y, th); w.z = l1(w.z, th); w.w = l1(w.w, th);
     }
     if (!is_item && P.user_nonnegative) {  // K7 smaller_then_fill(w, 0)
         if (w.x <= 0.0f) w.x = 0.0f;
@@ -188,13 +195,26 @@ __device__ __forceinline__ void reg_row(const DevParams &P, float4 &w, float wd,
         if (w.w <= 0.0f) w.w = 0.0f;
     }
 }
-__device__ __forceinline__ float reg_gbias(const DevParams &P, unsigned gid, float g) {  // :188-210
+__device__ __forceinline__ float reg_gbias(const DevParams &P, unsigned gid, float g, unsigned counter = 0) {  // :188-210
     float lambda = P.lr * get_wd(P.g_rng, gid, P.wd_global);
     if (gid >= P.num_regfree_global) {
         if (P.reg_global == 0) g = g * (1.0f - lambda);
-        else g = l1(g, lambda);
+        else if (P.reg_global == 1) g = l1(g, lambda);
+        else {  // 4 lazy L2, 5 lazy L1 (:194-205); regfree ids keep their ref untouched like the reference
+            const float kk = (float)(unsigned)(P.ref_global[gid] - counter);
+            P.ref_global[gid] = counter;
+            if (P.reg_global == 4) g = g * expf(logf(1.0f - lambda) * kk);
+            else g = l1(g, lambda * kk);
+        }
     }
     return g;
+}
+// kk of a factor row for the lazy modes; every lane of the group reads the same ref word, then writes the same value
+__device__ __forceinline__ float lazy_span(const DevParams &P, unsigned row, unsigned counter) {
+    if (P.reg_method < 4) return 0.0f;
+    const float kk = (float)(unsigned)(P.ref_ui[row] - counter);
+    P.ref_ui[row] = counter;
+    return kk;
 }
 
 template <int LPI>
@@ -557,28 +577,53 @@ __device__ __forceinline__ void rmw_row(const DevParams &P, unsigned row, const 
     if (with_bias) { float b = P.bias[row]; b = b + sc; P.bias[row] = b; }
 }
 template <int LPI>
-__device__ __forceinline__ void reg_user(const DevParams &P, unsigned uid, int L) {  // :211-250
+__device__ __forceinline__ void reg_user(const DevParams &P, unsigned uid, int L, unsigned counter) {  // :211-250
     const unsigned row = P.user_off + uid;
     float4 w = load_row<LPI>(P.W, row, P.pitch, L, P.k);
-    reg_row<LPI>(P, w, get_wd(P.u_rng, uid, P.wd_user), false, L);
+    reg_row<LPI>(P, w, get_wd(P.u_rng, uid, P.wd_user), false, L, lazy_span(P, row, counter));
     store_row<LPI>(P.W, row, P.pitch, L, P.k, w);
     if (P.no_user_bias == 0) { float b = P.bias[row]; b = b * (1.0f - P.lr * P.wd_user_bias); P.bias[row] = b; }
 }
 template <int LPI>
-__device__ __forceinline__ void reg_item(const DevParams &P, unsigned iid, int L) {  // :251-283
+__device__ __forceinline__ void reg_item(const DevParams &P, unsigned iid, int L, unsigned counter) {  // :251-283
     const unsigned row = P.item_off + iid;
     float4 w = load_row<LPI>(P.W, row, P.pitch, L, P.k);
-    reg_row<LPI>(P, w, get_wd(P.i_rng, iid, P.wd_item), true, L);
+    reg_row<LPI>(P, w, get_wd(P.i_rng, iid, P.wd_item), true, L, lazy_span(P, row, counter));
     store_row<LPI>(P.W, row, P.pitch, L, P.k, w);
     float b = P.bias[row]; b = b * (1.0f - P.lr * P.wd_item_bias); P.bias[row] = b;
 }
 
-// update_inner (:456-462) for reg modes 0..3 (lazy modes 4/5 are rejected on the host)
+// regularize(feature, is_after_update) (:286-311): globals and factor rows each run either before the step
+// (lazy modes 4/5, with the sample counter of BEFORE the step) or after it (modes 0..3)
+template <int LPI>
+__device__ __forceinline__ void instance_regularize(const DevParams &P, int ng, int nu, int ni, const unsigned *idx, int L,
+                                                    bool after, unsigned counter) {
+    const unsigned *ig = idx, *iu = idx + ng, *ii = idx + ng + nu;
+    if (after == (P.reg_global < 4))
+        for (int j = 0; j < ng; j++) { const unsigned gid = ig[j]; float g = reg_gbias(P, gid, P.g_bias[gid], counter); P.g_bias[gid] = g; }
+    if (after == (P.reg_method < 4)) {
+        for (int j = 0; j < nu; j++) {
+            const unsigned uid = iu[j];
+            reg_user<LPI>(P, uid, L, counter);
+            if (uid < P.feat_user.num_row)
+                for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++) reg_user<LPI>(P, P.feat_user.index[c], L, counter);
+        }
+        for (int j = 0; j < ni; j++) {
+            const unsigned iid = ii[j];
+            reg_item<LPI>(P, iid, L, counter);
+            if (iid < P.feat_item.num_row)
+                for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++) reg_item<LPI>(P, P.feat_item.index[c], L, counter);
+        }
+    }
+}
+
+// update_inner (:456-462); counter = sample_counter before this instance (only the lazy modes look at it)
 template <int LPI>
 __device__ __forceinline__ void instance_update(const DevParams &P, float label, int ng, int nu, int ni,
-                                                const unsigned *idx, const float *val, int L, SvdppRegs *pp) {
+                                                const unsigned *idx, const float *val, int L, SvdppRegs *pp, unsigned counter) {
     const unsigned *ig = idx, *iu = idx + ng, *ii = idx + ng + nu;
     const float *vg = val, *vu = val + ng, *vi = val + ng + nu;
+    if (P.reg_method >= 4 || P.reg_global >= 4) instance_regularize<LPI>(P, ng, nu, ni, idx, L, false, counter);
     float4 tu, ti;
     const double sum = instance_score<LPI>(P, ng, nu, ni, idx, val, L, pp, tu, ti);
     const float pred = map_active((float)sum, P.active_type);
@@ -611,25 +656,14 @@ __device__ __forceinline__ void instance_update(const DevParams &P, float label,
             pp->tmp_bias = pp->tmp_bias * (1.0f - lr2 * P.wd_ufeedback_bias);
         }
     }
-    // ---- regularize(feature, true) (:286-311)
-    for (int j = 0; j < ng; j++) { const unsigned gid = ig[j]; float g = reg_gbias(P, gid, P.g_bias[gid]); P.g_bias[gid] = g; }
-    for (int j = 0; j < nu; j++) {
-        const unsigned uid = iu[j];
-        reg_user<LPI>(P, uid, L);
-        if (uid < P.feat_user.num_row)
-            for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++) reg_user<LPI>(P, P.feat_user.index[c], L);
-    }
-    for (int j = 0; j < ni; j++) {
-        const unsigned iid = ii[j];
-        reg_item<LPI>(P, iid, L);
-        if (iid < P.feat_item.num_row)
-            for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++) reg_item<LPI>(P, P.feat_item.index[c], L);
-    }
+    // ---- sample_counter++ ; regularize(feature, true)
+    instance_regularize<LPI>(P, ng, nu, ni, idx, L, true, counter + 1u);
 }
 
 // Kernel 2: one conflict-free batch of general instances; order[] lists instance ids of the batch.
 template <int LPI>
-__global__ __launch_bounds__(256) void k_general(const DevParams P, const DevCSR D, const int *order, long begin, long end) {
+__global__ __launch_bounds__(256) void k_general(const DevParams P, const DevCSR D, const int *order, long begin, long end,
+                                                 unsigned counter_base) {
     constexpr int IPW = 64 / LPI;
     const int lane = threadIdx.x & 63;
     const int L = lane & (LPI - 1);
@@ -638,7 +672,8 @@ __global__ __launch_bounds__(256) void k_general(const DevParams P, const DevCSR
     for (long s = begin + gidx; s < end; s += stride) {
         const int r = order ? order[s] : (int)s;
         const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
-        instance_update<LPI>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, nullptr);
+        instance_update<LPI>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, nullptr,
+                             counter_base + (unsigned)r);
     }
 }
 
@@ -868,7 +903,7 @@ __device__ __forceinline__ void svdpp_rows_simple(const DevParams &P, const DevC
 // Kernel 4: one conflict-free batch of user units; one lane group walks one user's rows in order
 template <int LPI>
 __global__ __launch_bounds__(256) void k_svdpp(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
-                                               const float *fb_value, const int *order, long begin, long end) {
+                                               const float *fb_value, const int *order, long begin, long end, unsigned counter_base) {
     constexpr int IPW = 64 / LPI;
     const int lane = threadIdx.x & 63;
     const int L = lane & (LPI - 1);
@@ -890,7 +925,8 @@ __global__ __launch_bounds__(256) void k_svdpp(const DevParams P, const DevCSR D
         } else {
             for (int r = u.row_begin; r < u.row_end; r++) {
                 const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
-                instance_update<LPI>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp);
+                instance_update<LPI>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp,
+                                     counter_base + (unsigned)r);
             }
         }
         if (u.flags & UNIT_END) {
@@ -1038,11 +1074,11 @@ void launch_predict_fused(const DevParams &P, const FusedSchedule &S, int max_nu
     const int grid = grid_for(n, lpi, 256 * 8);
     SVDF_DISPATCH_LPI(lpi, launch_predict_fused_lpi<LPI>(P, S, max_nu, max_ni, n, out, grid, st));
 }
-void launch_general(const DevParams &P, const DevCSR &D, const int *order, long begin, long end, hipStream_t st) {
+void launch_general(const DevParams &P, const DevCSR &D, const int *order, long begin, long end, unsigned counter_base, hipStream_t st) {
     if (end <= begin) return;
     const int lpi = lanes_per_instance(P.k);
     const int grid = grid_for(end - begin, lpi, 256 * 8);
-    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_general<LPI>), dim3(grid), dim3(256), 0, st, P, D, order, begin, end));
+    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_general<LPI>), dim3(grid), dim3(256), 0, st, P, D, order, begin, end, counter_base));
 }
 void launch_predict(const DevParams &P, const DevCSR &D, long n, float *out, hipStream_t st) {
     if (n <= 0) return;
@@ -1058,11 +1094,11 @@ void launch_predict_basic(const DevParams &P, const BasicSchedule &S, long n, fl
     else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_predict_basic<LPI, false>), dim3(grid), dim3(256), 0, st, P, S, n, out)); }
 }
 void launch_svdpp(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
-                  const int *order, long begin, long end, hipStream_t st) {
+                  const int *order, long begin, long end, unsigned counter_base, hipStream_t st) {
     if (end <= begin) return;
     const int lpi = lanes_per_instance(P.k);
     const int grid = grid_for(end - begin, lpi, 256 * 8);
-    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_svdpp<LPI>), dim3(grid), dim3(256), 0, st, P, D, units, fb_index, fb_value, order, begin, end));
+    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_svdpp<LPI>), dim3(grid), dim3(256), 0, st, P, D, units, fb_index, fb_value, order, begin, end, counter_base));
 }
 void launch_svdpp_predict(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
                           long nunit, float *out, hipStream_t st) {

@@ -75,6 +75,8 @@ struct DevParams {
     int num_user, num_item, num_global, num_ufeedback;
     float base_score;
     int active_type, no_user_bias, user_nonnegative, user_group;
+    unsigned *ref_ui;         // lazy decay (reg_method 4/5): sample_counter of the last touch per W_uiset row
+    unsigned *ref_global;     // the same per global id (reg_global 4/5)
     int xcd_remap;            // 1: consecutive tiles of a batch go to the same XCD (blockIdx%8), see k_basicmf
     int store_mode;           // row-store cache policy of k_basicmf: 0 plain, 1 nontemporal, 2 sc1 write-through
     // SVDTrainParam

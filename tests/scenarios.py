@@ -117,7 +117,15 @@ SCENARIOS = {
         ("ip:wd", "0.02"), ("ip:bound", "7"), ("uip:wd", "0.003"), ("ip:bound", "30"),
         ("gp:wd", "0.05"), ("gp:bound", "9")]),
     "sparse_wd_tiny_skipmul": lambda t: _sparse(t, 116, wd_user=0.00005, wd_item=0.00002),
+    # lazy decay: the reference forms (float)(ref - sample_counter) from UNSIGNED counters (apex_svd_base.h:195,226,266),
+    # i.e. ~4.29e9 for every id seen before -- rows are wiped before each reuse unless lambda rounds 1-lambda to 1.
+    # Restated as is; these pin that behaviour.
+    "sparse_lazy_l2": lambda t: _sparse(t, 117, reg_method=4, reg_global=4),
+    "sparse_lazy_l1": lambda t: _sparse(t, 118, reg_method=5, reg_global=5, num_regfree_global=2),
+    "sparse_lazy_rows_only_side": lambda t: _sparse(t, 119, side=True, reg_method=4, reg_global=1, wd_user=0.0),
+    "sparse_lazy_globals_only": lambda t: _sparse(t, 120, reg_method=1, reg_global=4, wd_user=0.02, wd_item=0.03),
     "svdpp_random": _scn_svdpp_random,
+    "svdpp_random_lazy": lambda t: _scn_svdpp_random(t, reg_method=5),
     "svdpp_random_nobias": lambda t: _scn_svdpp_random(t, no_user_bias=1),
 }
 

@@ -55,7 +55,8 @@ def test_scenarios_match_reference_golden(name):
         assert dg["rmse"] == float(GOLD[name + "/rmse"])
 
 
-@pytest.mark.parametrize("name", ["sparse_side_tables", "svdpp_random", "basicmf_ml100k_k16", "sparse_reg_project"])
+@pytest.mark.parametrize("name", ["sparse_side_tables", "svdpp_random", "basicmf_ml100k_k16", "sparse_reg_project",
+                                  "sparse_lazy_l2", "svdpp_random_lazy"])
 @pytest.mark.parametrize("chunk,window", [(7, 1 << 22), (64, 50), (1, 3)])
 def test_staging_boundaries_do_not_change_the_result(name, chunk, window):
     """Feeding rows in small update() chunks and flushing every `window` staged instances must give the
@@ -591,3 +592,44 @@ def test_buffer_file_errors(tmp_path):
     open(badp, "wb").write(bytes(bad))
     with pytest.raises(sa.SvdfError, match="user feature index exceed bound"):
         t.dataset_from_buffer_file(badp)
+
+
+def test_lazy_decay_on_resident_datasets():
+    """reg_method/reg_global 4/5 (lazy decay, restated with the reference's unsigned counter arithmetic) through the
+    resident-dataset path: the sample counter keeps running across passes, basicMF-shaped triples fall back to
+    the general kernel, user-group units leave the register-resident fast path; bit-exact against the oracle."""
+    nu, ni = 500, 300
+    u, i, r = cases.planted_triples(20000, nu, ni, seed=31)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=20, reg_method=4)
+    o, t = _ready(port, 0, conf), _ready(hip, 0, conf)
+    ds = t.dataset_from_triples(u, i, r)
+    assert ds.kind == 1
+    d = sa.CSRData.from_triples(u, i, r)
+    for _ in range(3):
+        o.update_batch(d)
+        t.train_dataset(ds)
+    for name in ("W_user", "W_item", "u_bias", "i_bias"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+    assert np.count_nonzero(t.view("u_bias")) > 0   # (factor rows are wiped by the wrapped exponent; biases keep training)
+
+    blocks = cases.user_blocks(200, nu, ni, ni, seed=32, max_rows=20, max_fb=15, split_every=7)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=32, num_ufeedback=ni, wd_ufeedback=0.004,
+                           ufeedback_init_sigma=0.01, reg_method=5, wd_user=0.0)
+    o, t = _ready(port, 1, conf), _ready(hip, 1, conf)
+    ds = t.dataset_from_blocks(blocks)
+    assert ds.kind == 3 and ds.num_simple_units == 0
+    for _ in range(2):
+        for b in blocks:
+            o.update_block(b)
+        t.train_dataset(ds)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "W_ufeedback"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+
+    # a dataset scheduled for the fast kernels cannot be trained after switching to a lazy mode
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=20)
+    t = _ready(hip, 0, conf)
+    ds = t.dataset_from_triples(u, i, r)
+    assert ds.kind == 0
+    t.set_param("reg_method", "4")
+    with pytest.raises(sa.SvdfError, match="lazy decay"):
+        t.train_dataset(ds)
