@@ -167,13 +167,21 @@ def main():
     import svdfeature_amd as sa
     from svdfeature_amd.multi_gpu import HipShard, ShardedTrainer, shard_windows
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
+    # debug only (1-GPU boxes): SVDF_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and exchanges through gloo, so the
+    # whole N>1 flow (sharding, windows, exchange, timing, RMSE reduction) can be exercised without N GPUs
+    share_gpu = os.environ.get("SVDF_BENCH_SHARE_GPU", "0") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or a.force_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     t0 = time.time()
     n = a.ratings
