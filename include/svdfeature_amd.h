@@ -148,6 +148,12 @@ int svdf_item_delta_import(svdf_trainer *t, const float *device_src);
  * svdf_set_stream so the collective and these kernels share one stream order. */
 int svdf_item_delta_into(svdf_trainer *t, float *device_dst, int64_t *count);
 int svdf_item_delta_apply_from(svdf_trainer *t, const float *device_src);
+/* the same in ONE launch over all replicated ranges and in the wire format of the collective: half = 0 packs fp32,
+ * half = 1 packs IEEE fp16 (round to nearest even; parameters and arithmetic stay fp32).  device_dst = NULL only
+ * returns *count (elements).  unpack sets current = snapshot + delta and, with refresh_snapshot != 0, also
+ * snapshot = current, so the next window can pack again without svdf_item_delta_begin's copy. */
+int svdf_item_delta_pack(svdf_trainer *t, void *device_dst, int half, int64_t *count);
+int svdf_item_delta_unpack(svdf_trainer *t, const void *device_src, int half, int refresh_snapshot);
 
 /* ---- introspection used by tests, bench.py and the harness ---- */
 /* raw copies of parameter views: 0 u_bias 1 W_user 2 i_bias 3 W_item 4 g_bias 5 ufeedback_bias

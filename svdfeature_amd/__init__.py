@@ -93,6 +93,8 @@ def load_library():
     lib.svdf_item_delta_import.argtypes = [P, P]
     lib.svdf_item_delta_into.argtypes = [P, P, C.POINTER(C.c_int64)]
     lib.svdf_item_delta_apply_from.argtypes = [P, P]
+    lib.svdf_item_delta_pack.argtypes = [P, P, C.c_int, C.POINTER(C.c_int64)]
+    lib.svdf_item_delta_unpack.argtypes = [P, P, C.c_int, C.c_int]
     lib.svdf_set_stream.argtypes = [P, P]
     lib.svdf_get_view.restype = C.c_int64
     lib.svdf_get_view.argtypes = [P, C.c_int, _f32p, C.c_int64]
@@ -329,13 +331,18 @@ class Trainer:
         self._ok(self.lib.svdf_item_delta_export(self.h, C.c_void_p(device_ptr)))
 
     def item_delta_count(self):
-        """number of floats of the packed item-side delta"""
-        rows, cols = C.c_int(), C.c_int()
-        n = 0
-        for v in (3, 2, 4):   # W_item, i_bias, g_bias
-            self._ok(self.lib.svdf_view_shape(self.h, v, C.byref(rows), C.byref(cols)))
-            n += max(rows.value, 0) * max(cols.value, 1) if rows.value > 0 else 0
-        return n
+        """number of elements of the packed item-side delta"""
+        n = C.c_int64()
+        self._ok(self.lib.svdf_item_delta_pack(self.h, None, 0, C.byref(n)))
+        return n.value
+
+    def item_delta_pack(self, device_ptr, half=False):
+        n = C.c_int64()
+        self._ok(self.lib.svdf_item_delta_pack(self.h, C.c_void_p(device_ptr), 1 if half else 0, C.byref(n)))
+        return n.value
+
+    def item_delta_unpack(self, device_ptr, half=False, refresh_snapshot=True):
+        self._ok(self.lib.svdf_item_delta_unpack(self.h, C.c_void_p(device_ptr), 1 if half else 0, 1 if refresh_snapshot else 0))
 
     def item_delta_into(self, device_ptr):
         n = C.c_int64()

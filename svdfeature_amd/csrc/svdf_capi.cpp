@@ -149,6 +149,10 @@ int svdf_item_delta_export(svdf_trainer *t, float *dst) { SVDF_GUARD(-1, { t->e-
 int svdf_item_delta_import(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->item_delta_copy(nullptr, src); return 0; }) }
 
 int svdf_item_delta_into(svdf_trainer *t, float *dst, int64_t *count) { SVDF_GUARD(-1, { t->e->item_delta_into(dst, count); return 0; }) }
+int svdf_item_delta_pack(svdf_trainer *t, void *dst, int half, int64_t *count) { SVDF_GUARD(-1, { t->e->item_delta_pack(dst, half, count); return 0; }) }
+int svdf_item_delta_unpack(svdf_trainer *t, const void *src, int half, int refresh_snapshot) {
+    SVDF_GUARD(-1, { t->e->item_delta_unpack(src, half, refresh_snapshot); return 0; })
+}
 int svdf_item_delta_apply_from(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->item_delta_apply_from(src); return 0; }) }
 int svdf_set_stream(svdf_trainer *t, void *hip_stream) { SVDF_GUARD(-1, { t->e->set_stream((hipStream_t)hip_stream); return 0; }) }
 

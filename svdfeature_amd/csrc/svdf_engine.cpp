@@ -1399,6 +1399,35 @@ void Engine::item_delta_apply_from(const float *device_src) {
     }
     HIPCHECK(hipGetLastError());
 }
+DeltaRanges Engine::delta_ranges() {
+    DeltaRanges R;
+    memset(&R, 0, sizeof(R));
+    auto rg = shared_ranges();
+    check(rg.size() <= SVDF_MAX_DELTA_RANGES, "item_delta: too many replicated ranges");
+    long off = 0;
+    for (size_t q = 0; q < rg.size(); q++) { R.base[q] = rg[q].base; R.off[q] = off; off += rg[q].n; }
+    R.n = (int)rg.size();
+    for (int q = R.n; q <= SVDF_MAX_DELTA_RANGES; q++) R.off[q] = off;
+    return R;
+}
+void Engine::item_delta_pack(void *device_dst, int half, int64_t *count) {
+    check(trainer_ready_, "item_delta: init_trainer has not been called");
+    if (device_dst) need_device("item_delta");
+    const DeltaRanges R = delta_ranges();
+    if (count) *count = R.off[R.n];
+    if (!device_dst) return;   // size query
+    check(d_snap_.p != nullptr && (long)d_snap_.cap >= R.off[R.n], "item_delta: call item_delta_begin first");
+    flush();
+    launch_delta_pack(R, d_snap_.p, device_dst, half, stream_);
+    HIPCHECK(hipGetLastError());
+}
+void Engine::item_delta_unpack(const void *device_src, int half, int refresh_snapshot) {
+    need_device("item_delta");
+    const DeltaRanges R = delta_ranges();
+    check(d_snap_.p != nullptr && (long)d_snap_.cap >= R.off[R.n], "item_delta: call item_delta_begin first");
+    launch_delta_unpack(R, d_snap_.p, device_src, half, refresh_snapshot, stream_);
+    HIPCHECK(hipGetLastError());
+}
 void Engine::set_stream(hipStream_t s) {
     need_device("set_stream");
     flush();

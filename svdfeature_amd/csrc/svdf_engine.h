@@ -173,6 +173,8 @@ class Engine {
     void item_delta_copy(float *device_dst, const float *device_src);
     void item_delta_into(float *device_dst, int64_t *count);
     void item_delta_apply_from(const float *device_src);
+    void item_delta_pack(void *device_dst, int half, int64_t *count);          // one launch, fp32 or fp16 wire format
+    void item_delta_unpack(const void *device_src, int half, int refresh_snapshot);
     void set_stream(hipStream_t s);
 
     // introspection
@@ -282,6 +284,7 @@ class Engine {
     int64_t n_instances_ = 0, n_launches_ = 0, n_batches_ = 0, n_flushes_ = 0;
     int64_t ns_flush_ = 0, ns_model_ = 0;   // host-side time accounting (SVDF_PROFILE=1 prints it)
     int64_t n_kind_[3] = {0, 0, 0};   // launches of k_basicmf / k_general / k_fused
+    DeltaRanges delta_ranges();
     friend struct Dataset;
 };
 

@@ -31,6 +31,8 @@ void launch_predict_basic(const DevParams &P, const BasicSchedule &S, long n, fl
 void launch_svdpp_predict(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
                           long nunit, float *out, hipStream_t st);
 // multi-GPU item-side delta over n floats
+void launch_delta_pack(const DeltaRanges &R, const float *snap, void *dst, int half, hipStream_t st);
+void launch_delta_unpack(const DeltaRanges &R, float *snap, const void *src, int half, int refresh, hipStream_t st);
 void launch_delta_sub(const float *cur, const float *snap, float *delta, long n, hipStream_t st);
 void launch_delta_add(float *cur, const float *snap, const float *delta, long n, hipStream_t st);
 

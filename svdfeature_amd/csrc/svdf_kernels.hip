@@ -24,6 +24,7 @@
 // divide/sqrt, fp64 bias/score accumulation.  Only expf (sigmoid links) differs from glibc by
 // ulps; everything else is bit-exact against oracle/svdf_oracle.c.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 
 #include "svdf_kernels.h"
 
@@ -1106,6 +1107,50 @@ void launch_svdpp_predict(const DevParams &P, const DevCSR &D, const DevUnit *un
     const int lpi = lanes_per_instance(P.k);
     const int grid = grid_for(nunit, lpi, 256 * 8);
     SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_svdpp_predict<LPI>), dim3(grid), dim3(256), 0, st, P, D, units, fb_index, fb_value, nunit, out));
+}
+// One launch over ALL replicated ranges (W_item, biases, globals ...): pack = (current - snapshot) in the wire type,
+// unpack = current <- snapshot + delta, optionally snapshot <- current so that the next window needs no copy.
+// fp16 conversion is round-to-nearest-even (what a separate .half() pass would do).
+__device__ __forceinline__ float *delta_slot(const DeltaRanges &R, long j) {
+    int r = 0;
+#pragma unroll
+    for (int q = 1; q < SVDF_MAX_DELTA_RANGES; q++) r += (q < R.n && j >= R.off[q]) ? 1 : 0;
+    return R.base[r] + (j - R.off[r]);
+}
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_delta_pack(const DeltaRanges R, const float *snap, void *dst, long total) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        const float d = *delta_slot(R, j) - snap[j];
+        if (HALF) reinterpret_cast<__half *>(dst)[j] = __float2half_rn(d);
+        else reinterpret_cast<float *>(dst)[j] = d;
+    }
+}
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_delta_unpack(const DeltaRanges R, float *snap, const void *src, long total, int refresh) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        const float d = HALF ? __half2float(reinterpret_cast<const __half *>(src)[j]) : reinterpret_cast<const float *>(src)[j];
+        const float v = snap[j] + d;
+        *delta_slot(R, j) = v;
+        if (refresh) snap[j] = v;
+    }
+}
+void launch_delta_pack(const DeltaRanges &R, const float *snap, void *dst, int half, hipStream_t st) {
+    const long total = R.off[R.n];
+    if (total <= 0) return;
+    long grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (half) hipLaunchKernelGGL(k_delta_pack<true>, dim3((int)grid), dim3(256), 0, st, R, snap, dst, total);
+    else hipLaunchKernelGGL(k_delta_pack<false>, dim3((int)grid), dim3(256), 0, st, R, snap, dst, total);
+}
+void launch_delta_unpack(const DeltaRanges &R, float *snap, const void *src, int half, int refresh, hipStream_t st) {
+    const long total = R.off[R.n];
+    if (total <= 0) return;
+    long grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (half) hipLaunchKernelGGL(k_delta_unpack<true>, dim3((int)grid), dim3(256), 0, st, R, snap, src, total, refresh);
+    else hipLaunchKernelGGL(k_delta_unpack<false>, dim3((int)grid), dim3(256), 0, st, R, snap, src, total, refresh);
 }
 void launch_delta_sub(const float *cur, const float *snap, float *delta, long n, hipStream_t st) {
     if (n <= 0) return;

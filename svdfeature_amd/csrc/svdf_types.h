@@ -133,4 +133,13 @@ enum { UNIT_START = 1, UNIT_END = 2, UNIT_SAVE = 4, UNIT_LOAD = 8,
        UNIT_SIMPLE = 16 };   // host-verified: rows are (0,1,1) with one user id, distinct item ids, distinct feedback ids
 
 }  // namespace svdf
+// replicated (item-side) parameter ranges of the multi-GPU exchange, packed back to back: range r covers packed
+// positions [off[r], off[r+1])
+#define SVDF_MAX_DELTA_RANGES 6
+struct DeltaRanges {
+    float *base[SVDF_MAX_DELTA_RANGES];
+    long off[SVDF_MAX_DELTA_RANGES + 1];
+    int n;
+};
+
 #endif

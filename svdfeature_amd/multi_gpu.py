@@ -54,6 +54,10 @@ class ShardedTrainer:
       delta_begin()             snapshot the replicated (item-side) parameters
       delta_get() -> tensor     flat fp32 tensor holding current - snapshot (on the collective's device)
       delta_set(tensor)         replicated = snapshot + tensor
+    optional:
+      set_wire_half(bool)       the adaptor packs / unpacks the wire format itself (delta_get returns fp16)
+      all_reduce(dist, tensor)  issue the collective in the adaptor's own stream order
+      apply_refreshes_snapshot  delta_set also moves the snapshot, so delta_begin is needed once per pass only
     """
 
     def __init__(self, adaptor, window_handles, world, dist=None, force_exchange=False, half_delta=False):
@@ -62,10 +66,13 @@ class ShardedTrainer:
         # exchange the window deltas as fp16 (parameters and all arithmetic stay fp32): halves the bytes on
         # xGMI; measured RMSE effect at configs[2] density: 5.32e-5 vs 5.33e-5 with fp32 deltas
         self.half_delta = half_delta
+        self.native_wire = hasattr(adaptor, "set_wire_half")
+        if self.native_wire:
+            adaptor.set_wire_half(half_delta)
 
     def _reduce(self, d):
         if hasattr(self.a, "all_reduce"):
-            self.a.all_reduce(self.dist, d, self.half_delta)   # ordered on the adaptor's stream
+            self.a.all_reduce(self.dist, d)   # ordered on the adaptor's stream, d already in the wire format
         elif self.half_delta:
             h = d.half()
             self.dist.all_reduce(h)
@@ -74,11 +81,13 @@ class ShardedTrainer:
             self.dist.all_reduce(d)
 
     def train_pass(self):
-        for w in self.windows:
+        keep_snapshot = getattr(self.a, "apply_refreshes_snapshot", False)
+        for wi, w in enumerate(self.windows):
             if self.world == 1 and not self.force_exchange:
                 self.a.train(w)
                 continue
-            self.a.delta_begin()
+            if wi == 0 or not keep_snapshot:
+                self.a.delta_begin()
             self.a.train(w)
             d = self.a.delta_get()
             self._reduce(d)   # SUM over ranks, in place
@@ -86,15 +95,22 @@ class ShardedTrainer:
 
 
 class HipShard:
-    """Adaptor over svdfeature_amd.Trainer: windows are HBM-resident scheduled datasets; the delta is written
-    straight into a torch tensor and everything (SGD kernels, delta kernels, the RCCL all-reduce issued by
-    torch.distributed backend nccl) is ordered on ONE torch-owned HIP stream, so a pass needs no host
-    synchronisation at all."""
+    """Adaptor over svdfeature_amd.Trainer: windows are HBM-resident scheduled datasets; per window ONE kernel packs
+    (current - snapshot) of all replicated ranges straight into a torch tensor in the wire format (fp32 or fp16),
+    torch.distributed (backend nccl = RCCL) all-reduces it, ONE kernel sets current = snapshot + sum and moves the
+    snapshot along.  Everything is ordered on ONE torch-owned HIP stream: a pass needs no host synchronisation."""
+
+    apply_refreshes_snapshot = True
 
     def __init__(self, trainer, torch, device):
         self.t, self.torch, self.device = trainer, torch, device
         self.stream = torch.cuda.Stream(device=device)
         trainer.set_stream(self.stream.cuda_stream)
+        self.buf = None
+        self.half = False
+
+    def set_wire_half(self, half):
+        self.half = bool(half)
         self.buf = None
 
     def make_windows(self, shards):
@@ -109,18 +125,14 @@ class HipShard:
     def delta_get(self):
         if self.buf is None:
             with self.torch.cuda.stream(self.stream):
-                self.buf = self.torch.empty(self.t.item_delta_count(), dtype=self.torch.float32, device=self.device)
-        self.t.item_delta_into(self.buf.data_ptr())
+                self.buf = self.torch.empty(self.t.item_delta_count(), device=self.device,
+                                            dtype=self.torch.float16 if self.half else self.torch.float32)
+        self.t.item_delta_pack(self.buf.data_ptr(), self.half)
         return self.buf
 
-    def all_reduce(self, dist, d, half=False):
-        with self.torch.cuda.stream(self.stream):   # the collective is ordered after the delta kernel on our stream
-            if half:
-                h = d.half()
-                dist.all_reduce(h)
-                d.copy_(h)
-            else:
-                dist.all_reduce(d)
+    def all_reduce(self, dist, d):
+        with self.torch.cuda.stream(self.stream):   # the collective is ordered after the pack kernel on our stream
+            dist.all_reduce(d)
 
     def delta_set(self, d):
-        self.t.item_delta_apply_from(d.data_ptr())
+        self.t.item_delta_unpack(d.data_ptr(), self.half, refresh_snapshot=True)

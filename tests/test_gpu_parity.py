@@ -262,7 +262,8 @@ def test_two_simulated_ranks_on_one_gpu_match_the_oracle_simulation():
         for w in range(windows):
             ds = []
             for a, wins in shards:
-                a.delta_begin()
+                if w == 0:                 # like ShardedTrainer: delta_set moves the snapshot along inside a pass
+                    a.delta_begin()
                 a.train(wins[w])
                 d = a.delta_get()          # enqueued on the adaptor's own stream
                 a.stream.synchronize()
@@ -312,8 +313,10 @@ def test_sharded_trainer_world_one_with_nccl_process_group():
         a.delta_begin()
         a.train(ds)
         w3 = t.view("W_item").copy()
+        a.set_wire_half(True)
         d = a.delta_get()
-        a.all_reduce(dist, d, half=True)
+        assert d.dtype == torch.float16
+        a.all_reduce(dist, d)
         a.delta_set(d)
         np.testing.assert_array_equal(t.view("W_item"), w2 + (w3 - w2).astype(np.float16).astype(np.float32))
     finally:
@@ -633,3 +636,55 @@ def test_lazy_decay_on_resident_datasets():
     t.set_param("reg_method", "4")
     with pytest.raises(sa.SvdfError, match="lazy decay"):
         t.train_dataset(ds)
+
+
+@pytest.mark.parametrize("k,ng,fmt", [(64, 0, 0), (10, 7, 0), (33, 0, 1)])
+def test_fused_delta_pack_unpack_equals_the_separate_kernels(k, ng, fmt):
+    """svdf_item_delta_pack / _unpack (one launch over all replicated ranges, fp32 or fp16 on the wire, snapshot
+    moved along) against the per-range sub / add kernels: same packed delta, same parameters after apply, and a
+    second window packed from the refreshed snapshot equals begin + pack.  k=10 / 33: pitch != k; ng > 0: the
+    global-bias range; format 1: the feedback rows in front of the user rows."""
+    import torch
+    nu, ni = 400, 250
+    kw = dict(num_user=nu, num_item=ni, num_factor=k, num_global=ng)
+    if fmt == 1:
+        kw.update(num_ufeedback=ni, ufeedback_init_sigma=0.01)
+    conf = cases.conf_with(cases.BASICMF_CONF, **kw)
+    t1, t2 = _ready(hip, fmt, conf), _ready(hip, fmt, conf)
+    if fmt == 1:
+        blocks = cases.user_blocks(150, nu, ni, ni, seed=k, max_rows=10, max_fb=8)
+        steps = [blocks[:70], blocks[70:]]
+        train = lambda t, part: ([t.update_block(b) for b in part], t.finish_round())
+    else:
+        rows = cases.sparse_feature_rows(6000, nu, ni, max(ng, 1), seed=k) if ng else None
+        u, i, r = cases.planted_triples(6000, nu, ni, seed=k)
+        data = rows if ng else sa.CSRData.from_triples(u, i, r)
+        steps = [data.slice_rows(0, 3000), data.slice_rows(3000, 6000)]
+        train = lambda t, part: (t.update_batch(part), t.finish_round())
+    n = t1.item_delta_count()
+    pitch = (k + 3) // 4 * 4
+    assert n == (ni * pitch + ni + ng) + ((ni * pitch + ni) if fmt == 1 else 0)
+    dev = torch.device("cuda", 0)
+    for half in (False, True):
+        legacy = torch.empty(n, dtype=torch.float32, device=dev)
+        fused = torch.empty(n, dtype=torch.float16 if half else torch.float32, device=dev)
+        t1.item_delta_begin()
+        t2.item_delta_begin()
+        for w, part in enumerate(steps):
+            train(t1, part)
+            train(t2, part)
+            t1.item_delta_into(legacy.data_ptr())
+            t2.item_delta_pack(fused.data_ptr(), half)
+            t1.synchronize()
+            t2.synchronize()
+            want = legacy.half() if half else legacy
+            assert torch.equal(want, fused)
+            summed = want + want               # "two identical ranks"
+            t1.item_delta_apply_from(summed.float().contiguous().data_ptr())
+            t2.item_delta_unpack(summed.data_ptr(), half, refresh_snapshot=True)
+            t1.synchronize()
+            t2.synchronize()
+            names = ["W_item", "i_bias"] + (["g_bias"] if ng else []) + (["W_ufeedback", "ufeedback_bias"] if fmt == 1 else [])
+            for name in names + ["W_user"]:
+                np.testing.assert_array_equal(t1.view(name).view(np.uint32), t2.view(name).view(np.uint32))
+            t1.item_delta_begin()              # legacy path copies; the fused path already moved its snapshot

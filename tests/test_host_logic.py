@@ -108,10 +108,16 @@ def test_parameter_errors_match_reference_messages():
     with pytest.raises(sa.SvdfError, match="sigmoid range constrain"):
         t.init_model()
     t = sa.Trainer(0, 0, device=-2)
-    for k, v in cases.conf_with(cases.BASICMF_CONF, reg_method=4):
+    for k, v in cases.conf_with(cases.BASICMF_CONF, reg_method=6):   # 0..5 exist (4, 5 = lazy decay), apex_svd_base.h:239,279
         t.set_param(k, v)
     t.init_model()
-    with pytest.raises(sa.SvdfError, match="lazy decay"):
+    with pytest.raises(sa.SvdfError, match="unknown reg_method"):
+        t.init_trainer()
+    t = sa.Trainer(0, 0, device=-2)
+    for k, v in cases.conf_with(cases.BASICMF_CONF, reg_global=2):   # 0, 1, 4, 5 exist, apex_svd_base.h:192-207
+        t.set_param(k, v)
+    t.init_model()
+    with pytest.raises(sa.SvdfError, match="unknown global decay method"):
         t.init_trainer()
 
 
