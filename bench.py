@@ -150,6 +150,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--groups-per-wave", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--use-graph", type=int, default=0, help="replay each resident dataset's pass as a captured hipGraph (0 = plain launches)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="debug: run the item-delta exchange path even with one rank (exercises the N>1 code on one GPU)")
     a = ap.parse_args()
@@ -199,6 +200,7 @@ def main():
     tr.init_trainer()
     if a.groups_per_wave:
         tr.set_knob("groups_per_wave", a.groups_per_wave)
+    tr.set_knob("use_graph", a.use_graph)
     log("model init (libc rand, %d normals) + upload: %.1fs" % ((a.users + a.items) * a.factor, time.time() - t0))
 
     cpu_base, parity = None, None

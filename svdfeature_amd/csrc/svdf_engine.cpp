@@ -517,6 +517,7 @@ const DevParams &Engine::params() {
     up_table(feat_item_, d_fi_ptr_, d_fi_idx_, d_fi_val_, P.feat_item);
     HIPCHECK(hipStreamSynchronize(stream_));
     params_dirty_ = false;
+    launch_version_++;
     return dev_params_;
 }
 
@@ -1265,27 +1266,53 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
     return ds.release();
 }
 
+Dataset::~Dataset() {
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+}
+
 void Engine::train_dataset(Dataset *ds) {
     check(ds && ds->owner == this, "train_dataset: dataset belongs to another trainer");
     flush();
     const DevParams &P = params();
     const Schedule &sc = ds->sched;
-    check(!lazy_decay() || ds->kind == 1 || (ds->kind == 3 && ds->num_simple_units == 0), "train_dataset: the dataset was scheduled before lazy decay (reg_method/reg_global >= 4) was selected");
-    if (ds->kind == 0) {
-        BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
-        for (size_t l = 0; l < sc.num_levels(); l++) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
-    } else if (ds->kind == 3) {
-        const UnitDev &d = ds->unitdev;
-        DevCSR D{d.label.p, d.ptr.p, d.index.p, d.value.p};
-        for (size_t l = 0; l < sc.num_levels(); l++)
-            launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_ptr[l], sc.level_ptr[l + 1], sample_counter_, stream_);
-    } else if (ds->kind == 2) {
-        const FusedSchedule S = ds->fused.view();
-        for (size_t l = 0; l < sc.num_levels(); l++)
-            launch_fused(P, S, ds->fused.max_nu, ds->fused.max_ni, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
+    check(!lazy_decay() || ds->kind == 1 || (ds->kind == 3 && ds->num_simple_units == 0),
+          "train_dataset: the dataset was scheduled before lazy decay (reg_method/reg_global >= 4) was selected");
+    auto issue = [&]() {
+        if (ds->kind == 0) {
+            BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
+            for (size_t l = 0; l < sc.num_levels(); l++) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
+        } else if (ds->kind == 3) {
+            const UnitDev &d = ds->unitdev;
+            DevCSR D{d.label.p, d.ptr.p, d.index.p, d.value.p};
+            for (size_t l = 0; l < sc.num_levels(); l++)
+                launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_ptr[l], sc.level_ptr[l + 1], sample_counter_, stream_);
+        } else if (ds->kind == 2) {
+            const FusedSchedule S = ds->fused.view();
+            for (size_t l = 0; l < sc.num_levels(); l++)
+                launch_fused(P, S, ds->fused.max_nu, ds->fused.max_ni, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
+        } else {
+            DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
+            for (size_t l = 0; l < sc.num_levels(); l++) launch_general(P, D, ds->order.p, sc.level_ptr[l], sc.level_ptr[l + 1], sample_counter_, stream_);
+        }
+    };
+    // A pass over a resident dataset is the same launch sequence every time: capture it once into a hipGraph and
+    // replay it (short batches are launch-bound on the host otherwise).  Re-captured when kernel parameters, launch
+    // knobs or the stream change; the lazy decay modes pass a per-pass counter and stay on plain launches.
+    if (use_graph_ && !lazy_decay() && sc.num_levels() >= (size_t)graph_min_levels_) {
+        if (!ds->graph_exec || ds->graph_version != launch_version_ || ds->graph_stream != stream_) {
+            if (ds->graph_exec) { (void)hipGraphExecDestroy(ds->graph_exec); ds->graph_exec = nullptr; }
+            hipGraph_t g = nullptr;
+            HIPCHECK(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+            issue();
+            HIPCHECK(hipStreamEndCapture(stream_, &g));
+            HIPCHECK(hipGraphInstantiate(&ds->graph_exec, g, nullptr, nullptr, 0));
+            (void)hipGraphDestroy(g);
+            ds->graph_version = launch_version_;
+            ds->graph_stream = stream_;
+        }
+        HIPCHECK(hipGraphLaunch(ds->graph_exec, stream_));
     } else {
-        DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
-        for (size_t l = 0; l < sc.num_levels(); l++) launch_general(P, D, ds->order.p, sc.level_ptr[l], sc.level_ptr[l + 1], sample_counter_, stream_);
+        issue();
     }
     HIPCHECK(hipGetLastError());
     n_launches_ += (int64_t)sc.num_levels();
@@ -1502,6 +1529,9 @@ int64_t Engine::counter(int what) const {
     }
 }
 int Engine::set_knob(const char *name, long value) {
+    launch_version_++;   // any knob may change what a captured pass would launch
+    if (!strcmp(name, "use_graph")) { use_graph_ = value != 0; return 0; }
+    if (!strcmp(name, "graph_min_levels")) { check(value >= 1, "graph_min_levels must be >= 1"); graph_min_levels_ = (int)value; return 0; }
     if (!strcmp(name, "stage_window")) { check(value >= 1, "stage_window must be >= 1"); stage_window_ = value; return 0; }
     if (!strcmp(name, "groups_per_wave")) {
         check(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "groups_per_wave must be 0 (auto), 1, 2, 4 or 8");

@@ -131,6 +131,14 @@ struct Dataset {
     DevBuf<unsigned> feat_index;
     long algorithmic_bytes = 0;
     long num_units = 0, num_simple_units = 0;
+    // captured launch sequence of one pass (Engine::train_dataset)
+    hipGraphExec_t graph_exec = nullptr;
+    uint64_t graph_version = 0;
+    hipStream_t graph_stream = nullptr;
+    Dataset() = default;
+    ~Dataset();
+    Dataset(const Dataset &) = delete;
+    Dataset &operator=(const Dataset &) = delete;
 };
 
 class Engine {
@@ -234,6 +242,9 @@ class Engine {
     bool unit_open_ = false;          // a START block was staged and its END has not arrived
     bool unit_open_on_device_ = false;  // ... and its first part was already flushed (state saved on device)
     long stage_window_ = 1 << 22;
+    bool use_graph_ = false;   // measured: no gain, dependent short kernels are bound on the GPU side
+    int graph_min_levels_ = 2;
+    uint64_t launch_version_ = 1;
     // lazy decay modes (apex_svd_base.h:95-97,157-170): the reference's sample_counter and per-id ref words
     unsigned sample_counter_ = 0;
     DevBuf<unsigned> d_ref_ui_, d_ref_global_;

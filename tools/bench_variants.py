@@ -27,6 +27,7 @@ ap.add_argument("--users", type=int, default=1_000_000)
 ap.add_argument("--items", type=int, default=100_000)
 ap.add_argument("--factor", type=int, default=128)
 ap.add_argument("--passes", type=int, default=3)
+ap.add_argument("--use-graph", type=int, default=0)
 a = ap.parse_args()
 
 
@@ -39,6 +40,7 @@ def mk(format_type, active_type, extra):
         t.set_param(k, v)
     t.init_model()
     t.init_trainer()
+    t.set_knob("use_graph", a.use_graph)
     return t
 
 
