@@ -688,3 +688,26 @@ def test_fused_delta_pack_unpack_equals_the_separate_kernels(k, ng, fmt):
             for name in names + ["W_user"]:
                 np.testing.assert_array_equal(t1.view(name).view(np.uint32), t2.view(name).view(np.uint32))
             t1.item_delta_begin()              # legacy path copies; the fused path already moved its snapshot
+
+
+def test_graph_replay_of_a_pass_is_the_same_launch_sequence():
+    """use_graph=1 captures a resident dataset's pass into a hipGraph and replays it; a learning-rate change
+    (decay_learning_rate, per round) must re-capture.  Same bytes as plain launches and as the oracle."""
+    nu, ni = 3000, 800
+    u, i, r = cases.planted_triples(200000, nu, ni, seed=12)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64, decay_learning_rate=1, decay_rate=0.9)
+    o, t_plain, t_graph = _ready(port, 0, conf), _ready(hip, 0, conf), _ready(hip, 0, conf)
+    t_graph.set_knob("use_graph", 1)
+    d = sa.CSRData.from_triples(u, i, r)
+    ds_p, ds_g = t_plain.dataset_from_triples(u, i, r), t_graph.dataset_from_triples(u, i, r)
+    for rnd in range(3):
+        for t in (o, t_plain, t_graph):
+            t.set_round(rnd)
+        for _ in range(2):                  # second pass of a round replays the captured graph
+            o.update_batch(d)
+            t_plain.train_dataset(ds_p)
+            t_graph.train_dataset(ds_g)
+    for name in ("W_user", "W_item", "u_bias", "i_bias"):
+        ref = o.view(name).view(np.uint32)
+        np.testing.assert_array_equal(t_plain.view(name).view(np.uint32), ref)
+        np.testing.assert_array_equal(t_graph.view(name).view(np.uint32), ref)
