@@ -442,7 +442,7 @@ void Engine::init_trainer() {  // apex_svd_base.h:151-173, 499-503
     sample_counter_ = 0;   // :157
     if (host_only_) return;
     if (mp_.num_factor > max_supported_factor())
-        fail("svdfeature_amd: num_factor > 256 is not supported by the gfx950 kernels yet");
+        fail("svdfeature_amd: num_factor > 1024 is not supported by the gfx950 kernels");
     if (!device_model_) upload_model();
     tracker_.resize(num_resources() + 1);
     d_ref_ui_.release(); d_ref_global_.release();   // ref_user/ref_item/ref_global start at 0 (:159-170)
@@ -543,7 +543,7 @@ void Engine::stage_rows(int num_row, const float *row_label, const int *row_ptr,
     }
 }
 bool Engine::basic_fast_path_allowed() const {
-    return !lazy_decay() && !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
+    return !lazy_decay() && mp_.num_factor <= max_fast_path_factor() && !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
 }
 
 void Engine::update_csr(float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
@@ -853,7 +853,7 @@ void Engine::flush_csr(HostCSR &src) {
 
 // ---- few-row fused path -------------------------------------------------------------------------
 bool Engine::fused_allowed() const {
-    return use_fused_ && !lazy_decay() && !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
+    return use_fused_ && !lazy_decay() && mp_.num_factor <= max_fast_path_factor() && !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
 }
 // every instance has <= 2 user ids, <= 2 item ids and no id twice in a section (ptr is int or int64)
 template <typename PtrT>
@@ -967,7 +967,7 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
         for (int j = u.fb_begin; j < u.fb_end; j++) last[fb_off_ + staged_fb_index_[(size_t)j]] = lvl;
         if (u.flags & (UNIT_LOAD | UNIT_SAVE)) last[state_res] = lvl;
         levels[(size_t)t] = lvl;
-        du[(size_t)t] = DevUnit{u.fb_begin, u.fb_end, u.row_begin, u.row_end, u.flags | (simple && use_simple_units_ && !lazy_decay() ? UNIT_SIMPLE : 0)};
+        du[(size_t)t] = DevUnit{u.fb_begin, u.fb_end, u.row_begin, u.row_end, u.flags | (simple && use_simple_units_ && !lazy_decay() && mp_.num_factor <= max_fast_path_factor() ? UNIT_SIMPLE : 0)};
     }
     build_schedule(levels, base, sched);
 }

@@ -13,6 +13,7 @@ namespace svdf {
 // lanes of a wave that own one factor row (one float4 each): next power of two >= ceil(k/4)
 int lanes_per_instance(int k);
 int max_supported_factor();
+int max_fast_path_factor();   // widest row of the register-tiled kernels (k_basicmf, k_fused, simple SVD++ units)
 
 // every launch below processes ONE conflict-free batch [begin,end) on stream st
 void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long end, int groups_per_wave, int block_threads, hipStream_t st);

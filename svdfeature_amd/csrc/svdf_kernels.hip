@@ -131,6 +131,93 @@ __device__ __forceinline__ float group_dot(const float4 a, const float4 b, int L
     return sum;
 }
 
+// ------------------------------------------------------------------ wide rows (256 < num_factor <= 1024)
+// A whole wave owns the row, VPL float4 per lane: chunk c (elements 4c..4c+3) sits in lane c % 64, slot c / 64, so a
+// row gather is VPL fully coalesced 1 KiB loads.  Only the general kernels are instantiated for wide rows; the
+// helpers below are overloads of the float4 ones, so the per-instance code is written once for both (typename R).
+template <int VPL>
+struct WideRow { float4 v[VPL]; };
+template <typename R> struct row_traits;
+template <> struct row_traits<float4> {
+    static constexpr int VPL = 1;
+    static __device__ __forceinline__ float4 zero() { return f4zero(); }
+};
+template <int V> struct row_traits<WideRow<V>> {
+    static constexpr int VPL = V;
+    static __device__ __forceinline__ WideRow<V> zero() {
+        WideRow<V> r;
+#pragma unroll
+        for (int v = 0; v < V; v++) r.v[v] = f4zero();
+        return r;
+    }
+};
+template <int V> __device__ __forceinline__ void axpy4(WideRow<V> &d, const WideRow<V> &s, float a) {
+#pragma unroll
+    for (int v = 0; v < V; v++) axpy4(d.v[v], s.v[v], a);
+}
+template <int V> __device__ __forceinline__ void scale4(WideRow<V> &d, float a) {
+#pragma unroll
+    for (int v = 0; v < V; v++) scale4(d.v[v], a);
+}
+__device__ __forceinline__ void sub4(float4 &d, const float4 s) { d.x = d.x - s.x; d.y = d.y - s.y; d.z = d.z - s.z; d.w = d.w - s.w; }  // K5
+template <int V> __device__ __forceinline__ void sub4(WideRow<V> &d, const WideRow<V> &s) {
+#pragma unroll
+    for (int v = 0; v < V; v++) sub4(d.v[v], s.v[v]);
+}
+__device__ __forceinline__ void l1_row(float4 &w, float th) { w.x = l1(w.x, th); w.y = l1(w.y, th); w.z = l1(w.z, th); w.w = l1(w.w, th); }
+template <int V> __device__ __forceinline__ void l1_row(WideRow<V> &w, float th) {
+#pragma unroll
+    for (int v = 0; v < V; v++) l1_row(w.v[v], th);
+}
+__device__ __forceinline__ void clamp_nonneg(float4 &w) {  // K7 smaller_then_fill(w, 0)
+    if (w.x <= 0.0f) w.x = 0.0f;
+    if (w.y <= 0.0f) w.y = 0.0f;
+    if (w.z <= 0.0f) w.z = 0.0f;
+    if (w.w <= 0.0f) w.w = 0.0f;
+}
+template <int V> __device__ __forceinline__ void clamp_nonneg(WideRow<V> &w) {
+#pragma unroll
+    for (int v = 0; v < V; v++) clamp_nonneg(w.v[v]);
+}
+// K3 for wide rows: the same chain a[c] = a[c-1] + prod[c] over all chunks in index order; slot v is scanned across the
+// 64 lanes with wave_shr:1 adds, and the finished sum of slot v-1 (lane 63) is folded into the addend of slot v's
+// lane 0 -- the carry trick of the 32-lane groups above, one slot at a time.
+template <int LPI, int V>
+__device__ __forceinline__ float group_dot(const WideRow<V> &a, const WideRow<V> &b, int L, int k) {
+    static_assert(LPI == 64, "wide rows are owned by a whole wave");
+    const int nfull = k >> 2;
+    const int ntail = k & 3;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;   // products of the tail chunk
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        const float m0 = a.v[v].x * b.v[v].x, m1 = a.v[v].y * b.v[v].y, m2 = a.v[v].z * b.v[v].z, m3 = a.v[v].w * b.v[v].w;
+        const bool full = L + 64 * v < nfull;
+        float c0 = full ? m0 : 0.0f, c1 = full ? m1 : 0.0f, c2 = full ? m2 : 0.0f, c3 = full ? m3 : 0.0f;
+        if (v > 0) {
+            const float s0 = group_bcast<64>(a0, 63), s1 = group_bcast<64>(a1, 63), s2 = group_bcast<64>(a2, 63), s3 = group_bcast<64>(a3, 63);
+            if (L == 0) { c0 = s0 + c0; c1 = s1 + c1; c2 = s2 + c2; c3 = s3 + c3; }
+        }
+        a0 = 0.0f + c0; a1 = 0.0f + c1; a2 = 0.0f + c2; a3 = 0.0f + c3;
+#pragma unroll
+        for (int s = 1; s < 64; s++) {
+            a0 = prev_lane<64>(a0, L) + c0; a1 = prev_lane<64>(a1, L) + c1;
+            a2 = prev_lane<64>(a2, L) + c2; a3 = prev_lane<64>(a3, L) + c3;
+        }
+        if (ntail && (nfull >> 6) == v) {   // the tail chunk lives in this slot, lane nfull % 64
+            t0 = group_bcast<64>(m0, nfull & 63); t1 = group_bcast<64>(m1, nfull & 63); t2 = group_bcast<64>(m2, nfull & 63);
+        }
+    }
+    const float h = (a0 + a2) + (a1 + a3);
+    float sum = group_bcast<64>(h, 63);
+    if (ntail) {
+        sum = sum + t0;
+        if (ntail > 1) sum = sum + t1;
+        if (ntail > 2) sum = sum + t2;
+    }
+    return sum;
+}
+
 // apex_svd_model.h:112-123
 __device__ __forceinline__ float map_active(float sum, int type) {
     if (type == ACT_SIGMOID_L2 || type == ACT_SIGMOID_LIKELIHOOD) return 1.0f / (1.0f + expf(-sum));
@@ -171,30 +258,24 @@ __device__ __forceinline__ float get_wd(const DevRanges &rg, unsigned id, float 
 // registers.  is_item selects the item flavour of reg_method 3 (L2) and skips the nonneg clamp.
 // Lazy modes 4/5 (:225-238, :265-278) take kk = (float)(ref[id] - sample_counter): the reference subtracts two
 // UNSIGNED counters, so kk is 0 for an id touched in this very instance and about 4.29e9 otherwise; restated as is.
-template <int LPI>
-__device__ __forceinline__ void reg_row(const DevParams &P, float4 &w, float wd, bool is_item, int L, float kk = 0.0f) {
+template <int LPI, typename R>
+__device__ __forceinline__ void reg_row(const DevParams &P, R &w, float wd, bool is_item, int L, float kk = 0.0f) {
     const float lambda = P.lr * wd;
     int method = P.reg_method;
     if (method == 3) method = is_item ? 0 : 1;
     if (method == 0) {
         scale4(w, 1.0f - lambda);
     } else if (method == 1) {
-        w.x = l1(w.x, lambda); w.y = l1(w.y, lambda); w.z = l1(w.z, lambda); w.w = l1(w.w, lambda);
+        l1_row(w, lambda);
     } else if (method == 2) {  // project(): ||w||^2 <= wd
         float sum = group_dot<LPI>(w, w, L, P.k);
         if (sum > wd) scale4(w, sqrtf(wd / sum));
     } else if (method == 4) {  // lazy L2
         scale4(w, expf(logf(1.0f - lambda) * kk));
     } else if (method == 5) {  // lazy L1
-        const float th = lambda * kk;
-        w.x = l1(w.x, th); w.y = l1(w.y, th); w.z = l1(w.z, th); w.w = l1(w.w, th);
+        l1_row(w, lambda * kk);
     }
-    if (!is_item && P.user_nonnegative) {  // K7 smaller_then_fill(w, 0)
-        if (w.x <= 0.0f) w.x = 0.0f;
-        if (w.y <= 0.0f) w.y = 0.0f;
-        if (w.z <= 0.0f) w.z = 0.0f;
-        if (w.w <= 0.0f) w.w = 0.0f;
-    }
+    if (!is_item && P.user_nonnegative) clamp_nonneg(w);
 }
 __device__ __forceinline__ float reg_gbias(const DevParams &P, unsigned gid, float g, unsigned counter = 0) {  // :188-210
     float lambda = P.lr * get_wd(P.g_rng, gid, P.wd_global);
@@ -244,6 +325,32 @@ __device__ __forceinline__ void store_row_policy(float *W, size_t row, int pitch
         else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(x) : "memory");
     }
 }
+
+// row load / store by row type (float4: one lane group per row; WideRow: the whole wave, VPL slots)
+template <int LPI, typename R> struct row_io;
+template <int LPI> struct row_io<LPI, float4> {
+    static __device__ __forceinline__ float4 load(const float *W, size_t row, int pitch, int L, int k) { return load_row<LPI>(W, row, pitch, L, k); }
+    static __device__ __forceinline__ void store(float *W, size_t row, int pitch, int L, int k, const float4 &v) { store_row<LPI>(W, row, pitch, L, k, v); }
+};
+template <int LPI, int V> struct row_io<LPI, WideRow<V>> {
+    static_assert(LPI == 64, "wide rows are owned by a whole wave");
+    static __device__ __forceinline__ WideRow<V> load(const float *W, size_t row, int pitch, int L, int k) {
+        WideRow<V> r;
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int e = 4 * (L + 64 * v);
+            r.v[v] = e < k ? *reinterpret_cast<const float4 *>(W + row * (size_t)pitch + (size_t)e) : f4zero();
+        }
+        return r;
+    }
+    static __device__ __forceinline__ void store(float *W, size_t row, int pitch, int L, int k, const WideRow<V> &r) {
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int e = 4 * (L + 64 * v);
+            if (e < k) *reinterpret_cast<float4 *>(W + row * (size_t)pitch + (size_t)e) = r.v[v];
+        }
+    }
+};
 
 // =====================================================================================
 // Kernel 1: basicMF fused SGD step -- no global feature, one user id, one item id, no side
@@ -512,15 +619,18 @@ __global__ __launch_bounds__(256) void k_predict_basic(const DevParams P, const 
 // every regulariser).  Rows are read-modify-written through memory in the reference's order, so
 // an id that appears twice in one instance is updated and decayed twice like the reference does.
 // =====================================================================================
-struct SvdppRegs {   // SVDPPFeature members (apex_svd_base.h:486-488) held in registers
-    float4 tmp_fb, old_fb;
+template <typename R>
+struct SvdppRegsT {   // SVDPPFeature members (apex_svd_base.h:486-488) held in registers
+    R tmp_fb, old_fb;
     float norm, tmp_bias, old_bias;
 };
+using SvdppRegs = SvdppRegsT<float4>;
 
 // pred() (:445-454): fills tmp_u / tmp_i, returns the score before the link function (double)
-template <int LPI>
+template <int LPI, typename R>
 __device__ __forceinline__ double instance_score(const DevParams &P, int ng, int nu, int ni, const unsigned *idx,
-                                                 const float *val, int L, const SvdppRegs *pp, float4 &tu, float4 &ti) {
+                                                 const float *val, int L, const SvdppRegsT<R> *pp, R &tu, R &ti) {
+    using io = row_io<LPI, R>;
     const int k = P.k, pitch = P.pitch;
     const unsigned *ig = idx, *iu = idx + ng, *ii = idx + ng + nu;
     const float *vg = val, *vu = val + ng, *vi = val + ng + nu;
@@ -546,22 +656,22 @@ __device__ __forceinline__ double instance_score(const DevParams &P, int ng, int
                 bs += (double)(P.bias[P.item_off + P.feat_item.index[c]] * P.feat_item.value[c] * ival);
     }
     double sum = (double)P.base_score + bs;
-    tu = pp ? pp->tmp_fb : f4zero();
-    ti = f4zero();
+    tu = pp ? pp->tmp_fb : row_traits<R>::zero();
+    ti = row_traits<R>::zero();
     for (int j = 0; j < nu; j++) {
         const unsigned uid = iu[j];
-        axpy4(tu, load_row<LPI>(P.W, P.user_off + uid, pitch, L, k), vu[j]);
+        axpy4(tu, io::load(P.W, P.user_off + uid, pitch, L, k), vu[j]);
         if (uid < P.feat_user.num_row)
             for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++)
-                axpy4(tu, load_row<LPI>(P.W, P.user_off + P.feat_user.index[c], pitch, L, k), P.feat_user.value[c]);
+                axpy4(tu, io::load(P.W, P.user_off + P.feat_user.index[c], pitch, L, k), P.feat_user.value[c]);
     }
     for (int j = 0; j < ni; j++) {
         const unsigned iid = ii[j];
         const float ival = vi[j];
-        axpy4(ti, load_row<LPI>(P.W, P.item_off + iid, pitch, L, k), ival);
+        axpy4(ti, io::load(P.W, P.item_off + iid, pitch, L, k), ival);
         if (iid < P.feat_item.num_row)
             for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++)  // scalar formed in double
-                axpy4(ti, load_row<LPI>(P.W, P.item_off + P.feat_item.index[c], pitch, L, k),
+                axpy4(ti, io::load(P.W, P.item_off + P.feat_item.index[c], pitch, L, k),
                       (float)((double)P.feat_item.value[c] * (double)ival));
     }
     sum += (double)group_dot<LPI>(tu, ti, L, k);
@@ -570,33 +680,33 @@ __device__ __forceinline__ double instance_score(const DevParams &P, int ng, int
 
 // W[row] += tmp*sc ; bias[row] += sc   (every lane of the group stores the same bias value so
 // each thread later reads back its own write)
-template <int LPI>
-__device__ __forceinline__ void rmw_row(const DevParams &P, unsigned row, const float4 tmp, float sc, bool with_bias, int L) {
-    float4 w = load_row<LPI>(P.W, row, P.pitch, L, P.k);
+template <int LPI, typename R>
+__device__ __forceinline__ void rmw_row(const DevParams &P, unsigned row, const R &tmp, float sc, bool with_bias, int L) {
+    R w = row_io<LPI, R>::load(P.W, row, P.pitch, L, P.k);
     axpy4(w, tmp, sc);
-    store_row<LPI>(P.W, row, P.pitch, L, P.k, w);
+    row_io<LPI, R>::store(P.W, row, P.pitch, L, P.k, w);
     if (with_bias) { float b = P.bias[row]; b = b + sc; P.bias[row] = b; }
 }
-template <int LPI>
+template <int LPI, typename R>
 __device__ __forceinline__ void reg_user(const DevParams &P, unsigned uid, int L, unsigned counter) {  // :211-250
     const unsigned row = P.user_off + uid;
-    float4 w = load_row<LPI>(P.W, row, P.pitch, L, P.k);
+    R w = row_io<LPI, R>::load(P.W, row, P.pitch, L, P.k);
     reg_row<LPI>(P, w, get_wd(P.u_rng, uid, P.wd_user), false, L, lazy_span(P, row, counter));
-    store_row<LPI>(P.W, row, P.pitch, L, P.k, w);
+    row_io<LPI, R>::store(P.W, row, P.pitch, L, P.k, w);
     if (P.no_user_bias == 0) { float b = P.bias[row]; b = b * (1.0f - P.lr * P.wd_user_bias); P.bias[row] = b; }
 }
-template <int LPI>
+template <int LPI, typename R>
 __device__ __forceinline__ void reg_item(const DevParams &P, unsigned iid, int L, unsigned counter) {  // :251-283
     const unsigned row = P.item_off + iid;
-    float4 w = load_row<LPI>(P.W, row, P.pitch, L, P.k);
+    R w = row_io<LPI, R>::load(P.W, row, P.pitch, L, P.k);
     reg_row<LPI>(P, w, get_wd(P.i_rng, iid, P.wd_item), true, L, lazy_span(P, row, counter));
-    store_row<LPI>(P.W, row, P.pitch, L, P.k, w);
+    row_io<LPI, R>::store(P.W, row, P.pitch, L, P.k, w);
     float b = P.bias[row]; b = b * (1.0f - P.lr * P.wd_item_bias); P.bias[row] = b;
 }
 
 // regularize(feature, is_after_update) (:286-311): globals and factor rows each run either before the step
 // (lazy modes 4/5, with the sample counter of BEFORE the step) or after it (modes 0..3)
-template <int LPI>
+template <int LPI, typename R>
 __device__ __forceinline__ void instance_regularize(const DevParams &P, int ng, int nu, int ni, const unsigned *idx, int L,
                                                     bool after, unsigned counter) {
     const unsigned *ig = idx, *iu = idx + ng, *ii = idx + ng + nu;
@@ -605,28 +715,28 @@ __device__ __forceinline__ void instance_regularize(const DevParams &P, int ng, 
     if (after == (P.reg_method < 4)) {
         for (int j = 0; j < nu; j++) {
             const unsigned uid = iu[j];
-            reg_user<LPI>(P, uid, L, counter);
+            reg_user<LPI, R>(P, uid, L, counter);
             if (uid < P.feat_user.num_row)
-                for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++) reg_user<LPI>(P, P.feat_user.index[c], L, counter);
+                for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++) reg_user<LPI, R>(P, P.feat_user.index[c], L, counter);
         }
         for (int j = 0; j < ni; j++) {
             const unsigned iid = ii[j];
-            reg_item<LPI>(P, iid, L, counter);
+            reg_item<LPI, R>(P, iid, L, counter);
             if (iid < P.feat_item.num_row)
-                for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++) reg_item<LPI>(P, P.feat_item.index[c], L, counter);
+                for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++) reg_item<LPI, R>(P, P.feat_item.index[c], L, counter);
         }
     }
 }
 
 // update_inner (:456-462); counter = sample_counter before this instance (only the lazy modes look at it)
-template <int LPI>
+template <int LPI, typename R>
 __device__ __forceinline__ void instance_update(const DevParams &P, float label, int ng, int nu, int ni,
-                                                const unsigned *idx, const float *val, int L, SvdppRegs *pp, unsigned counter) {
+                                                const unsigned *idx, const float *val, int L, SvdppRegsT<R> *pp, unsigned counter) {
     const unsigned *ig = idx, *iu = idx + ng, *ii = idx + ng + nu;
     const float *vg = val, *vu = val + ng, *vi = val + ng + nu;
-    if (P.reg_method >= 4 || P.reg_global >= 4) instance_regularize<LPI>(P, ng, nu, ni, idx, L, false, counter);
-    float4 tu, ti;
-    const double sum = instance_score<LPI>(P, ng, nu, ni, idx, val, L, pp, tu, ti);
+    if (P.reg_method >= 4 || P.reg_global >= 4) instance_regularize<LPI, R>(P, ng, nu, ni, idx, L, false, counter);
+    R tu, ti;
+    const double sum = instance_score<LPI, R>(P, ng, nu, ni, idx, val, L, pp, tu, ti);
     const float pred = map_active((float)sum, P.active_type);
     const float err = cal_grad(label, pred, P.active_type) * 1.0f;
     const float lr = P.lr;
@@ -635,18 +745,18 @@ __device__ __forceinline__ void instance_update(const DevParams &P, float label,
     for (int j = 0; j < ng; j++) { float g = P.g_bias[ig[j]]; g = g + lr * err * vg[j]; P.g_bias[ig[j]] = g; }
     for (int j = 0; j < nu; j++) {
         const unsigned uid = iu[j];
-        rmw_row<LPI>(P, P.user_off + uid, ti, lr * err * vu[j], ub, L);
+        rmw_row<LPI, R>(P, P.user_off + uid, ti, lr * err * vu[j], ub, L);
         if (uid < P.feat_user.num_row)
             for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++)
-                rmw_row<LPI>(P, P.user_off + P.feat_user.index[c], ti, lr * err * P.feat_user.value[c], ub, L);
+                rmw_row<LPI, R>(P, P.user_off + P.feat_user.index[c], ti, lr * err * P.feat_user.value[c], ub, L);
     }
     for (int j = 0; j < ni; j++) {
         const unsigned iid = ii[j];
         const float ival = vi[j];
-        rmw_row<LPI>(P, P.item_off + iid, tu, lr * err * ival, true, L);
+        rmw_row<LPI, R>(P, P.item_off + iid, tu, lr * err * ival, true, L);
         if (iid < P.feat_item.num_row)
             for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++)
-                rmw_row<LPI>(P, P.item_off + P.feat_item.index[c], tu, lr * err * P.feat_item.value[c] * ival, true, L);
+                rmw_row<LPI, R>(P, P.item_off + P.feat_item.index[c], tu, lr * err * P.feat_item.value[c] * ival, true, L);
     }
     if (pp) {  // update_svdpp (:512-520)
         const float lr2 = lr * P.scale_lr_ufeedback;
@@ -658,11 +768,11 @@ __device__ __forceinline__ void instance_update(const DevParams &P, float label,
         }
     }
     // ---- sample_counter++ ; regularize(feature, true)
-    instance_regularize<LPI>(P, ng, nu, ni, idx, L, true, counter + 1u);
+    instance_regularize<LPI, R>(P, ng, nu, ni, idx, L, true, counter + 1u);
 }
 
 // Kernel 2: one conflict-free batch of general instances; order[] lists instance ids of the batch.
-template <int LPI>
+template <int LPI, typename R>
 __global__ __launch_bounds__(256) void k_general(const DevParams P, const DevCSR D, const int *order, long begin, long end,
                                                  unsigned counter_base) {
     constexpr int IPW = 64 / LPI;
@@ -673,13 +783,13 @@ __global__ __launch_bounds__(256) void k_general(const DevParams P, const DevCSR
     for (long s = begin + gidx; s < end; s += stride) {
         const int r = order ? order[s] : (int)s;
         const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
-        instance_update<LPI>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, nullptr,
-                             counter_base + (unsigned)r);
+        instance_update<LPI, R>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, nullptr,
+                                counter_base + (unsigned)r);
     }
 }
 
 // Kernel 3: predictions for a CSR stream (read-only, every instance independent)
-template <int LPI>
+template <int LPI, typename R>
 __global__ __launch_bounds__(256) void k_predict(const DevParams P, const DevCSR D, long n, float *out) {
     constexpr int IPW = 64 / LPI;
     const int lane = threadIdx.x & 63;
@@ -688,45 +798,45 @@ __global__ __launch_bounds__(256) void k_predict(const DevParams P, const DevCSR
     const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
     for (long r = gidx; r < n; r += stride) {
         const int p0 = D.row_ptr[3 * r], p1 = D.row_ptr[3 * r + 1], p2 = D.row_ptr[3 * r + 2], p3 = D.row_ptr[3 * r + 3];
-        float4 tu, ti;
-        const double sum = instance_score<LPI>(P, p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, nullptr, tu, ti);
+        R tu, ti;
+        const double sum = instance_score<LPI, R>(P, p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, nullptr, tu, ti);
         if (L == 0) out[r] = map_active((float)sum, P.active_type);
     }
 }
 
 // ---- SVD++ user units (SVDPPFeature, apex_svd_base.h:484-592) --------------------------------
-template <int LPI>
-__device__ __forceinline__ void svdpp_load_state(const DevParams &P, SvdppRegs &pp, int L) {
+template <int LPI, typename R>
+__device__ __forceinline__ void svdpp_load_state(const DevParams &P, SvdppRegsT<R> &pp, int L) {
     const float *st = P.svdpp_state;
-    pp.tmp_fb = load_row<LPI>(st, 0, P.pitch, L, P.k);
-    pp.old_fb = load_row<LPI>(st, 1, P.pitch, L, P.k);
+    pp.tmp_fb = row_io<LPI, R>::load(st, 0, P.pitch, L, P.k);
+    pp.old_fb = row_io<LPI, R>::load(st, 1, P.pitch, L, P.k);
     pp.norm = st[2 * P.pitch]; pp.tmp_bias = st[2 * P.pitch + 1]; pp.old_bias = st[2 * P.pitch + 2];
 }
-template <int LPI>
-__device__ __forceinline__ void svdpp_save_state(const DevParams &P, const SvdppRegs &pp, int L) {
+template <int LPI, typename R>
+__device__ __forceinline__ void svdpp_save_state(const DevParams &P, const SvdppRegsT<R> &pp, int L) {
     float *st = P.svdpp_state;
-    store_row<LPI>(st, 0, P.pitch, L, P.k, pp.tmp_fb);
-    store_row<LPI>(st, 1, P.pitch, L, P.k, pp.old_fb);
+    row_io<LPI, R>::store(st, 0, P.pitch, L, P.k, pp.tmp_fb);
+    row_io<LPI, R>::store(st, 1, P.pitch, L, P.k, pp.old_fb);
     if (L == 0) { st[2 * P.pitch] = pp.norm; st[2 * P.pitch + 1] = pp.tmp_bias; st[2 * P.pitch + 2] = pp.old_bias; }
 }
 // prepare_ufeedback (:523-538)
-template <int LPI>
-__device__ __forceinline__ void svdpp_prepare(const DevParams &P, SvdppRegs &pp, const unsigned *fidx, const float *fval, int nfb, int L) {
-    pp.norm = 0.0f; pp.tmp_fb = f4zero(); pp.tmp_bias = 0.0f;
+template <int LPI, typename R>
+__device__ __forceinline__ void svdpp_prepare(const DevParams &P, SvdppRegsT<R> &pp, const unsigned *fidx, const float *fval, int nfb, int L) {
+    pp.norm = 0.0f; pp.tmp_fb = row_traits<R>::zero(); pp.tmp_bias = 0.0f;
     for (int j = 0; j < nfb; j++) {
         const unsigned row = P.fb_off + fidx[j];
         const float v = fval[j];
-        axpy4(pp.tmp_fb, load_row<LPI>(P.W, row, P.pitch, L, P.k), v);
+        axpy4(pp.tmp_fb, row_io<LPI, R>::load(P.W, row, P.pitch, L, P.k), v);
         pp.norm = pp.norm + v * v;
         if (P.no_user_bias == 0) pp.tmp_bias = pp.tmp_bias + P.bias[row] * v;
     }
 }
 // update_ufeedback (:539-554)
-template <int LPI>
-__device__ __forceinline__ void svdpp_scatter(const DevParams &P, SvdppRegs &pp, const unsigned *fidx, const float *fval, int nfb, int L) {
+template <int LPI, typename R>
+__device__ __forceinline__ void svdpp_scatter(const DevParams &P, SvdppRegsT<R> &pp, const unsigned *fidx, const float *fval, int nfb, int L) {
     if (nfb == 0) return;
-    float4 d = pp.tmp_fb;
-    d.x = d.x - pp.old_fb.x; d.y = d.y - pp.old_fb.y; d.z = d.z - pp.old_fb.z; d.w = d.w - pp.old_fb.w;  // K5
+    R d = pp.tmp_fb;
+    sub4(d, pp.old_fb);  // K5
     float db = pp.tmp_bias - pp.old_bias;
     const float inv = 1.0f / pp.norm;
     scale4(d, inv);
@@ -735,9 +845,9 @@ __device__ __forceinline__ void svdpp_scatter(const DevParams &P, SvdppRegs &pp,
     for (int j = 0; j < nfb; j++) {
         const unsigned row = P.fb_off + fidx[j];
         const float v = fval[j];
-        float4 w = load_row<LPI>(P.W, row, P.pitch, L, P.k);
+        R w = row_io<LPI, R>::load(P.W, row, P.pitch, L, P.k);
         axpy4(w, d, v);
-        store_row<LPI>(P.W, row, P.pitch, L, P.k, w);
+        row_io<LPI, R>::store(P.W, row, P.pitch, L, P.k, w);
         if (P.no_user_bias == 0) { float b = P.bias[row]; b = b + db * v; P.bias[row] = b; }
     }
 }
@@ -902,7 +1012,7 @@ __device__ __forceinline__ void svdpp_rows_simple(const DevParams &P, const DevC
 }
 
 // Kernel 4: one conflict-free batch of user units; one lane group walks one user's rows in order
-template <int LPI>
+template <int LPI, typename R>
 __global__ __launch_bounds__(256) void k_svdpp(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
                                                const float *fb_value, const int *order, long begin, long end, unsigned counter_base) {
     constexpr int IPW = 64 / LPI;
@@ -912,33 +1022,42 @@ __global__ __launch_bounds__(256) void k_svdpp(const DevParams P, const DevCSR D
     const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
     for (long s = begin + gidx; s < end; s += stride) {
         const DevUnit u = units[order ? order[s] : (int)s];
-        const bool simple = (u.flags & UNIT_SIMPLE) != 0;
-        SvdppRegs pp;
-        if (u.flags & UNIT_LOAD) svdpp_load_state<LPI>(P, pp, L);
+        constexpr bool narrow = row_traits<R>::VPL == 1;   // the register-resident fast path exists for float4 rows only
+        const bool simple = narrow && (u.flags & UNIT_SIMPLE) != 0;
+        SvdppRegsT<R> pp;
+        if (u.flags & UNIT_LOAD) svdpp_load_state<LPI, R>(P, pp, L);
         if (u.flags & UNIT_START) {
-            if (simple) svdpp_prepare_batched<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
-            else svdpp_prepare<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
+            bool done = false;
+            if constexpr (narrow) {
+                if (simple) { svdpp_prepare_batched<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L); done = true; }
+            }
+            if (!done) svdpp_prepare<LPI, R>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
             pp.old_bias = pp.tmp_bias;
             pp.old_fb = pp.tmp_fb;
         }
-        if (simple) {
-            svdpp_rows_simple<LPI>(P, D, u, pp, L);
-        } else {
+        bool rows_done = false;
+        if constexpr (narrow) {
+            if (simple) { svdpp_rows_simple<LPI>(P, D, u, pp, L); rows_done = true; }
+        }
+        if (!rows_done) {
             for (int r = u.row_begin; r < u.row_end; r++) {
                 const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
-                instance_update<LPI>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp,
-                                     counter_base + (unsigned)r);
+                instance_update<LPI, R>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp,
+                                        counter_base + (unsigned)r);
             }
         }
         if (u.flags & UNIT_END) {
-            if (simple) svdpp_scatter_batched<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
-            else svdpp_scatter<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
+            bool scattered = false;
+            if constexpr (narrow) {
+                if (simple) { svdpp_scatter_batched<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L); scattered = true; }
+            }
+            if (!scattered) svdpp_scatter<LPI, R>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
         }
-        if (u.flags & UNIT_SAVE) svdpp_save_state<LPI>(P, pp, L);
+        if (u.flags & UNIT_SAVE) svdpp_save_state<LPI, R>(P, pp, L);
     }
 }
 // Kernel 5: predictions for user units (predict(vector<float>&, SVDPlusBlock), :583-591)
-template <int LPI>
+template <int LPI, typename R>
 __global__ __launch_bounds__(256) void k_svdpp_predict(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
                                                        const float *fb_value, long nunit, float *out) {
     constexpr int IPW = 64 / LPI;
@@ -948,16 +1067,16 @@ __global__ __launch_bounds__(256) void k_svdpp_predict(const DevParams P, const 
     const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
     for (long s = gidx; s < nunit; s += stride) {
         const DevUnit u = units[s];
-        SvdppRegs pp;
-        if (u.flags & UNIT_LOAD) svdpp_load_state<LPI>(P, pp, L);
-        if (u.flags & UNIT_START) svdpp_prepare<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
+        SvdppRegsT<R> pp;
+        if (u.flags & UNIT_LOAD) svdpp_load_state<LPI, R>(P, pp, L);
+        if (u.flags & UNIT_START) svdpp_prepare<LPI, R>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
         for (int r = u.row_begin; r < u.row_end; r++) {
             const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
-            float4 tu, ti;
-            const double sum = instance_score<LPI>(P, p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp, tu, ti);
+            R tu, ti;
+            const double sum = instance_score<LPI, R>(P, p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp, tu, ti);
             if (L == 0) out[r] = map_active((float)sum, P.active_type);
         }
-        if (u.flags & UNIT_SAVE) svdpp_save_state<LPI>(P, pp, L);
+        if (u.flags & UNIT_SAVE) svdpp_save_state<LPI, R>(P, pp, L);
     }
 }
 
@@ -979,10 +1098,11 @@ __global__ void k_delta_add(float *cur, const float *snap, const float *delta, l
 int lanes_per_instance(int k) {
     int chunks = (k + 3) / 4;
     int lpi = 1;
-    while (lpi < chunks) lpi <<= 1;
-    return lpi;
+    while (lpi < chunks && lpi < 64) lpi <<= 1;
+    return lpi;   // 64 also for wide rows (k > 256: several float4 slots per lane)
 }
-int max_supported_factor() { return 256; }
+int max_supported_factor() { return 1024; }
+int max_fast_path_factor() { return 256; }
 
 static inline int grid_for(long groups, int lpi, int cap) {
     const long per_block = 4L * (64 / lpi);
@@ -1012,16 +1132,25 @@ static void launch_basicmf_lpi(const DevParams &P, const BasicSchedule &S, long 
     }
 }
 
-#define SVDF_DISPATCH_LPI(lpi, CALL)                  \
-    switch (lpi) {                                    \
-    case 1: { constexpr int LPI = 1; CALL; } break;   \
-    case 2: { constexpr int LPI = 2; CALL; } break;   \
-    case 4: { constexpr int LPI = 4; CALL; } break;   \
-    case 8: { constexpr int LPI = 8; CALL; } break;   \
-    case 16: { constexpr int LPI = 16; CALL; } break; \
-    case 32: { constexpr int LPI = 32; CALL; } break; \
-    default: { constexpr int LPI = 64; CALL; } break; \
+// (variadic: a launch expands to kernel<<<a, b, c, d>>>(...), whose bare commas must survive being passed on)
+#define SVDF_DISPATCH_LPI(lpi, ...)                          \
+    switch (lpi) {                                           \
+    case 1: { constexpr int LPI = 1; __VA_ARGS__; } break;   \
+    case 2: { constexpr int LPI = 2; __VA_ARGS__; } break;   \
+    case 4: { constexpr int LPI = 4; __VA_ARGS__; } break;   \
+    case 8: { constexpr int LPI = 8; __VA_ARGS__; } break;   \
+    case 16: { constexpr int LPI = 16; __VA_ARGS__; } break; \
+    case 32: { constexpr int LPI = 32; __VA_ARGS__; } break; \
+    default: { constexpr int LPI = 64; __VA_ARGS__; } break; \
     }
+// general-path kernels: LPI as above with float4 rows up to 256 factors, a whole wave with 2..4 float4 slots beyond
+#define SVDF_DISPATCH_ROW(k, ...)                                                          \
+    if ((k) <= 256) {                                                                      \
+        using R = float4;                                                                  \
+        SVDF_DISPATCH_LPI(lanes_per_instance(k), __VA_ARGS__)                              \
+    } else if ((k) <= 512) { constexpr int LPI = 64; using R = WideRow<2>; __VA_ARGS__; }  \
+    else if ((k) <= 768) { constexpr int LPI = 64; using R = WideRow<3>; __VA_ARGS__; }    \
+    else { constexpr int LPI = 64; using R = WideRow<4>; __VA_ARGS__; }
 
 void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long end, int groups_per_wave, int block_threads, hipStream_t st) {
     if (end <= begin) return;
@@ -1079,13 +1208,13 @@ void launch_general(const DevParams &P, const DevCSR &D, const int *order, long 
     if (end <= begin) return;
     const int lpi = lanes_per_instance(P.k);
     const int grid = grid_for(end - begin, lpi, 256 * 8);
-    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_general<LPI>), dim3(grid), dim3(256), 0, st, P, D, order, begin, end, counter_base));
+    SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_general<LPI, R>), dim3(grid), dim3(256), 0, st, P, D, order, begin, end, counter_base));
 }
 void launch_predict(const DevParams &P, const DevCSR &D, long n, float *out, hipStream_t st) {
     if (n <= 0) return;
     const int lpi = lanes_per_instance(P.k);
     const int grid = grid_for(n, lpi, 256 * 8);
-    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_predict<LPI>), dim3(grid), dim3(256), 0, st, P, D, n, out));
+    SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_predict<LPI, R>), dim3(grid), dim3(256), 0, st, P, D, n, out));
 }
 void launch_predict_basic(const DevParams &P, const BasicSchedule &S, long n, float *out, hipStream_t st) {
     if (n <= 0) return;
@@ -1099,14 +1228,14 @@ void launch_svdpp(const DevParams &P, const DevCSR &D, const DevUnit *units, con
     if (end <= begin) return;
     const int lpi = lanes_per_instance(P.k);
     const int grid = grid_for(end - begin, lpi, 256 * 8);
-    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_svdpp<LPI>), dim3(grid), dim3(256), 0, st, P, D, units, fb_index, fb_value, order, begin, end, counter_base));
+    SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_svdpp<LPI, R>), dim3(grid), dim3(256), 0, st, P, D, units, fb_index, fb_value, order, begin, end, counter_base));
 }
 void launch_svdpp_predict(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
                           long nunit, float *out, hipStream_t st) {
     if (nunit <= 0) return;
     const int lpi = lanes_per_instance(P.k);
     const int grid = grid_for(nunit, lpi, 256 * 8);
-    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_svdpp_predict<LPI>), dim3(grid), dim3(256), 0, st, P, D, units, fb_index, fb_value, nunit, out));
+    SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_svdpp_predict<LPI, R>), dim3(grid), dim3(256), 0, st, P, D, units, fb_index, fb_value, nunit, out));
 }
 // One launch over ALL replicated ranges (W_item, biases, globals ...): pack = (current - snapshot) in the wire type,
 // unpack = current <- snapshot + delta, optionally snapshot <- current so that the next window needs no copy.

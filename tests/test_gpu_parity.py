@@ -73,9 +73,11 @@ def test_staging_boundaries_do_not_change_the_result(name, chunk, window):
     assert hashlib.md5(res["pred"].tobytes()).hexdigest() == str(GOLD[name + "/pred_md5"])
 
 
-@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8, 10, 16, 17, 31, 32, 33, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("k", [1, 2, 3, 4, 5, 8, 10, 16, 17, 31, 32, 33, 64, 100, 128, 200, 256,
+                               257, 300, 511, 512, 513, 700, 768, 770, 1023, 1024])
 def test_every_factor_width_basic_and_general(k):
-    """All lane-group shapes (1..64 lanes per row, ragged tails) on both kernels, bit-exact vs the oracle."""
+    """All lane-group shapes (1..64 lanes per row, ragged tails) on both kernels, and the wide rows beyond 256 factors
+    (whole wave per row, 2..4 float4 slots per lane, general kernel only), bit-exact vs the oracle."""
     nu, ni, ng = 60, 45, 5
     u, i, r = cases.planted_triples(3000, nu, ni, seed=k)
     basic = sa.CSRData.from_triples(u, i, r)
@@ -711,3 +713,36 @@ def test_graph_replay_of_a_pass_is_the_same_launch_sequence():
         ref = o.view(name).view(np.uint32)
         np.testing.assert_array_equal(t_plain.view(name).view(np.uint32), ref)
         np.testing.assert_array_equal(t_graph.view(name).view(np.uint32), ref)
+
+
+@pytest.mark.parametrize("k,method", [(320, 0), (600, 2), (1000, 1)])
+def test_wide_rows_user_groups_and_regularisers(k, method):
+    """num_factor > 256 on the user-group (SVD++) path and with the L1 / projection regularisers, side tables and
+    lazy decay excluded from nothing: wide rows run the same per-instance code as narrow ones."""
+    nu, ni = 120, 90
+    blocks = cases.user_blocks(60, nu, ni, ni, seed=k, max_rows=8, max_fb=6, split_every=5)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni, wd_ufeedback=0.004,
+                           ufeedback_init_sigma=0.01, learning_rate=0.01, reg_method=method, wd_user=0.02 if method else 0.004)
+    o, t = _ready(port, 1, conf), _ready(hip, 1, conf)
+    ds = t.dataset_from_blocks(blocks)
+    assert ds.num_simple_units == 0
+    for _ in range(2):
+        for b in blocks:
+            o.update_block(b)
+        t.train_dataset(ds)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "W_ufeedback", "ufeedback_bias"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+    want = np.concatenate([o.predict_block(b) for b in blocks if b.extend_tag == 0])
+    rows = np.concatenate([np.full(b.data.num_row, b.extend_tag == 0) for b in blocks])
+    np.testing.assert_array_equal(t.predict_dataset(ds)[rows].view(np.uint32), want.view(np.uint32))
+    # basicMF-shaped triples at this width are scheduled onto the general kernel
+    u, i, r = cases.planted_triples(2000, nu, ni, seed=k)
+    conf0 = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k)
+    o, t = _ready(port, 0, conf0), _ready(hip, 0, conf0)
+    ds = t.dataset_from_triples(u, i, r)
+    assert ds.kind == 1
+    o.update_batch(sa.CSRData.from_triples(u, i, r))
+    t.train_dataset(ds)
+    np.testing.assert_array_equal(t.view("W_item").view(np.uint32), o.view("W_item").view(np.uint32))
+    with pytest.raises(sa.SvdfError, match="num_factor > 1024"):
+        _ready(hip, 0, cases.conf_with(cases.BASICMF_CONF, num_factor=1025))
