@@ -933,6 +933,8 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
     const unsigned *idx = staged_.feat_index.data();
     const bool simple_ok = feat_user_.num_row() == 0 && feat_item_.num_row() == 0 && mp_.common_latent_space == 0 && mp_.common_feedback_space == 0;
     if (simple_ok && stamp_.size() < (size_t)n_uiset_) stamp_.assign((size_t)n_uiset_, -1);
+    staged_fresh_.assign((size_t)staged_.num_row(), 0);
+    any_fresh_ = false;
     for (long t = 0; t < nu; t++) {
         const HostUnit &u = staged_units_[(size_t)t];
         int lvl = base;
@@ -945,7 +947,7 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
                 simple = (p[1] == p[0]) && (p[2] == p[1] + 1) && (p[3] == p[2] + 1) && idx[p[1]] == uid0;
                 if (simple) {
                     const unsigned row = item_off_ + idx[p[2]];
-                    if (stamp_[row] == (int)t) simple = false;   // the same item twice in one user's rows
+                    if (stamp_[row] == (int)t) { staged_fresh_[(size_t)r] = 1; any_fresh_ = true; }   // the same item again: read at use
                     stamp_[row] = (int)t;
                 }
             }
@@ -970,6 +972,14 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
         du[(size_t)t] = DevUnit{u.fb_begin, u.fb_end, u.row_begin, u.row_end, u.flags | (simple && use_simple_units_ && !lazy_decay() && mp_.num_factor <= max_fast_path_factor() ? UNIT_SIMPLE : 0)};
     }
     build_schedule(levels, base, sched);
+    // inside a batch the fast-path users go first: they are launched as one wave per user (k_svdpp_wave), the rest as
+    // lane groups (k_svdpp); units of a batch are independent, so the split changes nothing but the launch shape
+    sched.level_mid.resize(sched.num_levels());
+    for (size_t l = 0; l < sched.num_levels(); l++) {
+        int *b = sched.order.data() + sched.level_ptr[l], *e = sched.order.data() + sched.level_ptr[l + 1];
+        int *m = std::stable_partition(b, e, [&](int t) { return (du[(size_t)t].flags & UNIT_SIMPLE) != 0; });
+        sched.level_mid[l] = sched.level_ptr[l] + (long)(m - b);
+    }
 }
 void Engine::upload_units(UnitDev &d, const Schedule &sched, const std::vector<DevUnit> &du) {
     d.label.upload(staged_.row_label.data(), staged_.row_label.size(), stream_);
@@ -980,6 +990,8 @@ void Engine::upload_units(UnitDev &d, const Schedule &sched, const std::vector<D
     d.fbval.upload(staged_fb_value_.data(), staged_fb_value_.size(), stream_);
     d.units.upload(du.data(), du.size(), stream_);
     d.order.upload(sched.order.data(), sched.order.size(), stream_);
+    d.has_fresh = any_fresh_;
+    if (any_fresh_) d.fresh.upload(staged_fresh_.data(), staged_fresh_.size(), stream_);
     HIPCHECK(hipStreamSynchronize(stream_));
 }
 
@@ -999,9 +1011,10 @@ void Engine::flush_units() {
     const long n = staged_.num_row();
     UnitDev &d = w_unitdev_;
     upload_units(d, sched, du);
-    DevCSR D{d.label.p, d.ptr.p, d.index.p, d.value.p};
+    const DevCSR D = d.csr();
     for (size_t l = 0; l < sched.num_levels(); l++) {
-        launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sched.level_ptr[l], sched.level_ptr[l + 1], sample_counter_, stream_);
+        launch_svdpp_wave(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sched.level_ptr[l], sched.level_mid[l], stream_);
+        launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sched.level_mid[l], sched.level_ptr[l + 1], sample_counter_, stream_);
         n_launches_++;
     }
     HIPCHECK(hipGetLastError());
@@ -1283,9 +1296,11 @@ void Engine::train_dataset(Dataset *ds) {
             for (size_t l = 0; l < sc.num_levels(); l++) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
         } else if (ds->kind == 3) {
             const UnitDev &d = ds->unitdev;
-            DevCSR D{d.label.p, d.ptr.p, d.index.p, d.value.p};
-            for (size_t l = 0; l < sc.num_levels(); l++)
-                launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_ptr[l], sc.level_ptr[l + 1], sample_counter_, stream_);
+            const DevCSR D = d.csr();
+            for (size_t l = 0; l < sc.num_levels(); l++) {
+                launch_svdpp_wave(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_ptr[l], sc.level_mid[l], stream_);
+                launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_mid[l], sc.level_ptr[l + 1], sample_counter_, stream_);
+            }
         } else if (ds->kind == 2) {
             const FusedSchedule S = ds->fused.view();
             for (size_t l = 0; l < sc.num_levels(); l++)
@@ -1331,7 +1346,7 @@ void Engine::predict_dataset(Dataset *ds, float *out) {
     w_out_.reserve((size_t)n);
     if (ds->kind == 3) {
         const UnitDev &d = ds->unitdev;
-        DevCSR D{d.label.p, d.ptr.p, d.index.p, d.value.p};
+        const DevCSR D = d.csr();
         launch_svdpp_predict(P, D, d.units.p, d.fbidx.p, d.fbval.p, ds->num_units, w_out_.p, stream_);
         HIPCHECK(hipMemcpyAsync(out, w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
         HIPCHECK(hipStreamSynchronize(stream_));

@@ -56,6 +56,7 @@ struct LevelTracker {
 struct Schedule {
     std::vector<int> order;        // unit ids sorted by level, stable
     std::vector<long> level_ptr;   // level l occupies order[level_ptr[l] .. level_ptr[l+1])
+    std::vector<long> level_mid;   // user-unit schedules only: [level_ptr[l], level_mid[l]) are the fast-path (UNIT_SIMPLE) units
     long max_level_size = 0;
     size_t num_levels() const { return level_ptr.empty() ? 0 : level_ptr.size() - 1; }
 };
@@ -109,6 +110,9 @@ struct UnitDev {
     DevBuf<int> ptr, order;
     DevBuf<unsigned> index, fbidx;
     DevBuf<DevUnit> units;
+    DevBuf<unsigned char> fresh;   // DevCSR::row_fresh (allocated only when some row needs it)
+    bool has_fresh = false;
+    DevCSR csr() const { return DevCSR{label.p, ptr.p, index.p, value.p, has_fresh ? fresh.p : nullptr}; }
 };
 
 class Engine;
@@ -245,6 +249,8 @@ class Engine {
     bool use_graph_ = false;   // measured: no gain, dependent short kernels are bound on the GPU side
     int graph_min_levels_ = 2;
     uint64_t launch_version_ = 1;
+    std::vector<unsigned char> staged_fresh_;   // per staged row, see DevCSR::row_fresh
+    bool any_fresh_ = false;
     // lazy decay modes (apex_svd_base.h:95-97,157-170): the reference's sample_counter and per-id ref words
     unsigned sample_counter_ = 0;
     DevBuf<unsigned> d_ref_ui_, d_ref_global_;

@@ -35,8 +35,10 @@ namespace svdf {
 // ------------------------------------------------------------------ small helpers
 __device__ __forceinline__ float4 f4zero() { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
 
-// apex_tensor_sse.h:231-242: multiply is skipped when |s-1| <= 1e-6 (test done in double)
-__device__ __forceinline__ bool scalar_is_one(float s) { return !((double)fabsf(s - 1.0f) > 1e-6); }
+// apex_tensor_sse.h:231-242: multiply is skipped when |s-1| <= 1e-6.  The reference compares (double)fabsf(s - 1.0f)
+// with the double 1e-6; no float lies between (float)1e-6 = 9.99999997e-7 and that double, so the float compare
+// below decides identically for every input (NaN included: both say "one") without fp64 instructions.
+__device__ __forceinline__ bool scalar_is_one(float s) { return !(fabsf(s - 1.0f) > 1e-6f); }
 
 // K1: dst += src*s (separate mul and add)
 __device__ __forceinline__ void axpy4(float4 &d, const float4 s, float a) {
@@ -852,166 +854,352 @@ __device__ __forceinline__ void svdpp_scatter(const DevParams &P, SvdppRegsT<R> 
     }
 }
 
-// ---- fast path for "simple" units (host-verified, UNIT_SIMPLE): every row is (no global, ONE user id --
-// the same for the whole unit --, one item id), the unit's item ids are pairwise distinct, its feedback
-// ids are pairwise distinct, no side tables, separate feedback/user/item row spaces.  Then
-//   * the user's factor row and bias live in registers for the whole unit (the reference re-reads
-//     and re-writes them every row; the values are identical),
-//   * item rows of the next PF rows are gathered while the current rows are computed (distinct
-//     ids => nothing in flight is modified), item rows are written once, fire and forget,
-//   * feedback rows are gathered / scattered PF at a time (accumulation order unchanged).
-// What remains sequential is the true recurrence p_u, tmp_ufeedback -> err -> p_u, tmp_ufeedback.
-constexpr int SVDPP_PF = 4;   // rows in flight; measured: 8 spills (167 VGPR + scratch) and is slower
-constexpr int SVDPP_FB = 8;   // feedback rows gathered / scattered per batch
+// ---- fast path for "simple" units (host-verified, UNIT_SIMPLE): every row is (no global, ONE user id -- the same for
+// the whole unit --, one item id), the unit's item ids are pairwise distinct, its feedback ids are pairwise distinct,
+// no side tables, separate feedback/user/item row spaces.
+//
+// A user's rows are a strict recurrence (p_u, tmp_ufeedback -> err -> p_u, tmp_ufeedback), and exact sequential
+// semantics leave only a handful of users per conflict-free batch, so this path is LATENCY-bound: what counts is the
+// number of dependent instructions per row, not bytes.  Layout for that: ONE WAVE PER USER, one element per lane and
+// register, arranged so that the reference's four SSE accumulation chains (elements j, j+4, j+8, ... for j = 0..3)
+// each live in their own 16-lane DPP row:
+//      lane = 16*j + m,  register q   <->   element 4*(m + 16*q) + j
+// The whole dot product is then ONE v_add_f32_dpp row_shr:1 per step for all four chains at once (15 steps per 64
+// factors, carry of register q-1 folded into lane m=0 through row_ror:1), against 4 instructions per step and
+// bpermute carries in the float4-per-lane layout; every elementwise op (axpy, decay, L1 ...) is k/64 instructions
+// instead of 4.  Measured on MI355X (tools/svdpp_latency2.py): DESIGN.md section 5.
+//   * the user's factor row, bias and the feedback state stay in registers for the whole unit,
+//   * item rows (and their records, via scalar loads: everything about a row is wave-uniform) are fetched
+//     SVDPP_PFW rows ahead, item rows are written once, fire and forget,
+//   * feedback rows are gathered / scattered a batch (16 or 32) at a time, the next batch in flight meanwhile
+//     (accumulation order unchanged).
+constexpr int SVDPP_PFW = 8;   // rows fetched ahead (double-buffered: 8..16 rows = 2..4 us of lookahead)
+// feedback rows per gather / scatter batch; two batches are in flight (HBM + translation latency is ~2 us, a batch of
+// 32 accumulates in ~0.8 us), bounded by the register file for the wider rows
+template <int NR> struct svdpp_fbw { static constexpr int value = NR <= 2 ? 32 : 16; };
 
-// NOTE on control flow: the gathers below are issued with CLAMPED indices and no per-element branch, so the
-// compiler can put all index loads, then all row loads of a batch back to back (a branch per element makes
-// every load wait for the previous one: s_waitcnt vmcnt(1) chains).  Only the arithmetic / stores are predicated.
-template <int LPI>
-__device__ __forceinline__ void svdpp_prepare_batched(const DevParams &P, SvdppRegs &pp, const unsigned *fidx, const float *fval, int nfb, int L) {
-    pp.norm = 0.0f; pp.tmp_fb = f4zero(); pp.tmp_bias = 0.0f;
-    const bool ub = P.no_user_bias == 0;
-    for (int j0 = 0; j0 < nfb; j0 += SVDPP_FB) {
-        float4 w[SVDPP_FB]; float v[SVDPP_FB], b[SVDPP_FB]; unsigned row[SVDPP_FB];
+template <int NR>
+struct ChainRow { float r[NR]; };
+
+__device__ __forceinline__ float dpp_row_shr1(float v) {   // lane m <- lane m-1 of its 16-lane row, 0 into m = 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dpp_row_ror1(float v) {   // lane m <- lane (m-1) mod 16: m = 0 receives lane 15
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ float wave_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+template <int NR> __device__ __forceinline__ ChainRow<NR> chain_zero() {
+    ChainRow<NR> z;
 #pragma unroll
-        for (int c = 0; c < SVDPP_FB; c++) {
-            const int j = min(j0 + c, nfb - 1);
-            row[c] = P.fb_off + fidx[j];
-            v[c] = fval[j];
-        }
+    for (int q = 0; q < NR; q++) z.r[q] = 0.0f;
+    return z;
+}
+template <int NR> __device__ __forceinline__ ChainRow<NR> chain_load(const float *W, size_t row, int pitch, int lane, int k) {
+    const float *base = W + row * (size_t)pitch;
+    const int e0 = 4 * (lane & 15) + (lane >> 4);
+    ChainRow<NR> x;
 #pragma unroll
-        for (int c = 0; c < SVDPP_FB; c++) {
-            w[c] = load_row<LPI>(P.W, row[c], P.pitch, L, P.k);
-            b[c] = ub ? P.bias[row[c]] : 0.0f;
-        }
+    for (int q = 0; q < NR; q++) { const int e = e0 + 64 * q; x.r[q] = e < k ? base[e] : 0.0f; }
+    return x;
+}
+template <int NR> __device__ __forceinline__ void chain_store(float *W, size_t row, int pitch, int lane, int k, const ChainRow<NR> &x) {
+    float *base = W + row * (size_t)pitch;
+    const int e0 = 4 * (lane & 15) + (lane >> 4);
 #pragma unroll
-        for (int c = 0; c < SVDPP_FB; c++) {
-            if (j0 + c < nfb) {
-                axpy4(pp.tmp_fb, w[c], v[c]);
-                pp.norm = pp.norm + v[c] * v[c];
-                if (ub) pp.tmp_bias = pp.tmp_bias + b[c] * v[c];
-            }
-        }
+    for (int q = 0; q < NR; q++) { const int e = e0 + 64 * q; if (e < k) base[e] = x.r[q]; }
+}
+// K1 / K2 with a wave-uniform scalar
+template <int NR> __device__ __forceinline__ void chain_axpy(ChainRow<NR> &d, const ChainRow<NR> &s, float a) {
+    if (scalar_is_one(a)) {
+#pragma unroll
+        for (int q = 0; q < NR; q++) d.r[q] = d.r[q] + s.r[q];
+    } else {
+#pragma unroll
+        for (int q = 0; q < NR; q++) { const float m = s.r[q] * a; d.r[q] = d.r[q] + m; }
     }
 }
-template <int LPI>
-__device__ __forceinline__ void svdpp_scatter_batched(const DevParams &P, SvdppRegs &pp, const unsigned *fidx, const float *fval, int nfb, int L) {
-    if (nfb == 0) return;
-    float4 d = pp.tmp_fb;
-    d.x = d.x - pp.old_fb.x; d.y = d.y - pp.old_fb.y; d.z = d.z - pp.old_fb.z; d.w = d.w - pp.old_fb.w;
-    float db = pp.tmp_bias - pp.old_bias;
-    const float inv = 1.0f / pp.norm;
-    scale4(d, inv);
-    db = db * inv;
-    pp.tmp_fb = d; pp.tmp_bias = db;
-    const bool ub = P.no_user_bias == 0;
-    for (int j0 = 0; j0 < nfb; j0 += SVDPP_FB) {
-        float4 w[SVDPP_FB]; float v[SVDPP_FB], b[SVDPP_FB]; unsigned row[SVDPP_FB];
+template <int NR> __device__ __forceinline__ void chain_scale(ChainRow<NR> &d, float a) {
+    if (!scalar_is_one(a)) {
 #pragma unroll
-        for (int c = 0; c < SVDPP_FB; c++) {
-            const int j = min(j0 + c, nfb - 1);
-            row[c] = P.fb_off + fidx[j];
-            v[c] = fval[j];
-        }
-#pragma unroll
-        for (int c = 0; c < SVDPP_FB; c++) {
-            w[c] = load_row<LPI>(P.W, row[c], P.pitch, L, P.k);
-            b[c] = ub ? P.bias[row[c]] : 0.0f;
-        }
-#pragma unroll
-        for (int c = 0; c < SVDPP_FB; c++) {
-            if (j0 + c < nfb) {
-                axpy4(w[c], d, v[c]);
-                store_row<LPI>(P.W, row[c], P.pitch, L, P.k, w[c]);
-                if (ub && L == 0) P.bias[row[c]] = b[c] + db * v[c];
-            }
-        }
+        for (int q = 0; q < NR; q++) d.r[q] = d.r[q] * a;
     }
 }
-struct SvdppRowPF {   // one prefetched row of a simple unit
-    float4 q;
+// K3 in the chain layout; the result is wave-uniform
+template <int NR> __device__ __forceinline__ float chain_dot(const ChainRow<NR> &a, const ChainRow<NR> &b, int lane, int k) {
+    const int nfull = k >> 2, ntail = k & 3, m = lane & 15;
+    float prod[NR];
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        prod[q] = a.r[q] * b.r[q];
+        float c = (m + 16 * q < nfull) ? prod[q] : 0.0f;   // chunks beyond the full ones feed +0, the sums travel on
+        if (q > 0) { const float carry = dpp_row_ror1(acc); if (m == 0) c = carry + c; }
+        acc = 0.0f + c;
+#pragma unroll
+        for (int s = 1; s < 16; s++) acc = dpp_row_shr1(acc) + c;
+    }
+    const float s0 = lane_value(acc, 15), s1 = lane_value(acc, 31), s2 = lane_value(acc, 47), s3 = lane_value(acc, 63);
+    float sum = (s0 + s2) + (s1 + s3);   // sum_all: movehl add, then shuffle add_ss
+    if (ntail) {                         // scalar tail, in index order: chunk nfull, SSE lanes 0..ntail-1
+        float pt = prod[0];
+#pragma unroll
+        for (int q = 1; q < NR; q++) pt = (nfull >> 4) == q ? prod[q] : pt;
+        const int tm = nfull & 15;
+        sum = sum + lane_value(pt, tm);
+        if (ntail > 1) sum = sum + lane_value(pt, 16 + tm);
+        if (ntail > 2) sum = sum + lane_value(pt, 32 + tm);
+    }
+    return sum;
+}
+// reg_user / reg_item on a row in registers (reg modes 0..3; lazy modes never reach the fast path)
+template <int NR> __device__ __forceinline__ void chain_reg(const DevParams &P, ChainRow<NR> &w, float wd, bool is_item, int lane) {
+    const float lambda = P.lr * wd;
+    int method = P.reg_method;
+    if (method == 3) method = is_item ? 0 : 1;
+    if (method == 0) {
+        chain_scale(w, 1.0f - lambda);
+    } else if (method == 1) {
+#pragma unroll
+        for (int q = 0; q < NR; q++) w.r[q] = l1(w.r[q], lambda);
+    } else if (method == 2) {
+        const float sum = chain_dot(w, w, lane, P.k);
+        if (sum > wd) chain_scale(w, sqrtf(wd / sum));
+    }
+    if (!is_item && P.user_nonnegative) {
+#pragma unroll
+        for (int q = 0; q < NR; q++) if (w.r[q] <= 0.0f) w.r[q] = 0.0f;
+    }
+}
+template <int NR>
+struct ChainRowPF {   // one prefetched row of a simple unit
+    ChainRow<NR> q;
     float bi, label, uv, iv;
     unsigned irow;
+    int fresh;
 };
-// rows beyond the unit's end re-fetch its last row (results unused, nothing stored)
-template <int LPI>
-__device__ __forceinline__ void svdpp_fetch_rows(const DevParams &P, const DevCSR &D, int row_begin, int e0, int j0, int nrow, int L,
-                                                 SvdppRowPF (&o)[SVDPP_PF]) {
+// rows beyond the unit's end re-fetch its last row (results unused, nothing stored); indices are clamped instead of
+// branched on so that all record loads, then all row loads of a batch are issued back to back
+template <int NR>
+__device__ __forceinline__ void chain_fetch_rows(const DevParams &P, const DevCSR &D, int row_begin, int e0, int j0, int nrow, int lane,
+                                                 ChainRowPF<NR> (&o)[SVDPP_PFW]) {
 #pragma unroll
-    for (int c = 0; c < SVDPP_PF; c++) {
+    for (int c = 0; c < SVDPP_PFW; c++) {
         const int j = min(j0 + c, nrow - 1);
         o[c].label = D.row_label[row_begin + j];
         o[c].uv = D.feat_value[e0 + 2 * j];
         o[c].iv = D.feat_value[e0 + 2 * j + 1];
         o[c].irow = P.item_off + D.feat_index[e0 + 2 * j + 1];
+        o[c].fresh = D.row_fresh ? (int)D.row_fresh[row_begin + j] : 0;
     }
 #pragma unroll
-    for (int c = 0; c < SVDPP_PF; c++) {
-        o[c].q = load_row<LPI>(P.W, o[c].irow, P.pitch, L, P.k);
+    for (int c = 0; c < SVDPP_PFW; c++) {
+        o[c].q = chain_load<NR>(P.W, o[c].irow, P.pitch, lane, P.k);
         o[c].bi = P.bias[o[c].irow];
     }
 }
-template <int LPI>
-__device__ __forceinline__ void svdpp_rows_simple(const DevParams &P, const DevCSR &D, const DevUnit &u, SvdppRegs &pp, int L) {
-    const int nrow = u.row_end - u.row_begin;
-    if (nrow <= 0) return;
-    const int e0 = D.row_ptr[3 * (long)u.row_begin];   // rows are (0,1,1): entries of row j start at e0 + 2j
-    const bool ub = P.no_user_bias == 0;
-    const unsigned urow = P.user_off + D.feat_index[e0];
-    float4 p = load_row<LPI>(P.W, urow, P.pitch, L, P.k);
-    float bu = ub ? P.bias[urow] : 0.0f;
-    const float wd_u = get_wd(P.u_rng, urow - P.user_off, P.wd_user);
-    const float lr = P.lr;
-    SvdppRowPF cur[SVDPP_PF], nxt[SVDPP_PF];
-    svdpp_fetch_rows<LPI>(P, D, u.row_begin, e0, 0, nrow, L, cur);
-    for (int j0 = 0; j0 < nrow; j0 += SVDPP_PF) {
-        svdpp_fetch_rows<LPI>(P, D, u.row_begin, e0, j0 + SVDPP_PF, nrow, L, nxt);
+
+// feedback rows in flight: ids of a batch, then its rows; both are fetched a batch ahead of their use (ids two ahead),
+// so a batch costs its arithmetic, not two dependent memory round trips.  Indices past the end are clamped to the last
+// id: such rows are loaded but never accumulated or stored.
+template <int NR> struct FbIds { unsigned row[svdpp_fbw<NR>::value]; float v[svdpp_fbw<NR>::value]; };
+template <int NR> struct FbRows { ChainRow<NR> w[svdpp_fbw<NR>::value]; float b[svdpp_fbw<NR>::value]; };
+template <int NR>
+__device__ __forceinline__ void fb_fetch_ids(const DevParams &P, const unsigned *fidx, const float *fval, int j0, int nfb, FbIds<NR> &o) {
 #pragma unroll
-        for (int c = 0; c < SVDPP_PF; c++) {
-            if (j0 + c < nrow) {
-                const SvdppRowPF &x = cur[c];
-                double bs = 0.0;                                   // calc_bias (:313-353)
-                if (ub) { bs += (double)(x.uv * bu); bs += (double)pp.tmp_bias; }
-                bs += (double)(x.iv * x.bi);
-                double sum = (double)P.base_score + bs;
-                float4 tu = pp.tmp_fb, ti = f4zero();              // prepare_tmp (:354-381, :506-508)
-                axpy4(tu, p, x.uv);
-                axpy4(ti, x.q, x.iv);
-                // (an LDS-staged variant of the dot -- every lane sums all chunks itself from shared memory -- was
-                // measured 1.6-1.9x SLOWER per row here than the DPP scan: 32 dependent-latency ds_read_b128)
-                sum += (double)group_dot<LPI>(tu, ti, L, P.k);
-                const float pred = map_active((float)sum, P.active_type);
-                const float err = cal_grad(x.label, pred, P.active_type) * 1.0f;
-                const float su = lr * err * x.uv;                  // update_no_decay (:383-427)
-                axpy4(p, ti, su);
-                if (ub) bu = bu + su;
-                const float si = lr * err * x.iv;
-                float4 w = x.q;
-                axpy4(w, tu, si);
-                float nbi = x.bi + si;
-                const float lr2 = lr * P.scale_lr_ufeedback;       // update_svdpp (:512-520)
-                axpy4(pp.tmp_fb, ti, lr2 * err * pp.norm);
-                scale4(pp.tmp_fb, 1.0f - lr2 * P.wd_ufeedback);
-                if (ub) {
-                    pp.tmp_bias = pp.tmp_bias + lr2 * err * pp.norm;
-                    pp.tmp_bias = pp.tmp_bias * (1.0f - lr2 * P.wd_ufeedback_bias);
-                }
-                reg_row<LPI>(P, p, wd_u, false, L);                // regularize(feature, true) (:286-311)
-                if (ub) bu = bu * (1.0f - lr * P.wd_user_bias);
-                reg_row<LPI>(P, w, get_wd(P.i_rng, x.irow - P.item_off, P.wd_item), true, L);
-                nbi = nbi * (1.0f - lr * P.wd_item_bias);
-                store_row<LPI>(P.W, x.irow, P.pitch, L, P.k, w);
-                if (L == 0) P.bias[x.irow] = nbi;
-            }
-        }
-#pragma unroll
-        for (int c = 0; c < SVDPP_PF; c++) cur[c] = nxt[c];
+    for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
+        const int j = min(j0 + c, nfb - 1);
+        o.row[c] = P.fb_off + fidx[j];
+        o.v[c] = fval[j];
     }
-    store_row<LPI>(P.W, urow, P.pitch, L, P.k, p);
-    if (ub && L == 0) P.bias[urow] = bu;
+}
+template <int NR>
+__device__ __forceinline__ void fb_fetch_rows(const DevParams &P, const FbIds<NR> &ids, bool ub, int lane, FbRows<NR> &o) {
+#pragma unroll
+    for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
+        o.w[c] = chain_load<NR>(P.W, ids.row[c], P.pitch, lane, P.k);
+        o.b[c] = ub ? P.bias[ids.row[c]] : 0.0f;
+    }
 }
 
-// Kernel 4: one conflict-free batch of user units; one lane group walks one user's rows in order
+// one simple unit, start to end, by one wave (u and everything derived from it is wave-uniform).
+// FAST: the configuration of every BASELINE run -- linear link, L2 decay (reg_method 0), user bias on, no per-range
+// decay, no nonnegativity clamp -- compiled without the per-row switches; anything else takes the general instantiation.
+template <int NR, bool FAST>
+__device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR &D, const DevUnit &u, const unsigned *fb_index,
+                                                const float *fb_value, int lane) {
+    const int k = P.k, pitch = P.pitch;
+    const bool ub = FAST ? true : P.no_user_bias == 0;
+    const unsigned *fidx = fb_index + u.fb_begin;
+    const float *fval = fb_value + u.fb_begin;
+    const int nfb = u.fb_end - u.fb_begin;
+    ChainRow<NR> tmp_fb = chain_zero<NR>(), old_fb = chain_zero<NR>();
+    float norm = 0.0f, tmp_bias = 0.0f, old_bias = 0.0f;
+    float *st = P.svdpp_state;
+    if (u.flags & UNIT_LOAD) {
+        tmp_fb = chain_load<NR>(st, 0, pitch, lane, k);
+        old_fb = chain_load<NR>(st, 1, pitch, lane, k);
+        norm = st[2 * pitch]; tmp_bias = st[2 * pitch + 1]; old_bias = st[2 * pitch + 2];
+    }
+    if (u.flags & UNIT_START) {   // prepare_ufeedback (:523-538)
+        norm = 0.0f; tmp_fb = chain_zero<NR>(); tmp_bias = 0.0f;
+        if (nfb > 0) {
+            FbIds<NR> ids0, ids1;
+            FbRows<NR> r0;
+            fb_fetch_ids<NR>(P, fidx, fval, 0, nfb, ids0);
+            fb_fetch_ids<NR>(P, fidx, fval, svdpp_fbw<NR>::value, nfb, ids1);
+            fb_fetch_rows<NR>(P, ids0, ub, lane, r0);
+            for (int j0 = 0; j0 < nfb; j0 += svdpp_fbw<NR>::value) {
+                FbRows<NR> r1;
+                FbIds<NR> ids2;
+                fb_fetch_rows<NR>(P, ids1, ub, lane, r1);
+                fb_fetch_ids<NR>(P, fidx, fval, j0 + 2 * svdpp_fbw<NR>::value, nfb, ids2);
+#pragma unroll
+                for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
+                    if (j0 + c < nfb) {
+                        chain_axpy(tmp_fb, r0.w[c], ids0.v[c]);
+                        norm = norm + ids0.v[c] * ids0.v[c];
+                        if (ub) tmp_bias = tmp_bias + r0.b[c] * ids0.v[c];
+                    }
+                }
+                r0 = r1; ids0 = ids1; ids1 = ids2;
+            }
+        }
+        old_bias = tmp_bias;
+        old_fb = tmp_fb;
+    }
+    const int nrow = u.row_end - u.row_begin;
+    if (nrow > 0) {
+        const int e0 = D.row_ptr[3 * (long)u.row_begin];   // rows are (0,1,1): entries of row j start at e0 + 2j
+        const unsigned urow = P.user_off + D.feat_index[e0];
+        ChainRow<NR> p = chain_load<NR>(P.W, urow, pitch, lane, k);
+        float bu = ub ? P.bias[urow] : 0.0f;
+        const float wd_u = FAST ? P.wd_user : get_wd(P.u_rng, urow - P.user_off, P.wd_user);
+        const float lr = P.lr;
+        // row-invariant scalars of update_svdpp and of the L2 decays, and whether their multiply is skipped
+        const float lr2 = lr * P.scale_lr_ufeedback;
+        const float dec_fb = 1.0f - lr2 * P.wd_ufeedback, dec_fbb = 1.0f - lr2 * P.wd_ufeedback_bias;
+        const float dec_u = 1.0f - lr * wd_u, dec_i = 1.0f - lr * P.wd_item;
+        const float dec_ub = 1.0f - lr * P.wd_user_bias, dec_ib = 1.0f - lr * P.wd_item_bias;
+        const bool dec_fb_one = scalar_is_one(dec_fb), dec_u_one = scalar_is_one(dec_u), dec_i_one = scalar_is_one(dec_i);
+        ChainRowPF<NR> cur[SVDPP_PFW], nxt[SVDPP_PFW];
+        chain_fetch_rows<NR>(P, D, u.row_begin, e0, 0, nrow, lane, cur);
+        for (int j0 = 0; j0 < nrow; j0 += SVDPP_PFW) {
+            chain_fetch_rows<NR>(P, D, u.row_begin, e0, j0 + SVDPP_PFW, nrow, lane, nxt);
+#pragma unroll
+            for (int c = 0; c < SVDPP_PFW; c++) {
+                if (j0 + c < nrow) {
+                    ChainRowPF<NR> &x = cur[c];
+                    if (x.fresh) {   // this item was written by an earlier row of the unit after (or while) it was fetched ahead
+                        x.q = chain_load<NR>(P.W, x.irow, pitch, lane, k);
+                        x.bi = P.bias[x.irow];
+                    }
+                    double bs = 0.0;                                   // calc_bias (:313-353)
+                    if (ub) { bs += (double)(x.uv * bu); bs += (double)tmp_bias; }
+                    bs += (double)(x.iv * x.bi);
+                    double sum = (double)P.base_score + bs;
+                    ChainRow<NR> tu = tmp_fb, ti = chain_zero<NR>();   // prepare_tmp (:354-381, :506-508)
+                    chain_axpy(tu, p, x.uv);
+                    chain_axpy(ti, x.q, x.iv);
+                    sum += (double)chain_dot(tu, ti, lane, k);
+                    const float pred = FAST ? (float)sum : map_active((float)sum, P.active_type);
+                    const float err = (FAST ? x.label - pred : cal_grad(x.label, pred, P.active_type)) * 1.0f;
+                    const float su = lr * err * x.uv;                  // update_no_decay (:383-427)
+                    chain_axpy(p, ti, su);
+                    if (ub) bu = bu + su;
+                    const float si = lr * err * x.iv;
+                    ChainRow<NR> w = x.q;
+                    chain_axpy(w, tu, si);
+                    float nbi = x.bi + si;
+                    chain_axpy(tmp_fb, ti, lr2 * err * norm);          // update_svdpp (:512-520)
+                    if (!dec_fb_one) {
+#pragma unroll
+                        for (int q = 0; q < NR; q++) tmp_fb.r[q] = tmp_fb.r[q] * dec_fb;
+                    }
+                    if (ub) {
+                        tmp_bias = tmp_bias + lr2 * err * norm;
+                        tmp_bias = tmp_bias * dec_fbb;
+                    }
+                    if (FAST) {                                        // regularize(feature, true) (:286-311), L2 form
+                        if (!dec_u_one) {
+#pragma unroll
+                            for (int q = 0; q < NR; q++) p.r[q] = p.r[q] * dec_u;
+                        }
+                        if (!dec_i_one) {
+#pragma unroll
+                            for (int q = 0; q < NR; q++) w.r[q] = w.r[q] * dec_i;
+                        }
+                    } else {
+                        chain_reg(P, p, wd_u, false, lane);
+                        chain_reg(P, w, get_wd(P.i_rng, x.irow - P.item_off, P.wd_item), true, lane);
+                    }
+                    if (ub) bu = bu * dec_ub;
+                    nbi = nbi * dec_ib;
+                    chain_store<NR>(P.W, x.irow, pitch, lane, k, w);
+                    if (lane == 0) P.bias[x.irow] = nbi;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < SVDPP_PFW; c++) cur[c] = nxt[c];
+        }
+        chain_store<NR>(P.W, urow, pitch, lane, k, p);
+        if (ub && lane == 0) P.bias[urow] = bu;
+    }
+    if ((u.flags & UNIT_END) && nfb > 0) {   // update_ufeedback (:539-554)
+        ChainRow<NR> d = tmp_fb;
+#pragma unroll
+        for (int q = 0; q < NR; q++) d.r[q] = d.r[q] - old_fb.r[q];   // K5
+        float db = tmp_bias - old_bias;
+        const float inv = 1.0f / norm;
+        chain_scale(d, inv);
+        db = db * inv;
+        tmp_fb = d; tmp_bias = db;   // the reference leaves the scaled delta in tmp_ufeedback
+        FbIds<NR> ids0, ids1;
+        FbRows<NR> r0;
+        fb_fetch_ids<NR>(P, fidx, fval, 0, nfb, ids0);
+        fb_fetch_ids<NR>(P, fidx, fval, svdpp_fbw<NR>::value, nfb, ids1);
+        fb_fetch_rows<NR>(P, ids0, ub, lane, r0);
+        for (int j0 = 0; j0 < nfb; j0 += svdpp_fbw<NR>::value) {
+            FbRows<NR> r1;
+            FbIds<NR> ids2;
+            fb_fetch_rows<NR>(P, ids1, ub, lane, r1);   // distinct ids: nothing fetched here is written below
+            fb_fetch_ids<NR>(P, fidx, fval, j0 + 2 * svdpp_fbw<NR>::value, nfb, ids2);
+#pragma unroll
+            for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
+                if (j0 + c < nfb) {
+                    chain_axpy(r0.w[c], d, ids0.v[c]);
+                    chain_store<NR>(P.W, ids0.row[c], pitch, lane, k, r0.w[c]);
+                    if (ub && lane == 0) P.bias[ids0.row[c]] = r0.b[c] + db * ids0.v[c];
+                }
+            }
+            r0 = r1; ids0 = ids1; ids1 = ids2;
+        }
+    }
+    if (u.flags & UNIT_SAVE) {
+        chain_store<NR>(st, 0, pitch, lane, k, tmp_fb);
+        chain_store<NR>(st, 1, pitch, lane, k, old_fb);
+        if (lane == 0) { st[2 * pitch] = norm; st[2 * pitch + 1] = tmp_bias; st[2 * pitch + 2] = old_bias; }
+    }
+}
+
+// Kernel 4a: the simple units of one conflict-free batch, one wave per user
+template <int NR, bool FAST>
+__global__ __launch_bounds__(64) void k_svdpp_wave(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
+                                                   const float *fb_value, const int *order, long begin, long end) {
+    const int lane = threadIdx.x & 63;
+    for (long s = begin + blockIdx.x; s < end; s += gridDim.x) {
+        const int uid = __builtin_amdgcn_readfirstlane(order ? order[s] : (int)s);
+        const DevUnit *up = units + uid;
+        DevUnit u;
+        u.fb_begin = __builtin_amdgcn_readfirstlane(up->fb_begin); u.fb_end = __builtin_amdgcn_readfirstlane(up->fb_end);
+        u.row_begin = __builtin_amdgcn_readfirstlane(up->row_begin); u.row_end = __builtin_amdgcn_readfirstlane(up->row_end);
+        u.flags = __builtin_amdgcn_readfirstlane(up->flags);
+        svdpp_unit_wave<NR, FAST>(P, D, u, fb_index, fb_value, lane);
+    }
+}
+
+// Kernel 4b: the other units of a conflict-free batch (any row shape); one lane group walks one user's rows in order
 template <int LPI, typename R>
 __global__ __launch_bounds__(256) void k_svdpp(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
                                                const float *fb_value, const int *order, long begin, long end, unsigned counter_base) {
@@ -1022,37 +1210,21 @@ __global__ __launch_bounds__(256) void k_svdpp(const DevParams P, const DevCSR D
     const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
     for (long s = begin + gidx; s < end; s += stride) {
         const DevUnit u = units[order ? order[s] : (int)s];
-        constexpr bool narrow = row_traits<R>::VPL == 1;   // the register-resident fast path exists for float4 rows only
-        const bool simple = narrow && (u.flags & UNIT_SIMPLE) != 0;
         SvdppRegsT<R> pp;
         if (u.flags & UNIT_LOAD) svdpp_load_state<LPI, R>(P, pp, L);
         if (u.flags & UNIT_START) {
-            bool done = false;
-            if constexpr (narrow) {
-                if (simple) { svdpp_prepare_batched<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L); done = true; }
-            }
-            if (!done) svdpp_prepare<LPI, R>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
+            svdpp_prepare<LPI, R>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
             pp.old_bias = pp.tmp_bias;
             pp.old_fb = pp.tmp_fb;
         }
-        bool rows_done = false;
-        if constexpr (narrow) {
-            if (simple) { svdpp_rows_simple<LPI>(P, D, u, pp, L); rows_done = true; }
-        }
-        if (!rows_done) {
+        {
             for (int r = u.row_begin; r < u.row_end; r++) {
                 const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
                 instance_update<LPI, R>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp,
                                         counter_base + (unsigned)r);
             }
         }
-        if (u.flags & UNIT_END) {
-            bool scattered = false;
-            if constexpr (narrow) {
-                if (simple) { svdpp_scatter_batched<LPI>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L); scattered = true; }
-            }
-            if (!scattered) svdpp_scatter<LPI, R>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
-        }
+        if (u.flags & UNIT_END) svdpp_scatter<LPI, R>(P, pp, fb_index + u.fb_begin, fb_value + u.fb_begin, u.fb_end - u.fb_begin, L);
         if (u.flags & UNIT_SAVE) svdpp_save_state<LPI, R>(P, pp, L);
     }
 }
@@ -1229,6 +1401,28 @@ void launch_svdpp(const DevParams &P, const DevCSR &D, const DevUnit *units, con
     const int lpi = lanes_per_instance(P.k);
     const int grid = grid_for(end - begin, lpi, 256 * 8);
     SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_svdpp<LPI, R>), dim3(grid), dim3(256), 0, st, P, D, units, fb_index, fb_value, order, begin, end, counter_base));
+}
+void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
+                       const int *order, long begin, long end, hipStream_t st) {
+    if (end <= begin) return;
+    long grid = end - begin;           // one 64-thread workgroup (= one wave) per user: a batch rarely holds more users than CUs
+    if (grid > 16384) grid = 16384;
+    const int nr = (P.k + 63) / 64;
+    const bool fast = P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 && P.user_nonnegative == 0 &&
+                      P.u_rng.n == 0 && P.i_rng.n == 0;
+#define SVDF_WAVE_CASE(NR_)                                                                                                            \
+    case NR_:                                                                                                                          \
+        if (fast) hipLaunchKernelGGL((k_svdpp_wave<NR_, true>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end); \
+        else hipLaunchKernelGGL((k_svdpp_wave<NR_, false>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end);    \
+        break;
+    switch (nr) {
+        SVDF_WAVE_CASE(1)
+        SVDF_WAVE_CASE(2)
+        SVDF_WAVE_CASE(3)
+    default:
+        SVDF_WAVE_CASE(4)
+    }
+#undef SVDF_WAVE_CASE
 }
 void launch_svdpp_predict(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
                           long nunit, float *out, hipStream_t st) {

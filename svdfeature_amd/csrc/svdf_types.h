@@ -120,6 +120,8 @@ struct DevCSR {
     const int *row_ptr;        // 3*num_row+1
     const unsigned *feat_index;
     const float *feat_value;
+    const unsigned char *row_fresh;   // user-unit streams only, may be null: 1 = this row's item already occurred earlier in
+                                      // the same fast-path unit, so its row / bias must be read when the row is reached
 };
 
 // One SVD++ unit = all rows of one user (START..END blocks concatenated).
@@ -130,7 +132,7 @@ struct DevUnit {
                                // bit2: save state at exit, bit3: load state at entry, bit4: UNIT_SIMPLE fast path
 };
 enum { UNIT_START = 1, UNIT_END = 2, UNIT_SAVE = 4, UNIT_LOAD = 8,
-       UNIT_SIMPLE = 16 };   // host-verified: rows are (0,1,1) with one user id, distinct item ids, distinct feedback ids
+       UNIT_SIMPLE = 16 };   // host-verified: rows are (0,1,1) with one user id, distinct feedback ids (repeated items: row_fresh)
 
 }  // namespace svdf
 // replicated (item-side) parameter ranges of the multi-GPU exchange, packed back to back: range r covers packed

@@ -387,16 +387,21 @@ def test_few_row_fused_kernel_matches_oracle_and_general_kernel(shape, k):
 @pytest.mark.parametrize("k", [16, 64, 128])
 @pytest.mark.parametrize("nobias", [0, 1])
 def test_svdpp_simple_unit_fast_path_and_block_dataset(k, nobias):
-    """User-group data as a resident dataset (svdf_dataset_from_blocks): register-resident fast path
-    (UNIT_SIMPLE: one user id, distinct items, distinct feedback ids) and the generic path
-    (use_simple_units=0) both byte-identical to the oracle; split users (START/MIDDLE/END) and users
-    with a repeated item (not simple) included."""
+    """User-group data as a resident dataset (svdf_dataset_from_blocks): wave-per-user fast path
+    (UNIT_SIMPLE: one user id per unit, distinct feedback ids) and the generic path
+    (use_simple_units=0) both byte-identical to the oracle; split users (START/MIDDLE/END), users
+    with a repeated item (fast path, the repeated rows re-read their item at use) and users with a
+    repeated feedback id (not simple: generic path) included."""
     nu, ni = 600, 500
     blocks = cases.user_blocks(400, nu, ni, ni, seed=k + nobias, max_rows=40, max_fb=30, split_every=6)
-    # make every 9th user rate one item twice -> that unit must take the generic path
-    for b in blocks[::9]:
+    for b in blocks[::9]:     # the same item twice, a few rows apart and far apart
         if b.data.num_row >= 2 and b.extend_tag == 0:
             b.data.feat_index[3] = b.data.feat_index[1]
+            if b.data.num_row >= 30:
+                b.data.feat_index[2 * 29 + 1] = b.data.feat_index[1]
+    for b in blocks[4::11]:   # a feedback id listed twice
+        if b.num_ufeedback >= 2 and b.extend_tag == 0:
+            b.index_ufeedback[1] = b.index_ufeedback[0]
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni, wd_ufeedback=0.004,
                            wd_ufeedback_bias=0.002, scale_lr_ufeedback=0.7, ufeedback_init_sigma=0.01, learning_rate=0.01,
                            no_user_bias=nobias, wd_user_bias=0.001)

@@ -5,8 +5,9 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import svdfeature_amd as sa
 from svdfeature_amd.data import CSRData, PlusBlock
-for K in (16, 32, 64, 128, 256):
-    for rows, nfb in ((400, 1), (1, 400)):
+KS = [int(x) for x in os.environ.get("SVDPP_K", "16,32,64,128,256").split(",")]
+for K in KS:
+    for rows, nfb in ((1, 1), (100, 1), (400, 1), (1, 100), (1, 400), (100, 100)):
         ni = max(rows, nfb) + 8
         t = sa.Trainer(1, 0)
         t.seed(10)
