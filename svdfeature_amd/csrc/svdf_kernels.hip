@@ -875,8 +875,8 @@ __device__ __forceinline__ void svdpp_scatter(const DevParams &P, SvdppRegsT<R> 
 //     (accumulation order unchanged).
 constexpr int SVDPP_PFW = 8;   // rows fetched ahead (double-buffered: 8..16 rows = 2..4 us of lookahead)
 // feedback rows per gather / scatter batch; two batches are in flight (HBM + translation latency is ~2 us, a batch of
-// 32 accumulates in ~0.8 us), bounded by the register file for the wider rows
-template <int NR> struct svdpp_fbw { static constexpr int value = NR <= 2 ? 32 : 16; };
+// 16 accumulates in ~0.4 us)
+template <int NR> struct svdpp_fbw { static constexpr int value = 16; };   // 32 measured slower (VGPRs spill to AGPRs)
 
 template <int NR>
 struct ChainRow { float r[NR]; };
@@ -896,19 +896,21 @@ template <int NR> __device__ __forceinline__ ChainRow<NR> chain_zero() {
     for (int q = 0; q < NR; q++) z.r[q] = 0.0f;
     return z;
 }
+// k < 0 tells the row is FULL (num_factor == 64*NR, the usual case): no per-lane bounds test, hence no exec-mask branch
+// around every load and store of the instruction-bound row loop
 template <int NR> __device__ __forceinline__ ChainRow<NR> chain_load(const float *W, size_t row, int pitch, int lane, int k) {
     const float *base = W + row * (size_t)pitch;
     const int e0 = 4 * (lane & 15) + (lane >> 4);
     ChainRow<NR> x;
 #pragma unroll
-    for (int q = 0; q < NR; q++) { const int e = e0 + 64 * q; x.r[q] = e < k ? base[e] : 0.0f; }
+    for (int q = 0; q < NR; q++) { const int e = e0 + 64 * q; x.r[q] = (k < 0 || e < k) ? base[e] : 0.0f; }
     return x;
 }
 template <int NR> __device__ __forceinline__ void chain_store(float *W, size_t row, int pitch, int lane, int k, const ChainRow<NR> &x) {
     float *base = W + row * (size_t)pitch;
     const int e0 = 4 * (lane & 15) + (lane >> 4);
 #pragma unroll
-    for (int q = 0; q < NR; q++) { const int e = e0 + 64 * q; if (e < k) base[e] = x.r[q]; }
+    for (int q = 0; q < NR; q++) { const int e = e0 + 64 * q; if (k < 0 || e < k) base[e] = x.r[q]; }
 }
 // K1 / K2 with a wave-uniform scalar
 template <int NR> __device__ __forceinline__ void chain_axpy(ChainRow<NR> &d, const ChainRow<NR> &s, float a) {
@@ -954,7 +956,7 @@ template <int NR> __device__ __forceinline__ float chain_dot(const ChainRow<NR> 
     return sum;
 }
 // reg_user / reg_item on a row in registers (reg modes 0..3; lazy modes never reach the fast path)
-template <int NR> __device__ __forceinline__ void chain_reg(const DevParams &P, ChainRow<NR> &w, float wd, bool is_item, int lane) {
+template <int NR> __device__ __forceinline__ void chain_reg(const DevParams &P, ChainRow<NR> &w, float wd, bool is_item, int lane, int k) {
     const float lambda = P.lr * wd;
     int method = P.reg_method;
     if (method == 3) method = is_item ? 0 : 1;
@@ -964,7 +966,7 @@ template <int NR> __device__ __forceinline__ void chain_reg(const DevParams &P, 
 #pragma unroll
         for (int q = 0; q < NR; q++) w.r[q] = l1(w.r[q], lambda);
     } else if (method == 2) {
-        const float sum = chain_dot(w, w, lane, P.k);
+        const float sum = chain_dot(w, w, lane, k);
         if (sum > wd) chain_scale(w, sqrtf(wd / sum));
     }
     if (!is_item && P.user_nonnegative) {
@@ -982,7 +984,7 @@ struct ChainRowPF {   // one prefetched row of a simple unit
 // rows beyond the unit's end re-fetch its last row (results unused, nothing stored); indices are clamped instead of
 // branched on so that all record loads, then all row loads of a batch are issued back to back
 template <int NR>
-__device__ __forceinline__ void chain_fetch_rows(const DevParams &P, const DevCSR &D, int row_begin, int e0, int j0, int nrow, int lane,
+__device__ __forceinline__ void chain_fetch_rows(const DevParams &P, const DevCSR &D, int row_begin, int e0, int j0, int nrow, int lane, int kio,
                                                  ChainRowPF<NR> (&o)[SVDPP_PFW]) {
 #pragma unroll
     for (int c = 0; c < SVDPP_PFW; c++) {
@@ -995,7 +997,7 @@ __device__ __forceinline__ void chain_fetch_rows(const DevParams &P, const DevCS
     }
 #pragma unroll
     for (int c = 0; c < SVDPP_PFW; c++) {
-        o[c].q = chain_load<NR>(P.W, o[c].irow, P.pitch, lane, P.k);
+        o[c].q = chain_load<NR>(P.W, o[c].irow, P.pitch, lane, kio);
         o[c].bi = P.bias[o[c].irow];
     }
 }
@@ -1015,10 +1017,10 @@ __device__ __forceinline__ void fb_fetch_ids(const DevParams &P, const unsigned 
     }
 }
 template <int NR>
-__device__ __forceinline__ void fb_fetch_rows(const DevParams &P, const FbIds<NR> &ids, bool ub, int lane, FbRows<NR> &o) {
+__device__ __forceinline__ void fb_fetch_rows(const DevParams &P, const FbIds<NR> &ids, bool ub, int lane, int kio, FbRows<NR> &o) {
 #pragma unroll
     for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
-        o.w[c] = chain_load<NR>(P.W, ids.row[c], P.pitch, lane, P.k);
+        o.w[c] = chain_load<NR>(P.W, ids.row[c], P.pitch, lane, kio);
         o.b[c] = ub ? P.bias[ids.row[c]] : 0.0f;
     }
 }
@@ -1026,10 +1028,13 @@ __device__ __forceinline__ void fb_fetch_rows(const DevParams &P, const FbIds<NR
 // one simple unit, start to end, by one wave (u and everything derived from it is wave-uniform).
 // FAST: the configuration of every BASELINE run -- linear link, L2 decay (reg_method 0), user bias on, no per-range
 // decay, no nonnegativity clamp -- compiled without the per-row switches; anything else takes the general instantiation.
-template <int NR, bool FAST>
+// FULL: num_factor == 64*NR, so no lane is ever out of the row and the dot has no masked chunks and no tail.
+template <int NR, bool FAST, bool FULL>
 __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR &D, const DevUnit &u, const unsigned *fb_index,
                                                 const float *fb_value, int lane) {
-    const int k = P.k, pitch = P.pitch;
+    const int pitch = P.pitch;
+    const int k = FULL ? 64 * NR : P.k;      // dot / projection width
+    const int kio = FULL ? -1 : P.k;         // bound of row loads / stores (-1: none)
     const bool ub = FAST ? true : P.no_user_bias == 0;
     const unsigned *fidx = fb_index + u.fb_begin;
     const float *fval = fb_value + u.fb_begin;
@@ -1038,8 +1043,8 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
     float norm = 0.0f, tmp_bias = 0.0f, old_bias = 0.0f;
     float *st = P.svdpp_state;
     if (u.flags & UNIT_LOAD) {
-        tmp_fb = chain_load<NR>(st, 0, pitch, lane, k);
-        old_fb = chain_load<NR>(st, 1, pitch, lane, k);
+        tmp_fb = chain_load<NR>(st, 0, pitch, lane, kio);
+        old_fb = chain_load<NR>(st, 1, pitch, lane, kio);
         norm = st[2 * pitch]; tmp_bias = st[2 * pitch + 1]; old_bias = st[2 * pitch + 2];
     }
     if (u.flags & UNIT_START) {   // prepare_ufeedback (:523-538)
@@ -1049,11 +1054,11 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
             FbRows<NR> r0;
             fb_fetch_ids<NR>(P, fidx, fval, 0, nfb, ids0);
             fb_fetch_ids<NR>(P, fidx, fval, svdpp_fbw<NR>::value, nfb, ids1);
-            fb_fetch_rows<NR>(P, ids0, ub, lane, r0);
+            fb_fetch_rows<NR>(P, ids0, ub, lane, kio, r0);
             for (int j0 = 0; j0 < nfb; j0 += svdpp_fbw<NR>::value) {
                 FbRows<NR> r1;
                 FbIds<NR> ids2;
-                fb_fetch_rows<NR>(P, ids1, ub, lane, r1);
+                fb_fetch_rows<NR>(P, ids1, ub, lane, kio, r1);
                 fb_fetch_ids<NR>(P, fidx, fval, j0 + 2 * svdpp_fbw<NR>::value, nfb, ids2);
 #pragma unroll
                 for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
@@ -1073,7 +1078,7 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
     if (nrow > 0) {
         const int e0 = D.row_ptr[3 * (long)u.row_begin];   // rows are (0,1,1): entries of row j start at e0 + 2j
         const unsigned urow = P.user_off + D.feat_index[e0];
-        ChainRow<NR> p = chain_load<NR>(P.W, urow, pitch, lane, k);
+        ChainRow<NR> p = chain_load<NR>(P.W, urow, pitch, lane, kio);
         float bu = ub ? P.bias[urow] : 0.0f;
         const float wd_u = FAST ? P.wd_user : get_wd(P.u_rng, urow - P.user_off, P.wd_user);
         const float lr = P.lr;
@@ -1084,15 +1089,15 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
         const float dec_ub = 1.0f - lr * P.wd_user_bias, dec_ib = 1.0f - lr * P.wd_item_bias;
         const bool dec_fb_one = scalar_is_one(dec_fb), dec_u_one = scalar_is_one(dec_u), dec_i_one = scalar_is_one(dec_i);
         ChainRowPF<NR> cur[SVDPP_PFW], nxt[SVDPP_PFW];
-        chain_fetch_rows<NR>(P, D, u.row_begin, e0, 0, nrow, lane, cur);
+        chain_fetch_rows<NR>(P, D, u.row_begin, e0, 0, nrow, lane, kio, cur);
         for (int j0 = 0; j0 < nrow; j0 += SVDPP_PFW) {
-            chain_fetch_rows<NR>(P, D, u.row_begin, e0, j0 + SVDPP_PFW, nrow, lane, nxt);
+            chain_fetch_rows<NR>(P, D, u.row_begin, e0, j0 + SVDPP_PFW, nrow, lane, kio, nxt);
 #pragma unroll
             for (int c = 0; c < SVDPP_PFW; c++) {
                 if (j0 + c < nrow) {
                     ChainRowPF<NR> &x = cur[c];
                     if (x.fresh) {   // this item was written by an earlier row of the unit after (or while) it was fetched ahead
-                        x.q = chain_load<NR>(P.W, x.irow, pitch, lane, k);
+                        x.q = chain_load<NR>(P.W, x.irow, pitch, lane, kio);
                         x.bi = P.bias[x.irow];
                     }
                     double bs = 0.0;                                   // calc_bias (:313-353)
@@ -1131,19 +1136,19 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
                             for (int q = 0; q < NR; q++) w.r[q] = w.r[q] * dec_i;
                         }
                     } else {
-                        chain_reg(P, p, wd_u, false, lane);
-                        chain_reg(P, w, get_wd(P.i_rng, x.irow - P.item_off, P.wd_item), true, lane);
+                        chain_reg(P, p, wd_u, false, lane, k);
+                        chain_reg(P, w, get_wd(P.i_rng, x.irow - P.item_off, P.wd_item), true, lane, k);
                     }
                     if (ub) bu = bu * dec_ub;
                     nbi = nbi * dec_ib;
-                    chain_store<NR>(P.W, x.irow, pitch, lane, k, w);
-                    if (lane == 0) P.bias[x.irow] = nbi;
+                    chain_store<NR>(P.W, x.irow, pitch, lane, kio, w);
+                    P.bias[x.irow] = nbi;   // every lane writes the same word: one request, and no exec-mask branch
                 }
             }
 #pragma unroll
             for (int c = 0; c < SVDPP_PFW; c++) cur[c] = nxt[c];
         }
-        chain_store<NR>(P.W, urow, pitch, lane, k, p);
+        chain_store<NR>(P.W, urow, pitch, lane, kio, p);
         if (ub && lane == 0) P.bias[urow] = bu;
     }
     if ((u.flags & UNIT_END) && nfb > 0) {   // update_ufeedback (:539-554)
@@ -1159,32 +1164,32 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
         FbRows<NR> r0;
         fb_fetch_ids<NR>(P, fidx, fval, 0, nfb, ids0);
         fb_fetch_ids<NR>(P, fidx, fval, svdpp_fbw<NR>::value, nfb, ids1);
-        fb_fetch_rows<NR>(P, ids0, ub, lane, r0);
+        fb_fetch_rows<NR>(P, ids0, ub, lane, kio, r0);
         for (int j0 = 0; j0 < nfb; j0 += svdpp_fbw<NR>::value) {
             FbRows<NR> r1;
             FbIds<NR> ids2;
-            fb_fetch_rows<NR>(P, ids1, ub, lane, r1);   // distinct ids: nothing fetched here is written below
+            fb_fetch_rows<NR>(P, ids1, ub, lane, kio, r1);   // distinct ids: nothing fetched here is written below
             fb_fetch_ids<NR>(P, fidx, fval, j0 + 2 * svdpp_fbw<NR>::value, nfb, ids2);
 #pragma unroll
             for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
                 if (j0 + c < nfb) {
                     chain_axpy(r0.w[c], d, ids0.v[c]);
-                    chain_store<NR>(P.W, ids0.row[c], pitch, lane, k, r0.w[c]);
-                    if (ub && lane == 0) P.bias[ids0.row[c]] = r0.b[c] + db * ids0.v[c];
+                    chain_store<NR>(P.W, ids0.row[c], pitch, lane, kio, r0.w[c]);
+                    if (ub) P.bias[ids0.row[c]] = r0.b[c] + db * ids0.v[c];
                 }
             }
             r0 = r1; ids0 = ids1; ids1 = ids2;
         }
     }
     if (u.flags & UNIT_SAVE) {
-        chain_store<NR>(st, 0, pitch, lane, k, tmp_fb);
-        chain_store<NR>(st, 1, pitch, lane, k, old_fb);
+        chain_store<NR>(st, 0, pitch, lane, kio, tmp_fb);
+        chain_store<NR>(st, 1, pitch, lane, kio, old_fb);
         if (lane == 0) { st[2 * pitch] = norm; st[2 * pitch + 1] = tmp_bias; st[2 * pitch + 2] = old_bias; }
     }
 }
 
 // Kernel 4a: the simple units of one conflict-free batch, one wave per user
-template <int NR, bool FAST>
+template <int NR, bool FAST, bool FULL>
 __global__ __launch_bounds__(64) void k_svdpp_wave(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
                                                    const float *fb_value, const int *order, long begin, long end) {
     const int lane = threadIdx.x & 63;
@@ -1195,7 +1200,7 @@ __global__ __launch_bounds__(64) void k_svdpp_wave(const DevParams P, const DevC
         u.fb_begin = __builtin_amdgcn_readfirstlane(up->fb_begin); u.fb_end = __builtin_amdgcn_readfirstlane(up->fb_end);
         u.row_begin = __builtin_amdgcn_readfirstlane(up->row_begin); u.row_end = __builtin_amdgcn_readfirstlane(up->row_end);
         u.flags = __builtin_amdgcn_readfirstlane(up->flags);
-        svdpp_unit_wave<NR, FAST>(P, D, u, fb_index, fb_value, lane);
+        svdpp_unit_wave<NR, FAST, FULL>(P, D, u, fb_index, fb_value, lane);
     }
 }
 
@@ -1410,11 +1415,15 @@ void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units
     const int nr = (P.k + 63) / 64;
     const bool fast = P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 && P.user_nonnegative == 0 &&
                       P.u_rng.n == 0 && P.i_rng.n == 0;
-#define SVDF_WAVE_CASE(NR_)                                                                                                            \
-    case NR_:                                                                                                                          \
-        if (fast) hipLaunchKernelGGL((k_svdpp_wave<NR_, true>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end); \
-        else hipLaunchKernelGGL((k_svdpp_wave<NR_, false>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end);    \
+#define SVDF_WAVE_LAUNCH(NR_, FAST_, FULL_) \
+    hipLaunchKernelGGL((k_svdpp_wave<NR_, FAST_, FULL_>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end)
+#define SVDF_WAVE_CASE(NR_)                                                        \
+    case NR_:                                                                      \
+        if (fast && full) SVDF_WAVE_LAUNCH(NR_, true, true);                       \
+        else if (fast) SVDF_WAVE_LAUNCH(NR_, true, false);                         \
+        else SVDF_WAVE_LAUNCH(NR_, false, false);                                  \
         break;
+    const bool full = P.k == 64 * nr;
     switch (nr) {
         SVDF_WAVE_CASE(1)
         SVDF_WAVE_CASE(2)
@@ -1422,6 +1431,7 @@ void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units
     default:
         SVDF_WAVE_CASE(4)
     }
+#undef SVDF_WAVE_LAUNCH
 #undef SVDF_WAVE_CASE
 }
 void launch_svdpp_predict(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
