@@ -164,6 +164,7 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     import torch
     import svdfeature_amd as sa
     from svdfeature_amd.multi_gpu import HipShard, ShardedTrainer, shard_windows
