@@ -150,6 +150,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--groups-per-wave", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--defer-tails", type=float, default=0.05,
+                    help="N>1: batches smaller than this fraction of a window's largest, at the end of the window, move to the next window (0 = off)")
     ap.add_argument("--use-graph", type=int, default=0, help="replay each resident dataset's pass as a captured hipGraph (0 = plain launches)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="debug: run the item-delta exchange path even with one rank (exercises the N>1 code on one GPU)")
@@ -167,7 +169,7 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     import torch
     import svdfeature_amd as sa
-    from svdfeature_amd.multi_gpu import HipShard, ShardedTrainer, shard_windows
+    from svdfeature_amd.multi_gpu import HipShard, ShardedTrainer, defer_tails, shard_windows
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     # debug only (1-GPU boxes): SVDF_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and exchanges through gloo, so the
     # whole N>1 flow (sharding, windows, exchange, timing, RMSE reduction) can be exercised without N GPUs
@@ -215,7 +217,10 @@ def main():
         per_item = a.ratings / max(a.items, 1)
         a.windows = max(1, int(np.ceil(per_item / (64.0 if world <= 2 else 32.0))))
     nwin = 1 if (world == 1 and not a.force_exchange) else a.windows
-    wins = adaptor.make_windows(shard_windows(u, i, r, rank, world, nwin))
+    shards = shard_windows(u, i, r, rank, world, nwin)
+    if nwin > 1 and a.defer_tails > 0:
+        shards = defer_tails(shards, a.users, a.items, a.defer_tails)
+    wins = adaptor.make_windows(shards)
     sched_s = time.time() - t0
     n_batches = sum(w.num_batches for w in wins)
     alg_bytes = sum(w.algorithmic_bytes for w in wins)

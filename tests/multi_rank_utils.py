@@ -5,7 +5,7 @@ import numpy as np
 import cases
 from oracle import oracle
 from svdfeature_amd import CSRData
-from svdfeature_amd.multi_gpu import shard_windows
+from svdfeature_amd.multi_gpu import defer_tails, shard_windows
 
 
 def make_oracle(conf, seed=10):
@@ -49,10 +49,15 @@ class OracleShard:
         self.t.set_view("i_bias", new[w.size:])
 
 
-def simulate(conf, u, i, r, world, windows, passes, seed=10):
-    """All ranks in one process, all-reduce replaced by an explicit sum in rank order."""
+def simulate(conf, u, i, r, world, windows, passes, seed=10, defer=0.0):
+    """All ranks in one process, all-reduce replaced by an explicit sum in rank order.  defer > 0: the window
+    lists go through multi_gpu.defer_tails like bench.py's (needs num_user / num_item in conf)."""
     ranks = [OracleShard(make_oracle(conf, seed)) for _ in range(world)]
-    wins = [a.make_windows(shard_windows(u, i, r, rk, world, windows)) for rk, a in enumerate(ranks)]
+    shards = [shard_windows(u, i, r, rk, world, windows) for rk in range(world)]
+    if defer > 0 and world > 1:
+        c = dict(conf)
+        shards = [defer_tails(sh, int(c["num_user"]), int(c["num_item"]), defer) for sh in shards]
+    wins = [a.make_windows(sh) for a, sh in zip(ranks, shards)]
     for _ in range(passes):
         for w in range(windows):
             if world == 1:

@@ -11,7 +11,7 @@ import pytest
 
 import cases
 from multi_rank_utils import OracleShard, make_oracle, merged_predict, simulate
-from svdfeature_amd.multi_gpu import ShardedTrainer, shard_by_user, shard_windows, window_bounds
+from svdfeature_amd.multi_gpu import ShardedTrainer, defer_tails, shard_by_user, shard_windows, window_bounds
 
 NU, NI = 3000, 400
 CONF = cases.conf_with(cases.BASICMF_CONF, num_user=NU, num_item=NI, num_factor=16)
@@ -102,6 +102,29 @@ def test_rmse_contract_of_the_exchange(world, windows):
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=16)
     ref = cases.rmse(merged_predict(simulate(conf, u, i, r, 1, 1, 5), 1, tu, ti, tr), tr)
     got = cases.rmse(merged_predict(simulate(conf, u, i, r, world, windows, 5), world, tu, ti, tr), tr)
+    assert abs(got - ref) <= 1e-4
+
+
+def test_deferred_tails_use_every_instance_once_and_keep_the_rmse_contract():
+    """multi_gpu.defer_tails (bench.py applies it for N > 1): the short trailing batches of a window move to the
+    next window.  Per rank the multiset of instances of a pass is unchanged, an instance moves by at most one
+    window, the last window keeps its tail; accuracy stays within the 1e-4 contract."""
+    nu, ni, n = 20000, 2000, 1_000_000
+    u, i, r = cases.planted_triples(n + 100_000, nu, ni, seed=5)
+    tu, ti, tr = u[n:], i[n:], r[n:]
+    u, i, r = u[:n], i[:n], r[:n]
+    world, windows = 8, 16
+    before = shard_windows(u, i, r, 3, world, windows)
+    after = defer_tails(before, nu, ni, 0.05)
+    key = lambda ws: np.sort(np.concatenate([x[0].astype(np.int64) * ni + x[1] for x in ws]))
+    np.testing.assert_array_equal(key(before), key(after))
+    moved = sum(abs(len(a[2]) - len(b[2])) for a, b in zip(before, after))
+    assert 0 < moved < 0.1 * sum(len(b[2]) for b in before)
+    cum_b, cum_a = np.cumsum([len(x[2]) for x in before]), np.cumsum([len(x[2]) for x in after])
+    assert np.all(cum_a <= cum_b) and cum_a[-1] == cum_b[-1] and np.all(cum_a[1:] >= cum_b[:-1])
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=16)
+    ref = cases.rmse(merged_predict(simulate(conf, u, i, r, 1, 1, 5), 1, tu, ti, tr), tr)
+    got = cases.rmse(merged_predict(simulate(conf, u, i, r, world, windows, 5, defer=0.05), world, tu, ti, tr), tr)
     assert abs(got - ref) <= 1e-4
 
 
