@@ -384,7 +384,7 @@ def test_few_row_fused_kernel_matches_oracle_and_general_kernel(shape, k):
     np.testing.assert_array_equal(t_ds.predict_dataset(ds).view(np.uint32), o.predict_batch(d).view(np.uint32))
 
 
-@pytest.mark.parametrize("k", [16, 64, 128])
+@pytest.mark.parametrize("k", [3, 10, 16, 33, 64, 100, 128, 130, 192, 203, 256])
 @pytest.mark.parametrize("nobias", [0, 1])
 def test_svdpp_simple_unit_fast_path_and_block_dataset(k, nobias):
     """User-group data as a resident dataset (svdf_dataset_from_blocks): wave-per-user fast path
@@ -751,3 +751,49 @@ def test_wide_rows_user_groups_and_regularisers(k, method):
     np.testing.assert_array_equal(t.view("W_item").view(np.uint32), o.view("W_item").view(np.uint32))
     with pytest.raises(sa.SvdfError, match="num_factor > 1024"):
         _ready(hip, 0, cases.conf_with(cases.BASICMF_CONF, num_factor=1025))
+
+
+@pytest.mark.parametrize("variant", ["l1", "project", "mixed3_nonneg", "ranges", "logistic"])
+@pytest.mark.parametrize("k", [24, 128])
+def test_svdpp_wave_path_general_configuration(variant, k):
+    """The one-wave-per-user kernel outside its specialised configuration (k_svdpp_wave<NR, FAST=false>): L1 / projection /
+    mixed regularisers, nonnegativity clamp, per-range decay, sigmoid link -- against the oracle, bit for bit (the
+    sigmoid case within the expf tolerance)."""
+    nu, ni = 300, 260
+    extra, kw, act = [], {}, 0
+    if variant == "l1":
+        kw = dict(reg_method=1, wd_user=0.02, wd_item=0.03)
+    elif variant == "project":
+        kw = dict(reg_method=2, wd_user=0.0008, wd_item=0.0009, ui_init_sigma=0.02)
+    elif variant == "mixed3_nonneg":
+        kw = dict(reg_method=3, wd_user=0.02, user_nonnegative=1)
+    elif variant == "ranges":
+        extra = [("up:wd", "0.01"), ("up:bound", "150"), ("up:wd", "0.001"), ("up:bound", str(nu)),
+                 ("ip:wd", "0.02"), ("ip:bound", "100"), ("ip:wd", "0.003"), ("ip:bound", str(ni))]
+    elif variant == "logistic":
+        act, kw = 2, dict(base_score=0.4)
+    blocks = cases.user_blocks(200, nu, ni, ni, seed=k, max_rows=25, max_fb=20, split_every=7,
+                               **({"binary_label": True} if variant == "logistic" else {}))
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni, wd_ufeedback=0.004,
+                           wd_ufeedback_bias=0.002, scale_lr_ufeedback=0.7, ufeedback_init_sigma=0.01, learning_rate=0.01, **kw) + extra
+
+    def make(mk):
+        t = mk(1, act)
+        t.seed(5)
+        for kk, v in conf:
+            t.set_param(kk, v)
+        t.init_model()
+        t.init_trainer()
+        return t
+    o, t = make(port), make(hip)
+    ds = t.dataset_from_blocks(blocks)
+    assert ds.num_simple_units > 0
+    for _ in range(2):
+        for b in blocks:
+            o.update_block(b)
+        t.train_dataset(ds)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "W_ufeedback", "ufeedback_bias"):
+        if variant == "logistic":
+            np.testing.assert_allclose(t.view(name), o.view(name), rtol=RTOL, atol=ATOL)
+        else:
+            np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
