@@ -863,11 +863,12 @@ __device__ __forceinline__ void svdpp_scatter(const DevParams &P, SvdppRegsT<R> 
 // number of dependent instructions per row, not bytes.  Layout for that: ONE WAVE PER USER, one element per lane and
 // register, arranged so that the reference's four SSE accumulation chains (elements j, j+4, j+8, ... for j = 0..3)
 // each live in their own 16-lane DPP row:
-//      lane = 16*j + m,  register q   <->   element 4*(m + 16*q) + j
-// The whole dot product is then ONE v_add_f32_dpp row_shr:1 per step for all four chains at once (15 steps per 64
-// factors, carry of register q-1 folded into lane m=0 through row_ror:1), against 4 instructions per step and
-// bpermute carries in the float4-per-lane layout; every elementwise op (axpy, decay, L1 ...) is k/64 instructions
-// instead of 4.  Measured on MI355X (tools/svdpp_latency2.py): DESIGN.md section 5.
+//      lane = 16*j + m,  register q   <->   element 4*(NR*m + q) + j        (NR = registers per row = ceil(k/64))
+// i.e. lane m of a DPP row holds the NR consecutive chunks NR*m .. NR*m+NR-1 of its chain.  The whole dot product
+// is then 15 steps of ONE v_add_f32_dpp row_shr:1 (all four chains at once) followed by NR-1 plain adds inside the
+// lane -- a dependent DPP add costs ~19 cycles, a plain one ~8, so wide rows pay 15 slow steps, not 16*NR-1 --
+// against 4 instructions per step and bpermute carries in the float4-per-lane layout; every elementwise op (axpy,
+// decay, L1 ...) is k/64 instructions instead of 4.  Measured on MI355X (tools/svdpp_latency2.py): DESIGN.md section 5.
 //   * the user's factor row, bias and the feedback state stay in registers for the whole unit,
 //   * item rows (and their records, via scalar loads: everything about a row is wave-uniform) are fetched
 //     SVDPP_PFW rows ahead, item rows are written once, fire and forget,
@@ -883,9 +884,6 @@ struct ChainRow { float r[NR]; };
 
 __device__ __forceinline__ float dpp_row_shr1(float v) {   // lane m <- lane m-1 of its 16-lane row, 0 into m = 0
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float dpp_row_ror1(float v) {   // lane m <- lane (m-1) mod 16: m = 0 receives lane 15
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));
 }
 __device__ __forceinline__ float lane_value(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
 __device__ __forceinline__ float wave_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
@@ -908,17 +906,17 @@ template <int NR> __device__ __forceinline__ ChainRow<NR> chain_zero() {
 // around every load and store of the instruction-bound row loop
 template <int NR> __device__ __forceinline__ ChainRow<NR> chain_load(const float *W, size_t row, int pitch, int lane, int k) {
     const float *base = W + row * (size_t)pitch;
-    const int e0 = 4 * (lane & 15) + (lane >> 4);
+    const int e0 = 4 * NR * (lane & 15) + (lane >> 4);
     ChainRow<NR> x;
 #pragma unroll
-    for (int q = 0; q < NR; q++) { const int e = e0 + 64 * q; x.r[q] = (k < 0 || e < k) ? base[e] : 0.0f; }
+    for (int q = 0; q < NR; q++) { const int e = e0 + 4 * q; x.r[q] = (k < 0 || e < k) ? base[e] : 0.0f; }
     return x;
 }
 template <int NR> __device__ __forceinline__ void chain_store(float *W, size_t row, int pitch, int lane, int k, const ChainRow<NR> &x) {
     float *base = W + row * (size_t)pitch;
-    const int e0 = 4 * (lane & 15) + (lane >> 4);
+    const int e0 = 4 * NR * (lane & 15) + (lane >> 4);
 #pragma unroll
-    for (int q = 0; q < NR; q++) { const int e = e0 + 64 * q; if (k < 0 || e < k) base[e] = x.r[q]; }
+    for (int q = 0; q < NR; q++) { const int e = e0 + 4 * q; if (k < 0 || e < k) base[e] = x.r[q]; }
 }
 // K1 / K2 with a wave-uniform scalar
 template <int NR> __device__ __forceinline__ void chain_axpy(ChainRow<NR> &d, const ChainRow<NR> &s, float a) {
@@ -936,27 +934,33 @@ template <int NR> __device__ __forceinline__ void chain_scale(ChainRow<NR> &d, f
         for (int q = 0; q < NR; q++) d.r[q] = d.r[q] * a;
     }
 }
-// K3 in the chain layout; the result is wave-uniform
+// K3 in the chain layout; the result is wave-uniform.  Lane m adds its NR chunks, in order, to the running sum handed
+// over by lane m-1; all lanes run the 15 hand-over steps (lanes below the step index are final already and recompute the
+// same value), so there is no select and no cross-register carry.
 template <int NR> __device__ __forceinline__ float chain_dot(const ChainRow<NR> &a, const ChainRow<NR> &b, int lane, int k) {
     const int nfull = k >> 2, ntail = k & 3, m = lane & 15;
-    float prod[NR];
-    float acc = 0.0f;
+    float prod[NR], c[NR];
 #pragma unroll
     for (int q = 0; q < NR; q++) {
         prod[q] = a.r[q] * b.r[q];
-        float c = (m + 16 * q < nfull) ? prod[q] : 0.0f;   // chunks beyond the full ones feed +0, the sums travel on
-        if (q > 0) { const float carry = dpp_row_ror1(acc); if (m == 0) c = carry + c; }
-        acc = 0.0f + c;
+        c[q] = (NR * m + q < nfull) ? prod[q] : 0.0f;   // chunks beyond the full ones feed +0, the sums travel on
+    }
+    float acc = 0.0f + c[0];
 #pragma unroll
-        for (int s = 1; s < 16; s++) acc = dpp_row_shr1(acc) + c;
+    for (int q = 1; q < NR; q++) acc = acc + c[q];
+#pragma unroll
+    for (int s = 1; s < 16; s++) {
+        acc = dpp_row_shr1(acc) + c[0];
+#pragma unroll
+        for (int q = 1; q < NR; q++) acc = acc + c[q];
     }
     const float s0 = lane_value(acc, 15), s1 = lane_value(acc, 31), s2 = lane_value(acc, 47), s3 = lane_value(acc, 63);
     float sum = (s0 + s2) + (s1 + s3);   // sum_all: movehl add, then shuffle add_ss
-    if (ntail) {                         // scalar tail, in index order: chunk nfull, SSE lanes 0..ntail-1
+    if (ntail) {                         // scalar tail, in index order: chunk nfull = lane nfull / NR, register nfull % NR
         float pt = prod[0];
 #pragma unroll
-        for (int q = 1; q < NR; q++) pt = (nfull >> 4) == q ? prod[q] : pt;
-        const int tm = nfull & 15;
+        for (int q = 1; q < NR; q++) pt = (nfull % NR) == q ? prod[q] : pt;
+        const int tm = nfull / NR;
         sum = sum + lane_value(pt, tm);
         if (ntail > 1) sum = sum + lane_value(pt, 16 + tm);
         if (ntail > 2) sum = sum + lane_value(pt, 32 + tm);
