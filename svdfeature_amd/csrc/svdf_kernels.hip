@@ -40,18 +40,20 @@ __device__ __forceinline__ float4 f4zero() { return make_float4(0.0f, 0.0f, 0.0f
 // below decides identically for every input (NaN included: both say "one") without fp64 instructions.
 __device__ __forceinline__ bool scalar_is_one(float s) { return !(fabsf(s - 1.0f) > 1e-6f); }
 
+// The skipped multiply, branch-free: x * 1.0f is x for every x (IEEE multiplication by one is exact, signs of zero and
+// infinities included), so "skip the multiply when |s-1| <= 1e-6" is the same as multiplying by exactly 1.0f then --
+// one select on the scalar instead of one per element.
+__device__ __forceinline__ float snap_to_one(float s) { return scalar_is_one(s) ? 1.0f : s; }
 // K1: dst += src*s (separate mul and add)
 __device__ __forceinline__ void axpy4(float4 &d, const float4 s, float a) {
-    if (scalar_is_one(a)) {
-        d.x = d.x + s.x; d.y = d.y + s.y; d.z = d.z + s.z; d.w = d.w + s.w;
-    } else {
-        float mx = s.x * a, my = s.y * a, mz = s.z * a, mw = s.w * a;
-        d.x = d.x + mx; d.y = d.y + my; d.z = d.z + mz; d.w = d.w + mw;
-    }
+    const float a1 = snap_to_one(a);
+    float mx = s.x * a1, my = s.y * a1, mz = s.z * a1, mw = s.w * a1;
+    d.x = d.x + mx; d.y = d.y + my; d.z = d.z + mz; d.w = d.w + mw;
 }
 // K2: dst *= s
 __device__ __forceinline__ void scale4(float4 &d, float a) {
-    if (!scalar_is_one(a)) { d.x = d.x * a; d.y = d.y * a; d.z = d.z * a; d.w = d.w * a; }
+    const float a1 = snap_to_one(a);
+    d.x = d.x * a1; d.y = d.y * a1; d.z = d.z * a1; d.w = d.w * a1;
 }
 __device__ __forceinline__ float l1(float w, float eps) {  // K6
     if (w > eps) return w - eps;
@@ -920,19 +922,14 @@ template <int NR> __device__ __forceinline__ void chain_store(float *W, size_t r
 }
 // K1 / K2 with a wave-uniform scalar
 template <int NR> __device__ __forceinline__ void chain_axpy(ChainRow<NR> &d, const ChainRow<NR> &s, float a) {
-    if (scalar_is_one(a)) {
+    const float a1 = snap_to_one(a);
 #pragma unroll
-        for (int q = 0; q < NR; q++) d.r[q] = d.r[q] + s.r[q];
-    } else {
-#pragma unroll
-        for (int q = 0; q < NR; q++) { const float m = s.r[q] * a; d.r[q] = d.r[q] + m; }
-    }
+    for (int q = 0; q < NR; q++) { const float m = s.r[q] * a1; d.r[q] = d.r[q] + m; }
 }
 template <int NR> __device__ __forceinline__ void chain_scale(ChainRow<NR> &d, float a) {
-    if (!scalar_is_one(a)) {
+    const float a1 = snap_to_one(a);
 #pragma unroll
-        for (int q = 0; q < NR; q++) d.r[q] = d.r[q] * a;
-    }
+    for (int q = 0; q < NR; q++) d.r[q] = d.r[q] * a1;
 }
 // K3 in the chain layout; the result is wave-uniform.  Lane m adds its NR chunks, in order, to the running sum handed
 // over by lane m-1; all lanes run the 15 hand-over steps (lanes below the step index are final already and recompute the
@@ -1099,7 +1096,7 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
         const float dec_fb = 1.0f - lr2 * P.wd_ufeedback, dec_fbb = 1.0f - lr2 * P.wd_ufeedback_bias;
         const float dec_u = 1.0f - lr * wd_u, dec_i = 1.0f - lr * P.wd_item;
         const float dec_ub = 1.0f - lr * P.wd_user_bias, dec_ib = 1.0f - lr * P.wd_item_bias;
-        const bool dec_fb_one = scalar_is_one(dec_fb), dec_u_one = scalar_is_one(dec_u), dec_i_one = scalar_is_one(dec_i);
+        const float dec_fb1 = snap_to_one(dec_fb), dec_u1 = snap_to_one(dec_u), dec_i1 = snap_to_one(dec_i);
         ChainRowPF<NR> cur[SVDPP_PFW], nxt[SVDPP_PFW];
         chain_fetch_rows<NR>(P, D, u.row_begin, e0, 0, nrow, lane, kio, cur);
         for (int j0 = 0; j0 < nrow; j0 += SVDPP_PFW) {
@@ -1139,23 +1136,17 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
                     chain_axpy(w, tu, si);
                     float nbi = x.bi + si;
                     chain_axpy(tmp_fb, ti, lr2 * err * norm);          // update_svdpp (:512-520)
-                    if (!dec_fb_one) {
 #pragma unroll
-                        for (int q = 0; q < NR; q++) tmp_fb.r[q] = tmp_fb.r[q] * dec_fb;
-                    }
+                    for (int q = 0; q < NR; q++) tmp_fb.r[q] = tmp_fb.r[q] * dec_fb1;
                     if (ub) {
                         tmp_bias = tmp_bias + lr2 * err * norm;
                         tmp_bias = tmp_bias * dec_fbb;
                     }
                     if (FAST) {                                        // regularize(feature, true) (:286-311), L2 form
-                        if (!dec_u_one) {
 #pragma unroll
-                            for (int q = 0; q < NR; q++) p.r[q] = p.r[q] * dec_u;
-                        }
-                        if (!dec_i_one) {
+                        for (int q = 0; q < NR; q++) p.r[q] = p.r[q] * dec_u1;
 #pragma unroll
-                            for (int q = 0; q < NR; q++) w.r[q] = w.r[q] * dec_i;
-                        }
+                        for (int q = 0; q < NR; q++) w.r[q] = w.r[q] * dec_i1;
                     } else {
                         chain_reg(P, p, wd_u, false, lane, k);
                         chain_reg(P, w, get_wd(P.i_rng, x.irow - P.item_off, P.wd_item), true, lane, k);
