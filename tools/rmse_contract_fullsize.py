@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--ratings", type=int, default=100_000_000); ap.add_argument("--users", type=int, default=1_000_000)
 ap.add_argument("--items", type=int, default=100_000); ap.add_argument("--factor", type=int, default=64)
 ap.add_argument("--passes", type=int, default=3); ap.add_argument("--ranks", default="2,4,8")
+ap.add_argument("--windows", default="", help="override: one window count per entry of --ranks (default: bench.py's rule)")
 a = ap.parse_args()
 n = a.ratings
 u, i, r = bench.synth_triples(n + 1_000_000, a.users, a.items)
@@ -44,9 +45,11 @@ for _ in range(a.passes): t.train_dataset(ds)
 ref = rmse([t], 1)
 print("sequential (1 GPU, exact): rmse %.6f after %d passes" % (ref, a.passes), flush=True)
 ds.close(); t.close()
-for world in [int(x) for x in a.ranks.split(",")]:
+worlds = [int(x) for x in a.ranks.split(",")]
+override = [int(x) for x in a.windows.split(",")] if a.windows else None
+for wi_, world in enumerate(worlds):
     per_item = a.ratings / a.items
-    windows = max(1, int(np.ceil(per_item / (64.0 if world <= 2 else 32.0))))
+    windows = override[wi_] if override else max(1, int(np.ceil(per_item / (64.0 if world <= 2 else 32.0))))
     t0 = time.time()
     ranks = []
     for rk in range(world):
