@@ -935,6 +935,8 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
     if (simple_ok && stamp_.size() < (size_t)n_uiset_) stamp_.assign((size_t)n_uiset_, -1);
     staged_fresh_.assign((size_t)staged_.num_row(), 0);
     any_fresh_ = false;
+    simple_unit_values_ = true;
+    const float *val = staged_.feat_value.data();
     for (long t = 0; t < nu; t++) {
         const HostUnit &u = staged_units_[(size_t)t];
         int lvl = base;
@@ -946,6 +948,7 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
             if (simple) {
                 simple = (p[1] == p[0]) && (p[2] == p[1] + 1) && (p[3] == p[2] + 1) && idx[p[1]] == uid0;
                 if (simple) {
+                    if (val[p[1]] != 1.0f || val[p[2]] != 1.0f) simple_unit_values_ = false;
                     const unsigned row = item_off_ + idx[p[2]];
                     if (stamp_[row] == (int)t) { staged_fresh_[(size_t)r] = 1; any_fresh_ = true; }   // the same item again: read at use
                     stamp_[row] = (int)t;
@@ -990,6 +993,7 @@ void Engine::upload_units(UnitDev &d, const Schedule &sched, const std::vector<D
     d.fbval.upload(staged_fb_value_.data(), staged_fb_value_.size(), stream_);
     d.units.upload(du.data(), du.size(), stream_);
     d.order.upload(sched.order.data(), sched.order.size(), stream_);
+    d.unit_values = simple_unit_values_;
     d.has_fresh = any_fresh_;
     if (any_fresh_) d.fresh.upload(staged_fresh_.data(), staged_fresh_.size(), stream_);
     HIPCHECK(hipStreamSynchronize(stream_));

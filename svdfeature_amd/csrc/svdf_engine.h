@@ -111,8 +111,8 @@ struct UnitDev {
     DevBuf<unsigned> index, fbidx;
     DevBuf<DevUnit> units;
     DevBuf<unsigned char> fresh;   // DevCSR::row_fresh (allocated only when some row needs it)
-    bool has_fresh = false;
-    DevCSR csr() const { return DevCSR{label.p, ptr.p, index.p, value.p, has_fresh ? fresh.p : nullptr}; }
+    bool has_fresh = false, unit_values = false;
+    DevCSR csr() const { return DevCSR{label.p, ptr.p, index.p, value.p, unit_values ? 1 : 0, has_fresh ? fresh.p : nullptr}; }
 };
 
 class Engine;
@@ -250,7 +250,7 @@ class Engine {
     int graph_min_levels_ = 2;
     uint64_t launch_version_ = 1;
     std::vector<unsigned char> staged_fresh_;   // per staged row, see DevCSR::row_fresh
-    bool any_fresh_ = false;
+    bool any_fresh_ = false, simple_unit_values_ = false;
     // lazy decay modes (apex_svd_base.h:95-97,157-170): the reference's sample_counter and per-id ref words
     unsigned sample_counter_ = 0;
     DevBuf<unsigned> d_ref_ui_, d_ref_global_;

@@ -1021,15 +1021,15 @@ struct ChainRowPF {   // one prefetched row of a simple unit
 };
 // rows beyond the unit's end re-fetch its last row (results unused, nothing stored); indices are clamped instead of
 // branched on so that all record loads, then all row loads of a batch are issued back to back
-template <int NR>
+template <int NR, bool UV>
 __device__ __forceinline__ void chain_fetch_rows(const DevParams &P, const DevCSR &D, int row_begin, int e0, int j0, int nrow, int lane, int kio,
                                                  ChainRowPF<NR> (&o)[SVDPP_PFW]) {
 #pragma unroll
     for (int c = 0; c < SVDPP_PFW; c++) {
         const int j = min(j0 + c, nrow - 1);
         o[c].label = uniform_load(D.row_label + row_begin + j);
-        o[c].uv = uniform_load(D.feat_value + e0 + 2 * j);
-        o[c].iv = uniform_load(D.feat_value + e0 + 2 * j + 1);
+        o[c].uv = UV ? 1.0f : uniform_load(D.feat_value + e0 + 2 * j);   // UV: host-verified all ones, not even loaded
+        o[c].iv = UV ? 1.0f : uniform_load(D.feat_value + e0 + 2 * j + 1);
         o[c].irow = P.item_off + uniform_load(D.feat_index + e0 + 2 * j + 1);
         o[c].fresh = D.row_fresh ? (int)uniform_load(D.row_fresh + row_begin + j) : 0;
     }
@@ -1067,7 +1067,8 @@ __device__ __forceinline__ void fb_fetch_rows(const DevParams &P, const FbIds<NR
 // FAST: the configuration of every BASELINE run -- linear link, L2 decay (reg_method 0), user bias on, no per-range
 // decay, no nonnegativity clamp -- compiled without the per-row switches; anything else takes the general instantiation.
 // FULL: num_factor == 64*NR, so no lane is ever out of the row and the dot has no masked chunks and no tail.
-template <int NR, bool FAST, bool FULL>
+// UV: every feature value of the fast-path units is 1.0 (the usual rating data): values are compile-time constants.
+template <int NR, bool FAST, bool FULL, bool UV>
 __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR &D, const DevUnit &u, const unsigned *fb_index,
                                                 const float *fb_value, int lane) {
     const int pitch = P.pitch;
@@ -1127,9 +1128,9 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
         const float dec_ub = 1.0f - lr * P.wd_user_bias, dec_ib = 1.0f - lr * P.wd_item_bias;
         const float dec_fb1 = snap_to_one(dec_fb), dec_u1 = snap_to_one(dec_u), dec_i1 = snap_to_one(dec_i);
         ChainRowPF<NR> cur[SVDPP_PFW], nxt[SVDPP_PFW];
-        chain_fetch_rows<NR>(P, D, u.row_begin, e0, 0, nrow, lane, kio, cur);
+        chain_fetch_rows<NR, UV>(P, D, u.row_begin, e0, 0, nrow, lane, kio, cur);
         for (int j0 = 0; j0 < nrow; j0 += SVDPP_PFW) {
-            chain_fetch_rows<NR>(P, D, u.row_begin, e0, j0 + SVDPP_PFW, nrow, lane, kio, nxt);
+            chain_fetch_rows<NR, UV>(P, D, u.row_begin, e0, j0 + SVDPP_PFW, nrow, lane, kio, nxt);
 #pragma unroll
             for (int c = 0; c < SVDPP_PFW; c++) {
                 if (j0 + c < nrow) {
@@ -1230,7 +1231,7 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
 }
 
 // Kernel 4a: the simple units of one conflict-free batch, one wave per user
-template <int NR, bool FAST, bool FULL>
+template <int NR, bool FAST, bool FULL, bool UV>
 __global__ __launch_bounds__(64) void k_svdpp_wave(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
                                                    const float *fb_value, const int *order, long begin, long end) {
     const int lane = threadIdx.x & 63;
@@ -1241,7 +1242,7 @@ __global__ __launch_bounds__(64) void k_svdpp_wave(const DevParams P, const DevC
         u.fb_begin = __builtin_amdgcn_readfirstlane(up->fb_begin); u.fb_end = __builtin_amdgcn_readfirstlane(up->fb_end);
         u.row_begin = __builtin_amdgcn_readfirstlane(up->row_begin); u.row_end = __builtin_amdgcn_readfirstlane(up->row_end);
         u.flags = __builtin_amdgcn_readfirstlane(up->flags);
-        svdpp_unit_wave<NR, FAST, FULL>(P, D, u, fb_index, fb_value, lane);
+        svdpp_unit_wave<NR, FAST, FULL, UV>(P, D, u, fb_index, fb_value, lane);
     }
 }
 
@@ -1461,13 +1462,14 @@ void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units
     const int nr = (P.k + 63) / 64;
     const bool fast = P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 && P.user_nonnegative == 0 &&
                       P.u_rng.n == 0 && P.i_rng.n == 0;
-#define SVDF_WAVE_LAUNCH(NR_, FAST_, FULL_) \
-    hipLaunchKernelGGL((k_svdpp_wave<NR_, FAST_, FULL_>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end)
+#define SVDF_WAVE_LAUNCH(NR_, FAST_, FULL_, UV_) \
+    hipLaunchKernelGGL((k_svdpp_wave<NR_, FAST_, FULL_, UV_>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end)
 #define SVDF_WAVE_CASE(NR_)                                                        \
     case NR_:                                                                      \
-        if (fast && full) SVDF_WAVE_LAUNCH(NR_, true, true);                       \
-        else if (fast) SVDF_WAVE_LAUNCH(NR_, true, false);                         \
-        else SVDF_WAVE_LAUNCH(NR_, false, false);                                  \
+        if (fast && full && D.unit_values) SVDF_WAVE_LAUNCH(NR_, true, true, true);  \
+        else if (fast && full) SVDF_WAVE_LAUNCH(NR_, true, true, false);           \
+        else if (fast) SVDF_WAVE_LAUNCH(NR_, true, false, false);                  \
+        else SVDF_WAVE_LAUNCH(NR_, false, false, false);                           \
         break;
     const bool full = P.k == 64 * nr;
     switch (nr) {

@@ -120,6 +120,7 @@ struct DevCSR {
     const int *row_ptr;        // 3*num_row+1
     const unsigned *feat_index;
     const float *feat_value;
+    int unit_values;                  // user-unit streams only: 1 = every row of every fast-path unit has feature values 1.0
     const unsigned char *row_fresh;   // user-unit streams only, may be null: 1 = this row's item already occurred earlier in
                                       // the same fast-path unit, so its row / bias must be read when the row is reached
 };
