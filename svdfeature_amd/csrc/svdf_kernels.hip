@@ -909,6 +909,9 @@ constexpr int SVDPP_PFW = 8;   // rows fetched ahead (double-buffered: 8..16 row
 // feedback rows per gather / scatter batch; two batches are in flight (HBM + translation latency is ~2 us, a batch of
 // 16 accumulates in ~0.4 us)
 template <int NR> struct svdpp_fbw { static constexpr int value = 16; };   // 32 measured slower (VGPRs spill to AGPRs)
+// batches of feedback rows in flight ahead of the one being accumulated / scattered (2 measured no faster than 1:
+// 64.3 vs 62.1 us for a unit of 100 rows + 100 ids at k=128 -- the phase is bound by the loads' issue, not their latency)
+template <int NR> struct svdpp_fbdepth { static constexpr int value = 1; };
 
 template <int NR>
 struct ChainRow { float r[NR]; };
@@ -1040,26 +1043,33 @@ __device__ __forceinline__ void chain_fetch_rows(const DevParams &P, const DevCS
     }
 }
 
-// feedback rows in flight: ids of a batch, then its rows; both are fetched a batch ahead of their use (ids two ahead),
-// so a batch costs its arithmetic, not two dependent memory round trips.  Indices past the end are clamped to the last
-// id: such rows are loaded but never accumulated or stored.
-template <int NR> struct FbIds { unsigned row[svdpp_fbw<NR>::value]; float v[svdpp_fbw<NR>::value]; };
+// Feedback ids and values of a user, 64 at a time: lane l of the wave holds entry first + l (clamped to the last one), loaded
+// with ONE coalesced vector load per 64 entries; an entry is picked with v_readlane right where it is used.  (Fetching
+// them one by one through the scalar unit serialises: each s_load result was spilled to a VGPR lane behind its own
+// lgkmcnt(0) wait -- three batches of ids do not fit the SGPR file -- 0.12 us per id.)
+struct FbBlock {
+    unsigned id;   // this lane's feedback id
+    float v;       // and its value
+};
+__device__ __forceinline__ FbBlock fb_block(const unsigned *fidx, const float *fval, int first, int nfb, int lane) {
+    const int j = min(first + lane, nfb - 1);
+    FbBlock b;
+    b.id = fidx[j];
+    b.v = fval[j];
+    return b;
+}
+__device__ __forceinline__ unsigned fb_id(const FbBlock &b, int l) { return (unsigned)__builtin_amdgcn_readlane((int)b.id, l); }
+__device__ __forceinline__ float fb_val(const FbBlock &b, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b.v), l)); }
+// rows of one batch (entries off .. off+FBW-1 of block b); indices past the end were clamped when the block was loaded:
+// such rows are fetched but never accumulated or stored
 template <int NR> struct FbRows { ChainRow<NR> w[svdpp_fbw<NR>::value]; float b[svdpp_fbw<NR>::value]; };
 template <int NR>
-__device__ __forceinline__ void fb_fetch_ids(const DevParams &P, const unsigned *fidx, const float *fval, int j0, int nfb, FbIds<NR> &o) {
+__device__ __forceinline__ void fb_fetch_rows(const DevParams &P, const FbBlock &blk, int off, bool ub, int lane, int kio, FbRows<NR> &o) {
 #pragma unroll
     for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
-        const int j = min(j0 + c, nfb - 1);
-        o.row[c] = P.fb_off + uniform_load(fidx + j);
-        o.v[c] = uniform_load(fval + j);
-    }
-}
-template <int NR>
-__device__ __forceinline__ void fb_fetch_rows(const DevParams &P, const FbIds<NR> &ids, bool ub, int lane, int kio, FbRows<NR> &o) {
-#pragma unroll
-    for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
-        o.w[c] = chain_load<NR>(P.W, ids.row[c], P.pitch, lane, kio);
-        o.b[c] = ub ? P.bias[ids.row[c]] : 0.0f;
+        const unsigned row = P.fb_off + fb_id(blk, off + c);
+        o.w[c] = chain_load<NR>(P.W, row, P.pitch, lane, kio);
+        o.b[c] = ub ? P.bias[row] : 0.0f;
     }
 }
 
@@ -1089,25 +1099,37 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
     if (u.flags & UNIT_START) {   // prepare_ufeedback (:523-538)
         norm = 0.0f; tmp_fb = chain_zero<NR>(); tmp_bias = 0.0f;
         if (nfb > 0) {
-            FbIds<NR> ids0, ids1;
-            FbRows<NR> r0;
-            fb_fetch_ids<NR>(P, fidx, fval, 0, nfb, ids0);
-            fb_fetch_ids<NR>(P, fidx, fval, svdpp_fbw<NR>::value, nfb, ids1);
-            fb_fetch_rows<NR>(P, ids0, ub, lane, kio, r0);
-            for (int j0 = 0; j0 < nfb; j0 += svdpp_fbw<NR>::value) {
-                FbRows<NR> r1;
-                FbIds<NR> ids2;
-                fb_fetch_rows<NR>(P, ids1, ub, lane, kio, r1);
-                fb_fetch_ids<NR>(P, fidx, fval, j0 + 2 * svdpp_fbw<NR>::value, nfb, ids2);
+            static_assert(64 % svdpp_fbw<NR>::value == 0, "a batch must not straddle two id blocks");
+            // queue slot 0: the batch being accumulated; slots 1..DEPTH: batches whose rows are in flight; blkn: the id
+            // block after the newest slot's, loaded a block ahead
+            constexpr int FBW = svdpp_fbw<NR>::value, DEPTH = svdpp_fbdepth<NR>::value;
+            FbBlock blk[DEPTH + 1], blkn;
+            int off[DEPTH + 1];
+            FbRows<NR> rq[DEPTH + 1];
+            blk[0] = fb_block(fidx, fval, 0, nfb, lane);
+            blkn = fb_block(fidx, fval, 64, nfb, lane);
+            off[0] = 0;
+            fb_fetch_rows<NR>(P, blk[0], 0, ub, lane, kio, rq[0]);
 #pragma unroll
-                for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
+            for (int d = 1; d <= DEPTH; d++) {   // (DEPTH * FBW < 64: the first batches all sit in the first block)
+                blk[d] = blk[0]; off[d] = d * FBW;
+                if (d < DEPTH) fb_fetch_rows<NR>(P, blk[d], off[d], ub, lane, kio, rq[d]);
+            }
+            for (int j0 = 0; j0 < nfb; j0 += FBW) {
+                off[DEPTH] = (j0 + DEPTH * FBW) & 63;
+                if (off[DEPTH] == 0) { blk[DEPTH] = blkn; blkn = fb_block(fidx, fval, j0 + DEPTH * FBW + 64, nfb, lane); }
+                fb_fetch_rows<NR>(P, blk[DEPTH], off[DEPTH], ub, lane, kio, rq[DEPTH]);
+#pragma unroll
+                for (int c = 0; c < FBW; c++) {
                     if (j0 + c < nfb) {
-                        chain_axpy(tmp_fb, r0.w[c], ids0.v[c]);
-                        norm = norm + ids0.v[c] * ids0.v[c];
-                        if (ub) tmp_bias = tmp_bias + r0.b[c] * ids0.v[c];
+                        const float v = fb_val(blk[0], off[0] + c);
+                        chain_axpy(tmp_fb, rq[0].w[c], v);
+                        norm = norm + v * v;
+                        if (ub) tmp_bias = tmp_bias + rq[0].b[c] * v;
                     }
                 }
-                r0 = r1; ids0 = ids1; ids1 = ids2;
+#pragma unroll
+                for (int d = 0; d < DEPTH; d++) { rq[d] = rq[d + 1]; blk[d] = blk[d + 1]; off[d] = off[d + 1]; }
             }
         }
         old_bias = tmp_bias;
@@ -1202,25 +1224,35 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
         chain_scale(d, inv);
         db = db * inv;
         tmp_fb = d; tmp_bias = db;   // the reference leaves the scaled delta in tmp_ufeedback
-        FbIds<NR> ids0, ids1;
-        FbRows<NR> r0;
-        fb_fetch_ids<NR>(P, fidx, fval, 0, nfb, ids0);
-        fb_fetch_ids<NR>(P, fidx, fval, svdpp_fbw<NR>::value, nfb, ids1);
-        fb_fetch_rows<NR>(P, ids0, ub, lane, kio, r0);
-        for (int j0 = 0; j0 < nfb; j0 += svdpp_fbw<NR>::value) {
-            FbRows<NR> r1;
-            FbIds<NR> ids2;
-            fb_fetch_rows<NR>(P, ids1, ub, lane, kio, r1);   // distinct ids: nothing fetched here is written below
-            fb_fetch_ids<NR>(P, fidx, fval, j0 + 2 * svdpp_fbw<NR>::value, nfb, ids2);
+        constexpr int FBW = svdpp_fbw<NR>::value, DEPTH = svdpp_fbdepth<NR>::value;
+        FbBlock blk[DEPTH + 1], blkn;
+        int off[DEPTH + 1];
+        FbRows<NR> rq[DEPTH + 1];
+        blk[0] = fb_block(fidx, fval, 0, nfb, lane);
+        blkn = fb_block(fidx, fval, 64, nfb, lane);
+        off[0] = 0;
+        fb_fetch_rows<NR>(P, blk[0], 0, ub, lane, kio, rq[0]);
 #pragma unroll
-            for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
+        for (int d = 1; d <= DEPTH; d++) {
+            blk[d] = blk[0]; off[d] = d * FBW;
+            if (d < DEPTH) fb_fetch_rows<NR>(P, blk[d], off[d], ub, lane, kio, rq[d]);
+        }
+        for (int j0 = 0; j0 < nfb; j0 += FBW) {
+            off[DEPTH] = (j0 + DEPTH * FBW) & 63;
+            if (off[DEPTH] == 0) { blk[DEPTH] = blkn; blkn = fb_block(fidx, fval, j0 + DEPTH * FBW + 64, nfb, lane); }
+            fb_fetch_rows<NR>(P, blk[DEPTH], off[DEPTH], ub, lane, kio, rq[DEPTH]);   // distinct ids: nothing fetched here is written below
+#pragma unroll
+            for (int c = 0; c < FBW; c++) {
                 if (j0 + c < nfb) {
-                    chain_axpy(r0.w[c], d, ids0.v[c]);
-                    chain_store<NR>(P.W, ids0.row[c], pitch, lane, kio, r0.w[c]);
-                    if (ub) P.bias[ids0.row[c]] = r0.b[c] + db * ids0.v[c];
+                    const float v = fb_val(blk[0], off[0] + c);
+                    const unsigned row = P.fb_off + fb_id(blk[0], off[0] + c);
+                    chain_axpy(rq[0].w[c], d, v);
+                    chain_store<NR>(P.W, row, pitch, lane, kio, rq[0].w[c]);
+                    if (ub) P.bias[row] = rq[0].b[c] + db * v;
                 }
             }
-            r0 = r1; ids0 = ids1; ids1 = ids2;
+#pragma unroll
+            for (int q = 0; q < DEPTH; q++) { rq[q] = rq[q + 1]; blk[q] = blk[q + 1]; off[q] = off[q + 1]; }
         }
     }
     if (u.flags & UNIT_SAVE) {
