@@ -1015,29 +1015,39 @@ template <int NR> __device__ __forceinline__ void chain_reg(const DevParams &P, 
         for (int q = 0; q < NR; q++) if (w.r[q] <= 0.0f) w.r[q] = 0.0f;
     }
 }
-template <int NR>
-struct ChainRowPF {   // one prefetched row of a simple unit
-    ChainRow<NR> q;
-    float bi, label, uv, iv;
-    unsigned irow;
+// Records of a user's rows, 64 rows at a time, one row per lane (same scheme as FbBlock below): label, item id, the
+// re-read flag and -- unless the unit-value specialisation applies -- the two feature values
+struct RowBlock {
+    float label, uv, iv;
+    unsigned item;
     int fresh;
 };
-// rows beyond the unit's end re-fetch its last row (results unused, nothing stored); indices are clamped instead of
-// branched on so that all record loads, then all row loads of a batch are issued back to back
-template <int NR, bool UV>
-__device__ __forceinline__ void chain_fetch_rows(const DevParams &P, const DevCSR &D, int row_begin, int e0, int j0, int nrow, int lane, int kio,
-                                                 ChainRowPF<NR> (&o)[SVDPP_PFW]) {
+template <bool UV>
+__device__ __forceinline__ RowBlock row_block(const DevCSR &D, int row_begin, int e0, int first, int nrow, int lane) {
+    const int j = min(first + lane, nrow - 1);   // rows beyond the unit's end repeat its last row (fetched, never used)
+    RowBlock b;
+    b.label = D.row_label[row_begin + j];
+    b.item = D.feat_index[e0 + 2 * j + 1];
+    b.fresh = D.row_fresh ? (int)D.row_fresh[row_begin + j] : 0;
+    b.uv = UV ? 1.0f : D.feat_value[e0 + 2 * j];
+    b.iv = UV ? 1.0f : D.feat_value[e0 + 2 * j + 1];
+    return b;
+}
+__device__ __forceinline__ float pick(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int pick(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ unsigned pick(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+template <int NR>
+struct ChainRowPF {   // the fetched-ahead part of one row: the item's factor row and bias (its id for the store)
+    ChainRow<NR> q;
+    float bi;
+    unsigned irow;
+};
+// the SVDPP_PFW rows at offsets off .. off+SVDPP_PFW-1 of block b
+template <int NR>
+__device__ __forceinline__ void chain_fetch_rows(const DevParams &P, const RowBlock &b, int off, int lane, int kio, ChainRowPF<NR> (&o)[SVDPP_PFW]) {
 #pragma unroll
     for (int c = 0; c < SVDPP_PFW; c++) {
-        const int j = min(j0 + c, nrow - 1);
-        o[c].label = uniform_load(D.row_label + row_begin + j);
-        o[c].uv = UV ? 1.0f : uniform_load(D.feat_value + e0 + 2 * j);   // UV: host-verified all ones, not even loaded
-        o[c].iv = UV ? 1.0f : uniform_load(D.feat_value + e0 + 2 * j + 1);
-        o[c].irow = P.item_off + uniform_load(D.feat_index + e0 + 2 * j + 1);
-        o[c].fresh = D.row_fresh ? (int)uniform_load(D.row_fresh + row_begin + j) : 0;
-    }
-#pragma unroll
-    for (int c = 0; c < SVDPP_PFW; c++) {
+        o[c].irow = P.item_off + pick(b.item, off + c);
         o[c].q = chain_load<NR>(P.W, o[c].irow, P.pitch, lane, kio);
         o[c].bi = P.bias[o[c].irow];
     }
@@ -1149,15 +1159,25 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
         const float dec_u = 1.0f - lr * wd_u, dec_i = 1.0f - lr * P.wd_item;
         const float dec_ub = 1.0f - lr * P.wd_user_bias, dec_ib = 1.0f - lr * P.wd_item_bias;
         const float dec_fb1 = snap_to_one(dec_fb), dec_u1 = snap_to_one(dec_u), dec_i1 = snap_to_one(dec_i);
+        static_assert(64 % SVDPP_PFW == 0, "a group of rows must not straddle two record blocks");
+        // rb_cur / rb_pre: record blocks of the group being processed / being fetched ahead; rb_next: the block after rb_pre's
+        RowBlock rb_cur = row_block<UV>(D, u.row_begin, e0, 0, nrow, lane), rb_pre = rb_cur;
+        RowBlock rb_next = row_block<UV>(D, u.row_begin, e0, 64, nrow, lane);
         ChainRowPF<NR> cur[SVDPP_PFW], nxt[SVDPP_PFW];
-        chain_fetch_rows<NR, UV>(P, D, u.row_begin, e0, 0, nrow, lane, kio, cur);
+        chain_fetch_rows<NR>(P, rb_cur, 0, lane, kio, cur);
         for (int j0 = 0; j0 < nrow; j0 += SVDPP_PFW) {
-            chain_fetch_rows<NR, UV>(P, D, u.row_begin, e0, j0 + SVDPP_PFW, nrow, lane, kio, nxt);
+            const int off_pre = (j0 + SVDPP_PFW) & 63, off_cur = j0 & 63;
+            if (off_pre == 0) { rb_pre = rb_next; rb_next = row_block<UV>(D, u.row_begin, e0, j0 + SVDPP_PFW + 64, nrow, lane); }
+            chain_fetch_rows<NR>(P, rb_pre, off_pre, lane, kio, nxt);
 #pragma unroll
             for (int c = 0; c < SVDPP_PFW; c++) {
                 if (j0 + c < nrow) {
-                    ChainRowPF<NR> &x = cur[c];
-                    if (x.fresh) {   // this item was written by an earlier row of the unit after (or while) it was fetched ahead
+                    struct { ChainRow<NR> q; float bi, label, uv, iv; unsigned irow; } x;
+                    x.q = cur[c].q; x.bi = cur[c].bi; x.irow = cur[c].irow;
+                    x.label = pick(rb_cur.label, off_cur + c);
+                    x.uv = UV ? 1.0f : pick(rb_cur.uv, off_cur + c);
+                    x.iv = UV ? 1.0f : pick(rb_cur.iv, off_cur + c);
+                    if (pick(rb_cur.fresh, off_cur + c)) {   // this item was written by an earlier row of the unit after (or while) it was fetched ahead
                         // The re-read must be COMPLETE before this block is left: loads and stores share one in-order
                         // counter on gfx9, and a load still pending at the join would make every row of the common
                         // path wait for everything in flight (measured 0.54 instead of 0.41 us per row at k=128).  The
@@ -1211,6 +1231,7 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
             }
 #pragma unroll
             for (int c = 0; c < SVDPP_PFW; c++) cur[c] = nxt[c];
+            rb_cur = rb_pre;
         }
         chain_store<NR>(P.W, urow, pitch, lane, kio, p);
         if (ub && lane == 0) P.bias[urow] = bu;
