@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void k_basicmf(const DevParams P, const BasicS
 // registers, rows are written once.  Because the ids of an instance are distinct, "update every row,
 // then regularise every row" (apex_svd_base.h:456-462) equals "update+regularise row by row".
 // =====================================================================================
-template <int LPI, int NU, int NI, int G>
+template <int LPI, int NU, int NI, int G, bool FULL>   // FULL: num_factor == 4*LPI, see basicmf_wave
 __global__ __launch_bounds__(256) void k_fused(const DevParams P, const FusedSchedule S, long begin, long end) {
     constexpr int IPW = 64 / LPI;
     const int lane = threadIdx.x & 63;
@@ -491,7 +491,7 @@ __global__ __launch_bounds__(256) void k_fused(const DevParams P, const FusedSch
     if (P.xcd_remap) tile = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const long wave = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const long w0 = begin + wave * (long)(G * IPW);
-    const int k = P.k, pitch = P.pitch;
+    const int k = FULL ? 4 * LPI : P.k, pitch = P.pitch;
     const bool use_ubias = P.no_user_bias == 0;
 
     bool valid[G];
@@ -1445,12 +1445,14 @@ static void launch_fused_shape(const DevParams &P, const FusedSchedule &S, long 
         const long per_block = (long)(block_threads / 64) * 2 * (64 / LPI);
         int grid = (int)((n + per_block - 1) / per_block);
         if (P.xcd_remap) grid = (grid + 7) & ~7;
-        hipLaunchKernelGGL((k_fused<LPI, NU, NI, 2>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
+        if (P.k == 4 * LPI) hipLaunchKernelGGL((k_fused<LPI, NU, NI, 2, true>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
+        else hipLaunchKernelGGL((k_fused<LPI, NU, NI, 2, false>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
     } else {
         const long per_block = (long)(block_threads / 64) * (64 / LPI);
         int grid = (int)((n + per_block - 1) / per_block);
         if (P.xcd_remap) grid = (grid + 7) & ~7;
-        hipLaunchKernelGGL((k_fused<LPI, NU, NI, 1>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
+        if (P.k == 4 * LPI) hipLaunchKernelGGL((k_fused<LPI, NU, NI, 1, true>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
+        else hipLaunchKernelGGL((k_fused<LPI, NU, NI, 1, false>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
     }
 }
 template <int LPI>
