@@ -797,3 +797,36 @@ def test_svdpp_wave_path_general_configuration(variant, k):
             np.testing.assert_allclose(t.view(name), o.view(name), rtol=RTOL, atol=ATOL)
         else:
             np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+
+
+@pytest.mark.parametrize("wd", [(0.00005, 0.00002), (0.0, 0.0), (0.004, 0.0)])
+def test_specialised_kernels_with_decay_factors_that_round_to_one(wd):
+    """The specialised basicMF and SVD++ kernels hoist the L2 decay factors and apply "skip the multiply when |s-1| <= 1e-6"
+    as a multiply by exactly 1.0f: with lr*wd below 1e-6 (or zero) the factor snaps to one -- results must still be the
+    oracle's bit for bit."""
+    wd_user, wd_item = wd
+    nu, ni = 2000, 700
+    u, i, r = cases.planted_triples(100000, nu, ni, seed=17)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64, wd_user=wd_user, wd_item=wd_item,
+                           wd_user_bias=0.0, wd_item_bias=0.00001)
+    o, t = _ready(port, 0, conf), _ready(hip, 0, conf)
+    ds = t.dataset_from_triples(u, i, r)
+    assert ds.kind == 0
+    d = sa.CSRData.from_triples(u, i, r)
+    for _ in range(2):
+        o.update_batch(d)
+        t.train_dataset(ds)
+    for name in ("W_user", "W_item", "u_bias", "i_bias"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+    blocks = cases.user_blocks(150, nu, ni, ni, seed=18, max_rows=30, max_fb=20)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=128, num_ufeedback=ni, wd_ufeedback=0.00001,
+                           ufeedback_init_sigma=0.01, wd_user=wd_user, wd_item=wd_item)
+    o, t = _ready(port, 1, conf), _ready(hip, 1, conf)
+    ds = t.dataset_from_blocks(blocks)
+    assert ds.num_simple_units > 0
+    for _ in range(2):
+        for b in blocks:
+            o.update_block(b)
+        t.train_dataset(ds)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "W_ufeedback"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
