@@ -238,6 +238,10 @@ void Engine::set_param(const char *name, const char *val) {  // apex_svd_base.h:
     if (trainer_ready_ && !host_only_) flush();   // staged instances were issued under the old parameters
     if (!strcmp(name, "feature_user")) name_feat_user_ = val;
     if (!strcmp(name, "feature_item")) name_feat_item_ = val;
+    // extension keys (ignored by the reference like any unknown key): relaxed handling of shared ids
+    if (!strcmp(name, "amd:relax_global")) relax_global_ = atoi(val) != 0;
+    if (!strcmp(name, "amd:relax_user_from")) relax_user_from_ = (unsigned)strtoul(val, nullptr, 10);
+    if (!strcmp(name, "amd:relax_item_from")) relax_item_from_ = (unsigned)strtoul(val, nullptr, 10);
     tp_set_param(tp_, name, val);
     u_param_.set_param(name, val);
     i_param_.set_param(name, val);
@@ -478,6 +482,7 @@ const DevParams &Engine::params() {
     P.user_group = user_group() ? 1 : 0;
     P.store_mode = store_mode_;
     P.xcd_remap = xcd_remap_;
+    P.relax_global = relax_global_ ? 1 : 0; P.relax_user_from = relax_user_from_; P.relax_item_from = relax_item_from_;
     P.lr = tp_.learning_rate; P.wd_user = tp_.wd_user; P.wd_item = tp_.wd_item;
     P.wd_user_bias = tp_.wd_user_bias; P.wd_item_bias = tp_.wd_item_bias; P.wd_global = tp_.wd_global;
     P.reg_method = tp_.reg_method; P.reg_global = tp_.reg_global; P.num_regfree_global = tp_.num_regfree_global;
@@ -543,7 +548,7 @@ void Engine::stage_rows(int num_row, const float *row_label, const int *row_ptr,
     }
 }
 bool Engine::basic_fast_path_allowed() const {
-    return !lazy_decay() && mp_.num_factor <= max_fast_path_factor() && !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
+    return !relaxed() && !lazy_decay() && mp_.num_factor <= max_fast_path_factor() && !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
 }
 
 void Engine::update_csr(float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
@@ -636,15 +641,17 @@ void Engine::update_block(int nfb, int tag, const unsigned *ifb, const float *vf
 int Engine::level_of_row(const unsigned *ig, int ng, const unsigned *iu, int nu, const unsigned *ii, int ni, int lvl) {
     const int *last = tracker_.last.data();
     const size_t goff = (size_t)n_uiset_;
-    for (int j = 0; j < ng; j++) lvl = std::max(lvl, last[goff + ig[j]]);
+    if (!relax_global_) for (int j = 0; j < ng; j++) lvl = std::max(lvl, last[goff + ig[j]]);
     for (int j = 0; j < nu; j++) {
         const unsigned uid = iu[j];
+        if (uid >= relax_user_from_) continue;   // shared id in relaxed mode: not a scheduling resource
         lvl = std::max(lvl, last[user_off_ + uid]);
         if (uid < feat_user_.num_row())
             for (unsigned c = feat_user_.row_ptr[uid]; c < feat_user_.row_ptr[uid + 1]; c++) lvl = std::max(lvl, last[user_off_ + feat_user_.index[c]]);
     }
     for (int j = 0; j < ni; j++) {
         const unsigned iid = ii[j];
+        if (iid >= relax_item_from_) continue;
         lvl = std::max(lvl, last[item_off_ + iid]);
         if (iid < feat_item_.num_row())
             for (unsigned c = feat_item_.row_ptr[iid]; c < feat_item_.row_ptr[iid + 1]; c++) lvl = std::max(lvl, last[item_off_ + feat_item_.index[c]]);
@@ -654,15 +661,17 @@ int Engine::level_of_row(const unsigned *ig, int ng, const unsigned *iu, int nu,
 void Engine::touch_row(const unsigned *ig, int ng, const unsigned *iu, int nu, const unsigned *ii, int ni, int lvl) {
     int *last = tracker_.last.data();
     const size_t goff = (size_t)n_uiset_;
-    for (int j = 0; j < ng; j++) last[goff + ig[j]] = lvl;
+    if (!relax_global_) for (int j = 0; j < ng; j++) last[goff + ig[j]] = lvl;
     for (int j = 0; j < nu; j++) {
         const unsigned uid = iu[j];
+        if (uid >= relax_user_from_) continue;
         last[user_off_ + uid] = lvl;
         if (uid < feat_user_.num_row())
             for (unsigned c = feat_user_.row_ptr[uid]; c < feat_user_.row_ptr[uid + 1]; c++) last[user_off_ + feat_user_.index[c]] = lvl;
     }
     for (int j = 0; j < ni; j++) {
         const unsigned iid = ii[j];
+        if (iid >= relax_item_from_) continue;
         last[item_off_ + iid] = lvl;
         if (iid < feat_item_.num_row())
             for (unsigned c = feat_item_.row_ptr[iid]; c < feat_item_.row_ptr[iid + 1]; c++) last[item_off_ + feat_item_.index[c]] = lvl;
@@ -831,6 +840,7 @@ void Engine::flush_csr(HostCSR &src) {
             n_launches_++; n_kind_[2]++;
         }
     } else {
+        check(!relaxed(), "svdfeature_amd: relaxed shared ids need few-row instances (at most 2 user and 2 item ids, no side tables)");
         w_label_.upload(src.row_label.data(), (size_t)n, stream_);
         w_ptr_.upload(src.row_ptr.data(), src.row_ptr.size(), stream_);
         w_index_.upload(src.feat_index.data(), src.feat_index.size(), stream_);
@@ -1271,6 +1281,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
             return ds.release();
         }
     }
+    check(!relaxed(), "svdfeature_amd: relaxed shared ids need few-row instances (at most 2 user and 2 item ids, no side tables)");
     ds->kind = 1;
     std::vector<int> ptr32((size_t)3 * n + 1);
     for (long j = 0; j <= 3 * n; j++) ptr32[(size_t)j] = (int)(row_ptr[j] - p00);

@@ -251,6 +251,10 @@ class Engine {
     uint64_t launch_version_ = 1;
     std::vector<unsigned char> staged_fresh_;   // per staged row, see DevCSR::row_fresh
     bool any_fresh_ = false, simple_unit_values_ = false;
+    // relaxed mode for shared ids (extension keys "amd:relax_global", "amd:relax_user_from", "amd:relax_item_from")
+    bool relax_global_ = false;
+    unsigned relax_user_from_ = 0xFFFFFFFFu, relax_item_from_ = 0xFFFFFFFFu;
+    bool relaxed() const { return relax_global_ || relax_user_from_ != 0xFFFFFFFFu || relax_item_from_ != 0xFFFFFFFFu; }
     // lazy decay modes (apex_svd_base.h:95-97,157-170): the reference's sample_counter and per-id ref words
     unsigned sample_counter_ = 0;
     DevBuf<unsigned> d_ref_ui_, d_ref_global_;

@@ -481,6 +481,16 @@ __global__ __launch_bounds__(256) void k_basicmf(const DevParams P, const BasicS
 // registers, rows are written once.  Because the ids of an instance are distinct, "update every row,
 // then regularise every row" (apex_svd_base.h:456-462) equals "update+regularise row by row".
 // =====================================================================================
+// relaxed shared ids: W[row] += (now - was) with hardware float atomics (agent scope: coherent across the XCDs' L2s)
+template <int LPI>
+__device__ __forceinline__ void atomic_row_add(float *W, size_t row, int pitch, int L, int k, const float4 now, const float4 was) {
+    if (LPI * 4 > k && L * 4 >= k) return;
+    float *ptr = W + row * (size_t)pitch + (size_t)L * 4;
+    unsafeAtomicAdd(ptr + 0, now.x - was.x);
+    unsafeAtomicAdd(ptr + 1, now.y - was.y);
+    unsafeAtomicAdd(ptr + 2, now.z - was.z);
+    unsafeAtomicAdd(ptr + 3, now.w - was.w);
+}
 template <int LPI, int NU, int NI, int G, bool FULL>   // FULL: num_factor == 4*LPI, see basicmf_wave
 __global__ __launch_bounds__(256) void k_fused(const DevParams P, const FusedSchedule S, long begin, long end) {
     constexpr int IPW = 64 / LPI;
@@ -553,15 +563,26 @@ __global__ __launch_bounds__(256) void k_fused(const DevParams P, const FusedSch
         const float lr = P.lr;
         // global biases go through memory in the reference's order (all updates, then all decays), so a
         // global id listed twice behaves like the reference; every lane stores the same value
-        for (int j = g0[g]; j < g1[g]; j++) {
-            const unsigned gid = S.gidx[j];
-            float gb = P.g_bias[gid];
-            gb = gb + lr * err * S.gval[j];
-            P.g_bias[gid] = gb;
-        }
-        for (int j = g0[g]; j < g1[g]; j++) {
-            const unsigned gid = S.gidx[j];
-            P.g_bias[gid] = reg_gbias(P, gid, P.g_bias[gid]);
+        if (P.relax_global) {
+            // relaxed shared ids: other instances of this launch may be updating the same global -- add this instance's
+            // change (update, then decay of the value it read) atomically; one lane per group
+            for (int j = g0[g]; j < g1[g]; j++) {
+                const unsigned gid = S.gidx[j];
+                const float gb = P.g_bias[gid];
+                const float nb = reg_gbias(P, gid, gb + lr * err * S.gval[j]);
+                if (L == 0) unsafeAtomicAdd(&P.g_bias[gid], nb - gb);
+            }
+        } else {
+            for (int j = g0[g]; j < g1[g]; j++) {
+                const unsigned gid = S.gidx[j];
+                float gb = P.g_bias[gid];
+                gb = gb + lr * err * S.gval[j];
+                P.g_bias[gid] = gb;
+            }
+            for (int j = g0[g]; j < g1[g]; j++) {
+                const unsigned gid = S.gidx[j];
+                P.g_bias[gid] = reg_gbias(P, gid, P.g_bias[gid]);
+            }
         }
 #pragma unroll
         for (int a = 0; a < NU; a++) {
@@ -572,6 +593,11 @@ __global__ __launch_bounds__(256) void k_fused(const DevParams P, const FusedSch
             float nb = bu[g][a] + su;
             reg_row<LPI>(P, w, get_wd(P.u_rng, ur[g][a], P.wd_user), false, L);
             nb = nb * (1.0f - lr * P.wd_user_bias);
+            if (ur[g][a] >= P.relax_user_from) {   // relaxed shared id: add the change, element by element
+                atomic_row_add<LPI>(P.W, P.user_off + ur[g][a], pitch, L, k, w, p[g][a]);
+                if (use_ubias && L == 0) unsafeAtomicAdd(&P.bias[P.user_off + ur[g][a]], nb - bu[g][a]);
+                continue;
+            }
             store_row<LPI>(P.W, P.user_off + ur[g][a], pitch, L, k, w);
             if (use_ubias && L == 0) P.bias[P.user_off + ur[g][a]] = nb;
         }
@@ -584,6 +610,11 @@ __global__ __launch_bounds__(256) void k_fused(const DevParams P, const FusedSch
             float nb = bi[g][b] + si;
             reg_row<LPI>(P, w, get_wd(P.i_rng, ir[g][b], P.wd_item), true, L);
             nb = nb * (1.0f - lr * P.wd_item_bias);
+            if (ir[g][b] >= P.relax_item_from) {
+                atomic_row_add<LPI>(P.W, P.item_off + ir[g][b], pitch, L, k, w, q[g][b]);
+                if (L == 0) unsafeAtomicAdd(&P.bias[P.item_off + ir[g][b]], nb - bi[g][b]);
+                continue;
+            }
             store_row<LPI>(P.W, P.item_off + ir[g][b], pitch, L, k, w);
             if (L == 0) P.bias[P.item_off + ir[g][b]] = nb;
         }

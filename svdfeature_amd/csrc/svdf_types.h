@@ -77,6 +77,10 @@ struct DevParams {
     int active_type, no_user_bias, user_nonnegative, user_group;
     unsigned *ref_ui;         // lazy decay (reg_method 4/5): sample_counter of the last touch per W_uiset row
     unsigned *ref_global;     // the same per global id (reg_global 4/5)
+    // opt-in relaxed mode for SHARED ids (not the reference's semantics): ids at or above these
+    // thresholds (and all global ids when relax_global) are left out of the conflict schedule and updated with atomic adds
+    unsigned relax_user_from, relax_item_from;
+    int relax_global;
     int xcd_remap;            // 1: consecutive tiles of a batch go to the same XCD (blockIdx%8), see k_basicmf
     int store_mode;           // row-store cache policy of k_basicmf: 0 plain, 1 nontemporal, 2 sc1 write-through
     // SVDTrainParam

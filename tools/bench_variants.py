@@ -89,13 +89,13 @@ if "pairwise" in which:
           "kind %d batches %d" % (ds.kind, ds.num_batches))
     ds.close(); t.close()
 
-for ng, G in ((4, 10000), (4, 4_000_000)):
+for ng, G, relax in ((4, 10000, 0), (4, 4_000_000, 0), (4, 10000, 1)):
     # 10 K global ids: every id is shared by ~1600 instances, exact order serialises on them; 4 M ids (item-pair style
     # neighbourhood weights): conflicts are rare and the batches are as large as basicMF's
     if "neighbor" not in which:
         break
-    t = mk(0, 0, [("base_score", "3"), ("num_global", str(G)), ("wd_global", "0.001")])
-    nn = min(n, 4_000_000) if G <= 100_000 else n
+    t = mk(0, 0, [("base_score", "3"), ("num_global", str(G)), ("wd_global", "0.001")] + ([("amd:relax_global", "1")] if relax else []))
+    nn = min(n, 4_000_000) if (G <= 100_000 and not relax) else n
     g = rng.integers(0, G, (nn, ng), dtype=np.uint32)
     row_ptr = np.empty(3 * nn + 1, np.int64)
     base = (ng + 2) * np.arange(nn, dtype=np.int64)
@@ -104,9 +104,32 @@ for ng, G in ((4, 10000), (4, 4_000_000)):
     val = np.ones((nn, ng + 2), np.float32); val[:, :ng] = rng.uniform(0, 1, (nn, ng))
     d = CSRData(r[:nn], row_ptr.astype(np.int32), idx.ravel(), val.ravel())
     ds = t.dataset_from_csr(d)
-    timed(t, lambda: t.train_dataset(ds), nn, ds.algorithmic_bytes, "neighborhood ng=4 of %d global ids k=%d" % (G, a.factor),
+    timed(t, lambda: t.train_dataset(ds), nn, ds.algorithmic_bytes, "neighborhood ng=4 of %d global ids k=%d%s" % (G, a.factor, ", RELAXED globals" if relax else ""),
           "kind %d batches %d" % (ds.kind, ds.num_batches))
     ds.close(); t.close()
+
+if "sidefeat" in which:
+    # SURVEY 8(d2) side-feature variant: 4 global ids out of 10 K (value U(0,1)) + one extra user-feature id (64 "age
+    # bucket" ids after the real users).  Exact order serialises on the shared ids; the opt-in relaxed mode (amd:relax_*)
+    # updates them with atomics instead.
+    ng, G, NB = 4, 10000, 64
+    for relaxed in (0, 1):
+        nn = min(n, 2_000_000) if not relaxed else n
+        extra = [("base_score", "3"), ("num_global", str(G)), ("wd_global", "0.001"), ("num_user", a.users + NB)]
+        if relaxed: extra += [("amd:relax_global", "1"), ("amd:relax_user_from", str(a.users))]
+        t = mk(0, 0, extra)
+        g = np.sort(rng.integers(0, G, (nn, ng), dtype=np.uint32), axis=1)
+        per = ng + 3
+        row_ptr = np.empty(3 * nn + 1, np.int64)
+        base = per * np.arange(nn, dtype=np.int64)
+        row_ptr[0:3 * nn:3] = base; row_ptr[1:3 * nn:3] = base + ng; row_ptr[2:3 * nn:3] = base + ng + 2; row_ptr[3 * nn] = per * nn
+        idx = np.empty((nn, per), np.uint32); idx[:, :ng] = g; idx[:, ng] = u[:nn]; idx[:, ng + 1] = a.users + (u[:nn] % NB); idx[:, ng + 2] = i[:nn]
+        val = np.ones((nn, per), np.float32); val[:, :ng] = rng.uniform(0, 1, (nn, ng))
+        d = CSRData(r[:nn], row_ptr.astype(np.int32), idx.ravel(), val.ravel())
+        ds = t.dataset_from_csr(d)
+        timed(t, lambda: t.train_dataset(ds), nn, ds.algorithmic_bytes, "side features (4 of 10K globals + 1 of 64 shared user ids) k=%d, %s" % (a.factor, "RELAXED shared ids" if relaxed else "exact"),
+              "kind %d batches %d" % (ds.kind, ds.num_batches))
+        ds.close(); t.close()
 
 if "svdpp" in which:
     # user-grouped: sort the ratings by user, feedback set = the user's items with value n^-1/2
