@@ -214,8 +214,10 @@ def main():
     t0 = time.time()
     adaptor = HipShard(tr, torch, torch.device("cuda", local_rank))
     if a.windows <= 0:
+        # ratings per item per window that keep |dRMSE| <= 1e-4 with a factor ~1.6 of margin at the full configs[2] size
+        # (tools/rmse_contract_fullsize.py): 64 at 2 ranks, 42 at 3-4, 32 beyond
         per_item = a.ratings / max(a.items, 1)
-        a.windows = max(1, int(np.ceil(per_item / (64.0 if world <= 2 else 32.0))))
+        a.windows = max(1, int(np.ceil(per_item / (64.0 if world <= 2 else (42.0 if world <= 4 else 32.0)))))
     nwin = 1 if (world == 1 and not a.force_exchange) else a.windows
     shards = shard_windows(u, i, r, rank, world, nwin)
     if nwin > 1 and a.defer_tails > 0:

@@ -92,7 +92,7 @@ def test_world_one_is_the_sequential_reference_bit_for_bit():
 def test_rmse_contract_of_the_exchange(world, windows):
     """north_star: RMSE within 1e-4 of the reference after equal epochs.  1M ratings, 20k x 2k (500 ratings
     per item per pass), k=16, 5 passes, windows chosen by bench.py's rule (about 64 ratings per item per
-    window at 2 ranks, 32 at 4+ ranks).  At BASELINE configs[2] density (1000 per item) the same rule gives
+    window at 2 ranks, 42 at 3-4 ranks, 32 beyond).  At BASELINE configs[2] density (1000 per item) the same rule gives
     16 / 32 windows: measured 6.4e-5 (2 ranks), 4.3e-5 (4 ranks), 5.3e-5 (8 ranks) on a 10M-rating replica
     (DESIGN.md section 6)."""
     nu, ni, n = 20000, 2000, 1_000_000

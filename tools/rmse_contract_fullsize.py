@@ -49,7 +49,7 @@ worlds = [int(x) for x in a.ranks.split(",")]
 override = [int(x) for x in a.windows.split(",")] if a.windows else None
 for wi_, world in enumerate(worlds):
     per_item = a.ratings / a.items
-    windows = override[wi_] if override else max(1, int(np.ceil(per_item / (64.0 if world <= 2 else 32.0))))
+    windows = override[wi_] if override else max(1, int(np.ceil(per_item / (64.0 if world <= 2 else (42.0 if world <= 4 else 32.0)))))
     t0 = time.time()
     ranks = []
     for rk in range(world):
