@@ -482,7 +482,7 @@ const DevParams &Engine::params() {
     P.user_group = user_group() ? 1 : 0;
     P.store_mode = store_mode_;
     P.xcd_remap = xcd_remap_;
-    P.relax_global = relax_global_ ? 1 : 0; P.relax_user_from = relax_user_from_; P.relax_item_from = relax_item_from_;
+    P.hot_reduce = hot_reduce_; P.relax_global = relax_global_ ? 1 : 0; P.relax_user_from = relax_user_from_; P.relax_item_from = relax_item_from_;
     P.lr = tp_.learning_rate; P.wd_user = tp_.wd_user; P.wd_item = tp_.wd_item;
     P.wd_user_bias = tp_.wd_user_bias; P.wd_item_bias = tp_.wd_item_bias; P.wd_global = tp_.wd_global;
     P.reg_method = tp_.reg_method; P.reg_global = tp_.reg_global; P.num_regfree_global = tp_.num_regfree_global;
@@ -1270,7 +1270,9 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
                 std::vector<unsigned> key((size_t)n, 0u);
                 for (long r = 0; r < n; r++) {
                     const int64_t *p = row_ptr + 3 * r;
-                    if (sort_batches_ == 1 && p[3] > p[2]) key[(size_t)r] = feat_index[p[2]];
+                    if (relax_user_from_ != 0xFFFFFFFFu) {   // relaxed shared user feature: runs of the same shared id
+                        key[(size_t)r] = (p[2] - p[1] == 2 && feat_index[p[1] + 1] >= relax_user_from_) ? feat_index[p[1] + 1] : 0xFFFFFFFFu;
+                    } else if (sort_batches_ == 1 && p[3] > p[2]) key[(size_t)r] = feat_index[p[2]];
                     else if (sort_batches_ == 2 && p[2] > p[1]) key[(size_t)r] = feat_index[p[1]];
                 }
                 sort_batches(ds->sched, key.data());
@@ -1569,6 +1571,7 @@ int Engine::set_knob(const char *name, long value) {
         return 0;
     }
     if (!strcmp(name, "xcd_remap")) { xcd_remap_ = value != 0; params_dirty_ = true; return 0; }
+    if (!strcmp(name, "hot_reduce")) { hot_reduce_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "store_mode")) { check(value >= 0 && value <= 2, "store_mode must be 0, 1 or 2"); store_mode_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "sort_batches")) { check(value >= 0 && value <= 2, "sort_batches must be 0, 1 (by item) or 2 (by user)"); sort_batches_ = (int)value; return 0; }
     if (!strcmp(name, "async_flush")) { flush(); async_flush_ = value != 0; return 0; }

@@ -491,8 +491,12 @@ __device__ __forceinline__ void atomic_row_add(float *W, size_t row, int pitch, 
     unsafeAtomicAdd(ptr + 2, now.z - was.z);
     unsafeAtomicAdd(ptr + 3, now.w - was.w);
 }
-template <int LPI, int NU, int NI, int G, bool FULL>   // FULL: num_factor == 4*LPI, see basicmf_wave
-__global__ __launch_bounds__(256) void k_fused(const DevParams P, const FusedSchedule S, long begin, long end) {
+// HOTU (relaxed mode, NU == 2, G == 1, up to 1024 threads): the LAST user slot holds a shared side-feature id.  A batch is
+// sorted by that id, so the instances of a workgroup mostly share it: their changes of the shared row are summed in LDS
+// (fixed order inside the workgroup) and the leader of each run issues ONE set of atomics -- 32x fewer contended atomics
+// per shared row at k=128 than one set per instance.
+template <int LPI, int NU, int NI, int G, bool FULL, bool HOTU = false>   // FULL: num_factor == 4*LPI, see basicmf_wave
+__global__ __launch_bounds__(HOTU ? 1024 : 256) void k_fused(const DevParams P, const FusedSchedule S, long begin, long end) {
     constexpr int IPW = 64 / LPI;
     const int lane = threadIdx.x & 63;
     const int L = lane & (LPI - 1);
@@ -584,6 +588,11 @@ __global__ __launch_bounds__(256) void k_fused(const DevParams P, const FusedSch
                 P.g_bias[gid] = reg_gbias(P, gid, P.g_bias[gid]);
             }
         }
+        // HOTU: this instance's change of the shared row in the last user slot, handed to the workgroup reduction below
+        bool hot_here = false;
+        unsigned hot_row = SLOT_ABSENT;
+        float4 hot_delta = f4zero();
+        float hot_db = 0.0f;
 #pragma unroll
         for (int a = 0; a < NU; a++) {
             if (ur[g][a] == SLOT_ABSENT) continue;
@@ -593,6 +602,13 @@ __global__ __launch_bounds__(256) void k_fused(const DevParams P, const FusedSch
             float nb = bu[g][a] + su;
             reg_row<LPI>(P, w, get_wd(P.u_rng, ur[g][a], P.wd_user), false, L);
             nb = nb * (1.0f - lr * P.wd_user_bias);
+            if (HOTU && a == NU - 1 && ur[g][a] >= P.relax_user_from) {
+                hot_here = true;
+                hot_row = P.user_off + ur[g][a];
+                hot_delta = make_float4(w.x - p[g][a].x, w.y - p[g][a].y, w.z - p[g][a].z, w.w - p[g][a].w);
+                hot_db = nb - bu[g][a];
+                continue;
+            }
             if (ur[g][a] >= P.relax_user_from) {   // relaxed shared id: add the change, element by element
                 atomic_row_add<LPI>(P.W, P.user_off + ur[g][a], pitch, L, k, w, p[g][a]);
                 if (use_ubias && L == 0) unsafeAtomicAdd(&P.bias[P.user_off + ur[g][a]], nb - bu[g][a]);
@@ -600,6 +616,32 @@ __global__ __launch_bounds__(256) void k_fused(const DevParams P, const FusedSch
             }
             store_row<LPI>(P.W, P.user_off + ur[g][a], pitch, L, k, w);
             if (use_ubias && L == 0) P.bias[P.user_off + ur[g][a]] = nb;
+        }
+        if constexpr (HOTU) {
+            extern __shared__ float4 hot_lds[];                       // [BI][LPI] deltas, then BI row ids, BI bias deltas
+            const int BI = (int)(blockDim.x >> 6) * IPW;              // instances per workgroup
+            unsigned *hot_ids = reinterpret_cast<unsigned *>(hot_lds + BI * LPI);
+            float *hot_dbs = reinterpret_cast<float *>(hot_ids + BI);
+            const int e = (int)(threadIdx.x >> 6) * IPW + gslot;
+            hot_lds[e * LPI + L] = hot_delta;
+            if (L == 0) { hot_ids[e] = hot_here ? hot_row : (unsigned)SLOT_ABSENT; hot_dbs[e] = hot_db; }
+            __syncthreads();
+            if (hot_here && (e == 0 || hot_ids[e - 1] != hot_row)) {   // first instance of a run of the same shared row
+                float4 sum = hot_delta;
+                float sb = hot_db;
+                for (int e2 = e + 1; e2 < BI && hot_ids[e2] == hot_row; e2++) {
+                    const float4 d = hot_lds[e2 * LPI + L];
+                    sum.x = sum.x + d.x; sum.y = sum.y + d.y; sum.z = sum.z + d.z; sum.w = sum.w + d.w;
+                    sb = sb + hot_dbs[e2];
+                }
+                if (!(LPI * 4 > k && L * 4 >= k)) {
+                    float *ptr = P.W + (size_t)hot_row * pitch + (size_t)L * 4;
+                    unsafeAtomicAdd(ptr + 0, sum.x); unsafeAtomicAdd(ptr + 1, sum.y);
+                    unsafeAtomicAdd(ptr + 2, sum.z); unsafeAtomicAdd(ptr + 3, sum.w);
+                }
+                if (use_ubias && L == 0) unsafeAtomicAdd(&P.bias[hot_row], sb);
+            }
+            __syncthreads();
         }
 #pragma unroll
         for (int b = 0; b < NI; b++) {
@@ -1472,12 +1514,21 @@ void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long
 template <int LPI, int NU, int NI>
 static void launch_fused_shape(const DevParams &P, const FusedSchedule &S, long begin, long end, int G, int block_threads, hipStream_t st) {
     const long n = end - begin;
-    if (G >= 2 && NU + NI <= 3) {
+    if (G >= 2 && NU + NI <= 3 && !(NU == 2 && P.relax_user_from != 0xFFFFFFFFu && P.hot_reduce)) {
         const long per_block = (long)(block_threads / 64) * 2 * (64 / LPI);
         int grid = (int)((n + per_block - 1) / per_block);
         if (P.xcd_remap) grid = (grid + 7) & ~7;
         if (P.k == 4 * LPI) hipLaunchKernelGGL((k_fused<LPI, NU, NI, 2, true>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
         else hipLaunchKernelGGL((k_fused<LPI, NU, NI, 2, false>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
+    } else if (NU == 2 && P.relax_user_from != 0xFFFFFFFFu && P.hot_reduce) {
+        // relaxed shared user feature in the last user slot: big workgroups that pre-reduce its changes in LDS
+        constexpr int HB = 1024;
+        const long per_block = (long)(HB / 64) * (64 / LPI);
+        int grid = (int)((n + per_block - 1) / per_block);
+        if (P.xcd_remap) grid = (grid + 7) & ~7;
+        const size_t lds = (size_t)per_block * (LPI * 16 + 8);
+        if (P.k == 4 * LPI) hipLaunchKernelGGL((k_fused<LPI, NU, NI, 1, true, NU == 2>), dim3(grid), dim3(HB), lds, st, P, S, begin, end);
+        else hipLaunchKernelGGL((k_fused<LPI, NU, NI, 1, false, NU == 2>), dim3(grid), dim3(HB), lds, st, P, S, begin, end);
     } else {
         const long per_block = (long)(block_threads / 64) * (64 / LPI);
         int grid = (int)((n + per_block - 1) / per_block);
