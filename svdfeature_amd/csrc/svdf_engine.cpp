@@ -407,12 +407,29 @@ void Engine::save_model(FILE *fo) {  // apex_svd_base.h:142-144
     if (device_model_) { hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hg_.clear(); host_model_valid_ = false; }
 }
 
+// g_bias on the device: hg_ scattered with `stride` floats between entries (padding zero)
+void Engine::upload_globals(int stride) {
+    g_stride_ = stride;
+    const size_t n = hg_.size();
+    dg_.reserve(std::max<size_t>(n * (size_t)stride, 1));
+    if (n == 0) return;
+    if (stride == 1) { dg_.upload(hg_.data(), n, stream_); return; }
+    HIPCHECK(hipMemsetAsync(dg_.p, 0, n * (size_t)stride * sizeof(float), stream_));
+    HIPCHECK(hipMemcpy2DAsync(dg_.p, (size_t)stride * sizeof(float), hg_.data(), sizeof(float), sizeof(float), n, hipMemcpyHostToDevice, stream_));
+}
+void Engine::download_globals(float *dst) {
+    const size_t n = (size_t)mp_.num_global;
+    if (n == 0) return;
+    if (g_stride_ == 1) HIPCHECK(hipMemcpyAsync(dst, dg_.p, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    else HIPCHECK(hipMemcpy2DAsync(dst, sizeof(float), dg_.p, (size_t)g_stride_ * sizeof(float), sizeof(float), n, hipMemcpyDeviceToHost, stream_));
+}
+
 void Engine::upload_model() {
     need_device("uploading the model");
     check(host_model_valid_, "upload_model: no host model");
     dW_.upload(hW_.data(), hW_.size(), stream_);
     dbias_.upload(hbias_.data(), hbias_.size(), stream_);
-    dg_.upload(hg_.data(), hg_.size(), stream_);
+    upload_globals(wanted_g_stride());
     std::vector<float> zero((size_t)2 * pitch_ + 4, 0.0f);
     dstate_.upload(zero.data(), zero.size(), stream_);
     HIPCHECK(hipStreamSynchronize(stream_));
@@ -428,7 +445,7 @@ void Engine::download_model() {
     hg_.resize((size_t)mp_.num_global);
     if (!hW_.empty()) HIPCHECK(hipMemcpyAsync(hW_.data(), dW_.p, hW_.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
     if (!hbias_.empty()) HIPCHECK(hipMemcpyAsync(hbias_.data(), dbias_.p, hbias_.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    if (!hg_.empty()) HIPCHECK(hipMemcpyAsync(hg_.data(), dg_.p, hg_.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (!hg_.empty()) download_globals(hg_.data());
     HIPCHECK(hipStreamSynchronize(stream_));
     host_model_valid_ = true;
 }
@@ -482,7 +499,17 @@ const DevParams &Engine::params() {
     P.user_group = user_group() ? 1 : 0;
     P.store_mode = store_mode_;
     P.xcd_remap = xcd_remap_;
-    P.hot_reduce = hot_reduce_; P.relax_global = relax_global_ ? 1 : 0; P.relax_user_from = relax_user_from_; P.relax_item_from = relax_item_from_;
+    P.hot_reduce = hot_reduce_; P.relax_global = relax_global_ ? 1 : 0;
+    if (device_model_ && g_stride_ != wanted_g_stride() && mp_.num_global > 0) {   // relax_global switched after the upload: re-lay out
+        std::vector<float> g((size_t)mp_.num_global);
+        download_globals(g.data());
+        HIPCHECK(hipStreamSynchronize(stream_));
+        std::swap(g, hg_);
+        upload_globals(wanted_g_stride());
+        HIPCHECK(hipStreamSynchronize(stream_));
+        std::swap(g, hg_);
+    }
+    P.g_stride = g_stride_; P.g_bias = dg_.p; P.relax_user_from = relax_user_from_; P.relax_item_from = relax_item_from_;
     P.lr = tp_.learning_rate; P.wd_user = tp_.wd_user; P.wd_item = tp_.wd_item;
     P.wd_user_bias = tp_.wd_user_bias; P.wd_item_bias = tp_.wd_item_bias; P.wd_global = tp_.wd_global;
     P.reg_method = tp_.reg_method; P.reg_global = tp_.reg_global; P.num_regfree_global = tp_.num_regfree_global;
@@ -1396,7 +1423,7 @@ std::vector<Engine::Range> Engine::shared_ranges() {
     r.push_back({dW_.p + (size_t)item_off_ * pitch_, (long)(n_uiset_ - item_off_) * pitch_});
     if (user_off_ > 0) r.push_back({dbias_.p, (long)user_off_});
     r.push_back({dbias_.p + item_off_, (long)(n_uiset_ - item_off_)});
-    if (mp_.num_global > 0) r.push_back({dg_.p, (long)mp_.num_global});
+    if (mp_.num_global > 0) r.push_back({dg_.p, (long)mp_.num_global * g_stride_});   // (padding floats stay 0: zero deltas)
     return r;
 }
 void Engine::item_delta_begin() {
@@ -1531,7 +1558,7 @@ int64_t Engine::get_view(int which, float *out, int64_t capacity) {
     const unsigned off = (which <= 1) ? user_off_ : (which <= 3) ? item_off_ : fb_off_;
     if (device_model_) {
         flush();
-        if (which == 4) HIPCHECK(hipMemcpyAsync(out, dg_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        if (which == 4) download_globals(out);
         else if (!matrix) HIPCHECK(hipMemcpyAsync(out, dbias_.p + off, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
         else HIPCHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(float), dW_.p + (size_t)off * pitch_, (size_t)pitch_ * sizeof(float),
                                        (size_t)cols * sizeof(float), (size_t)rows, hipMemcpyDeviceToHost, stream_));

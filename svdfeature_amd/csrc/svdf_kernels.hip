@@ -258,6 +258,9 @@ __device__ __forceinline__ float get_wd(const DevRanges &rg, unsigned id, float 
     return rg.wd[lo < rg.n ? lo : rg.n - 1];
 }
 
+// position of a global bias in device memory: contiguous (stride 1) normally; in relaxed-global mode one per 128-byte
+// line (stride 32), because atomics to the same line serialise
+__device__ __forceinline__ size_t gpos(const DevParams &P, unsigned gid) { return (size_t)gid * (size_t)P.g_stride; }
 // factor-row regularisation (reg_user / reg_item, apex_svd_base.h:211-283) on a row held in
 // registers.  is_item selects the item flavour of reg_method 3 (L2) and skips the nonneg clamp.
 // Lazy modes 4/5 (:225-238, :265-278) take kk = (float)(ref[id] - sample_counter): the reference subtracts two
@@ -548,7 +551,7 @@ __global__ __launch_bounds__(HOTU ? 1024 : 256) void k_fused(const DevParams P, 
 #pragma unroll
     for (int g = 0; g < G; g++) {
         double bs = 0.0;
-        for (int j = g0[g]; j < g1[g]; j++) bs += (double)(S.gval[j] * P.g_bias[S.gidx[j]]);
+        for (int j = g0[g]; j < g1[g]; j++) bs += (double)(S.gval[j] * P.g_bias[gpos(P, S.gidx[j])]);
         if (use_ubias) {
 #pragma unroll
             for (int a = 0; a < NU; a++) if (ur[g][a] != SLOT_ABSENT) bs += (double)(ua[g][a] * bu[g][a]);
@@ -572,20 +575,20 @@ __global__ __launch_bounds__(HOTU ? 1024 : 256) void k_fused(const DevParams P, 
             // change (update, then decay of the value it read) atomically; one lane per group
             for (int j = g0[g]; j < g1[g]; j++) {
                 const unsigned gid = S.gidx[j];
-                const float gb = P.g_bias[gid];
+                const float gb = P.g_bias[gpos(P, gid)];
                 const float nb = reg_gbias(P, gid, gb + lr * err * S.gval[j]);
-                if (L == 0) unsafeAtomicAdd(&P.g_bias[gid], nb - gb);
+                if (L == 0) unsafeAtomicAdd(&P.g_bias[gpos(P, gid)], nb - gb);
             }
         } else {
             for (int j = g0[g]; j < g1[g]; j++) {
                 const unsigned gid = S.gidx[j];
-                float gb = P.g_bias[gid];
+                float gb = P.g_bias[gpos(P, gid)];
                 gb = gb + lr * err * S.gval[j];
-                P.g_bias[gid] = gb;
+                P.g_bias[gpos(P, gid)] = gb;
             }
             for (int j = g0[g]; j < g1[g]; j++) {
                 const unsigned gid = S.gidx[j];
-                P.g_bias[gid] = reg_gbias(P, gid, P.g_bias[gid]);
+                P.g_bias[gpos(P, gid)] = reg_gbias(P, gid, P.g_bias[gpos(P, gid)]);
             }
         }
         // HOTU: this instance's change of the shared row in the last user slot, handed to the workgroup reduction below
@@ -673,7 +676,7 @@ __global__ __launch_bounds__(256) void k_predict_fused(const DevParams P, const 
     const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
     for (long s = gidx; s < n; s += stride) {
         double bs = 0.0;
-        if (S.gptr) for (int j = S.gptr[s]; j < S.gptr[s + 1]; j++) bs += (double)(S.gval[j] * P.g_bias[S.gidx[j]]);
+        if (S.gptr) for (int j = S.gptr[s]; j < S.gptr[s + 1]; j++) bs += (double)(S.gval[j] * P.g_bias[gpos(P, S.gidx[j])]);
         float4 tu = f4zero(), ti = f4zero();
 #pragma unroll
         for (int a = 0; a < NU; a++) {
@@ -741,7 +744,7 @@ __device__ __forceinline__ double instance_score(const DevParams &P, int ng, int
     const unsigned *ig = idx, *iu = idx + ng, *ii = idx + ng + nu;
     const float *vg = val, *vu = val + ng, *vi = val + ng + nu;
     double bs = 0.0;
-    for (int j = 0; j < ng; j++) bs += (double)(vg[j] * P.g_bias[ig[j]]);
+    for (int j = 0; j < ng; j++) bs += (double)(vg[j] * P.g_bias[gpos(P, ig[j])]);
     if (P.no_user_bias == 0) {
         for (int j = 0; j < nu; j++) {
             const unsigned uid = iu[j];
@@ -817,7 +820,7 @@ __device__ __forceinline__ void instance_regularize(const DevParams &P, int ng, 
                                                     bool after, unsigned counter) {
     const unsigned *ig = idx, *iu = idx + ng, *ii = idx + ng + nu;
     if (after == (P.reg_global < 4))
-        for (int j = 0; j < ng; j++) { const unsigned gid = ig[j]; float g = reg_gbias(P, gid, P.g_bias[gid], counter); P.g_bias[gid] = g; }
+        for (int j = 0; j < ng; j++) { const unsigned gid = ig[j]; float g = reg_gbias(P, gid, P.g_bias[gpos(P, gid)], counter); P.g_bias[gpos(P, gid)] = g; }
     if (after == (P.reg_method < 4)) {
         for (int j = 0; j < nu; j++) {
             const unsigned uid = iu[j];
@@ -848,7 +851,7 @@ __device__ __forceinline__ void instance_update(const DevParams &P, float label,
     const float lr = P.lr;
     const bool ub = P.no_user_bias == 0;
     // ---- update_no_decay (:383-427)
-    for (int j = 0; j < ng; j++) { float g = P.g_bias[ig[j]]; g = g + lr * err * vg[j]; P.g_bias[ig[j]] = g; }
+    for (int j = 0; j < ng; j++) { float g = P.g_bias[gpos(P, ig[j])]; g = g + lr * err * vg[j]; P.g_bias[gpos(P, ig[j])] = g; }
     for (int j = 0; j < nu; j++) {
         const unsigned uid = iu[j];
         rmw_row<LPI, R>(P, P.user_off + uid, ti, lr * err * vu[j], ub, L);
