@@ -879,3 +879,33 @@ def test_relaxed_shared_ids_lose_no_update_and_keep_the_accuracy():
     many = sa.CSRData.from_rows([(1.0, [], [(0, 1.0), (1, 1.0), (2, 1.0)], [(0, 1.0)])])
     with pytest.raises(sa.SvdfError, match="relaxed shared ids need few-row"):
         t.dataset_from_csr(many)
+
+
+def test_relaxed_global_layout_is_invisible_outside_the_device(tmp_path):
+    """Relaxed-global mode keeps one global bias per 128-byte line in HBM; model files, views and predictions must be
+    unaffected by the layout, also when the mode is switched after the model is on the device."""
+    nu, ni, ng = 300, 200, 37
+    rows = cases.sparse_feature_rows(3000, nu, ni, ng, seed=9, max_u=1, max_i=1)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=16, wd_global=0.002)
+    exact = _ready(hip, 0, conf)
+    exact.update_batch(rows)
+    exact.finish_round()
+    g_before = exact.view("g_bias").copy()
+    pred_before = exact.predict_batch(rows)
+    path = str(tmp_path / "m.model")
+    exact.save_model(path)
+    exact.set_param("amd:relax_global", "1")          # re-lays the device copy out (stride 32), values unchanged
+    np.testing.assert_array_equal(exact.view("g_bias"), g_before)
+    np.testing.assert_array_equal(exact.predict_batch(rows).view(np.uint32), pred_before.view(np.uint32))
+    path2 = str(tmp_path / "m2.model")
+    exact.save_model(path2)
+    assert open(path, "rb").read() == open(path2, "rb").read()
+    relaxed = sa.Trainer(0, 0)
+    for kk, v in conf + [("amd:relax_global", "1")]:
+        relaxed.set_param(kk, v)
+    relaxed.load_model(path)
+    relaxed.init_trainer()
+    np.testing.assert_array_equal(relaxed.view("g_bias"), g_before)
+    np.testing.assert_array_equal(relaxed.predict_batch(rows).view(np.uint32), pred_before.view(np.uint32))
+    relaxed.set_param("amd:relax_global", "0")        # and back
+    np.testing.assert_array_equal(relaxed.view("g_bias"), g_before)
