@@ -240,6 +240,7 @@ void Engine::set_param(const char *name, const char *val) {  // apex_svd_base.h:
     if (!strcmp(name, "feature_item")) name_feat_item_ = val;
     // extension keys (ignored by the reference like any unknown key): relaxed handling of shared ids
     if (!strcmp(name, "amd:relax_global")) relax_global_ = atoi(val) != 0;
+    if (!strcmp(name, "amd:relax_feedback")) relax_feedback_ = atoi(val) != 0;
     if (!strcmp(name, "amd:relax_user_from")) relax_user_from_ = (unsigned)strtoul(val, nullptr, 10);
     if (!strcmp(name, "amd:relax_item_from")) relax_item_from_ = (unsigned)strtoul(val, nullptr, 10);
     tp_set_param(tp_, name, val);
@@ -499,7 +500,7 @@ const DevParams &Engine::params() {
     P.user_group = user_group() ? 1 : 0;
     P.store_mode = store_mode_;
     P.xcd_remap = xcd_remap_;
-    P.hot_reduce = hot_reduce_; P.relax_global = relax_global_ ? 1 : 0;
+    P.hot_reduce = hot_reduce_; P.relax_global = relax_global_ ? 1 : 0; P.relax_feedback = relax_feedback_ ? 1 : 0;
     if (device_model_ && g_stride_ != wanted_g_stride() && mp_.num_global > 0) {   // relax_global switched after the upload: re-lay out
         std::vector<float> g((size_t)mp_.num_global);
         download_globals(g.data());
@@ -970,6 +971,9 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
     const unsigned *idx = staged_.feat_index.data();
     const bool simple_ok = feat_user_.num_row() == 0 && feat_item_.num_row() == 0 && mp_.common_latent_space == 0 && mp_.common_feedback_space == 0;
     if (simple_ok && stamp_.size() < (size_t)n_uiset_) stamp_.assign((size_t)n_uiset_, -1);
+    if (relaxed())
+        check((relax_item_from_ == 0u || relax_item_from_ == 0xFFFFFFFFu) && relax_user_from_ == 0xFFFFFFFFu,
+              "svdfeature_amd: on user-group data the relaxed mode is amd:relax_item_from = 0 (all item rows) and / or amd:relax_feedback = 1");
     staged_fresh_.assign((size_t)staged_.num_row(), 0);
     any_fresh_ = false;
     simple_unit_values_ = true;
@@ -994,7 +998,7 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
         }
         for (int j = u.fb_begin; j < u.fb_end; j++) {
             const unsigned row = fb_off_ + staged_fb_index_[(size_t)j];
-            lvl = std::max(lvl, last[row]);
+            if (!relax_feedback_) lvl = std::max(lvl, last[row]);
             if (simple) {
                 if (stamp_[row] == (int)t) simple = false;       // a feedback id listed twice
                 stamp_[row] = (int)t;
@@ -1006,10 +1010,13 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
             const int *p = &staged_.row_ptr[(size_t)3 * r];
             touch_row(idx + p[0], p[1] - p[0], idx + p[1], p[2] - p[1], idx + p[2], p[3] - p[2], lvl);
         }
-        for (int j = u.fb_begin; j < u.fb_end; j++) last[fb_off_ + staged_fb_index_[(size_t)j]] = lvl;
+        if (!relax_feedback_) for (int j = u.fb_begin; j < u.fb_end; j++) last[fb_off_ + staged_fb_index_[(size_t)j]] = lvl;
         if (u.flags & (UNIT_LOAD | UNIT_SAVE)) last[state_res] = lvl;
         levels[(size_t)t] = lvl;
-        du[(size_t)t] = DevUnit{u.fb_begin, u.fb_end, u.row_begin, u.row_end, u.flags | (simple && use_simple_units_ && !lazy_decay() && mp_.num_factor <= max_fast_path_factor() ? UNIT_SIMPLE : 0)};
+        const bool fast_unit = simple && use_simple_units_ && !lazy_decay() && mp_.num_factor <= max_fast_path_factor();
+        if (relaxed() && !fast_unit && u.row_end > u.row_begin)
+            fail("svdfeature_amd: relaxed shared ids on user-group data need simple units (one user id per row, rows of one item, distinct feedback ids)");
+        du[(size_t)t] = DevUnit{u.fb_begin, u.fb_end, u.row_begin, u.row_end, u.flags | (fast_unit ? UNIT_SIMPLE : 0)};
     }
     build_schedule(levels, base, sched);
     // inside a batch the fast-path users go first: they are launched as one wave per user (k_svdpp_wave), the rest as

@@ -252,13 +252,13 @@ class Engine {
     std::vector<unsigned char> staged_fresh_;   // per staged row, see DevCSR::row_fresh
     bool any_fresh_ = false, simple_unit_values_ = false;
     // relaxed mode for shared ids (extension keys "amd:relax_global", "amd:relax_user_from", "amd:relax_item_from")
-    bool relax_global_ = false;
+    bool relax_global_ = false, relax_feedback_ = false;
     int g_stride_ = 1;                  // device layout of g_bias, see DevParams::g_stride
     int wanted_g_stride() const { return (relax_global_ && mp_.num_global <= (1 << 24)) ? 32 : 1; }
     void upload_globals(int stride);
     void download_globals(float *dst);
     unsigned relax_user_from_ = 0xFFFFFFFFu, relax_item_from_ = 0xFFFFFFFFu;
-    bool relaxed() const { return relax_global_ || relax_user_from_ != 0xFFFFFFFFu || relax_item_from_ != 0xFFFFFFFFu; }
+    bool relaxed() const { return relax_global_ || relax_feedback_ || relax_user_from_ != 0xFFFFFFFFu || relax_item_from_ != 0xFFFFFFFFu; }
     // lazy decay modes (apex_svd_base.h:95-97,157-170): the reference's sample_counter and per-id ref words
     unsigned sample_counter_ = 0;
     DevBuf<unsigned> d_ref_ui_, d_ref_global_;

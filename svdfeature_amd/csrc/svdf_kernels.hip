@@ -1028,6 +1028,13 @@ template <int NR> __device__ __forceinline__ void chain_store(float *W, size_t r
 #pragma unroll
     for (int q = 0; q < NR; q++) { const int e = e0 + 4 * q; if (k < 0 || e < k) base[e] = x.r[q]; }
 }
+// relaxed shared rows: W[row] += x, element by element, with hardware float atomics (chain layout addresses)
+template <int NR> __device__ __forceinline__ void chain_atomic_add(float *W, size_t row, int pitch, int lane, int k, const ChainRow<NR> &x) {
+    float *base = W + row * (size_t)pitch;
+    const int e0 = 4 * NR * (lane & 15) + (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < NR; q++) { const int e = e0 + 4 * q; if (k < 0 || e < k) unsafeAtomicAdd(base + e, x.r[q]); }
+}
 // K1 / K2 with a wave-uniform scalar
 template <int NR> __device__ __forceinline__ void chain_axpy(ChainRow<NR> &d, const ChainRow<NR> &s, float a) {
     const float a1 = snap_to_one(a);
@@ -1164,13 +1171,15 @@ __device__ __forceinline__ void fb_fetch_rows(const DevParams &P, const FbBlock 
 // decay, no nonnegativity clamp -- compiled without the per-row switches; anything else takes the general instantiation.
 // FULL: num_factor == 64*NR, so no lane is ever out of the row and the dot has no masked chunks and no tail.
 // UV: every feature value of the fast-path units is 1.0 (the usual rating data): values are compile-time constants.
-template <int NR, bool FAST, bool FULL, bool UV>
+// RX: relaxed mode compiled in (atomic adds to item / feedback rows); the exact kernels carry none of it.
+template <int NR, bool FAST, bool FULL, bool UV, bool RX>
 __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR &D, const DevUnit &u, const unsigned *fb_index,
                                                 const float *fb_value, int lane) {
     const int pitch = P.pitch;
     const int k = FULL ? 64 * NR : P.k;      // dot / projection width
     const int kio = FULL ? -1 : P.k;         // bound of row loads / stores (-1: none)
     const bool ub = FAST ? true : P.no_user_bias == 0;
+    const bool rx_item = RX && P.relax_item_from == 0u, rx_fb = RX && P.relax_feedback != 0;   // wave-uniform
     const unsigned *fidx = fb_index + u.fb_begin;
     const float *fval = fb_value + u.fb_begin;
     const int nfb = u.fb_end - u.fb_begin;
@@ -1301,8 +1310,16 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
                     }
                     if (ub) bu = bu * dec_ub;
                     nbi = nbi * dec_ib;
-                    chain_store<NR>(P.W, x.irow, pitch, lane, kio, w);
-                    P.bias[x.irow] = nbi;   // every lane writes the same word: one request, and no exec-mask branch
+                    if (rx_item) {   // relaxed item rows: other users of this launch may be updating the same item -- add the change
+                        ChainRow<NR> dw;
+#pragma unroll
+                        for (int q = 0; q < NR; q++) dw.r[q] = w.r[q] - x.q.r[q];
+                        chain_atomic_add<NR>(P.W, x.irow, pitch, lane, kio, dw);
+                        if (lane == 0) unsafeAtomicAdd(&P.bias[x.irow], nbi - x.bi);
+                    } else {
+                        chain_store<NR>(P.W, x.irow, pitch, lane, kio, w);
+                        P.bias[x.irow] = nbi;   // every lane writes the same word: one request, and no exec-mask branch
+                    }
                 }
             }
 #pragma unroll
@@ -1343,9 +1360,18 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
                 if (j0 + c < nfb) {
                     const float v = fb_val(blk[0], off[0] + c);
                     const unsigned row = P.fb_off + fb_id(blk[0], off[0] + c);
-                    chain_axpy(rq[0].w[c], d, v);
-                    chain_store<NR>(P.W, row, pitch, lane, kio, rq[0].w[c]);
-                    if (ub) P.bias[row] = rq[0].b[c] + db * v;
+                    if (rx_fb) {   // relaxed feedback rows: the scatter is an addition anyway -- make it atomic
+                        const float v1 = snap_to_one(v);
+                        ChainRow<NR> dw;
+#pragma unroll
+                        for (int q = 0; q < NR; q++) dw.r[q] = d.r[q] * v1;
+                        chain_atomic_add<NR>(P.W, row, pitch, lane, kio, dw);
+                        if (ub && lane == 0) unsafeAtomicAdd(&P.bias[row], db * v);
+                    } else {
+                        chain_axpy(rq[0].w[c], d, v);
+                        chain_store<NR>(P.W, row, pitch, lane, kio, rq[0].w[c]);
+                        if (ub) P.bias[row] = rq[0].b[c] + db * v;
+                    }
                 }
             }
 #pragma unroll
@@ -1360,7 +1386,7 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
 }
 
 // Kernel 4a: the simple units of one conflict-free batch, one wave per user
-template <int NR, bool FAST, bool FULL, bool UV>
+template <int NR, bool FAST, bool FULL, bool UV, bool RX>
 __global__ __launch_bounds__(64) void k_svdpp_wave(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
                                                    const float *fb_value, const int *order, long begin, long end) {
     const int lane = threadIdx.x & 63;
@@ -1371,7 +1397,7 @@ __global__ __launch_bounds__(64) void k_svdpp_wave(const DevParams P, const DevC
         u.fb_begin = __builtin_amdgcn_readfirstlane(up->fb_begin); u.fb_end = __builtin_amdgcn_readfirstlane(up->fb_end);
         u.row_begin = __builtin_amdgcn_readfirstlane(up->row_begin); u.row_end = __builtin_amdgcn_readfirstlane(up->row_end);
         u.flags = __builtin_amdgcn_readfirstlane(up->flags);
-        svdpp_unit_wave<NR, FAST, FULL, UV>(P, D, u, fb_index, fb_value, lane);
+        svdpp_unit_wave<NR, FAST, FULL, UV, RX>(P, D, u, fb_index, fb_value, lane);
     }
 }
 
@@ -1602,15 +1628,18 @@ void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units
     const int nr = (P.k + 63) / 64;
     const bool fast = P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 && P.user_nonnegative == 0 &&
                       P.u_rng.n == 0 && P.i_rng.n == 0;
-#define SVDF_WAVE_LAUNCH(NR_, FAST_, FULL_, UV_) \
-    hipLaunchKernelGGL((k_svdpp_wave<NR_, FAST_, FULL_, UV_>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end)
-#define SVDF_WAVE_CASE(NR_)                                                        \
-    case NR_:                                                                      \
-        if (fast && full && D.unit_values) SVDF_WAVE_LAUNCH(NR_, true, true, true);  \
-        else if (fast && full) SVDF_WAVE_LAUNCH(NR_, true, true, false);           \
-        else if (fast) SVDF_WAVE_LAUNCH(NR_, true, false, false);                  \
-        else SVDF_WAVE_LAUNCH(NR_, false, false, false);                           \
+#define SVDF_WAVE_LAUNCH(NR_, FAST_, FULL_, UV_, RX_) \
+    hipLaunchKernelGGL((k_svdpp_wave<NR_, FAST_, FULL_, UV_, RX_>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end)
+#define SVDF_WAVE_CASE(NR_)                                                                   \
+    case NR_:                                                                                 \
+        if (relaxed && fast && full && D.unit_values) SVDF_WAVE_LAUNCH(NR_, true, true, true, true);   \
+        else if (relaxed) SVDF_WAVE_LAUNCH(NR_, false, false, false, true);                   \
+        else if (fast && full && D.unit_values) SVDF_WAVE_LAUNCH(NR_, true, true, true, false); \
+        else if (fast && full) SVDF_WAVE_LAUNCH(NR_, true, true, false, false);               \
+        else if (fast) SVDF_WAVE_LAUNCH(NR_, true, false, false, false);                      \
+        else SVDF_WAVE_LAUNCH(NR_, false, false, false, false);                               \
         break;
+    const bool relaxed = P.relax_item_from == 0u || P.relax_feedback != 0;
     const bool full = P.k == 64 * nr;
     switch (nr) {
         SVDF_WAVE_CASE(1)

@@ -81,6 +81,7 @@ struct DevParams {
     // thresholds (and all global ids when relax_global) are left out of the conflict schedule and updated with atomic adds
     unsigned relax_user_from, relax_item_from;
     int relax_global;
+    int relax_feedback;       // relaxed mode for the implicit-feedback rows of user-group trainers (atomic scatter)
     int g_stride;             // floats between consecutive global biases in device memory (1, or 32 in relaxed-global mode)
     int hot_reduce;           // knob: workgroup pre-reduction of a relaxed shared user row (k_fused HOTU)
     int xcd_remap;            // 1: consecutive tiles of a batch go to the same XCD (blockIdx%8), see k_basicmf

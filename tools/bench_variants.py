@@ -148,12 +148,16 @@ if "svdpp" in which:
         fb = np.unique(ii[s:e])
         blocks.append(PlusBlock(fb, np.full(fb.size, 1.0 / np.sqrt(fb.size), np.float32), CSRData.from_triples(uu[s:e], ii[s:e], rr[s:e])))
     k = a.factor
-    for simple in (1, 0):
-        t = mk(1, 0, [("base_score", "3"), ("num_global", "0"), ("num_ufeedback", a.items), ("wd_ufeedback", "0.004")]) if simple == 0 else t
-        t.set_knob("use_simple_units", simple)
+    for simple in (1, 0, 2):   # 2 = fast path with RELAXED item / feedback rows (Hogwild on the rows users share)
+        if simple == 2:
+            t = mk(1, 0, [("base_score", "3"), ("num_global", "0"), ("num_ufeedback", a.items), ("wd_ufeedback", "0.004"),
+                          ("amd:relax_item_from", "0"), ("amd:relax_feedback", "1")])
+        elif simple == 0:
+            t = mk(1, 0, [("base_score", "3"), ("num_global", "0"), ("num_ufeedback", a.items), ("wd_ufeedback", "0.004")])
+        t.set_knob("use_simple_units", 1 if simple else 0)
         t0 = time.perf_counter()
         ds = t.dataset_from_blocks(blocks)
         build_s = time.perf_counter() - t0
-        timed(t, lambda: t.train_dataset(ds), nn, ds.algorithmic_bytes, "svdpp user blocks k=%d resident dataset, simple_units=%d" % (k, simple),
+        timed(t, lambda: t.train_dataset(ds), nn, ds.algorithmic_bytes, "svdpp user blocks k=%d resident dataset, %s" % (k, ("simple_units=%d" % simple) if simple < 2 else "RELAXED item+feedback rows"),
               "%d users, %d on fast path, %d batches, dataset build %.1fs" % (ds.num_units, ds.num_simple_units, ds.num_batches, build_s))
         ds.close(); t.close()
