@@ -1035,6 +1035,78 @@ template <int NR> __device__ __forceinline__ void chain_atomic_add(float *W, siz
 #pragma unroll
     for (int q = 0; q < NR; q++) { const int e = e0 + 4 * q; if (k < 0 || e < k) unsafeAtomicAdd(base + e, x.r[q]); }
 }
+// The same registers in LINEAR layout: lane l holds the NR consecutive elements NR*l .. NR*l+NR-1, i.e. a row is ONE fully
+// contiguous 256*NR-byte load or store per wave.  The feedback phases (prepare_ufeedback / update_ufeedback) only do
+// elementwise work on hundreds of rows, which is layout-agnostic: they run in linear layout and convert the one row that
+// crosses into the chain-layout row loop (tmp_ufeedback, the scatter delta) with NR*NR ds_bpermutes per phase.
+template <int NR> __device__ __forceinline__ ChainRow<NR> lin_load(const float *W, size_t row, int pitch, int lane, int k) {
+    const float *base = W + row * (size_t)pitch + NR * lane;
+    ChainRow<NR> x;
+    if (k < 0) {
+        if constexpr (NR == 1) x.r[0] = base[0];
+        else if constexpr (NR == 2) { const float2 t = *reinterpret_cast<const float2 *>(base); x.r[0] = t.x; x.r[1] = t.y; }
+        else if constexpr (NR == 4) { const float4 t = *reinterpret_cast<const float4 *>(base); x.r[0] = t.x; x.r[1] = t.y; x.r[2] = t.z; x.r[3] = t.w; }
+        else {
+#pragma unroll
+            for (int c = 0; c < NR; c++) x.r[c] = base[c];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NR; c++) x.r[c] = (NR * lane + c < k) ? base[c] : 0.0f;
+    }
+    return x;
+}
+template <int NR> __device__ __forceinline__ void lin_store(float *W, size_t row, int pitch, int lane, int k, const ChainRow<NR> &x) {
+    float *base = W + row * (size_t)pitch + NR * lane;
+    if (k < 0) {
+        if constexpr (NR == 1) base[0] = x.r[0];
+        else if constexpr (NR == 2) *reinterpret_cast<float2 *>(base) = make_float2(x.r[0], x.r[1]);
+        else if constexpr (NR == 4) *reinterpret_cast<float4 *>(base) = make_float4(x.r[0], x.r[1], x.r[2], x.r[3]);
+        else {
+#pragma unroll
+            for (int c = 0; c < NR; c++) base[c] = x.r[c];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NR; c++) if (NR * lane + c < k) base[c] = x.r[c];
+    }
+}
+template <int NR> __device__ __forceinline__ void lin_atomic_add(float *W, size_t row, int pitch, int lane, int k, const ChainRow<NR> &x) {
+    float *base = W + row * (size_t)pitch + NR * lane;
+#pragma unroll
+    for (int c = 0; c < NR; c++) if (k < 0 || NR * lane + c < k) unsafeAtomicAdd(base + c, x.r[c]);
+}
+__device__ __forceinline__ float lane_gather(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+// chain layout (lane 16j+m, register q <-> element 4*(NR*m+q)+j)  <->  linear layout (lane l, slot c <-> element NR*l+c)
+template <int NR> __device__ __forceinline__ ChainRow<NR> lin_to_chain(const ChainRow<NR> &lin, int lane) {
+    ChainRow<NR> out;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        const int e = 4 * (NR * (lane & 15) + q) + (lane >> 4);
+        const int src = e / NR, comp = e % NR;
+        float v = lane_gather(lin.r[0], src);
+#pragma unroll
+        for (int c = 1; c < NR; c++) { const float t = lane_gather(lin.r[c], src); v = (comp == c) ? t : v; }
+        out.r[q] = v;
+    }
+    return out;
+}
+template <int NR> __device__ __forceinline__ ChainRow<NR> chain_to_lin(const ChainRow<NR> &ch, int lane) {
+    ChainRow<NR> out;
+#pragma unroll
+    for (int c = 0; c < NR; c++) {
+        const int e = NR * lane + c;
+        const int chunk = e >> 2;
+        const int src = 16 * (e & 3) + chunk / NR, qsel = chunk % NR;
+        float v = lane_gather(ch.r[0], src);
+#pragma unroll
+        for (int q = 1; q < NR; q++) { const float t = lane_gather(ch.r[q], src); v = (qsel == q) ? t : v; }
+        out.r[c] = v;
+    }
+    return out;
+}
 // K1 / K2 with a wave-uniform scalar
 template <int NR> __device__ __forceinline__ void chain_axpy(ChainRow<NR> &d, const ChainRow<NR> &s, float a) {
     const float a1 = snap_to_one(a);
@@ -1161,7 +1233,7 @@ __device__ __forceinline__ void fb_fetch_rows(const DevParams &P, const FbBlock 
 #pragma unroll
     for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
         const unsigned row = P.fb_off + fb_id(blk, off + c);
-        o.w[c] = chain_load<NR>(P.W, row, P.pitch, lane, kio);
+        o.w[c] = lin_load<NR>(P.W, row, P.pitch, lane, kio);   // LINEAR layout: one contiguous load per row
         o.b[c] = ub ? P.bias[row] : 0.0f;
     }
 }
@@ -1218,7 +1290,7 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
                 for (int c = 0; c < FBW; c++) {
                     if (j0 + c < nfb) {
                         const float v = fb_val(blk[0], off[0] + c);
-                        chain_axpy(tmp_fb, rq[0].w[c], v);
+                        chain_axpy(tmp_fb, rq[0].w[c], v);   // (tmp_fb is in LINEAR layout during this phase)
                         norm = norm + v * v;
                         if (ub) tmp_bias = tmp_bias + rq[0].b[c] * v;
                     }
@@ -1226,6 +1298,7 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
 #pragma unroll
                 for (int d = 0; d < DEPTH; d++) { rq[d] = rq[d + 1]; blk[d] = blk[d + 1]; off[d] = off[d + 1]; }
             }
+            tmp_fb = lin_to_chain<NR>(tmp_fb, lane);   // elementwise sums are layout-agnostic: convert the result once
         }
         old_bias = tmp_bias;
         old_fb = tmp_fb;
@@ -1338,6 +1411,7 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
         chain_scale(d, inv);
         db = db * inv;
         tmp_fb = d; tmp_bias = db;   // the reference leaves the scaled delta in tmp_ufeedback
+        const ChainRow<NR> dl = chain_to_lin<NR>(d, lane);   // the scatter below runs in LINEAR layout
         constexpr int FBW = svdpp_fbw<NR>::value, DEPTH = svdpp_fbdepth<NR>::value;
         FbBlock blk[DEPTH + 1], blkn;
         int off[DEPTH + 1];
@@ -1364,12 +1438,12 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
                         const float v1 = snap_to_one(v);
                         ChainRow<NR> dw;
 #pragma unroll
-                        for (int q = 0; q < NR; q++) dw.r[q] = d.r[q] * v1;
-                        chain_atomic_add<NR>(P.W, row, pitch, lane, kio, dw);
+                        for (int q = 0; q < NR; q++) dw.r[q] = dl.r[q] * v1;
+                        lin_atomic_add<NR>(P.W, row, pitch, lane, kio, dw);
                         if (ub && lane == 0) unsafeAtomicAdd(&P.bias[row], db * v);
                     } else {
-                        chain_axpy(rq[0].w[c], d, v);
-                        chain_store<NR>(P.W, row, pitch, lane, kio, rq[0].w[c]);
+                        chain_axpy(rq[0].w[c], dl, v);
+                        lin_store<NR>(P.W, row, pitch, lane, kio, rq[0].w[c]);
                         if (ub) P.bias[row] = rq[0].b[c] + db * v;
                     }
                 }
