@@ -1,0 +1,398 @@
+// svdf_device.h -- hand-written gfx950 (CDNA4, wave64) kernels of the apex_svd SGD hot path.
+//
+// What is computed, and in which order, follows the reference's base solver
+// (solvers/base-solver/apex_svd_base.h: pred :445-454, calc_bias :313-353, prepare_tmp :354-381,
+// update_no_decay :383-427, regularize :188-311, SVD++ hooks :506-554) and its SSE2 tensor ops
+// (apex-tensor/apex_tensor_sse.h: scalar_map :261-272 with the |s-1|<=1e-6 skip :231-242,
+// sdot :289-317 + sum_all :88-97).  HOW it is computed is CDNA4-first:
+//
+//  * a factor row (k fp32, pitch ceil(k/4)*4) is owned by a LANE GROUP of LPI lanes, one float4
+//    per lane, so a wave issues one 16 B/lane load per row set: 64/LPI rows x (LPI*16) bytes,
+//    e.g. 4 rows x 256 B per instruction at k=64 -- fully coalesced gathers, no LDS round trip;
+//  * the dot product reproduces the reference's 4-lane SSE accumulation order bit for bit with a
+//    DPP scan: lane m of the group holds chunk m's four products, and
+//    acc[m] = acc[m-1] + prod[m] is applied LPI-1 times through row_shr:1 / wave_shr:1 DPP adds
+//    (no LDS, no bpermute); lanes < step index are already final and are recomputed to the
+//    same value, so no select is needed;
+//  * instances of one launch are CONFLICT-FREE (no shared parameter row; the host scheduler
+//    builds such batches in file order), so every read-modify-write is a plain load/store and
+//    the result equals the reference's one-instance-at-a-time SGD exactly;
+//  * each wave keeps G independent row sets in flight (G*2 KiB of gathers per wave at k=64)
+//    to cover HBM latency without relying on occupancy alone.
+//
+// Arithmetic contract: fp32, unfused (-ffp-contract=off and the pragma below), correctly rounded
+// divide/sqrt, fp64 bias/score accumulation.  Only expf (sigmoid links) differs from glibc by
+// ulps; everything else is bit-exact against oracle/svdf_oracle.c.
+#ifndef SVDF_DEVICE_H_
+#define SVDF_DEVICE_H_
+// Device-side helpers shared by the kernel translation units (svdf_k_*.hip): arithmetic in the reference's order, the
+// DPP scans of the bit-exact dot product, row loads / stores, regularisers, and the host-side launch dispatch macros.
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include "svdf_kernels.h"
+
+#pragma clang fp contract(off)
+
+namespace svdf {
+
+// ------------------------------------------------------------------ small helpers
+__device__ __forceinline__ float4 f4zero() { return make_float4(0.0f, 0.0f, 0.0f, 0.0f); }
+
+// apex_tensor_sse.h:231-242: multiply is skipped when |s-1| <= 1e-6.  The reference compares (double)fabsf(s - 1.0f)
+// with the double 1e-6; no float lies between (float)1e-6 = 9.99999997e-7 and that double, so the float compare
+// below decides identically for every input (NaN included: both say "one") without fp64 instructions.
+__device__ __forceinline__ bool scalar_is_one(float s) { return !(fabsf(s - 1.0f) > 1e-6f); }
+
+// The skipped multiply, branch-free: x * 1.0f is x for every x (IEEE multiplication by one is exact, signs of zero and
+// infinities included), so "skip the multiply when |s-1| <= 1e-6" is the same as multiplying by exactly 1.0f then --
+// one select on the scalar instead of one per element.
+__device__ __forceinline__ float snap_to_one(float s) { return scalar_is_one(s) ? 1.0f : s; }
+// K1: dst += src*s (separate mul and add)
+__device__ __forceinline__ void axpy4(float4 &d, const float4 s, float a) {
+    const float a1 = snap_to_one(a);
+    float mx = s.x * a1, my = s.y * a1, mz = s.z * a1, mw = s.w * a1;
+    d.x = d.x + mx; d.y = d.y + my; d.z = d.z + mz; d.w = d.w + mw;
+}
+// K2: dst *= s
+__device__ __forceinline__ void scale4(float4 &d, float a) {
+    const float a1 = snap_to_one(a);
+    d.x = d.x * a1; d.y = d.y * a1; d.z = d.z * a1; d.w = d.w * a1;
+}
+__device__ __forceinline__ float l1(float w, float eps) {  // K6
+    if (w > eps) return w - eps;
+    if (w < -eps) return w + eps;
+    return 0.0f;
+}
+
+// previous lane's value inside the lane group (0 for the group's first lane)
+template <int LPI>
+__device__ __forceinline__ float prev_lane(float v, int L) {
+    int iv = __float_as_int(v);
+    int r;
+    if constexpr (LPI <= 16) {
+        r = __builtin_amdgcn_update_dpp(0, iv, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+        if constexpr (LPI < 16) r = (L == 0) ? 0 : r;
+    } else {
+        r = __builtin_amdgcn_update_dpp(0, iv, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+        if constexpr (LPI < 64) r = (L == 0) ? 0 : r;
+    }
+    return __int_as_float(r);
+}
+template <int LPI>
+__device__ __forceinline__ float group_bcast(float v, int src_L) {
+    if constexpr (LPI == 1) return v;
+    const int lane = (int)(threadIdx.x & 63);
+    return __shfl(v, (lane & ~(LPI - 1)) + src_L, 64);
+}
+
+// K3: apex_tensor_sse.h:289-317.  a,b: this lane's chunk (lane L holds elements 4L..4L+3; pad and
+// out-of-range chunks are 0).  Returns the dot product, identical on every lane of the group.
+template <int LPI>
+__device__ __forceinline__ float group_dot(const float4 a, const float4 b, int L, int k) {
+    const int nfull = k >> 2;
+    const int ntail = k & 3;
+    float m0 = a.x * b.x, m1 = a.y * b.y, m2 = a.z * b.z, m3 = a.w * b.w;
+    const bool full = L < nfull;
+    // lanes beyond the full chunks feed +0 so the running sums just travel on to the last lane
+    float c0 = full ? m0 : 0.0f, c1 = full ? m1 : 0.0f, c2 = full ? m2 : 0.0f, c3 = full ? m3 : 0.0f;
+    float a0 = 0.0f + c0, a1 = 0.0f + c1, a2 = 0.0f + c2, a3 = 0.0f + c3;
+    if constexpr (LPI <= 16 || LPI == 64) {   // 64: wave_shr:1 needs no select (lane 0 reads 0), measured faster than row scans
+#pragma unroll
+        for (int s = 1; s < LPI; s++) {
+            a0 = prev_lane<LPI>(a0, L) + c0;
+            a1 = prev_lane<LPI>(a1, L) + c1;
+            a2 = prev_lane<LPI>(a2, L) + c2;
+            a3 = prev_lane<LPI>(a3, L) + c3;
+        }
+    } else {
+        // LPI == 32, two 16-lane DPP rows per group: scan one row at a time with the cheap fused
+        // v_add_f32_dpp row_shr:1 (a row's first lane reads 0), and carry the finished sum of row r-1 into
+        // row r by FOLDING it into the addend of that row's first lane: a[16r] = 0 + (carry + c[16r]).
+        // Same additions in the same order as the chain a[m] = a[m-1] + c[m]; no per-step select
+        // (measured 23 ns per step with wave_shr + select vs 8 ns per step for a plain row_shr add).
+#pragma unroll
+        for (int s = 1; s < 16; s++) {
+            a0 = prev_lane<16>(a0, L) + c0; a1 = prev_lane<16>(a1, L) + c1;
+            a2 = prev_lane<16>(a2, L) + c2; a3 = prev_lane<16>(a3, L) + c3;
+        }
+#pragma unroll
+        for (int r = 1; r < LPI / 16; r++) {
+            const float s0 = group_bcast<LPI>(a0, 16 * r - 1), s1 = group_bcast<LPI>(a1, 16 * r - 1);
+            const float s2 = group_bcast<LPI>(a2, 16 * r - 1), s3 = group_bcast<LPI>(a3, 16 * r - 1);
+            if (L == 16 * r) { c0 = s0 + c0; c1 = s1 + c1; c2 = s2 + c2; c3 = s3 + c3; }
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                a0 = prev_lane<16>(a0, L) + c0; a1 = prev_lane<16>(a1, L) + c1;
+                a2 = prev_lane<16>(a2, L) + c2; a3 = prev_lane<16>(a3, L) + c3;
+            }
+        }
+    }
+    float h = (a0 + a2) + (a1 + a3);  // sum_all: movehl add, then shuffle add_ss
+    float sum = group_bcast<LPI>(h, LPI - 1);
+    if (ntail) {  // scalar tail, in index order
+        float t0 = group_bcast<LPI>(m0, nfull);
+        sum = sum + t0;
+        if (ntail > 1) { float t1 = group_bcast<LPI>(m1, nfull); sum = sum + t1; }
+        if (ntail > 2) { float t2 = group_bcast<LPI>(m2, nfull); sum = sum + t2; }
+    }
+    return sum;
+}
+
+// ------------------------------------------------------------------ wide rows (256 < num_factor <= 1024)
+// A whole wave owns the row, VPL float4 per lane: chunk c (elements 4c..4c+3) sits in lane c % 64, slot c / 64, so a
+// row gather is VPL fully coalesced 1 KiB loads.  Only the general kernels are instantiated for wide rows; the
+// helpers below are overloads of the float4 ones, so the per-instance code is written once for both (typename R).
+template <int VPL>
+struct WideRow { float4 v[VPL]; };
+template <typename R> struct row_traits;
+template <> struct row_traits<float4> {
+    static constexpr int VPL = 1;
+    static __device__ __forceinline__ float4 zero() { return f4zero(); }
+};
+template <int V> struct row_traits<WideRow<V>> {
+    static constexpr int VPL = V;
+    static __device__ __forceinline__ WideRow<V> zero() {
+        WideRow<V> r;
+#pragma unroll
+        for (int v = 0; v < V; v++) r.v[v] = f4zero();
+        return r;
+    }
+};
+template <int V> __device__ __forceinline__ void axpy4(WideRow<V> &d, const WideRow<V> &s, float a) {
+#pragma unroll
+    for (int v = 0; v < V; v++) axpy4(d.v[v], s.v[v], a);
+}
+template <int V> __device__ __forceinline__ void scale4(WideRow<V> &d, float a) {
+#pragma unroll
+    for (int v = 0; v < V; v++) scale4(d.v[v], a);
+}
+__device__ __forceinline__ void sub4(float4 &d, const float4 s) { d.x = d.x - s.x; d.y = d.y - s.y; d.z = d.z - s.z; d.w = d.w - s.w; }  // K5
+template <int V> __device__ __forceinline__ void sub4(WideRow<V> &d, const WideRow<V> &s) {
+#pragma unroll
+    for (int v = 0; v < V; v++) sub4(d.v[v], s.v[v]);
+}
+__device__ __forceinline__ void l1_row(float4 &w, float th) { w.x = l1(w.x, th); w.y = l1(w.y, th); w.z = l1(w.z, th); w.w = l1(w.w, th); }
+template <int V> __device__ __forceinline__ void l1_row(WideRow<V> &w, float th) {
+#pragma unroll
+    for (int v = 0; v < V; v++) l1_row(w.v[v], th);
+}
+__device__ __forceinline__ void clamp_nonneg(float4 &w) {  // K7 smaller_then_fill(w, 0)
+    if (w.x <= 0.0f) w.x = 0.0f;
+    if (w.y <= 0.0f) w.y = 0.0f;
+    if (w.z <= 0.0f) w.z = 0.0f;
+    if (w.w <= 0.0f) w.w = 0.0f;
+}
+template <int V> __device__ __forceinline__ void clamp_nonneg(WideRow<V> &w) {
+#pragma unroll
+    for (int v = 0; v < V; v++) clamp_nonneg(w.v[v]);
+}
+// K3 for wide rows: the same chain a[c] = a[c-1] + prod[c] over all chunks in index order; slot v is scanned across the
+// 64 lanes with wave_shr:1 adds, and the finished sum of slot v-1 (lane 63) is folded into the addend of slot v's
+// lane 0 -- the carry trick of the 32-lane groups above, one slot at a time.
+template <int LPI, int V>
+__device__ __forceinline__ float group_dot(const WideRow<V> &a, const WideRow<V> &b, int L, int k) {
+    static_assert(LPI == 64, "wide rows are owned by a whole wave");
+    const int nfull = k >> 2;
+    const int ntail = k & 3;
+    float a0 = 0.0f, a1 = 0.0f, a2 = 0.0f, a3 = 0.0f;
+    float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f;   // products of the tail chunk
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        const float m0 = a.v[v].x * b.v[v].x, m1 = a.v[v].y * b.v[v].y, m2 = a.v[v].z * b.v[v].z, m3 = a.v[v].w * b.v[v].w;
+        const bool full = L + 64 * v < nfull;
+        float c0 = full ? m0 : 0.0f, c1 = full ? m1 : 0.0f, c2 = full ? m2 : 0.0f, c3 = full ? m3 : 0.0f;
+        if (v > 0) {
+            const float s0 = group_bcast<64>(a0, 63), s1 = group_bcast<64>(a1, 63), s2 = group_bcast<64>(a2, 63), s3 = group_bcast<64>(a3, 63);
+            if (L == 0) { c0 = s0 + c0; c1 = s1 + c1; c2 = s2 + c2; c3 = s3 + c3; }
+        }
+        a0 = 0.0f + c0; a1 = 0.0f + c1; a2 = 0.0f + c2; a3 = 0.0f + c3;
+#pragma unroll
+        for (int s = 1; s < 64; s++) {
+            a0 = prev_lane<64>(a0, L) + c0; a1 = prev_lane<64>(a1, L) + c1;
+            a2 = prev_lane<64>(a2, L) + c2; a3 = prev_lane<64>(a3, L) + c3;
+        }
+        if (ntail && (nfull >> 6) == v) {   // the tail chunk lives in this slot, lane nfull % 64
+            t0 = group_bcast<64>(m0, nfull & 63); t1 = group_bcast<64>(m1, nfull & 63); t2 = group_bcast<64>(m2, nfull & 63);
+        }
+    }
+    const float h = (a0 + a2) + (a1 + a3);
+    float sum = group_bcast<64>(h, 63);
+    if (ntail) {
+        sum = sum + t0;
+        if (ntail > 1) sum = sum + t1;
+        if (ntail > 2) sum = sum + t2;
+    }
+    return sum;
+}
+
+// apex_svd_model.h:112-123
+__device__ __forceinline__ float map_active(float sum, int type) {
+    if (type == ACT_SIGMOID_L2 || type == ACT_SIGMOID_LIKELIHOOD) return 1.0f / (1.0f + expf(-sum));
+    return sum;
+}
+__device__ __forceinline__ float smooth_hinge_grad(float z) {
+    if (z > 1.0f) return 0.0f;
+    if (z < 0.0f) return 1.0f;
+    return 1.0f - z;
+}
+// apex_svd_model.h:132-156
+__device__ __forceinline__ float cal_grad(float r, float pred, int type) {
+    switch (type) {
+    case ACT_LINEAR: return r - pred;
+    case ACT_SIGMOID_L2: return (r - pred) * pred * (1 - pred);
+    case ACT_SIGMOID_LIKELIHOOD: return r - pred;
+    case ACT_SIGMOID_QSGRAD:
+    case ACT_SIGMOID_RANK: return r - 1.0f / (1.0f + expf(-pred));
+    case ACT_HINGE_SMOOTH:
+        if (r > 0.5f) return smooth_hinge_grad(pred - 0.5f);
+        return -smooth_hinge_grad(0.5f - pred);
+    case ACT_HINGE_L2:
+        if (r > 0.5f) { if (pred > 1.0f) return 0.0f; return r - pred; }
+        if (pred < 0.0f) return 0.0f;
+        return r - pred;
+    default: return 0.0f;
+    }
+}
+// ParameterSet::get_wd (apex_svd_base.h:69-74); ranges are validated on the host
+__device__ __forceinline__ float get_wd(const DevRanges &rg, unsigned id, float dflt) {
+    if (rg.n == 0) return dflt;
+    int lo = 0, hi = rg.n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (rg.bound[mid] < id) lo = mid + 1; else hi = mid; }
+    return rg.wd[lo < rg.n ? lo : rg.n - 1];
+}
+
+// position of a global bias in device memory: contiguous (stride 1) normally; in relaxed-global mode one per 128-byte
+// line (stride 32), because atomics to the same line serialise
+__device__ __forceinline__ size_t gpos(const DevParams &P, unsigned gid) { return (size_t)gid * (size_t)P.g_stride; }
+// factor-row regularisation (reg_user / reg_item, apex_svd_base.h:211-283) on a row held in
+// registers.  is_item selects the item flavour of reg_method 3 (L2) and skips the nonneg clamp.
+// Lazy modes 4/5 (:225-238, :265-278) take kk = (float)(ref[id] - sample_counter): the reference subtracts two
+// UNSIGNED counters, so kk is 0 for an id touched in this very instance and about 4.29e9 otherwise; restated as is.
+template <int LPI, typename R>
+__device__ __forceinline__ void reg_row(const DevParams &P, R &w, float wd, bool is_item, int L, float kk = 0.0f) {
+    const float lambda = P.lr * wd;
+    int method = P.reg_method;
+    if (method == 3) method = is_item ? 0 : 1;
+    if (method == 0) {
+        scale4(w, 1.0f - lambda);
+    } else if (method == 1) {
+        l1_row(w, lambda);
+    } else if (method == 2) {  // project(): ||w||^2 <= wd
+        float sum = group_dot<LPI>(w, w, L, P.k);
+        if (sum > wd) scale4(w, sqrtf(wd / sum));
+    } else if (method == 4) {  // lazy L2
+        scale4(w, expf(logf(1.0f - lambda) * kk));
+    } else if (method == 5) {  // lazy L1
+        l1_row(w, lambda * kk);
+    }
+    if (!is_item && P.user_nonnegative) clamp_nonneg(w);
+}
+__device__ __forceinline__ float reg_gbias(const DevParams &P, unsigned gid, float g, unsigned counter = 0) {  // :188-210
+    float lambda = P.lr * get_wd(P.g_rng, gid, P.wd_global);
+    if (gid >= P.num_regfree_global) {
+        if (P.reg_global == 0) g = g * (1.0f - lambda);
+        else if (P.reg_global == 1) g = l1(g, lambda);
+        else {  // 4 lazy L2, 5 lazy L1 (:194-205); regfree ids keep their ref untouched like the reference
+            const float kk = (float)(unsigned)(P.ref_global[gid] - counter);
+            P.ref_global[gid] = counter;
+            if (P.reg_global == 4) g = g * expf(logf(1.0f - lambda) * kk);
+            else g = l1(g, lambda * kk);
+        }
+    }
+    return g;
+}
+// kk of a factor row for the lazy modes; every lane of the group reads the same ref word, then writes the same value
+__device__ __forceinline__ float lazy_span(const DevParams &P, unsigned row, unsigned counter) {
+    if (P.reg_method < 4) return 0.0f;
+    const float kk = (float)(unsigned)(P.ref_ui[row] - counter);
+    P.ref_ui[row] = counter;
+    return kk;
+}
+
+template <int LPI>
+__device__ __forceinline__ float4 load_row(const float *W, size_t row, int pitch, int L, int k) {
+    if (LPI * 4 > k && L * 4 >= k) return f4zero();
+    return *reinterpret_cast<const float4 *>(W + row * (size_t)pitch + (size_t)L * 4);
+}
+template <int LPI>
+__device__ __forceinline__ void store_row(float *W, size_t row, int pitch, int L, int k, const float4 v) {
+    if (LPI * 4 > k && L * 4 >= k) return;
+    *reinterpret_cast<float4 *>(W + row * (size_t)pitch + (size_t)L * 4) = v;
+}
+
+// row store with a cache policy: 0 plain (line stays dirty in the XCD's L2 until the kernel ends),
+// 1 nontemporal hint, 2 sc1 write-through (the line leaves L2 as soon as it is written)
+typedef float svdf_f4 __attribute__((ext_vector_type(4)));
+template <int LPI>
+__device__ __forceinline__ void store_row_policy(float *W, size_t row, int pitch, int L, int k, const float4 v, int mode) {
+    if (LPI * 4 > k && L * 4 >= k) return;
+    float *ptr = W + row * (size_t)pitch + (size_t)L * 4;
+    if (mode == 0) {
+        *reinterpret_cast<float4 *>(ptr) = v;
+    } else {
+        svdf_f4 x = {v.x, v.y, v.z, v.w};
+        if (mode == 1) __builtin_nontemporal_store(x, reinterpret_cast<svdf_f4 *>(ptr));
+        else asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(ptr), "v"(x) : "memory");
+    }
+}
+
+// row load / store by row type (float4: one lane group per row; WideRow: the whole wave, VPL slots)
+template <int LPI, typename R> struct row_io;
+template <int LPI> struct row_io<LPI, float4> {
+    static __device__ __forceinline__ float4 load(const float *W, size_t row, int pitch, int L, int k) { return load_row<LPI>(W, row, pitch, L, k); }
+    static __device__ __forceinline__ void store(float *W, size_t row, int pitch, int L, int k, const float4 &v) { store_row<LPI>(W, row, pitch, L, k, v); }
+};
+template <int LPI, int V> struct row_io<LPI, WideRow<V>> {
+    static_assert(LPI == 64, "wide rows are owned by a whole wave");
+    static __device__ __forceinline__ WideRow<V> load(const float *W, size_t row, int pitch, int L, int k) {
+        WideRow<V> r;
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int e = 4 * (L + 64 * v);
+            r.v[v] = e < k ? *reinterpret_cast<const float4 *>(W + row * (size_t)pitch + (size_t)e) : f4zero();
+        }
+        return r;
+    }
+    static __device__ __forceinline__ void store(float *W, size_t row, int pitch, int L, int k, const WideRow<V> &r) {
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const int e = 4 * (L + 64 * v);
+            if (e < k) *reinterpret_cast<float4 *>(W + row * (size_t)pitch + (size_t)e) = r.v[v];
+        }
+    }
+};
+
+
+// ---- launch helpers (host side)
+static inline int grid_for(long groups, int lpi, int cap) {
+    const long per_block = 4L * (64 / lpi);
+    long g = (groups + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// (variadic: a launch expands to kernel<<<a, b, c, d>>>(...), whose bare commas must survive being passed on)
+#define SVDF_DISPATCH_LPI(lpi, ...)                          \
+    switch (lpi) {                                           \
+    case 1: { constexpr int LPI = 1; __VA_ARGS__; } break;   \
+    case 2: { constexpr int LPI = 2; __VA_ARGS__; } break;   \
+    case 4: { constexpr int LPI = 4; __VA_ARGS__; } break;   \
+    case 8: { constexpr int LPI = 8; __VA_ARGS__; } break;   \
+    case 16: { constexpr int LPI = 16; __VA_ARGS__; } break; \
+    case 32: { constexpr int LPI = 32; __VA_ARGS__; } break; \
+    default: { constexpr int LPI = 64; __VA_ARGS__; } break; \
+    }
+// general-path kernels: LPI as above with float4 rows up to 256 factors, a whole wave with 2..4 float4 slots beyond
+#define SVDF_DISPATCH_ROW(k, ...)                                                          \
+    if ((k) <= 256) {                                                                      \
+        using R = float4;                                                                  \
+        SVDF_DISPATCH_LPI(lanes_per_instance(k), __VA_ARGS__)                              \
+    } else if ((k) <= 512) { constexpr int LPI = 64; using R = WideRow<2>; __VA_ARGS__; }  \
+    else if ((k) <= 768) { constexpr int LPI = 64; using R = WideRow<3>; __VA_ARGS__; }    \
+    else { constexpr int LPI = 64; using R = WideRow<4>; __VA_ARGS__; }
+
+
+}  // namespace svdf
+#endif

@@ -5,7 +5,7 @@
 // rand_init (libc rand(), bit-identical start), staging of borrowed instances, and the
 // CONFLICT-FREE BATCH SCHEDULER that turns the reference's strictly sequential SGD into
 // dependency-respecting parallel launches.  All arithmetic on parameters
-// happens in the HIP kernels (svdf_kernels.hip); there is no CPU compute fallback.
+// happens in the HIP kernels (svdf_k_*.hip); there is no CPU compute fallback.
 #ifndef SVDF_ENGINE_H_
 #define SVDF_ENGINE_H_
 

@@ -1,0 +1,86 @@
+// svdf_k_misc.hip -- multi-GPU delta kernels, layout queries
+// (part of the gfx950 kernel set described at the top of svdf_device.h)
+#include "svdf_device.h"
+
+namespace svdf {
+
+// ---- multi-GPU item-side delta exchange -------------------------------------
+__global__ void k_delta_sub(const float *cur, const float *snap, float *delta, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = i; j < n; j += stride) delta[j] = cur[j] - snap[j];
+}
+__global__ void k_delta_add(float *cur, const float *snap, const float *delta, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = i; j < n; j += stride) cur[j] = snap[j] + delta[j];
+}
+
+int lanes_per_instance(int k) {
+    int chunks = (k + 3) / 4;
+    int lpi = 1;
+    while (lpi < chunks && lpi < 64) lpi <<= 1;
+    return lpi;   // 64 also for wide rows (k > 256: several float4 slots per lane)
+}
+int max_supported_factor() { return 1024; }
+int max_fast_path_factor() { return 256; }
+
+// One launch over ALL replicated ranges (W_item, biases, globals ...): pack = (current - snapshot) in the wire type,
+// unpack = current <- snapshot + delta, optionally snapshot <- current so that the next window needs no copy.
+// fp16 conversion is round-to-nearest-even (what a separate .half() pass would do).
+__device__ __forceinline__ float *delta_slot(const DeltaRanges &R, long j) {
+    int r = 0;
+#pragma unroll
+    for (int q = 1; q < SVDF_MAX_DELTA_RANGES; q++) r += (q < R.n && j >= R.off[q]) ? 1 : 0;
+    return R.base[r] + (j - R.off[r]);
+}
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_delta_pack(const DeltaRanges R, const float *snap, void *dst, long total) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        const float d = *delta_slot(R, j) - snap[j];
+        if (HALF) reinterpret_cast<__half *>(dst)[j] = __float2half_rn(d);
+        else reinterpret_cast<float *>(dst)[j] = d;
+    }
+}
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_delta_unpack(const DeltaRanges R, float *snap, const void *src, long total, int refresh) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        const float d = HALF ? __half2float(reinterpret_cast<const __half *>(src)[j]) : reinterpret_cast<const float *>(src)[j];
+        const float v = snap[j] + d;
+        *delta_slot(R, j) = v;
+        if (refresh) snap[j] = v;
+    }
+}
+void launch_delta_pack(const DeltaRanges &R, const float *snap, void *dst, int half, hipStream_t st) {
+    const long total = R.off[R.n];
+    if (total <= 0) return;
+    long grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (half) hipLaunchKernelGGL(k_delta_pack<true>, dim3((int)grid), dim3(256), 0, st, R, snap, dst, total);
+    else hipLaunchKernelGGL(k_delta_pack<false>, dim3((int)grid), dim3(256), 0, st, R, snap, dst, total);
+}
+void launch_delta_unpack(const DeltaRanges &R, float *snap, const void *src, int half, int refresh, hipStream_t st) {
+    const long total = R.off[R.n];
+    if (total <= 0) return;
+    long grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (half) hipLaunchKernelGGL(k_delta_unpack<true>, dim3((int)grid), dim3(256), 0, st, R, snap, src, total, refresh);
+    else hipLaunchKernelGGL(k_delta_unpack<false>, dim3((int)grid), dim3(256), 0, st, R, snap, src, total, refresh);
+}
+void launch_delta_sub(const float *cur, const float *snap, float *delta, long n, hipStream_t st) {
+    if (n <= 0) return;
+    long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_delta_sub, dim3((int)grid), dim3(256), 0, st, cur, snap, delta, n);
+}
+void launch_delta_add(float *cur, const float *snap, const float *delta, long n, hipStream_t st) {
+    if (n <= 0) return;
+    long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_delta_add, dim3((int)grid), dim3(256), 0, st, cur, snap, delta, n);
+}
+
+
+}  // namespace svdf

@@ -1,0 +1,553 @@
+// svdf_k_wave.hip -- one-wave-per-user SVD++ kernel (k_svdpp_wave) and its launcher
+// (part of the gfx950 kernel set described at the top of svdf_device.h)
+#include "svdf_device.h"
+
+namespace svdf {
+
+// ---- fast path for "simple" units (host-verified, UNIT_SIMPLE): every row is (no global, ONE user id -- the same for
+// the whole unit --, one item id), the unit's item ids are pairwise distinct, its feedback ids are pairwise distinct,
+// no side tables, separate feedback/user/item row spaces.
+//
+// A user's rows are a strict recurrence (p_u, tmp_ufeedback -> err -> p_u, tmp_ufeedback), and exact sequential
+// semantics leave only a handful of users per conflict-free batch, so this path is LATENCY-bound: what counts is the
+// number of dependent instructions per row, not bytes.  Layout for that: ONE WAVE PER USER, one element per lane and
+// register, arranged so that the reference's four SSE accumulation chains (elements j, j+4, j+8, ... for j = 0..3)
+// each live in their own 16-lane DPP row:
+//      lane = 16*j + m,  register q   <->   element 4*(NR*m + q) + j        (NR = registers per row = ceil(k/64))
+// i.e. lane m of a DPP row holds the NR consecutive chunks NR*m .. NR*m+NR-1 of its chain.  The whole dot product
+// is then 15 steps of ONE v_add_f32_dpp row_shr:1 (all four chains at once) followed by NR-1 plain adds inside the
+// lane -- a dependent DPP add costs ~19 cycles, a plain one ~8, so wide rows pay 15 slow steps, not 16*NR-1 --
+// against 4 instructions per step and bpermute carries in the float4-per-lane layout; every elementwise op (axpy,
+// decay, L1 ...) is k/64 instructions instead of 4.  Measured on MI355X (tools/svdpp_latency2.py): DESIGN.md section 5.
+//   * the user's factor row, bias and the feedback state stay in registers for the whole unit,
+//   * item rows (and their records, via scalar loads: everything about a row is wave-uniform) are fetched
+//     SVDPP_PFW rows ahead, item rows are written once, fire and forget,
+//   * feedback rows are gathered / scattered a batch (16 or 32) at a time, the next batch in flight meanwhile
+//     (accumulation order unchanged).
+constexpr int SVDPP_PFW = 8;   // rows fetched ahead (double-buffered: 8..16 rows = 2..4 us of lookahead)
+// feedback rows per gather / scatter batch; two batches are in flight (HBM + translation latency is ~2 us, a batch of
+// 16 accumulates in ~0.4 us)
+template <int NR> struct svdpp_fbw { static constexpr int value = 16; };   // 32 measured slower (VGPRs spill to AGPRs)
+// batches of feedback rows in flight ahead of the one being accumulated / scattered (2 measured no faster than 1:
+// 64.3 vs 62.1 us for a unit of 100 rows + 100 ids at k=128 -- the phase is bound by the loads' issue, not their latency)
+template <int NR> struct svdpp_fbdepth { static constexpr int value = 1; };
+
+template <int NR>
+struct ChainRow { float r[NR]; };
+
+__device__ __forceinline__ float dpp_row_shr1(float v) {   // lane m <- lane m-1 of its 16-lane row, 0 into m = 0
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float lane_value(float v, int lane) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane)); }
+__device__ __forceinline__ float wave_uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// Load of read-only launch data (schedule records, unit descriptors, feedback lists) at a wave-uniform address through
+// the constant address space: the backend may then use the scalar unit (s_load, lgkmcnt) instead of a vector load
+// with 64 identical addresses -- the kernel never writes these arrays, which it cannot prove by itself because the
+// parameter tables it does write are reachable through plain pointers too.  Keeps vmcnt for the row traffic.
+template <typename T> __device__ __forceinline__ T uniform_load(const T *p) {
+    typedef const T __attribute__((address_space(4))) * cptr;
+    return *reinterpret_cast<cptr>(reinterpret_cast<uintptr_t>(p));
+}
+template <int NR> __device__ __forceinline__ ChainRow<NR> chain_zero() {
+    ChainRow<NR> z;
+#pragma unroll
+    for (int q = 0; q < NR; q++) z.r[q] = 0.0f;
+    return z;
+}
+// k < 0 tells the row is FULL (num_factor == 64*NR, the usual case): no per-lane bounds test, hence no exec-mask branch
+// around every load and store of the instruction-bound row loop
+template <int NR> __device__ __forceinline__ ChainRow<NR> chain_load(const float *W, size_t row, int pitch, int lane, int k) {
+    const float *base = W + row * (size_t)pitch;
+    const int e0 = 4 * NR * (lane & 15) + (lane >> 4);
+    ChainRow<NR> x;
+#pragma unroll
+    for (int q = 0; q < NR; q++) { const int e = e0 + 4 * q; x.r[q] = (k < 0 || e < k) ? base[e] : 0.0f; }
+    return x;
+}
+template <int NR> __device__ __forceinline__ void chain_store(float *W, size_t row, int pitch, int lane, int k, const ChainRow<NR> &x) {
+    float *base = W + row * (size_t)pitch;
+    const int e0 = 4 * NR * (lane & 15) + (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < NR; q++) { const int e = e0 + 4 * q; if (k < 0 || e < k) base[e] = x.r[q]; }
+}
+// relaxed shared rows: W[row] += x, element by element, with hardware float atomics (chain layout addresses)
+template <int NR> __device__ __forceinline__ void chain_atomic_add(float *W, size_t row, int pitch, int lane, int k, const ChainRow<NR> &x) {
+    float *base = W + row * (size_t)pitch;
+    const int e0 = 4 * NR * (lane & 15) + (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < NR; q++) { const int e = e0 + 4 * q; if (k < 0 || e < k) unsafeAtomicAdd(base + e, x.r[q]); }
+}
+// The same registers in LINEAR layout: lane l holds the NR consecutive elements NR*l .. NR*l+NR-1, i.e. a row is ONE fully
+// contiguous 256*NR-byte load or store per wave.  The feedback phases (prepare_ufeedback / update_ufeedback) only do
+// elementwise work on hundreds of rows, which is layout-agnostic: they run in linear layout and convert the one row that
+// crosses into the chain-layout row loop (tmp_ufeedback, the scatter delta) with NR*NR ds_bpermutes per phase.
+template <int NR> __device__ __forceinline__ ChainRow<NR> lin_load(const float *W, size_t row, int pitch, int lane, int k) {
+    const float *base = W + row * (size_t)pitch + NR * lane;
+    ChainRow<NR> x;
+    if (k < 0) {
+        if constexpr (NR == 1) x.r[0] = base[0];
+        else if constexpr (NR == 2) { const float2 t = *reinterpret_cast<const float2 *>(base); x.r[0] = t.x; x.r[1] = t.y; }
+        else if constexpr (NR == 4) { const float4 t = *reinterpret_cast<const float4 *>(base); x.r[0] = t.x; x.r[1] = t.y; x.r[2] = t.z; x.r[3] = t.w; }
+        else {
+#pragma unroll
+            for (int c = 0; c < NR; c++) x.r[c] = base[c];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NR; c++) x.r[c] = (NR * lane + c < k) ? base[c] : 0.0f;
+    }
+    return x;
+}
+template <int NR> __device__ __forceinline__ void lin_store(float *W, size_t row, int pitch, int lane, int k, const ChainRow<NR> &x) {
+    float *base = W + row * (size_t)pitch + NR * lane;
+    if (k < 0) {
+        if constexpr (NR == 1) base[0] = x.r[0];
+        else if constexpr (NR == 2) *reinterpret_cast<float2 *>(base) = make_float2(x.r[0], x.r[1]);
+        else if constexpr (NR == 4) *reinterpret_cast<float4 *>(base) = make_float4(x.r[0], x.r[1], x.r[2], x.r[3]);
+        else {
+#pragma unroll
+            for (int c = 0; c < NR; c++) base[c] = x.r[c];
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NR; c++) if (NR * lane + c < k) base[c] = x.r[c];
+    }
+}
+template <int NR> __device__ __forceinline__ void lin_atomic_add(float *W, size_t row, int pitch, int lane, int k, const ChainRow<NR> &x) {
+    float *base = W + row * (size_t)pitch + NR * lane;
+#pragma unroll
+    for (int c = 0; c < NR; c++) if (k < 0 || NR * lane + c < k) unsafeAtomicAdd(base + c, x.r[c]);
+}
+__device__ __forceinline__ float lane_gather(float v, int src_lane) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+// chain layout (lane 16j+m, register q <-> element 4*(NR*m+q)+j)  <->  linear layout (lane l, slot c <-> element NR*l+c)
+template <int NR> __device__ __forceinline__ ChainRow<NR> lin_to_chain(const ChainRow<NR> &lin, int lane) {
+    ChainRow<NR> out;
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        const int e = 4 * (NR * (lane & 15) + q) + (lane >> 4);
+        const int src = e / NR, comp = e % NR;
+        float v = lane_gather(lin.r[0], src);
+#pragma unroll
+        for (int c = 1; c < NR; c++) { const float t = lane_gather(lin.r[c], src); v = (comp == c) ? t : v; }
+        out.r[q] = v;
+    }
+    return out;
+}
+template <int NR> __device__ __forceinline__ ChainRow<NR> chain_to_lin(const ChainRow<NR> &ch, int lane) {
+    ChainRow<NR> out;
+#pragma unroll
+    for (int c = 0; c < NR; c++) {
+        const int e = NR * lane + c;
+        const int chunk = e >> 2;
+        const int src = 16 * (e & 3) + chunk / NR, qsel = chunk % NR;
+        float v = lane_gather(ch.r[0], src);
+#pragma unroll
+        for (int q = 1; q < NR; q++) { const float t = lane_gather(ch.r[q], src); v = (qsel == q) ? t : v; }
+        out.r[c] = v;
+    }
+    return out;
+}
+// K1 / K2 with a wave-uniform scalar
+template <int NR> __device__ __forceinline__ void chain_axpy(ChainRow<NR> &d, const ChainRow<NR> &s, float a) {
+    const float a1 = snap_to_one(a);
+#pragma unroll
+    for (int q = 0; q < NR; q++) { const float m = s.r[q] * a1; d.r[q] = d.r[q] + m; }
+}
+template <int NR> __device__ __forceinline__ void chain_scale(ChainRow<NR> &d, float a) {
+    const float a1 = snap_to_one(a);
+#pragma unroll
+    for (int q = 0; q < NR; q++) d.r[q] = d.r[q] * a1;
+}
+// K3 in the chain layout; the result is wave-uniform.  Lane m adds its NR chunks, in order, to the running sum handed
+// over by lane m-1; all lanes run the 15 hand-over steps (lanes below the step index are final already and recompute the
+// same value), so there is no select and no cross-register carry.
+template <int NR> __device__ __forceinline__ float chain_dot(const ChainRow<NR> &a, const ChainRow<NR> &b, int lane, int k) {
+    const int nfull = k >> 2, ntail = k & 3, m = lane & 15;
+    float prod[NR], c[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+        prod[q] = a.r[q] * b.r[q];
+        c[q] = (NR * m + q < nfull) ? prod[q] : 0.0f;   // chunks beyond the full ones feed +0, the sums travel on
+    }
+    float acc = 0.0f + c[0];
+#pragma unroll
+    for (int q = 1; q < NR; q++) acc = acc + c[q];
+#pragma unroll
+    for (int s = 1; s < 16; s++) {
+        acc = dpp_row_shr1(acc) + c[0];
+#pragma unroll
+        for (int q = 1; q < NR; q++) acc = acc + c[q];
+    }
+    const float s0 = lane_value(acc, 15), s1 = lane_value(acc, 31), s2 = lane_value(acc, 47), s3 = lane_value(acc, 63);
+    float sum = (s0 + s2) + (s1 + s3);   // sum_all: movehl add, then shuffle add_ss
+    if (ntail) {                         // scalar tail, in index order: chunk nfull = lane nfull / NR, register nfull % NR
+        float pt = prod[0];
+#pragma unroll
+        for (int q = 1; q < NR; q++) pt = (nfull % NR) == q ? prod[q] : pt;
+        const int tm = nfull / NR;
+        sum = sum + lane_value(pt, tm);
+        if (ntail > 1) sum = sum + lane_value(pt, 16 + tm);
+        if (ntail > 2) sum = sum + lane_value(pt, 32 + tm);
+    }
+    return sum;
+}
+// reg_user / reg_item on a row in registers (reg modes 0..3; lazy modes never reach the fast path)
+template <int NR> __device__ __forceinline__ void chain_reg(const DevParams &P, ChainRow<NR> &w, float wd, bool is_item, int lane, int k) {
+    const float lambda = P.lr * wd;
+    int method = P.reg_method;
+    if (method == 3) method = is_item ? 0 : 1;
+    if (method == 0) {
+        chain_scale(w, 1.0f - lambda);
+    } else if (method == 1) {
+#pragma unroll
+        for (int q = 0; q < NR; q++) w.r[q] = l1(w.r[q], lambda);
+    } else if (method == 2) {
+        const float sum = chain_dot(w, w, lane, k);
+        if (sum > wd) chain_scale(w, sqrtf(wd / sum));
+    }
+    if (!is_item && P.user_nonnegative) {
+#pragma unroll
+        for (int q = 0; q < NR; q++) if (w.r[q] <= 0.0f) w.r[q] = 0.0f;
+    }
+}
+// Records of a user's rows, 64 rows at a time, one row per lane (same scheme as FbBlock below): label, item id, the
+// re-read flag and -- unless the unit-value specialisation applies -- the two feature values
+struct RowBlock {
+    float label, uv, iv;
+    unsigned item;
+    int fresh;
+};
+template <bool UV>
+__device__ __forceinline__ RowBlock row_block(const DevCSR &D, int row_begin, int e0, int first, int nrow, int lane) {
+    const int j = min(first + lane, nrow - 1);   // rows beyond the unit's end repeat its last row (fetched, never used)
+    RowBlock b;
+    b.label = D.row_label[row_begin + j];
+    b.item = D.feat_index[e0 + 2 * j + 1];
+    b.fresh = D.row_fresh ? (int)D.row_fresh[row_begin + j] : 0;
+    b.uv = UV ? 1.0f : D.feat_value[e0 + 2 * j];
+    b.iv = UV ? 1.0f : D.feat_value[e0 + 2 * j + 1];
+    return b;
+}
+__device__ __forceinline__ float pick(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ int pick(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ unsigned pick(unsigned v, int l) { return (unsigned)__builtin_amdgcn_readlane((int)v, l); }
+template <int NR>
+struct ChainRowPF {   // the fetched-ahead part of one row: the item's factor row and bias (its id for the store)
+    ChainRow<NR> q;
+    float bi;
+    unsigned irow;
+};
+// the SVDPP_PFW rows at offsets off .. off+SVDPP_PFW-1 of block b
+template <int NR>
+__device__ __forceinline__ void chain_fetch_rows(const DevParams &P, const RowBlock &b, int off, int lane, int kio, ChainRowPF<NR> (&o)[SVDPP_PFW]) {
+#pragma unroll
+    for (int c = 0; c < SVDPP_PFW; c++) {
+        o[c].irow = P.item_off + pick(b.item, off + c);
+        o[c].q = chain_load<NR>(P.W, o[c].irow, P.pitch, lane, kio);
+        o[c].bi = P.bias[o[c].irow];
+    }
+}
+
+// Feedback ids and values of a user, 64 at a time: lane l of the wave holds entry first + l (clamped to the last one), loaded
+// with ONE coalesced vector load per 64 entries; an entry is picked with v_readlane right where it is used.  (Fetching
+// them one by one through the scalar unit serialises: each s_load result was spilled to a VGPR lane behind its own
+// lgkmcnt(0) wait -- three batches of ids do not fit the SGPR file -- 0.12 us per id.)
+struct FbBlock {
+    unsigned id;   // this lane's feedback id
+    float v;       // and its value
+};
+__device__ __forceinline__ FbBlock fb_block(const unsigned *fidx, const float *fval, int first, int nfb, int lane) {
+    const int j = min(first + lane, nfb - 1);
+    FbBlock b;
+    b.id = fidx[j];
+    b.v = fval[j];
+    return b;
+}
+__device__ __forceinline__ unsigned fb_id(const FbBlock &b, int l) { return (unsigned)__builtin_amdgcn_readlane((int)b.id, l); }
+__device__ __forceinline__ float fb_val(const FbBlock &b, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(b.v), l)); }
+// rows of one batch (entries off .. off+FBW-1 of block b); indices past the end were clamped when the block was loaded:
+// such rows are fetched but never accumulated or stored
+template <int NR> struct FbRows { ChainRow<NR> w[svdpp_fbw<NR>::value]; float b[svdpp_fbw<NR>::value]; };
+template <int NR>
+__device__ __forceinline__ void fb_fetch_rows(const DevParams &P, const FbBlock &blk, int off, bool ub, int lane, int kio, FbRows<NR> &o) {
+#pragma unroll
+    for (int c = 0; c < svdpp_fbw<NR>::value; c++) {
+        const unsigned row = P.fb_off + fb_id(blk, off + c);
+        o.w[c] = lin_load<NR>(P.W, row, P.pitch, lane, kio);   // LINEAR layout: one contiguous load per row
+        o.b[c] = ub ? P.bias[row] : 0.0f;
+    }
+}
+
+// one simple unit, start to end, by one wave (u and everything derived from it is wave-uniform).
+// FAST: the configuration of every BASELINE run -- linear link, L2 decay (reg_method 0), user bias on, no per-range
+// decay, no nonnegativity clamp -- compiled without the per-row switches; anything else takes the general instantiation.
+// FULL: num_factor == 64*NR, so no lane is ever out of the row and the dot has no masked chunks and no tail.
+// UV: every feature value of the fast-path units is 1.0 (the usual rating data): values are compile-time constants.
+// RX: relaxed mode compiled in (atomic adds to item / feedback rows); the exact kernels carry none of it.
+template <int NR, bool FAST, bool FULL, bool UV, bool RX>
+__device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR &D, const DevUnit &u, const unsigned *fb_index,
+                                                const float *fb_value, int lane) {
+    const int pitch = P.pitch;
+    const int k = FULL ? 64 * NR : P.k;      // dot / projection width
+    const int kio = FULL ? -1 : P.k;         // bound of row loads / stores (-1: none)
+    const bool ub = FAST ? true : P.no_user_bias == 0;
+    const bool rx_item = RX && P.relax_item_from == 0u, rx_fb = RX && P.relax_feedback != 0;   // wave-uniform
+    const unsigned *fidx = fb_index + u.fb_begin;
+    const float *fval = fb_value + u.fb_begin;
+    const int nfb = u.fb_end - u.fb_begin;
+    ChainRow<NR> tmp_fb = chain_zero<NR>(), old_fb = chain_zero<NR>();
+    float norm = 0.0f, tmp_bias = 0.0f, old_bias = 0.0f;
+    float *st = P.svdpp_state;
+    if (u.flags & UNIT_LOAD) {
+        tmp_fb = chain_load<NR>(st, 0, pitch, lane, kio);
+        old_fb = chain_load<NR>(st, 1, pitch, lane, kio);
+        norm = st[2 * pitch]; tmp_bias = st[2 * pitch + 1]; old_bias = st[2 * pitch + 2];
+    }
+    if (u.flags & UNIT_START) {   // prepare_ufeedback (:523-538)
+        norm = 0.0f; tmp_fb = chain_zero<NR>(); tmp_bias = 0.0f;
+        if (nfb > 0) {
+            static_assert(64 % svdpp_fbw<NR>::value == 0, "a batch must not straddle two id blocks");
+            // queue slot 0: the batch being accumulated; slots 1..DEPTH: batches whose rows are in flight; blkn: the id
+            // block after the newest slot's, loaded a block ahead
+            constexpr int FBW = svdpp_fbw<NR>::value, DEPTH = svdpp_fbdepth<NR>::value;
+            FbBlock blk[DEPTH + 1], blkn;
+            int off[DEPTH + 1];
+            FbRows<NR> rq[DEPTH + 1];
+            blk[0] = fb_block(fidx, fval, 0, nfb, lane);
+            blkn = fb_block(fidx, fval, 64, nfb, lane);
+            off[0] = 0;
+            fb_fetch_rows<NR>(P, blk[0], 0, ub, lane, kio, rq[0]);
+#pragma unroll
+            for (int d = 1; d <= DEPTH; d++) {   // (DEPTH * FBW < 64: the first batches all sit in the first block)
+                blk[d] = blk[0]; off[d] = d * FBW;
+                if (d < DEPTH) fb_fetch_rows<NR>(P, blk[d], off[d], ub, lane, kio, rq[d]);
+            }
+            for (int j0 = 0; j0 < nfb; j0 += FBW) {
+                off[DEPTH] = (j0 + DEPTH * FBW) & 63;
+                if (off[DEPTH] == 0) { blk[DEPTH] = blkn; blkn = fb_block(fidx, fval, j0 + DEPTH * FBW + 64, nfb, lane); }
+                fb_fetch_rows<NR>(P, blk[DEPTH], off[DEPTH], ub, lane, kio, rq[DEPTH]);
+#pragma unroll
+                for (int c = 0; c < FBW; c++) {
+                    if (j0 + c < nfb) {
+                        const float v = fb_val(blk[0], off[0] + c);
+                        chain_axpy(tmp_fb, rq[0].w[c], v);   // (tmp_fb is in LINEAR layout during this phase)
+                        norm = norm + v * v;
+                        if (ub) tmp_bias = tmp_bias + rq[0].b[c] * v;
+                    }
+                }
+#pragma unroll
+                for (int d = 0; d < DEPTH; d++) { rq[d] = rq[d + 1]; blk[d] = blk[d + 1]; off[d] = off[d + 1]; }
+            }
+            tmp_fb = lin_to_chain<NR>(tmp_fb, lane);   // elementwise sums are layout-agnostic: convert the result once
+        }
+        old_bias = tmp_bias;
+        old_fb = tmp_fb;
+    }
+    const int nrow = u.row_end - u.row_begin;
+    if (nrow > 0) {
+        const int e0 = uniform_load(D.row_ptr + 3 * (long)u.row_begin);   // rows are (0,1,1): entries of row j start at e0 + 2j
+        const unsigned urow = P.user_off + uniform_load(D.feat_index + e0);
+        ChainRow<NR> p = chain_load<NR>(P.W, urow, pitch, lane, kio);
+        float bu = ub ? P.bias[urow] : 0.0f;
+        const float wd_u = FAST ? P.wd_user : get_wd(P.u_rng, urow - P.user_off, P.wd_user);
+        const float lr = P.lr;
+        // row-invariant scalars of update_svdpp and of the L2 decays, and whether their multiply is skipped
+        const float lr2 = lr * P.scale_lr_ufeedback;
+        const float dec_fb = 1.0f - lr2 * P.wd_ufeedback, dec_fbb = 1.0f - lr2 * P.wd_ufeedback_bias;
+        const float dec_u = 1.0f - lr * wd_u, dec_i = 1.0f - lr * P.wd_item;
+        const float dec_ub = 1.0f - lr * P.wd_user_bias, dec_ib = 1.0f - lr * P.wd_item_bias;
+        const float dec_fb1 = snap_to_one(dec_fb), dec_u1 = snap_to_one(dec_u), dec_i1 = snap_to_one(dec_i);
+        static_assert(64 % SVDPP_PFW == 0, "a group of rows must not straddle two record blocks");
+        // rb_cur / rb_pre: record blocks of the group being processed / being fetched ahead; rb_next: the block after rb_pre's
+        RowBlock rb_cur = row_block<UV>(D, u.row_begin, e0, 0, nrow, lane), rb_pre = rb_cur;
+        RowBlock rb_next = row_block<UV>(D, u.row_begin, e0, 64, nrow, lane);
+        ChainRowPF<NR> cur[SVDPP_PFW], nxt[SVDPP_PFW];
+        chain_fetch_rows<NR>(P, rb_cur, 0, lane, kio, cur);
+        for (int j0 = 0; j0 < nrow; j0 += SVDPP_PFW) {
+            const int off_pre = (j0 + SVDPP_PFW) & 63, off_cur = j0 & 63;
+            if (off_pre == 0) { rb_pre = rb_next; rb_next = row_block<UV>(D, u.row_begin, e0, j0 + SVDPP_PFW + 64, nrow, lane); }
+            chain_fetch_rows<NR>(P, rb_pre, off_pre, lane, kio, nxt);
+#pragma unroll
+            for (int c = 0; c < SVDPP_PFW; c++) {
+                if (j0 + c < nrow) {
+                    struct { ChainRow<NR> q; float bi, label, uv, iv; unsigned irow; } x;
+                    x.q = cur[c].q; x.bi = cur[c].bi; x.irow = cur[c].irow;
+                    x.label = pick(rb_cur.label, off_cur + c);
+                    x.uv = UV ? 1.0f : pick(rb_cur.uv, off_cur + c);
+                    x.iv = UV ? 1.0f : pick(rb_cur.iv, off_cur + c);
+                    if (pick(rb_cur.fresh, off_cur + c)) {   // this item was written by an earlier row of the unit after (or while) it was fetched ahead
+                        // The re-read must be COMPLETE before this block is left: loads and stores share one in-order
+                        // counter on gfx9, and a load still pending at the join would make every row of the common
+                        // path wait for everything in flight (measured 0.54 instead of 0.41 us per row at k=128).  The
+                        // empty asm statements consume the loaded values here, so the wait lands inside the block.
+                        ChainRow<NR> t = chain_load<NR>(P.W, x.irow, pitch, lane, kio);
+                        float tb = P.bias[x.irow];
+#pragma unroll
+                        for (int q = 0; q < NR; q++) asm volatile("" : "+v"(t.r[q]));
+                        asm volatile("" : "+v"(tb));
+                        x.q = t;
+                        x.bi = tb;
+                    }
+                    double bs = 0.0;                                   // calc_bias (:313-353)
+                    if (ub) { bs += (double)(x.uv * bu); bs += (double)tmp_bias; }
+                    bs += (double)(x.iv * x.bi);
+                    double sum = (double)P.base_score + bs;
+                    ChainRow<NR> tu = tmp_fb, ti = chain_zero<NR>();   // prepare_tmp (:354-381, :506-508)
+                    chain_axpy(tu, p, x.uv);
+                    chain_axpy(ti, x.q, x.iv);
+                    sum += (double)chain_dot(tu, ti, lane, k);
+                    const float pred = FAST ? (float)sum : map_active((float)sum, P.active_type);
+                    const float err = (FAST ? x.label - pred : cal_grad(x.label, pred, P.active_type)) * 1.0f;
+                    const float su = lr * err * x.uv;                  // update_no_decay (:383-427)
+                    chain_axpy(p, ti, su);
+                    if (ub) bu = bu + su;
+                    const float si = lr * err * x.iv;
+                    ChainRow<NR> w = x.q;
+                    chain_axpy(w, tu, si);
+                    float nbi = x.bi + si;
+                    chain_axpy(tmp_fb, ti, lr2 * err * norm);          // update_svdpp (:512-520)
+#pragma unroll
+                    for (int q = 0; q < NR; q++) tmp_fb.r[q] = tmp_fb.r[q] * dec_fb1;
+                    if (ub) {
+                        tmp_bias = tmp_bias + lr2 * err * norm;
+                        tmp_bias = tmp_bias * dec_fbb;
+                    }
+                    if (FAST) {                                        // regularize(feature, true) (:286-311), L2 form
+#pragma unroll
+                        for (int q = 0; q < NR; q++) p.r[q] = p.r[q] * dec_u1;
+#pragma unroll
+                        for (int q = 0; q < NR; q++) w.r[q] = w.r[q] * dec_i1;
+                    } else {
+                        chain_reg(P, p, wd_u, false, lane, k);
+                        chain_reg(P, w, get_wd(P.i_rng, x.irow - P.item_off, P.wd_item), true, lane, k);
+                    }
+                    if (ub) bu = bu * dec_ub;
+                    nbi = nbi * dec_ib;
+                    if (rx_item) {   // relaxed item rows: other users of this launch may be updating the same item -- add the change
+                        ChainRow<NR> dw;
+#pragma unroll
+                        for (int q = 0; q < NR; q++) dw.r[q] = w.r[q] - x.q.r[q];
+                        chain_atomic_add<NR>(P.W, x.irow, pitch, lane, kio, dw);
+                        if (lane == 0) unsafeAtomicAdd(&P.bias[x.irow], nbi - x.bi);
+                    } else {
+                        chain_store<NR>(P.W, x.irow, pitch, lane, kio, w);
+                        P.bias[x.irow] = nbi;   // every lane writes the same word: one request, and no exec-mask branch
+                    }
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < SVDPP_PFW; c++) cur[c] = nxt[c];
+            rb_cur = rb_pre;
+        }
+        chain_store<NR>(P.W, urow, pitch, lane, kio, p);
+        if (ub && lane == 0) P.bias[urow] = bu;
+    }
+    if ((u.flags & UNIT_END) && nfb > 0) {   // update_ufeedback (:539-554)
+        ChainRow<NR> d = tmp_fb;
+#pragma unroll
+        for (int q = 0; q < NR; q++) d.r[q] = d.r[q] - old_fb.r[q];   // K5
+        float db = tmp_bias - old_bias;
+        const float inv = 1.0f / norm;
+        chain_scale(d, inv);
+        db = db * inv;
+        tmp_fb = d; tmp_bias = db;   // the reference leaves the scaled delta in tmp_ufeedback
+        const ChainRow<NR> dl = chain_to_lin<NR>(d, lane);   // the scatter below runs in LINEAR layout
+        constexpr int FBW = svdpp_fbw<NR>::value, DEPTH = svdpp_fbdepth<NR>::value;
+        FbBlock blk[DEPTH + 1], blkn;
+        int off[DEPTH + 1];
+        FbRows<NR> rq[DEPTH + 1];
+        blk[0] = fb_block(fidx, fval, 0, nfb, lane);
+        blkn = fb_block(fidx, fval, 64, nfb, lane);
+        off[0] = 0;
+        fb_fetch_rows<NR>(P, blk[0], 0, ub, lane, kio, rq[0]);
+#pragma unroll
+        for (int d = 1; d <= DEPTH; d++) {
+            blk[d] = blk[0]; off[d] = d * FBW;
+            if (d < DEPTH) fb_fetch_rows<NR>(P, blk[d], off[d], ub, lane, kio, rq[d]);
+        }
+        for (int j0 = 0; j0 < nfb; j0 += FBW) {
+            off[DEPTH] = (j0 + DEPTH * FBW) & 63;
+            if (off[DEPTH] == 0) { blk[DEPTH] = blkn; blkn = fb_block(fidx, fval, j0 + DEPTH * FBW + 64, nfb, lane); }
+            fb_fetch_rows<NR>(P, blk[DEPTH], off[DEPTH], ub, lane, kio, rq[DEPTH]);   // distinct ids: nothing fetched here is written below
+#pragma unroll
+            for (int c = 0; c < FBW; c++) {
+                if (j0 + c < nfb) {
+                    const float v = fb_val(blk[0], off[0] + c);
+                    const unsigned row = P.fb_off + fb_id(blk[0], off[0] + c);
+                    if (rx_fb) {   // relaxed feedback rows: the scatter is an addition anyway -- make it atomic
+                        const float v1 = snap_to_one(v);
+                        ChainRow<NR> dw;
+#pragma unroll
+                        for (int q = 0; q < NR; q++) dw.r[q] = dl.r[q] * v1;
+                        lin_atomic_add<NR>(P.W, row, pitch, lane, kio, dw);
+                        if (ub && lane == 0) unsafeAtomicAdd(&P.bias[row], db * v);
+                    } else {
+                        chain_axpy(rq[0].w[c], dl, v);
+                        lin_store<NR>(P.W, row, pitch, lane, kio, rq[0].w[c]);
+                        if (ub) P.bias[row] = rq[0].b[c] + db * v;
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < DEPTH; q++) { rq[q] = rq[q + 1]; blk[q] = blk[q + 1]; off[q] = off[q + 1]; }
+        }
+    }
+    if (u.flags & UNIT_SAVE) {
+        chain_store<NR>(st, 0, pitch, lane, kio, tmp_fb);
+        chain_store<NR>(st, 1, pitch, lane, kio, old_fb);
+        if (lane == 0) { st[2 * pitch] = norm; st[2 * pitch + 1] = tmp_bias; st[2 * pitch + 2] = old_bias; }
+    }
+}
+
+// Kernel 4a: the simple units of one conflict-free batch, one wave per user
+template <int NR, bool FAST, bool FULL, bool UV, bool RX>
+__global__ __launch_bounds__(64) void k_svdpp_wave(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
+                                                   const float *fb_value, const int *order, long begin, long end) {
+    const int lane = threadIdx.x & 63;
+    for (long s = begin + blockIdx.x; s < end; s += gridDim.x) {
+        const int uid = __builtin_amdgcn_readfirstlane(order ? order[s] : (int)s);
+        const DevUnit *up = units + uid;
+        DevUnit u;
+        u.fb_begin = __builtin_amdgcn_readfirstlane(up->fb_begin); u.fb_end = __builtin_amdgcn_readfirstlane(up->fb_end);
+        u.row_begin = __builtin_amdgcn_readfirstlane(up->row_begin); u.row_end = __builtin_amdgcn_readfirstlane(up->row_end);
+        u.flags = __builtin_amdgcn_readfirstlane(up->flags);
+        svdpp_unit_wave<NR, FAST, FULL, UV, RX>(P, D, u, fb_index, fb_value, lane);
+    }
+}
+
+void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
+                       const int *order, long begin, long end, hipStream_t st) {
+    if (end <= begin) return;
+    long grid = end - begin;           // one 64-thread workgroup (= one wave) per user: a batch rarely holds more users than CUs
+    if (grid > 16384) grid = 16384;
+    const int nr = (P.k + 63) / 64;
+    const bool fast = P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 && P.user_nonnegative == 0 &&
+                      P.u_rng.n == 0 && P.i_rng.n == 0;
+#define SVDF_WAVE_LAUNCH(NR_, FAST_, FULL_, UV_, RX_) \
+    hipLaunchKernelGGL((k_svdpp_wave<NR_, FAST_, FULL_, UV_, RX_>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end)
+#define SVDF_WAVE_CASE(NR_)                                                                   \
+    case NR_:                                                                                 \
+        if (relaxed && fast && full && D.unit_values) SVDF_WAVE_LAUNCH(NR_, true, true, true, true);   \
+        else if (relaxed) SVDF_WAVE_LAUNCH(NR_, false, false, false, true);                   \
+        else if (fast && full && D.unit_values) SVDF_WAVE_LAUNCH(NR_, true, true, true, false); \
+        else if (fast && full) SVDF_WAVE_LAUNCH(NR_, true, true, false, false);               \
+        else if (fast) SVDF_WAVE_LAUNCH(NR_, true, false, false, false);                      \
+        else SVDF_WAVE_LAUNCH(NR_, false, false, false, false);                               \
+        break;
+    const bool relaxed = P.relax_item_from == 0u || P.relax_feedback != 0;
+    const bool full = P.k == 64 * nr;
+    switch (nr) {
+        SVDF_WAVE_CASE(1)
+        SVDF_WAVE_CASE(2)
+        SVDF_WAVE_CASE(3)
+    default:
+        SVDF_WAVE_CASE(4)
+    }
+#undef SVDF_WAVE_LAUNCH
+#undef SVDF_WAVE_CASE
+}
+
+}  // namespace svdf

@@ -1,4 +1,4 @@
-// svdf_kernels.h -- launch wrappers of the gfx950 kernels (svdf_kernels.hip)
+// svdf_kernels.h -- launch wrappers of the gfx950 kernels (svdf_k_*.hip)
 #ifndef SVDF_KERNELS_H_
 #define SVDF_KERNELS_H_
 
