@@ -31,7 +31,7 @@ cat $OUT/kernel_trace_summary.txt
 rm -rf $OUT/kt
 # hardware counters: one pass per counter group, 1 pass over the data, no warm-up
 : > $OUT/pmc_summary.txt
-for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum"; do
+for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS"; do
   n=$(echo $c | tr " " "_")
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_$n -o p -- python bench.py --no-cpu-baseline --steps 1 --warmup 0 > /dev/null 2> $OUT/pmc_$n.stderr.log
   python tools/pmc_summary.py $OUT/pmc_$n | grep -v copyBuffer >> $OUT/pmc_summary.txt
