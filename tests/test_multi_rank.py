@@ -154,3 +154,19 @@ def test_fp16_wire_format_keeps_the_rmse_contract():
     ref = cases.rmse(merged_predict(simulate(conf, u, i, r, 1, 1, passes), 1, tu, ti, tr), tr)
     got = cases.rmse(merged_predict(ranks, world, tu, ti, tr), tr)
     assert abs(got - ref) <= 1e-4
+
+
+def test_defer_tails_edge_cases():
+    """Empty shards, a single window and a disabled threshold leave the windows alone; tiny windows whose batches are all
+    'short' keep at least their first batch."""
+    e = (np.zeros(0, np.uint32), np.zeros(0, np.uint32), np.zeros(0, np.float32))
+    one = (np.array([0, 1, 2], np.uint32), np.array([0, 1, 2], np.uint32), np.ones(3, np.float32))
+    out = defer_tails([e, one, e], 10, 10, 0.05)
+    assert [len(x[2]) for x in out] == [0, 3, 0]
+    assert [len(x[2]) for x in defer_tails([one], 10, 10, 0.05)] == [3]
+    assert [len(x[2]) for x in defer_tails([one, one], 10, 10, 0.0)] == [3, 3]
+    # one hot item: every instance conflicts with the previous one -> 6 batches of 1; the first batch always stays
+    hot = (np.arange(6, dtype=np.uint32), np.zeros(6, np.uint32), np.ones(6, np.float32))
+    out = defer_tails([hot, one], 10, 10, 0.5)
+    assert len(out[0][2]) >= 1 and len(out[0][2]) + len(out[1][2]) == 9
+    assert list(out[1][0][:len(out[1][2]) - 3]) == list(hot[0][len(out[0][2]):])   # deferred instances come first, in order
