@@ -170,9 +170,15 @@ int svdf_synchronize(svdf_trainer *t);
 /* counters: 0 instances trained, 1 kernels launched, 2 conflict-free batches executed,
  * 3 staged-window flushes, 4/5/6 launches of the basicMF / general / few-row fused kernel */
 int64_t svdf_counter(svdf_trainer *t, int what);
-/* tuning knobs (not part of the reference surface): "stage_window" (instances staged before an
- * automatic flush), "groups_per_wave", "block_threads", "use_fused" (0 routes few-row instances through the general
- * kernel).  Returns 0 if the knob exists. */
+/* tuning knobs (not part of the reference surface; none changes a result bit): "stage_window" (instances staged
+ * before an automatic flush), "async_flush" (background scheduling of full windows), "groups_per_wave",
+ * "block_threads" (0 = tuned per factor width), "sort_batches" (0 file order, 1 by item, 2 by user inside a
+ * conflict-free batch), "xcd_remap", "store_mode" (0 plain, 1 nontemporal, 2 write-through row stores), "use_fused"
+ * (0 routes few-row instances through the general kernel), "use_simple_units" (0 routes user units through the
+ * lane-group kernel), "use_graph" / "graph_min_levels" (hipGraph replay of a resident dataset's pass), "hot_reduce"
+ * (relaxed mode: workgroup pre-reduction of a shared user row).  Returns 0 if the knob exists.
+ * The relaxed mode itself is switched by CONFIG keys through svdf_set_param ("amd:relax_global",
+ * "amd:relax_user_from", "amd:relax_item_from", "amd:relax_feedback"), not by knobs: it changes results. */
 int svdf_set_knob(svdf_trainer *t, const char *name, long value);
 
 /* ---- host-side conflict-free batch scheduler, exposed so it can be tested without a GPU.
