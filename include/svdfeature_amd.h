@@ -120,6 +120,18 @@ svdf_dataset *svdf_dataset_from_blocks(svdf_trainer *t, long num_block, const in
  * save/load, apex_svd_data.h:419-450; apex_svd_data.cpp:558-595).  Replaces the loader thread + one virtual
  * update() per instance of svd_feature.cpp:220-248 for callers that train whole passes. */
 svdf_dataset *svdf_dataset_from_buffer_file(svdf_trainer *t, const char *path, int user_group_format);
+/* input_type = 2 of the reference (input_type::BINARY_BUFFER_RANK, apex_svd_data.h:516, apex_svd_data.cpp:1330-1332): the
+ * user-group buffer file seen through PairwiseRankGenerator (apex_svd_data.cpp:812-1025).  Every block's rows are
+ * replaced by rank pairs (positive entries merged with the sign-flipped negative's, label 1), drawn with libc rand()
+ * in the generator's call order, so a process seeded like the reference's (srand(seed), then svdf_init_model) trains
+ * on the same pairs.  One call = one pass of the iterator: the reference re-draws the pairs every round, so build a
+ * new dataset per round.  Sampler keys are taken from svdf_set_param like the reference's iterator takes them from the
+ * config: pos_sample_lowerb, neg_sample_upperb, rank_sample_num, rank_sample_max, rank_sample_method (0, 1),
+ * rank_sample_gap, rank_sample_pointwise, seed_sampler_bytime.  Needs format_type = 1. */
+svdf_dataset *svdf_dataset_from_rank_buffer_file(svdf_trainer *t, const char *path);
+/* The same pass written to out_path as a user-group buffer file instead of being uploaded (host only, works on a
+ * handle created with device = -2).  Returns the number of generated rows, -1 on error. */
+int64_t svdf_rank_sample_buffer_file(svdf_trainer *t, const char *in_path, const char *out_path);
 void svdf_dataset_destroy(svdf_dataset *ds);
 int svdf_train_dataset(svdf_trainer *t, svdf_dataset *ds);       /* one pass, asynchronous on the trainer's stream */
 int svdf_predict_dataset(svdf_trainer *t, svdf_dataset *ds, float *out); /* out[num_row], file order */
@@ -175,7 +187,8 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  * "block_threads" (0 = tuned per factor width), "sort_batches" (0 file order, 1 by item, 2 by user inside a
  * conflict-free batch), "xcd_remap", "store_mode" (0 plain, 1 nontemporal, 2 write-through row stores), "use_fused"
  * (0 routes few-row instances through the general kernel), "use_simple_units" (0 routes user units through the
- * lane-group kernel), "use_graph" / "graph_min_levels" (hipGraph replay of a resident dataset's pass), "hot_reduce"
+ * lane-group kernel), "rows_without_feedback" (0 keeps whole users as sequential units even when no block of a block
+ * dataset carries a feedback id; default 1 schedules such rows one by one), "use_graph" / "graph_min_levels" (hipGraph replay of a resident dataset's pass), "hot_reduce"
  * (relaxed mode: workgroup pre-reduction of a shared user row).  Returns 0 if the knob exists.
  * The relaxed mode itself is switched by CONFIG keys through svdf_set_param ("amd:relax_global",
  * "amd:relax_user_from", "amd:relax_item_from", "amd:relax_feedback"), not by knobs: it changes results. */

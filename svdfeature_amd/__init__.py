@@ -80,6 +80,10 @@ def load_library():
     lib.svdf_dataset_from_triples.argtypes = [P, C.c_long, _u32p, _u32p, _f32p]
     lib.svdf_dataset_from_buffer_file.restype = P
     lib.svdf_dataset_from_buffer_file.argtypes = [P, C.c_char_p, C.c_int]
+    lib.svdf_dataset_from_rank_buffer_file.restype = P
+    lib.svdf_dataset_from_rank_buffer_file.argtypes = [P, C.c_char_p]
+    lib.svdf_rank_sample_buffer_file.restype = C.c_int64
+    lib.svdf_rank_sample_buffer_file.argtypes = [P, C.c_char_p, C.c_char_p]
     lib.svdf_dataset_from_blocks.restype = P
     lib.svdf_dataset_from_blocks.argtypes = [P, C.c_long, _i32p, _i64p, _u32p, _f32p, _i64p, _f32p, _i64p, _u32p, _f32p]
     lib.svdf_dataset_destroy.argtypes = [P]
@@ -303,6 +307,20 @@ class Trainer:
         if not h:
             raise SvdfError(self.lib.svdf_last_error().decode())
         return Dataset(self, h)
+
+    def dataset_from_rank_buffer_file(self, path):
+        """One pass of the reference's input_type = 2 (user-group buffer file through the rank-pair sampler)."""
+        h = self.lib.svdf_dataset_from_rank_buffer_file(self.h, str(path).encode())
+        if not h:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return Dataset(self, h)
+
+    def rank_sample_buffer_file(self, in_path, out_path):
+        """The same pass written as a user-group buffer file (host only); returns the number of generated rows."""
+        n = self.lib.svdf_rank_sample_buffer_file(self.h, str(in_path).encode(), str(out_path).encode())
+        if n < 0:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return int(n)
 
     def train_dataset(self, ds):
         self._ok(self.lib.svdf_train_dataset(self.h, ds.h))

@@ -19,6 +19,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
+#include <cstdio>
 #include <cstring>
 
 namespace svdf {
@@ -103,6 +105,74 @@ struct CsrArrays {
     }
 };
 
+struct UserGroupArrays {
+    std::vector<int> tag;
+    std::vector<int64_t> fb_ptr, block_row_ptr;
+    std::vector<unsigned> fb_index;
+    std::vector<float> fb_value;
+    CsrArrays rows;
+};
+
+// Walks a user-group buffer file.  With a sampler every block's rows are replaced by the rank pairs drawn from them
+// (the feedback part of the block is kept as it is, like PairwiseRankGenerator::next, apex_svd_data.cpp:999-1019).
+void read_user_group(const MappedFile &file, PairSampler *sampler, UserGroupArrays &g) {
+    Cursor c(file);
+    const int num_block = c.i32();
+    c.i32(); c.i32(); c.i32();   // max_num_ufeedback, max_num_row, max_num_val
+    check(num_block >= 0, "buffer file is corrupt (negative block count)");
+    g.tag.assign((size_t)num_block, 0);
+    g.fb_ptr.assign((size_t)num_block + 1, 0);
+    g.block_row_ptr.assign((size_t)num_block + 1, 0);
+    size_t rows = 0, vals = 0, fbs = 0;
+    for (int b = 0; b < num_block; b++) {
+        int nfb = c.i32();
+        if (nfb < 0) { nfb &= 0x7fffffff; g.tag[(size_t)b] = c.i32(); }
+        c.take(8 * (size_t)nfb);
+        CsrBatchView v = read_batch(c);
+        fbs += (size_t)nfb; rows += (size_t)v.num_row; vals += (size_t)v.num_val;
+        g.fb_ptr[(size_t)b + 1] = (int64_t)fbs;
+        g.block_row_ptr[(size_t)b + 1] = (int64_t)rows;
+    }
+    g.fb_index.resize(fbs);
+    g.fb_value.resize(fbs);
+    if (!sampler) g.rows.reserve(rows, vals);
+    else { g.rows.row_ptr.assign(1, 0); }
+    Cursor d(file);
+    d.take(16);
+    size_t r = 0, v = 0;
+    std::vector<RankRow> view;
+    std::vector<int> rp;
+    for (int b = 0; b < num_block; b++) {
+        int nfb = d.i32();
+        if (nfb < 0) { nfb &= 0x7fffffff; d.i32(); }
+        const size_t f0 = (size_t)g.fb_ptr[(size_t)b];
+        if (nfb) {
+            memcpy(&g.fb_index[f0], d.take(4 * (size_t)nfb), 4 * (size_t)nfb);
+            memcpy(&g.fb_value[f0], d.take(4 * (size_t)nfb), 4 * (size_t)nfb);
+        }
+        CsrBatchView bv = read_batch(d);
+        if (!sampler) {
+            g.rows.splice(bv, r, v);
+            r += (size_t)bv.num_row; v += (size_t)bv.num_val;
+            continue;
+        }
+        rp.resize((size_t)3 * bv.num_row + 1);
+        memcpy(rp.data(), bv.row_ptr, 4 * rp.size());
+        view.resize((size_t)bv.num_row);
+        for (int i = 0; i < bv.num_row; i++) {   // SVDFeatureCSR::operator[], apex_svd_data.h:129-142
+            const int p0 = rp[(size_t)3 * i], p1 = rp[(size_t)3 * i + 1], p2 = rp[(size_t)3 * i + 2], p3 = rp[(size_t)3 * i + 3];
+            if (p0 < 0 || p0 > p1 || p1 > p2 || p2 > p3 || p3 > bv.num_val) fail("buffer file is corrupt (row_ptr outside its batch)");
+            RankRow &e = view[(size_t)i];
+            memcpy(&e.label, bv.label + 4 * (size_t)i, 4);
+            e.ng = p1 - p0; e.nu = p2 - p1; e.ni = p3 - p2;
+            e.index = (const unsigned *)(bv.index + 4 * (size_t)p0);   // the mapping is page aligned and every field 4-byte sized
+            e.value = (const float *)(bv.value + 4 * (size_t)p0);
+        }
+        sampler->sample_block(view, g.rows.label, g.rows.row_ptr, g.rows.index, g.rows.value);
+        g.block_row_ptr[(size_t)b + 1] = (int64_t)g.rows.label.size();
+    }
+}
+
 }  // namespace
 
 Dataset *Engine::dataset_from_buffer_file(const char *path, int user_group_format) {
@@ -127,44 +197,72 @@ Dataset *Engine::dataset_from_buffer_file(const char *path, int user_group_forma
         }
         return dataset_from_csr((long)rows, a.label.data(), a.row_ptr.data(), a.index.data(), a.value.data());
     }
-    Cursor c(file);
-    const int num_block = c.i32();
-    c.i32(); c.i32(); c.i32();   // max_num_ufeedback, max_num_row, max_num_val
-    check(num_block >= 0, "buffer file is corrupt (negative block count)");
-    std::vector<int> tag((size_t)num_block);
-    std::vector<int64_t> fb_ptr((size_t)num_block + 1, 0), block_row_ptr((size_t)num_block + 1, 0);
-    size_t rows = 0, vals = 0, fbs = 0;
-    for (int b = 0; b < num_block; b++) {
-        int nfb = c.i32();
-        tag[(size_t)b] = 0;
-        if (nfb < 0) { nfb &= 0x7fffffff; tag[(size_t)b] = c.i32(); }
-        c.take(8 * (size_t)nfb);
-        CsrBatchView v = read_batch(c);
-        fbs += (size_t)nfb; rows += (size_t)v.num_row; vals += (size_t)v.num_val;
-        fb_ptr[(size_t)b + 1] = (int64_t)fbs;
-        block_row_ptr[(size_t)b + 1] = (int64_t)rows;
+    UserGroupArrays g;
+    read_user_group(file, nullptr, g);
+    return dataset_from_blocks((long)g.tag.size(), g.tag.data(), g.fb_ptr.data(), g.fb_index.data(), g.fb_value.data(),
+                               g.block_row_ptr.data(), g.rows.label.data(), g.rows.row_ptr.data(), g.rows.index.data(),
+                               g.rows.value.data());
+}
+
+// input_type = 2 of the reference (BINARY_BUFFER_RANK, apex_svd_data.cpp:1330-1332): the user-group buffer file seen
+// through PairwiseRankGenerator.  One call = one pass of the iterator (pairs are re-drawn from libc rand() every pass).
+Dataset *Engine::dataset_from_rank_buffer_file(const char *path) {
+    check(path != nullptr, "dataset_from_rank_buffer_file: null path");
+    check(user_group(), "rank-pair input needs the user-group format (format_type = 1), svd_feature.cpp:129-133");
+    MappedFile file(path);
+    UserGroupArrays g;
+    pair_sampler_.init();
+    read_user_group(file, &pair_sampler_, g);
+    return dataset_from_blocks((long)g.tag.size(), g.tag.data(), g.fb_ptr.data(), g.fb_index.data(), g.fb_value.data(),
+                               g.block_row_ptr.data(), g.rows.label.data(), g.rows.row_ptr.data(), g.rows.index.data(),
+                               g.rows.value.data());
+}
+
+// The same pass written back as a user-group buffer file (host only: works without a device).
+long Engine::rank_sample_buffer_file(const char *in_path, const char *out_path) {
+    check(in_path != nullptr && out_path != nullptr, "rank_sample_buffer_file: null path");
+    MappedFile file(in_path);
+    UserGroupArrays g;
+    pair_sampler_.init();
+    read_user_group(file, &pair_sampler_, g);
+    FILE *fo = fopen(out_path, "wb");
+    if (!fo) fail(std::string("can not open file \"") + out_path + "\"");
+    const size_t nb = g.tag.size();
+    int head[4] = {(int)nb, 0, 0, 0};
+    for (size_t b = 0; b < nb; b++) {
+        const int64_t r0 = g.block_row_ptr[b], r1 = g.block_row_ptr[b + 1];
+        head[1] = std::max(head[1], (int)(g.fb_ptr[b + 1] - g.fb_ptr[b]));
+        head[2] = std::max(head[2], (int)(r1 - r0));
+        head[3] = std::max(head[3], (int)(g.rows.row_ptr[3 * r1] - g.rows.row_ptr[3 * r0]));
     }
-    std::vector<unsigned> fb_index(fbs);
-    std::vector<float> fb_value(fbs);
-    CsrArrays a;
-    a.reserve(rows, vals);
-    Cursor d(file);
-    d.take(16);
-    size_t r = 0, v = 0;
-    for (int b = 0; b < num_block; b++) {
-        int nfb = d.i32();
-        if (nfb < 0) { nfb &= 0x7fffffff; d.i32(); }
-        const size_t f0 = (size_t)fb_ptr[(size_t)b];
-        if (nfb) {
-            memcpy(&fb_index[f0], d.take(4 * (size_t)nfb), 4 * (size_t)nfb);
-            memcpy(&fb_value[f0], d.take(4 * (size_t)nfb), 4 * (size_t)nfb);
+    fwrite(head, 4, 4, fo);
+    std::vector<int> rp;
+    for (size_t b = 0; b < nb; b++) {
+        const int64_t f0 = g.fb_ptr[b], f1 = g.fb_ptr[b + 1], r0 = g.block_row_ptr[b], r1 = g.block_row_ptr[b + 1];
+        int nfb = (int)(f1 - f0);
+        if (g.tag[b] != 0) {   // SVDPlusBlock::save_to_file, apex_svd_data.h:419-431
+            int marked = nfb | (int)(1u << 31);
+            fwrite(&marked, 4, 1, fo);
+            fwrite(&g.tag[b], 4, 1, fo);
+        } else {
+            fwrite(&nfb, 4, 1, fo);
         }
-        CsrBatchView bv = read_batch(d);
-        a.splice(bv, r, v);
-        r += (size_t)bv.num_row; v += (size_t)bv.num_val;
+        fwrite(g.fb_index.data() + f0, 4, (size_t)nfb, fo);
+        fwrite(g.fb_value.data() + f0, 4, (size_t)nfb, fo);
+        const int64_t v0 = g.rows.row_ptr[3 * r0], v1 = g.rows.row_ptr[3 * r1];
+        int nrow = (int)(r1 - r0), nval = (int)(v1 - v0);
+        fwrite(&nrow, 4, 1, fo);
+        fwrite(&nval, 4, 1, fo);
+        rp.resize((size_t)3 * nrow + 1);
+        for (int j = 0; j <= 3 * nrow; j++) rp[(size_t)j] = (int)(g.rows.row_ptr[3 * r0 + j] - v0);
+        fwrite(rp.data(), 4, rp.size(), fo);
+        fwrite(g.rows.label.data() + r0, 4, (size_t)nrow, fo);
+        fwrite(g.rows.index.data() + v0, 4, (size_t)nval, fo);
+        fwrite(g.rows.value.data() + v0, 4, (size_t)nval, fo);
     }
-    return dataset_from_blocks(num_block, tag.data(), fb_ptr.data(), fb_index.data(), fb_value.data(), block_row_ptr.data(),
-                               a.label.data(), a.row_ptr.data(), a.index.data(), a.value.data());
+    const bool ok = !ferror(fo);
+    if (fclose(fo) != 0 || !ok) fail(std::string("error writing \"") + out_path + "\"");
+    return (long)g.block_row_ptr[nb];
 }
 
 }  // namespace svdf

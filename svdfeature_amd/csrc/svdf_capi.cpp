@@ -120,6 +120,17 @@ svdf_dataset *svdf_dataset_from_buffer_file(svdf_trainer *t, const char *path, i
         return h;
     })
 }
+svdf_dataset *svdf_dataset_from_rank_buffer_file(svdf_trainer *t, const char *path) {
+    SVDF_GUARD(nullptr, {
+        svdf::Dataset *d = t->e->dataset_from_rank_buffer_file(path);
+        svdf_dataset *h = new svdf_dataset();
+        h->d = d;
+        return h;
+    })
+}
+int64_t svdf_rank_sample_buffer_file(svdf_trainer *t, const char *in_path, const char *out_path) {
+    SVDF_GUARD(-1, { return (int64_t)t->e->rank_sample_buffer_file(in_path, out_path); })
+}
 void svdf_dataset_destroy(svdf_dataset *ds) {
     if (!ds) return;
     try { if (ds->d && ds->d->owner) ds->d->owner->synchronize(); } catch (...) {}

@@ -243,6 +243,7 @@ void Engine::set_param(const char *name, const char *val) {  // apex_svd_base.h:
     if (!strcmp(name, "amd:relax_feedback")) relax_feedback_ = atoi(val) != 0;
     if (!strcmp(name, "amd:relax_user_from")) relax_user_from_ = (unsigned)strtoul(val, nullptr, 10);
     if (!strcmp(name, "amd:relax_item_from")) relax_item_from_ = (unsigned)strtoul(val, nullptr, 10);
+    pair_sampler_.set_param(name, val);   // the reference hands every config pair to the data iterator too (svd_feature.cpp:128-143)
     tp_set_param(tp_, name, val);
     u_param_.set_param(name, val);
     i_param_.set_param(name, val);
@@ -576,7 +577,7 @@ void Engine::stage_rows(int num_row, const float *row_label, const int *row_ptr,
     }
 }
 bool Engine::basic_fast_path_allowed() const {
-    return !relaxed() && !lazy_decay() && mp_.num_factor <= max_fast_path_factor() && !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
+    return !relaxed() && !lazy_decay() && mp_.num_factor <= max_fast_path_factor() && (!user_group() || rows_as_instances_) && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
 }
 
 void Engine::update_csr(float label, int ng, int nu, int ni, const unsigned *index, const float *value) {
@@ -891,7 +892,7 @@ void Engine::flush_csr(HostCSR &src) {
 
 // ---- few-row fused path -------------------------------------------------------------------------
 bool Engine::fused_allowed() const {
-    return use_fused_ && !lazy_decay() && mp_.num_factor <= max_fast_path_factor() && !user_group() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
+    return use_fused_ && !lazy_decay() && mp_.num_factor <= max_fast_path_factor() && (!user_group() || rows_as_instances_) && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
 }
 // every instance has <= 2 user ids, <= 2 item ids and no id twice in a section (ptr is int or int64)
 template <typename PtrT>
@@ -1085,6 +1086,23 @@ Dataset *Engine::dataset_from_blocks(long num_block, const int *extend_tag, cons
     check(user_group(), "svdfeature_amd: block datasets are for user-group (format_type 1) trainers");
     flush();
     check(!unit_open_, "dataset_from_blocks: a START block is pending in the trainer");
+    if (rows_without_feedback_ && fb_ptr[num_block] == fb_ptr[0]) {
+        // No block carries implicit feedback (the shape of demo/pairwiseRank): tmp_ufeedback and its bias stay +0 and
+        // norm_ufeedback is 0 through every update_svdpp (apex_svd_base.h:512-520, 524-527), update_ufeedback returns at
+        // once (:539), so update(block) is exactly update_inner(row) for its rows (:557-561) -- the users need not be
+        // walked as sequential units and the rows are scheduled one by one like a random-order pass.
+        bool open = false;
+        for (long b = 0; b < num_block; b++) {
+            const int tag = extend_tag[b];
+            check(tag == TAG_DEFAULT || tag == TAG_START || tag == TAG_MIDDLE || tag == TAG_END, "dataset_from_blocks: unknown extend_tag");
+            open = !(tag == TAG_DEFAULT || tag == TAG_END);
+        }
+        if (open) fail("dataset_from_blocks: the last user's END block is missing");
+        const int64_t r0 = block_row_ptr[0], r1 = block_row_ptr[num_block];
+        rows_as_instances_ = true;
+        struct Reset { bool &f; ~Reset() { f = false; } } reset{rows_as_instances_};
+        return dataset_from_csr((long)(r1 - r0), row_label + r0, row_ptr + 3 * r0, feat_index, feat_value);
+    }
     const long saved_window = stage_window_;
     stage_window_ = (long)1 << 60;
     std::vector<int> ptr32;
@@ -1235,7 +1253,7 @@ Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsign
 Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
-    check(!user_group(), "svdfeature_amd: resident datasets are for random-order (format_type 0) trainers");
+    check(!user_group() || rows_as_instances_, "svdfeature_amd: resident datasets are for random-order (format_type 0) trainers");
     const long n = num_row;
     const int64_t p00 = row_ptr[0];
     check(row_ptr[3 * n] - p00 < (int64_t)2147483647, "dataset: more than 2^31-1 feature entries");
@@ -1611,6 +1629,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "async_flush")) { flush(); async_flush_ = value != 0; return 0; }
     if (!strcmp(name, "use_fused")) { use_fused_ = value != 0; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
+    if (!strcmp(name, "rows_without_feedback")) { rows_without_feedback_ = value != 0; return 0; }
     if (!strcmp(name, "block_threads")) {
         check(value == 0 || value == 64 || value == 128 || value == 256, "block_threads must be 0 (auto), 64, 128 or 256");
         block_threads_ = (int)value;

@@ -115,6 +115,31 @@ struct UnitDev {
     DevCSR csr() const { return DevCSR{label.p, ptr.p, index.p, value.p, unit_values ? 1 : 0, has_fresh ? fresh.p : nullptr}; }
 };
 
+// One instance of a user block as PairwiseRankGenerator sees it (SVDFeatureCSR::Elem, apex_svd_data.h:38-107): the
+// global, user and item entries are contiguous in that order.
+struct RankRow {
+    float label;
+    int ng, nu, ni;
+    const unsigned *index;
+    const float *value;
+};
+
+// PairwiseRankGenerator (apex_svd_data.cpp:812-1025) restated for whole passes: the rows of a user block are replaced by
+// rank pairs drawn with libc rand() in the reference's call order, so that a seeded run sees the same pairs.
+class PairSampler {
+public:
+    void set_param(const char *name, const char *val);   // apex_svd_data.cpp:971-981
+    void init();                                          // apex_svd_data.cpp:982-988 (once per handle)
+    // appends the rows generated from one block; row_ptr holds absolute value offsets and starts as {0}
+    void sample_block(const std::vector<RankRow> &rows, std::vector<float> &label, std::vector<int64_t> &row_ptr,
+                      std::vector<unsigned> &index, std::vector<float> &value);
+private:
+    int sample_num_ = -1, sample_max_ = 0x7fffffff, method_ = 0, pointwise_ = 0, seed_bytime_ = 0;
+    float gap_ = 0.0001f, pos_lowerb_ = 0.8f, neg_upperb_ = 1e-6f;
+    bool init_done_ = false;
+    std::vector<RankRow> pos_, neg_;
+};
+
 class Engine;
 
 // HBM-resident scheduled training set
@@ -175,6 +200,9 @@ class Engine {
                                  const float *feat_value);
     // the reference's binary buffer files, read natively (svdf_buffer.cpp): CSR buffer or user-group buffer
     Dataset *dataset_from_buffer_file(const char *path, int user_group_format);
+    // input_type = 2: a user-group buffer file through the rank-pair sampler, one pass per call
+    Dataset *dataset_from_rank_buffer_file(const char *path);
+    long rank_sample_buffer_file(const char *in_path, const char *out_path);   // host only; returns the number of rows written
     void train_dataset(Dataset *ds);
     void predict_dataset(Dataset *ds, float *out);
 
@@ -258,6 +286,9 @@ class Engine {
     void upload_globals(int stride);
     void download_globals(float *dst);
     unsigned relax_user_from_ = 0xFFFFFFFFu, relax_item_from_ = 0xFFFFFFFFu;
+    PairSampler pair_sampler_;
+    bool rows_without_feedback_ = true;   // knob: block datasets without any feedback id are scheduled row by row
+    bool rows_as_instances_ = false;      // set while such a dataset is being built
     bool relaxed() const { return relax_global_ || relax_feedback_ || relax_user_from_ != 0xFFFFFFFFu || relax_item_from_ != 0xFFFFFFFFu; }
     // lazy decay modes (apex_svd_base.h:95-97,157-170): the reference's sample_counter and per-id ref words
     unsigned sample_counter_ = 0;

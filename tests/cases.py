@@ -114,3 +114,68 @@ def user_blocks(num_user_blocks, num_user, num_item, num_ufeedback, seed, max_ro
 def rmse(pred, label):
     d = pred.astype(np.float64) - label.astype(np.float64)
     return float(np.sqrt(np.mean(d * d)))
+
+
+# ---- rank-pair input (input_type = 2): user blocks whose rows are the candidates PairwiseRankGenerator pairs up
+RANK_SAMPLER_CASES = [   # (name, graded labels, sampler keys)
+    ("posneg_default", False, {}),
+    ("posneg_num_max", False, {"rank_sample_num": "5", "rank_sample_max": "4"}),
+    ("posneg_pointwise", False, {"rank_sample_pointwise": "1"}),
+    ("cmp_default_gap", True, {"rank_sample_method": "1"}),
+    ("cmp_wide_gap", True, {"rank_sample_method": "1", "rank_sample_gap": "1.5"}),
+    ("posneg_thresholds", True, {"pos_sample_lowerb": "4", "neg_sample_upperb": "2"}),
+]
+RANK_SAMPLER_SEED = 10   # svd_feature.cpp:293
+RANK_SAMPLER_ROUNDS = 2
+
+
+def rank_blocks(nblocks, num_user, num_item, num_global, seed, graded=False, max_rows=8, side_user=True, max_fb=3):
+    """One block per user visit: 0..max_rows candidate rows (label 0/1, or 1..5 when graded) with sorted global and
+    item entries (the generator merges sorted lists, apex_svd_data.cpp:828-860), sometimes a second user entry whose
+    value is 0 / 1e-7 (dropped, :897-903) or 0.5 (kept), and 0..3 feedback ids.  Some blocks are empty."""
+    rng = np.random.default_rng(seed)
+    blocks = []
+    for b in range(nblocks):
+        uid = int(rng.integers(0, num_user - 3))
+        nrow = int(rng.integers(0 if b % 9 == 4 else 1, max_rows + 1))
+        nfb = int(rng.integers(0, max_fb + 1))
+        fbi = np.sort(rng.choice(num_item, size=nfb, replace=False)).astype(np.uint32)
+        fbv = np.full(nfb, 1.0 / np.sqrt(max(nfb, 1)), np.float32)
+        rows = []
+        for _ in range(nrow):
+            label = float(rng.integers(1, 6)) if graded else float(rng.integers(0, 2))
+            ng = int(rng.integers(0, 3)) if num_global else 0
+            g = [(int(x), float(np.float32(rng.uniform(-1, 1)))) for x in np.sort(rng.choice(num_global, size=ng, replace=False))] if ng else []
+            u = [(uid, 1.0)]
+            if side_user and rng.integers(0, 3) == 0:
+                u.append((int(num_user - 1 - rng.integers(0, 3)), float(rng.choice([0.0, 0.5, 1e-7]))))
+            ni = int(rng.integers(1, 4))
+            it = [(int(x), float(np.float32(rng.choice([1.0, 0.5, rng.uniform(0.1, 1)]))))
+                  for x in np.sort(rng.choice(num_item, size=ni, replace=False))]
+            rows.append((label, g, u, it))
+        data = CSRData.from_rows(rows) if rows else CSRData.empty()
+        blocks.append(PlusBlock(fbi, fbv, data, TAG_DEFAULT))
+    return blocks
+
+
+def blocks_digest(blocks):
+    """md5 over everything a list of user blocks carries, field by field in block order."""
+    import hashlib
+    h = hashlib.md5()
+    for b in blocks:
+        h.update(np.int32(b.extend_tag).tobytes())
+        h.update(np.ascontiguousarray(b.index_ufeedback, np.uint32).tobytes())
+        h.update(np.ascontiguousarray(b.value_ufeedback, np.float32).tobytes())
+        h.update(np.ascontiguousarray(b.data.row_ptr, np.int64).tobytes())
+        h.update(np.ascontiguousarray(b.data.row_label, np.float32).tobytes())
+        h.update(np.ascontiguousarray(b.data.feat_index, np.uint32).tobytes())
+        h.update(np.ascontiguousarray(b.data.feat_value, np.float32).tobytes())
+    return h.hexdigest()
+
+
+RANK_E2E_CONF = [   # demo/pairwiseRank/pairwiseRank.conf shape, shrunk
+    ("learning_rate", "0.01"), ("wd_item", "0.004"), ("wd_user", "0.004"), ("num_item", "50"), ("num_user", "60"),
+    ("num_global", "8"), ("wd_global", "0.001"), ("num_factor", "8"), ("active_type", "3"), ("format_type", "1"),
+    ("num_ufeedback", "50"), ("wd_ufeedback", "0.004"), ("ufeedback_init_sigma", "0.01"), ("no_user_bias", "1"), ("input_type", "2"),
+]
+RANK_E2E_ROUNDS = 3

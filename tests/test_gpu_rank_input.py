@@ -1,0 +1,116 @@
+"""Rank-pair input (input_type = 2) end to end on the GPU: svdf_dataset_from_rank_buffer_file draws the pairs of one
+pass on the host (libc rand(), the reference's order), schedules them and trains them as resident user units.
+Compared with the model files the reference's trainer CLI wrote (tests/golden/rank_input.npz), with the per-block
+path fed from the sampled buffer, and -- where oracle/_ref is present -- with the reference's own generator feeding the
+engine through the CLI binding."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import cases
+import svdfeature_amd as sa
+from svdfeature_amd import data as D
+
+pytestmark = pytest.mark.gpu
+
+GOLD = np.load(os.path.join(cases.GOLDEN, "rank_input.npz"))
+REFDIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+AMD_CLI = os.path.join(REFDIR, "svd_feature_amd")
+HEAD = 4 + 1056   # SVDTypeParam + SVDModelParam (apex_svd_model.h:373-477)
+
+
+def _train_resident(tmp_path, src, conf, rounds, seed=10, kinds=None):
+    t = sa.Trainer(1, 3)
+    t.seed(seed)
+    for k, v in conf:
+        t.set_param(k, v)
+    t.init_model()
+    t.init_trainer()
+    models = []
+    p = str(tmp_path / "m.model")
+    t.save_model(p)
+    models.append(open(p, "rb").read())
+    rows = 0
+    for r in range(rounds):
+        t.set_round(r)
+        ds = t.dataset_from_rank_buffer_file(src)   # a new draw every pass, like itr->before_first()
+        rows += ds.info(0)
+        if kinds is not None:
+            kinds.append(ds.kind)
+        t.train_dataset(ds)
+        t.finish_round()
+        t.save_model(p)
+        models.append(open(p, "rb").read())
+        ds.close()
+    t.close()
+    return models, rows
+
+
+def test_resident_rank_input_matches_the_reference_cli_models(tmp_path):
+    src = str(tmp_path / "train.buffer")
+    D.write_ugroup_buffer(src, cases.rank_blocks(150, 60, 50, 8, 900))
+    models, rows = _train_resident(tmp_path, src, cases.RANK_E2E_CONF, cases.RANK_E2E_ROUNDS)
+    assert rows > 500
+    for r, m in enumerate(models):
+        ref = GOLD["e2e/model_r%d" % r].tobytes()
+        assert len(m) == len(ref) and m[:HEAD] == ref[:HEAD]
+        a, b = np.frombuffer(m[HEAD:], np.float32), np.frombuffer(ref[HEAD:], np.float32)
+        if r == 0:
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))   # rand_init: same libc stream
+        else:   # sigmoid through expf: device libm vs glibc, the tolerance of the other active_type = 3 tests
+            np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("max_fb", [3, 0], ids=["feedback", "nofeedback"])
+@pytest.mark.parametrize("keys", [{}, {"rank_sample_method": "1", "rank_sample_gap": "0.5"}, {"rank_sample_pointwise": "1"}],
+                         ids=["posneg", "cmp", "pointwise"])
+def test_resident_rank_input_equals_the_per_block_path_on_the_sampled_file(keys, max_fb, tmp_path):
+    """Same seed, same draws: training the resident dataset is byte-identical to sampling the pass into a buffer file
+    and pushing its blocks through update(SVDPlusBlock) one by one.  Without any feedback id (the shape of
+    demo/pairwiseRank) the resident path schedules the pairs one by one instead of walking whole users."""
+    graded = "rank_sample_method" in keys
+    src = str(tmp_path / "train.buffer")
+    D.write_ugroup_buffer(src, cases.rank_blocks(120, 60, 50, 8, 31, graded, max_fb=max_fb))
+    conf = cases.RANK_E2E_CONF + list(keys.items())
+    kinds = []
+    resident, _ = _train_resident(tmp_path, src, conf, 2, kinds=kinds)
+    assert all(k == 3 for k in kinds) if max_fb else all(k in (1, 2) for k in kinds)   # user units vs single instances
+    t = sa.Trainer(1, 3)
+    t.seed(10)
+    for k, v in conf:
+        t.set_param(k, v)
+    t.init_model()
+    t.init_trainer()
+    p = str(tmp_path / "b.model")
+    for r in range(2):
+        t.set_round(r)
+        out = str(tmp_path / ("pass%d.buffer" % r))
+        t.rank_sample_buffer_file(src, out)
+        for b in D.read_ugroup_buffer(out):
+            t.update_block(b)
+        t.finish_round()
+        t.save_model(p)
+        assert open(p, "rb").read() == resident[r + 1], "round %d differs" % r
+    t.close()
+
+
+@pytest.mark.skipif(not os.path.exists(AMD_CLI), reason="oracle/_ref CLIs are built in the build container only")
+def test_resident_rank_input_equals_the_reference_generator_feeding_the_engine(tmp_path):
+    """The reference's CLI + its own PairwiseRankGenerator, linked against this engine (per-instance virtual calls),
+    writes byte-identical models to the resident path: same pairs, same arithmetic."""
+    d = tmp_path / "cli"
+    d.mkdir()
+    src = str(d / "train.buffer")
+    D.write_ugroup_buffer(src, cases.rank_blocks(150, 60, 50, 8, 900))
+    with open(str(d / "run.conf"), "w") as f:
+        for k, v in cases.RANK_E2E_CONF:
+            f.write("%s = %s\n" % (k, v))
+        f.write('buffer_feature = "train.buffer"\nmodel_out_folder = "./"\n')
+    p = subprocess.run([AMD_CLI, "run.conf", "num_round=%d" % cases.RANK_E2E_ROUNDS, "silent=1"], cwd=str(d),
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()
+    models, _ = _train_resident(tmp_path, src, cases.RANK_E2E_CONF, cases.RANK_E2E_ROUNDS)
+    for r, m in enumerate(models):
+        assert m == open(str(d / ("%04d.model" % r)), "rb").read(), "round %d differs" % r
