@@ -149,6 +149,7 @@ def main():
                     help="wire format of the item-side window deltas when --gpus > 1 (parameters stay fp32)")
     ap.add_argument("--cpu-sample", type=int, default=20_000_000)
     ap.add_argument("--groups-per-wave", type=int, default=0)
+    ap.add_argument("--knob", action="append", default=[], help="extra tuning knob name=value (svdf_set_knob), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--defer-tails", type=float, default=0.05,
                     help="N>1: batches smaller than this fraction of a window's largest, at the end of the window, move to the next window (0 = off)")
@@ -204,6 +205,9 @@ def main():
     if a.groups_per_wave:
         tr.set_knob("groups_per_wave", a.groups_per_wave)
     tr.set_knob("use_graph", a.use_graph)
+    for kv in a.knob:
+        name, value = kv.split("=")
+        tr.set_knob(name, int(value))
     log("model init (libc rand, %d normals) + upload: %.1fs" % ((a.users + a.items) * a.factor, time.time() - t0))
 
     cpu_base, parity = None, None
