@@ -114,3 +114,36 @@ def test_resident_rank_input_equals_the_reference_generator_feeding_the_engine(t
     models, _ = _train_resident(tmp_path, src, cases.RANK_E2E_CONF, cases.RANK_E2E_ROUNDS)
     for r, m in enumerate(models):
         assert m == open(str(d / ("%04d.model" % r)), "rb").read(), "round %d differs" % r
+
+
+@pytest.mark.parametrize("factor", [32, 100])
+def test_feedback_free_blocks_row_by_row_equal_whole_users(factor, tmp_path):
+    """Blocks without feedback ids: scheduling the rows one by one (default) and walking every user as a sequential unit
+    (knob rows_without_feedback = 0, the literal update(SVDPlusBlock) order) leave byte-identical models, at a size where
+    users conflict heavily on items (2 000 users x up to 16 candidates over 300 items)."""
+    src = str(tmp_path / "train.buffer")
+    D.write_ugroup_buffer(src, cases.rank_blocks(2000, 500, 300, 8, 5, max_rows=16, max_fb=0))
+    conf = cases.conf_with(cases.RANK_E2E_CONF, num_user=500, num_item=300, num_ufeedback=300, num_factor=factor)
+    models = []
+    for rows_knob in (1, 0):
+        t = sa.Trainer(1, 3)
+        t.set_knob("rows_without_feedback", rows_knob)
+        t.seed(4)
+        for k, v in conf:
+            t.set_param(k, v)
+        t.init_model()
+        t.init_trainer()
+        kinds = []
+        for r in range(2):
+            t.set_round(r)
+            ds = t.dataset_from_rank_buffer_file(src)
+            kinds.append(ds.kind)
+            t.train_dataset(ds)
+            t.finish_round()
+            ds.close()
+        p = str(tmp_path / ("k%d.model" % rows_knob))
+        t.save_model(p)
+        models.append(open(p, "rb").read())
+        assert all(k == 3 for k in kinds) if rows_knob == 0 else all(k in (1, 2) for k in kinds)
+        t.close()
+    assert models[0] == models[1]
