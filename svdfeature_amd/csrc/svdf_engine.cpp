@@ -934,6 +934,22 @@ void Engine::fill_fused(long n, const float *row_label, const PtrT *row_ptr, con
             out.gptr[(size_t)s + 1] = (int)out.gidx.size();
         }
     }
+    // inline slots: the global ids of an instance next to its user / item slots, when all instances fit
+    out.inline_g = out.has_g;
+    for (long s = 0; s < n && out.inline_g; s++) {
+        const int b = out.gptr[(size_t)s], e = out.gptr[(size_t)s + 1];
+        if (e - b > 4) out.inline_g = false;
+        for (int x = b; x < e && out.inline_g; x++)
+            for (int y = x + 1; y < e; y++) if (out.gidx[(size_t)x] == out.gidx[(size_t)y]) out.inline_g = false;
+    }
+    for (int j = 0; j < 4; j++) { out.gsi[j].clear(); out.gsv[j].clear(); }
+    if (out.inline_g) {
+        for (int j = 0; j < 4; j++) { out.gsi[j].assign((size_t)n, (unsigned)SLOT_ABSENT); out.gsv[j].assign((size_t)n, 0.0f); }
+        for (long s = 0; s < n; s++) {
+            const int b = out.gptr[(size_t)s], e = out.gptr[(size_t)s + 1];
+            for (int x = b; x < e; x++) { out.gsi[x - b][(size_t)s] = out.gidx[(size_t)x]; out.gsv[x - b][(size_t)s] = out.gval[(size_t)x]; }
+        }
+    }
 }
 void FusedDev::upload(const FusedHost &h, hipStream_t st) {
     max_nu = h.max_nu; max_ni = h.max_ni; has_g = h.has_g;
@@ -947,6 +963,9 @@ void FusedDev::upload(const FusedHost &h, hipStream_t st) {
         gidx.upload(h.gidx.data(), h.gidx.size(), st);
         gval.upload(h.gval.data(), h.gval.size(), st);
     }
+    inline_g = h.inline_g;
+    if (inline_g)
+        for (int j = 0; j < 4; j++) { gsi[j].upload(h.gsi[j].data(), h.gsi[j].size(), st); gsv[j].upload(h.gsv[j].data(), h.gsv[j].size(), st); }
 }
 FusedSchedule FusedDev::view() const {
     FusedSchedule S;
@@ -959,6 +978,7 @@ FusedSchedule FusedDev::view() const {
     S.gptr = has_g ? gptr.p : nullptr;
     S.gidx = has_g ? gidx.p : nullptr;
     S.gval = has_g ? gval.p : nullptr;
+    for (int j = 0; j < 4; j++) { S.gsi[j] = inline_g ? gsi[j].p : nullptr; S.gsv[j] = inline_g ? gsv[j].p : nullptr; }
     return S;
 }
 

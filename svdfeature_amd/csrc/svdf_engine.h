@@ -91,15 +91,17 @@ struct FusedHost {
     std::vector<float> label, uval[2], ival[2], gval;
     std::vector<unsigned> uidx[2], iidx[2], gidx;
     std::vector<int> gptr;
+    std::vector<unsigned> gsi[4];   // inline global slots, filled when every instance has <= 4 distinct global ids
+    std::vector<float> gsv[4];
     int max_nu = 1, max_ni = 1;
-    bool has_g = false;
+    bool has_g = false, inline_g = false;
 };
 struct FusedDev {
-    DevBuf<float> label, uval[2], ival[2], gval;
-    DevBuf<unsigned> uidx[2], iidx[2], gidx;
+    DevBuf<float> label, uval[2], ival[2], gval, gsv[4];
+    DevBuf<unsigned> uidx[2], iidx[2], gidx, gsi[4];
     DevBuf<int> gptr;
     int max_nu = 1, max_ni = 1;
-    bool has_g = false;
+    bool has_g = false, inline_g = false;
     void upload(const FusedHost &h, hipStream_t st);
     FusedSchedule view() const;
 };

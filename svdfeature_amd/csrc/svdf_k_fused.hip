@@ -42,6 +42,12 @@ __global__ __launch_bounds__(HOTU ? 1024 : 256) void k_fused(const DevParams P, 
     unsigned ur[G][NU], ir[G][NI];
     float label[G], ua[G][NU], ia[G][NI], bu[G][NU], bi[G][NI];
     int g0[G], g1[G];
+    // global features of an instance, kept in registers when it has at most GR of them and no id twice (the usual case);
+    // otherwise they are walked through memory in the reference's order below
+    constexpr int GR = 4;
+    bool greg[G], gon[G][GR];
+    unsigned gid[G][GR];
+    float gv[G][GR], gb[G][GR];
     float4 p[G][NU], q[G][NI];
 #pragma unroll
     for (int g = 0; g < G; g++) {
@@ -54,7 +60,41 @@ __global__ __launch_bounds__(HOTU ? 1024 : 256) void k_fused(const DevParams P, 
 #pragma unroll
         for (int b = 0; b < NI; b++) { ir[g][b] = valid[g] ? S.iidx[b][sc] : (unsigned)SLOT_ABSENT; ia[g][b] = S.ival[b][sc]; }
         g0[g] = 0; g1[g] = 0;
-        if (S.gptr && valid[g]) { g0[g] = S.gptr[sc]; g1[g] = S.gptr[sc + 1]; }
+        greg[g] = false;
+        if (S.gptr && valid[g] && (!S.gsi[0] || P.relax_global)) { g0[g] = S.gptr[sc]; g1[g] = S.gptr[sc + 1]; }
+    }
+    if (S.gptr && !P.relax_global) {   // kernel arguments: wave-uniform, data sets without global features skip all of it
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (S.gsi[0]) {
+                // inline slots (every instance of the data set has <= GR distinct global ids): ids and values sit next to
+                // the user / item slots of the record, one dependent load less in front of the bias gather
+                const long s = w0 + (long)g * IPW + gslot;
+                const long sc = valid[g] ? s : begin;
+                greg[g] = valid[g];
+#pragma unroll
+                for (int j = 0; j < GR; j++) {
+                    gid[g][j] = valid[g] ? S.gsi[j][sc] : (unsigned)SLOT_ABSENT;
+                    gv[g][j] = S.gsv[j][sc];
+                    gon[g][j] = gid[g][j] != SLOT_ABSENT;
+                }
+            } else {
+                const int ngl = g1[g] - g0[g];
+                greg[g] = ngl <= GR;
+#pragma unroll
+                for (int j = 0; j < GR; j++) {
+                    gon[g][j] = j < ngl && ngl <= GR;
+                    gid[g][j] = gon[g][j] ? S.gidx[g0[g] + j] : 0xFFFFFFF0u + (unsigned)j;
+                    gv[g][j] = gon[g][j] ? S.gval[g0[g] + j] : 0.0f;
+                }
+#pragma unroll
+                for (int a = 0; a < GR; a++)
+#pragma unroll
+                    for (int b = a + 1; b < GR; b++) if (gid[g][a] == gid[g][b]) greg[g] = false;
+            }
+#pragma unroll
+            for (int j = 0; j < GR; j++) gb[g][j] = (greg[g] && gon[g][j]) ? P.g_bias[gpos(P, gid[g][j])] : 0.0f;
+        }
     }
 #pragma unroll
     for (int g = 0; g < G; g++) {
@@ -78,7 +118,12 @@ __global__ __launch_bounds__(HOTU ? 1024 : 256) void k_fused(const DevParams P, 
 #pragma unroll
     for (int g = 0; g < G; g++) {
         double bs = 0.0;
-        for (int j = g0[g]; j < g1[g]; j++) bs += (double)(S.gval[j] * P.g_bias[gpos(P, S.gidx[j])]);
+        if (greg[g]) {
+#pragma unroll
+            for (int j = 0; j < GR; j++) if (gon[g][j]) bs += (double)(gv[g][j] * gb[g][j]);
+        } else {
+            for (int j = g0[g]; j < g1[g]; j++) bs += (double)(S.gval[j] * P.g_bias[gpos(P, S.gidx[j])]);
+        }
         if (use_ubias) {
 #pragma unroll
             for (int a = 0; a < NU; a++) if (ur[g][a] != SLOT_ABSENT) bs += (double)(ua[g][a] * bu[g][a]);
@@ -95,27 +140,33 @@ __global__ __launch_bounds__(HOTU ? 1024 : 256) void k_fused(const DevParams P, 
         const float pred = map_active((float)sum, P.active_type);
         const float err = cal_grad(label[g], pred, P.active_type) * 1.0f;
         const float lr = P.lr;
-        // global biases go through memory in the reference's order (all updates, then all decays), so a
-        // global id listed twice behaves like the reference; every lane stores the same value
+        // global biases: registers when the instance's ids are distinct (greg), otherwise through memory in the reference's
+        // order (all updates, then all decays), so a global id listed twice behaves like the reference; every lane stores
+        // the same value
         if (P.relax_global) {
             // relaxed shared ids: other instances of this launch may be updating the same global -- add this instance's
             // change (update, then decay of the value it read) atomically; one lane per group
             for (int j = g0[g]; j < g1[g]; j++) {
-                const unsigned gid = S.gidx[j];
-                const float gb = P.g_bias[gpos(P, gid)];
-                const float nb = reg_gbias(P, gid, gb + lr * err * S.gval[j]);
-                if (L == 0) unsafeAtomicAdd(&P.g_bias[gpos(P, gid)], nb - gb);
+                const unsigned gi = S.gidx[j];
+                const float was = P.g_bias[gpos(P, gi)];
+                const float nb = reg_gbias(P, gi, was + lr * err * S.gval[j]);
+                if (L == 0) unsafeAtomicAdd(&P.g_bias[gpos(P, gi)], nb - was);
             }
+        } else if (greg[g]) {
+            // distinct ids: "all updates, then all decays" (apex_svd_base.h:384-387, 288-292) is update+decay id by id
+#pragma unroll
+            for (int j = 0; j < GR; j++)
+                if (gon[g][j]) P.g_bias[gpos(P, gid[g][j])] = reg_gbias(P, gid[g][j], gb[g][j] + lr * err * gv[g][j]);
         } else {
             for (int j = g0[g]; j < g1[g]; j++) {
-                const unsigned gid = S.gidx[j];
-                float gb = P.g_bias[gpos(P, gid)];
-                gb = gb + lr * err * S.gval[j];
-                P.g_bias[gpos(P, gid)] = gb;
+                const unsigned gi = S.gidx[j];
+                float gbm = P.g_bias[gpos(P, gi)];
+                gbm = gbm + lr * err * S.gval[j];
+                P.g_bias[gpos(P, gi)] = gbm;
             }
             for (int j = g0[g]; j < g1[g]; j++) {
-                const unsigned gid = S.gidx[j];
-                P.g_bias[gpos(P, gid)] = reg_gbias(P, gid, P.g_bias[gpos(P, gid)]);
+                const unsigned gi = S.gidx[j];
+                P.g_bias[gpos(P, gi)] = reg_gbias(P, gi, P.g_bias[gpos(P, gi)]);
             }
         }
         // HOTU: this instance's change of the shared row in the last user slot, handed to the workgroup reduction below

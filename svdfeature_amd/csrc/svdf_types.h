@@ -118,6 +118,8 @@ struct FusedSchedule {
     const int *gptr;          // [n+1], nullptr when the data set has no global feature
     const unsigned *gidx;
     const float *gval;
+    const unsigned *gsi[4];   // inline global slots (SLOT_ABSENT = none), nullptr unless every instance has <= 4 distinct global ids
+    const float *gsv[4];
 };
 enum { SLOT_ABSENT = 0xFFFFFFFFu };
 

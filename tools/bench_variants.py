@@ -28,6 +28,7 @@ ap.add_argument("--items", type=int, default=100_000)
 ap.add_argument("--factor", type=int, default=128)
 ap.add_argument("--passes", type=int, default=3)
 ap.add_argument("--use-graph", type=int, default=0)
+ap.add_argument("--knob", action="append", default=[], help="extra tuning knob name=value, repeatable")
 a = ap.parse_args()
 
 
@@ -41,6 +42,8 @@ def mk(format_type, active_type, extra):
     t.init_model()
     t.init_trainer()
     t.set_knob("use_graph", a.use_graph)
+    for kv in a.knob:
+        t.set_knob(kv.split("=")[0], int(kv.split("=")[1]))
     return t
 
 
