@@ -2,9 +2,9 @@
 """Rate of the rank-pair input path: pairs drawn on the host per second by the native sampler, time to
 schedule + upload one pass, and the device training rate on it, next to the reference's own generator (oracle/_ref/
 ref_pairgen_dump, when present) run over the same user-group buffer file.  Secondary numbers for DESIGN.md; writes one
-JSON line.
+JSON line.  Lives under tests/ because it runs an oracle binary (perf_* files are not collected by pytest).
 
-    python tools/rank_input_rate.py [--users 100000] [--rows 64] [--items 100000] [--factor 128] [--passes 3]
+    python tests/perf_rank_input.py [--users 100000] [--rows 64] [--items 100000] [--factor 128] [--passes 3]
 """
 import argparse
 import json
