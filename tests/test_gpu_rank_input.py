@@ -147,3 +147,45 @@ def test_feedback_free_blocks_row_by_row_equal_whole_users(factor, tmp_path):
         assert all(k == 3 for k in kinds) if rows_knob == 0 else all(k in (1, 2) for k in kinds)
         t.close()
     assert models[0] == models[1]
+
+
+def test_rank_input_at_scale_count_and_determinism(tmp_path):
+    """Size-independent properties at a size the host oracle would not finish quickly (50 K users x 64 candidates,
+    100 K items, k=128, ~1.6 M pairs per pass): the number of pairs of a pass equals the number of negatives of the users
+    that have both kinds (apex_svd_data.cpp:949-961, no rank_sample_num), every pass draws a different set, and two runs from
+    the same seed write the same bytes."""
+    import perf_rank_input
+    users, rows, items = 50000, 64, 100000
+    src = str(tmp_path / "cand.buffer")
+    perf_rank_input.write_candidates(src, users, rows, items, 7)
+    raw = np.fromfile(src, np.uint8)[16:]
+    rec = 4 * (3 + (3 * rows + 1) + rows + 2 * rows + 2 * rows)
+    labels = raw.reshape(users, rec)[:, 4 * (3 + 3 * rows + 1):4 * (3 + 3 * rows + 1 + rows)].copy().view(np.float32)
+    npos, nneg = (labels >= 0.8).sum(1), (labels <= 0.0).sum(1)
+    expected = int(nneg[(npos > 0) & (nneg > 0)].sum())
+    conf = [("num_user", users), ("num_item", items), ("num_global", 0), ("num_factor", 128), ("num_ufeedback", 0), ("learning_rate", 0.005),
+            ("wd_user", 0.004), ("wd_item", 0.004), ("active_type", 3), ("no_user_bias", 1)]
+    outs = []
+    for run in range(2):
+        t = sa.Trainer(1, 3)
+        t.seed(10)
+        for k, v in conf:
+            t.set_param(k, str(v))
+        t.init_model()
+        t.init_trainer()
+        batches = []
+        for r in range(2):
+            t.set_round(r)
+            ds = t.dataset_from_rank_buffer_file(src)
+            assert ds.num_row == expected and ds.kind == 2
+            batches.append(ds.num_batches)
+            t.train_dataset(ds)
+            t.finish_round()
+            ds.close()
+        assert batches[0] != batches[1]   # a new draw per pass
+        outs.append((t.view("W_item").copy(), t.view("W_user").copy(), t.view("i_bias").copy(), tuple(batches)))
+        t.close()
+    assert outs[0][3] == outs[1][3]
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][0]).max() < 10
