@@ -936,3 +936,51 @@ def test_relaxed_svdpp_rows_shared_between_users():
     with pytest.raises(sa.SvdfError, match="relaxed mode is amd:relax_item_from = 0"):
         bad = _ready(hip, 1, conf + [("amd:relax_item_from", "100")])
         bad.dataset_from_blocks(blocks)
+
+
+@pytest.mark.parametrize("shape", ["inline_distinct", "more_than_four", "repeated_ids"])
+@pytest.mark.parametrize("reg_global", [0, 1])
+def test_fused_kernel_global_bias_paths(shape, reg_global):
+    """The three ways k_fused handles an instance's global biases -- inline slots of the schedule record (every instance
+    has <= 4 distinct ids), registers decided per instance (<= 4 distinct ids in a data set where others have more), and
+    the walk through memory in the reference's order (an id listed twice: updated twice, then decayed twice,
+    apex_svd_base.h:384-387, 288-292) -- against the oracle, bit for bit, with decay-free ids and per-range decay."""
+    nu, ni, ng, k = 300, 120, 50, 32
+    rng = np.random.default_rng(7 + reg_global)
+    rows = []
+    for r in range(4000):
+        if shape == "inline_distinct":
+            g = rng.choice(ng, size=int(rng.integers(0, 5)), replace=False)
+        elif shape == "more_than_four":
+            g = rng.choice(ng, size=int(rng.integers(0, 8)), replace=False)
+        else:
+            g = rng.integers(0, ng, size=int(rng.integers(1, 5)))
+            if r % 3 == 0 and len(g) >= 2:
+                g[1] = g[0]
+        gl = [(int(x), float(np.float32(rng.uniform(-1, 1)))) for x in g]
+        rows.append((float(rng.integers(1, 6)), gl, [(int(rng.integers(0, nu)), 1.0)], [(int(rng.integers(0, ni)), float(np.float32(rng.uniform(0.5, 1.5))))]))
+    d = sa.CSRData.from_rows(rows)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=k, wd_global=0.02, reg_global=reg_global,
+                           num_regfree_global=5, learning_rate=0.01) + [("gp:wd", "0.05"), ("gp:bound", "20"), ("gp:wd", "0.001"), ("gp:bound", "50")]
+
+    def make(mk):
+        t = mk(0, 0)
+        t.seed(3)
+        for kk, v in conf:
+            t.set_param(kk, v)
+        t.init_model()
+        t.init_trainer()
+        return t
+    o, t_ds, t_staged = make(port), make(hip), make(hip)
+    ds = t_ds.dataset_from_csr(d)
+    assert ds.kind == 2
+    for _ in range(2):
+        o.update_batch(d)
+        t_ds.train_dataset(ds)
+        t_staged.update_batch(d)
+        t_staged.finish_round()
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "g_bias"):
+        ref = o.view(name).view(np.uint32)
+        np.testing.assert_array_equal(t_ds.view(name).view(np.uint32), ref)
+        np.testing.assert_array_equal(t_staged.view(name).view(np.uint32), ref)
+    np.testing.assert_array_equal(t_ds.predict_dataset(ds).view(np.uint32), o.predict_batch(d).view(np.uint32))
