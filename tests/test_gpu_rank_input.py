@@ -189,3 +189,28 @@ def test_rank_input_at_scale_count_and_determinism(tmp_path):
     for a, b in zip(outs[0][:3], outs[1][:3]):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert np.isfinite(outs[0][0]).all() and np.abs(outs[0][0]).max() < 10
+
+
+@pytest.mark.parametrize("max_fb", [0, 2], ids=["nofeedback", "feedback"])
+def test_rank_input_without_any_pair_is_a_no_op(max_fb, tmp_path):
+    """No user has a negative: the generator emits empty blocks (apex_svd_data.cpp:949), a pass changes nothing."""
+    blocks = cases.rank_blocks(40, 60, 50, 8, 3, max_fb=max_fb)
+    for b in blocks:
+        b.data.row_label[:] = 1.0
+    src = str(tmp_path / "train.buffer")
+    D.write_ugroup_buffer(src, blocks)
+    t = sa.Trainer(1, 3)
+    t.seed(10)
+    for k, v in cases.RANK_E2E_CONF:
+        t.set_param(k, v)
+    t.init_model()
+    t.init_trainer()
+    before = [t.view(v).copy() for v in ("W_user", "W_item", "i_bias", "g_bias", "W_ufeedback")]
+    ds = t.dataset_from_rank_buffer_file(src)
+    assert ds.num_row == 0
+    t.train_dataset(ds)
+    t.finish_round()
+    for a, v in zip(before, ("W_user", "W_item", "i_bias", "g_bias", "W_ufeedback")):
+        np.testing.assert_array_equal(a.view(np.uint32), t.view(v).view(np.uint32))
+    ds.close()
+    t.close()
