@@ -129,6 +129,11 @@ svdf_dataset *svdf_dataset_from_buffer_file(svdf_trainer *t, const char *path, i
  * config: pos_sample_lowerb, neg_sample_upperb, rank_sample_num, rank_sample_max, rank_sample_method (0, 1),
  * rank_sample_gap, rank_sample_pointwise, seed_sampler_bytime.  Needs format_type = 1. */
 svdf_dataset *svdf_dataset_from_rank_buffer_file(svdf_trainer *t, const char *path);
+/* Draws the NEXT pass on a background host thread (the sampler is host work on the mapped file and libc rand(); the
+ * device can train the current pass meanwhile).  The next svdf_dataset_from_rank_buffer_file / svdf_rank_sample_buffer_file
+ * call for the same path takes the prefetched pass; the pairs are the ones that call would have drawn itself as long as
+ * nothing else calls rand() in between (the reference's round loop does not, svd_feature.cpp:272-283).  0 on success. */
+int svdf_rank_prefetch_buffer_file(svdf_trainer *t, const char *path);
 /* The same pass written to out_path as a user-group buffer file instead of being uploaded (host only, works on a
  * handle created with device = -2).  Returns the number of generated rows, -1 on error. */
 int64_t svdf_rank_sample_buffer_file(svdf_trainer *t, const char *in_path, const char *out_path);

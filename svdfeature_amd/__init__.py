@@ -82,6 +82,8 @@ def load_library():
     lib.svdf_dataset_from_buffer_file.argtypes = [P, C.c_char_p, C.c_int]
     lib.svdf_dataset_from_rank_buffer_file.restype = P
     lib.svdf_dataset_from_rank_buffer_file.argtypes = [P, C.c_char_p]
+    lib.svdf_rank_prefetch_buffer_file.restype = C.c_int
+    lib.svdf_rank_prefetch_buffer_file.argtypes = [P, C.c_char_p]
     lib.svdf_rank_sample_buffer_file.restype = C.c_int64
     lib.svdf_rank_sample_buffer_file.argtypes = [P, C.c_char_p, C.c_char_p]
     lib.svdf_dataset_from_blocks.restype = P
@@ -314,6 +316,10 @@ class Trainer:
         if not h:
             raise SvdfError(self.lib.svdf_last_error().decode())
         return Dataset(self, h)
+
+    def rank_prefetch_buffer_file(self, path):
+        """Draw the next rank-pair pass on a background thread; the next dataset_from_rank_buffer_file takes it."""
+        self._ok(self.lib.svdf_rank_prefetch_buffer_file(self.h, str(path).encode()))
 
     def rank_sample_buffer_file(self, in_path, out_path):
         """The same pass written as a user-group buffer file (host only); returns the number of generated rows."""

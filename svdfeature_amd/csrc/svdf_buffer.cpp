@@ -22,6 +22,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 namespace svdf {
 namespace {
@@ -105,6 +106,8 @@ struct CsrArrays {
     }
 };
 
+}  // namespace
+
 struct UserGroupArrays {
     std::vector<int> tag;
     std::vector<int64_t> fb_ptr, block_row_ptr;
@@ -112,6 +115,8 @@ struct UserGroupArrays {
     std::vector<float> fb_value;
     CsrArrays rows;
 };
+
+namespace {
 
 // Walks a user-group buffer file.  With a sampler every block's rows are replaced by the rank pairs drawn from them
 // (the feedback part of the block is kept as it is, like PairwiseRankGenerator::next, apex_svd_data.cpp:999-1019).
@@ -175,6 +180,60 @@ void read_user_group(const MappedFile &file, PairSampler *sampler, UserGroupArra
 
 }  // namespace
 
+// One pass of the rank-pair sampler drawn ahead of time on a background thread (svdf_rank_prefetch_buffer_file): the
+// sampler is pure host work on the mapped file and libc rand(), so it can run while the device trains the previous pass.
+struct RankPrefetch {
+    std::string path;
+    std::thread worker;
+    UserGroupArrays arrays;
+    std::string error;
+    bool failed = false;
+};
+
+void Engine::rank_prefetch_drop() {
+    if (!rank_prefetch_) return;
+    if (rank_prefetch_->worker.joinable()) rank_prefetch_->worker.join();
+    delete rank_prefetch_;
+    rank_prefetch_ = nullptr;
+}
+
+void Engine::rank_prefetch(const char *path) {
+    check(path != nullptr, "rank_prefetch: null path");
+    check(user_group(), "rank-pair input needs the user-group format (format_type = 1), svd_feature.cpp:129-133");
+    check(rank_prefetch_ == nullptr, "rank_prefetch: a prefetched pass is still waiting to be used");
+    pair_sampler_.init();
+    rank_prefetch_ = new RankPrefetch();
+    rank_prefetch_->path = path;
+    RankPrefetch *pf = rank_prefetch_;
+    PairSampler *sampler = &pair_sampler_;
+    pf->worker = std::thread([pf, sampler]() {
+        try {
+            MappedFile file(pf->path.c_str());
+            read_user_group(file, sampler, pf->arrays);
+        } catch (const std::exception &e) {
+            pf->failed = true;
+            pf->error = e.what();
+        }
+    });
+}
+
+// the pass for `path`: the prefetched one if there is one (it must be for the same file), drawn now otherwise
+void Engine::rank_pass(const char *path, UserGroupArrays &g) {
+    if (rank_prefetch_) {
+        if (rank_prefetch_->worker.joinable()) rank_prefetch_->worker.join();
+        const bool same = rank_prefetch_->path == path, failed = rank_prefetch_->failed;
+        const std::string err = rank_prefetch_->error;
+        if (same && !failed) g = std::move(rank_prefetch_->arrays);
+        rank_prefetch_drop();
+        if (failed) fail(err);
+        if (!same) fail("rank_prefetch: the prefetched pass was drawn from another file");
+        return;
+    }
+    MappedFile file(path);
+    pair_sampler_.init();
+    read_user_group(file, &pair_sampler_, g);
+}
+
 Dataset *Engine::dataset_from_buffer_file(const char *path, int user_group_format) {
     check(path != nullptr, "dataset_from_buffer_file: null path");
     MappedFile file(path);
@@ -209,10 +268,8 @@ Dataset *Engine::dataset_from_buffer_file(const char *path, int user_group_forma
 Dataset *Engine::dataset_from_rank_buffer_file(const char *path) {
     check(path != nullptr, "dataset_from_rank_buffer_file: null path");
     check(user_group(), "rank-pair input needs the user-group format (format_type = 1), svd_feature.cpp:129-133");
-    MappedFile file(path);
     UserGroupArrays g;
-    pair_sampler_.init();
-    read_user_group(file, &pair_sampler_, g);
+    rank_pass(path, g);
     return dataset_from_blocks((long)g.tag.size(), g.tag.data(), g.fb_ptr.data(), g.fb_index.data(), g.fb_value.data(),
                                g.block_row_ptr.data(), g.rows.label.data(), g.rows.row_ptr.data(), g.rows.index.data(),
                                g.rows.value.data());
@@ -221,10 +278,8 @@ Dataset *Engine::dataset_from_rank_buffer_file(const char *path) {
 // The same pass written back as a user-group buffer file (host only: works without a device).
 long Engine::rank_sample_buffer_file(const char *in_path, const char *out_path) {
     check(in_path != nullptr && out_path != nullptr, "rank_sample_buffer_file: null path");
-    MappedFile file(in_path);
     UserGroupArrays g;
-    pair_sampler_.init();
-    read_user_group(file, &pair_sampler_, g);
+    rank_pass(in_path, g);
     FILE *fo = fopen(out_path, "wb");
     if (!fo) fail(std::string("can not open file \"") + out_path + "\"");
     const size_t nb = g.tag.size();

@@ -128,6 +128,7 @@ svdf_dataset *svdf_dataset_from_rank_buffer_file(svdf_trainer *t, const char *pa
         return h;
     })
 }
+int svdf_rank_prefetch_buffer_file(svdf_trainer *t, const char *path) { SVDF_GUARD(-1, { t->e->rank_prefetch(path); return 0; }) }
 int64_t svdf_rank_sample_buffer_file(svdf_trainer *t, const char *in_path, const char *out_path) {
     SVDF_GUARD(-1, { return (int64_t)t->e->rank_sample_buffer_file(in_path, out_path); })
 }

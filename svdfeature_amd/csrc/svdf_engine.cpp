@@ -214,6 +214,7 @@ struct ScopedNs {
 }  // namespace
 
 Engine::~Engine() {
+    rank_prefetch_drop();
     if (getenv("SVDF_PROFILE"))
         fprintf(stderr, "[svdfeature_amd] host time: flush (schedule+upload+launch) %.3fs  model save/load %.3fs  instances %ld flushes %ld\n",
                 ns_flush_ * 1e-9, ns_model_ * 1e-9, (long)n_instances_, (long)n_flushes_);

@@ -142,6 +142,8 @@ private:
     std::vector<RankRow> pos_, neg_;
 };
 
+struct RankPrefetch;
+struct UserGroupArrays;
 class Engine;
 
 // HBM-resident scheduled training set
@@ -205,6 +207,10 @@ class Engine {
     // input_type = 2: a user-group buffer file through the rank-pair sampler, one pass per call
     Dataset *dataset_from_rank_buffer_file(const char *path);
     long rank_sample_buffer_file(const char *in_path, const char *out_path);   // host only; returns the number of rows written
+    // draws the NEXT pass on a background thread; the next dataset_from_rank_buffer_file / rank_sample_buffer_file call
+    // for the same file takes it.  Nothing else may call rand() until then (the reference's loop does not, svd_feature.cpp:272-283)
+    void rank_prefetch(const char *path);
+    void rank_prefetch_drop();
     void train_dataset(Dataset *ds);
     void predict_dataset(Dataset *ds, float *out);
 
@@ -289,6 +295,8 @@ class Engine {
     void download_globals(float *dst);
     unsigned relax_user_from_ = 0xFFFFFFFFu, relax_item_from_ = 0xFFFFFFFFu;
     PairSampler pair_sampler_;
+    RankPrefetch *rank_prefetch_ = nullptr;
+    void rank_pass(const char *path, UserGroupArrays &g);
     bool rows_without_feedback_ = true;   // knob: block datasets without any feedback id are scheduled row by row
     bool rows_as_instances_ = false;      // set while such a dataset is being built
     bool relaxed() const { return relax_global_ || relax_feedback_ || relax_user_from_ != 0xFFFFFFFFu || relax_item_from_ != 0xFFFFFFFFu; }

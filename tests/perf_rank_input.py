@@ -101,6 +101,24 @@ def main():
             out["train_s"] = min(train)
             out["train_pairs_per_s"] = n / min(train)
             out["end_to_end_pairs_per_s"] = n / (min(build) + min(train))
+            # the same with the next pass drawn on the background thread (svdf_rank_prefetch_buffer_file) while this thread
+            # issues the current pass's launches
+            t.synchronize()
+            t0 = time.perf_counter()
+            ds = t.dataset_from_rank_buffer_file(src)
+            total = 0
+            for r in range(args.passes):
+                t.set_round(args.passes + r)
+                if r + 1 < args.passes:
+                    t.rank_prefetch_buffer_file(src)
+                t.train_dataset(ds)
+                total += ds.num_row
+                nxt = t.dataset_from_rank_buffer_file(src) if r + 1 < args.passes else None
+                t.finish_round()
+                ds.close()
+                ds = nxt
+            t.synchronize()
+            out["overlapped_end_to_end_pairs_per_s"] = total / (time.perf_counter() - t0)
             t.close()
     print(json.dumps(out))
 

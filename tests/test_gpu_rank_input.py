@@ -214,3 +214,30 @@ def test_rank_input_without_any_pair_is_a_no_op(max_fb, tmp_path):
         np.testing.assert_array_equal(a.view(np.uint32), t.view(v).view(np.uint32))
     ds.close()
     t.close()
+
+
+def test_prefetched_rank_passes_train_the_same_bytes(tmp_path):
+    """Drawing pass r+1 on the background thread while the device trains pass r changes nothing but the wall time."""
+    src = str(tmp_path / "train.buffer")
+    D.write_ugroup_buffer(src, cases.rank_blocks(300, 60, 50, 8, 12, max_rows=12, max_fb=0))
+    plain, _ = _train_resident(tmp_path, src, cases.RANK_E2E_CONF, 3)
+    t = sa.Trainer(1, 3)
+    t.seed(10)
+    for k, v in cases.RANK_E2E_CONF:
+        t.set_param(k, v)
+    t.init_model()
+    t.init_trainer()
+    p = str(tmp_path / "pf.model")
+    ds = t.dataset_from_rank_buffer_file(src)
+    for r in range(3):
+        t.set_round(r)
+        t.train_dataset(ds)                      # asynchronous
+        if r + 1 < 3:
+            t.rank_prefetch_buffer_file(src)     # host draws the next pass meanwhile
+        t.finish_round()
+        t.save_model(p)
+        assert open(p, "rb").read() == plain[r + 1], "round %d differs" % r
+        ds.close()
+        if r + 1 < 3:
+            ds = t.dataset_from_rank_buffer_file(src)
+    t.close()

@@ -117,3 +117,35 @@ def test_sampler_against_the_reference_generator_run_live(seed, tmp_path):
     subprocess.check_call([REF_DUMP, src, ref_out, str(seed), "3"] + ["%s=%s" % kv for kv in keys.items()],
                           cwd=str(tmp_path), stdout=subprocess.DEVNULL)
     assert cases.blocks_digest(D.read_ugroup_buffer(ref_out)) == cases.blocks_digest(got)
+
+
+def test_prefetched_passes_are_the_same_draws(tmp_path):
+    """svdf_rank_prefetch_buffer_file draws the next pass on a background thread; taken by the next call for the same
+    file it is the pass that call would have drawn (golden digest of two consecutive passes)."""
+    name, graded, keys = cases.RANK_SAMPLER_CASES[3]
+    blocks = cases.rank_blocks(200, 60, 50, 8, 503, graded)
+    src = str(tmp_path / "in.buffer")
+    D.write_ugroup_buffer(src, blocks)
+    t = sa.Trainer(1, 3, device=-2)
+    t.seed(cases.RANK_SAMPLER_SEED)
+    for k, v in keys.items():
+        t.set_param(k, v)
+    got = []
+    t.rank_prefetch_buffer_file(src)
+    for r in range(cases.RANK_SAMPLER_ROUNDS):
+        out = str(tmp_path / ("pass%d.buffer" % r))
+        t.rank_sample_buffer_file(src, out)          # takes the prefetched pass
+        if r + 1 < cases.RANK_SAMPLER_ROUNDS:
+            t.rank_prefetch_buffer_file(src)
+        got += D.read_ugroup_buffer(out)
+    assert cases.blocks_digest(got) == str(GOLD["sampler/%s/md5" % name])
+    # a second prefetch before the first is used, and a pick-up for another file, are errors
+    t.rank_prefetch_buffer_file(src)
+    with pytest.raises(sa.SvdfError, match="still waiting"):
+        t.rank_prefetch_buffer_file(src)
+    with pytest.raises(sa.SvdfError, match="another file"):
+        t.rank_sample_buffer_file(str(tmp_path / "pass0.buffer"), str(tmp_path / "x"))
+    t.rank_prefetch_buffer_file(str(tmp_path / "missing"))   # errors of the background pass surface at the pick-up
+    with pytest.raises(sa.SvdfError, match="can not open"):
+        t.rank_sample_buffer_file(str(tmp_path / "missing"), str(tmp_path / "x"))
+    t.close()
