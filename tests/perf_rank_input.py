@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--items", type=int, default=100000)
     ap.add_argument("--factor", type=int, default=128)
     ap.add_argument("--passes", type=int, default=3)
+    ap.add_argument("--knob", action="append", default=[], help="tuning knob name=value, repeatable")
     args = ap.parse_args()
     out = {"users": args.users, "rows_per_user": args.rows, "items": args.items, "factor": args.factor}
     with tempfile.TemporaryDirectory() as tmp:
@@ -80,6 +81,8 @@ def main():
                 t.set_param(k, str(v))
             t.init_model()
             t.init_trainer()
+            for kv in args.knob:
+                t.set_knob(kv.split("=")[0], int(kv.split("=")[1]))
             build, train = [], []
             for r in range(args.passes):
                 t.set_round(r)
