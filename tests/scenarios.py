@@ -64,8 +64,8 @@ def _scn_implicit_example(tmp):  # demo/implicitFeedback
                 train_blocks=blocks, test_blocks=blocks)
 
 
-def _sparse(tmp, seed, active_type=0, binary=False, side=False, n=600, k=12, extra=(), **conf_kw):
-    nu, ni, ng = 40, 30, 9
+def _sparse(tmp, seed, active_type=0, binary=False, side=False, n=600, k=12, extra=(), nu=40, ni=30, **conf_kw):
+    ng = 9
     train = cases.sparse_feature_rows(n, nu, ni, ng, seed, binary_label=binary)
     test = cases.sparse_feature_rows(80, nu, ni, ng, seed + 1, binary_label=binary)
     kw = dict(num_user=nu, num_item=ni, num_global=ng, num_factor=k, wd_global=0.002,
@@ -81,8 +81,22 @@ def _sparse(tmp, seed, active_type=0, binary=False, side=False, n=600, k=12, ext
     return dict(conf=_conf(**kw) + list(extra), format_type=0, active_type=active_type, rounds=3, train=train, test=test)
 
 
-def _scn_svdpp_random(tmp, **kw):
-    nu, ni = 50, 40
+def _scn_common_latent_triples(tmp):
+    """(u, i, r) triples over ONE id space (common_latent_space, apex_svd_model.h:516-536: W_item IS W_user), including
+    instances whose user id equals their item id -- the same row is updated twice, through memory, in the reference."""
+    n, ids = 900, 35
+    rng = np.random.default_rng(123)
+    u = rng.integers(0, ids, n).astype(np.uint32)
+    i = rng.integers(0, ids, n).astype(np.uint32)
+    i[::7] = u[::7]
+    r = rng.integers(1, 6, n).astype(np.float32)
+    train = CSRData.from_triples(u, i, r)
+    test = CSRData.from_triples(u[:90], i[::-1][:90].copy(), r[:90])
+    conf = _conf(num_user=ids, num_item=ids, num_factor=8, common_latent_space=1, common_feedback_space=1, learning_rate=0.01)
+    return dict(conf=conf, format_type=0, active_type=0, rounds=3, train=train, test=test)
+
+
+def _scn_svdpp_random(tmp, nu=50, ni=40, **kw):
     blocks = cases.user_blocks(45, nu, ni, ni, 77, split_every=4)
     test = cases.user_blocks(20, nu, ni, ni, 78)
     conf = _conf(num_user=nu, num_item=ni, num_factor=16, num_ufeedback=ni, wd_ufeedback=0.004,
@@ -127,6 +141,11 @@ SCENARIOS = {
     "svdpp_random": _scn_svdpp_random,
     "svdpp_random_lazy": lambda t: _scn_svdpp_random(t, reg_method=5),
     "svdpp_random_nobias": lambda t: _scn_svdpp_random(t, no_user_bias=1),
+    # shared parameter spaces (apex_svd_model.h:511-556): users and items in one matrix, feedback rows = user rows
+    "sparse_common_latent": lambda t: _sparse(t, 121, nu=30, ni=30, common_latent_space=1, common_feedback_space=1),
+    "common_latent_triples": _scn_common_latent_triples,
+    "svdpp_common_feedback": lambda t: _scn_svdpp_random(t, common_feedback_space=1),
+    "svdpp_common_latent": lambda t: _scn_svdpp_random(t, nu=50, ni=50, common_latent_space=1, common_feedback_space=1),
 }
 
 
