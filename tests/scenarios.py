@@ -142,6 +142,10 @@ SCENARIOS = {
     "svdpp_random_lazy": lambda t: _scn_svdpp_random(t, reg_method=5),
     "svdpp_random_nobias": lambda t: _scn_svdpp_random(t, no_user_bias=1),
     # shared parameter spaces (apex_svd_model.h:511-556): users and items in one matrix, feedback rows = user rows
+    # alias keys of the parameter parsers (apex_svd_model.h:350-368, 456-476) and the init-time options they reach
+    "sparse_alias_keys": lambda t: _sparse(t, 122, nu=30, ni=30, user_nonnegative=1, decay_learning_rate=1, decay_rate=0.8, extra=[
+        ("num_uiset", "30"), ("wd_uiset", "0.003"), ("wd_uiset_bias", "0.002"), ("ui_init_sigma", "0.02"), ("u_init_sigma", "0.015"),
+        ("item_nonnegative", "1"), ("min_learning_rate", "0.1")]),   # (num_randinit_* leaves uninitialised rows in the reference: test_oracle.py)
     "sparse_common_latent": lambda t: _sparse(t, 121, nu=30, ni=30, common_latent_space=1, common_feedback_space=1),
     "common_latent_triples": _scn_common_latent_triples,
     "svdpp_common_feedback": lambda t: _scn_svdpp_random(t, common_feedback_space=1),

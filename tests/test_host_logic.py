@@ -46,7 +46,7 @@ def test_no_silent_cpu_fallback():
 
 
 @pytest.mark.parametrize("name", ["basicmf_ml100k_k16", "sparse_k10_tail", "sparse_logistic", "svdpp_random", "implicit_example",
-                                  "sparse_nonneg_decaylr"])
+                                  "sparse_nonneg_decaylr", "sparse_alias_keys", "svdpp_common_latent", "common_latent_triples"])
 def test_rand_init_and_model_file_match_reference_bytes(name, tmp_path):
     """init_model (libc rand, Marsaglia polar, row-major draw order, base_score transform) followed by
     save_model reproduces the reference's 0000.model byte for byte (golden md5 from the compiled
