@@ -104,6 +104,22 @@ def _scn_svdpp_random(tmp, nu=50, ni=40, **kw):
     return dict(conf=conf, format_type=1, active_type=0, rounds=3, train_blocks=blocks, test_blocks=test)
 
 
+def _scn_svdpp_rich_rows(tmp, side):
+    """User blocks whose rows carry global features, a second user id and several item ids (cases.rank_blocks, used as
+    plain training blocks), with implicit feedback and -- optionally -- both side tables: the generic user-unit path."""
+    nu, ni, ng = 60, 50, 8
+    blocks = cases.rank_blocks(70, nu, ni, ng, 5, graded=True)
+    test = cases.rank_blocks(25, nu, ni, ng, 6, graded=True)
+    kw = dict(num_user=nu, num_item=ni, num_global=ng, num_factor=12, num_ufeedback=ni, wd_ufeedback=0.004, wd_ufeedback_bias=0.001,
+              wd_global=0.002, ufeedback_init_sigma=0.01, learning_rate=0.01, wd_user_bias=0.001)
+    if side:
+        fu, fi = os.path.join(tmp, "feat_user.txt"), os.path.join(tmp, "feat_item.txt")
+        cases.write_side_table(fu, nu - 7, nu, 31)
+        cases.write_side_table(fi, ni, ni, 32)
+        kw.update(feature_user=fu, feature_item=fi)
+    return dict(conf=_conf(**kw), format_type=1, active_type=0, rounds=3, train_blocks=blocks, test_blocks=test)
+
+
 SCENARIOS = {
     "basicmf_ml100k_k16": _scn_basicmf_ml100k_k16,
     "basicmf_ml100k_k64": _scn_basicmf_ml100k_k64,
@@ -142,6 +158,8 @@ SCENARIOS = {
     "svdpp_random_lazy": lambda t: _scn_svdpp_random(t, reg_method=5),
     "svdpp_random_nobias": lambda t: _scn_svdpp_random(t, no_user_bias=1),
     # shared parameter spaces (apex_svd_model.h:511-556): users and items in one matrix, feedback rows = user rows
+    "svdpp_rich_rows": lambda t: _scn_svdpp_rich_rows(t, False),
+    "svdpp_rich_rows_side_tables": lambda t: _scn_svdpp_rich_rows(t, True),
     # alias keys of the parameter parsers (apex_svd_model.h:350-368, 456-476) and the init-time options they reach
     "sparse_alias_keys": lambda t: _sparse(t, 122, nu=30, ni=30, user_nonnegative=1, decay_learning_rate=1, decay_rate=0.8, extra=[
         ("num_uiset", "30"), ("wd_uiset", "0.003"), ("wd_uiset_bias", "0.002"), ("ui_init_sigma", "0.02"), ("u_init_sigma", "0.015"),
