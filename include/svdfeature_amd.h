@@ -137,7 +137,7 @@ int svdf_rank_prefetch_buffer_file(svdf_trainer *t, const char *path);
 /* The same pass written to out_path as a user-group buffer file instead of being uploaded (host only, works on a
  * handle created with device = -2).  Returns the number of generated rows, -1 on error. */
 int64_t svdf_rank_sample_buffer_file(svdf_trainer *t, const char *in_path, const char *out_path);
-void svdf_dataset_destroy(svdf_dataset *ds);
+void svdf_dataset_destroy(svdf_dataset *ds);                     /* also valid after svdf_destroy of its trainer */
 int svdf_train_dataset(svdf_trainer *t, svdf_dataset *ds);       /* one pass, asynchronous on the trainer's stream */
 int svdf_predict_dataset(svdf_trainer *t, svdf_dataset *ds, float *out); /* out[num_row], file order */
 /* dataset facts: 0 num_row, 1 number of conflict-free batches, 2 largest batch, 3 kernel kind

@@ -215,6 +215,8 @@ struct ScopedNs {
 
 Engine::~Engine() {
     rank_prefetch_drop();
+    for (Dataset *ds : datasets_) ds->owner = nullptr;
+    datasets_.clear();
     if (getenv("SVDF_PROFILE"))
         fprintf(stderr, "[svdfeature_amd] host time: flush (schedule+upload+launch) %.3fs  model save/load %.3fs  instances %ld flushes %ld\n",
                 ns_flush_ * 1e-9, ns_model_ * 1e-9, (long)n_instances_, (long)n_flushes_);
@@ -1139,7 +1141,7 @@ Dataset *Engine::dataset_from_blocks(long num_block, const int *extend_tag, cons
     auto drop = [&]() { staged_.clear(); staged_units_.clear(); staged_fb_index_.clear(); staged_fb_value_.clear(); unit_open_ = false; unit_open_on_device_ = false; };
     if (unit_open_) { drop(); fail("dataset_from_blocks: the last user's END block is missing"); }
     std::unique_ptr<Dataset> ds(new Dataset());
-    ds->owner = this; ds->kind = 3; ds->num_row = staged_.num_row();
+    adopt(ds.get()); ds->kind = 3; ds->num_row = staged_.num_row();
     if (!staged_units_.empty()) staged_units_.back().flags |= UNIT_SAVE;
     LevelTracker saved;
     std::swap(saved, tracker_);   // a dataset pass is preceded by a flush: schedule against an empty tracker
@@ -1240,7 +1242,7 @@ Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsign
         if (item[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound");
     }
     std::unique_ptr<Dataset> ds(new Dataset());
-    ds->owner = this; ds->num_row = n; ds->kind = 0;
+    adopt(ds.get()); ds->num_row = n; ds->kind = 0;
     // levels relative to an empty tracker: a dataset pass is always preceded by a flush and all launches
     // are stream ordered, so it only has to be conflict-free within itself
     std::vector<int> lastu((size_t)mp_.num_user, 0), lasti((size_t)mp_.num_item, 0), levels((size_t)n);
@@ -1295,7 +1297,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
         }
     }
     std::unique_ptr<Dataset> ds(new Dataset());
-    ds->owner = this; ds->num_row = n;
+    adopt(ds.get()); ds->num_row = n;
     std::vector<int> levels((size_t)n);
     LevelTracker saved;
     std::swap(saved, tracker_);   // schedule against an empty tracker (see dataset_from_triples)
@@ -1371,6 +1373,14 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
 
 Dataset::~Dataset() {
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    if (owner) owner->disown(this);
+}
+// A dataset outliving its trainer must not reach into it: the trainer forgets its datasets when it goes (their device
+// buffers stay valid and are freed by the dataset itself).
+void Engine::adopt(Dataset *ds) { ds->owner = this; datasets_.push_back(ds); }
+void Engine::disown(Dataset *ds) {
+    for (size_t i = 0; i < datasets_.size(); i++)
+        if (datasets_[i] == ds) { datasets_[i] = datasets_.back(); datasets_.pop_back(); break; }
 }
 
 void Engine::train_dataset(Dataset *ds) {

@@ -296,6 +296,9 @@ class Engine {
     unsigned relax_user_from_ = 0xFFFFFFFFu, relax_item_from_ = 0xFFFFFFFFu;
     PairSampler pair_sampler_;
     RankPrefetch *rank_prefetch_ = nullptr;
+    std::vector<Dataset *> datasets_;     // live datasets of this trainer (Dataset::owner back-pointers)
+    void adopt(Dataset *ds);
+    void disown(Dataset *ds);
     void rank_pass(const char *path, UserGroupArrays &g);
     bool rows_without_feedback_ = true;   // knob: block datasets without any feedback id are scheduled row by row
     bool rows_as_instances_ = false;      // set while such a dataset is being built

@@ -1,0 +1,14 @@
+"""A short run of the randomised differential script (tests/fuzz_parity.py: random format / link / regulariser / decay
+mode / factor width / shared spaces / side tables / staging plan, HIP engine vs the C oracle, bit for bit except for the
+expf tolerance of sigmoid links) inside the GPU suite; longer runs: python tests/fuzz_parity.py --iters 2500 --seed N."""
+import pytest
+
+import fuzz_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", [101, 102])
+def test_random_configurations_match_the_oracle(seed):
+    stats = fuzz_parity.main(["--iters", "250", "--seed", str(seed)])
+    assert stats["iters"] == 250 and stats["exact"] > 50

@@ -984,3 +984,19 @@ def test_fused_kernel_global_bias_paths(shape, reg_global):
         np.testing.assert_array_equal(t_ds.view(name).view(np.uint32), ref)
         np.testing.assert_array_equal(t_staged.view(name).view(np.uint32), ref)
     np.testing.assert_array_equal(t_ds.predict_dataset(ds).view(np.uint32), o.predict_batch(d).view(np.uint32))
+
+
+def test_dataset_may_outlive_its_trainer():
+    """svdf_destroy before svdf_dataset_destroy (garbage collection order in a host language) must not touch freed state."""
+    base, _ = cases.ml100k()
+    for _ in range(20):
+        t = hip(0, 0)
+        for k, v in cases.conf_with(cases.BASICMF_CONF, num_factor=8):
+            t.set_param(k, v)
+        t.init_model()
+        t.init_trainer()
+        ds = [t.dataset_from_csr(base.slice_rows(0, 3000)), t.dataset_from_csr(cases.sparse_feature_rows(300, 943, 1682, 0, 1))]
+        t.train_dataset(ds[0])
+        t.close()
+        for d in ds:
+            d.close()
