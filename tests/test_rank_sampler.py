@@ -149,3 +149,33 @@ def test_prefetched_passes_are_the_same_draws(tmp_path):
     with pytest.raises(sa.SvdfError, match="can not open"):
         t.rank_sample_buffer_file(str(tmp_path / "missing"), str(tmp_path / "x"))
     t.close()
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DUMP), reason="oracle/_ref/ref_pairgen_dump is built in the build container only")
+def test_sampler_random_settings_against_the_reference_generator(tmp_path):
+    """40 random sampler settings x random candidate sets, two passes each, against the reference's generator run live."""
+    rng = np.random.default_rng(99)
+    for case in range(40):
+        keys = {"rank_sample_method": str(int(rng.integers(0, 2)))}
+        if rng.integers(0, 2):
+            keys["rank_sample_num"] = str(int(rng.integers(1, 12)))
+        if rng.integers(0, 3) == 0:
+            keys["rank_sample_max"] = str(int(rng.integers(1, 6)))
+        if rng.integers(0, 3) == 0:
+            keys["rank_sample_pointwise"] = "1"
+        if rng.integers(0, 2):
+            keys["rank_sample_gap"] = str(float(rng.choice([0.0001, 0.5, 1.0, 2.5])))
+        graded = bool(rng.integers(0, 2))
+        if graded and rng.integers(0, 2):
+            keys["pos_sample_lowerb"] = str(float(rng.choice([2, 3.5, 4])))
+            keys["neg_sample_upperb"] = str(float(rng.choice([1, 2, 3])))
+        seed = int(rng.integers(1, 1 << 20))
+        d = tmp_path / ("c%d" % case)
+        d.mkdir()
+        blocks = cases.rank_blocks(int(rng.integers(1, 120)), 40, 30, int(rng.choice([0, 5])), seed, graded=graded,
+                                   max_rows=int(rng.integers(1, 30)), max_fb=int(rng.integers(0, 4)))
+        src, got, _ = _sample(d, blocks, keys, seed, 2)
+        ref_out = str(d / "ref.buffer")
+        subprocess.check_call([REF_DUMP, src, ref_out, str(seed), "2"] + ["%s=%s" % kv for kv in keys.items()],
+                              cwd=str(d), stdout=subprocess.DEVNULL)
+        assert cases.blocks_digest(D.read_ugroup_buffer(ref_out)) == cases.blocks_digest(got), (case, keys)
