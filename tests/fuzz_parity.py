@@ -33,7 +33,7 @@ def same_bits(a, b):
 VIEWS = ("W_user", "W_item", "u_bias", "i_bias", "g_bias", "W_ufeedback", "ufeedback_bias")
 
 
-def draw(rng, tmp):
+def draw(rng, tmp, wide=False):
     fmt = int(rng.integers(0, 2))
     active = int(rng.choice([0, 0, 0, 1, 2, 3, 5, 6, 7]))
     binary = active != 0
@@ -41,7 +41,7 @@ def draw(rng, tmp):
     nu = int(rng.integers(8, 60))
     ni = nu if shared else int(rng.integers(6, 50))
     ng = int(rng.integers(0, 10))
-    k = int(rng.choice([1, 3, 4, 7, 8, 12, 16, 31, 32, 33, 64, 65, 100, 128, 130, 200, 256, 300]))
+    k = int(rng.choice([257, 400, 512, 700, 1000, 1024] if wide else [1, 3, 4, 7, 8, 12, 16, 31, 32, 33, 64, 65, 100, 128, 130, 200, 256, 300]))
     reg_method = int(rng.choice([0, 0, 1, 2, 3, 4, 5]))
     reg_global = int(rng.choice([0, 0, 1, 4, 5]))
     conf = dict(num_user=nu, num_item=ni, num_global=ng, num_factor=k, learning_rate=float(rng.choice([0.005, 0.01, 0.05])),
@@ -155,6 +155,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--wide", action="store_true", help="factor widths 257..1024 (general kernels, several registers per lane)")
     ap.add_argument("--only", type=int, default=-1, help="run only this iteration (the generator is advanced up to it)")
     ap.add_argument("--reference", action="store_true", help="compare the oracle port with the compiled reference instead of the GPU")
     ap.add_argument("--trace", default="", help="file that always holds the configuration being run (to locate a crash)")
@@ -163,7 +164,7 @@ def main(argv=None):
     stats = dict(iters=0, exact=0, tolerance=0, skipped=0)
     for it in range(a.iters):
         with tempfile.TemporaryDirectory() as tmp:
-            fmt, active, conf, data, plan = draw(rng, tmp)
+            fmt, active, conf, data, plan = draw(rng, tmp, a.wide)
             if a.only >= 0 and it != a.only:
                 continue
             if a.trace:
