@@ -93,7 +93,7 @@ def draw(rng, tmp, wide=False):
                 b.value_ufeedback = b.value_ufeedback[:len(b.index_ufeedback)]
         data = dict(train_blocks=blocks)
     plan = dict(rounds=int(rng.integers(1, 4)), chunk=int(rng.choice([0, 0, 7, 64])), window=int(rng.choice([0, 0, 50, 400])),
-                resident=bool(rng.integers(0, 2)), knobs={})
+                resident=bool(rng.integers(0, 2)), knobs={}, single=bool(rng.integers(0, 5) == 0), peek=bool(rng.integers(0, 3) == 0))
     if rng.integers(0, 3) == 0:
         plan["knobs"]["use_fused"] = 0
     if rng.integers(0, 3) == 0:
@@ -116,11 +116,17 @@ def run(make, fmt, active, conf, data, plan, is_hip):
         if plan["window"]:
             t.set_knob("stage_window", plan["window"])
     ds = None
+    peeks = []
     for r in range(plan["rounds"]):
         t.set_round(r)
         if "train" in data:
             d = data["train"]
-            if is_hip and plan["resident"]:
+            if plan["single"]:   # one update(Elem) per instance, now and then a predict(Elem) in between (the reference CLI's calls)
+                for j in range(d.num_row):
+                    t.update_csr(*d.row(j))
+                    if plan["peek"] and j % 37 == 5:
+                        peeks.append(t.predict_csr(*d.row((j * 7) % d.num_row)))
+            elif is_hip and plan["resident"]:
                 ds = ds or t.dataset_from_csr(d)
                 t.train_dataset(ds)
             elif plan["chunk"]:
@@ -129,12 +135,15 @@ def run(make, fmt, active, conf, data, plan, is_hip):
             else:
                 t.update_batch(d)
         else:
-            if is_hip and plan["resident"]:
+            if is_hip and plan["resident"] and not plan["peek"]:
                 ds = ds or t.dataset_from_blocks(data["train_blocks"])
                 t.train_dataset(ds)
             else:
-                for b in data["train_blocks"]:
+                for j, b in enumerate(data["train_blocks"]):
                     t.update_block(b)
+                    if plan["peek"] and j % 5 == 2 and b.extend_tag in (0, 2):   # predict(block) between whole users
+                        peeks.extend(t.predict_block(data["train_blocks"][(j * 3) % len(data["train_blocks"])]).tolist()
+                                     if data["train_blocks"][(j * 3) % len(data["train_blocks"])].extend_tag == 0 else [])
         t.finish_round()
     if "train" in data:
         pred = t.predict_batch(data["train"])
@@ -148,7 +157,7 @@ def run(make, fmt, active, conf, data, plan, is_hip):
             a = None
         views[v] = None if a is None else np.array(a, copy=True)
     t.close()
-    return views, np.array(pred, np.float32, copy=True)
+    return views, np.concatenate([np.array(pred, np.float32, copy=True), np.array(peeks, np.float32)])
 
 
 def main(argv=None):
