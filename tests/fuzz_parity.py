@@ -93,7 +93,8 @@ def draw(rng, tmp, wide=False):
                 b.value_ufeedback = b.value_ufeedback[:len(b.index_ufeedback)]
         data = dict(train_blocks=blocks)
     plan = dict(rounds=int(rng.integers(1, 4)), chunk=int(rng.choice([0, 0, 7, 64])), window=int(rng.choice([0, 0, 50, 400])),
-                resident=bool(rng.integers(0, 2)), knobs={}, single=bool(rng.integers(0, 5) == 0), peek=bool(rng.integers(0, 3) == 0))
+                resident=bool(rng.integers(0, 2)), knobs={}, single=bool(rng.integers(0, 5) == 0), peek=bool(rng.integers(0, 3) == 0),
+                reload=bool(rng.integers(0, 4) == 0))
     if rng.integers(0, 3) == 0:
         plan["knobs"]["use_fused"] = 0
     if rng.integers(0, 3) == 0:
@@ -104,17 +105,23 @@ def draw(rng, tmp, wide=False):
 
 
 def run(make, fmt, active, conf, data, plan, is_hip):
-    t = make(fmt, active)
-    t.seed(11)
-    for k, v in conf:
-        t.set_param(k, v)
-    t.init_model()
-    t.init_trainer()
-    if is_hip:
-        for k, v in plan["knobs"].items():
-            t.set_knob(k, v)
-        if plan["window"]:
-            t.set_knob("stage_window", plan["window"])
+    def fresh(model_path=None):
+        t = make(fmt, active)
+        t.seed(11)
+        if model_path:   # warm start (svd_feature.cpp:175-182, continue training from a saved model)
+            t.load_model(model_path)
+        for k, v in conf:
+            t.set_param(k, v)
+        if not model_path:
+            t.init_model()
+        t.init_trainer()
+        if is_hip:
+            for k, v in plan["knobs"].items():
+                t.set_knob(k, v)
+            if plan["window"]:
+                t.set_knob("stage_window", plan["window"])
+        return t
+    t = fresh()
     ds = None
     peeks = []
     for r in range(plan["rounds"]):
@@ -145,6 +152,16 @@ def run(make, fmt, active, conf, data, plan, is_hip):
                         peeks.extend(t.predict_block(data["train_blocks"][(j * 3) % len(data["train_blocks"])]).tolist()
                                      if data["train_blocks"][(j * 3) % len(data["train_blocks"])].extend_tag == 0 else [])
         t.finish_round()
+        if plan.get("reload") and r == 0 and plan["rounds"] > 1:   # save, drop the trainer, load into a new one, go on
+            fd, path = tempfile.mkstemp(suffix=".model")
+            os.close(fd)
+            t.save_model(path)
+            if ds is not None:
+                ds.close()
+                ds = None
+            t.close()
+            t = fresh(path)
+            os.unlink(path)
     if "train" in data:
         pred = t.predict_batch(data["train"])
     else:
