@@ -237,7 +237,8 @@ def test_item_delta_roundtrip():
     np.testing.assert_allclose(b2, b0 + (b1 - b0), rtol=0, atol=0)
 
 
-def test_two_simulated_ranks_on_one_gpu_match_the_oracle_simulation():
+@pytest.mark.parametrize("world,windows,k", [(2, 4, 16), (3, 5, 10), (4, 3, 64)])
+def test_two_simulated_ranks_on_one_gpu_match_the_oracle_simulation(world, windows, k):
     """The MI355X side of the multi-GPU exchange (HipShard: item_delta begin/export/import/apply on torch
     device tensors) driven by ShardedTrainer with a fake all-reduce that sums the two ranks' tensors;
     must equal the oracle-backed single-process simulation bit for bit."""
@@ -245,9 +246,9 @@ def test_two_simulated_ranks_on_one_gpu_match_the_oracle_simulation():
     from multi_rank_utils import simulate
     from svdfeature_amd.multi_gpu import HipShard, ShardedTrainer, shard_windows
     nu, ni, n = 3000, 400, 40000
-    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=16)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k)
     u, i, r = cases.planted_triples(n, nu, ni, seed=9)
-    world, windows, passes = 2, 4, 2
+    passes = 2
     dev = torch.device("cuda", 0)
     shards = []
     for rk in range(world):
@@ -270,7 +271,9 @@ def test_two_simulated_ranks_on_one_gpu_match_the_oracle_simulation():
                 d = a.delta_get()          # enqueued on the adaptor's own stream
                 a.stream.synchronize()
                 ds.append(d.clone())
-            total = ds[0] + ds[1]
+            total = ds[0]
+            for d in ds[1:]:
+                total = total + d
             torch.cuda.synchronize()
             for a, _ in shards:
                 a.delta_set(total)
