@@ -33,13 +33,13 @@ def same_bits(a, b):
 VIEWS = ("W_user", "W_item", "u_bias", "i_bias", "g_bias", "W_ufeedback", "ufeedback_bias")
 
 
-def draw(rng, tmp, wide=False):
+def draw(rng, tmp, wide=False, big=False):
     fmt = int(rng.integers(0, 2))
     active = int(rng.choice([0, 0, 0, 1, 2, 3, 5, 6, 7]))
     binary = active != 0
     shared = int(rng.integers(0, 6)) == 0
-    nu = int(rng.integers(8, 60))
-    ni = nu if shared else int(rng.integers(6, 50))
+    nu = int(rng.integers(8, 3000 if big else 60))
+    ni = nu if shared else int(rng.integers(6, 800 if big else 50))
     ng = int(rng.integers(0, 10))
     k = int(rng.choice([257, 400, 512, 700, 1000, 1024] if wide else [1, 3, 4, 7, 8, 12, 16, 31, 32, 33, 64, 65, 100, 128, 130, 200, 256, 300]))
     reg_method = int(rng.choice([0, 0, 1, 2, 3, 4, 5]))
@@ -70,12 +70,12 @@ def draw(rng, tmp, wide=False):
     if fmt == 0:
         shape = int(rng.integers(0, 3))
         if shape == 0:   # basicMF triples
-            u, i, r = cases.planted_triples(int(rng.integers(50, 1500)), nu, ni, seed)
+            u, i, r = cases.planted_triples(int(rng.integers(50, 40000 if big else 1500)), nu, ni, seed)
             if binary:
                 r = (r > 3).astype(np.float32)
             train = sa.CSRData.from_triples(u, i, r)
         else:
-            train = cases.sparse_feature_rows(int(rng.integers(50, 900)), nu, ni, ng, seed, max_u=2 if shape == 1 else 3,
+            train = cases.sparse_feature_rows(int(rng.integers(50, 6000 if big else 900)), nu, ni, ng, seed, max_u=2 if shape == 1 else 3,
                                               max_i=2 if shape == 1 else 3, binary_label=binary, allow_dup=shape == 2)
         data = dict(train=train)
     else:
@@ -83,10 +83,10 @@ def draw(rng, tmp, wide=False):
         conf.update(num_ufeedback=nfb, wd_ufeedback=0.004, wd_ufeedback_bias=float(rng.choice([0.0, 0.002])),
                     scale_lr_ufeedback=float(rng.choice([1.0, 0.7])), ufeedback_init_sigma=0.01)
         if rng.integers(0, 2) == 0:
-            blocks = cases.user_blocks(int(rng.integers(5, min(nu, 40))), nu, ni, nfb, seed, split_every=int(rng.choice([0, 3])),
+            blocks = cases.user_blocks(int(rng.integers(5, min(nu, 600 if big else 40))), nu, ni, nfb, seed, split_every=int(rng.choice([0, 3])),
                                        binary_label=binary)
         else:
-            blocks = cases.rank_blocks(int(rng.integers(5, 40)), max(nu, 4), ni, ng if ng >= 2 else 0, seed, graded=not binary, max_fb=int(rng.integers(0, 4)))
+            blocks = cases.rank_blocks(int(rng.integers(5, 400 if big else 40)), max(nu, 4), ni, ng if ng >= 2 else 0, seed, graded=not binary, max_fb=int(rng.integers(0, 4)))
             for b in blocks:   # rank_blocks draws feedback ids below num_item
                 b.index_ufeedback = b.index_ufeedback % np.uint32(nfb)
                 b.index_ufeedback = np.unique(b.index_ufeedback)
@@ -182,6 +182,7 @@ def main(argv=None):
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--wide", action="store_true", help="factor widths 257..1024 (general kernels, several registers per lane)")
+    ap.add_argument("--big", action="store_true", help="up to 3000 users / 800 items / 40 K instances per data set")
     ap.add_argument("--only", type=int, default=-1, help="run only this iteration (the generator is advanced up to it)")
     ap.add_argument("--reference", action="store_true", help="compare the oracle port with the compiled reference instead of the GPU")
     ap.add_argument("--trace", default="", help="file that always holds the configuration being run (to locate a crash)")
@@ -190,7 +191,7 @@ def main(argv=None):
     stats = dict(iters=0, exact=0, tolerance=0, skipped=0)
     for it in range(a.iters):
         with tempfile.TemporaryDirectory() as tmp:
-            fmt, active, conf, data, plan = draw(rng, tmp, a.wide)
+            fmt, active, conf, data, plan = draw(rng, tmp, a.wide, a.big)
             if a.only >= 0 and it != a.only:
                 continue
             if a.trace:
