@@ -7,8 +7,8 @@
  * :484-592).  The reference has no FFI layer of its own -- solvers are swapped at link time by
  * providing `apex_svd::create_svd_trainer` (apex_svd.h:212, solvers/base-solver/Makefile:17-23) --
  * so every entry point below is one ISVDTrainer virtual flattened to C: plain pointers and
- * sizes, no C++ or torch types.  `svdfeature_amd/csrc/apex_svd_shim.{h,cpp}` is the C++ class
- * with the reference's vtable order that forwards to these functions (INTEGRATION.md shows the
+ * sizes, no C++ or torch types.  `integration/apex_svd_amd.cpp` is the C++ class deriving
+ * from the reference's own ISVDTrainer that forwards to these functions (INTEGRATION.md shows the
  * reference-side link line).
  *
  * Error behaviour follows the reference (apex-utils/apex_utils.h:47-58: message on stderr, then
@@ -198,6 +198,11 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  * The relaxed mode itself is switched by CONFIG keys through svdf_set_param ("amd:relax_global",
  * "amd:relax_user_from", "amd:relax_item_from", "amd:relax_feedback"), not by knobs: it changes results. */
 int svdf_set_knob(svdf_trainer *t, const char *name, long value);
+
+/* ---- probe of the device-side expf used by the sigmoid links (active_type::map_active / cal_grad call libm's expf,
+ * apex_svd_model.h:112-156): out[j] = expf evaluated ON THE GPU for in[j], or, with in == NULL, for the float whose bit
+ * pattern is first_bits + j*step_bits.  Tests compare it with the host libm bit for bit.  Needs a GPU. */
+int svdf_device_expf(const float *in, unsigned first_bits, unsigned step_bits, float *out, long n);
 
 /* ---- host-side conflict-free batch scheduler, exposed so it can be tested without a GPU.
  * Unit r touches resources res[res_ptr[r] .. res_ptr[r+1]) out of num_res.  Writes the batch-sorted

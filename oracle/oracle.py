@@ -67,8 +67,22 @@ def _load(kind):
     lib.svdo_set_view.argtypes = [P, C.c_int, _f32p, C.c_long]
     lib.svdo_set_view.restype = C.c_long
     lib.svdo_kind.restype = C.c_int
+    lib.svdo_libm_expf.argtypes = [C.c_void_p, C.c_uint, C.c_uint, _f32p, C.c_long]
     _libs[kind] = lib
     return lib
+
+
+def libm_expf(x=None, first=0, step=1, n=None):
+    """expf of the host libm (the reference's link functions call it) over an array, or over bit patterns first + j*step."""
+    lib = _load("port")
+    if x is not None:
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty(len(x), np.float32)
+        lib.svdo_libm_expf(x.ctypes.data_as(C.c_void_p), 0, 0, out, len(x))
+        return out
+    out = np.empty(n, np.float32)
+    lib.svdo_libm_expf(None, first, step, out, n)
+    return out
 
 
 def _pad(a, dtype):

@@ -34,6 +34,15 @@ struct svdo_trainer {
 extern "C" {
 
 int svdo_kind(void) { return 2; }
+void svdo_libm_expf(const float *in, unsigned first, unsigned step, float *out, long n) {
+    for (long j = 0; j < n; j++) {
+        float x;
+        if (in) x = in[j];
+        else { unsigned u = first + (unsigned)j * step; memcpy(&x, &u, 4); }
+        out[j] = expf(x);
+    }
+}
+
 
 svdo_trainer *svdo_create(int format_type, int active_type, int extend_type, int variant_type) {
     svdo_trainer *t = new svdo_trainer();

@@ -4,7 +4,7 @@
  * TEST INFRASTRUCTURE, NOT PRODUCT.  Loaded only by tests/, __graft_entry__.smoke() and
  * bench.py's cpu_baseline leg (kind "port").  The product path never links or calls this file.
  *
- * Parity status: PINNED.  tests/test_oracle_vs_reference.py compares this file, byte for byte on
+ * Parity status: PINNED.  tests/test_oracle.py compares this file, byte for byte on
  * model files and bit for bit on predictions, against the compiled reference
  * (oracle/_ref/libsvdf_ref.so, built by oracle/Makefile from /root/reference) and against the
  * golden vectors under tests/golden/ that were generated from that compiled reference.
@@ -89,6 +89,15 @@ static void die(const char *msg) { /* apex-utils/apex_utils.h:47-50 */
 static void assert_true(int ok, const char *msg) { if (!ok) die(msg); }
 
 int svdo_kind(void) { return 1; }
+void svdo_libm_expf(const float *in, unsigned first, unsigned step, float *out, long n) {
+    for (long j = 0; j < n; j++) {
+        float x;
+        if (in) x = in[j];
+        else { unsigned u = first + (unsigned)j * step; memcpy(&x, &u, 4); }
+        out[j] = expf(x);
+    }
+}
+
 
 /* ================= tensor micro-ops ================= */
 

@@ -73,6 +73,9 @@ void svdo_view_shape(svdo_trainer *t, int which, int *rows, int *cols);
 long svdo_set_view(svdo_trainer *t, int which, const float *in, long count);
 /* 1 for the plain-C restatement, 2 for the compiled reference */
 int svdo_kind(void);
+/* the host libm's expf (what active_type::map_active / cal_grad call, apex_svd_model.h:112-156) over an array, or with
+ * in == NULL over the floats with bit patterns first + j*step: checker for the device's expf restatement */
+void svdo_libm_expf(const float *in, unsigned first, unsigned step, float *out, long n);
 
 #ifdef __cplusplus
 }

@@ -111,6 +111,7 @@ def load_library():
     lib.svdf_counter.argtypes = [P, C.c_int]
     lib.svdf_set_knob.argtypes = [P, C.c_char_p, C.c_long]
     lib.svdf_schedule_resources.argtypes = [C.c_long, _i64p, _u32p, C.c_long, _i32p, _i64p, C.c_long]
+    lib.svdf_device_expf.argtypes = [C.c_void_p, C.c_uint, C.c_uint, _f32p, C.c_long]
     lib.svdf_set_error_mode(1)   # python callers get exceptions instead of exit(-1)
     _lib = lib
     return lib
@@ -118,6 +119,22 @@ def load_library():
 
 def device_count():
     return load_library().svdf_device_count()
+
+
+def device_expf(x=None, first=0, step=1, n=None):
+    """The expf the sigmoid links use ON THE GPU (svdf_device.h: glibc_expf), over an array or over the floats with bit
+    patterns first + j*step; tests compare it with the host libm bit for bit."""
+    lib = load_library()
+    if x is not None:
+        x = np.ascontiguousarray(x, np.float32)
+        out = np.empty(len(x), np.float32)
+        rc = lib.svdf_device_expf(x.ctypes.data_as(C.c_void_p), 0, 0, out, len(x))
+    else:
+        out = np.empty(n, np.float32)
+        rc = lib.svdf_device_expf(None, first, step, out, n)
+    if rc != 0:
+        raise SvdfError("svdf_device_expf failed")
+    return out
 
 
 def _pad(a, dtype):

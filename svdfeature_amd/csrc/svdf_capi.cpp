@@ -175,6 +175,10 @@ int svdf_synchronize(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->synchronize(); re
 int64_t svdf_counter(svdf_trainer *t, int what) { return t->e->counter(what); }
 int svdf_set_knob(svdf_trainer *t, const char *name, long value) { SVDF_GUARD(-1, { return t->e->set_knob(name, value); }) }
 
+int svdf_device_expf(const float *in, unsigned first_bits, unsigned step_bits, float *out, long n) {
+    SVDF_GUARD(-1, { return svdf::device_expf(in, first_bits, step_bits, out, n); })
+}
+
 // host-side scheduler exposed for CPU tests (tests/test_scheduler.py): levels for a CSR stream over
 // `num_res` resources where instance r touches resources res[res_ptr[r]..res_ptr[r+1]).
 int svdf_schedule_resources(long n, const int64_t *res_ptr, const unsigned *res, long num_res, int *order_out,

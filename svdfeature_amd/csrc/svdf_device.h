@@ -21,8 +21,8 @@
 //    to cover HBM latency without relying on occupancy alone.
 //
 // Arithmetic contract: fp32, unfused (-ffp-contract=off and the pragma below), correctly rounded
-// divide/sqrt, fp64 bias/score accumulation.  Only expf (sigmoid links) differs from glibc by
-// ulps; everything else is bit-exact against oracle/svdf_oracle.c.
+// divide/sqrt, fp64 bias/score accumulation, glibc's expf restated (glibc_expf below): every configuration is
+// bit-exact against oracle/svdf_oracle.c.
 #ifndef SVDF_DEVICE_H_
 #define SVDF_DEVICE_H_
 // Device-side helpers shared by the kernel translation units (svdf_k_*.hip): arithmetic in the reference's order, the
@@ -226,9 +226,79 @@ __device__ __forceinline__ float group_dot(const WideRow<V> &a, const WideRow<V>
     return sum;
 }
 
+// glibc's expf restated for the device (sysdeps/ieee754/flt-32/e_expf.c of glibc >= 2.27, the libm the reference links
+// against; glibc is a system library, not part of the reference tree): x*32/ln2 = k + r, exp(x) = 2^(k/32) * p(r) with a
+// 32-entry table of 2^(i/32) and a cubic in fp64, result rounded to fp32 once.  On x86-64 hosts with FMA the dynamic
+// linker selects the build of that file in which the range reduction r = x*InvLn2N - k is ONE fused operation (the other
+// steps stay unfused): restated like that, this function returns the host libm's result for every one of the 2^32 float
+// inputs (tools/check_expf.c compares them all on the CPU: 0 mismatches); the unfused build differs on exactly two
+// inputs (0x4202422f, 0xc27c65d9).  The table entries are 2^(i/32) correctly rounded to fp64 minus (i << 47).
+static __constant__ unsigned long long kExp2fTab[32] = {
+0x3ff0000000000000ULL,
+0x3fefd9b0d3158574ULL,
+0x3fefb5586cf9890fULL,
+0x3fef9301d0125b51ULL,
+0x3fef72b83c7d517bULL,
+0x3fef54873168b9aaULL,
+0x3fef387a6e756238ULL,
+0x3fef1e9df51fdee1ULL,
+0x3fef06fe0a31b715ULL,
+0x3feef1a7373aa9cbULL,
+0x3feedea64c123422ULL,
+0x3feece086061892dULL,
+0x3feebfdad5362a27ULL,
+0x3feeb42b569d4f82ULL,
+0x3feeab07dd485429ULL,
+0x3feea47eb03a5585ULL,
+0x3feea09e667f3bcdULL,
+0x3fee9f75e8ec5f74ULL,
+0x3feea11473eb0187ULL,
+0x3feea589994cce13ULL,
+0x3feeace5422aa0dbULL,
+0x3feeb737b0cdc5e5ULL,
+0x3feec49182a3f090ULL,
+0x3feed503b23e255dULL,
+0x3feee89f995ad3adULL,
+0x3feeff76f2fb5e47ULL,
+0x3fef199bdd85529cULL,
+0x3fef3720dcef9069ULL,
+0x3fef5818dcfba487ULL,
+0x3fef7c97337b9b5fULL,
+0x3fefa4afa2a490daULL,
+0x3fefd0765b6e4540ULL
+
+};
+__device__ __forceinline__ float glibc_expf(float x) {
+    const unsigned ux = __float_as_uint(x);
+    const unsigned abstop = (ux >> 20) & 0x7ffu;
+    if (abstop >= 0x42bu) {                             // |x| >= 88 or NaN
+        if (ux == 0xff800000u) return 0.0f;             // -inf
+        if (abstop >= 0x7f8u) return x + x;             // +inf, NaN
+        if (x > 0x1.62e42ep6f) return __uint_as_float(0x7f800000u);   // overflow
+        if (x < -0x1.9fe368p6f) return 0.0f;            // underflow
+    }
+    const double xd = (double)x;
+    const double inv_ln2_n = 0x1.71547652b82fep+5;      // 32 / ln 2
+    const double shift = 0x1.8p+52;
+    const double z = inv_ln2_n * xd;
+    double kd = z + shift;
+    const unsigned long long ki = (unsigned long long)__double_as_longlong(kd);
+    kd = kd - shift;
+    const double r = __fma_rn(inv_ln2_n, xd, -kd);
+    unsigned long long t = kExp2fTab[ki & 31];
+    t += ki << 47;
+    const double s = __longlong_as_double((long long)t);
+    const double zz = 0x1.c6af84b912394p-20 * r + 0x1.ebfce50fac4f3p-13;
+    const double r2 = r * r;
+    double y = 0x1.62e42ff0c52d6p-6 * r + 1.0;
+    y = zz * r2 + y;
+    y = y * s;
+    return (float)y;
+}
+
 // apex_svd_model.h:112-123
 __device__ __forceinline__ float map_active(float sum, int type) {
-    if (type == ACT_SIGMOID_L2 || type == ACT_SIGMOID_LIKELIHOOD) return 1.0f / (1.0f + expf(-sum));
+    if (type == ACT_SIGMOID_L2 || type == ACT_SIGMOID_LIKELIHOOD) return 1.0f / (1.0f + glibc_expf(-sum));
     return sum;
 }
 __device__ __forceinline__ float smooth_hinge_grad(float z) {
@@ -243,7 +313,7 @@ __device__ __forceinline__ float cal_grad(float r, float pred, int type) {
     case ACT_SIGMOID_L2: return (r - pred) * pred * (1 - pred);
     case ACT_SIGMOID_LIKELIHOOD: return r - pred;
     case ACT_SIGMOID_QSGRAD:
-    case ACT_SIGMOID_RANK: return r - 1.0f / (1.0f + expf(-pred));
+    case ACT_SIGMOID_RANK: return r - 1.0f / (1.0f + glibc_expf(-pred));
     case ACT_HINGE_SMOOTH:
         if (r > 0.5f) return smooth_hinge_grad(pred - 0.5f);
         return -smooth_hinge_grad(0.5f - pred);
@@ -282,7 +352,7 @@ __device__ __forceinline__ void reg_row(const DevParams &P, R &w, float wd, bool
         float sum = group_dot<LPI>(w, w, L, P.k);
         if (sum > wd) scale4(w, sqrtf(wd / sum));
     } else if (method == 4) {  // lazy L2
-        scale4(w, expf(logf(1.0f - lambda) * kk));
+        scale4(w, glibc_expf(logf(1.0f - lambda) * kk));
     } else if (method == 5) {  // lazy L1
         l1_row(w, lambda * kk);
     }
@@ -296,7 +366,7 @@ __device__ __forceinline__ float reg_gbias(const DevParams &P, unsigned gid, flo
         else {  // 4 lazy L2, 5 lazy L1 (:194-205); regfree ids keep their ref untouched like the reference
             const float kk = (float)(unsigned)(P.ref_global[gid] - counter);
             P.ref_global[gid] = counter;
-            if (P.reg_global == 4) g = g * expf(logf(1.0f - lambda) * kk);
+            if (P.reg_global == 4) g = g * glibc_expf(logf(1.0f - lambda) * kk);
             else g = l1(g, lambda * kk);
         }
     }

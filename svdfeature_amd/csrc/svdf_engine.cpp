@@ -565,11 +565,20 @@ void Engine::check_row(int ng, int nu, int ni, const unsigned *index) {  // asse
     for (int j = 0; j < ni; j++) check(index[ng + nu + j] < (unsigned)mp_.num_item, "item feature index exceed bound");
 }
 void Engine::stage_rows(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value) {
+    stage_rows_into(staged_, num_row, row_label, row_ptr, feat_index, feat_value);
+}
+// All rows are validated before the first one is appended: a failing row (error mode 1 throws) leaves `dst` untouched.
+void Engine::stage_rows_into(HostCSR &staged_, int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index,
+                             const float *feat_value) {
     for (int r = 0; r < num_row; r++) {
         const int p0 = row_ptr[3 * r], p1 = row_ptr[3 * r + 1], p2 = row_ptr[3 * r + 2], p3 = row_ptr[3 * r + 3];
         check(p0 <= p1 && p1 <= p2 && p2 <= p3, "CSR row_ptr must be non-decreasing");
         check_row(p1 - p0, p2 - p1, p3 - p2, feat_index + p0);
-        check((long)staged_.row_ptr.back() + (long)(p3 - p0) < 2147483647L, "svdfeature_amd: more than 2^31-1 feature entries in one window");
+    }
+    if (num_row > 0)
+        check((long)staged_.row_ptr.back() + (long)(row_ptr[3 * num_row] - row_ptr[0]) < 2147483647L, "svdfeature_amd: more than 2^31-1 feature entries in one window");
+    for (int r = 0; r < num_row; r++) {
+        const int p0 = row_ptr[3 * r], p1 = row_ptr[3 * r + 1], p2 = row_ptr[3 * r + 2], p3 = row_ptr[3 * r + 3];
         const int base = staged_.row_ptr.back() - p0;
         staged_.row_label.push_back(row_label[r]);
         staged_.row_ptr.push_back(p1 + base);
@@ -626,9 +635,19 @@ void Engine::update_block(int nfb, int tag, const unsigned *ifb, const float *vf
     check(user_group(), "not implemented");   // SVDFeature has no update(SVDPlusBlock) (apex_svd.h:97)
     for (int j = 0; j < nfb; j++) check(ifb[j] < (unsigned)mp_.num_ufeedback, "ufeedback id exceed bound");
     const int h = (int)staged_.num_row();
-    stage_rows(num_row, row_label, row_ptr, feat_index, feat_value);
     const bool starts = (tag == TAG_DEFAULT || tag == TAG_START);
     const bool ends = (tag == TAG_DEFAULT || tag == TAG_END);
+    const bool continues = !starts && !staged_units_.empty() && unit_open_ && !unit_open_on_device_ && staged_units_.back().row_end == h &&
+                           !(staged_units_.back().flags & UNIT_END);
+    if (continues && tag == TAG_END && (staged_units_.back().flags & UNIT_START)) {
+        // START and END merged in one flush: the scatter list must equal the prepare list (checked before anything is staged)
+        const HostUnit &su = staged_units_.back();
+        bool same = (su.fb_end - su.fb_begin) == nfb;
+        for (int j = 0; same && j < nfb; j++)
+            same = staged_fb_index_[(size_t)su.fb_begin + j] == ifb[j] && staged_fb_value_[(size_t)su.fb_begin + j] == vfb[j];
+        check(same, "svdfeature_amd: START and END blocks of one user must carry the same feedback list");
+    }
+    stage_rows(num_row, row_label, row_ptr, feat_index, feat_value);
     auto push_fb = [&](int &b, int &e) {
         b = (int)staged_fb_index_.size();
         staged_fb_index_.insert(staged_fb_index_.end(), ifb, ifb + nfb);
@@ -637,8 +656,7 @@ void Engine::update_block(int nfb, int tag, const unsigned *ifb, const float *vf
     };
     HostUnit *u = nullptr;
     // a MIDDLE/END block continues the unit staged just before it, if that unit is still open here
-    if (!starts && !staged_units_.empty() && unit_open_ && !unit_open_on_device_ && staged_units_.back().row_end == h &&
-        !(staged_units_.back().flags & UNIT_END)) {
+    if (continues) {
         u = &staged_units_.back();
         u->row_end = h + num_row;
     } else {
@@ -653,13 +671,6 @@ void Engine::update_block(int nfb, int tag, const unsigned *ifb, const float *vf
         // It is kept next to the prepare list: [fb_begin,fb_end) prepare, the scatter list is appended and
         // recorded by re-pointing fb_* when the unit did not start here.
         if (!(u->flags & UNIT_START)) push_fb(u->fb_begin, u->fb_end);
-        else if (tag == TAG_END) {
-            // START and END merged in one flush: the scatter list must equal the prepare list
-            bool same = (u->fb_end - u->fb_begin) == nfb;
-            for (int j = 0; same && j < nfb; j++)
-                same = staged_fb_index_[(size_t)u->fb_begin + j] == ifb[j] && staged_fb_value_[(size_t)u->fb_begin + j] == vfb[j];
-            check(same, "svdfeature_amd: START and END blocks of one user must carry the same feedback list");
-        }
         u->flags |= UNIT_END;
         unit_open_ = false;
         unit_open_on_device_ = false;
@@ -994,7 +1005,11 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
     int *last = tracker_.last.data();
     const unsigned *idx = staged_.feat_index.data();
     const bool simple_ok = feat_user_.num_row() == 0 && feat_item_.num_row() == 0 && mp_.common_latent_space == 0 && mp_.common_feedback_space == 0;
+    // per-call epoch: the stamp of unit t is stamp_epoch_ + t, so marks left by an earlier call (unit indices restart at 0
+    // on every flush / dataset build) can never look like "seen in this unit"
     if (simple_ok && stamp_.size() < (size_t)n_uiset_) stamp_.assign((size_t)n_uiset_, -1);
+    const int64_t epoch = stamp_epoch_;
+    stamp_epoch_ += nu;
     if (relaxed())
         check((relax_item_from_ == 0u || relax_item_from_ == 0xFFFFFFFFu) && relax_user_from_ == 0xFFFFFFFFu,
               "svdfeature_amd: on user-group data the relaxed mode is amd:relax_item_from = 0 (all item rows) and / or amd:relax_feedback = 1");
@@ -1015,8 +1030,8 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
                 if (simple) {
                     if (val[p[1]] != 1.0f || val[p[2]] != 1.0f) simple_unit_values_ = false;
                     const unsigned row = item_off_ + idx[p[2]];
-                    if (stamp_[row] == (int)t) { staged_fresh_[(size_t)r] = 1; any_fresh_ = true; }   // the same item again: read at use
-                    stamp_[row] = (int)t;
+                    if (stamp_[row] == epoch + t) { staged_fresh_[(size_t)r] = 1; any_fresh_ = true; }   // the same item again: read at use
+                    stamp_[row] = epoch + t;
                 }
             }
         }
@@ -1024,8 +1039,8 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
             const unsigned row = fb_off_ + staged_fb_index_[(size_t)j];
             if (!relax_feedback_) lvl = std::max(lvl, last[row]);
             if (simple) {
-                if (stamp_[row] == (int)t) simple = false;       // a feedback id listed twice
-                stamp_[row] = (int)t;
+                if (stamp_[row] == epoch + t) simple = false;       // a feedback id listed twice
+                stamp_[row] = epoch + t;
             }
         }
         if (u.flags & (UNIT_LOAD | UNIT_SAVE)) lvl = std::max(lvl, last[state_res]);
@@ -1176,11 +1191,9 @@ void Engine::predict_csr_batch(int num_row, const float *row_label, const int *r
     }
     flush();
     const DevParams &P = params();
-    HostCSR tmp;
+    HostCSR tmp;   // prediction rows never enter the training stage
     tmp.row_label.reserve((size_t)num_row);
-    std::swap(tmp, staged_);
-    stage_rows(num_row, row_label, row_ptr, feat_index, feat_value);
-    std::swap(tmp, staged_);
+    stage_rows_into(tmp, num_row, row_label, row_ptr, feat_index, feat_value);
     w_label_.upload(tmp.row_label.data(), tmp.row_label.size(), stream_);
     w_ptr_.upload(tmp.row_ptr.data(), tmp.row_ptr.size(), stream_);
     w_index_.upload(tmp.feat_index.data(), tmp.feat_index.size(), stream_);
@@ -1200,10 +1213,8 @@ void Engine::predict_block(int nfb, int tag, const unsigned *ifb, const float *v
     for (int j = 0; j < nfb; j++) check(ifb[j] < (unsigned)mp_.num_ufeedback, "ufeedback id exceed bound");
     flush();
     const DevParams &P = params();
-    HostCSR tmp;
-    std::swap(tmp, staged_);
-    stage_rows(num_row, row_label, row_ptr, feat_index, feat_value);
-    std::swap(tmp, staged_);
+    HostCSR tmp;   // prediction rows never enter the training stage
+    stage_rows_into(tmp, num_row, row_label, row_ptr, feat_index, feat_value);
     const bool starts = (tag == TAG_DEFAULT || tag == TAG_START);
     DevUnit u{0, starts ? nfb : 0, 0, num_row, (starts ? UNIT_START : UNIT_LOAD) | UNIT_SAVE};
     w_label_.upload(tmp.row_label.data(), tmp.row_label.size(), stream_);
@@ -1377,7 +1388,18 @@ Dataset::~Dataset() {
 }
 // A dataset outliving its trainer must not reach into it: the trainer forgets its datasets when it goes (their device
 // buffers stay valid and are freed by the dataset itself).
-void Engine::adopt(Dataset *ds) { ds->owner = this; datasets_.push_back(ds); }
+void Engine::adopt(Dataset *ds) { ds->owner = this; ds->sched_signature = schedule_signature(); datasets_.push_back(ds); }
+// Everything a dataset's conflict schedule and kernel routing were computed under: a dataset built under one setting must
+// not be launched under another (e.g. scheduled with relaxed globals, then run with plain read-modify-writes).
+uint64_t Engine::schedule_signature() const {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](uint64_t v) { h = (h ^ v) * 1099511628211ull; };
+    mix(relax_global_); mix(relax_feedback_); mix(relax_user_from_); mix(relax_item_from_);
+    mix(feat_user_.num_row()); mix(feat_user_.index.size()); mix(feat_item_.num_row()); mix(feat_item_.index.size());
+    mix(user_group()); mix(lazy_decay()); mix((uint64_t)mp_.num_factor); mix(use_fused_); mix(use_simple_units_);
+    mix((uint64_t)mtype_.extend_type);
+    return h;
+}
 void Engine::disown(Dataset *ds) {
     for (size_t i = 0; i < datasets_.size(); i++)
         if (datasets_[i] == ds) { datasets_[i] = datasets_.back(); datasets_.pop_back(); break; }
@@ -1385,6 +1407,8 @@ void Engine::disown(Dataset *ds) {
 
 void Engine::train_dataset(Dataset *ds) {
     check(ds && ds->owner == this, "train_dataset: dataset belongs to another trainer");
+    check(ds->sched_signature == schedule_signature(),
+          "train_dataset: the dataset was scheduled under another configuration (relaxed-id keys, side tables, lazy decay or kernel-routing knobs changed since it was built); build it again");
     flush();
     const DevParams &P = params();
     const Schedule &sc = ds->sched;
@@ -1439,6 +1463,8 @@ void Engine::train_dataset(Dataset *ds) {
 
 void Engine::predict_dataset(Dataset *ds, float *out) {
     check(ds && ds->owner == this, "predict_dataset: dataset belongs to another trainer");
+    check(ds->sched_signature == schedule_signature(),
+          "predict_dataset: the dataset was scheduled under another configuration; build it again");
     flush();
     const DevParams &P = params();
     const long n = ds->num_row;

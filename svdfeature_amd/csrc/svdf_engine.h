@@ -164,6 +164,7 @@ struct Dataset {
     DevBuf<unsigned> feat_index;
     long algorithmic_bytes = 0;
     long num_units = 0, num_simple_units = 0;
+    uint64_t sched_signature = 0;  // Engine::schedule_signature() at build time
     // captured launch sequence of one pass (Engine::train_dataset)
     hipGraphExec_t graph_exec = nullptr;
     uint64_t graph_version = 0;
@@ -298,6 +299,7 @@ class Engine {
     RankPrefetch *rank_prefetch_ = nullptr;
     std::vector<Dataset *> datasets_;     // live datasets of this trainer (Dataset::owner back-pointers)
     void adopt(Dataset *ds);
+    uint64_t schedule_signature() const;
     void disown(Dataset *ds);
     void rank_pass(const char *path, UserGroupArrays &g);
     bool rows_without_feedback_ = true;   // knob: block datasets without any feedback id are scheduled row by row
@@ -310,6 +312,7 @@ class Engine {
     int groups_per_wave_ = 0, block_threads_ = 0, store_mode_ = 0, sort_batches_ = 1, xcd_remap_ = 1, hot_reduce_ = 1;   // 0 = tuned per factor width
     LevelTracker tracker_;
     void stage_rows(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value);
+    void stage_rows_into(HostCSR &dst, int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value);
     void check_row(int ng, int nu, int ni, const unsigned *index);
     bool basic_fast_path_allowed() const;
     bool fused_allowed() const;
@@ -338,7 +341,8 @@ class Engine {
     // levels + DevUnit records for the staged units (marks UNIT_SIMPLE); returns the schedule
     void schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du);
     void upload_units(UnitDev &dst, const Schedule &sched, const std::vector<DevUnit> &du);
-    std::vector<int> stamp_;   // scratch for per-unit distinctness checks
+    std::vector<int64_t> stamp_;   // scratch for per-unit distinctness checks: stamp_epoch_ + unit index of the last toucher
+    int64_t stamp_epoch_ = 0;
     // reusable device staging buffers
     DevBuf<float> w_label_, w_value_, w_uval_, w_ival_, w_fbval_, w_out_;
     DevBuf<int> w_ptr_, w_order_;

@@ -82,5 +82,35 @@ void launch_delta_add(float *cur, const float *snap, const float *delta, long n,
     hipLaunchKernelGGL(k_delta_add, dim3((int)grid), dim3(256), 0, st, cur, snap, delta, n);
 }
 
+// ---- probe of the device expf (tests: compared with the host libm's expf bit for bit) ------------------
+__global__ __launch_bounds__(256) void k_expf_probe(const float *in, float *out, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) out[j] = glibc_expf(in[j]);
+}
+// out[j] = glibc_expf(first + j * step) over float BIT PATTERNS (sweeps of the whole input space without host arrays)
+__global__ __launch_bounds__(256) void k_expf_sweep(unsigned first, unsigned step, float *out, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride)
+        out[j] = glibc_expf(__uint_as_float(first + (unsigned)j * step));
+}
+int device_expf(const float *in, unsigned first, unsigned step, float *out, long n) {
+    if (n <= 0) return 0;
+    float *din = nullptr, *dout = nullptr;
+    if (hipMalloc((void **)&dout, (size_t)n * sizeof(float)) != hipSuccess) return -1;
+    int rc = 0;
+    long grid = (n + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (in) {
+        if (hipMalloc((void **)&din, (size_t)n * sizeof(float)) != hipSuccess) { (void)hipFree(dout); return -1; }
+        if (hipMemcpy(din, in, (size_t)n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) rc = -1;
+        hipLaunchKernelGGL(k_expf_probe, dim3((int)grid), dim3(256), 0, nullptr, din, dout, n);
+    } else {
+        hipLaunchKernelGGL(k_expf_sweep, dim3((int)grid), dim3(256), 0, nullptr, first, step, dout, n);
+    }
+    if (hipMemcpy(out, dout, (size_t)n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+    if (din) (void)hipFree(din);
+    (void)hipFree(dout);
+    return rc;
+}
 
 }  // namespace svdf

@@ -39,6 +39,8 @@ void launch_delta_pack(const DeltaRanges &R, const float *snap, void *dst, int h
 void launch_delta_unpack(const DeltaRanges &R, float *snap, const void *src, int half, int refresh, hipStream_t st);
 void launch_delta_sub(const float *cur, const float *snap, float *delta, long n, hipStream_t st);
 void launch_delta_add(float *cur, const float *snap, const float *delta, long n, hipStream_t st);
+// test probe: out[j] = device expf of in[j], or (in == nullptr) of the float with bit pattern first + j*step
+int device_expf(const float *in, unsigned first, unsigned step, float *out, long n);
 
 }  // namespace svdf
 #endif

@@ -2,8 +2,8 @@
 """Randomised differential run of the HIP engine against the C oracle (tests/ because it drives the oracle; not collected
 by pytest).  Every iteration draws a configuration -- format, link, regulariser, decay modes, per-range decay, factor
 width, flags, shared parameter spaces, side tables, staging window / chunking, resident data set or staged calls -- and
-seeded data, trains both engines the same way and compares every parameter and the predictions bit for bit (sigmoid links:
-the rtol/atol of test_gpu_parity.py).  Prints one JSON line; exits non-zero on the first mismatch with the configuration.
+seeded data, trains both engines the same way and compares every parameter and the predictions bit for bit (sigmoid links
+included).  Prints one JSON line; exits non-zero on the first mismatch with the configuration.
 
     python tests/fuzz_parity.py --iters 300 --seed 1
 """
@@ -214,7 +214,7 @@ def main(argv=None):
                 except sa.SvdfError as e:
                     print("iteration %d: engine refused what the oracle ran: %s\n%s %s" % (it, e, conf, plan), file=sys.stderr)
                     sys.exit(1)
-            tol = active in EXPF
+            tol = False   # the device restates glibc's expf (svdf_device.h: glibc_expf): sigmoid links compare with == too
             for v in VIEWS:
                 if ov[v] is None or hv[v] is None:
                     continue

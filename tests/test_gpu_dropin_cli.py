@@ -71,8 +71,8 @@ def test_cli_implicit_feedback_user_groups(tmp_path):
 def test_cli_pairwise_rank_generator(tmp_path):
     """demo/pairwiseRank: input_type=2 wraps the buffer in the reference's PairwiseRankGenerator (host, libc
     rand()) and trains with active_type=3.  The AMD trainer consumes rand() exactly like the reference's
-    rand_init, so the sampled pairs are the same; the sigmoid uses expf, so parameters are compared with
-    the tolerance of tests/test_gpu_parity.py instead of bytes."""
+    rand_init, so the sampled pairs are the same; the sigmoid goes through the device restatement of glibc's expf, so the
+    model files are byte-identical like everywhere else."""
     blocks = cases.user_blocks(200, 943, 1682, 1682, 8, max_rows=10, max_fb=4, binary_label=True)
     for b in blocks:   # the demo's feedback file carries no implicit feedback
         b.index_ufeedback = np.zeros(0, np.uint32)
@@ -81,5 +81,4 @@ def test_cli_pairwise_rank_generator(tmp_path):
                                                active_type=3, no_user_bias=1, input_type=2, num_factor=16) if k != "base_score"]
     ref, amd = _run_both(tmp_path, conf, lambda p: D.write_ugroup_buffer(p, blocks), 3)
     for a, b in zip(ref, amd):
-        assert len(a) == len(b) and a[:4 + 1056] == b[:4 + 1056]
-        np.testing.assert_allclose(np.frombuffer(a[4 + 1056:], np.float32), np.frombuffer(b[4 + 1056:], np.float32), rtol=2e-5, atol=2e-6)
+        assert a == b
