@@ -106,6 +106,12 @@ svdf_dataset *svdf_dataset_from_csr(svdf_trainer *t, long num_row, const float *
                                     const unsigned *feat_index, const float *feat_value);
 svdf_dataset *svdf_dataset_from_triples(svdf_trainer *t, long n, const unsigned *user, const unsigned *item,
                                         const float *label);
+/* rank pairs (user, positive item, negative item) in three columns: the instance PairwiseRankGenerator emits for two rows
+ * with one unit item entry each (apex_svd_data.cpp:828-860 merge by index with the negative's sign flipped, :905-911
+ * label 1): no global entry, user:1, {min(pos,neg): +-1, max(pos,neg): -+1}.  svdf_train_dataset == update(x) for
+ * every such instance in order.  pos_item[r] != neg_item[r]. */
+svdf_dataset *svdf_dataset_from_pairs(svdf_trainer *t, long n, const unsigned *user, const unsigned *pos_item,
+                                      const unsigned *neg_item);
 /* user-group form: equivalent to update(SVDPlusBlock b) for b = 0..num_block-1 in order (the content of a
  * user-group buffer file, apex_svd_data.cpp:558-595).  Block b has extend_tag[b], feedback entries
  * fb_index/fb_value[fb_ptr[b] .. fb_ptr[b+1]) and rows block_row_ptr[b] .. block_row_ptr[b+1] of the CSR
@@ -177,6 +183,9 @@ int svdf_item_delta_unpack(svdf_trainer *t, const void *device_src, int half, in
  * 6 W_ufeedback; rows are returned unpadded.  Returns number of floats or -1. */
 int64_t svdf_get_view(svdf_trainer *t, int which, float *out, int64_t capacity);
 int svdf_view_shape(svdf_trainer *t, int which, int *rows, int *cols);
+/* overwrite a view from rows*cols unpadded floats (multi-GPU: every rank owns a slice of the user rows, the slices are
+ * gathered before a model is saved).  Returns the number of floats or -1. */
+int64_t svdf_set_view(svdf_trainer *t, int which, const float *in, int64_t count);
 /* the HIP stream (hipStream_t) all of this trainer's work is enqueued on; timing code records
  * HIP events on it. */
 void *svdf_stream(svdf_trainer *t);

@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from .data import CSRData, PlusBlock  # noqa: F401
+from .data import BlockArrays, CSRData, PlusBlock, pairs_as_csr  # noqa: F401
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libsvdfeature_amd.so")
@@ -78,6 +78,10 @@ def load_library():
     lib.svdf_dataset_from_csr.argtypes = [P, C.c_long, _f32p, _i64p, _u32p, _f32p]
     lib.svdf_dataset_from_triples.restype = P
     lib.svdf_dataset_from_triples.argtypes = [P, C.c_long, _u32p, _u32p, _f32p]
+    lib.svdf_dataset_from_pairs.restype = P
+    lib.svdf_dataset_from_pairs.argtypes = [P, C.c_long, _u32p, _u32p, _u32p]
+    lib.svdf_set_view.restype = C.c_int64
+    lib.svdf_set_view.argtypes = [P, C.c_int, _f32p, C.c_int64]
     lib.svdf_dataset_from_buffer_file.restype = P
     lib.svdf_dataset_from_buffer_file.argtypes = [P, C.c_char_p, C.c_int]
     lib.svdf_dataset_from_rank_buffer_file.restype = P
@@ -302,20 +306,19 @@ class Trainer:
             raise SvdfError(self.lib.svdf_last_error().decode())
         return Dataset(self, h)
 
+    def dataset_from_pairs(self, user, pos, neg):
+        """Rank pairs (user, positive item, negative item), see svdf_dataset_from_pairs."""
+        h = self.lib.svdf_dataset_from_pairs(self.h, len(user), _pad(user, np.uint32), _pad(pos, np.uint32), _pad(neg, np.uint32))
+        if not h:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return Dataset(self, h)
+
     def dataset_from_blocks(self, blocks):
-        """blocks: list of PlusBlock in file order (one pass of a user-group buffer)."""
-        tags = np.array([b.extend_tag for b in blocks], np.int32)
-        fb_ptr = np.zeros(len(blocks) + 1, np.int64)
-        brp = np.zeros(len(blocks) + 1, np.int64)
-        for j, b in enumerate(blocks):
-            fb_ptr[j + 1] = fb_ptr[j] + b.num_ufeedback
-            brp[j + 1] = brp[j] + b.data.num_row
-        cat = CSRData.concat([b.data for b in blocks])
-        fbi = np.concatenate([b.index_ufeedback for b in blocks]) if blocks else np.zeros(0, np.uint32)
-        fbv = np.concatenate([b.value_ufeedback for b in blocks]) if blocks else np.zeros(0, np.float32)
-        h = self.lib.svdf_dataset_from_blocks(self.h, len(blocks), _pad(tags, np.int32), fb_ptr, _pad(fbi, np.uint32), _pad(fbv, np.float32),
-                                              brp, _pad(cat.row_label, np.float32), _pad(cat.row_ptr, np.int64), _pad(cat.feat_index, np.uint32),
-                                              _pad(cat.feat_value, np.float32))
+        """blocks: list of PlusBlock in file order (one pass of a user-group buffer), or a flat BlockArrays."""
+        ba = blocks if isinstance(blocks, BlockArrays) else BlockArrays.from_blocks(blocks)
+        h = self.lib.svdf_dataset_from_blocks(self.h, ba.num_block, _pad(ba.extend_tag, np.int32), ba.fb_ptr, _pad(ba.fb_index, np.uint32),
+                                              _pad(ba.fb_value, np.float32), ba.block_row_ptr, _pad(ba.row_label, np.float32),
+                                              _pad(ba.row_ptr, np.int64), _pad(ba.feat_index, np.uint32), _pad(ba.feat_value, np.float32))
         if not h:
             raise SvdfError(self.lib.svdf_last_error().decode())
         return Dataset(self, h)
@@ -411,6 +414,11 @@ class Trainer:
             raise SvdfError(self.lib.svdf_last_error().decode())
         out = out[:n]
         return out.reshape(rows.value, cols.value) if name.startswith("W_") else out
+
+    def set_view(self, name, values):
+        v = np.ascontiguousarray(values, np.float32).ravel()
+        if self.lib.svdf_set_view(self.h, VIEW[name], _pad(v, np.float32), v.size) < 0:
+            raise SvdfError(self.lib.svdf_last_error().decode() or "set_view: shape mismatch")
 
     def synchronize(self):
         self._ok(self.lib.svdf_synchronize(self.h))

@@ -100,6 +100,14 @@ svdf_dataset *svdf_dataset_from_triples(svdf_trainer *t, long n, const unsigned 
         return h;
     })
 }
+svdf_dataset *svdf_dataset_from_pairs(svdf_trainer *t, long n, const unsigned *user, const unsigned *pos_item, const unsigned *neg_item) {
+    SVDF_GUARD(nullptr, {
+        svdf::Dataset *d = t->e->dataset_from_pairs(n, user, pos_item, neg_item);
+        svdf_dataset *h = new svdf_dataset();
+        h->d = d;
+        return h;
+    })
+}
 svdf_dataset *svdf_dataset_from_blocks(svdf_trainer *t, long num_block, const int *extend_tag, const int64_t *fb_ptr,
                                        const unsigned *fb_index, const float *fb_value, const int64_t *block_row_ptr,
                                        const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
@@ -169,6 +177,7 @@ int svdf_item_delta_apply_from(svdf_trainer *t, const float *src) { SVDF_GUARD(-
 int svdf_set_stream(svdf_trainer *t, void *hip_stream) { SVDF_GUARD(-1, { t->e->set_stream((hipStream_t)hip_stream); return 0; }) }
 
 int64_t svdf_get_view(svdf_trainer *t, int which, float *out, int64_t capacity) { SVDF_GUARD(-1, { return t->e->get_view(which, out, capacity); }) }
+int64_t svdf_set_view(svdf_trainer *t, int which, const float *in, int64_t count) { SVDF_GUARD(-1, { return t->e->set_view(which, in, count); }) }
 int svdf_view_shape(svdf_trainer *t, int which, int *rows, int *cols) { SVDF_GUARD(-1, { t->e->view_shape(which, rows, cols); return 0; }) }
 void *svdf_stream(svdf_trainer *t) { return (void *)t->e->stream(); }
 int svdf_synchronize(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->synchronize(); return 0; }) }

@@ -1284,6 +1284,66 @@ Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsign
     return ds.release();
 }
 
+// Rank pairs (user, positive item, negative item): the instance PairwiseRankGenerator emits for two rows that carry one
+// item entry of value 1 each (apex_svd_data.cpp:828-860 merges the two item lists by index with the negative's sign flipped,
+// label 1, :905-911): no global entry, user:1, {min(pos,neg): +-1, max(pos,neg): -+1}.  Few-row fused kernel, 3 rows per pair.
+Dataset *Engine::dataset_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg) {
+    check(trainer_ready_, "dataset: init_trainer has not been called");
+    need_device("dataset");
+    for (long r = 0; r < n; r++) {
+        if (user[r] >= (unsigned)mp_.num_user) fail("user feature index exceed bound");
+        if (pos[r] >= (unsigned)mp_.num_item || neg[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound");
+        if (pos[r] == neg[r]) fail("dataset_from_pairs: positive and negative item of a pair must differ");
+    }
+    if (!fused_allowed() || user_group() || relaxed()) {   // general representation (side tables, lazy decay, wide rows ...)
+        std::vector<int64_t> ptr((size_t)3 * n + 1);
+        std::vector<unsigned> idx((size_t)3 * n);
+        std::vector<float> val((size_t)3 * n), lab((size_t)n, 1.0f);
+        for (long r = 0; r < n; r++) {
+            ptr[(size_t)3 * r] = 3 * r; ptr[(size_t)3 * r + 1] = 3 * r; ptr[(size_t)3 * r + 2] = 3 * r + 1;
+            const bool pf = pos[r] < neg[r];
+            idx[(size_t)3 * r] = user[r]; val[(size_t)3 * r] = 1.0f;
+            idx[(size_t)3 * r + 1] = pf ? pos[r] : neg[r]; val[(size_t)3 * r + 1] = pf ? 1.0f : -1.0f;
+            idx[(size_t)3 * r + 2] = pf ? neg[r] : pos[r]; val[(size_t)3 * r + 2] = pf ? -1.0f : 1.0f;
+        }
+        ptr[(size_t)3 * n] = 3 * n;
+        return dataset_from_csr(n, lab.data(), ptr.data(), idx.data(), val.data());
+    }
+    std::unique_ptr<Dataset> ds(new Dataset());
+    adopt(ds.get()); ds->num_row = n; ds->kind = 2;
+    {
+        std::vector<int> lastu((size_t)mp_.num_user, 0), lasti((size_t)mp_.num_item, 0), levels((size_t)n);
+        for (long r = 0; r < n; r++) {
+            const int l = std::max(lastu[user[r]], std::max(lasti[pos[r]], lasti[neg[r]])) + 1;
+            lastu[user[r]] = l; lasti[pos[r]] = l; lasti[neg[r]] = l;
+            levels[(size_t)r] = l;
+        }
+        build_schedule(levels, 0, ds->sched);
+    }
+    std::vector<unsigned> lo((size_t)n);
+    for (long r = 0; r < n; r++) lo[(size_t)r] = std::min(pos[r], neg[r]);
+    if (sort_batches_ == 1) sort_batches(ds->sched, lo.data());
+    else if (sort_batches_ == 2) sort_batches(ds->sched, user);
+    const int *order = ds->sched.order.data();
+    FusedHost fh;
+    fh.max_nu = 1; fh.max_ni = 2; fh.has_g = false; fh.inline_g = false;
+    fh.label.assign((size_t)n, 1.0f);
+    fh.uidx[0].resize((size_t)n); fh.uval[0].assign((size_t)n, 1.0f);
+    for (int a = 0; a < 2; a++) { fh.iidx[a].resize((size_t)n); fh.ival[a].resize((size_t)n); }
+    for (long s = 0; s < n; s++) {
+        const long r = order[s];
+        const bool pf = pos[r] < neg[r];
+        fh.uidx[0][(size_t)s] = user[r];
+        fh.iidx[0][(size_t)s] = pf ? pos[r] : neg[r]; fh.ival[0][(size_t)s] = pf ? 1.0f : -1.0f;
+        fh.iidx[1][(size_t)s] = pf ? neg[r] : pos[r]; fh.ival[1][(size_t)s] = pf ? -1.0f : 1.0f;
+    }
+    ds->fused.upload(fh, stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    const long nb = (mp_.no_user_bias ? 0 : 1) + 2;
+    ds->algorithmic_bytes = n * (8L * mp_.num_factor * 3 + 8 * nb + 16 + 8 * 3);   // 3128 B/pair at k=128 without user bias
+    return ds.release();
+}
+
 Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
@@ -1650,6 +1710,39 @@ int64_t Engine::get_view(int which, float *out, int64_t capacity) {
         if (which == 4) memcpy(out, hg_.data(), (size_t)n * sizeof(float));
         else if (!matrix) memcpy(out, hbias_.data() + off, (size_t)n * sizeof(float));
         else for (int y = 0; y < rows; y++) memcpy(out + (size_t)y * cols, hW_.data() + ((size_t)off + y) * pitch_, (size_t)cols * sizeof(float));
+    }
+    return n;
+}
+// overwrite a parameter view from rows*cols unpadded floats (multi-GPU: gathering the owners' user rows before a save)
+int64_t Engine::set_view(int which, const float *in, int64_t count) {
+    int rows, cols;
+    view_shape(which, &rows, &cols);
+    if (rows < 0) return -1;
+    const int64_t n = (int64_t)rows * cols;
+    if (n != count) return -1;
+    if (n == 0) return 0;
+    const bool matrix = (which == 1 || which == 3 || which == 6);
+    const unsigned off = (which <= 1) ? user_off_ : (which <= 3) ? item_off_ : fb_off_;
+    if (device_model_) {
+        flush();
+        if (which == 4) {
+            std::vector<float> keep;
+            keep.assign(in, in + n);
+            std::swap(keep, hg_);
+            upload_globals(g_stride_);
+            HIPCHECK(hipStreamSynchronize(stream_));
+            std::swap(keep, hg_);
+            return n;
+        }
+        if (!matrix) HIPCHECK(hipMemcpyAsync(dbias_.p + off, in, (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream_));
+        else HIPCHECK(hipMemcpy2DAsync(dW_.p + (size_t)off * pitch_, (size_t)pitch_ * sizeof(float), in, (size_t)cols * sizeof(float),
+                                       (size_t)cols * sizeof(float), (size_t)rows, hipMemcpyHostToDevice, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
+    } else {
+        check(host_model_valid_, "set_view: no model");
+        if (which == 4) memcpy(hg_.data(), in, (size_t)n * sizeof(float));
+        else if (!matrix) memcpy(hbias_.data() + off, in, (size_t)n * sizeof(float));
+        else for (int y = 0; y < rows; y++) memcpy(hW_.data() + ((size_t)off + y) * pitch_, in + (size_t)y * cols, (size_t)cols * sizeof(float));
     }
     return n;
 }

@@ -200,6 +200,7 @@ class Engine {
     // resident datasets
     Dataset *dataset_from_csr(long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
     Dataset *dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
+    Dataset *dataset_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg);
     Dataset *dataset_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
                                  const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
                                  const float *feat_value);
@@ -228,6 +229,7 @@ class Engine {
 
     // introspection
     int64_t get_view(int which, float *out, int64_t capacity);
+    int64_t set_view(int which, const float *in, int64_t count);
     void view_shape(int which, int *rows, int *cols);
     hipStream_t stream() const { return stream_; }
     void synchronize();

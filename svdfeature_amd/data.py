@@ -116,6 +116,139 @@ class PlusBlock:
         return int(self.index_ufeedback.size)
 
 
+@dataclass
+class BlockArrays:
+    """One pass of a user-group buffer as FLAT arrays -- exactly the argument list of svdf_dataset_from_blocks: block b has
+    extend_tag[b], feedback entries fb_index/fb_value[fb_ptr[b]:fb_ptr[b+1]] and the rows block_row_ptr[b]:block_row_ptr[b+1]
+    of the CSR arrays (row_ptr: int64, 3*num_row+1 entries).  Millions of blocks without a Python object per block."""
+    extend_tag: np.ndarray
+    fb_ptr: np.ndarray
+    fb_index: np.ndarray
+    fb_value: np.ndarray
+    block_row_ptr: np.ndarray
+    row_label: np.ndarray
+    row_ptr: np.ndarray
+    feat_index: np.ndarray
+    feat_value: np.ndarray
+
+    def __post_init__(self):
+        self.extend_tag = np.ascontiguousarray(self.extend_tag, np.int32)
+        self.fb_ptr = np.ascontiguousarray(self.fb_ptr, np.int64)
+        self.fb_index = np.ascontiguousarray(self.fb_index, np.uint32)
+        self.fb_value = np.ascontiguousarray(self.fb_value, np.float32)
+        self.block_row_ptr = np.ascontiguousarray(self.block_row_ptr, np.int64)
+        self.row_label = np.ascontiguousarray(self.row_label, np.float32)
+        self.row_ptr = np.ascontiguousarray(self.row_ptr, np.int64)
+        self.feat_index = np.ascontiguousarray(self.feat_index, np.uint32)
+        self.feat_value = np.ascontiguousarray(self.feat_value, np.float32)
+        assert self.fb_ptr.size == self.extend_tag.size + 1 and self.block_row_ptr.size == self.extend_tag.size + 1
+        assert self.row_ptr.size == 3 * self.row_label.size + 1
+
+    @property
+    def num_block(self):
+        return int(self.extend_tag.size)
+
+    @property
+    def num_row(self):
+        return int(self.row_label.size)
+
+    @staticmethod
+    def from_blocks(blocks):
+        nb = len(blocks)
+        fb_ptr, brp = np.zeros(nb + 1, np.int64), np.zeros(nb + 1, np.int64)
+        for j, b in enumerate(blocks):
+            fb_ptr[j + 1] = fb_ptr[j] + b.num_ufeedback
+            brp[j + 1] = brp[j] + b.data.num_row
+        cat = CSRData.concat([b.data for b in blocks])
+        fbi = np.concatenate([b.index_ufeedback for b in blocks]) if blocks else np.zeros(0, np.uint32)
+        fbv = np.concatenate([b.value_ufeedback for b in blocks]) if blocks else np.zeros(0, np.float32)
+        return BlockArrays(np.array([b.extend_tag for b in blocks], np.int32), fb_ptr, fbi, fbv, brp, cat.row_label,
+                           cat.row_ptr.astype(np.int64), cat.feat_index, cat.feat_value)
+
+    def to_blocks(self):
+        out = []
+        for b in range(self.num_block):
+            r0, r1 = int(self.block_row_ptr[b]), int(self.block_row_ptr[b + 1])
+            p = self.row_ptr[3 * r0:3 * r1 + 1]
+            d = CSRData(self.row_label[r0:r1], (p - p[0]).astype(np.int32), self.feat_index[p[0]:p[-1]], self.feat_value[p[0]:p[-1]])
+            f0, f1 = int(self.fb_ptr[b]), int(self.fb_ptr[b + 1])
+            out.append(PlusBlock(self.fb_index[f0:f1], self.fb_value[f0:f1], d, int(self.extend_tag[b])))
+        return out
+
+    def block_user(self):
+        """The user a block belongs to: the first user entry of its first row; MIDDLE / END blocks (and blocks without a
+        user entry) inherit from the block before them, so a START..END span stays together."""
+        nb = self.num_block
+        user = np.full(nb, 0xFFFFFFFF, np.uint32)
+        has_row = self.block_row_ptr[1:] > self.block_row_ptr[:-1]
+        r0 = self.block_row_ptr[:-1][has_row]
+        pu, pi = self.row_ptr[3 * r0 + 1], self.row_ptr[3 * r0 + 2]
+        ok = pi > pu
+        idx = np.flatnonzero(has_row)[ok]
+        user[idx] = self.feat_index[pu[ok]]
+        own = (user != 0xFFFFFFFF) & ((self.extend_tag == TAG_DEFAULT) | (self.extend_tag == TAG_START))
+        src = np.where(own, np.arange(nb), -1)
+        np.maximum.accumulate(src, out=src)
+        filled = np.where(src >= 0, user[np.maximum(src, 0)], user)
+        return np.where(own, user, filled).astype(np.uint32)
+
+    def span_closed_before(self):
+        """closed[b] (b = 0..num_block): no START..END span is open between block b-1 and block b (a pass may be cut there)."""
+        opens = (self.extend_tag == TAG_START) | (self.extend_tag == TAG_MIDDLE)
+        return np.concatenate([[True], ~opens])
+
+    def select(self, keep):
+        """The blocks with keep[b] true, order preserved."""
+        keep = np.asarray(keep, bool)
+        nrow_b = np.diff(self.block_row_ptr)
+        nfb_b = np.diff(self.fb_ptr)
+        row_keep = np.repeat(keep, nrow_b)
+        sec = np.diff(self.row_ptr).reshape(-1, 3)
+        ent_keep = np.repeat(row_keep, sec.sum(axis=1)) if sec.size else np.zeros(0, bool)
+        fb_keep = np.repeat(keep, nfb_b)
+        base = int(self.row_ptr[0])
+        new_ptr = np.concatenate([[0], np.cumsum(sec[row_keep].reshape(-1))]).astype(np.int64)
+        fi, fv = self.feat_index[base:base + ent_keep.size][ent_keep], self.feat_value[base:base + ent_keep.size][ent_keep]
+        f0 = int(self.fb_ptr[0])
+        return BlockArrays(self.extend_tag[keep], np.concatenate([[0], np.cumsum(nfb_b[keep])]),
+                           self.fb_index[f0:f0 + fb_keep.size][fb_keep], self.fb_value[f0:f0 + fb_keep.size][fb_keep],
+                           np.concatenate([[0], np.cumsum(nrow_b[keep])]), self.row_label[row_keep], new_ptr, fi, fv)
+
+    def slice(self, b0, b1):
+        keep = np.zeros(self.num_block, bool)
+        keep[b0:b1] = True
+        return self.select(keep)
+
+    def rows(self):
+        """All rows as one CSRData (int32 offsets)."""
+        p = self.row_ptr - self.row_ptr[0]
+        return CSRData(self.row_label, p.astype(np.int32), self.feat_index[self.row_ptr[0]:self.row_ptr[-1]],
+                       self.feat_value[self.row_ptr[0]:self.row_ptr[-1]])
+
+
+def pairs_as_csr(user, pos, neg):
+    """(user, positive item, negative item) -> the rank-pair instances of apex_svd_data.cpp:828-860, 905-911: label 1,
+    user:1, the two item entries in index order with the negative's sign flipped."""
+    user, pos, neg = (np.asarray(x, np.uint32) for x in (user, pos, neg))
+    n = len(user)
+    pf = pos < neg
+    idx = np.empty(3 * n, np.uint32)
+    val = np.empty(3 * n, np.float32)
+    idx[0::3] = user
+    val[0::3] = 1.0
+    idx[1::3] = np.where(pf, pos, neg)
+    val[1::3] = np.where(pf, 1.0, -1.0)
+    idx[2::3] = np.where(pf, neg, pos)
+    val[2::3] = np.where(pf, -1.0, 1.0)
+    ptr = np.empty(3 * n + 1, np.int32)
+    base = 3 * np.arange(n, dtype=np.int64)
+    ptr[0:3 * n:3] = base
+    ptr[1:3 * n:3] = base
+    ptr[2:3 * n:3] = base + 1
+    ptr[3 * n] = 3 * n
+    return CSRData(np.ones(n, np.float32), ptr, idx, val)
+
+
 # ---------------------------------------------------------------- text formats
 def read_text_features(path, scale_score=1.0, sort_sections=False):
     """``label ng nu ni idx:val ...`` lines (SVDFeatureCSRLoader, apex_svd_data.cpp:70-112).

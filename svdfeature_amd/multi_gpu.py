@@ -4,7 +4,10 @@ The reference is single-process; this exchange step is new design, not a transla
 
 * instances are partitioned BY USER (rank = user % world), so W_user / u_bias rows are touched by
   exactly one rank and never exchanged;
-* item-side parameters (W_item, i_bias, g_bias [, W_ufeedback]) are replicated; a pass over the data
+* the same holds for rank pairs (Pairs: user, positive item, negative item -- BASELINE configs[4]) and for user-group data
+  (data.BlockArrays: a block belongs to its user's rank; SVD++ state lives inside a user's blocks, so it never crosses
+  ranks) -- shard_pair_windows / shard_block_windows;
+* item-side parameters (W_item, i_bias, g_bias [, W_ufeedback, ufeedback_bias]) are replicated; a pass over the data
   is cut into `windows` windows; inside a window every rank runs its own exact, conflict-free
   sequential SGD on its shard, then the item-side DELTAS of the window are summed over ranks with
   ONE all-reduce (RCCL over xGMI: one contiguous fp32 buffer of num_item*(k+1)+num_global floats)
@@ -18,7 +21,12 @@ to one window stale on the other ranks' contributions, so the acceptance bar is 
 The class is engine-agnostic: it drives an adaptor with train/delta methods, so the same code runs
 on MI355X ranks (HipShard, RCCL) and in the world_size-2 gloo tests on CPU.
 """
+from collections import namedtuple
+
 import numpy as np
+
+# rank pairs (user, positive item, negative item): the instance stream of BASELINE configs[4]
+Pairs = namedtuple("Pairs", ["user", "pos", "neg"])
 
 
 def shard_by_user(user, item, label, rank, world):
@@ -46,6 +54,44 @@ def shard_windows(user, item, label, rank, world, windows):
     return out
 
 
+def shard_pair_windows(user, pos, neg, rank, world, windows):
+    """Rank pairs sharded like triples: this rank's pairs (user % world == rank) of every global window, order kept."""
+    b = window_bounds(len(user), windows)
+    out = []
+    for w in range(windows):
+        s = slice(b[w], b[w + 1])
+        out.append(Pairs(*shard_by_user(user[s], pos[s], neg[s], rank, world)))
+    return out
+
+
+def block_window_bounds(ba, windows):
+    """Window cuts of a user-group pass (data.BlockArrays) at BLOCK positions, the same on every rank: the even cut
+    points are moved forward to the next position where no START..END span is open."""
+    closed = ba.span_closed_before()
+    nb = ba.num_block
+    out = [0]
+    for w in range(1, windows):
+        p = max((nb * w) // windows, out[-1])
+        while p < nb and not closed[p]:
+            p += 1
+        out.append(p)
+    out.append(nb)
+    return out
+
+
+def shard_block_windows(ba, rank, world, windows):
+    """User-group data (SVDPlusBlock streams, apex_svd_data.h:376-466): a block belongs to the rank of its user
+    (user % world; a START..END span follows its START block), windows cut at global block positions.  Every rank keeps
+    its blocks in file order, so per rank this is the reference's update(block) loop on a sub-stream."""
+    b = block_window_bounds(ba, windows)
+    owner = ba.block_user() % np.uint32(world)
+    idx = np.arange(ba.num_block)
+    out = []
+    for w in range(windows):
+        out.append(ba.select((owner == rank) & (idx >= b[w]) & (idx < b[w + 1])))
+    return out
+
+
 def defer_tails(windows, num_user, num_item, min_frac=0.05):
     """Move the short tail of every window's conflict-free batch sequence into the next window.
 
@@ -58,18 +104,28 @@ def defer_tails(windows, num_user, num_item, min_frac=0.05):
     applies to multi-rank runs, whose acceptance bar is the RMSE tolerance anyway.  windows: [(u, i, r)] of ONE rank."""
     from . import schedule_resources
     out, carry = [], None
-    for w, (u, i, r) in enumerate(windows):
+    for w, win in enumerate(windows):
+        pairs = isinstance(win, Pairs)
+        u, i, r = win
         if carry is not None and len(carry[2]):
             u, i, r = np.concatenate([carry[0], u]), np.concatenate([carry[1], i]), np.concatenate([carry[2], r])
         carry = None
         n = len(r)
+        wrap = (lambda a, b, c: Pairs(a, b, c)) if pairs else (lambda a, b, c: (a, b, c))
         if w == len(windows) - 1 or n == 0 or min_frac <= 0:
-            out.append((u, i, r))
+            out.append(wrap(u, i, r))
             continue
-        res = np.empty(2 * n, np.uint32)
-        res[0::2] = u
-        res[1::2] = np.asarray(i, np.uint32) + np.uint32(num_user)
-        order, level_ptr = schedule_resources(2 * np.arange(n + 1, dtype=np.int64), res, num_user + num_item)
+        if pairs:   # three rows per pair: the user's and both items'
+            res = np.empty(3 * n, np.uint32)
+            res[0::3] = u
+            res[1::3] = np.asarray(i, np.uint32) + np.uint32(num_user)
+            res[2::3] = np.asarray(r, np.uint32) + np.uint32(num_user)
+            order, level_ptr = schedule_resources(3 * np.arange(n + 1, dtype=np.int64), res, num_user + num_item)
+        else:
+            res = np.empty(2 * n, np.uint32)
+            res[0::2] = u
+            res[1::2] = np.asarray(i, np.uint32) + np.uint32(num_user)
+            order, level_ptr = schedule_resources(2 * np.arange(n + 1, dtype=np.int64), res, num_user + num_item)
         sizes = np.diff(level_ptr)
         cut = len(sizes)
         floor = min_frac * float(sizes.max())
@@ -77,7 +133,7 @@ def defer_tails(windows, num_user, num_item, min_frac=0.05):
             cut -= 1
         keep = np.sort(order[:level_ptr[cut]])
         late = np.sort(order[level_ptr[cut]:])
-        out.append((u[keep], i[keep], r[keep]))
+        out.append(wrap(u[keep], i[keep], r[keep]))
         carry = (u[late], i[late], r[late])
     return out
 
@@ -116,6 +172,11 @@ class ShardedTrainer:
         else:
             self.dist.all_reduce(d)
 
+    def gather_model(self, rank):
+        """Complete the model on every rank (user rows live on their owners during training); call before save_model."""
+        if self.world > 1 and hasattr(self.a, "gather_user_side"):
+            self.a.gather_user_side(self.dist, rank, self.world)
+
     def train_pass(self):
         keep_snapshot = getattr(self.a, "apply_refreshes_snapshot", False)
         for wi, w in enumerate(self.windows):
@@ -150,10 +211,34 @@ class HipShard:
         self.buf = None
 
     def make_windows(self, shards):
-        return [self.t.dataset_from_triples(u, i, r) for (u, i, r) in shards]
+        """shards: per window (user, item, label) triples, Pairs(user, pos, neg) or a data.BlockArrays (user-group data)."""
+        from .data import BlockArrays
+        out = []
+        for sh in shards:
+            if isinstance(sh, BlockArrays):
+                out.append(self.t.dataset_from_blocks(sh))
+            elif isinstance(sh, Pairs):
+                out.append(self.t.dataset_from_pairs(sh.user, sh.pos, sh.neg))
+            else:
+                out.append(self.t.dataset_from_triples(*sh))
+        return out
 
     def train(self, ds):
         self.t.train_dataset(ds)
+
+    def gather_user_side(self, dist, rank, world):
+        """W_user / u_bias rows are private to their owner (user % world): sum the owners' rows over the ranks so that every
+        rank (and a model file written by any of them) holds the complete model.  Supports are disjoint: a plain SUM."""
+        torch = self.torch
+        for name in ("W_user", "u_bias"):
+            v = self.t.view(name)
+            if v is None or v.size == 0:
+                continue
+            mine = (np.arange(v.shape[0]) % world) == rank
+            v = np.where(mine.reshape((-1,) + (1,) * (v.ndim - 1)), v, np.float32(0))
+            tns = torch.from_numpy(np.ascontiguousarray(v)).to(self.device)
+            dist.all_reduce(tns)
+            self.t.set_view(name, tns.cpu().numpy())
 
     def delta_begin(self):
         self.t.item_delta_begin()

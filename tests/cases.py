@@ -179,3 +179,31 @@ RANK_E2E_CONF = [   # demo/pairwiseRank/pairwiseRank.conf shape, shrunk
     ("num_ufeedback", "50"), ("wd_ufeedback", "0.004"), ("ufeedback_init_sigma", "0.01"), ("no_user_bias", "1"), ("input_type", "2"),
 ]
 RANK_E2E_ROUNDS = 3
+
+
+# ---- rank pairs (BASELINE configs[4]): (user, positive item, negative item) from a planted preference model
+PAIR_CONF = [  # demo/pairwiseRank/pairwiseRank.conf: sigmoid rank loss, no user bias
+    ("base_score", "0.5"), ("learning_rate", "0.005"), ("wd_item", "0.004"), ("wd_user", "0.004"),
+    ("num_global", "0"), ("active_type", "3"), ("no_user_bias", "1"),
+]
+
+
+def planted_pairs(n, num_user, num_item, seed, rank=8):
+    """n pairs in random order; the positive item is the one the planted low-rank model scores higher for the user
+    (with noise), pos != neg."""
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, num_user, n, dtype=np.int64)
+    a = rng.integers(0, num_item, n, dtype=np.int64)
+    b = (a + 1 + rng.integers(0, num_item - 1, n, dtype=np.int64)) % num_item
+    pu = rng.standard_normal((num_user, rank)).astype(np.float32)
+    qi = rng.standard_normal((num_item, rank)).astype(np.float32)
+    sa_ = np.einsum("nk,nk->n", pu[u], qi[a]) + 0.5 * rng.standard_normal(n)
+    sb_ = np.einsum("nk,nk->n", pu[u], qi[b])
+    first = sa_ > sb_
+    pos, neg = np.where(first, a, b), np.where(first, b, a)
+    return u.astype(np.uint32), pos.astype(np.uint32), neg.astype(np.uint32)
+
+
+def pair_accuracy(score_pos_minus_neg):
+    """share of held-out pairs ranked the right way round (score difference > 0)"""
+    return float(np.mean(np.asarray(score_pos_minus_neg) > 0))

@@ -4,12 +4,12 @@ import numpy as np
 
 import cases
 from oracle import oracle
-from svdfeature_amd import CSRData
-from svdfeature_amd.multi_gpu import defer_tails, shard_windows
+from svdfeature_amd import BlockArrays, CSRData, pairs_as_csr
+from svdfeature_amd.multi_gpu import Pairs, defer_tails, shard_block_windows, shard_pair_windows, shard_windows
 
 
-def make_oracle(conf, seed=10):
-    t = oracle.OracleTrainer("port", 0, 0)
+def make_oracle(conf, seed=10, fmt=0, active=0):
+    t = oracle.OracleTrainer("port", fmt, active)
     t.seed(seed)
     for k, v in conf:
         t.set_param(k, v)
@@ -26,13 +26,35 @@ class OracleShard:
         self.snap = None
 
     def make_windows(self, shards):
-        return [CSRData.from_triples(u, i, r) for (u, i, r) in shards]
+        out = []
+        for sh in shards:
+            if isinstance(sh, BlockArrays):
+                out.append(sh.to_blocks())
+            elif isinstance(sh, Pairs):
+                out.append(pairs_as_csr(sh.user, sh.pos, sh.neg))
+            else:
+                out.append(CSRData.from_triples(*sh))
+        return out
 
     def train(self, d):
-        self.t.update_batch(d)
+        if isinstance(d, list):
+            for b in d:
+                self.t.update_block(b)
+        else:
+            self.t.update_batch(d)
+
+    SHARED = ("W_ufeedback", "W_item", "ufeedback_bias", "i_bias", "g_bias")   # every replicated range (svdf_engine.cpp: shared_ranges)
+
+    def _views(self):
+        out = []
+        for name in self.SHARED:
+            v = self.t.view(name)
+            if v is not None and v.size:
+                out.append((name, v))
+        return out
 
     def _shared(self):
-        return np.concatenate([self.t.view("W_item").ravel(), self.t.view("i_bias").ravel()])
+        return np.concatenate([v.ravel() for _, v in self._views()])
 
     def delta_begin(self):
         self.snap = self._shared()
@@ -44,16 +66,23 @@ class OracleShard:
     def delta_set(self, d):
         d = d.numpy() if hasattr(d, "numpy") else d
         new = self.snap + d
-        w = self.t.view("W_item")
-        self.t.set_view("W_item", new[:w.size])
-        self.t.set_view("i_bias", new[w.size:])
+        off = 0
+        for name, v in self._views():
+            self.t.set_view(name, new[off:off + v.size])
+            off += v.size
 
 
-def simulate(conf, u, i, r, world, windows, passes, seed=10, defer=0.0):
+def simulate(conf, u, i, r, world, windows, passes, seed=10, defer=0.0, fmt=0, active=0):
     """All ranks in one process, all-reduce replaced by an explicit sum in rank order.  defer > 0: the window
-    lists go through multi_gpu.defer_tails like bench.py's (needs num_user / num_item in conf)."""
-    ranks = [OracleShard(make_oracle(conf, seed)) for _ in range(world)]
-    shards = [shard_windows(u, i, r, rk, world, windows) for rk in range(world)]
+    lists go through multi_gpu.defer_tails like bench.py's (needs num_user / num_item in conf).
+    u: user column of triples (u, i, r), of rank pairs (u = Pairs) or a BlockArrays (user-group pass; fmt = 1)."""
+    ranks = [OracleShard(make_oracle(conf, seed, fmt, active)) for _ in range(world)]
+    if isinstance(u, BlockArrays):
+        shards = [shard_block_windows(u, rk, world, windows) for rk in range(world)]
+    elif isinstance(u, Pairs):
+        shards = [shard_pair_windows(u.user, u.pos, u.neg, rk, world, windows) for rk in range(world)]
+    else:
+        shards = [shard_windows(u, i, r, rk, world, windows) for rk in range(world)]
     if defer > 0 and world > 1:
         c = dict(conf)
         shards = [defer_tails(sh, int(c["num_user"]), int(c["num_item"]), defer) for sh in shards]
