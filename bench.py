@@ -8,20 +8,27 @@ Inputs (the scheduled instance stream and the model) are resident in HBM when th
 starts; every pass performs all 100M sequentially-consistent SGD updates (the result is bit-identical
 to the reference's one-instance-at-a-time loop -- checked in-run on a prefix, see "parity").
 
-    python bench.py                       # 1 GPU, 5 timed passes, 1 warm-up
+    python bench.py                       # 1 GPU, 5 timed passes, 1 warm-up, + the secondary workloads
+    python bench.py --gpus N              # spawns its own N ranks (torch.distributed.run) when WORLD_SIZE is unset
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
+    python bench.py --workload pairwise|svdpp|neighbourhood [--gpus N]   # the other BASELINE configs as the main line
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   "roofline"      algorithmic HBM bytes (1072 B/instance at k=64) / HIP-event time of
                   the dominant kernel's launches, against the 8 TB/s HBM3E peak
   "cpu_baseline"  the reference's own solver (oracle/_ref/libsvdf_ref.so, kind "reference"; or the C
                   port when that is absent) timed on this box's host, 1 thread, on a prefix sample
+  "secondary"     (N=1 default run) BASELINE configs[3] / configs[4] at their configured sizes: pairwise rank pairs
+                  k=128 (200 M pairs), SVD++ user blocks k=128, neighbourhood (4 of 10 K global ids) k=128 -- each with
+                  value, ms_per_step, roofline, cpu_baseline, in-run parity against the CPU path and, where the data's
+                  dependency depth is the bound, the DAG bound (levels x latency of one unit)
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
 import sys
 import time
 
@@ -33,30 +40,151 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
+# =============================================================================== synthetic data
+class Planted:
+    """Planted low-rank preference model: ratings 1..5 = clip(round(3 + b_u + b_i + <p_u,q_i>/2 + noise))."""
+
+    def __init__(self, num_user, num_item, rng, rank=4):
+        self.rank = rank
+        self.pu = rng.standard_normal((num_user, rank)).astype(np.float32)
+        self.qi = rng.standard_normal((num_item, rank)).astype(np.float32)
+        self.bu = (0.3 * rng.standard_normal(num_user)).astype(np.float32)
+        self.bi = (0.3 * rng.standard_normal(num_item)).astype(np.float32)
+
+    def score(self, u, i, chunk=10_000_000):
+        out = np.empty(len(u), np.float32)
+        for s in range(0, len(u), chunk):
+            uu, ii = u[s:s + chunk], i[s:s + chunk]
+            out[s:s + chunk] = 3.0 + self.bu[uu] + self.bi[ii] + 0.5 * np.einsum("nk,nk->n", self.pu[uu], self.qi[ii]) / np.sqrt(self.rank)
+        return out
+
+    def rate(self, u, i, rng, noise=0.35, chunk=10_000_000):
+        r = np.empty(len(u), np.float32)
+        for s in range(0, len(u), chunk):
+            e = min(len(u), s + chunk)
+            sc = self.score(u[s:e], i[s:e]) + noise * rng.standard_normal(e - s).astype(np.float32)
+            r[s:e] = np.clip(np.rint(sc), 1, 5)
+        return r
+
+
 def synth_triples(n, num_user, num_item, seed=12345, rank=4, noise=0.35, chunk=10_000_000):
     """(user, item, rating): u, i uniform; rating in 1..5 from a planted low-rank model + noise so that
     RMSE is meaningful."""
     rng = np.random.default_rng(seed)
     u = rng.integers(0, num_user, n, dtype=np.uint32)
     i = rng.integers(0, num_item, n, dtype=np.uint32)
-    pu = rng.standard_normal((num_user, rank)).astype(np.float32)
-    qi = rng.standard_normal((num_item, rank)).astype(np.float32)
-    bu = (0.3 * rng.standard_normal(num_user)).astype(np.float32)
-    bi = (0.3 * rng.standard_normal(num_item)).astype(np.float32)
+    pl = Planted(num_user, num_item, rng, rank)
     r = np.empty(n, np.float32)
     for s in range(0, n, chunk):
         e = min(n, s + chunk)
-        uu, ii = u[s:e], i[s:e]
-        score = 3.0 + bu[uu] + bi[ii] + 0.5 * np.einsum("nk,nk->n", pu[uu], qi[ii]) / np.sqrt(rank)
-        score += noise * rng.standard_normal(e - s).astype(np.float32)
+        score = pl.score(u[s:e], i[s:e]) + noise * rng.standard_normal(e - s).astype(np.float32)
         r[s:e] = np.clip(np.rint(score), 1, 5)
     return u, i, r
 
 
+def synth_pairs(n, num_user, num_item, seed=777, chunk=10_000_000):
+    """BASELINE configs[4] / SURVEY 8d2 C5: n (user, positive item, negative item) rank pairs in uniform random order;
+    the positive item is the one the planted model (+ noise) scores higher, pos != neg."""
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, num_user, n, dtype=np.uint32)
+    a = rng.integers(0, num_item, n, dtype=np.uint32)
+    b = rng.integers(0, num_item - 1, n, dtype=np.uint32)
+    b = ((a.astype(np.int64) + 1 + b) % num_item).astype(np.uint32)
+    pl = Planted(num_user, num_item, rng)
+    pos, neg = np.empty(n, np.uint32), np.empty(n, np.uint32)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        sa_ = pl.score(u[s:e], a[s:e]) + 0.35 * rng.standard_normal(e - s).astype(np.float32)
+        first = sa_ > pl.score(u[s:e], b[s:e])
+        pos[s:e] = np.where(first, a[s:e], b[s:e])
+        neg[s:e] = np.where(first, b[s:e], a[s:e])
+    return u, pos, neg
+
+
+def synth_user_blocks(num_blocks, per_user, num_user, num_item, seed=4242):
+    """BASELINE configs[3] implicitFeedback: user-grouped blocks, each user's rows (per_user ratings of uniformly drawn items)
+    + that user's feedback set = the items it rated, value n_u^-1/2 (demo/implicitFeedback/mkimplicitfeedbackfeature.py:46-55),
+    users in random order.  Returns (BlockArrays train, BlockArrays held-out: the same users' feedback + 2 fresh rows)."""
+    from svdfeature_amd import BlockArrays
+    rng = np.random.default_rng(seed)
+    users = rng.permutation(num_user)[:num_blocks].astype(np.uint32)
+    n = num_blocks * per_user
+    u = np.repeat(users, per_user)
+    i = rng.integers(0, num_item, n, dtype=np.uint32)
+    pl = Planted(num_user, num_item, rng)
+    r = pl.rate(u, i, rng)
+    # feedback set of a block = its distinct items, sorted (np.unique per block, vectorised through a sort of (block, item))
+    blk = np.repeat(np.arange(num_blocks, dtype=np.int64), per_user)
+    key = np.unique(blk * num_item + i)
+    fb_blk, fb_idx = key // num_item, (key % num_item).astype(np.uint32)
+    fb_cnt = np.bincount(fb_blk, minlength=num_blocks)
+    fb_ptr = np.concatenate([[0], np.cumsum(fb_cnt)]).astype(np.int64)
+    fb_val = (1.0 / np.sqrt(np.repeat(fb_cnt, fb_cnt))).astype(np.float32)
+
+    def rows(uu, ii, rr, per):
+        m = len(rr)
+        ptr = np.empty(3 * m + 1, np.int64)
+        base = 2 * np.arange(m, dtype=np.int64)
+        ptr[0:3 * m:3] = base; ptr[1:3 * m:3] = base; ptr[2:3 * m:3] = base + 1; ptr[3 * m] = 2 * m
+        idx = np.empty(2 * m, np.uint32); idx[0::2] = uu; idx[1::2] = ii
+        return BlockArrays(np.zeros(num_blocks, np.int32), fb_ptr, fb_idx, fb_val, per * np.arange(num_blocks + 1, dtype=np.int64),
+                           rr, ptr, idx, np.ones(2 * m, np.float32))
+    train = rows(u, i, r, per_user)
+    tu = np.repeat(users, 2)
+    ti = rng.integers(0, num_item, len(tu), dtype=np.uint32)
+    test = rows(tu, ti, pl.rate(tu, ti, rng), 2)
+    return train, test
+
+
+def synth_neighbourhood(n, num_user, num_item, num_global, ng, seed=99):
+    """BASELINE configs[3] neighborhoodModel shape: (user, item, rating) + ng global features per instance drawn from
+    num_global ids with values U(0,1) (demo/neighborhoodModel: k-NN style global weights), distinct ids inside an instance."""
+    from svdfeature_amd import CSRData
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, num_user, n, dtype=np.uint32)
+    i = rng.integers(0, num_item, n, dtype=np.uint32)
+    pl = Planted(num_user, num_item, rng)
+    r = pl.rate(u, i, rng)
+    g = rng.integers(0, num_global - ng, (n, ng), dtype=np.uint32)
+    g.sort(axis=1)
+    g += np.arange(ng, dtype=np.uint32)[None, :]     # strictly increasing -> distinct
+    per = ng + 2
+    ptr = np.empty(3 * n + 1, np.int64)
+    base = per * np.arange(n, dtype=np.int64)
+    ptr[0:3 * n:3] = base; ptr[1:3 * n:3] = base + ng; ptr[2:3 * n:3] = base + ng + 1; ptr[3 * n] = per * n
+    idx = np.empty((n, per), np.uint32); idx[:, :ng] = g; idx[:, ng] = u; idx[:, ng + 1] = i
+    val = np.ones((n, per), np.float32); val[:, :ng] = rng.uniform(0, 1, (n, ng))
+    return CSRData(r, ptr.astype(np.int32), idx.ravel(), val.ravel())
+
+
+# =============================================================================== configuration per workload
 def conf_for(a):
     return [("base_score", "3"), ("learning_rate", "0.005"), ("wd_item", "0.004"), ("wd_user", "0.004"),
             ("num_item", str(a.items)), ("num_user", str(a.users)), ("num_global", "0"),
             ("num_factor", str(a.factor)), ("active_type", "0")]   # demo/basicMF/basicMF.conf:4-23
+
+
+WORKLOADS = {
+    # name: (format_type, active_type, default factor, dominant kernel, unit name)
+    "basicmf": (0, 0, 64, "k_basicmf", "instances/s"),
+    "pairwise": (0, 3, 128, "k_fused<32,1,2> (few-row fused kernel, 3 rows per pair)", "pairs/s"),
+    "svdpp": (1, 0, 128, "k_svdpp_wave<2> (one wave per user)", "instances/s"),
+    "neighbourhood": (0, 0, 128, "k_fused<32,1,1> (few-row fused kernel, inline global slots)", "instances/s"),
+}
+
+
+def workload_conf(name, a, factor):
+    base = [("learning_rate", "0.005"), ("wd_item", "0.004"), ("wd_user", "0.004"), ("num_item", str(a.items)), ("num_user", str(a.users)),
+            ("num_factor", str(factor))]
+    if name == "basicmf":
+        return conf_for(a)
+    if name == "pairwise":     # demo/pairwiseRank/pairwiseRank.conf: sigmoid rank loss (active_type 3), no user bias
+        return base + [("num_global", "0"), ("no_user_bias", "1")]
+    if name == "svdpp":        # demo/implicitFeedback/implicitFeedback.conf
+        return base + [("base_score", "3"), ("num_global", "0"), ("num_ufeedback", str(a.items)), ("wd_ufeedback", "0.004")]
+    if name == "neighbourhood":   # demo/neighborhoodModel: global neighbourhood weights + wd_global
+        return base + [("base_score", "3"), ("num_global", str(a.globals)), ("wd_global", "0.001")]
+    raise ValueError(name)
 
 
 class HipEvents:
@@ -89,47 +217,304 @@ def rmse(pred, label):
     return float(np.sqrt(np.mean(d * d)))
 
 
-def cpu_baseline_and_parity(a, trainer, u, i, r, test, log):
-    """Times the reference CPU path on a prefix sample and checks the GPU engine against it bit for bit
-    on that same prefix.  Returns (cpu_baseline dict, parity dict)."""
-    import svdfeature_amd as sa
+def make_trainer(sa, name, a, factor, device, oracle_kind=None):
+    fmt, act = WORKLOADS[name][0], WORKLOADS[name][1]
+    if oracle_kind:
+        from oracle import oracle   # checker only: never on the measured GPU path
+        t = oracle.OracleTrainer(oracle_kind, fmt, act)
+    else:
+        t = sa.Trainer(fmt, act, device=device)
+    t.seed(10)   # svd_feature.cpp:293
+    for k, v in workload_conf(name, a, factor):
+        t.set_param(k, v)
+    t.init_model()
+    t.init_trainer()
+    return t
+
+
+# =============================================================================== CPU baseline + in-run parity
+def cpu_baseline_and_parity(sa, name, a, factor, trainer, sample, n_total, log):
+    """Times the reference CPU path (1 thread) on a prefix `sample` of the workload and runs the same prefix through the
+    GPU bench path; every parameter must be identical bit for bit.  sample: ("triples", u, i, r) | ("pairs", u, p, q) |
+    ("blocks", BlockArrays) | ("csr", CSRData).  Returns (cpu_baseline dict, parity dict)."""
     from oracle import oracle   # checker only: never on the measured GPU path
     oracle.build()
     kind = "reference" if oracle.have_reference() else "port"
-    S = min(a.cpu_sample, len(r))
-    cpu = oracle.OracleTrainer(kind, 0, 0)
-    cpu.seed(10)
-    for k, v in conf_for(a):
-        cpu.set_param(k, v)
+    cpu = make_trainer(sa, name, a, factor, 0, oracle_kind=kind)
+    what = sample[0]
+    if what == "triples":
+        d, S = sa.CSRData.from_triples(*sample[1:]), len(sample[3])
+        ds = trainer.dataset_from_triples(*sample[1:])
+    elif what == "pairs":
+        d, S = sa.pairs_as_csr(*sample[1:]), len(sample[1])
+        ds = trainer.dataset_from_pairs(*sample[1:])
+    elif what == "csr":
+        d, S = sample[1], sample[1].num_row
+        ds = trainer.dataset_from_csr(d)
+    else:
+        d, S = sample[1].to_blocks(), sample[1].num_row
+        ds = trainer.dataset_from_blocks(sample[1])
     t0 = time.time()
-    cpu.init_model()
-    cpu.init_trainer()
-    log("cpu baseline (%s): init %.1fs" % (kind, time.time() - t0))
-    d = sa.CSRData.from_triples(u[:S], i[:S], r[:S])
-    t0 = time.time()
-    cpu.update_batch(d)
+    if what == "blocks":
+        for b in d:
+            cpu.update_block(b)
+    else:
+        cpu.update_batch(d)
     dt = time.time() - t0
-    log("cpu baseline: %d instances in %.2fs = %.3f M inst/s" % (S, dt, S / dt / 1e6))
-    base = {"value": S / dt, "unit": "instances/s", "cores": 1, "kind": kind,
-            "sample": "first %d of the %d ratings (same stream, same seed-10 init), 1 pass, data preloaded in memory, "
-                      "model init and I/O excluded; host has %d logical cores" % (S, len(r), os.cpu_count())}
-    # parity: the GPU engine (same init) runs the same prefix through the bench path
-    ds = trainer.dataset_from_triples(u[:S], i[:S], r[:S])
+    unit = WORKLOADS[name][4]
+    log("%s cpu baseline (%s): %d in %.2fs = %.3f M %s" % (name, kind, S, dt, S / dt / 1e6, unit))
+    base = {"value": S / dt, "unit": unit, "cores": 1, "kind": kind,
+            "sample": "first %d of the %d %s (same stream, same seed-10 init), 1 pass, data preloaded in memory, "
+                      "model init and I/O excluded; host has %d logical cores" % (S, n_total, unit.split("/")[0], os.cpu_count())}
     trainer.train_dataset(ds)
-    ok = True
-    for name in ("W_item", "i_bias", "u_bias", "W_user"):
-        g, c = trainer.view(name), cpu.view(name)
-        same = np.array_equal(g.view(np.uint32), c.view(np.uint32))
-        ok = ok and same
-    tu, ti, tr = test
-    dtest = sa.CSRData.from_triples(tu, ti, tr)
-    par = {"checked": "all parameters after %d sequential SGD updates vs the %s CPU path" % (S, kind),
-           "bit_exact": bool(ok), "rmse_gpu": rmse(trainer.predict_batch(dtest), tr),
-           "rmse_cpu": rmse(cpu.predict_batch(dtest), tr)}
+    ok, checked = True, []
+    for vname in ("W_item", "i_bias", "u_bias", "W_user", "g_bias", "W_ufeedback", "ufeedback_bias"):
+        g, c = trainer.view(vname), cpu.view(vname)
+        if g is None or c is None or g.size == 0:
+            continue
+        checked.append(vname)
+        ok = ok and np.array_equal(g.view(np.uint32), c.view(np.uint32))
+    par = {"checked": "%s after %d sequential SGD updates vs the %s CPU path" % ("/".join(checked), S, kind), "bit_exact": bool(ok)}
     ds.close()
     cpu.close()
-    log("parity on the prefix: bit_exact=%s rmse gpu %.6f cpu %.6f" % (ok, par["rmse_gpu"], par["rmse_cpu"]))
+    log("%s parity on the prefix: bit_exact=%s" % (name, ok))
     return base, par
+
+
+# =============================================================================== one workload
+def run_workload(name, a, env, steps, warmup, main_line):
+    """Builds the workload, trains warmup + steps passes, returns the result dict (rank 0) or None."""
+    import svdfeature_amd as sa
+    from svdfeature_amd.multi_gpu import HipShard, Pairs, ShardedTrainer, defer_tails, shard_block_windows, shard_pair_windows, shard_windows
+    torch, dist, rank, world, local_rank, log = env["torch"], env["dist"], env["rank"], env["world"], env["local_rank"], env["log"]
+    factor = a.factor if (main_line and a.factor) else WORKLOADS[name][2]
+    unit = WORKLOADS[name][4]
+    t0 = time.time()
+    quality = {}
+    # ---- data (every rank generates the same stream from the same seed, then keeps its shard)
+    if name == "basicmf":
+        n = a.ratings
+        u, i, r = synth_triples(n + 1_000_000, a.users, a.items)
+        test = (u[n:n + 200000], i[n:n + 200000], r[n:n + 200000])
+        u, i, r = u[:n], i[:n], r[:n]
+        per_item = n / max(a.items, 1)
+        sample = ("triples", u[:a.cpu_sample], i[:a.cpu_sample], r[:a.cpu_sample])
+    elif name == "pairwise":
+        n = a.pairs
+        u, p, q = synth_pairs(n + 200_000, a.users, a.items)
+        test = (u[n:], p[n:], q[n:])
+        u, p, q = u[:n], p[:n], q[:n]
+        per_item = 2.0 * n / max(a.items, 1)
+        S = min(n, a.cpu_sample // 4)
+        sample = ("pairs", u[:S], p[:S], q[:S])
+    elif name == "svdpp":
+        nblk = a.svdpp_users
+        train, test = synth_user_blocks(nblk, a.svdpp_per_user, a.users, a.items)
+        n = train.num_row
+        per_item = n / max(a.items, 1)
+        sample = ("blocks", train.slice(0, min(nblk, max(1, (a.cpu_sample // 8) // a.svdpp_per_user))))
+    else:
+        n = a.neighbour_rows
+        d_all = synth_neighbourhood(n + 100_000, a.users, a.items, a.globals, 4)
+        test = d_all.slice_rows(n, n + 100_000)
+        d_all = d_all.slice_rows(0, n)
+        per_item = n / max(a.items, 1)
+        sample = ("csr", d_all.slice_rows(0, min(n, a.cpu_sample // 8)))
+    log("%s: synthetic data (%d %s per pass) in %.1fs" % (name, n, unit.split("/")[0], time.time() - t0))
+
+    t0 = time.time()
+    tr = make_trainer(sa, name, a, factor, local_rank)
+    if name == "basicmf" and a.groups_per_wave:
+        tr.set_knob("groups_per_wave", a.groups_per_wave)
+    tr.set_knob("use_graph", a.use_graph)
+    for kv in a.knob:
+        kname, value = kv.split("=")
+        tr.set_knob(kname, int(value))
+    log("%s: model init (libc rand) + upload: %.1fs" % (name, time.time() - t0))
+
+    cpu_base, parity = None, None
+    if rank == 0 and not a.no_cpu_baseline:
+        cpu_base, parity = cpu_baseline_and_parity(sa, name, a, factor, tr, sample, n, log)
+        if world > 1:
+            parity = None   # the N-rank result is window-synchronous SGD: accuracy contract, not bit parity (DESIGN.md 6)
+        # fresh model for the measured run: the parity prefix trained this one
+        tr.close()
+        tr = make_trainer(sa, name, a, factor, local_rank)
+        tr.set_knob("use_graph", a.use_graph)
+        if name == "basicmf" and a.groups_per_wave:
+            tr.set_knob("groups_per_wave", a.groups_per_wave)
+        for kv in a.knob:
+            kname, value = kv.split("=")
+            tr.set_knob(kname, int(value))
+
+    # ---- schedule the instance stream once and keep it in HBM
+    t0 = time.time()
+    adaptor = HipShard(tr, torch, torch.device("cuda", local_rank))
+    if a.windows > 0:
+        nwin = a.windows
+    else:
+        # updates per item per window that keep the accuracy contract (tools/rmse_contract_fullsize.py, DESIGN.md 6):
+        # 64 at 2 ranks, 42 at 3-4, 32 beyond for ratings; 50 for rank pairs (tests/test_multi_rank.py)
+        tgt = 50.0 if name == "pairwise" else (64.0 if world <= 2 else (42.0 if world <= 4 else 32.0))
+        nwin = max(1, int(np.ceil(per_item / tgt)))
+    if world == 1 and not a.force_exchange:
+        nwin = 1
+    if name == "basicmf":
+        shards = shard_windows(u, i, r, rank, world, nwin)
+    elif name == "pairwise":
+        shards = shard_pair_windows(u, p, q, rank, world, nwin)
+    elif name == "svdpp":
+        shards = shard_block_windows(train, rank, world, nwin) if (world > 1 or nwin > 1) else [train]
+    else:
+        assert world == 1, "the neighbourhood workload is single-GPU (BASELINE configs[3])"
+        shards = [d_all]
+    if nwin > 1 and a.defer_tails > 0 and name in ("basicmf", "pairwise"):
+        shards = defer_tails(shards, a.users, a.items, a.defer_tails)
+    if name == "neighbourhood":
+        wins = [tr.dataset_from_csr(d_all)]
+    else:
+        wins = adaptor.make_windows(shards)
+    sched_s = time.time() - t0
+    n_batches = sum(w.num_batches for w in wins)
+    alg_bytes = sum(w.algorithmic_bytes for w in wins)
+    my_n = sum(w.num_row for w in wins)
+    log("%s: scheduled %d into %d conflict-free batches (largest %d) in %.1fs" % (name, my_n, n_batches, max(w.max_batch for w in wins), sched_s))
+    st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange, half_delta=(a.delta_dtype == "fp16"))
+
+    def sync_all():
+        tr.synchronize()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        st.train_pass()
+    ev = HipEvents()
+    e0, e1 = ev.new(), ev.new()
+    launches0 = tr.counter(1)
+    sync_all()
+    t0 = time.perf_counter()
+    ev.record(e0, tr.stream())
+    for _ in range(steps):
+        st.train_pass()
+    ev.record(e1, tr.stream())
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev.elapsed_ms(e0, e1)
+    launches = tr.counter(1) - launches0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- held-out quality after the run; with N ranks every rank scores the test rows of the users it owns
+    def reduce_sum(vals):
+        if dist is None:
+            return vals
+        acc = torch.tensor(vals, dtype=torch.float64, device="cuda")
+        dist.all_reduce(acc)
+        return [float(x) for x in acc.tolist()]
+    if name == "basicmf":
+        tu, ti, tl = test
+        mine = (tu % world) == rank
+        pred = tr.predict_batch(sa.CSRData.from_triples(tu[mine], ti[mine], tl[mine]))
+        sse, cnt = reduce_sum([float(np.sum((pred.astype(np.float64) - tl[mine].astype(np.float64)) ** 2)), float(mine.sum())])
+        quality = {"rmse_test_after_run": float(np.sqrt(sse / max(cnt, 1.0)))}
+    elif name == "pairwise":
+        tu, tp, tq = test
+        mine = (tu % world) == rank
+        margin = tr.predict_batch(sa.pairs_as_csr(tu[mine], tp[mine], tq[mine]))   # score(pos) - score(neg): active_type 3 predicts the raw score
+        right, msum, cnt = reduce_sum([float(np.sum(margin > 0)), float(np.sum(margin, dtype=np.float64)), float(mine.sum())])
+        quality = {"pair_accuracy_test_after_run": right / max(cnt, 1.0), "mean_margin_test_after_run": msum / max(cnt, 1.0)}
+    elif name == "svdpp":
+        owner = test.block_user() % np.uint32(world)
+        mine = test.select(owner == rank)
+        dt_ = tr.dataset_from_blocks(mine)
+        pred = tr.predict_dataset(dt_)
+        dt_.close()
+        sse, cnt = reduce_sum([float(np.sum((pred.astype(np.float64) - mine.row_label.astype(np.float64)) ** 2)), float(mine.num_row)])
+        quality = {"rmse_test_after_run": float(np.sqrt(sse / max(cnt, 1.0)))}
+    else:
+        quality = {"rmse_test_after_run": rmse(tr.predict_batch(test), test.row_label)}
+
+    # ---- the dependency (DAG) bound of exact sequential semantics: levels x latency of ONE unit launched alone
+    dag = None
+    if rank == 0 and world == 1 and name in ("svdpp", "neighbourhood", "pairwise"):
+        if name == "svdpp":
+            one = tr.dataset_from_blocks(train.slice(0, 1))
+        elif name == "pairwise":
+            one = tr.dataset_from_pairs(u[:1], p[:1], q[:1])
+        else:
+            one = tr.dataset_from_csr(d_all.slice_rows(0, 1))
+        reps = 200
+        for _ in range(20):
+            tr.train_dataset(one)
+        tr.synchronize()
+        ev.record(e0, tr.stream())
+        for _ in range(reps):
+            tr.train_dataset(one)
+        ev.record(e1, tr.stream())
+        lat_us = ev.elapsed_ms(e0, e1) * 1e3 / reps
+        one.close()
+        dag = {"levels_per_pass": n_batches, "unit_latency_us": lat_us, "bound_ms_per_pass": n_batches * lat_us * 1e-3,
+               "measured_over_bound": (elapsed * 1e3 / steps) / max(n_batches * lat_us * 1e-3, 1e-9),
+               "what": "conflict-free levels of exact sequential semantics x the latency of one %s launched alone "
+                       "(back to back on one stream); a pass cannot be faster than this however fast the kernel streams"
+                       % ("user unit (%d rows + its feedback list)" % a.svdpp_per_user if name == "svdpp" else "instance")}
+
+    res = None
+    if rank == 0:
+        value = steps * n / elapsed
+        # dominant kernel: one launch per conflict-free batch.  algorithmic bytes per launch and average launch duration
+        # measured with HIP events on the engine's stream over the timed region (launch gaps included, so this is a lower
+        # bound on the in-kernel rate).
+        per_launch_bytes = alg_bytes * steps / max(launches, 1)
+        per_launch_us = ev_ms * 1e3 / max(launches, 1)
+        achieved = per_launch_bytes / (per_launch_us * 1e-6) / 1e9
+        traffic, traffic_src = None, None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if world == 1 and os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(name if name != "basicmf" else "hbm_bytes_per_launch")
+                if isinstance(traffic, dict):
+                    traffic = traffic.get("hbm_bytes_per_launch")
+                traffic_src = "profiles/hbm_traffic.json (builder's rocprofv3 PMC run of this command, not measured in this run)"
+            except Exception:
+                traffic = None
+        res = {
+            "value": value, "unit": unit, "ms_per_step": elapsed * 1e3 / steps,
+            "workload": {"basicmf": "basicMF synthetic %dx%d, %d ratings, k=%d fp32 (BASELINE configs[%d])" % (a.users, a.items, n, factor, 1 if world == 1 else 2),
+                         "pairwise": "pairwiseRank synthetic %dx%d, %d (user, pos, neg) pairs, k=%d fp32, active_type=3, no user bias (BASELINE configs[4])" % (a.users, a.items, n, factor),
+                         "svdpp": "implicitFeedback (SVD++) %d users x %d ratings, feedback set = own items, k=%d fp32 (BASELINE configs[3])" % (a.svdpp_users, a.svdpp_per_user, factor),
+                         "neighbourhood": "neighborhoodModel shape: %d ratings + 4 of %d global ids each, k=%d fp32 (BASELINE configs[3])" % (n, a.globals, factor)}[name],
+            "order": "uniform random (file order preserved: result == sequential SGD)" if world == 1 else
+                     "user-sharded, item-delta all-reduce (%s on the wire) every 1/%d pass" % (a.delta_dtype, nwin),
+            "conflict_free_batches_per_pass": n_batches, "schedule_build_s": round(sched_s, 2),
+            "parallelism": "1 GPU" if world == 1 else "dp%d user shards + RCCL all-reduce" % world,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": WORKLOADS[name][3], "launches": launches, "avg_launch_us": per_launch_us,
+                         "algorithmic_bytes_per_launch": per_launch_bytes,
+                         "algorithmic_bytes_per_instance": alg_bytes / max(my_n, 1)},
+            "cpu_baseline": cpu_base, "parity": parity, "dag_bound": dag,
+            # end to end: what a training run of `rounds` passes sees when the one-off schedule build is counted in
+            "end_to_end": {"rounds": 40, "value": 40 * n / (sched_s + 40 * elapsed / steps), "unit": unit,
+                           "what": "40 passes (demo/basicMF num_round) + the one-off schedule build + upload of this run"},
+        }
+        res.update(quality)
+    for w in wins:
+        w.close()
+    tr.close()
+    return res
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
 
 def main():
@@ -137,31 +522,50 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="basicmf", help="which BASELINE config is the main JSON line")
     ap.add_argument("--ratings", type=int, default=100_000_000)
+    ap.add_argument("--pairs", type=int, default=200_000_000, help="pairwise workload: rank pairs per pass (BASELINE configs[4])")
+    ap.add_argument("--svdpp-users", type=int, default=40_000)
+    ap.add_argument("--svdpp-per-user", type=int, default=100)
+    ap.add_argument("--neighbour-rows", type=int, default=4_000_000)
+    ap.add_argument("--globals", type=int, default=10_000)
     ap.add_argument("--users", type=int, default=1_000_000)
     ap.add_argument("--items", type=int, default=100_000)
-    ap.add_argument("--factor", type=int, default=64)
+    ap.add_argument("--factor", type=int, default=0, help="0 = the workload's configured width (64 for basicMF, 128 otherwise)")
     ap.add_argument("--windows", type=int, default=0,
                     help="item-delta exchanges per pass when --gpus > 1 (0 = chosen from the data density so that the "
                          "RMSE stays within 1e-4 of the sequential reference: about 64 ratings per item per window at "
                          "2 ranks, 32 at 4+ ranks; calibration in DESIGN.md section 6)")
     ap.add_argument("--delta-dtype", choices=["fp16", "fp32"], default="fp16",
                     help="wire format of the item-side window deltas when --gpus > 1 (parameters stay fp32)")
-    ap.add_argument("--cpu-sample", type=int, default=20_000_000)
+    ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="basicMF ratings of the CPU baseline sample (other workloads scale it down)")
     ap.add_argument("--groups-per-wave", type=int, default=0)
     ap.add_argument("--knob", action="append", default=[], help="extra tuning knob name=value (svdf_set_knob), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--secondary", default="auto", help="comma list of secondary workloads for the N=1 line (auto = all three with the default main line, none otherwise)")
+    ap.add_argument("--secondary-steps", type=int, default=2)
     ap.add_argument("--defer-tails", type=float, default=0.05,
                     help="N>1: batches smaller than this fraction of a window's largest, at the end of the window, move to the next window (0 = off)")
     ap.add_argument("--use-graph", type=int, default=0, help="replay each resident dataset's pass as a captured hipGraph (0 = plain launches)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="debug: run the item-delta exchange path even with one rank (exercises the N>1 code on one GPU)")
     a = ap.parse_args()
+    if not a.factor and a.workload == "basicmf":
+        a.factor = 64
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: become the launcher of our own N ranks (one process per GPU, RCCL)
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == a.gpus, "--gpus must equal WORLD_SIZE (launch with torch.distributed.run for N > 1)"
+    if world != a.gpus:
+        print("[bench] WORLD_SIZE=%d overrides --gpus %d" % (world, a.gpus), file=sys.stderr)
+        a.gpus = world
 
     def log(msg):
         if rank == 0:
@@ -169,8 +573,7 @@ def main():
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     import torch
-    import svdfeature_amd as sa
-    from svdfeature_amd.multi_gpu import HipShard, ShardedTrainer, defer_tails, shard_windows
+    import svdfeature_amd as sa   # noqa: F401  (fails loudly when the HIP library is missing: there is no CPU fallback)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
     # debug only (1-GPU boxes): SVDF_BENCH_SHARE_GPU=1 puts every rank on GPU 0 and exchanges through gloo, so the
     # whole N>1 flow (sharding, windows, exchange, timing, RMSE reduction) can be exercised without N GPUs
@@ -187,128 +590,42 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    env = {"torch": torch, "dist": dist, "rank": rank, "world": world, "local_rank": local_rank, "log": log}
 
-    t0 = time.time()
-    n = a.ratings
-    u, i, r = synth_triples(n + 1_000_000, a.users, a.items)
-    test = (u[n:], i[n:], r[n:])
-    u, i, r = u[:n], i[:n], r[:n]
-    log("synthetic data: %d ratings, %d users x %d items in %.1fs" % (n, a.users, a.items, time.time() - t0))
-
-    t0 = time.time()
-    tr = sa.Trainer(0, 0, device=local_rank)
-    tr.seed(10)   # svd_feature.cpp:293
-    for k, v in conf_for(a):
-        tr.set_param(k, v)
-    tr.init_model()
-    tr.init_trainer()
-    if a.groups_per_wave:
-        tr.set_knob("groups_per_wave", a.groups_per_wave)
-    tr.set_knob("use_graph", a.use_graph)
-    for kv in a.knob:
-        name, value = kv.split("=")
-        tr.set_knob(name, int(value))
-    log("model init (libc rand, %d normals) + upload: %.1fs" % ((a.users + a.items) * a.factor, time.time() - t0))
-
-    cpu_base, parity = None, None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        cpu_base, parity = cpu_baseline_and_parity(a, tr, u, i, r, test, log)
-
-    # ---- schedule the instance stream once and keep it in HBM
-    t0 = time.time()
-    adaptor = HipShard(tr, torch, torch.device("cuda", local_rank))
-    if a.windows <= 0:
-        # ratings per item per window that keep |dRMSE| <= 1e-4 with a factor ~1.6 of margin at the full configs[2] size
-        # (tools/rmse_contract_fullsize.py): 64 at 2 ranks, 42 at 3-4, 32 beyond
-        per_item = a.ratings / max(a.items, 1)
-        a.windows = max(1, int(np.ceil(per_item / (64.0 if world <= 2 else (42.0 if world <= 4 else 32.0)))))
-    nwin = 1 if (world == 1 and not a.force_exchange) else a.windows
-    shards = shard_windows(u, i, r, rank, world, nwin)
-    if nwin > 1 and a.defer_tails > 0:
-        shards = defer_tails(shards, a.users, a.items, a.defer_tails)
-    wins = adaptor.make_windows(shards)
-    sched_s = time.time() - t0
-    n_batches = sum(w.num_batches for w in wins)
-    alg_bytes = sum(w.algorithmic_bytes for w in wins)
-    my_n = sum(w.num_row for w in wins)
-    log("scheduled %d instances into %d conflict-free batches (largest %d) in %.1fs"
-        % (my_n, n_batches, max(w.max_batch for w in wins), sched_s))
-    st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange, half_delta=(a.delta_dtype == "fp16"))
-
-    def sync_all():
-        tr.synchronize()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        st.train_pass()
-    ev = HipEvents()
-    e0, e1 = ev.new(), ev.new()
-    launches0 = tr.counter(1)
-    sync_all()
-    t0 = time.perf_counter()
-    ev.record(e0, tr.stream())
-    for _ in range(a.steps):
-        st.train_pass()
-    ev.record(e1, tr.stream())
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    ev_ms = ev.elapsed_ms(e0, e1)
-    launches = tr.counter(1) - launches0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-
-    # held-out RMSE after the run; with N ranks every rank scores the test rows of the users it owns
-    tu, ti, tl = test[0][:200000], test[1][:200000], test[2][:200000]
-    mine = (tu % world) == rank
-    pred = tr.predict_batch(sa.CSRData.from_triples(tu[mine], ti[mine], tl[mine]))
-    sse = float(np.sum((pred.astype(np.float64) - tl[mine].astype(np.float64)) ** 2))
-    cnt = float(mine.sum())
-    if dist is not None:
-        acc = torch.tensor([sse, cnt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(acc)
-        sse, cnt = float(acc[0].item()), float(acc[1].item())
-    final_rmse = float(np.sqrt(sse / max(cnt, 1.0)))
-
+    main_res = run_workload(a.workload, a, env, a.steps, a.warmup, True)
+    secondary = {}
+    sec = a.secondary
+    if sec == "auto":
+        sec = "pairwise,svdpp,neighbourhood" if (a.workload == "basicmf" and world == 1 and a.ratings == 100_000_000) else ""
+    for name in [s for s in sec.split(",") if s]:
+        if name == a.workload or (world > 1 and name == "neighbourhood"):
+            continue
+        t0 = time.time()
+        r = run_workload(name, a, env, a.secondary_steps, 1, False)
+        if r is not None:
+            r["wall_s"] = round(time.time() - t0, 1)
+            secondary["%s_k%d" % (name, WORKLOADS[name][2])] = r
     if rank == 0:
-        value = a.steps * n / elapsed
-        # dominant kernel: k_basicmf (one launch per conflict-free batch).  algorithmic bytes per launch and
-        # average launch duration measured with HIP events on the engine's stream over the timed region
-        # (launch gaps included, so this is a lower bound on the in-kernel rate).
-        per_launch_bytes = alg_bytes * a.steps / max(launches, 1)
-        per_launch_us = ev_ms * 1e3 / max(launches, 1)
-        achieved = per_launch_bytes / (per_launch_us * 1e-6) / 1e9
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if world == 1 and os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        m = main_res
+        metric = {"basicmf": "training instances/sec (SGD updates/s), basicMF k=%d" % (a.factor or 64),
+                  "pairwise": "training pairs/sec (SGD updates/s), pairwiseRank k=%d" % (a.factor or 128),
+                  "svdpp": "training instances/sec (SGD updates/s), SVD++ implicit feedback k=%d" % (a.factor or 128),
+                  "neighbourhood": "training instances/sec (SGD updates/s), neighbourhood model k=%d" % (a.factor or 128)}[a.workload]
         out = {
-            "metric": "training instances/sec (SGD updates/s), basicMF k=%d" % a.factor,
-            "value": value, "unit": "instances/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": elapsed * 1e3 / a.steps, "higher_is_better": True,
+            "metric": metric, "value": m["value"], "unit": m["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": m["ms_per_step"], "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "basicMF synthetic %dx%d, %d ratings, k=%d fp32 (BASELINE configs[%d])"
-                                   % (a.users, a.items, n, a.factor, 1 if world == 1 else 2),
-                       "order": "uniform random (file order preserved: result == sequential SGD)" if world == 1 else
-                                "user-sharded, item-delta all-reduce (%s on the wire) every 1/%d pass" % (a.delta_dtype, nwin),
-                       "conflict_free_batches_per_pass": n_batches, "schedule_build_s": round(sched_s, 2),
-                       "parallelism": "1 GPU" if world == 1 else "dp%d user shards + RCCL all-reduce" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "k_basicmf", "launches": launches, "avg_launch_us": per_launch_us,
-                         "algorithmic_bytes_per_launch": per_launch_bytes,
-                         "algorithmic_bytes_per_instance": alg_bytes / max(my_n, 1)},
-            "cpu_baseline": cpu_base,
-            "parity": parity,
-            "rmse_test_after_run": final_rmse,
+            "config": {"workload": m["workload"], "order": m["order"],
+                       "conflict_free_batches_per_pass": m["conflict_free_batches_per_pass"], "schedule_build_s": m["schedule_build_s"],
+                       "parallelism": m["parallelism"]},
+            "roofline": m["roofline"], "cpu_baseline": m["cpu_baseline"], "parity": m["parity"],
+            "end_to_end": m["end_to_end"],
         }
+        for k in ("rmse_test_after_run", "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound"):
+            if m.get(k) is not None:
+                out[k] = m[k]
+        if secondary:
+            out["secondary"] = secondary
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
