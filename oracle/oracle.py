@@ -14,6 +14,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_SO = os.path.join(HERE, "libsvdf_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libsvdf_ref.so")
+REF_FULL_SO = os.path.join(HERE, "_ref", "libsvdf_ref_full.so")   # the reference's default factory: variant solvers (extend_type 2 / 15)
 
 VIEW = {"u_bias": 0, "W_user": 1, "i_bias": 2, "W_item": 3, "g_bias": 4, "ufeedback_bias": 5, "W_ufeedback": 6}
 
@@ -33,13 +34,17 @@ def have_reference():
     return os.path.exists(REF_SO)
 
 
+def have_reference_full():
+    return os.path.exists(REF_FULL_SO)
+
+
 _libs = {}
 
 
 def _load(kind):
     if kind in _libs:
         return _libs[kind]
-    path = PORT_SO if kind == "port" else REF_SO
+    path = PORT_SO if kind == "port" else (REF_FULL_SO if kind == "reference_full" else REF_SO)
     if not os.path.exists(path):
         build()
     lib = C.CDLL(path, mode=C.RTLD_LOCAL)

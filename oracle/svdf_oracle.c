@@ -62,6 +62,7 @@ typedef struct {
 typedef struct { unsigned index; float value; } sf_entry;
 typedef struct { unsigned num_row; unsigned *row_ptr; sf_entry *data; size_t ndata; } sparse_feat;
 
+#define IMFB_MAX 64
 struct svdo_trainer {
     uint8_t mtype[4]; /* format_type, active_type, extend_type, variant_type */
     model_param mp;
@@ -80,6 +81,13 @@ struct svdo_trainer {
     unsigned sample_counter;
     unsigned *ref_user, *ref_item, *ref_global;
     param_set u_param, i_param, g_param;
+    /* extend_type 2: SVDPPMultiIMFB (solvers/multi-imfb/apex_multi_imfb.h:33-44) -- a stack of implicit-feedback levels */
+    struct { int num_ufeedback; float norm, tmp_bias, old_bias; float *tmp, *old; } imfb[IMFB_MAX];
+    int imfb_top, imfb_alloc;
+    unsigned char imfb_disable[IMFB_MAX];
+    /* extend_type 15: SVDBiLinearTrainer (solvers/bilinear/apex_svd_bilinear.h:30-77): BParam + W_bi ride along in the model file */
+    struct { int num_bi_feedback, start_ufeedback, reserved[32]; } bparam;
+    float *W_bi; int bi_allocated, reg_bi_feedback;
 };
 
 static void die(const char *msg) { /* apex-utils/apex_utils.h:47-50 */
@@ -339,6 +347,8 @@ void svdo_destroy(svdo_trainer *t) {
     if (!t) return;
     free_model(t);
     free(t->tmp_u); free(t->tmp_i); free(t->tmp_fb); free(t->old_fb);
+    for (int i = 0; i < t->imfb_alloc; i++) { free(t->imfb[i].tmp); free(t->imfb[i].old); }
+    free(t->W_bi);
     free(t->ref_user); if (t->ref_item != t->ref_user) free(t->ref_item); free(t->ref_global);
     free(t->feat_user.row_ptr); free(t->feat_user.data);
     free(t->feat_item.row_ptr); free(t->feat_item.data);
@@ -350,6 +360,18 @@ void svdo_destroy(svdo_trainer *t) {
 
 /* apex_svd_base.h:126-136 */
 void svdo_set_param(svdo_trainer *t, const char *name, const char *val) {
+    if (t->mtype[2] == 2 && !strcmp(name, "ufeedback_disable_level")) { /* apex_multi_imfb.h:58-67 */
+        int level = atoi(val);
+        assert_true(level >= 0 && level < IMFB_MAX, "oracle: ufeedback_disable_level beyond IMFB_MAX");
+        t->imfb_disable[level] = 1;
+    }
+    if (t->mtype[2] == 15) { /* apex_svd_bilinear.h:187-193 */
+        if (!strcmp(name, "reg_bi_feedback")) t->reg_bi_feedback = atoi(val);
+        if (t->bi_allocated == 0) {
+            if (!strcmp(name, "num_bi_feedback")) t->bparam.num_bi_feedback = atoi(val);
+            if (!strcmp(name, "start_ufeedback")) t->bparam.start_ufeedback = atoi(val);
+        }
+    }
     if (!strcmp(name, "feature_user")) strcpy(t->name_feat_user, val);
     if (!strcmp(name, "feature_item")) strcpy(t->name_feat_item, val);
     tp_set_param(&t->tp, name, val);
@@ -429,9 +451,15 @@ static void rand_init(svdo_trainer *t) {
     }
 }
 
+static void bi_alloc(svdo_trainer *t) { /* BModel::alloc_space apex_svd_bilinear.h:49-54: W_bi[num_item][num_bi_feedback] = 0 */
+    free(t->W_bi);
+    t->W_bi = (float *)calloc((size_t)t->mp.num_item * (size_t)(t->bparam.num_bi_feedback > 0 ? t->bparam.num_bi_feedback : 0) + 1, sizeof(float));
+    t->bi_allocated = 1;
+}
 void svdo_init_model(svdo_trainer *t) { /* apex_svd_base.h:146-149 */
     alloc_space(t);
     rand_init(t);
+    if (t->mtype[2] == 15) bi_alloc(t); /* apex_svd_bilinear.h:202-205 */
 }
 
 /* apex_svd_base.h:151-173 (+ :499-503 for the user-group trainer) */
@@ -524,11 +552,24 @@ static void load_model(svdo_trainer *t, FILE *fi) {
         load_2d(fi, t->W_ufb, p->num_ufeedback, p->num_factor, t->pitch);
     }
 }
+/* BModel::save_to_file / load_from_file (apex_svd_bilinear.h:60-68): BParam, then W_bi as a 2D tensor.  Training never
+ * changes W_bi: SVDPPFeature::update calls ITS OWN non-virtual prepare_ufeedback (apex_svd_base.h:523,571), so the derived
+ * class's version that would fill up_index is never reached and get_bias_plugin / update_bias_plugin loop over nothing. */
+static void bi_save(svdo_trainer *t, FILE *fo) {
+    fwrite(&t->bparam, sizeof(t->bparam), 1, fo);
+    save_2d(fo, t->W_bi, t->mp.num_item, t->bparam.num_bi_feedback, t->bparam.num_bi_feedback);
+}
+static void bi_load(svdo_trainer *t, FILE *fi) {
+    assert_true(fread(&t->bparam, sizeof(t->bparam), 1, fi) > 0, "load from file");
+    if (t->bi_allocated == 0) bi_alloc(t);
+    load_2d(fi, t->W_bi, t->mp.num_item, t->bparam.num_bi_feedback, t->bparam.num_bi_feedback);
+}
 int svdo_save_model_path(svdo_trainer *t, const char *path, int with_type_header) {
     FILE *fo = fopen(path, "wb");
     if (!fo) return -1;
     if (with_type_header) fwrite(t->mtype, 1, 4, fo);
     save_model(t, fo);
+    if (t->mtype[2] == 15) bi_save(t, fo);
     fclose(fo);
     return 0;
 }
@@ -537,6 +578,7 @@ int svdo_load_model_path(svdo_trainer *t, const char *path, int with_type_header
     if (!fi) return -1;
     if (with_type_header) assert_true(fread(t->mtype, 1, 4, fi) == 4, "loading model");
     load_model(t, fi);
+    if (t->mtype[2] == 15) bi_load(t, fi);
     fclose(fi);
     return 0;
 }
@@ -672,6 +714,11 @@ static double calc_bias(svdo_trainer *t, const elem *f) {
             int n = sf_get(&t->feat_user, uid, &vec);
             for (int j = 0; j < n; j++) sum += t->u_bias[vec[j].index] * vec[j].value;
         }
+        if (t->mtype[2] == 2) { /* apex_multi_imfb.h:80-86 */
+            float s2 = 0.0f;
+            for (int i = 0; i < t->imfb_top; i++) s2 += t->imfb[i].tmp_bias;
+            sum += s2;
+        } else
         sum += is_user_group(t) ? t->tmp_fb_bias : 0.0f; /* get_bias_svdpp :433-435,509-511 */
     }
     sum += 0.0f; /* get_bias_plugin :436-438 */
@@ -689,6 +736,11 @@ static double calc_bias(svdo_trainer *t, const elem *f) {
 static void prepare_tmp(svdo_trainer *t, const elem *f) {
     const int k = t->mp.num_factor;
     const sf_entry *vec;
+    if (t->mtype[2] == 2) { /* apex_multi_imfb.h:70-79 */
+        if (t->imfb_top == 0) for (int j = 0; j < k; j++) t->tmp_u[j] = 0.0f;
+        else memcpy(t->tmp_u, t->imfb[0].tmp, sizeof(float) * (size_t)k);
+        for (int i = 1; i < t->imfb_top; i++) for (int j = 0; j < k; j++) t->tmp_u[j] = t->tmp_u[j] + t->imfb[i].tmp[j];
+    } else
     if (is_user_group(t)) memcpy(t->tmp_u, t->tmp_fb, sizeof(float) * (size_t)k); /* :506-508 */
     else for (int j = 0; j < k; j++) t->tmp_u[j] = 0.0f;                          /* :430-432 */
     for (int j = 0; j < k; j++) t->tmp_i[j] = 0.0f;
@@ -720,6 +772,18 @@ static float pred(svdo_trainer *t, const elem *f) {
 static void update_svdpp(svdo_trainer *t, float err) {
     const int k = t->mp.num_factor;
     float lr = t->tp.learning_rate * t->tp.scale_lr_ufeedback;
+    if (t->mtype[2] == 2) { /* apex_multi_imfb.h:87-98 */
+        for (int i = 0; i < t->imfb_top; i++) {
+            if (t->imfb_disable[i] || t->imfb[i].num_ufeedback == 0) continue;
+            axpy(t->imfb[i].tmp, t->tmp_i, (float)(double)(lr * err * t->imfb[i].norm), k);
+            scale(t->imfb[i].tmp, (float)(double)(1.0f - lr * t->tp.wd_ufeedback), k);
+            if (t->mp.no_user_bias == 0) {
+                t->imfb[i].tmp_bias += lr * err * t->imfb[i].norm;
+                t->imfb[i].tmp_bias *= (1.0f - lr * t->tp.wd_ufeedback_bias);
+            }
+        }
+        return;
+    }
     axpy(t->tmp_fb, t->tmp_i, (float)(double)(lr * err * t->norm_fb), k);
     scale(t->tmp_fb, (float)(double)(1.0f - lr * t->tp.wd_ufeedback), k);
     if (t->mp.no_user_bias == 0) {
@@ -758,8 +822,10 @@ static void update_no_decay(svdo_trainer *t, float err, const elem *f) {
             axpy(t->W_item + (size_t)vec[j].index * t->pitch, t->tmp_u, s2, k);
         }
     }
-    if (is_user_group(t)) update_svdpp(t, err);
-    /* update_bias_plugin :439-440 no-op */
+    if (is_user_group(t) || t->mtype[2] == 2) update_svdpp(t, err);
+    /* update_bias_plugin :439-440 no-op; bilinear (apex_svd_bilinear.h:148-162): nothing but reg_feedback(lr, iid) per item entry */
+    if (t->mtype[2] == 15 && f->ni > 0)
+        assert_true(t->reg_bi_feedback >= 0 && t->reg_bi_feedback <= 5, "unknown bi feedback decay method");
 }
 /* apex_svd_base.h:456-462 */
 static void update_inner(svdo_trainer *t, const elem *f) {
@@ -833,9 +899,61 @@ static void update_ufeedback(svdo_trainer *t, int nfb, const unsigned *idx, cons
         if (t->mp.no_user_bias == 0) t->ufb_bias[fid] += t->tmp_fb_bias * v;
     }
 }
+/* ---- extend_type 2, apex_multi_imfb.h:121-195 ---- */
+static void imfb_push(svdo_trainer *t, int nfb, const unsigned *idx, const float *val) { /* push_ufeedback :161-171 + prepare_ufeedback :121-137 */
+    const int k = t->mp.num_factor;
+    assert_true(t->imfb_top < IMFB_MAX, "oracle: more nested implicit-feedback levels than IMFB_MAX");
+    if (t->imfb_top == t->imfb_alloc) {
+        t->imfb[t->imfb_alloc].tmp = (float *)calloc((size_t)t->pitch + 4, sizeof(float));
+        t->imfb[t->imfb_alloc].old = (float *)calloc((size_t)t->pitch + 4, sizeof(float));
+        t->imfb_alloc++;
+    }
+    float *tmp = t->imfb[t->imfb_top].tmp;
+    float norm = 0.0f, bias = 0.0f;
+    for (int j = 0; j < k; j++) tmp[j] = 0.0f;
+    for (int i = 0; i < nfb; i++) {
+        unsigned fid = idx[i];
+        float v = val[i];
+        assert_true(fid < (unsigned)t->mp.num_ufeedback, "ufeedback id exceed bound");
+        axpy(tmp, t->W_ufb + (size_t)fid * t->pitch, (float)(double)v, k);
+        norm += v * v;
+        if (t->mp.no_user_bias == 0) bias += t->ufb_bias[fid] * v;
+    }
+    t->imfb[t->imfb_top].norm = norm;
+    t->imfb[t->imfb_top].tmp_bias = bias;
+    t->imfb[t->imfb_top].old_bias = bias;
+    t->imfb[t->imfb_top].num_ufeedback = nfb;
+    memcpy(t->imfb[t->imfb_top].old, tmp, sizeof(float) * (size_t)k);
+    t->imfb_top++;
+}
+static void imfb_scatter(svdo_trainer *t, int lvl, int nfb, const unsigned *idx, const float *val) { /* update_ufeedback :138-153 */
+    const int k = t->mp.num_factor;
+    if (nfb == 0) return;
+    float *tmp = t->imfb[lvl].tmp;
+    for (int j = 0; j < k; j++) tmp[j] = tmp[j] - t->imfb[lvl].old[j];
+    t->imfb[lvl].tmp_bias -= t->imfb[lvl].old_bias;
+    scale(tmp, (float)(double)(1.0f / t->imfb[lvl].norm), k);
+    t->imfb[lvl].tmp_bias *= 1.0f / t->imfb[lvl].norm;
+    for (int i = 0; i < nfb; i++) {
+        unsigned fid = idx[i];
+        float v = val[i];
+        axpy(t->W_ufb + (size_t)fid * t->pitch, tmp, (float)(double)v, k);
+        if (t->mp.no_user_bias == 0) t->ufb_bias[fid] += t->imfb[lvl].tmp_bias * v;
+    }
+}
 void svdo_update_block(svdo_trainer *t, int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb,
                        int num_row, const float *row_label, const int *row_ptr,
                        const unsigned *feat_index, const float *feat_value) {
+    if (t->mtype[2] == 2) { /* SVDPPMultiIMFB::update :173-192 */
+        if (extend_tag == 0 || extend_tag == 1) imfb_push(t, nfb, idx_fb, val_fb);
+        svdo_update_csr_batch(t, num_row, row_label, row_ptr, feat_index, feat_value);
+        if (extend_tag == 0 || extend_tag == 2) {
+            assert_true(t->imfb_top != 0, "start tag,end tag error in implicit feedback");
+            --t->imfb_top;
+            if (!t->imfb_disable[t->imfb_top]) imfb_scatter(t, t->imfb_top, nfb, idx_fb, val_fb);
+        }
+        return;
+    }
     if (extend_tag == 0 || extend_tag == 1) { /* DEFAULT or START_TAG */
         prepare_ufeedback(t, nfb, idx_fb, val_fb);
         t->old_fb_bias = t->tmp_fb_bias;
@@ -847,6 +965,15 @@ void svdo_update_block(svdo_trainer *t, int nfb, int extend_tag, const unsigned 
 void svdo_predict_block(svdo_trainer *t, int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb,
                         int num_row, const float *row_label, const int *row_ptr,
                         const unsigned *feat_index, const float *feat_value, float *out) {
+    if (t->mtype[2] == 2) { /* SVDPPMultiIMFB::predict :193-207 */
+        if (extend_tag == 0 || extend_tag == 1) imfb_push(t, nfb, idx_fb, val_fb);
+        svdo_predict_csr_batch(t, num_row, row_label, row_ptr, feat_index, feat_value, out);
+        if (extend_tag == 0 || extend_tag == 2) {
+            assert_true(t->imfb_top != 0, "start tag,end tag error in implicit feedback");
+            --t->imfb_top;
+        }
+        return;
+    }
     if (extend_tag == 0 || extend_tag == 1) prepare_ufeedback(t, nfb, idx_fb, val_fb);
     svdo_predict_csr_batch(t, num_row, row_label, row_ptr, feat_index, feat_value, out);
 }

@@ -167,6 +167,11 @@ template <int V> __device__ __forceinline__ void scale4(WideRow<V> &d, float a) 
 #pragma unroll
     for (int v = 0; v < V; v++) scale4(d.v[v], a);
 }
+__device__ __forceinline__ void add_rows(float4 &d, const float4 s) { d.x = d.x + s.x; d.y = d.y + s.y; d.z = d.z + s.z; d.w = d.w + s.w; }  // tensor += tensor
+template <int V> __device__ __forceinline__ void add_rows(WideRow<V> &d, const WideRow<V> &s) {
+#pragma unroll
+    for (int v = 0; v < V; v++) add_rows(d.v[v], s.v[v]);
+}
 __device__ __forceinline__ void sub4(float4 &d, const float4 s) { d.x = d.x - s.x; d.y = d.y - s.y; d.z = d.z - s.z; d.w = d.w - s.w; }  // K5
 template <int V> __device__ __forceinline__ void sub4(WideRow<V> &d, const WideRow<V> &s) {
 #pragma unroll

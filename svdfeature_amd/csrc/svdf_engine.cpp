@@ -60,6 +60,7 @@ template struct DevBuf<float>;
 template struct DevBuf<int>;
 template struct DevBuf<unsigned>;
 template struct DevBuf<DevUnit>;
+template struct DevBuf<DevBlk>;
 
 // =============================================================================== scheduler
 void build_schedule(const std::vector<int> &levels, int base, Schedule &out) {
@@ -182,6 +183,11 @@ Engine::Engine(TypeParam mtype, int device) : mtype_(mtype) {
     i_param_.prefix_a = "ip:"; i_param_.prefix_b = "uip:";
     g_param_.prefix_a = "gp:"; g_param_.prefix_b = "gp:";
     memset(&dev_params_, 0, sizeof(dev_params_));
+    memset(&bi_param_, 0, sizeof(bi_param_));
+    // apex_svd.cpp:32-44 dispatches on extend_type: 2 = multi-level implicit feedback, 15 = bilinear, 30 / 31 = GBRT, 1 = SVD++
+    if (mtype.extend_type != 0 && mtype.extend_type != 1 && mtype.extend_type != 2 && mtype.extend_type != 15)
+        fail("svdfeature_amd: extend_type " + std::to_string((int)mtype.extend_type) +
+             " is not supported (0 / 1 base solver, 2 multi-level implicit feedback, 15 bilinear; the GBRT solvers 30 / 31 are another algorithm family)");
     if (device == -2) {   // host-only handle: config / model file / scheduler logic, no compute
         host_only_ = true;
         return;
@@ -242,6 +248,18 @@ void Engine::set_param(const char *name, const char *val) {  // apex_svd_base.h:
     if (!strcmp(name, "feature_user")) name_feat_user_ = val;
     if (!strcmp(name, "feature_item")) name_feat_item_ = val;
     // extension keys (ignored by the reference like any unknown key): relaxed handling of shared ids
+    if (imfb() && !strcmp(name, "ufeedback_disable_level")) {   // apex_multi_imfb.h:58-67
+        const int level = atoi(val);
+        check(level >= 0, "ufeedback_disable_level must not be negative");
+        if (level < 32) imfb_disable_ |= 1u << level;          // levels beyond IMFB_DEPTH can never open here
+    }
+    if (bilinear()) {   // apex_svd_bilinear.h:187-193
+        if (!strcmp(name, "reg_bi_feedback")) reg_bi_feedback_ = atoi(val);
+        if (!bi_allocated_) {
+            if (!strcmp(name, "num_bi_feedback")) bi_param_.num_bi_feedback = atoi(val);
+            if (!strcmp(name, "start_ufeedback")) bi_param_.start_ufeedback = atoi(val);
+        }
+    }
     if (!strcmp(name, "amd:relax_global")) relax_global_ = atoi(val) != 0;
     if (!strcmp(name, "amd:relax_feedback")) relax_feedback_ = atoi(val) != 0;
     if (!strcmp(name, "amd:relax_user_from")) relax_user_from_ = (unsigned)strtoul(val, nullptr, 10);
@@ -329,6 +347,11 @@ void Engine::rand_init() {  // SVDModel::rand_init apex_svd_model.h:665-705
 void Engine::init_model() {  // apex_svd_base.h:146-149
     alloc_host_model();
     rand_init();
+    if (bilinear()) {   // BModel::alloc_space (apex_svd_bilinear.h:49-54, :202-205): W_bi[num_item][num_bi_feedback] = 0
+        check(bi_param_.num_bi_feedback >= 0, "num_bi_feedback must not be negative");
+        hbi_.assign((size_t)mp_.num_item * (size_t)bi_param_.num_bi_feedback, 0.0f);
+        bi_allocated_ = true;
+    }
     if (device_model_) upload_model();
 }
 
@@ -400,6 +423,13 @@ void Engine::read_model(FILE *fi) {
 void Engine::load_model(FILE *fi) {  // apex_svd_base.h:138-140
     if (trainer_ready_ && !host_only_) flush();
     read_model(fi);
+    if (bilinear()) {   // BModel::load_from_file (apex_svd_bilinear.h:64-68, :194-197)
+        check(fread(&bi_param_, sizeof(BiParam), 1, fi) > 0, "load from file");
+        check(bi_param_.num_bi_feedback >= 0, "num_bi_feedback must not be negative");
+        hbi_.assign((size_t)mp_.num_item * (size_t)bi_param_.num_bi_feedback, 0.0f);
+        bi_allocated_ = true;
+        load_2d(fi, hbi_.data(), mp_.num_item, bi_param_.num_bi_feedback, bi_param_.num_bi_feedback);
+    }
     params_dirty_ = true;
     if (device_model_) upload_model();
 }
@@ -409,6 +439,13 @@ void Engine::save_model(FILE *fo) {  // apex_svd_base.h:142-144
     if (device_model_) { flush(); download_model(); }
     check(host_model_valid_, "save_model: no model");
     write_model(fo);
+    if (bilinear()) {   // BModel::save_to_file (apex_svd_bilinear.h:60-63, :198-201).  W_bi is inert: SVDPPFeature::update binds its OWN
+        // non-virtual prepare_ufeedback (apex_svd_base.h:523,571), so the derived one that would fill up_index never runs and
+        // get_bias_plugin / update_bias_plugin (:133-162) loop over nothing -- training is SVDPPFeature's, W_bi rides along
+        check(bi_allocated_, "save_model: bilinear model is not initialised");
+        fwrite(&bi_param_, sizeof(BiParam), 1, fo);
+        save_2d(fo, hbi_.data(), mp_.num_item, bi_param_.num_bi_feedback, bi_param_.num_bi_feedback);
+    }
     if (device_model_) { hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hg_.clear(); host_model_valid_ = false; }
 }
 
@@ -435,7 +472,7 @@ void Engine::upload_model() {
     dW_.upload(hW_.data(), hW_.size(), stream_);
     dbias_.upload(hbias_.data(), hbias_.size(), stream_);
     upload_globals(wanted_g_stride());
-    std::vector<float> zero((size_t)2 * pitch_ + 4, 0.0f);
+    std::vector<float> zero(imfb() ? (size_t)4 + IMFB_DEPTH * ((size_t)2 * pitch_ + 4) : (size_t)2 * pitch_ + 4, 0.0f);
     dstate_.upload(zero.data(), zero.size(), stream_);
     HIPCHECK(hipStreamSynchronize(stream_));
     device_model_ = true;
@@ -464,6 +501,19 @@ void Engine::init_trainer() {  // apex_svd_base.h:151-173, 499-503
     for (unsigned c : feat_item_.index) check(c < (unsigned)mp_.num_item, "feature_item: child index exceed bound");
     check(tp_.reg_method >= 0 && tp_.reg_method <= 5, "unknown reg_method");
     check(tp_.reg_global == 0 || tp_.reg_global == 1 || tp_.reg_global == 4 || tp_.reg_global == 5, "unknown global decay method");
+    if (mtype_.extend_type != 0 && !user_group())
+        fail("svdfeature_amd: extend_type 1 / 2 / 15 (implicit-feedback solvers) need the user-group format (format_type = 1)");
+    if (bilinear()) {
+        // reg_feedback(lr, iid) (apex_svd_bilinear.h:103-119) runs once per item entry of every update: modes 2 / 3 decay the
+        // row of W_bi, which only matters for a loaded model with non-zero W_bi (training itself never makes it non-zero)
+        check(reg_bi_feedback_ >= 0 && reg_bi_feedback_ <= 5, "unknown bi feedback decay method");
+        bool nz = false;
+        for (float v : hbi_) nz = nz || v != 0.0f;
+        if (nz && (reg_bi_feedback_ == 2 || reg_bi_feedback_ == 3))
+            fail("svdfeature_amd: a loaded bilinear model with non-zero W_bi and reg_bi_feedback 2 / 3 is not supported");
+    }
+    if (imfb()) check(mp_.common_latent_space == 0, "svdfeature_amd: extend_type 2 with common_latent_space is not supported");
+    imfb_depth_ = 0; iunit_open_ = false;   // the reference's `top` starts at 0 (apex_multi_imfb.h:46-48)
     trainer_ready_ = true;
     sample_counter_ = 0;   // :157
     if (host_only_) return;
@@ -504,6 +554,7 @@ const DevParams &Engine::params() {
     P.user_group = user_group() ? 1 : 0;
     P.store_mode = store_mode_;
     P.xcd_remap = xcd_remap_;
+    P.imfb_disable = imfb_disable_;
     P.hot_reduce = hot_reduce_; P.relax_global = relax_global_ ? 1 : 0; P.relax_feedback = relax_feedback_ ? 1 : 0;
     if (device_model_ && g_stride_ != wanted_g_stride() && mp_.num_global > 0) {   // relax_global switched after the upload: re-lay out
         std::vector<float> g((size_t)mp_.num_global);
@@ -613,6 +664,10 @@ void Engine::update_csr_batch(int num_row, const float *row_label, const int *ro
     // hot when the reference's CLI feeds one instance per call: no HIP API call and no timer in here
     check(trainer_ready_, "update: init_trainer has not been called");
     if (host_only_) need_device("update");
+    if (imfb()) {   // update(Elem) of the multi-level solver: the rows see whatever levels are open (a MIDDLE block without tags)
+        update_block_imfb(0, TAG_MIDDLE, nullptr, nullptr, num_row, row_label, row_ptr, feat_index, feat_value);
+        return;
+    }
     if (user_group()) {
         // SVDPPFeature inherits update(Elem) (apex_svd_base.h:464-466): rows run against the current
         // implicit-feedback state without prepare/scatter
@@ -634,6 +689,7 @@ void Engine::update_block(int nfb, int tag, const unsigned *ifb, const float *vf
     if (host_only_) need_device("update");
     check(user_group(), "not implemented");   // SVDFeature has no update(SVDPlusBlock) (apex_svd.h:97)
     for (int j = 0; j < nfb; j++) check(ifb[j] < (unsigned)mp_.num_ufeedback, "ufeedback id exceed bound");
+    if (imfb()) { update_block_imfb(nfb, tag, ifb, vfb, num_row, row_label, row_ptr, feat_index, feat_value); return; }
     const int h = (int)staged_.num_row();
     const bool starts = (tag == TAG_DEFAULT || tag == TAG_START);
     const bool ends = (tag == TAG_DEFAULT || tag == TAG_END);
@@ -678,6 +734,119 @@ void Engine::update_block(int nfb, int tag, const unsigned *ifb, const float *vf
         unit_open_ = true;
     }
     if (staged_.num_row() >= stage_window_) flush();
+}
+
+// ---- extend_type 2: SVDPPMultiIMFB::update (apex_multi_imfb.h:173-192) staged as blocks; a unit is a run of blocks from an
+// empty stack (or the start of the window) until the stack is empty again (or the window ends)
+void Engine::update_block_imfb(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label,
+                               const int *row_ptr, const unsigned *feat_index, const float *feat_value) {
+    check(tag == TAG_DEFAULT || tag == TAG_START || tag == TAG_MIDDLE || tag == TAG_END, "unknown extend_tag");
+    const bool starts = (tag == TAG_DEFAULT || tag == TAG_START), ends = (tag == TAG_DEFAULT || tag == TAG_END);
+    if (starts) check(imfb_depth_ < IMFB_DEPTH, "svdfeature_amd: more than 4 nested implicit-feedback levels are not supported");
+    if (ends && !starts) check(imfb_depth_ > 0, "start tag,end tag error in implicit feedback");   // :183
+    const int h = (int)staged_.num_row();
+    stage_rows(num_row, row_label, row_ptr, feat_index, feat_value);
+    DevBlk k;
+    memset(&k, 0, sizeof(k));
+    k.row_begin = h; k.row_end = h + num_row; k.tag = tag;
+    if (starts || ends) {
+        const int b = (int)staged_fb_index_.size();
+        staged_fb_index_.insert(staged_fb_index_.end(), ifb, ifb + nfb);
+        staged_fb_value_.insert(staged_fb_value_.end(), vfb, vfb + nfb);
+        if (starts) { k.fb_begin = b; k.fb_end = b + nfb; }
+        if (ends) { k.sc_begin = b; k.sc_end = b + nfb; }
+    }
+    const int bi = (int)staged_blks_.size();
+    staged_blks_.push_back(k);
+    if (!iunit_open_) {
+        staged_iunits_.push_back(DevUnit{bi, bi + 1, h, h + num_row, imfb_depth_ > 0 ? UNIT_LOAD : 0});   // open levels live in the device state slot
+        iunit_open_ = true;
+    } else {
+        staged_iunits_.back().fb_end = bi + 1;
+        staged_iunits_.back().row_end = h + num_row;
+    }
+    if (starts) imfb_depth_++;
+    if (ends) imfb_depth_--;
+    if (imfb_depth_ == 0) iunit_open_ = false;
+    if (staged_.num_row() >= stage_window_) flush();
+}
+void Engine::schedule_iunits(int base, Schedule &sched) {
+    const long nu = (long)staged_iunits_.size();
+    tracker_.resize(num_resources() + 1);
+    const size_t state_res = num_resources();
+    std::vector<int> levels((size_t)nu);
+    int *last = tracker_.last.data();
+    const unsigned *idx = staged_.feat_index.data();
+    check(!relaxed(), "svdfeature_amd: the relaxed modes are not available for extend_type 2");
+    for (long t = 0; t < nu; t++) {
+        const DevUnit &u = staged_iunits_[(size_t)t];
+        int lvl = base;
+        for (int r = u.row_begin; r < u.row_end; r++) {
+            const int *p = &staged_.row_ptr[(size_t)3 * r];
+            lvl = level_of_row(idx + p[0], p[1] - p[0], idx + p[1], p[2] - p[1], idx + p[2], p[3] - p[2], lvl);
+        }
+        for (int b = u.fb_begin; b < u.fb_end; b++) {
+            const DevBlk &k = staged_blks_[(size_t)b];
+            for (int j = k.fb_begin; j < k.fb_end; j++) lvl = std::max(lvl, last[fb_off_ + staged_fb_index_[(size_t)j]]);
+            for (int j = k.sc_begin; j < k.sc_end; j++) lvl = std::max(lvl, last[fb_off_ + staged_fb_index_[(size_t)j]]);
+        }
+        if (u.flags & (UNIT_LOAD | UNIT_SAVE)) lvl = std::max(lvl, last[state_res]);
+        lvl += 1;
+        for (int r = u.row_begin; r < u.row_end; r++) {
+            const int *p = &staged_.row_ptr[(size_t)3 * r];
+            touch_row(idx + p[0], p[1] - p[0], idx + p[1], p[2] - p[1], idx + p[2], p[3] - p[2], lvl);
+        }
+        for (int b = u.fb_begin; b < u.fb_end; b++) {
+            const DevBlk &k = staged_blks_[(size_t)b];
+            for (int j = k.fb_begin; j < k.fb_end; j++) last[fb_off_ + staged_fb_index_[(size_t)j]] = lvl;
+            for (int j = k.sc_begin; j < k.sc_end; j++) last[fb_off_ + staged_fb_index_[(size_t)j]] = lvl;
+        }
+        if (u.flags & (UNIT_LOAD | UNIT_SAVE)) last[state_res] = lvl;
+        levels[(size_t)t] = lvl;
+    }
+    build_schedule(levels, base, sched);
+}
+void Engine::upload_iunits(UnitDev &d, const Schedule &sched) {
+    d.label.upload(staged_.row_label.data(), staged_.row_label.size(), stream_);
+    d.ptr.upload(staged_.row_ptr.data(), staged_.row_ptr.size(), stream_);
+    d.index.upload(staged_.feat_index.data(), staged_.feat_index.size(), stream_);
+    d.value.upload(staged_.feat_value.data(), staged_.feat_value.size(), stream_);
+    d.fbidx.upload(staged_fb_index_.data(), staged_fb_index_.size(), stream_);
+    d.fbval.upload(staged_fb_value_.data(), staged_fb_value_.size(), stream_);
+    d.units.upload(staged_iunits_.data(), staged_iunits_.size(), stream_);
+    d.blks.upload(staged_blks_.data(), staged_blks_.size(), stream_);
+    d.order.upload(sched.order.data(), sched.order.size(), stream_);
+    d.unit_values = false; d.has_fresh = false;
+    HIPCHECK(hipStreamSynchronize(stream_));
+}
+void Engine::drop_staged_units() {
+    staged_.clear(); staged_units_.clear(); staged_fb_index_.clear(); staged_fb_value_.clear();
+    staged_blks_.clear(); staged_iunits_.clear();
+}
+void Engine::flush_iunits() {
+    if (staged_iunits_.empty()) { drop_staged_units(); return; }
+    need_device("update");
+    const DevParams &P = params();
+    const int base = tracker_.base;
+    if (iunit_open_) staged_iunits_.back().flags |= UNIT_SAVE;   // open levels wait in the device state slot for the next window
+    Schedule sched;
+    schedule_iunits(base, sched);
+    tracker_.base = base + (int)sched.num_levels();
+    const long n = staged_.num_row();
+    UnitDev &d = w_unitdev_;
+    upload_iunits(d, sched);
+    const DevCSR D = d.csr();
+    for (size_t l = 0; l < sched.num_levels(); l++) {
+        launch_imfb(P, D, d.units.p, d.blks.p, d.fbidx.p, d.fbval.p, d.order.p, sched.level_ptr[l], sched.level_ptr[l + 1], sample_counter_, nullptr, stream_);
+        n_launches_++;
+    }
+    HIPCHECK(hipGetLastError());
+    n_batches_ += (int64_t)sched.num_levels();
+    n_instances_ += n;
+    sample_counter_ += (unsigned)n;
+    n_flushes_++;
+    iunit_open_ = false;   // what is still open continues as a new unit with UNIT_LOAD
+    drop_staged_units();
 }
 
 // =============================================================================== scheduling helpers
@@ -766,7 +935,8 @@ void Engine::flush() {
     if (host_only_ || !trainer_ready_) return;
     wait_worker();   // a window handed to the background thread earlier must land first
     ScopedNs timer(ns_flush_);
-    if (user_group()) flush_units();
+    if (imfb()) flush_iunits();
+    else if (user_group()) flush_units();
     else flush_csr(staged_);
 }
 
@@ -1124,6 +1294,36 @@ Dataset *Engine::dataset_from_blocks(long num_block, const int *extend_tag, cons
     check(user_group(), "svdfeature_amd: block datasets are for user-group (format_type 1) trainers");
     flush();
     check(!unit_open_, "dataset_from_blocks: a START block is pending in the trainer");
+    if (imfb()) {   // multi-level units: every span of the pass must be closed inside it
+        check(imfb_depth_ == 0, "dataset_from_blocks: a START block is pending in the trainer");
+        const long saved_window = stage_window_;
+        stage_window_ = (long)1 << 60;
+        struct Restore { Engine *e; long w; ~Restore() { e->stage_window_ = w; } } restore{this, saved_window};
+        std::vector<int> p32;
+        try {
+            for (long b = 0; b < num_block; b++) {
+                const int64_t r0 = block_row_ptr[b], r1 = block_row_ptr[b + 1];
+                const int64_t e0 = row_ptr[3 * r0];
+                p32.resize((size_t)(3 * (r1 - r0) + 1));
+                for (int64_t j = 0; j <= 3 * (r1 - r0); j++) p32[(size_t)j] = (int)(row_ptr[3 * r0 + j] - e0);
+                update_block((int)(fb_ptr[b + 1] - fb_ptr[b]), extend_tag[b], fb_index + fb_ptr[b], fb_value + fb_ptr[b], (int)(r1 - r0),
+                             row_label + r0, p32.data(), feat_index + e0, feat_value + e0);
+            }
+            check(imfb_depth_ == 0, "dataset_from_blocks: the last user's END block is missing");
+        } catch (...) { drop_staged_units(); imfb_depth_ = 0; iunit_open_ = false; throw; }
+        std::unique_ptr<Dataset> ds(new Dataset());
+        adopt(ds.get()); ds->kind = 4; ds->num_row = staged_.num_row();
+        LevelTracker saved;
+        std::swap(saved, tracker_);
+        schedule_iunits(0, ds->sched);
+        std::swap(saved, tracker_);
+        upload_iunits(ds->unitdev, ds->sched);
+        const long nb = mp_.no_user_bias ? 1 : 2;
+        ds->algorithmic_bytes = ds->num_row * (8L * mp_.num_factor * 2 + 8 * nb + 16 + 16) + (long)staged_fb_index_.size() * (12L * mp_.num_factor + 20);
+        ds->num_units = (long)staged_iunits_.size();
+        drop_staged_units();
+        return ds.release();
+    }
     if (rows_without_feedback_ && fb_ptr[num_block] == fb_ptr[0]) {
         // No block carries implicit feedback (the shape of demo/pairwiseRank): tmp_ufeedback and its bias stay +0 and
         // norm_ufeedback is 0 through every update_svdpp (apex_svd_base.h:512-520, 524-527), update_ufeedback returns at
@@ -1213,6 +1413,36 @@ void Engine::predict_block(int nfb, int tag, const unsigned *ifb, const float *v
     for (int j = 0; j < nfb; j++) check(ifb[j] < (unsigned)mp_.num_ufeedback, "ufeedback id exceed bound");
     flush();
     const DevParams &P = params();
+    if (imfb()) {   // SVDPPMultiIMFB::predict (apex_multi_imfb.h:193-207): push on DEFAULT / START, score, pop (no scatter) on DEFAULT / END
+        const bool st = (tag == TAG_DEFAULT || tag == TAG_START), en = (tag == TAG_DEFAULT || tag == TAG_END);
+        if (st) check(imfb_depth_ < IMFB_DEPTH, "svdfeature_amd: more than 4 nested implicit-feedback levels are not supported");
+        if (en && !st) check(imfb_depth_ > 0, "start tag,end tag error in implicit feedback");
+        HostCSR rows;
+        stage_rows_into(rows, num_row, row_label, row_ptr, feat_index, feat_value);
+        DevBlk k;
+        memset(&k, 0, sizeof(k));
+        k.row_end = num_row; k.tag = tag;
+        if (st) k.fb_end = nfb;
+        if (en) k.sc_end = nfb;
+        const int after = imfb_depth_ + (st ? 1 : 0) - (en ? 1 : 0);
+        DevUnit u{0, 1, 0, num_row, (imfb_depth_ > 0 ? UNIT_LOAD : 0) | (after > 0 ? UNIT_SAVE : 0)};
+        w_label_.upload(rows.row_label.data(), rows.row_label.size(), stream_);
+        w_ptr_.upload(rows.row_ptr.data(), rows.row_ptr.size(), stream_);
+        w_index_.upload(rows.feat_index.data(), rows.feat_index.size(), stream_);
+        w_value_.upload(rows.feat_value.data(), rows.feat_value.size(), stream_);
+        w_fbidx_.upload(ifb, (size_t)nfb, stream_);
+        w_fbval_.upload(vfb, (size_t)nfb, stream_);
+        w_units_.upload(&u, 1, stream_);
+        w_unitdev_.blks.upload(&k, 1, stream_);
+        w_out_.reserve((size_t)std::max(num_row, 1));
+        DevCSR D{w_label_.p, w_ptr_.p, w_index_.p, w_value_.p};
+        launch_imfb(P, D, w_units_.p, w_unitdev_.blks.p, w_fbidx_.p, w_fbval_.p, nullptr, 0, 1, sample_counter_, w_out_.p, stream_);
+        n_launches_++;
+        if (num_row > 0) HIPCHECK(hipMemcpyAsync(out, w_out_.p, (size_t)num_row * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
+        imfb_depth_ = after;
+        return;
+    }
     HostCSR tmp;   // prediction rows never enter the training stage
     stage_rows_into(tmp, num_row, row_label, row_ptr, feat_index, feat_value);
     const bool starts = (tag == TAG_DEFAULT || tag == TAG_START);
@@ -1472,7 +1702,7 @@ void Engine::train_dataset(Dataset *ds) {
     flush();
     const DevParams &P = params();
     const Schedule &sc = ds->sched;
-    check(!lazy_decay() || ds->kind == 1 || (ds->kind == 3 && ds->num_simple_units == 0),
+    check(!lazy_decay() || ds->kind == 1 || ds->kind == 4 || (ds->kind == 3 && ds->num_simple_units == 0),
           "train_dataset: the dataset was scheduled before lazy decay (reg_method/reg_global >= 4) was selected");
     auto issue = [&]() {
         if (ds->kind == 0) {
@@ -1485,6 +1715,11 @@ void Engine::train_dataset(Dataset *ds) {
                 launch_svdpp_wave(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_ptr[l], sc.level_mid[l], stream_);
                 launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_mid[l], sc.level_ptr[l + 1], sample_counter_, stream_);
             }
+        } else if (ds->kind == 4) {
+            const UnitDev &d = ds->unitdev;
+            const DevCSR D = d.csr();
+            for (size_t l = 0; l < sc.num_levels(); l++)
+                launch_imfb(P, D, d.units.p, d.blks.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_ptr[l], sc.level_ptr[l + 1], sample_counter_, nullptr, stream_);
         } else if (ds->kind == 2) {
             const FusedSchedule S = ds->fused.view();
             for (size_t l = 0; l < sc.num_levels(); l++)
@@ -1530,7 +1765,12 @@ void Engine::predict_dataset(Dataset *ds, float *out) {
     const long n = ds->num_row;
     if (n == 0) return;
     w_out_.reserve((size_t)n);
-    if (ds->kind == 3) {
+    if (ds->kind == 4) {
+        const UnitDev &d = ds->unitdev;
+        launch_imfb(P, d.csr(), d.units.p, d.blks.p, d.fbidx.p, d.fbval.p, nullptr, 0, ds->num_units, sample_counter_, w_out_.p, stream_);
+        HIPCHECK(hipMemcpyAsync(out, w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
+    } else if (ds->kind == 3) {
         const UnitDev &d = ds->unitdev;
         const DevCSR D = d.csr();
         launch_svdpp_predict(P, D, d.units.p, d.fbidx.p, d.fbval.p, ds->num_units, w_out_.p, stream_);

@@ -112,6 +112,7 @@ struct UnitDev {
     DevBuf<int> ptr, order;
     DevBuf<unsigned> index, fbidx;
     DevBuf<DevUnit> units;
+    DevBuf<DevBlk> blks;           // extend_type 2: the blocks the units range over
     DevBuf<unsigned char> fresh;   // DevCSR::row_fresh (allocated only when some row needs it)
     bool has_fresh = false, unit_values = false;
     DevCSR csr() const { return DevCSR{label.p, ptr.p, index.p, value.p, unit_values ? 1 : 0, has_fresh ? fresh.p : nullptr}; }
@@ -150,7 +151,7 @@ class Engine;
 struct Dataset {
     Engine *owner = nullptr;
     long num_row = 0;
-    int kind = 0;                 // 0 basicMF fused kernel, 1 general sparse kernel, 2 few-row fused kernel
+    int kind = 0;                 // 0 basicMF fused kernel, 1 general sparse kernel, 2 few-row fused kernel, 3 SVD++ units, 4 multi-level units
     FusedDev fused;               // kind 2
     UnitDev unitdev;              // kind 3: user-group (SVD++) units
     Schedule sched;               // order kept on the host for predict un-permutation
@@ -282,6 +283,26 @@ class Engine {
     std::vector<HostUnit> staged_units_;
     std::vector<unsigned> staged_fb_index_;
     std::vector<float> staged_fb_value_;
+    // extend_type 2 (SVDPPMultiIMFB, solvers/multi-imfb/apex_multi_imfb.h): blocks + units over block ranges, depth = the
+    // reference's `top` after everything staged or issued so far
+    bool imfb() const { return mtype_.extend_type == 2; }
+    std::vector<DevBlk> staged_blks_;
+    std::vector<DevUnit> staged_iunits_;
+    int imfb_depth_ = 0;
+    bool iunit_open_ = false;
+    unsigned imfb_disable_ = 0;
+    void update_block_imfb(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label,
+                           const int *row_ptr, const unsigned *feat_index, const float *feat_value);
+    void schedule_iunits(int base, Schedule &sched);
+    void upload_iunits(UnitDev &dst, const Schedule &sched);
+    void flush_iunits();
+    void drop_staged_units();
+    // extend_type 15 (SVDBiLinearTrainer, solvers/bilinear/apex_svd_bilinear.h): BParam + W_bi travel with the model file
+    bool bilinear() const { return mtype_.extend_type == 15; }
+    struct BiParam { int num_bi_feedback, start_ufeedback, reserved[32]; } bi_param_;
+    std::vector<float> hbi_;
+    bool bi_allocated_ = false;
+    int reg_bi_feedback_ = 0;
     bool unit_open_ = false;          // a START block was staged and its END has not arrived
     bool unit_open_on_device_ = false;  // ... and its first part was already flushed (state saved on device)
     long stage_window_ = 1 << 22;

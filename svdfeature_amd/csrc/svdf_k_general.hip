@@ -1,165 +1,8 @@
 // svdf_k_general.hip -- general sparse kernels (k_general, k_predict) and the lane-group SVD++ kernels (k_svdpp, k_svdpp_predict)
 // (part of the gfx950 kernel set described at the top of svdf_device.h)
-#include "svdf_device.h"
+#include "svdf_instance.h"
 
 namespace svdf {
-
-// =====================================================================================
-// General sparse instance (any number of global / user / item features, side-feature children,
-// every regulariser).  Rows are read-modify-written through memory in the reference's order, so
-// an id that appears twice in one instance is updated and decayed twice like the reference does.
-// =====================================================================================
-template <typename R>
-struct SvdppRegsT {   // SVDPPFeature members (apex_svd_base.h:486-488) held in registers
-    R tmp_fb, old_fb;
-    float norm, tmp_bias, old_bias;
-};
-using SvdppRegs = SvdppRegsT<float4>;
-
-// pred() (:445-454): fills tmp_u / tmp_i, returns the score before the link function (double)
-template <int LPI, typename R>
-__device__ __forceinline__ double instance_score(const DevParams &P, int ng, int nu, int ni, const unsigned *idx,
-                                                 const float *val, int L, const SvdppRegsT<R> *pp, R &tu, R &ti) {
-    using io = row_io<LPI, R>;
-    const int k = P.k, pitch = P.pitch;
-    const unsigned *ig = idx, *iu = idx + ng, *ii = idx + ng + nu;
-    const float *vg = val, *vu = val + ng, *vi = val + ng + nu;
-    double bs = 0.0;
-    for (int j = 0; j < ng; j++) bs += (double)(vg[j] * P.g_bias[gpos(P, ig[j])]);
-    if (P.no_user_bias == 0) {
-        for (int j = 0; j < nu; j++) {
-            const unsigned uid = iu[j];
-            bs += (double)(vu[j] * P.bias[P.user_off + uid]);
-            if (uid < P.feat_user.num_row)
-                for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++)
-                    bs += (double)(P.bias[P.user_off + P.feat_user.index[c]] * P.feat_user.value[c]);
-        }
-        bs += (double)(pp ? pp->tmp_bias : 0.0f);
-    }
-    bs += 0.0;
-    for (int j = 0; j < ni; j++) {
-        const unsigned iid = ii[j];
-        const float ival = vi[j];
-        bs += (double)(ival * P.bias[P.item_off + iid]);
-        if (iid < P.feat_item.num_row)
-            for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++)
-                bs += (double)(P.bias[P.item_off + P.feat_item.index[c]] * P.feat_item.value[c] * ival);
-    }
-    double sum = (double)P.base_score + bs;
-    tu = pp ? pp->tmp_fb : row_traits<R>::zero();
-    ti = row_traits<R>::zero();
-    for (int j = 0; j < nu; j++) {
-        const unsigned uid = iu[j];
-        axpy4(tu, io::load(P.W, P.user_off + uid, pitch, L, k), vu[j]);
-        if (uid < P.feat_user.num_row)
-            for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++)
-                axpy4(tu, io::load(P.W, P.user_off + P.feat_user.index[c], pitch, L, k), P.feat_user.value[c]);
-    }
-    for (int j = 0; j < ni; j++) {
-        const unsigned iid = ii[j];
-        const float ival = vi[j];
-        axpy4(ti, io::load(P.W, P.item_off + iid, pitch, L, k), ival);
-        if (iid < P.feat_item.num_row)
-            for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++)  // scalar formed in double
-                axpy4(ti, io::load(P.W, P.item_off + P.feat_item.index[c], pitch, L, k),
-                      (float)((double)P.feat_item.value[c] * (double)ival));
-    }
-    sum += (double)group_dot<LPI>(tu, ti, L, k);
-    return sum;
-}
-
-// W[row] += tmp*sc ; bias[row] += sc   (every lane of the group stores the same bias value so
-// each thread later reads back its own write)
-template <int LPI, typename R>
-__device__ __forceinline__ void rmw_row(const DevParams &P, unsigned row, const R &tmp, float sc, bool with_bias, int L) {
-    R w = row_io<LPI, R>::load(P.W, row, P.pitch, L, P.k);
-    axpy4(w, tmp, sc);
-    row_io<LPI, R>::store(P.W, row, P.pitch, L, P.k, w);
-    if (with_bias) { float b = P.bias[row]; b = b + sc; P.bias[row] = b; }
-}
-template <int LPI, typename R>
-__device__ __forceinline__ void reg_user(const DevParams &P, unsigned uid, int L, unsigned counter) {  // :211-250
-    const unsigned row = P.user_off + uid;
-    R w = row_io<LPI, R>::load(P.W, row, P.pitch, L, P.k);
-    reg_row<LPI>(P, w, get_wd(P.u_rng, uid, P.wd_user), false, L, lazy_span(P, row, counter));
-    row_io<LPI, R>::store(P.W, row, P.pitch, L, P.k, w);
-    if (P.no_user_bias == 0) { float b = P.bias[row]; b = b * (1.0f - P.lr * P.wd_user_bias); P.bias[row] = b; }
-}
-template <int LPI, typename R>
-__device__ __forceinline__ void reg_item(const DevParams &P, unsigned iid, int L, unsigned counter) {  // :251-283
-    const unsigned row = P.item_off + iid;
-    R w = row_io<LPI, R>::load(P.W, row, P.pitch, L, P.k);
-    reg_row<LPI>(P, w, get_wd(P.i_rng, iid, P.wd_item), true, L, lazy_span(P, row, counter));
-    row_io<LPI, R>::store(P.W, row, P.pitch, L, P.k, w);
-    float b = P.bias[row]; b = b * (1.0f - P.lr * P.wd_item_bias); P.bias[row] = b;
-}
-
-// regularize(feature, is_after_update) (:286-311): globals and factor rows each run either before the step
-// (lazy modes 4/5, with the sample counter of BEFORE the step) or after it (modes 0..3)
-template <int LPI, typename R>
-__device__ __forceinline__ void instance_regularize(const DevParams &P, int ng, int nu, int ni, const unsigned *idx, int L,
-                                                    bool after, unsigned counter) {
-    const unsigned *ig = idx, *iu = idx + ng, *ii = idx + ng + nu;
-    if (after == (P.reg_global < 4))
-        for (int j = 0; j < ng; j++) { const unsigned gid = ig[j]; float g = reg_gbias(P, gid, P.g_bias[gpos(P, gid)], counter); P.g_bias[gpos(P, gid)] = g; }
-    if (after == (P.reg_method < 4)) {
-        for (int j = 0; j < nu; j++) {
-            const unsigned uid = iu[j];
-            reg_user<LPI, R>(P, uid, L, counter);
-            if (uid < P.feat_user.num_row)
-                for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++) reg_user<LPI, R>(P, P.feat_user.index[c], L, counter);
-        }
-        for (int j = 0; j < ni; j++) {
-            const unsigned iid = ii[j];
-            reg_item<LPI, R>(P, iid, L, counter);
-            if (iid < P.feat_item.num_row)
-                for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++) reg_item<LPI, R>(P, P.feat_item.index[c], L, counter);
-        }
-    }
-}
-
-// update_inner (:456-462); counter = sample_counter before this instance (only the lazy modes look at it)
-template <int LPI, typename R>
-__device__ __forceinline__ void instance_update(const DevParams &P, float label, int ng, int nu, int ni,
-                                                const unsigned *idx, const float *val, int L, SvdppRegsT<R> *pp, unsigned counter) {
-    const unsigned *ig = idx, *iu = idx + ng, *ii = idx + ng + nu;
-    const float *vg = val, *vu = val + ng, *vi = val + ng + nu;
-    if (P.reg_method >= 4 || P.reg_global >= 4) instance_regularize<LPI, R>(P, ng, nu, ni, idx, L, false, counter);
-    R tu, ti;
-    const double sum = instance_score<LPI, R>(P, ng, nu, ni, idx, val, L, pp, tu, ti);
-    const float pred = map_active((float)sum, P.active_type);
-    const float err = cal_grad(label, pred, P.active_type) * 1.0f;
-    const float lr = P.lr;
-    const bool ub = P.no_user_bias == 0;
-    // ---- update_no_decay (:383-427)
-    for (int j = 0; j < ng; j++) { float g = P.g_bias[gpos(P, ig[j])]; g = g + lr * err * vg[j]; P.g_bias[gpos(P, ig[j])] = g; }
-    for (int j = 0; j < nu; j++) {
-        const unsigned uid = iu[j];
-        rmw_row<LPI, R>(P, P.user_off + uid, ti, lr * err * vu[j], ub, L);
-        if (uid < P.feat_user.num_row)
-            for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++)
-                rmw_row<LPI, R>(P, P.user_off + P.feat_user.index[c], ti, lr * err * P.feat_user.value[c], ub, L);
-    }
-    for (int j = 0; j < ni; j++) {
-        const unsigned iid = ii[j];
-        const float ival = vi[j];
-        rmw_row<LPI, R>(P, P.item_off + iid, tu, lr * err * ival, true, L);
-        if (iid < P.feat_item.num_row)
-            for (unsigned c = P.feat_item.row_ptr[iid]; c < P.feat_item.row_ptr[iid + 1]; c++)
-                rmw_row<LPI, R>(P, P.item_off + P.feat_item.index[c], tu, lr * err * P.feat_item.value[c] * ival, true, L);
-    }
-    if (pp) {  // update_svdpp (:512-520)
-        const float lr2 = lr * P.scale_lr_ufeedback;
-        axpy4(pp->tmp_fb, ti, lr2 * err * pp->norm);
-        scale4(pp->tmp_fb, 1.0f - lr2 * P.wd_ufeedback);
-        if (ub) {
-            pp->tmp_bias = pp->tmp_bias + lr2 * err * pp->norm;
-            pp->tmp_bias = pp->tmp_bias * (1.0f - lr2 * P.wd_ufeedback_bias);
-        }
-    }
-    // ---- sample_counter++ ; regularize(feature, true)
-    instance_regularize<LPI, R>(P, ng, nu, ni, idx, L, true, counter + 1u);
-}
 
 // Kernel 2: one conflict-free batch of general instances; order[] lists instance ids of the batch.
 template <int LPI, typename R>
@@ -173,7 +16,8 @@ __global__ __launch_bounds__(256) void k_general(const DevParams P, const DevCSR
     for (long s = begin + gidx; s < end; s += stride) {
         const int r = order ? order[s] : (int)s;
         const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
-        instance_update<LPI, R>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, nullptr,
+        NoFeedback<R> none;
+        instance_update<LPI, R>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, none,
                                 counter_base + (unsigned)r);
     }
 }
@@ -189,7 +33,7 @@ __global__ __launch_bounds__(256) void k_predict(const DevParams P, const DevCSR
     for (long r = gidx; r < n; r += stride) {
         const int p0 = D.row_ptr[3 * r], p1 = D.row_ptr[3 * r + 1], p2 = D.row_ptr[3 * r + 2], p3 = D.row_ptr[3 * r + 3];
         R tu, ti;
-        const double sum = instance_score<LPI, R>(P, p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, nullptr, tu, ti);
+        const double sum = instance_score<LPI, R>(P, p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, NoFeedback<R>(), tu, ti);
         if (L == 0) out[r] = map_active((float)sum, P.active_type);
     }
 }
@@ -263,7 +107,7 @@ __global__ __launch_bounds__(256) void k_svdpp(const DevParams P, const DevCSR D
         {
             for (int r = u.row_begin; r < u.row_end; r++) {
                 const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
-                instance_update<LPI, R>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp,
+                instance_update<LPI, R>(P, D.row_label[r], p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, pp,
                                         counter_base + (unsigned)r);
             }
         }
@@ -288,7 +132,7 @@ __global__ __launch_bounds__(256) void k_svdpp_predict(const DevParams P, const 
         for (int r = u.row_begin; r < u.row_end; r++) {
             const int p0 = D.row_ptr[3 * (long)r], p1 = D.row_ptr[3 * (long)r + 1], p2 = D.row_ptr[3 * (long)r + 2], p3 = D.row_ptr[3 * (long)r + 3];
             R tu, ti;
-            const double sum = instance_score<LPI, R>(P, p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, &pp, tu, ti);
+            const double sum = instance_score<LPI, R>(P, p1 - p0, p2 - p1, p3 - p2, D.feat_index + p0, D.feat_value + p0, L, pp, tu, ti);
             if (L == 0) out[r] = map_active((float)sum, P.active_type);
         }
         if (u.flags & UNIT_SAVE) svdpp_save_state<LPI, R>(P, pp, L);

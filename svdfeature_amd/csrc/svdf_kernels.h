@@ -29,6 +29,9 @@ void launch_svdpp(const DevParams &P, const DevCSR &D, const DevUnit *units, con
 // units flagged UNIT_SIMPLE (num_factor <= 256): one wave per user, see k_svdpp_wave
 void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
                        const int *order, long begin, long end, hipStream_t st);
+// extend_type 2 (multi-level implicit feedback): units = block ranges of blks[]; predict_out != nullptr scores instead of training
+void launch_imfb(const DevParams &P, const DevCSR &D, const DevUnit *units, const DevBlk *blks, const unsigned *fb_index, const float *fb_value,
+                 const int *order, long begin, long end, unsigned counter_base, float *predict_out, hipStream_t st);
 // read-only scoring
 void launch_predict(const DevParams &P, const DevCSR &D, long n, float *out, hipStream_t st);
 void launch_predict_basic(const DevParams &P, const BasicSchedule &S, long n, float *out, hipStream_t st);

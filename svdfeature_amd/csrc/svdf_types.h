@@ -85,6 +85,7 @@ struct DevParams {
     int g_stride;             // floats between consecutive global biases in device memory (1, or 32 in relaxed-global mode)
     int hot_reduce;           // knob: workgroup pre-reduction of a relaxed shared user row (k_fused HOTU)
     int xcd_remap;            // 1: consecutive tiles of a batch go to the same XCD (blockIdx%8), see k_basicmf
+    unsigned imfb_disable;    // extend_type 2: bit l = ufeedback_disable_level l (apex_multi_imfb.h:58-67)
     int store_mode;           // row-store cache policy of k_basicmf: 0 plain, 1 nontemporal, 2 sc1 write-through
     // SVDTrainParam
     float lr, wd_user, wd_item, wd_user_bias, wd_item_bias, wd_global;
@@ -141,6 +142,15 @@ struct DevUnit {
     int flags;                 // bit0: starts here (prepare_ufeedback), bit1: ends here (update_ufeedback),
                                // bit2: save state at exit, bit3: load state at entry, bit4: UNIT_SIMPLE fast path
 };
+// extend_type 2 (multi-level implicit feedback): one block of a unit.  [fb_begin, fb_end) is the list a DEFAULT / START block
+// prepares its level from, [sc_begin, sc_end) the list a DEFAULT / END block scatters through (its own list, which may differ
+// from the one the level was opened with, apex_multi_imfb.h:186-190).
+struct DevBlk {
+    int fb_begin, fb_end, sc_begin, sc_end;
+    int row_begin, row_end;
+    int tag;
+};
+#define IMFB_DEPTH 4   // nested implicit-feedback levels held in registers; deeper data is refused
 enum { UNIT_START = 1, UNIT_END = 2, UNIT_SAVE = 4, UNIT_LOAD = 8,
        UNIT_SIMPLE = 16 };   // host-verified: rows are (0,1,1) with one user id, distinct feedback ids (repeated items: row_fresh)
 

@@ -207,3 +207,41 @@ def planted_pairs(n, num_user, num_item, seed, rank=8):
 def pair_accuracy(score_pos_minus_neg):
     """share of held-out pairs ranked the right way round (score difference > 0)"""
     return float(np.mean(np.asarray(score_pos_minus_neg) > 0))
+
+
+def nested_blocks(num_spans, num_user, num_item, num_ufeedback, seed, max_depth=3, max_rows=4, max_fb=5):
+    """User-group blocks with NESTED START..END spans, the input of the multi-level implicit-feedback solver (extend_type 2,
+    solvers/multi-imfb/apex_multi_imfb.h:173-192): START pushes a feedback level, END pops and scatters it, DEFAULT blocks
+    may sit inside an open span (push + pop at once), MIDDLE blocks carry rows only.  Top-level spans belong to one user."""
+    rng = np.random.default_rng(seed)
+    blocks = []
+    e = np.zeros(0, np.uint32), np.zeros(0, np.float32)
+
+    def fb():
+        n = int(rng.integers(0, max_fb + 1))
+        idx = np.sort(rng.choice(num_ufeedback, size=n, replace=False)).astype(np.uint32)
+        return idx, np.full(n, 1.0 / np.sqrt(max(n, 1)), np.float32)
+
+    def rows(uid):
+        n = int(rng.integers(0, max_rows + 1))
+        rs = [(float(rng.integers(1, 6)), [], [(int(uid), 1.0)], [(int(rng.integers(0, num_item)), 1.0)]) for _ in range(n)]
+        return CSRData.from_rows(rs) if rs else CSRData.empty()
+
+    def span(uid, depth):
+        kind = int(rng.integers(0, 3))
+        if kind == 0 or depth >= max_depth:
+            f = fb()
+            blocks.append(PlusBlock(f[0], f[1], rows(uid), TAG_DEFAULT))
+            return
+        f = fb()
+        blocks.append(PlusBlock(f[0], f[1], rows(uid), TAG_START))
+        for _ in range(int(rng.integers(0, 3))):
+            if rng.integers(0, 2):
+                span(uid, depth + 1)
+            else:
+                blocks.append(PlusBlock(e[0], e[1], rows(uid), TAG_MIDDLE))
+        blocks.append(PlusBlock(f[0], f[1], rows(uid), TAG_END))
+
+    for _ in range(num_spans):
+        span(int(rng.integers(0, num_user)), 0)
+    return blocks

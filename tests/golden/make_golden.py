@@ -10,6 +10,8 @@ Outputs (data only -- inputs and expected outputs, no reference source):
                        and ua.test as 0-based (user, item, rating) arrays
   scenarios.npz        for every scenario in tests/scenarios.py: md5 of the initial and final model
                        file the reference wrote, 256 sampled parameters, predictions, RMSE
+  variants.npz         the same digests for tests/scenarios.py's VARIANT_SCENARIOS (extend_type 1 / 2 / 15), written from the
+                       reference's default factory (oracle/_ref/libsvdf_ref_full.so); `make_golden.py variants` writes only this
   fixtures/            the reference tree's own committed binary fixtures for the path
                        (demo/basicMF/ua.base.buffer, ua.test.buffer) and its golden prediction
                        (demo/basicMF/eg.pred.txt)
@@ -57,6 +59,21 @@ def make_scenarios():
     np.savez_compressed(os.path.join(HERE, "scenarios.npz"), **out)
 
 
+def make_variants():
+    """variant solvers (extend_type 1 / 2 / 15) from the reference's DEFAULT factory: oracle/_ref/libsvdf_ref_full.so"""
+    from oracle import oracle
+    import scenarios
+    oracle.build()
+    assert oracle.have_reference_full(), "oracle/_ref/libsvdf_ref_full.so missing: run make -C oracle in the build container"
+    out = {}
+    for name in scenarios.VARIANT_SCENARIOS:
+        res = scenarios.run_scenario(name, lambda f, a, e: oracle.OracleTrainer("reference_full", f, a, e))
+        for k, v in scenarios.digest(res).items():
+            out["%s/%s" % (name, k)] = np.asarray(v)
+        print("%-36s rmse=%.6f model_md5=%s len=%d" % (name, res["rmse"], out["%s/model_md5" % name], len(res["model"])))
+    np.savez_compressed(os.path.join(HERE, "variants.npz"), **out)
+
+
 def copy_fixtures():
     dst = os.path.join(HERE, "fixtures")
     os.makedirs(dst, exist_ok=True)
@@ -66,6 +83,10 @@ def copy_fixtures():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "variants":
+        make_variants()
+        sys.exit(0)
     make_ml100k()
     copy_fixtures()
     make_scenarios()
+    make_variants()

@@ -171,13 +171,54 @@ SCENARIOS = {
 }
 
 
+# ---- variant solvers of the reference's default factory (apex_svd.cpp:32-44): make_trainer gets a third
+# argument, the extend_type.  Goldens: tests/golden/variants.npz, written from oracle/_ref/libsvdf_ref_full.so.
+def _scn_imfb(tmp, seed=31, nested=True, **kw):
+    nu, ni = 70, 45
+    if nested:
+        blocks = cases.nested_blocks(70, nu, ni, ni, seed)
+        test = cases.nested_blocks(25, nu, ni, ni, seed + 1)
+    else:   # the shapes the reference's own loader writes: DEFAULT blocks and START / MIDDLE / END splits of one user
+        blocks = cases.user_blocks(45, nu, ni, ni, seed, split_every=4)
+        test = cases.user_blocks(20, nu, ni, ni, seed + 1)
+    extra = kw.pop("extra", [])
+    conf = _conf(num_user=nu, num_item=ni, num_factor=kw.pop("num_factor", 12), num_ufeedback=ni, wd_ufeedback=0.004, wd_ufeedback_bias=0.002,
+                 scale_lr_ufeedback=0.7, ufeedback_init_sigma=0.02, learning_rate=0.01, **kw) + list(extra)
+    return dict(conf=conf, format_type=1, active_type=0, extend_type=2, rounds=3, train_blocks=blocks, test_blocks=test)
+
+
+def _scn_bilinear(tmp, **kw):
+    s = _scn_svdpp_random(tmp, **kw)
+    s["conf"] = s["conf"] + [("num_bi_feedback", "6"), ("start_ufeedback", "2"), ("reg_bi_feedback", "2"), ("wd_bi_feedback", "0.01"),
+                             ("slr_bi_feedback", "0.5")]
+    s["extend_type"] = 15
+    return s
+
+
+VARIANT_SCENARIOS = {
+    "imfb_loader_shapes": lambda t: _scn_imfb(t, nested=False),                    # == SVD++ on such data
+    "imfb_nested": lambda t: _scn_imfb(t),
+    "imfb_nested_nobias_k33": lambda t: _scn_imfb(t, seed=41, no_user_bias=1, num_factor=33),
+    "imfb_nested_disable_level1": lambda t: _scn_imfb(t, seed=51, extra=[("ufeedback_disable_level", "1")]),
+    "imfb_nested_disable_level0": lambda t: _scn_imfb(t, seed=61, extra=[("ufeedback_disable_level", "0")]),
+    "imfb_nested_l1_ranges": lambda t: _scn_imfb(t, seed=71, reg_method=1, wd_user=0.02, wd_item=0.03),
+    "imfb_nested_lazy": lambda t: _scn_imfb(t, seed=81, reg_method=5),
+    "bilinear_is_svdpp_plus_file_tail": _scn_bilinear,
+    "extend1_is_svdpp": lambda t: dict(_scn_svdpp_random(t), extend_type=1),
+}
+SCENARIOS_ALL = dict(SCENARIOS, **VARIANT_SCENARIOS)
+
+
 def run_scenario(name, make_trainer, chunk=None):
     """make_trainer(format_type, active_type) -> engine with the OracleTrainer method set.
     chunk: if set, feed training rows through update_batch in chunks of this many rows
     (exercises staging/flush boundaries); None feeds each round as one batch."""
     with tempfile.TemporaryDirectory() as tmp:
-        s = SCENARIOS[name](tmp)
-        tr = make_trainer(s["format_type"], s["active_type"])
+        s = SCENARIOS_ALL[name](tmp)
+        if "extend_type" in s:
+            tr = make_trainer(s["format_type"], s["active_type"], s["extend_type"])
+        else:
+            tr = make_trainer(s["format_type"], s["active_type"])
         tr.seed(SEED)
         for k, v in s["conf"]:
             tr.set_param(k, v)
