@@ -1463,6 +1463,49 @@ void Engine::predict_block(int nfb, int tag, const unsigned *ifb, const float *v
 }
 
 // =============================================================================== datasets
+// Column-shaped data sets are scheduled on the GPU: the raw columns go up in file order, svdf_k_sched.hip builds the
+// conflict-free levels (same order[] / level_ptr[] as the host scheduler), and the level-sorted copies are gathered in HBM.
+void Engine::schedule_columns_on_device(Dataset *ds, long n, int K, const int *res_col, const unsigned *off, const unsigned *limit,
+                                        const char *const *msg, int sort_col, unsigned sort_max, const std::vector<UCol> &ucols,
+                                        const std::vector<FCol> &fcols) {
+    std::vector<std::unique_ptr<DevBuf<unsigned>>> rawu;
+    std::vector<std::unique_ptr<DevBuf<float>>> rawf;
+    for (const UCol &c : ucols) { rawu.emplace_back(new DevBuf<unsigned>()); rawu.back()->upload(c.src, (size_t)n, stream_); }
+    for (const FCol &c : fcols) { rawf.emplace_back(new DevBuf<float>()); rawf.back()->upload(c.src, (size_t)n, stream_); }
+    SchedColumns in;
+    memset(&in, 0, sizeof(in));
+    in.K = K; in.n = n;
+    unsigned nres = 0;
+    for (int s = 0; s < K; s++) {
+        in.col[s] = rawu[(size_t)res_col[s]]->p; in.off[s] = off[s]; in.limit[s] = limit[s]; in.limit_msg[s] = msg[s];
+        nres = std::max(nres, off[s] + limit[s]);
+    }
+    in.num_res = nres;
+    in.sort_key = sort_col >= 0 ? rawu[(size_t)sort_col]->p : nullptr;
+    in.sort_key_max = sort_max;
+    ds->order_dev.reserve((size_t)std::max<long>(n, 1));
+    try {
+        device_schedule(in, ds->order_dev.p, ds->sched.level_ptr, &ds->sched.max_level_size, stream_);
+    } catch (const std::runtime_error &ex) {
+        fail(ex.what());
+    }
+    ds->sched.order.clear();
+    for (size_t c = 0; c < ucols.size(); c++) { ucols[c].dst->reserve((size_t)n); device_gather_u32(rawu[c]->p, ds->order_dev.p, ucols[c].dst->p, n, stream_); }
+    for (size_t c = 0; c < fcols.size(); c++) { fcols[c].dst->reserve((size_t)n); device_gather_f32(rawf[c]->p, ds->order_dev.p, fcols[c].dst->p, n, stream_); }
+    HIPCHECK(hipGetLastError());
+    HIPCHECK(hipStreamSynchronize(stream_));
+}
+const int *Engine::host_order(Dataset *ds) {
+    if ((long)ds->sched.order.size() != ds->num_row && ds->order_dev.p) {
+        ds->sched.order.resize((size_t)ds->num_row);
+        if (ds->num_row > 0) {
+            HIPCHECK(hipMemcpyAsync(ds->sched.order.data(), ds->order_dev.p, (size_t)ds->num_row * sizeof(int), hipMemcpyDeviceToHost, stream_));
+            HIPCHECK(hipStreamSynchronize(stream_));
+        }
+    }
+    return ds->sched.order.data();
+}
+
 Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
@@ -1478,12 +1521,24 @@ Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsign
         ptr[(size_t)3 * n] = 2 * n;
         return dataset_from_csr(n, label, ptr.data(), idx.data(), val.data());
     }
+    std::unique_ptr<Dataset> ds(new Dataset());
+    adopt(ds.get()); ds->num_row = n; ds->kind = 0;
+    const long nb_ = mp_.no_user_bias ? 1 : 2;
+    if (device_sched_ && n > 0) {   // bounds are checked by the device pass (same messages)
+        const int res_col[2] = {0, 1};
+        const unsigned off[2] = {0u, (unsigned)mp_.num_user}, limit[2] = {(unsigned)mp_.num_user, (unsigned)mp_.num_item};
+        const char *msg[2] = {"user feature index exceed bound", "item feature index exceed bound"};
+        const int sort_col = sort_batches_ == 1 ? 1 : (sort_batches_ == 2 ? 0 : -1);
+        schedule_columns_on_device(ds.get(), n, 2, res_col, off, limit, msg, sort_col, sort_col >= 0 ? limit[sort_col] : 0u,
+                                   {UCol{user, &ds->user}, UCol{item, &ds->item}}, {FCol{label, &ds->label}});
+        ds->unit_values = true;
+        ds->algorithmic_bytes = n * (8L * mp_.num_factor * 2 + 8 * nb_ + 16 + 8 * 2);
+        return ds.release();
+    }
     for (long r = 0; r < n; r++) {
         if (user[r] >= (unsigned)mp_.num_user) fail("user feature index exceed bound");
         if (item[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound");
     }
-    std::unique_ptr<Dataset> ds(new Dataset());
-    adopt(ds.get()); ds->num_row = n; ds->kind = 0;
     // levels relative to an empty tracker: a dataset pass is always preceded by a flush and all launches
     // are stream ordered, so it only has to be conflict-free within itself
     std::vector<int> lastu((size_t)mp_.num_user, 0), lasti((size_t)mp_.num_item, 0), levels((size_t)n);
@@ -1541,6 +1596,29 @@ Dataset *Engine::dataset_from_pairs(long n, const unsigned *user, const unsigned
     }
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = n; ds->kind = 2;
+    if (device_sched_ && n > 0) {
+        // columns of the few-row schedule in file order: user, lower item id, higher item id, and their +-1 values
+        std::vector<unsigned> lo_((size_t)n), hi_((size_t)n);
+        std::vector<float> vlo((size_t)n), vhi((size_t)n), one((size_t)n, 1.0f);
+        for (long r = 0; r < n; r++) {
+            const bool pf = pos[r] < neg[r];
+            lo_[(size_t)r] = pf ? pos[r] : neg[r]; hi_[(size_t)r] = pf ? neg[r] : pos[r];
+            vlo[(size_t)r] = pf ? 1.0f : -1.0f; vhi[(size_t)r] = pf ? -1.0f : 1.0f;
+        }
+        const int res_col[3] = {0, 1, 2};
+        const unsigned off[3] = {0u, (unsigned)mp_.num_user, (unsigned)mp_.num_user};
+        const unsigned limit[3] = {(unsigned)mp_.num_user, (unsigned)mp_.num_item, (unsigned)mp_.num_item};
+        const char *msg[3] = {"user feature index exceed bound", "item feature index exceed bound", "item feature index exceed bound"};
+        const int sort_col = sort_batches_ == 1 ? 1 : (sort_batches_ == 2 ? 0 : -1);
+        FusedDev &f = ds->fused;
+        f.max_nu = 1; f.max_ni = 2; f.has_g = false; f.inline_g = false;
+        schedule_columns_on_device(ds.get(), n, 3, res_col, off, limit, msg, sort_col, sort_col >= 0 ? limit[sort_col] : 0u,
+                                   {UCol{user, &f.uidx[0]}, UCol{lo_.data(), &f.iidx[0]}, UCol{hi_.data(), &f.iidx[1]}},
+                                   {FCol{one.data(), &f.label}, FCol{one.data(), &f.uval[0]}, FCol{vlo.data(), &f.ival[0]}, FCol{vhi.data(), &f.ival[1]}});
+        const long nb2 = (mp_.no_user_bias ? 0 : 1) + 2;
+        ds->algorithmic_bytes = n * (8L * mp_.num_factor * 3 + 8 * nb2 + 16 + 8 * 3);
+        return ds.release();
+    }
     {
         std::vector<int> lastu((size_t)mp_.num_user, 0), lasti((size_t)mp_.num_item, 0), levels((size_t)n);
         for (long r = 0; r < n; r++) {
@@ -1786,7 +1864,7 @@ void Engine::predict_dataset(Dataset *ds, float *out) {
         std::vector<float> tmp((size_t)n);
         HIPCHECK(hipMemcpyAsync(tmp.data(), w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
         HIPCHECK(hipStreamSynchronize(stream_));
-        const int *order = ds->sched.order.data();
+        const int *order = host_order(ds);
         for (long s = 0; s < n; s++) out[order[s]] = tmp[(size_t)s];
     } else {
         DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
@@ -2018,6 +2096,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "sort_batches")) { check(value >= 0 && value <= 2, "sort_batches must be 0, 1 (by item) or 2 (by user)"); sort_batches_ = (int)value; return 0; }
     if (!strcmp(name, "async_flush")) { flush(); async_flush_ = value != 0; return 0; }
     if (!strcmp(name, "use_fused")) { use_fused_ = value != 0; return 0; }
+    if (!strcmp(name, "device_schedule")) { device_sched_ = value != 0; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "rows_without_feedback")) { rows_without_feedback_ = value != 0; return 0; }
     if (!strcmp(name, "block_threads")) {

@@ -154,7 +154,8 @@ struct Dataset {
     int kind = 0;                 // 0 basicMF fused kernel, 1 general sparse kernel, 2 few-row fused kernel, 3 SVD++ units, 4 multi-level units
     FusedDev fused;               // kind 2
     UnitDev unitdev;              // kind 3: user-group (SVD++) units
-    Schedule sched;               // order kept on the host for predict un-permutation
+    Schedule sched;               // level_ptr always; order on the host only when built there or asked for (host_order)
+    DevBuf<int> order_dev;        // device-built schedules: the unit order stays in HBM until a prediction needs it un-permuted
     // kind 0: level-sorted compact records
     DevBuf<unsigned> user, item;
     DevBuf<float> label, uval, ival;
@@ -322,6 +323,14 @@ class Engine {
     RankPrefetch *rank_prefetch_ = nullptr;
     std::vector<Dataset *> datasets_;     // live datasets of this trainer (Dataset::owner back-pointers)
     void adopt(Dataset *ds);
+    // device-side scheduling of column-shaped data sets (svdf_k_sched.hip): ucols / fcols = (host column in file order, destination
+    // buffer in level order); res_col[s] = index into ucols of slot s's id column
+    struct UCol { const unsigned *src; DevBuf<unsigned> *dst; };
+    struct FCol { const float *src; DevBuf<float> *dst; };
+    void schedule_columns_on_device(Dataset *ds, long n, int K, const int *res_col, const unsigned *off, const unsigned *limit,
+                                    const char *const *msg, int sort_col, unsigned sort_max, const std::vector<UCol> &ucols, const std::vector<FCol> &fcols);
+    const int *host_order(Dataset *ds);
+    bool device_sched_ = true;            // knob "device_schedule"
     uint64_t schedule_signature() const;
     void disown(Dataset *ds);
     void rank_pass(const char *path, UserGroupArrays &g);

@@ -1,0 +1,291 @@
+// svdf_k_sched.hip -- conflict-free level scheduling ON THE DEVICE.
+//
+// The host scheduler (svdf_engine.cpp: level_of_row / touch_row / build_schedule) walks the instance stream once and keeps
+// `last[row]`; that is a sequential longest-path computation: 1.1 s for the 100 M ratings of BASELINE configs[1].  Here the
+// same levels come out of a frontier peel over the per-row successor links:
+//   1. one (row, entry) pair per touched parameter row, entry = unit*K + slot, radix-sorted by row (stable: units of one row
+//      stay in file order)                                                                  -- rocPRIM radix_sort_pairs
+//   2. neighbours in the sorted array give every entry its successor (the next unit touching the same row) and tell which
+//      units head their rows; a unit is READY when it heads all of its rows
+//   3. level l = the ready units; retiring a unit promotes its successors (one atomic counter per unit), the units that
+//      become ready form level l+1.  One short launch per level, frontier sizes stay on the device (last-block-done hand-over),
+//      the host only looks every few hundred levels whether everything is scheduled
+//   4. units sorted by (level, batch key, file position) with one more radix sort: the order inside a level is free
+//      (its units commute), the key is the item / user id so that neighbouring lane groups walk the factor table in order.
+// level(u) = 1 + max(level of the predecessors) is unique, and ties are broken exactly like the host's stable sorts, so the
+// resulting order[] and level_ptr[] are IDENTICAL to the host scheduler's (tests/test_gpu_sched.py compares them).
+//
+// The sort is a library primitive (rocPRIM), like a plain GEMM would be rocBLAS's; everything else is hand-written.
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "svdf_kernels.h"
+
+namespace svdf {
+
+namespace {
+
+struct Cols {
+    const unsigned *col[SVDF_SCHED_MAX_SLOTS];
+    unsigned off[SVDF_SCHED_MAX_SLOTS];     // resource id = off[slot] + id
+    unsigned limit[SVDF_SCHED_MAX_SLOTS];   // ids must be < limit (else the error flag is raised)
+    int K;
+};
+
+// state words in device memory
+enum { ST_CURSOR = 0, ST_BLOCKS_DONE = 1, ST_ERROR = 2, ST_NLEVELS = 3, ST_WORDS = 8 };
+
+__global__ __launch_bounds__(256) void k_sched_keys(const Cols C, long n, unsigned absent_key, unsigned *keys, unsigned *vals, int *need,
+                                                    unsigned *state) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride) {
+        int nd = 0;
+        for (int s = 0; s < C.K; s++) {
+            const unsigned id = C.col[s][u];
+            unsigned key = absent_key;
+            if (id != SLOT_ABSENT) {
+                if (id >= C.limit[s]) atomicOr(&state[ST_ERROR], 1u << s);
+                else { key = C.off[s] + id; nd++; }
+            }
+            keys[u * C.K + s] = key;
+            vals[u * C.K + s] = (unsigned)(u * C.K + s);
+        }
+        need[u] = nd;
+    }
+}
+
+// sorted (row, entry): successor link of every entry, and one credit for the unit that heads each row
+__global__ __launch_bounds__(256) void k_sched_links(const unsigned *keys, const unsigned *vals, long m, unsigned absent_key, int K, int *succ,
+                                                     int *cnt) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const unsigned key = keys[j];
+        if (key == absent_key) continue;
+        const unsigned e = vals[j];
+        int nxt = -1;
+        if (j + 1 < m && keys[j + 1] == key) nxt = (int)(vals[j + 1] / (unsigned)K);
+        succ[e] = nxt;
+        if (j == 0 || keys[j - 1] != key) atomicAdd(&cnt[e / (unsigned)K], 1);
+    }
+}
+
+// appends `mine` (valid when have) to order[] at the shared cursor: one atomic per wave
+__device__ __forceinline__ void wave_append(bool have, int mine, int *order, unsigned *cursor) {
+    const unsigned long long mask = __ballot(have);
+    if (mask == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63);
+    const int leader = __ffsll((long long)mask) - 1;
+    unsigned base = 0;
+    if (lane == leader) base = atomicAdd(cursor, (unsigned)__popcll(mask));
+    base = __shfl(base, leader, 64);
+    if (have) order[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = mine;
+}
+
+// last block of a launch publishes where the next level ends (= the cursor now that every append of this launch is done)
+__device__ __forceinline__ void publish_level_end(unsigned *state, unsigned *level_end, int l) {
+    __shared__ bool last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(&state[ST_BLOCKS_DONE], 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x == 0) {
+        __threadfence();
+        const unsigned cur = atomicAdd(&state[ST_CURSOR], 0u);
+        level_end[l + 1] = cur;
+        if (cur > level_end[l]) state[ST_NLEVELS] = (unsigned)(l + 1);   // level l+1 (1-based) is not empty
+        state[ST_BLOCKS_DONE] = 0;
+        __threadfence();
+    }
+}
+
+// level 1: the units that head all of their rows.  level_end[0] = 0, level_end[1] = number of such units
+__global__ __launch_bounds__(256) void k_sched_seed(long n, const int *need, const int *cnt, int *order, int *level, unsigned *state,
+                                                    unsigned *level_end) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long rounds = (n + stride - 1) / stride;
+    for (long it = 0; it < rounds; it++) {   // whole waves stay in the loop: wave_append uses ballots
+        const long u = it * stride + (long)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool ready = u < n && cnt[u] == need[u];
+        if (ready) level[u] = 1;
+        wave_append(ready, (int)u, order, &state[ST_CURSOR]);
+    }
+    publish_level_end(state, level_end, 0);
+}
+
+// level l+1 from level l (l >= 1): order[level_end[l-1] .. level_end[l]) are the units of level l
+__global__ __launch_bounds__(256) void k_sched_peel(int l, int K, const int *need, const int *succ, int *cnt, int *order, int *level,
+                                                    unsigned *state, unsigned *level_end) {
+    const unsigned begin = level_end[l - 1], end = level_end[l];
+    const unsigned total = end - begin;
+    const unsigned stride = gridDim.x * blockDim.x;
+    const unsigned rounds = (total + stride - 1) / stride;
+    for (unsigned it = 0; it < rounds; it++) {
+        const unsigned i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
+        const bool on = i < total;
+        const int u = on ? order[begin + i] : 0;
+        for (int s = 0; s < K; s++) {
+            int v = -1;
+            if (on) v = succ[(long)u * K + s];
+            bool ready = false;
+            if (v >= 0) ready = atomicAdd(&cnt[v], 1) + 1 == need[v];
+            if (ready) level[v] = l + 1;
+            wave_append(ready, v, order, &state[ST_CURSOR]);
+        }
+    }
+    publish_level_end(state, level_end, l);
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_sched_final_keys(long n, const int *level, const unsigned *sort_key, int key_bits, KeyT *keys, unsigned *vals) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride) {
+        KeyT k = (KeyT)(unsigned)level[u];
+        if (key_bits > 0) k = (k << key_bits) | (KeyT)sort_key[u];
+        keys[u] = k;
+        vals[u] = (unsigned)u;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather(const T *src, const int *order, T *dst, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += stride) dst[s] = src[order[s]];
+}
+
+inline int bits_for(unsigned long long v) {   // bits needed to hold values 0..v
+    int b = 1;
+    while (b < 64 && (v >> b) != 0ull) b++;
+    return b;
+}
+inline int grid_for_n(long n) {
+    long g = (n + 255) / 256;
+    if (g > 4096) g = 4096;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+#define SCHK(call)                                                                                                       \
+    do {                                                                                                                 \
+        hipError_t e_ = (call);                                                                                          \
+        if (e_ != hipSuccess) throw std::runtime_error(std::string("device scheduler: ") + hipGetErrorString(e_) + " at " #call); \
+    } while (0)
+
+struct Scratch {   // freed when the call returns: a schedule is built once per data set
+    std::vector<void *> ptrs;
+    ~Scratch() { for (void *p : ptrs) (void)hipFree(p); }
+    template <typename T> T *get(size_t n) {
+        void *p = nullptr;
+        SCHK(hipMalloc(&p, (n ? n : 1) * sizeof(T)));
+        ptrs.push_back(p);
+        return (T *)p;
+    }
+};
+
+}  // namespace
+
+void device_gather_u32(const unsigned *src, const int *order, unsigned *dst, long n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_gather<unsigned>, dim3(grid_for_n(n)), dim3(256), 0, st, src, order, dst, n);
+}
+void device_gather_f32(const float *src, const int *order, float *dst, long n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_gather<float>, dim3(grid_for_n(n)), dim3(256), 0, st, src, order, dst, n);
+}
+
+// See svdf_kernels.h.  Returns the number of levels; throws std::runtime_error with the reference's bound messages.
+long device_schedule(const SchedColumns &in, int *order_out, std::vector<long> &level_ptr, long *max_level_size, hipStream_t st) {
+    const long n = in.n;
+    const int K = in.K;
+    level_ptr.assign(1, 0);
+    if (max_level_size) *max_level_size = 0;
+    if (n == 0) return 0;
+    if (K < 1 || K > SVDF_SCHED_MAX_SLOTS) throw std::runtime_error("device scheduler: bad slot count");
+    if ((unsigned long long)n * (unsigned long long)K >= 0xFFFFFFFFull || n >= 0x7FFFFFFFL)
+        throw std::runtime_error("device scheduler: more than 2^32 row entries in one data set");
+    const long m = n * K;
+    Cols C;
+    memset(&C, 0, sizeof(C));
+    C.K = K;
+    for (int s = 0; s < K; s++) { C.col[s] = in.col[s]; C.off[s] = in.off[s]; C.limit[s] = in.limit[s]; }
+    const unsigned absent_key = in.num_res;   // one past the largest resource id: sorts behind every real row
+    const int res_bits = bits_for(absent_key);
+
+    Scratch S;
+    unsigned *keys_a = S.get<unsigned>((size_t)m), *keys_b = S.get<unsigned>((size_t)m);
+    unsigned *vals_a = S.get<unsigned>((size_t)m), *vals_b = S.get<unsigned>((size_t)m);
+    int *need = S.get<int>((size_t)n), *cnt = S.get<int>((size_t)n), *level = S.get<int>((size_t)n);
+    int *succ = S.get<int>((size_t)m);
+    int *frontier = S.get<int>((size_t)n);
+    unsigned *state = S.get<unsigned>(ST_WORDS);
+    const long level_cap = n + 2;   // a chain can be as deep as the data set
+    unsigned *level_end = S.get<unsigned>((size_t)level_cap);
+    SCHK(hipMemsetAsync(state, 0, ST_WORDS * sizeof(unsigned), st));
+    SCHK(hipMemsetAsync(cnt, 0, (size_t)n * sizeof(int), st));
+    SCHK(hipMemsetAsync(level_end, 0, sizeof(unsigned), st));
+
+    hipLaunchKernelGGL(k_sched_keys, dim3(grid_for_n(n)), dim3(256), 0, st, C, n, absent_key, keys_a, vals_a, need, state);
+    {
+        size_t tmp_bytes = 0;
+        SCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0u, (unsigned)res_bits, st));
+        void *tmp = S.get<char>(tmp_bytes);
+        SCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0u, (unsigned)res_bits, st));
+    }
+    hipLaunchKernelGGL(k_sched_links, dim3(grid_for_n(m)), dim3(256), 0, st, keys_b, vals_b, m, absent_key, K, succ, cnt);
+    hipLaunchKernelGGL(k_sched_seed, dim3(grid_for_n(n)), dim3(256), 0, st, n, need, cnt, frontier, level, state, level_end);
+
+    // peel: levels are launched in chunks, the host only checks between chunks whether every unit has been placed
+    unsigned host_state[ST_WORDS];
+    long l = 1;
+    const int peel_grid = 512;
+    for (;;) {
+        const long chunk = l < 512 ? 256 : 1024;
+        for (long j = 0; j < chunk && l + 1 < level_cap; j++, l++)
+            hipLaunchKernelGGL(k_sched_peel, dim3(peel_grid), dim3(256), 0, st, (int)l, K, need, succ, cnt, frontier, level, state, level_end);
+        SCHK(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
+        SCHK(hipStreamSynchronize(st));
+        if (host_state[ST_ERROR]) {
+            for (int s = 0; s < K; s++)
+                if (host_state[ST_ERROR] & (1u << s)) throw std::runtime_error(in.limit_msg[s] ? in.limit_msg[s] : "feature index exceed bound");
+        }
+        if ((long)host_state[ST_CURSOR] >= n) break;
+        if (l + 1 >= level_cap) throw std::runtime_error("device scheduler: the dependency graph did not drain");
+    }
+    const long nlevels = (long)host_state[ST_NLEVELS];
+    std::vector<unsigned> ends((size_t)nlevels + 1);
+    SCHK(hipMemcpyAsync(ends.data(), level_end, ((size_t)nlevels + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+
+    // final order: by (level, batch key, file position)
+    const int lvl_bits = bits_for((unsigned long long)nlevels);
+    const int key_bits = in.sort_key ? bits_for(in.sort_key_max) : 0;
+    if (lvl_bits + key_bits <= 32) {
+        unsigned *k2a = keys_a, *k2b = keys_b;   // the entry arrays are free again (m >= n)
+        hipLaunchKernelGGL(k_sched_final_keys<unsigned>, dim3(grid_for_n(n)), dim3(256), 0, st, n, level, in.sort_key, key_bits, k2a, vals_a);
+        size_t tmp_bytes = 0;
+        SCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k2a, k2b, vals_a, (unsigned *)order_out, (size_t)n, 0u, (unsigned)(lvl_bits + key_bits), st));
+        void *tmp = S.get<char>(tmp_bytes);
+        SCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, k2a, k2b, vals_a, (unsigned *)order_out, (size_t)n, 0u, (unsigned)(lvl_bits + key_bits), st));
+    } else {
+        unsigned long long *k2a = S.get<unsigned long long>((size_t)n), *k2b = S.get<unsigned long long>((size_t)n);
+        hipLaunchKernelGGL(k_sched_final_keys<unsigned long long>, dim3(grid_for_n(n)), dim3(256), 0, st, n, level, in.sort_key, key_bits, k2a, vals_a);
+        size_t tmp_bytes = 0;
+        SCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, k2a, k2b, vals_a, (unsigned *)order_out, (size_t)n, 0u, (unsigned)(lvl_bits + key_bits), st));
+        void *tmp = S.get<char>(tmp_bytes);
+        SCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, k2a, k2b, vals_a, (unsigned *)order_out, (size_t)n, 0u, (unsigned)(lvl_bits + key_bits), st));
+    }
+    SCHK(hipStreamSynchronize(st));
+    SCHK(hipGetLastError());
+    level_ptr.resize((size_t)nlevels + 1);
+    long biggest = 0;
+    for (long j = 0; j <= nlevels; j++) {
+        level_ptr[(size_t)j] = (long)ends[(size_t)j];
+        if (j > 0) biggest = std::max(biggest, level_ptr[(size_t)j] - level_ptr[(size_t)j - 1]);
+    }
+    if (max_level_size) *max_level_size = biggest;
+    return nlevels;
+}
+
+}  // namespace svdf

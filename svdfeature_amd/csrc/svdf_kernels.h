@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <type_traits>
+#include <vector>
 
 #include "svdf_types.h"
 
@@ -42,6 +43,24 @@ void launch_delta_pack(const DeltaRanges &R, const float *snap, void *dst, int h
 void launch_delta_unpack(const DeltaRanges &R, float *snap, const void *src, int half, int refresh, hipStream_t st);
 void launch_delta_sub(const float *cur, const float *snap, float *delta, long n, hipStream_t st);
 void launch_delta_add(float *cur, const float *snap, const float *delta, long n, hipStream_t st);
+// ---- conflict-free level scheduling on the device (svdf_k_sched.hip).  Unit u touches the parameter rows off[s] + col[s][u]
+// for its K slots (SLOT_ABSENT = none; ids >= limit[s] raise limit_msg[s]); no row may repeat inside a unit.  Writes the
+// level-sorted unit order (ties: sort_key, then file position -- the order of the host scheduler's stable sorts) to the
+// device array order_out[n] and the level boundaries to level_ptr; returns the number of levels.  Throws std::runtime_error.
+#define SVDF_SCHED_MAX_SLOTS 8
+struct SchedColumns {
+    int K;
+    long n;
+    const unsigned *col[SVDF_SCHED_MAX_SLOTS];     // device pointers, file order
+    unsigned off[SVDF_SCHED_MAX_SLOTS], limit[SVDF_SCHED_MAX_SLOTS];
+    const char *limit_msg[SVDF_SCHED_MAX_SLOTS];
+    unsigned num_res;                               // resource ids are < num_res
+    const unsigned *sort_key;                       // device, per unit; nullptr = file order inside a level
+    unsigned sort_key_max;
+};
+long device_schedule(const SchedColumns &in, int *order_out, std::vector<long> &level_ptr, long *max_level_size, hipStream_t st);
+void device_gather_u32(const unsigned *src, const int *order, unsigned *dst, long n, hipStream_t st);
+void device_gather_f32(const float *src, const int *order, float *dst, long n, hipStream_t st);
 // test probe: out[j] = device expf of in[j], or (in == nullptr) of the float with bit pattern first + j*step
 int device_expf(const float *in, unsigned first, unsigned step, float *out, long n);
 
