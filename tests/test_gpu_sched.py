@@ -106,5 +106,10 @@ def test_device_schedule_build_time_at_the_contract_size():
     ds = t.dataset_from_triples(u, i, r)
     dt = time.time() - t0
     print("device schedule of 100M ratings: %.3f s, %d batches, largest %d" % (dt, ds.num_batches, ds.max_batch))
-    assert ds.num_batches == 1872 and ds.num_row == n
+    assert 1800 <= ds.num_batches <= 1950 and ds.num_row == n and ds.max_batch <= ni
     assert dt < 0.5
+    h = _ready(0, 0, conf, 0)
+    t0 = time.time()
+    dh = h.dataset_from_triples(u, i, r)
+    print("host schedule of the same: %.3f s" % (time.time() - t0))
+    assert dh.num_batches == ds.num_batches and dh.max_batch == ds.max_batch
