@@ -33,6 +33,7 @@ extern "C" {
 
 typedef struct svdf_trainer svdf_trainer; /* opaque: one ISVDTrainer instance */
 typedef struct svdf_dataset svdf_dataset; /* opaque: a scheduled, HBM-resident training set */
+typedef struct svdf_ranker svdf_ranker;   /* opaque: one ISVDRanker instance */
 
 /* ---- library ---- */
 const char *svdf_version(void);
@@ -207,6 +208,36 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  * The relaxed mode itself is switched by CONFIG keys through svdf_set_param ("amd:relax_global",
  * "amd:relax_user_from", "amd:relax_item_from", "amd:relax_feedback"), not by knobs: it changes results. */
 int svdf_set_knob(svdf_trainer *t, const char *name, long value);
+
+/* ---- evaluation: RMSEEvaluator of svd_feature_infer.cpp:38-56,243-277 over a resident data set.  Predictions
+ * stay in HBM; *sum_sq_err = sum over instances of ((pred - label) * scale_score)^2 (difference and scaling in fp32, square and
+ * sum in fp64 like add_eval), *count = instances; RMSE = sqrt(sum / count) (print_stat).  The sum is a fixed fp64 tree on the
+ * device + long double over the partial sums, the reference's is a sequential long double sum: equal to ~1e-13 relative. */
+int svdf_eval_dataset(svdf_trainer *t, svdf_dataset *ds, float scale_score, double *sum_sq_err, int64_t *count);
+
+/* ---- ranking: class apex_svd::ISVDRanker (apex_svd.h:160-197) as implemented by SVDFeatureRanker
+ * (solvers/base-solver/apex_svd_base.h:597-813), obtained from create_svd_ranker(SVDTypeParam) (apex_svd.h:222).
+ *   svdf_ranker_set_param   ISVDRanker::set_param: feature_user, feature_item, top_k (:656-660)
+ *   svdf_ranker_load_model  ISVDRanker::load_model (:662-664); the caller has consumed the 4-byte SVDTypeParam
+ *   svdf_ranker_init        ISVDRanker::init_ranker(num_item_set) (:666-685)
+ *   svdf_ranker_process_*   ISVDRanker::process(std::vector<int>&, Elem / SVDPlusBlock) (:797-812): the tag travels in the
+ *                           label field (svdranker_tag, apex_svd.h:115-152: 0 ITEM, 2 USER, 1 POS, -1 BAN, 3 SPEC, 4 PROCESS).
+ *                           Results of the line (top_k item indices, or the rank positions of the positive samples) are
+ *                           written to out[0..capacity); the return value is the number of results (may exceed capacity:
+ *                           call again with a larger buffer is NOT possible, size it num_item_set), -1 on error.
+ * Scores are computed on the GPU in the reference's fp32 order; the results are the reference's, index for index. */
+svdf_ranker *svdf_ranker_create(uint8_t format_type, uint8_t active_type, uint8_t extend_type, uint8_t variant_type, int device);
+void svdf_ranker_destroy(svdf_ranker *r);
+int svdf_ranker_set_param(svdf_ranker *r, const char *name, const char *val);
+int svdf_ranker_load_model(svdf_ranker *r, FILE *fi);
+int svdf_ranker_init(svdf_ranker *r, int num_item_set);
+int64_t svdf_ranker_process_csr(svdf_ranker *r, float label, int num_global, int num_ufactor, int num_ifactor, const unsigned *index,
+                                const float *value, int *out, int64_t capacity);
+int64_t svdf_ranker_process_block(svdf_ranker *r, int num_ufeedback, int extend_tag, const unsigned *index_ufeedback,
+                                  const float *value_ufeedback, int num_row, const float *row_label, const int *row_ptr,
+                                  const unsigned *feat_index, const float *feat_value, int *out, int64_t capacity);
+/* counters: 0 user sections ranked, 1 sections finished by the host sort because scores tied at a requested position */
+int64_t svdf_ranker_counter(svdf_ranker *r, int what);
 
 /* ---- probe of the device-side expf used by the sigmoid links (active_type::map_active / cal_grad call libm's expf,
  * apex_svd_model.h:112-156): out[j] = expf evaluated ON THE GPU for in[j], or, with in == NULL, for the float whose bit

@@ -88,10 +88,44 @@ class SVDFeatureAMD : public ISVDTrainer {
 // decides between the random-order and the user-group trainer; both live behind one handle here.
 ISVDTrainer *create_svd_trainer(SVDTypeParam mtype) { return new SVDFeatureAMD(mtype); }
 
-ISVDRanker *create_svd_ranker(SVDTypeParam mtype) {
-    (void)mtype;
-    apex_utils::error("svdfeature_amd: SVDFeatureRanker is outside the accelerated path (use the reference base solver for ranking)");
-    return NULL;
-}
+// ISVDRanker (apex_svd.h:160-197) over svdf_ranker_*: what svd_feature_infer.cpp's task_pred_rank drives (:347-375)
+class SVDRankerAMD : public ISVDRanker {
+    svdf_ranker *h;
+    std::vector<unsigned> tmp_index;
+    std::vector<float> tmp_value;
+    std::vector<int> buf;
+    void take(std::vector<int> &result, int64_t n) {
+        if (n < 0) apex_utils::error(svdf_last_error());
+        for (int64_t i = 0; i < n && i < (int64_t)buf.size(); i++) result.push_back(buf[(size_t)i]);
+    }
+  public:
+    explicit SVDRankerAMD(const SVDTypeParam &mtype) : buf(1024) {
+        h = svdf_ranker_create(mtype.format_type, mtype.active_type, mtype.extend_type, mtype.variant_type, -1);
+    }
+    virtual ~SVDRankerAMD() { svdf_ranker_destroy(h); }
+    virtual void load_model(FILE *fi) { svdf_ranker_load_model(h, fi); }
+    virtual void init_ranker(int num_item_set) {
+        buf.resize(static_cast<size_t>(num_item_set) + 1024);
+        svdf_ranker_init(h, num_item_set);
+    }
+    virtual void set_param(const char *name, const char *val) { svdf_ranker_set_param(h, name, val); }
+    virtual void process(std::vector<int> &result, const SVDFeatureCSR::Elem &e) {
+        const int nv = e.num_global + e.num_ufactor + e.num_ifactor;
+        tmp_index.resize(nv + 1); tmp_value.resize(nv + 1);
+        int p = 0;
+        for (int i = 0; i < e.num_global; i++, p++) { tmp_index[p] = e.index_global[i]; tmp_value[p] = e.value_global[i]; }
+        for (int i = 0; i < e.num_ufactor; i++, p++) { tmp_index[p] = e.index_ufactor[i]; tmp_value[p] = e.value_ufactor[i]; }
+        for (int i = 0; i < e.num_ifactor; i++, p++) { tmp_index[p] = e.index_ifactor[i]; tmp_value[p] = e.value_ifactor[i]; }
+        take(result, svdf_ranker_process_csr(h, e.label, e.num_global, e.num_ufactor, e.num_ifactor, &tmp_index[0], &tmp_value[0], &buf[0],
+                                             (int64_t)buf.size()));
+    }
+    virtual void process(std::vector<int> &result, const SVDPlusBlock &b) {
+        if (buf.size() < 1024 + static_cast<size_t>(b.data.num_row) * 64) buf.resize(1024 + static_cast<size_t>(b.data.num_row) * 64);
+        take(result, svdf_ranker_process_block(h, b.num_ufeedback, b.extend_tag, b.index_ufeedback, b.value_ufeedback, b.data.num_row,
+                                               b.data.row_label, b.data.row_ptr, b.data.feat_index, b.data.feat_value, &buf[0], (int64_t)buf.size()));
+    }
+};
+
+ISVDRanker *create_svd_ranker(SVDTypeParam mtype) { return new SVDRankerAMD(mtype); }
 
 };  // namespace apex_svd

@@ -72,6 +72,19 @@ def _load(kind):
     lib.svdo_set_view.argtypes = [P, C.c_int, _f32p, C.c_long]
     lib.svdo_set_view.restype = C.c_long
     lib.svdo_kind.restype = C.c_int
+    RP = C.c_void_p
+    lib.svdo_ranker_create.restype = RP
+    lib.svdo_ranker_create.argtypes = [C.c_int] * 4
+    lib.svdo_ranker_destroy.argtypes = [RP]
+    lib.svdo_ranker_set_param.argtypes = [RP, C.c_char_p, C.c_char_p]
+    lib.svdo_ranker_load_model_path.argtypes = [RP, C.c_char_p, C.c_int]
+    lib.svdo_ranker_init.argtypes = [RP, C.c_int]
+    lib.svdo_ranker_process_csr.restype = C.c_long
+    lib.svdo_ranker_process_csr.argtypes = [RP, C.c_float, C.c_int, C.c_int, C.c_int, _u32p, _f32p, _i32p, C.c_long]
+    lib.svdo_ranker_process_block.restype = C.c_long
+    lib.svdo_ranker_process_block.argtypes = [RP, C.c_int, C.c_int, _u32p, _f32p, C.c_int, _f32p, _i32p, _u32p, _f32p, _i32p, C.c_long]
+    lib.svdo_sum_sq_err.restype = C.c_double
+    lib.svdo_sum_sq_err.argtypes = [_f32p, _f32p, C.c_long, C.c_float]
     lib.svdo_libm_expf.argtypes = [C.c_void_p, C.c_uint, C.c_uint, _f32p, C.c_long]
     _libs[kind] = lib
     return lib
@@ -185,3 +198,61 @@ class OracleTrainer:
     def set_view(self, name, arr):
         a = np.ascontiguousarray(arr, dtype=np.float32).ravel()
         assert self.lib.svdo_set_view(self.h, VIEW[name], _pad(a, np.float32), a.size) == a.size
+
+
+def sum_sq_err(pred, label, scale=1.0, kind="port"):
+    """RMSEEvaluator's accumulator (svd_feature_infer.cpp:38-56): sequential long double sum of ((pred - label) * scale)^2."""
+    lib = _load(kind)
+    pred, label = np.ascontiguousarray(pred, np.float32), np.ascontiguousarray(label, np.float32)
+    return float(lib.svdo_sum_sq_err(_pad(pred, np.float32), _pad(label, np.float32), len(pred), float(scale)))
+
+
+class OracleRanker:
+    """ISVDRanker-shaped handle on one of the CPU checkers (apex_svd.h:160-197)."""
+
+    def __init__(self, kind="port", format_type=0, active_type=0, extend_type=0, variant_type=0):
+        self.lib = _load(kind)
+        self.h = self.lib.svdo_ranker_create(format_type, active_type, extend_type, variant_type)
+        self.cap = 16
+
+    def close(self):
+        if self.h:
+            self.lib.svdo_ranker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_param(self, name, val):
+        self.lib.svdo_ranker_set_param(self.h, str(name).encode(), str(val).encode())
+
+    def load_model(self, path, with_type_header=True):
+        assert self.lib.svdo_ranker_load_model_path(self.h, str(path).encode(), int(with_type_header)) == 0
+
+    def init_ranker(self, num_item_set):
+        self.cap = max(16, int(num_item_set) + 16)
+        self.lib.svdo_ranker_init(self.h, int(num_item_set))
+
+    def process(self, label, ng, nu, ni, index, value):
+        out = np.zeros(self.cap, np.int32)
+        n = self.lib.svdo_ranker_process_csr(self.h, float(label), ng, nu, ni, _pad(index, np.uint32), _pad(value, np.float32), out, self.cap)
+        return out[:n].copy()
+
+    def process_rows(self, d):
+        """every row of a CSRData through process(); returns the concatenated results"""
+        res = []
+        for r in range(d.num_row):
+            res.append(self.process(*d.row(r)))
+        return np.concatenate(res) if res else np.zeros(0, np.int32)
+
+    def process_block(self, b):
+        d = b.data
+        cap = self.cap * max(1, d.num_row)
+        out = np.zeros(cap, np.int32)
+        n = self.lib.svdo_ranker_process_block(self.h, b.num_ufeedback, b.extend_tag, _pad(b.index_ufeedback, np.uint32),
+                                               _pad(b.value_ufeedback, np.float32), d.num_row, _pad(d.row_label, np.float32),
+                                               _pad(d.row_ptr, np.int32), _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32), out, cap)
+        return out[:n].copy()

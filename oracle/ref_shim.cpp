@@ -205,4 +205,54 @@ long svdo_get_view(svdo_trainer *t, int which, float *out, long capacity) {
 
 long svdo_set_view(svdo_trainer *, int, const float *, long) { return -1; }
 
+
+/* ---- the reference's own ranker, obtained like svd_feature_infer.cpp obtains it: create_svd_ranker(SVDTypeParam) ---- */
+struct svdo_ranker { SVDTypeParam mtype; ISVDRanker *rk; };
+svdo_ranker *svdo_ranker_create(int format_type, int active_type, int extend_type, int variant_type) {
+    svdo_ranker *r = new svdo_ranker();
+    r->mtype.format_type = (uint8_t)format_type; r->mtype.active_type = (uint8_t)active_type;
+    r->mtype.extend_type = (uint8_t)extend_type; r->mtype.variant_type = (uint8_t)variant_type;
+    r->rk = create_svd_ranker(r->mtype);
+    return r;
+}
+void svdo_ranker_destroy(svdo_ranker *r) { if (r) { delete r->rk; delete r; } }
+void svdo_ranker_set_param(svdo_ranker *r, const char *name, const char *val) { r->rk->set_param(name, val); }
+int svdo_ranker_load_model_path(svdo_ranker *r, const char *path, int with_type_header) {
+    FILE *fi = fopen(path, "rb");
+    if (!fi) return -1;
+    if (with_type_header) { SVDTypeParam mt; if (fread(&mt, sizeof(SVDTypeParam), 1, fi) != 1) { fclose(fi); return -1; } }
+    char cwd[4096];
+    char tmpl[] = "/tmp/svdf_ref_XXXXXX";
+    char *scratch = mkdtemp(tmpl);   /* load_from_file drops text dumps into the CWD (apex_svd_model.h:586-621) */
+    bool moved = scratch && getcwd(cwd, sizeof(cwd)) && chdir(scratch) == 0;
+    r->rk->load_model(fi);
+    if (moved) {
+        const char *junk[] = {"u_bias.txt", "i_bias.txt", "w_user.txt", "w_item.txt"};
+        for (int i = 0; i < 4; i++) unlink(junk[i]);
+        if (chdir(cwd) != 0) { }
+        rmdir(scratch);
+    }
+    fclose(fi);
+    return 0;
+}
+void svdo_ranker_init(svdo_ranker *r, int num_item_set) { r->rk->init_ranker(num_item_set); }
+long svdo_ranker_process_csr(svdo_ranker *r, float label, int ng, int nu, int ni, const unsigned *index, const float *value, int *out, long cap) {
+    std::vector<int> res;
+    r->rk->process(res, make_elem(label, ng, nu, ni, index, value));
+    for (size_t i = 0; i < res.size() && (long)i < cap; i++) out[i] = res[i];
+    return (long)res.size();
+}
+long svdo_ranker_process_block(svdo_ranker *r, int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb, int num_row,
+                               const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value, int *out, long cap) {
+    std::vector<int> res;
+    r->rk->process(res, make_block(nfb, extend_tag, idx_fb, val_fb, num_row, row_label, row_ptr, feat_index, feat_value));
+    for (size_t i = 0; i < res.size() && (long)i < cap; i++) out[i] = res[i];
+    return (long)res.size();
+}
+double svdo_sum_sq_err(const float *pred, const float *label, long n, float scale) {   /* svd_feature_infer.cpp:43-47 */
+    long double sum = 0.0f;
+    for (long i = 0; i < n; i++) { double diff = (pred[i] - label[i]) * scale; sum += diff * diff; }
+    return (double)sum;
+}
+
 } /* extern "C" */

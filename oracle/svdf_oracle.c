@@ -1033,3 +1033,175 @@ long svdo_set_view(svdo_trainer *t, int which, const float *in, long count) {
     else for (int y = 0; y < rows; y++) memcpy(mat + (size_t)y * t->pitch, in + (size_t)y * cols, sizeof(float) * (size_t)cols);
     return count;
 }
+
+/* ================= ISVDRanker: SVDFeatureRanker, solvers/base-solver/apex_svd_base.h:597-813 =================
+ * The model, its file format and the side tables are the trainer's (SVDModel, SparseFeatureArray), so the ranker keeps a
+ * trainer object for them.  Ordering of candidates with EQUAL scores: the reference leaves it to std::sort (:767), which is
+ * not a stable sort; this restatement orders ties by candidate index.  The compiled reference (oracle/_ref) is the checker
+ * for tied scores, the tests for this file keep the scores distinct. */
+struct svdo_ranker {
+    svdo_trainer *m;
+    int top_k, num_item_set, num_item_processed, init_end;
+    float *tmp_ifactors, *bias_ifactors, *item_score, *tmp_ufactor, *tmp_ifactor, *tmp_ufeedback;
+    int *item_tag, *pos_item, npos;
+};
+svdo_ranker *svdo_ranker_create(int format_type, int active_type, int extend_type, int variant_type) {
+    svdo_ranker *r = (svdo_ranker *)calloc(1, sizeof(*r));
+    r->m = svdo_create(format_type, active_type, extend_type, variant_type);
+    return r;
+}
+void svdo_ranker_destroy(svdo_ranker *r) {
+    if (!r) return;
+    svdo_destroy(r->m);
+    free(r->tmp_ifactors); free(r->bias_ifactors); free(r->item_score); free(r->tmp_ufactor); free(r->tmp_ifactor); free(r->tmp_ufeedback);
+    free(r->item_tag); free(r->pos_item);
+    free(r);
+}
+void svdo_ranker_set_param(svdo_ranker *r, const char *name, const char *val) { /* :656-660 */
+    if (!strcmp(name, "feature_user")) strcpy(r->m->name_feat_user, val);
+    if (!strcmp(name, "feature_item")) strcpy(r->m->name_feat_item, val);
+    if (!strcmp(name, "top_k")) r->top_k = atoi(val);
+}
+int svdo_ranker_load_model_path(svdo_ranker *r, const char *path, int with_type_header) { /* :662-664 */
+    FILE *fi = fopen(path, "rb");
+    if (!fi) return -1;
+    if (with_type_header) { uint8_t mt[4]; assert_true(fread(mt, 1, 4, fi) == 4, "loading model"); }
+    load_model(r->m, fi);
+    fclose(fi);
+    return 0;
+}
+void svdo_ranker_init(svdo_ranker *r, int num_item_set) { /* :666-685 */
+    svdo_trainer *t = r->m;
+    if (strcmp(t->name_feat_user, "NULL")) sf_load(&t->feat_user, t->name_feat_user);
+    if (strcmp(t->name_feat_item, "NULL")) sf_load(&t->feat_item, t->name_feat_item);
+    const size_t row = (size_t)t->pitch + 4;
+    r->num_item_processed = 0;
+    r->num_item_set = num_item_set;
+    r->tmp_ufactor = (float *)calloc(row, sizeof(float));
+    r->tmp_ifactor = (float *)calloc(row, sizeof(float));
+    r->tmp_ufeedback = (float *)calloc(row, sizeof(float));
+    r->tmp_ifactors = (float *)calloc((size_t)(num_item_set > 0 ? num_item_set : 1) * (size_t)t->pitch + 4, sizeof(float));
+    r->bias_ifactors = (float *)calloc((size_t)num_item_set + 1, sizeof(float));
+    r->item_score = (float *)calloc((size_t)num_item_set + 1, sizeof(float));
+    r->item_tag = (int *)calloc((size_t)num_item_set + 1, sizeof(int));
+    r->pos_item = (int *)calloc((size_t)num_item_set + 1, sizeof(int));
+    r->init_end = 1;
+}
+/* :676-700 */
+static void rk_prepare_ifactor(svdo_ranker *r, float *ifactor, float *bias_out, const elem *f) {
+    svdo_trainer *t = r->m;
+    const int k = t->mp.num_factor;
+    const sf_entry *vec;
+    float bias = 0.0f;
+    for (int j = 0; j < k; j++) ifactor[j] = 0.0f;
+    for (int i = 0; i < f->ni; i++) {
+        unsigned iid = f->ii[i];
+        float ival = f->vi[i];
+        assert_true(iid < (unsigned)t->mp.num_item, "item feature index exceed setting");
+        axpy(ifactor, t->W_item + (size_t)iid * t->pitch, (float)(double)ival, k);
+        bias += t->i_bias[iid] * ival;
+        int n = sf_get(&t->feat_item, iid, &vec);
+        for (int j = 0; j < n; j++) {
+            axpy(ifactor, t->W_item + (size_t)vec[j].index * t->pitch, (float)((double)vec[j].value * (double)ival), k);
+            bias += t->i_bias[vec[j].index] * vec[j].value * ival;
+        }
+    }
+    for (int i = 0; i < f->ng; i++) {
+        unsigned gid = f->ig[i];
+        assert_true(gid < (unsigned)t->mp.num_global, "global feature index exceed setting");
+        bias += f->vg[i] * t->g_bias[gid];
+    }
+    *bias_out = bias;
+}
+typedef struct { int iid; float score; } rk_entry;
+static int rk_cmp(const void *a, const void *b) { /* Entry::operator< (:623): descending score; ties by index (see the note above) */
+    const rk_entry *x = (const rk_entry *)a, *y = (const rk_entry *)b;
+    if (x->score > y->score) return -1;
+    if (y->score > x->score) return 1;
+    return (x->iid > y->iid) - (x->iid < y->iid);
+}
+static long rk_proc(svdo_ranker *r, const elem *f, int *out, long cap) { /* proc :786-796 */
+    svdo_trainer *t = r->m;
+    const int k = t->mp.num_factor;
+    const sf_entry *vec;
+    const int tag = (int)f->label;
+    long nout = 0;
+    if (tag == 0) { /* ITEM_TAG, proc_item :702-707 */
+        const int idx = r->num_item_processed++;
+        assert_true(r->num_item_processed <= r->num_item_set, "item instance exceed specified item set size");
+        rk_prepare_ifactor(r, r->tmp_ifactors + (size_t)idx * t->pitch, &r->bias_ifactors[idx], f);
+    } else if (tag == 2) { /* USER_TAG, proc_user :709-728 */
+        if (t->mtype[0] == 1) memcpy(r->tmp_ufactor, r->tmp_ufeedback, sizeof(float) * (size_t)k);
+        else for (int j = 0; j < k; j++) r->tmp_ufactor[j] = 0.0f;
+        for (int i = 0; i < f->nu; i++) {
+            unsigned uid = f->iu[i];
+            assert_true(uid < (unsigned)t->mp.num_user, "user feature index exceed bound");
+            axpy(r->tmp_ufactor, t->W_user + (size_t)uid * t->pitch, (float)(double)f->vu[i], k);
+            int n = sf_get(&t->feat_user, uid, &vec);
+            for (int j = 0; j < n; j++) axpy(r->tmp_ufactor, t->W_user + (size_t)vec[j].index * t->pitch, (float)(double)vec[j].value, k);
+        }
+        r->npos = 0;
+        for (int i = 0; i < r->num_item_set; i++) r->item_score[i] = 0.0f;
+        for (int i = 0; i < r->num_item_processed; i++) r->item_tag[i] = 0;
+    } else if (tag == 1 || tag == -1) { /* POS_SAMPLE / BAN_SAMPLE, proc_tag :729-738 */
+        for (int i = 0; i < f->nu; i++) {
+            const int idx = (int)f->iu[i];
+            assert_true(idx < r->num_item_processed, "sample item index exceed bound");
+            assert_true(r->item_tag[idx] == 0, "each pos sample item can not occur in baned sample list");
+            r->item_tag[idx] = tag;
+            if (tag == 1) r->pos_item[r->npos++] = idx;
+        }
+    } else if (tag == 3) { /* SPEC_SAMPLE, proc_spec :739-747 */
+        assert_true(f->nu == 1, "must specify item index of sample in user feature field\n");
+        const int idx = (int)f->iu[0];
+        assert_true(idx < r->num_item_processed, "sample item index exceed bound");
+        float bias;
+        rk_prepare_ifactor(r, r->tmp_ifactor, &bias, f);
+        r->item_score[idx] = bias + sdot(r->tmp_ufactor, r->tmp_ifactor, k);
+    } else if (tag == 4) { /* PROCESS_TAG, proc_rank :748-785 */
+        rk_entry *e = (rk_entry *)malloc(sizeof(rk_entry) * (size_t)(r->num_item_processed + 1));
+        int ne = 0;
+        for (int i = 0; i < r->num_item_processed; i++) {
+            if (r->item_tag[i] == -1) continue;
+            r->item_score[i] += r->bias_ifactors[i] + sdot(r->tmp_ufactor, r->tmp_ifactors + (size_t)i * t->pitch, k);
+            e[ne].iid = i; e[ne].score = r->item_score[i]; ne++;
+        }
+        qsort(e, (size_t)ne, sizeof(rk_entry), rk_cmp);
+        if (r->top_k > 0) {
+            assert_true(ne >= r->top_k, "k can not exceed candidate size");
+            for (int j = 0; j < r->top_k; j++) { if (nout < cap) out[nout] = e[j].iid; nout++; }
+        } else {
+            for (int i = 0; i < ne; i++) r->item_tag[e[i].iid] = i;
+            for (int i = 0; i < r->npos; i++) { if (nout < cap) out[nout] = r->item_tag[r->pos_item[i]]; nout++; }
+        }
+        free(e);
+    }
+    return nout;
+}
+long svdo_ranker_process_csr(svdo_ranker *r, float label, int ng, int nu, int ni, const unsigned *index, const float *value, int *out, long cap) {
+    elem e = make_elem(label, ng, nu, ni, index, value);
+    return rk_proc(r, &e, out, cap);
+}
+long svdo_ranker_process_block(svdo_ranker *r, int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb, int num_row,
+                               const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value, int *out, long cap) {
+    svdo_trainer *t = r->m; /* :797-812 */
+    if (extend_tag == 0 || extend_tag == 1) {
+        const int k = t->mp.num_factor;
+        for (int j = 0; j < k; j++) r->tmp_ufeedback[j] = 0.0f;
+        for (int i = 0; i < nfb; i++) {
+            assert_true(idx_fb[i] < (unsigned)t->mp.num_ufeedback, "ufeedback id exceed bound");
+            axpy(r->tmp_ufeedback, t->W_ufb + (size_t)idx_fb[i] * t->pitch, (float)(double)val_fb[i], k);
+        }
+    }
+    long total = 0;
+    for (int i = 0; i < num_row; i++) {
+        elem e = csr_row(i, row_label, row_ptr, feat_index, feat_value);
+        total += rk_proc(r, &e, out + total, cap - total);
+    }
+    return total;
+}
+double svdo_sum_sq_err(const float *pred, const float *label, long n, float scale) { /* svd_feature_infer.cpp:43-47 */
+    long double sum = 0.0f;
+    for (long i = 0; i < n; i++) { double diff = (pred[i] - label[i]) * scale; sum += diff * diff; }
+    return (double)sum;
+}

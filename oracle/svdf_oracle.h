@@ -77,6 +77,21 @@ int svdo_kind(void);
  * in == NULL over the floats with bit patterns first + j*step: checker for the device's expf restatement */
 void svdo_libm_expf(const float *in, unsigned first, unsigned step, float *out, long n);
 
+/* ---- ISVDRanker (apex_svd.h:160-197) / SVDFeatureRanker (solvers/base-solver/apex_svd_base.h:597-813) ---- */
+typedef struct svdo_ranker svdo_ranker;
+svdo_ranker *svdo_ranker_create(int format_type, int active_type, int extend_type, int variant_type);
+void svdo_ranker_destroy(svdo_ranker *r);
+void svdo_ranker_set_param(svdo_ranker *r, const char *name, const char *val);
+int svdo_ranker_load_model_path(svdo_ranker *r, const char *path, int with_type_header);
+void svdo_ranker_init(svdo_ranker *r, int num_item_set);
+/* process(vector<int>&, Elem / SVDPlusBlock): the results of the line go to out[0..cap); returns their number */
+long svdo_ranker_process_csr(svdo_ranker *r, float label, int ng, int nu, int ni, const unsigned *index, const float *value, int *out, long cap);
+long svdo_ranker_process_block(svdo_ranker *r, int num_ufeedback, int extend_tag, const unsigned *index_ufeedback, const float *value_ufeedback,
+                               int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value,
+                               int *out, long cap);
+/* RMSEEvaluator (svd_feature_infer.cpp:38-56): sequential long double sum of ((pred - label) * scale)^2, returned as double */
+double svdo_sum_sq_err(const float *pred, const float *label, long n, float scale);
+
 #ifdef __cplusplus
 }
 #endif

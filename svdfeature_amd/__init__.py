@@ -115,6 +115,19 @@ def load_library():
     lib.svdf_counter.argtypes = [P, C.c_int]
     lib.svdf_set_knob.argtypes = [P, C.c_char_p, C.c_long]
     lib.svdf_schedule_resources.argtypes = [C.c_long, _i64p, _u32p, C.c_long, _i32p, _i64p, C.c_long]
+    lib.svdf_eval_dataset.argtypes = [P, P, C.c_float, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+    lib.svdf_ranker_create.restype = P
+    lib.svdf_ranker_create.argtypes = [C.c_uint8] * 4 + [C.c_int]
+    lib.svdf_ranker_destroy.argtypes = [P]
+    lib.svdf_ranker_set_param.argtypes = [P, C.c_char_p, C.c_char_p]
+    lib.svdf_ranker_load_model.argtypes = [P, C.c_void_p]
+    lib.svdf_ranker_init.argtypes = [P, C.c_int]
+    lib.svdf_ranker_process_csr.restype = C.c_int64
+    lib.svdf_ranker_process_csr.argtypes = [P, C.c_float, C.c_int, C.c_int, C.c_int, _u32p, _f32p, _i32p, C.c_int64]
+    lib.svdf_ranker_process_block.restype = C.c_int64
+    lib.svdf_ranker_process_block.argtypes = [P, C.c_int, C.c_int, _u32p, _f32p, C.c_int, _f32p, _i32p, _u32p, _f32p, _i32p, C.c_int64]
+    lib.svdf_ranker_counter.restype = C.c_int64
+    lib.svdf_ranker_counter.argtypes = [P, C.c_int]
     lib.svdf_device_expf.argtypes = [C.c_void_p, C.c_uint, C.c_uint, _f32p, C.c_long]
     lib.svdf_set_error_mode(1)   # python callers get exceptions instead of exit(-1)
     _lib = lib
@@ -351,6 +364,12 @@ class Trainer:
     def train_dataset(self, ds):
         self._ok(self.lib.svdf_train_dataset(self.h, ds.h))
 
+    def eval_dataset(self, ds, scale_score=1.0):
+        """RMSEEvaluator over a resident data set (svd_feature_infer.cpp:38-56, 243-277): (sum of squared errors, count)."""
+        ss, cnt = C.c_double(), C.c_int64()
+        self._ok(self.lib.svdf_eval_dataset(self.h, ds.h, float(scale_score), C.byref(ss), C.byref(cnt)))
+        return ss.value, cnt.value
+
     def predict_dataset(self, ds):
         out = np.zeros(max(ds.num_row, 1), dtype=np.float32)
         self._ok(self.lib.svdf_predict_dataset(self.h, ds.h, out))
@@ -435,3 +454,73 @@ class Trainer:
 
 _libc.fwrite.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
 _libc.fread.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]
+
+
+class Ranker:
+    """ISVDRanker over the HIP engine (apex_svd.h:160-197; SVDFeatureRanker apex_svd_base.h:597-813)."""
+
+    def __init__(self, format_type=0, active_type=0, extend_type=0, variant_type=0, device=-1):
+        self.lib = load_library()
+        self.h = self.lib.svdf_ranker_create(format_type, active_type, extend_type, variant_type, device)
+        if not self.h:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        self.cap = 16
+
+    def close(self):
+        if self.h:
+            self.lib.svdf_ranker_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ok(self, rc):
+        if rc < 0:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return rc
+
+    def set_param(self, name, val):
+        self._ok(self.lib.svdf_ranker_set_param(self.h, str(name).encode(), str(val).encode()))
+
+    def load_model(self, path, with_type_header=True):
+        fi = _libc.fopen(str(path).encode(), b"rb")
+        if not fi:
+            raise SvdfError("cannot open %s" % path)
+        try:
+            if with_type_header:
+                buf = C.create_string_buffer(4)
+                _libc.fread(buf, 1, 4, C.c_void_p(fi))
+            self._ok(self.lib.svdf_ranker_load_model(self.h, fi))
+        finally:
+            _libc.fclose(fi)
+
+    def init_ranker(self, num_item_set):
+        self.cap = max(16, int(num_item_set) + 16)
+        self._ok(self.lib.svdf_ranker_init(self.h, int(num_item_set)))
+
+    def process(self, label, ng, nu, ni, index, value):
+        out = np.zeros(self.cap, np.int32)
+        n = self._ok(self.lib.svdf_ranker_process_csr(self.h, float(label), ng, nu, ni, _pad(index, np.uint32), _pad(value, np.float32), out, self.cap))
+        return out[:n].copy()
+
+    def process_rows(self, d):
+        res = []
+        for r in range(d.num_row):
+            res.append(self.process(*d.row(r)))
+        return np.concatenate(res) if res else np.zeros(0, np.int32)
+
+    def process_block(self, b):
+        d = b.data
+        cap = self.cap * max(1, d.num_row)
+        out = np.zeros(cap, np.int32)
+        n = self._ok(self.lib.svdf_ranker_process_block(self.h, b.num_ufeedback, b.extend_tag, _pad(b.index_ufeedback, np.uint32),
+                                                        _pad(b.value_ufeedback, np.float32), d.num_row, _pad(d.row_label, np.float32),
+                                                        _pad(d.row_ptr, np.int32), _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32),
+                                                        out, cap))
+        return out[:n].copy()
+
+    def counter(self, what):
+        return int(self.lib.svdf_ranker_counter(self.h, what))

@@ -18,6 +18,7 @@ void note_error(const std::string &m);
 
 struct svdf_trainer { svdf::Engine *e; };
 struct svdf_dataset { svdf::Dataset *d; };
+struct svdf_ranker { svdf::Ranker *r; };
 
 // In error mode 0 svdf::fail() has already printed and exited (reference behaviour); in mode 1 it
 // throws and the wrapper turns that into a status code.
@@ -183,6 +184,38 @@ void *svdf_stream(svdf_trainer *t) { return (void *)t->e->stream(); }
 int svdf_synchronize(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->synchronize(); return 0; }) }
 int64_t svdf_counter(svdf_trainer *t, int what) { return t->e->counter(what); }
 int svdf_set_knob(svdf_trainer *t, const char *name, long value) { SVDF_GUARD(-1, { return t->e->set_knob(name, value); }) }
+
+int svdf_eval_dataset(svdf_trainer *t, svdf_dataset *ds, float scale_score, double *sum_sq_err, int64_t *count) {
+    SVDF_GUARD(-1, { t->e->eval_dataset(ds->d, scale_score, sum_sq_err, count); return 0; })
+}
+
+/* ---- ISVDRanker ---- */
+svdf_ranker *svdf_ranker_create(uint8_t format_type, uint8_t active_type, uint8_t extend_type, uint8_t variant_type, int device) {
+    SVDF_GUARD(nullptr, {
+        svdf::TypeParam tp{format_type, active_type, extend_type, variant_type};
+        svdf_ranker *h = new svdf_ranker();
+        h->r = nullptr;
+        try { h->r = new svdf::Ranker(tp, device); } catch (...) { delete h; throw; }
+        return h;
+    })
+}
+void svdf_ranker_destroy(svdf_ranker *r) {
+    if (!r) return;
+    try { delete r->r; } catch (...) {}
+    delete r;
+}
+int svdf_ranker_set_param(svdf_ranker *r, const char *name, const char *val) { SVDF_GUARD(-1, { r->r->set_param(name, val); return 0; }) }
+int svdf_ranker_load_model(svdf_ranker *r, FILE *fi) { SVDF_GUARD(-1, { r->r->load_model(fi); return 0; }) }
+int svdf_ranker_init(svdf_ranker *r, int num_item_set) { SVDF_GUARD(-1, { r->r->init_ranker(num_item_set); return 0; }) }
+int64_t svdf_ranker_process_csr(svdf_ranker *r, float label, int ng, int nu, int ni, const unsigned *index, const float *value, int *out,
+                                int64_t capacity) {
+    SVDF_GUARD(-1, { return (int64_t)r->r->process(label, ng, nu, ni, index, value, out, (long)capacity); })
+}
+int64_t svdf_ranker_process_block(svdf_ranker *r, int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label,
+                                  const int *row_ptr, const unsigned *feat_index, const float *feat_value, int *out, int64_t capacity) {
+    SVDF_GUARD(-1, { return (int64_t)r->r->process_block(nfb, tag, ifb, vfb, num_row, row_label, row_ptr, feat_index, feat_value, out, (long)capacity); })
+}
+int64_t svdf_ranker_counter(svdf_ranker *r, int what) { return r->r->counter(what); }
 
 int svdf_device_expf(const float *in, unsigned first_bits, unsigned step_bits, float *out, long n) {
     SVDF_GUARD(-1, { return svdf::device_expf(in, first_bits, step_bits, out, n); })

@@ -61,6 +61,8 @@ template struct DevBuf<int>;
 template struct DevBuf<unsigned>;
 template struct DevBuf<DevUnit>;
 template struct DevBuf<DevBlk>;
+template struct DevBuf<signed char>;
+template struct DevBuf<double>;
 
 // =============================================================================== scheduler
 void build_schedule(const std::vector<int> &levels, int base, Schedule &out) {
@@ -1873,6 +1875,52 @@ void Engine::predict_dataset(Dataset *ds, float *out) {
         HIPCHECK(hipStreamSynchronize(stream_));
     }
     n_launches_++;
+}
+
+// RMSEEvaluator (svd_feature_infer.cpp:38-56) over a resident data set without bringing the predictions back: the squared
+// errors are summed in fp64 per workgroup on the device (fixed tree), the few hundred partial sums in long double on the host
+// like the reference's accumulator.  The reference adds one instance at a time in long double; the tree differs from that by
+// rounding only (relative 1e-13 at 1e8 instances), stated in the test.
+void Engine::eval_dataset(Dataset *ds, float scale, double *sum_sq, int64_t *count) {
+    check(ds && ds->owner == this, "eval_dataset: dataset belongs to another trainer");
+    check(ds->sched_signature == schedule_signature(), "eval_dataset: the dataset was scheduled under another configuration; build it again");
+    flush();
+    const DevParams &P = params();
+    const long n = ds->num_row;
+    *sum_sq = 0.0; *count = n;
+    if (n == 0) return;
+    w_out_.reserve((size_t)n);
+    const float *labels = nullptr;
+    if (ds->kind == 4) {
+        const UnitDev &d = ds->unitdev;
+        launch_imfb(P, d.csr(), d.units.p, d.blks.p, d.fbidx.p, d.fbval.p, nullptr, 0, ds->num_units, sample_counter_, w_out_.p, stream_);
+        labels = d.label.p;
+    } else if (ds->kind == 3) {
+        const UnitDev &d = ds->unitdev;
+        launch_svdpp_predict(P, d.csr(), d.units.p, d.fbidx.p, d.fbval.p, ds->num_units, w_out_.p, stream_);
+        labels = d.label.p;
+    } else if (ds->kind == 0) {
+        BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
+        launch_predict_basic(P, S, n, w_out_.p, stream_);
+        labels = ds->label.p;   // same (level) order as the predictions
+    } else if (ds->kind == 2) {
+        launch_predict_fused(P, ds->fused.view(), ds->fused.max_nu, ds->fused.max_ni, n, w_out_.p, stream_);
+        labels = ds->fused.label.p;
+    } else {
+        DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
+        launch_predict(P, D, n, w_out_.p, stream_);
+        labels = ds->row_label.p;
+    }
+    const int g = sqerr_partials_grid(n);
+    if (d_partials_.cap < (size_t)g) { if (d_partials_.p) (void)hipFree(d_partials_.p); d_partials_.p = nullptr; HIPCHECK(hipMalloc((void **)&d_partials_.p, (size_t)g * sizeof(double))); d_partials_.cap = (size_t)g; }
+    launch_sqerr_partials(w_out_.p, labels, n, scale, d_partials_.p, stream_);
+    std::vector<double> part((size_t)g);
+    HIPCHECK(hipMemcpyAsync(part.data(), d_partials_.p, (size_t)g * sizeof(double), hipMemcpyDeviceToHost, stream_));
+    HIPCHECK(hipStreamSynchronize(stream_));
+    long double acc = 0.0L;
+    for (double x : part) acc += (long double)x;
+    *sum_sq = (double)acc;
+    n_launches_ += 2;
 }
 
 // =============================================================================== item-side delta (multi-GPU)

@@ -13,6 +13,7 @@
 
 #include <condition_variable>
 #include <cstdio>
+#include <memory>
 #include <mutex>
 #include <stdexcept>
 #include <thread>
@@ -146,6 +147,7 @@ private:
 struct RankPrefetch;
 struct UserGroupArrays;
 class Engine;
+class Ranker;
 
 // HBM-resident scheduled training set
 struct Dataset {
@@ -217,6 +219,7 @@ class Engine {
     void rank_prefetch_drop();
     void train_dataset(Dataset *ds);
     void predict_dataset(Dataset *ds, float *out);
+    void eval_dataset(Dataset *ds, float scale, double *sum_sq, int64_t *count);
 
     // multi-GPU item-side delta
     void item_delta_begin();
@@ -383,6 +386,7 @@ class Engine {
     UnitDev w_unitdev_;
     // ---- item delta
     DevBuf<float> d_snap_, d_delta_;
+    DevBuf<double> d_partials_;
     struct Range { float *base; long n; };
     std::vector<Range> shared_ranges();
     // ---- counters
@@ -391,6 +395,41 @@ class Engine {
     int64_t n_kind_[3] = {0, 0, 0};   // launches of k_basicmf / k_general / k_fused
     DeltaRanges delta_ranges();
     friend struct Dataset;
+    friend class Ranker;
+};
+
+// ISVDRanker (apex_svd.h:160-197) / SVDFeatureRanker (apex_svd_base.h:597-813) on the device, see svdf_ranker.cpp
+class Ranker {
+  public:
+    Ranker(TypeParam mtype, int device);
+    ~Ranker();
+    void set_param(const char *name, const char *val);
+    void load_model(FILE *fi);
+    void init_ranker(int num_item_set);
+    // process(vector<int>&, Elem) / process(vector<int>&, SVDPlusBlock): results appended to out (up to cap), count returned
+    long process(float label, int ng, int nu, int ni, const unsigned *index, const float *value, int *out, long cap);
+    long process_block(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label, const int *row_ptr,
+                       const unsigned *feat_index, const float *feat_value, int *out, long cap);
+    int64_t counter(int what) const { return what == 0 ? n_sections_ : (what == 1 ? n_host_sorts_ : -1); }
+  private:
+    TypeParam mtype_;
+    std::unique_ptr<Engine> eng_;   // owns the model in HBM, the side tables and the kernel parameter block
+    int top_k_ = 0, num_item_set_ = 0, num_item_processed_ = 0;
+    long items_on_device_ = 0;
+    bool init_end_ = false, user_open_ = false;
+    HostCSR items_, spec_;
+    std::vector<int> spec_idx_, pos_item_;
+    std::vector<signed char> tag_;
+    std::vector<unsigned> user_idx_;
+    std::vector<float> user_val_, host_score_;
+    DevBuf<float> d_ifactors_, d_ibias_, d_score_, d_tu_, d_fb_, w_label_, w_value_, w_uval_, w_fbval_, s_label_, s_value_;
+    DevBuf<int> w_ptr_, s_ptr_, s_idx_, d_pos_, d_cnt_;
+    DevBuf<unsigned> w_index_, w_uidx_, w_fbidx_, s_index_;
+    DevBuf<signed char> d_tag_;
+    int64_t n_sections_ = 0, n_host_sorts_ = 0;
+    void stage(HostCSR &dst, int ng, int nu, int ni, const unsigned *index, const float *value);
+    void check_item_side(int ng, int nu, int ni, const unsigned *index);
+    long rank(int *out, long cap);
 };
 
 }  // namespace svdf

@@ -43,6 +43,16 @@ void launch_delta_pack(const DeltaRanges &R, const float *snap, void *dst, int h
 void launch_delta_unpack(const DeltaRanges &R, float *snap, const void *src, int half, int refresh, hipStream_t st);
 void launch_delta_sub(const float *cur, const float *snap, float *delta, long n, hipStream_t st);
 void launch_delta_add(float *cur, const float *snap, const float *delta, long n, hipStream_t st);
+// ---- ranker (svdf_k_rank.hip): SVDFeatureRanker's prepare_ifactor / proc_user / proc_spec / proc_rank, and the evaluator's sum
+void launch_rank_items(const DevParams &P, const DevCSR &D, long first, long n, float *ifactors, float *ibias, hipStream_t st);
+void launch_rank_feedback(const DevParams &P, const unsigned *fidx, const float *fval, int nfb, float *fb_out, hipStream_t st);
+void launch_rank_user(const DevParams &P, const unsigned *uidx, const float *uval, int nu, const float *fb_in, float *tu_out, hipStream_t st);
+void launch_rank_spec(const DevParams &P, const DevCSR &D, long n, const int *spec_idx, const float *tu, float *item_score, hipStream_t st);
+void launch_rank_score(const DevParams &P, long n, const float *tu, const float *ifactors, const float *ibias, const signed char *tag,
+                       float *item_score, hipStream_t st);
+void launch_rank_positions(long n, const float *score, const signed char *tag, const int *pos_item, int npos, int *greater, int *ties, hipStream_t st);
+int sqerr_partials_grid(long n);
+void launch_sqerr_partials(const float *pred, const float *label, long n, float scale, double *partials, hipStream_t st);
 // ---- conflict-free level scheduling on the device (svdf_k_sched.hip).  Unit u touches the parameter rows off[s] + col[s][u]
 // for its K slots (SLOT_ABSENT = none; ids >= limit[s] raise limit_msg[s]); no row may repeat inside a unit.  Writes the
 // level-sorted unit order (ties: sort_key, then file position -- the order of the host scheduler's stable sorts) to the

@@ -1,0 +1,255 @@
+// svdf_ranker.cpp -- host side of the device ranker: ISVDRanker (apex_svd.h:160-197) as implemented by SVDFeatureRanker
+// (solvers/base-solver/apex_svd_base.h:597-813), behind the svdf_ranker_* entry points of include/svdfeature_amd.h.
+//
+// The protocol is a stream of tagged lines (svdranker_tag, apex_svd.h:115-152): ITEM lines build the candidate set once, then
+// per user section USER / POS / BAN / SPEC lines and a PROCESS line that returns either the top_k candidates or the rank
+// positions of the positive samples.  Lines are staged on the host; the device work happens at PROCESS:
+//   k_rank_items (once per new candidates), k_rank_user, k_rank_spec, k_rank_score, k_rank_positions  (svdf_k_rank.hip)
+// Ordering is index work and has to be the reference's: scores are computed in its fp32 order on the device; where several
+// ranked candidates tie with a requested position (or inside the top_k prefix) the order is whatever std::sort makes of
+// the reference's entry vector, so those rare sections are finished by running exactly that sort on the host.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <memory>
+
+#include "svdf_engine.h"
+#include "svdf_kernels.h"
+
+namespace svdf {
+
+#define RCHECK(call)                                                                             \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) fail(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #call); \
+    } while (0)
+static inline void rcheck(bool ok, const char *msg) { if (!ok) fail(msg); }
+
+Ranker::Ranker(TypeParam mtype, int device) : mtype_(mtype), eng_(new Engine(TypeParam{mtype.format_type, mtype.active_type, 0, 0}, device)) {}
+Ranker::~Ranker() {}
+
+void Ranker::set_param(const char *name, const char *val) {   // :656-660
+    if (!strcmp(name, "feature_user") || !strcmp(name, "feature_item")) eng_->set_param(name, val);
+    if (!strcmp(name, "top_k")) top_k_ = atoi(val);
+}
+void Ranker::load_model(FILE *fi) { eng_->load_model(fi); }   // :662-664
+void Ranker::init_ranker(int num_item_set) {                   // :666-685
+    rcheck(num_item_set >= 0, "init_ranker: negative item set size");
+    eng_->init_trainer();   // side tables, model upload
+    num_item_set_ = num_item_set;
+    num_item_processed_ = 0;
+    items_on_device_ = 0;
+    const size_t pitch = (size_t)eng_->pitch_;
+    d_ifactors_.reserve((size_t)std::max(num_item_set, 1) * pitch);
+    d_ibias_.reserve((size_t)std::max(num_item_set, 1));
+    d_score_.reserve((size_t)std::max(num_item_set, 1));
+    d_tag_.reserve((size_t)std::max(num_item_set, 1));
+    d_tu_.reserve(pitch + 4);
+    d_fb_.reserve(pitch + 4);
+    RCHECK(hipMemsetAsync(d_fb_.p, 0, (pitch + 4) * sizeof(float), eng_->stream_));   // tmp_ufeedback before the first block
+    tag_.assign((size_t)num_item_set, 0);
+    items_.clear();
+    init_end_ = true;
+    user_open_ = false;
+}
+
+void Ranker::stage(HostCSR &dst, int ng, int nu, int ni, const unsigned *index, const float *value) {
+    const int b = dst.row_ptr.back();
+    dst.row_label.push_back(0.0f);
+    dst.row_ptr.push_back(b + ng);
+    dst.row_ptr.push_back(b + ng + nu);
+    dst.row_ptr.push_back(b + ng + nu + ni);
+    dst.feat_index.insert(dst.feat_index.end(), index, index + ng + nu + ni);
+    dst.feat_value.insert(dst.feat_value.end(), value, value + ng + nu + ni);
+}
+void Ranker::check_item_side(int ng, int nu, int ni, const unsigned *index) {   // asserts of prepare_ifactor (:684,696)
+    for (int j = 0; j < ni; j++) rcheck(index[ng + nu + j] < (unsigned)eng_->mp_.num_item, "item feature index exceed setting");
+    for (int j = 0; j < ng; j++) rcheck(index[j] < (unsigned)eng_->mp_.num_global, "global feature index exceed setting");
+}
+
+long Ranker::process(float label, int ng, int nu, int ni, const unsigned *index, const float *value, int *out, long cap) {   // proc (:786-796)
+    rcheck(init_end_, "ranker: init_ranker has not been called");
+    const int tag = (int)label;
+    const unsigned *iu = index + ng;
+    switch (tag) {
+    case 0: {   // ITEM_TAG: proc_item (:702-707)
+        rcheck(num_item_processed_ + 1 <= num_item_set_, "item instance exceed specified item set size");
+        check_item_side(ng, nu, ni, index);
+        stage(items_, ng, nu, ni, index, value);
+        num_item_processed_++;
+        return 0;
+    }
+    case 2: {   // USER_TAG: proc_user (:709-728)
+        for (int j = 0; j < nu; j++) rcheck(iu[j] < (unsigned)eng_->mp_.num_user, "user feature index exceed bound");
+        user_idx_.assign(iu, iu + nu);
+        user_val_.assign(value + ng, value + ng + nu);
+        pos_item_.clear();
+        std::fill(tag_.begin(), tag_.begin() + num_item_processed_, 0);
+        spec_.clear();
+        spec_idx_.clear();
+        user_open_ = true;
+        return 0;
+    }
+    case 1: case -1: {   // POS_SAMPLE / BAN_SAMPLE: proc_tag (:729-738)
+        for (int j = 0; j < nu; j++) {
+            const int idx = (int)iu[j];
+            rcheck(idx < num_item_processed_, "sample item index exceed bound");
+            rcheck(tag_[(size_t)idx] == 0, "each pos sample item can not occur in baned sample list");
+            tag_[(size_t)idx] = (signed char)tag;
+            if (tag == 1) pos_item_.push_back(idx);
+        }
+        return 0;
+    }
+    case 3: {   // SPEC_SAMPLE: proc_spec (:739-747); a later special sample of the same candidate replaces the earlier one
+        rcheck(nu == 1, "must specify item index of sample in user feature field\n");
+        const int idx = (int)iu[0];
+        rcheck(idx < num_item_processed_, "sample item index exceed bound");
+        check_item_side(ng, nu, ni, index);
+        for (size_t j = 0; j < spec_idx_.size(); j++)
+            if (spec_idx_[j] == idx) { spec_idx_[j] = -1; }   // superseded
+        stage(spec_, ng, nu, ni, index, value);
+        spec_idx_.push_back(idx);
+        return 0;
+    }
+    case 4: return rank(out, cap);   // PROCESS_TAG: proc_rank (:748-785)
+    default: return 0;
+    }
+}
+
+long Ranker::process_block(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label, const int *row_ptr,
+                           const unsigned *feat_index, const float *feat_value, int *out, long cap) {   // :797-812
+    rcheck(init_end_, "ranker: init_ranker has not been called");
+    if (tag == TAG_DEFAULT || tag == TAG_START) {
+        rcheck(eng_->user_group(), "ranker: user-grouped input needs a user-group model (format_type = 1)");
+        for (int j = 0; j < nfb; j++) rcheck(ifb[j] < (unsigned)eng_->mp_.num_ufeedback, "ufeedback id exceed bound");
+        const DevParams &P = eng_->params();
+        w_fbidx_.upload(ifb, (size_t)nfb, eng_->stream_);
+        w_fbval_.upload(vfb, (size_t)nfb, eng_->stream_);
+        launch_rank_feedback(P, w_fbidx_.p, w_fbval_.p, nfb, d_fb_.p, eng_->stream_);
+        RCHECK(hipStreamSynchronize(eng_->stream_));   // the staging buffers are reused by the next block
+    }
+    long total = 0;
+    for (int r = 0; r < num_row; r++) {
+        const int p0 = row_ptr[3 * r], p1 = row_ptr[3 * r + 1], p2 = row_ptr[3 * r + 2], p3 = row_ptr[3 * r + 3];
+        const long got = process(row_label[r], p1 - p0, p2 - p1, p3 - p2, feat_index + p0, feat_value + p0, out ? out + total : nullptr, cap - total);
+        total += got;
+    }
+    return total;
+}
+
+struct RankEntry {   // SVDFeatureRanker::Entry (:617-624)
+    int iid;
+    float score;
+    bool operator<(const RankEntry &p) const { return score > p.score; }
+};
+
+long Ranker::rank(int *out, long cap) {
+    rcheck(user_open_, "ranker: PROCESS_TAG without a USER_TAG section");
+    const DevParams &P = eng_->params();
+    hipStream_t st = eng_->stream_;
+    const long n = num_item_processed_;
+    // candidates that arrived since the last section
+    if (items_on_device_ < n) {
+        w_label_.upload(items_.row_label.data(), items_.row_label.size(), st);
+        w_ptr_.upload(items_.row_ptr.data(), items_.row_ptr.size(), st);
+        w_index_.upload(items_.feat_index.data(), items_.feat_index.size(), st);
+        w_value_.upload(items_.feat_value.data(), items_.feat_value.size(), st);
+        DevCSR D{w_label_.p, w_ptr_.p, w_index_.p, w_value_.p};
+        launch_rank_items(P, D, items_on_device_, n, d_ifactors_.p, d_ibias_.p, st);
+        RCHECK(hipStreamSynchronize(st));
+        items_on_device_ = n;
+    }
+    w_uidx_.upload(user_idx_.data(), user_idx_.size(), st);
+    w_uval_.upload(user_val_.data(), user_val_.size(), st);
+    launch_rank_user(P, w_uidx_.p, w_uval_.p, (int)user_idx_.size(), eng_->user_group() ? d_fb_.p : nullptr, d_tu_.p, st);
+    if (n == 0) {
+        rcheck(top_k_ <= 0, "k can not exceed candidate size");
+        return 0;
+    }
+    RCHECK(hipMemsetAsync(d_score_.p, 0, (size_t)n * sizeof(float), st));   // item_score = 0 (:726)
+    RCHECK(hipMemcpyAsync(d_tag_.p, tag_.data(), (size_t)n, hipMemcpyHostToDevice, st));
+    // special samples: only the last one per candidate counts (an assignment, :746)
+    {
+        HostCSR live;
+        std::vector<int> live_idx;
+        for (size_t j = 0; j < spec_idx_.size(); j++) {
+            if (spec_idx_[j] < 0) continue;
+            const int *p = &spec_.row_ptr[3 * j];
+            stage(live, p[1] - p[0], p[2] - p[1], p[3] - p[2], spec_.feat_index.data() + p[0], spec_.feat_value.data() + p[0]);
+            live_idx.push_back(spec_idx_[j]);
+        }
+        if (!live_idx.empty()) {
+            s_label_.upload(live.row_label.data(), live.row_label.size(), st);
+            s_ptr_.upload(live.row_ptr.data(), live.row_ptr.size(), st);
+            s_index_.upload(live.feat_index.data(), live.feat_index.size(), st);
+            s_value_.upload(live.feat_value.data(), live.feat_value.size(), st);
+            s_idx_.upload(live_idx.data(), live_idx.size(), st);
+            DevCSR D{s_label_.p, s_ptr_.p, s_index_.p, s_value_.p};
+            launch_rank_spec(P, D, (long)live_idx.size(), s_idx_.p, d_tu_.p, d_score_.p, st);
+            RCHECK(hipStreamSynchronize(st));
+        }
+    }
+    launch_rank_score(P, n, d_tu_.p, d_ifactors_.p, d_ibias_.p, d_tag_.p, d_score_.p, st);
+    n_sections_++;
+
+    auto full_sort = [&](std::vector<RankEntry> &entry) {   // the reference's own ordering step (:767)
+        host_score_.resize((size_t)n);
+        RCHECK(hipMemcpyAsync(host_score_.data(), d_score_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+        RCHECK(hipStreamSynchronize(st));
+        entry.clear();
+        for (long i = 0; i < n; i++)
+            if (tag_[(size_t)i] != -1) entry.push_back(RankEntry{(int)i, host_score_[(size_t)i]});
+        std::sort(entry.begin(), entry.end());
+    };
+    std::vector<RankEntry> entry;
+    long nout = 0;
+    if (top_k_ > 0) {
+        // top_k: threshold selection on the host copy of the scores, exact std::sort order only if scores tie inside the prefix
+        host_score_.resize((size_t)n);
+        RCHECK(hipMemcpyAsync(host_score_.data(), d_score_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+        RCHECK(hipStreamSynchronize(st));
+        for (long i = 0; i < n; i++)
+            if (tag_[(size_t)i] != -1) entry.push_back(RankEntry{(int)i, host_score_[(size_t)i]});
+        rcheck(entry.size() >= (size_t)top_k_, "k can not exceed candidate size");
+        bool exact = true;
+        for (const RankEntry &e : entry) if (std::isnan(e.score)) exact = false;
+        std::vector<RankEntry> head;
+        if (exact) {
+            std::vector<RankEntry> work(entry);
+            const size_t kk = std::min(work.size() - 1, (size_t)top_k_);   // one past the prefix when there is one
+            std::nth_element(work.begin(), work.begin() + (long)kk, work.end());
+            const float thr = work[kk].score;
+            for (const RankEntry &e : entry) if (e.score >= thr) head.push_back(e);
+            std::sort(head.begin(), head.end());
+            for (size_t j = 0; j + 1 < head.size() && j < (size_t)top_k_; j++)
+                if (head[j].score == head[j + 1].score) exact = false;
+            if (head.size() < (size_t)top_k_) exact = false;
+        }
+        if (!exact) { std::sort(entry.begin(), entry.end()); head = entry; n_host_sorts_++; }
+        for (int k = 0; k < top_k_; k++) { if (nout < cap && out) out[nout] = head[(size_t)k].iid; nout++; }
+    } else {
+        const int npos = (int)pos_item_.size();
+        if (npos == 0) { RCHECK(hipStreamSynchronize(st)); return 0; }
+        d_pos_.upload(pos_item_.data(), pos_item_.size(), st);
+        d_cnt_.reserve((size_t)2 * npos);
+        RCHECK(hipMemsetAsync(d_cnt_.p, 0, (size_t)2 * npos * sizeof(int), st));
+        launch_rank_positions(n, d_score_.p, d_tag_.p, d_pos_.p, npos, d_cnt_.p, d_cnt_.p + npos, st);
+        std::vector<int> cnt((size_t)2 * npos);
+        RCHECK(hipMemcpyAsync(cnt.data(), d_cnt_.p, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+        RCHECK(hipStreamSynchronize(st));
+        bool ties = false;
+        for (int j = 0; j < npos; j++) ties = ties || cnt[(size_t)npos + j] != 0;
+        if (ties) {   // positions inside a group of equal scores: the reference's sort decides
+            full_sort(entry);
+            n_host_sorts_++;
+            std::vector<int> where((size_t)n, 0);
+            for (size_t i = 0; i < entry.size(); i++) where[(size_t)entry[i].iid] = (int)i;
+            for (int j = 0; j < npos; j++) { if (nout < cap && out) out[nout] = where[(size_t)pos_item_[(size_t)j]]; nout++; }
+        } else {
+            for (int j = 0; j < npos; j++) { if (nout < cap && out) out[nout] = cnt[(size_t)j]; nout++; }
+        }
+    }
+    return nout;
+}
+
+}  // namespace svdf

@@ -245,3 +245,40 @@ def nested_blocks(num_spans, num_user, num_item, num_ufeedback, seed, max_depth=
     for _ in range(num_spans):
         span(int(rng.integers(0, num_user)), 0)
     return blocks
+
+
+# ---- ranker input (svdranker_tag, apex_svd.h:115-152): the tag travels in the label field
+def ranker_stream(num_cand, num_sections, num_user, num_item, num_global, seed, extra_item_feats=True, spec=True):
+    """(item lines, [user sections]) for ISVDRanker::process: ITEM lines (tag 0) define the candidates -- one or two item
+    features and sometimes global features each --, every section is USER (2), POS (1), BAN (-1), some SPEC (3) and PROCESS (4)."""
+    rng = np.random.default_rng(seed)
+    items = []
+    for c in range(num_cand):
+        it = [(int(c % num_item), 1.0)]
+        if extra_item_feats and rng.integers(0, 3) == 0:
+            it.append((int(rng.integers(0, num_item)), float(np.float32(rng.uniform(0.2, 1.0)))))
+            it.sort(key=lambda e: e[0])
+            if it[0][0] == it[1][0]:
+                it = it[:1]
+        g = [(int(rng.integers(0, num_global)), float(np.float32(rng.uniform(-1, 1))))] if (num_global and rng.integers(0, 4) == 0) else []
+        items.append((0.0, g, [], it))
+    sections = []
+    for s in range(num_sections):
+        rows = []
+        u = [(int(rng.integers(0, num_user)), 1.0)]
+        if rng.integers(0, 3) == 0:
+            u.append((int(rng.integers(0, num_user)), float(np.float32(rng.uniform(0.1, 1.0)))))
+        rows.append((2.0, [], u, []))
+        chosen = rng.choice(num_cand, size=min(num_cand, 6), replace=False)
+        npos = int(rng.integers(1, 4))
+        rows.append((1.0, [], [(int(x), 1.0) for x in chosen[:npos]], []))
+        if rng.integers(0, 2):
+            rows.append((-1.0, [], [(int(x), 1.0) for x in chosen[npos:npos + 2]], []))
+        if spec:
+            for x in chosen[4:6]:
+                g = [(int(rng.integers(0, num_global)), float(np.float32(rng.uniform(-1, 1))))] if num_global else []
+                it = [(int(rng.integers(0, num_item)), float(np.float32(rng.uniform(0.1, 0.5))))] if rng.integers(0, 2) else []
+                rows.append((3.0, g, [(int(x), 1.0)], it))
+        rows.append((4.0, [], [], []))
+        sections.append(CSRData.from_rows(rows))
+    return CSRData.from_rows(items), sections

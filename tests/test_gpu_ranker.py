@@ -1,0 +1,117 @@
+"""GPU parity of the ranker and the on-device evaluator: svdf_ranker_* against tests/golden/ranker.npz (compiled
+reference) and the C oracle -- the int results are identical, including sections whose scores tie (finished by the
+reference's own sort on the host); svdf_eval_dataset against the reference's long double accumulator."""
+import numpy as np
+import pytest
+
+import cases
+import svdfeature_amd as sa
+from oracle import oracle
+from test_ranker import GOLD_PATH, RANK_CASES, run_ranker, trained_model
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", list(RANK_CASES))
+def test_ranker_matches_reference_golden(name, tmp_path):
+    gold = np.load(GOLD_PATH)
+    got = run_ranker(lambda f: sa.Ranker(f, 0), name, str(tmp_path))
+    np.testing.assert_array_equal(got, gold[name])
+
+
+@pytest.mark.parametrize("k", [5, 64, 128, 300])
+@pytest.mark.parametrize("top_k", [0, 10])
+def test_ranker_large_item_set_matches_the_oracle(k, top_k, tmp_path):
+    """2000 candidates x 40 user sections at several factor widths (lane groups and wide rows), top_k and position mode."""
+    nu, ni, ng = 300, 2000, 5
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=k, ui_init_sigma=0.1, wd_global=0.001)
+    t = oracle.OracleTrainer("port", 0, 0)
+    t.seed(3)
+    for kk, v in conf:
+        t.set_param(kk, v)
+    t.init_model()
+    t.init_trainer()
+    t.update_batch(cases.sparse_feature_rows(3000, nu, ni, ng, 11))
+    path = str(tmp_path / "m.model")
+    t.save_model(path)
+    items, sections = cases.ranker_stream(2000, 40, nu, ni, ng, seed=k)
+    outs = []
+    for mk in (lambda: oracle.OracleRanker("port", 0, 0), lambda: sa.Ranker(0, 0)):
+        r = mk()
+        r.set_param("top_k", str(top_k))
+        r.load_model(path)
+        r.init_ranker(items.num_row)
+        r.process_rows(items)
+        outs.append(np.concatenate([r.process_rows(s) for s in sections]))
+        if isinstance(r, sa.Ranker):
+            assert r.counter(0) == 40 and r.counter(1) == 0
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
+@pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference (oracle/_ref) not present")
+def test_ranker_tied_scores_follow_the_reference_sort(tmp_path):
+    """Candidates that are copies of one another score exactly the same: their order is whatever std::sort makes of the
+    reference's entry vector.  The engine detects the tie on the device and finishes the section with that very sort."""
+    nu, ni = 40, 30
+    path, extra, _ = trained_model(str(tmp_path), 0, 12, False)
+    rows = [(0.0, [], [], [(int(c % 7), 1.0)]) for c in range(60)]   # 60 candidates, only 7 distinct items
+    items = sa.CSRData.from_rows(rows)
+    sec = sa.CSRData.from_rows([(2.0, [], [(3, 1.0)], []), (1.0, [], [(0, 1.0), (8, 1.0), (20, 1.0)], []), (4.0, [], [], [])])
+    for top_k in (0, 9):
+        outs = []
+        for mk in (lambda: oracle.OracleRanker("reference", 0, 0), lambda: sa.Ranker(0, 0)):
+            r = mk()
+            r.set_param("top_k", str(top_k))
+            r.load_model(path)
+            r.init_ranker(60)
+            r.process_rows(items)
+            outs.append(r.process_rows(sec))
+            if isinstance(r, sa.Ranker):
+                assert r.counter(1) == 1   # finished on the host
+        np.testing.assert_array_equal(outs[0], outs[1])
+
+
+def test_ranker_errors():
+    r = sa.Ranker(0, 0)
+    with pytest.raises(sa.SvdfError, match="init_ranker has not been called"):
+        r.process(0.0, 0, 0, 1, np.array([1], np.uint32), np.array([1], np.float32))
+
+
+@pytest.mark.parametrize("kind", ["triples", "blocks", "csr"])
+def test_eval_dataset_matches_the_reference_accumulator(kind):
+    """svdf_eval_dataset: squared errors summed on the device; equal to the reference's sequential long double sum over the
+    same predictions to 1e-12 relative, for every dataset kind; RMSE = sqrt(sum / count)."""
+    nu, ni, ng = 500, 300, 6
+    if kind == "triples":
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=32)
+        t = sa.Trainer(0, 0)
+    elif kind == "csr":
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=20, wd_global=0.001)
+        t = sa.Trainer(0, 0)
+    else:
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=16, num_ufeedback=ni, wd_ufeedback=0.004, ufeedback_init_sigma=0.01)
+        t = sa.Trainer(1, 0)
+    t.seed(10)
+    for k, v in conf:
+        t.set_param(k, v)
+    t.init_model()
+    t.init_trainer()
+    if kind == "triples":
+        u, i, r = cases.planted_triples(200_000, nu, ni, seed=1)
+        ds = t.dataset_from_triples(u, i, r)
+        labels = r
+    elif kind == "csr":
+        d = cases.sparse_feature_rows(5000, nu, ni, ng, 5)
+        ds = t.dataset_from_csr(d)
+        labels = d.row_label
+    else:
+        blocks = cases.user_blocks(400, nu, ni, ni, seed=6, max_rows=12, max_fb=8)
+        ds = t.dataset_from_blocks(blocks)
+        labels = np.concatenate([b.data.row_label for b in blocks])
+    t.train_dataset(ds)
+    pred = t.predict_dataset(ds)
+    for scale in (1.0, 0.2):
+        ss, cnt = t.eval_dataset(ds, scale)
+        ref = oracle.sum_sq_err(pred, labels, scale)
+        assert cnt == len(labels)
+        assert abs(ss - ref) <= 1e-12 * ref, (ss, ref)
