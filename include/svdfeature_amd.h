@@ -239,6 +239,13 @@ int64_t svdf_ranker_process_block(svdf_ranker *r, int num_ufeedback, int extend_
 /* counters: 0 user sections ranked, 1 sections finished by the host sort because scores tied at a requested position */
 int64_t svdf_ranker_counter(svdf_ranker *r, int what);
 
+/* ---- libc rand() as a random-access stream (the reference draws rank pairs with rand(), apex-tensor/apex_random.h:42-67;
+ * SURVEY 8f2).  svdf_rand_peek writes the next n rand() results WITHOUT consuming them, svdf_rand_skip advances the generator
+ * by n draws without calling rand() n times (jump-ahead of glibc's additive-feedback table).  Host functions, no GPU needed;
+ * the device sampler uses the same machinery.  -1 when libc's generator is not in its default 31-word mode. */
+int svdf_rand_peek(long n, int *out);
+int svdf_rand_skip(long n);
+
 /* ---- probe of the device-side expf used by the sigmoid links (active_type::map_active / cal_grad call libm's expf,
  * apex_svd_model.h:112-156): out[j] = expf evaluated ON THE GPU for in[j], or, with in == NULL, for the float whose bit
  * pattern is first_bits + j*step_bits.  Tests compare it with the host libm bit for bit.  Needs a GPU. */

@@ -128,6 +128,8 @@ def load_library():
     lib.svdf_ranker_process_block.argtypes = [P, C.c_int, C.c_int, _u32p, _f32p, C.c_int, _f32p, _i32p, _u32p, _f32p, _i32p, C.c_int64]
     lib.svdf_ranker_counter.restype = C.c_int64
     lib.svdf_ranker_counter.argtypes = [P, C.c_int]
+    lib.svdf_rand_peek.argtypes = [C.c_long, _i32p]
+    lib.svdf_rand_skip.argtypes = [C.c_long]
     lib.svdf_device_expf.argtypes = [C.c_void_p, C.c_uint, C.c_uint, _f32p, C.c_long]
     lib.svdf_set_error_mode(1)   # python callers get exceptions instead of exit(-1)
     _lib = lib
@@ -136,6 +138,20 @@ def load_library():
 
 def device_count():
     return load_library().svdf_device_count()
+
+
+def rand_peek(n):
+    """the next n libc rand() results, without consuming them (svdf_rand_peek)"""
+    out = np.zeros(max(int(n), 1), np.int32)
+    if load_library().svdf_rand_peek(int(n), out) != 0:
+        raise SvdfError(load_library().svdf_last_error().decode())
+    return out[:n]
+
+
+def rand_skip(n):
+    """advance libc rand() by n draws (svdf_rand_skip)"""
+    if load_library().svdf_rand_skip(int(n)) != 0:
+        raise SvdfError(load_library().svdf_last_error().decode())
 
 
 def device_expf(x=None, first=0, step=1, n=None):

@@ -13,6 +13,13 @@
 // offset array; labels already carry scale_score (the reference applies it when the buffer is made,
 // apex_svd_data.cpp:403,426,516).
 #include "svdf_engine.h"
+#include "svdf_kernels.h"
+#include <sys/stat.h>
+#define HIPCHECK(call)                                                                           \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) fail(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #call); \
+    } while (0)
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -268,11 +275,142 @@ Dataset *Engine::dataset_from_buffer_file(const char *path, int user_group_forma
 Dataset *Engine::dataset_from_rank_buffer_file(const char *path) {
     check(path != nullptr, "dataset_from_rank_buffer_file: null path");
     check(user_group(), "rank-pair input needs the user-group format (format_type = 1), svd_feature.cpp:129-133");
+    if (device_rank_ && device_sched_ && !rank_prefetch_ && !host_only_) {
+        Dataset *ds = rank_pass_device(path);
+        if (ds) return ds;
+    }
     UserGroupArrays g;
     rank_pass(path, g);
     return dataset_from_blocks((long)g.tag.size(), g.tag.data(), g.fb_ptr.data(), g.fb_index.data(), g.fb_value.data(),
                                g.block_row_ptr.data(), g.rows.label.data(), g.rows.row_ptr.data(), g.rows.index.data(),
                                g.rows.value.data());
+}
+
+// The device form of the same pass: the file's rows live in HBM (uploaded once per file), every pass draws
+// its pairs there with the libc rand() stream the host sampler would have consumed (svdf_randstream.cpp, svdf_k_sample.hip),
+// schedules them there (svdf_k_sched.hip) and leaves libc's generator where the host sampler would have left it.  Taken when
+// the pass needs no per-user state -- no block carries implicit feedback, so update(block) == update_inner(row)
+// (apex_svd_base.h:512-527,539,557-561) -- every row has no global, one user entry that survives the |value| > 1e-6 filter
+// (apex_svd_data.cpp:897-903) and one item entry, and the sampler runs positives against negatives without pointwise
+// output.  Everything else goes through the host sampler above.  Returns nullptr to decline.
+Dataset *Engine::rank_pass_device(const char *path) {
+    if (pair_sampler_.method() != 0 || pair_sampler_.pointwise() != 0) return nullptr;
+    if (!rows_without_feedback_ || !fused_allowed_for_rows()) return nullptr;
+    struct stat sb;
+    if (stat(path, &sb) != 0) return nullptr;   // the host path reports the error
+    if (!rank_source_ || rank_source_->path != path || rank_source_->file_size != (long)sb.st_size || rank_source_->file_mtime != (long)sb.st_mtime) {
+        std::unique_ptr<RankSource> src(new RankSource());
+        src->path = path; src->file_size = (long)sb.st_size; src->file_mtime = (long)sb.st_mtime;
+        MappedFile file(path);
+        UserGroupArrays g;
+        read_user_group(file, nullptr, g);
+        const long nb = (long)g.tag.size(), nr = (long)g.rows.label.size();
+        bool ok = g.fb_index.empty();
+        for (long b = 0; b < nb && ok; b++) ok = g.tag[(size_t)b] == TAG_DEFAULT || g.tag[(size_t)b] == TAG_START || g.tag[(size_t)b] == TAG_MIDDLE || g.tag[(size_t)b] == TAG_END;
+        std::vector<unsigned> ui((size_t)nr), ii((size_t)nr);
+        std::vector<float> uv((size_t)nr), iv((size_t)nr);
+        for (long r = 0; r < nr && ok; r++) {
+            const int64_t *p = &g.rows.row_ptr[(size_t)3 * r];
+            ok = p[1] == p[0] && p[2] == p[1] + 1 && p[3] == p[2] + 1;
+            if (!ok) break;
+            ui[(size_t)r] = g.rows.index[(size_t)p[1]]; uv[(size_t)r] = g.rows.value[(size_t)p[1]];
+            ii[(size_t)r] = g.rows.index[(size_t)p[2]]; iv[(size_t)r] = g.rows.value[(size_t)p[2]];
+            ok = uv[(size_t)r] > 1e-6f || uv[(size_t)r] < -1e-6f;
+        }
+        src->eligible = ok && nr < 0x7FFFFFFFL;
+        if (src->eligible) {
+            need_device("rank input");
+            src->num_block = nb; src->num_row = nr;
+            std::vector<long> brp((size_t)nb + 1);
+            for (long b = 0; b <= nb; b++) brp[(size_t)b] = (long)g.block_row_ptr[(size_t)b];
+            src->block_row_ptr.upload(brp.data(), brp.size(), stream_);
+            src->label.upload(g.rows.label.data(), (size_t)nr, stream_);
+            src->uidx.upload(ui.data(), (size_t)nr, stream_); src->uval.upload(uv.data(), (size_t)nr, stream_);
+            src->iidx.upload(ii.data(), (size_t)nr, stream_); src->ival.upload(iv.data(), (size_t)nr, stream_);
+            src->draws.reserve((size_t)nb + 1); src->pairs.reserve((size_t)nb + 1);
+            src->draw_off.reserve((size_t)nb + 2); src->pair_off.reserve((size_t)nb + 2);
+            src->pos_list.reserve((size_t)nr + 1); src->neg_list.reserve((size_t)nr + 1);
+            HIPCHECK(hipStreamSynchronize(stream_));
+        }
+        rank_source_ = std::move(src);
+    }
+    RankSource &S = *rank_source_;
+    if (!S.eligible) return nullptr;
+    check(trainer_ready_, "dataset: init_trainer has not been called");
+    need_device("dataset");
+    flush();
+    check(!unit_open_, "dataset_from_blocks: a START block is pending in the trainer");
+    LibcRand rs;
+    if (!libc_rand_capture(rs)) return nullptr;   // a caller-installed generator of another size: the host path just calls rand()
+    pair_sampler_.init();
+    if (pair_sampler_.seed_bytime()) { if (!libc_rand_capture(rs)) return nullptr; }   // init() re-seeded (apex_svd_data.cpp:984-986)
+    const long nb = S.num_block;
+    RankSourceDev D{nb, S.num_row, S.block_row_ptr.p, S.label.p, S.uval.p, S.ival.p, S.uidx.p, S.iidx.p};
+    SamplerParams sp{pair_sampler_.pos_lowerb(), pair_sampler_.neg_upperb(), pair_sampler_.sample_num(), pair_sampler_.sample_max()};
+    launch_sample_counts(D, sp, S.draws.p, S.pairs.p, stream_);
+    std::vector<long> hd((size_t)nb + 1), hp((size_t)nb + 1);
+    if (nb > 0) {
+        HIPCHECK(hipMemcpyAsync(hd.data(), S.draws.p, (size_t)nb * sizeof(long), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipMemcpyAsync(hp.data(), S.pairs.p, (size_t)nb * sizeof(long), hipMemcpyDeviceToHost, stream_));
+    }
+    HIPCHECK(hipStreamSynchronize(stream_));
+    long D_total = 0, P_total = 0;
+    for (long b = 0; b < nb; b++) { const long d = hd[(size_t)b], p = hp[(size_t)b]; hd[(size_t)b] = D_total; hp[(size_t)b] = P_total; D_total += d; P_total += p; }
+    hd[(size_t)nb] = D_total; hp[(size_t)nb] = P_total;
+    check(P_total < 0x7FFFFFFFL, "rank input: more than 2^31-1 pairs in one pass");
+    S.draw_off.upload(hd.data(), hd.size(), stream_);
+    S.pair_off.upload(hp.data(), hp.size(), stream_);
+    // the rand() stream of this pass, expanded in chunks from jump-ahead tables
+    const long C = 2048, nchunks = (D_total + C - 1) / C;
+    std::vector<uint32_t> tables;
+    libc_rand_chunk_states(rs, nchunks, C, tables);
+    S.tables.upload(tables.data(), tables.size(), stream_);
+    S.raw.reserve((size_t)std::max<long>(D_total, 1));
+    launch_rand_expand(S.tables.p, nchunks, C, D_total, S.raw.p, stream_);
+    // the generated instances, file order
+    std::unique_ptr<Dataset> ds(new Dataset());
+    adopt(ds.get()); ds->kind = 2; ds->num_row = P_total;
+    FusedDev &f = ds->fused;
+    f.max_nu = 1; f.max_ni = 2; f.has_g = false; f.inline_g = false;
+    DevBuf<float> rl, ruv, rv0, rv1;
+    DevBuf<unsigned> rui, ri0, ri1;
+    const size_t np = (size_t)std::max<long>(P_total, 1);
+    rl.reserve(np); ruv.reserve(np); rv0.reserve(np); rv1.reserve(np); rui.reserve(np); ri0.reserve(np); ri1.reserve(np);
+    PairColumns out{rl.p, ruv.p, rv0.p, rv1.p, rui.p, ri0.p, ri1.p};
+    launch_sample_posneg(D, sp, S.draw_off.p, S.pair_off.p, S.raw.p, S.pos_list.p, S.neg_list.p, out, stream_);
+    // libc's generator moves on by exactly the draws of this pass
+    if (D_total > 0) {
+        LibcRand after = rs;
+        if (D_total >= 31) {
+            HIPCHECK(hipMemcpyAsync(after.x, S.raw.p + (D_total - 31), 31 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+            HIPCHECK(hipStreamSynchronize(stream_));
+        } else {
+            std::vector<uint32_t> tail((size_t)D_total);
+            HIPCHECK(hipMemcpyAsync(tail.data(), S.raw.p, (size_t)D_total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+            HIPCHECK(hipStreamSynchronize(stream_));
+            for (long j = 0; j < 31 - D_total; j++) after.x[j] = rs.x[j + D_total];
+            for (long j = 0; j < D_total; j++) after.x[31 - D_total + j] = tail[(size_t)j];
+        }
+        libc_rand_restore(after);
+    }
+    HIPCHECK(hipGetLastError());
+    if (P_total > 0) {
+        const unsigned *res[3] = {rui.p, ri0.p, ri1.p};
+        const unsigned off[3] = {0u, (unsigned)mp_.num_user, (unsigned)mp_.num_user};
+        const unsigned limit[3] = {(unsigned)mp_.num_user, (unsigned)mp_.num_item, (unsigned)mp_.num_item};
+        const char *msg[3] = {"user feature index exceed bound", "item feature index exceed bound", "item feature index exceed bound"};
+        const unsigned *key = sort_batches_ == 1 ? ri0.p : (sort_batches_ == 2 ? rui.p : nullptr);
+        schedule_device_columns(ds.get(), P_total, 3, res, off, limit, msg, key, sort_batches_ == 1 ? limit[1] : limit[0],
+                                {DUCol{rui.p, &f.uidx[0]}, DUCol{ri0.p, &f.iidx[0]}, DUCol{ri1.p, &f.iidx[1]}},
+                                {DFCol{rl.p, &f.label}, DFCol{ruv.p, &f.uval[0]}, DFCol{rv0.p, &f.ival[0]}, DFCol{rv1.p, &f.ival[1]}});
+    } else {
+        HIPCHECK(hipStreamSynchronize(stream_));
+        ds->sched.level_ptr.assign(1, 0);
+    }
+    const long nbias = (mp_.no_user_bias ? 0 : 1) + 2;
+    ds->algorithmic_bytes = P_total * (8L * mp_.num_factor * 3 + 8 * nbias + 16 + 8 * 3);
+    n_device_rank_passes_++;
+    return ds.release();
 }
 
 // The same pass written back as a user-group buffer file (host only: works without a device).

@@ -217,6 +217,9 @@ int64_t svdf_ranker_process_block(svdf_ranker *r, int nfb, int tag, const unsign
 }
 int64_t svdf_ranker_counter(svdf_ranker *r, int what) { return r->r->counter(what); }
 
+int svdf_rand_peek(long n, int *out) { SVDF_GUARD(-1, { svdf::libc_rand_peek(n, out); return 0; }) }
+int svdf_rand_skip(long n) { SVDF_GUARD(-1, { svdf::libc_rand_skip(n); return 0; }) }
+
 int svdf_device_expf(const float *in, unsigned first_bits, unsigned step_bits, float *out, long n) {
     SVDF_GUARD(-1, { return svdf::device_expf(in, first_bits, step_bits, out, n); })
 }

@@ -63,6 +63,7 @@ template struct DevBuf<DevUnit>;
 template struct DevBuf<DevBlk>;
 template struct DevBuf<signed char>;
 template struct DevBuf<double>;
+template struct DevBuf<long>;
 
 // =============================================================================== scheduler
 void build_schedule(const std::vector<int> &levels, int base, Schedule &out) {
@@ -1080,6 +1081,10 @@ void Engine::flush_csr(HostCSR &src) {
 bool Engine::fused_allowed() const {
     return use_fused_ && !lazy_decay() && mp_.num_factor <= max_fast_path_factor() && (!user_group() || rows_as_instances_) && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
 }
+bool Engine::fused_allowed_for_rows() const {
+    return use_fused_ && !lazy_decay() && !relaxed() && mp_.num_factor <= max_fast_path_factor() && mp_.common_latent_space == 0 &&
+           feat_user_.num_row() == 0 && feat_item_.num_row() == 0;
+}
 // every instance has <= 2 user ids, <= 2 item ids and no id twice in a section (ptr is int or int64)
 template <typename PtrT>
 bool Engine::fused_shape_ok(long n, const PtrT *row_ptr, const unsigned *idx, FusedHost &out) {
@@ -1474,16 +1479,27 @@ void Engine::schedule_columns_on_device(Dataset *ds, long n, int K, const int *r
     std::vector<std::unique_ptr<DevBuf<float>>> rawf;
     for (const UCol &c : ucols) { rawu.emplace_back(new DevBuf<unsigned>()); rawu.back()->upload(c.src, (size_t)n, stream_); }
     for (const FCol &c : fcols) { rawf.emplace_back(new DevBuf<float>()); rawf.back()->upload(c.src, (size_t)n, stream_); }
+    const unsigned *res[SVDF_SCHED_MAX_SLOTS];
+    for (int s = 0; s < K; s++) res[s] = rawu[(size_t)res_col[s]]->p;
+    std::vector<DUCol> du;
+    std::vector<DFCol> df;
+    for (size_t c = 0; c < ucols.size(); c++) du.push_back(DUCol{rawu[c]->p, ucols[c].dst});
+    for (size_t c = 0; c < fcols.size(); c++) df.push_back(DFCol{rawf[c]->p, fcols[c].dst});
+    schedule_device_columns(ds, n, K, res, off, limit, msg, sort_col >= 0 ? rawu[(size_t)sort_col]->p : nullptr, sort_max, du, df);
+}
+void Engine::schedule_device_columns(Dataset *ds, long n, int K, const unsigned *const *res_col, const unsigned *off, const unsigned *limit,
+                                     const char *const *msg, const unsigned *sort_key, unsigned sort_max, const std::vector<DUCol> &ucols,
+                                     const std::vector<DFCol> &fcols) {
     SchedColumns in;
     memset(&in, 0, sizeof(in));
     in.K = K; in.n = n;
     unsigned nres = 0;
     for (int s = 0; s < K; s++) {
-        in.col[s] = rawu[(size_t)res_col[s]]->p; in.off[s] = off[s]; in.limit[s] = limit[s]; in.limit_msg[s] = msg[s];
+        in.col[s] = res_col[s]; in.off[s] = off[s]; in.limit[s] = limit[s]; in.limit_msg[s] = msg[s];
         nres = std::max(nres, off[s] + limit[s]);
     }
     in.num_res = nres;
-    in.sort_key = sort_col >= 0 ? rawu[(size_t)sort_col]->p : nullptr;
+    in.sort_key = sort_key;
     in.sort_key_max = sort_max;
     ds->order_dev.reserve((size_t)std::max<long>(n, 1));
     try {
@@ -1492,8 +1508,8 @@ void Engine::schedule_columns_on_device(Dataset *ds, long n, int K, const int *r
         fail(ex.what());
     }
     ds->sched.order.clear();
-    for (size_t c = 0; c < ucols.size(); c++) { ucols[c].dst->reserve((size_t)n); device_gather_u32(rawu[c]->p, ds->order_dev.p, ucols[c].dst->p, n, stream_); }
-    for (size_t c = 0; c < fcols.size(); c++) { fcols[c].dst->reserve((size_t)n); device_gather_f32(rawf[c]->p, ds->order_dev.p, fcols[c].dst->p, n, stream_); }
+    for (const DUCol &c : ucols) { c.dst->reserve((size_t)n); device_gather_u32(c.src, ds->order_dev.p, c.dst->p, n, stream_); }
+    for (const DFCol &c : fcols) { c.dst->reserve((size_t)n); device_gather_f32(c.src, ds->order_dev.p, c.dst->p, n, stream_); }
     HIPCHECK(hipGetLastError());
     HIPCHECK(hipStreamSynchronize(stream_));
 }
@@ -2125,6 +2141,7 @@ int64_t Engine::counter(int what) const {
     case 4: return n_kind_[0];
     case 5: return n_kind_[1];
     case 6: return n_kind_[2];
+    case 7: return n_device_rank_passes_;
     default: return -1;
     }
 }
@@ -2145,6 +2162,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "async_flush")) { flush(); async_flush_ = value != 0; return 0; }
     if (!strcmp(name, "use_fused")) { use_fused_ = value != 0; return 0; }
     if (!strcmp(name, "device_schedule")) { device_sched_ = value != 0; return 0; }
+    if (!strcmp(name, "device_rank")) { device_rank_ = value != 0; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "rows_without_feedback")) { rows_without_feedback_ = value != 0; return 0; }
     if (!strcmp(name, "block_threads")) {

@@ -128,6 +128,15 @@ struct RankRow {
     const float *value;
 };
 
+// libc rand() as a random-access stream (svdf_randstream.cpp): the generator's last 31 values, oldest first
+struct LibcRand { uint32_t x[31]; char *handle = nullptr; };
+bool libc_rand_capture(LibcRand &s);
+void libc_rand_restore(const LibcRand &s);
+void libc_jump_poly(uint64_t J, uint32_t a[31]);
+void libc_rand_chunk_states(const LibcRand &s0, long nchunks, long C, std::vector<uint32_t> &states);
+void libc_rand_peek(long n, int *out);
+void libc_rand_skip(long n);
+
 // PairwiseRankGenerator (apex_svd_data.cpp:812-1025) restated for whole passes: the rows of a user block are replaced by
 // rank pairs drawn with libc rand() in the reference's call order, so that a seeded run sees the same pairs.
 class PairSampler {
@@ -137,6 +146,14 @@ public:
     // appends the rows generated from one block; row_ptr holds absolute value offsets and starts as {0}
     void sample_block(const std::vector<RankRow> &rows, std::vector<float> &label, std::vector<int64_t> &row_ptr,
                       std::vector<unsigned> &index, std::vector<float> &value);
+    // what the device sampler (svdf_k_sample.hip) needs to know
+    int method() const { return method_; }
+    int pointwise() const { return pointwise_; }
+    int sample_num() const { return sample_num_; }
+    int sample_max() const { return sample_max_; }
+    float pos_lowerb() const { return pos_lowerb_; }
+    float neg_upperb() const { return neg_upperb_; }
+    int seed_bytime() const { return seed_bytime_; }
 private:
     int sample_num_ = -1, sample_max_ = 0x7fffffff, method_ = 0, pointwise_ = 0, seed_bytime_ = 0;
     float gap_ = 0.0001f, pos_lowerb_ = 0.8f, neg_upperb_ = 1e-6f;
@@ -146,6 +163,17 @@ private:
 
 struct RankPrefetch;
 struct UserGroupArrays;
+// a user-group buffer file kept in HBM for the device sampler (svdf_k_sample.hip); built once per file, reused every pass
+struct RankSource {
+    std::string path;
+    long file_size = -1, file_mtime = -1;
+    bool eligible = false;
+    long num_block = 0, num_row = 0;
+    DevBuf<long> block_row_ptr, draws, pairs, draw_off, pair_off;
+    DevBuf<float> label, uval, ival;
+    DevBuf<unsigned> uidx, iidx, raw, tables;
+    DevBuf<int> pos_list, neg_list;
+};
 class Engine;
 class Ranker;
 
@@ -337,6 +365,15 @@ class Engine {
     uint64_t schedule_signature() const;
     void disown(Dataset *ds);
     void rank_pass(const char *path, UserGroupArrays &g);
+    Dataset *rank_pass_device(const char *path);   // nullptr when the file or the sampler settings need the host path
+    std::unique_ptr<RankSource> rank_source_;
+    bool device_rank_ = true;                       // knob "device_rank"
+    // columns that are already in HBM (file order) -> level schedule + level-sorted copies
+    struct DUCol { const unsigned *src; DevBuf<unsigned> *dst; };
+    struct DFCol { const float *src; DevBuf<float> *dst; };
+    void schedule_device_columns(Dataset *ds, long n, int K, const unsigned *const *res_col, const unsigned *off, const unsigned *limit,
+                                 const char *const *msg, const unsigned *sort_key, unsigned sort_max, const std::vector<DUCol> &ucols,
+                                 const std::vector<DFCol> &fcols);
     bool rows_without_feedback_ = true;   // knob: block datasets without any feedback id are scheduled row by row
     bool rows_as_instances_ = false;      // set while such a dataset is being built
     bool relaxed() const { return relax_global_ || relax_feedback_ || relax_user_from_ != 0xFFFFFFFFu || relax_item_from_ != 0xFFFFFFFFu; }
@@ -351,6 +388,7 @@ class Engine {
     void check_row(int ng, int nu, int ni, const unsigned *index);
     bool basic_fast_path_allowed() const;
     bool fused_allowed() const;
+    bool fused_allowed_for_rows() const;   // the same for the rows of a feedback-free user-group pass
     template <typename PtrT> bool fused_shape_ok(long n, const PtrT *row_ptr, const unsigned *idx, FusedHost &out);
     template <typename PtrT> void fill_fused(long n, const float *row_label, const PtrT *row_ptr, const unsigned *idx, const float *val,
                                              const int *order, FusedHost &out);
@@ -392,6 +430,7 @@ class Engine {
     // ---- counters
     int64_t n_instances_ = 0, n_launches_ = 0, n_batches_ = 0, n_flushes_ = 0;
     int64_t ns_flush_ = 0, ns_model_ = 0;   // host-side time accounting (SVDF_PROFILE=1 prints it)
+    int64_t n_device_rank_passes_ = 0;
     int64_t n_kind_[3] = {0, 0, 0};   // launches of k_basicmf / k_general / k_fused
     DeltaRanges delta_ranges();
     friend struct Dataset;

@@ -74,28 +74,35 @@ __global__ __launch_bounds__(256) void k_sched_links(const unsigned *keys, const
     }
 }
 
-// appends `mine` (valid when have) to order[] at the shared cursor: one atomic per wave
-__device__ __forceinline__ void wave_append(bool have, int mine, int *order, unsigned *cursor) {
-    const unsigned long long mask = __ballot(have);
-    if (mask == 0ull) return;
-    const int lane = (int)(threadIdx.x & 63);
-    const int leader = __ffsll((long long)mask) - 1;
-    unsigned base = 0;
-    if (lane == leader) base = atomicAdd(cursor, (unsigned)__popcll(mask));
-    base = __shfl(base, leader, 64);
-    if (have) order[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = mine;
+// Appends are staged per WORKGROUP in LDS and flushed with ONE atomic on the shared cursor per round: thousands of same-address
+// device-scope atomics per level (one per wave, plus one per workgroup for the hand-over) were what a level cost before --
+// 23 us measured with 512 x 256 threads; the peel therefore runs few, large workgroups (PEEL_BLOCKS x 1024).
+#define PEEL_THREADS 1024
+#define PEEL_STAGE (PEEL_THREADS * SVDF_SCHED_MAX_SLOTS)
+struct Stage {
+    int items[PEEL_STAGE];
+    int count;
+    unsigned base;
+    bool last;
+};
+__device__ __forceinline__ void stage_flush(Stage &sh, int *order, unsigned *cursor) {
+    __syncthreads();
+    if (threadIdx.x == 0 && sh.count > 0) sh.base = atomicAdd(cursor, (unsigned)sh.count);
+    __syncthreads();
+    for (int j = threadIdx.x; j < sh.count; j += blockDim.x) order[sh.base + (unsigned)j] = sh.items[j];
+    __syncthreads();
+    if (threadIdx.x == 0) sh.count = 0;
+    __syncthreads();
 }
-
-// last block of a launch publishes where the next level ends (= the cursor now that every append of this launch is done)
-__device__ __forceinline__ void publish_level_end(unsigned *state, unsigned *level_end, int l) {
-    __shared__ bool last;
+// last workgroup of a launch publishes where the next level ends (= the cursor now that every append of this launch is done)
+__device__ __forceinline__ void publish_level_end(Stage &sh, unsigned *state, unsigned *level_end, int l) {
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
-        last = atomicAdd(&state[ST_BLOCKS_DONE], 1u) == gridDim.x - 1;
+        sh.last = atomicAdd(&state[ST_BLOCKS_DONE], 1u) == gridDim.x - 1;
     }
     __syncthreads();
-    if (last && threadIdx.x == 0) {
+    if (sh.last && threadIdx.x == 0) {
         __threadfence();
         const unsigned cur = atomicAdd(&state[ST_CURSOR], 0u);
         level_end[l + 1] = cur;
@@ -106,40 +113,52 @@ __device__ __forceinline__ void publish_level_end(unsigned *state, unsigned *lev
 }
 
 // level 1: the units that head all of their rows.  level_end[0] = 0, level_end[1] = number of such units
-__global__ __launch_bounds__(256) void k_sched_seed(long n, const int *need, const int *cnt, int *order, int *level, unsigned *state,
-                                                    unsigned *level_end) {
+__global__ __launch_bounds__(PEEL_THREADS) void k_sched_seed(long n, const int *need, const int *cnt, int *order, int *level, unsigned *state,
+                                                             unsigned *level_end) {
+    __shared__ Stage sh;
+    if (threadIdx.x == 0) sh.count = 0;
+    __syncthreads();
     const long stride = (long)gridDim.x * blockDim.x;
     const long rounds = (n + stride - 1) / stride;
-    for (long it = 0; it < rounds; it++) {   // whole waves stay in the loop: wave_append uses ballots
+    for (long it = 0; it < rounds; it++) {
         const long u = it * stride + (long)blockIdx.x * blockDim.x + threadIdx.x;
-        const bool ready = u < n && cnt[u] == need[u];
-        if (ready) level[u] = 1;
-        wave_append(ready, (int)u, order, &state[ST_CURSOR]);
+        if (u < n && cnt[u] == need[u]) {
+            level[u] = 1;
+            sh.items[atomicAdd(&sh.count, 1)] = (int)u;
+        }
+        stage_flush(sh, order, &state[ST_CURSOR]);
     }
-    publish_level_end(state, level_end, 0);
+    publish_level_end(sh, state, level_end, 0);
 }
 
 // level l+1 from level l (l >= 1): order[level_end[l-1] .. level_end[l]) are the units of level l
-__global__ __launch_bounds__(256) void k_sched_peel(int l, int K, const int *need, const int *succ, int *cnt, int *order, int *level,
-                                                    unsigned *state, unsigned *level_end) {
+template <int K>
+__global__ __launch_bounds__(PEEL_THREADS) void k_sched_peel(int l, const int *need, const int *succ, int *cnt, int *order, int *level,
+                                                             unsigned *state, unsigned *level_end) {
+    __shared__ Stage sh;
+    if (threadIdx.x == 0) sh.count = 0;
+    __syncthreads();
     const unsigned begin = level_end[l - 1], end = level_end[l];
     const unsigned total = end - begin;
     const unsigned stride = gridDim.x * blockDim.x;
     const unsigned rounds = (total + stride - 1) / stride;
     for (unsigned it = 0; it < rounds; it++) {
         const unsigned i = it * stride + blockIdx.x * blockDim.x + threadIdx.x;
-        const bool on = i < total;
-        const int u = on ? order[begin + i] : 0;
-        for (int s = 0; s < K; s++) {
-            int v = -1;
-            if (on) v = succ[(long)u * K + s];
-            bool ready = false;
-            if (v >= 0) ready = atomicAdd(&cnt[v], 1) + 1 == need[v];
-            if (ready) level[v] = l + 1;
-            wave_append(ready, v, order, &state[ST_CURSOR]);
+        if (i < total) {
+            const int u = order[begin + i];
+            int v[K];
+            bool ready[K];
+#pragma unroll
+            for (int s = 0; s < K; s++) v[s] = succ[(long)u * K + s];
+#pragma unroll
+            for (int s = 0; s < K; s++) ready[s] = v[s] >= 0 && atomicAdd(&cnt[v[s]], 1) + 1 == need[v[s]];   // K atomics in flight
+#pragma unroll
+            for (int s = 0; s < K; s++)
+                if (ready[s]) { level[v[s]] = l + 1; sh.items[atomicAdd(&sh.count, 1)] = v[s]; }
         }
+        stage_flush(sh, order, &state[ST_CURSOR]);
     }
-    publish_level_end(state, level_end, l);
+    publish_level_end(sh, state, level_end, l);
 }
 
 template <typename KeyT>
@@ -235,16 +254,28 @@ long device_schedule(const SchedColumns &in, int *order_out, std::vector<long> &
         SCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0u, (unsigned)res_bits, st));
     }
     hipLaunchKernelGGL(k_sched_links, dim3(grid_for_n(m)), dim3(256), 0, st, keys_b, vals_b, m, absent_key, K, succ, cnt);
-    hipLaunchKernelGGL(k_sched_seed, dim3(grid_for_n(n)), dim3(256), 0, st, n, need, cnt, frontier, level, state, level_end);
+    const int peel_grid = 32;   // few large workgroups: see Stage
+    hipLaunchKernelGGL(k_sched_seed, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, n, need, cnt, frontier, level, state, level_end);
+    auto peel = [&](int lvl) {
+        switch (K) {
+        case 1: hipLaunchKernelGGL(k_sched_peel<1>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
+        case 2: hipLaunchKernelGGL(k_sched_peel<2>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
+        case 3: hipLaunchKernelGGL(k_sched_peel<3>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
+        case 4: hipLaunchKernelGGL(k_sched_peel<4>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
+        case 5: hipLaunchKernelGGL(k_sched_peel<5>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
+        case 6: hipLaunchKernelGGL(k_sched_peel<6>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
+        case 7: hipLaunchKernelGGL(k_sched_peel<7>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
+        default: hipLaunchKernelGGL(k_sched_peel<8>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
+        }
+    };
 
     // peel: levels are launched in chunks, the host only checks between chunks whether every unit has been placed
     unsigned host_state[ST_WORDS];
     long l = 1;
-    const int peel_grid = 512;
     for (;;) {
         const long chunk = l < 512 ? 256 : 1024;
         for (long j = 0; j < chunk && l + 1 < level_cap; j++, l++)
-            hipLaunchKernelGGL(k_sched_peel, dim3(peel_grid), dim3(256), 0, st, (int)l, K, need, succ, cnt, frontier, level, state, level_end);
+            peel((int)l);
         SCHK(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
         SCHK(hipStreamSynchronize(st));
         if (host_state[ST_ERROR]) {

@@ -53,6 +53,20 @@ void launch_rank_score(const DevParams &P, long n, const float *tu, const float 
 void launch_rank_positions(long n, const float *score, const signed char *tag, const int *pos_item, int npos, int *greater, int *ties, hipStream_t st);
 int sqerr_partials_grid(long n);
 void launch_sqerr_partials(const float *pred, const float *label, long n, float scale, double *partials, hipStream_t st);
+// ---- rank-pair sampling on the device (svdf_k_sample.hip)
+struct RankSourceDev {          // a user-group buffer file resident in HBM, rows of shape (0 globals, 1 user entry, 1 item entry)
+    long num_block, num_row;
+    const long *block_row_ptr;  // [num_block + 1]
+    const float *label, *uval, *ival;
+    const unsigned *uidx, *iidx;
+};
+struct SamplerParams { float pos_lowerb, neg_upperb; int sample_num, sample_max; };
+struct PairColumns { float *label, *uval, *v0, *v1; unsigned *uidx, *i0, *i1; };   // generated instances, file order
+void launch_rand_expand(const unsigned *tables, long nchunks, long C, long D, unsigned *raw, hipStream_t st);
+void launch_sample_counts(const RankSourceDev &S, const SamplerParams &sp, long *draws, long *pairs, hipStream_t st);
+void launch_sample_posneg(const RankSourceDev &S, const SamplerParams &sp, const long *draw_off, const long *pair_off, const unsigned *raw,
+                          int *pos_list, int *neg_list, const PairColumns &out, hipStream_t st);
+// device-resident columns (already in HBM, file order) -> level schedule + level-sorted copies; see Engine::schedule_device_columns
 // ---- conflict-free level scheduling on the device (svdf_k_sched.hip).  Unit u touches the parameter rows off[s] + col[s][u]
 // for its K slots (SLOT_ABSENT = none; ids >= limit[s] raise limit_msg[s]); no row may repeat inside a unit.  Writes the
 // level-sorted unit order (ties: sort_key, then file position -- the order of the host scheduler's stable sorts) to the
