@@ -38,7 +38,7 @@ struct Cols {
 };
 
 // state words in device memory
-enum { ST_CURSOR = 0, ST_BLOCKS_DONE = 1, ST_ERROR = 2, ST_NLEVELS = 3, ST_WORDS = 8 };
+enum { ST_CURSOR = 0, ST_BLOCKS_DONE = 1, ST_ERROR = 2, ST_NLEVELS = 3, ST_NEXT_LEVEL = 4, ST_WORDS = 8 };
 
 __global__ __launch_bounds__(256) void k_sched_keys(const Cols C, long n, unsigned absent_key, unsigned *keys, unsigned *vals, int *need,
                                                     unsigned *state) {
@@ -161,6 +161,68 @@ __global__ __launch_bounds__(PEEL_THREADS) void k_sched_peel(int l, const int *n
     publish_level_end(sh, state, level_end, l);
 }
 
+// Deep, narrow dependency graphs (a rank pass in file order: 58 K levels of ~50 units) are bound by the launch-to-launch
+// latency of the one-level kernel (~6 us).  While a frontier fits into LDS ONE workgroup peels level after level inside a
+// single launch: the frontier never leaves LDS, the cursor is a register, a level costs two barriers and one round of
+// atomics on the successors' counters.  The kernel returns as soon as a frontier outgrows CHAIN_CAP (the wide kernel
+// continues from the global order array, which is always kept complete) or after max_levels.
+#define CHAIN_CAP 4096
+template <int K>
+__global__ __launch_bounds__(PEEL_THREADS) void k_sched_peel_chain(int l, int max_levels, const int *need, const int *succ, int *cnt, int *order,
+                                                                   int *level, unsigned *state, unsigned *level_end) {
+    __shared__ int fr[2][CHAIN_CAP];
+    __shared__ int nnext;
+    __shared__ unsigned cursor;
+    unsigned begin = level_end[l - 1], end = level_end[l];
+    int ncur = (int)(end - begin);
+    if (ncur > CHAIN_CAP || ncur == 0) {   // too wide for one workgroup (or nothing left): leave it to the caller
+        if (threadIdx.x == 0) state[ST_NEXT_LEVEL] = (unsigned)l;
+        return;
+    }
+    for (int i = threadIdx.x; i < ncur; i += blockDim.x) fr[0][i] = order[begin + (unsigned)i];
+    if (threadIdx.x == 0) { nnext = 0; cursor = end; }
+    __syncthreads();
+    int cur = 0, done = 0;
+    while (done < max_levels && ncur > 0 && ncur <= CHAIN_CAP) {
+        const unsigned base = cursor;
+        for (int i = threadIdx.x; i < ncur; i += blockDim.x) {
+            const int u = fr[cur][i];
+            int v[K];
+            bool ready[K];
+#pragma unroll
+            for (int s = 0; s < K; s++) v[s] = succ[(long)u * K + s];
+#pragma unroll
+            for (int s = 0; s < K; s++) ready[s] = v[s] >= 0 && atomicAdd(&cnt[v[s]], 1) + 1 == need[v[s]];
+#pragma unroll
+            for (int s = 0; s < K; s++)
+                if (ready[s]) {
+                    level[v[s]] = l + 1;
+                    const int pos = atomicAdd(&nnext, 1);
+                    order[base + (unsigned)pos] = v[s];            // the global order stays complete
+                    if (pos < CHAIN_CAP) fr[cur ^ 1][pos] = v[s];
+                }
+        }
+        __syncthreads();
+        const int made = nnext;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            cursor = base + (unsigned)made;
+            level_end[l + 1] = cursor;
+            nnext = 0;
+        }
+        __syncthreads();
+        l++; done++;
+        cur ^= 1;
+        ncur = made;
+    }
+    if (threadIdx.x == 0) {
+        state[ST_CURSOR] = cursor;
+        state[ST_NEXT_LEVEL] = (unsigned)l;
+        // level l's frontier is order[level_end[l-1], level_end[l]); levels up to l-1 have been retired, level l exists iff ncur > 0
+        if (ncur > 0) state[ST_NLEVELS] = (unsigned)l; else state[ST_NLEVELS] = (unsigned)(l - 1);
+    }
+}
+
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_sched_final_keys(long n, const int *level, const unsigned *sort_key, int key_bits, KeyT *keys, unsigned *vals) {
     const long stride = (long)gridDim.x * blockDim.x;
@@ -244,6 +306,7 @@ long device_schedule(const SchedColumns &in, int *order_out, std::vector<long> &
     unsigned *level_end = S.get<unsigned>((size_t)level_cap);
     SCHK(hipMemsetAsync(state, 0, ST_WORDS * sizeof(unsigned), st));
     SCHK(hipMemsetAsync(cnt, 0, (size_t)n * sizeof(int), st));
+    SCHK(hipMemsetAsync(succ, 0xFF, (size_t)m * sizeof(int), st));   // absent slots have no successor (-1)
     SCHK(hipMemsetAsync(level_end, 0, sizeof(unsigned), st));
 
     hipLaunchKernelGGL(k_sched_keys, dim3(grid_for_n(n)), dim3(256), 0, st, C, n, absent_key, keys_a, vals_a, need, state);
@@ -269,22 +332,41 @@ long device_schedule(const SchedColumns &in, int *order_out, std::vector<long> &
         }
     };
 
-    // peel: levels are launched in chunks, the host only checks between chunks whether every unit has been placed
+    // peel.  Narrow frontiers are chained inside one launch (k_sched_peel_chain), wide ones take one launch per level; the host
+    // looks at the state between phases: how far the levels got, and whether every unit has been placed
+    auto chain = [&](int lvl, int max_levels) {
+        switch (K) {
+        case 1: hipLaunchKernelGGL(k_sched_peel_chain<1>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
+        case 2: hipLaunchKernelGGL(k_sched_peel_chain<2>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
+        case 3: hipLaunchKernelGGL(k_sched_peel_chain<3>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
+        case 4: hipLaunchKernelGGL(k_sched_peel_chain<4>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
+        case 5: hipLaunchKernelGGL(k_sched_peel_chain<5>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
+        case 6: hipLaunchKernelGGL(k_sched_peel_chain<6>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
+        case 7: hipLaunchKernelGGL(k_sched_peel_chain<7>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
+        default: hipLaunchKernelGGL(k_sched_peel_chain<8>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
+        }
+    };
     unsigned host_state[ST_WORDS];
-    long l = 1;
+    long l = 1;   // the level whose frontier is known: order[level_end[l-1], level_end[l])
+    long placed_before = -1;
     for (;;) {
-        const long chunk = l < 512 ? 256 : 1024;
-        for (long j = 0; j < chunk && l + 1 < level_cap; j++, l++)
-            peel((int)l);
+        chain((int)l, 1 << 20);
         SCHK(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
         SCHK(hipStreamSynchronize(st));
         if (host_state[ST_ERROR]) {
             for (int s = 0; s < K; s++)
                 if (host_state[ST_ERROR] & (1u << s)) throw std::runtime_error(in.limit_msg[s] ? in.limit_msg[s] : "feature index exceed bound");
         }
+        l = (long)host_state[ST_NEXT_LEVEL];
         if ((long)host_state[ST_CURSOR] >= n) break;
+        if ((long)host_state[ST_CURSOR] == placed_before) throw std::runtime_error("device scheduler: the dependency graph did not drain");
+        placed_before = (long)host_state[ST_CURSOR];
         if (l + 1 >= level_cap) throw std::runtime_error("device scheduler: the dependency graph did not drain");
+        const long wide = 128;   // the frontier is wider than one workgroup's LDS: one launch per level for a while
+        for (long j = 0; j < wide && l + 1 < level_cap; j++, l++) peel((int)l);
     }
+    SCHK(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
+    SCHK(hipStreamSynchronize(st));
     const long nlevels = (long)host_state[ST_NLEVELS];
     std::vector<unsigned> ends((size_t)nlevels + 1);
     SCHK(hipMemcpyAsync(ends.data(), level_end, ((size_t)nlevels + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, st));
