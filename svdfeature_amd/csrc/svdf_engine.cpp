@@ -64,6 +64,7 @@ template struct DevBuf<DevBlk>;
 template struct DevBuf<signed char>;
 template struct DevBuf<double>;
 template struct DevBuf<long>;
+template struct DevBuf<char>;
 
 // =============================================================================== scheduler
 void build_schedule(const std::vector<int> &levels, int base, Schedule &out) {
@@ -223,6 +224,9 @@ struct ScopedNs {
 }  // namespace
 
 Engine::~Engine() {
+    if (multi_ && !host_only_ && stream_) { try { flush(); } catch (...) {} }
+    multi_.reset();
+    if (!host_only_ && device_ >= 0) (void)hipSetDevice(device_);
     rank_prefetch_drop();
     for (Dataset *ds : datasets_) ds->owner = nullptr;
     datasets_.clear();
@@ -248,6 +252,12 @@ void Engine::need_device(const char *what) {
 
 void Engine::set_param(const char *name, const char *val) {  // apex_svd_base.h:126-136
     if (trainer_ready_ && !host_only_) flush();   // staged instances were issued under the old parameters
+    // N GPUs behind one handle (svdf_multi.cpp): extension keys, ignored by the reference like any unknown key
+    if (!strcmp(name, "amd:gpus")) { check(!multi_ && !space_allocated_, "amd:gpus must be set before the model is created"); gpus_ = std::max(1, atoi(val)); }
+    else if (!is_peer_) param_log_.emplace_back(name, val);
+    if (!strcmp(name, "amd:delta_half")) delta_half_ = atoi(val) != 0;
+    if (!strcmp(name, "amd:window")) { stage_window_ = std::max<long>(1, atol(val)); window_set_ = true; }
+    if (multi_) for (int d = 1; d < gpus_; d++) rank_engine(d)->set_param(name, val);
     if (!strcmp(name, "feature_user")) name_feat_user_ = val;
     if (!strcmp(name, "feature_item")) name_feat_item_ = val;
     // extension keys (ignored by the reference like any unknown key): relaxed handling of shared ids
@@ -355,7 +365,13 @@ void Engine::init_model() {  // apex_svd_base.h:146-149
         hbi_.assign((size_t)mp_.num_item * (size_t)bi_param_.num_bi_feedback, 0.0f);
         bi_allocated_ = true;
     }
-    if (device_model_) upload_model();
+    multi_setup();
+    multi_copy_model_to_peers();
+    if (device_model_) {
+        if (multi_) for (int d = 1; d < gpus_; d++) { Engine *e = rank_engine(d); if (e->device_model_) { HIPCHECK(hipSetDevice(e->device_)); e->upload_model(); } }
+        HIPCHECK(hipSetDevice(device_));
+        upload_model();
+    }
 }
 
 // ---- model file: apex_svd_model.h:570-660; tensors: int header x_max[,y_max] + unpadded rows
@@ -434,12 +450,16 @@ void Engine::load_model(FILE *fi) {  // apex_svd_base.h:138-140
         load_2d(fi, hbi_.data(), mp_.num_item, bi_param_.num_bi_feedback, bi_param_.num_bi_feedback);
     }
     params_dirty_ = true;
+    multi_setup();
+    multi_copy_model_to_peers();
+    if (multi_) for (int d = 1; d < gpus_; d++) { Engine *e = rank_engine(d); e->params_dirty_ = true; if (e->device_model_) { HIPCHECK(hipSetDevice(e->device_)); e->upload_model(); } }
+    if (multi_ && !host_only_) HIPCHECK(hipSetDevice(device_));
     if (device_model_) upload_model();
 }
 void Engine::save_model(FILE *fo) {  // apex_svd_base.h:142-144
     ScopedNs timer(ns_model_);
     check(space_allocated_, "save_model: model is not initialised");
-    if (device_model_) { flush(); download_model(); }
+    if (device_model_) { flush(); download_model(); if (multi_) multi_gather_user_rows(); }
     check(host_model_valid_, "save_model: no model");
     write_model(fo);
     if (bilinear()) {   // BModel::save_to_file (apex_svd_bilinear.h:60-63, :198-201).  W_bi is inert: SVDPPFeature::update binds its OWN
@@ -522,6 +542,10 @@ void Engine::init_trainer() {  // apex_svd_base.h:151-173, 499-503
     if (host_only_) return;
     if (mp_.num_factor > max_supported_factor())
         fail("svdfeature_amd: num_factor > 1024 is not supported by the gfx950 kernels");
+    if (multi_) {
+        for (int d = 1; d < gpus_; d++) { Engine *e = rank_engine(d); HIPCHECK(hipSetDevice(e->device_)); e->init_trainer(); }
+        HIPCHECK(hipSetDevice(device_));
+    }
     if (!device_model_) upload_model();
     tracker_.resize(num_resources() + 1);
     d_ref_ui_.release(); d_ref_global_.release();   // ref_user/ref_item/ref_global start at 0 (:159-170)
@@ -529,6 +553,7 @@ void Engine::init_trainer() {  // apex_svd_base.h:151-173, 499-503
 }
 
 void Engine::set_round(int nround) {  // apex_svd_base.h:470-478
+    if (multi_ && tp_.decay_learning_rate != 0) { flush(); for (int d = 1; d < gpus_; d++) rank_engine(d)->set_round(nround); }
     if (tp_.decay_learning_rate != 0) {
         check(round_counter_ <= nround, "round counter restriction");
         if (round_counter_ < nround && trainer_ready_ && !host_only_) flush();
@@ -935,12 +960,16 @@ static void parallel_gather(T *dst, const T *src, const int *order, long n, long
 
 // =============================================================================== flush
 void Engine::flush() {
-    if (host_only_ || !trainer_ready_) return;
+    if (host_only_ || !trainer_ready_ || in_multi_) return;
     wait_worker();   // a window handed to the background thread earlier must land first
     ScopedNs timer(ns_flush_);
     if (imfb()) flush_iunits();
     else if (user_group()) flush_units();
-    else flush_csr(staged_);
+    else if (multi_) {
+        in_multi_ = true;
+        struct Leave { bool &f; ~Leave() { f = false; } } leave{in_multi_};
+        multi_flush(staged_);
+    } else flush_csr(staged_);
 }
 
 // ---- background window flush -----------------------------------------------------------------------
@@ -980,7 +1009,7 @@ void Engine::worker_main() {
     }
 }
 void Engine::submit_window() {
-    if (!async_flush_ || user_group()) { flush(); return; }
+    if (!async_flush_ || user_group() || multi_) { flush(); return; }
     if (!worker_.joinable()) worker_ = std::thread([this] { worker_main(); });
     wait_worker();
     {
@@ -1397,6 +1426,14 @@ void Engine::predict_csr_batch(int num_row, const float *row_label, const int *r
         return;
     }
     flush();
+    if (multi_) { multi_predict(num_row, row_label, row_ptr, feat_index, feat_value, out); return; }
+    predict_csr_batch_local(num_row, row_label, row_ptr, feat_index, feat_value, out);
+}
+void Engine::predict_csr_batch_local(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index,
+                                     const float *feat_value, float *out) {
+    need_device("predict");
+    if (num_row <= 0) return;
+    flush();
     const DevParams &P = params();
     HostCSR tmp;   // prediction rows never enter the training stage
     tmp.row_label.reserve((size_t)num_row);
@@ -1527,6 +1564,7 @@ const int *Engine::host_order(Dataset *ds) {
 Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
+    check(!multi_, "svdfeature_amd: resident datasets belong to one GPU; with amd:gpus > 1 feed the instances through update() (one exchange window per staging window)");
     if (!basic_fast_path_allowed()) {
         // fall back to the general representation (side tables / shared latent space / user-group trainer)
         std::vector<int64_t> ptr((size_t)3 * n + 1);
@@ -1674,6 +1712,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
     check(!user_group() || rows_as_instances_, "svdfeature_amd: resident datasets are for random-order (format_type 0) trainers");
+    check(!multi_, "svdfeature_amd: resident datasets belong to one GPU; with amd:gpus > 1 feed the instances through update() (one exchange window per staging window)");
     const long n = num_row;
     const int64_t p00 = row_ptr[0];
     check(row_ptr[3 * n] - p00 < (int64_t)2147483647, "dataset: more than 2^31-1 feature entries");
@@ -1954,6 +1993,10 @@ void Engine::item_delta_begin() {
     check(trainer_ready_, "item_delta: init_trainer has not been called");
     need_device("item_delta");
     flush();
+    item_delta_begin_local();
+}
+void Engine::item_delta_begin_local() {
+    need_device("item_delta");
     auto rg = shared_ranges();
     long total = 0;
     for (auto &x : rg) total += x.n;
@@ -2080,6 +2123,15 @@ int64_t Engine::get_view(int which, float *out, int64_t capacity) {
     if (n == 0) return 0;
     const bool matrix = (which == 1 || which == 3 || which == 6);
     const unsigned off = (which <= 1) ? user_off_ : (which <= 3) ? item_off_ : fb_off_;
+    if (device_model_ && multi_ && which <= 1) {   // user rows live on their owners
+        flush();
+        download_model();
+        multi_gather_user_rows();
+        if (!matrix) memcpy(out, hbias_.data() + off, (size_t)n * sizeof(float));
+        else for (int y = 0; y < rows; y++) memcpy(out + (size_t)y * cols, hW_.data() + ((size_t)off + y) * pitch_, (size_t)cols * sizeof(float));
+        hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hg_.clear(); host_model_valid_ = false;
+        return n;
+    }
     if (device_model_) {
         flush();
         if (which == 4) download_globals(out);
@@ -2103,6 +2155,7 @@ int64_t Engine::set_view(int which, const float *in, int64_t count) {
     const int64_t n = (int64_t)rows * cols;
     if (n != count) return -1;
     if (n == 0) return 0;
+    check(!multi_, "set_view: not available with amd:gpus > 1");
     const bool matrix = (which == 1 || which == 3 || which == 6);
     const unsigned off = (which <= 1) ? user_off_ : (which <= 3) ? item_off_ : fb_off_;
     if (device_model_) {
@@ -2142,6 +2195,9 @@ int64_t Engine::counter(int what) const {
     case 5: return n_kind_[1];
     case 6: return n_kind_[2];
     case 7: return n_device_rank_passes_;
+    case 8: return multi_counter(0);    // item-delta exchanges of an amd:gpus > 1 handle
+    case 9: return multi_counter(1);    // 1 when they run through RCCL
+    case 10: return multi_counter(2);   // 1 when every rank has a device of its own
     default: return -1;
     }
 }
@@ -2149,7 +2205,7 @@ int Engine::set_knob(const char *name, long value) {
     launch_version_++;   // any knob may change what a captured pass would launch
     if (!strcmp(name, "use_graph")) { use_graph_ = value != 0; return 0; }
     if (!strcmp(name, "graph_min_levels")) { check(value >= 1, "graph_min_levels must be >= 1"); graph_min_levels_ = (int)value; return 0; }
-    if (!strcmp(name, "stage_window")) { check(value >= 1, "stage_window must be >= 1"); stage_window_ = value; return 0; }
+    if (!strcmp(name, "stage_window")) { check(value >= 1, "stage_window must be >= 1"); stage_window_ = value; window_set_ = true; return 0; }
     if (!strcmp(name, "groups_per_wave")) {
         check(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "groups_per_wave must be 0 (auto), 1, 2, 4 or 8");
         groups_per_wave_ = (int)value;

@@ -163,6 +163,8 @@ private:
 
 struct RankPrefetch;
 struct UserGroupArrays;
+struct MultiState;                                   // svdf_multi.cpp: the other ranks of an "amd:gpus = N" handle
+struct MultiDeleter { void operator()(MultiState *m) const; };
 // a user-group buffer file kept in HBM for the device sampler (svdf_k_sample.hip); built once per file, reused every pass
 struct RankSource {
     std::string path;
@@ -427,6 +429,21 @@ class Engine {
     DevBuf<double> d_partials_;
     struct Range { float *base; long n; };
     std::vector<Range> shared_ranges();
+    // ---- N GPUs behind this handle (svdf_multi.cpp)
+    int gpus_ = 1;
+    bool is_peer_ = false, delta_half_ = true, window_set_ = false, in_multi_ = false;
+    std::vector<std::pair<std::string, std::string>> param_log_;   // every set_param so far, replayed on the other ranks
+    std::unique_ptr<MultiState, MultiDeleter> multi_;
+    Engine *rank_engine(int d);
+    void multi_setup();
+    void multi_copy_model_to_peers();
+    void multi_flush(HostCSR &src);
+    void multi_exchange();
+    void multi_predict(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value, float *out);
+    void multi_gather_user_rows();
+    int64_t multi_counter(int what) const;
+    void item_delta_begin_local();
+    void predict_csr_batch_local(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value, float *out);
     // ---- counters
     int64_t n_instances_ = 0, n_launches_ = 0, n_batches_ = 0, n_flushes_ = 0;
     int64_t ns_flush_ = 0, ns_model_ = 0;   // host-side time accounting (SVDF_PROFILE=1 prints it)

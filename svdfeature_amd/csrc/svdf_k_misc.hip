@@ -82,6 +82,29 @@ void launch_delta_add(float *cur, const float *snap, const float *delta, long n,
     hipLaunchKernelGGL(k_delta_add, dim3((int)grid), dim3(256), 0, st, cur, snap, delta, n);
 }
 
+// sum of N packed delta buffers (virtual ranks / no RCCL): dst = sum_d src[d], fp32 accumulation, fp16 or fp32 storage
+struct SumSrcs { const void *p[16]; int n; };
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_delta_sum(const SumSrcs S, void *dst, long total) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        float acc = 0.0f;
+        for (int d = 0; d < S.n; d++) acc += HALF ? __half2float(reinterpret_cast<const __half *>(S.p[d])[j]) : reinterpret_cast<const float *>(S.p[d])[j];
+        if (HALF) reinterpret_cast<__half *>(dst)[j] = __float2half_rn(acc);
+        else reinterpret_cast<float *>(dst)[j] = acc;
+    }
+}
+void launch_delta_sum(const void *const *srcs, int n, void *dst, long total, int half, hipStream_t st) {
+    if (total <= 0 || n <= 0) return;
+    SumSrcs S;
+    S.n = n > 16 ? 16 : n;
+    for (int d = 0; d < S.n; d++) S.p[d] = srcs[d];
+    long grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (half) hipLaunchKernelGGL(k_delta_sum<true>, dim3((int)grid), dim3(256), 0, st, S, dst, total);
+    else hipLaunchKernelGGL(k_delta_sum<false>, dim3((int)grid), dim3(256), 0, st, S, dst, total);
+}
+
 // ---- probe of the device expf (tests: compared with the host libm's expf bit for bit) ------------------
 __global__ __launch_bounds__(256) void k_expf_probe(const float *in, float *out, long n) {
     const long stride = (long)gridDim.x * blockDim.x;
