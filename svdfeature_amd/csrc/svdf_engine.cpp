@@ -1631,6 +1631,36 @@ Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsign
 Dataset *Engine::dataset_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
+    if (device_sched_ && n > 0 && fused_allowed() && !user_group() && !relaxed()) {
+        // everything on the device: the three columns go up as they are, the schedule columns (lower / higher item id, signs)
+        // are formed there, ids are checked by the scheduling pass, pos == neg by the preparation kernel
+        std::unique_ptr<Dataset> ds(new Dataset());
+        adopt(ds.get()); ds->num_row = n; ds->kind = 2;
+        DevBuf<unsigned> ru, rp, rq, lo_, hi_, flag;
+        DevBuf<float> vlo, vhi, one;
+        ru.upload(user, (size_t)n, stream_); rp.upload(pos, (size_t)n, stream_); rq.upload(neg, (size_t)n, stream_);
+        lo_.reserve((size_t)n); hi_.reserve((size_t)n); vlo.reserve((size_t)n); vhi.reserve((size_t)n); one.reserve((size_t)n); flag.reserve(1);
+        HIPCHECK(hipMemsetAsync(flag.p, 0, sizeof(unsigned), stream_));
+        launch_pairs_prepare(n, rp.p, rq.p, lo_.p, hi_.p, vlo.p, vhi.p, one.p, flag.p, stream_);
+        unsigned bad = 0;
+        HIPCHECK(hipMemcpyAsync(&bad, flag.p, sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
+        if (bad) fail("dataset_from_pairs: positive and negative item of a pair must differ");
+        rp.release(); rq.release();
+        const unsigned *res[3] = {ru.p, lo_.p, hi_.p};
+        const unsigned off[3] = {0u, (unsigned)mp_.num_user, (unsigned)mp_.num_user};
+        const unsigned limit[3] = {(unsigned)mp_.num_user, (unsigned)mp_.num_item, (unsigned)mp_.num_item};
+        const char *msg[3] = {"user feature index exceed bound", "item feature index exceed bound", "item feature index exceed bound"};
+        const unsigned *key = sort_batches_ == 1 ? lo_.p : (sort_batches_ == 2 ? ru.p : nullptr);
+        FusedDev &f = ds->fused;
+        f.max_nu = 1; f.max_ni = 2; f.has_g = false; f.inline_g = false;
+        schedule_device_columns(ds.get(), n, 3, res, off, limit, msg, key, sort_batches_ == 1 ? limit[1] : limit[0],
+                                {DUCol{ru.p, &f.uidx[0]}, DUCol{lo_.p, &f.iidx[0]}, DUCol{hi_.p, &f.iidx[1]}},
+                                {DFCol{one.p, &f.label}, DFCol{one.p, &f.uval[0]}, DFCol{vlo.p, &f.ival[0]}, DFCol{vhi.p, &f.ival[1]}});
+        const long nb2 = (mp_.no_user_bias ? 0 : 1) + 2;
+        ds->algorithmic_bytes = n * (8L * mp_.num_factor * 3 + 8 * nb2 + 16 + 8 * 3);
+        return ds.release();
+    }
     for (long r = 0; r < n; r++) {
         if (user[r] >= (unsigned)mp_.num_user) fail("user feature index exceed bound");
         if (pos[r] >= (unsigned)mp_.num_item || neg[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound");
@@ -1652,29 +1682,6 @@ Dataset *Engine::dataset_from_pairs(long n, const unsigned *user, const unsigned
     }
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = n; ds->kind = 2;
-    if (device_sched_ && n > 0) {
-        // columns of the few-row schedule in file order: user, lower item id, higher item id, and their +-1 values
-        std::vector<unsigned> lo_((size_t)n), hi_((size_t)n);
-        std::vector<float> vlo((size_t)n), vhi((size_t)n), one((size_t)n, 1.0f);
-        for (long r = 0; r < n; r++) {
-            const bool pf = pos[r] < neg[r];
-            lo_[(size_t)r] = pf ? pos[r] : neg[r]; hi_[(size_t)r] = pf ? neg[r] : pos[r];
-            vlo[(size_t)r] = pf ? 1.0f : -1.0f; vhi[(size_t)r] = pf ? -1.0f : 1.0f;
-        }
-        const int res_col[3] = {0, 1, 2};
-        const unsigned off[3] = {0u, (unsigned)mp_.num_user, (unsigned)mp_.num_user};
-        const unsigned limit[3] = {(unsigned)mp_.num_user, (unsigned)mp_.num_item, (unsigned)mp_.num_item};
-        const char *msg[3] = {"user feature index exceed bound", "item feature index exceed bound", "item feature index exceed bound"};
-        const int sort_col = sort_batches_ == 1 ? 1 : (sort_batches_ == 2 ? 0 : -1);
-        FusedDev &f = ds->fused;
-        f.max_nu = 1; f.max_ni = 2; f.has_g = false; f.inline_g = false;
-        schedule_columns_on_device(ds.get(), n, 3, res_col, off, limit, msg, sort_col, sort_col >= 0 ? limit[sort_col] : 0u,
-                                   {UCol{user, &f.uidx[0]}, UCol{lo_.data(), &f.iidx[0]}, UCol{hi_.data(), &f.iidx[1]}},
-                                   {FCol{one.data(), &f.label}, FCol{one.data(), &f.uval[0]}, FCol{vlo.data(), &f.ival[0]}, FCol{vhi.data(), &f.ival[1]}});
-        const long nb2 = (mp_.no_user_bias ? 0 : 1) + 2;
-        ds->algorithmic_bytes = n * (8L * mp_.num_factor * 3 + 8 * nb2 + 16 + 8 * 3);
-        return ds.release();
-    }
     {
         std::vector<int> lastu((size_t)mp_.num_user, 0), lasti((size_t)mp_.num_item, 0), levels((size_t)n);
         for (long r = 0; r < n; r++) {

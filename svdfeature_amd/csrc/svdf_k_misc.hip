@@ -105,6 +105,28 @@ void launch_delta_sum(const void *const *srcs, int n, void *dst, long total, int
     else hipLaunchKernelGGL(k_delta_sum<false>, dim3((int)grid), dim3(256), 0, st, S, dst, total);
 }
 
+// rank pairs (user, pos, neg) -> columns of the few-row schedule: lower / higher item id with the negative's sign flipped
+// (apex_svd_data.cpp:828-860), label and user value 1; *flag is raised when a pair has pos == neg
+__global__ __launch_bounds__(256) void k_pairs_prepare(long n, const unsigned *pos, const unsigned *neg, unsigned *lo, unsigned *hi, float *vlo,
+                                                       float *vhi, float *ones, unsigned *flag) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < n; r += stride) {
+        const unsigned p = pos[r], q = neg[r];
+        if (p == q) atomicOr(flag, 1u);
+        const bool pf = p < q;
+        lo[r] = pf ? p : q; hi[r] = pf ? q : p;
+        vlo[r] = pf ? 1.0f : -1.0f; vhi[r] = pf ? -1.0f : 1.0f;
+        ones[r] = 1.0f;
+    }
+}
+void launch_pairs_prepare(long n, const unsigned *pos, const unsigned *neg, unsigned *lo, unsigned *hi, float *vlo, float *vhi, float *ones,
+                          unsigned *flag, hipStream_t st) {
+    if (n <= 0) return;
+    long grid = (n + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(k_pairs_prepare, dim3((int)grid), dim3(256), 0, st, n, pos, neg, lo, hi, vlo, vhi, ones, flag);
+}
+
 // ---- probe of the device expf (tests: compared with the host libm's expf bit for bit) ------------------
 __global__ __launch_bounds__(256) void k_expf_probe(const float *in, float *out, long n) {
     const long stride = (long)gridDim.x * blockDim.x;

@@ -41,6 +41,8 @@ void launch_svdpp_predict(const DevParams &P, const DevCSR &D, const DevUnit *un
 // multi-GPU item-side delta over n floats
 void launch_delta_pack(const DeltaRanges &R, const float *snap, void *dst, int half, hipStream_t st);
 void launch_delta_unpack(const DeltaRanges &R, float *snap, const void *src, int half, int refresh, hipStream_t st);
+void launch_pairs_prepare(long n, const unsigned *pos, const unsigned *neg, unsigned *lo, unsigned *hi, float *vlo, float *vhi, float *ones,
+                          unsigned *flag, hipStream_t st);
 void launch_delta_sum(const void *const *srcs, int n, void *dst, long total, int half, hipStream_t st);   // up to 16 buffers
 void launch_delta_sub(const float *cur, const float *snap, float *delta, long n, hipStream_t st);
 void launch_delta_add(float *cur, const float *snap, const float *delta, long n, hipStream_t st);
