@@ -204,7 +204,9 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  * (0 routes few-row instances through the general kernel), "use_simple_units" (0 routes user units through the
  * lane-group kernel), "rows_without_feedback" (0 keeps whole users as sequential units even when no block of a block
  * dataset carries a feedback id; default 1 schedules such rows one by one), "use_graph" / "graph_min_levels" (hipGraph replay of a resident dataset's pass), "hot_reduce"
- * (relaxed mode: workgroup pre-reduction of a shared user row).  Returns 0 if the knob exists.
+ * (relaxed mode: workgroup pre-reduction of a shared user row), "device_schedule" (0 = build the conflict-free levels on the host
+ * instead of the GPU; same schedule), "device_schedule_min" (staged windows with fewer instances stay on the host scheduler),
+ * "device_rank" (0 = draw rank pairs with the host sampler; same pairs).  Returns 0 if the knob exists.
  * The relaxed mode itself is switched by CONFIG keys through svdf_set_param ("amd:relax_global",
  * "amd:relax_user_from", "amd:relax_item_from", "amd:relax_feedback"), not by knobs: it changes results. */
 int svdf_set_knob(svdf_trainer *t, const char *name, long value);

@@ -1035,6 +1035,40 @@ void Engine::flush_csr(HostCSR &src) {
             basic = (p[1] == p[0]) && (p[2] == p[1] + 1) && (p[3] == p[2] + 1);
         }
     }
+    if (basic && device_sched_ && n >= device_sched_min_) {
+        // a window of plain (user, item) instances: columns up, levels built on the GPU (svdf_k_sched.hip).  Launches of
+        // successive windows are ordered on one stream, so a window is scheduled on its own -- no level state carried over
+        std::vector<unsigned> cu((size_t)n), ci((size_t)n);
+        std::vector<float> ua((size_t)n), ia((size_t)n);
+        bool unit = true;
+        for (long r = 0; r < n; r++) {
+            cu[(size_t)r] = src.feat_index[(size_t)2 * r]; ci[(size_t)r] = src.feat_index[(size_t)2 * r + 1];
+            ua[(size_t)r] = src.feat_value[(size_t)2 * r]; ia[(size_t)r] = src.feat_value[(size_t)2 * r + 1];
+            unit = unit && ua[(size_t)r] == 1.0f && ia[(size_t)r] == 1.0f;
+        }
+        Dataset &wd = w_dataset_;
+        const int res_col[2] = {0, 1};
+        const unsigned off[2] = {0u, (unsigned)mp_.num_user}, limit[2] = {(unsigned)mp_.num_user, (unsigned)mp_.num_item};
+        const char *msg[2] = {"user feature index exceed bound", "item feature index exceed bound"};
+        const int sort_col = sort_batches_ == 1 ? 1 : (sort_batches_ == 2 ? 0 : -1);
+        std::vector<FCol> fc{FCol{src.row_label.data(), &w_label_}};
+        if (!unit) { fc.push_back(FCol{ua.data(), &w_uval_}); fc.push_back(FCol{ia.data(), &w_ival_}); }
+        schedule_columns_on_device(&wd, n, 2, res_col, off, limit, msg, sort_col, sort_col >= 0 ? limit[sort_col] : 0u,
+                                   {UCol{cu.data(), &w_user_}, UCol{ci.data(), &w_item_}}, fc);
+        BasicSchedule S{w_user_.p, w_item_.p, w_label_.p, unit ? nullptr : w_uval_.p, unit ? nullptr : w_ival_.p};
+        const Schedule &sc = wd.sched;
+        for (size_t l = 0; l < sc.num_levels(); l++) {
+            launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
+            n_launches_++; n_kind_[0]++;
+        }
+        HIPCHECK(hipGetLastError());
+        n_batches_ += (int64_t)sc.num_levels();
+        n_instances_ += n;
+        sample_counter_ += (unsigned)n;
+        n_flushes_++;
+        src.clear();
+        return;
+    }
     int *last = tracker_.last.data();
     for (long r = 0; r < n; r++) {
         const int *p = &src.row_ptr[(size_t)3 * r];
@@ -2226,6 +2260,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "use_fused")) { use_fused_ = value != 0; return 0; }
     if (!strcmp(name, "device_schedule")) { device_sched_ = value != 0; return 0; }
     if (!strcmp(name, "device_rank")) { device_rank_ = value != 0; return 0; }
+    if (!strcmp(name, "device_schedule_min")) { check(value >= 1, "device_schedule_min must be >= 1"); device_sched_min_ = value; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "rows_without_feedback")) { rows_without_feedback_ = value != 0; return 0; }
     if (!strcmp(name, "block_threads")) {

@@ -364,6 +364,8 @@ class Engine {
                                     const char *const *msg, int sort_col, unsigned sort_max, const std::vector<UCol> &ucols, const std::vector<FCol> &fcols);
     const int *host_order(Dataset *ds);
     bool device_sched_ = true;            // knob "device_schedule"
+    long device_sched_min_ = 1 << 16;     // staged windows smaller than this stay on the host scheduler (knob "device_schedule_min")
+    Dataset w_dataset_;                   // schedule scratch of device-scheduled staging windows (never adopted)
     uint64_t schedule_signature() const;
     void disown(Dataset *ds);
     void rank_pass(const char *path, UserGroupArrays &g);

@@ -113,3 +113,36 @@ def test_device_schedule_build_time_at_the_contract_size():
     dh = h.dataset_from_triples(u, i, r)
     print("host schedule of the same: %.3f s" % (time.time() - t0))
     assert dh.num_batches == ds.num_batches and dh.max_batch == ds.max_batch
+
+
+@pytest.mark.parametrize("unit_values", [True, False])
+def test_staged_windows_scheduled_on_the_device_match_the_oracle(unit_values):
+    """The per-instance / per-batch update path: full staging windows of plain (user, item) instances are scheduled on the GPU
+    too (one window at a time, no level state carried over); several windows, chunked calls, predictions in between -- byte for
+    byte the oracle.  device_schedule_min = 1 sends even tiny windows through the device scheduler."""
+    nu, ni, n = 4000, 600, 150_000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=12)
+    d = sa.CSRData.from_triples(u, i, r)
+    if not unit_values:
+        rng = np.random.default_rng(3)
+        d.feat_value[:] = rng.choice(np.array([1.0, 0.5, 0.25, 1.5], np.float32), size=d.feat_value.size)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=32)
+    t = _ready(0, 0, conf)
+    t.set_knob("device_schedule_min", 1)
+    t.set_knob("stage_window", 40_000)
+    o = oracle.OracleTrainer("port", 0, 0)
+    o.seed(10)
+    for k, v in conf:
+        o.set_param(k, v)
+    o.init_model()
+    o.init_trainer()
+    for st in range(0, n, 7001):
+        t.update_batch(d.slice_rows(st, st + 7001))
+        o.update_batch(d.slice_rows(st, st + 7001))
+        if st % 5 == 0:
+            probe = d.slice_rows(st, st + 50)
+            assert np.array_equal(t.predict_batch(probe).view(np.uint32), o.predict_batch(probe).view(np.uint32))
+    t.finish_round()
+    assert t.counter(3) >= 3   # several windows were flushed
+    for name in ("W_user", "W_item", "u_bias", "i_bias"):
+        assert np.array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32)), name
