@@ -583,6 +583,7 @@ const DevParams &Engine::params() {
     P.store_mode = store_mode_;
     P.xcd_remap = xcd_remap_;
     P.imfb_disable = imfb_disable_;
+    P.fewrow_fast = fewrow_fast_ ? 1 : 0;
     P.hot_reduce = hot_reduce_; P.relax_global = relax_global_ ? 1 : 0; P.relax_feedback = relax_feedback_ ? 1 : 0;
     if (device_model_ && g_stride_ != wanted_g_stride() && mp_.num_global > 0) {   // relax_global switched after the upload: re-lay out
         std::vector<float> g((size_t)mp_.num_global);
@@ -2260,6 +2261,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "use_fused")) { use_fused_ = value != 0; return 0; }
     if (!strcmp(name, "device_schedule")) { device_sched_ = value != 0; return 0; }
     if (!strcmp(name, "device_rank")) { device_rank_ = value != 0; return 0; }
+    if (!strcmp(name, "fewrow_fast")) { fewrow_fast_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "device_schedule_min")) { check(value >= 1, "device_schedule_min must be >= 1"); device_sched_min_ = value; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "rows_without_feedback")) { rows_without_feedback_ = value != 0; return 0; }

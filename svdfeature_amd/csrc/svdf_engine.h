@@ -372,6 +372,7 @@ class Engine {
     Dataset *rank_pass_device(const char *path);   // nullptr when the file or the sampler settings need the host path
     std::unique_ptr<RankSource> rank_source_;
     bool device_rank_ = true;                       // knob "device_rank"
+    bool fewrow_fast_ = true;                       // knob "fewrow_fast": specialised few-row kernel (svdf_k_fewrow.hip)
     // columns that are already in HBM (file order) -> level schedule + level-sorted copies
     struct DUCol { const unsigned *src; DevBuf<unsigned> *dst; };
     struct DFCol { const float *src; DevBuf<float> *dst; };

@@ -1,0 +1,123 @@
+// svdf_k_fewrow.hip -- the few-row fused step specialised for its usual configuration (rank pairs, BASELINE configs[4]; basicMF
+// with side ids): no global feature in the data set, no relaxed ids, L2 decay (reg_method 0), no per-range decay, no clamp.
+// Same arithmetic, same order, same bits as k_fused (svdf_k_fused.hip) -- which stays the general few-row kernel -- with the
+// instruction stream stripped of everything this configuration never executes: the global-bias paths, the per-row decay
+// switch and range lookup, the relaxed-id tests, the exec-mask branch around the bias stores.  k_fused<32,1,2> spends 448 VALU
+// + 165 SALU instructions per wave on a pair (profiles/r02_pmc_pairwise.txt) and a level of 11.5 K pairs is one occupancy
+// wave of the chip, so instruction issue is ~40 % of a launch: the same lever as k_basicmf's FULL / FAST specialisation.
+#include "svdf_device.h"
+
+namespace svdf {
+
+template <int LPI, int NU, int NI, bool FULL>
+__global__ __launch_bounds__(256) void k_fewrow_fast(const DevParams P, const FusedSchedule S, long begin, long end) {
+    constexpr int IPW = 64 / LPI;
+    const int lane = threadIdx.x & 63;
+    const int L = lane & (LPI - 1);
+    const int gslot = lane / LPI;
+    long tile = blockIdx.x;   // XCD-aware tile mapping, see k_basicmf
+    if (P.xcd_remap) tile = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long wave = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long s = begin + wave * (long)IPW + gslot;
+    if (begin + wave * (long)IPW >= end) return;
+    const bool valid = s < end;
+    const long sc = valid ? s : begin;
+    const int k = FULL ? 4 * LPI : P.k, pitch = P.pitch;
+    const bool use_ubias = P.no_user_bias == 0;
+
+    unsigned ur[NU], ir[NI];
+    float ua[NU], ia[NI], bu[NU], bi[NI];
+    float4 p[NU], q[NI];
+    const float label = S.label[sc];
+#pragma unroll
+    for (int a = 0; a < NU; a++) { ur[a] = valid ? S.uidx[a][sc] : (unsigned)SLOT_ABSENT; ua[a] = S.uval[a][sc]; }
+#pragma unroll
+    for (int b = 0; b < NI; b++) { ir[b] = valid ? S.iidx[b][sc] : (unsigned)SLOT_ABSENT; ia[b] = S.ival[b][sc]; }
+#pragma unroll
+    for (int a = 0; a < NU; a++) {
+        p[a] = f4zero(); bu[a] = 0.0f;
+        if (ur[a] != SLOT_ABSENT) {
+            p[a] = load_row<LPI>(P.W, P.user_off + ur[a], pitch, L, k);
+            if (use_ubias) bu[a] = P.bias[P.user_off + ur[a]];
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < NI; b++) {
+        q[b] = f4zero(); bi[b] = 0.0f;
+        if (ir[b] != SLOT_ABSENT) {
+            q[b] = load_row<LPI>(P.W, P.item_off + ir[b], pitch, L, k);
+            bi[b] = P.bias[P.item_off + ir[b]];
+        }
+    }
+    // row-invariant decay factors (L2: W *= 1 - lr*wd, the multiply skipped when that rounds to one; biases are plain multiplies)
+    const float dec_u = snap_to_one(1.0f - P.lr * P.wd_user), dec_i = snap_to_one(1.0f - P.lr * P.wd_item);
+    const float dec_ub = 1.0f - P.lr * P.wd_user_bias, dec_ib = 1.0f - P.lr * P.wd_item_bias;
+    // calc_bias (:313-353) in double, prepare_tmp (:354-381), dot, link, gradient -- as in k_fused
+    double bs = 0.0;
+    if (use_ubias) {
+#pragma unroll
+        for (int a = 0; a < NU; a++) if (ur[a] != SLOT_ABSENT) bs += (double)(ua[a] * bu[a]);
+    }
+#pragma unroll
+    for (int b = 0; b < NI; b++) if (ir[b] != SLOT_ABSENT) bs += (double)(ia[b] * bi[b]);
+    double sum = (double)P.base_score + bs;
+    float4 tu = f4zero(), ti = f4zero();
+#pragma unroll
+    for (int a = 0; a < NU; a++) if (ur[a] != SLOT_ABSENT) axpy4(tu, p[a], ua[a]);
+#pragma unroll
+    for (int b = 0; b < NI; b++) if (ir[b] != SLOT_ABSENT) axpy4(ti, q[b], ia[b]);
+    sum += (double)group_dot<LPI>(tu, ti, L, k);
+    const float pred = map_active((float)sum, P.active_type);
+    const float err = cal_grad(label, pred, P.active_type) * 1.0f;
+    const float lr = P.lr;
+    // update_no_decay (:383-427) + regularize (:286-311), rows written once; every lane of the group writes the same bias word
+#pragma unroll
+    for (int a = 0; a < NU; a++) {
+        if (ur[a] == SLOT_ABSENT) continue;
+        const float su = lr * err * ua[a];
+        float4 w = p[a];
+        axpy4(w, ti, su);
+        w.x = w.x * dec_u; w.y = w.y * dec_u; w.z = w.z * dec_u; w.w = w.w * dec_u;
+        store_row<LPI>(P.W, P.user_off + ur[a], pitch, L, k, w);
+        if (use_ubias) P.bias[P.user_off + ur[a]] = (bu[a] + su) * dec_ub;
+    }
+#pragma unroll
+    for (int b = 0; b < NI; b++) {
+        if (ir[b] == SLOT_ABSENT) continue;
+        const float si = lr * err * ia[b];
+        float4 w = q[b];
+        axpy4(w, tu, si);
+        w.x = w.x * dec_i; w.y = w.y * dec_i; w.z = w.z * dec_i; w.w = w.w * dec_i;
+        store_row<LPI>(P.W, P.item_off + ir[b], pitch, L, k, w);
+        P.bias[P.item_off + ir[b]] = (bi[b] + si) * dec_ib;
+    }
+}
+
+template <int LPI, int NU, int NI>
+static void launch_fewrow_shape(const DevParams &P, const FusedSchedule &S, long begin, long end, int block_threads, hipStream_t st) {
+    const long n = end - begin;
+    const long per_block = (long)(block_threads / 64) * (64 / LPI);
+    int grid = (int)((n + per_block - 1) / per_block);
+    if (P.xcd_remap) grid = (grid + 7) & ~7;
+    if (P.k == 4 * LPI) hipLaunchKernelGGL((k_fewrow_fast<LPI, NU, NI, true>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
+    else hipLaunchKernelGGL((k_fewrow_fast<LPI, NU, NI, false>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
+}
+template <int LPI>
+static void launch_fewrow_lpi(const DevParams &P, const FusedSchedule &S, int nu, int ni, long begin, long end, int bt, hipStream_t st) {
+    if (nu <= 1 && ni <= 1) launch_fewrow_shape<LPI, 1, 1>(P, S, begin, end, bt, st);
+    else if (nu <= 1) launch_fewrow_shape<LPI, 1, 2>(P, S, begin, end, bt, st);
+    else if (ni <= 1) launch_fewrow_shape<LPI, 2, 1>(P, S, begin, end, bt, st);
+    else launch_fewrow_shape<LPI, 2, 2>(P, S, begin, end, bt, st);
+}
+// true when the configuration / data set is the one this kernel is specialised for
+bool fewrow_fast_applies(const DevParams &P, const FusedSchedule &S) {
+    return S.gptr == nullptr && !P.relax_global && P.relax_user_from == 0xFFFFFFFFu && P.relax_item_from == 0xFFFFFFFFu &&
+           P.reg_method == 0 && P.u_rng.n == 0 && P.i_rng.n == 0 && P.user_nonnegative == 0;
+}
+void launch_fewrow_fast(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int block_threads, hipStream_t st) {
+    if (end <= begin) return;
+    if (block_threads <= 0) block_threads = 256;
+    SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_fewrow_lpi<LPI>(P, S, max_nu, max_ni, begin, end, block_threads, st));
+}
+
+}  // namespace svdf

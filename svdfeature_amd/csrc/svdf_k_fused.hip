@@ -315,6 +315,7 @@ static void launch_fused_lpi(const DevParams &P, const FusedSchedule &S, int nu,
 void launch_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int groups_per_wave,
                   int block_threads, hipStream_t st) {
     if (end <= begin) return;
+    if (P.fewrow_fast && fewrow_fast_applies(P, S)) { launch_fewrow_fast(P, S, max_nu, max_ni, begin, end, block_threads, st); return; }
     const int lpi_ = lanes_per_instance(P.k);
     if (groups_per_wave <= 0) groups_per_wave = lpi_ == 16 ? 2 : 1;
     if (block_threads <= 0) block_threads = lpi_ == 16 ? 128 : 256;

@@ -21,6 +21,9 @@ void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long
 // few-row fused kernel: instances with <= max_nu (1|2) user ids and <= max_ni (1|2) item ids
 void launch_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int groups_per_wave,
                   int block_threads, hipStream_t st);
+// the same step specialised for data sets without global features under L2 decay without ranges / relaxed ids (svdf_k_fewrow.hip)
+bool fewrow_fast_applies(const DevParams &P, const FusedSchedule &S);
+void launch_fewrow_fast(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int block_threads, hipStream_t st);
 void launch_predict_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long n, float *out, hipStream_t st);
 // counter_base: the reference's sample_counter at the first instance of D (row r runs with counter_base + r); only the
 // lazy decay modes read it

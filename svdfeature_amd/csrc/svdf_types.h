@@ -86,6 +86,7 @@ struct DevParams {
     int hot_reduce;           // knob: workgroup pre-reduction of a relaxed shared user row (k_fused HOTU)
     int xcd_remap;            // 1: consecutive tiles of a batch go to the same XCD (blockIdx%8), see k_basicmf
     unsigned imfb_disable;    // extend_type 2: bit l = ufeedback_disable_level l (apex_multi_imfb.h:58-67)
+    int fewrow_fast;          // knob: 1 = few-row data sets in the usual configuration run k_fewrow_fast instead of k_fused
     int store_mode;           // row-store cache policy of k_basicmf: 0 plain, 1 nontemporal, 2 sc1 write-through
     // SVDTrainParam
     float lr, wd_user, wd_item, wd_user_bias, wd_item_bias, wd_global;

@@ -101,12 +101,40 @@ def draw(rng, tmp, wide=False, big=False):
         plan["knobs"]["use_simple_units"] = 0
     if rng.integers(0, 4) == 0:
         plan["knobs"]["rows_without_feedback"] = 0
+    # round 2: the device scheduler against the host scheduler, windows of plain instances scheduled on the device
+    if rng.integers(0, 2) == 0:
+        plan["knobs"]["device_schedule"] = 0
+    elif rng.integers(0, 2) == 0:
+        plan["knobs"]["device_schedule_min"] = 1
+    # the multi-level implicit-feedback solver (extend_type 2) on nested spans, the bilinear solver (15) on plain blocks
+    plan["extend"] = 0
+    if fmt == 1 and not shared:
+        pick = int(rng.integers(0, 5))
+        if pick == 0:
+            plan["extend"] = 2
+            data = dict(train_blocks=cases.nested_blocks(int(rng.integers(5, 60)), nu, ni, nfb, seed))
+            if rng.integers(0, 3) == 0:
+                extra = extra + [("ufeedback_disable_level", str(int(rng.integers(0, 3))))]
+            plan["knobs"].pop("use_simple_units", None)
+        elif pick == 1:
+            plan["extend"] = 15
+            extra = extra + [("num_bi_feedback", str(int(rng.integers(0, 5)))), ("reg_bi_feedback", str(int(rng.integers(0, 6))))]
+    # rank pairs through the three-column entry point (random-order trainers, plain data)
+    if fmt == 0 and not shared and not side and rng.integers(0, 4) == 0:
+        pu, pp, pq = cases.planted_pairs(int(rng.integers(50, 30000 if big else 1500)), nu, max(ni, 2), seed)
+        if ni >= 2:
+            data = dict(pairs=(pu, pp, pq))
     return fmt, active, [(a, str(b)) for a, b in conf.items()] + extra, data, plan
 
 
 def run(make, fmt, active, conf, data, plan, is_hip):
+    if "pairs" in data:   # the same instances either as three columns (HIP engine) or as CSR rows (everything else)
+        pu, pp, pq = data["pairs"]
+        csr = sa.pairs_as_csr(pu, pp, pq)
+        data = dict(train=csr, pairs=data["pairs"])
+
     def fresh(model_path=None):
-        t = make(fmt, active)
+        t = make(fmt, active, plan.get("extend", 0))
         t.seed(11)
         if model_path:   # warm start (svd_feature.cpp:175-182, continue training from a saved model)
             t.load_model(model_path)
@@ -134,7 +162,7 @@ def run(make, fmt, active, conf, data, plan, is_hip):
                     if plan["peek"] and j % 37 == 5:
                         peeks.append(t.predict_csr(*d.row((j * 7) % d.num_row)))
             elif is_hip and plan["resident"]:
-                ds = ds or t.dataset_from_csr(d)
+                ds = ds or (t.dataset_from_pairs(*data["pairs"]) if "pairs" in data else t.dataset_from_csr(d))
                 t.train_dataset(ds)
             elif plan["chunk"]:
                 for st in range(0, d.num_row, plan["chunk"]):
@@ -199,18 +227,18 @@ def main(argv=None):
                     f.write("iteration %d format %d active %d\n%s\n%s\n%s\n" % (it, fmt, active, conf, plan,
                             {k: (len(v) if isinstance(v, list) else v.num_row) for k, v in data.items()}))
             try:
-                ov, op = run(lambda f, x: oracle.OracleTrainer("port", f, x), fmt, active, conf, data, plan, False)
+                ov, op = run(lambda f, x, e=0: oracle.OracleTrainer("port", f, x, e), fmt, active, conf, data, plan, False)
             except Exception as e:   # configuration the reference rejects (e.g. an id out of a shrunken range)
                 stats["skipped"] += 1
                 continue
             if a.reference:
-                hv, hp = run(lambda f, x: oracle.OracleTrainer("reference", f, x), fmt, active, conf, data, plan, False)
+                hv, hp = run(lambda f, x, e=0: oracle.OracleTrainer("reference_full" if e else "reference", f, x, e), fmt, active, conf, data, plan, False)
             elif sa.device_count() == 0:   # dry run of the generator and the oracle half on a box without a GPU
                 stats["skipped"] += 1
                 continue
             else:
                 try:
-                    hv, hp = run(lambda f, x: sa.Trainer(f, x), fmt, active, conf, data, plan, True)
+                    hv, hp = run(lambda f, x, e=0: sa.Trainer(f, x, e), fmt, active, conf, data, plan, True)
                 except sa.SvdfError as e:
                     print("iteration %d: engine refused what the oracle ran: %s\n%s %s" % (it, e, conf, plan), file=sys.stderr)
                     sys.exit(1)
