@@ -497,6 +497,12 @@ def run_workload(name, a, env, steps, warmup, main_line):
                          "kernel": WORKLOADS[name][3], "launches": launches, "avg_launch_us": per_launch_us,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "algorithmic_bytes_per_instance": alg_bytes / max(my_n, 1)},
+            # what bounds one launch of this kernel: its measured HBM traffic at the achievable streaming rate + one dependent
+            # kernel boundary (/opt/skills/guides/MI355X_MICROARCH.md: 6.3 TB/s achievable, 1.7-1.9 us between streaming kernels)
+            "launch_model": None if not traffic else {
+                "hbm_traffic_bytes_per_launch": traffic, "stream_us_at_6300GBps": traffic / 6.3e12 * 1e6, "boundary_us": 1.8,
+                "model_us": traffic / 6.3e12 * 1e6 + 1.8, "measured_us": per_launch_us,
+                "measured_over_model": per_launch_us / (traffic / 6.3e12 * 1e6 + 1.8)},
             "cpu_baseline": cpu_base, "parity": parity, "dag_bound": dag,
             # end to end: what a training run of `rounds` passes sees when the one-off schedule build is counted in
             "end_to_end": {"rounds": 40, "value": 40 * n / (sched_s + 40 * elapsed / steps), "unit": unit,
@@ -621,7 +627,7 @@ def main():
             "roofline": m["roofline"], "cpu_baseline": m["cpu_baseline"], "parity": m["parity"],
             "end_to_end": m["end_to_end"],
         }
-        for k in ("rmse_test_after_run", "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound"):
+        for k in ("rmse_test_after_run", "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound", "launch_model"):
             if m.get(k) is not None:
                 out[k] = m[k]
         if secondary:
