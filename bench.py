@@ -285,7 +285,8 @@ def cpu_baseline_and_parity(sa, name, a, factor, trainer, sample, n_total, log):
 def run_workload(name, a, env, steps, warmup, main_line):
     """Builds the workload, trains warmup + steps passes, returns the result dict (rank 0) or None."""
     import svdfeature_amd as sa
-    from svdfeature_amd.multi_gpu import HipShard, Pairs, ShardedTrainer, defer_tails, shard_block_windows, shard_pair_windows, shard_windows
+    from svdfeature_amd.multi_gpu import (HipShard, Pairs, ShardedTrainer, defer_tails, shard_block_windows, shard_pair_windows,
+                                          shard_windows, split_by_item_range)
     torch, dist, rank, world, local_rank, log = env["torch"], env["dist"], env["rank"], env["world"], env["local_rank"], env["log"]
     factor = a.factor if (main_line and a.factor) else WORKLOADS[name][2]
     unit = WORKLOADS[name][4]
@@ -349,7 +350,10 @@ def run_workload(name, a, env, steps, warmup, main_line):
 
     # ---- schedule the instance stream once and keep it in HBM
     t0 = time.time()
-    adaptor = HipShard(tr, torch, torch.device("cuda", local_rank))
+    # N > 1, ratings: the exchange of a window is cut into item-range pieces so that every piece's all-reduce runs while the
+    # next piece trains (svdf_item_delta_select; multi_gpu.ShardedTrainer(parts=p)); 1 = one synchronous all-reduce per window
+    parts = a.exchange_parts if (name == "basicmf" and (world > 1 or a.force_exchange)) else 1
+    adaptor = HipShard(tr, torch, torch.device("cuda", local_rank), parts=parts)
     if a.windows > 0:
         nwin = a.windows
     else:
@@ -368,18 +372,25 @@ def run_workload(name, a, env, steps, warmup, main_line):
     else:
         assert world == 1, "the neighbourhood workload is single-GPU (BASELINE configs[3])"
         shards = [d_all]
-    if nwin > 1 and a.defer_tails > 0 and name in ("basicmf", "pairwise"):
+    if parts > 1:   # piece p of every window, as a window sequence of its own for the tail deferral
+        pieces = [split_by_item_range(uu, ii, rr, a.items, parts) for (uu, ii, rr) in shards]
+        per_part = [[pc[q] for pc in pieces] for q in range(parts)]
+        if nwin > 1 and a.defer_tails > 0:
+            per_part = [defer_tails(seq, a.users, a.items, a.defer_tails) for seq in per_part]
+        shards = [[per_part[q][w] for q in range(parts)] for w in range(nwin)]
+    elif nwin > 1 and a.defer_tails > 0 and name in ("basicmf", "pairwise"):
         shards = defer_tails(shards, a.users, a.items, a.defer_tails)
     if name == "neighbourhood":
         wins = [tr.dataset_from_csr(d_all)]
     else:
         wins = adaptor.make_windows(shards)
     sched_s = time.time() - t0
-    n_batches = sum(w.num_batches for w in wins)
-    alg_bytes = sum(w.algorithmic_bytes for w in wins)
-    my_n = sum(w.num_row for w in wins)
-    log("%s: scheduled %d into %d conflict-free batches (largest %d) in %.1fs" % (name, my_n, n_batches, max(w.max_batch for w in wins), sched_s))
-    st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange, half_delta=(a.delta_dtype == "fp16"))
+    flat = [d for w in wins for d in (w if isinstance(w, list) else [w])]
+    n_batches = sum(w.num_batches for w in flat)
+    alg_bytes = sum(w.algorithmic_bytes for w in flat)
+    my_n = sum(w.num_row for w in flat)
+    log("%s: scheduled %d into %d conflict-free batches (largest %d) in %.1fs" % (name, my_n, n_batches, max(w.max_batch for w in flat), sched_s))
+    st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange, half_delta=(a.delta_dtype == "fp16"), parts=parts)
 
     def sync_all():
         tr.synchronize()
@@ -489,7 +500,8 @@ def run_workload(name, a, env, steps, warmup, main_line):
                          "svdpp": "implicitFeedback (SVD++) %d users x %d ratings, feedback set = own items, k=%d fp32 (BASELINE configs[3])" % (a.svdpp_users, a.svdpp_per_user, factor),
                          "neighbourhood": "neighborhoodModel shape: %d ratings + 4 of %d global ids each, k=%d fp32 (BASELINE configs[3])" % (n, a.globals, factor)}[name],
             "order": "uniform random (file order preserved: result == sequential SGD)" if world == 1 else
-                     "user-sharded, item-delta all-reduce (%s on the wire) every 1/%d pass" % (a.delta_dtype, nwin),
+                     "user-sharded, item-delta all-reduce (%s on the wire) every 1/%d pass%s" % (
+                         a.delta_dtype, nwin, (", in %d item-range pieces overlapped with training" % parts) if parts > 1 else ""),
             "conflict_free_batches_per_pass": n_batches, "schedule_build_s": round(sched_s, 2),
             "parallelism": "1 GPU" if world == 1 else "dp%d user shards + RCCL all-reduce" % world,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -509,7 +521,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
                            "what": "40 passes (demo/basicMF num_round) + the one-off schedule build + upload of this run"},
         }
         res.update(quality)
-    for w in wins:
+    for w in flat:
         w.close()
     tr.close()
     return res
@@ -542,6 +554,8 @@ def main():
                     help="item-delta exchanges per pass when --gpus > 1 (0 = chosen from the data density so that the "
                          "RMSE stays within 1e-4 of the sequential reference: about 64 ratings per item per window at "
                          "2 ranks, 32 at 4+ ranks; calibration in DESIGN.md section 6)")
+    ap.add_argument("--exchange-parts", type=int, default=2,
+                    help="N>1, ratings: item-range pieces per window exchange; piece p's all-reduce overlaps with training piece p+1 (1 = off)")
     ap.add_argument("--delta-dtype", choices=["fp16", "fp32"], default="fp16",
                     help="wire format of the item-side window deltas when --gpus > 1 (parameters stay fp32)")
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="basicMF ratings of the CPU baseline sample (other workloads scale it down)")

@@ -177,6 +177,11 @@ int svdf_item_delta_apply_from(svdf_trainer *t, const float *device_src);
  * returns *count (elements).  unpack sets current = snapshot + delta and, with refresh_snapshot != 0, also
  * snapshot = current, so the next window can pack again without svdf_item_delta_begin's copy. */
 int svdf_item_delta_pack(svdf_trainer *t, void *device_dst, int half, int64_t *count);
+/* The exchange of a window can be cut into nparts pieces by ITEM ID RANGE (part p = items [num_item*p/nparts, num_item*(p+1)/nparts);
+ * ranges that are not indexed by item id travel with part 0): pack / unpack then cover the selected piece only, so the
+ * all-reduce of one piece can run while the rank trains the instances whose items lie in another piece (no added staleness:
+ * a piece's rows are not touched between its pack and its unpack).  svdf_item_delta_begin always snapshots everything. */
+int svdf_item_delta_select(svdf_trainer *t, int part, int nparts);
 int svdf_item_delta_unpack(svdf_trainer *t, const void *device_src, int half, int refresh_snapshot);
 
 /* ---- introspection used by tests, bench.py and the harness ---- */

@@ -106,6 +106,7 @@ def load_library():
     lib.svdf_item_delta_pack.argtypes = [P, P, C.c_int, C.POINTER(C.c_int64)]
     lib.svdf_item_delta_unpack.argtypes = [P, P, C.c_int, C.c_int]
     lib.svdf_set_stream.argtypes = [P, P]
+    lib.svdf_item_delta_select.argtypes = [P, C.c_int, C.c_int]
     lib.svdf_get_view.restype = C.c_int64
     lib.svdf_get_view.argtypes = [P, C.c_int, _f32p, C.c_int64]
     lib.svdf_view_shape.argtypes = [P, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
@@ -414,6 +415,9 @@ class Trainer:
         n = C.c_int64()
         self._ok(self.lib.svdf_item_delta_pack(self.h, None, 0, C.byref(n)))
         return n.value
+
+    def item_delta_select(self, part, nparts):
+        self._ok(self.lib.svdf_item_delta_select(self.h, int(part), int(nparts)))
 
     def item_delta_pack(self, device_ptr, half=False):
         n = C.c_int64()

@@ -174,6 +174,7 @@ int svdf_item_delta_pack(svdf_trainer *t, void *dst, int half, int64_t *count) {
 int svdf_item_delta_unpack(svdf_trainer *t, const void *src, int half, int refresh_snapshot) {
     SVDF_GUARD(-1, { t->e->item_delta_unpack(src, half, refresh_snapshot); return 0; })
 }
+int svdf_item_delta_select(svdf_trainer *t, int part, int nparts) { SVDF_GUARD(-1, { t->e->item_delta_select(part, nparts); return 0; }) }
 int svdf_item_delta_apply_from(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->item_delta_apply_from(src); return 0; }) }
 int svdf_set_stream(svdf_trainer *t, void *hip_stream) { SVDF_GUARD(-1, { t->e->set_stream((hipStream_t)hip_stream); return 0; }) }
 

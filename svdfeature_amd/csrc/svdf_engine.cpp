@@ -2094,16 +2094,39 @@ void Engine::item_delta_apply_from(const float *device_src) {
     }
     HIPCHECK(hipGetLastError());
 }
+// Replicated ranges of the ACTIVE exchange partition (svdf_item_delta_select): the item rows are cut into nparts id ranges so
+// that a window's exchange can be split into pieces that overlap with training on the other pieces' instances; everything that
+// is not indexed by item id (feedback rows, global biases) travels with partition 0.  snap_off addresses the full snapshot.
 DeltaRanges Engine::delta_ranges() {
     DeltaRanges R;
     memset(&R, 0, sizeof(R));
     auto rg = shared_ranges();
     check(rg.size() <= SVDF_MAX_DELTA_RANGES, "item_delta: too many replicated ranges");
-    long off = 0;
-    for (size_t q = 0; q < rg.size(); q++) { R.base[q] = rg[q].base; R.off[q] = off; off += rg[q].n; }
-    R.n = (int)rg.size();
-    for (int q = R.n; q <= SVDF_MAX_DELTA_RANGES; q++) R.off[q] = off;
+    // shared_ranges(): [W_fb] W_item [bias_fb] bias_item [g_bias]; item ranges are the ones starting at item_off_
+    const long ni = (long)(n_uiset_ - item_off_);
+    const long lo = ni * delta_part_ / delta_nparts_, hi = ni * (delta_part_ + 1) / delta_nparts_;
+    long off = 0, snap = 0;
+    int n = 0;
+    for (size_t q = 0; q < rg.size(); q++) {
+        const bool is_w_item = rg[q].base == dW_.p + (size_t)item_off_ * pitch_;
+        const bool is_b_item = rg[q].base == dbias_.p + item_off_;
+        if (delta_nparts_ > 1 && (is_w_item || is_b_item)) {
+            const long unit = is_w_item ? pitch_ : 1;
+            R.base[n] = rg[q].base + lo * unit; R.off[n] = off; R.snap_off[n] = snap + lo * unit;
+            off += (hi - lo) * unit; n++;
+        } else if (delta_nparts_ == 1 || delta_part_ == 0) {
+            R.base[n] = rg[q].base; R.off[n] = off; R.snap_off[n] = snap;
+            off += rg[q].n; n++;
+        }
+        snap += rg[q].n;
+    }
+    R.n = n;
+    for (int q = n; q <= SVDF_MAX_DELTA_RANGES; q++) R.off[q] = off;
     return R;
+}
+void Engine::item_delta_select(int part, int nparts) {
+    check(nparts >= 1 && part >= 0 && part < nparts, "item_delta_select: bad partition");
+    delta_part_ = part; delta_nparts_ = nparts;
 }
 void Engine::item_delta_pack(void *device_dst, int half, int64_t *count) {
     check(trainer_ready_, "item_delta: init_trainer has not been called");

@@ -258,6 +258,7 @@ class Engine {
     void item_delta_copy(float *device_dst, const float *device_src);
     void item_delta_into(float *device_dst, int64_t *count);
     void item_delta_apply_from(const float *device_src);
+    void item_delta_select(int part, int nparts);                              // active exchange partition (item id ranges)
     void item_delta_pack(void *device_dst, int half, int64_t *count);          // one launch, fp32 or fp16 wire format
     void item_delta_unpack(const void *device_src, int half, int refresh_snapshot);
     void set_stream(hipStream_t s);
@@ -429,6 +430,7 @@ class Engine {
     UnitDev w_unitdev_;
     // ---- item delta
     DevBuf<float> d_snap_, d_delta_;
+    int delta_part_ = 0, delta_nparts_ = 1;
     DevBuf<double> d_partials_;
     struct Range { float *base; long n; };
     std::vector<Range> shared_ranges();

@@ -28,17 +28,20 @@ int max_fast_path_factor() { return 256; }
 // One launch over ALL replicated ranges (W_item, biases, globals ...): pack = (current - snapshot) in the wire type,
 // unpack = current <- snapshot + delta, optionally snapshot <- current so that the next window needs no copy.
 // fp16 conversion is round-to-nearest-even (what a separate .half() pass would do).
-__device__ __forceinline__ float *delta_slot(const DeltaRanges &R, long j) {
+__device__ __forceinline__ float *delta_slot(const DeltaRanges &R, long j, long &snap_pos) {
     int r = 0;
 #pragma unroll
     for (int q = 1; q < SVDF_MAX_DELTA_RANGES; q++) r += (q < R.n && j >= R.off[q]) ? 1 : 0;
+    snap_pos = R.snap_off[r] + (j - R.off[r]);
     return R.base[r] + (j - R.off[r]);
 }
 template <bool HALF>
 __global__ __launch_bounds__(256) void k_delta_pack(const DeltaRanges R, const float *snap, void *dst, long total) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
-        const float d = *delta_slot(R, j) - snap[j];
+        long sp;
+        const float *cur = delta_slot(R, j, sp);
+        const float d = *cur - snap[sp];
         if (HALF) reinterpret_cast<__half *>(dst)[j] = __float2half_rn(d);
         else reinterpret_cast<float *>(dst)[j] = d;
     }
@@ -48,9 +51,11 @@ __global__ __launch_bounds__(256) void k_delta_unpack(const DeltaRanges R, float
     const long stride = (long)gridDim.x * blockDim.x;
     for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
         const float d = HALF ? __half2float(reinterpret_cast<const __half *>(src)[j]) : reinterpret_cast<const float *>(src)[j];
-        const float v = snap[j] + d;
-        *delta_slot(R, j) = v;
-        if (refresh) snap[j] = v;
+        long sp;
+        float *cur = delta_slot(R, j, sp);
+        const float v = snap[sp] + d;
+        *cur = v;
+        if (refresh) snap[sp] = v;
     }
 }
 void launch_delta_pack(const DeltaRanges &R, const float *snap, void *dst, int half, hipStream_t st) {

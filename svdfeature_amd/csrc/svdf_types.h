@@ -161,7 +161,8 @@ enum { UNIT_START = 1, UNIT_END = 2, UNIT_SAVE = 4, UNIT_LOAD = 8,
 #define SVDF_MAX_DELTA_RANGES 6
 struct DeltaRanges {
     float *base[SVDF_MAX_DELTA_RANGES];
-    long off[SVDF_MAX_DELTA_RANGES + 1];
+    long off[SVDF_MAX_DELTA_RANGES + 1];       // position in the packed (wire) buffer
+    long snap_off[SVDF_MAX_DELTA_RANGES];      // position of the range's first float in the snapshot (full layout)
     int n;
 };
 

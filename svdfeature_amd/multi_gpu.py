@@ -54,6 +54,20 @@ def shard_windows(user, item, label, rank, world, windows):
     return out
 
 
+def split_by_item_range(user, item, label, num_item, parts):
+    """One shard cut into `parts` pieces by item id range (piece p: items [num_item*p/parts, num_item*(p+1)/parts)), order kept.
+    The pieces of a window touch disjoint item rows, so the exchange of one piece can overlap with training on another."""
+    if parts == 1:
+        return [(user, item, label)]
+    piece = (np.asarray(item, np.int64) * parts) // max(int(num_item), 1)
+    return [(user[piece == p], item[piece == p], label[piece == p]) for p in range(parts)]
+
+
+def shard_windows_parts(user, item, label, rank, world, windows, num_item, parts):
+    """List over windows of a list over item-range pieces of (u, i, r) for this rank."""
+    return [split_by_item_range(u, i, r, num_item, parts) for (u, i, r) in shard_windows(user, item, label, rank, world, windows)]
+
+
 def shard_pair_windows(user, pos, neg, rank, world, windows):
     """Rank pairs sharded like triples: this rank's pairs (user % world == rank) of every global window, order kept."""
     b = window_bounds(len(user), windows)
@@ -152,8 +166,13 @@ class ShardedTrainer:
       apply_refreshes_snapshot  delta_set also moves the snapshot, so delta_begin is needed once per pass only
     """
 
-    def __init__(self, adaptor, window_handles, world, dist=None, force_exchange=False, half_delta=False):
+    def __init__(self, adaptor, window_handles, world, dist=None, force_exchange=False, half_delta=False, parts=1):
         self.a, self.windows, self.world, self.dist = adaptor, window_handles, world, dist
+        # parts > 1: every window handle is a LIST of `parts` handles (pieces by item id range, split_by_item_range); the
+        # all-reduce of piece p runs while piece p+1 trains.  A piece's item rows are not touched between its pack and its
+        # unpack, so the values are those of the synchronous piece-by-piece schedule: no added staleness, only the order of
+        # the instances inside a window changes (per rank still exact SGD on a permuted stream, like defer_tails)
+        self.parts = parts
         self.force_exchange = force_exchange   # run the exchange even with one rank (plumbing tests)
         # exchange the window deltas as fp16 (parameters and all arithmetic stay fp32): halves the bytes on
         # xGMI; measured RMSE effect at configs[2] density: 5.32e-5 vs 5.33e-5 with fp32 deltas (DESIGN.md 6)
@@ -177,7 +196,40 @@ class ShardedTrainer:
         if self.world > 1 and hasattr(self.a, "gather_user_side"):
             self.a.gather_user_side(self.dist, rank, self.world)
 
+    def _train_pass_parts(self):
+        a = self.a
+        keep_snapshot = getattr(a, "apply_refreshes_snapshot", False)
+        pending = None   # (work handle or None, delta buffer, part): an exchange in flight
+
+        def finish(p):
+            work, d, part = p
+            if work is not None:
+                work.wait()          # the adaptor's stream waits for the collective
+            a.delta_set(d, part)
+
+        for wi, w in enumerate(self.windows):
+            if self.world == 1 and not self.force_exchange:
+                for ds in w:
+                    a.train(ds)
+                continue
+            if wi == 0 or not keep_snapshot:
+                if pending is not None:
+                    finish(pending)
+                    pending = None
+                a.delta_begin()
+            for part, ds in enumerate(w):
+                a.train(ds)
+                d = a.delta_get(part)
+                work = a.all_reduce_async(self.dist, d) if hasattr(a, "all_reduce_async") else self._reduce(d)
+                if pending is not None:
+                    finish(pending)   # enqueued AFTER this piece's training: the previous collective had all of it to overlap with
+                pending = (work, d, part)
+        if pending is not None:
+            finish(pending)
+
     def train_pass(self):
+        if self.parts > 1:
+            return self._train_pass_parts()
         keep_snapshot = getattr(self.a, "apply_refreshes_snapshot", False)
         for wi, w in enumerate(self.windows):
             if self.world == 1 and not self.force_exchange:
@@ -199,22 +251,28 @@ class HipShard:
 
     apply_refreshes_snapshot = True
 
-    def __init__(self, trainer, torch, device):
+    def __init__(self, trainer, torch, device, parts=1):
         self.t, self.torch, self.device = trainer, torch, device
         self.stream = torch.cuda.Stream(device=device)
         trainer.set_stream(self.stream.cuda_stream)
         self.buf = None
+        self.bufs = {}
         self.half = False
+        self.parts = parts
 
     def set_wire_half(self, half):
         self.half = bool(half)
         self.buf = None
+        self.bufs = {}
 
     def make_windows(self, shards):
         """shards: per window (user, item, label) triples, Pairs(user, pos, neg) or a data.BlockArrays (user-group data)."""
         from .data import BlockArrays
         out = []
         for sh in shards:
+            if isinstance(sh, list):    # item-range pieces of one window
+                out.append([self.t.dataset_from_triples(*piece) for piece in sh])
+                continue
             if isinstance(sh, BlockArrays):
                 out.append(self.t.dataset_from_blocks(sh))
             elif isinstance(sh, Pairs):
@@ -243,7 +301,16 @@ class HipShard:
     def delta_begin(self):
         self.t.item_delta_begin()
 
-    def delta_get(self):
+    def delta_get(self, part=None):
+        if part is not None:   # one item-range piece of the exchange, a buffer of its own (its collective may still be in flight)
+            self.t.item_delta_select(part, self.parts)
+            if part not in self.bufs:
+                with self.torch.cuda.stream(self.stream):
+                    self.bufs[part] = self.torch.empty(self.t.item_delta_count(), device=self.device,
+                                                       dtype=self.torch.float16 if self.half else self.torch.float32)
+            self.t.item_delta_pack(self.bufs[part].data_ptr(), self.half)
+            self.t.item_delta_select(0, 1)
+            return self.bufs[part]
         if self.buf is None:
             with self.torch.cuda.stream(self.stream):
                 self.buf = self.torch.empty(self.t.item_delta_count(), device=self.device,
@@ -255,5 +322,23 @@ class HipShard:
         with self.torch.cuda.stream(self.stream):   # the collective is ordered after the pack kernel on our stream
             dist.all_reduce(d)
 
-    def delta_set(self, d):
+    def all_reduce_async(self, dist, d):
+        """the collective starts after the pack kernel on our stream and runs beside what we enqueue next; .wait() on the
+        returned handle (inside our stream context) makes our stream wait for it"""
+        with self.torch.cuda.stream(self.stream):
+            work = dist.all_reduce(d, async_op=True)
+        torch, stream = self.torch, self.stream
+
+        class _Wait:
+            def wait(self_inner):
+                with torch.cuda.stream(stream):
+                    work.wait()
+        return _Wait()
+
+    def delta_set(self, d, part=None):
+        if part is not None:
+            self.t.item_delta_select(part, self.parts)
+            self.t.item_delta_unpack(d.data_ptr(), self.half, refresh_snapshot=True)
+            self.t.item_delta_select(0, 1)
+            return
         self.t.item_delta_unpack(d.data_ptr(), self.half, refresh_snapshot=True)

@@ -21,13 +21,18 @@ def make_oracle(conf, seed=10, fmt=0, active=0):
 class OracleShard:
     """multi_gpu adaptor protocol on top of the C oracle; deltas travel as torch CPU tensors (gloo)."""
 
-    def __init__(self, trainer, torch=None):
+    def __init__(self, trainer, torch=None, parts=1):
         self.t, self.torch = trainer, torch
         self.snap = None
+        self.parts = parts
+        self.apply_refreshes_snapshot = parts > 1   # piece-wise exchange keeps one running snapshot per pass
 
     def make_windows(self, shards):
         out = []
         for sh in shards:
+            if isinstance(sh, list):   # item-range pieces of one window
+                out.append([CSRData.from_triples(*piece) for piece in sh])
+                continue
             if isinstance(sh, BlockArrays):
                 out.append(sh.to_blocks())
             elif isinstance(sh, Pairs):
@@ -59,17 +64,64 @@ class OracleShard:
     def delta_begin(self):
         self.snap = self._shared()
 
-    def delta_get(self):
+    def _piece(self, part):
+        """flat positions of item-range piece `part` in the packed layout (svdf_item_delta_select): the item rows of W_item
+        and i_bias in [num_item*part/parts, num_item*(part+1)/parts); everything else travels with piece 0"""
+        pos, off = [], 0
+        for name, v in self._views():
+            if name in ("W_item", "i_bias"):
+                ni = v.shape[0]
+                lo, hi = ni * part // self.parts, ni * (part + 1) // self.parts
+                width = v.size // ni
+                pos.append(np.arange(off + lo * width, off + hi * width))
+            elif part == 0:
+                pos.append(np.arange(off, off + v.size))
+            off += v.size
+        return np.concatenate(pos)
+
+    def delta_get(self, part=None):
         d = self._shared() - self.snap
+        if part is not None:
+            d = np.ascontiguousarray(d[self._piece(part)])
         return self.torch.from_numpy(d) if self.torch is not None else d
 
-    def delta_set(self, d):
+    def delta_set(self, d, part=None):
         d = d.numpy() if hasattr(d, "numpy") else d
-        new = self.snap + d
+        cur = self._shared()
+        if part is not None:
+            pos = self._piece(part)
+            new = cur
+            new[pos] = self.snap[pos] + d
+            self.snap[pos] = new[pos]      # the piece's snapshot moves along (apply_refreshes_snapshot semantics)
+        else:
+            new = self.snap + d
         off = 0
         for name, v in self._views():
             self.t.set_view(name, new[off:off + v.size])
             off += v.size
+
+
+def simulate_parts(conf, u, i, r, world, windows, passes, parts, num_item, seed=10):
+    """The piece-wise exchange (ShardedTrainer(parts=p)) run synchronously in one process: per window every rank trains
+    piece 0 then exchanges it, trains piece 1 then exchanges it, ...  The overlapped schedule computes the same values."""
+    from svdfeature_amd.multi_gpu import shard_windows_parts
+    ranks = [OracleShard(make_oracle(conf, seed), parts=parts) for _ in range(world)]
+    wins = [a.make_windows(shard_windows_parts(u, i, r, rk, world, windows, num_item, parts)) for rk, a in enumerate(ranks)]
+    for _ in range(passes):
+        for w in range(windows):
+            if w == 0:
+                for a in ranks:
+                    a.delta_begin()
+            for part in range(parts):
+                for rk, a in enumerate(ranks):
+                    a.train(wins[rk][w][part])
+                total = None
+                for a in ranks:
+                    d = a.delta_get(part)
+                    total = d.copy() if total is None else total + d
+                for a in ranks:
+                    a.delta_set(total, part)
+    return ranks
 
 
 def simulate(conf, u, i, r, world, windows, passes, seed=10, defer=0.0, fmt=0, active=0):

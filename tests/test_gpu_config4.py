@@ -207,3 +207,47 @@ def test_gather_of_user_rows_completes_the_model():
         np.testing.assert_array_equal(ts[0].view("u_bias")[own], ts[rk].view("u_bias")[own])
     with pytest.raises(sa.SvdfError):
         ts[0].set_view("W_user", full_w[:-1])
+
+
+@pytest.mark.parametrize("world,windows,parts,k", [(2, 4, 2, 16), (3, 3, 3, 64)])
+def test_simulated_ranks_piecewise_exchange(world, windows, parts, k):
+    """svdf_item_delta_select: the exchange cut into item-range pieces (what bench.py --gpus N overlaps with training), N
+    trainers playing the ranks on one GPU with the collective replaced by a sum, in the pipelined order of
+    ShardedTrainer._train_pass_parts -- against the synchronous oracle simulation, bit for bit."""
+    import torch
+    from multi_rank_utils import simulate_parts
+    from svdfeature_amd.multi_gpu import HipShard, shard_windows_parts
+    nu, ni, n, passes = 3000, 400, 40000, 2
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k)
+    u, i, r = cases.planted_triples(n, nu, ni, seed=9)
+    dev = torch.device("cuda", 0)
+    ranks = []
+    for rk in range(world):
+        a = HipShard(_ready(hip, 0, 0, conf), torch, dev, parts=parts)
+        ranks.append((a, a.make_windows(shard_windows_parts(u, i, r, rk, world, windows, ni, parts))))
+    for _ in range(passes):
+        pending = None
+        for w in range(windows):
+            if w == 0:
+                for a, _w in ranks:
+                    a.delta_begin()
+            for part in range(parts):
+                ds = []
+                for a, wins in ranks:
+                    a.train(wins[w][part])
+                    d = a.delta_get(part)
+                    a.stream.synchronize()
+                    ds.append(d.clone())
+                total = ds[0]
+                for d in ds[1:]:
+                    total = total + d
+                torch.cuda.synchronize()
+                if pending is not None:      # the previous piece is applied only now, after this piece has trained
+                    for a, _w in ranks:
+                        a.delta_set(pending[0], pending[1])
+                pending = (total, part)
+        for a, _w in ranks:
+            a.delta_set(pending[0], pending[1])
+    sim = simulate_parts(conf, u, i, r, world, windows, passes, parts, ni)
+    for rk in range(world):
+        _same(ranks[rk][0].t, sim[rk].t, ("W_item", "i_bias", "W_user", "u_bias"))
