@@ -251,3 +251,30 @@ def test_simulated_ranks_piecewise_exchange(world, windows, parts, k):
     sim = simulate_parts(conf, u, i, r, world, windows, passes, parts, ni)
     for rk in range(world):
         _same(ranks[rk][0].t, sim[rk].t, ("W_item", "i_bias", "W_user", "u_bias"))
+
+
+def test_piecewise_exchange_through_rccl_async_collectives_world_one():
+    """The real pipeline of bench.py --gpus N -- ShardedTrainer(parts=2) over HipShard with torch.distributed backend "nccl"
+    (RCCL) and async_op collectives ordered against the trainer's stream -- on the one GPU of this box (world 1: the sum is the
+    identity, the delta round trip snapshot + (current - snapshot) is not): equal to the synchronous simulation bit for bit."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from multi_rank_utils import simulate_parts
+    from svdfeature_amd.multi_gpu import HipShard, ShardedTrainer, shard_windows_parts
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ["MASTER_PORT"] = "29617"
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        nu, ni, n, windows, parts, passes = 2000, 300, 30000, 3, 2, 2
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
+        u, i, r = cases.planted_triples(n, nu, ni, seed=2)
+        a = HipShard(_ready(hip, 0, 0, conf), torch, torch.device("cuda", 0), parts=parts)
+        wins = a.make_windows(shard_windows_parts(u, i, r, 0, 1, windows, ni, parts))
+        st = ShardedTrainer(a, wins, 1, dist, force_exchange=True, parts=parts)
+        for _ in range(passes):
+            st.train_pass()
+        sim = simulate_parts(conf, u, i, r, 1, windows, passes, parts, ni)
+        _same(a.t, sim[0].t, ("W_item", "i_bias", "W_user", "u_bias"))
+    finally:
+        dist.destroy_process_group()
