@@ -40,7 +40,9 @@ struct Cols {
 // state words in device memory
 enum { ST_CURSOR = 0, ST_BLOCKS_DONE = 1, ST_ERROR = 2, ST_NLEVELS = 3, ST_NEXT_LEVEL = 4, ST_WORDS = 8 };
 
-__global__ __launch_bounds__(256) void k_sched_keys(const Cols C, long n, unsigned absent_key, unsigned *keys, unsigned *vals, int *need,
+// remaining[u] starts as the number of rows unit u touches; every row it heads (links kernel) and every retired predecessor
+// (peel) takes one off; the unit is ready when it reaches 0 -- one atomic per dependency, no second array to look up
+__global__ __launch_bounds__(256) void k_sched_keys(const Cols C, long n, unsigned absent_key, unsigned *keys, unsigned *vals, int *remaining,
                                                     unsigned *state) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < n; u += stride) {
@@ -55,13 +57,13 @@ __global__ __launch_bounds__(256) void k_sched_keys(const Cols C, long n, unsign
             keys[u * C.K + s] = key;
             vals[u * C.K + s] = (unsigned)(u * C.K + s);
         }
-        need[u] = nd;
+        remaining[u] = nd;
     }
 }
 
 // sorted (row, entry): successor link of every entry, and one credit for the unit that heads each row
 __global__ __launch_bounds__(256) void k_sched_links(const unsigned *keys, const unsigned *vals, long m, unsigned absent_key, int K, int *succ,
-                                                     int *cnt) {
+                                                     int *remaining) {
     const long stride = (long)gridDim.x * blockDim.x;
     for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
         const unsigned key = keys[j];
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void k_sched_links(const unsigned *keys, const
         int nxt = -1;
         if (j + 1 < m && keys[j + 1] == key) nxt = (int)(vals[j + 1] / (unsigned)K);
         succ[e] = nxt;
-        if (j == 0 || keys[j - 1] != key) atomicAdd(&cnt[e / (unsigned)K], 1);
+        if (j == 0 || keys[j - 1] != key) atomicSub(&remaining[e / (unsigned)K], 1);
     }
 }
 
@@ -113,7 +115,7 @@ __device__ __forceinline__ void publish_level_end(Stage &sh, unsigned *state, un
 }
 
 // level 1: the units that head all of their rows.  level_end[0] = 0, level_end[1] = number of such units
-__global__ __launch_bounds__(PEEL_THREADS) void k_sched_seed(long n, const int *need, const int *cnt, int *order, int *level, unsigned *state,
+__global__ __launch_bounds__(PEEL_THREADS) void k_sched_seed(long n, const int *remaining, int *order, int *level, unsigned *state,
                                                              unsigned *level_end) {
     __shared__ Stage sh;
     if (threadIdx.x == 0) sh.count = 0;
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(PEEL_THREADS) void k_sched_seed(long n, const int *
     const long rounds = (n + stride - 1) / stride;
     for (long it = 0; it < rounds; it++) {
         const long u = it * stride + (long)blockIdx.x * blockDim.x + threadIdx.x;
-        if (u < n && cnt[u] == need[u]) {
+        if (u < n && remaining[u] == 0) {
             level[u] = 1;
             sh.items[atomicAdd(&sh.count, 1)] = (int)u;
         }
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(PEEL_THREADS) void k_sched_seed(long n, const int *
 
 // level l+1 from level l (l >= 1): order[level_end[l-1] .. level_end[l]) are the units of level l
 template <int K>
-__global__ __launch_bounds__(PEEL_THREADS) void k_sched_peel(int l, const int *need, const int *succ, int *cnt, int *order, int *level,
+__global__ __launch_bounds__(PEEL_THREADS) void k_sched_peel(int l, const int *succ, int *remaining, int *order, int *level,
                                                              unsigned *state, unsigned *level_end) {
     __shared__ Stage sh;
     if (threadIdx.x == 0) sh.count = 0;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(PEEL_THREADS) void k_sched_peel(int l, const int *n
 #pragma unroll
             for (int s = 0; s < K; s++) v[s] = succ[(long)u * K + s];
 #pragma unroll
-            for (int s = 0; s < K; s++) ready[s] = v[s] >= 0 && atomicAdd(&cnt[v[s]], 1) + 1 == need[v[s]];   // K atomics in flight
+            for (int s = 0; s < K; s++) ready[s] = v[s] >= 0 && atomicSub(&remaining[v[s]], 1) == 1;   // K atomics in flight
 #pragma unroll
             for (int s = 0; s < K; s++)
                 if (ready[s]) { level[v[s]] = l + 1; sh.items[atomicAdd(&sh.count, 1)] = v[s]; }
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(PEEL_THREADS) void k_sched_peel(int l, const int *n
 // continues from the global order array, which is always kept complete) or after max_levels.
 #define CHAIN_CAP 4096
 template <int K>
-__global__ __launch_bounds__(PEEL_THREADS) void k_sched_peel_chain(int l, int max_levels, const int *need, const int *succ, int *cnt, int *order,
+__global__ __launch_bounds__(PEEL_THREADS) void k_sched_peel_chain(int l, int max_levels, const int *succ, int *remaining, int *order,
                                                                    int *level, unsigned *state, unsigned *level_end) {
     __shared__ int fr[2][CHAIN_CAP];
     __shared__ int nnext;
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(PEEL_THREADS) void k_sched_peel_chain(int l, int ma
 #pragma unroll
             for (int s = 0; s < K; s++) v[s] = succ[(long)u * K + s];
 #pragma unroll
-            for (int s = 0; s < K; s++) ready[s] = v[s] >= 0 && atomicAdd(&cnt[v[s]], 1) + 1 == need[v[s]];
+            for (int s = 0; s < K; s++) ready[s] = v[s] >= 0 && atomicSub(&remaining[v[s]], 1) == 1;
 #pragma unroll
             for (int s = 0; s < K; s++)
                 if (ready[s]) {
@@ -298,37 +300,36 @@ long device_schedule(const SchedColumns &in, int *order_out, std::vector<long> &
     Scratch S;
     unsigned *keys_a = S.get<unsigned>((size_t)m), *keys_b = S.get<unsigned>((size_t)m);
     unsigned *vals_a = S.get<unsigned>((size_t)m), *vals_b = S.get<unsigned>((size_t)m);
-    int *need = S.get<int>((size_t)n), *cnt = S.get<int>((size_t)n), *level = S.get<int>((size_t)n);
+    int *remaining = S.get<int>((size_t)n), *level = S.get<int>((size_t)n);
     int *succ = S.get<int>((size_t)m);
     int *frontier = S.get<int>((size_t)n);
     unsigned *state = S.get<unsigned>(ST_WORDS);
     const long level_cap = n + 2;   // a chain can be as deep as the data set
     unsigned *level_end = S.get<unsigned>((size_t)level_cap);
     SCHK(hipMemsetAsync(state, 0, ST_WORDS * sizeof(unsigned), st));
-    SCHK(hipMemsetAsync(cnt, 0, (size_t)n * sizeof(int), st));
     SCHK(hipMemsetAsync(succ, 0xFF, (size_t)m * sizeof(int), st));   // absent slots have no successor (-1)
     SCHK(hipMemsetAsync(level_end, 0, sizeof(unsigned), st));
 
-    hipLaunchKernelGGL(k_sched_keys, dim3(grid_for_n(n)), dim3(256), 0, st, C, n, absent_key, keys_a, vals_a, need, state);
+    hipLaunchKernelGGL(k_sched_keys, dim3(grid_for_n(n)), dim3(256), 0, st, C, n, absent_key, keys_a, vals_a, remaining, state);
     {
         size_t tmp_bytes = 0;
         SCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0u, (unsigned)res_bits, st));
         void *tmp = S.get<char>(tmp_bytes);
         SCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0u, (unsigned)res_bits, st));
     }
-    hipLaunchKernelGGL(k_sched_links, dim3(grid_for_n(m)), dim3(256), 0, st, keys_b, vals_b, m, absent_key, K, succ, cnt);
-    const int peel_grid = 32;   // few large workgroups: see Stage
-    hipLaunchKernelGGL(k_sched_seed, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, n, need, cnt, frontier, level, state, level_end);
+    hipLaunchKernelGGL(k_sched_links, dim3(grid_for_n(m)), dim3(256), 0, st, keys_b, vals_b, m, absent_key, K, succ, remaining);
+    const int peel_grid = 64;   // few large workgroups: see Stage
+    hipLaunchKernelGGL(k_sched_seed, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, n, remaining, frontier, level, state, level_end);
     auto peel = [&](int lvl) {
         switch (K) {
-        case 1: hipLaunchKernelGGL(k_sched_peel<1>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
-        case 2: hipLaunchKernelGGL(k_sched_peel<2>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
-        case 3: hipLaunchKernelGGL(k_sched_peel<3>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
-        case 4: hipLaunchKernelGGL(k_sched_peel<4>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
-        case 5: hipLaunchKernelGGL(k_sched_peel<5>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
-        case 6: hipLaunchKernelGGL(k_sched_peel<6>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
-        case 7: hipLaunchKernelGGL(k_sched_peel<7>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
-        default: hipLaunchKernelGGL(k_sched_peel<8>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, need, succ, cnt, frontier, level, state, level_end); break;
+        case 1: hipLaunchKernelGGL(k_sched_peel<1>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, succ, remaining, frontier, level, state, level_end); break;
+        case 2: hipLaunchKernelGGL(k_sched_peel<2>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, succ, remaining, frontier, level, state, level_end); break;
+        case 3: hipLaunchKernelGGL(k_sched_peel<3>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, succ, remaining, frontier, level, state, level_end); break;
+        case 4: hipLaunchKernelGGL(k_sched_peel<4>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, succ, remaining, frontier, level, state, level_end); break;
+        case 5: hipLaunchKernelGGL(k_sched_peel<5>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, succ, remaining, frontier, level, state, level_end); break;
+        case 6: hipLaunchKernelGGL(k_sched_peel<6>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, succ, remaining, frontier, level, state, level_end); break;
+        case 7: hipLaunchKernelGGL(k_sched_peel<7>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, succ, remaining, frontier, level, state, level_end); break;
+        default: hipLaunchKernelGGL(k_sched_peel<8>, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, lvl, succ, remaining, frontier, level, state, level_end); break;
         }
     };
 
@@ -336,14 +337,14 @@ long device_schedule(const SchedColumns &in, int *order_out, std::vector<long> &
     // looks at the state between phases: how far the levels got, and whether every unit has been placed
     auto chain = [&](int lvl, int max_levels) {
         switch (K) {
-        case 1: hipLaunchKernelGGL(k_sched_peel_chain<1>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
-        case 2: hipLaunchKernelGGL(k_sched_peel_chain<2>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
-        case 3: hipLaunchKernelGGL(k_sched_peel_chain<3>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
-        case 4: hipLaunchKernelGGL(k_sched_peel_chain<4>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
-        case 5: hipLaunchKernelGGL(k_sched_peel_chain<5>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
-        case 6: hipLaunchKernelGGL(k_sched_peel_chain<6>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
-        case 7: hipLaunchKernelGGL(k_sched_peel_chain<7>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
-        default: hipLaunchKernelGGL(k_sched_peel_chain<8>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, need, succ, cnt, frontier, level, state, level_end); break;
+        case 1: hipLaunchKernelGGL(k_sched_peel_chain<1>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, succ, remaining, frontier, level, state, level_end); break;
+        case 2: hipLaunchKernelGGL(k_sched_peel_chain<2>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, succ, remaining, frontier, level, state, level_end); break;
+        case 3: hipLaunchKernelGGL(k_sched_peel_chain<3>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, succ, remaining, frontier, level, state, level_end); break;
+        case 4: hipLaunchKernelGGL(k_sched_peel_chain<4>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, succ, remaining, frontier, level, state, level_end); break;
+        case 5: hipLaunchKernelGGL(k_sched_peel_chain<5>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, succ, remaining, frontier, level, state, level_end); break;
+        case 6: hipLaunchKernelGGL(k_sched_peel_chain<6>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, succ, remaining, frontier, level, state, level_end); break;
+        case 7: hipLaunchKernelGGL(k_sched_peel_chain<7>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, succ, remaining, frontier, level, state, level_end); break;
+        default: hipLaunchKernelGGL(k_sched_peel_chain<8>, dim3(1), dim3(PEEL_THREADS), 0, st, lvl, max_levels, succ, remaining, frontier, level, state, level_end); break;
         }
     };
     unsigned host_state[ST_WORDS];
