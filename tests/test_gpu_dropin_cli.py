@@ -82,3 +82,48 @@ def test_cli_pairwise_rank_generator(tmp_path):
     ref, amd = _run_both(tmp_path, conf, lambda p: D.write_ugroup_buffer(p, blocks), 3)
     for a, b in zip(ref, amd):
         assert a == b
+
+
+def _build_bulk(tmp_path):
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "svdf_train_bulk")
+    subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "integration", "svdf_train_bulk.c"), "-o", exe, "-L", os.path.join(root, "svdfeature_amd"),
+                           "-lsvdfeature_amd", "-Wl,-rpath," + os.path.join(root, "svdfeature_amd"), "-Wl,-rpath,/opt/rocm/lib"])
+    return exe
+
+
+@need_cli
+@pytest.mark.parametrize("shape", ["basicmf", "implicit", "rank"])
+def test_bulk_round_loop_in_plain_c_writes_the_reference_models(shape, tmp_path):
+    """The patched round loop of INTEGRATION.md as a plain-C program (integration/svdf_train_bulk.c): whole passes through
+    svdf_dataset_from_buffer_file / svdf_dataset_from_rank_buffer_file instead of one virtual call per instance, driven by the
+    reference's config file -- byte-identical NNNN.model files to the unmodified reference CLI for basicMF, implicit feedback
+    (user-group buffer) and rank-pair input (input_type = 2, pairs drawn on the device from the same rand() stream)."""
+    exe = _build_bulk(tmp_path)
+    if shape == "basicmf":
+        base, _ = cases.ml100k()
+        conf, make, rounds = cases.BASICMF_CONF, (lambda p: D.write_csr_buffer(p, base)), 3
+    elif shape == "implicit":
+        blocks = cases.user_blocks(300, 943, 1682, 1682, 5, max_rows=9, max_fb=12, split_every=5)
+        conf = cases.conf_with(cases.BASICMF_CONF, format_type=1, num_ufeedback=1682, wd_ufeedback=0.004, num_factor=32)
+        make, rounds = (lambda p: D.write_ugroup_buffer(p, blocks)), 3
+    else:
+        blocks = cases.user_blocks(200, 943, 1682, 1682, 8, max_rows=10, max_fb=4, binary_label=True)
+        for b in blocks:
+            b.index_ufeedback = np.zeros(0, np.uint32)
+            b.value_ufeedback = np.zeros(0, np.float32)
+        conf = [(k, v) for k, v in cases.conf_with(cases.BASICMF_CONF, format_type=1, num_ufeedback=1682, wd_ufeedback=0.004,
+                                                   active_type=3, no_user_bias=1, input_type=2, num_factor=16) if k != "base_score"]
+        make, rounds = (lambda p: D.write_ugroup_buffer(p, blocks)), 3
+    outs = []
+    for name, cli in (("ref", REF_CLI), ("bulk", exe)):
+        d = tmp_path / name
+        d.mkdir()
+        make(str(d / "train.buffer"))
+        _write_conf(str(d / "run.conf"), conf + [("buffer_feature", "train.buffer"), ("model_out_folder", "./")])
+        p = subprocess.run([cli, "run.conf", "num_round=%d" % rounds, "silent=1"], cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()
+        outs.append([open(str(d / ("%04d.model" % r)), "rb").read() for r in range(rounds + 1)])
+    for r, (a, b) in enumerate(zip(*outs)):
+        assert a == b, "round %d model differs" % r
