@@ -32,13 +32,18 @@ conf = os.path.join(tmp, "run.conf")
 with open(conf, "w") as f:
     f.write("base_score = 3\nlearning_rate = 0.005\nwd_item = 0.004\nwd_user = 0.004\nnum_item = %d\nnum_user = %d\nnum_global = 0\n"
             "num_factor = %d\nactive_type = 0\nbuffer_feature = \"%s\"\nmodel_out_folder = \"./\"\n" % (NI, NU, K, buf))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+bulk = os.path.join(tmp, "svdf_train_bulk")   # the patched round loop in plain C (integration/svdf_train_bulk.c): whole passes
+subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-w", "-I", os.path.join(ROOT, "include"),
+                       os.path.join(ROOT, "integration", "svdf_train_bulk.c"), "-o", bulk, "-L", os.path.join(ROOT, "svdfeature_amd"),
+                       "-lsvdfeature_amd", "-Wl,-rpath," + os.path.join(ROOT, "svdfeature_amd"), "-Wl,-rpath,/opt/rocm/lib"])
 res = {}
-for name in ("svd_feature_amd", "svd_feature"):
+for name in ("svdf_train_bulk", "svd_feature_amd", "svd_feature"):
     times = {}
     for rounds in (0, 2):
         d = os.path.join(tmp, "%s_%d" % (name, rounds)); os.makedirs(d)
         t0 = time.time()
-        p = subprocess.run([os.path.join(REFDIR, name), conf, "num_round=%d" % rounds, "silent=1"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+        p = subprocess.run([bulk if name == "svdf_train_bulk" else os.path.join(REFDIR, name), conf, "num_round=%d" % rounds, "silent=1"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                            env=dict(os.environ, SVDF_PROFILE="1"))
         times[rounds] = time.time() - t0
         if rounds: print(p.stdout.decode()[-300:].strip(), flush=True)
@@ -48,4 +53,7 @@ for name in ("svd_feature_amd", "svd_feature"):
     print(name, json.dumps(res[name]), flush=True)
 a = open(os.path.join(tmp, "svd_feature_amd_2", "0002.model"), "rb").read()
 b = open(os.path.join(tmp, "svd_feature_2", "0002.model"), "rb").read()
+c = open(os.path.join(tmp, "svdf_train_bulk_2", "0002.model"), "rb").read()
+print("bulk loop: models byte-identical to the reference CLI's:", c == b, " %.1fx the reference CLI end to end (model save every round included)"
+      % (res["svdf_train_bulk"]["inst_per_s"] / res["svd_feature"]["inst_per_s"]))
 print("models after 2 rounds byte-identical:", a == b, " speedup end-to-end: %.1fx" % (res["svd_feature_amd"]["inst_per_s"] / res["svd_feature"]["inst_per_s"]))
