@@ -123,3 +123,41 @@ def test_reference_cli_trains_on_two_ranks_from_its_config_file(tmp_path):
         rm[name] = cases.rmse(t.predict_batch(test), test.row_label)
     assert abs(rm["ref"] - rm["amd2"]) <= 1e-4, rm
     assert open(models["ref"], "rb").read() != open(models["amd2"], "rb").read()   # window-synchronous, not sequential
+
+
+def test_virtual_ranks_with_global_features_and_ragged_rows():
+    """instances with global features and several user / item entries on an amd:gpus handle: a row follows its FIRST user id,
+    rows without a user entry go to rank 0, g_bias travels with the item side -- against the same algorithm run by hand with
+    one single-GPU trainer per rank (explicit sharding, explicit delta sum)."""
+    nu, ni, ng, n, world, windows = 300, 120, 6, 6000, 3, 3
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=20, wd_global=0.002)
+    d = cases.sparse_feature_rows(n, nu, ni, ng, seed=4)
+    t = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows)])
+    t.update_batch(d)
+    t.finish_round()
+    # by hand
+    ranks = [_ready(conf) for _ in range(world)]
+    first_user = np.array([d.feat_index[d.row_ptr[3 * r + 1]] if d.row_ptr[3 * r + 2] > d.row_ptr[3 * r + 1] else 0 for r in range(n)])
+    owner = np.where(np.array([d.row_ptr[3 * r + 2] > d.row_ptr[3 * r + 1] for r in range(n)]), first_user % world, 0)
+    names = ("W_item", "i_bias", "g_bias")
+    for w in range(windows):
+        lo, hi = w * (n // windows), (w + 1) * (n // windows)
+        snaps = [{v: x.view(v).copy() for v in names} for x in ranks]
+        for rk, x in enumerate(ranks):
+            rows = [r for r in range(lo, hi) if owner[r] == rk]
+            if rows:
+                x.update_batch(sa.CSRData.concat([d.slice_rows(r, r + 1) for r in rows]))
+            x.finish_round()
+        for v in names:
+            total = None
+            for rk, x in enumerate(ranks):
+                dv = x.view(v) - snaps[rk][v]
+                total = dv if total is None else total + dv
+            for rk, x in enumerate(ranks):
+                x.set_view(v, snaps[rk][v] + total)
+    for v in names:
+        np.testing.assert_array_equal(t.view(v).view(np.uint32), ranks[0].view(v).view(np.uint32))
+    wu = t.view("W_user")
+    for rk in range(world):
+        own = (np.arange(nu) % world) == rk
+        np.testing.assert_array_equal(wu[own].view(np.uint32), ranks[rk].view("W_user")[own].view(np.uint32))

@@ -115,3 +115,38 @@ def test_eval_dataset_matches_the_reference_accumulator(kind):
         ref = oracle.sum_sq_err(pred, labels, scale)
         assert cnt == len(labels)
         assert abs(ss - ref) <= 1e-12 * ref, (ss, ref)
+
+
+def test_ranker_edge_cases_match_the_oracle(tmp_path):
+    """all candidates banned but one, a positive that is also the only ranked candidate, special samples overriding one another,
+    candidates added between user sections, a section without positives, empty feature lines"""
+    path, extra, (nu, ni, ng) = trained_model(str(tmp_path), 0, 12, False)
+    R = sa.CSRData.from_rows
+    items1 = R([(0.0, [], [], [(j % ni, 1.0)]) for j in range(6)])
+    items2 = R([(0.0, [(1, 0.5)], [], [(7, 1.0), (9, 0.25)]), (0.0, [], [], [])])   # the second one has no feature at all
+    secs = [
+        R([(2.0, [], [(3, 1.0)], []), (-1.0, [], [(0, 1), (1, 1), (2, 1), (3, 1), (4, 1)], []), (1.0, [], [(5, 1.0)], []), (4.0, [], [], [])]),
+        R([(2.0, [], [], []), (1.0, [], [(2, 1.0), (4, 1.0)], []), (3.0, [(0, 1.0)], [(2, 1.0)], [(1, 0.5)]), (3.0, [], [(2, 1.0)], []), (4.0, [], [], [])]),
+        R([(2.0, [], [(5, 1.0), (6, 0.5)], []), (4.0, [], [], [])]),
+    ]
+    outs = []
+    for mk in (lambda: oracle.OracleRanker("port", 0, 0), lambda: sa.Ranker(0, 0)):
+        r = mk()
+        r.load_model(path)
+        r.init_ranker(8)
+        res = [r.process_rows(items1), r.process_rows(secs[0]), r.process_rows(secs[1]), r.process_rows(items2), r.process_rows(secs[2]),
+               r.process_rows(secs[1])]
+        outs.append(np.concatenate(res))
+    np.testing.assert_array_equal(outs[0], outs[1])
+    assert outs[0].size == 1 + 2 + 0 + 2
+    g = sa.Ranker(0, 0)
+    g.set_param("top_k", "5")
+    g.load_model(path)
+    g.init_ranker(3)
+    g.process_rows(R([(0.0, [], [], [(1, 1.0)]), (0.0, [], [], [(2, 1.0)])]))
+    with pytest.raises(sa.SvdfError, match="k can not exceed candidate size"):
+        g.process_rows(R([(2.0, [], [(1, 1.0)], []), (4.0, [], [], [])]))
+    with pytest.raises(sa.SvdfError, match="item instance exceed specified item set size"):
+        g.process_rows(R([(0.0, [], [], [(1, 1.0)]), (0.0, [], [], [(2, 1.0)])]))
+    with pytest.raises(sa.SvdfError, match="sample item index exceed bound"):
+        g.process_rows(R([(2.0, [], [(1, 1.0)], []), (1.0, [], [(7, 1.0)], [])]))
