@@ -480,12 +480,20 @@ class Ranker {
     bool init_end_ = false, user_open_ = false;
     HostCSR items_, spec_;
     std::vector<int> spec_idx_, pos_item_;
+    std::vector<int> tagged_, dev_tagged_;   // candidates tagged in the open section / in the section the device's tag array reflects
+    long n_banned_ = 0;
+    unsigned *pin_ = nullptr, *back_ = nullptr;   // pinned staging (one upload per section) and readback
+    size_t pin_words_ = 0, back_words_ = 0;
+    DevBuf<unsigned> d_stage_;
+    unsigned *readback(size_t words);
     std::vector<signed char> tag_;
     std::vector<unsigned> user_idx_;
     std::vector<float> user_val_, host_score_;
-    DevBuf<float> d_ifactors_, d_ibias_, d_score_, d_tu_, d_fb_, w_label_, w_value_, w_uval_, w_fbval_, s_label_, s_value_;
+    DevBuf<float> d_ifactors_, d_ift_, d_ps_, d_ibias_, d_score_, d_tu_, d_fb_, w_label_, w_value_, w_uval_, w_fbval_, s_label_, s_value_;
     DevBuf<int> w_ptr_, s_ptr_, s_idx_, d_pos_, d_cnt_;
-    DevBuf<unsigned> w_index_, w_uidx_, w_fbidx_, s_index_;
+    DevBuf<unsigned> w_index_, w_uidx_, w_fbidx_, s_index_, d_keys_, d_vals_, d_flag_;
+    void *sort_tmp_ = nullptr;
+    size_t sort_tmp_bytes_ = 0;
     DevBuf<signed char> d_tag_;
     int64_t n_sections_ = 0, n_host_sorts_ = 0;
     void stage(HostCSR &dst, int ng, int nu, int ni, const unsigned *index, const float *value);

@@ -279,6 +279,19 @@ void device_gather_f32(const float *src, const int *order, float *dst, long n, h
     if (n > 0) hipLaunchKernelGGL(k_gather<float>, dim3(grid_for_n(n)), dim3(256), 0, st, src, order, dst, n);
 }
 
+void device_sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, unsigned *vals_out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st) {
+    if (n <= 0) return;
+    size_t need = 0;
+    SCHK(rocprim::radix_sort_pairs(nullptr, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, 32u, st));
+    if (need > *tmp_bytes) {
+        if (*tmp) (void)hipFree(*tmp);
+        *tmp = nullptr;
+        SCHK(hipMalloc(tmp, need));
+        *tmp_bytes = need;
+    }
+    SCHK(rocprim::radix_sort_pairs(*tmp, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, 32u, st));
+}
+
 // See svdf_kernels.h.  Returns the number of levels; throws std::runtime_error with the reference's bound messages.
 long device_schedule(const SchedColumns &in, int *order_out, std::vector<long> &level_ptr, long *max_level_size, hipStream_t st) {
     const long n = in.n;

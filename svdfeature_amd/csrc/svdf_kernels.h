@@ -52,11 +52,18 @@ void launch_delta_add(float *cur, const float *snap, const float *delta, long n,
 // ---- ranker (svdf_k_rank.hip): SVDFeatureRanker's prepare_ifactor / proc_user / proc_spec / proc_rank, and the evaluator's sum
 void launch_rank_items(const DevParams &P, const DevCSR &D, long first, long n, float *ifactors, float *ibias, hipStream_t st);
 void launch_rank_feedback(const DevParams &P, const unsigned *fidx, const float *fval, int nfb, float *fb_out, hipStream_t st);
-void launch_rank_user(const DevParams &P, const unsigned *uidx, const float *uval, int nu, const float *fb_in, float *tu_out, hipStream_t st);
+struct RankSection { int nu, npos, nprev, nnew; };   // words staged per ranker section: uidx[nu] uval[nu] pos[npos] prev[nprev] new_idx[nnew] new_tag[nnew]
+void launch_rank_user(const DevParams &P, const unsigned *stage, const RankSection &S, const float *fb_in, float *tu_out, signed char *tag, int *cnt,
+                      unsigned *flag, long cap, const float *ifT, const float *ibias, float *pos_score, hipStream_t st);
 void launch_rank_spec(const DevParams &P, const DevCSR &D, long n, const int *spec_idx, const float *tu, float *item_score, hipStream_t st);
-void launch_rank_score(const DevParams &P, long n, const float *tu, const float *ifactors, const float *ibias, const signed char *tag,
-                       float *item_score, hipStream_t st);
+void launch_rank_transpose(const DevParams &P, long first, long n, long cap, const float *ifactors, float *ifT, hipStream_t st);
+// what the scoring pass does besides the scores: 1 = count the positives' rank positions, 2 = emit the top_k sort keys
+struct RankFused { int mode; const int *pos_item; const float *pos_score; int npos; int *greater, *ties; unsigned *keys, *vals, *flag; };
+void launch_rank_score(const DevParams &P, long n, long cap, const float *tu, const float *ifT, const float *ibias, const signed char *tag,
+                       float *item_score, int fresh, const RankFused &F, hipStream_t st);
 void launch_rank_positions(long n, const float *score, const signed char *tag, const int *pos_item, int npos, int *greater, int *ties, hipStream_t st);
+// ascending radix sort of (key, value) pairs (svdf_k_sched.hip, rocPRIM); tmp is grown as needed
+void device_sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, unsigned *vals_out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st);
 int sqerr_partials_grid(long n);
 void launch_sqerr_partials(const float *pred, const float *label, long n, float scale, double *partials, hipStream_t st);
 // ---- rank-pair sampling on the device (svdf_k_sample.hip)

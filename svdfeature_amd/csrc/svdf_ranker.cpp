@@ -26,7 +26,19 @@ namespace svdf {
 static inline void rcheck(bool ok, const char *msg) { if (!ok) fail(msg); }
 
 Ranker::Ranker(TypeParam mtype, int device) : mtype_(mtype), eng_(new Engine(TypeParam{mtype.format_type, mtype.active_type, 0, 0}, device)) {}
-Ranker::~Ranker() {}
+Ranker::~Ranker() {
+    if (sort_tmp_) (void)hipFree(sort_tmp_);
+    if (pin_) (void)hipHostFree(pin_);
+    if (back_) (void)hipHostFree(back_);
+}
+unsigned *Ranker::readback(size_t words) {   // pinned landing area for the section's (small) results
+    if (words > back_words_) {
+        if (back_) (void)hipHostFree(back_);
+        back_words_ = 2 * words + 256;
+        RCHECK(hipHostMalloc(reinterpret_cast<void **>(&back_), back_words_ * sizeof(unsigned), hipHostMallocDefault));
+    }
+    return back_;
+}
 
 void Ranker::set_param(const char *name, const char *val) {   // :656-660
     if (!strcmp(name, "feature_user") || !strcmp(name, "feature_item")) eng_->set_param(name, val);
@@ -41,13 +53,18 @@ void Ranker::init_ranker(int num_item_set) {                   // :666-685
     items_on_device_ = 0;
     const size_t pitch = (size_t)eng_->pitch_;
     d_ifactors_.reserve((size_t)std::max(num_item_set, 1) * pitch);
+    d_ift_.reserve((size_t)std::max(num_item_set, 1) * pitch);   // the same matrix chunk-major, what the scoring pass streams
     d_ibias_.reserve((size_t)std::max(num_item_set, 1));
     d_score_.reserve((size_t)std::max(num_item_set, 1));
     d_tag_.reserve((size_t)std::max(num_item_set, 1));
     d_tu_.reserve(pitch + 4);
     d_fb_.reserve(pitch + 4);
     RCHECK(hipMemsetAsync(d_fb_.p, 0, (pitch + 4) * sizeof(float), eng_->stream_));   // tmp_ufeedback before the first block
+    RCHECK(hipMemsetAsync(d_tag_.p, 0, (size_t)std::max(num_item_set, 1), eng_->stream_));
     tag_.assign((size_t)num_item_set, 0);
+    tagged_.clear();
+    dev_tagged_.clear();
+    n_banned_ = 0;
     items_.clear();
     init_end_ = true;
     user_open_ = false;
@@ -84,7 +101,9 @@ long Ranker::process(float label, int ng, int nu, int ni, const unsigned *index,
         user_idx_.assign(iu, iu + nu);
         user_val_.assign(value + ng, value + ng + nu);
         pos_item_.clear();
-        std::fill(tag_.begin(), tag_.begin() + num_item_processed_, 0);
+        for (int idx : tagged_) tag_[(size_t)idx] = 0;   // every candidate is back to "ranked, not positive" (:727)
+        tagged_.clear();
+        n_banned_ = 0;
         spec_.clear();
         spec_idx_.clear();
         user_open_ = true;
@@ -96,7 +115,8 @@ long Ranker::process(float label, int ng, int nu, int ni, const unsigned *index,
             rcheck(idx < num_item_processed_, "sample item index exceed bound");
             rcheck(tag_[(size_t)idx] == 0, "each pos sample item can not occur in baned sample list");
             tag_[(size_t)idx] = (signed char)tag;
-            if (tag == 1) pos_item_.push_back(idx);
+            tagged_.push_back(idx);
+            if (tag == 1) pos_item_.push_back(idx); else n_banned_++;
         }
         return 0;
     }
@@ -156,40 +176,78 @@ long Ranker::rank(int *out, long cap) {
         w_value_.upload(items_.feat_value.data(), items_.feat_value.size(), st);
         DevCSR D{w_label_.p, w_ptr_.p, w_index_.p, w_value_.p};
         launch_rank_items(P, D, items_on_device_, n, d_ifactors_.p, d_ibias_.p, st);
+        launch_rank_transpose(P, items_on_device_, n, (long)std::max(num_item_set_, 1), d_ifactors_.p, d_ift_.p, st);
         RCHECK(hipStreamSynchronize(st));
         items_on_device_ = n;
     }
-    w_uidx_.upload(user_idx_.data(), user_idx_.size(), st);
-    w_uval_.upload(user_val_.data(), user_val_.size(), st);
-    launch_rank_user(P, w_uidx_.p, w_uval_.p, (int)user_idx_.size(), eng_->user_group() ? d_fb_.p : nullptr, d_tu_.p, st);
+    // special samples: only the last one per candidate counts (an assignment, :746)
+    HostCSR live;
+    std::vector<int> live_idx;
+    for (size_t j = 0; j < spec_idx_.size(); j++) {
+        if (spec_idx_[j] < 0) continue;
+        const int *p = &spec_.row_ptr[3 * j];
+        stage(live, p[1] - p[0], p[2] - p[1], p[3] - p[2], spec_.feat_index.data() + p[0], spec_.feat_value.data() + p[0]);
+        live_idx.push_back(spec_idx_[j]);
+    }
+    const bool fresh = live_idx.empty();   // no special sample this section: k_rank_score writes 0 + (bias + dot) without reading item_score
+    const long cap_items = (long)std::max(num_item_set_, 1);
+    // one pinned upload per section: the user's rows, the positives, and the tag changes against the device's tag array
+    const int nu = (int)user_idx_.size(), npos = (int)pos_item_.size();
+    const RankSection S{nu, npos, (int)dev_tagged_.size(), (int)tagged_.size()};
+    const size_t words = (size_t)2 * nu + npos + S.nprev + 2 * (size_t)S.nnew;
+    if (words + 4 > pin_words_) {
+        RCHECK(hipStreamSynchronize(st));
+        if (pin_) (void)hipHostFree(pin_);
+        pin_words_ = 2 * (words + 4) + 1024;
+        RCHECK(hipHostMalloc(reinterpret_cast<void **>(&pin_), pin_words_ * sizeof(unsigned), hipHostMallocDefault));
+    }
+    d_stage_.reserve(pin_words_);
+    {
+        unsigned *w = pin_;
+        memcpy(w, user_idx_.data(), (size_t)nu * 4); w += nu;
+        memcpy(w, user_val_.data(), (size_t)nu * 4); w += nu;
+        memcpy(w, pos_item_.data(), (size_t)npos * 4); w += npos;
+        memcpy(w, dev_tagged_.data(), (size_t)S.nprev * 4); w += S.nprev;
+        memcpy(w, tagged_.data(), (size_t)S.nnew * 4); w += S.nnew;
+        for (int idx : tagged_) *w++ = (unsigned)(int)tag_[(size_t)idx];
+    }
+    if (words) RCHECK(hipMemcpyAsync(d_stage_.p, pin_, words * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    d_cnt_.reserve((size_t)2 * std::max(npos, 1));
+    d_flag_.reserve(1);
+    d_ps_.reserve((size_t)std::max(npos, 1));
+    // positions mode without special samples: the positives' scores are known before the scoring pass, which then counts
+    const bool fused_positions = top_k_ <= 0 && fresh && npos > 0 && n > 0;
+    launch_rank_user(P, d_stage_.p, S, eng_->user_group() ? d_fb_.p : nullptr, d_tu_.p, d_tag_.p, d_cnt_.p, d_flag_.p, cap_items, d_ift_.p, d_ibias_.p,
+                     fused_positions ? d_ps_.p : nullptr, st);
+    dev_tagged_ = tagged_;
+    const int *d_pos = reinterpret_cast<const int *>(d_stage_.p + 2 * nu);
     if (n == 0) {
         rcheck(top_k_ <= 0, "k can not exceed candidate size");
+        RCHECK(hipStreamSynchronize(st));
         return 0;
     }
-    RCHECK(hipMemsetAsync(d_score_.p, 0, (size_t)n * sizeof(float), st));   // item_score = 0 (:726)
-    RCHECK(hipMemcpyAsync(d_tag_.p, tag_.data(), (size_t)n, hipMemcpyHostToDevice, st));
-    // special samples: only the last one per candidate counts (an assignment, :746)
-    {
-        HostCSR live;
-        std::vector<int> live_idx;
-        for (size_t j = 0; j < spec_idx_.size(); j++) {
-            if (spec_idx_[j] < 0) continue;
-            const int *p = &spec_.row_ptr[3 * j];
-            stage(live, p[1] - p[0], p[2] - p[1], p[3] - p[2], spec_.feat_index.data() + p[0], spec_.feat_value.data() + p[0]);
-            live_idx.push_back(spec_idx_[j]);
-        }
-        if (!live_idx.empty()) {
-            s_label_.upload(live.row_label.data(), live.row_label.size(), st);
-            s_ptr_.upload(live.row_ptr.data(), live.row_ptr.size(), st);
-            s_index_.upload(live.feat_index.data(), live.feat_index.size(), st);
-            s_value_.upload(live.feat_value.data(), live.feat_value.size(), st);
-            s_idx_.upload(live_idx.data(), live_idx.size(), st);
-            DevCSR D{s_label_.p, s_ptr_.p, s_index_.p, s_value_.p};
-            launch_rank_spec(P, D, (long)live_idx.size(), s_idx_.p, d_tu_.p, d_score_.p, st);
-            RCHECK(hipStreamSynchronize(st));
-        }
+    if (!fresh) {
+        s_label_.upload(live.row_label.data(), live.row_label.size(), st);
+        s_ptr_.upload(live.row_ptr.data(), live.row_ptr.size(), st);
+        s_index_.upload(live.feat_index.data(), live.feat_index.size(), st);
+        s_value_.upload(live.feat_value.data(), live.feat_value.size(), st);
+        s_idx_.upload(live_idx.data(), live_idx.size(), st);
+        DevCSR D{s_label_.p, s_ptr_.p, s_index_.p, s_value_.p};
+        RCHECK(hipMemsetAsync(d_score_.p, 0, (size_t)n * sizeof(float), st));   // item_score = 0 (:726)
+        launch_rank_spec(P, D, (long)live_idx.size(), s_idx_.p, d_tu_.p, d_score_.p, st);
+        RCHECK(hipStreamSynchronize(st));   // the host staging vectors go out of use
     }
-    launch_rank_score(P, n, d_tu_.p, d_ifactors_.p, d_ibias_.p, d_tag_.p, d_score_.p, st);
+    const long nranked = n - n_banned_;
+    RankFused F{0, d_pos, d_ps_.p, npos, d_cnt_.p, d_cnt_.p + npos, nullptr, nullptr, d_flag_.p};
+    if (top_k_ > 0) {
+        rcheck(nranked >= (long)top_k_, "k can not exceed candidate size");
+        d_keys_.reserve((size_t)2 * n);
+        d_vals_.reserve((size_t)2 * n);
+        F.mode = 2; F.keys = d_keys_.p; F.vals = d_vals_.p;
+    } else if (fused_positions) {
+        F.mode = 1;
+    }
+    launch_rank_score(P, n, cap_items, d_tu_.p, d_ift_.p, d_ibias_.p, d_tag_.p, d_score_.p, fresh ? 1 : 0, F, st);
     n_sections_++;
 
     auto full_sort = [&](std::vector<RankEntry> &entry) {   // the reference's own ordering step (:767)
@@ -204,38 +262,27 @@ long Ranker::rank(int *out, long cap) {
     std::vector<RankEntry> entry;
     long nout = 0;
     if (top_k_ > 0) {
-        // top_k: threshold selection on the host copy of the scores, exact std::sort order only if scores tie inside the prefix
-        host_score_.resize((size_t)n);
-        RCHECK(hipMemcpyAsync(host_score_.data(), d_score_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+        // top_k: radix sort of order-preserving score keys on the device, only the first top_k+1 (key, candidate) pairs come
+        // back; the reference's std::sort (:767) decides only when scores tie inside that prefix or a score is NaN
+        device_sort_pairs_u32(d_keys_.p, d_keys_.p + n, d_vals_.p, d_vals_.p + n, n, &sort_tmp_, &sort_tmp_bytes_, st);
+        const size_t take = (size_t)std::min<long>(nranked, (long)top_k_ + 1);
+        unsigned *back = readback(2 * take + 1);
+        unsigned *hk = back, *hv = back + take;
+        RCHECK(hipMemcpyAsync(hk, d_keys_.p + n, take * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        RCHECK(hipMemcpyAsync(hv, d_vals_.p + n, take * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        RCHECK(hipMemcpyAsync(back + 2 * take, d_flag_.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
         RCHECK(hipStreamSynchronize(st));
-        for (long i = 0; i < n; i++)
-            if (tag_[(size_t)i] != -1) entry.push_back(RankEntry{(int)i, host_score_[(size_t)i]});
-        rcheck(entry.size() >= (size_t)top_k_, "k can not exceed candidate size");
-        bool exact = true;
-        for (const RankEntry &e : entry) if (std::isnan(e.score)) exact = false;
+        bool exact = back[2 * take] == 0;
+        for (size_t j = 0; j + 1 < take; j++) if (hk[j] == hk[j + 1]) exact = false;
         std::vector<RankEntry> head;
-        if (exact) {
-            std::vector<RankEntry> work(entry);
-            const size_t kk = std::min(work.size() - 1, (size_t)top_k_);   // one past the prefix when there is one
-            std::nth_element(work.begin(), work.begin() + (long)kk, work.end());
-            const float thr = work[kk].score;
-            for (const RankEntry &e : entry) if (e.score >= thr) head.push_back(e);
-            std::sort(head.begin(), head.end());
-            for (size_t j = 0; j + 1 < head.size() && j < (size_t)top_k_; j++)
-                if (head[j].score == head[j + 1].score) exact = false;
-            if (head.size() < (size_t)top_k_) exact = false;
-        }
-        if (!exact) { std::sort(entry.begin(), entry.end()); head = entry; n_host_sorts_++; }
+        if (exact) for (int k = 0; k < top_k_; k++) head.push_back(RankEntry{(int)hv[(size_t)k], 0.0f});
+        if (!exact) { full_sort(entry); head = entry; n_host_sorts_++; }
         for (int k = 0; k < top_k_; k++) { if (nout < cap && out) out[nout] = head[(size_t)k].iid; nout++; }
     } else {
-        const int npos = (int)pos_item_.size();
         if (npos == 0) { RCHECK(hipStreamSynchronize(st)); return 0; }
-        d_pos_.upload(pos_item_.data(), pos_item_.size(), st);
-        d_cnt_.reserve((size_t)2 * npos);
-        RCHECK(hipMemsetAsync(d_cnt_.p, 0, (size_t)2 * npos * sizeof(int), st));
-        launch_rank_positions(n, d_score_.p, d_tag_.p, d_pos_.p, npos, d_cnt_.p, d_cnt_.p + npos, st);
-        std::vector<int> cnt((size_t)2 * npos);
-        RCHECK(hipMemcpyAsync(cnt.data(), d_cnt_.p, cnt.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+        if (!fused_positions) launch_rank_positions(n, d_score_.p, d_tag_.p, d_pos, npos, d_cnt_.p, d_cnt_.p + npos, st);
+        const int *cnt = reinterpret_cast<const int *>(readback((size_t)2 * npos));
+        RCHECK(hipMemcpyAsync(const_cast<int *>(cnt), d_cnt_.p, (size_t)2 * npos * sizeof(int), hipMemcpyDeviceToHost, st));
         RCHECK(hipStreamSynchronize(st));
         bool ties = false;
         for (int j = 0; j < npos; j++) ties = ties || cnt[(size_t)npos + j] != 0;
