@@ -240,10 +240,16 @@ int svdf_ranker_load_model(svdf_ranker *r, FILE *fi);
 int svdf_ranker_init(svdf_ranker *r, int num_item_set);
 int64_t svdf_ranker_process_csr(svdf_ranker *r, float label, int num_global, int num_ufactor, int num_ifactor, const unsigned *index,
                                 const float *value, int *out, int64_t capacity);
+/* Bulk form: the rank task's loop over a whole CSR input (svd_feature_infer.cpp:347-375: every line of the iterator goes through
+ * process(), results appended) in ONE call.  Same results in the same order as num_row calls of svdf_ranker_process_csr; user
+ * sections are pipelined on the device (up to 8 in flight), so a section costs its enqueue, not a launch + sync round trip. */
+int64_t svdf_ranker_process_rows(svdf_ranker *r, int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index,
+                                 const float *feat_value, int *out, int64_t capacity);
 int64_t svdf_ranker_process_block(svdf_ranker *r, int num_ufeedback, int extend_tag, const unsigned *index_ufeedback,
                                   const float *value_ufeedback, int num_row, const float *row_label, const int *row_ptr,
                                   const unsigned *feat_index, const float *feat_value, int *out, int64_t capacity);
-/* counters: 0 user sections ranked, 1 sections finished by the host sort because scores tied at a requested position */
+/* counters: 0 user sections ranked, 1 sections finished by the host sort because scores tied at a requested position,
+ * 2 positive samples of the open user section (what a PROCESS line would report now when top_k = 0: sizes the output) */
 int64_t svdf_ranker_counter(svdf_ranker *r, int what);
 
 /* ---- libc rand() as a random-access stream (the reference draws rank pairs with rand(), apex-tensor/apex_random.h:42-67;

@@ -212,6 +212,10 @@ int64_t svdf_ranker_process_csr(svdf_ranker *r, float label, int ng, int nu, int
                                 int64_t capacity) {
     SVDF_GUARD(-1, { return (int64_t)r->r->process(label, ng, nu, ni, index, value, out, (long)capacity); })
 }
+int64_t svdf_ranker_process_rows(svdf_ranker *r, int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index,
+                                 const float *feat_value, int *out, int64_t capacity) {
+    SVDF_GUARD(-1, { return (int64_t)r->r->process_rows(num_row, row_label, row_ptr, feat_index, feat_value, out, (long)capacity); })
+}
 int64_t svdf_ranker_process_block(svdf_ranker *r, int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label,
                                   const int *row_ptr, const unsigned *feat_index, const float *feat_value, int *out, int64_t capacity) {
     SVDF_GUARD(-1, { return (int64_t)r->r->process_block(nfb, tag, ifb, vfb, num_row, row_label, row_ptr, feat_index, feat_value, out, (long)capacity); })

@@ -18,6 +18,7 @@
 #include <stdexcept>
 #include <thread>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "svdf_types.h"
@@ -469,9 +470,13 @@ class Ranker {
     void init_ranker(int num_item_set);
     // process(vector<int>&, Elem) / process(vector<int>&, SVDPlusBlock): results appended to out (up to cap), count returned
     long process(float label, int ng, int nu, int ni, const unsigned *index, const float *value, int *out, long cap);
+    // a whole CSR input of the rank task in one call (the loop of svd_feature_infer.cpp:347-375), sections pipelined
+    long process_rows(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value, int *out, long cap);
     long process_block(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label, const int *row_ptr,
                        const unsigned *feat_index, const float *feat_value, int *out, long cap);
-    int64_t counter(int what) const { return what == 0 ? n_sections_ : (what == 1 ? n_host_sorts_ : -1); }
+    int64_t counter(int what) const {
+        return what == 0 ? n_sections_ : (what == 1 ? n_host_sorts_ : (what == 2 ? (int64_t)pos_item_.size() : -1));
+    }
   private:
     TypeParam mtype_;
     std::unique_ptr<Engine> eng_;   // owns the model in HBM, the side tables and the kernel parameter block
@@ -482,16 +487,35 @@ class Ranker {
     std::vector<int> spec_idx_, pos_item_;
     std::vector<int> tagged_, dev_tagged_;   // candidates tagged in the open section / in the section the device's tag array reflects
     long n_banned_ = 0;
-    unsigned *pin_ = nullptr, *back_ = nullptr;   // pinned staging (one upload per section) and readback
-    size_t pin_words_ = 0, back_words_ = 0;
-    DevBuf<unsigned> d_stage_;
-    unsigned *readback(size_t words);
+    // sections in flight (svdf_ranker.cpp): per slot the pinned staging (one upload per section), its device copy, the
+    // section's counters / positives' scores / NaN flag / item_score, the pinned readback and the event behind it
+    static constexpr int RANK_SLOTS = 8;
+    struct RankSlot {
+        unsigned *pin = nullptr, *back = nullptr;
+        size_t pin_words = 0, back_words = 0;
+        DevBuf<unsigned> d_stage, d_flag;
+        DevBuf<int> d_cnt;
+        DevBuf<float> d_ps, d_score;
+        hipEvent_t ev = nullptr;
+    };
+    struct RankPending { int slot = 0, npos = 0, take = 0; long n = 0; std::vector<int> pos_item, banned; };
+    RankSlot slots_[RANK_SLOTS];
+    std::deque<RankPending> pending_;
+    int next_slot_ = 0;
+    bool deferred_ = false;
+    int *out_ptr_ = nullptr;
+    long out_cap_ = 0, out_n_ = 0;
+    void slot_reserve_pin(RankSlot &S, size_t words);
+    void slot_reserve_back(RankSlot &S, size_t words);
+    void enqueue();
+    void resolve();
+    void drain_quietly();
     std::vector<signed char> tag_;
     std::vector<unsigned> user_idx_;
     std::vector<float> user_val_, host_score_;
-    DevBuf<float> d_ifactors_, d_ift_, d_ps_, d_ibias_, d_score_, d_tu_, d_fb_, w_label_, w_value_, w_uval_, w_fbval_, s_label_, s_value_;
-    DevBuf<int> w_ptr_, s_ptr_, s_idx_, d_pos_, d_cnt_;
-    DevBuf<unsigned> w_index_, w_uidx_, w_fbidx_, s_index_, d_keys_, d_vals_, d_flag_;
+    DevBuf<float> d_ifactors_, d_ift_, d_ibias_, d_tu_, d_fb_, w_label_, w_value_, w_uval_, w_fbval_, s_label_, s_value_;
+    DevBuf<int> w_ptr_, s_ptr_, s_idx_;
+    DevBuf<unsigned> w_index_, w_fbidx_, s_index_, d_keys_, d_vals_;
     void *sort_tmp_ = nullptr;
     size_t sort_tmp_bytes_ = 0;
     DevBuf<signed char> d_tag_;

@@ -27,17 +27,13 @@ static inline void rcheck(bool ok, const char *msg) { if (!ok) fail(msg); }
 
 Ranker::Ranker(TypeParam mtype, int device) : mtype_(mtype), eng_(new Engine(TypeParam{mtype.format_type, mtype.active_type, 0, 0}, device)) {}
 Ranker::~Ranker() {
+    (void)hipStreamSynchronize(eng_->stream_);
     if (sort_tmp_) (void)hipFree(sort_tmp_);
-    if (pin_) (void)hipHostFree(pin_);
-    if (back_) (void)hipHostFree(back_);
-}
-unsigned *Ranker::readback(size_t words) {   // pinned landing area for the section's (small) results
-    if (words > back_words_) {
-        if (back_) (void)hipHostFree(back_);
-        back_words_ = 2 * words + 256;
-        RCHECK(hipHostMalloc(reinterpret_cast<void **>(&back_), back_words_ * sizeof(unsigned), hipHostMallocDefault));
+    for (RankSlot &S : slots_) {
+        if (S.pin) (void)hipHostFree(S.pin);
+        if (S.back) (void)hipHostFree(S.back);
+        if (S.ev) (void)hipEventDestroy(S.ev);
     }
-    return back_;
 }
 
 void Ranker::set_param(const char *name, const char *val) {   // :656-660
@@ -55,7 +51,6 @@ void Ranker::init_ranker(int num_item_set) {                   // :666-685
     d_ifactors_.reserve((size_t)std::max(num_item_set, 1) * pitch);
     d_ift_.reserve((size_t)std::max(num_item_set, 1) * pitch);   // the same matrix chunk-major, what the scoring pass streams
     d_ibias_.reserve((size_t)std::max(num_item_set, 1));
-    d_score_.reserve((size_t)std::max(num_item_set, 1));
     d_tag_.reserve((size_t)std::max(num_item_set, 1));
     d_tu_.reserve(pitch + 4);
     d_fb_.reserve(pitch + 4);
@@ -163,7 +158,27 @@ struct RankEntry {   // SVDFeatureRanker::Entry (:617-624)
     bool operator<(const RankEntry &p) const { return score > p.score; }
 };
 
-long Ranker::rank(int *out, long cap) {
+// A PROCESS_TAG line = one section: enqueue() puts its work on the stream (one pinned upload, k_rank_user, the scoring pass, one
+// small readback) into one of RANK_SLOTS slots, resolve() waits for a slot's event and turns the readback into results.
+// process() resolves at once; process_rows() -- a whole input of the rank task (svd_feature_infer.cpp:347-375) in one call --
+// keeps up to RANK_SLOTS sections in flight, so the per-section cost is the enqueue, not a launch + sync round trip.
+void Ranker::slot_reserve_pin(RankSlot &S, size_t words) {
+    if (words + 4 <= S.pin_words) return;
+    if (S.pin) (void)hipHostFree(S.pin);
+    S.pin = nullptr;
+    S.pin_words = 2 * (words + 4) + 1024;
+    RCHECK(hipHostMalloc(reinterpret_cast<void **>(&S.pin), S.pin_words * sizeof(unsigned), hipHostMallocDefault));
+    S.d_stage.reserve(S.pin_words);
+}
+void Ranker::slot_reserve_back(RankSlot &S, size_t words) {
+    if (words <= S.back_words) return;
+    if (S.back) (void)hipHostFree(S.back);
+    S.back = nullptr;
+    S.back_words = 2 * words + 256;
+    RCHECK(hipHostMalloc(reinterpret_cast<void **>(&S.back), S.back_words * sizeof(unsigned), hipHostMallocDefault));
+}
+
+void Ranker::enqueue() {
     rcheck(user_open_, "ranker: PROCESS_TAG without a USER_TAG section");
     const DevParams &P = eng_->params();
     hipStream_t st = eng_->stream_;
@@ -191,19 +206,22 @@ long Ranker::rank(int *out, long cap) {
     }
     const bool fresh = live_idx.empty();   // no special sample this section: k_rank_score writes 0 + (bias + dot) without reading item_score
     const long cap_items = (long)std::max(num_item_set_, 1);
-    // one pinned upload per section: the user's rows, the positives, and the tag changes against the device's tag array
     const int nu = (int)user_idx_.size(), npos = (int)pos_item_.size();
+    const long nranked = n - n_banned_;
+    if (top_k_ > 0) rcheck(nranked >= (long)top_k_, "k can not exceed candidate size");
+
+    if (pending_.size() == RANK_SLOTS) resolve();
+    const int slot = next_slot_;
+    next_slot_ = (next_slot_ + 1) % RANK_SLOTS;
+    RankSlot &L = slots_[slot];
+    if (!L.ev) RCHECK(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
+
+    // one pinned upload per section: the user's rows, the positives, and the tag changes against the device's tag array
     const RankSection S{nu, npos, (int)dev_tagged_.size(), (int)tagged_.size()};
     const size_t words = (size_t)2 * nu + npos + S.nprev + 2 * (size_t)S.nnew;
-    if (words + 4 > pin_words_) {
-        RCHECK(hipStreamSynchronize(st));
-        if (pin_) (void)hipHostFree(pin_);
-        pin_words_ = 2 * (words + 4) + 1024;
-        RCHECK(hipHostMalloc(reinterpret_cast<void **>(&pin_), pin_words_ * sizeof(unsigned), hipHostMallocDefault));
-    }
-    d_stage_.reserve(pin_words_);
+    slot_reserve_pin(L, words);
     {
-        unsigned *w = pin_;
+        unsigned *w = L.pin;
         memcpy(w, user_idx_.data(), (size_t)nu * 4); w += nu;
         memcpy(w, user_val_.data(), (size_t)nu * 4); w += nu;
         memcpy(w, pos_item_.data(), (size_t)npos * 4); w += npos;
@@ -211,92 +229,146 @@ long Ranker::rank(int *out, long cap) {
         memcpy(w, tagged_.data(), (size_t)S.nnew * 4); w += S.nnew;
         for (int idx : tagged_) *w++ = (unsigned)(int)tag_[(size_t)idx];
     }
-    if (words) RCHECK(hipMemcpyAsync(d_stage_.p, pin_, words * sizeof(unsigned), hipMemcpyHostToDevice, st));
-    d_cnt_.reserve((size_t)2 * std::max(npos, 1));
-    d_flag_.reserve(1);
-    d_ps_.reserve((size_t)std::max(npos, 1));
+    if (words) RCHECK(hipMemcpyAsync(L.d_stage.p, L.pin, words * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    L.d_cnt.reserve((size_t)2 * std::max(npos, 1));
+    L.d_flag.reserve(1);
+    L.d_ps.reserve((size_t)std::max(npos, 1));
+    L.d_score.reserve((size_t)cap_items);
     // positions mode without special samples: the positives' scores are known before the scoring pass, which then counts
     const bool fused_positions = top_k_ <= 0 && fresh && npos > 0 && n > 0;
-    launch_rank_user(P, d_stage_.p, S, eng_->user_group() ? d_fb_.p : nullptr, d_tu_.p, d_tag_.p, d_cnt_.p, d_flag_.p, cap_items, d_ift_.p, d_ibias_.p,
-                     fused_positions ? d_ps_.p : nullptr, st);
+    launch_rank_user(P, L.d_stage.p, S, eng_->user_group() ? d_fb_.p : nullptr, d_tu_.p, d_tag_.p, L.d_cnt.p, L.d_flag.p, cap_items, d_ift_.p, d_ibias_.p,
+                     fused_positions ? L.d_ps.p : nullptr, st);
     dev_tagged_ = tagged_;
-    const int *d_pos = reinterpret_cast<const int *>(d_stage_.p + 2 * nu);
-    if (n == 0) {
-        rcheck(top_k_ <= 0, "k can not exceed candidate size");
-        RCHECK(hipStreamSynchronize(st));
-        return 0;
-    }
-    if (!fresh) {
-        s_label_.upload(live.row_label.data(), live.row_label.size(), st);
-        s_ptr_.upload(live.row_ptr.data(), live.row_ptr.size(), st);
-        s_index_.upload(live.feat_index.data(), live.feat_index.size(), st);
-        s_value_.upload(live.feat_value.data(), live.feat_value.size(), st);
-        s_idx_.upload(live_idx.data(), live_idx.size(), st);
-        DevCSR D{s_label_.p, s_ptr_.p, s_index_.p, s_value_.p};
-        RCHECK(hipMemsetAsync(d_score_.p, 0, (size_t)n * sizeof(float), st));   // item_score = 0 (:726)
-        launch_rank_spec(P, D, (long)live_idx.size(), s_idx_.p, d_tu_.p, d_score_.p, st);
-        RCHECK(hipStreamSynchronize(st));   // the host staging vectors go out of use
-    }
-    const long nranked = n - n_banned_;
-    RankFused F{0, d_pos, d_ps_.p, npos, d_cnt_.p, d_cnt_.p + npos, nullptr, nullptr, d_flag_.p};
-    if (top_k_ > 0) {
-        rcheck(nranked >= (long)top_k_, "k can not exceed candidate size");
-        d_keys_.reserve((size_t)2 * n);
-        d_vals_.reserve((size_t)2 * n);
-        F.mode = 2; F.keys = d_keys_.p; F.vals = d_vals_.p;
-    } else if (fused_positions) {
-        F.mode = 1;
-    }
-    launch_rank_score(P, n, cap_items, d_tu_.p, d_ift_.p, d_ibias_.p, d_tag_.p, d_score_.p, fresh ? 1 : 0, F, st);
+    const int *d_pos = reinterpret_cast<const int *>(L.d_stage.p + 2 * nu);
     n_sections_++;
 
+    RankPending Q;
+    Q.slot = slot; Q.n = n; Q.npos = 0; Q.take = 0;
+    if (n > 0) {
+        if (!fresh) {
+            s_label_.upload(live.row_label.data(), live.row_label.size(), st);
+            s_ptr_.upload(live.row_ptr.data(), live.row_ptr.size(), st);
+            s_index_.upload(live.feat_index.data(), live.feat_index.size(), st);
+            s_value_.upload(live.feat_value.data(), live.feat_value.size(), st);
+            s_idx_.upload(live_idx.data(), live_idx.size(), st);
+            DevCSR D{s_label_.p, s_ptr_.p, s_index_.p, s_value_.p};
+            RCHECK(hipMemsetAsync(L.d_score.p, 0, (size_t)n * sizeof(float), st));   // item_score = 0 (:726)
+            launch_rank_spec(P, D, (long)live_idx.size(), s_idx_.p, d_tu_.p, L.d_score.p, st);
+            RCHECK(hipStreamSynchronize(st));   // the host staging vectors go out of use
+        }
+        RankFused F{0, d_pos, L.d_ps.p, npos, L.d_cnt.p, L.d_cnt.p + npos, nullptr, nullptr, L.d_flag.p};
+        if (top_k_ > 0) {
+            d_keys_.reserve((size_t)2 * cap_items);
+            d_vals_.reserve((size_t)2 * cap_items);
+            F.mode = 2; F.keys = d_keys_.p; F.vals = d_vals_.p;
+        } else if (fused_positions) {
+            F.mode = 1;
+        }
+        launch_rank_score(P, n, cap_items, d_tu_.p, d_ift_.p, d_ibias_.p, d_tag_.p, L.d_score.p, fresh ? 1 : 0, F, st);
+        if (top_k_ > 0) {
+            // top_k: radix sort of order-preserving score keys on the device, only the first top_k+1 (key, candidate) pairs come
+            // back; the reference's std::sort (:767) decides only when scores tie inside that prefix or a score is NaN
+            device_sort_pairs_u32(d_keys_.p, d_keys_.p + n, d_vals_.p, d_vals_.p + n, n, &sort_tmp_, &sort_tmp_bytes_, st);
+            const size_t take = (size_t)std::min<long>(nranked, (long)top_k_ + 1);
+            slot_reserve_back(L, 2 * take + 1);
+            RCHECK(hipMemcpyAsync(L.back, d_keys_.p + n, take * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            RCHECK(hipMemcpyAsync(L.back + take, d_vals_.p + n, take * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            RCHECK(hipMemcpyAsync(L.back + 2 * take, L.d_flag.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            Q.take = (int)take;
+        } else if (npos > 0) {
+            if (!fused_positions) launch_rank_positions(n, L.d_score.p, d_tag_.p, d_pos, npos, L.d_cnt.p, L.d_cnt.p + npos, st);
+            slot_reserve_back(L, (size_t)2 * npos);
+            RCHECK(hipMemcpyAsync(L.back, L.d_cnt.p, (size_t)2 * npos * sizeof(int), hipMemcpyDeviceToHost, st));
+            Q.npos = npos;
+        }
+    } else {
+        rcheck(top_k_ <= 0, "k can not exceed candidate size");
+    }
+    RCHECK(hipEventRecord(L.ev, st));
+    if (Q.npos > 0) Q.pos_item = pos_item_;
+    for (int idx : tagged_) if (tag_[(size_t)idx] == -1) Q.banned.push_back(idx);
+    pending_.push_back(std::move(Q));
+}
+
+// oldest section in flight -> its results appended at the output cursor
+void Ranker::resolve() {
+    RankPending Q = std::move(pending_.front());
+    pending_.pop_front();
+    RankSlot &L = slots_[Q.slot];
+    hipStream_t st = eng_->stream_;
+    RCHECK(hipEventSynchronize(L.ev));
+    const long n = Q.n;
+    auto emit = [&](int v) { if (out_n_ < out_cap_ && out_ptr_) out_ptr_[out_n_] = v; out_n_++; };
     auto full_sort = [&](std::vector<RankEntry> &entry) {   // the reference's own ordering step (:767)
         host_score_.resize((size_t)n);
-        RCHECK(hipMemcpyAsync(host_score_.data(), d_score_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+        RCHECK(hipMemcpyAsync(host_score_.data(), L.d_score.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
         RCHECK(hipStreamSynchronize(st));
+        std::vector<char> banned((size_t)n, 0);
+        for (int idx : Q.banned) banned[(size_t)idx] = 1;
         entry.clear();
         for (long i = 0; i < n; i++)
-            if (tag_[(size_t)i] != -1) entry.push_back(RankEntry{(int)i, host_score_[(size_t)i]});
+            if (!banned[(size_t)i]) entry.push_back(RankEntry{(int)i, host_score_[(size_t)i]});
         std::sort(entry.begin(), entry.end());
+        n_host_sorts_++;
     };
     std::vector<RankEntry> entry;
-    long nout = 0;
-    if (top_k_ > 0) {
-        // top_k: radix sort of order-preserving score keys on the device, only the first top_k+1 (key, candidate) pairs come
-        // back; the reference's std::sort (:767) decides only when scores tie inside that prefix or a score is NaN
-        device_sort_pairs_u32(d_keys_.p, d_keys_.p + n, d_vals_.p, d_vals_.p + n, n, &sort_tmp_, &sort_tmp_bytes_, st);
-        const size_t take = (size_t)std::min<long>(nranked, (long)top_k_ + 1);
-        unsigned *back = readback(2 * take + 1);
-        unsigned *hk = back, *hv = back + take;
-        RCHECK(hipMemcpyAsync(hk, d_keys_.p + n, take * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        RCHECK(hipMemcpyAsync(hv, d_vals_.p + n, take * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        RCHECK(hipMemcpyAsync(back + 2 * take, d_flag_.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        RCHECK(hipStreamSynchronize(st));
-        bool exact = back[2 * take] == 0;
+    if (Q.take > 0) {
+        const size_t take = (size_t)Q.take;
+        const unsigned *hk = L.back, *hv = L.back + take;
+        bool exact = L.back[2 * take] == 0;
         for (size_t j = 0; j + 1 < take; j++) if (hk[j] == hk[j + 1]) exact = false;
-        std::vector<RankEntry> head;
-        if (exact) for (int k = 0; k < top_k_; k++) head.push_back(RankEntry{(int)hv[(size_t)k], 0.0f});
-        if (!exact) { full_sort(entry); head = entry; n_host_sorts_++; }
-        for (int k = 0; k < top_k_; k++) { if (nout < cap && out) out[nout] = head[(size_t)k].iid; nout++; }
-    } else {
-        if (npos == 0) { RCHECK(hipStreamSynchronize(st)); return 0; }
-        if (!fused_positions) launch_rank_positions(n, d_score_.p, d_tag_.p, d_pos, npos, d_cnt_.p, d_cnt_.p + npos, st);
-        const int *cnt = reinterpret_cast<const int *>(readback((size_t)2 * npos));
-        RCHECK(hipMemcpyAsync(const_cast<int *>(cnt), d_cnt_.p, (size_t)2 * npos * sizeof(int), hipMemcpyDeviceToHost, st));
-        RCHECK(hipStreamSynchronize(st));
+        if (exact) {
+            for (int k = 0; k < top_k_; k++) emit((int)hv[(size_t)k]);
+        } else {
+            full_sort(entry);
+            for (int k = 0; k < top_k_; k++) emit(entry[(size_t)k].iid);
+        }
+    } else if (Q.npos > 0) {
+        const int npos = Q.npos;
+        const int *cnt = reinterpret_cast<const int *>(L.back);
         bool ties = false;
         for (int j = 0; j < npos; j++) ties = ties || cnt[(size_t)npos + j] != 0;
         if (ties) {   // positions inside a group of equal scores: the reference's sort decides
             full_sort(entry);
-            n_host_sorts_++;
             std::vector<int> where((size_t)n, 0);
             for (size_t i = 0; i < entry.size(); i++) where[(size_t)entry[i].iid] = (int)i;
-            for (int j = 0; j < npos; j++) { if (nout < cap && out) out[nout] = where[(size_t)pos_item_[(size_t)j]]; nout++; }
+            for (int j = 0; j < npos; j++) emit(where[(size_t)Q.pos_item[(size_t)j]]);
         } else {
-            for (int j = 0; j < npos; j++) { if (nout < cap && out) out[nout] = cnt[(size_t)j]; nout++; }
+            for (int j = 0; j < npos; j++) emit(cnt[(size_t)j]);
         }
     }
-    return nout;
+}
+
+void Ranker::drain_quietly() {   // after an error: nothing of the sections in flight is reported
+    (void)hipStreamSynchronize(eng_->stream_);
+    pending_.clear();
+}
+
+long Ranker::rank(int *out, long cap) {
+    if (!deferred_) { out_ptr_ = out; out_cap_ = cap; out_n_ = 0; }
+    enqueue();
+    if (deferred_) return 0;
+    while (!pending_.empty()) resolve();
+    return out_n_;
+}
+
+long Ranker::process_rows(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value, int *out, long cap) {
+    rcheck(init_end_, "ranker: init_ranker has not been called");
+    out_ptr_ = out; out_cap_ = cap; out_n_ = 0;
+    deferred_ = true;
+    try {
+        for (int r = 0; r < num_row; r++) {
+            const int p0 = row_ptr[3 * r], p1 = row_ptr[3 * r + 1], p2 = row_ptr[3 * r + 2], p3 = row_ptr[3 * r + 3];
+            process(row_label[r], p1 - p0, p2 - p1, p3 - p2, feat_index + p0, feat_value + p0, nullptr, 0);
+        }
+        while (!pending_.empty()) resolve();
+    } catch (...) {
+        deferred_ = false;
+        drain_quietly();
+        throw;
+    }
+    deferred_ = false;
+    return out_n_;
 }
 
 }  // namespace svdf

@@ -68,6 +68,20 @@ def main():
             out[name].update({"host_sorts": r.counter(1), "bytes_per_section": byts, "GBps": byts / dt / 1e9, "frac_of_8TBps": byts / dt / 8e12,
                               "note": "wall clock per process() section: staging of the section's lines, one pinned upload, k_rank_user, k_rank_score over the "
                                       "candidate matrix, k_rank_positions (or key + radix sort for top_k), one readback + sync"})
+    # the same sections as ONE svdf_ranker_process_rows call: up to 8 sections in flight on the device
+    r = sa.Ranker(0, 0)
+    r.set_param("top_k", str(a.top_k))
+    r.load_model(path)
+    r.init_ranker(a.cand)
+    r.process_rows(items)
+    r.process_rows(secs[0])
+    bulk = sa.CSRData.concat(secs[1:a.sections])
+    t0 = time.time()
+    got = r.process_rows(bulk)
+    dt = (time.time() - t0) / max(1, a.sections - 1)
+    out["gpu_bulk"] = {"ms_per_section": dt * 1e3, "sections_per_s": 1.0 / dt, "host_sorts": r.counter(1),
+                       "GBps": out["gpu"]["bytes_per_section"] / dt / 1e9, "frac_of_8TBps": out["gpu"]["bytes_per_section"] / dt / 8e12,
+                       "identical_to_per_section_calls": bool(np.array_equal(got, res["gpu"]))}
     n = len(res["cpu_port"])
     if a.cpu_sections > 1:
         out["identical_results"] = bool(np.array_equal(res["gpu"][:n], res["cpu_port"]))

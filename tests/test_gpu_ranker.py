@@ -71,6 +71,49 @@ def test_ranker_tied_scores_follow_the_reference_sort(tmp_path):
         np.testing.assert_array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("top_k", [0, 7])
+@pytest.mark.parametrize("spec", [False, True])
+def test_ranker_bulk_rows_pipelined_equals_line_by_line(top_k, spec, tmp_path):
+    """svdf_ranker_process_rows keeps up to 8 user sections in flight on the device; its results must be those of one
+    svdf_ranker_process_csr call per line, in the same order: 100 sections (bans, special samples, duplicate candidates =
+    tied scores that finish on the host, candidates arriving between sections) in ONE call against line-by-line calls
+    and against the C oracle."""
+    nu, ni, ng = 200, 1500, 4
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=48, ui_init_sigma=0.1, wd_global=0.001)
+    t = oracle.OracleTrainer("port", 0, 0)
+    t.seed(5)
+    for kk, v in conf:
+        t.set_param(kk, v)
+    t.init_model()
+    t.init_trainer()
+    t.update_batch(cases.sparse_feature_rows(3000, nu, ni, ng, 12))
+    path = str(tmp_path / "m.model")
+    t.save_model(path)
+    items, sections = cases.ranker_stream(1200, 100, nu, ni, ng, seed=17 + top_k, spec=spec)
+    # 40 more candidates arrive after the 50th section; with the compiled reference at hand they duplicate earlier ones (exactly
+    # tied scores: the order inside a tie is libstdc++'s std::sort's, which only the reference itself and the engine's host
+    # fallback reproduce -- the C port's sort is not bound to it)
+    kind = "reference" if oracle.have_reference() else "port"
+    late = sa.CSRData.from_rows([(0.0, [], [], [(int(c % 11) if kind == "reference" else 1200 + c, 1.0)]) for c in range(40)])
+    stream = sa.CSRData.concat([items] + sections[:50] + [late] + sections[50:])
+    outs, hosted = {}, {}
+    for name in ("oracle", "lines", "bulk"):
+        r = oracle.OracleRanker(kind, 0, 0) if name == "oracle" else sa.Ranker(0, 0)
+        r.set_param("top_k", str(top_k))
+        r.load_model(path)
+        r.init_ranker(items.num_row + late.num_row)
+        if name == "bulk":
+            outs[name] = r.process_rows(stream)
+        else:
+            outs[name] = np.concatenate([r.process(*stream.row(i)) for i in range(stream.num_row)])
+        if name != "oracle":
+            assert r.counter(0) == 100
+            hosted[name] = r.counter(1)
+    np.testing.assert_array_equal(outs["lines"], outs["oracle"])
+    np.testing.assert_array_equal(outs["bulk"], outs["oracle"])
+    assert hosted["bulk"] == hosted["lines"]   # the same sections needed the reference's sort either way
+
+
 def test_ranker_errors():
     r = sa.Ranker(0, 0)
     with pytest.raises(sa.SvdfError, match="init_ranker has not been called"):
