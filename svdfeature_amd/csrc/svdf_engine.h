@@ -515,7 +515,7 @@ class Ranker {
     std::vector<float> user_val_, host_score_;
     DevBuf<float> d_ifactors_, d_ift_, d_ibias_, d_tu_, d_fb_, w_label_, w_value_, w_uval_, w_fbval_, s_label_, s_value_;
     DevBuf<int> w_ptr_, s_ptr_, s_idx_;
-    DevBuf<unsigned> w_index_, w_fbidx_, s_index_, d_keys_, d_vals_;
+    DevBuf<unsigned> w_index_, w_fbidx_, s_index_, d_keys_, d_vals_, d_sel_;
     void *sort_tmp_ = nullptr;
     size_t sort_tmp_bytes_ = 0;
     DevBuf<signed char> d_tag_;

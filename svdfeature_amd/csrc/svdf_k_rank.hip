@@ -102,7 +102,7 @@ __device__ __forceinline__ float rank_lane_score(int k, long cap, const float4 *
 template <int LPI, typename R>
 __global__ __launch_bounds__(64) void k_rank_user(const DevParams P, const unsigned *stage, const RankSection S, const float *fb_in, float *tu_out,
                                                   signed char *tag, int *cnt, unsigned *flag, long cap, const float4 *ifT, const float *ibias,
-                                                  float *pos_score) {
+                                                  float *pos_score, unsigned *zero_words, int nzero) {
     extern __shared__ float tus[];   // the section's tmp_ufactor, for the positives' scores below
     const int lane = threadIdx.x & 63;
     const unsigned *prev = stage + 2 * S.nu + S.npos, *nidx = prev + S.nprev, *ntag = nidx + S.nnew;
@@ -110,6 +110,7 @@ __global__ __launch_bounds__(64) void k_rank_user(const DevParams P, const unsig
     __syncthreads();
     for (int j = lane; j < S.nnew; j += 64) tag[nidx[j]] = (signed char)(int)ntag[j];
     for (int j = lane; j < 2 * S.npos; j += 64) cnt[j] = 0;
+    for (int j = lane; j < nzero; j += 64) zero_words[j] = 0u;   // top_k: histograms and counters of the radix selection
     if (lane == 0) *flag = 0u;
     using io = row_io<LPI, R>;
     if (lane < LPI) {
@@ -178,6 +179,49 @@ __global__ __launch_bounds__(256) void k_rank_transpose(int k, int pitch, long f
     }
 }
 
+// ---- top_k: the top_k+1 smallest sort keys, in order, by radix selection instead of a full sort (a rocPRIM merge sort of
+// 100 K (key, candidate) pairs is 55 us, 5x the scoring pass).  Three histogram passes over the key digits (11 + 11 + 10 bits,
+// most significant first) find the K-th smallest key T exactly; one pass appends every key <= T to a small buffer, one
+// workgroup sorts that buffer.  Work area (unsigned words): hist[3][2048], then state: 0 b1, 1 K2, 2 b2, 3 K3, 4 appended.
+constexpr int RSEL_BINS = 2048;
+constexpr int RSEL_CAP = 4096;
+__device__ __forceinline__ unsigned rsel_digit(unsigned key, int pass) { return pass == 1 ? key >> 21 : (pass == 2 ? (key >> 10) & 0x7FFu : key & 0x3FFu); }
+// bin holding the K-th smallest entry (K >= 1) of a 2048-bin histogram, and K minus the entries in the bins below it; 256 threads
+__device__ __forceinline__ void rsel_find(const unsigned *hist, unsigned K, unsigned *sh, unsigned &bin, unsigned &Krem) {
+    const int t = threadIdx.x;
+    unsigned h[8], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) { h[j] = hist[8 * t + j]; mine += h[j]; }
+    unsigned incl = mine;   // inclusive scan over the 256 threads: inside each wave by shuffles, wave totals through LDS
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned up = __shfl_up(incl, d);
+        if ((t & 63) >= d) incl += up;
+    }
+    if ((t & 63) == 63) sh[t >> 6] = incl;
+    __syncthreads();
+    unsigned base = 0;
+    for (int w = 0; w < (t >> 6); w++) base += sh[w];
+    incl += base;
+    const unsigned excl = incl - mine;
+    if (excl < K && K <= incl) {
+        unsigned c = excl;
+        for (int j = 0; j < 8; j++) {
+            if (K <= c + h[j]) { sh[8] = (unsigned)(8 * t + j); sh[9] = K - c; break; }
+            c += h[j];
+        }
+    }
+    __syncthreads();
+    bin = sh[8];
+    Krem = sh[9];
+    __syncthreads();
+}
+// plain LDS atomics: a wave whose keys share a bin serialises inside the LDS unit, which measured cheaper than aggregating the
+// lanes with ballots first (k_rank_score<.,2> 17.5 us with the ballot loop)
+__device__ __forceinline__ void rsel_lds_add(unsigned *lh, bool on, unsigned bin) {
+    if (on) atomicAdd(&lh[bin], 1u);
+}
+
 // proc_rank (:754-765): item_score[i] += bias_ifactors[i] + <tmp_ufactor, tmp_ifactors[i]> for every candidate that is not
 // banned (BAN_SAMPLE candidates are not ranked at all).  One lane per candidate.
 //   MODE 0: scores only (a special sample wrote scores this section; k_rank_positions / k_rank_keys follow)
@@ -199,8 +243,12 @@ template <int UNROLL, int MODE>
 __global__ __launch_bounds__(256) void k_rank_score(int k, long n, long cap, const float *__restrict__ tu, const float4 *__restrict__ ifT,
                                                     const float *__restrict__ ibias, const signed char *__restrict__ tag, float *item_score, int fresh,
                                                     const int *pos_item, const float *pos_score, int npos, int *greater, int *ties,
-                                                    unsigned *keys, unsigned *vals, unsigned *flag) {
-    extern __shared__ int cnt[];   // MODE 1: 2 * npos counters
+                                                    unsigned *keys, unsigned *vals, unsigned *flag, unsigned *hist1) {
+    extern __shared__ int cnt[];   // MODE 1: 2 * npos counters; MODE 2 with hist1: RSEL_BINS bins of the selection's first pass
+    if (MODE == 2 && hist1) {
+        for (int j = threadIdx.x; j < RSEL_BINS; j += blockDim.x) cnt[j] = 0;
+        __syncthreads();
+    }
     if (MODE == 1) {
         for (int j = threadIdx.x; j < 2 * npos; j += blockDim.x) cnt[j] = 0;
         __syncthreads();
@@ -229,9 +277,106 @@ __global__ __launch_bounds__(256) void k_rank_score(int k, long n, long cap, con
             if (cnt[npos + j]) atomicAdd(&ties[j], cnt[npos + j]);
         }
     }
-    if (MODE == 2 && i < n) {
-        keys[i] = rank_sort_key(s, !on, flag);
-        vals[i] = (unsigned)i;
+    if (MODE == 2) {
+        const unsigned key = i < n ? rank_sort_key(s, !on, flag) : 0u;
+        if (i < n) { keys[i] = key; vals[i] = (unsigned)i; }
+        if (hist1) {   // first histogram pass of the radix selection, while the keys are in registers
+            unsigned *lh = reinterpret_cast<unsigned *>(cnt);
+            rsel_lds_add(lh, i < n, key >> 21);
+            __syncthreads();
+            for (int j = threadIdx.x; j < RSEL_BINS; j += blockDim.x)
+                if (lh[j]) atomicAdd(&hist1[j], lh[j]);
+        }
+    }
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void k_rsel_hist(long n, const unsigned *keys, unsigned *work, unsigned K1) {
+    __shared__ unsigned lh[RSEL_BINS];
+    __shared__ unsigned sh[16];
+    unsigned *hist = work + (PASS - 1) * RSEL_BINS, *state = work + 3 * RSEL_BINS;
+    unsigned prefix = 0;
+    int shift = 32;   // keys match when key >> shift == prefix
+    if (PASS == 2) {
+        unsigned b1, K2;
+        rsel_find(work, K1, sh, b1, K2);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { state[0] = b1; state[1] = K2; }
+        prefix = b1; shift = 21;
+    } else if (PASS == 3) {
+        unsigned b2, K3;
+        rsel_find(work + RSEL_BINS, state[1], sh, b2, K3);
+        if (blockIdx.x == 0 && threadIdx.x == 0) { state[2] = b2; state[3] = K3; }
+        prefix = (state[0] << 11) | b2; shift = 10;
+    }
+    for (int j = threadIdx.x; j < RSEL_BINS; j += blockDim.x) lh[j] = 0;
+    __syncthreads();
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long rounds = (n + stride - 1) / stride;
+    for (long r = 0; r < rounds; r++) {
+        const long i = r * stride + (long)blockIdx.x * blockDim.x + threadIdx.x;
+        const unsigned key = i < n ? keys[i] : 0u;
+        const bool on = i < n && (PASS == 1 || (key >> shift) == prefix);
+        rsel_lds_add(lh, on, rsel_digit(key, PASS));
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < RSEL_BINS; j += blockDim.x)
+        if (lh[j]) atomicAdd(&hist[j], lh[j]);
+}
+__global__ __launch_bounds__(256) void k_rsel_compact(long n, const unsigned *keys, const unsigned *vals, unsigned *work, unsigned *ck, unsigned *cv) {
+    __shared__ unsigned sh[16];
+    unsigned *state = work + 3 * RSEL_BINS;
+    unsigned b3, K4;
+    rsel_find(work + 2 * RSEL_BINS, state[3], sh, b3, K4);
+    const unsigned T = (state[0] << 21) | (state[2] << 10) | b3;   // the K1-th smallest key
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long rounds = (n + stride - 1) / stride;
+    for (long r = 0; r < rounds; r++) {
+        const long i = r * stride + (long)blockIdx.x * blockDim.x + threadIdx.x;
+        const unsigned key = i < n ? keys[i] : 0xFFFFFFFFu;
+        const bool on = i < n && key <= T;
+        const unsigned long long m = __ballot(on);
+        if (m) {
+            const int lane = threadIdx.x & 63;
+            unsigned base = 0;
+            if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&state[4], (unsigned)__popcll(m));
+            base = (unsigned)__builtin_amdgcn_readlane((int)base, __ffsll((long long)m) - 1);
+            const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
+            if (on && pos < (unsigned)RSEL_CAP) { ck[pos] = key; cv[pos] = vals[i]; }
+        }
+    }
+}
+// one workgroup: bitonic sort of the appended (key, candidate) pairs, the first K1 written out; more than RSEL_CAP keys <= T
+// (thousands of candidates tied at the threshold) raises flag bit 1: the host's sort takes the section
+// out: K1 keys, K1 candidates, then the section's flag word (1 = a NaN score, 2 = overflow here): ONE readback
+__global__ __launch_bounds__(1024) void k_rsel_sort(const unsigned *work, const unsigned *ck, const unsigned *cv, unsigned K1, unsigned *out,
+                                                    const unsigned *flag) {
+    __shared__ unsigned sk[RSEL_CAP], sv[RSEL_CAP];
+    unsigned *out_keys = out, *out_vals = out + K1;
+    const unsigned appended = work[3 * RSEL_BINS + 4];
+    if (threadIdx.x == 0) out[2 * K1] = *flag | (appended > (unsigned)RSEL_CAP ? 2u : 0u);
+    const unsigned count = appended < (unsigned)RSEL_CAP ? appended : (unsigned)RSEL_CAP;
+    unsigned P = 2;
+    while (P < count) P <<= 1;
+    for (unsigned i = threadIdx.x; i < P; i += blockDim.x) {
+        sk[i] = i < count ? ck[i] : 0xFFFFFFFFu;
+        sv[i] = i < count ? cv[i] : 0xFFFFFFFFu;
+    }
+    __syncthreads();
+    for (unsigned k = 2; k <= P; k <<= 1)
+        for (unsigned j = k >> 1; j > 0; j >>= 1) {
+            for (unsigned i = threadIdx.x; i < P; i += blockDim.x) {
+                const unsigned x = i ^ j;
+                if (x > i) {
+                    const bool asc = (i & k) == 0;
+                    const unsigned a = sk[i], b = sk[x];
+                    if ((a > b) == asc && a != b) { sk[i] = b; sk[x] = a; const unsigned t = sv[i]; sv[i] = sv[x]; sv[x] = t; }
+                }
+            }
+            __syncthreads();
+        }
+    for (unsigned i = threadIdx.x; i < K1; i += blockDim.x) {
+        out_keys[i] = i < P ? sk[i] : 0xFFFFFFFFu;
+        out_vals[i] = i < P ? sv[i] : 0xFFFFFFFFu;
     }
 }
 
@@ -299,10 +444,10 @@ void launch_rank_feedback(const DevParams &P, const unsigned *fidx, const float 
     SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_rank_feedback<LPI, R>), dim3(1), dim3(64), 0, st, P, fidx, fval, nfb, fb_out));
 }
 void launch_rank_user(const DevParams &P, const unsigned *stage, const RankSection &S, const float *fb_in, float *tu_out, signed char *tag, int *cnt,
-                      unsigned *flag, long cap, const float *ifT, const float *ibias, float *pos_score, hipStream_t st) {
+                      unsigned *flag, long cap, const float *ifT, const float *ibias, float *pos_score, unsigned *zero_words, int nzero, hipStream_t st) {
     const size_t lds = pos_score ? ((size_t)P.pitch + 4) * sizeof(float) : 0;
     SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_rank_user<LPI, R>), dim3(1), dim3(64), lds, st, P, stage, S, fb_in, tu_out, tag, cnt, flag, cap,
-                                              reinterpret_cast<const float4 *>(ifT), ibias, pos_score));
+                                              reinterpret_cast<const float4 *>(ifT), ibias, pos_score, zero_words, nzero));
 }
 void launch_rank_spec(const DevParams &P, const DevCSR &D, long n, const int *spec_idx, const float *tu, float *item_score, hipStream_t st) {
     if (n <= 0) return;
@@ -323,19 +468,32 @@ void launch_rank_score(const DevParams &P, long n, long cap, const float *tu, co
     const float4 *q = reinterpret_cast<const float4 *>(ifT);
     if (F.mode == 1)
         hipLaunchKernelGGL((k_rank_score<8, 1>), dim3(grid), dim3(256), (size_t)2 * F.npos * sizeof(int), st, P.k, n, cap, tu, q, ibias, tag, item_score, fresh,
-                           F.pos_item, F.pos_score, F.npos, F.greater, F.ties, nullptr, nullptr, nullptr);
+                           F.pos_item, F.pos_score, F.npos, F.greater, F.ties, nullptr, nullptr, nullptr, nullptr);
     else if (F.mode == 2)
-        hipLaunchKernelGGL((k_rank_score<8, 2>), dim3(grid), dim3(256), 0, st, P.k, n, cap, tu, q, ibias, tag, item_score, fresh, nullptr, nullptr, 0, nullptr,
-                           nullptr, F.keys, F.vals, F.flag);
+        hipLaunchKernelGGL((k_rank_score<8, 2>), dim3(grid), dim3(256), F.hist1 ? (size_t)RSEL_BINS * sizeof(unsigned) : 0, st, P.k, n, cap, tu, q, ibias, tag,
+                           item_score, fresh, nullptr, nullptr, 0, nullptr, nullptr, F.keys, F.vals, F.flag, F.hist1);
     else
         hipLaunchKernelGGL((k_rank_score<8, 0>), dim3(grid), dim3(256), 0, st, P.k, n, cap, tu, q, ibias, tag, item_score, fresh, nullptr, nullptr, 0, nullptr,
-                           nullptr, nullptr, nullptr, nullptr);
+                           nullptr, nullptr, nullptr, nullptr, nullptr);
 }
 void launch_rank_positions(long n, const float *score, const signed char *tag, const int *pos_item, int npos, int *greater, int *ties, hipStream_t st) {
     if (n <= 0 || npos <= 0) return;
     long grid = (n + 255) / 256;
     if (grid > 128) grid = 128;
     hipLaunchKernelGGL(k_rank_positions, dim3((int)grid), dim3(256), (size_t)npos * (sizeof(float) + 2 * sizeof(int)), st, n, score, tag, pos_item, npos, greater, ties);
+}
+long rank_select_work_words() { return 3L * RSEL_BINS + 8; }
+long rank_select_cap() { return RSEL_CAP; }
+// the K1 smallest keys of keys[0..n) and their values, ascending, then the flag word, into out[0 .. 2*K1] (K1 <= RSEL_CAP / 2,
+// K1 <= n).  work must be zero and its first histogram filled: k_rank_user zeroes it, k_rank_score<.,2> fills hist[0].
+void launch_rank_select(long n, const unsigned *keys, const unsigned *vals, unsigned K1, unsigned *work, unsigned *ck, unsigned *cv, unsigned *out,
+                        const unsigned *flag, hipStream_t st) {
+    long grid = (n + 255) / 256;
+    if (grid > 256) grid = 256;
+    hipLaunchKernelGGL((k_rsel_hist<2>), dim3((int)grid), dim3(256), 0, st, n, keys, work, K1);
+    hipLaunchKernelGGL((k_rsel_hist<3>), dim3((int)grid), dim3(256), 0, st, n, keys, work, K1);
+    hipLaunchKernelGGL(k_rsel_compact, dim3((int)grid), dim3(256), 0, st, n, keys, vals, work, ck, cv);
+    hipLaunchKernelGGL(k_rsel_sort, dim3(1), dim3(1024), 0, st, work, ck, cv, K1, out, flag);
 }
 int sqerr_partials_grid(long n) {
     long grid = (n + 255) / 256;

@@ -54,14 +54,21 @@ void launch_rank_items(const DevParams &P, const DevCSR &D, long first, long n, 
 void launch_rank_feedback(const DevParams &P, const unsigned *fidx, const float *fval, int nfb, float *fb_out, hipStream_t st);
 struct RankSection { int nu, npos, nprev, nnew; };   // words staged per ranker section: uidx[nu] uval[nu] pos[npos] prev[nprev] new_idx[nnew] new_tag[nnew]
 void launch_rank_user(const DevParams &P, const unsigned *stage, const RankSection &S, const float *fb_in, float *tu_out, signed char *tag, int *cnt,
-                      unsigned *flag, long cap, const float *ifT, const float *ibias, float *pos_score, hipStream_t st);
+                      unsigned *flag, long cap, const float *ifT, const float *ibias, float *pos_score, unsigned *zero_words, int nzero, hipStream_t st);
 void launch_rank_spec(const DevParams &P, const DevCSR &D, long n, const int *spec_idx, const float *tu, float *item_score, hipStream_t st);
 void launch_rank_transpose(const DevParams &P, long first, long n, long cap, const float *ifactors, float *ifT, hipStream_t st);
 // what the scoring pass does besides the scores: 1 = count the positives' rank positions, 2 = emit the top_k sort keys
-struct RankFused { int mode; const int *pos_item; const float *pos_score; int npos; int *greater, *ties; unsigned *keys, *vals, *flag; };
+struct RankFused { int mode; const int *pos_item; const float *pos_score; int npos; int *greater, *ties; unsigned *keys, *vals, *flag, *hist1; };
 void launch_rank_score(const DevParams &P, long n, long cap, const float *tu, const float *ifT, const float *ibias, const signed char *tag,
                        float *item_score, int fresh, const RankFused &F, hipStream_t st);
 void launch_rank_positions(long n, const float *score, const signed char *tag, const int *pos_item, int npos, int *greater, int *ties, hipStream_t st);
+// radix selection of the K1 smallest (key, value) pairs, ascending (svdf_k_rank.hip): work = rank_select_work_words() words
+// (zeroed by k_rank_user, first histogram filled by the scoring pass: RankFused::hist1 = work), ck / cv = rank_select_cap()
+// words each, K1 <= rank_select_cap() / 2; out = K1 keys, K1 values, flag word (| 2 when too many keys tie at the threshold)
+long rank_select_work_words();
+long rank_select_cap();
+void launch_rank_select(long n, const unsigned *keys, const unsigned *vals, unsigned K1, unsigned *work, unsigned *ck, unsigned *cv, unsigned *out,
+                        const unsigned *flag, hipStream_t st);
 // ascending radix sort of (key, value) pairs (svdf_k_sched.hip, rocPRIM); tmp is grown as needed
 void device_sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, unsigned *vals_out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st);
 int sqerr_partials_grid(long n);

@@ -236,8 +236,12 @@ void Ranker::enqueue() {
     L.d_score.reserve((size_t)cap_items);
     // positions mode without special samples: the positives' scores are known before the scoring pass, which then counts
     const bool fused_positions = top_k_ <= 0 && fresh && npos > 0 && n > 0;
+    // top_k with a short prefix: radix selection (its work area is zeroed by k_rank_user, its first pass rides on the scoring pass)
+    const size_t take = top_k_ > 0 ? (size_t)std::min<long>(nranked, (long)top_k_ + 1) : 0;
+    const bool select = top_k_ > 0 && n > 0 && (long)take <= rank_select_cap() / 2;
+    if (select) d_sel_.reserve((size_t)rank_select_work_words() + 4 * (size_t)rank_select_cap() + 4);
     launch_rank_user(P, L.d_stage.p, S, eng_->user_group() ? d_fb_.p : nullptr, d_tu_.p, d_tag_.p, L.d_cnt.p, L.d_flag.p, cap_items, d_ift_.p, d_ibias_.p,
-                     fused_positions ? L.d_ps.p : nullptr, st);
+                     fused_positions ? L.d_ps.p : nullptr, select ? d_sel_.p : nullptr, select ? (int)rank_select_work_words() : 0, st);
     dev_tagged_ = tagged_;
     const int *d_pos = reinterpret_cast<const int *>(L.d_stage.p + 2 * nu);
     n_sections_++;
@@ -256,24 +260,31 @@ void Ranker::enqueue() {
             launch_rank_spec(P, D, (long)live_idx.size(), s_idx_.p, d_tu_.p, L.d_score.p, st);
             RCHECK(hipStreamSynchronize(st));   // the host staging vectors go out of use
         }
-        RankFused F{0, d_pos, L.d_ps.p, npos, L.d_cnt.p, L.d_cnt.p + npos, nullptr, nullptr, L.d_flag.p};
+        RankFused F{0, d_pos, L.d_ps.p, npos, L.d_cnt.p, L.d_cnt.p + npos, nullptr, nullptr, L.d_flag.p, nullptr};
         if (top_k_ > 0) {
             d_keys_.reserve((size_t)2 * cap_items);
             d_vals_.reserve((size_t)2 * cap_items);
             F.mode = 2; F.keys = d_keys_.p; F.vals = d_vals_.p;
+            if (select) F.hist1 = d_sel_.p;
         } else if (fused_positions) {
             F.mode = 1;
         }
         launch_rank_score(P, n, cap_items, d_tu_.p, d_ift_.p, d_ibias_.p, d_tag_.p, L.d_score.p, fresh ? 1 : 0, F, st);
         if (top_k_ > 0) {
-            // top_k: radix sort of order-preserving score keys on the device, only the first top_k+1 (key, candidate) pairs come
-            // back; the reference's std::sort (:767) decides only when scores tie inside that prefix or a score is NaN
-            device_sort_pairs_u32(d_keys_.p, d_keys_.p + n, d_vals_.p, d_vals_.p + n, n, &sort_tmp_, &sort_tmp_bytes_, st);
-            const size_t take = (size_t)std::min<long>(nranked, (long)top_k_ + 1);
+            // top_k: order-preserving score keys sorted / selected on the device, only the first top_k+1 (key, candidate) pairs come
+            // back (radix selection, svdf_k_rank.hip; a full rocPRIM sort when the prefix is long); the reference's std::sort
+            // (:767) decides only when scores tie inside that prefix or a score is NaN
             slot_reserve_back(L, 2 * take + 1);
-            RCHECK(hipMemcpyAsync(L.back, d_keys_.p + n, take * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-            RCHECK(hipMemcpyAsync(L.back + take, d_vals_.p + n, take * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-            RCHECK(hipMemcpyAsync(L.back + 2 * take, L.d_flag.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            if (select) {
+                unsigned *work = d_sel_.p, *ck = work + rank_select_work_words(), *cv = ck + rank_select_cap(), *res = cv + rank_select_cap();
+                launch_rank_select(n, d_keys_.p, d_vals_.p, (unsigned)take, work, ck, cv, res, L.d_flag.p, st);
+                RCHECK(hipMemcpyAsync(L.back, res, (2 * take + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            } else {
+                device_sort_pairs_u32(d_keys_.p, d_keys_.p + n, d_vals_.p, d_vals_.p + n, n, &sort_tmp_, &sort_tmp_bytes_, st);
+                RCHECK(hipMemcpyAsync(L.back, d_keys_.p + n, take * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                RCHECK(hipMemcpyAsync(L.back + take, d_vals_.p + n, take * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+                RCHECK(hipMemcpyAsync(L.back + 2 * take, L.d_flag.p, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+            }
             Q.take = (int)take;
         } else if (npos > 0) {
             if (!fused_positions) launch_rank_positions(n, L.d_score.p, d_tag_.p, d_pos, npos, L.d_cnt.p, L.d_cnt.p + npos, st);

@@ -48,6 +48,37 @@ def test_ranker_large_item_set_matches_the_oracle(k, top_k, tmp_path):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("top_k", [1, 2047, 2048, 3500, 3990])
+def test_ranker_long_top_k_prefixes(top_k, tmp_path):
+    """top_k + 1 <= 2048 goes through the radix selection (three digit passes, append, one-workgroup sort), longer prefixes
+    through the full device sort; 4000 candidates of which some are banned, top_k up to all ranked candidates but ten."""
+    nu, ni = 100, 4000
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=20, ui_init_sigma=0.3)
+    t = oracle.OracleTrainer("port", 0, 0)
+    t.seed(9)
+    for kk, v in conf:
+        t.set_param(kk, v)
+    t.init_model()
+    t.init_trainer()
+    path = str(tmp_path / "m.model")
+    t.save_model(path)
+    items = sa.CSRData.from_rows([(0.0, [], [], [(c, 1.0)]) for c in range(ni)])
+    secs = sa.CSRData.from_rows([row for u in range(6) for row in ((2.0, [], [(u * 7, 1.0)], []), (-1.0, [], [(u, 1.0), (u + 50, 1.0)], []),
+                                                                     (4.0, [], [], []))])
+    outs = []
+    for mk in (lambda: oracle.OracleRanker("port", 0, 0), lambda: sa.Ranker(0, 0)):
+        r = mk()
+        r.set_param("top_k", str(top_k))
+        r.load_model(path)
+        r.init_ranker(ni)
+        r.process_rows(items)
+        outs.append(r.process_rows(secs))
+        if isinstance(r, sa.Ranker):
+            assert r.counter(1) == 0   # distinct random rows: no tie, nothing finished on the host
+    assert len(outs[0]) == 6 * top_k
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
 @pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference (oracle/_ref) not present")
 def test_ranker_tied_scores_follow_the_reference_sort(tmp_path):
     """Candidates that are copies of one another score exactly the same: their order is whatever std::sort makes of the
