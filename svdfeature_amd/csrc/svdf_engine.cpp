@@ -1960,11 +1960,13 @@ void Engine::predict_dataset(Dataset *ds, float *out) {
         } else {
             launch_predict_fused(P, ds->fused.view(), ds->fused.max_nu, ds->fused.max_ni, n, w_out_.p, stream_);
         }
-        std::vector<float> tmp((size_t)n);
-        HIPCHECK(hipMemcpyAsync(tmp.data(), w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        // back into the caller's instance order on the device (a host scatter of 1e8 predictions costs more than the scoring),
+        // then one copy out; a host-built schedule's order goes to HBM once
+        if (!ds->order_dev.p) ds->order_dev.upload(ds->sched.order.data(), (size_t)n, stream_);
+        w_pred_.reserve((size_t)n);
+        device_scatter_f32(w_out_.p, ds->order_dev.p, w_pred_.p, n, stream_);
+        HIPCHECK(hipMemcpyAsync(out, w_pred_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
         HIPCHECK(hipStreamSynchronize(stream_));
-        const int *order = host_order(ds);
-        for (long s = 0; s < n; s++) out[order[s]] = tmp[(size_t)s];
     } else {
         DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
         launch_predict(P, D, n, w_out_.p, stream_);

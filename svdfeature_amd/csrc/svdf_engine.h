@@ -424,7 +424,7 @@ class Engine {
     std::vector<int64_t> stamp_;   // scratch for per-unit distinctness checks: stamp_epoch_ + unit index of the last toucher
     int64_t stamp_epoch_ = 0;
     // reusable device staging buffers
-    DevBuf<float> w_label_, w_value_, w_uval_, w_ival_, w_fbval_, w_out_;
+    DevBuf<float> w_label_, w_value_, w_uval_, w_ival_, w_fbval_, w_out_, w_pred_;
     DevBuf<int> w_ptr_, w_order_;
     DevBuf<unsigned> w_index_, w_user_, w_item_, w_fbidx_;
     DevBuf<DevUnit> w_units_;

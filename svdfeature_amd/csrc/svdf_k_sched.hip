@@ -279,6 +279,15 @@ void device_gather_f32(const float *src, const int *order, float *dst, long n, h
     if (n > 0) hipLaunchKernelGGL(k_gather<float>, dim3(grid_for_n(n)), dim3(256), 0, st, src, order, dst, n);
 }
 
+// dst[order[s]] = src[s]: predictions of a scheduled data set back into the caller's instance order
+__global__ __launch_bounds__(256) void k_scatter_f32(const float *src, const int *order, float *dst, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < n; s += stride) dst[order[s]] = src[s];
+}
+void device_scatter_f32(const float *src, const int *order, float *dst, long n, hipStream_t st) {
+    if (n > 0) hipLaunchKernelGGL(k_scatter_f32, dim3(grid_for_n(n)), dim3(256), 0, st, src, order, dst, n);
+}
+
 void device_sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, unsigned *vals_out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st) {
     if (n <= 0) return;
     size_t need = 0;

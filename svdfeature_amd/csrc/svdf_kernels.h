@@ -105,6 +105,7 @@ struct SchedColumns {
 long device_schedule(const SchedColumns &in, int *order_out, std::vector<long> &level_ptr, long *max_level_size, hipStream_t st);
 void device_gather_u32(const unsigned *src, const int *order, unsigned *dst, long n, hipStream_t st);
 void device_gather_f32(const float *src, const int *order, float *dst, long n, hipStream_t st);
+void device_scatter_f32(const float *src, const int *order, float *dst, long n, hipStream_t st);   // dst[order[s]] = src[s]
 // test probe: out[j] = device expf of in[j], or (in == nullptr) of the float with bit pattern first + j*step
 int device_expf(const float *in, unsigned first, unsigned step, float *out, long n);
 
