@@ -22,7 +22,8 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with extra objec
   "secondary"     (N=1 default run) BASELINE configs[3] / configs[4] at their configured sizes: pairwise rank pairs
                   k=128 (200 M pairs), SVD++ user blocks k=128, neighbourhood (4 of 10 K global ids) k=128 -- each with
                   value, ms_per_step, roofline, cpu_baseline, in-run parity against the CPU path and, where the data's
-                  dependency depth is the bound, the DAG bound (levels x latency of one unit)
+                  dependency depth is the bound, the DAG bound (levels x latency of one unit); plus SURVEY 8 f3: the evaluator
+                  (evaluate_k64) and the ranker (ranker_k128_positions / _top10) with roofline, CPU baseline and identity check
 """
 import argparse
 import ctypes as C
@@ -527,6 +528,103 @@ def run_workload(name, a, env, steps, warmup, main_line):
     return res
 
 
+def run_f3_secondary(a, env):
+    """SURVEY 8 f3 next to the training numbers (N=1 default run only): the evaluator (svdf_eval_dataset = RMSEEvaluator over a
+    resident test set, the read-only half of the hot path) and the ranker (svdf_ranker_process_rows, 100 K candidates, k=128),
+    each with its HBM roofline figure, the CPU path on a bounded sample and an in-run identity check."""
+    import tempfile
+    import svdfeature_amd as sa
+    from oracle import oracle   # checker / CPU baseline only
+    oracle.build()
+    log = env["log"]
+    out = {}
+    # ---- evaluator: basicMF shape of the main line, 20 M held-out-style ratings
+    n, k = 20_000_000, 64
+    rng = np.random.default_rng(31)
+    u = rng.integers(0, a.users, n, dtype=np.uint32)
+    i = rng.integers(0, a.items, n, dtype=np.uint32)
+    r = rng.integers(1, 6, n).astype(np.float32)
+    conf = [(kk, v) for kk, v in conf_for(a) if kk != "num_factor"] + [("num_factor", str(k)), ("ui_init_sigma", "0.1")]
+    t, o = sa.Trainer(0, 0), oracle.OracleTrainer("port", 0, 0)
+    for x in (t, o):
+        x.seed(10)
+        for kk, v in conf:
+            x.set_param(kk, v)
+        x.init_model()
+        x.init_trainer()
+    ds = t.dataset_from_triples(u, i, r)
+    t.eval_dataset(ds)
+    reps = 10
+    t0 = time.time()
+    for _ in range(reps):
+        sse, cnt = t.eval_dataset(ds)
+    dt = (time.time() - t0) / reps
+    S = 1_000_000
+    t0 = time.time()
+    cpu_pred = np.asarray(o.predict_batch(sa.CSRData.from_triples(u[:S], i[:S], r[:S])), np.float32)
+    dt_cpu = time.time() - t0
+    gpu_pred = t.predict_dataset(ds)[:S]
+    byts = 2 * k * 4 + 8 + 12   # two rows, two bias words, the (user, item, label) record
+    out["evaluate_k64"] = {
+        "workload": "RMSEEvaluator over %d resident (user, item, rating) instances, basicMF k=64" % n,
+        "value": n / dt, "unit": "instances/s", "ms_per_step": dt * 1e3, "rmse": float(np.sqrt(sse / cnt)),
+        "roofline": {"bound": "hbm", "achieved": n * byts / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": n * byts / dt / 1e9 / HBM_PEAK_GBS,
+                     "kernel": "k_predict_basic", "algorithmic_bytes_per_instance": byts,
+                     "timing": "host clock around svdf_eval_dataset (one launch + the partial-sum reduction + sync)", "traffic": None},
+        "cpu_baseline": {"value": S / dt_cpu, "unit": "instances/s", "cores": 1, "kind": "port", "sample": "predict of the first %d instances" % S},
+        "parity": {"predictions_bit_exact_on_sample": bool(np.array_equal(gpu_pred.view(np.uint32), cpu_pred.view(np.uint32)))}}
+    log("f3 evaluate: %.2f G inst/s (%.1f%% of peak), cpu %.2f M inst/s" % (n / dt / 1e9, 100 * out["evaluate_k64"]["roofline"]["frac"], S / dt_cpu / 1e6))
+    path = os.path.join(tempfile.mkdtemp(), "rank.model")
+    t.close()
+    o.close()
+    # ---- ranker: 100 K candidates, k=128, 5 positives per user section, positions and top-10
+    cand, k, nsec, ncpu = 100_000, 128, 300, 12
+    tr = oracle.OracleTrainer("port", 0, 0)
+    tr.seed(7)
+    for kk, v in [("num_user", "100000"), ("num_item", str(cand)), ("num_factor", str(k)), ("base_score", "0"), ("ui_init_sigma", "0.1"),
+                  ("num_global", "0"), ("active_type", "0")]:
+        tr.set_param(kk, v)
+    tr.init_model()
+    tr.init_trainer()
+    tr.save_model(path)
+    items = sa.CSRData.from_rows([(0.0, [], [], [(c, 1.0)]) for c in range(cand)])
+    secs = []
+    for s_ in range(nsec):
+        pos = rng.choice(cand, size=5, replace=False)
+        secs.append(sa.CSRData.from_rows([(2.0, [], [(int(rng.integers(0, 100_000)), 1.0)], []), (1.0, [], [(int(x), 1.0) for x in pos], []),
+                                          (4.0, [], [], [])]))
+    bulk = sa.CSRData.concat(secs)
+    byts = cand * (k * 4 + 4 + 4 + 1)
+    for top_k in (0, 10):
+        g = sa.Ranker(0, 0)
+        c = oracle.OracleRanker("port", 0, 0)
+        for x in (g, c):
+            x.set_param("top_k", str(top_k))
+            x.load_model(path)
+            x.init_ranker(cand)
+            x.process_rows(items)
+        g.process_rows(secs[0])
+        t0 = time.time()
+        got = g.process_rows(bulk)
+        dt = (time.time() - t0) / nsec
+        t0 = time.time()
+        ref = np.concatenate([c.process_rows(s_) for s_ in secs[:ncpu]])
+        dt_cpu = (time.time() - t0) / ncpu
+        out["ranker_k128_top%d" % top_k if top_k else "ranker_k128_positions"] = {
+            "workload": "ISVDRanker: %d candidates, k=128, %d user sections in one svdf_ranker_process_rows call, %s" % (
+                cand, nsec, "top_k=%d" % top_k if top_k else "rank positions of 5 positives"),
+            "value": 1.0 / dt, "unit": "user sections/s", "ms_per_step": dt * 1e3, "sections_finished_by_host_sort": g.counter(1),
+            "roofline": {"bound": "hbm", "achieved": byts / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / dt / 1e9 / HBM_PEAK_GBS,
+                         "kernel": "k_rank_score", "algorithmic_bytes_per_section": byts,
+                         "timing": "host clock over the whole call / sections: upload, k_rank_user, k_rank_score, selection, readback of every "
+                                   "section (the scoring kernel alone: profiles/r02_ranker_*_kernel_stats.csv)", "traffic": None},
+            "cpu_baseline": {"value": 1.0 / dt_cpu, "unit": "user sections/s", "cores": 1, "kind": "port", "sample": "the first %d sections" % ncpu},
+            "parity": {"results_identical_on_sample": bool(np.array_equal(got[:len(ref)], ref))}}
+        log("f3 ranker top_k=%d: %.1f us/section, cpu %.2f ms/section" % (top_k, dt * 1e6, dt_cpu * 1e3))
+        g.close()
+    return out
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -625,6 +723,11 @@ def main():
         if r is not None:
             r["wall_s"] = round(time.time() - t0, 1)
             secondary["%s_k%d" % (name, WORKLOADS[name][2])] = r
+    if rank == 0 and world == 1 and a.secondary == "auto" and secondary:
+        try:
+            secondary.update(run_f3_secondary(a, env))
+        except Exception as e:   # the f3 rows are extras: never lose the contract line over them
+            secondary["f3_error"] = repr(e)
     if rank == 0:
         m = main_res
         metric = {"basicmf": "training instances/sec (SGD updates/s), basicMF k=%d" % (a.factor or 64),
