@@ -19,6 +19,7 @@
 #include <thread>
 #include <string>
 #include <deque>
+#include <future>
 #include <vector>
 
 #include "svdf_types.h"
@@ -500,7 +501,10 @@ class Ranker {
     };
     struct RankPending { int slot = 0, npos = 0, take = 0; long n = 0; std::vector<int> pos_item, banned; };
     RankSlot slots_[RANK_SLOTS];
+    struct RankChunk { std::vector<int> vals; std::future<std::vector<int>> fut; bool pending = false; };   // one section's results
     std::deque<RankPending> pending_;
+    std::deque<RankChunk> chunks_;
+    void flush_chunks();
     int next_slot_ = 0;
     bool deferred_ = false;
     int *out_ptr_ = nullptr;
@@ -512,7 +516,7 @@ class Ranker {
     void drain_quietly();
     std::vector<signed char> tag_;
     std::vector<unsigned> user_idx_;
-    std::vector<float> user_val_, host_score_;
+    std::vector<float> user_val_;
     DevBuf<float> d_ifactors_, d_ift_, d_ibias_, d_tu_, d_fb_, w_label_, w_value_, w_uval_, w_fbval_, s_label_, s_value_;
     DevBuf<int> w_ptr_, s_ptr_, s_idx_;
     DevBuf<unsigned> w_index_, w_fbidx_, s_index_, d_keys_, d_vals_, d_sel_;

@@ -9,6 +9,7 @@
 // ranked candidates tie with a requested position (or inside the top_k prefix) the order is whatever std::sort makes of
 // the reference's entry vector, so those rare sections are finished by running exactly that sort on the host.
 #include <algorithm>
+#include <future>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -301,7 +302,30 @@ void Ranker::enqueue() {
     pending_.push_back(std::move(Q));
 }
 
-// oldest section in flight -> its results appended at the output cursor
+// The reference's own ordering step (:767) for a section whose scores tie: std::sort over the entry vector (ranked candidates
+// in index order).  100 K entries take ~8 ms on one core, two hundred sections' worth of device time: it runs on a helper
+// thread over a private copy of the section's scores while the pipeline goes on; results are still reported in section order.
+static std::vector<int> host_sort_section(std::vector<float> score, std::vector<int> banned_idx, std::vector<int> pos_item, int top_k) {
+    const long n = (long)score.size();
+    std::vector<char> banned((size_t)n, 0);
+    for (int idx : banned_idx) banned[(size_t)idx] = 1;
+    std::vector<RankEntry> entry;
+    entry.reserve((size_t)n);
+    for (long i = 0; i < n; i++)
+        if (!banned[(size_t)i]) entry.push_back(RankEntry{(int)i, score[(size_t)i]});
+    std::sort(entry.begin(), entry.end());
+    std::vector<int> out;
+    if (top_k > 0) {
+        for (int k = 0; k < top_k; k++) out.push_back(entry[(size_t)k].iid);
+    } else {
+        std::vector<int> where((size_t)n, 0);
+        for (size_t i = 0; i < entry.size(); i++) where[(size_t)entry[i].iid] = (int)i;
+        for (int p : pos_item) out.push_back(where[(size_t)p]);
+    }
+    return out;
+}
+
+// oldest section in flight -> its results (or the future of its host sort) appended to the result chunks
 void Ranker::resolve() {
     RankPending Q = std::move(pending_.front());
     pending_.pop_front();
@@ -309,50 +333,52 @@ void Ranker::resolve() {
     hipStream_t st = eng_->stream_;
     RCHECK(hipEventSynchronize(L.ev));
     const long n = Q.n;
-    auto emit = [&](int v) { if (out_n_ < out_cap_ && out_ptr_) out_ptr_[out_n_] = v; out_n_++; };
-    auto full_sort = [&](std::vector<RankEntry> &entry) {   // the reference's own ordering step (:767)
-        host_score_.resize((size_t)n);
-        RCHECK(hipMemcpyAsync(host_score_.data(), L.d_score.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
-        RCHECK(hipStreamSynchronize(st));
-        std::vector<char> banned((size_t)n, 0);
-        for (int idx : Q.banned) banned[(size_t)idx] = 1;
-        entry.clear();
-        for (long i = 0; i < n; i++)
-            if (!banned[(size_t)i]) entry.push_back(RankEntry{(int)i, host_score_[(size_t)i]});
-        std::sort(entry.begin(), entry.end());
+    RankChunk C;
+    auto host_sort = [&]() {
+        std::vector<float> score((size_t)n);
+        RCHECK(hipMemcpyAsync(score.data(), L.d_score.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+        RCHECK(hipStreamSynchronize(st));   // the slot's item_score is free again after this
         n_host_sorts_++;
+        size_t running = 0;
+        for (RankChunk &c : chunks_) running += c.pending ? 1 : 0;
+        if (running >= 8)   // bound the helper threads: wait for the oldest unfinished sort
+            for (RankChunk &c : chunks_) if (c.pending) { c.vals = c.fut.get(); c.pending = false; break; }
+        C.pending = true;
+        C.fut = std::async(std::launch::async, host_sort_section, std::move(score), Q.banned, Q.pos_item, top_k_);
     };
-    std::vector<RankEntry> entry;
     if (Q.take > 0) {
         const size_t take = (size_t)Q.take;
         const unsigned *hk = L.back, *hv = L.back + take;
         bool exact = L.back[2 * take] == 0;
         for (size_t j = 0; j + 1 < take; j++) if (hk[j] == hk[j + 1]) exact = false;
-        if (exact) {
-            for (int k = 0; k < top_k_; k++) emit((int)hv[(size_t)k]);
-        } else {
-            full_sort(entry);
-            for (int k = 0; k < top_k_; k++) emit(entry[(size_t)k].iid);
-        }
+        if (exact) for (int k = 0; k < top_k_; k++) C.vals.push_back((int)hv[(size_t)k]);
+        else host_sort();
     } else if (Q.npos > 0) {
         const int npos = Q.npos;
         const int *cnt = reinterpret_cast<const int *>(L.back);
         bool ties = false;
         for (int j = 0; j < npos; j++) ties = ties || cnt[(size_t)npos + j] != 0;
-        if (ties) {   // positions inside a group of equal scores: the reference's sort decides
-            full_sort(entry);
-            std::vector<int> where((size_t)n, 0);
-            for (size_t i = 0; i < entry.size(); i++) where[(size_t)entry[i].iid] = (int)i;
-            for (int j = 0; j < npos; j++) emit(where[(size_t)Q.pos_item[(size_t)j]]);
-        } else {
-            for (int j = 0; j < npos; j++) emit(cnt[(size_t)j]);
-        }
+        if (ties) host_sort();   // positions inside a group of equal scores: the reference's sort decides
+        else for (int j = 0; j < npos; j++) C.vals.push_back(cnt[(size_t)j]);
+    }
+    if (C.pending || !C.vals.empty()) chunks_.push_back(std::move(C));
+}
+
+// results of the resolved sections, in section order, to the caller's buffer
+void Ranker::flush_chunks() {
+    while (!chunks_.empty()) {
+        RankChunk &c = chunks_.front();
+        if (c.pending) { c.vals = c.fut.get(); c.pending = false; }
+        for (int v : c.vals) { if (out_n_ < out_cap_ && out_ptr_) out_ptr_[out_n_] = v; out_n_++; }
+        chunks_.pop_front();
     }
 }
 
 void Ranker::drain_quietly() {   // after an error: nothing of the sections in flight is reported
     (void)hipStreamSynchronize(eng_->stream_);
     pending_.clear();
+    for (RankChunk &c : chunks_) if (c.pending) { try { (void)c.fut.get(); } catch (...) {} }
+    chunks_.clear();
 }
 
 long Ranker::rank(int *out, long cap) {
@@ -360,6 +386,7 @@ long Ranker::rank(int *out, long cap) {
     enqueue();
     if (deferred_) return 0;
     while (!pending_.empty()) resolve();
+    flush_chunks();
     return out_n_;
 }
 
@@ -373,6 +400,7 @@ long Ranker::process_rows(int num_row, const float *row_label, const int *row_pt
             process(row_label[r], p1 - p0, p2 - p1, p3 - p2, feat_index + p0, feat_value + p0, nullptr, 0);
         }
         while (!pending_.empty()) resolve();
+        flush_chunks();
     } catch (...) {
         deferred_ = false;
         drain_quietly();
