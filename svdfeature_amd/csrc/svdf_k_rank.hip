@@ -133,7 +133,7 @@ __global__ __launch_bounds__(64) void k_rank_user(const DevParams P, const unsig
     __syncthreads();
     const int *pos = reinterpret_cast<const int *>(stage + 2 * S.nu);
     for (int j = lane; j < S.npos; j += 64)
-        pos_score[j] = 0.0f + rank_lane_score<1>(P.k, cap, reinterpret_cast<const float4 *>(tus), ifT + pos[j], ibias[pos[j]]);
+        pos_score[j] = 0.0f + rank_lane_score<8>(P.k, cap, reinterpret_cast<const float4 *>(tus), ifT + pos[j], ibias[pos[j]]);
 }
 
 // proc_spec (:739-747) for the special samples of one user section (at most one per candidate, the last one given):
