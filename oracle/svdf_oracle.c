@@ -1080,6 +1080,9 @@ void svdo_ranker_init(svdo_ranker *r, int num_item_set) { /* :666-685 */
     r->tmp_ufactor = (float *)calloc(row, sizeof(float));
     r->tmp_ifactor = (float *)calloc(row, sizeof(float));
     r->tmp_ufeedback = (float *)calloc(row, sizeof(float));
+    /* user-group models: tmp_ufeedback = clone( model.W_user[0] ) (:680-682) -- a COPY of user row 0 (CloneSolver,
+     * apex_tensor_func_decl_common.h:265-274), which user sections see until the first block arrives */
+    if (t->mtype[0] == 1 && t->mp.num_user > 0) memcpy(r->tmp_ufeedback, t->W_user, sizeof(float) * (size_t)t->mp.num_factor);
     r->tmp_ifactors = (float *)calloc((size_t)(num_item_set > 0 ? num_item_set : 1) * (size_t)t->pitch + 4, sizeof(float));
     r->bias_ifactors = (float *)calloc((size_t)num_item_set + 1, sizeof(float));
     r->item_score = (float *)calloc((size_t)num_item_set + 1, sizeof(float));

@@ -55,7 +55,14 @@ void Ranker::init_ranker(int num_item_set) {                   // :666-685
     d_tag_.reserve((size_t)std::max(num_item_set, 1));
     d_tu_.reserve(pitch + 4);
     d_fb_.reserve(pitch + 4);
-    RCHECK(hipMemsetAsync(d_fb_.p, 0, (pitch + 4) * sizeof(float), eng_->stream_));   // tmp_ufeedback before the first block
+    RCHECK(hipMemsetAsync(d_fb_.p, 0, (pitch + 4) * sizeof(float), eng_->stream_));
+    if (eng_->user_group() && eng_->mp_.num_user > 0) {
+        // tmp_ufeedback = clone( model.W_user[0] ) (:680-682) is a COPY of user row 0 (CloneSolver,
+        // apex_tensor_func_decl_common.h:265-274): what user sections see until the first block arrives
+        const DevParams &P = eng_->params();
+        RCHECK(hipMemcpyAsync(d_fb_.p, P.W + (size_t)P.user_off * (size_t)P.pitch, (size_t)eng_->mp_.num_factor * sizeof(float), hipMemcpyDeviceToDevice,
+                              eng_->stream_));
+    }
     RCHECK(hipMemsetAsync(d_tag_.p, 0, (size_t)std::max(num_item_set, 1), eng_->stream_));
     tag_.assign((size_t)num_item_set, 0);
     tagged_.clear();

@@ -7,7 +7,7 @@ import pytest
 import cases
 import svdfeature_amd as sa
 from oracle import oracle
-from test_ranker import GOLD_PATH, RANK_CASES, run_ranker, trained_model
+from test_ranker import GOLD_PATH, RANK_CASES, run_ranker, trained_model, user_group_lines_before_any_block
 
 pytestmark = pytest.mark.gpu
 
@@ -143,6 +143,12 @@ def test_ranker_bulk_rows_pipelined_equals_line_by_line(top_k, spec, tmp_path):
     np.testing.assert_array_equal(outs["lines"], outs["oracle"])
     np.testing.assert_array_equal(outs["bulk"], outs["oracle"])
     assert hosted["bulk"] == hosted["lines"]   # the same sections needed the reference's sort either way
+
+
+def test_ranker_initial_feedback_is_user_row_zero(tmp_path):
+    a = user_group_lines_before_any_block(lambda f: oracle.OracleRanker("port", f, 0), str(tmp_path))
+    b = user_group_lines_before_any_block(lambda f: sa.Ranker(f, 0), str(tmp_path))
+    np.testing.assert_array_equal(a, b)
 
 
 def test_ranker_errors():

@@ -87,6 +87,28 @@ def test_oracle_ranker_matches_live_reference(name, tmp_path):
     np.testing.assert_array_equal(a, b)
 
 
+def user_group_lines_before_any_block(make, tmp):
+    """a user-group model whose user sections arrive as plain lines, no block yet: tmp_ufeedback is still the clone of
+    W_user[0] made by init_ranker (apex_svd_base.h:680-682)"""
+    path, extra, (nu, ni, ng) = trained_model(tmp, 1, 9, False)
+    items, sections = cases.ranker_stream(30, 6, nu, ni, ng, seed=3)
+    r = make(1)
+    r.set_param("top_k", "0")
+    r.load_model(path)
+    r.init_ranker(items.num_row)
+    out = [r.process_rows(items)] + [r.process_rows(s) for s in sections]
+    r.close()
+    return np.concatenate(out).astype(np.int32)
+
+
+@pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference (oracle/_ref) not present")
+def test_oracle_ranker_initial_feedback_is_user_row_zero(tmp_path):
+    a = user_group_lines_before_any_block(lambda f: oracle.OracleRanker("port", f, 0), str(tmp_path))
+    b = user_group_lines_before_any_block(lambda f: oracle.OracleRanker("reference", f, 0), str(tmp_path))
+    np.testing.assert_array_equal(a, b)
+    assert a.size > 0
+
+
 def test_rmse_accumulator_restatement():
     rng = np.random.default_rng(1)
     p, l = rng.uniform(1, 5, 100000).astype(np.float32), rng.integers(1, 6, 100000).astype(np.float32)
