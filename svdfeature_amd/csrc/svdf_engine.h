@@ -479,7 +479,6 @@ class Ranker {
         return what == 0 ? n_sections_ : (what == 1 ? n_host_sorts_ : (what == 2 ? (int64_t)pos_item_.size() : -1));
     }
   private:
-    TypeParam mtype_;
     std::unique_ptr<Engine> eng_;   // owns the model in HBM, the side tables and the kernel parameter block
     int top_k_ = 0, num_item_set_ = 0, num_item_processed_ = 0;
     long items_on_device_ = 0;
