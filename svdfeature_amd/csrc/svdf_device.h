@@ -396,6 +396,15 @@ __device__ __forceinline__ void store_row(float *W, size_t row, int pitch, int L
     *reinterpret_cast<float4 *>(W + row * (size_t)pitch + (size_t)L * 4) = v;
 }
 
+// row load with the nontemporal hint (load_mode knob, k_basicmf only: rows of a level are read once)
+typedef float svdf_f4_ld __attribute__((ext_vector_type(4)));
+template <int LPI>
+__device__ __forceinline__ float4 load_row_nt(const float *W, size_t row, int pitch, int L, int k) {
+    if (LPI * 4 > k && L * 4 >= k) return f4zero();
+    const svdf_f4_ld v = __builtin_nontemporal_load(reinterpret_cast<const svdf_f4_ld *>(W + row * (size_t)pitch + (size_t)L * 4));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // row store with a cache policy: 0 plain (line stays dirty in the XCD's L2 until the kernel ends),
 // 1 nontemporal hint, 2 sc1 write-through (the line leaves L2 as soon as it is written)
 typedef float svdf_f4 __attribute__((ext_vector_type(4)));

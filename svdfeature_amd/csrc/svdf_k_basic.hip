@@ -46,8 +46,13 @@ __device__ __forceinline__ void basicmf_wave(const DevParams &P, const BasicSche
     for (int g = 0; g < G; g++) {
         p[g] = f4zero(); q[g] = f4zero(); bu[g] = 0.0f; bi[g] = 0.0f;
         if (valid[g]) {
-            p[g] = load_row<LPI>(P.W, ur[g], pitch, L, k);
-            q[g] = load_row<LPI>(P.W, ir[g], pitch, L, k);
+            if (P.load_mode) {
+                p[g] = load_row_nt<LPI>(P.W, ur[g], pitch, L, k);
+                q[g] = load_row_nt<LPI>(P.W, ir[g], pitch, L, k);
+            } else {
+                p[g] = load_row<LPI>(P.W, ur[g], pitch, L, k);
+                q[g] = load_row<LPI>(P.W, ir[g], pitch, L, k);
+            }
             if (use_ubias) bu[g] = P.bias[ur[g]];
             bi[g] = P.bias[ir[g]];
         }
