@@ -46,7 +46,7 @@ __device__ __forceinline__ void basicmf_wave(const DevParams &P, const BasicSche
     for (int g = 0; g < G; g++) {
         p[g] = f4zero(); q[g] = f4zero(); bu[g] = 0.0f; bi[g] = 0.0f;
         if (valid[g]) {
-            if (P.load_mode) {
+            if (P.load_mode & 1) {   // default: a level reads each row exactly once -- nontemporal hint, -2.2 ... -4.2 % per pass (tools/ab_knob.py)
                 p[g] = load_row_nt<LPI>(P.W, ur[g], pitch, L, k);
                 q[g] = load_row_nt<LPI>(P.W, ir[g], pitch, L, k);
             } else {

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(256) void k_fewrow_fast(const DevParams P, const Fu
     for (int a = 0; a < NU; a++) {
         p[a] = f4zero(); bu[a] = 0.0f;
         if (ur[a] != SLOT_ABSENT) {
-            p[a] = load_row<LPI>(P.W, P.user_off + ur[a], pitch, L, k);
+            p[a] = (P.load_mode & 1) ? load_row_nt<LPI>(P.W, P.user_off + ur[a], pitch, L, k) : load_row<LPI>(P.W, P.user_off + ur[a], pitch, L, k);
             if (use_ubias) bu[a] = P.bias[P.user_off + ur[a]];
         }
     }
@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void k_fewrow_fast(const DevParams P, const Fu
     for (int b = 0; b < NI; b++) {
         q[b] = f4zero(); bi[b] = 0.0f;
         if (ir[b] != SLOT_ABSENT) {
-            q[b] = load_row<LPI>(P.W, P.item_off + ir[b], pitch, L, k);
+            q[b] = (P.load_mode & 1) ? load_row_nt<LPI>(P.W, P.item_off + ir[b], pitch, L, k) : load_row<LPI>(P.W, P.item_off + ir[b], pitch, L, k);
             bi[b] = P.bias[P.item_off + ir[b]];
         }
     }
