@@ -582,6 +582,7 @@ const DevParams &Engine::params() {
     P.user_group = user_group() ? 1 : 0;
     P.store_mode = store_mode_;
     P.load_mode = load_mode_;
+    P.basic_i8 = basic_i8_;
     P.xcd_remap = xcd_remap_;
     P.imfb_disable = imfb_disable_;
     P.fewrow_fast = fewrow_fast_ ? 1 : 0;
@@ -2281,6 +2282,7 @@ int Engine::set_knob(const char *name, long value) {
     }
     if (!strcmp(name, "xcd_remap")) { xcd_remap_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "hot_reduce")) { hot_reduce_ = value != 0; params_dirty_ = true; return 0; }
+    if (!strcmp(name, "basic_i8")) { check(value >= 0 && value <= 1, "basic_i8 must be 0 or 1"); basic_i8_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "load_mode")) { check(value >= 0 && value <= 1, "load_mode must be 0 or 1"); load_mode_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "store_mode")) { check(value >= 0 && value <= 2, "store_mode must be 0, 1 or 2"); store_mode_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "sort_batches")) { check(value >= 0 && value <= 2, "sort_batches must be 0, 1 (by item) or 2 (by user)"); sort_batches_ = (int)value; return 0; }

@@ -117,15 +117,18 @@ def test_single_instance_calls_interleaved_with_predict():
     assert trs[0].counter(0) == d.num_row
 
 
+@pytest.mark.parametrize("i8", [0, 1])
 @pytest.mark.parametrize("gpw", [1, 2, 4, 8])
-def test_resident_dataset_basicmf_two_million_ratings(gpw):
+def test_resident_dataset_basicmf_two_million_ratings(gpw, i8):
     """svdf_dataset_from_triples + svdf_train_dataset (the bench path) on 2M ratings, 50k x 5k, k=64,
-    two passes: byte-identical parameters vs the sequential oracle, for every groups_per_wave."""
-    nu, ni, n = 50000, 5000, 2_000_000 if gpw == 4 else 300_000
+    two passes: byte-identical parameters vs the sequential oracle, for every groups_per_wave and both row layouts of the
+    specialised kernel (16 lanes per row; 8 lanes with two chunks each, k_basicmf_i8)."""
+    nu, ni, n = 50000, 5000, 2_000_000 if gpw == 4 else 300_000 + 13 * gpw
     u, i, r = cases.planted_triples(n, nu, ni, seed=42)
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
     t = hip(0, 0)
     t.set_knob("groups_per_wave", gpw)
+    t.set_knob("basic_i8", i8)
     o = port(0, 0)
     for x in (t, o):
         x.seed(10)
@@ -789,8 +792,9 @@ def test_svdpp_wave_path_general_configuration(variant, k):
         np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
 
 
+@pytest.mark.parametrize("i8", [0, 1])
 @pytest.mark.parametrize("wd", [(0.00005, 0.00002), (0.0, 0.0), (0.004, 0.0)])
-def test_specialised_kernels_with_decay_factors_that_round_to_one(wd):
+def test_specialised_kernels_with_decay_factors_that_round_to_one(wd, i8):
     """The specialised basicMF and SVD++ kernels hoist the L2 decay factors and apply "skip the multiply when |s-1| <= 1e-6"
     as a multiply by exactly 1.0f: with lr*wd below 1e-6 (or zero) the factor snaps to one -- results must still be the
     oracle's bit for bit."""
@@ -800,6 +804,7 @@ def test_specialised_kernels_with_decay_factors_that_round_to_one(wd):
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64, wd_user=wd_user, wd_item=wd_item,
                            wd_user_bias=0.0, wd_item_bias=0.00001)
     o, t = _ready(port, 0, conf), _ready(hip, 0, conf)
+    t.set_knob("basic_i8", i8)
     ds = t.dataset_from_triples(u, i, r)
     assert ds.kind == 0
     d = sa.CSRData.from_triples(u, i, r)
@@ -808,6 +813,8 @@ def test_specialised_kernels_with_decay_factors_that_round_to_one(wd):
         t.train_dataset(ds)
     for name in ("W_user", "W_item", "u_bias", "i_bias"):
         np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+    if i8:
+        return
     blocks = cases.user_blocks(150, nu, ni, ni, seed=18, max_rows=30, max_fb=20)
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=128, num_ufeedback=ni, wd_ufeedback=0.00001,
                            ufeedback_init_sigma=0.01, wd_user=wd_user, wd_item=wd_item)
