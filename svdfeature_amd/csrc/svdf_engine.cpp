@@ -2276,7 +2276,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "graph_min_levels")) { check(value >= 1, "graph_min_levels must be >= 1"); graph_min_levels_ = (int)value; return 0; }
     if (!strcmp(name, "stage_window")) { check(value >= 1, "stage_window must be >= 1"); stage_window_ = value; window_set_ = true; return 0; }
     if (!strcmp(name, "groups_per_wave")) {
-        check(value == 0 || value == 1 || value == 2 || value == 4 || value == 8, "groups_per_wave must be 0 (auto), 1, 2, 4 or 8");
+        check(value >= 0 && value <= 8 && value != 7, "groups_per_wave must be 0 (auto), 1 ... 6 or 8");
         groups_per_wave_ = (int)value;
         return 0;
     }

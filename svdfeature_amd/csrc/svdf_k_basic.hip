@@ -279,6 +279,9 @@ static void launch_basicmf_lpi(const DevParams &P, const BasicSchedule &S, long 
     switch (G) {
     case 1: go(std::integral_constant<int, 1>()); break;
     case 2: go(std::integral_constant<int, 2>()); break;
+    case 3: go(std::integral_constant<int, 3>()); break;
+    case 5: go(std::integral_constant<int, 5>()); break;
+    case 6: go(std::integral_constant<int, 6>()); break;
     case 8: go(std::integral_constant<int, 8>()); break;
     default: go(std::integral_constant<int, 4>()); break;
     }
