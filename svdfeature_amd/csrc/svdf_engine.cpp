@@ -583,6 +583,7 @@ const DevParams &Engine::params() {
     P.store_mode = store_mode_;
     P.load_mode = load_mode_;
     P.basic_i8 = basic_i8_;
+    P.fewrow_i16 = fewrow_i16_;
     P.xcd_remap = xcd_remap_;
     P.imfb_disable = imfb_disable_;
     P.fewrow_fast = fewrow_fast_ ? 1 : 0;
@@ -2282,6 +2283,7 @@ int Engine::set_knob(const char *name, long value) {
     }
     if (!strcmp(name, "xcd_remap")) { xcd_remap_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "hot_reduce")) { hot_reduce_ = value != 0; params_dirty_ = true; return 0; }
+    if (!strcmp(name, "fewrow_i16")) { check(value >= 0 && value <= 1, "fewrow_i16 must be 0 or 1"); fewrow_i16_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "basic_i8")) { check(value >= 0 && value <= 1, "basic_i8 must be 0 or 1"); basic_i8_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "load_mode")) { check(value >= 0 && value <= 1, "load_mode must be 0 or 1"); load_mode_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "store_mode")) { check(value >= 0 && value <= 2, "store_mode must be 0, 1 or 2"); store_mode_ = (int)value; params_dirty_ = true; return 0; }

@@ -88,6 +88,7 @@ struct DevParams {
     unsigned imfb_disable;    // extend_type 2: bit l = ufeedback_disable_level l (apex_multi_imfb.h:58-67)
     int fewrow_fast;          // knob: 1 = few-row data sets in the usual configuration run k_fewrow_fast instead of k_fused
     int store_mode;           // row-store cache policy of k_basicmf: 0 plain, 1 nontemporal, 2 sc1 write-through
+    int fewrow_i16;           // k = 128 few-row kernel: sixteen lanes per row, 4 instances per wave (k_fewrow_i16)
     int basic_i8;             // k = 64 basicMF: eight lanes per row, 8 instances per wave instruction (k_basicmf_i8)
     int load_mode;            // row-load cache policy of k_basicmf / k_fewrow_fast: 1 (default) nontemporal hint -- a level reads each row once,
                               // measured -2.2 ... -4.2 % per pass; 0 plain

@@ -381,6 +381,49 @@ def test_few_row_fused_kernel_matches_oracle_and_general_kernel(shape, k):
     np.testing.assert_array_equal(t_ds.predict_dataset(ds).view(np.uint32), o.predict_batch(d).view(np.uint32))
 
 
+@pytest.mark.parametrize("i16", [0, 1])
+@pytest.mark.parametrize("shape", ["pairs_sigmoid", "one_by_one", "two_by_two_absent"])
+def test_few_row_kernel_k128_both_row_layouts(shape, i16):
+    """k = 128 through the specialised few-row kernel in both layouts (32 lanes per row; 16 lanes with two chunks each,
+    k_fewrow_i16): rank pairs with the sigmoid rank loss, plain (user, item) rows, rows with one or two user / item ids
+    (absent slots), resident data sets whose last wave is partly filled -- parameters identical to the oracle's."""
+    nu, ni = 500, 180
+    rng = np.random.default_rng(7)
+    if shape == "pairs_sigmoid":
+        pu, pp, pq = cases.planted_pairs(9001, nu, ni, seed=3)
+        d = sa.pairs_as_csr(pu, pp, pq)
+        active, extra = 3, dict(no_user_bias=1)
+    elif shape == "one_by_one":
+        u, i, r = cases.planted_triples(9003, nu, ni, seed=4)
+        d = sa.CSRData.from_triples(u, i, r)
+        active, extra = 0, dict(wd_user=0.00001)   # decay factor that snaps to one
+    else:
+        rows = []
+        for _ in range(7002):
+            us = rng.choice(nu, int(rng.integers(1, 3)), replace=False)
+            its = rng.choice(ni, int(rng.integers(1, 3)), replace=False)
+            rows.append((float(rng.integers(1, 6)), [], [(int(x), float(np.float32(rng.uniform(0.2, 1.0)))) for x in sorted(us)],
+                         [(int(x), float(np.float32(rng.uniform(0.2, 1.0)))) for x in sorted(its)]))
+        d = sa.CSRData.from_rows(rows)
+        active, extra = 0, {}
+    conf = cases.conf_with(cases.PAIR_CONF if shape == "pairs_sigmoid" else cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=128,
+                           wd_user_bias=0.002, wd_item_bias=0.001, learning_rate=0.01, ui_init_sigma=0.05, **extra)
+    o, t = port(0, active), hip(0, active)
+    for x in (o, t):
+        x.seed(12)
+        for kk, v in conf:
+            x.set_param(kk, v)
+        x.init_model()
+        x.init_trainer()
+    t.set_knob("fewrow_i16", i16)
+    ds = t.dataset_from_csr(d)
+    for _ in range(2):
+        o.update_batch(d)
+        t.train_dataset(ds)
+    for name in ("W_user", "W_item", "u_bias", "i_bias"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+
+
 @pytest.mark.parametrize("k", [3, 10, 16, 33, 64, 100, 128, 130, 192, 203, 256])
 @pytest.mark.parametrize("nobias", [0, 1])
 def test_svdpp_simple_unit_fast_path_and_block_dataset(k, nobias):
