@@ -93,136 +93,158 @@ __global__ __launch_bounds__(256) void k_fewrow_fast(const DevParams P, const Fu
     }
 }
 
-// ---- k = 128 with SIXTEEN lanes per row (fewrow_i16 knob): a lane holds chunks m and m + 16 of a row (two coalesced 256-byte pieces
-// per instance and load instruction), one instance per 16-lane DPP row, four per wave instead of two -- the layout idea of
-// k_basicmf_i8 (svdf_k_basic.hip): every wave instruction serves twice the instances.  The dot product is the chain of
-// group_dot<32>: chunks 0..15 through the first slots (15 row_shr:1 steps), the finished sums rotate from lane 15 to lane 0
-// (row_ror:1) and are folded into chunk 16's addend, then chunks 16..31 through the second slots.  Same additions, same order.
-__device__ __forceinline__ float dpp_row_shr1f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xf, 0xf, true)); }
-__device__ __forceinline__ float dpp_row_ror1f(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false)); }
-__device__ __forceinline__ float dot128_i16(const float4 a0, const float4 a1, const float4 b0, const float4 b1, int m, int lane) {
-    const float c0 = a0.x * b0.x, c1 = a0.y * b0.y, c2 = a0.z * b0.z, c3 = a0.w * b0.w;   // chunk m
-    float d0 = a1.x * b1.x, d1 = a1.y * b1.y, d2 = a1.z * b1.z, d3 = a1.w * b1.w;         // chunk m + 16
-    float s0 = 0.0f + c0, s1 = 0.0f + c1, s2 = 0.0f + c2, s3 = 0.0f + c3;
+// ---- full rows with FEWER lanes per row (fewrow_i16 knob): a lane holds V chunks of a row -- chunk m, m + LANES, m + 2 LANES, ... (V
+// coalesced pieces of 16 * LANES bytes per instance, one per load instruction) --, the T = 16 / LANES instances of a 16-lane DPP row are
+// interleaved lane by lane (instance a on lanes T m + a), 64 / LANES instances per wave instead of 64 / (LANES V): the layout idea of
+// k_basicmf_i8 (svdf_k_basic.hip), every wave instruction serves V times the instances.  The dot product is the reference's chain:
+// the chunks of slot 0 in lane order (LANES - 1 row_shr:T steps), the finished sums rotate from the row's last lanes to its first
+// (row_ror:T) and are folded into the addend of the next slot's first chunk -- the carry trick of group_dot<32> --, and so on
+// through the slots.  Same additions in the same order.  k = 128: LANES = 16, V = 2 (one instance per DPP row).
+template <int T> __device__ __forceinline__ float dpp_shr_t(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + T, 0xf, 0xf, true));
+}
+template <int T> __device__ __forceinline__ float dpp_ror_t(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + T, 0xf, 0xf, false));
+}
+template <int LANES, int V>
+__device__ __forceinline__ float dot_slots(const float4 (&a)[V], const float4 (&b)[V], int m, int lane) {
+    constexpr int T = 16 / LANES;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
 #pragma unroll
-    for (int t = 1; t < 16; t++) {
-        s0 = dpp_row_shr1f(s0) + c0; s1 = dpp_row_shr1f(s1) + c1; s2 = dpp_row_shr1f(s2) + c2; s3 = dpp_row_shr1f(s3) + c3;
-    }
-    const float k0 = dpp_row_ror1f(s0), k1 = dpp_row_ror1f(s1), k2 = dpp_row_ror1f(s2), k3 = dpp_row_ror1f(s3);
-    if (m == 0) { d0 = k0 + d0; d1 = k1 + d1; d2 = k2 + d2; d3 = k3 + d3; }
-    s0 = 0.0f + d0; s1 = 0.0f + d1; s2 = 0.0f + d2; s3 = 0.0f + d3;
+    for (int v = 0; v < V; v++) {
+        float c0 = a[v].x * b[v].x, c1 = a[v].y * b[v].y, c2 = a[v].z * b[v].z, c3 = a[v].w * b[v].w;   // chunk m + v * LANES
+        if (v > 0) {
+            const float k0 = dpp_ror_t<T>(s0), k1 = dpp_ror_t<T>(s1), k2 = dpp_ror_t<T>(s2), k3 = dpp_ror_t<T>(s3);
+            if (m == 0) { c0 = k0 + c0; c1 = k1 + c1; c2 = k2 + c2; c3 = k3 + c3; }
+        }
+        s0 = 0.0f + c0; s1 = 0.0f + c1; s2 = 0.0f + c2; s3 = 0.0f + c3;
 #pragma unroll
-    for (int t = 1; t < 16; t++) {
-        s0 = dpp_row_shr1f(s0) + d0; s1 = dpp_row_shr1f(s1) + d1; s2 = dpp_row_shr1f(s2) + d2; s3 = dpp_row_shr1f(s3) + d3;
+        for (int t = 1; t < LANES; t++) {
+            s0 = dpp_shr_t<T>(s0) + c0; s1 = dpp_shr_t<T>(s1) + c1; s2 = dpp_shr_t<T>(s2) + c2; s3 = dpp_shr_t<T>(s3) + c3;
+        }
     }
     const float h = (s0 + s2) + (s1 + s3);
-    return __shfl(h, (lane & ~15) + 15, 64);
+    return __shfl(h, (lane & ~15) + T * (LANES - 1) + (lane & (T - 1)), 64);
 }
 
-template <int NU, int NI, int G>
-__global__ __launch_bounds__(256) void k_fewrow_i16(const DevParams P, const FusedSchedule S, long begin, long end) {
+template <int LANES, int V, int NU, int NI>
+__global__ __launch_bounds__(256) void k_fewrow_slots(const DevParams P, const FusedSchedule S, long begin, long end) {
+    constexpr int T = 16 / LANES;          // instances interleaved in one DPP row
+    constexpr int IPW = 64 / LANES;        // instances per wave
+    constexpr int K = 4 * LANES * V;
     const int lane = threadIdx.x & 63;
-    const int m = lane & 15;
-    const int gslot = lane >> 4;
+    const int m = (lane & 15) / T;
+    const int gslot = (lane >> 4) * T + (lane & (T - 1));
     long tile = blockIdx.x;
     if (P.xcd_remap) tile = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const long wave = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long w0 = begin + wave * (4L * G);
-    if (w0 >= end) return;
+    const long s = begin + wave * (long)IPW + gslot;
+    if (begin + wave * (long)IPW >= end) return;
+    const bool valid = s < end;
+    const long sc = valid ? s : begin;
     const int pitch = P.pitch;
     const bool use_ubias = P.no_user_bias == 0;
 
-    unsigned ur[G][NU], ir[G][NI];
-    float label[G], ua[G][NU], ia[G][NI], bu[G][NU], bi[G][NI];
-    float4 p0[G][NU], p1[G][NU], q0[G][NI], q1[G][NI];
+    unsigned ur[NU], ir[NI];
+    float ua[NU], ia[NI], bu[NU], bi[NI];
+    float4 p[NU][V], q[NI][V];
+    const float label = S.label[sc];
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-        const long s = w0 + 4L * g + gslot;
-        const bool valid = s < end;
-        const long sc = valid ? s : begin;
-        label[g] = S.label[sc];
+    for (int a = 0; a < NU; a++) { ur[a] = valid ? S.uidx[a][sc] : (unsigned)SLOT_ABSENT; ua[a] = S.uval[a][sc]; }
 #pragma unroll
-        for (int a = 0; a < NU; a++) { ur[g][a] = valid ? S.uidx[a][sc] : (unsigned)SLOT_ABSENT; ua[g][a] = S.uval[a][sc]; }
+    for (int b = 0; b < NI; b++) { ir[b] = valid ? S.iidx[b][sc] : (unsigned)SLOT_ABSENT; ia[b] = S.ival[b][sc]; }
 #pragma unroll
-        for (int b = 0; b < NI; b++) { ir[g][b] = valid ? S.iidx[b][sc] : (unsigned)SLOT_ABSENT; ia[g][b] = S.ival[b][sc]; }
+    for (int a = 0; a < NU; a++) {
+#pragma unroll
+        for (int v = 0; v < V; v++) p[a][v] = f4zero();
+        bu[a] = 0.0f;
+        if (ur[a] != SLOT_ABSENT) {
+#pragma unroll
+            for (int v = 0; v < V; v++) p[a][v] = load_row_nt<K / 4>(P.W, P.user_off + ur[a], pitch, m + v * LANES, K);
+            if (use_ubias) bu[a] = P.bias[P.user_off + ur[a]];
+        }
     }
 #pragma unroll
-    for (int g = 0; g < G; g++) {
+    for (int b = 0; b < NI; b++) {
 #pragma unroll
-        for (int a = 0; a < NU; a++) {
-            p0[g][a] = f4zero(); p1[g][a] = f4zero(); bu[g][a] = 0.0f;
-            if (ur[g][a] != SLOT_ABSENT) {
-                p0[g][a] = load_row_nt<32>(P.W, P.user_off + ur[g][a], pitch, m, 128);
-                p1[g][a] = load_row_nt<32>(P.W, P.user_off + ur[g][a], pitch, m + 16, 128);
-                if (use_ubias) bu[g][a] = P.bias[P.user_off + ur[g][a]];
-            }
-        }
+        for (int v = 0; v < V; v++) q[b][v] = f4zero();
+        bi[b] = 0.0f;
+        if (ir[b] != SLOT_ABSENT) {
 #pragma unroll
-        for (int b = 0; b < NI; b++) {
-            q0[g][b] = f4zero(); q1[g][b] = f4zero(); bi[g][b] = 0.0f;
-            if (ir[g][b] != SLOT_ABSENT) {
-                q0[g][b] = load_row_nt<32>(P.W, P.item_off + ir[g][b], pitch, m, 128);
-                q1[g][b] = load_row_nt<32>(P.W, P.item_off + ir[g][b], pitch, m + 16, 128);
-                bi[g][b] = P.bias[P.item_off + ir[g][b]];
-            }
+            for (int v = 0; v < V; v++) q[b][v] = load_row_nt<K / 4>(P.W, P.item_off + ir[b], pitch, m + v * LANES, K);
+            bi[b] = P.bias[P.item_off + ir[b]];
         }
     }
     const float dec_u = snap_to_one(1.0f - P.lr * P.wd_user), dec_i = snap_to_one(1.0f - P.lr * P.wd_item);
     const float dec_ub = 1.0f - P.lr * P.wd_user_bias, dec_ib = 1.0f - P.lr * P.wd_item_bias;
+    // the arithmetic of k_fewrow_fast<K / 4, NU, NI, true>, V chunks per lane
+    double bs = 0.0;
+    if (use_ubias) {
+#pragma unroll
+        for (int a = 0; a < NU; a++) if (ur[a] != SLOT_ABSENT) bs += (double)(ua[a] * bu[a]);
+    }
+#pragma unroll
+    for (int b = 0; b < NI; b++) if (ir[b] != SLOT_ABSENT) bs += (double)(ia[b] * bi[b]);
+    double sum = (double)P.base_score + bs;
+    float4 tu[V], ti[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) { tu[v] = f4zero(); ti[v] = f4zero(); }
+#pragma unroll
+    for (int a = 0; a < NU; a++) if (ur[a] != SLOT_ABSENT) {
+#pragma unroll
+        for (int v = 0; v < V; v++) axpy4(tu[v], p[a][v], ua[a]);
+    }
+#pragma unroll
+    for (int b = 0; b < NI; b++) if (ir[b] != SLOT_ABSENT) {
+#pragma unroll
+        for (int v = 0; v < V; v++) axpy4(ti[v], q[b][v], ia[b]);
+    }
+    sum += (double)dot_slots<LANES, V>(tu, ti, m, lane);
+    const float pred = map_active((float)sum, P.active_type);
+    const float err = cal_grad(label, pred, P.active_type) * 1.0f;
     const float lr = P.lr;
 #pragma unroll
-    for (int g = 0; g < G; g++) {
-        // the arithmetic of k_fewrow_fast<32, NU, NI, true>, two chunks per lane
-        double bs = 0.0;
-        if (use_ubias) {
+    for (int a = 0; a < NU; a++) {
+        if (ur[a] == SLOT_ABSENT) continue;
+        const float su = lr * err * ua[a];
 #pragma unroll
-            for (int a = 0; a < NU; a++) if (ur[g][a] != SLOT_ABSENT) bs += (double)(ua[g][a] * bu[g][a]);
+        for (int v = 0; v < V; v++) {
+            float4 w = p[a][v];
+            axpy4(w, ti[v], su);
+            w.x = w.x * dec_u; w.y = w.y * dec_u; w.z = w.z * dec_u; w.w = w.w * dec_u;
+            store_row<K / 4>(P.W, P.user_off + ur[a], pitch, m + v * LANES, K, w);
         }
+        if (use_ubias) P.bias[P.user_off + ur[a]] = (bu[a] + su) * dec_ub;
+    }
 #pragma unroll
-        for (int b = 0; b < NI; b++) if (ir[g][b] != SLOT_ABSENT) bs += (double)(ia[g][b] * bi[g][b]);
-        double sum = (double)P.base_score + bs;
-        float4 tu0 = f4zero(), tu1 = f4zero(), ti0 = f4zero(), ti1 = f4zero();
+    for (int b = 0; b < NI; b++) {
+        if (ir[b] == SLOT_ABSENT) continue;
+        const float si = lr * err * ia[b];
 #pragma unroll
-        for (int a = 0; a < NU; a++) if (ur[g][a] != SLOT_ABSENT) { axpy4(tu0, p0[g][a], ua[g][a]); axpy4(tu1, p1[g][a], ua[g][a]); }
-#pragma unroll
-        for (int b = 0; b < NI; b++) if (ir[g][b] != SLOT_ABSENT) { axpy4(ti0, q0[g][b], ia[g][b]); axpy4(ti1, q1[g][b], ia[g][b]); }
-        sum += (double)dot128_i16(tu0, tu1, ti0, ti1, m, lane);
-        const float pred = map_active((float)sum, P.active_type);
-        const float err = cal_grad(label[g], pred, P.active_type) * 1.0f;
-#pragma unroll
-        for (int a = 0; a < NU; a++) {
-            if (ur[g][a] == SLOT_ABSENT) continue;
-            const float su = lr * err * ua[g][a];
-            float4 w0 = p0[g][a], w1 = p1[g][a];
-            axpy4(w0, ti0, su); axpy4(w1, ti1, su);
-            w0.x = w0.x * dec_u; w0.y = w0.y * dec_u; w0.z = w0.z * dec_u; w0.w = w0.w * dec_u;
-            w1.x = w1.x * dec_u; w1.y = w1.y * dec_u; w1.z = w1.z * dec_u; w1.w = w1.w * dec_u;
-            store_row<32>(P.W, P.user_off + ur[g][a], pitch, m, 128, w0);
-            store_row<32>(P.W, P.user_off + ur[g][a], pitch, m + 16, 128, w1);
-            if (use_ubias) P.bias[P.user_off + ur[g][a]] = (bu[g][a] + su) * dec_ub;
+        for (int v = 0; v < V; v++) {
+            float4 w = q[b][v];
+            axpy4(w, tu[v], si);
+            w.x = w.x * dec_i; w.y = w.y * dec_i; w.z = w.z * dec_i; w.w = w.w * dec_i;
+            store_row<K / 4>(P.W, P.item_off + ir[b], pitch, m + v * LANES, K, w);
         }
-#pragma unroll
-        for (int b = 0; b < NI; b++) {
-            if (ir[g][b] == SLOT_ABSENT) continue;
-            const float si = lr * err * ia[g][b];
-            float4 w0 = q0[g][b], w1 = q1[g][b];
-            axpy4(w0, tu0, si); axpy4(w1, tu1, si);
-            w0.x = w0.x * dec_i; w0.y = w0.y * dec_i; w0.z = w0.z * dec_i; w0.w = w0.w * dec_i;
-            w1.x = w1.x * dec_i; w1.y = w1.y * dec_i; w1.z = w1.z * dec_i; w1.w = w1.w * dec_i;
-            store_row<32>(P.W, P.item_off + ir[g][b], pitch, m, 128, w0);
-            store_row<32>(P.W, P.item_off + ir[g][b], pitch, m + 16, 128, w1);
-            P.bias[P.item_off + ir[g][b]] = (bi[g][b] + si) * dec_ib;
-        }
+        P.bias[P.item_off + ir[b]] = (bi[b] + si) * dec_ib;
     }
 }
 
-template <int NU, int NI>
-static void launch_fewrow_i16_shape(const DevParams &P, const FusedSchedule &S, long begin, long end, int block_threads, int G, hipStream_t st) {
+template <int LANES, int V, int NU, int NI>
+static void launch_fewrow_slots_shape(const DevParams &P, const FusedSchedule &S, long begin, long end, int block_threads, hipStream_t st) {
     const long n = end - begin;
-    const long per_block = (long)(block_threads / 64) * 4 * G;
+    const long per_block = (long)(block_threads / 64) * (64 / LANES);
     int grid = (int)((n + per_block - 1) / per_block);
     if (P.xcd_remap) grid = (grid + 7) & ~7;
-    hipLaunchKernelGGL((k_fewrow_i16<NU, NI, 1>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
+    hipLaunchKernelGGL((k_fewrow_slots<LANES, V, NU, NI>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
+}
+template <int LANES, int V>
+static void launch_fewrow_slots(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int block_threads, hipStream_t st) {
+    if (max_nu <= 1 && max_ni <= 1) launch_fewrow_slots_shape<LANES, V, 1, 1>(P, S, begin, end, block_threads, st);
+    else if (max_nu <= 1) launch_fewrow_slots_shape<LANES, V, 1, 2>(P, S, begin, end, block_threads, st);
+    else if (max_ni <= 1) launch_fewrow_slots_shape<LANES, V, 2, 1>(P, S, begin, end, block_threads, st);
+    else launch_fewrow_slots_shape<LANES, V, 2, 2>(P, S, begin, end, block_threads, st);
 }
 
 template <int LPI, int NU, int NI>
@@ -249,14 +271,8 @@ bool fewrow_fast_applies(const DevParams &P, const FusedSchedule &S) {
 void launch_fewrow_fast(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int block_threads, hipStream_t st) {
     if (end <= begin) return;
     if (block_threads <= 0) block_threads = 256;
-    if (P.k == 128 && P.fewrow_i16) {
-        const int G = 1;   // row sets per wave (4 instances each); 2 measured slower: 53.0 vs 45.4 ms per 50 M pairs (32-lane layout: 49.0)
-        if (max_nu <= 1 && max_ni <= 1) launch_fewrow_i16_shape<1, 1>(P, S, begin, end, block_threads, G, st);
-        else if (max_nu <= 1) launch_fewrow_i16_shape<1, 2>(P, S, begin, end, block_threads, G, st);
-        else if (max_ni <= 1) launch_fewrow_i16_shape<2, 1>(P, S, begin, end, block_threads, G, st);
-        else launch_fewrow_i16_shape<2, 2>(P, S, begin, end, block_threads, G, st);
-        return;
-    }
+    if (P.k == 128 && P.fewrow_i16 == 1) { launch_fewrow_slots<16, 2>(P, S, max_nu, max_ni, begin, end, block_threads, st); return; }
+    // (eight lanes with four chunks each measured slower at k = 128: 46.7 vs 45.2 ms per 50 M pairs; 32 lanes, one chunk: 48.9)
     SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_fewrow_lpi<LPI>(P, S, max_nu, max_ni, begin, end, block_threads, st));
 }
 
