@@ -168,7 +168,7 @@ def conf_for(a):
 WORKLOADS = {
     # name: (format_type, active_type, default factor, dominant kernel, unit name)
     "basicmf": (0, 0, 64, "k_basicmf_i8<4> at k=64 (8 lanes per row, 32 instances per wave), k_basicmf<k/4,.> otherwise", "instances/s"),
-    "pairwise": (0, 3, 128, "k_fused<32,1,2> (few-row fused kernel, 3 rows per pair)", "pairs/s"),
+    "pairwise": (0, 3, 128, "k_fewrow_slots<16,2,1,2> (few-row kernel, 3 rows per pair, 16 lanes x 2 chunks per row)", "pairs/s"),
     "svdpp": (1, 0, 128, "k_svdpp_wave<2> (one wave per user)", "instances/s"),
     "neighbourhood": (0, 0, 128, "k_fused<32,1,1> (few-row fused kernel, inline global slots)", "instances/s"),
 }

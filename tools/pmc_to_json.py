@@ -8,7 +8,7 @@ import re
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-names = {"basicmf": "k_basicmf", "pairwise": "k_fewrow_fast", "svdpp": "k_svdpp_wave", "neighbourhood": "k_fused"}
+names = {"basicmf": "k_basicmf", "pairwise": "k_fewrow", "svdpp": "k_svdpp_wave", "neighbourhood": "k_fused"}
 out = {}
 for w, kern in names.items():
     cand = glob.glob(os.path.join(src, "*pmc_%s.txt" % w))
