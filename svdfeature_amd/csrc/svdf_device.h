@@ -231,6 +231,38 @@ __device__ __forceinline__ float group_dot(const WideRow<V> &a, const WideRow<V>
     return sum;
 }
 
+// K3 for full rows held V chunks per lane by LANES <= 16 lanes (k = 4 * LANES * V): lane m of an instance holds chunks m, m + LANES,
+// m + 2 LANES, ...; the T = 16 / LANES instances of a 16-lane DPP row are interleaved lane by lane (instance a on lanes T m + a).
+// The chain is the reference's: slot 0's chunks in lane order (LANES - 1 row_shr:T adds), the finished sums rotate from the row's
+// last lanes to its first (row_ror:T) and are folded into the addend of the next slot's first chunk -- a[first] = 0 + (carry + c),
+// the carry trick of group_dot<32> above --, and so on through the slots.  Used by k_basicmf_slots and k_fewrow_slots.
+template <int T> __device__ __forceinline__ float dpp_shr_t(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + T, 0xf, 0xf, true));
+}
+template <int T> __device__ __forceinline__ float dpp_ror_t(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + T, 0xf, 0xf, false));
+}
+template <int LANES, int V>
+__device__ __forceinline__ float dot_slots(const float4 (&a)[V], const float4 (&b)[V], int m, int lane) {
+    constexpr int T = 16 / LANES;
+    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        float c0 = a[v].x * b[v].x, c1 = a[v].y * b[v].y, c2 = a[v].z * b[v].z, c3 = a[v].w * b[v].w;   // chunk m + v * LANES
+        if (v > 0) {
+            const float k0 = dpp_ror_t<T>(s0), k1 = dpp_ror_t<T>(s1), k2 = dpp_ror_t<T>(s2), k3 = dpp_ror_t<T>(s3);
+            if (m == 0) { c0 = k0 + c0; c1 = k1 + c1; c2 = k2 + c2; c3 = k3 + c3; }
+        }
+        s0 = 0.0f + c0; s1 = 0.0f + c1; s2 = 0.0f + c2; s3 = 0.0f + c3;
+#pragma unroll
+        for (int t = 1; t < LANES; t++) {
+            s0 = dpp_shr_t<T>(s0) + c0; s1 = dpp_shr_t<T>(s1) + c1; s2 = dpp_shr_t<T>(s2) + c2; s3 = dpp_shr_t<T>(s3) + c3;
+        }
+    }
+    const float h = (s0 + s2) + (s1 + s3);
+    return __shfl(h, (lane & ~15) + T * (LANES - 1) + (lane & (T - 1)), 64);
+}
+
 // glibc's expf restated for the device (sysdeps/ieee754/flt-32/e_expf.c of glibc >= 2.27, the libm the reference links
 // against; glibc is a system library, not part of the reference tree): x*32/ln2 = k + r, exp(x) = 2^(k/32) * p(r) with a
 // 32-entry table of 2^(i/32) and a cubic in fp64, result rounded to fp32 once.  On x86-64 hosts with FMA the dynamic

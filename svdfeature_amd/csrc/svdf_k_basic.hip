@@ -128,55 +128,36 @@ __global__ __launch_bounds__(256) void k_basicmf(const DevParams P, const BasicS
 }
 
 // =====================================================================================
-// k = 64 with EIGHT lanes per row (basic_i8 knob).  The 16-lane layout above spends its instructions per ROW SET (4 instances per
-// wave instruction): 60 dependent DPP adds for the dot product, ~100 more for addressing, the fp64 bias sums, link and decay -- the
-// arithmetic is ~3.5 us of a 13.9 us launch that memory cannot overlap (anatomy).  Here a lane holds TWO
-// 16-byte chunks of a row, chunk m and chunk m + 8 (two fully coalesced 128-byte pieces per instance and load instruction), and
-// the two instances of a 16-lane DPP row are interleaved lane by lane (instance a on lanes 2m + a), so that the dot product's
-// hand-over is ONE row_shr:2 add per step for both and every wave instruction serves 8 instances.  The chain is the reference's:
-// chunks 0..7 through the first slots (7 steps), the finished sums rotate from lanes 14/15 to lanes 0/1 (row_ror:2) and are folded
-// into chunk 8's addend -- the carry trick of the 32-lane groups in svdf_device.h -- then chunks 8..15 through the second slots.
-// Same additions in the same order as the 16-lane scan; the per-instance instruction count drops by ~40 %.
-__device__ __forceinline__ float dpp_row_shr2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xf, 0xf, true)); }
-__device__ __forceinline__ float dpp_row_ror2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false)); }
-__device__ __forceinline__ float dot64_i8(const float4 a0, const float4 a1, const float4 b0, const float4 b1, int m, int lane) {
-    const float c0 = a0.x * b0.x, c1 = a0.y * b0.y, c2 = a0.z * b0.z, c3 = a0.w * b0.w;   // chunk m
-    float d0 = a1.x * b1.x, d1 = a1.y * b1.y, d2 = a1.z * b1.z, d3 = a1.w * b1.w;         // chunk m + 8
-    float s0 = 0.0f + c0, s1 = 0.0f + c1, s2 = 0.0f + c2, s3 = 0.0f + c3;
-#pragma unroll
-    for (int t = 1; t < 8; t++) {
-        s0 = dpp_row_shr2(s0) + c0; s1 = dpp_row_shr2(s1) + c1; s2 = dpp_row_shr2(s2) + c2; s3 = dpp_row_shr2(s3) + c3;
-    }
-    const float k0 = dpp_row_ror2(s0), k1 = dpp_row_ror2(s1), k2 = dpp_row_ror2(s2), k3 = dpp_row_ror2(s3);
-    if (m == 0) { d0 = k0 + d0; d1 = k1 + d1; d2 = k2 + d2; d3 = k3 + d3; }
-    s0 = 0.0f + d0; s1 = 0.0f + d1; s2 = 0.0f + d2; s3 = 0.0f + d3;
-#pragma unroll
-    for (int t = 1; t < 8; t++) {
-        s0 = dpp_row_shr2(s0) + d0; s1 = dpp_row_shr2(s1) + d1; s2 = dpp_row_shr2(s2) + d2; s3 = dpp_row_shr2(s3) + d3;
-    }
-    const float h = (s0 + s2) + (s1 + s3);   // sum_all: movehl add, then shuffle add_ss
-    return __shfl(h, (lane & ~15) + 14 + (lane & 1), 64);
-}
-
-template <int G>
-__global__ __launch_bounds__(256) void k_basicmf_i8(const DevParams P, const BasicSchedule S, long begin, long end) {
+// The contract configuration with FEWER lanes per row (basic_i8 knob; k = 64: EIGHT lanes).  The lane-group layout above spends its
+// instructions per ROW SET (64 / LPI instances per wave instruction): 60 dependent DPP adds for the dot product at k = 64, ~100 more
+// for addressing, the fp64 bias sums, link and decay -- the arithmetic is ~3.5 us of a 13.9 us launch that memory cannot overlap
+// (anatomy).  Here a lane holds V 16-byte chunks of a row, chunk m, m + LANES, ... (V fully coalesced pieces
+// of 16 LANES bytes per instance, one per load instruction), and the 16 / LANES instances of a 16-lane DPP row are interleaved
+// lane by lane, so that the dot product's hand-over is ONE row_shr:T add per step for all of them (dot_slots, svdf_device.h) and
+// every wave instruction serves V times the instances.  Same additions in the same order as the lane-group scan; at k = 64
+// (LANES = 8, V = 2, G = 4: 32 instances per wave) the per-instance instruction count drops by 40 %.
+template <int LANES, int V, int G>
+__global__ __launch_bounds__(256) void k_basicmf_slots(const DevParams P, const BasicSchedule S, long begin, long end) {
+    constexpr int T = 16 / LANES;      // instances interleaved in one DPP row
+    constexpr int IPS = 64 / LANES;    // instances per row set
+    constexpr int K = 4 * LANES * V;
     const int lane = threadIdx.x & 63;
     long tile = blockIdx.x;
     if (P.xcd_remap) tile = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     const long wave = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long w0 = begin + wave * (long)(G * 8);
+    const long w0 = begin + wave * (long)(G * IPS);
     if (w0 >= end) return;
-    const int m = (lane & 15) >> 1;
-    const int gslot = ((lane >> 4) << 1) | (lane & 1);
+    const int m = (lane & 15) / T;
+    const int gslot = (lane >> 4) * T + (lane & (T - 1));
     const int pitch = P.pitch;
 
     bool valid[G];
     unsigned ur[G], ir[G];
     float label[G], bu[G], bi[G];
-    float4 p0[G], p1[G], q0[G], q1[G];
+    float4 p[G][V], q[G][V];
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        const long s = w0 + (long)g * 8 + gslot;
+        const long s = w0 + (long)g * IPS + gslot;
         valid[g] = s < end;
         const long sc = valid[g] ? s : begin;
         ur[g] = P.user_off + S.user[sc];
@@ -185,12 +166,14 @@ __global__ __launch_bounds__(256) void k_basicmf_i8(const DevParams P, const Bas
     }
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        p0[g] = f4zero(); p1[g] = f4zero(); q0[g] = f4zero(); q1[g] = f4zero(); bu[g] = 0.0f; bi[g] = 0.0f;
+#pragma unroll
+        for (int v = 0; v < V; v++) { p[g][v] = f4zero(); q[g][v] = f4zero(); }
+        bu[g] = 0.0f; bi[g] = 0.0f;
         if (valid[g]) {
-            p0[g] = load_row_nt<16>(P.W, ur[g], pitch, m, 64);
-            p1[g] = load_row_nt<16>(P.W, ur[g], pitch, m + 8, 64);
-            q0[g] = load_row_nt<16>(P.W, ir[g], pitch, m, 64);
-            q1[g] = load_row_nt<16>(P.W, ir[g], pitch, m + 8, 64);
+#pragma unroll
+            for (int v = 0; v < V; v++) p[g][v] = load_row_nt<K / 4>(P.W, ur[g], pitch, m + v * LANES, K);
+#pragma unroll
+            for (int v = 0; v < V; v++) q[g][v] = load_row_nt<K / 4>(P.W, ir[g], pitch, m + v * LANES, K);
             bu[g] = P.bias[ur[g]];
             bi[g] = P.bias[ir[g]];
         }
@@ -198,35 +181,37 @@ __global__ __launch_bounds__(256) void k_basicmf_i8(const DevParams P, const Bas
     const float dec_u1 = snap_to_one(1.0f - P.lr * P.wd_user), dec_i1 = snap_to_one(1.0f - P.lr * P.wd_item);
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        // the arithmetic of basicmf_wave<16, ., true, true, true>, two chunks per lane
+        // the arithmetic of basicmf_wave<K / 4, ., true, true, true>, V chunks per lane
         double bs = 0.0;
         bs += (double)(1.0f * bu[g]); bs += 0.0;
         bs += 0.0;
         bs += (double)(1.0f * bi[g]);
         double sum = (double)P.base_score + bs;
-        float4 tu0 = f4zero(), tu1 = f4zero(), ti0 = f4zero(), ti1 = f4zero();
-        axpy4(tu0, p0[g], 1.0f); axpy4(tu1, p1[g], 1.0f);
-        axpy4(ti0, q0[g], 1.0f); axpy4(ti1, q1[g], 1.0f);
-        sum += (double)dot64_i8(tu0, tu1, ti0, ti1, m, lane);
+        float4 tu[V], ti[V];
+#pragma unroll
+        for (int v = 0; v < V; v++) { tu[v] = f4zero(); ti[v] = f4zero(); axpy4(tu[v], p[g][v], 1.0f); axpy4(ti[v], q[g][v], 1.0f); }
+        sum += (double)dot_slots<LANES, V>(tu, ti, m, lane);
         const float pred = (float)sum;
         const float err = (label[g] - pred) * 1.0f;
         const float su = P.lr * err * 1.0f;
         const float si = P.lr * err * 1.0f;
-        float4 wu0 = p0[g], wu1 = p1[g], wi0 = q0[g], wi1 = q1[g];
-        axpy4(wu0, ti0, su); axpy4(wu1, ti1, su);
-        axpy4(wi0, tu0, si); axpy4(wi1, tu1, si);
         float nbu = bu[g] + su, nbi = bi[g] + si;
-        wu0.x = wu0.x * dec_u1; wu0.y = wu0.y * dec_u1; wu0.z = wu0.z * dec_u1; wu0.w = wu0.w * dec_u1;
-        wu1.x = wu1.x * dec_u1; wu1.y = wu1.y * dec_u1; wu1.z = wu1.z * dec_u1; wu1.w = wu1.w * dec_u1;
-        wi0.x = wi0.x * dec_i1; wi0.y = wi0.y * dec_i1; wi0.z = wi0.z * dec_i1; wi0.w = wi0.w * dec_i1;
-        wi1.x = wi1.x * dec_i1; wi1.y = wi1.y * dec_i1; wi1.z = wi1.z * dec_i1; wi1.w = wi1.w * dec_i1;
         nbu = nbu * (1.0f - P.lr * P.wd_user_bias);
         nbi = nbi * (1.0f - P.lr * P.wd_item_bias);
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            float4 wu = p[g][v], wi = q[g][v];
+            axpy4(wu, ti[v], su);
+            axpy4(wi, tu[v], si);
+            wu.x = wu.x * dec_u1; wu.y = wu.y * dec_u1; wu.z = wu.z * dec_u1; wu.w = wu.w * dec_u1;
+            wi.x = wi.x * dec_i1; wi.y = wi.y * dec_i1; wi.z = wi.z * dec_i1; wi.w = wi.w * dec_i1;
+            p[g][v] = wu; q[g][v] = wi;
+        }
         if (valid[g]) {
-            store_row<16>(P.W, ur[g], pitch, m, 64, wu0);
-            store_row<16>(P.W, ur[g], pitch, m + 8, 64, wu1);
-            store_row<16>(P.W, ir[g], pitch, m, 64, wi0);
-            store_row<16>(P.W, ir[g], pitch, m + 8, 64, wi1);
+#pragma unroll
+            for (int v = 0; v < V; v++) store_row<K / 4>(P.W, ur[g], pitch, m + v * LANES, K, p[g][v]);
+#pragma unroll
+            for (int v = 0; v < V; v++) store_row<K / 4>(P.W, ir[g], pitch, m + v * LANES, K, q[g][v]);
             P.bias[ur[g]] = nbu;
             P.bias[ir[g]] = nbi;
         }
@@ -267,11 +252,17 @@ static void launch_basicmf_lpi(const DevParams &P, const BasicSchedule &S, long 
         // specialised instruction stream for the configuration of the contract workload, general one otherwise
         const bool fast = P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 && P.user_nonnegative == 0 &&
                           P.u_rng.n == 0 && P.i_rng.n == 0 && P.store_mode == 0;
-        if (unit && fast && LPI == 16 && P.k == 64 && P.basic_i8) {   // eight lanes per row: GG row sets of 8 instances per wave
-            const long per_block8 = (long)(block_threads / 64) * GG * 8;
+        auto slots = [&](auto lanes, auto vv) {   // LANES lanes per row, V chunks per lane: GG row sets of 64 / LANES instances per wave
+            constexpr int LANES = decltype(lanes)::value, V = decltype(vv)::value;
+            const long per_block8 = (long)(block_threads / 64) * GG * (64 / LANES);
             int grid8 = (int)((n + per_block8 - 1) / per_block8);
             if (P.xcd_remap) grid8 = (grid8 + 7) & ~7;
-            hipLaunchKernelGGL((k_basicmf_i8<GG>), dim3(grid8), dim3(block_threads), 0, st, P, S, begin, end);
+            hipLaunchKernelGGL((k_basicmf_slots<LANES, V, GG>), dim3(grid8), dim3(block_threads), 0, st, P, S, begin, end);
+        };
+        if (unit && fast && LPI == 16 && P.k == 64 && P.basic_i8) {
+            slots(std::integral_constant<int, 8>(), std::integral_constant<int, 2>());
+        } else if (unit && fast && LPI == 64 && P.k == 256 && P.basic_i8) {
+            slots(std::integral_constant<int, 16>(), std::integral_constant<int, 4>());
         } else if (unit && fast && P.k == 4 * LPI) hipLaunchKernelGGL((k_basicmf<LPI, GG, true, true, true>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
         else if (unit) hipLaunchKernelGGL((k_basicmf<LPI, GG, true, false, false>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
         else hipLaunchKernelGGL((k_basicmf<LPI, GG, false, false, false>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end);
@@ -293,7 +284,11 @@ void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long
     // 4 row sets in flight per wave in 64-thread blocks (24.9 ms/pass; 26.3 with one row set), k=256 two row sets, every
     // other width one row set per wave in 256-thread blocks
     const int lpi_ = lanes_per_instance(P.k);
-    if (groups_per_wave <= 0) groups_per_wave = lpi_ == 16 ? 4 : (lpi_ == 64 ? 2 : 1);
+    // (tools/ab_knob.py, in-process A/B: k=64 8 lanes x 2 chunks with 4 row sets 23.6 vs 24.4 ms per 100 M; k=256 16 lanes x 4 chunks with
+    // one row set 18.5 vs 20.2 ms per 25 M; k=128 16 lanes x 2 chunks 22.3 vs 22.3 ms per 50 M: no gain, the lane-group kernel stays)
+    const bool slots256 = P.basic_i8 && P.k == 256 && S.uval == nullptr && P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 &&
+                          P.user_nonnegative == 0 && P.u_rng.n == 0 && P.i_rng.n == 0;   // the configuration k_basicmf_slots is specialised for
+    if (groups_per_wave <= 0) groups_per_wave = lpi_ == 16 ? 4 : (lpi_ == 64 ? (slots256 ? 1 : 2) : 1);
     if (block_threads <= 0) block_threads = lpi_ == 16 ? 64 : 256;
     SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_basicmf_lpi<LPI>(P, S, begin, end, groups_per_wave, block_threads, st));
 }

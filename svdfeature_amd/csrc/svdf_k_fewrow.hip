@@ -99,34 +99,7 @@ __global__ __launch_bounds__(256) void k_fewrow_fast(const DevParams P, const Fu
 // k_basicmf_i8 (svdf_k_basic.hip), every wave instruction serves V times the instances.  The dot product is the reference's chain:
 // the chunks of slot 0 in lane order (LANES - 1 row_shr:T steps), the finished sums rotate from the row's last lanes to its first
 // (row_ror:T) and are folded into the addend of the next slot's first chunk -- the carry trick of group_dot<32> --, and so on
-// through the slots.  Same additions in the same order.  k = 128: LANES = 16, V = 2 (one instance per DPP row).
-template <int T> __device__ __forceinline__ float dpp_shr_t(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x110 + T, 0xf, 0xf, true));
-}
-template <int T> __device__ __forceinline__ float dpp_ror_t(float v) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + T, 0xf, 0xf, false));
-}
-template <int LANES, int V>
-__device__ __forceinline__ float dot_slots(const float4 (&a)[V], const float4 (&b)[V], int m, int lane) {
-    constexpr int T = 16 / LANES;
-    float s0 = 0.0f, s1 = 0.0f, s2 = 0.0f, s3 = 0.0f;
-#pragma unroll
-    for (int v = 0; v < V; v++) {
-        float c0 = a[v].x * b[v].x, c1 = a[v].y * b[v].y, c2 = a[v].z * b[v].z, c3 = a[v].w * b[v].w;   // chunk m + v * LANES
-        if (v > 0) {
-            const float k0 = dpp_ror_t<T>(s0), k1 = dpp_ror_t<T>(s1), k2 = dpp_ror_t<T>(s2), k3 = dpp_ror_t<T>(s3);
-            if (m == 0) { c0 = k0 + c0; c1 = k1 + c1; c2 = k2 + c2; c3 = k3 + c3; }
-        }
-        s0 = 0.0f + c0; s1 = 0.0f + c1; s2 = 0.0f + c2; s3 = 0.0f + c3;
-#pragma unroll
-        for (int t = 1; t < LANES; t++) {
-            s0 = dpp_shr_t<T>(s0) + c0; s1 = dpp_shr_t<T>(s1) + c1; s2 = dpp_shr_t<T>(s2) + c2; s3 = dpp_shr_t<T>(s3) + c3;
-        }
-    }
-    const float h = (s0 + s2) + (s1 + s3);
-    return __shfl(h, (lane & ~15) + T * (LANES - 1) + (lane & (T - 1)), 64);
-}
-
+// through the slots (dot_slots, svdf_device.h).  Same additions in the same order.  k = 128: LANES = 16, V = 2 (one instance per DPP row).
 template <int LANES, int V, int NU, int NI>
 __global__ __launch_bounds__(256) void k_fewrow_slots(const DevParams P, const FusedSchedule S, long begin, long end) {
     constexpr int T = 16 / LANES;          // instances interleaved in one DPP row

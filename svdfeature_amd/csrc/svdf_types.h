@@ -90,8 +90,9 @@ struct DevParams {
     int store_mode;           // row-store cache policy of k_basicmf: 0 plain, 1 nontemporal, 2 sc1 write-through
     int fewrow_i16;           // k = 128 few-row kernel: sixteen lanes per row, 4 instances per wave (k_fewrow_i16)
     int basic_i8;             // k = 64 basicMF: eight lanes per row, 8 instances per wave instruction (k_basicmf_i8)
-    int load_mode;            // row-load cache policy of k_basicmf / k_fewrow_fast: 1 (default) nontemporal hint -- a level reads each row once,
-                              // measured -2.2 ... -4.2 % per pass; 0 plain
+    int load_mode;            // row-load cache policy of k_basicmf / k_fewrow_fast: 1 nontemporal hint -- a level reads each row once; measured
+                              // -2.2 ... -4.2 % per pass at k = 64 (two cache lines per row), flat at 128 / 256, +16 % at k = 32 (one line): the
+                              // engine picks 1 for rows of >= 256 bytes, 0 below (load_mode knob 2 = auto)
     // SVDTrainParam
     float lr, wd_user, wd_item, wd_user_bias, wd_item_bias, wd_global;
     int reg_method, reg_global;

@@ -19,6 +19,7 @@ if os.environ.get("AB_LIB"):   # another build of the engine (e.g. the previous 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     pairwise = "--pairwise" in sys.argv
+    factor = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--factor=")]
     values = args
     nu, ni = 1_000_000, 100_000
     if pairwise:
@@ -28,7 +29,9 @@ def main():
         conf = [("learning_rate", "0.005"), ("wd_item", "0.004"), ("wd_user", "0.004"), ("num_item", str(ni)), ("num_user", str(nu)),
                 ("num_factor", str(k)), ("num_global", "0"), ("no_user_bias", "1")]
     else:
-        n, k = 100_000_000, 64
+        n, k = 100_000_000, (factor[0] if factor else 64)
+        if k > 64:
+            n = n * 64 // k
         u, i, r = bench.synth_triples(n, nu, ni)
         t = sa.Trainer(0, 0)
         conf = [("base_score", "3"), ("learning_rate", "0.005"), ("wd_item", "0.004"), ("wd_user", "0.004"), ("num_item", str(ni)),
