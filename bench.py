@@ -353,7 +353,8 @@ def run_workload(name, a, env, steps, warmup, main_line):
     t0 = time.time()
     # N > 1, ratings: the exchange of a window is cut into item-range pieces so that every piece's all-reduce runs while the
     # next piece trains (svdf_item_delta_select; multi_gpu.ShardedTrainer(parts=p)); 1 = one synchronous all-reduce per window
-    parts = a.exchange_parts if (name == "basicmf" and (world > 1 or a.force_exchange)) else 1
+    auto_parts = 1 if world <= 2 else 2
+    parts = (a.exchange_parts or auto_parts) if (name == "basicmf" and (world > 1 or a.force_exchange)) else 1
     adaptor = HipShard(tr, torch, torch.device("cuda", local_rank), parts=parts)
     if a.windows > 0:
         nwin = a.windows
@@ -652,8 +653,11 @@ def main():
                     help="item-delta exchanges per pass when --gpus > 1 (0 = chosen from the data density so that the "
                          "RMSE stays within 1e-4 of the sequential reference: about 64 ratings per item per window at "
                          "2 ranks, 32 at 4+ ranks; calibration in DESIGN.md section 6)")
-    ap.add_argument("--exchange-parts", type=int, default=2,
-                    help="N>1, ratings: item-range pieces per window exchange; piece p's all-reduce overlaps with training piece p+1 (1 = off)")
+    ap.add_argument("--exchange-parts", type=int, default=0,
+                    help="N>1, ratings: item-range pieces per window exchange; piece p's all-reduce overlaps with training piece p+1 "
+                         "(1 = one synchronous all-reduce per window; 0 = auto: 1 at 2 ranks, 2 beyond -- a piece keeps the window's item-chain "
+                         "depth, so pieces double a rank's launches: 12.9 -> 32.7 ms per pass at 2 ranks, 7.9 -> 10.6 at 4, 5.3 -> 7.7 at 8 "
+                         "(tools/shard_parts_probe.sh), which only pays once the exchange it hides is the larger part)")
     ap.add_argument("--delta-dtype", choices=["fp16", "fp32"], default="fp16",
                     help="wire format of the item-side window deltas when --gpus > 1 (parameters stay fp32)")
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="basicMF ratings of the CPU baseline sample (other workloads scale it down)")

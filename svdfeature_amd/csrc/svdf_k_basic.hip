@@ -286,9 +286,16 @@ void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long
     const int lpi_ = lanes_per_instance(P.k);
     // (tools/ab_knob.py, in-process A/B: k=64 8 lanes x 2 chunks with 4 row sets 23.6 vs 24.4 ms per 100 M; k=256 16 lanes x 4 chunks with
     // one row set 18.5 vs 20.2 ms per 25 M; k=128 16 lanes x 2 chunks 22.3 vs 22.3 ms per 50 M: no gain, the lane-group kernel stays)
-    const bool slots256 = P.basic_i8 && P.k == 256 && S.uval == nullptr && P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 &&
-                          P.user_nonnegative == 0 && P.u_rng.n == 0 && P.i_rng.n == 0;   // the configuration k_basicmf_slots is specialised for
-    if (groups_per_wave <= 0) groups_per_wave = lpi_ == 16 ? 4 : (lpi_ == 64 ? (slots256 ? 1 : 2) : 1);
+    const bool slots_cfg = P.basic_i8 && S.uval == nullptr && P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 &&
+                           P.user_nonnegative == 0 && P.u_rng.n == 0 && P.i_rng.n == 0;   // the configuration k_basicmf_slots is specialised for
+    const bool slots256 = slots_cfg && P.k == 256;
+    if (groups_per_wave <= 0) {
+        groups_per_wave = lpi_ == 16 ? 4 : (lpi_ == 64 ? (slots256 ? 1 : 2) : 1);
+        // k = 64 in the 8-lane layout: 8 instances per row set.  A full-size level (53 K instances) wants 4 row sets per wave (1.6 waves
+        // per SIMD: 23.6 ms per pass against 26.6 with 2 and 27.5 with 1), the 17 K-instance levels of one rank's window of an 8-GPU
+        // run want 1 (7.66 ms per pass against 8.09 with 2 and 9.10 with 4, tools/shard8_knobs.sh): aim at ~1 800 waves per launch
+        if (slots_cfg && P.k == 64) groups_per_wave = (int)std::min<long>(4, std::max<long>(1, (end - begin + 7200) / 14400));
+    }
     if (block_threads <= 0) block_threads = lpi_ == 16 ? 64 : 256;
     SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_basicmf_lpi<LPI>(P, S, begin, end, groups_per_wave, block_threads, st));
 }
