@@ -287,9 +287,16 @@ __device__ __forceinline__ void fb_fetch_rows(const DevParams &P, const FbBlock 
 // FULL: num_factor == 64*NR, so no lane is ever out of the row and the dot has no masked chunks and no tail.
 // UV: every feature value of the fast-path units is 1.0 (the usual rating data): values are compile-time constants.
 // RX: relaxed mode compiled in (atomic adds to item / feedback rows); the exact kernels carry none of it.
-template <int NR, bool FAST, bool FULL, bool UV, bool RX>
+// HW > 1: HW waves per user (one workgroup).  A user's rows are a strict recurrence and stay with wave 0, but the two feedback phases
+// are not: prepare_ufeedback GATHERS nfb independent rows (only their accumulation is ordered) and update_ufeedback SCATTERS the same
+// delta into nfb independent rows.  One wave keeps 16 rows in flight (0.18 us per id: 36 of the 56 us a 100-row, 100-id user takes,
+// and a level holds ~6 users on a 256-CU chip); with helpers, every wave gathers its share of the rows into LDS (linear layout), wave
+// 0 accumulates them from there in the reference's order, and the scatter is applied by every wave to its share straight from the
+// LDS copies (distinct ids, nothing else touches the rows inside the unit), no second fetch.  Users whose list does not fit the LDS
+// budget (lds_rows) and split users' END blocks take the global path.
+template <int NR, bool FAST, bool FULL, bool UV, bool RX, int HW = 1>
 __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR &D, const DevUnit &u, const unsigned *fb_index,
-                                                const float *fb_value, int lane) {
+                                                const float *fb_value, int lane, int wv = 0, float *lds = nullptr, int lds_rows = 0) {
     const int pitch = P.pitch;
     const int k = FULL ? 64 * NR : P.k;      // dot / projection width
     const int kio = FULL ? -1 : P.k;         // bound of row loads / stores (-1: none)
@@ -301,6 +308,43 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
     ChainRow<NR> tmp_fb = chain_zero<NR>(), old_fb = chain_zero<NR>();
     float norm = 0.0f, tmp_bias = 0.0f, old_bias = 0.0f;
     float *st = P.svdpp_state;
+    // ---- helper waves (HW > 1): block-uniform decisions, LDS = rows[lds_rows][64 NR] | bias[lds_rows] | delta[64 NR] | db
+    constexpr bool HELP = HW > 1;
+    const bool help = HELP && nfb > 0 && nfb <= lds_rows;
+    const bool rows_in_lds = help && (u.flags & UNIT_START);
+    float *l_rows = lds, *l_bias = lds + (size_t)lds_rows * 64 * NR, *l_delta = l_bias + lds_rows;
+    unsigned my_id = 0;
+    float my_v = 0.0f;
+    if (help) {   // this wave's share of the list: entries wv, wv + HW, ...; lane l keeps entry wv + HW l
+        const int j = min(wv + HW * lane, nfb - 1);
+        my_id = fidx[j];
+        my_v = fval[j];
+    }
+    if (rows_in_lds) {
+        constexpr int GC = 16;   // rows a wave requests before it parks any of them in LDS: HW x GC gathers in flight per user
+        for (int t0 = 0; wv + HW * t0 < nfb; t0 += GC) {
+            ChainRow<NR> w[GC];
+            float b[GC];
+#pragma unroll
+            for (int c = 0; c < GC; c++) {
+                const int j = min(wv + HW * (t0 + c), nfb - 1);   // (past the end: the last row again, not stored)
+                const unsigned row = P.fb_off + fidx[j];
+                w[c] = lin_load<NR>(P.W, row, pitch, lane, kio);
+                b[c] = ub ? P.bias[row] : 0.0f;
+            }
+#pragma unroll
+            for (int c = 0; c < GC; c++) {
+                const int j = wv + HW * (t0 + c);
+                if (j < nfb) {
+#pragma unroll
+                    for (int q = 0; q < NR; q++) l_rows[((size_t)j * 64 + lane) * NR + q] = w[c].r[q];
+                    if (lane == 0) l_bias[j] = b[c];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (!HELP || wv == 0) {
     if (u.flags & UNIT_LOAD) {
         tmp_fb = chain_load<NR>(st, 0, pitch, lane, kio);
         old_fb = chain_load<NR>(st, 1, pitch, lane, kio);
@@ -308,7 +352,32 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
     }
     if (u.flags & UNIT_START) {   // prepare_ufeedback (:523-538)
         norm = 0.0f; tmp_fb = chain_zero<NR>(); tmp_bias = 0.0f;
-        if (nfb > 0) {
+        if (rows_in_lds) {   // the rows are in LDS: accumulate them in list order (same operations as the global path below)
+            FbBlock blk = fb_block(fidx, fval, 0, nfb, lane);
+            constexpr int AC = 8;   // LDS rows read ahead of their (ordered) accumulation; 64 % AC == 0
+            for (int j0 = 0; j0 < nfb; j0 += AC) {
+                if (j0 > 0 && (j0 & 63) == 0) blk = fb_block(fidx, fval, j0, nfb, lane);
+                ChainRow<NR> w[AC];
+                float b[AC];
+#pragma unroll
+                for (int c = 0; c < AC; c++) {
+                    const int j = min(j0 + c, nfb - 1);
+#pragma unroll
+                    for (int q = 0; q < NR; q++) w[c].r[q] = l_rows[((size_t)j * 64 + lane) * NR + q];
+                    b[c] = l_bias[j];
+                }
+#pragma unroll
+                for (int c = 0; c < AC; c++) {
+                    if (j0 + c < nfb) {
+                        const float v = fb_val(blk, (j0 + c) & 63);
+                        chain_axpy(tmp_fb, w[c], v);
+                        norm = norm + v * v;
+                        if (ub) tmp_bias = tmp_bias + b[c] * v;
+                    }
+                }
+            }
+            tmp_fb = lin_to_chain<NR>(tmp_fb, lane);
+        } else if (nfb > 0) {
             static_assert(64 % svdpp_fbw<NR>::value == 0, "a batch must not straddle two id blocks");
             // queue slot 0: the batch being accumulated; slots 1..DEPTH: batches whose rows are in flight; blkn: the id
             // block after the newest slot's, loaded a block ahead
@@ -455,6 +524,11 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
         db = db * inv;
         tmp_fb = d; tmp_bias = db;   // the reference leaves the scaled delta in tmp_ufeedback
         const ChainRow<NR> dl = chain_to_lin<NR>(d, lane);   // the scatter below runs in LINEAR layout
+        if (help) {   // every wave scatters its share (after the barrier below): hand the delta over through LDS
+#pragma unroll
+            for (int q = 0; q < NR; q++) l_delta[lane * NR + q] = dl.r[q];
+            if (lane == 0) l_delta[64 * NR] = db;
+        } else {
         constexpr int FBW = svdpp_fbw<NR>::value, DEPTH = svdpp_fbdepth<NR>::value;
         FbBlock blk[DEPTH + 1], blkn;
         int off[DEPTH + 1];
@@ -494,19 +568,62 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
 #pragma unroll
             for (int q = 0; q < DEPTH; q++) { rq[q] = rq[q + 1]; blk[q] = blk[q + 1]; off[q] = off[q + 1]; }
         }
+        }   // !help
     }
     if (u.flags & UNIT_SAVE) {
         chain_store<NR>(st, 0, pitch, lane, kio, tmp_fb);
         chain_store<NR>(st, 1, pitch, lane, kio, old_fb);
         if (lane == 0) { st[2 * pitch] = norm; st[2 * pitch + 1] = tmp_bias; st[2 * pitch + 2] = old_bias; }
     }
+    }   // wave 0
+    if (HELP) {
+        if (help && (u.flags & UNIT_END)) {   // update_ufeedback (:539-554), every wave its share of the rows
+            __syncthreads();
+            ChainRow<NR> dl;
+#pragma unroll
+            for (int q = 0; q < NR; q++) dl.r[q] = l_delta[lane * NR + q];
+            const float db = l_delta[64 * NR];
+            constexpr int SC = 8;
+            for (int t0 = 0; wv + HW * t0 < nfb; t0 += SC) {
+                ChainRow<NR> w[SC];
+                float b[SC];
+#pragma unroll
+                for (int c = 0; c < SC; c++) {
+                    const int j = min(wv + HW * (t0 + c), nfb - 1);
+                    if (rows_in_lds) {
+#pragma unroll
+                        for (int q = 0; q < NR; q++) w[c].r[q] = l_rows[((size_t)j * 64 + lane) * NR + q];
+                        b[c] = l_bias[j];
+                    } else {   // a split user's END block: the rows were gathered by an earlier unit
+                        const unsigned row = P.fb_off + fidx[j];
+                        w[c] = lin_load<NR>(P.W, row, pitch, lane, kio);
+                        b[c] = ub ? P.bias[row] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int c = 0; c < SC; c++) {
+                    const int j = wv + HW * (t0 + c);
+                    if (j < nfb) {
+                        const unsigned row = P.fb_off + (unsigned)__builtin_amdgcn_readlane((int)my_id, t0 + c);
+                        const float v = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_v), t0 + c));
+                        chain_axpy(w[c], dl, v);
+                        lin_store<NR>(P.W, row, pitch, lane, kio, w[c]);
+                        if (ub) P.bias[row] = b[c] + db * v;
+                    }
+                }
+            }
+        }
+        __syncthreads();   // the LDS rows / delta are free for the workgroup's next user
+    }
 }
 
-// Kernel 4a: the simple units of one conflict-free batch, one wave per user
-template <int NR, bool FAST, bool FULL, bool UV, bool RX>
-__global__ __launch_bounds__(64) void k_svdpp_wave(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
-                                                   const float *fb_value, const int *order, long begin, long end) {
+// Kernel 4a: the simple units of one conflict-free batch, one wave per user (HW = 1) or one workgroup of HW waves per user
+template <int NR, bool FAST, bool FULL, bool UV, bool RX, int HW = 1>
+__global__ __launch_bounds__(64 * HW) void k_svdpp_wave(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
+                                                        const float *fb_value, const int *order, long begin, long end, int lds_rows) {
+    extern __shared__ float svdpp_lds[];
     const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
     for (long s = begin + blockIdx.x; s < end; s += gridDim.x) {
         const int uid = __builtin_amdgcn_readfirstlane(order ? order[s] : (int)s);
         const DevUnit *up = units + uid;
@@ -514,7 +631,7 @@ __global__ __launch_bounds__(64) void k_svdpp_wave(const DevParams P, const DevC
         u.fb_begin = __builtin_amdgcn_readfirstlane(up->fb_begin); u.fb_end = __builtin_amdgcn_readfirstlane(up->fb_end);
         u.row_begin = __builtin_amdgcn_readfirstlane(up->row_begin); u.row_end = __builtin_amdgcn_readfirstlane(up->row_end);
         u.flags = __builtin_amdgcn_readfirstlane(up->flags);
-        svdpp_unit_wave<NR, FAST, FULL, UV, RX>(P, D, u, fb_index, fb_value, lane);
+        svdpp_unit_wave<NR, FAST, FULL, UV, RX, HW>(P, D, u, fb_index, fb_value, lane, wv, svdpp_lds, lds_rows);
     }
 }
 
@@ -527,7 +644,28 @@ void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units
     const bool fast = P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 && P.user_nonnegative == 0 &&
                       P.u_rng.n == 0 && P.i_rng.n == 0;
 #define SVDF_WAVE_LAUNCH(NR_, FAST_, FULL_, UV_, RX_) \
-    hipLaunchKernelGGL((k_svdpp_wave<NR_, FAST_, FULL_, UV_, RX_>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end)
+    hipLaunchKernelGGL((k_svdpp_wave<NR_, FAST_, FULL_, UV_, RX_>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end, 0)
+    // helper waves (svdpp_helpers knob: 8 waves per user by default -- 301.6 ms per pass of the 40 K-user set against 316.8 with 4,
+    // 311.0 with 16 and 368.7 with one wave per user) for the configuration every BASELINE run uses; LDS budget 64 KB
+    if (P.svdpp_helpers > 1 && fast && P.k == 64 * nr && D.unit_values && !(P.relax_item_from == 0u || P.relax_feedback != 0) && nr <= 4) {
+        const int lds_floats = 16384;
+        int rows = (lds_floats - 64 * nr - 4) / (64 * nr + 1);
+        const int hw = P.svdpp_helpers >= 16 ? 16 : (P.svdpp_helpers >= 8 ? 8 : 4);
+        if (rows > 64 * hw) rows = 64 * hw;   // a wave keeps its share of the ids in one register: 64 entries per wave
+        const size_t lds_bytes = ((size_t)rows * (64 * nr + 1) + 64 * nr + 4) * sizeof(float);
+#define SVDF_WAVE_HELP(NR_, HW_) hipLaunchKernelGGL((k_svdpp_wave<NR_, true, true, true, false, HW_>), dim3((int)grid), dim3(64 * HW_), lds_bytes, st, P, D, units, fb_index, fb_value, order, begin, end, rows)
+#define SVDF_WAVE_HELP_NR(NR_) \
+        if (P.svdpp_helpers >= 16) SVDF_WAVE_HELP(NR_, 16); else if (P.svdpp_helpers >= 8) SVDF_WAVE_HELP(NR_, 8); else SVDF_WAVE_HELP(NR_, 4)
+        switch (nr) {
+        case 1: SVDF_WAVE_HELP_NR(1); break;
+        case 2: SVDF_WAVE_HELP_NR(2); break;
+        case 3: SVDF_WAVE_HELP_NR(3); break;
+        default: SVDF_WAVE_HELP_NR(4); break;
+        }
+#undef SVDF_WAVE_HELP_NR
+#undef SVDF_WAVE_HELP
+        return;
+    }
 #define SVDF_WAVE_CASE(NR_)                                                                   \
     case NR_:                                                                                 \
         if (relaxed && fast && full && D.unit_values) SVDF_WAVE_LAUNCH(NR_, true, true, true, true);   \

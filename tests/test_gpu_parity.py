@@ -424,6 +424,34 @@ def test_few_row_kernel_k128_both_row_layouts(shape, i16):
         np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
 
 
+@pytest.mark.parametrize("helpers", [4, 8, 16])
+@pytest.mark.parametrize("k", [64, 128, 192, 256])
+def test_svdpp_helper_waves_equal_one_wave_per_user(k, helpers):
+    """svdpp_helpers = 4: four waves per user, the feedback rows gathered into LDS by all of them, accumulated by wave 0 in list
+    order, the scatter applied by every wave to its share -- the same parameters as one wave per user and as the oracle; users with
+    long lists (beyond the LDS budget), empty lists, split users (START / MIDDLE / END blocks) included."""
+    nu, ni = 500, 700
+    blocks = cases.user_blocks(260, nu, ni, ni, seed=31, max_rows=25, max_fb=40, split_every=5)
+    blocks += cases.user_blocks(6, nu, ni, ni, seed=32, max_rows=8, max_fb=300)   # lists longer than the LDS rows at k = 192 / 256
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni, wd_ufeedback=0.004,
+                           ufeedback_init_sigma=0.01)
+    o = _ready(port, 1, conf)
+    ts = [_ready(hip, 1, conf), _ready(hip, 1, conf)]
+    ts[0].set_knob("svdpp_helpers", 1)
+    ts[1].set_knob("svdpp_helpers", helpers)
+    dss = [t.dataset_from_blocks(blocks) for t in ts]
+    assert dss[0].num_simple_units > 0
+    for _ in range(2):
+        for b in blocks:
+            o.update_block(b)
+        for t, ds in zip(ts, dss):
+            t.train_dataset(ds)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "W_ufeedback", "ufeedback_bias"):
+        ref = o.view(name).view(np.uint32)
+        for t in ts:
+            np.testing.assert_array_equal(t.view(name).view(np.uint32), ref)
+
+
 @pytest.mark.parametrize("k", [3, 10, 16, 33, 64, 100, 128, 130, 192, 203, 256])
 @pytest.mark.parametrize("nobias", [0, 1])
 def test_svdpp_simple_unit_fast_path_and_block_dataset(k, nobias):
