@@ -17,8 +17,12 @@ for w, kern in names.items():
     txt = open(cand[0]).read()
 
     def mean(counter):
-        m = re.search(r"%s[^\n]*?\s%s\s+n=\s*(\d+)\s+mean=(\S+)" % (kern, counter), txt)
-        return (float(m.group(2)), int(m.group(1))) if m else (None, 0)
+        # every instantiation of the kernel (e.g. k_basicmf_slots<8, 2, G> for the G chosen per launch): total / dispatches
+        tot, n = 0.0, 0
+        for m in re.finditer(r"%s[^\n]*?\s%s\s+n=\s*(\d+)\s+mean=(\S+)\s+total=(\S+)" % (kern, counter), txt):
+            n += int(m.group(1))
+            tot += float(m.group(3))
+        return (tot / n, n) if n else (None, 0)
     f, nf = mean("FETCH_SIZE")
     wr, _ = mean("WRITE_SIZE")
     if f is None or wr is None:
