@@ -5,7 +5,7 @@ d = sys.argv[1]
 for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
     acc = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
-        k = (r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])
+        k = (r["Kernel_Name"].split("(")[0].replace("void ", "").replace("svdf::", "")[-56:], r["Counter_Name"])
         acc[k][0] += 1
         acc[k][1] += float(r["Counter_Value"])
     print(f)

@@ -16,7 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python 
 cp $OUT/kt/kt_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null || find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 rm -rf $OUT/kt
 head -12 $OUT/kernel_stats.csv
-# hardware counters: one pass per counter group and workload, 1 pass over the data, no warm-up
+# hardware counters: one pass per counter group and workload, 1 pass over the data, no warm-up (tools/pmc_one_workload.sh = the same for one workload)
 for W in basicmf pairwise svdpp neighbourhood; do
   : > $OUT/pmc_$W.txt
   for c in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS"; do
