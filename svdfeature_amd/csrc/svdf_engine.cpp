@@ -1321,6 +1321,20 @@ void Engine::upload_units(UnitDev &d, const Schedule &sched, const std::vector<D
     d.fbval.upload(staged_fb_value_.data(), staged_fb_value_.size(), stream_);
     d.units.upload(du.data(), du.size(), stream_);
     d.order.upload(sched.order.data(), sched.order.size(), stream_);
+    {   // launch records of the wave-per-user kernel: schedule order, first row entry and user id inline
+        std::vector<DevUnitX> xu(sched.order.size());
+        for (size_t s = 0; s < sched.order.size(); s++) {
+            const DevUnit &u = du[(size_t)sched.order[s]];
+            DevUnitX x{u, 0, 0u, 0};
+            if (u.row_end > u.row_begin) {
+                x.e0 = staged_.row_ptr[3 * (size_t)u.row_begin];
+                if ((u.flags & UNIT_SIMPLE) && staged_.row_ptr[3 * (size_t)u.row_begin + 2] > staged_.row_ptr[3 * (size_t)u.row_begin + 1])
+                    x.user = staged_.feat_index[(size_t)staged_.row_ptr[3 * (size_t)u.row_begin + 1]];
+            }
+            xu[s] = x;
+        }
+        d.xunits.upload(xu.data(), xu.size(), stream_);
+    }
     d.unit_values = simple_unit_values_;
     d.has_fresh = any_fresh_;
     if (any_fresh_) d.fresh.upload(staged_fresh_.data(), staged_fresh_.size(), stream_);
@@ -1345,7 +1359,7 @@ void Engine::flush_units() {
     upload_units(d, sched, du);
     const DevCSR D = d.csr();
     for (size_t l = 0; l < sched.num_levels(); l++) {
-        launch_svdpp_wave(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sched.level_ptr[l], sched.level_mid[l], stream_);
+        launch_svdpp_wave(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, svdpp_xunits_ ? d.xunits.p : nullptr, sched.level_ptr[l], sched.level_mid[l], stream_);
         launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sched.level_mid[l], sched.level_ptr[l + 1], sample_counter_, stream_);
         n_launches_++;
     }
@@ -1893,7 +1907,7 @@ void Engine::train_dataset(Dataset *ds) {
             const UnitDev &d = ds->unitdev;
             const DevCSR D = d.csr();
             for (size_t l = 0; l < sc.num_levels(); l++) {
-                launch_svdpp_wave(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_ptr[l], sc.level_mid[l], stream_);
+                launch_svdpp_wave(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, svdpp_xunits_ ? d.xunits.p : nullptr, sc.level_ptr[l], sc.level_mid[l], stream_);
                 launch_svdpp(P, D, d.units.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_mid[l], sc.level_ptr[l + 1], sample_counter_, stream_);
             }
         } else if (ds->kind == 4) {
@@ -2285,6 +2299,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "xcd_remap")) { xcd_remap_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "hot_reduce")) { hot_reduce_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "fewrow_i16")) { check(value >= 0 && value <= 1, "fewrow_i16 must be 0 or 1"); fewrow_i16_ = (int)value; params_dirty_ = true; return 0; }
+    if (!strcmp(name, "svdpp_xunits")) { check(value == 0 || value == 1, "svdpp_xunits must be 0 or 1"); svdpp_xunits_ = (int)value; return 0; }
     if (!strcmp(name, "svdpp_helpers")) { check(value == 1 || value == 4 || value == 8 || value == 16, "svdpp_helpers must be 1, 4, 8 or 16"); svdpp_helpers_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "basic_i8")) { check(value >= 0 && value <= 1, "basic_i8 must be 0 or 1"); basic_i8_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "load_mode")) { check(value >= 0 && value <= 2, "load_mode must be 0, 1 or 2 (auto)"); load_mode_ = (int)value; params_dirty_ = true; return 0; }

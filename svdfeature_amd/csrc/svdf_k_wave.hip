@@ -296,7 +296,8 @@ __device__ __forceinline__ void fb_fetch_rows(const DevParams &P, const FbBlock 
 // budget (lds_rows) and split users' END blocks take the global path.
 template <int NR, bool FAST, bool FULL, bool UV, bool RX, int HW = 1>
 __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR &D, const DevUnit &u, const unsigned *fb_index,
-                                                const float *fb_value, int lane, int wv = 0, float *lds = nullptr, int lds_rows = 0) {
+                                                const float *fb_value, int lane, int wv = 0, float *lds = nullptr, int lds_rows = 0,
+                                                bool have_x = false, int x_e0 = 0, unsigned x_user = 0) {
     const int pitch = P.pitch;
     const int k = FULL ? 64 * NR : P.k;      // dot / projection width
     const int kio = FULL ? -1 : P.k;         // bound of row loads / stores (-1: none)
@@ -417,8 +418,10 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
     }
     const int nrow = u.row_end - u.row_begin;
     if (nrow > 0) {
-        const int e0 = uniform_load(D.row_ptr + 3 * (long)u.row_begin);   // rows are (0,1,1): entries of row j start at e0 + 2j
-        const unsigned urow = P.user_off + uniform_load(D.feat_index + e0);
+        // rows are (0,1,1): entries of row j start at e0 + 2j; e0 and the user id come with the launch record when there is one
+        // (two dependent loads less in front of the user's row)
+        const int e0 = have_x ? x_e0 : uniform_load(D.row_ptr + 3 * (long)u.row_begin);
+        const unsigned urow = P.user_off + (have_x ? x_user : uniform_load(D.feat_index + e0));
         ChainRow<NR> p = chain_load<NR>(P.W, urow, pitch, lane, kio);
         float bu = ub ? P.bias[urow] : 0.0f;
         const float wd_u = FAST ? P.wd_user : get_wd(P.u_rng, urow - P.user_off, P.wd_user);
@@ -620,23 +623,24 @@ __device__ __forceinline__ void svdpp_unit_wave(const DevParams &P, const DevCSR
 // Kernel 4a: the simple units of one conflict-free batch, one wave per user (HW = 1) or one workgroup of HW waves per user
 template <int NR, bool FAST, bool FULL, bool UV, bool RX, int HW = 1>
 __global__ __launch_bounds__(64 * HW) void k_svdpp_wave(const DevParams P, const DevCSR D, const DevUnit *units, const unsigned *fb_index,
-                                                        const float *fb_value, const int *order, long begin, long end, int lds_rows) {
+                                                        const float *fb_value, const int *order, const DevUnitX *xunits, long begin, long end, int lds_rows) {
     extern __shared__ float svdpp_lds[];
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     for (long s = begin + blockIdx.x; s < end; s += gridDim.x) {
-        const int uid = __builtin_amdgcn_readfirstlane(order ? order[s] : (int)s);
-        const DevUnit *up = units + uid;
+        const DevUnit *up = xunits ? &xunits[s].u : units + __builtin_amdgcn_readfirstlane(order ? order[s] : (int)s);
         DevUnit u;
         u.fb_begin = __builtin_amdgcn_readfirstlane(up->fb_begin); u.fb_end = __builtin_amdgcn_readfirstlane(up->fb_end);
         u.row_begin = __builtin_amdgcn_readfirstlane(up->row_begin); u.row_end = __builtin_amdgcn_readfirstlane(up->row_end);
         u.flags = __builtin_amdgcn_readfirstlane(up->flags);
-        svdpp_unit_wave<NR, FAST, FULL, UV, RX, HW>(P, D, u, fb_index, fb_value, lane, wv, svdpp_lds, lds_rows);
+        const int x_e0 = xunits ? __builtin_amdgcn_readfirstlane(xunits[s].e0) : 0;
+        const unsigned x_user = xunits ? (unsigned)__builtin_amdgcn_readfirstlane((int)xunits[s].user) : 0u;
+        svdpp_unit_wave<NR, FAST, FULL, UV, RX, HW>(P, D, u, fb_index, fb_value, lane, wv, svdpp_lds, lds_rows, xunits != nullptr, x_e0, x_user);
     }
 }
 
 void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
-                       const int *order, long begin, long end, hipStream_t st) {
+                       const int *order, const DevUnitX *xunits, long begin, long end, hipStream_t st) {
     if (end <= begin) return;
     long grid = end - begin;           // one 64-thread workgroup (= one wave) per user: a batch rarely holds more users than CUs
     if (grid > 16384) grid = 16384;
@@ -644,7 +648,7 @@ void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units
     const bool fast = P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 && P.user_nonnegative == 0 &&
                       P.u_rng.n == 0 && P.i_rng.n == 0;
 #define SVDF_WAVE_LAUNCH(NR_, FAST_, FULL_, UV_, RX_) \
-    hipLaunchKernelGGL((k_svdpp_wave<NR_, FAST_, FULL_, UV_, RX_>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, begin, end, 0)
+    hipLaunchKernelGGL((k_svdpp_wave<NR_, FAST_, FULL_, UV_, RX_>), dim3((int)grid), dim3(64), 0, st, P, D, units, fb_index, fb_value, order, xunits, begin, end, 0)
     // helper waves (svdpp_helpers knob: 8 waves per user by default -- 301.6 ms per pass of the 40 K-user set against 316.8 with 4,
     // 311.0 with 16 and 368.7 with one wave per user) for the configuration every BASELINE run uses; LDS budget 64 KB
     if (P.svdpp_helpers > 1 && fast && P.k == 64 * nr && D.unit_values && !(P.relax_item_from == 0u || P.relax_feedback != 0) && nr <= 4) {
@@ -653,7 +657,7 @@ void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units
         const int hw = P.svdpp_helpers >= 16 ? 16 : (P.svdpp_helpers >= 8 ? 8 : 4);
         if (rows > 64 * hw) rows = 64 * hw;   // a wave keeps its share of the ids in one register: 64 entries per wave
         const size_t lds_bytes = ((size_t)rows * (64 * nr + 1) + 64 * nr + 4) * sizeof(float);
-#define SVDF_WAVE_HELP(NR_, HW_) hipLaunchKernelGGL((k_svdpp_wave<NR_, true, true, true, false, HW_>), dim3((int)grid), dim3(64 * HW_), lds_bytes, st, P, D, units, fb_index, fb_value, order, begin, end, rows)
+#define SVDF_WAVE_HELP(NR_, HW_) hipLaunchKernelGGL((k_svdpp_wave<NR_, true, true, true, false, HW_>), dim3((int)grid), dim3(64 * HW_), lds_bytes, st, P, D, units, fb_index, fb_value, order, xunits, begin, end, rows)
 #define SVDF_WAVE_HELP_NR(NR_) \
         if (P.svdpp_helpers >= 16) SVDF_WAVE_HELP(NR_, 16); else if (P.svdpp_helpers >= 8) SVDF_WAVE_HELP(NR_, 8); else SVDF_WAVE_HELP(NR_, 4)
         switch (nr) {

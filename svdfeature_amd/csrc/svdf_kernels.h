@@ -32,7 +32,7 @@ void launch_svdpp(const DevParams &P, const DevCSR &D, const DevUnit *units, con
                   const int *order, long begin, long end, unsigned counter_base, hipStream_t st);
 // units flagged UNIT_SIMPLE (num_factor <= 256): one wave per user, see k_svdpp_wave
 void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
-                       const int *order, long begin, long end, hipStream_t st);
+                       const int *order, const DevUnitX *xunits, long begin, long end, hipStream_t st);
 // extend_type 2 (multi-level implicit feedback): units = block ranges of blks[]; predict_out != nullptr scores instead of training
 void launch_imfb(const DevParams &P, const DevCSR &D, const DevUnit *units, const DevBlk *blks, const unsigned *fb_index, const float *fb_value,
                  const int *order, long begin, long end, unsigned counter_base, float *predict_out, hipStream_t st);

@@ -149,6 +149,14 @@ struct DevUnit {
     int flags;                 // bit0: starts here (prepare_ufeedback), bit1: ends here (update_ufeedback),
                                // bit2: save state at exit, bit3: load state at entry, bit4: UNIT_SIMPLE fast path
 };
+// A unit as k_svdpp_wave wants it: in LAUNCH order (entry s of a level's range, no order[] indirection) and with what the wave would
+// otherwise fetch through two more dependent loads -- the first entry of its rows (row_ptr[3 row_begin]) and its user id.
+struct DevUnitX {
+    DevUnit u;
+    int e0;
+    unsigned user;
+    int pad;
+};
 // extend_type 2 (multi-level implicit feedback): one block of a unit.  [fb_begin, fb_end) is the list a DEFAULT / START block
 // prepares its level from, [sc_begin, sc_end) the list a DEFAULT / END block scatters through (its own list, which may differ
 // from the one the level was opened with, apex_multi_imfb.h:186-190).
