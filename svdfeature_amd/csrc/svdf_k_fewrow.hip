@@ -243,7 +243,9 @@ bool fewrow_fast_applies(const DevParams &P, const FusedSchedule &S) {
 }
 void launch_fewrow_fast(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int block_threads, hipStream_t st) {
     if (end <= begin) return;
-    if (block_threads <= 0) block_threads = 256;
+    // one-wave workgroups: a level of these workloads is a few hundred to a few thousand waves, and 64-thread blocks spread them over
+    // four times as many CUs (tools/ab_knob.py: neighbourhood 87.3 vs 91.8 ms per pass with 256; rank pairs 45.2 vs 45.4: flat)
+    if (block_threads <= 0) block_threads = 64;
     if (P.k == 128 && P.fewrow_i16 == 1) { launch_fewrow_slots<16, 2>(P, S, max_nu, max_ni, begin, end, block_threads, st); return; }
     // (eight lanes with four chunks each measured slower at k = 128: 46.7 vs 45.2 ms per 50 M pairs; 32 lanes, one chunk: 48.9)
     SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_fewrow_lpi<LPI>(P, S, max_nu, max_ni, begin, end, block_threads, st));

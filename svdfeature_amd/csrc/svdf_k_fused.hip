@@ -102,7 +102,7 @@ __global__ __launch_bounds__(HOTU ? 1024 : 256) void k_fused(const DevParams P, 
         for (int a = 0; a < NU; a++) {
             p[g][a] = f4zero(); bu[g][a] = 0.0f;
             if (ur[g][a] != SLOT_ABSENT) {
-                p[g][a] = load_row<LPI>(P.W, P.user_off + ur[g][a], pitch, L, k);
+                p[g][a] = (P.load_mode & 1) ? load_row_nt<LPI>(P.W, P.user_off + ur[g][a], pitch, L, k) : load_row<LPI>(P.W, P.user_off + ur[g][a], pitch, L, k);
                 if (use_ubias) bu[g][a] = P.bias[P.user_off + ur[g][a]];
             }
         }
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(HOTU ? 1024 : 256) void k_fused(const DevParams P, 
         for (int b = 0; b < NI; b++) {
             q[g][b] = f4zero(); bi[g][b] = 0.0f;
             if (ir[g][b] != SLOT_ABSENT) {
-                q[g][b] = load_row<LPI>(P.W, P.item_off + ir[g][b], pitch, L, k);
+                q[g][b] = (P.load_mode & 1) ? load_row_nt<LPI>(P.W, P.item_off + ir[g][b], pitch, L, k) : load_row<LPI>(P.W, P.item_off + ir[g][b], pitch, L, k);
                 bi[g][b] = P.bias[P.item_off + ir[g][b]];
             }
         }
@@ -318,7 +318,7 @@ void launch_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int ma
     if (P.fewrow_fast && fewrow_fast_applies(P, S)) { launch_fewrow_fast(P, S, max_nu, max_ni, begin, end, block_threads, st); return; }
     const int lpi_ = lanes_per_instance(P.k);
     if (groups_per_wave <= 0) groups_per_wave = lpi_ == 16 ? 2 : 1;
-    if (block_threads <= 0) block_threads = lpi_ == 16 ? 128 : 256;
+    if (block_threads <= 0) block_threads = 64;   // one-wave workgroups, see launch_fewrow_fast
     SVDF_DISPATCH_LPI(lanes_per_instance(P.k), launch_fused_lpi<LPI>(P, S, max_nu, max_ni, begin, end, groups_per_wave, block_threads, st));
 }
 template <int LPI>

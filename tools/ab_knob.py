@@ -20,10 +20,16 @@ def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     pairwise = "--pairwise" in sys.argv
     svdpp = "--svdpp" in sys.argv
+    neigh = "--neighbourhood" in sys.argv
     factor = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--factor=")]
     values = args
     nu, ni = 1_000_000, 100_000
-    if svdpp:
+    if neigh:
+        d_all = bench.synth_neighbourhood(4_000_000, nu, ni, 10000, 4)
+        t = sa.Trainer(0, 0)
+        conf = [("learning_rate", "0.005"), ("wd_item", "0.004"), ("wd_user", "0.004"), ("num_item", str(ni)), ("num_user", str(nu)),
+                ("num_factor", "128"), ("base_score", "3"), ("num_global", "10000"), ("wd_global", "0.001")]
+    elif svdpp:
         train, _ = bench.synth_user_blocks(40000, 100, nu, ni)
         t = sa.Trainer(1, 0)
         conf = [("learning_rate", "0.005"), ("wd_item", "0.004"), ("wd_user", "0.004"), ("num_item", str(ni)), ("num_user", str(nu)),
@@ -55,7 +61,7 @@ def main():
         if key not in dsets:
             if sb:
                 t.set_knob("sort_batches", int(sb[0].split("=")[1]))
-            dsets[key] = t.dataset_from_blocks(train) if svdpp else (t.dataset_from_pairs(u, p, q) if pairwise else t.dataset_from_triples(u, i, r))
+            dsets[key] = t.dataset_from_csr(d_all) if neigh else t.dataset_from_blocks(train) if svdpp else (t.dataset_from_pairs(u, p, q) if pairwise else t.dataset_from_triples(u, i, r))
     for ds in dsets.values():
         t.train_dataset(ds)
     t.synchronize()
