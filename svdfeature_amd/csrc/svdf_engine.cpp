@@ -583,6 +583,7 @@ const DevParams &Engine::params() {
     P.store_mode = store_mode_;
     P.load_mode = load_mode_ == 2 ? (pitch_ >= 64 ? 1 : 0) : load_mode_;   // auto: nontemporal row gathers for rows of two cache lines or more
     P.basic_i8 = basic_i8_;
+    P.small_blocks = small_blocks_;
     P.svdpp_helpers = svdpp_helpers_;
     P.fewrow_i16 = fewrow_i16_;
     P.xcd_remap = xcd_remap_;
@@ -2299,6 +2300,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "xcd_remap")) { xcd_remap_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "hot_reduce")) { hot_reduce_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "fewrow_i16")) { check(value >= 0 && value <= 1, "fewrow_i16 must be 0 or 1"); fewrow_i16_ = (int)value; params_dirty_ = true; return 0; }
+    if (!strcmp(name, "small_blocks")) { check(value == 0 || value == 1, "small_blocks must be 0 or 1"); small_blocks_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "svdpp_xunits")) { check(value == 0 || value == 1, "svdpp_xunits must be 0 or 1"); svdpp_xunits_ = (int)value; return 0; }
     if (!strcmp(name, "svdpp_helpers")) { check(value == 1 || value == 4 || value == 8 || value == 16, "svdpp_helpers must be 1, 4, 8 or 16"); svdpp_helpers_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "basic_i8")) { check(value >= 0 && value <= 1, "basic_i8 must be 0 or 1"); basic_i8_ = (int)value; params_dirty_ = true; return 0; }

@@ -390,7 +390,7 @@ class Engine {
     unsigned sample_counter_ = 0;
     DevBuf<unsigned> d_ref_ui_, d_ref_global_;
     bool lazy_decay() const { return tp_.reg_method >= 4 || tp_.reg_global >= 4; }
-    int groups_per_wave_ = 0, block_threads_ = 0, store_mode_ = 0, load_mode_ = 2, basic_i8_ = 1, svdpp_helpers_ = 8, svdpp_xunits_ = 1, fewrow_i16_ = 1, sort_batches_ = 1, xcd_remap_ = 1, hot_reduce_ = 1;   // 0 = tuned per factor width
+    int groups_per_wave_ = 0, block_threads_ = 0, store_mode_ = 0, load_mode_ = 2, basic_i8_ = 1, svdpp_helpers_ = 8, svdpp_xunits_ = 1, small_blocks_ = 1, fewrow_i16_ = 1, sort_batches_ = 1, xcd_remap_ = 1, hot_reduce_ = 1;   // 0 = tuned per factor width
     LevelTracker tracker_;
     void stage_rows(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value);
     void stage_rows_into(HostCSR &dst, int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value);

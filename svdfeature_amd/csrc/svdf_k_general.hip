@@ -142,8 +142,9 @@ __global__ __launch_bounds__(256) void k_svdpp_predict(const DevParams P, const 
 void launch_general(const DevParams &P, const DevCSR &D, const int *order, long begin, long end, unsigned counter_base, hipStream_t st) {
     if (end <= begin) return;
     const int lpi = lanes_per_instance(P.k);
-    const int grid = grid_for(end - begin, lpi, 256 * 8);
-    SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_general<LPI, R>), dim3(grid), dim3(256), 0, st, P, D, order, begin, end, counter_base));
+    int grid, block;
+    launch_shape(end - begin, lpi, 256 * 8, P.small_blocks != 0, grid, block);
+    SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_general<LPI, R>), dim3(grid), dim3(block), 0, st, P, D, order, begin, end, counter_base));
 }
 void launch_predict(const DevParams &P, const DevCSR &D, long n, float *out, hipStream_t st) {
     if (n <= 0) return;
@@ -155,8 +156,9 @@ void launch_svdpp(const DevParams &P, const DevCSR &D, const DevUnit *units, con
                   const int *order, long begin, long end, unsigned counter_base, hipStream_t st) {
     if (end <= begin) return;
     const int lpi = lanes_per_instance(P.k);
-    const int grid = grid_for(end - begin, lpi, 256 * 8);
-    SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_svdpp<LPI, R>), dim3(grid), dim3(256), 0, st, P, D, units, fb_index, fb_value, order, begin, end, counter_base));
+    int grid, block;
+    launch_shape(end - begin, lpi, 256 * 8, P.small_blocks != 0, grid, block);
+    SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_svdpp<LPI, R>), dim3(grid), dim3(block), 0, st, P, D, units, fb_index, fb_value, order, begin, end, counter_base));
 }
 void launch_svdpp_predict(const DevParams &P, const DevCSR &D, const DevUnit *units, const unsigned *fb_index, const float *fb_value,
                           long nunit, float *out, hipStream_t st) {

@@ -161,11 +161,12 @@ void launch_imfb(const DevParams &P, const DevCSR &D, const DevUnit *units, cons
                  const int *order, long begin, long end, unsigned counter_base, float *predict_out, hipStream_t st) {
     if (end <= begin) return;
     const int lpi = lanes_per_instance(P.k);
-    const int grid = grid_for(end - begin, lpi, 256 * 8);
+    int grid, block;
+    launch_shape(end - begin, lpi, 256 * 8, P.small_blocks != 0 && predict_out == nullptr, grid, block);
     if (predict_out) {
-        SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_imfb<LPI, R, true>), dim3(grid), dim3(256), 0, st, P, D, units, blks, fb_index, fb_value, order, begin, end, counter_base, predict_out));
+        SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_imfb<LPI, R, true>), dim3(grid), dim3(block), 0, st, P, D, units, blks, fb_index, fb_value, order, begin, end, counter_base, predict_out));
     } else {
-        SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_imfb<LPI, R, false>), dim3(grid), dim3(256), 0, st, P, D, units, blks, fb_index, fb_value, order, begin, end, counter_base, predict_out));
+        SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_imfb<LPI, R, false>), dim3(grid), dim3(block), 0, st, P, D, units, blks, fb_index, fb_value, order, begin, end, counter_base, predict_out));
     }
 }
 

@@ -90,6 +90,7 @@ struct DevParams {
     int store_mode;           // row-store cache policy of k_basicmf: 0 plain, 1 nontemporal, 2 sc1 write-through
     int fewrow_i16;           // k = 128 few-row kernel: sixteen lanes per row, 4 instances per wave (k_fewrow_i16)
     int svdpp_helpers;        // waves per user in k_svdpp_wave (1 = one wave per user; 4: helper waves gather / scatter the feedback rows through LDS)
+    int small_blocks;         // one-wave workgroups for levels of <= 8192 waves in the grid-stride kernels (launch_shape, svdf_device.h)
     int basic_i8;             // k = 64 basicMF: eight lanes per row, 8 instances per wave instruction (k_basicmf_i8)
     int load_mode;            // row-load cache policy of k_basicmf / k_fewrow_fast: 1 nontemporal hint -- a level reads each row once; measured
                               // -2.2 ... -4.2 % per pass at k = 64 (two cache lines per row), flat at 128 / 256, +16 % at k = 32 (one line): the

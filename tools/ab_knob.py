@@ -53,6 +53,9 @@ def main():
         t.set_param(kk, v)
     t.init_model()
     t.init_trainer()
+    for a in sys.argv[1:]:   # --pre=use_fused=0: a knob set once BEFORE the data sets are built (routes them to other kernels)
+        if a.startswith("--pre="):
+            t.set_knob(a[6:].split("=")[0], int(a[6:].split("=")[1]))
     # knobs that shape the data set (batch order) need a data set of their own per value: "sort_batches=2" inside a setting
     dsets = {}
     for v in values:
