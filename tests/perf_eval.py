@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--factor", type=int, default=64)
     ap.add_argument("--cpu-sample", type=int, default=5_000_000)
     ap.add_argument("--reps", type=int, default=5)
+    ap.add_argument("--knob", action="append", default=[], help="tuning knob name=value, repeatable")
     a = ap.parse_args()
     import cases
     import svdfeature_amd as sa
@@ -39,6 +40,8 @@ def main():
             x.set_param(k, v)
         x.init_model()
         x.init_trainer()
+    for kv in a.knob:
+        t.set_knob(kv.split("=")[0], int(kv.split("=")[1]))
     ds = t.dataset_from_triples(u, i, r)
     t.predict_dataset(ds)
     t0 = time.time()
