@@ -184,6 +184,22 @@ int svdf_item_delta_pack(svdf_trainer *t, void *device_dst, int half, int64_t *c
 int svdf_item_delta_select(svdf_trainer *t, int part, int nparts);
 int svdf_item_delta_unpack(svdf_trainer *t, const void *device_src, int half, int refresh_snapshot);
 
+/* ---- window-minibatch step of the N-rank path (svdf_k_window.hip).  The reference has no counterpart: it
+ * is single-process.  What is re-arranged is what ONE instance contributes in SVDFeature::update_no_decay +
+ * regularize (solvers/base-solver/apex_svd_base.h:383-427, :286-311): the user-side change is applied at once (users are
+ * private to a rank: exact sequential SGD), the item-side change is collected per window and applied after the all-reduce.
+ *   ds = svdf_dataset_window_from_triples(t, ...)   one exchange window of this rank's shard (user % N == rank), grouped by user
+ *   svdf_train_dataset(t, ds)                       every instance = the reference's update_inner on (current user side,
+ *                                                   window-start item side); W_item / i_bias are NOT written
+ *   svdf_window_delta_pack(t, ds, dst, half, &n)    dst = per item, the sum in file order of what its instances would have changed
+ *                                                   (same packed layout / item-range partition as svdf_item_delta_pack; NULL dst = size)
+ *   all-reduce(dst) over the ranks
+ *   svdf_window_delta_apply(t, dst, half)           replicated ranges += dst
+ * Deterministic (no float atomics); equals oracle/svdf_oracle.c: svdo_update_csr_batch_stale bit for bit with fp32 deltas. */
+svdf_dataset *svdf_dataset_window_from_triples(svdf_trainer *t, long n, const unsigned *user, const unsigned *item, const float *label);
+int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *device_dst, int half, int64_t *count);
+int svdf_window_delta_apply(svdf_trainer *t, const void *device_src, int half);
+
 /* ---- introspection used by tests, bench.py and the harness ---- */
 /* raw copies of parameter views: 0 u_bias 1 W_user 2 i_bias 3 W_item 4 g_bias 5 ufeedback_bias
  * 6 W_ufeedback; rows are returned unpadded.  Returns number of floats or -1. */

@@ -64,6 +64,8 @@ def _load(kind):
     lib.svdo_predict_csr.restype = C.c_float
     lib.svdo_update_csr_batch.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p]
     lib.svdo_predict_csr_batch.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p]
+    lib.svdo_update_csr_batch_stale.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p, _f32p, _f32p]
+    lib.svdo_update_csr_batch_stale.restype = C.c_int
     lib.svdo_update_block.argtypes = [P, C.c_int, C.c_int, _u32p, _f32p, C.c_int, _f32p, _i32p, _u32p, _f32p]
     lib.svdo_predict_block.argtypes = lib.svdo_update_block.argtypes + [_f32p]
     lib.svdo_get_view.argtypes = [P, C.c_int, _f32p, C.c_long]
@@ -163,6 +165,26 @@ class OracleTrainer:
     def update_batch(self, d):
         self.lib.svdo_update_csr_batch(self.h, d.num_row, _pad(d.row_label, np.float32), _pad(d.row_ptr, np.int32),
                                        _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32))
+
+    def update_batch_stale(self, d, delta=None):
+        """The window-minibatch checker step (svdf_oracle.h: svdo_update_csr_batch_stale): every row is the reference's
+        update_inner on (current user side, window-start replicated side); the replicated side stays as it is and its change is
+        accumulated in file order.  Returns (dW_item [num_item x k], di_bias, dg_bias); pass the previous result as `delta`
+        to keep accumulating into it."""
+        if delta is None:
+            shp = {}
+            for name in ("W_item", "i_bias", "g_bias"):
+                rows, cols = C.c_int(), C.c_int()
+                self.lib.svdo_view_shape(self.h, VIEW[name], C.byref(rows), C.byref(cols))
+                shp[name] = (max(rows.value, 0), max(cols.value, 1))
+            delta = (np.zeros(shp["W_item"], np.float32), np.zeros(shp["i_bias"][0], np.float32), np.zeros(shp["g_bias"][0], np.float32))
+        dW, db, dg = delta
+        rc = self.lib.svdo_update_csr_batch_stale(self.h, d.num_row, _pad(d.row_label, np.float32), _pad(d.row_ptr, np.int32),
+                                                  _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32),
+                                                  dW.reshape(-1) if dW.size else np.zeros(1, np.float32), db if db.size else np.zeros(1, np.float32),
+                                                  dg if dg.size else np.zeros(1, np.float32))
+        assert rc == 0, "window-minibatch step: configuration not supported by this checker"
+        return delta
 
     def predict_batch(self, d):
         out = np.zeros(max(d.num_row, 1), dtype=np.float32)

@@ -205,6 +205,61 @@ long svdo_get_view(svdo_trainer *t, int which, float *out, long capacity) {
 
 long svdo_set_view(svdo_trainer *, int, const float *, long) { return -1; }
 
+/* the window-minibatch checker step (svdf_oracle.h) on the REFERENCE's own classes: every row is one ISVDTrainer::update on a
+ * trainer whose replicated side has been put back to the window-start values through the reference's own save_model /
+ * load_model (model bytes patched in memory).  O(model size) per row: for small pinning tests only. */
+static void load_from_bytes(svdo_trainer *t, std::vector<char> &buf) {
+    FILE *fi = fmemopen(buf.data(), buf.size(), "rb");
+    char cwd[4096];
+    char tmpl[] = "/tmp/svdf_ref_XXXXXX";
+    char *scratch = mkdtemp(tmpl);   /* load_from_file drops text dumps into the CWD (apex_svd_model.h:586-621) */
+    bool moved = scratch && getcwd(cwd, sizeof(cwd)) && chdir(scratch) == 0;
+    t->tr->load_model(fi);
+    if (moved) {
+        const char *junk[] = {"u_bias.txt", "i_bias.txt", "w_user.txt", "w_item.txt"};
+        for (int i = 0; i < 4; i++) unlink(junk[i]);
+        if (chdir(cwd) != 0) { }
+        rmdir(scratch);
+    }
+    fclose(fi);
+}
+int svdo_update_csr_batch_stale(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                                const unsigned *feat_index, const float *feat_value, float *dW_item, float *di_bias, float *dg_bias) {
+    if (t->mtype.format_type != 0 || t->mtype.extend_type != 0) return -1;
+    SVDFeatureCSR m = make_csr(num_row, row_label, row_ptr, feat_index, feat_value);
+    std::vector<char> before, after;
+    view_pos vw, vb, vg;
+    for (int r = 0; r < num_row; r++) {
+        if (!dump_model(t, before)) return -1;
+        if (!locate(t, before, 3, vw) || !locate(t, before, 2, vb) || !locate(t, before, 4, vg)) return -1;
+        SVDFeatureCSR::Elem e = m[r];
+        t->tr->update(e);
+        if (!dump_model(t, after)) return -1;
+        const int k = vw.cols;
+        for (int i = 0; i < e.num_ifactor; i++) {
+            const unsigned iid = e.index_ifactor[i];
+            float *a = reinterpret_cast<float *>(after.data() + vw.off) + (size_t)iid * k;
+            const float *b = reinterpret_cast<const float *>(before.data() + vw.off) + (size_t)iid * k;
+            for (int j = 0; j < k; j++) { float c = a[j] - b[j]; dW_item[(size_t)iid * k + j] = dW_item[(size_t)iid * k + j] + c; a[j] = b[j]; }
+            float *ab = reinterpret_cast<float *>(after.data() + vb.off) + iid;
+            const float *bb = reinterpret_cast<const float *>(before.data() + vb.off) + iid;
+            float cb = *ab - *bb;
+            di_bias[iid] = di_bias[iid] + cb;
+            *ab = *bb;
+        }
+        for (int i = 0; i < e.num_global; i++) {
+            const unsigned gid = e.index_global[i];
+            float *ag = reinterpret_cast<float *>(after.data() + vg.off) + gid;
+            const float *bg = reinterpret_cast<const float *>(before.data() + vg.off) + gid;
+            float c = *ag - *bg;
+            dg_bias[gid] = dg_bias[gid] + c;
+            *ag = *bg;
+        }
+        load_from_bytes(t, after);
+    }
+    return 0;
+}
+
 
 /* ---- the reference's own ranker, obtained like svd_feature_infer.cpp obtains it: create_svd_ranker(SVDTypeParam) ---- */
 struct svdo_ranker { SVDTypeParam mtype; ISVDRanker *rk; };

@@ -862,6 +862,54 @@ void svdo_update_csr_batch(svdo_trainer *t, int num_row, const float *row_label,
         update_inner(t, &e);
     }
 }
+/* NOT a reference function -- the "window minibatch" step of the multi-GPU design restated on the CPU so
+ * that the HIP kernels (svdf_k_window.hip) can be checked bit for bit.  Every instance IS the reference's update_inner
+ * (apex_svd_base.h:456-462), applied to (the current user side, the WINDOW-START replicated side): whatever the instance
+ * changed on the replicated side -- W_item / i_bias rows of its item entries, g_bias of its global entries -- is put back
+ * afterwards, and the change is ADDED, instance after instance in file order, to the caller's delta arrays instead
+ * (dW_item: num_item x num_factor unpadded, di_bias: num_item, dg_bias: num_global).  The user side therefore sees exact
+ * sequential SGD, the replicated side one minibatch step per window: replicated += sum of the deltas of all ranks.
+ * Returns 0, or -1 for configurations whose per-instance step has side effects outside those rows (lazy decay, side tables on
+ * the item side, user-group trainers). */
+int svdo_update_csr_batch_stale(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                                const unsigned *feat_index, const float *feat_value, float *dW_item, float *di_bias, float *dg_bias) {
+    const int k = t->mp.num_factor;
+    if (t->tp.reg_method >= 4 || t->tp.reg_global >= 4 || t->feat_item.num_row > 0 || t->feat_user.num_row > 0 || is_user_group(t) || t->mtype[2] != 0 ||
+        t->mp.common_latent_space != 0) return -1;
+    float *save = (float *)malloc(sizeof(float) * (size_t)(k + 1) * 64);
+    size_t cap = 64;
+    for (int r = 0; r < num_row; r++) {
+        elem e = csr_row(r, row_label, row_ptr, feat_index, feat_value);
+        const size_t need = (size_t)e.ni + (size_t)e.ng;
+        if (need > cap) { cap = need * 2; save = (float *)realloc(save, sizeof(float) * (size_t)(k + 1) * cap); }
+        for (int i = 0; i < e.ni; i++) {
+            assert_true(e.ii[i] < (unsigned)t->mp.num_item, "item feature index exceed bound");
+            memcpy(save + (size_t)i * (k + 1), t->W_item + (size_t)e.ii[i] * t->pitch, sizeof(float) * (size_t)k);
+            save[(size_t)i * (k + 1) + k] = t->i_bias[e.ii[i]];
+        }
+        float *gsave = save + (size_t)e.ni * (k + 1);
+        for (int i = 0; i < e.ng; i++) {
+            assert_true(e.ig[i] < (unsigned)t->mp.num_global, "global feature index exceed setting");
+            gsave[i] = t->g_bias[e.ig[i]];
+        }
+        update_inner(t, &e);
+        for (int i = 0; i < e.ni; i++) {   /* an id listed twice: the first entry carries the whole change, the second sees none */
+            float *w = t->W_item + (size_t)e.ii[i] * t->pitch, *d = dW_item + (size_t)e.ii[i] * k;
+            const float *s = save + (size_t)i * (k + 1);
+            for (int j = 0; j < k; j++) { float c = w[j] - s[j]; d[j] = d[j] + c; w[j] = s[j]; }
+            float cb = t->i_bias[e.ii[i]] - s[k];
+            di_bias[e.ii[i]] = di_bias[e.ii[i]] + cb;
+            t->i_bias[e.ii[i]] = s[k];
+        }
+        for (int i = 0; i < e.ng; i++) {
+            float c = t->g_bias[e.ig[i]] - gsave[i];
+            dg_bias[e.ig[i]] = dg_bias[e.ig[i]] + c;
+            t->g_bias[e.ig[i]] = gsave[i];
+        }
+    }
+    free(save);
+    return 0;
+}
 void svdo_predict_csr_batch(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
                             const unsigned *feat_index, const float *feat_value, float *out) {
     for (int r = 0; r < num_row; r++) {

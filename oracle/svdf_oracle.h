@@ -53,6 +53,14 @@ void svdo_update_csr_batch(svdo_trainer *t, int num_row, const float *row_label,
 void svdo_predict_csr_batch(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
                             const unsigned *feat_index, const float *feat_value, float *out);
 
+/* NOT a reference function: the window-minibatch step of the multi-GPU design, the checker of
+ * svdf_train_dataset on a window data set.  Every row is the reference's update_inner applied to (current user side,
+ * window-start replicated side); the replicated side (W_item / i_bias / g_bias) is left unchanged and its would-be change is
+ * added, in file order, to dW_item (num_item x num_factor, unpadded) / di_bias (num_item) / dg_bias (num_global).
+ * Returns 0, -1 where the configuration is not supported. */
+int svdo_update_csr_batch_stale(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                                const unsigned *feat_index, const float *feat_value, float *dW_item, float *di_bias, float *dg_bias);
+
 /* ISVDTrainer::update(const SVDPlusBlock&) / predict(vector<float>&, const SVDPlusBlock&) */
 void svdo_update_block(svdo_trainer *t, int num_ufeedback, int extend_tag,
                        const unsigned *index_ufeedback, const float *value_ufeedback,

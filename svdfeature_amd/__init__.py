@@ -80,6 +80,10 @@ def load_library():
     lib.svdf_dataset_from_triples.argtypes = [P, C.c_long, _u32p, _u32p, _f32p]
     lib.svdf_dataset_from_pairs.restype = P
     lib.svdf_dataset_from_pairs.argtypes = [P, C.c_long, _u32p, _u32p, _u32p]
+    lib.svdf_dataset_window_from_triples.restype = P
+    lib.svdf_dataset_window_from_triples.argtypes = [P, C.c_long, _u32p, _u32p, _f32p]
+    lib.svdf_window_delta_pack.argtypes = [P, P, P, C.c_int, C.POINTER(C.c_int64)]
+    lib.svdf_window_delta_apply.argtypes = [P, P, C.c_int]
     lib.svdf_set_view.restype = C.c_int64
     lib.svdf_set_view.argtypes = [P, C.c_int, _f32p, C.c_int64]
     lib.svdf_dataset_from_buffer_file.restype = P
@@ -337,6 +341,23 @@ class Trainer:
         if not h:
             raise SvdfError(self.lib.svdf_last_error().decode())
         return Dataset(self, h)
+
+    def dataset_window_from_triples(self, user, item, label):
+        """One exchange window of a rank's shard for the window-minibatch step (svdf_dataset_window_from_triples)."""
+        h = self.lib.svdf_dataset_window_from_triples(self.h, len(label), _pad(user, np.uint32), _pad(item, np.uint32), _pad(label, np.float32))
+        if not h:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return Dataset(self, h)
+
+    def window_delta_pack(self, ds, device_ptr, half=False):
+        """Sum of the trained window's item-side contributions into the wire buffer at device_ptr; returns its element count."""
+        n = C.c_int64()
+        self._ok(self.lib.svdf_window_delta_pack(self.h, ds.h, C.c_void_p(device_ptr), 1 if half else 0, C.byref(n)))
+        return n.value
+
+    def window_delta_apply(self, device_ptr, half=False):
+        """replicated ranges += the (all-reduced) wire buffer"""
+        self._ok(self.lib.svdf_window_delta_apply(self.h, C.c_void_p(device_ptr), 1 if half else 0))
 
     def dataset_from_pairs(self, user, pos, neg):
         """Rank pairs (user, positive item, negative item), see svdf_dataset_from_pairs."""

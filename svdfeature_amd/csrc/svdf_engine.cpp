@@ -65,6 +65,7 @@ template struct DevBuf<signed char>;
 template struct DevBuf<double>;
 template struct DevBuf<long>;
 template struct DevBuf<char>;
+template struct DevBuf<WinUser>;
 
 // =============================================================================== scheduler
 void build_schedule(const std::vector<int> &levels, int base, Schedule &out) {
@@ -1887,8 +1888,98 @@ uint64_t Engine::schedule_signature() const {
     return h;
 }
 void Engine::disown(Dataset *ds) {
+    if (window_trained_ == ds) window_trained_ = nullptr;
     for (size_t i = 0; i < datasets_.size(); i++)
         if (datasets_[i] == ds) { datasets_[i] = datasets_.back(); datasets_.pop_back(); break; }
+}
+
+// =============================================================================== window-minibatch data sets (N > 1 ranks)
+// One exchange window of a rank's shard, grouped by user (svdf_k_window.hip).  svdf_train_dataset on it is
+// the first half of the window step (user side exact, item side read-only); window_delta_pack sums the item-side contributions
+// into the wire buffer; after the all-reduce window_delta_apply adds the sum on every rank.  Replaces what one instance
+// contributes in /root/reference/solvers/base-solver/apex_svd_base.h:383-427 being applied at once by "applied at the window's end".
+WindowSchedule Engine::window_view(const Dataset *ds) const {
+    return WindowSchedule{ds->win_urec.p, ds->num_units, ds->item.p, ds->label.p, ds->win_slot.p, ds->unit_values ? nullptr : ds->uval.p,
+                          ds->unit_values ? nullptr : ds->ival.p, ds->win_iptr.p, d_contrib_.p, d_cbias_.p};
+}
+Dataset *Engine::dataset_window_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
+    check(trainer_ready_, "dataset: init_trainer has not been called");
+    need_device("dataset");
+    check(!user_group() && mtype_.extend_type == 0, "window data sets: random-order trainers only");
+    check(basic_fast_path_allowed(), "window data sets: no side tables, relaxed ids, lazy decay or shared latent space; num_factor <= 256");
+    check(n >= 0 && n < (1L << 31), "window data sets: at most 2^31-1 instances per window");
+    const long NU = mp_.num_user, NI = mp_.num_item;
+    std::unique_ptr<Dataset> ds(new Dataset());
+    adopt(ds.get()); ds->num_row = n; ds->kind = 5;
+    std::vector<int> ucnt((size_t)NU, 0), iptr((size_t)NI + 1, 0);
+    for (long r = 0; r < n; r++) {
+        if (user[r] >= (unsigned)NU) fail("user feature index exceed bound");
+        if (item[r] >= (unsigned)NI) fail("item feature index exceed bound");
+        ucnt[user[r]]++;
+        iptr[(size_t)item[r] + 1]++;
+    }
+    for (long i = 0; i < NI; i++) iptr[(size_t)i + 1] += iptr[(size_t)i];
+    // users in launch order: by instance count, descending (the lane groups of a wave then run the same number of iterations),
+    // ties by user id; a user's instances are contiguous in that order
+    int maxc = 0;
+    long nact = 0;
+    for (long u = 0; u < NU; u++) { maxc = std::max(maxc, ucnt[(size_t)u]); nact += ucnt[(size_t)u] > 0; }
+    std::vector<long> start((size_t)maxc + 2, 0);
+    for (long u = 0; u < NU; u++) if (ucnt[(size_t)u] > 0) start[(size_t)ucnt[(size_t)u]]++;
+    { long acc = 0; for (int c = maxc; c >= 1; c--) { const long m = start[(size_t)c]; start[(size_t)c] = acc; acc += m; } }
+    std::vector<WinUser> urec((size_t)nact);
+    for (long u = 0; u < NU; u++) {
+        const int c = ucnt[(size_t)u];
+        if (c > 0) urec[(size_t)start[(size_t)c]++] = WinUser{(unsigned)u, 0, c, 0};
+    }
+    std::vector<int> ubegin((size_t)NU, 0);
+    { long acc = 0; for (long j = 0; j < nact; j++) { urec[(size_t)j].begin = (int)acc; ubegin[urec[(size_t)j].user] = (int)acc; acc += urec[(size_t)j].count; } }
+    std::vector<unsigned> w_item((size_t)n);
+    std::vector<float> w_label((size_t)n);
+    std::vector<int> w_slot((size_t)n), icur(iptr.begin(), iptr.end() - 1);
+    for (long r = 0; r < n; r++) {   // file order: a user's instances and an item's slots both keep it
+        const int pos = ubegin[user[r]]++;
+        w_item[(size_t)pos] = item[r];
+        w_label[(size_t)pos] = label[r];
+        w_slot[(size_t)pos] = icur[item[r]]++;
+    }
+    ds->win_urec.upload(urec.data(), (size_t)nact, stream_);
+    ds->item.upload(w_item.data(), (size_t)n, stream_);
+    ds->label.upload(w_label.data(), (size_t)n, stream_);
+    ds->win_slot.upload(w_slot.data(), (size_t)n, stream_);
+    ds->win_iptr.upload(iptr.data(), (size_t)NI + 1, stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    ds->unit_values = true;
+    ds->num_units = nact;
+    ds->sched.level_ptr = {0, n};
+    ds->sched.max_level_size = n;
+    const long nb = mp_.no_user_bias ? 1 : 2;
+    ds->algorithmic_bytes = n * (8L * mp_.num_factor * 2 + 8 * nb + 16 + 8 * 2);   // SURVEY 8(d4), what the reference's step moves per instance
+    return ds.release();
+}
+void Engine::window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t *count) {
+    check(trainer_ready_, "window_delta: init_trainer has not been called");
+    check(ds && ds->owner == this && ds->kind == 5, "window_delta_pack: not a window data set of this trainer");
+    check(!relaxed() && g_stride_ == 1 && user_off_ == 0, "window_delta_pack: random-order trainers without relaxed ids only");
+    const long ni = mp_.num_item;
+    const long lo = ni * delta_part_ / delta_nparts_, hi = ni * (delta_part_ + 1) / delta_nparts_;
+    const long nglobal = (delta_nparts_ == 1 || delta_part_ == 0) ? (long)mp_.num_global : 0;
+    const DeltaRanges R = delta_ranges();
+    check(R.off[R.n] == (hi - lo) * (pitch_ + 1) + nglobal, "window_delta_pack: unexpected layout of the replicated ranges");
+    if (count) *count = R.off[R.n];
+    if (!device_dst) return;
+    need_device("window_delta");
+    check(window_trained_ == ds, "window_delta_pack: train this window data set first (svdf_train_dataset)");
+    launch_window_items(window_view(ds), pitch_, mp_.num_factor, lo, hi, nglobal, device_dst, half, stream_);
+    HIPCHECK(hipGetLastError());
+    n_launches_++;
+}
+void Engine::window_delta_apply(const void *device_src, int half) {
+    need_device("window_delta");
+    flush();
+    launch_delta_addto(delta_ranges(), device_src, half, stream_);
+    HIPCHECK(hipGetLastError());
+    n_launches_++;
 }
 
 void Engine::train_dataset(Dataset *ds) {
@@ -1904,6 +1995,13 @@ void Engine::train_dataset(Dataset *ds) {
         if (ds->kind == 0) {
             BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
             for (size_t l = 0; l < sc.num_levels(); l++) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
+        } else if (ds->kind == 5) {
+            // window-minibatch step, first half: the users' exact walks; the item side is only read, its would-be change goes to the
+            // contribution slots that window_delta_pack sums (svdf_k_window.hip)
+            d_contrib_.reserve((size_t)ds->num_row * (size_t)pitch_);
+            d_cbias_.reserve((size_t)ds->num_row);
+            launch_window_users(P, window_view(ds), window_slots_, window_groups_, stream_);
+            window_trained_ = ds;
         } else if (ds->kind == 3) {
             const UnitDev &d = ds->unitdev;
             const DevCSR D = d.csr();
@@ -2315,6 +2413,8 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "device_schedule_min")) { check(value >= 1, "device_schedule_min must be >= 1"); device_sched_min_ = value; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "rows_without_feedback")) { rows_without_feedback_ = value != 0; return 0; }
+    if (!strcmp(name, "window_slots")) { window_slots_ = value != 0; return 0; }
+    if (!strcmp(name, "window_groups")) { check(value >= 0 && value <= 2, "window_groups must be 0 (auto), 1 or 2"); window_groups_ = (int)value; return 0; }
     if (!strcmp(name, "block_threads")) {
         check(value == 0 || value == 64 || value == 128 || value == 256, "block_threads must be 0 (auto), 64, 128 or 256");
         block_threads_ = (int)value;

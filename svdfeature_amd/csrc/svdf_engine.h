@@ -186,7 +186,11 @@ class Ranker;
 struct Dataset {
     Engine *owner = nullptr;
     long num_row = 0;
-    int kind = 0;                 // 0 basicMF fused kernel, 1 general sparse kernel, 2 few-row fused kernel, 3 SVD++ units, 4 multi-level units
+    int kind = 0;                 // 0 basicMF fused kernel, 1 general sparse kernel, 2 few-row fused kernel, 3 SVD++ units, 4 multi-level units,
+                                  // 5 window-minibatch (user-grouped instances of one exchange window, svdf_k_window.hip)
+    // kind 5: user records in launch order, user-grouped columns (item / label / uval / ival above), contribution slots, item segments
+    DevBuf<WinUser> win_urec;
+    DevBuf<int> win_slot, win_iptr;
     FusedDev fused;               // kind 2
     UnitDev unitdev;              // kind 3: user-group (SVD++) units
     Schedule sched;               // level_ptr always; order on the host only when built there or asked for (host_order)
@@ -250,6 +254,10 @@ class Engine {
     // for the same file takes it.  Nothing else may call rand() until then (the reference's loop does not, svd_feature.cpp:272-283)
     void rank_prefetch(const char *path);
     void rank_prefetch_drop();
+    // window-minibatch data set of one exchange window (N > 1 ranks: user side exact, item side one minibatch step per window)
+    Dataset *dataset_window_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
+    void window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t *count);   // per-item sum of the window's contributions -> wire buffer
+    void window_delta_apply(const void *device_src, int half);                           // replicated ranges += wire buffer
     void train_dataset(Dataset *ds);
     void predict_dataset(Dataset *ds, float *out);
     void eval_dataset(Dataset *ds, float scale, double *sum_sq, int64_t *count);
@@ -433,6 +441,10 @@ class Engine {
     UnitDev w_unitdev_;
     // ---- item delta
     DevBuf<float> d_snap_, d_delta_;
+    DevBuf<float> d_contrib_, d_cbias_;   // window-minibatch scratch: one contribution row + bias word per instance of the largest window
+    WindowSchedule window_view(const Dataset *ds) const;
+    Dataset *window_trained_ = nullptr;   // the window data set whose contributions the scratch holds
+    int window_slots_ = 1, window_groups_ = 0;   // knobs "window_slots", "window_groups"
     int delta_part_ = 0, delta_nparts_ = 1;
     DevBuf<double> d_partials_;
     struct Range { float *base; long n; };

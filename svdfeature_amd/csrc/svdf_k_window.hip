@@ -1,0 +1,332 @@
+// svdf_k_window.hip -- the WINDOW-MINIBATCH step of the multi-GPU path: three launches per exchange window
+// instead of one launch per conflict-free level.
+// (part of the gfx950 kernel set described at the top of svdf_device.h)
+//
+// With N ranks the contract is |dRMSE| <= 1e-4, not bit parity, and users are private to a rank (rank = user % N).  So inside a window
+//   * the USER side stays exact: a lane group walks ONE user's instances of the window in file order with the user's row and bias in
+//     registers -- the reference's update_inner (apex_svd_base.h:456-462) instance after instance;
+//   * the ITEM side is read as it was at the window start (W_item / i_bias are not written inside a window: they are their own
+//     snapshot, L2 / Infinity-Cache resident at 25.6 MB) and what update_inner WOULD have changed on it, (q + s*p)*decay - q, is
+//     stored per instance into a contribution slot;
+//   * k_window_items sums every item's contributions IN FILE ORDER (slots are laid out item by item, so the sum is a streaming
+//     read; no float atomics: the result is deterministic and equals oracle/svdf_oracle.c: svdo_update_csr_batch_stale bit for bit)
+//     straight into the wire buffer of the all-reduce, fp32 or fp16;
+//   * k_delta_addto adds the all-reduced sum to the replicated ranges on every rank.
+// Pack, snapshot copy and the ~15 dependent level launches per window of the level-scheduled shard are gone.
+#include "svdf_device.h"
+
+namespace svdf {
+
+// One user's instances of a window: entries [begin, begin + count) of the user-grouped columns.
+// Records are in LAUNCH order: users sorted by count (descending), so the lane groups of a wave run the same number of iterations.
+
+// ------------------------------------------------------------------------------------------------- kernel A, any width <= 256
+template <int LPI, bool UNITVAL>
+__global__ __launch_bounds__(256) void k_window_users(const DevParams P, const WindowSchedule S) {
+    constexpr int IPW = 64 / LPI;
+    const int lane = threadIdx.x & 63;
+    const int L = lane & (LPI - 1);
+    const int gslot = lane / LPI;
+    const long uidx = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * IPW + gslot;
+    const long wave_first = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * IPW;
+    if (wave_first >= S.nusers) return;
+    const bool valid = uidx < S.nusers;
+    const WinUser rec = S.urec[valid ? uidx : wave_first];
+    const int maxc = S.urec[wave_first].count;          // records are sorted by count, descending: the wave's first user has the most
+    const int pitch = P.pitch, k = P.k;
+    const bool use_ubias = P.no_user_bias == 0;
+    const unsigned ur = P.user_off + rec.user;
+    float4 p = load_row<LPI>(P.W, ur, pitch, L, k);
+    float bu = use_ubias ? P.bias[ur] : 0.0f;
+    const float wd_u = get_wd(P.u_rng, rec.user, P.wd_user);
+    for (int j = 0; j < maxc; j++) {
+        const bool act = valid && j < rec.count;
+        const long s = (long)rec.begin + (act ? j : 0);
+        const unsigned item = S.item[s];
+        const unsigned ir = P.item_off + item;
+        const float label = S.label[s];
+        const float ua = UNITVAL ? 1.0f : S.uval[s], ia = UNITVAL ? 1.0f : S.ival[s];
+        const float4 q = load_row<LPI>(P.W, ir, pitch, L, k);
+        const float bi = P.bias[ir];
+        // calc_bias (:313-353) in double; "+ 0.0" terms are the svdpp / plugin hooks returning 0.0f
+        double bs = 0.0;
+        if (use_ubias) { bs += (double)(ua * bu); bs += 0.0; }
+        bs += 0.0;
+        bs += (double)(ia * bi);
+        double sum = (double)P.base_score + bs;
+        float4 tu = f4zero(), ti = f4zero();
+        axpy4(tu, p, ua);
+        axpy4(ti, q, ia);
+        sum += (double)group_dot<LPI>(tu, ti, L, k);
+        const float pred = map_active((float)sum, P.active_type);
+        const float err = cal_grad(label, pred, P.active_type) * 1.0f;
+        const float su = P.lr * err * ua;
+        const float si = P.lr * err * ia;
+        float4 wu = p, wi = q;
+        axpy4(wu, ti, su);
+        axpy4(wi, tu, si);
+        float nbu = bu + su, nbi = bi + si;
+        reg_row<LPI>(P, wu, wd_u, false, L);
+        reg_row<LPI>(P, wi, get_wd(P.i_rng, item, P.wd_item), true, L);
+        nbu = nbu * (1.0f - P.lr * P.wd_user_bias);
+        nbi = nbi * (1.0f - P.lr * P.wd_item_bias);
+        if (act) {
+            p = wu;
+            if (use_ubias) bu = nbu;
+            // what the reference would have changed on the item side
+            sub4(wi, q);
+            const long slot = S.slot[s];
+            store_row<LPI>(S.contrib, (size_t)slot, pitch, L, k, wi);
+            if (L == 0) S.cbias[slot] = nbi - bi;
+        }
+    }
+    if (valid) {
+        store_row<LPI>(P.W, ur, pitch, L, k, p);
+        if (use_ubias && L == 0) P.bias[ur] = bu;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------- kernel A, the contract configuration
+// k = 4 * LANES * V full rows, unit values, linear link, L2 decay without ranges, user bias on (k_basicmf_slots' configuration): LANES
+// lanes per user with V chunks each, the 16 / LANES users of a DPP row interleaved (dot_slots), G user sets per wave, and the NEXT
+// instance's item row, bias and record in flight while this one is computed (the item side is read-only inside a window, so the
+// prefetch cannot go stale).
+template <int LANES, int V, int G>
+__global__ __launch_bounds__(256) void k_window_users_slots(const DevParams P, const WindowSchedule S) {
+    constexpr int T = 16 / LANES;
+    constexpr int IPS = 64 / LANES;    // users per user set
+    constexpr int K = 4 * LANES * V;
+    const int lane = threadIdx.x & 63;
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long w0 = wave * (long)(G * IPS);
+    if (w0 >= S.nusers) return;
+    const int m = (lane & 15) / T;
+    const int gslot = (lane >> 4) * T + (lane & (T - 1));
+    const int pitch = P.pitch;
+    const int maxc = S.urec[w0].count;
+    const float dec_u1 = snap_to_one(1.0f - P.lr * P.wd_user), dec_i1 = snap_to_one(1.0f - P.lr * P.wd_item);
+    const float dec_ub = 1.0f - P.lr * P.wd_user_bias, dec_ib = 1.0f - P.lr * P.wd_item_bias;
+
+    bool valid[G];
+    int begin[G], count[G];
+    unsigned ur[G];
+    float bu[G];
+    float4 p[G][V];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const long u = w0 + (long)g * IPS + gslot;
+        valid[g] = u < S.nusers;
+        const WinUser rec = S.urec[valid[g] ? u : w0];
+        begin[g] = rec.begin; count[g] = valid[g] ? rec.count : 0;
+        ur[g] = P.user_off + rec.user;
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+#pragma unroll
+        for (int v = 0; v < V; v++) p[g][v] = load_row_nt<K / 4>(P.W, ur[g], pitch, m + v * LANES, K);
+        bu[g] = P.bias[ur[g]];
+    }
+    // software pipeline: record / item row / item bias of iteration j + 1 are requested before iteration j is computed
+    unsigned nir[G];
+    float nlabel[G], nbi_[G];
+    int nslot[G];
+    float4 nq[G][V];
+    auto fetch = [&](int j) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const long s = (long)begin[g] + (j < count[g] ? j : 0);
+            nir[g] = P.item_off + S.item[s];
+            nlabel[g] = S.label[s];
+            nslot[g] = S.slot[s];
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+#pragma unroll
+            for (int v = 0; v < V; v++) nq[g][v] = load_row<K / 4>(P.W, nir[g], pitch, m + v * LANES, K);
+            nbi_[g] = P.bias[nir[g]];
+        }
+    };
+    fetch(0);
+    for (int j = 0; j < maxc; j++) {
+        float label[G], bi[G];
+        int slot[G];
+        float4 q[G][V];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            label[g] = nlabel[g]; bi[g] = nbi_[g]; slot[g] = nslot[g];
+#pragma unroll
+            for (int v = 0; v < V; v++) q[g][v] = nq[g][v];
+        }
+        if (j + 1 < maxc) fetch(j + 1);
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const bool act = j < count[g];
+            // the arithmetic of k_basicmf_slots, the user's row and bias carried in registers
+            double bs = 0.0;
+            bs += (double)(1.0f * bu[g]); bs += 0.0;
+            bs += 0.0;
+            bs += (double)(1.0f * bi[g]);
+            double sum = (double)P.base_score + bs;
+            float4 tu[V], ti[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) { tu[v] = f4zero(); ti[v] = f4zero(); axpy4(tu[v], p[g][v], 1.0f); axpy4(ti[v], q[g][v], 1.0f); }
+            sum += (double)dot_slots<LANES, V>(tu, ti, m, lane);
+            const float pred = (float)sum;
+            const float err = (label[g] - pred) * 1.0f;
+            const float su = P.lr * err * 1.0f;
+            const float si = P.lr * err * 1.0f;
+            float nbu = bu[g] + su, nbi = bi[g] + si;
+            nbu = nbu * dec_ub;
+            nbi = nbi * dec_ib;
+            float4 c[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                float4 wu = p[g][v], wi = q[g][v];
+                axpy4(wu, ti[v], su);
+                axpy4(wi, tu[v], si);
+                wu.x = wu.x * dec_u1; wu.y = wu.y * dec_u1; wu.z = wu.z * dec_u1; wu.w = wu.w * dec_u1;
+                wi.x = wi.x * dec_i1; wi.y = wi.y * dec_i1; wi.z = wi.z * dec_i1; wi.w = wi.w * dec_i1;
+                sub4(wi, q[g][v]);
+                c[v] = wi;
+                if (act) p[g][v] = wu;
+            }
+            if (act) {
+                bu[g] = nbu;
+#pragma unroll
+                for (int v = 0; v < V; v++) store_row<K / 4>(S.contrib, (size_t)slot[g], pitch, m + v * LANES, K, c[v]);
+                S.cbias[slot[g]] = nbi - bi[g];
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        if (valid[g]) {
+#pragma unroll
+            for (int v = 0; v < V; v++) store_row<K / 4>(P.W, ur[g], pitch, m + v * LANES, K, p[g][v]);
+            P.bias[ur[g]] = bu[g];
+        }
+    }
+}
+
+bool window_slots_applies(const DevParams &P, const WindowSchedule &S) {
+    return S.uval == nullptr && P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 && P.user_nonnegative == 0 &&
+           P.u_rng.n == 0 && P.i_rng.n == 0 && (P.k == 64 || P.k == 128);
+}
+
+void launch_window_users(const DevParams &P, const WindowSchedule &S, int slots, int groups_per_wave, hipStream_t st) {
+    if (S.nusers <= 0) return;
+    if (slots && window_slots_applies(P, S)) {
+        auto go = [&](auto lanes, auto gg) {
+            constexpr int LANES = decltype(lanes)::value, G = decltype(gg)::value;
+            const long per_wave = (long)G * (64 / LANES);
+            const long waves = (S.nusers + per_wave - 1) / per_wave;
+            hipLaunchKernelGGL((k_window_users_slots<LANES, 2, G>), dim3((unsigned)waves), dim3(64), 0, st, P, S);
+        };
+        const int g = groups_per_wave > 0 ? groups_per_wave : 1;
+        if (P.k == 64) {
+            if (g >= 2) go(std::integral_constant<int, 8>(), std::integral_constant<int, 2>());
+            else go(std::integral_constant<int, 8>(), std::integral_constant<int, 1>());
+        } else {
+            if (g >= 2) go(std::integral_constant<int, 16>(), std::integral_constant<int, 2>());
+            else go(std::integral_constant<int, 16>(), std::integral_constant<int, 1>());
+        }
+        return;
+    }
+    const int lpi = lanes_per_instance(P.k);
+    const long ipw = 64 / lpi;
+    const long waves = (S.nusers + ipw - 1) / ipw;
+    if (S.uval == nullptr) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_users<LPI, true>), dim3((unsigned)waves), dim3(64), 0, st, P, S)); }
+    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_users<LPI, false>), dim3((unsigned)waves), dim3(64), 0, st, P, S)); }
+}
+
+// ------------------------------------------------------------------------------------------------- kernel B
+// Item i's contributions sit in slots [iptr[i], iptr[i + 1]), in file order.  One lane group per item sums them in that order
+// (acc = 0 + c_1 + c_2 ..., four rows requested ahead) and writes the item's row and bias of the wire buffer:
+// dst = [ (hi - lo) rows of `pitch` | (hi - lo) item biases | nglobal zeros ] for the item range [lo, hi) of the active
+// exchange partition (svdf_item_delta_select) -- the packed layout of k_delta_pack.
+template <int LPI, bool HALF>
+__global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, int pitch, int k, long lo, long hi, long nglobal, void *dst) {
+    constexpr int IPW = 64 / LPI;
+    const int lane = threadIdx.x & 63;
+    const int L = lane & (LPI - 1);
+    const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
+    const long first = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * IPW + lane / LPI;
+    const long nitem = hi - lo;
+    for (long it = first; it < nitem; it += stride) {
+        const long i = lo + it;
+        const int b = S.iptr[i], e = S.iptr[i + 1];
+        float4 acc = f4zero();
+        float accb = 0.0f;
+        int t = b;
+        for (; t + 4 <= e; t += 4) {
+            const float4 c0 = load_row<LPI>(S.contrib, (size_t)t, pitch, L, k), c1 = load_row<LPI>(S.contrib, (size_t)t + 1, pitch, L, k);
+            const float4 c2 = load_row<LPI>(S.contrib, (size_t)t + 2, pitch, L, k), c3 = load_row<LPI>(S.contrib, (size_t)t + 3, pitch, L, k);
+            const float b0 = S.cbias[t], b1 = S.cbias[t + 1], b2 = S.cbias[t + 2], b3 = S.cbias[t + 3];
+            add_rows(acc, c0); add_rows(acc, c1); add_rows(acc, c2); add_rows(acc, c3);
+            accb = accb + b0; accb = accb + b1; accb = accb + b2; accb = accb + b3;
+        }
+        for (; t < e; t++) {
+            add_rows(acc, load_row<LPI>(S.contrib, (size_t)t, pitch, L, k));
+            accb = accb + S.cbias[t];
+        }
+        if (!(LPI * 4 > k && L * 4 >= k)) {
+            const size_t pos = (size_t)it * pitch + (size_t)L * 4;
+            if (HALF) {
+                __half2 *h = reinterpret_cast<__half2 *>(reinterpret_cast<__half *>(dst) + pos);
+                h[0] = __halves2half2(__float2half_rn(acc.x), __float2half_rn(acc.y));
+                h[1] = __halves2half2(__float2half_rn(acc.z), __float2half_rn(acc.w));
+            } else {
+                *reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + pos) = acc;
+            }
+        }
+        if (L == 0) {
+            const size_t pos = (size_t)nitem * pitch + (size_t)it;
+            if (HALF) reinterpret_cast<__half *>(dst)[pos] = __float2half_rn(accb);
+            else reinterpret_cast<float *>(dst)[pos] = accb;
+        }
+    }
+    // the global biases' part of the wire buffer: a window data set carries no global entry
+    const long g0 = nitem * (long)(pitch + 1);
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < nglobal; j += (long)gridDim.x * blockDim.x) {
+        if (HALF) reinterpret_cast<__half *>(dst)[g0 + j] = __float2half_rn(0.0f);
+        else reinterpret_cast<float *>(dst)[g0 + j] = 0.0f;
+    }
+}
+void launch_window_items(const WindowSchedule &S, int pitch, int k, long lo, long hi, long nglobal, void *dst, int half, hipStream_t st) {
+    if (hi <= lo && nglobal <= 0) return;
+    const int lpi = lanes_per_instance(k);
+    const long ipw = 64 / lpi;
+    long waves = (std::max<long>(hi - lo, 1) + ipw - 1) / ipw;
+    long grid = (waves + 3) / 4;
+    if (grid > 16384) grid = 16384;
+    if (half) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, true>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst)); }
+    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst)); }
+}
+
+// ------------------------------------------------------------------------------------------------- kernel C
+// replicated ranges += the all-reduced window delta (packed layout of k_delta_pack)
+__device__ __forceinline__ float *addto_slot(const DeltaRanges &R, long j) {
+    int r = 0;
+#pragma unroll
+    for (int q = 1; q < SVDF_MAX_DELTA_RANGES; q++) r += (q < R.n && j >= R.off[q]) ? 1 : 0;
+    return R.base[r] + (j - R.off[r]);
+}
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_delta_addto(const DeltaRanges R, const void *src, long total) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        const float d = HALF ? __half2float(reinterpret_cast<const __half *>(src)[j]) : reinterpret_cast<const float *>(src)[j];
+        float *cur = addto_slot(R, j);
+        *cur = *cur + d;
+    }
+}
+void launch_delta_addto(const DeltaRanges &R, const void *src, int half, hipStream_t st) {
+    const long total = R.off[R.n];
+    if (total <= 0) return;
+    long grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (half) hipLaunchKernelGGL(k_delta_addto<true>, dim3((int)grid), dim3(256), 0, st, R, src, total);
+    else hipLaunchKernelGGL(k_delta_addto<false>, dim3((int)grid), dim3(256), 0, st, R, src, total);
+}
+
+}  // namespace svdf

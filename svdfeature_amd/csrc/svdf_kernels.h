@@ -44,6 +44,12 @@ void launch_svdpp_predict(const DevParams &P, const DevCSR &D, const DevUnit *un
 // multi-GPU item-side delta over n floats
 void launch_delta_pack(const DeltaRanges &R, const float *snap, void *dst, int half, hipStream_t st);
 void launch_delta_unpack(const DeltaRanges &R, float *snap, const void *src, int half, int refresh, hipStream_t st);
+// window-minibatch step (svdf_k_window.hip): user walk with the item side read-only, per-item sum of the contributions into the wire
+// buffer (item range [lo, hi) + nglobal zeros), and replicated ranges += all-reduced wire buffer
+bool window_slots_applies(const DevParams &P, const WindowSchedule &S);
+void launch_window_users(const DevParams &P, const WindowSchedule &S, int slots, int groups_per_wave, hipStream_t st);
+void launch_window_items(const WindowSchedule &S, int pitch, int k, long lo, long hi, long nglobal, void *dst, int half, hipStream_t st);
+void launch_delta_addto(const DeltaRanges &R, const void *src, int half, hipStream_t st);
 void launch_pairs_prepare(long n, const unsigned *pos, const unsigned *neg, unsigned *lo, unsigned *hi, float *vlo, float *vhi, float *ones,
                           unsigned *flag, hipStream_t st);
 void launch_delta_sum(const void *const *srcs, int n, void *dst, long total, int half, hipStream_t st);   // up to 16 buffers

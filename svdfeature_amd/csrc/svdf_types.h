@@ -170,6 +170,23 @@ struct DevBlk {
 enum { UNIT_START = 1, UNIT_END = 2, UNIT_SAVE = 4, UNIT_LOAD = 8,
        UNIT_SIMPLE = 16 };   // host-verified: rows are (0,1,1) with one user id, distinct feedback ids (repeated items: row_fresh)
 
+// Window-minibatch data set (svdf_k_window.hip): the instances of one exchange window grouped by user.
+// urec is in LAUNCH order (users sorted by instance count, descending); a user's instances are entries [begin, begin + count)
+// of the user-grouped columns, in file order; slot[s] is where instance s's item-side contribution goes: slots are laid out item
+// by item (iptr), inside an item in file order.
+struct WinUser { unsigned user; int begin; int count; int pad; };
+struct WindowSchedule {
+    const WinUser *urec;
+    long nusers;
+    const unsigned *item;
+    const float *label;
+    const int *slot;
+    const float *uval, *ival;   // nullptr when every feature value is 1.0f
+    const int *iptr;            // [num_item + 1]
+    float *contrib;             // [n][pitch] scratch, owned by the trainer
+    float *cbias;               // [n]
+};
+
 }  // namespace svdf
 // replicated (item-side) parameter ranges of the multi-GPU exchange, packed back to back: range r covers packed
 // positions [off[r], off[r+1])

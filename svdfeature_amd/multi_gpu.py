@@ -168,6 +168,11 @@ class ShardedTrainer:
 
     def __init__(self, adaptor, window_handles, world, dist=None, force_exchange=False, half_delta=False, parts=1):
         self.a, self.windows, self.world, self.dist = adaptor, window_handles, world, dist
+        # window-minibatch adaptors (HipShard(minibatch=True)): train() leaves the replicated side as it was at the window start
+        # and collects its change, delta_get() returns the per-item sums, delta_set() ADDS the all-reduced sum.  The exchange step
+        # is then part of the algorithm (the item side only moves through it), so it runs with one rank as well -- without the
+        # collective -- and the result does not depend on the number of ranks beyond the order of fp32 additions.
+        self.minibatch = bool(getattr(adaptor, "minibatch", False))
         # parts > 1: every window handle is a LIST of `parts` handles (pieces by item id range, split_by_item_range); the
         # all-reduce of piece p runs while piece p+1 trains.  A piece's item rows are not touched between its pack and its
         # unpack, so the values are those of the synchronous piece-by-piece schedule: no added staleness, only the order of
@@ -182,6 +187,8 @@ class ShardedTrainer:
             adaptor.set_wire_half(half_delta)
 
     def _reduce(self, d):
+        if self.world == 1 and self.dist is None:
+            return   # one rank, window-minibatch mode: the sum over ranks is the rank's own delta
         if hasattr(self.a, "all_reduce"):
             self.a.all_reduce(self.dist, d)   # ordered on the adaptor's stream, d already in the wire format
         elif self.half_delta:
@@ -208,7 +215,7 @@ class ShardedTrainer:
             a.delta_set(d, part)
 
         for wi, w in enumerate(self.windows):
-            if self.world == 1 and not self.force_exchange:
+            if self.world == 1 and not self.force_exchange and not self.minibatch:
                 for ds in w:
                     a.train(ds)
                 continue
@@ -220,7 +227,7 @@ class ShardedTrainer:
             for part, ds in enumerate(w):
                 a.train(ds)
                 d = a.delta_get(part)
-                work = a.all_reduce_async(self.dist, d) if hasattr(a, "all_reduce_async") else self._reduce(d)
+                work = a.all_reduce_async(self.dist, d) if (hasattr(a, "all_reduce_async") and self.dist is not None) else self._reduce(d)
                 if pending is not None:
                     finish(pending)   # enqueued AFTER this piece's training: the previous collective had all of it to overlap with
                 pending = (work, d, part)
@@ -232,7 +239,7 @@ class ShardedTrainer:
             return self._train_pass_parts()
         keep_snapshot = getattr(self.a, "apply_refreshes_snapshot", False)
         for wi, w in enumerate(self.windows):
-            if self.world == 1 and not self.force_exchange:
+            if self.world == 1 and not self.force_exchange and not self.minibatch:
                 self.a.train(w)
                 continue
             if wi == 0 or not keep_snapshot:
@@ -251,8 +258,13 @@ class HipShard:
 
     apply_refreshes_snapshot = True
 
-    def __init__(self, trainer, torch, device, parts=1):
+    def __init__(self, trainer, torch, device, parts=1, minibatch=False):
         self.t, self.torch, self.device = trainer, torch, device
+        # window-minibatch mode (svdf_k_window.hip): windows are svdf_dataset_window_from_triples data sets; train = the users'
+        # exact walks with the item side read-only, delta_get = per-item sum of the contributions straight into the wire buffer,
+        # delta_set = replicated ranges += all-reduced buffer.  No snapshot, no pack.
+        self.minibatch = bool(minibatch)
+        self.last = None
         self.stream = torch.cuda.Stream(device=device)
         trainer.set_stream(self.stream.cuda_stream)
         self.buf = None
@@ -271,7 +283,12 @@ class HipShard:
         out = []
         for sh in shards:
             if isinstance(sh, list):    # item-range pieces of one window
-                out.append([self.t.dataset_from_triples(*piece) for piece in sh])
+                mk = self.t.dataset_window_from_triples if self.minibatch else self.t.dataset_from_triples
+                out.append([mk(*piece) for piece in sh])
+                continue
+            if self.minibatch:
+                assert not isinstance(sh, (BlockArrays, Pairs)), "window-minibatch mode: (user, item, rating) triples only"
+                out.append(self.t.dataset_window_from_triples(*sh))
                 continue
             if isinstance(sh, BlockArrays):
                 out.append(self.t.dataset_from_blocks(sh))
@@ -283,6 +300,7 @@ class HipShard:
 
     def train(self, ds):
         self.t.train_dataset(ds)
+        self.last = ds
 
     def gather_user_side(self, dist, rank, world):
         """W_user / u_bias rows are private to their owner (user % world): sum the owners' rows over the ranks so that every
@@ -299,7 +317,20 @@ class HipShard:
             self.t.set_view(name, tns.cpu().numpy())
 
     def delta_begin(self):
-        self.t.item_delta_begin()
+        if not self.minibatch:
+            self.t.item_delta_begin()
+
+    def _pack(self, ptr):
+        if self.minibatch:
+            self.t.window_delta_pack(self.last, ptr, self.half)
+        else:
+            self.t.item_delta_pack(ptr, self.half)
+
+    def _apply(self, ptr):
+        if self.minibatch:
+            self.t.window_delta_apply(ptr, self.half)
+        else:
+            self.t.item_delta_unpack(ptr, self.half, refresh_snapshot=True)
 
     def delta_get(self, part=None):
         if part is not None:   # one item-range piece of the exchange, a buffer of its own (its collective may still be in flight)
@@ -308,14 +339,14 @@ class HipShard:
                 with self.torch.cuda.stream(self.stream):
                     self.bufs[part] = self.torch.empty(self.t.item_delta_count(), device=self.device,
                                                        dtype=self.torch.float16 if self.half else self.torch.float32)
-            self.t.item_delta_pack(self.bufs[part].data_ptr(), self.half)
+            self._pack(self.bufs[part].data_ptr())
             self.t.item_delta_select(0, 1)
             return self.bufs[part]
         if self.buf is None:
             with self.torch.cuda.stream(self.stream):
                 self.buf = self.torch.empty(self.t.item_delta_count(), device=self.device,
                                             dtype=self.torch.float16 if self.half else self.torch.float32)
-        self.t.item_delta_pack(self.buf.data_ptr(), self.half)
+        self._pack(self.buf.data_ptr())
         return self.buf
 
     def all_reduce(self, dist, d):
@@ -338,7 +369,7 @@ class HipShard:
     def delta_set(self, d, part=None):
         if part is not None:
             self.t.item_delta_select(part, self.parts)
-            self.t.item_delta_unpack(d.data_ptr(), self.half, refresh_snapshot=True)
+            self._apply(d.data_ptr())
             self.t.item_delta_select(0, 1)
             return
-        self.t.item_delta_unpack(d.data_ptr(), self.half, refresh_snapshot=True)
+        self._apply(d.data_ptr())

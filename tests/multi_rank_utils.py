@@ -21,11 +21,15 @@ def make_oracle(conf, seed=10, fmt=0, active=0):
 class OracleShard:
     """multi_gpu adaptor protocol on top of the C oracle; deltas travel as torch CPU tensors (gloo)."""
 
-    def __init__(self, trainer, torch=None, parts=1):
+    def __init__(self, trainer, torch=None, parts=1, minibatch=False):
         self.t, self.torch = trainer, torch
         self.snap = None
         self.parts = parts
         self.apply_refreshes_snapshot = parts > 1   # piece-wise exchange keeps one running snapshot per pass
+        # window-minibatch mode (multi_gpu.ShardedTrainer(minibatch=True)): train() leaves the replicated side untouched and
+        # collects its change (oracle.update_batch_stale); delta_get returns it; delta_set ADDS the all-reduced sum
+        self.minibatch = minibatch
+        self.mb_delta = None
 
     def make_windows(self, shards):
         out = []
@@ -42,7 +46,10 @@ class OracleShard:
         return out
 
     def train(self, d):
-        if isinstance(d, list):
+        if self.minibatch:
+            assert not isinstance(d, list), "window-minibatch mode: random-order data only"
+            self.mb_delta = self.t.update_batch_stale(d)
+        elif isinstance(d, list):
             for b in d:
                 self.t.update_block(b)
         else:
@@ -62,6 +69,8 @@ class OracleShard:
         return np.concatenate([v.ravel() for _, v in self._views()])
 
     def delta_begin(self):
+        if self.minibatch:
+            return   # the replicated side does not move inside a window: it is its own snapshot
         self.snap = self._shared()
 
     def _piece(self, part):
@@ -80,6 +89,12 @@ class OracleShard:
         return np.concatenate(pos)
 
     def delta_get(self, part=None):
+        if self.minibatch:
+            dW, db, dg = self.mb_delta
+            d = np.concatenate([dW.ravel(), db, dg])   # the SHARED order of a random-order trainer: W_item, i_bias, g_bias
+            if part is not None:
+                d = np.ascontiguousarray(d[self._piece(part)])
+            return self.torch.from_numpy(d) if self.torch is not None else d
         d = self._shared() - self.snap
         if part is not None:
             d = np.ascontiguousarray(d[self._piece(part)])
@@ -88,6 +103,18 @@ class OracleShard:
     def delta_set(self, d, part=None):
         d = d.numpy() if hasattr(d, "numpy") else d
         cur = self._shared()
+        if self.minibatch:
+            if part is not None:
+                new = cur
+                pos = self._piece(part)
+                new[pos] = cur[pos] + d
+            else:
+                new = cur + d
+            off = 0
+            for name, v in self._views():
+                self.t.set_view(name, new[off:off + v.size])
+                off += v.size
+            return
         if part is not None:
             pos = self._piece(part)
             new = cur
@@ -101,11 +128,11 @@ class OracleShard:
             off += v.size
 
 
-def simulate_parts(conf, u, i, r, world, windows, passes, parts, num_item, seed=10):
+def simulate_parts(conf, u, i, r, world, windows, passes, parts, num_item, seed=10, minibatch=False):
     """The piece-wise exchange (ShardedTrainer(parts=p)) run synchronously in one process: per window every rank trains
     piece 0 then exchanges it, trains piece 1 then exchanges it, ...  The overlapped schedule computes the same values."""
     from svdfeature_amd.multi_gpu import shard_windows_parts
-    ranks = [OracleShard(make_oracle(conf, seed), parts=parts) for _ in range(world)]
+    ranks = [OracleShard(make_oracle(conf, seed), parts=parts, minibatch=minibatch) for _ in range(world)]
     wins = [a.make_windows(shard_windows_parts(u, i, r, rk, world, windows, num_item, parts)) for rk, a in enumerate(ranks)]
     for _ in range(passes):
         for w in range(windows):
@@ -124,11 +151,11 @@ def simulate_parts(conf, u, i, r, world, windows, passes, parts, num_item, seed=
     return ranks
 
 
-def simulate(conf, u, i, r, world, windows, passes, seed=10, defer=0.0, fmt=0, active=0):
+def simulate(conf, u, i, r, world, windows, passes, seed=10, defer=0.0, fmt=0, active=0, minibatch=False):
     """All ranks in one process, all-reduce replaced by an explicit sum in rank order.  defer > 0: the window
     lists go through multi_gpu.defer_tails like bench.py's (needs num_user / num_item in conf).
     u: user column of triples (u, i, r), of rank pairs (u = Pairs) or a BlockArrays (user-group pass; fmt = 1)."""
-    ranks = [OracleShard(make_oracle(conf, seed, fmt, active)) for _ in range(world)]
+    ranks = [OracleShard(make_oracle(conf, seed, fmt, active), minibatch=minibatch) for _ in range(world)]
     if isinstance(u, BlockArrays):
         shards = [shard_block_windows(u, rk, world, windows) for rk in range(world)]
     elif isinstance(u, Pairs):
@@ -141,7 +168,7 @@ def simulate(conf, u, i, r, world, windows, passes, seed=10, defer=0.0, fmt=0, a
     wins = [a.make_windows(sh) for a, sh in zip(ranks, shards)]
     for _ in range(passes):
         for w in range(windows):
-            if world == 1:
+            if world == 1 and not minibatch:
                 ranks[0].train(wins[0][w])
                 continue
             for rk, a in enumerate(ranks):

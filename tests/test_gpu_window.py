@@ -1,0 +1,142 @@
+"""Window-minibatch step of the N-rank path on one MI355X (svdf_k_window.hip): N trainers play the N
+ranks (HipShard(minibatch=True) windows, explicit sum in rank order instead of the collective) and must equal the
+oracle-backed simulation of tests/multi_rank_utils.py -- every instance the reference's update_inner on (current user side,
+window-start item side), item-side changes summed per item in file order -- bit for bit."""
+import numpy as np
+import pytest
+
+import cases
+import svdfeature_amd as sa
+from multi_rank_utils import simulate
+from svdfeature_amd.multi_gpu import HipShard, ShardedTrainer, shard_windows, shard_windows_parts
+
+pytestmark = pytest.mark.gpu
+NAMES = ("W_item", "i_bias", "W_user", "u_bias")
+
+
+def _trainer(conf, active=0, knobs=()):
+    t = sa.Trainer(0, active)
+    t.seed(10)
+    for k, v in conf:
+        t.set_param(k, v)
+    t.init_model()
+    t.init_trainer()
+    for k, v in knobs:
+        t.set_knob(k, v)
+    return t
+
+
+def _run_ranks(conf, u, i, r, world, windows, passes, active=0, knobs=(), half=False, parts=1, num_item=None):
+    import torch
+    dev = torch.device("cuda", 0)
+    ranks = []
+    for rk in range(world):
+        ad = HipShard(_trainer(conf, active, knobs), torch, dev, parts=parts, minibatch=True)
+        ad.set_wire_half(half)
+        sh = shard_windows(u, i, r, rk, world, windows) if parts == 1 else shard_windows_parts(u, i, r, rk, world, windows, num_item, parts)
+        ranks.append((ad, ad.make_windows(sh)))
+    for _ in range(passes):
+        for w in range(windows):
+            for part in range(parts):
+                ds_ = []
+                for ad, wins in ranks:
+                    ad.train(wins[w] if parts == 1 else wins[w][part])
+                    d = ad.delta_get() if parts == 1 else ad.delta_get(part)
+                    ad.stream.synchronize()
+                    ds_.append(d.clone())
+                total = ds_[0]
+                for d in ds_[1:]:
+                    total = total + d
+                torch.cuda.synchronize()
+                for ad, _ in ranks:
+                    if parts == 1:
+                        ad.delta_set(total)
+                    else:
+                        ad.delta_set(total, part)
+    for ad, _ in ranks:
+        ad.t.synchronize()
+    return [ad for ad, _ in ranks]
+
+
+def _check(ranks, sim):
+    for ad, s in zip(ranks, sim):
+        for name in NAMES:
+            a, b = ad.t.view(name), s.t.view(name)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+
+
+@pytest.mark.parametrize("k,world,knobs", [(16, 2, ()), (64, 3, ()), (64, 3, (("window_slots", 0),)), (64, 2, (("window_groups", 2),)),
+                                           (128, 2, ()), (128, 2, (("window_groups", 2),)), (100, 2, ()), (7, 4, ()), (256, 2, ())])
+def test_simulated_ranks_equal_the_oracle_simulation(k, world, knobs):
+    """fp32 wire: bit for bit, every kernel variant (lane-group kernel at any width, 8 / 16-lane slot kernels at k = 64 / 128 with
+    one or two user sets per wave), users with 1 ... ~40 instances per window, items without any."""
+    nu, ni, n = 1500, 700, 60000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=k + world)
+    u[:3000] = u[:3000] % 7          # a few heavy users: long sequential walks, ragged waves
+    i[i == 5] = 6                    # an item nobody rates
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k)
+    ranks = _run_ranks(conf, u, i, r, world, 4, 2, knobs=knobs)
+    _check(ranks, simulate(conf, u, i, r, world, 4, 2, minibatch=True))
+    assert ranks[0].make_windows([(u[:10], i[:10], r[:10])])[0].kind == 5
+
+
+@pytest.mark.parametrize("active,extra", [(2, (("base_score", "0.5"),)), (0, (("reg_method", "1"),)), (0, (("reg_method", "2"), ("wd_user", "0.5"), ("wd_item", "0.5"))),
+                                          (0, (("no_user_bias", "1"),)), (0, (("user_nonnegative", "1"),)), (0, (("up:bound", "100"), ("up:wd", "0.1"), ("up:bound", "100000"), ("up:wd", "0.002")))])
+def test_other_links_and_regularisers(active, extra):
+    nu, ni, n = 800, 300, 30000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=3)
+    if active == 2:
+        r = (r > 3).astype(np.float32)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=24) + list(extra)
+    ranks = _run_ranks(conf, u, i, r, 2, 3, 2, active=active)
+    _check(ranks, simulate(conf, u, i, r, 2, 3, 2, active=active, minibatch=True))
+
+
+def test_sharded_trainer_with_one_rank_and_empty_windows():
+    """multi_gpu.ShardedTrainer over HipShard(minibatch=True) with one rank (the exchange step runs without a collective), a
+    window without instances in the middle."""
+    import torch
+    nu, ni, n = 900, 250, 20000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=8)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
+    ad = HipShard(_trainer(conf), torch, torch.device("cuda", 0), minibatch=True)
+    ad.set_wire_half(False)
+    sh = shard_windows(u, i, r, 0, 1, 3)
+    sh.insert(1, (u[:0], i[:0], r[:0]))
+    st = ShardedTrainer(ad, ad.make_windows(sh), 1, None)
+    for _ in range(2):
+        st.train_pass()
+    ad.t.synchronize()
+    sim = simulate(conf, u, i, r, 1, 3, 2, minibatch=True)
+    _check([ad], sim)
+
+
+def test_fp16_wire_stays_close_and_item_range_pieces_are_exact():
+    """(i) fp16 wire format: the deltas are rounded once per window -- parameters within 1e-3 relative of the fp32-wire run;
+    (ii) item-range pieces (svdf_item_delta_select): piece by piece == the simulation of the piece-wise schedule."""
+    nu, ni, n = 1200, 400, 50000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=21)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
+    full = _run_ranks(conf, u, i, r, 2, 4, 2)
+    half = _run_ranks(conf, u, i, r, 2, 4, 2, half=True)
+    a, b = full[0].t.view("W_item"), half[0].t.view("W_item")
+    assert np.abs(a - b).max() <= 1e-3 * np.abs(a).max() and not np.array_equal(a, b)
+    from multi_rank_utils import simulate_parts
+    pieces = _run_ranks(conf, u, i, r, 2, 4, 2, parts=2, num_item=ni)
+    _check(pieces, simulate_parts(conf, u, i, r, 2, 4, 2, 2, ni, minibatch=True))
+
+
+def test_refused_configurations():
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=50, num_item=20, num_factor=8)
+    t = _trainer(conf + [("reg_method", "4")])
+    u, i, r = cases.planted_triples(100, 50, 20, seed=1)
+    with pytest.raises(sa.SvdfError, match="window data sets"):
+        t.dataset_window_from_triples(u, i, r)
+    t = _trainer(conf)
+    with pytest.raises(sa.SvdfError, match="item feature index exceed bound"):
+        t.dataset_window_from_triples(u[:3], np.array([20, 0, 1], np.uint32), r[:3])
+    ds = t.dataset_window_from_triples(u, i, r)
+    import torch
+    buf = torch.zeros(20 * 9, device="cuda")
+    with pytest.raises(sa.SvdfError, match="train this window data set first"):
+        t.window_delta_pack(ds, buf.data_ptr())
