@@ -167,10 +167,10 @@ def conf_for(a):
 
 WORKLOADS = {
     # name: (format_type, active_type, default factor, dominant kernel, unit name)
-    "basicmf": (0, 0, 64, "k_basicmf_i8<4> at k=64 (8 lanes per row, 32 instances per wave), k_basicmf<k/4,.> otherwise", "instances/s"),
+    "basicmf": (0, 0, 64, "k_basicmf_slots<8,2,4> at k=64 (8 lanes per row x 2 chunks, 4 row sets = 32 instances per wave), k_basicmf<k/4,G,...> at other widths", "instances/s"),
     "pairwise": (0, 3, 128, "k_fewrow_slots<16,2,1,2> (few-row kernel, 3 rows per pair, 16 lanes x 2 chunks per row)", "pairs/s"),
-    "svdpp": (1, 0, 128, "k_svdpp_wave<2> (one wave per user)", "instances/s"),
-    "neighbourhood": (0, 0, 128, "k_fused<32,1,1> (few-row fused kernel, inline global slots)", "instances/s"),
+    "svdpp": (1, 0, 128, "k_svdpp_wave<2,true,true,true,false,8> (one wave per user for the row recurrence + 7 helper waves for the feedback phases)", "instances/s"),
+    "neighbourhood": (0, 0, 128, "k_fused<32,1,1,1,true,false> (few-row fused kernel, inline global slots)", "instances/s"),
 }
 
 
@@ -353,15 +353,21 @@ def run_workload(name, a, env, steps, warmup, main_line):
     t0 = time.time()
     # N > 1, ratings: the exchange of a window is cut into item-range pieces so that every piece's all-reduce runs while the
     # next piece trains (svdf_item_delta_select; multi_gpu.ShardedTrainer(parts=p)); 1 = one synchronous all-reduce per window
-    auto_parts = 1 if world <= 2 else 2
-    parts = (a.exchange_parts or auto_parts) if (name == "basicmf" and (world > 1 or a.force_exchange)) else 1
-    adaptor = HipShard(tr, torch, torch.device("cuda", local_rank), parts=parts)
+    # how a window is trained when the exchange runs (N > 1 or --force-exchange): "minibatch" = the window-minibatch step
+    # (svdf_k_window.hip: user side exact, item side one minibatch step per window; three launches per window), "levels" = the
+    # round-2 scheme (exact conflict-free levels per rank, item side stale across ranks only)
+    exchanging = world > 1 or a.force_exchange
+    minibatch = exchanging and name == "basicmf" and a.exchange != "levels"
+    auto_parts = 1 if (world <= 2 or minibatch) else 2
+    parts = (a.exchange_parts or auto_parts) if (name == "basicmf" and exchanging) else 1
+    adaptor = HipShard(tr, torch, torch.device("cuda", local_rank), parts=parts, minibatch=minibatch)
     if a.windows > 0:
         nwin = a.windows
     else:
-        # updates per item per window that keep the accuracy contract (tools/rmse_contract_fullsize.py):
-        # 64 at 2 ranks, 42 at 3-4, 32 beyond for ratings; 50 for rank pairs (tests/test_multi_rank.py)
-        tgt = 50.0 if name == "pairwise" else (64.0 if world <= 2 else (42.0 if world <= 4 else 32.0))
+        # updates per item per window that keep the accuracy contract: window-minibatch step 32 at any number of ranks
+        # (tools/minibatch_calibration.py: the result does not depend on the rank count); level scheme 64 at 2 ranks, 42 at 3-4, 32
+        # beyond for ratings (tools/rmse_contract_fullsize.py); 50 for rank pairs (tests/test_multi_rank.py)
+        tgt = 50.0 if name == "pairwise" else (32.0 if minibatch else (64.0 if world <= 2 else (42.0 if world <= 4 else 32.0)))
         nwin = max(1, int(np.ceil(per_item / tgt)))
     if world == 1 and not a.force_exchange:
         nwin = 1
@@ -377,10 +383,10 @@ def run_workload(name, a, env, steps, warmup, main_line):
     if parts > 1:   # piece p of every window, as a window sequence of its own for the tail deferral
         pieces = [split_by_item_range(uu, ii, rr, a.items, parts) for (uu, ii, rr) in shards]
         per_part = [[pc[q] for pc in pieces] for q in range(parts)]
-        if nwin > 1 and a.defer_tails > 0:
+        if nwin > 1 and a.defer_tails > 0 and not minibatch:
             per_part = [defer_tails(seq, a.users, a.items, a.defer_tails) for seq in per_part]
         shards = [[per_part[q][w] for q in range(parts)] for w in range(nwin)]
-    elif nwin > 1 and a.defer_tails > 0 and name in ("basicmf", "pairwise"):
+    elif nwin > 1 and a.defer_tails > 0 and name in ("basicmf", "pairwise") and not minibatch:
         shards = defer_tails(shards, a.users, a.items, a.defer_tails)
     if name == "neighbourhood":
         wins = [tr.dataset_from_csr(d_all)]
@@ -421,6 +427,33 @@ def run_workload(name, a, env, steps, warmup, main_line):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    # ---- one more pass with a HIP event after every phase (outside the timed region): stream time per phase of the exchange
+    phase_ms = None
+    if exchanging and name == "basicmf":
+        marks = []
+
+        def mark(phase):
+            e = ev.new()
+            ev.record(e, tr.stream())
+            marks.append((phase, e))
+        sync_all()
+        first = ev.new()
+        ev.record(first, tr.stream())
+        st.train_pass(mark)
+        sync_all()
+        phase_ms = {"compute": 0.0, "pack": 0.0, "allreduce": 0.0, "unpack": 0.0}
+        prev = first
+        for phase, e in marks:
+            phase_ms[phase] += ev.elapsed_ms(prev, e)
+            prev = e
+        phase_ms["what"] = ("stream time of ONE extra pass (not in the timed region), HIP events on the trainer's stream after each phase was "
+                            "enqueued; compute = %s, pack = %s, allreduce = the collective (incl. waiting for the slowest rank), unpack = %s" % (
+                                ("k_window_users (user walks)", "k_window_items (per-item sums into the wire buffer)", "k_delta_addto") if minibatch else
+                                ("the conflict-free levels of the window", "k_delta_pack", "k_delta_unpack")))
+        steps_done = warmup + steps + 1
+    else:
+        steps_done = warmup + steps
+
     # ---- held-out quality after the run; with N ranks every rank scores the test rows of the users it owns
     def reduce_sum(vals):
         if dist is None:
@@ -433,7 +466,21 @@ def run_workload(name, a, env, steps, warmup, main_line):
         mine = (tu % world) == rank
         pred = tr.predict_batch(sa.CSRData.from_triples(tu[mine], ti[mine], tl[mine]))
         sse, cnt = reduce_sum([float(np.sum((pred.astype(np.float64) - tl[mine].astype(np.float64)) ** 2)), float(mine.sum())])
-        quality = {"rmse_test_after_run": float(np.sqrt(sse / max(cnt, 1.0)))}
+        quality = {"rmse_test_after_run": float(np.sqrt(sse / max(cnt, 1.0))), "passes_before_rmse": steps_done}
+        if exchanging and rank == 0 and not a.no_sequential_reference:
+            # the contract of the exchange (|dRMSE| <= 1e-4): the same passes as exact sequential SGD (the reference's result) on this GPU
+            t0 = time.time()
+            sq = make_trainer(sa, name, a, factor, local_rank)
+            dsq = sq.dataset_from_triples(u, i, r)
+            for _ in range(steps_done):
+                sq.train_dataset(dsq)
+            ps = sq.predict_batch(sa.CSRData.from_triples(tu, ti, tl))
+            quality["rmse_sequential_reference"] = rmse(ps, tl)
+            quality["rmse_minus_sequential"] = quality["rmse_test_after_run"] - quality["rmse_sequential_reference"]
+            dsq.close()
+            sq.close()
+            log("%s: sequential reference of the same %d passes on rank 0: rmse %.6f (this run %.6f) in %.1fs" % (
+                name, steps_done, quality["rmse_sequential_reference"], quality["rmse_test_after_run"], time.time() - t0))
     elif name == "pairwise":
         tu, tp, tq = test
         mine = (tu % world) == rank
@@ -501,14 +548,23 @@ def run_workload(name, a, env, steps, warmup, main_line):
                          "pairwise": "pairwiseRank synthetic %dx%d, %d (user, pos, neg) pairs, k=%d fp32, active_type=3, no user bias (BASELINE configs[4])" % (a.users, a.items, n, factor),
                          "svdpp": "implicitFeedback (SVD++) %d users x %d ratings, feedback set = own items, k=%d fp32 (BASELINE configs[3])" % (a.svdpp_users, a.svdpp_per_user, factor),
                          "neighbourhood": "neighborhoodModel shape: %d ratings + 4 of %d global ids each, k=%d fp32 (BASELINE configs[3])" % (n, a.globals, factor)}[name],
-            "order": "uniform random (file order preserved: result == sequential SGD)" if world == 1 else
-                     "user-sharded, item-delta all-reduce (%s on the wire) every 1/%d pass%s" % (
+            "order": "uniform random (file order preserved: result == sequential SGD)" if not exchanging else
+                     "user-sharded, %s, item-delta all-reduce (%s on the wire) every 1/%d pass%s" % (
+                         "window-minibatch step (user side exact, item side applied at the window's end)" if minibatch else "exact conflict-free levels per rank",
                          a.delta_dtype, nwin, (", in %d item-range pieces overlapped with training" % parts) if parts > 1 else ""),
+            "exchange": None if not exchanging else {
+                "path": ("torch.distributed %s all_reduce (RCCL over xGMI)" % dist.get_backend()) if (dist is not None and world > 1) else
+                        ("torch.distributed %s all_reduce with one rank (identity)" % dist.get_backend() if dist is not None else "none (one rank)"),
+                "step": "minibatch" if minibatch else "levels", "windows": nwin, "parts": parts,
+                "bytes_per_window": int(tr.item_delta_count() * (2 if a.delta_dtype == "fp16" else 4)),
+                "updates_per_item_per_window": per_item / nwin},
+            "phase_ms": phase_ms,
             "conflict_free_batches_per_pass": n_batches, "schedule_build_s": round(sched_s, 2),
             "parallelism": "1 GPU" if world == 1 else "dp%d user shards + RCCL all-reduce" % world,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": WORKLOADS[name][3], "launches": launches, "avg_launch_us": per_launch_us,
+                         "kernel": ("k_window_users_slots<8,2,G> + k_window_items<16,HALF> + k_delta_addto<HALF> (window-minibatch step, 3 launches per window)"
+                                    if minibatch else WORKLOADS[name][3]), "launches": launches, "avg_launch_us": per_launch_us,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "algorithmic_bytes_per_instance": alg_bytes / max(my_n, 1)},
             # what bounds one launch of this kernel: its measured HBM traffic at the achievable streaming rate + one dependent
@@ -658,6 +714,12 @@ def main():
                          "(1 = one synchronous all-reduce per window; 0 = auto: 1 at 2 ranks, 2 beyond -- a piece keeps the window's item-chain "
                          "depth, so pieces double a rank's launches: 12.9 -> 32.7 ms per pass at 2 ranks, 7.9 -> 10.6 at 4, 5.3 -> 7.7 at 8 "
                          "(tools/shard_parts_probe.sh), which only pays once the exchange it hides is the larger part)")
+    ap.add_argument("--exchange", choices=["auto", "minibatch", "levels"], default="auto",
+                    help="N>1 (or --force-exchange), ratings: how a window is trained.  minibatch (= auto): the window-minibatch step, user side "
+                         "exact, item side one minibatch step per window, three launches per window (svdf_k_window.hip); levels: the round-2 scheme, "
+                         "exact conflict-free levels per rank with the item side stale across ranks only")
+    ap.add_argument("--no-sequential-reference", action="store_true",
+                    help="N>1: skip the exact single-GPU run of the same passes on rank 0 that rmse_sequential_reference comes from")
     ap.add_argument("--delta-dtype", choices=["fp16", "fp32"], default="fp16",
                     help="wire format of the item-side window deltas when --gpus > 1 (parameters stay fp32)")
     ap.add_argument("--cpu-sample", type=int, default=20_000_000, help="basicMF ratings of the CPU baseline sample (other workloads scale it down)")
@@ -748,7 +810,8 @@ def main():
             "roofline": m["roofline"], "cpu_baseline": m["cpu_baseline"], "parity": m["parity"],
             "end_to_end": m["end_to_end"],
         }
-        for k in ("rmse_test_after_run", "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound", "launch_model"):
+        for k in ("rmse_test_after_run", "passes_before_rmse", "rmse_sequential_reference", "rmse_minus_sequential", "exchange", "phase_ms",
+                  "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound", "launch_model"):
             if m.get(k) is not None:
                 out[k] = m[k]
         if secondary:

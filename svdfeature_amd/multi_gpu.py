@@ -203,30 +203,36 @@ class ShardedTrainer:
         if self.world > 1 and hasattr(self.a, "gather_user_side"):
             self.a.gather_user_side(self.dist, rank, self.world)
 
-    def _train_pass_parts(self):
+    def _train_pass_parts(self, mark):
         a = self.a
-        keep_snapshot = getattr(a, "apply_refreshes_snapshot", False)
+        keep_snapshot = getattr(a, "apply_refreshes_snapshot", False) or self.minibatch
         pending = None   # (work handle or None, delta buffer, part): an exchange in flight
 
         def finish(p):
             work, d, part = p
             if work is not None:
                 work.wait()          # the adaptor's stream waits for the collective
+            mark("allreduce")
             a.delta_set(d, part)
+            mark("unpack")
 
         for wi, w in enumerate(self.windows):
             if self.world == 1 and not self.force_exchange and not self.minibatch:
                 for ds in w:
                     a.train(ds)
+                mark("compute")
                 continue
             if wi == 0 or not keep_snapshot:
                 if pending is not None:
                     finish(pending)
                     pending = None
                 a.delta_begin()
+                mark("pack")
             for part, ds in enumerate(w):
                 a.train(ds)
+                mark("compute")
                 d = a.delta_get(part)
+                mark("pack")
                 work = a.all_reduce_async(self.dist, d) if (hasattr(a, "all_reduce_async") and self.dist is not None) else self._reduce(d)
                 if pending is not None:
                     finish(pending)   # enqueued AFTER this piece's training: the previous collective had all of it to overlap with
@@ -234,20 +240,30 @@ class ShardedTrainer:
         if pending is not None:
             finish(pending)
 
-    def train_pass(self):
+    def train_pass(self, mark=None):
+        """mark(phase): optional callback invoked on the host right after the work of a phase ("compute", "pack", "allreduce",
+        "unpack") has been ENQUEUED -- bench.py records a HIP event on the adaptor's stream there, so that the stream time between
+        consecutive events can be charged to the phase that ends at the later one."""
+        mark = mark or (lambda phase: None)
         if self.parts > 1:
-            return self._train_pass_parts()
+            return self._train_pass_parts(mark)
         keep_snapshot = getattr(self.a, "apply_refreshes_snapshot", False)
         for wi, w in enumerate(self.windows):
             if self.world == 1 and not self.force_exchange and not self.minibatch:
                 self.a.train(w)
+                mark("compute")
                 continue
             if wi == 0 or not keep_snapshot:
                 self.a.delta_begin()
+                mark("pack")
             self.a.train(w)
+            mark("compute")
             d = self.a.delta_get()
+            mark("pack")
             self._reduce(d)   # SUM over ranks, in place
+            mark("allreduce")
             self.a.delta_set(d)
+            mark("unpack")
 
 
 class HipShard:
