@@ -358,7 +358,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
     # round-2 scheme (exact conflict-free levels per rank, item side stale across ranks only)
     exchanging = world > 1 or a.force_exchange
     minibatch = exchanging and name == "basicmf" and a.exchange != "levels"
-    auto_parts = 1 if (world <= 2 or minibatch) else 2
+    auto_parts = 1 if world <= 2 else 2
     parts = (a.exchange_parts or auto_parts) if (name == "basicmf" and exchanging) else 1
     adaptor = HipShard(tr, torch, torch.device("cuda", local_rank), parts=parts, minibatch=minibatch)
     if a.windows > 0:
@@ -534,7 +534,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
         achieved = per_launch_bytes / (per_launch_us * 1e-6) / 1e9
         traffic, traffic_src = None, None
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if world == 1 and os.path.exists(tfile):
+        if world == 1 and not exchanging and os.path.exists(tfile):
             try:
                 traffic = json.load(open(tfile)).get(name if name != "basicmf" else "hbm_bytes_per_launch")
                 if isinstance(traffic, dict):
@@ -816,6 +816,8 @@ def main():
                 out[k] = m[k]
         if secondary:
             out["secondary"] = secondary
+        sys.stdout.flush()
+        C.CDLL(None).fflush(None)   # RCCL prints its version banner through C stdio: push it out BEFORE the JSON line, which stays the last line
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

@@ -257,17 +257,19 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
         const int b = S.iptr[i], e = S.iptr[i + 1];
         float4 acc = f4zero();
         float accb = 0.0f;
-        int t = b;
-        for (; t + 4 <= e; t += 4) {
-            const float4 c0 = load_row<LPI>(S.contrib, (size_t)t, pitch, L, k), c1 = load_row<LPI>(S.contrib, (size_t)t + 1, pitch, L, k);
-            const float4 c2 = load_row<LPI>(S.contrib, (size_t)t + 2, pitch, L, k), c3 = load_row<LPI>(S.contrib, (size_t)t + 3, pitch, L, k);
-            const float b0 = S.cbias[t], b1 = S.cbias[t + 1], b2 = S.cbias[t + 2], b3 = S.cbias[t + 3];
-            add_rows(acc, c0); add_rows(acc, c1); add_rows(acc, c2); add_rows(acc, c3);
-            accb = accb + b0; accb = accb + b1; accb = accb + b2; accb = accb + b3;
-        }
-        for (; t < e; t++) {
-            add_rows(acc, load_row<LPI>(S.contrib, (size_t)t, pitch, L, k));
-            accb = accb + S.cbias[t];
+        // eight rows requested at a time; slots past the segment's end feed +0.0f, which leaves the running sum unchanged bit for bit
+        // (the sum starts at +0.0f and x + y is -0 only when both are, so acc is never -0)
+        for (int t = b; t < e; t += 8) {
+            float4 c[8];
+            float cb[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) {
+                const bool in = t + q < e;
+                c[q] = in ? load_row<LPI>(S.contrib, (size_t)(t + q), pitch, L, k) : f4zero();
+                cb[q] = in ? S.cbias[t + q] : 0.0f;
+            }
+#pragma unroll
+            for (int q = 0; q < 8; q++) { add_rows(acc, c[q]); accb = accb + cb[q]; }
         }
         if (!(LPI * 4 > k && L * 4 >= k)) {
             const size_t pos = (size_t)it * pitch + (size_t)L * 4;
@@ -311,10 +313,27 @@ __device__ __forceinline__ float *addto_slot(const DeltaRanges &R, long j) {
     for (int q = 1; q < SVDF_MAX_DELTA_RANGES; q++) r += (q < R.n && j >= R.off[q]) ? 1 : 0;
     return R.base[r] + (j - R.off[r]);
 }
+// The first range (item rows: a multiple of four floats, 16-byte aligned in the model and in the wire buffer) goes four floats per
+// lane; what follows (item biases, global biases) one float per lane.
 template <bool HALF>
-__global__ __launch_bounds__(256) void k_delta_addto(const DeltaRanges R, const void *src, long total) {
+__global__ __launch_bounds__(256) void k_delta_addto(const DeltaRanges R, const void *src, long total, long vec4) {
     const long stride = (long)gridDim.x * blockDim.x;
-    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    float4 *base4 = reinterpret_cast<float4 *>(R.base[0]);
+    for (long j = tid; j < vec4; j += stride) {
+        float4 d;
+        if (HALF) {
+            const uint2 raw = reinterpret_cast<const uint2 *>(src)[j];
+            const __half2 lo = *reinterpret_cast<const __half2 *>(&raw.x), hi = *reinterpret_cast<const __half2 *>(&raw.y);
+            d = make_float4(__low2float(lo), __high2float(lo), __low2float(hi), __high2float(hi));
+        } else {
+            d = reinterpret_cast<const float4 *>(src)[j];
+        }
+        float4 c = base4[j];
+        c.x = c.x + d.x; c.y = c.y + d.y; c.z = c.z + d.z; c.w = c.w + d.w;
+        base4[j] = c;
+    }
+    for (long j = 4 * vec4 + tid; j < total; j += stride) {
         const float d = HALF ? __half2float(reinterpret_cast<const __half *>(src)[j]) : reinterpret_cast<const float *>(src)[j];
         float *cur = addto_slot(R, j);
         *cur = *cur + d;
@@ -323,10 +342,16 @@ __global__ __launch_bounds__(256) void k_delta_addto(const DeltaRanges R, const 
 void launch_delta_addto(const DeltaRanges &R, const void *src, int half, hipStream_t st) {
     const long total = R.off[R.n];
     if (total <= 0) return;
-    long grid = (total + 255) / 256;
+    // vector path for range 0 when it is 16-byte aligned on both sides and a multiple of four floats
+    const long n0 = R.n > 1 ? R.off[1] : total;
+    const bool vec_ok = (n0 % 4 == 0) && ((reinterpret_cast<uintptr_t>(R.base[0]) & 15) == 0) && ((reinterpret_cast<uintptr_t>(src) & 15) == 0);
+    const long vec4 = vec_ok ? n0 / 4 : 0;
+    const long work = std::max(vec4, total - 4 * vec4);
+    long grid = (work + 255) / 256;
     if (grid > 8192) grid = 8192;
-    if (half) hipLaunchKernelGGL(k_delta_addto<true>, dim3((int)grid), dim3(256), 0, st, R, src, total);
-    else hipLaunchKernelGGL(k_delta_addto<false>, dim3((int)grid), dim3(256), 0, st, R, src, total);
+    if (grid < 1) grid = 1;
+    if (half) hipLaunchKernelGGL(k_delta_addto<true>, dim3((int)grid), dim3(256), 0, st, R, src, total, vec4);
+    else hipLaunchKernelGGL(k_delta_addto<false>, dim3((int)grid), dim3(256), 0, st, R, src, total, vec4);
 }
 
 }  // namespace svdf

@@ -81,7 +81,7 @@ def test_simulated_ranks_equal_the_oracle_simulation(k, world, knobs):
 
 
 @pytest.mark.parametrize("active,extra", [(2, (("base_score", "0.5"),)), (0, (("reg_method", "1"),)), (0, (("reg_method", "2"), ("wd_user", "0.5"), ("wd_item", "0.5"))),
-                                          (0, (("no_user_bias", "1"),)), (0, (("user_nonnegative", "1"),)), (0, (("up:bound", "100"), ("up:wd", "0.1"), ("up:bound", "100000"), ("up:wd", "0.002")))])
+                                          (0, (("no_user_bias", "1"),)), (0, (("user_nonnegative", "1"),)), (0, (("up:wd", "0.1"), ("up:bound", "100"), ("up:wd", "0.002"), ("up:bound", "100000")))])
 def test_other_links_and_regularisers(active, extra):
     nu, ni, n = 800, 300, 30000
     u, i, r = cases.planted_triples(n, nu, ni, seed=3)

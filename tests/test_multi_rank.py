@@ -322,7 +322,7 @@ def test_pairwise_accuracy_contract_of_the_exchange():
 
 
 # ---- piece-wise exchange: the all-reduce of one item range overlaps with training on another -------------------------------
-def _worker_parts(rank, world, port, windows, passes, parts, outdir):
+def _worker_parts(rank, world, port, windows, passes, parts, outdir, minibatch=False):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -331,7 +331,7 @@ def _worker_parts(rank, world, port, windows, passes, parts, outdir):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     u, i, r = cases.planted_triples(40000, NU, NI, seed=9)
-    a = OracleShard(make_oracle(CONF), torch, parts=parts)
+    a = OracleShard(make_oracle(CONF), torch, parts=parts, minibatch=minibatch)
 
     class AsyncShard(OracleShard):   # gloo: async collectives on CPU tensors
         pass
@@ -363,6 +363,22 @@ def test_two_gloo_ranks_piecewise_exchange_matches_the_synchronous_simulation(pa
             np.testing.assert_array_equal(z[name].view(np.uint32), sim[rk].t.view(name).view(np.uint32))
     z0, z1 = np.load(str(tmp_path / "rank0.npz")), np.load(str(tmp_path / "rank1.npz"))
     np.testing.assert_array_equal(z0["W_item"], z1["W_item"])
+
+
+def test_two_gloo_ranks_piecewise_window_minibatch_matches_the_synchronous_simulation(tmp_path):
+    """the same pipeline over the window-minibatch step (HipShard(minibatch=True, parts=2) on the GPU ranks): a piece's collective is
+    finished after the next piece's user walks were issued, and the next window's walks over a piece only start after that piece's sum
+    has been added -- values of the synchronous piece-by-piece schedule, bit for bit"""
+    import torch.multiprocessing as mp
+    from multi_rank_utils import simulate_parts
+    world, windows, passes, parts = 2, 4, 2, 2
+    mp.spawn(_worker_parts, args=(world, _free_port(), windows, passes, parts, str(tmp_path), True), nprocs=world, join=True)
+    u, i, r = cases.planted_triples(40000, NU, NI, seed=9)
+    sim = simulate_parts(CONF, u, i, r, world, windows, passes, parts, NI, minibatch=True)
+    for rk in range(world):
+        z = np.load(str(tmp_path / ("rank%d.npz" % rk)))
+        for name in ("W_item", "i_bias", "W_user", "u_bias"):
+            np.testing.assert_array_equal(z[name].view(np.uint32), sim[rk].t.view(name).view(np.uint32))
 
 
 def test_piecewise_exchange_keeps_the_rmse_contract():
