@@ -257,6 +257,16 @@ void Engine::set_param(const char *name, const char *val) {  // apex_svd_base.h:
     if (!strcmp(name, "amd:gpus")) { check(!multi_ && !space_allocated_, "amd:gpus must be set before the model is created"); gpus_ = std::max(1, atoi(val)); }
     else if (!is_peer_) param_log_.emplace_back(name, val);
     if (!strcmp(name, "amd:delta_half")) delta_half_ = atoi(val) != 0;
+    if (!strcmp(name, "amd:exchange")) {
+        check(!strcmp(val, "p2p") || !strcmp(val, "rccl"), "amd:exchange must be p2p or rccl");
+        check(!multi_, "amd:exchange must be set before the model is created");
+        multi_exchange_mode_ = !strcmp(val, "rccl") ? 1 : 0;
+    }
+    if (!strcmp(name, "amd:step")) {
+        check(!strcmp(val, "minibatch") || !strcmp(val, "levels"), "amd:step must be minibatch or levels");
+        check(!multi_, "amd:step must be set before the model is created");
+        multi_step_levels_ = !strcmp(val, "levels");
+    }
     if (!strcmp(name, "amd:window")) { stage_window_ = std::max<long>(1, atol(val)); window_set_ = true; }
     if (multi_) for (int d = 1; d < gpus_; d++) rank_engine(d)->set_param(name, val);
     if (!strcmp(name, "feature_user")) name_feat_user_ = val;
@@ -1383,6 +1393,10 @@ Dataset *Engine::dataset_from_blocks(long num_block, const int *extend_tag, cons
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
     check(user_group(), "svdfeature_amd: block datasets are for user-group (format_type 1) trainers");
+    if (multi_) {
+        check(mp_.common_feedback_space == 0, "svdfeature_amd: amd:gpus > 1 needs a feedback space of its own (common_feedback_space = 0)");
+        return multi_dataset_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
+    }
     flush();
     check(!unit_open_, "dataset_from_blocks: a START block is pending in the trainer");
     if (imfb()) {   // multi-level units: every span of the pass must be closed inside it
@@ -1619,7 +1633,7 @@ const int *Engine::host_order(Dataset *ds) {
 Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
-    check(!multi_, "svdfeature_amd: resident datasets belong to one GPU; with amd:gpus > 1 feed the instances through update() (one exchange window per staging window)");
+    if (multi_) return multi_dataset_from_triples(n, user, item, label);
     if (!basic_fast_path_allowed()) {
         // fall back to the general representation (side tables / shared latent space / user-group trainer)
         std::vector<int64_t> ptr((size_t)3 * n + 1);
@@ -1686,6 +1700,7 @@ Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsign
 Dataset *Engine::dataset_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
+    check(!multi_, "svdfeature_amd: rank pairs on an amd:gpus > 1 handle: hand them over as rows (svdf_dataset_from_csr) or shard them through svdfeature_amd.multi_gpu");
     if (device_sched_ && n > 0 && fused_allowed() && !user_group() && !relaxed()) {
         // everything on the device: the three columns go up as they are, the schedule columns (lower / higher item id, signs)
         // are formed there, ids are checked by the scheduling pass, pos == neg by the preparation kernel
@@ -1774,7 +1789,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
     check(!user_group() || rows_as_instances_, "svdfeature_amd: resident datasets are for random-order (format_type 0) trainers");
-    check(!multi_, "svdfeature_amd: resident datasets belong to one GPU; with amd:gpus > 1 feed the instances through update() (one exchange window per staging window)");
+    if (multi_) return multi_dataset_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);
     const long n = num_row;
     const int64_t p00 = row_ptr[0];
     check(row_ptr[3 * n] - p00 < (int64_t)2147483647, "dataset: more than 2^31-1 feature entries");
@@ -1870,6 +1885,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
 }
 
 Dataset::~Dataset() {
+    for (auto &per_rank : mchild) for (Dataset *c : per_rank) delete c;
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (owner) owner->disown(this);
 }
@@ -1905,12 +1921,20 @@ WindowSchedule Engine::window_view(const Dataset *ds) const {
 Dataset *Engine::dataset_window_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
+    check(!multi_, "window data sets are per rank; an amd:gpus handle builds them itself from svdf_dataset_from_triples");
+    std::unique_ptr<Dataset> ds(new Dataset());
+    adopt(ds.get());
+    window_build(ds.get(), n, user, item, label);
+    return ds.release();
+}
+// (re)fills ds in place: the staged path of an amd:gpus handle rebuilds one window data set per rank every window
+void Engine::window_build(Dataset *ds, long n, const unsigned *user, const unsigned *item, const float *label) {
     check(!user_group() && mtype_.extend_type == 0, "window data sets: random-order trainers only");
     check(basic_fast_path_allowed(), "window data sets: no side tables, relaxed ids, lazy decay or shared latent space; num_factor <= 256");
     check(n >= 0 && n < (1L << 31), "window data sets: at most 2^31-1 instances per window");
     const long NU = mp_.num_user, NI = mp_.num_item;
-    std::unique_ptr<Dataset> ds(new Dataset());
-    adopt(ds.get()); ds->num_row = n; ds->kind = 5;
+    if (window_trained_ == ds) window_trained_ = nullptr;
+    ds->num_row = n; ds->kind = 5;
     std::vector<int> ucnt((size_t)NU, 0), iptr((size_t)NI + 1, 0);
     for (long r = 0; r < n; r++) {
         if (user[r] >= (unsigned)NU) fail("user feature index exceed bound");
@@ -1948,14 +1972,13 @@ Dataset *Engine::dataset_window_from_triples(long n, const unsigned *user, const
     ds->label.upload(w_label.data(), (size_t)n, stream_);
     ds->win_slot.upload(w_slot.data(), (size_t)n, stream_);
     ds->win_iptr.upload(iptr.data(), (size_t)NI + 1, stream_);
-    HIPCHECK(hipStreamSynchronize(stream_));
+    HIPCHECK(hipStreamSynchronize(stream_));   // the host columns go out of scope
     ds->unit_values = true;
     ds->num_units = nact;
     ds->sched.level_ptr = {0, n};
     ds->sched.max_level_size = n;
     const long nb = mp_.no_user_bias ? 1 : 2;
     ds->algorithmic_bytes = n * (8L * mp_.num_factor * 2 + 8 * nb + 16 + 8 * 2);   // SURVEY 8(d4), what the reference's step moves per instance
-    return ds.release();
 }
 void Engine::window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t *count) {
     check(trainer_ready_, "window_delta: init_trainer has not been called");
@@ -1984,6 +2007,7 @@ void Engine::window_delta_apply(const void *device_src, int half) {
 
 void Engine::train_dataset(Dataset *ds) {
     check(ds && ds->owner == this, "train_dataset: dataset belongs to another trainer");
+    if (ds->kind == 6) { check(multi_ != nullptr, "train_dataset: the data set belongs to an amd:gpus handle"); multi_train_dataset(ds); return; }
     check(ds->sched_signature == schedule_signature(),
           "train_dataset: the dataset was scheduled under another configuration (relaxed-id keys, side tables, lazy decay or kernel-routing knobs changed since it was built); build it again");
     flush();
@@ -2052,6 +2076,7 @@ void Engine::train_dataset(Dataset *ds) {
 
 void Engine::predict_dataset(Dataset *ds, float *out) {
     check(ds && ds->owner == this, "predict_dataset: dataset belongs to another trainer");
+    check(ds->kind != 5 && ds->kind != 6, "predict_dataset: window / multi-GPU data sets are training sets; score rows with svdf_predict_csr_batch (routed to the owner of each user)");
     check(ds->sched_signature == schedule_signature(),
           "predict_dataset: the dataset was scheduled under another configuration; build it again");
     flush();
@@ -2099,6 +2124,7 @@ void Engine::predict_dataset(Dataset *ds, float *out) {
 // rounding only (relative 1e-13 at 1e8 instances), stated in the test.
 void Engine::eval_dataset(Dataset *ds, float scale, double *sum_sq, int64_t *count) {
     check(ds && ds->owner == this, "eval_dataset: dataset belongs to another trainer");
+    check(ds->kind != 5 && ds->kind != 6, "eval_dataset: window / multi-GPU data sets are training sets; score rows with svdf_predict_csr_batch (routed to the owner of each user)");
     check(ds->sched_signature == schedule_signature(), "eval_dataset: the dataset was scheduled under another configuration; build it again");
     flush();
     const DevParams &P = params();
@@ -2367,6 +2393,7 @@ int64_t Engine::set_view(int which, const float *in, int64_t count) {
 }
 void Engine::synchronize() {
     if (host_only_) return;
+    if (multi_) { multi_synchronize(); return; }
     HIPCHECK(hipStreamSynchronize(stream_));
 }
 int64_t Engine::counter(int what) const {
@@ -2382,6 +2409,8 @@ int64_t Engine::counter(int what) const {
     case 8: return multi_counter(0);    // item-delta exchanges of an amd:gpus > 1 handle
     case 9: return multi_counter(1);    // 1 when they run through RCCL
     case 10: return multi_counter(2);   // 1 when every rank has a device of its own
+    case 11: return multi_counter(3);   // exchange windows trained with the window-minibatch step
+    case 12: return multi_counter(4);   // exchange path: 0 p2p, 1 rccl
     default: return -1;
     }
 }

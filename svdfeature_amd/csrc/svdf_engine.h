@@ -19,6 +19,7 @@
 #include <thread>
 #include <string>
 #include <deque>
+#include <functional>
 #include <future>
 #include <vector>
 
@@ -191,6 +192,9 @@ struct Dataset {
     // kind 5: user records in launch order, user-grouped columns (item / label / uval / ival above), contribution slots, item segments
     DevBuf<WinUser> win_urec;
     DevBuf<int> win_slot, win_iptr;
+    // kind 6: a data set of an amd:gpus = N handle (svdf_multi.cpp): mchild[rank][window] lives in that rank's HBM
+    std::vector<std::vector<Dataset *>> mchild;
+    bool m_minibatch = false;     // the children are window-minibatch data sets (kind 5), else level-scheduled ones
     FusedDev fused;               // kind 2
     UnitDev unitdev;              // kind 3: user-group (SVD++) units
     Schedule sched;               // level_ptr always; order on the host only when built there or asked for (host_order)
@@ -458,7 +462,20 @@ class Engine {
     void multi_setup();
     void multi_copy_model_to_peers();
     void multi_flush(HostCSR &src);
-    void multi_exchange();
+    void multi_prepare();
+    void multi_window(const std::function<void(int, Engine *)> &train, bool minibatch, Dataset *const *mb);
+    bool multi_minibatch_allowed() const;
+    Dataset *multi_dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
+    Dataset *multi_dataset_from_csr(long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
+    Dataset *multi_dataset_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
+                                       const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
+                                       const float *feat_value);
+    void multi_train_dataset(Dataset *ds);
+    void multi_synchronize();
+    int multi_exchange_mode_ = 0;        // "amd:exchange": 0 p2p (peer loads / stores between the ranks of this process), 1 rccl
+    bool multi_step_levels_ = false;     // "amd:step = levels": exact conflict-free levels per rank instead of the window-minibatch step
+    std::unique_ptr<Dataset> w_window_;  // the staged path's window-minibatch data set of this rank, rebuilt in place every window
+    void window_build(Dataset *ds, long n, const unsigned *user, const unsigned *item, const float *label);
     void multi_predict(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value, float *out);
     void multi_gather_user_rows();
     int64_t multi_counter(int what) const;

@@ -110,6 +110,73 @@ void launch_delta_sum(const void *const *srcs, int n, void *dst, long total, int
     else hipLaunchKernelGGL(k_delta_sum<false>, dim3((int)grid), dim3(256), 0, st, S, dst, total);
 }
 
+// Direct exchange between the ranks of ONE process (svdf_multi.cpp, amd:exchange = p2p): rank d owns elements [begin, end) of the
+// packed delta; its kernel reads that slice from every rank's wire buffer through peer pointers (reduce-scatter over all xGMI
+// links at once), sums it in rank order in fp32 -- the order of k_delta_sum, so virtual ranks and real devices agree bit for bit --
+// and stores the sum back into the same slice of EVERY rank's buffer (all-gather), where the rank's own unpack / add kernel
+// picks it up.  16-byte accesses over the aligned body of the slice, scalar head / tail.
+struct PeerBufs { void *p[16]; int n; };
+template <bool HALF>
+__global__ __launch_bounds__(256) void k_delta_reduce_gather(const PeerBufs B, long begin, long end) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    constexpr int PER = HALF ? 8 : 4;                       // elements per 16-byte access
+    const long vb = (begin + PER - 1) / PER * PER, ve = end / PER * PER;
+    if (vb < ve) {
+        for (long j = vb / PER + tid; j < ve / PER; j += stride) {
+            float acc[PER];
+#pragma unroll
+            for (int q = 0; q < PER; q++) acc[q] = 0.0f;
+            for (int d = 0; d < B.n; d++) {
+                const uint4 raw = reinterpret_cast<const uint4 *>(B.p[d])[j];
+                if (HALF) {
+                    const __half2 *h = reinterpret_cast<const __half2 *>(&raw);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { acc[2 * q] += __low2float(h[q]); acc[2 * q + 1] += __high2float(h[q]); }
+                } else {
+                    const float *f = reinterpret_cast<const float *>(&raw);
+#pragma unroll
+                    for (int q = 0; q < 4; q++) acc[q] += f[q];
+                }
+            }
+            uint4 out;
+            if (HALF) {
+                __half2 *h = reinterpret_cast<__half2 *>(&out);
+#pragma unroll
+                for (int q = 0; q < 4; q++) h[q] = __halves2half2(__float2half_rn(acc[2 * q]), __float2half_rn(acc[2 * q + 1]));
+            } else {
+                float *f = reinterpret_cast<float *>(&out);
+#pragma unroll
+                for (int q = 0; q < 4; q++) f[q] = acc[q];
+            }
+            for (int d = 0; d < B.n; d++) reinterpret_cast<uint4 *>(B.p[d])[j] = out;
+        }
+    }
+    // head and tail of the slice, element by element
+    const long nhead = (vb < ve ? vb : end) - begin, ntail = vb < ve ? end - ve : 0;
+    for (long t = tid; t < nhead + ntail; t += stride) {
+        const long j = t < nhead ? begin + t : ve + (t - nhead);
+        float acc = 0.0f;
+        for (int d = 0; d < B.n; d++) acc += HALF ? __half2float(reinterpret_cast<const __half *>(B.p[d])[j]) : reinterpret_cast<const float *>(B.p[d])[j];
+        for (int d = 0; d < B.n; d++) {
+            if (HALF) reinterpret_cast<__half *>(B.p[d])[j] = __float2half_rn(acc);
+            else reinterpret_cast<float *>(B.p[d])[j] = acc;
+        }
+    }
+}
+void launch_delta_reduce_gather(void *const *bufs, int n, long begin, long end, int half, hipStream_t st) {
+    if (end <= begin || n <= 0) return;
+    PeerBufs B;
+    B.n = n > 16 ? 16 : n;
+    for (int d = 0; d < B.n; d++) B.p[d] = bufs[d];
+    const long per = half ? 8 : 4;
+    long grid = ((end - begin) / per + 255) / 256;
+    if (grid < 1) grid = 1;
+    if (grid > 4096) grid = 4096;
+    if (half) hipLaunchKernelGGL(k_delta_reduce_gather<true>, dim3((int)grid), dim3(256), 0, st, B, begin, end);
+    else hipLaunchKernelGGL(k_delta_reduce_gather<false>, dim3((int)grid), dim3(256), 0, st, B, begin, end);
+}
+
 // rank pairs (user, pos, neg) -> columns of the few-row schedule: lower / higher item id with the negative's sign flipped
 // (apex_svd_data.cpp:828-860), label and user value 1; *flag is raised when a pair has pos == neg
 __global__ __launch_bounds__(256) void k_pairs_prepare(long n, const unsigned *pos, const unsigned *neg, unsigned *lo, unsigned *hi, float *vlo,

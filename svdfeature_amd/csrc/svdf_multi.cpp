@@ -1,20 +1,33 @@
 // svdf_multi.cpp -- N GPUs behind ONE trainer handle, no Python: config key "amd:gpus = N" (ignored by the reference like any
 // unknown key).  SURVEY.md 8e, the C++ form of svdfeature_amd/multi_gpu.py:
-//   * rank d owns the users with id % N == d; instances follow their (first) user id, so user rows are touched by one rank;
-//   * item-side parameters (W_item, i_bias, g_bias [, W_ufeedback]) are replicated; a staging window is one exchange window:
-//     every rank runs its exact conflict-free SGD on its share of the window (one host thread per rank for scheduling and
-//     launching), then the item-side deltas are packed (svdf_item_delta_pack), summed over the ranks and unpacked;
-//   * the sum is an RCCL all-reduce over xGMI -- ncclCommInitAll in this process, ncclAllReduce per rank inside a group,
-//     librccl.so resolved at run time so that a single-GPU process never loads it -- when every rank sits on a device of its
-//     own; with fewer visible devices than ranks the ranks share devices ("virtual ranks": the same algorithm, deltas summed by
-//     a kernel), which is also how the path is tested on a one-GPU box;
+//   * rank d owns the users with id % N == d; a row follows its user ids (all of them must belong to one rank), so user rows are
+//     touched by one rank; user-group blocks follow the user of their START block;
+//   * item-side parameters (W_item, i_bias, g_bias [, W_ufeedback, ufeedback_bias]) are replicated; the data is cut into exchange
+//     windows at GLOBAL stream positions.  A window of plain (user, item, rating) rows is trained with the WINDOW-MINIBATCH step
+//     (svdf_k_window.hip: the users' exact walks with the item side read-only, per-item sums of the contributions straight into the
+//     wire buffer, sum over the ranks, add on every rank -- "amd:step = minibatch", the default); any other window (global features,
+//     several entries, user-group blocks, amd:step = levels) with exact conflict-free levels per rank and packed deltas
+//     (svdf_item_delta_pack / unpack).  Both exchange the same packed layout;
+//   * the sum over the ranks ("amd:exchange"):
+//       p2p   (default) the ranks live in ONE process, so every rank's wire buffer is addressable from every device
+//             (hipDeviceEnablePeerAccess): rank d reduces slice d of all buffers through peer loads and stores the sum back into
+//             slice d of all buffers (k_delta_reduce_gather): reduce-scatter + all-gather over all xGMI links at once, no ring;
+//       rccl  one ncclAllReduce per rank inside a group (librccl.so resolved at run time), every return code checked;
+//     there is no silent fallback: when the devices are distinct and the chosen path is not available the call fails;
+//   * one persistent host thread per rank enqueues that rank's work; ranks meet through HIP events (pack -> reduce -> apply), the
+//     host never waits for a stream inside a pass;
+//   * staged update() calls AND resident data sets (svdf_dataset_from_triples / _from_csr / _from_blocks / _from_buffer_file) work
+//     on such a handle: a resident data set is sharded and windowed once, every (rank, window) piece lives in that rank's HBM;
 //   * predictions go to the owner of the instance's user, model files and views gather the owners' user rows.
-// With N = 1 nothing here runs.  With N > 1 the result is window-synchronous SGD on the item side: the accuracy contract
-// (|dRMSE| <= 1e-4) instead of bit parity, exactly like the torch.distributed path of bench.py.
+// With fewer visible devices than ranks the ranks share devices ("virtual ranks": the same code, peer pointers are plain device
+// pointers) -- that is how the path is tested on a one-GPU box.  With N = 1 nothing here runs.  With N > 1 the result is
+// window-synchronous SGD on the item side: the accuracy contract (|dRMSE| <= 1e-4) instead of bit parity,
+// exactly like the torch.distributed path of bench.py.  Replaces the loop of /root/reference/svd_feature.cpp:220-248, :272-283.
 #include <dlfcn.h>
 
 #include <algorithm>
 #include <cstring>
+#include <functional>
 #include <thread>
 
 #include "svdf_engine.h"
@@ -30,7 +43,7 @@ namespace svdf {
 
 static inline void check(bool ok, const char *msg) { if (!ok) fail(msg); }
 
-// ---- RCCL, resolved at run time (rccl.h: ncclCommInitAll :236, ncclAllReduce :611; ncclHalf = 6, ncclFloat = 7, ncclSum = 0)
+// ---- RCCL, resolved at run time (rccl.h: ncclCommInitAll, ncclAllReduce; ncclHalf = 6, ncclFloat = 7, ncclSum = 0)
 struct Rccl {
     void *lib = nullptr;
     int (*CommInitAll)(void **, int, const int *) = nullptr;
@@ -38,6 +51,7 @@ struct Rccl {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
     std::vector<void *> comms;
     bool load() {
         if (lib) return true;
@@ -51,10 +65,64 @@ struct Rccl {
         GroupStart = (int (*)())dlsym(lib, "ncclGroupStart");
         GroupEnd = (int (*)())dlsym(lib, "ncclGroupEnd");
         CommDestroy = (int (*)(void *))dlsym(lib, "ncclCommDestroy");
+        GetErrorString = (const char *(*)(int))dlsym(lib, "ncclGetErrorString");
         return CommInitAll && AllReduce && GroupStart && GroupEnd && CommDestroy;
+    }
+    void ok(int rc, const char *what) const {
+        if (rc != 0) fail(std::string("svdfeature_amd: RCCL ") + what + " failed: " + (GetErrorString ? GetErrorString(rc) : "error") + " (amd:exchange = rccl)");
     }
     ~Rccl() {
         if (CommDestroy) for (void *c : comms) if (c) CommDestroy(c);
+    }
+};
+
+// ---- one persistent host thread per rank: run(job) executes job(d) on every rank's thread and returns when all are done
+struct RankPool {
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::vector<std::thread> th;
+    std::vector<int> device;
+    std::vector<std::string> err;
+    const std::function<void(int)> *job = nullptr;
+    uint64_t gen = 0;
+    int remaining = 0;
+    bool stop = false;
+    void start(const std::vector<int> &dev) {
+        device = dev;
+        err.assign(dev.size(), std::string());
+        for (size_t d = 0; d < dev.size(); d++) th.emplace_back([this, d]() { loop((int)d); });
+    }
+    void loop(int d) {
+        (void)hipSetDevice(device[(size_t)d]);
+        uint64_t seen = 0;
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            cv_job.wait(lk, [&] { return stop || gen != seen; });
+            if (stop) return;
+            seen = gen;
+            const std::function<void(int)> *f = job;
+            lk.unlock();
+            std::string m;
+            try { (*f)(d); } catch (const std::exception &ex) { m = ex.what(); if (m.empty()) m = "error"; }
+            lk.lock();
+            err[(size_t)d] = m;
+            if (--remaining == 0) cv_done.notify_all();
+        }
+    }
+    void run(const std::function<void(int)> &f) {
+        std::unique_lock<std::mutex> lk(mu);
+        job = &f;
+        remaining = (int)th.size();
+        gen++;
+        cv_job.notify_all();
+        cv_done.wait(lk, [&] { return remaining == 0; });
+        job = nullptr;
+        for (auto &m : err) if (!m.empty()) { std::string msg = m; for (auto &x : err) x.clear(); lk.unlock(); fail(msg); }
+    }
+    ~RankPool() {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        cv_job.notify_all();
+        for (auto &t : th) if (t.joinable()) t.join();
     }
 };
 
@@ -62,10 +130,21 @@ struct MultiState {
     std::vector<std::unique_ptr<Engine>> peers;   // ranks 1 .. N-1 (rank 0 is the handle itself)
     std::vector<int> device;                       // device of every rank
     std::vector<std::unique_ptr<DevBuf<char>>> wire;   // per rank: packed deltas in the wire format
-    bool distinct_devices = false, snapshot_taken = false;
+    std::vector<hipEvent_t> packed, gathered;      // per rank, on its device
+    bool distinct_devices = false, snapshot_taken = false, peer_ready = false;
+    int exchange = 0;                              // 0 p2p, 1 rccl
     Rccl rccl;
     bool rccl_ready = false;
-    int64_t exchanges = 0;
+    int64_t exchanges = 0, minibatch_windows = 0;
+    std::unique_ptr<RankPool> pool;
+    ~MultiState() {
+        pool.reset();   // threads first: nothing enqueues any more
+        for (size_t d = 0; d < packed.size(); d++) {
+            (void)hipSetDevice(device[d]);
+            if (packed[d]) (void)hipEventDestroy(packed[d]);
+            if (gathered[d]) (void)hipEventDestroy(gathered[d]);
+        }
+    }
 };
 
 void MultiDeleter::operator()(MultiState *m) const { delete m; }
@@ -75,12 +154,14 @@ Engine *Engine::rank_engine(int d) { return d == 0 ? this : multi_->peers[(size_
 // creates ranks 1..N-1 (same type, same configuration), places them on devices
 void Engine::multi_setup() {
     if (gpus_ <= 1 || multi_ || is_peer_ || host_only_) return;
-    check(!user_group(), "svdfeature_amd: amd:gpus > 1 is implemented for the random-order format (format_type = 0); user-group data shards through svdfeature_amd.multi_gpu");
+    check(gpus_ <= 16, "svdfeature_amd: amd:gpus supports at most 16 ranks behind one handle");
     check(mp_.common_latent_space == 0, "svdfeature_amd: amd:gpus > 1 needs separate user and item spaces");
+    check(!imfb(), "svdfeature_amd: amd:gpus > 1 is not implemented for extend_type 2 (nested implicit-feedback levels cross block boundaries)");
     int ndev = 0;
     MCHECK(hipGetDeviceCount(&ndev));
     multi_.reset(new MultiState());
     MultiState &M = *multi_;
+    M.exchange = multi_exchange_mode_;
     M.device.resize((size_t)gpus_);
     M.distinct_devices = ndev >= gpus_;
     for (int d = 0; d < gpus_; d++) M.device[(size_t)d] = M.distinct_devices ? (device_ + d) % ndev : device_;   // virtual ranks share this handle's device
@@ -91,12 +172,22 @@ void Engine::multi_setup() {
         M.peers.push_back(std::move(e));
     }
     for (int d = 0; d < gpus_; d++) M.wire.emplace_back(new DevBuf<char>());
-    // one exchange window = one staging window: about 64 / 42 / 32 updates per item (2 / 3-4 / more ranks), the calibration of
-    // DESIGN.md section 6; an explicit stage_window knob or amd:window key wins
-    if (!window_set_) {
-        const long per_item = gpus_ <= 2 ? 64 : (gpus_ <= 4 ? 42 : 32);
-        stage_window_ = std::max<long>(1024, per_item * (long)std::max(mp_.num_item, 1));
+    M.packed.assign((size_t)gpus_, nullptr);
+    M.gathered.assign((size_t)gpus_, nullptr);
+    for (int d = 0; d < gpus_; d++) {
+        MCHECK(hipSetDevice(M.device[(size_t)d]));
+        MCHECK(hipEventCreateWithFlags(&M.packed[(size_t)d], hipEventDisableTiming));
+        MCHECK(hipEventCreateWithFlags(&M.gathered[(size_t)d], hipEventDisableTiming));
     }
+    // one exchange window = `per_item` updates per item: 32 for the window-minibatch step at any number of
+    // ranks (tools/minibatch_calibration.py), 64 / 42 / 32 at 2 / 3-4 / more ranks for the level scheme; an explicit stage_window
+    // knob or amd:window key wins.  Capped so that a large catalogue does not stage tens of GB on the host per window.
+    if (!window_set_) {
+        const long per_item = multi_step_levels_ ? (gpus_ <= 2 ? 64 : (gpus_ <= 4 ? 42 : 32)) : 32;
+        stage_window_ = std::min<long>(1L << 24, std::max<long>(1024, per_item * (long)std::max(mp_.num_item, 1)));
+    }
+    M.pool.reset(new RankPool());
+    M.pool->start(M.device);
     MCHECK(hipSetDevice(device_));
 }
 
@@ -110,26 +201,150 @@ void Engine::multi_copy_model_to_peers() {
         p->hW_ = hW_; p->hbias_ = hbias_; p->hg_ = hg_;
         p->host_model_valid_ = true;
     }
+    multi_->snapshot_taken = false;   // a snapshot taken before this model arrived is not a snapshot of it
 }
 
+// the rank of a row: all of its user ids must belong to one rank (user rows are private to their owner and never exchanged)
+static inline int owner_of_entries(const unsigned *uidx, int nu, int n) {
+    if (nu <= 0) return 0;
+    const int d = (int)(uidx[0] % (unsigned)n);
+    for (int j = 1; j < nu; j++)
+        if ((int)(uidx[j] % (unsigned)n) != d)
+            fail("svdfeature_amd: amd:gpus > 1 shards by user id (rank = id % gpus): the user ids of one row belong to different ranks, "
+                 "so their rows would be updated on a rank that does not own them; train such data on one GPU");
+    return d;
+}
 static inline int owner_of_row(const HostCSR &src, long r, int n) {
     const int *p = &src.row_ptr[(size_t)3 * r];
-    return p[2] > p[1] ? (int)(src.feat_index[(size_t)p[1]] % (unsigned)n) : 0;
+    return owner_of_entries(&src.feat_index[(size_t)p[1]], p[2] - p[1], n);
+}
+
+void Engine::multi_prepare() {
+    MultiState &M = *multi_;
+    check(feat_user_.num_row() == 0, "svdfeature_amd: amd:gpus > 1 with a feature_user side table: a user's children may belong to other ranks; train on one GPU");
+    if (M.distinct_devices && M.exchange == 0 && !M.peer_ready) {
+        for (int a = 0; a < gpus_; a++) {
+            MCHECK(hipSetDevice(M.device[(size_t)a]));
+            for (int b = 0; b < gpus_; b++) {
+                if (a == b) continue;
+                int can = 0;
+                MCHECK(hipDeviceCanAccessPeer(&can, M.device[(size_t)a], M.device[(size_t)b]));
+                if (!can) fail("svdfeature_amd: amd:exchange = p2p needs peer access between the devices of all ranks (hipDeviceCanAccessPeer says no); use amd:exchange = rccl");
+                const hipError_t e = hipDeviceEnablePeerAccess(M.device[(size_t)b], 0);
+                if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) fail(std::string("svdfeature_amd: hipDeviceEnablePeerAccess failed: ") + hipGetErrorString(e));
+                (void)hipGetLastError();
+            }
+        }
+        M.peer_ready = true;
+        MCHECK(hipSetDevice(device_));
+    }
+    if (M.exchange == 1 && !M.rccl_ready) {
+        check(M.distinct_devices, "svdfeature_amd: amd:exchange = rccl needs one device per rank (ranks sharing a device exchange through p2p)");
+        if (!M.rccl.load()) fail("svdfeature_amd: amd:exchange = rccl: librccl.so could not be loaded");
+        M.rccl.comms.assign((size_t)gpus_, nullptr);
+        M.rccl.ok(M.rccl.CommInitAll(M.rccl.comms.data(), gpus_, M.device.data()), "ncclCommInitAll");
+        M.rccl_ready = true;
+        MCHECK(hipSetDevice(device_));
+    }
+}
+
+// One exchange window over all ranks.  train(d, e): enqueue rank d's share on e's stream (the caller made the device current);
+// minibatch: what train left behind is the contribution scratch of mb[d] (window_delta_pack / window_delta_apply), otherwise the
+// rank's parameters themselves (item_delta_pack / item_delta_unpack against the running snapshot).
+void Engine::multi_window(const std::function<void(int, Engine *)> &train, bool minibatch, Dataset *const *mb) {
+    MultiState &M = *multi_;
+    const int N = gpus_;
+    const int half = delta_half_ ? 1 : 0;
+    multi_prepare();
+    int64_t count = 0;
+    item_delta_pack(nullptr, half, &count);
+    const size_t bytes = (size_t)count * (half ? 2 : 4);
+    if (!minibatch && !M.snapshot_taken) {
+        M.pool->run([&](int d) { rank_engine(d)->item_delta_begin_local(); });
+        M.snapshot_taken = true;
+    }
+    // ---- phase 1: every rank trains its share and writes its wire buffer
+    M.pool->run([&](int d) {
+        Engine *e = rank_engine(d);
+        train(d, e);
+        M.wire[(size_t)d]->reserve(bytes + 16);
+        if (minibatch) e->window_delta_pack(mb[d], M.wire[(size_t)d]->p, half, nullptr);
+        else e->item_delta_pack(M.wire[(size_t)d]->p, half, nullptr);
+        MCHECK(hipEventRecord(M.packed[(size_t)d], e->stream_));
+    });
+    // ---- phase 2: sum over the ranks
+    if (M.exchange == 1) {
+        M.rccl.ok(M.rccl.GroupStart(), "ncclGroupStart");
+        for (int d = 0; d < N; d++) {
+            Engine *e = rank_engine(d);
+            M.rccl.ok(M.rccl.AllReduce(M.wire[(size_t)d]->p, M.wire[(size_t)d]->p, (size_t)count, half ? 6 : 7, 0, M.rccl.comms[(size_t)d], e->stream_), "ncclAllReduce");
+        }
+        M.rccl.ok(M.rccl.GroupEnd(), "ncclGroupEnd");
+    } else {
+        std::vector<void *> bufs((size_t)N);
+        for (int d = 0; d < N; d++) bufs[(size_t)d] = M.wire[(size_t)d]->p;
+        M.pool->run([&](int d) {
+            Engine *e = rank_engine(d);
+            for (int r = 0; r < N; r++) if (r != d) MCHECK(hipStreamWaitEvent(e->stream_, M.packed[(size_t)r], 0));
+            launch_delta_reduce_gather(bufs.data(), N, count * d / N, count * (d + 1) / N, half, e->stream_);
+            MCHECK(hipGetLastError());
+            MCHECK(hipEventRecord(M.gathered[(size_t)d], e->stream_));
+        });
+    }
+    // ---- phase 3: every rank applies the sum
+    M.pool->run([&](int d) {
+        Engine *e = rank_engine(d);
+        if (M.exchange == 0) for (int r = 0; r < N; r++) if (r != d) MCHECK(hipStreamWaitEvent(e->stream_, M.gathered[(size_t)r], 0));
+        if (minibatch) e->window_delta_apply(M.wire[(size_t)d]->p, half);
+        else e->item_delta_unpack(M.wire[(size_t)d]->p, half, 1);
+    });
+    if (minibatch) { M.snapshot_taken = false; M.minibatch_windows++; }   // the level scheme's running snapshot no longer matches
+    M.exchanges++;
+}
+
+// plain (user, item, rating) rows with unit values -> the window-minibatch step applies
+static bool rows_are_triples(const HostCSR &src, long r0, long r1) {
+    for (long r = r0; r < r1; r++) {
+        const int *p = &src.row_ptr[(size_t)3 * r];
+        if (!(p[1] == p[0] && p[2] == p[1] + 1 && p[3] == p[2] + 1)) return false;
+        if (src.feat_value[(size_t)p[1]] != 1.0f || src.feat_value[(size_t)p[2]] != 1.0f) return false;
+    }
+    return true;
+}
+bool Engine::multi_minibatch_allowed() const {
+    return !multi_step_levels_ && !user_group() && mtype_.extend_type == 0 && basic_fast_path_allowed() && g_stride_ == 1;
 }
 
 // the staged rows as exchange windows over all ranks (called instead of flush_csr on the handle): at most stage_window_ rows
 // per window, so one large update_csr_batch call is cut the same way a stream of single instances would be
 void Engine::multi_flush(HostCSR &src) {
-    MultiState &M = *multi_;
     const long n = src.num_row();
     if (n == 0) return;
     const int N = gpus_;
-    if (!M.snapshot_taken) {
-        for (int d = 0; d < N; d++) { Engine *e = rank_engine(d); MCHECK(hipSetDevice(e->device_)); e->item_delta_begin_local(); }
-        M.snapshot_taken = true;
-    }
     for (long w0 = 0; w0 < n; w0 += stage_window_) {
         const long w1 = std::min(n, w0 + stage_window_);
+        if (multi_minibatch_allowed() && rows_are_triples(src, w0, w1)) {
+            std::vector<std::vector<unsigned>> cu((size_t)N), ci((size_t)N);
+            std::vector<std::vector<float>> cl((size_t)N);
+            for (long r = w0; r < w1; r++) {
+                const int *p = &src.row_ptr[(size_t)3 * r];
+                const unsigned u = src.feat_index[(size_t)p[1]];
+                const size_t d = (size_t)(u % (unsigned)N);
+                cu[d].push_back(u); ci[d].push_back(src.feat_index[(size_t)p[2]]); cl[d].push_back(src.row_label[(size_t)r]);
+            }
+            std::vector<Dataset *> mb((size_t)N);
+            for (int d = 0; d < N; d++) {
+                Engine *e = rank_engine(d);
+                if (!e->w_window_) { e->w_window_.reset(new Dataset()); e->adopt(e->w_window_.get()); }
+                mb[(size_t)d] = e->w_window_.get();
+            }
+            multi_window([&](int d, Engine *e) {
+                e->window_build(mb[(size_t)d], (long)cl[(size_t)d].size(), cu[(size_t)d].data(), ci[(size_t)d].data(), cl[(size_t)d].data());
+                e->train_dataset(mb[(size_t)d]);
+            }, true, mb.data());
+            continue;
+        }
+        check(!user_group(), "svdfeature_amd: amd:gpus > 1 trains user-group data from resident data sets (svdf_dataset_from_blocks / _from_buffer_file), not block by block");
         std::vector<HostCSR> part((size_t)N);
         for (long r = w0; r < w1; r++) {
             const int d = owner_of_row(src, r, N);
@@ -141,85 +356,196 @@ void Engine::multi_flush(HostCSR &src) {
             o.feat_index.insert(o.feat_index.end(), src.feat_index.begin() + p[0], src.feat_index.begin() + p[3]);
             o.feat_value.insert(o.feat_value.end(), src.feat_value.begin() + p[0], src.feat_value.begin() + p[3]);
         }
-        // every rank schedules and launches its share on a host thread of its own
-        std::vector<std::string> errors((size_t)N);
-        std::vector<std::thread> th;
-        for (int d = 0; d < N; d++) {
-            th.emplace_back([&, d]() {
-                try {
-                    Engine *e = rank_engine(d);
-                    (void)hipSetDevice(e->device_);
-                    e->flush_csr(part[(size_t)d]);
-                } catch (const std::exception &ex) { errors[(size_t)d] = ex.what(); }
-            });
-        }
-        for (auto &t : th) t.join();
-        for (auto &m : errors) if (!m.empty()) fail(m);
-        multi_exchange();
+        multi_window([&](int d, Engine *e) { e->flush_csr(part[(size_t)d]); }, false, nullptr);
     }
     MCHECK(hipSetDevice(device_));
-    n_instances_ += 0;   // every rank counts its own share; svdf_counter(0) on the handle reports rank 0's
     src.clear();
 }
 
-void Engine::multi_exchange() {
-    MultiState &M = *multi_;
+// ---- resident data sets on the handle: sharded by user, cut into windows at global positions, one child per (rank, window)
+static long multi_num_windows(long n, long window) { return std::max<long>(1, (n + window - 1) / window); }
+
+Dataset *Engine::multi_dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     const int N = gpus_;
-    const int half = delta_half_ ? 1 : 0;
-    int64_t count = 0;
-    item_delta_pack(nullptr, half, &count);
-    const size_t bytes = (size_t)count * (half ? 2 : 4);
-    for (int d = 0; d < N; d++) {
-        Engine *e = rank_engine(d);
-        MCHECK(hipSetDevice(e->device_));
-        M.wire[(size_t)d]->reserve(bytes);
-        e->item_delta_pack(M.wire[(size_t)d]->p, half, nullptr);
+    for (long r = 0; r < n; r++) {
+        if (user[r] >= (unsigned)mp_.num_user) fail("user feature index exceed bound");
+        if (item[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound");
     }
-    bool reduced = false;
-    if (M.distinct_devices) {
-        if (!M.rccl_ready && M.rccl.load()) {
-            M.rccl.comms.assign((size_t)N, nullptr);
-            if (M.rccl.CommInitAll(M.rccl.comms.data(), N, M.device.data()) == 0) M.rccl_ready = true;
+    std::unique_ptr<Dataset> ds(new Dataset());
+    adopt(ds.get()); ds->num_row = n; ds->kind = 6;
+    const bool mbatch = multi_minibatch_allowed();
+    ds->m_minibatch = mbatch;
+    const long W = multi_num_windows(n, stage_window_);
+    ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
+    for (long w = 0; w < W; w++) {
+        const long b0 = n * w / W, b1 = n * (w + 1) / W;
+        std::vector<std::vector<unsigned>> cu((size_t)N), ci((size_t)N);
+        std::vector<std::vector<float>> cl((size_t)N);
+        for (long r = b0; r < b1; r++) {
+            const size_t d = (size_t)(user[r] % (unsigned)N);
+            cu[d].push_back(user[r]); ci[d].push_back(item[r]); cl[d].push_back(label[r]);
         }
-        if (M.rccl_ready) {
-            M.rccl.GroupStart();
-            for (int d = 0; d < N; d++) {
-                Engine *e = rank_engine(d);
-                M.rccl.AllReduce(M.wire[(size_t)d]->p, M.wire[(size_t)d]->p, (size_t)count, half ? 6 : 7, 0, M.rccl.comms[(size_t)d], e->stream_);
-            }
-            if (M.rccl.GroupEnd() != 0) fail("svdfeature_amd: RCCL all-reduce of the item-side deltas failed");
-            reduced = true;
-        }
+        multi_->pool->run([&](int d) {
+            Engine *e = rank_engine(d);
+            const long m = (long)cl[(size_t)d].size();
+            ds->mchild[(size_t)d][(size_t)w] = mbatch ? e->dataset_window_from_triples(m, cu[(size_t)d].data(), ci[(size_t)d].data(), cl[(size_t)d].data())
+                                                      : e->dataset_from_triples(m, cu[(size_t)d].data(), ci[(size_t)d].data(), cl[(size_t)d].data());
+        });
     }
-    if (!reduced) {
-        // shared devices (virtual ranks) or no RCCL: bring the buffers to rank 0's device, sum them there, hand the sum back
-        for (int d = 0; d < N; d++) { Engine *e = rank_engine(d); MCHECK(hipSetDevice(e->device_)); MCHECK(hipStreamSynchronize(e->stream_)); }
-        MCHECK(hipSetDevice(device_));
-        std::vector<const void *> srcs;
-        std::vector<std::unique_ptr<DevBuf<char>>> staged;
-        for (int d = 0; d < N; d++) staged.emplace_back(new DevBuf<char>());
-        for (int d = 0; d < N; d++) {
-            if (M.device[(size_t)d] == device_) { srcs.push_back(M.wire[(size_t)d]->p); continue; }
-            staged[(size_t)d]->reserve(bytes);
-            MCHECK(hipMemcpyPeerAsync(staged[(size_t)d]->p, device_, M.wire[(size_t)d]->p, M.device[(size_t)d], bytes, stream_));
-            srcs.push_back(staged[(size_t)d]->p);
-        }
-        launch_delta_sum(srcs.data(), N, M.wire[0]->p, count, half, stream_);
-        MCHECK(hipStreamSynchronize(stream_));
-        for (int d = 1; d < N; d++) {
-            if (M.device[(size_t)d] == device_) MCHECK(hipMemcpyAsync(M.wire[(size_t)d]->p, M.wire[0]->p, bytes, hipMemcpyDeviceToDevice, stream_));
-            else MCHECK(hipMemcpyPeerAsync(M.wire[(size_t)d]->p, M.device[(size_t)d], M.wire[0]->p, device_, bytes, stream_));
-        }
-        MCHECK(hipStreamSynchronize(stream_));
-    }
-    for (int d = 0; d < N; d++) {
-        Engine *e = rank_engine(d);
-        MCHECK(hipSetDevice(e->device_));
-        e->item_delta_unpack(M.wire[(size_t)d]->p, half, 1);
-    }
-    for (int d = 0; d < N; d++) { Engine *e = rank_engine(d); MCHECK(hipSetDevice(e->device_)); MCHECK(hipStreamSynchronize(e->stream_)); }
     MCHECK(hipSetDevice(device_));
-    M.exchanges++;
+    ds->sched.level_ptr = {0, n};
+    ds->sched.max_level_size = n;
+    const long nb = mp_.no_user_bias ? 1 : 2;
+    ds->algorithmic_bytes = n * (8L * mp_.num_factor * 2 + 8 * nb + 16 + 8 * 2);
+    return ds.release();
+}
+
+Dataset *Engine::multi_dataset_from_csr(long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) {
+    const int N = gpus_;
+    // plain (user, item, rating) rows take the three-column path (and with it the window-minibatch step)
+    bool triples = multi_minibatch_allowed();
+    for (long r = 0; r < num_row && triples; r++) {
+        const int64_t *p = &row_ptr[(size_t)3 * r];
+        triples = p[1] == p[0] && p[2] == p[1] + 1 && p[3] == p[2] + 1 && feat_value[(size_t)p[1]] == 1.0f && feat_value[(size_t)p[2]] == 1.0f;
+    }
+    if (triples) {
+        std::vector<unsigned> u((size_t)num_row), it((size_t)num_row);
+        for (long r = 0; r < num_row; r++) { u[(size_t)r] = feat_index[(size_t)row_ptr[(size_t)3 * r + 1]]; it[(size_t)r] = feat_index[(size_t)row_ptr[(size_t)3 * r + 2]]; }
+        return multi_dataset_from_triples(num_row, u.data(), it.data(), row_label);
+    }
+    std::unique_ptr<Dataset> ds(new Dataset());
+    adopt(ds.get()); ds->num_row = num_row; ds->kind = 6;
+    ds->m_minibatch = false;
+    const long W = multi_num_windows(num_row, stage_window_);
+    ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
+    struct Part { std::vector<float> label, value; std::vector<int64_t> ptr{0}; std::vector<unsigned> index; };
+    long alg = 0;
+    for (long w = 0; w < W; w++) {
+        const long b0 = num_row * w / W, b1 = num_row * (w + 1) / W;
+        std::vector<Part> part((size_t)N);
+        for (long r = b0; r < b1; r++) {
+            const int64_t *p = &row_ptr[(size_t)3 * r];
+            Part &o = part[(size_t)owner_of_entries(feat_index + p[1], (int)(p[2] - p[1]), N)];
+            const int64_t base = o.ptr.back() - p[0];
+            o.label.push_back(row_label[(size_t)r]);
+            o.ptr.push_back(p[1] + base); o.ptr.push_back(p[2] + base); o.ptr.push_back(p[3] + base);
+            o.index.insert(o.index.end(), feat_index + p[0], feat_index + p[3]);
+            o.value.insert(o.value.end(), feat_value + p[0], feat_value + p[3]);
+        }
+        multi_->pool->run([&](int d) {
+            Part &o = part[(size_t)d];
+            if (o.index.empty()) { o.index.push_back(0); o.value.push_back(0.0f); }
+            ds->mchild[(size_t)d][(size_t)w] = rank_engine(d)->dataset_from_csr((long)o.label.size(), o.label.data(), o.ptr.data(), o.index.data(), o.value.data());
+        });
+        for (int d = 0; d < N; d++) alg += ds->mchild[(size_t)d][(size_t)w]->algorithmic_bytes;
+    }
+    MCHECK(hipSetDevice(device_));
+    ds->sched.level_ptr = {0, num_row};
+    ds->sched.max_level_size = num_row;
+    ds->algorithmic_bytes = alg;
+    return ds.release();
+}
+
+// user-group data (SVDPlusBlock streams, apex_svd_data.h:376-466; update(block) = apex_svd_base.h:568-582): a block belongs to the
+// rank of its user (the first user entry of its first row; MIDDLE / END blocks and blocks without one inherit from the block
+// before them, so a START..END span stays together), windows are cut at block positions where no span is open -- the rule of
+// multi_gpu.shard_block_windows.  Exact conflict-free units per rank, W_ufeedback and its bias travel with the item side.
+Dataset *Engine::multi_dataset_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
+                                           const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
+                                           const float *feat_value) {
+    const int N = gpus_;
+    const long num_row = block_row_ptr[num_block] - block_row_ptr[0];
+    std::vector<int> owner((size_t)num_block, 0);
+    int cur = 0;
+    for (long b = 0; b < num_block; b++) {
+        const bool opens = extend_tag[b] == TAG_DEFAULT || extend_tag[b] == TAG_START;
+        if (opens && block_row_ptr[b + 1] > block_row_ptr[b]) {
+            const int64_t *p = &row_ptr[(size_t)3 * block_row_ptr[b]];
+            if (p[2] > p[1]) cur = (int)(feat_index[(size_t)p[1]] % (unsigned)N);
+        }
+        owner[(size_t)b] = cur;
+    }
+    // rows of a block must stay with the block's user
+    for (long b = 0; b < num_block; b++)
+        for (int64_t r = block_row_ptr[b]; r < block_row_ptr[b + 1]; r++) {
+            const int64_t *p = &row_ptr[(size_t)3 * r];
+            for (int64_t j = p[1]; j < p[2]; j++)
+                if ((int)(feat_index[(size_t)j] % (unsigned)N) != owner[(size_t)b])
+                    fail("svdfeature_amd: amd:gpus > 1 shards user-group data by the user of each block (rank = id % gpus): a block holds user ids of "
+                         "different ranks; train such data on one GPU");
+        }
+    // window cuts in blocks: stage_window_ counts rows; move a cut forward to the next position where no span is open
+    const long W0 = multi_num_windows(std::max<long>(num_row, 1), stage_window_);
+    std::vector<long> cut{0};
+    for (long w = 1; w < W0; w++) {
+        long pos = std::max<long>(num_block * w / W0, cut.back());
+        while (pos < num_block && pos > 0 && (extend_tag[pos - 1] == TAG_START || extend_tag[pos - 1] == TAG_MIDDLE)) pos++;
+        cut.push_back(pos);
+    }
+    cut.push_back(num_block);
+    const long W = (long)cut.size() - 1;
+    std::unique_ptr<Dataset> ds(new Dataset());
+    adopt(ds.get()); ds->num_row = num_row; ds->kind = 6;
+    ds->m_minibatch = false;
+    ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
+    struct Part {
+        std::vector<int> tag; std::vector<int64_t> fbp{0}, brp{0}, ptr{0};
+        std::vector<unsigned> fbi, index; std::vector<float> fbv, label, value;
+    };
+    long alg = 0, units = 0;
+    for (long w = 0; w < W; w++) {
+        std::vector<Part> part((size_t)N);
+        for (long b = cut[(size_t)w]; b < cut[(size_t)w + 1]; b++) {
+            Part &o = part[(size_t)owner[(size_t)b]];
+            o.tag.push_back(extend_tag[b]);
+            o.fbi.insert(o.fbi.end(), fb_index + fb_ptr[b], fb_index + fb_ptr[b + 1]);
+            o.fbv.insert(o.fbv.end(), fb_value + fb_ptr[b], fb_value + fb_ptr[b + 1]);
+            o.fbp.push_back((int64_t)o.fbi.size());
+            for (int64_t r = block_row_ptr[b]; r < block_row_ptr[b + 1]; r++) {
+                const int64_t *p = &row_ptr[(size_t)3 * r];
+                const int64_t base = o.ptr.back() - p[0];
+                o.label.push_back(row_label[(size_t)r]);
+                o.ptr.push_back(p[1] + base); o.ptr.push_back(p[2] + base); o.ptr.push_back(p[3] + base);
+                o.index.insert(o.index.end(), feat_index + p[0], feat_index + p[3]);
+                o.value.insert(o.value.end(), feat_value + p[0], feat_value + p[3]);
+            }
+            o.brp.push_back((int64_t)o.label.size());
+        }
+        multi_->pool->run([&](int d) {
+            Part &o = part[(size_t)d];
+            if (o.tag.empty()) o.tag.push_back(0);
+            if (o.fbi.empty()) { o.fbi.push_back(0); o.fbv.push_back(0.0f); }
+            if (o.index.empty()) { o.index.push_back(0); o.value.push_back(0.0f); }
+            if (o.label.empty()) o.label.push_back(0.0f);
+            ds->mchild[(size_t)d][(size_t)w] = rank_engine(d)->dataset_from_blocks((long)o.brp.size() - 1, o.tag.data(), o.fbp.data(), o.fbi.data(), o.fbv.data(),
+                                                                                     o.brp.data(), o.label.data(), o.ptr.data(), o.index.data(), o.value.data());
+        });
+        for (int d = 0; d < N; d++) { alg += ds->mchild[(size_t)d][(size_t)w]->algorithmic_bytes; units += ds->mchild[(size_t)d][(size_t)w]->num_units; }
+    }
+    MCHECK(hipSetDevice(device_));
+    ds->sched.level_ptr = {0, num_row};
+    ds->sched.max_level_size = num_row;
+    ds->algorithmic_bytes = alg;
+    ds->num_units = units;
+    return ds.release();
+}
+
+void Engine::multi_train_dataset(Dataset *ds) {
+    check(ds->kind == 6 && (int)ds->mchild.size() == gpus_, "train_dataset: not a data set of this amd:gpus handle");
+    flush();
+    const size_t W = ds->mchild.empty() ? 0 : ds->mchild[0].size();
+    std::vector<Dataset *> mb((size_t)gpus_);
+    for (size_t w = 0; w < W; w++) {
+        for (int d = 0; d < gpus_; d++) mb[(size_t)d] = ds->mchild[(size_t)d][w];
+        multi_window([&](int d, Engine *e) { e->train_dataset(mb[(size_t)d]); }, ds->m_minibatch, mb.data());
+    }
+    MCHECK(hipSetDevice(device_));
+    n_instances_ += ds->num_row;
+}
+
+void Engine::multi_synchronize() {
+    for (int d = 0; d < gpus_; d++) { Engine *e = rank_engine(d); MCHECK(hipSetDevice(e->device_)); MCHECK(hipStreamSynchronize(e->stream_)); }
+    MCHECK(hipSetDevice(device_));
 }
 
 // predictions: every row is scored by the owner of its user
@@ -270,6 +596,8 @@ int64_t Engine::multi_counter(int what) const {
     if (what == 0) return multi_->exchanges;
     if (what == 1) return multi_->rccl_ready ? 1 : 0;
     if (what == 2) return multi_->distinct_devices ? 1 : 0;
+    if (what == 3) return multi_->minibatch_windows;
+    if (what == 4) return multi_->exchange;
     return -1;
 }
 

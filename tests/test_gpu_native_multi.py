@@ -1,5 +1,5 @@
 """N GPUs behind ONE C-ABI handle, no Python in the exchange (svdf_multi.cpp; config key amd:gpus = N).  On the one-GPU test
-box the ranks share the device ("virtual ranks": same sharding, same windows, deltas summed by a kernel instead of RCCL):
+box the ranks share the device ("virtual ranks": same sharding, same windows, same peer-pointer exchange kernels and events as N devices):
   * bit for bit the oracle-backed simulation of the algorithm (tests/multi_rank_utils.py) with fp32 deltas,
   * predictions routed to the owner of the user, model files with the owners' user rows gathered,
   * the accuracy contract |dRMSE| <= 1e-4 with the default fp16 wire format,
@@ -28,19 +28,23 @@ def _ready(conf, extra=()):
     return t
 
 
-@pytest.mark.parametrize("world,windows,k", [(2, 4, 16), (3, 5, 10), (4, 2, 64)])
-def test_virtual_ranks_match_the_oracle_simulation(world, windows, k, tmp_path):
-    nu, ni, n = 3000, 400, 40000
+@pytest.mark.parametrize("world,windows,k,step", [(2, 4, 16, "levels"), (3, 5, 10, "levels"), (4, 2, 64, "levels"),
+                                                  (2, 4, 16, "minibatch"), (3, 5, 10, "minibatch"), (4, 2, 64, "minibatch"), (8, 3, 64, "minibatch")])
+def test_virtual_ranks_match_the_oracle_simulation(world, windows, k, step, tmp_path):
+    """staged update() calls on an amd:gpus handle, both window steps (amd:step): the window-minibatch step (default; user side
+    exact, item side applied at the window's end) and exact conflict-free levels per rank -- against the simulation of each"""
+    nu, ni, n = 3000, 400, 40000 if windows != 3 else 39000
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k)
     u, i, r = cases.planted_triples(n, nu, ni, seed=9)
     passes = 2
-    t = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows)])
+    t = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows), ("amd:step", step)])
     assert n % windows == 0
     for _ in range(passes):
         t.update_batch(sa.CSRData.from_triples(u, i, r))   # one call: cut into `windows` exchange windows by the engine
         t.finish_round()
     assert t.counter(8) == passes * windows and t.counter(10) == 0   # exchanges happened; ranks share the device here
-    sim = simulate(conf, u, i, r, world, windows, passes)
+    assert t.counter(11) == (passes * windows if step == "minibatch" else 0) and t.counter(12) == 0   # p2p exchange kernels
+    sim = simulate(conf, u, i, r, world, windows, passes, minibatch=(step == "minibatch"))
     # replicated side: identical on every rank, equal to the simulation's
     for name in ("W_item", "i_bias"):
         np.testing.assert_array_equal(t.view(name).view(np.uint32), sim[0].t.view(name).view(np.uint32))
@@ -62,16 +66,101 @@ def test_virtual_ranks_match_the_oracle_simulation(world, windows, k, tmp_path):
     s.init_trainer()
     np.testing.assert_array_equal(s.predict_batch(sa.CSRData.from_triples(tu, ti, tr)).view(np.uint32), got.view(np.uint32))
     # streaming single instances cuts the same windows as the one big call
-    t2 = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows)])
-    d = sa.CSRData.from_triples(u, i, r)
+    # the same data as ONE resident data set of the handle (sharded and windowed once, every piece in its rank's HBM): same result
+    t2 = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows), ("amd:step", step)])
+    ds = t2.dataset_from_triples(u, i, r)
+    assert ds.kind == 6 and ds.num_row == n
     for _ in range(passes):
-        for st in range(0, n, 777):
-            t2.update_batch(d.slice_rows(st, st + 777))
+        t2.train_dataset(ds)
         t2.finish_round()
-    if (n // windows) % 777 != 0:
-        pass   # chunked calls flush at the first chunk boundary past a window: other cuts, same contract (not compared bit for bit)
-    with pytest.raises(sa.SvdfError, match="resident datasets belong to one GPU"):
-        t.dataset_from_triples(u, i, r)
+    assert t2.counter(8) == passes * windows
+    for name in ("W_item", "i_bias", "W_user", "u_bias"):
+        np.testing.assert_array_equal(t2.view(name).view(np.uint32), t.view(name).view(np.uint32))
+    with pytest.raises(sa.SvdfError, match="training sets"):
+        t2.predict_dataset(ds)
+    ds.close()
+
+
+def test_resident_rows_with_globals_and_user_group_blocks_on_virtual_ranks(tmp_path):
+    """(i) rows with global features as a resident data set of the handle (level scheme, g_bias travels with the item side) == the
+    same rows staged through update(); (ii) a user-group (SVD++) pass as a resident data set on 2 / 4 virtual ranks == the
+    multi_gpu.py simulation (blocks follow their user, windows cut where no START..END span is open), bit for bit; the same pass
+    from a user-group buffer file."""
+    from multi_rank_utils import simulate as sim_blocks
+    nu, ni, ng, n, world, windows = 300, 120, 6, 6000, 3, 3
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=20, wd_global=0.002)
+    d = _rows_with_one_rank_per_row(n, nu, ni, ng, world, seed=4)
+    a = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows)])
+    b = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows)])
+    a.update_batch(d)
+    a.finish_round()
+    ds = b.dataset_from_csr(d)
+    assert ds.kind == 6
+    b.train_dataset(ds)
+    assert b.counter(8) == windows and b.counter(11) == 0
+    for name in ("W_item", "i_bias", "g_bias", "W_user", "u_bias"):
+        np.testing.assert_array_equal(a.view(name).view(np.uint32), b.view(name).view(np.uint32))
+    # (ii) SVD++ blocks
+    for world, windows in ((2, 3), (4, 2)):
+        nu, ni = 240, 90
+        blocks = cases.user_blocks(150, nu, ni, ni, seed=6 + world, max_rows=7, max_fb=5, split_every=4)
+        ba = sa.BlockArrays.from_blocks(blocks)
+        assert -(-ba.num_row // -(-ba.num_row // windows)) == windows
+        pconf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=16, num_ufeedback=ni, wd_ufeedback=0.004, ufeedback_init_sigma=0.01)
+        t = sa.Trainer(1, 0)
+        t.seed(10)
+        for k, v in pconf + [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", -(-ba.num_row // windows))]:
+            t.set_param(k, str(v))
+        t.init_model()
+        t.init_trainer()
+        ds = t.dataset_from_blocks(ba)
+        assert ds.kind == 6
+        for _ in range(2):
+            t.train_dataset(ds)
+        assert t.counter(8) == 2 * windows
+        sim = sim_blocks(pconf, ba, None, None, world, windows, 2, fmt=1)
+        for name in ("W_item", "i_bias", "W_ufeedback", "ufeedback_bias"):
+            np.testing.assert_array_equal(t.view(name).view(np.uint32), sim[0].t.view(name).view(np.uint32))
+        wu = t.view("W_user")
+        for rk in range(world):
+            own = (np.arange(nu) % world) == rk
+            np.testing.assert_array_equal(wu[own].view(np.uint32), sim[rk].t.view("W_user")[own].view(np.uint32))
+        path = str(tmp_path / ("ug%d.buffer" % world))
+        D.write_ugroup_buffer(path, blocks)
+        t3 = sa.Trainer(1, 0)
+        t3.seed(10)
+        for k, v in pconf + [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", -(-ba.num_row // windows))]:
+            t3.set_param(k, str(v))
+        t3.init_model()
+        t3.init_trainer()
+        ds3 = t3.dataset_from_buffer_file(path, user_group=True)
+        for _ in range(2):
+            t3.train_dataset(ds3)
+        np.testing.assert_array_equal(t3.view("W_ufeedback").view(np.uint32), t.view("W_ufeedback").view(np.uint32))
+        with pytest.raises(sa.SvdfError, match="resident data sets"):
+            t3.update_block(blocks[0])
+            t3.finish_round()
+
+
+def test_refusals_of_an_amd_gpus_handle():
+    """nothing is silently wrong: rows whose user ids belong to different ranks, a feature_user side table, RCCL with ranks that
+    share a device, more than 16 ranks"""
+    nu, ni = 60, 20
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=8)
+    t = _ready(conf, [("amd:gpus", 2)])
+    bad = sa.CSRData.from_rows([(3.0, [], [(2, 1.0), (5, 1.0)], [(1, 1.0)])])
+    with pytest.raises(sa.SvdfError, match="belong to different ranks"):
+        t.update_batch(bad)
+        t.finish_round()
+    t = _ready(conf, [("amd:gpus", 2), ("amd:exchange", "rccl")])
+    u, i, r = cases.planted_triples(200, nu, ni, seed=1)
+    with pytest.raises(sa.SvdfError, match="needs one device per rank"):
+        t.update_batch(sa.CSRData.from_triples(u, i, r))
+        t.finish_round()
+    with pytest.raises(sa.SvdfError, match="at most 16 ranks"):
+        _ready(conf, [("amd:gpus", 17)])
+    with pytest.raises(sa.SvdfError, match="amd:exchange must be p2p or rccl"):
+        _ready(conf, [("amd:exchange", "gloo")])
 
 
 def test_native_multi_gpu_rmse_contract_fp16_wire():
@@ -125,13 +214,28 @@ def test_reference_cli_trains_on_two_ranks_from_its_config_file(tmp_path):
     assert open(models["ref"], "rb").read() != open(models["amd2"], "rb").read()   # window-synchronous, not sequential
 
 
+def _rows_with_one_rank_per_row(n, nu, ni, ng, world, seed):
+    """ragged rows (0..2 global, 0..2 user, 1..2 item entries) whose user ids all belong to ONE rank (id % world), as the handle requires"""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(n):
+        rk = int(rng.integers(0, world))
+        nus = int(rng.integers(0, 3))
+        us = sorted(set(int(x) * world + rk for x in rng.integers(0, nu // world, nus)))
+        its = sorted(set(int(x) for x in rng.integers(0, ni, int(rng.integers(1, 3)))))
+        gs = sorted(set(int(x) for x in rng.integers(0, ng, int(rng.integers(0, 3)))))
+        rows.append((float(rng.integers(1, 6)), [(g, float(rng.uniform(0.2, 1))) for g in gs], [(x, float(rng.uniform(0.5, 1.5))) for x in us],
+                     [(x, float(rng.uniform(0.5, 1.5))) for x in its]))
+    return sa.CSRData.from_rows(rows)
+
+
 def test_virtual_ranks_with_global_features_and_ragged_rows():
-    """instances with global features and several user / item entries on an amd:gpus handle: a row follows its FIRST user id,
-    rows without a user entry go to rank 0, g_bias travels with the item side -- against the same algorithm run by hand with
+    """instances with global features and several user / item entries on an amd:gpus handle: a row follows its user ids (all of one
+    rank), rows without a user entry go to rank 0, g_bias travels with the item side -- against the same algorithm run by hand with
     one single-GPU trainer per rank (explicit sharding, explicit delta sum)."""
     nu, ni, ng, n, world, windows = 300, 120, 6, 6000, 3, 3
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=20, wd_global=0.002)
-    d = cases.sparse_feature_rows(n, nu, ni, ng, seed=4)
+    d = _rows_with_one_rank_per_row(n, nu, ni, ng, world, seed=4)
     t = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows)])
     t.update_batch(d)
     t.finish_round()
