@@ -733,6 +733,7 @@ void Engine::update_block(int nfb, int tag, const unsigned *ifb, const float *vf
     check(trainer_ready_, "update: init_trainer has not been called");
     if (host_only_) need_device("update");
     check(user_group(), "not implemented");   // SVDFeature has no update(SVDPlusBlock) (apex_svd.h:97)
+    check(!multi_ || in_multi_, "svdfeature_amd: amd:gpus > 1 trains user-group data from resident data sets (svdf_dataset_from_blocks / svdf_dataset_from_buffer_file), not block by block");
     for (int j = 0; j < nfb; j++) check(ifb[j] < (unsigned)mp_.num_ufeedback, "ufeedback id exceed bound");
     if (imfb()) { update_block_imfb(nfb, tag, ifb, vfb, num_row, row_label, row_ptr, feat_index, feat_value); return; }
     const int h = (int)staged_.num_row();
@@ -1393,7 +1394,7 @@ Dataset *Engine::dataset_from_blocks(long num_block, const int *extend_tag, cons
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
     check(user_group(), "svdfeature_amd: block datasets are for user-group (format_type 1) trainers");
-    if (multi_) {
+    if (multi_ && !in_multi_) {
         check(mp_.common_feedback_space == 0, "svdfeature_amd: amd:gpus > 1 needs a feedback space of its own (common_feedback_space = 0)");
         return multi_dataset_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
     }
@@ -1525,6 +1526,18 @@ void Engine::predict_block(int nfb, int tag, const unsigned *ifb, const float *v
     check(user_group(), "not implemented");
     for (int j = 0; j < nfb; j++) check(ifb[j] < (unsigned)mp_.num_ufeedback, "ufeedback id exceed bound");
     flush();
+    if (multi_ && !in_multi_) {
+        // the block is scored by the owner of its user (the first user entry of its first row; a block without one -- the MIDDLE / END
+        // pieces of a span carry their rows' user too -- goes where the previous block went)
+        if (num_row > 0 && row_ptr[2] > row_ptr[1]) multi_predict_rank_ = (int)(feat_index[row_ptr[1]] % (unsigned)gpus_);
+        Engine *e = rank_engine(multi_predict_rank_);
+        if (e != this) {
+            HIPCHECK(hipSetDevice(e->device_));
+            e->predict_block(nfb, tag, ifb, vfb, num_row, row_label, row_ptr, feat_index, feat_value, out);
+            HIPCHECK(hipSetDevice(device_));
+            return;
+        }
+    }
     const DevParams &P = params();
     if (imfb()) {   // SVDPPMultiIMFB::predict (apex_multi_imfb.h:193-207): push on DEFAULT / START, score, pop (no scatter) on DEFAULT / END
         const bool st = (tag == TAG_DEFAULT || tag == TAG_START), en = (tag == TAG_DEFAULT || tag == TAG_END);
@@ -1633,7 +1646,7 @@ const int *Engine::host_order(Dataset *ds) {
 Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
-    if (multi_) return multi_dataset_from_triples(n, user, item, label);
+    if (multi_ && !in_multi_) return multi_dataset_from_triples(n, user, item, label);
     if (!basic_fast_path_allowed()) {
         // fall back to the general representation (side tables / shared latent space / user-group trainer)
         std::vector<int64_t> ptr((size_t)3 * n + 1);
@@ -1789,7 +1802,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
     check(!user_group() || rows_as_instances_, "svdfeature_amd: resident datasets are for random-order (format_type 0) trainers");
-    if (multi_) return multi_dataset_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);
+    if (multi_ && !in_multi_) return multi_dataset_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);
     const long n = num_row;
     const int64_t p00 = row_ptr[0];
     check(row_ptr[3 * n] - p00 < (int64_t)2147483647, "dataset: more than 2^31-1 feature entries");
@@ -1921,7 +1934,7 @@ WindowSchedule Engine::window_view(const Dataset *ds) const {
 Dataset *Engine::dataset_window_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
-    check(!multi_, "window data sets are per rank; an amd:gpus handle builds them itself from svdf_dataset_from_triples");
+    check(!multi_ || in_multi_, "window data sets are per rank; an amd:gpus handle builds them itself from svdf_dataset_from_triples");
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get());
     window_build(ds.get(), n, user, item, label);
@@ -2007,7 +2020,7 @@ void Engine::window_delta_apply(const void *device_src, int half) {
 
 void Engine::train_dataset(Dataset *ds) {
     check(ds && ds->owner == this, "train_dataset: dataset belongs to another trainer");
-    if (ds->kind == 6) { check(multi_ != nullptr, "train_dataset: the data set belongs to an amd:gpus handle"); multi_train_dataset(ds); return; }
+    if (ds->kind == 6) { check(multi_ != nullptr && !in_multi_, "train_dataset: the data set belongs to an amd:gpus handle"); multi_train_dataset(ds); return; }
     check(ds->sched_signature == schedule_signature(),
           "train_dataset: the dataset was scheduled under another configuration (relaxed-id keys, side tables, lazy decay or kernel-routing knobs changed since it was built); build it again");
     flush();

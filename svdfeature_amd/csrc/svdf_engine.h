@@ -472,6 +472,7 @@ class Engine {
                                        const float *feat_value);
     void multi_train_dataset(Dataset *ds);
     void multi_synchronize();
+    int multi_predict_rank_ = 0;         // owner of the user-group block scored last (predict_block on an amd:gpus handle)
     int multi_exchange_mode_ = 0;        // "amd:exchange": 0 p2p (peer loads / stores between the ranks of this process), 1 rccl
     bool multi_step_levels_ = false;     // "amd:step = levels": exact conflict-free levels per rank instead of the window-minibatch step
     std::unique_ptr<Dataset> w_window_;  // the staged path's window-minibatch data set of this rank, rebuilt in place every window

@@ -26,6 +26,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <functional>
 #include <thread>
@@ -362,6 +363,14 @@ void Engine::multi_flush(HostCSR &src) {
     src.clear();
 }
 
+// while the handle builds or trains the ranks' pieces, rank 0 -- the handle itself -- must act as a plain single-GPU engine: its
+// dataset_from_* / flush() would otherwise route back into this file from inside a rank thread
+struct LocalMode {
+    bool &f, prev;
+    explicit LocalMode(bool &flag) : f(flag), prev(flag) { f = true; }
+    ~LocalMode() { f = prev; }
+};
+
 // ---- resident data sets on the handle: sharded by user, cut into windows at global positions, one child per (rank, window)
 static long multi_num_windows(long n, long window) { return std::max<long>(1, (n + window - 1) / window); }
 
@@ -371,11 +380,24 @@ Dataset *Engine::multi_dataset_from_triples(long n, const unsigned *user, const 
         if (user[r] >= (unsigned)mp_.num_user) fail("user feature index exceed bound");
         if (item[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound");
     }
+    flush();
+    LocalMode local(in_multi_);
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = n; ds->kind = 6;
     const bool mbatch = multi_minibatch_allowed();
     ds->m_minibatch = mbatch;
-    const long W = multi_num_windows(n, stage_window_);
+    long W = multi_num_windows(n, stage_window_);
+    if (!window_set_ && n > 0) {
+        // the automatic window assumes every item is rated equally often (per_item x num_item instances); a resident data set knows
+        // better: an instance meets  n * sum_i f_i^2  updates of its own item per pass (f_i = the item's share of the instances),
+        // which is n / num_item for uniform data and larger for skewed catalogues -- keep THAT at `per_item` per window
+        std::vector<long> cnt((size_t)mp_.num_item, 0);
+        for (long r = 0; r < n; r++) cnt[item[r]]++;
+        double s2 = 0.0;
+        for (long c : cnt) s2 += (double)c * (double)c;
+        const double per_item = multi_step_levels_ ? (gpus_ <= 2 ? 64.0 : (gpus_ <= 4 ? 42.0 : 32.0)) : 32.0;
+        W = std::max<long>(W, (long)std::ceil(s2 / (double)n / per_item));
+    }
     ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
     for (long w = 0; w < W; w++) {
         const long b0 = n * w / W, b1 = n * (w + 1) / W;
@@ -413,6 +435,8 @@ Dataset *Engine::multi_dataset_from_csr(long num_row, const float *row_label, co
         for (long r = 0; r < num_row; r++) { u[(size_t)r] = feat_index[(size_t)row_ptr[(size_t)3 * r + 1]]; it[(size_t)r] = feat_index[(size_t)row_ptr[(size_t)3 * r + 2]]; }
         return multi_dataset_from_triples(num_row, u.data(), it.data(), row_label);
     }
+    flush();
+    LocalMode local(in_multi_);
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = num_row; ds->kind = 6;
     ds->m_minibatch = false;
@@ -484,6 +508,8 @@ Dataset *Engine::multi_dataset_from_blocks(long num_block, const int *extend_tag
     }
     cut.push_back(num_block);
     const long W = (long)cut.size() - 1;
+    flush();
+    LocalMode local(in_multi_);
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = num_row; ds->kind = 6;
     ds->m_minibatch = false;
@@ -533,6 +559,7 @@ Dataset *Engine::multi_dataset_from_blocks(long num_block, const int *extend_tag
 void Engine::multi_train_dataset(Dataset *ds) {
     check(ds->kind == 6 && (int)ds->mchild.size() == gpus_, "train_dataset: not a data set of this amd:gpus handle");
     flush();
+    LocalMode local(in_multi_);
     const size_t W = ds->mchild.empty() ? 0 : ds->mchild[0].size();
     std::vector<Dataset *> mb((size_t)gpus_);
     for (size_t w = 0; w < W; w++) {
