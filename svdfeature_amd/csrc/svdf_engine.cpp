@@ -470,7 +470,7 @@ void Engine::load_model(FILE *fi) {  // apex_svd_base.h:138-140
 void Engine::save_model(FILE *fo) {  // apex_svd_base.h:142-144
     ScopedNs timer(ns_model_);
     check(space_allocated_, "save_model: model is not initialised");
-    if (device_model_) { flush(); download_model(); if (multi_) multi_gather_user_rows(); }
+    if (device_model_) { flush(); if (multi_) multi_gather_user_rows(); download_model(); }
     check(host_model_valid_, "save_model: no model");
     write_model(fo);
     if (bilinear()) {   // BModel::save_to_file (apex_svd_bilinear.h:60-63, :198-201).  W_bi is inert: SVDPPFeature::update binds its OWN
@@ -2348,8 +2348,8 @@ int64_t Engine::get_view(int which, float *out, int64_t capacity) {
     const unsigned off = (which <= 1) ? user_off_ : (which <= 3) ? item_off_ : fb_off_;
     if (device_model_ && multi_ && which <= 1) {   // user rows live on their owners
         flush();
-        download_model();
         multi_gather_user_rows();
+        download_model();
         if (!matrix) memcpy(out, hbias_.data() + off, (size_t)n * sizeof(float));
         else for (int y = 0; y < rows; y++) memcpy(out + (size_t)y * cols, hW_.data() + ((size_t)off + y) * pitch_, (size_t)cols * sizeof(float));
         hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hg_.clear(); host_model_valid_ = false;

@@ -177,6 +177,25 @@ void launch_delta_reduce_gather(void *const *bufs, int n, long begin, long end, 
     else hipLaunchKernelGGL(k_delta_reduce_gather<false>, dim3((int)grid), dim3(256), 0, st, B, begin, end);
 }
 
+// row r of dst (rows dst_first + r * dst_stride) <- row r of src (rows src_first + r * src_stride), `width` floats per row: packs the
+// user rows a rank owns (ids = rank mod N) for the hand-over to rank 0 and unpacks them there (svdf_multi.cpp, save_model / get_view)
+__global__ __launch_bounds__(256) void k_rows_strided_copy(float *dst, long dst_first, long dst_stride, const float *src, long src_first, long src_stride,
+                                                           long nrows, int width) {
+    const long total = nrows * width;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        const long r = j / width, c = j - r * width;
+        dst[(dst_first + r * dst_stride) * width + c] = src[(src_first + r * src_stride) * width + c];
+    }
+}
+void launch_rows_strided_copy(float *dst, long dst_first, long dst_stride, const float *src, long src_first, long src_stride, long nrows, int width,
+                              hipStream_t st) {
+    if (nrows <= 0 || width <= 0) return;
+    long grid = (nrows * width + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(k_rows_strided_copy, dim3((int)grid), dim3(256), 0, st, dst, dst_first, dst_stride, src, src_first, src_stride, nrows, width);
+}
+
 // rank pairs (user, pos, neg) -> columns of the few-row schedule: lower / higher item id with the negative's sign flipped
 // (apex_svd_data.cpp:828-860), label and user value 1; *flag is raised when a pair has pos == neg
 __global__ __launch_bounds__(256) void k_pairs_prepare(long n, const unsigned *pos, const unsigned *neg, unsigned *lo, unsigned *hi, float *vlo,

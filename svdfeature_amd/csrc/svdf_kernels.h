@@ -55,6 +55,8 @@ void launch_pairs_prepare(long n, const unsigned *pos, const unsigned *neg, unsi
 void launch_delta_sum(const void *const *srcs, int n, void *dst, long total, int half, hipStream_t st);   // up to 16 buffers
 // rank d's share of the direct exchange: elements [begin, end) of every buffer <- their sum over the n buffers (rank order, fp32)
 void launch_delta_reduce_gather(void *const *bufs, int n, long begin, long end, int half, hipStream_t st);
+void launch_rows_strided_copy(float *dst, long dst_first, long dst_stride, const float *src, long src_first, long src_stride, long nrows, int width,
+                              hipStream_t st);
 void launch_delta_sub(const float *cur, const float *snap, float *delta, long n, hipStream_t st);
 void launch_delta_add(float *cur, const float *snap, const float *delta, long n, hipStream_t st);
 // ---- ranker (svdf_k_rank.hip): SVDFeatureRanker's prepare_ifactor / proc_user / proc_spec / proc_rank, and the evaluator's sum

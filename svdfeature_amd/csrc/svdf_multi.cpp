@@ -602,18 +602,33 @@ void Engine::multi_predict(int num_row, const float *row_label, const int *row_p
     MCHECK(hipSetDevice(device_));
 }
 
-// the owners' user rows into rank 0's host model (after download_model on rank 0)
+// the owners' user rows into rank 0's DEVICE model (before download_model on rank 0): every rank packs the rows it owns (ids = rank mod
+// N: 1/N of W_user), the packed rows travel device to device, rank 0 puts them in place.  One model download per save, whatever N.
 void Engine::multi_gather_user_rows() {
     const int N = gpus_;
+    MultiState &M = *multi_;
     for (int d = 1; d < N; d++) {
         Engine *e = rank_engine(d);
+        const long m = (mp_.num_user - d + N - 1) / N;
+        if (m <= 0) continue;
         MCHECK(hipSetDevice(e->device_));
-        e->download_model();
-        for (long u = d; u < mp_.num_user; u += N) {
-            memcpy(&hW_[((size_t)user_off_ + (size_t)u) * pitch_], &e->hW_[((size_t)user_off_ + (size_t)u) * pitch_], (size_t)pitch_ * sizeof(float));
-            hbias_[(size_t)user_off_ + (size_t)u] = e->hbias_[(size_t)user_off_ + (size_t)u];
+        e->flush();
+        e->w_out_.reserve((size_t)m * (size_t)(pitch_ + 1));
+        launch_rows_strided_copy(e->w_out_.p, 0, 1, e->dW_.p + (size_t)user_off_ * pitch_, d, N, m, pitch_, e->stream_);
+        launch_rows_strided_copy(e->w_out_.p + (size_t)m * pitch_, 0, 1, e->dbias_.p + user_off_, d, N, m, 1, e->stream_);
+        MCHECK(hipGetLastError());
+        MCHECK(hipStreamSynchronize(e->stream_));
+        MCHECK(hipSetDevice(device_));
+        const float *src = e->w_out_.p;
+        if (M.device[(size_t)d] != device_) {
+            w_pred_.reserve((size_t)m * (size_t)(pitch_ + 1));
+            MCHECK(hipMemcpyPeerAsync(w_pred_.p, device_, e->w_out_.p, M.device[(size_t)d], (size_t)m * (size_t)(pitch_ + 1) * sizeof(float), stream_));
+            src = w_pred_.p;
         }
-        e->hW_.clear(); e->hW_.shrink_to_fit(); e->hbias_.clear(); e->hg_.clear(); e->host_model_valid_ = false;
+        launch_rows_strided_copy(dW_.p + (size_t)user_off_ * pitch_, d, N, src, 0, 1, m, pitch_, stream_);
+        launch_rows_strided_copy(dbias_.p + user_off_, d, N, src + (size_t)m * pitch_, 0, 1, m, 1, stream_);
+        MCHECK(hipGetLastError());
+        MCHECK(hipStreamSynchronize(stream_));
     }
     MCHECK(hipSetDevice(device_));
 }

@@ -38,12 +38,16 @@ subprocess.check_call(["gcc", "-O2", "-std=c99", "-D_POSIX_C_SOURCE=200809L", "-
                        os.path.join(ROOT, "integration", "svdf_train_bulk.c"), "-o", bulk, "-L", os.path.join(ROOT, "svdfeature_amd"),
                        "-lsvdfeature_amd", "-Wl,-rpath," + os.path.join(ROOT, "svdfeature_amd"), "-Wl,-rpath,/opt/rocm/lib"])
 res = {}
-for name in ("svdf_train_bulk", "svd_feature_amd", "svd_feature"):
+# "<binary> gpusN": the same binary with amd:gpus=N on its command line (ranks share the GPU when fewer devices are visible: the
+# same sharding, windows, exchange kernels and events as N devices -- what it measures on a one-GPU box is the handle's overhead)
+for name in ("svdf_train_bulk", "svdf_train_bulk gpus2", "svdf_train_bulk gpus8", "svd_feature_amd", "svd_feature_amd gpus2", "svd_feature"):
     times = {}
+    exe, _, gp = name.partition(" gpus")
+    extra = ["amd:gpus=%s" % gp] if gp else []
     for rounds in (0, 2):
-        d = os.path.join(tmp, "%s_%d" % (name, rounds)); os.makedirs(d)
+        d = os.path.join(tmp, "%s_%d" % (name.replace(" ", "_"), rounds)); os.makedirs(d)
         t0 = time.time()
-        p = subprocess.run([bulk if name == "svdf_train_bulk" else os.path.join(REFDIR, name), conf, "num_round=%d" % rounds, "silent=1"], cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+        p = subprocess.run([bulk if exe == "svdf_train_bulk" else os.path.join(REFDIR, exe), conf, "num_round=%d" % rounds, "silent=1"] + extra, cwd=d, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                            env=dict(os.environ, SVDF_PROFILE="1"))
         times[rounds] = time.time() - t0
         if rounds: print(p.stdout.decode()[-300:].strip(), flush=True)
@@ -56,4 +60,6 @@ b = open(os.path.join(tmp, "svd_feature_2", "0002.model"), "rb").read()
 c = open(os.path.join(tmp, "svdf_train_bulk_2", "0002.model"), "rb").read()
 print("bulk loop: models byte-identical to the reference CLI's:", c == b, " %.1fx the reference CLI end to end (model save every round included)"
       % (res["svdf_train_bulk"]["inst_per_s"] / res["svd_feature"]["inst_per_s"]))
+for nm in ("svdf_train_bulk gpus2", "svdf_train_bulk gpus8", "svd_feature_amd gpus2"):
+    print("%s: %.2fx its single-GPU form end to end" % (nm, res[nm]["inst_per_s"] / res[nm.split(" ")[0]]["inst_per_s"]))
 print("models after 2 rounds byte-identical:", a == b, " speedup end-to-end: %.1fx" % (res["svd_feature_amd"]["inst_per_s"] / res["svd_feature"]["inst_per_s"]))
