@@ -200,6 +200,11 @@ svdf_dataset *svdf_dataset_window_from_triples(svdf_trainer *t, long n, const un
 int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *device_dst, int half, int64_t *count);
 int svdf_window_delta_apply(svdf_trainer *t, const void *device_src, int half);
 
+/* test probe of the device rank sampler's sort (svdf_stdsort.h: libstdc++'s std::sort restated for host and device, because
+ * PairwiseRankGenerator::sample_cmp, apex_svd_data.cpp:920-944, picks rows by POSITION after an unstable std::sort): ids 0..n-1
+ * sorted by label with the restated code (restated[]) and with the C++ library's own std::sort (library[]). */
+int svdf_debug_sort_labels(long n, const float *label, int *restated, int *library);
+
 /* ---- introspection used by tests, bench.py and the harness ---- */
 /* raw copies of parameter views: 0 u_bias 1 W_user 2 i_bias 3 W_item 4 g_bias 5 ufeedback_bias
  * 6 W_ufeedback; rows are returned unpadded.  Returns number of floats or -1. */

@@ -138,6 +138,7 @@ def load_library():
     lib.svdf_rand_peek.argtypes = [C.c_long, _i32p]
     lib.svdf_rand_skip.argtypes = [C.c_long]
     lib.svdf_device_expf.argtypes = [C.c_void_p, C.c_uint, C.c_uint, _f32p, C.c_long]
+    lib.svdf_debug_sort_labels.argtypes = [C.c_long, _f32p, _i32p, _i32p]
     lib.svdf_set_error_mode(1)   # python callers get exceptions instead of exit(-1)
     _lib = lib
     return lib
@@ -159,6 +160,15 @@ def rand_skip(n):
     """advance libc rand() by n draws (svdf_rand_skip)"""
     if load_library().svdf_rand_skip(int(n)) != 0:
         raise SvdfError(load_library().svdf_last_error().decode())
+
+
+def debug_sort_labels(label):
+    """(ids sorted by label with the restated libstdc++ std::sort of svdf_stdsort.h, the same with the C++ library's std::sort)"""
+    label = np.ascontiguousarray(label, np.float32)
+    a, b = np.zeros(max(len(label), 1), np.int32), np.zeros(max(len(label), 1), np.int32)
+    if load_library().svdf_debug_sort_labels(len(label), _pad(label, np.float32), a, b) != 0:
+        raise SvdfError(load_library().svdf_last_error().decode())
+    return a[:len(label)], b[:len(label)]
 
 
 def device_expf(x=None, first=0, step=1, n=None):

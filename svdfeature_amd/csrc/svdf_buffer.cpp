@@ -280,7 +280,7 @@ Dataset *Engine::dataset_from_rank_buffer_file(const char *path) {
         if (ds) return ds;
     }
     UserGroupArrays g;
-    rank_pass(path, g);
+    if (!(device_rank_ && !rank_prefetch_ && !host_only_ && rank_pass_device_general(path, g))) rank_pass(path, g);
     return dataset_from_blocks((long)g.tag.size(), g.tag.data(), g.fb_ptr.data(), g.fb_index.data(), g.fb_value.data(),
                                g.block_row_ptr.data(), g.rows.label.data(), g.rows.row_ptr.data(), g.rows.index.data(),
                                g.rows.value.data());
@@ -293,47 +293,157 @@ Dataset *Engine::dataset_from_rank_buffer_file(const char *path) {
 // (apex_svd_base.h:512-527,539,557-561) -- every row has no global, one user entry that survives the |value| > 1e-6 filter
 // (apex_svd_data.cpp:897-903) and one item entry, and the sampler runs positives against negatives without pointwise
 // output.  Everything else goes through the host sampler above.  Returns nullptr to decline.
+// the candidate file of the device samplers, parsed and uploaded once per file: cached on path, size, inode and mtime (ns)
+bool Engine::rank_source_load(const char *path) {
+    struct stat sb;
+    if (stat(path, &sb) != 0) return false;   // the host path reports the error
+    const long mt = (long)sb.st_mtim.tv_sec * 1000000000L + (long)sb.st_mtim.tv_nsec;
+    if (rank_source_ && rank_source_->path == path && rank_source_->file_size == (long)sb.st_size && rank_source_->file_mtime == mt &&
+        rank_source_->file_ino == (long)sb.st_ino) return true;
+    std::unique_ptr<RankSource> src(new RankSource());
+    src->path = path; src->file_size = (long)sb.st_size; src->file_mtime = mt; src->file_ino = (long)sb.st_ino;
+    MappedFile file(path);
+    UserGroupArrays g;
+    read_user_group(file, nullptr, g);
+    const long nb = (long)g.tag.size(), nr = (long)g.rows.label.size();
+    const long nv = (long)g.rows.index.size();
+    // ---- plain rows without feedback (svdf_k_sample.hip): one user entry that survives the |value| > 1e-6 filter, one item entry
+    bool ok = g.fb_index.empty();
+    std::vector<unsigned> ui((size_t)nr), ii((size_t)nr);
+    std::vector<float> uv((size_t)nr), iv((size_t)nr);
+    for (long r = 0; r < nr && ok; r++) {
+        const int64_t *p = &g.rows.row_ptr[(size_t)3 * r];
+        ok = p[1] == p[0] && p[2] == p[1] + 1 && p[3] == p[2] + 1;
+        if (!ok) break;
+        ui[(size_t)r] = g.rows.index[(size_t)p[1]]; uv[(size_t)r] = g.rows.value[(size_t)p[1]];
+        ii[(size_t)r] = g.rows.index[(size_t)p[2]]; iv[(size_t)r] = g.rows.value[(size_t)p[2]];
+        ok = uv[(size_t)r] > 1e-6f || uv[(size_t)r] < -1e-6f;
+    }
+    src->eligible = ok && nr < 0x7FFFFFFFL;
+    src->general = nr < 0x7FFFFFFFL && nv < 0x7FFFFFFFL;
+    if (src->eligible || src->general) {
+        need_device("rank input");
+        src->num_block = nb; src->num_row = nr;
+        std::vector<long> brp((size_t)nb + 1);
+        for (long b = 0; b <= nb; b++) brp[(size_t)b] = (long)g.block_row_ptr[(size_t)b];
+        src->block_row_ptr.upload(brp.data(), brp.size(), stream_);
+        src->label.upload(g.rows.label.data(), (size_t)nr, stream_);
+        src->draws.reserve((size_t)nb + 1); src->pairs.reserve((size_t)nb + 1);
+        src->draw_off.reserve((size_t)nb + 2); src->pair_off.reserve((size_t)nb + 2);
+        src->pos_list.reserve((size_t)nr + 1); src->neg_list.reserve((size_t)nr + 1);
+    }
+    if (src->eligible) {
+        src->uidx.upload(ui.data(), (size_t)nr, stream_); src->uval.upload(uv.data(), (size_t)nr, stream_);
+        src->iidx.upload(ii.data(), (size_t)nr, stream_); src->ival.upload(iv.data(), (size_t)nr, stream_);
+    }
+    if (src->general) {
+        std::vector<int> rp((size_t)3 * nr + 1);
+        for (size_t j = 0; j < rp.size(); j++) rp[j] = (int)g.rows.row_ptr[j];
+        src->g_row_ptr.upload(rp.data(), rp.size(), stream_);
+        src->g_index.upload(g.rows.index.data(), (size_t)nv, stream_);
+        src->g_value.upload(g.rows.value.data(), (size_t)nv, stream_);
+        src->h_tag = g.tag; src->h_fb_ptr = g.fb_ptr; src->h_fb_index = g.fb_index; src->h_fb_value = g.fb_value;
+    }
+    if (src->eligible || src->general) HIPCHECK(hipStreamSynchronize(stream_));
+    rank_source_ = std::move(src);
+    return true;
+}
+
+// The pass drawn in HBM for ANY row shape and sampler setting (svdf_k_gsample.hip): counts -> scan -> rand() stream -> pairs -> sizes ->
+// scan -> merged rows, then the generated blocks come back to the host arrays the resident-dataset path takes (the feedback lists
+// and tags are the file's own).  Same draws as the host sampler, libc's generator left where it would have left it.
+bool Engine::rank_pass_device_general(const char *path, UserGroupArrays &g) {
+    if (!rank_source_load(path)) return false;
+    RankSource &S = *rank_source_;
+    if (!S.general) return false;
+    need_device("rank input");
+    LibcRand rs;
+    if (!libc_rand_capture(rs)) return false;   // a caller-installed generator of another size: the host path just calls rand()
+    pair_sampler_.init();
+    if (pair_sampler_.seed_bytime()) { if (!libc_rand_capture(rs)) return false; }
+    const int method = pair_sampler_.method();
+    check(method == 0 || method == 1, "unkown rank sample method\n");   // apex_svd_data.cpp:1010
+    const long nb = S.num_block;
+    RankRowsDev D{nb, S.num_row, S.block_row_ptr.p, S.label.p, S.g_row_ptr.p, S.g_index.p, S.g_value.p};
+    GSamplerParams sp{pair_sampler_.pos_lowerb(), pair_sampler_.neg_upperb(), pair_sampler_.gap(), pair_sampler_.sample_num(), pair_sampler_.sample_max(),
+                      method, method, pair_sampler_.pointwise() != 0 ? 1 : 0};
+    launch_gsample_counts(D, sp, S.pos_list.p, S.draws.p, S.pairs.p, stream_);
+    std::vector<long> hd((size_t)nb + 1), hp((size_t)nb + 1);
+    if (nb > 0) {
+        HIPCHECK(hipMemcpyAsync(hd.data(), S.draws.p, (size_t)nb * sizeof(long), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipMemcpyAsync(hp.data(), S.pairs.p, (size_t)nb * sizeof(long), hipMemcpyDeviceToHost, stream_));
+    }
+    HIPCHECK(hipStreamSynchronize(stream_));
+    long D_total = 0, P_total = 0;
+    for (long b = 0; b < nb; b++) { const long d = hd[(size_t)b], q = hp[(size_t)b]; hd[(size_t)b] = D_total; hp[(size_t)b] = P_total; D_total += d; P_total += q; }
+    hd[(size_t)nb] = D_total; hp[(size_t)nb] = P_total;
+    const long per_pair = sp.pointwise ? 2 : 1, R_total = P_total * per_pair;
+    check(R_total < 0x2AAAAAAAL, "rank input: too many generated rows in one pass");
+    S.draw_off.upload(hd.data(), hd.size(), stream_);
+    S.pair_off.upload(hp.data(), hp.size(), stream_);
+    const long C = 2048, nchunks = (D_total + C - 1) / C;
+    std::vector<uint32_t> tables;
+    libc_rand_chunk_states(rs, nchunks, C, tables);
+    S.tables.upload(tables.data(), tables.size(), stream_);
+    S.raw.reserve((size_t)std::max<long>(D_total, 1));
+    launch_rand_expand(S.tables.p, nchunks, C, D_total, S.raw.p, stream_);
+    const size_t np = (size_t)std::max<long>(P_total, 1);
+    S.pair_p.reserve(np); S.pair_n.reserve(np);
+    launch_gsample_pairs(D, sp, S.draw_off.p, S.pair_off.p, S.raw.p, S.pos_list.p, S.neg_list.p, S.pair_p.p, S.pair_n.p, stream_);
+    // libc's generator moves on by exactly the draws of this pass
+    if (D_total > 0) {
+        LibcRand after = rs;
+        if (D_total >= 31) {
+            HIPCHECK(hipMemcpyAsync(after.x, S.raw.p + (D_total - 31), 31 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+            HIPCHECK(hipStreamSynchronize(stream_));
+        } else {
+            std::vector<uint32_t> tail((size_t)D_total);
+            HIPCHECK(hipMemcpyAsync(tail.data(), S.raw.p, (size_t)D_total * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+            HIPCHECK(hipStreamSynchronize(stream_));
+            for (long j = 0; j < 31 - D_total; j++) after.x[j] = rs.x[j + D_total];
+            for (long j = 0; j < D_total; j++) after.x[31 - D_total + j] = tail[(size_t)j];
+        }
+        libc_rand_restore(after);
+    }
+    // section lengths -> row_ptr -> entries
+    const long nsec = 3 * R_total;
+    S.lens.reserve((size_t)nsec + 2); S.optr.reserve((size_t)nsec + 2);
+    HIPCHECK(hipMemsetAsync(S.lens.p, 0, ((size_t)nsec + 2) * sizeof(int), stream_));
+    launch_gpair_sizes(D, sp, P_total, S.pair_p.p, S.pair_n.p, S.lens.p, stream_);
+    try { device_exclusive_scan_i32(S.lens.p, S.optr.p, nsec, &S.scan_tmp, &S.scan_tmp_bytes, stream_); }
+    catch (const std::exception &e) { fail(std::string("rank input: ") + e.what()); }
+    int total_vals = 0;
+    HIPCHECK(hipMemcpyAsync(&total_vals, S.optr.p + nsec, sizeof(int), hipMemcpyDeviceToHost, stream_));
+    HIPCHECK(hipStreamSynchronize(stream_));
+    check(total_vals >= 0, "rank input: more than 2^31-1 feature entries in one pass");
+    const size_t nvout = (size_t)std::max(total_vals, 1);
+    S.out_label.reserve((size_t)std::max<long>(R_total, 1)); S.out_index.reserve(nvout); S.out_value.reserve(nvout);
+    launch_gpair_write(D, sp, P_total, S.pair_p.p, S.pair_n.p, S.optr.p, S.out_label.p, S.out_index.p, S.out_value.p, stream_);
+    HIPCHECK(hipGetLastError());
+    // back to the host form of a pass
+    g.tag = S.h_tag; g.fb_ptr = S.h_fb_ptr; g.fb_index = S.h_fb_index; g.fb_value = S.h_fb_value;
+    g.block_row_ptr.resize((size_t)nb + 1);
+    for (long b = 0; b <= nb; b++) g.block_row_ptr[(size_t)b] = (int64_t)hp[(size_t)b] * per_pair;
+    g.rows.label.resize((size_t)R_total); g.rows.index.resize((size_t)total_vals); g.rows.value.resize((size_t)total_vals);
+    std::vector<int> rp((size_t)nsec + 1, 0);
+    if (R_total > 0) {
+        HIPCHECK(hipMemcpyAsync(g.rows.label.data(), S.out_label.p, (size_t)R_total * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipMemcpyAsync(rp.data(), S.optr.p, ((size_t)nsec + 1) * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    }
+    if (total_vals > 0) {
+        HIPCHECK(hipMemcpyAsync(g.rows.index.data(), S.out_index.p, (size_t)total_vals * sizeof(unsigned), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipMemcpyAsync(g.rows.value.data(), S.out_value.p, (size_t)total_vals * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    }
+    HIPCHECK(hipStreamSynchronize(stream_));
+    g.rows.row_ptr.assign(rp.begin(), rp.end());
+    n_device_rank_passes_++;
+    return true;
+}
+
 Dataset *Engine::rank_pass_device(const char *path) {
     if (pair_sampler_.method() != 0 || pair_sampler_.pointwise() != 0) return nullptr;
     if (!rows_without_feedback_ || !fused_allowed_for_rows()) return nullptr;
-    struct stat sb;
-    if (stat(path, &sb) != 0) return nullptr;   // the host path reports the error
-    if (!rank_source_ || rank_source_->path != path || rank_source_->file_size != (long)sb.st_size || rank_source_->file_mtime != (long)sb.st_mtime) {
-        std::unique_ptr<RankSource> src(new RankSource());
-        src->path = path; src->file_size = (long)sb.st_size; src->file_mtime = (long)sb.st_mtime;
-        MappedFile file(path);
-        UserGroupArrays g;
-        read_user_group(file, nullptr, g);
-        const long nb = (long)g.tag.size(), nr = (long)g.rows.label.size();
-        bool ok = g.fb_index.empty();
-        for (long b = 0; b < nb && ok; b++) ok = g.tag[(size_t)b] == TAG_DEFAULT || g.tag[(size_t)b] == TAG_START || g.tag[(size_t)b] == TAG_MIDDLE || g.tag[(size_t)b] == TAG_END;
-        std::vector<unsigned> ui((size_t)nr), ii((size_t)nr);
-        std::vector<float> uv((size_t)nr), iv((size_t)nr);
-        for (long r = 0; r < nr && ok; r++) {
-            const int64_t *p = &g.rows.row_ptr[(size_t)3 * r];
-            ok = p[1] == p[0] && p[2] == p[1] + 1 && p[3] == p[2] + 1;
-            if (!ok) break;
-            ui[(size_t)r] = g.rows.index[(size_t)p[1]]; uv[(size_t)r] = g.rows.value[(size_t)p[1]];
-            ii[(size_t)r] = g.rows.index[(size_t)p[2]]; iv[(size_t)r] = g.rows.value[(size_t)p[2]];
-            ok = uv[(size_t)r] > 1e-6f || uv[(size_t)r] < -1e-6f;
-        }
-        src->eligible = ok && nr < 0x7FFFFFFFL;
-        if (src->eligible) {
-            need_device("rank input");
-            src->num_block = nb; src->num_row = nr;
-            std::vector<long> brp((size_t)nb + 1);
-            for (long b = 0; b <= nb; b++) brp[(size_t)b] = (long)g.block_row_ptr[(size_t)b];
-            src->block_row_ptr.upload(brp.data(), brp.size(), stream_);
-            src->label.upload(g.rows.label.data(), (size_t)nr, stream_);
-            src->uidx.upload(ui.data(), (size_t)nr, stream_); src->uval.upload(uv.data(), (size_t)nr, stream_);
-            src->iidx.upload(ii.data(), (size_t)nr, stream_); src->ival.upload(iv.data(), (size_t)nr, stream_);
-            src->draws.reserve((size_t)nb + 1); src->pairs.reserve((size_t)nb + 1);
-            src->draw_off.reserve((size_t)nb + 2); src->pair_off.reserve((size_t)nb + 2);
-            src->pos_list.reserve((size_t)nr + 1); src->neg_list.reserve((size_t)nr + 1);
-            HIPCHECK(hipStreamSynchronize(stream_));
-        }
-        rank_source_ = std::move(src);
-    }
+    if (!rank_source_load(path)) return nullptr;
     RankSource &S = *rank_source_;
     if (!S.eligible) return nullptr;
     check(trainer_ready_, "dataset: init_trainer has not been called");
@@ -417,7 +527,7 @@ Dataset *Engine::rank_pass_device(const char *path) {
 long Engine::rank_sample_buffer_file(const char *in_path, const char *out_path) {
     check(in_path != nullptr && out_path != nullptr, "rank_sample_buffer_file: null path");
     UserGroupArrays g;
-    rank_pass(in_path, g);
+    if (!(device_rank_ && !rank_prefetch_ && !host_only_ && device_ >= 0 && trainer_ready_ && rank_pass_device_general(in_path, g))) rank_pass(in_path, g);
     FILE *fo = fopen(out_path, "wb");
     if (!fo) fail(std::string("can not open file \"") + out_path + "\"");
     const size_t nb = g.tag.size();

@@ -113,6 +113,16 @@ int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *dst, int hal
     SVDF_GUARD(-1, { t->e->window_delta_pack(ds ? ds->d : nullptr, dst, half, count); return 0; })
 }
 int svdf_window_delta_apply(svdf_trainer *t, const void *src, int half) { SVDF_GUARD(-1, { t->e->window_delta_apply(src, half); return 0; }) }
+int svdf_debug_sort_labels(long n, const float *label, int *restated, int *library) {
+    SVDF_GUARD(-1, {
+        svdf::host_sort_by_label(label, n, restated);
+        std::vector<int> ids((size_t)std::max<long>(n, 0));
+        for (long j = 0; j < n; j++) ids[(size_t)j] = (int)j;
+        std::sort(ids.begin(), ids.end(), [label](int a, int b) { return label[a] < label[b]; });
+        for (long j = 0; j < n; j++) library[j] = ids[(size_t)j];
+        return 0;
+    })
+}
 svdf_dataset *svdf_dataset_from_pairs(svdf_trainer *t, long n, const unsigned *user, const unsigned *pos_item, const unsigned *neg_item) {
     SVDF_GUARD(nullptr, {
         svdf::Dataset *d = t->e->dataset_from_pairs(n, user, pos_item, neg_item);

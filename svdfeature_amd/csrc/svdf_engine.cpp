@@ -30,6 +30,14 @@ void note_error(const std::string &m) { g_last_error = m; }
     throw Error(msg);
 }
 static inline void check(bool ok, const char *msg) { if (!ok) fail(msg); }
+// "this thread is executing the multi-GPU code of a handle" (svdf_multi.cpp): rank 0 of an amd:gpus handle is the handle itself, so
+// while a window is being trained or a resident data set is being built its own flush() / dataset_from_*() must act like a plain
+// single-GPU engine's.  Per THREAD, not per handle: the background window thread may be inside multi_flush while the caller's
+// thread enters flush() and has to wait for it.
+static thread_local int tl_multi_depth = 0;
+bool in_multi_scope() { return tl_multi_depth > 0; }
+MultiScope::MultiScope() { tl_multi_depth++; }
+MultiScope::~MultiScope() { tl_multi_depth--; }
 #define HIPCHECK(call)                                                                           \
     do {                                                                                         \
         hipError_t e_ = (call);                                                                  \
@@ -733,7 +741,7 @@ void Engine::update_block(int nfb, int tag, const unsigned *ifb, const float *vf
     check(trainer_ready_, "update: init_trainer has not been called");
     if (host_only_) need_device("update");
     check(user_group(), "not implemented");   // SVDFeature has no update(SVDPlusBlock) (apex_svd.h:97)
-    check(!multi_ || in_multi_, "svdfeature_amd: amd:gpus > 1 trains user-group data from resident data sets (svdf_dataset_from_blocks / svdf_dataset_from_buffer_file), not block by block");
+    check(!multi_ || in_multi_scope(), "svdfeature_amd: amd:gpus > 1 trains user-group data from resident data sets (svdf_dataset_from_blocks / svdf_dataset_from_buffer_file), not block by block");
     for (int j = 0; j < nfb; j++) check(ifb[j] < (unsigned)mp_.num_ufeedback, "ufeedback id exceed bound");
     if (imfb()) { update_block_imfb(nfb, tag, ifb, vfb, num_row, row_label, row_ptr, feat_index, feat_value); return; }
     const int h = (int)staged_.num_row();
@@ -978,14 +986,13 @@ static void parallel_gather(T *dst, const T *src, const int *order, long n, long
 
 // =============================================================================== flush
 void Engine::flush() {
-    if (host_only_ || !trainer_ready_ || in_multi_) return;
+    if (host_only_ || !trainer_ready_ || in_multi_scope()) return;
     wait_worker();   // a window handed to the background thread earlier must land first
     ScopedNs timer(ns_flush_);
     if (imfb()) flush_iunits();
     else if (user_group()) flush_units();
     else if (multi_) {
-        in_multi_ = true;
-        struct Leave { bool &f; ~Leave() { f = false; } } leave{in_multi_};
+        MultiScope scope;
         multi_flush(staged_);
     } else flush_csr(staged_);
 }
@@ -1015,7 +1022,8 @@ void Engine::worker_main() {
         lk.unlock();
         try {
             ScopedNs timer(ns_flush_);
-            flush_csr(job_);
+            if (multi_) { MultiScope scope; multi_flush(job_); }
+            else flush_csr(job_);
         } catch (const std::exception &ex) {
             std::lock_guard<std::mutex> g(mu_);
             worker_error_ = ex.what();
@@ -1027,7 +1035,7 @@ void Engine::worker_main() {
     }
 }
 void Engine::submit_window() {
-    if (!async_flush_ || user_group() || multi_) { flush(); return; }
+    if (!async_flush_ || user_group()) { flush(); return; }
     if (!worker_.joinable()) worker_ = std::thread([this] { worker_main(); });
     wait_worker();
     {
@@ -1394,7 +1402,7 @@ Dataset *Engine::dataset_from_blocks(long num_block, const int *extend_tag, cons
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
     check(user_group(), "svdfeature_amd: block datasets are for user-group (format_type 1) trainers");
-    if (multi_ && !in_multi_) {
+    if (multi_ && !in_multi_scope()) {
         check(mp_.common_feedback_space == 0, "svdfeature_amd: amd:gpus > 1 needs a feedback space of its own (common_feedback_space = 0)");
         return multi_dataset_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
     }
@@ -1526,7 +1534,7 @@ void Engine::predict_block(int nfb, int tag, const unsigned *ifb, const float *v
     check(user_group(), "not implemented");
     for (int j = 0; j < nfb; j++) check(ifb[j] < (unsigned)mp_.num_ufeedback, "ufeedback id exceed bound");
     flush();
-    if (multi_ && !in_multi_) {
+    if (multi_ && !in_multi_scope()) {
         // the block is scored by the owner of its user (the first user entry of its first row; a block without one -- the MIDDLE / END
         // pieces of a span carry their rows' user too -- goes where the previous block went)
         if (num_row > 0 && row_ptr[2] > row_ptr[1]) multi_predict_rank_ = (int)(feat_index[row_ptr[1]] % (unsigned)gpus_);
@@ -1646,7 +1654,7 @@ const int *Engine::host_order(Dataset *ds) {
 Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
-    if (multi_ && !in_multi_) return multi_dataset_from_triples(n, user, item, label);
+    if (multi_ && !in_multi_scope()) return multi_dataset_from_triples(n, user, item, label);
     if (!basic_fast_path_allowed()) {
         // fall back to the general representation (side tables / shared latent space / user-group trainer)
         std::vector<int64_t> ptr((size_t)3 * n + 1);
@@ -1802,7 +1810,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
     check(!user_group() || rows_as_instances_, "svdfeature_amd: resident datasets are for random-order (format_type 0) trainers");
-    if (multi_ && !in_multi_) return multi_dataset_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);
+    if (multi_ && !in_multi_scope()) return multi_dataset_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);
     const long n = num_row;
     const int64_t p00 = row_ptr[0];
     check(row_ptr[3 * n] - p00 < (int64_t)2147483647, "dataset: more than 2^31-1 feature entries");
@@ -1934,7 +1942,7 @@ WindowSchedule Engine::window_view(const Dataset *ds) const {
 Dataset *Engine::dataset_window_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
-    check(!multi_ || in_multi_, "window data sets are per rank; an amd:gpus handle builds them itself from svdf_dataset_from_triples");
+    check(!multi_ || in_multi_scope(), "window data sets are per rank; an amd:gpus handle builds them itself from svdf_dataset_from_triples");
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get());
     window_build(ds.get(), n, user, item, label);
@@ -2020,7 +2028,7 @@ void Engine::window_delta_apply(const void *device_src, int half) {
 
 void Engine::train_dataset(Dataset *ds) {
     check(ds && ds->owner == this, "train_dataset: dataset belongs to another trainer");
-    if (ds->kind == 6) { check(multi_ != nullptr && !in_multi_, "train_dataset: the data set belongs to an amd:gpus handle"); multi_train_dataset(ds); return; }
+    if (ds->kind == 6) { check(multi_ != nullptr && !in_multi_scope(), "train_dataset: the data set belongs to an amd:gpus handle"); multi_train_dataset(ds); return; }
     check(ds->sched_signature == schedule_signature(),
           "train_dataset: the dataset was scheduled under another configuration (relaxed-id keys, side tables, lazy decay or kernel-routing knobs changed since it was built); build it again");
     flush();

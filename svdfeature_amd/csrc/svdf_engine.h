@@ -31,6 +31,9 @@ struct Error : std::runtime_error {
     explicit Error(const std::string &m) : std::runtime_error(m) {}
 };
 [[noreturn]] void fail(const std::string &msg);
+// true while the calling thread runs the multi-GPU code of an amd:gpus handle (svdf_engine.cpp)
+bool in_multi_scope();
+struct MultiScope { MultiScope(); ~MultiScope(); MultiScope(const MultiScope &) = delete; MultiScope &operator=(const MultiScope &) = delete; };
 
 // --------------------------------------------------------------------------- device memory
 template <typename T>
@@ -158,6 +161,7 @@ public:
     float pos_lowerb() const { return pos_lowerb_; }
     float neg_upperb() const { return neg_upperb_; }
     int seed_bytime() const { return seed_bytime_; }
+    float gap() const { return gap_; }
 private:
     int sample_num_ = -1, sample_max_ = 0x7fffffff, method_ = 0, pointwise_ = 0, seed_bytime_ = 0;
     float gap_ = 0.0001f, pos_lowerb_ = 0.8f, neg_upperb_ = 1e-6f;
@@ -172,13 +176,26 @@ struct MultiDeleter { void operator()(MultiState *m) const; };
 // a user-group buffer file kept in HBM for the device sampler (svdf_k_sample.hip); built once per file, reused every pass
 struct RankSource {
     std::string path;
-    long file_size = -1, file_mtime = -1;
+    long file_size = -1, file_mtime = -1, file_ino = -1;   // cache key: size, mtime in ns, inode
     bool eligible = false;
     long num_block = 0, num_row = 0;
     DevBuf<long> block_row_ptr, draws, pairs, draw_off, pair_off;
     DevBuf<float> label, uval, ival;
     DevBuf<unsigned> uidx, iidx, raw, tables;
     DevBuf<int> pos_list, neg_list;
+    // the general device sampler (svdf_k_gsample.hip): the file's rows in the reference's CSR layout, the host copy of everything a
+    // generated pass keeps from the file (tags, feedback lists), and the pass's scratch / output
+    bool general = false;
+    std::vector<int> h_tag;
+    std::vector<int64_t> h_fb_ptr;
+    std::vector<unsigned> h_fb_index;
+    std::vector<float> h_fb_value;
+    DevBuf<int> g_row_ptr, pair_p, pair_n, lens, optr;
+    DevBuf<unsigned> g_index, out_index;
+    DevBuf<float> g_value, out_label, out_value;
+    void *scan_tmp = nullptr;
+    size_t scan_tmp_bytes = 0;
+    ~RankSource() { if (scan_tmp) (void)hipFree(scan_tmp); }
 };
 class Engine;
 class Ranker;
@@ -386,6 +403,8 @@ class Engine {
     void disown(Dataset *ds);
     void rank_pass(const char *path, UserGroupArrays &g);
     Dataset *rank_pass_device(const char *path);   // nullptr when the file or the sampler settings need the host path
+    bool rank_source_load(const char *path);       // (re)loads rank_source_ for this file; false when it cannot be opened / stat'ed
+    bool rank_pass_device_general(const char *path, UserGroupArrays &g);   // any row shape / method: the pass drawn in HBM, blocks back in g
     std::unique_ptr<RankSource> rank_source_;
     bool device_rank_ = true;                       // knob "device_rank"
     bool fewrow_fast_ = true;                       // knob "fewrow_fast": specialised few-row kernel (svdf_k_fewrow.hip)
@@ -455,7 +474,7 @@ class Engine {
     std::vector<Range> shared_ranges();
     // ---- N GPUs behind this handle (svdf_multi.cpp)
     int gpus_ = 1;
-    bool is_peer_ = false, delta_half_ = true, window_set_ = false, in_multi_ = false;
+    bool is_peer_ = false, delta_half_ = true, window_set_ = false;
     std::vector<std::pair<std::string, std::string>> param_log_;   // every set_param so far, replayed on the other ranks
     std::unique_ptr<MultiState, MultiDeleter> multi_;
     Engine *rank_engine(int d);
@@ -471,6 +490,7 @@ class Engine {
                                        const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
                                        const float *feat_value);
     void multi_train_dataset(Dataset *ds);
+    long multi_windows_for(long n, const std::vector<long> &item_count) const;
     void multi_synchronize();
     int multi_predict_rank_ = 0;         // owner of the user-group block scored last (predict_block on an amd:gpus handle)
     int multi_exchange_mode_ = 0;        // "amd:exchange": 0 p2p (peer loads / stores between the ranks of this process), 1 rccl

@@ -92,6 +92,24 @@ struct RankSourceDev {          // a user-group buffer file resident in HBM, row
 };
 struct SamplerParams { float pos_lowerb, neg_upperb; int sample_num, sample_max; };
 struct PairColumns { float *label, *uval, *v0, *v1; unsigned *uidx, *i0, *i1; };   // generated instances, file order
+// the general device sampler (any row shape, both sampling methods, pointwise output): svdf_k_gsample.hip
+struct RankRowsDev {            // a user-group buffer file's rows resident in HBM, reference CSR layout
+    long num_block, num_row;
+    const long *block_row_ptr;  // [num_block + 1]
+    const float *label;         // [num_row]
+    const int *row_ptr;         // [3 * num_row + 1]
+    const unsigned *index;
+    const float *value;
+};
+struct GSamplerParams { float pos_lowerb, neg_upperb, gap; int sample_num, sample_max, method, method_raw, pointwise; };
+void launch_gsample_counts(const RankRowsDev &S, const GSamplerParams &sp, int *scratch, long *draws, long *pairs, hipStream_t st);
+void launch_gsample_pairs(const RankRowsDev &S, const GSamplerParams &sp, const long *draw_off, const long *pair_off, const unsigned *raw, int *pos_list,
+                          int *neg_list, int *pair_p, int *pair_n, hipStream_t st);
+void launch_gpair_sizes(const RankRowsDev &S, const GSamplerParams &sp, long npairs, const int *pair_p, const int *pair_n, int *lens, hipStream_t st);
+void launch_gpair_write(const RankRowsDev &S, const GSamplerParams &sp, long npairs, const int *pair_p, const int *pair_n, const int *optr, float *olabel,
+                        unsigned *oi, float *ov, hipStream_t st);
+void device_exclusive_scan_i32(const int *in, int *out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st);
+void host_sort_by_label(const float *label, long n, int *ids);   // the restated std::sort (svdf_stdsort.h) on the host, for tests
 void launch_rand_expand(const unsigned *tables, long nchunks, long C, long D, unsigned *raw, hipStream_t st);
 void launch_sample_counts(const RankSourceDev &S, const SamplerParams &sp, long *draws, long *pairs, hipStream_t st);
 void launch_sample_posneg(const RankSourceDev &S, const SamplerParams &sp, const long *draw_off, const long *pair_off, const unsigned *raw,

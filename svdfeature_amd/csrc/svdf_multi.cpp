@@ -94,6 +94,7 @@ struct RankPool {
         for (size_t d = 0; d < dev.size(); d++) th.emplace_back([this, d]() { loop((int)d); });
     }
     void loop(int d) {
+        MultiScope scope;   // everything a rank thread runs is the multi-GPU code of the handle (rank 0's engine is the handle itself)
         (void)hipSetDevice(device[(size_t)d]);
         uint64_t seen = 0;
         std::unique_lock<std::mutex> lk(mu);
@@ -180,11 +181,12 @@ void Engine::multi_setup() {
         MCHECK(hipEventCreateWithFlags(&M.packed[(size_t)d], hipEventDisableTiming));
         MCHECK(hipEventCreateWithFlags(&M.gathered[(size_t)d], hipEventDisableTiming));
     }
-    // one exchange window = `per_item` updates per item: 32 for the window-minibatch step at any number of
-    // ranks (tools/minibatch_calibration.py), 64 / 42 / 32 at 2 / 3-4 / more ranks for the level scheme; an explicit stage_window
-    // knob or amd:window key wins.  Capped so that a large catalogue does not stage tens of GB on the host per window.
+    // one exchange window = `per_item` updates per item: 24 for the window-minibatch step at any number of
+    // ranks (tools/minibatch_calibration.py: 32 keeps |dRMSE| at 6.3e-5 on the BASELINE configs[2] replica, which is what bench.py
+    // uses; the handle's own default leaves more room for data it has not been calibrated on), 64 / 42 / 32 at 2 / 3-4 / more ranks
+    // for the level scheme; an explicit stage_window knob or amd:window key wins.  Capped so that a large catalogue does not stage tens of GB on the host per window.
     if (!window_set_) {
-        const long per_item = multi_step_levels_ ? (gpus_ <= 2 ? 64 : (gpus_ <= 4 ? 42 : 32)) : 32;
+        const long per_item = multi_step_levels_ ? (gpus_ <= 2 ? 64 : (gpus_ <= 4 ? 42 : 32)) : 24;
         stage_window_ = std::min<long>(1L << 24, std::max<long>(1024, per_item * (long)std::max(mp_.num_item, 1)));
     }
     M.pool.reset(new RankPool());
@@ -363,13 +365,17 @@ void Engine::multi_flush(HostCSR &src) {
     src.clear();
 }
 
-// while the handle builds or trains the ranks' pieces, rank 0 -- the handle itself -- must act as a plain single-GPU engine: its
-// dataset_from_* / flush() would otherwise route back into this file from inside a rank thread
-struct LocalMode {
-    bool &f, prev;
-    explicit LocalMode(bool &flag) : f(flag), prev(flag) { f = true; }
-    ~LocalMode() { f = prev; }
-};
+// The automatic window assumes every item is updated equally often (per_item x num_item instances per window).  A resident data
+// set knows better: an instance meets  sum_i c_i^2 / n  updates of its own items per pass (c_i = rows that carry item i), which is
+// n / num_item for a uniform catalogue and larger for a skewed one -- THAT is kept at `per_item` per window.
+long Engine::multi_windows_for(long n, const std::vector<long> &item_count) const {
+    long W = std::max<long>(1, (n + stage_window_ - 1) / stage_window_);
+    if (window_set_ || n <= 0) return W;
+    double s2 = 0.0;
+    for (long c : item_count) s2 += (double)c * (double)c;
+    const double per_item = multi_step_levels_ || user_group() ? (gpus_ <= 2 ? 64.0 : (gpus_ <= 4 ? 42.0 : 32.0)) : 24.0;
+    return std::max<long>(W, (long)std::ceil(s2 / (double)n / per_item));
+}
 
 // ---- resident data sets on the handle: sharded by user, cut into windows at global positions, one child per (rank, window)
 static long multi_num_windows(long n, long window) { return std::max<long>(1, (n + window - 1) / window); }
@@ -381,23 +387,14 @@ Dataset *Engine::multi_dataset_from_triples(long n, const unsigned *user, const 
         if (item[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound");
     }
     flush();
-    LocalMode local(in_multi_);
+    MultiScope local;
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = n; ds->kind = 6;
     const bool mbatch = multi_minibatch_allowed();
     ds->m_minibatch = mbatch;
-    long W = multi_num_windows(n, stage_window_);
-    if (!window_set_ && n > 0) {
-        // the automatic window assumes every item is rated equally often (per_item x num_item instances); a resident data set knows
-        // better: an instance meets  n * sum_i f_i^2  updates of its own item per pass (f_i = the item's share of the instances),
-        // which is n / num_item for uniform data and larger for skewed catalogues -- keep THAT at `per_item` per window
-        std::vector<long> cnt((size_t)mp_.num_item, 0);
-        for (long r = 0; r < n; r++) cnt[item[r]]++;
-        double s2 = 0.0;
-        for (long c : cnt) s2 += (double)c * (double)c;
-        const double per_item = multi_step_levels_ ? (gpus_ <= 2 ? 64.0 : (gpus_ <= 4 ? 42.0 : 32.0)) : 32.0;
-        W = std::max<long>(W, (long)std::ceil(s2 / (double)n / per_item));
-    }
+    std::vector<long> cnt((size_t)mp_.num_item, 0);
+    for (long r = 0; r < n; r++) cnt[item[r]]++;
+    const long W = multi_windows_for(n, cnt);
     ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
     for (long w = 0; w < W; w++) {
         const long b0 = n * w / W, b1 = n * (w + 1) / W;
@@ -436,11 +433,14 @@ Dataset *Engine::multi_dataset_from_csr(long num_row, const float *row_label, co
         return multi_dataset_from_triples(num_row, u.data(), it.data(), row_label);
     }
     flush();
-    LocalMode local(in_multi_);
+    MultiScope local;
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = num_row; ds->kind = 6;
     ds->m_minibatch = false;
-    const long W = multi_num_windows(num_row, stage_window_);
+    std::vector<long> cnt((size_t)mp_.num_item, 0);
+    for (long r = 0; r < num_row; r++)
+        for (int64_t j = row_ptr[(size_t)3 * r + 2]; j < row_ptr[(size_t)3 * r + 3]; j++) if (feat_index[(size_t)j] < (unsigned)mp_.num_item) cnt[feat_index[(size_t)j]]++;
+    const long W = multi_windows_for(num_row, cnt);
     ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
     struct Part { std::vector<float> label, value; std::vector<int64_t> ptr{0}; std::vector<unsigned> index; };
     long alg = 0;
@@ -499,7 +499,25 @@ Dataset *Engine::multi_dataset_from_blocks(long num_block, const int *extend_tag
                          "different ranks; train such data on one GPU");
         }
     // window cuts in blocks: stage_window_ counts rows; move a cut forward to the next position where no span is open
-    const long W0 = multi_num_windows(std::max<long>(num_row, 1), stage_window_);
+    std::vector<long> cnt((size_t)mp_.num_item, 0);
+    for (int64_t r = block_row_ptr[0]; r < block_row_ptr[num_block]; r++)
+        for (int64_t j = row_ptr[(size_t)3 * r + 2]; j < row_ptr[(size_t)3 * r + 3]; j++) if (feat_index[(size_t)j] < (unsigned)mp_.num_item) cnt[feat_index[(size_t)j]]++;
+    long W0 = multi_windows_for(std::max<long>(num_row, 1), cnt);
+    if (!window_set_ && num_row > 0) {
+        // the implicit-feedback rows move by whole-block steps: a block of n rows pushes about n |value| instance-sized updates into
+        // every row of its feedback list at once (update_ufeedback, apex_svd_base.h:539-554), and stale sums of those overshoot much
+        // earlier than item rows do (ML-100K user blocks, 2 ranks, CPU simulation: 3 windows per pass +0.13 RMSE, 32 windows +1.1e-3,
+        // 64 windows +1.6e-5).  Heuristic, not a calibration: keep  sum_f m_f^2 / sum_f m_f  (m_f = instance-sized updates into
+        // feedback row f per pass) at 24 per window; amd:window overrides.
+        std::vector<double> mass((size_t)std::max(num_fb_rows(), 1), 0.0);
+        for (long b = 0; b < num_block; b++) {
+            const double nrow = (double)(block_row_ptr[b + 1] - block_row_ptr[b]);
+            for (int64_t j = fb_ptr[b]; j < fb_ptr[b + 1]; j++) if (fb_index[(size_t)j] < (unsigned)mass.size()) mass[fb_index[(size_t)j]] += nrow * std::fabs((double)fb_value[(size_t)j]);
+        }
+        double s1 = 0.0, s2 = 0.0;
+        for (double m : mass) { s1 += m; s2 += m * m; }
+        if (s1 > 0.0) W0 = std::max<long>(W0, std::min<long>(num_block, (long)std::ceil(s2 / s1 / 24.0)));
+    }
     std::vector<long> cut{0};
     for (long w = 1; w < W0; w++) {
         long pos = std::max<long>(num_block * w / W0, cut.back());
@@ -509,7 +527,7 @@ Dataset *Engine::multi_dataset_from_blocks(long num_block, const int *extend_tag
     cut.push_back(num_block);
     const long W = (long)cut.size() - 1;
     flush();
-    LocalMode local(in_multi_);
+    MultiScope local;
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = num_row; ds->kind = 6;
     ds->m_minibatch = false;
@@ -559,7 +577,7 @@ Dataset *Engine::multi_dataset_from_blocks(long num_block, const int *extend_tag
 void Engine::multi_train_dataset(Dataset *ds) {
     check(ds->kind == 6 && (int)ds->mchild.size() == gpus_, "train_dataset: not a data set of this amd:gpus handle");
     flush();
-    LocalMode local(in_multi_);
+    MultiScope local;
     const size_t W = ds->mchild.empty() ? 0 : ds->mchild[0].size();
     std::vector<Dataset *> mb((size_t)gpus_);
     for (size_t w = 0; w < W; w++) {

@@ -175,12 +175,12 @@ def test_native_multi_gpu_rmse_contract_fp16_wire():
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=16)
     d, dt = sa.CSRData.from_triples(u, i, r), sa.CSRData.from_triples(tu, ti, tr)
     seq = _ready(conf)
-    multi = _ready(conf, [("amd:gpus", 8)])   # window = 32 updates per item = 64 K instances
+    multi = _ready(conf, [("amd:gpus", 8)])   # window = 24 updates per item = 48 K instances
     for _ in range(5):
         for t in (seq, multi):
             t.update_batch(d)
             t.finish_round()
-    assert multi.counter(8) == 5 * 16
+    assert multi.counter(8) == 5 * 21 and multi.counter(11) == 5 * 21   # window-minibatch step, 21 windows per pass
     a, b = cases.rmse(seq.predict_batch(dt), tr), cases.rmse(multi.predict_batch(dt), tr)
     assert abs(a - b) <= 1e-4, (a, b)
 

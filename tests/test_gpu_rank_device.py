@@ -69,25 +69,105 @@ def test_device_sampler_equals_host_sampler(users, rows, k, keys, tmp_path):
         assert np.array_equal(dv[name].view(np.uint32), hv[name].view(np.uint32)), name
 
 
-def test_device_sampler_declines_what_it_does_not_cover(tmp_path):
-    """rows with global features / several item entries, blocks with feedback, rank_sample_method = 1: host sampler as before"""
-    from svdfeature_amd import data as D
-    src = str(tmp_path / "rich.buffer")
-    D.write_ugroup_buffer(src, cases.rank_blocks(100, 60, 50, 8, 900))
-    conf = cases.conf_with(cases.BASICMF_CONF, num_user=60, num_item=50, num_global=8, num_factor=8, num_ufeedback=50)
+GOLD = np.load(os.path.join(cases.GOLDEN, "rank_input.npz"))
+
+
+def _rich_trainer(keys, device_rank=1):
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=60, num_item=50, num_global=8, num_factor=8, num_ufeedback=50, wd_ufeedback="0.004",
+                           ufeedback_init_sigma="0.01", no_user_bias=1, wd_global="0.001")
     t = sa.Trainer(1, 3)
-    t.seed(10)
-    for k, v in [(a, b) for a, b in conf if a != "base_score"]:
-        t.set_param(k, v)
+    t.seed(3)
+    for k, v in [(a, b) for a, b in conf if a != "base_score"] + list(keys.items()):
+        t.set_param(k, str(v))
     t.init_model()
     t.init_trainer()
-    ds = t.dataset_from_rank_buffer_file(src)
-    assert t.counter(7) == 0 and ds.num_row > 0
-    src2 = str(tmp_path / "cand.buffer")
-    write_candidates(src2, 100, 8, 40, seed=3)
-    conf2 = _conf(100, 40, 8, rank_sample_method=1)
-    _, _, _, _, dpass = _run(src2, conf2, 1, 1)
-    assert dpass == 0
+    t.set_knob("device_rank", device_rank)
+    return t
+
+
+@pytest.mark.parametrize("n", range(len(cases.RANK_SAMPLER_CASES)), ids=[c[0] for c in cases.RANK_SAMPLER_CASES])
+def test_general_device_sampler_draws_the_reference_pairs(n, tmp_path):
+    """The GENERAL device sampler (svdf_k_gsample.hip: rows with global entries, several user / item entries, blocks with feedback,
+    rank_sample_method 0 and 1, pointwise output) against the golden vectors the REFERENCE's own PairwiseRankGenerator produced
+    (tests/golden/rank_input.npz, oracle/_ref/ref_pairgen_dump): the generated blocks of two passes after srand(10), byte for byte,
+    and libc's generator left where the host sampler leaves it."""
+    from svdfeature_amd import data as D
+    name, graded, keys = cases.RANK_SAMPLER_CASES[n]
+    blocks = cases.rank_blocks(200, 60, 50, 8, 500 + n, graded)
+    src = str(tmp_path / "in.buffer")
+    D.write_ugroup_buffer(src, blocks)
+    nxt = {}
+    for mode in (1, 0):
+        t = _rich_trainer(keys, mode)
+        t.seed(cases.RANK_SAMPLER_SEED)
+        got, rows = [], 0
+        for r in range(cases.RANK_SAMPLER_ROUNDS):
+            out = str(tmp_path / ("pass%d_%d.buffer" % (mode, r)))
+            rows += t.rank_sample_buffer_file(src, out)
+            got += D.read_ugroup_buffer(out)
+        nxt[mode] = [libc.rand() for _ in range(4)]
+        assert t.counter(7) == (cases.RANK_SAMPLER_ROUNDS if mode else 0), "device sampler %staken" % ("not " if mode else "")
+        assert rows == int(GOLD["sampler/%s/num_row" % name]) == sum(b.data.num_row for b in got)
+        if n == 0:
+            np.testing.assert_array_equal(np.concatenate([b.data.row_label for b in got]).view(np.uint32), GOLD["sampler/%s/label" % name].view(np.uint32))
+            np.testing.assert_array_equal(np.concatenate([np.diff(b.data.row_ptr) for b in got]), GOLD["sampler/%s/row_len" % name])
+            np.testing.assert_array_equal(np.concatenate([b.data.feat_index for b in got]), GOLD["sampler/%s/index" % name])
+            np.testing.assert_array_equal(np.concatenate([b.data.feat_value for b in got]).view(np.uint32), GOLD["sampler/%s/value" % name].view(np.uint32))
+        assert cases.blocks_digest(got) == str(GOLD["sampler/%s/md5" % name])
+        t.close()
+    assert nxt[1] == nxt[0], "libc rand() stands elsewhere after the device passes"
+
+
+@pytest.mark.parametrize("keys", [{}, {"rank_sample_method": 1}, {"rank_sample_pointwise": 1}, {"rank_sample_method": 1, "rank_sample_gap": "1.5"}],
+                         ids=["posneg", "cmp", "pointwise", "cmp_wide"])
+def test_rich_rank_input_trains_identically_from_device_and_host_samplers(keys, tmp_path):
+    """input_type = 2 on rich candidate files (global entries, side user entries, several item entries, implicit feedback, graded
+    labels): passes drawn in HBM -> byte-identical parameters and rand() position to passes drawn by the host sampler."""
+    from svdfeature_amd import data as D
+    src = str(tmp_path / "rich.buffer")
+    D.write_ugroup_buffer(src, cases.rank_blocks(300, 60, 50, 8, 900, graded=bool(keys.get("rank_sample_method"))))
+    res = {}
+    for mode in (1, 0):
+        t = _rich_trainer(keys, mode)
+        t.seed(10)
+        rows = []
+        for r in range(3):
+            t.set_round(r)
+            ds = t.dataset_from_rank_buffer_file(src)
+            rows.append(ds.num_row)
+            t.train_dataset(ds)
+            t.finish_round()
+        res[mode] = ({v: t.view(v).copy() for v in ("W_user", "W_item", "i_bias", "g_bias", "W_ufeedback")}, rows, [libc.rand() for _ in range(4)], t.counter(7))
+        t.close()
+    assert res[1][3] == 3 and res[0][3] == 0
+    assert res[1][1] == res[0][1] and sum(res[1][1]) > 0
+    assert res[1][2] == res[0][2]
+    for v in res[1][0]:
+        assert np.array_equal(res[1][0][v].view(np.uint32), res[0][0][v].view(np.uint32)), v
+
+
+def test_big_blocks_through_the_device_sort(tmp_path):
+    """blocks of thousands of rows with five distinct labels: the per-block std::sort restatement on the device (svdf_stdsort.h) at the
+    sizes where introsort partitions many times; device-drawn pass == host-drawn pass, byte for byte"""
+    from svdfeature_amd import data as D
+    rng = np.random.default_rng(4)
+    blocks = []
+    for b in range(6):
+        nrow = int(rng.integers(1500, 6000))
+        rows = [(float(rng.integers(1, 6)), [], [(b, 1.0)], [(int(rng.integers(0, 50)), 1.0)]) for _ in range(nrow)]
+        blocks.append(D.PlusBlock(np.zeros(0, np.uint32), np.zeros(0, np.float32), sa.CSRData.from_rows(rows), 0))
+    src = str(tmp_path / "big.buffer")
+    D.write_ugroup_buffer(src, blocks)
+    out = {}
+    for mode in (1, 0):
+        t = _rich_trainer({"rank_sample_method": 1}, mode)
+        t.seed(10)
+        o = str(tmp_path / ("o%d" % mode))
+        t.rank_sample_buffer_file(src, o)
+        out[mode] = cases.blocks_digest(D.read_ugroup_buffer(o))
+        assert t.counter(7) == mode
+        t.close()
+    assert out[1] == out[0]
 
 
 def test_device_sampler_pass_time(tmp_path):

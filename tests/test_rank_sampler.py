@@ -179,3 +179,35 @@ def test_sampler_random_settings_against_the_reference_generator(tmp_path):
         subprocess.check_call([REF_DUMP, src, ref_out, str(seed), "2"] + ["%s=%s" % kv for kv in keys.items()],
                               cwd=str(d), stdout=subprocess.DEVNULL)
         assert cases.blocks_digest(D.read_ugroup_buffer(ref_out)) == cases.blocks_digest(got), (case, keys)
+
+
+def test_restated_std_sort_equals_the_library_sort_position_for_position():
+    """svdf_stdsort.h restates libstdc++'s std::sort (introsort) because sample_cmp (apex_svd_data.cpp:920-944) picks rows by position
+    after an unstable sort of few distinct labels.  Same permutation as the library's own std::sort for every size class: <= 16
+    (insertion sort only), a few partitions, thousands of rows, few / many distinct keys, already sorted, reversed, organ pipe and
+    median-of-three killer inputs (the latter run into the heap-sort fallback at the depth limit)."""
+    rng = np.random.default_rng(5)
+    cases_ = []
+    for n in list(range(0, 40)) + [63, 64, 65, 100, 257, 1000, 4097, 20000]:
+        for distinct in (1, 2, 5, 50, 10 ** 6):
+            cases_.append(rng.integers(0, distinct, n).astype(np.float32))
+    for n in (17, 33, 200, 3000):
+        cases_.append(np.arange(n, dtype=np.float32))
+        cases_.append(np.arange(n, dtype=np.float32)[::-1].copy())
+        cases_.append(np.concatenate([np.arange(n // 2), np.arange(n - n // 2)[::-1]]).astype(np.float32))
+
+    def killer(n):   # Musser's median-of-3 killer sequence: quadratic for plain quicksort, forces the introsort depth limit
+        k = n // 2
+        a = np.zeros(n, np.float32)
+        for i in range(1, k + 1):
+            if i % 2 == 1:
+                a[i - 1] = i
+                a[i] = k + i
+            a[k + i - 1] = 2 * i
+        return a
+    for n in (64, 512, 4096, 30000):
+        cases_.append(killer(n))
+    for lab in cases_:
+        mine, lib = sa.debug_sort_labels(lab)
+        np.testing.assert_array_equal(mine, lib)
+        assert np.all(np.diff(lab[mine]) >= 0) and sorted(mine.tolist()) == list(range(len(lab)))
