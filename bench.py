@@ -357,7 +357,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
     # (svdf_k_window.hip: user side exact, item side one minibatch step per window; three launches per window), "levels" = the
     # round-2 scheme (exact conflict-free levels per rank, item side stale across ranks only)
     exchanging = world > 1 or a.force_exchange
-    minibatch = exchanging and name == "basicmf" and a.exchange != "levels"
+    minibatch = exchanging and name in ("basicmf", "pairwise") and a.exchange != "levels"
     auto_parts = 1 if world <= 2 else 2
     parts = (a.exchange_parts or auto_parts) if (name == "basicmf" and exchanging) else 1
     adaptor = HipShard(tr, torch, torch.device("cuda", local_rank), parts=parts, minibatch=minibatch)
@@ -367,7 +367,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
         # updates per item per window that keep the accuracy contract: window-minibatch step 32 at any number of ranks
         # (tools/minibatch_calibration.py: the result does not depend on the rank count); level scheme 64 at 2 ranks, 42 at 3-4, 32
         # beyond for ratings (tools/rmse_contract_fullsize.py); 50 for rank pairs (tests/test_multi_rank.py)
-        tgt = 50.0 if name == "pairwise" else (32.0 if minibatch else (64.0 if world <= 2 else (42.0 if world <= 4 else 32.0)))
+        tgt = 32.0 if minibatch else (50.0 if name == "pairwise" else (64.0 if world <= 2 else (42.0 if world <= 4 else 32.0)))
         nwin = max(1, int(np.ceil(per_item / tgt)))
     if world == 1 and not a.force_exchange:
         nwin = 1
@@ -429,7 +429,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
 
     # ---- one more pass with a HIP event after every phase (outside the timed region): stream time per phase of the exchange
     phase_ms = None
-    if exchanging and name == "basicmf":
+    if exchanging and name in ("basicmf", "pairwise"):
         marks = []
 
         def mark(phase):
@@ -563,8 +563,9 @@ def run_workload(name, a, env, steps, warmup, main_line):
             "parallelism": "1 GPU" if world == 1 else "dp%d user shards + RCCL all-reduce" % world,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": ("k_window_users_slots<8,2,G> + k_window_items<16,HALF> + k_delta_addto<HALF> (window-minibatch step, 3 launches per window)"
-                                    if minibatch else WORKLOADS[name][3]), "launches": launches, "avg_launch_us": per_launch_us,
+                         "kernel": (("k_window_users_slots<8,2,G,1,0,true> + k_window_items<16,HALF> + k_delta_addto<HALF>" if name == "basicmf" else
+                                     "k_window_users_slots<16,2,1,2,3,false> + k_window_items<32,HALF> + k_delta_addto<HALF>") +
+                                    " (window-minibatch step, 3 launches per window)" if minibatch else WORKLOADS[name][3]), "launches": launches, "avg_launch_us": per_launch_us,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "algorithmic_bytes_per_instance": alg_bytes / max(my_n, 1)},
             # what bounds one launch of this kernel: its measured HBM traffic at the achievable streaming rate + one dependent

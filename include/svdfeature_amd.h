@@ -197,6 +197,8 @@ int svdf_item_delta_unpack(svdf_trainer *t, const void *device_src, int half, in
  *   svdf_window_delta_apply(t, dst, half)           replicated ranges += dst
  * Deterministic (no float atomics); equals oracle/svdf_oracle.c: svdo_update_csr_batch_stale bit for bit with fp32 deltas. */
 svdf_dataset *svdf_dataset_window_from_triples(svdf_trainer *t, long n, const unsigned *user, const unsigned *item, const float *label);
+/* the same for rank pairs (user, positive item, negative item), the instances of svdf_dataset_from_pairs (BASELINE configs[4]) */
+svdf_dataset *svdf_dataset_window_from_pairs(svdf_trainer *t, long n, const unsigned *user, const unsigned *pos_item, const unsigned *neg_item);
 int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *device_dst, int half, int64_t *count);
 int svdf_window_delta_apply(svdf_trainer *t, const void *device_src, int half);
 

@@ -82,6 +82,8 @@ def load_library():
     lib.svdf_dataset_from_pairs.argtypes = [P, C.c_long, _u32p, _u32p, _u32p]
     lib.svdf_dataset_window_from_triples.restype = P
     lib.svdf_dataset_window_from_triples.argtypes = [P, C.c_long, _u32p, _u32p, _f32p]
+    lib.svdf_dataset_window_from_pairs.restype = P
+    lib.svdf_dataset_window_from_pairs.argtypes = [P, C.c_long, _u32p, _u32p, _u32p]
     lib.svdf_window_delta_pack.argtypes = [P, P, P, C.c_int, C.POINTER(C.c_int64)]
     lib.svdf_window_delta_apply.argtypes = [P, P, C.c_int]
     lib.svdf_set_view.restype = C.c_int64
@@ -355,6 +357,13 @@ class Trainer:
     def dataset_window_from_triples(self, user, item, label):
         """One exchange window of a rank's shard for the window-minibatch step (svdf_dataset_window_from_triples)."""
         h = self.lib.svdf_dataset_window_from_triples(self.h, len(label), _pad(user, np.uint32), _pad(item, np.uint32), _pad(label, np.float32))
+        if not h:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return Dataset(self, h)
+
+    def dataset_window_from_pairs(self, user, pos, neg):
+        """One exchange window of a rank's rank pairs for the window-minibatch step (svdf_dataset_window_from_pairs)."""
+        h = self.lib.svdf_dataset_window_from_pairs(self.h, len(user), _pad(user, np.uint32), _pad(pos, np.uint32), _pad(neg, np.uint32))
         if not h:
             raise SvdfError(self.lib.svdf_last_error().decode())
         return Dataset(self, h)

@@ -109,6 +109,14 @@ svdf_dataset *svdf_dataset_window_from_triples(svdf_trainer *t, long n, const un
         return h;
     })
 }
+svdf_dataset *svdf_dataset_window_from_pairs(svdf_trainer *t, long n, const unsigned *user, const unsigned *pos_item, const unsigned *neg_item) {
+    SVDF_GUARD(nullptr, {
+        svdf::Dataset *d = t->e->dataset_window_from_pairs(n, user, pos_item, neg_item);
+        svdf_dataset *h = new svdf_dataset();
+        h->d = d;
+        return h;
+    })
+}
 int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *dst, int half, int64_t *count) {
     SVDF_GUARD(-1, { t->e->window_delta_pack(ds ? ds->d : nullptr, dst, half, count); return 0; })
 }

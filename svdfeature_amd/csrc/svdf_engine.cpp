@@ -1936,8 +1936,10 @@ void Engine::disown(Dataset *ds) {
 // into the wire buffer; after the all-reduce window_delta_apply adds the sum on every rank.  Replaces what one instance
 // contributes in /root/reference/solvers/base-solver/apex_svd_base.h:383-427 being applied at once by "applied at the window's end".
 WindowSchedule Engine::window_view(const Dataset *ds) const {
-    return WindowSchedule{ds->win_urec.p, ds->num_units, ds->item.p, ds->label.p, ds->win_slot.p, ds->unit_values ? nullptr : ds->uval.p,
-                          ds->unit_values ? nullptr : ds->ival.p, ds->win_iptr.p, d_contrib_.p, d_cbias_.p};
+    const bool pairs = ds->win_item1.p != nullptr && ds->fused.max_ni == 2;
+    return WindowSchedule{ds->win_urec.p, ds->num_units, ds->item.p, pairs ? nullptr : ds->label.p, ds->win_slot.p, ds->unit_values ? nullptr : ds->uval.p,
+                          (ds->unit_values && !pairs) ? nullptr : ds->ival.p, ds->win_iptr.p, d_contrib_.p, d_cbias_.p,
+                          pairs ? ds->win_item1.p : nullptr, pairs ? ds->win_slot1.p : nullptr, pairs ? ds->win_ival1.p : nullptr};
 }
 Dataset *Engine::dataset_window_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
@@ -1948,20 +1950,41 @@ Dataset *Engine::dataset_window_from_triples(long n, const unsigned *user, const
     window_build(ds.get(), n, user, item, label);
     return ds.release();
 }
-// (re)fills ds in place: the staged path of an amd:gpus handle rebuilds one window data set per rank every window
-void Engine::window_build(Dataset *ds, long n, const unsigned *user, const unsigned *item, const float *label) {
+// rank pairs (user, positive item, negative item) of one exchange window: the instance PairwiseRankGenerator emits for two plain rows
+// (apex_svd_data.cpp:828-860, :905-911: label 1, user:1, the two items in index order with the negative's sign flipped), BASELINE
+// configs[4].  Two contribution slots per pair.
+Dataset *Engine::dataset_window_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg) {
+    check(trainer_ready_, "dataset: init_trainer has not been called");
+    need_device("dataset");
+    check(!multi_ || in_multi_scope(), "window data sets are per rank; shard rank pairs through svdfeature_amd.multi_gpu");
+    std::unique_ptr<Dataset> ds(new Dataset());
+    adopt(ds.get());
+    window_build(ds.get(), n, user, pos, nullptr, neg);
+    return ds.release();
+}
+// (re)fills ds in place: the staged path of an amd:gpus handle rebuilds one window data set per rank every window.
+// neg != nullptr: rank pairs, `item` holds the positive items and the labels are 1.
+void Engine::window_build(Dataset *ds, long n, const unsigned *user, const unsigned *item, const float *label, const unsigned *neg) {
     check(!user_group() && mtype_.extend_type == 0, "window data sets: random-order trainers only");
     check(basic_fast_path_allowed(), "window data sets: no side tables, relaxed ids, lazy decay or shared latent space; num_factor <= 256");
-    check(n >= 0 && n < (1L << 31), "window data sets: at most 2^31-1 instances per window");
+    check(n >= 0 && n < (1L << 30), "window data sets: at most 2^30-1 instances per window");
     const long NU = mp_.num_user, NI = mp_.num_item;
+    const bool pairs = neg != nullptr;
     if (window_trained_ == ds) window_trained_ = nullptr;
     ds->num_row = n; ds->kind = 5;
+    ds->win_slots = pairs ? 2 * n : n;
+    ds->fused.max_ni = pairs ? 2 : 1;
     std::vector<int> ucnt((size_t)NU, 0), iptr((size_t)NI + 1, 0);
     for (long r = 0; r < n; r++) {
         if (user[r] >= (unsigned)NU) fail("user feature index exceed bound");
         if (item[r] >= (unsigned)NI) fail("item feature index exceed bound");
         ucnt[user[r]]++;
         iptr[(size_t)item[r] + 1]++;
+        if (pairs) {
+            if (neg[r] >= (unsigned)NI) fail("item feature index exceed bound");
+            if (neg[r] == item[r]) fail("rank pair: positive and negative item must differ");
+            iptr[(size_t)neg[r] + 1]++;
+        }
     }
     for (long i = 0; i < NI; i++) iptr[(size_t)i + 1] += iptr[(size_t)i];
     // users in launch order: by instance count, descending (the lane groups of a wave then run the same number of iterations),
@@ -1979,27 +2002,43 @@ void Engine::window_build(Dataset *ds, long n, const unsigned *user, const unsig
     }
     std::vector<int> ubegin((size_t)NU, 0);
     { long acc = 0; for (long j = 0; j < nact; j++) { urec[(size_t)j].begin = (int)acc; ubegin[urec[(size_t)j].user] = (int)acc; acc += urec[(size_t)j].count; } }
-    std::vector<unsigned> w_item((size_t)n);
-    std::vector<float> w_label((size_t)n);
-    std::vector<int> w_slot((size_t)n), icur(iptr.begin(), iptr.end() - 1);
+    std::vector<unsigned> w_item((size_t)n), w_item1(pairs ? (size_t)n : 0);
+    std::vector<float> w_label(pairs ? 0 : (size_t)n), w_v0(pairs ? (size_t)n : 0), w_v1(pairs ? (size_t)n : 0);
+    std::vector<int> w_slot((size_t)n), w_slot1(pairs ? (size_t)n : 0), icur(iptr.begin(), iptr.end() - 1);
     for (long r = 0; r < n; r++) {   // file order: a user's instances and an item's slots both keep it
-        const int pos = ubegin[user[r]]++;
-        w_item[(size_t)pos] = item[r];
-        w_label[(size_t)pos] = label[r];
-        w_slot[(size_t)pos] = icur[item[r]]++;
+        const int at = ubegin[user[r]]++;
+        if (!pairs) {
+            w_item[(size_t)at] = item[r];
+            w_label[(size_t)at] = label[r];
+            w_slot[(size_t)at] = icur[item[r]]++;
+        } else {   // entry 0 = the lower item id (the merged row is index sorted), the negative's sign flipped
+            const bool pf = item[r] < neg[r];
+            const unsigned lo = pf ? item[r] : neg[r], hi = pf ? neg[r] : item[r];
+            w_item[(size_t)at] = lo; w_item1[(size_t)at] = hi;
+            w_v0[(size_t)at] = pf ? 1.0f : -1.0f; w_v1[(size_t)at] = pf ? -1.0f : 1.0f;
+            w_slot[(size_t)at] = icur[lo]++; w_slot1[(size_t)at] = icur[hi]++;
+        }
     }
     ds->win_urec.upload(urec.data(), (size_t)nact, stream_);
     ds->item.upload(w_item.data(), (size_t)n, stream_);
-    ds->label.upload(w_label.data(), (size_t)n, stream_);
     ds->win_slot.upload(w_slot.data(), (size_t)n, stream_);
     ds->win_iptr.upload(iptr.data(), (size_t)NI + 1, stream_);
+    if (!pairs) {
+        ds->label.upload(w_label.data(), (size_t)n, stream_);
+        ds->win_item1.release();
+    } else {
+        ds->win_item1.upload(w_item1.data(), (size_t)n, stream_);
+        ds->win_slot1.upload(w_slot1.data(), (size_t)n, stream_);
+        ds->ival.upload(w_v0.data(), (size_t)n, stream_);
+        ds->win_ival1.upload(w_v1.data(), (size_t)n, stream_);
+    }
     HIPCHECK(hipStreamSynchronize(stream_));   // the host columns go out of scope
     ds->unit_values = true;
     ds->num_units = nact;
     ds->sched.level_ptr = {0, n};
     ds->sched.max_level_size = n;
-    const long nb = mp_.no_user_bias ? 1 : 2;
-    ds->algorithmic_bytes = n * (8L * mp_.num_factor * 2 + 8 * nb + 16 + 8 * 2);   // SURVEY 8(d4), what the reference's step moves per instance
+    const long nrow_touched = pairs ? 3 : 2, nb = (mp_.no_user_bias ? 0 : 1) + (pairs ? 2 : 1);
+    ds->algorithmic_bytes = n * (8L * mp_.num_factor * nrow_touched + 8 * nb + 16 + 8 * nrow_touched);   // SURVEY 8(d4), what the reference's step moves per instance
 }
 void Engine::window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t *count) {
     check(trainer_ready_, "window_delta: init_trainer has not been called");
@@ -2043,8 +2082,8 @@ void Engine::train_dataset(Dataset *ds) {
         } else if (ds->kind == 5) {
             // window-minibatch step, first half: the users' exact walks; the item side is only read, its would-be change goes to the
             // contribution slots that window_delta_pack sums (svdf_k_window.hip)
-            d_contrib_.reserve((size_t)ds->num_row * (size_t)pitch_);
-            d_cbias_.reserve((size_t)ds->num_row);
+            d_contrib_.reserve((size_t)ds->win_slots * (size_t)pitch_);
+            d_cbias_.reserve((size_t)ds->win_slots);
             launch_window_users(P, window_view(ds), window_slots_, window_groups_, stream_);
             window_trained_ = ds;
         } else if (ds->kind == 3) {

@@ -208,7 +208,10 @@ struct Dataset {
                                   // 5 window-minibatch (user-grouped instances of one exchange window, svdf_k_window.hip)
     // kind 5: user records in launch order, user-grouped columns (item / label / uval / ival above), contribution slots, item segments
     DevBuf<WinUser> win_urec;
-    DevBuf<int> win_slot, win_iptr;
+    DevBuf<int> win_slot, win_iptr, win_slot1;
+    DevBuf<unsigned> win_item1;   // rank pairs: the second (higher-id) item entry, its slot and sign; entry 0 uses item / win_slot / ival
+    DevBuf<float> win_ival1;
+    long win_slots = 0;           // contribution slots of the window = item entries
     // kind 6: a data set of an amd:gpus = N handle (svdf_multi.cpp): mchild[rank][window] lives in that rank's HBM
     std::vector<std::vector<Dataset *>> mchild;
     bool m_minibatch = false;     // the children are window-minibatch data sets (kind 5), else level-scheduled ones
@@ -277,6 +280,7 @@ class Engine {
     void rank_prefetch_drop();
     // window-minibatch data set of one exchange window (N > 1 ranks: user side exact, item side one minibatch step per window)
     Dataset *dataset_window_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
+    Dataset *dataset_window_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg);
     void window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t *count);   // per-item sum of the window's contributions -> wire buffer
     void window_delta_apply(const void *device_src, int half);                           // replicated ranges += wire buffer
     void train_dataset(Dataset *ds);
@@ -496,7 +500,7 @@ class Engine {
     int multi_exchange_mode_ = 0;        // "amd:exchange": 0 p2p (peer loads / stores between the ranks of this process), 1 rccl
     bool multi_step_levels_ = false;     // "amd:step = levels": exact conflict-free levels per rank instead of the window-minibatch step
     std::unique_ptr<Dataset> w_window_;  // the staged path's window-minibatch data set of this rank, rebuilt in place every window
-    void window_build(Dataset *ds, long n, const unsigned *user, const unsigned *item, const float *label);
+    void window_build(Dataset *ds, long n, const unsigned *user, const unsigned *item, const float *label, const unsigned *neg = nullptr);
     void multi_predict(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value, float *out);
     void multi_gather_user_rows();
     int64_t multi_counter(int what) const;

@@ -21,7 +21,7 @@ namespace svdf {
 // Records are in LAUNCH order: users sorted by count (descending), so the lane groups of a wave run the same number of iterations.
 
 // ------------------------------------------------------------------------------------------------- kernel A, any width <= 256
-template <int LPI, bool UNITVAL>
+template <int LPI, bool UNITVAL, int NI>
 __global__ __launch_bounds__(256) void k_window_users(const DevParams P, const WindowSchedule S) {
     constexpr int IPW = 64 / LPI;
     const int lane = threadIdx.x & 63;
@@ -42,42 +42,57 @@ __global__ __launch_bounds__(256) void k_window_users(const DevParams P, const W
     for (int j = 0; j < maxc; j++) {
         const bool act = valid && j < rec.count;
         const long s = (long)rec.begin + (act ? j : 0);
-        const unsigned item = S.item[s];
-        const unsigned ir = P.item_off + item;
-        const float label = S.label[s];
-        const float ua = UNITVAL ? 1.0f : S.uval[s], ia = UNITVAL ? 1.0f : S.ival[s];
-        const float4 q = load_row<LPI>(P.W, ir, pitch, L, k);
-        const float bi = P.bias[ir];
+        unsigned item[NI];
+        float ia[NI], bi[NI];
+        float4 q[NI];
+        item[0] = S.item[s];
+        ia[0] = (UNITVAL && NI == 1) ? 1.0f : S.ival[s];
+        if (NI == 2) { item[1] = S.item1[s]; ia[1] = S.ival1[s]; }
+        const float label = S.label ? S.label[s] : 1.0f;
+        const float ua = UNITVAL ? 1.0f : S.uval[s];
+#pragma unroll
+        for (int e = 0; e < NI; e++) {
+            q[e] = load_row<LPI>(P.W, P.item_off + item[e], pitch, L, k);
+            bi[e] = P.bias[P.item_off + item[e]];
+        }
         // calc_bias (:313-353) in double; "+ 0.0" terms are the svdpp / plugin hooks returning 0.0f
         double bs = 0.0;
         if (use_ubias) { bs += (double)(ua * bu); bs += 0.0; }
         bs += 0.0;
-        bs += (double)(ia * bi);
+#pragma unroll
+        for (int e = 0; e < NI; e++) bs += (double)(ia[e] * bi[e]);
         double sum = (double)P.base_score + bs;
         float4 tu = f4zero(), ti = f4zero();
         axpy4(tu, p, ua);
-        axpy4(ti, q, ia);
+#pragma unroll
+        for (int e = 0; e < NI; e++) axpy4(ti, q[e], ia[e]);
         sum += (double)group_dot<LPI>(tu, ti, L, k);
         const float pred = map_active((float)sum, P.active_type);
         const float err = cal_grad(label, pred, P.active_type) * 1.0f;
         const float su = P.lr * err * ua;
-        const float si = P.lr * err * ia;
-        float4 wu = p, wi = q;
+        float4 wu = p;
         axpy4(wu, ti, su);
-        axpy4(wi, tu, si);
-        float nbu = bu + su, nbi = bi + si;
+        float nbu = bu + su;
         reg_row<LPI>(P, wu, wd_u, false, L);
-        reg_row<LPI>(P, wi, get_wd(P.i_rng, item, P.wd_item), true, L);
         nbu = nbu * (1.0f - P.lr * P.wd_user_bias);
-        nbi = nbi * (1.0f - P.lr * P.wd_item_bias);
+#pragma unroll
+        for (int e = 0; e < NI; e++) {
+            const float si = P.lr * err * ia[e];
+            float4 wi = q[e];
+            axpy4(wi, tu, si);
+            float nbi = bi[e] + si;
+            reg_row<LPI>(P, wi, get_wd(P.i_rng, item[e], P.wd_item), true, L);
+            nbi = nbi * (1.0f - P.lr * P.wd_item_bias);
+            if (act) {   // what the reference would have changed on the item side
+                sub4(wi, q[e]);
+                const long slot = e == 0 ? S.slot[s] : S.slot1[s];
+                store_row<LPI>(S.contrib, (size_t)slot, pitch, L, k, wi);
+                if (L == 0) S.cbias[slot] = nbi - bi[e];
+            }
+        }
         if (act) {
             p = wu;
             if (use_ubias) bu = nbu;
-            // what the reference would have changed on the item side
-            sub4(wi, q);
-            const long slot = S.slot[s];
-            store_row<LPI>(S.contrib, (size_t)slot, pitch, L, k, wi);
-            if (L == 0) S.cbias[slot] = nbi - bi;
         }
     }
     if (valid) {
@@ -91,7 +106,8 @@ __global__ __launch_bounds__(256) void k_window_users(const DevParams P, const W
 // lanes per user with V chunks each, the 16 / LANES users of a DPP row interleaved (dot_slots), G user sets per wave, and the NEXT
 // instance's item row, bias and record in flight while this one is computed (the item side is read-only inside a window, so the
 // prefetch cannot go stale).
-template <int LANES, int V, int G>
+// NI = 2: rank pairs (two signed item entries, labels 1); LINK = 0 linear / 3 sigmoid rank loss; UB = user bias on.
+template <int LANES, int V, int G, int NI, int LINK, bool UB>
 __global__ __launch_bounds__(256) void k_window_users_slots(const DevParams P, const WindowSchedule S) {
     constexpr int T = 16 / LANES;
     constexpr int IPS = 64 / LANES;    // users per user set
@@ -124,77 +140,100 @@ __global__ __launch_bounds__(256) void k_window_users_slots(const DevParams P, c
     for (int g = 0; g < G; g++) {
 #pragma unroll
         for (int v = 0; v < V; v++) p[g][v] = load_row_nt<K / 4>(P.W, ur[g], pitch, m + v * LANES, K);
-        bu[g] = P.bias[ur[g]];
+        bu[g] = UB ? P.bias[ur[g]] : 0.0f;
     }
-    // software pipeline: record / item row / item bias of iteration j + 1 are requested before iteration j is computed
-    unsigned nir[G];
-    float nlabel[G], nbi_[G];
-    int nslot[G];
-    float4 nq[G][V];
+    // software pipeline: record / item rows / item biases of iteration j + 1 are requested before iteration j is computed
+    unsigned nir[G][NI];
+    float nlabel[G], nbi_[G][NI], nia[G][NI];
+    int nslot[G][NI];
+    float4 nq[G][NI][V];
     auto fetch = [&](int j) {
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const long s = (long)begin[g] + (j < count[g] ? j : 0);
-            nir[g] = P.item_off + S.item[s];
-            nlabel[g] = S.label[s];
-            nslot[g] = S.slot[s];
+            nir[g][0] = P.item_off + S.item[s];
+            nslot[g][0] = S.slot[s];
+            nia[g][0] = NI == 2 ? S.ival[s] : 1.0f;
+            if (NI == 2) { nir[g][NI - 1] = P.item_off + S.item1[s]; nslot[g][NI - 1] = S.slot1[s]; nia[g][NI - 1] = S.ival1[s]; }
+            nlabel[g] = NI == 2 ? 1.0f : S.label[s];
         }
 #pragma unroll
         for (int g = 0; g < G; g++) {
 #pragma unroll
-            for (int v = 0; v < V; v++) nq[g][v] = load_row<K / 4>(P.W, nir[g], pitch, m + v * LANES, K);
-            nbi_[g] = P.bias[nir[g]];
+            for (int e = 0; e < NI; e++) {
+#pragma unroll
+                for (int v = 0; v < V; v++) nq[g][e][v] = load_row<K / 4>(P.W, nir[g][e], pitch, m + v * LANES, K);
+                nbi_[g][e] = P.bias[nir[g][e]];
+            }
         }
     };
     fetch(0);
     for (int j = 0; j < maxc; j++) {
-        float label[G], bi[G];
-        int slot[G];
-        float4 q[G][V];
+        float label[G], bi[G][NI], ia[G][NI];
+        int slot[G][NI];
+        float4 q[G][NI][V];
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            label[g] = nlabel[g]; bi[g] = nbi_[g]; slot[g] = nslot[g];
+            label[g] = nlabel[g];
 #pragma unroll
-            for (int v = 0; v < V; v++) q[g][v] = nq[g][v];
+            for (int e = 0; e < NI; e++) {
+                bi[g][e] = nbi_[g][e]; slot[g][e] = nslot[g][e]; ia[g][e] = nia[g][e];
+#pragma unroll
+                for (int v = 0; v < V; v++) q[g][e][v] = nq[g][e][v];
+            }
         }
         if (j + 1 < maxc) fetch(j + 1);
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const bool act = j < count[g];
-            // the arithmetic of k_basicmf_slots, the user's row and bias carried in registers
+            // the arithmetic of the lane-group kernel above, the user's row and bias carried in registers
             double bs = 0.0;
-            bs += (double)(1.0f * bu[g]); bs += 0.0;
+            if (UB) { bs += (double)(1.0f * bu[g]); bs += 0.0; }
             bs += 0.0;
-            bs += (double)(1.0f * bi[g]);
+#pragma unroll
+            for (int e = 0; e < NI; e++) bs += (double)(ia[g][e] * bi[g][e]);
             double sum = (double)P.base_score + bs;
             float4 tu[V], ti[V];
 #pragma unroll
-            for (int v = 0; v < V; v++) { tu[v] = f4zero(); ti[v] = f4zero(); axpy4(tu[v], p[g][v], 1.0f); axpy4(ti[v], q[g][v], 1.0f); }
+            for (int v = 0; v < V; v++) {
+                tu[v] = f4zero(); ti[v] = f4zero();
+                axpy4(tu[v], p[g][v], 1.0f);
+#pragma unroll
+                for (int e = 0; e < NI; e++) axpy4(ti[v], q[g][e][v], ia[g][e]);
+            }
             sum += (double)dot_slots<LANES, V>(tu, ti, m, lane);
             const float pred = (float)sum;
-            const float err = (label[g] - pred) * 1.0f;
+            const float err = (LINK == 0 ? label[g] - pred : label[g] - 1.0f / (1.0f + glibc_expf(-pred))) * 1.0f;
             const float su = P.lr * err * 1.0f;
-            const float si = P.lr * err * 1.0f;
-            float nbu = bu[g] + su, nbi = bi[g] + si;
+            float nbu = bu[g] + su;
             nbu = nbu * dec_ub;
-            nbi = nbi * dec_ib;
-            float4 c[V];
 #pragma unroll
             for (int v = 0; v < V; v++) {
-                float4 wu = p[g][v], wi = q[g][v];
+                float4 wu = p[g][v];
                 axpy4(wu, ti[v], su);
-                axpy4(wi, tu[v], si);
                 wu.x = wu.x * dec_u1; wu.y = wu.y * dec_u1; wu.z = wu.z * dec_u1; wu.w = wu.w * dec_u1;
-                wi.x = wi.x * dec_i1; wi.y = wi.y * dec_i1; wi.z = wi.z * dec_i1; wi.w = wi.w * dec_i1;
-                sub4(wi, q[g][v]);
-                c[v] = wi;
                 if (act) p[g][v] = wu;
             }
-            if (act) {
-                bu[g] = nbu;
+            if (act && UB) bu[g] = nbu;
 #pragma unroll
-                for (int v = 0; v < V; v++) store_row<K / 4>(S.contrib, (size_t)slot[g], pitch, m + v * LANES, K, c[v]);
-                S.cbias[slot[g]] = nbi - bi[g];
+            for (int e = 0; e < NI; e++) {
+                const float si = P.lr * err * ia[g][e];
+                float nbi = bi[g][e] + si;
+                nbi = nbi * dec_ib;
+                float4 c[V];
+#pragma unroll
+                for (int v = 0; v < V; v++) {
+                    float4 wi = q[g][e][v];
+                    axpy4(wi, tu[v], si);
+                    wi.x = wi.x * dec_i1; wi.y = wi.y * dec_i1; wi.z = wi.z * dec_i1; wi.w = wi.w * dec_i1;
+                    sub4(wi, q[g][e][v]);
+                    c[v] = wi;
+                }
+                if (act) {
+#pragma unroll
+                    for (int v = 0; v < V; v++) store_row<K / 4>(S.contrib, (size_t)slot[g][e], pitch, m + v * LANES, K, c[v]);
+                    S.cbias[slot[g][e]] = nbi - bi[g][e];
+                }
             }
         }
     }
@@ -203,40 +242,52 @@ __global__ __launch_bounds__(256) void k_window_users_slots(const DevParams P, c
         if (valid[g]) {
 #pragma unroll
             for (int v = 0; v < V; v++) store_row<K / 4>(P.W, ur[g], pitch, m + v * LANES, K, p[g][v]);
-            P.bias[ur[g]] = bu[g];
+            if (UB) P.bias[ur[g]] = bu[g];
         }
     }
 }
 
+// the configurations the slot kernel is instantiated for: ratings (one unit item entry, linear link, user bias) at k = 64 / 128, rank
+// pairs (two signed item entries, sigmoid rank loss, no user bias: demo/pairwiseRank, BASELINE configs[4]) at k = 64 / 128
 bool window_slots_applies(const DevParams &P, const WindowSchedule &S) {
-    return S.uval == nullptr && P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 && P.user_nonnegative == 0 &&
-           P.u_rng.n == 0 && P.i_rng.n == 0 && (P.k == 64 || P.k == 128);
+    if (S.uval != nullptr || P.reg_method != 0 || P.user_nonnegative != 0 || P.u_rng.n != 0 || P.i_rng.n != 0 || !(P.k == 64 || P.k == 128)) return false;
+    if (S.item1 == nullptr) return S.ival == nullptr && P.active_type == ACT_LINEAR && P.no_user_bias == 0;
+    return P.active_type == ACT_SIGMOID_RANK && P.no_user_bias != 0;
 }
 
 void launch_window_users(const DevParams &P, const WindowSchedule &S, int slots, int groups_per_wave, hipStream_t st) {
     if (S.nusers <= 0) return;
     if (slots && window_slots_applies(P, S)) {
-        auto go = [&](auto lanes, auto gg) {
-            constexpr int LANES = decltype(lanes)::value, G = decltype(gg)::value;
+        auto go = [&](auto lanes, auto gg, auto ni) {
+            constexpr int LANES = decltype(lanes)::value, G = decltype(gg)::value, NI = decltype(ni)::value;
             const long per_wave = (long)G * (64 / LANES);
             const long waves = (S.nusers + per_wave - 1) / per_wave;
-            hipLaunchKernelGGL((k_window_users_slots<LANES, 2, G>), dim3((unsigned)waves), dim3(64), 0, st, P, S);
+            if (NI == 1) hipLaunchKernelGGL((k_window_users_slots<LANES, 2, G, 1, 0, true>), dim3((unsigned)waves), dim3(64), 0, st, P, S);
+            else hipLaunchKernelGGL((k_window_users_slots<LANES, 2, G, 2, 3, false>), dim3((unsigned)waves), dim3(64), 0, st, P, S);
         };
         const int g = groups_per_wave > 0 ? groups_per_wave : 1;
-        if (P.k == 64) {
-            if (g >= 2) go(std::integral_constant<int, 8>(), std::integral_constant<int, 2>());
-            else go(std::integral_constant<int, 8>(), std::integral_constant<int, 1>());
+        using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>;
+        if (S.item1 != nullptr) {
+            if (P.k == 64) go(std::integral_constant<int, 8>(), I1(), I2());
+            else go(std::integral_constant<int, 16>(), I1(), I2());
+        } else if (P.k == 64) {
+            if (g >= 2) go(std::integral_constant<int, 8>(), I2(), I1());
+            else go(std::integral_constant<int, 8>(), I1(), I1());
         } else {
-            if (g >= 2) go(std::integral_constant<int, 16>(), std::integral_constant<int, 2>());
-            else go(std::integral_constant<int, 16>(), std::integral_constant<int, 1>());
+            if (g >= 2) go(std::integral_constant<int, 16>(), I2(), I1());
+            else go(std::integral_constant<int, 16>(), I1(), I1());
         }
         return;
     }
     const int lpi = lanes_per_instance(P.k);
     const long ipw = 64 / lpi;
     const long waves = (S.nusers + ipw - 1) / ipw;
-    if (S.uval == nullptr) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_users<LPI, true>), dim3((unsigned)waves), dim3(64), 0, st, P, S)); }
-    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_users<LPI, false>), dim3((unsigned)waves), dim3(64), 0, st, P, S)); }
+    if (S.item1 != nullptr) {
+        if (S.uval == nullptr) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_users<LPI, true, 2>), dim3((unsigned)waves), dim3(64), 0, st, P, S)); }
+        else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_users<LPI, false, 2>), dim3((unsigned)waves), dim3(64), 0, st, P, S)); }
+    } else if (S.uval == nullptr) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_users<LPI, true, 1>), dim3((unsigned)waves), dim3(64), 0, st, P, S)); }
+    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_users<LPI, false, 1>), dim3((unsigned)waves), dim3(64), 0, st, P, S)); }
 }
 
 // ------------------------------------------------------------------------------------------------- kernel B

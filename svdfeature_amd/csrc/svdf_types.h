@@ -179,12 +179,17 @@ struct WindowSchedule {
     const WinUser *urec;
     long nusers;
     const unsigned *item;
-    const float *label;
+    const float *label;         // nullptr: every label is 1.0f (rank pairs)
     const int *slot;
     const float *uval, *ival;   // nullptr when every feature value is 1.0f
     const int *iptr;            // [num_item + 1]
-    float *contrib;             // [n][pitch] scratch, owned by the trainer
-    float *cbias;               // [n]
+    float *contrib;             // [slots][pitch] scratch, owned by the trainer (one slot per item entry)
+    float *cbias;               // [slots]
+    // rank pairs (user, positive item, negative item): a second item entry per instance; entry 0 is the lower item id like in
+    // the reference's merged row (apex_svd_data.cpp:828-860), ival / ival1 carry the signs.  nullptr for one-item instances.
+    const unsigned *item1;
+    const int *slot1;
+    const float *ival1;
 };
 
 }  // namespace svdf

@@ -303,8 +303,8 @@ class HipShard:
                 out.append([mk(*piece) for piece in sh])
                 continue
             if self.minibatch:
-                assert not isinstance(sh, (BlockArrays, Pairs)), "window-minibatch mode: (user, item, rating) triples only"
-                out.append(self.t.dataset_window_from_triples(*sh))
+                assert not isinstance(sh, BlockArrays), "window-minibatch mode: (user, item, rating) triples and rank pairs"
+                out.append(self.t.dataset_window_from_pairs(sh.user, sh.pos, sh.neg) if isinstance(sh, Pairs) else self.t.dataset_window_from_triples(*sh))
                 continue
             if isinstance(sh, BlockArrays):
                 out.append(self.t.dataset_from_blocks(sh))

@@ -140,3 +140,43 @@ def test_refused_configurations():
     buf = torch.zeros(20 * 9, device="cuda")
     with pytest.raises(sa.SvdfError, match="train this window data set first"):
         t.window_delta_pack(ds, buf.data_ptr())
+
+
+@pytest.mark.parametrize("k,world", [(16, 2), (128, 3), (100, 2)])
+def test_rank_pairs_on_simulated_ranks_equal_the_oracle_simulation(k, world):
+    """BASELINE configs[4] shape through the window-minibatch step: rank pairs (user, positive, negative) = two signed item entries per
+    instance, sigmoid rank loss (glibc's expf restated on the device), no user bias; two contribution slots per pair, summed per item
+    in file order -- N simulated ranks == the oracle simulation, bit for bit."""
+    import torch
+    from svdfeature_amd.multi_gpu import Pairs, shard_pair_windows
+    nu, ni, n, windows, passes = 1200, 300, 40000, 4, 2
+    u, p, q = cases.planted_pairs(n, nu, ni, seed=k)
+    conf = cases.conf_with(cases.PAIR_CONF, num_user=nu, num_item=ni, num_factor=k, learning_rate=0.05, ui_init_sigma=0.1)
+    dev = torch.device("cuda", 0)
+    ranks = []
+    for rk in range(world):
+        ad = HipShard(_trainer(conf, 3), torch, dev, minibatch=True)
+        ad.set_wire_half(False)
+        ranks.append((ad, ad.make_windows(shard_pair_windows(u, p, q, rk, world, windows))))
+    assert ranks[0][1][0].kind == 5
+    for _ in range(passes):
+        for w in range(windows):
+            ds_ = []
+            for ad, wins in ranks:
+                ad.train(wins[w])
+                d = ad.delta_get()
+                ad.stream.synchronize()
+                ds_.append(d.clone())
+            total = ds_[0]
+            for d in ds_[1:]:
+                total = total + d
+            torch.cuda.synchronize()
+            for ad, _ in ranks:
+                ad.delta_set(total)
+    sim = simulate(conf, Pairs(u, p, q), None, None, world, windows, passes, active=3, minibatch=True)
+    for (ad, _), s in zip(ranks, sim):
+        ad.t.synchronize()
+        for name in ("W_item", "i_bias", "W_user"):
+            assert np.array_equal(ad.t.view(name).view(np.uint32), s.t.view(name).view(np.uint32)), name
+    with pytest.raises(sa.SvdfError, match="must differ"):
+        ranks[0][0].t.dataset_window_from_pairs(u[:3], p[:3], p[:3])

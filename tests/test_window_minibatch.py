@@ -154,3 +154,33 @@ def test_rmse_contract_of_the_window_minibatch_step(world):
     ref = cases.rmse(merged_predict(simulate(conf, u, i, r, 1, 1, 5), 1, tu, ti, tr), tr)
     got = cases.rmse(merged_predict(simulate(conf, u, i, r, world, windows, 5, minibatch=True), world, tu, ti, tr), tr)
     assert abs(got - ref) <= 1e-4
+
+
+# ---- rank pairs (BASELINE configs[4]) through the same step: two item entries per instance, sigmoid rank loss, no user bias
+def test_pairs_two_ranks_equal_one_rank_and_keep_the_pairwise_contract():
+    """(i) window-minibatch step on rank pairs: 4 ranks == 1 rank up to the order of fp32 additions; (ii) the pairwise analogue of
+    the RMSE contract (held-out pair accuracy within 3e-3, mean margin within 2 % of the sequential reference after equal passes):
+    400 K pairs, 5 K x 500, k = 16, 3 passes at 10x the demo learning rate, 50 windows = 32 item updates per item per window."""
+    from svdfeature_amd import pairs_as_csr
+    from svdfeature_amd.multi_gpu import Pairs
+    nu, ni, n = 5000, 500, 400_000
+    u, p, q = cases.planted_pairs(n + 40_000, nu, ni, seed=8)
+    tu, tp, tq = u[n:], p[n:], q[n:]
+    u, p, q = u[:n], p[:n], q[:n]
+    conf = cases.conf_with(cases.PAIR_CONF, num_user=nu, num_item=ni, num_factor=16, learning_rate=0.05, ui_init_sigma=0.1)
+
+    def margins(ranks, world):
+        out = np.zeros(len(tu), np.float32)
+        for rk, a in enumerate(ranks):
+            m = (tu % world) == rk
+            out[m] = a.t.predict_batch(pairs_as_csr(tu[m], tp[m], tq[m]))
+        return out
+    windows = int(np.ceil(2.0 * n / ni / 32.0))
+    seq = margins(simulate(conf, Pairs(u, p, q), None, None, 1, 1, 3, active=3), 1)
+    one = simulate(conf, Pairs(u, p, q), None, None, 1, windows, 3, active=3, minibatch=True)
+    four = simulate(conf, Pairs(u, p, q), None, None, 4, windows, 3, active=3, minibatch=True)
+    np.testing.assert_allclose(four[0].t.view("W_item"), one[0].t.view("W_item"), rtol=0, atol=5e-6)
+    par = margins(four, 4)
+    assert cases.pair_accuracy(seq) > 0.85
+    assert abs(cases.pair_accuracy(par) - cases.pair_accuracy(seq)) <= 3e-3
+    assert abs(float(par.mean()) - float(seq.mean())) <= 0.02 * abs(float(seq.mean()))
