@@ -96,7 +96,8 @@ class SVDRankerAMD : public ISVDRanker {
     std::vector<int> buf;
     void take(std::vector<int> &result, int64_t n) {
         if (n < 0) apex_utils::error(svdf_last_error());
-        for (int64_t i = 0; i < n && i < (int64_t)buf.size(); i++) result.push_back(buf[(size_t)i]);
+        if (n > (int64_t)buf.size()) apex_utils::error("svdfeature_amd ranker: more results than the result buffer holds");   // never a silent truncation
+        for (int64_t i = 0; i < n; i++) result.push_back(buf[(size_t)i]);
     }
   public:
     explicit SVDRankerAMD(const SVDTypeParam &mtype) : buf(1024) {

@@ -566,10 +566,18 @@ class Ranker:
         self.cap = max(16, int(num_item_set) + 16)
         self._ok(self.lib.svdf_ranker_init(self.h, int(num_item_set)))
 
+    @staticmethod
+    def _taken(out, n, cap):
+        """the native calls return the number of results of the line(s) and write at most `cap` of them: more than the buffer
+        holds is an error here, never a silent truncation"""
+        if n > cap:
+            raise SvdfError("ranker: the call produced %d results, the result buffer holds %d (several PROCESS lines in one call?)" % (n, cap))
+        return out[:n].copy()
+
     def process(self, label, ng, nu, ni, index, value):
         out = np.zeros(self.cap, np.int32)
         n = self._ok(self.lib.svdf_ranker_process_csr(self.h, float(label), ng, nu, ni, _pad(index, np.uint32), _pad(value, np.float32), out, self.cap))
-        return out[:n].copy()
+        return self._taken(out, n, self.cap)
 
     def process_rows(self, d):
         """every row of a CSRData through process() in ONE native call (svdf_ranker_process_rows: sections pipelined on the
@@ -583,7 +591,7 @@ class Ranker:
         out = np.zeros(cap, np.int32)
         n = self._ok(self.lib.svdf_ranker_process_rows(self.h, d.num_row, _pad(d.row_label, np.float32), _pad(d.row_ptr, np.int32),
                                                        _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32), out, cap))
-        return out[:n].copy()
+        return self._taken(out, n, cap)
 
     def process_block(self, b):
         d = b.data
@@ -593,7 +601,7 @@ class Ranker:
                                                         _pad(b.value_ufeedback, np.float32), d.num_row, _pad(d.row_label, np.float32),
                                                         _pad(d.row_ptr, np.int32), _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32),
                                                         out, cap))
-        return out[:n].copy()
+        return self._taken(out, n, cap)
 
     def counter(self, what):
         return int(self.lib.svdf_ranker_counter(self.h, what))

@@ -514,7 +514,7 @@ void Engine::upload_model() {
     dW_.upload(hW_.data(), hW_.size(), stream_);
     dbias_.upload(hbias_.data(), hbias_.size(), stream_);
     upload_globals(wanted_g_stride());
-    std::vector<float> zero(imfb() ? (size_t)4 + IMFB_DEPTH * ((size_t)2 * pitch_ + 4) : (size_t)2 * pitch_ + 4, 0.0f);
+    std::vector<float> zero(imfb() ? (size_t)4 + IMFB_DEPTH_MAX * ((size_t)2 * pitch_ + 4) : (size_t)2 * pitch_ + 4, 0.0f);
     dstate_.upload(zero.data(), zero.size(), stream_);
     HIPCHECK(hipStreamSynchronize(stream_));
     device_model_ = true;
@@ -607,6 +607,7 @@ const DevParams &Engine::params() {
     P.fewrow_i16 = fewrow_i16_;
     P.xcd_remap = xcd_remap_;
     P.imfb_disable = imfb_disable_;
+    P.imfb_deep = imfb_deep_ ? 1 : 0;
     P.fewrow_fast = fewrow_fast_ ? 1 : 0;
     P.hot_reduce = hot_reduce_; P.relax_global = relax_global_ ? 1 : 0; P.relax_feedback = relax_feedback_ ? 1 : 0;
     if (device_model_ && g_stride_ != wanted_g_stride() && mp_.num_global > 0) {   // relax_global switched after the upload: re-lay out
@@ -796,7 +797,10 @@ void Engine::update_block_imfb(int nfb, int tag, const unsigned *ifb, const floa
                                const int *row_ptr, const unsigned *feat_index, const float *feat_value) {
     check(tag == TAG_DEFAULT || tag == TAG_START || tag == TAG_MIDDLE || tag == TAG_END, "unknown extend_tag");
     const bool starts = (tag == TAG_DEFAULT || tag == TAG_START), ends = (tag == TAG_DEFAULT || tag == TAG_END);
-    if (starts) check(imfb_depth_ < IMFB_DEPTH, "svdfeature_amd: more than 4 nested implicit-feedback levels are not supported");
+    if (starts) {
+        check(imfb_depth_ < IMFB_DEPTH_MAX, "svdfeature_amd: more than 16 nested implicit-feedback levels (the reference's stack is an unbounded std::vector, apex_multi_imfb.h:41-58; this engine holds 16)");
+        if (imfb_depth_ >= IMFB_DEPTH && !imfb_deep_) { imfb_deep_ = true; params_dirty_ = true; }
+    }
     if (ends && !starts) check(imfb_depth_ > 0, "start tag,end tag error in implicit feedback");   // :183
     const int h = (int)staged_.num_row();
     stage_rows(num_row, row_label, row_ptr, feat_index, feat_value);
@@ -1549,7 +1553,10 @@ void Engine::predict_block(int nfb, int tag, const unsigned *ifb, const float *v
     const DevParams &P = params();
     if (imfb()) {   // SVDPPMultiIMFB::predict (apex_multi_imfb.h:193-207): push on DEFAULT / START, score, pop (no scatter) on DEFAULT / END
         const bool st = (tag == TAG_DEFAULT || tag == TAG_START), en = (tag == TAG_DEFAULT || tag == TAG_END);
-        if (st) check(imfb_depth_ < IMFB_DEPTH, "svdfeature_amd: more than 4 nested implicit-feedback levels are not supported");
+        if (st) {
+            check(imfb_depth_ < IMFB_DEPTH_MAX, "svdfeature_amd: more than 16 nested implicit-feedback levels (the reference's stack is an unbounded std::vector, apex_multi_imfb.h:41-58; this engine holds 16)");
+            if (imfb_depth_ >= IMFB_DEPTH && !imfb_deep_) { imfb_deep_ = true; params_dirty_ = true; }
+        }
         if (en && !st) check(imfb_depth_ > 0, "start tag,end tag error in implicit feedback");
         HostCSR rows;
         stage_rows_into(rows, num_row, row_label, row_ptr, feat_index, feat_value);

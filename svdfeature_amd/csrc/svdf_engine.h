@@ -362,6 +362,7 @@ class Engine {
     int imfb_depth_ = 0;
     bool iunit_open_ = false;
     unsigned imfb_disable_ = 0;
+    bool imfb_deep_ = false;   // the data nested deeper than IMFB_DEPTH levels at some point: launches use the IMFB_DEPTH_MAX build of k_imfb
     void update_block_imfb(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label,
                            const int *row_ptr, const unsigned *feat_index, const float *feat_value);
     void schedule_iunits(int base, Schedule &sched);

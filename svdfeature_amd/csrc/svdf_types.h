@@ -86,6 +86,7 @@ struct DevParams {
     int hot_reduce;           // knob: workgroup pre-reduction of a relaxed shared user row (k_fused HOTU)
     int xcd_remap;            // 1: consecutive tiles of a batch go to the same XCD (blockIdx%8), see k_basicmf
     unsigned imfb_disable;    // extend_type 2: bit l = ufeedback_disable_level l (apex_multi_imfb.h:58-67)
+    int imfb_deep;            // extend_type 2: the data nested deeper than IMFB_DEPTH levels at some point: k_imfb<..., IMFB_DEPTH_MAX>
     int fewrow_fast;          // knob: 1 = few-row data sets in the usual configuration run k_fewrow_fast instead of k_fused
     int store_mode;           // row-store cache policy of k_basicmf: 0 plain, 1 nontemporal, 2 sc1 write-through
     int fewrow_i16;           // k = 128 few-row kernel: sixteen lanes per row, 4 instances per wave (k_fewrow_i16)
@@ -166,7 +167,8 @@ struct DevBlk {
     int row_begin, row_end;
     int tag;
 };
-#define IMFB_DEPTH 4   // nested implicit-feedback levels held in registers; deeper data is refused
+#define IMFB_DEPTH 4        // nested implicit-feedback levels of the usual build of k_imfb (all in registers)
+#define IMFB_DEPTH_MAX 16   // ... of the build the engine switches to for deeper data; beyond that the data is refused
 enum { UNIT_START = 1, UNIT_END = 2, UNIT_SAVE = 4, UNIT_LOAD = 8,
        UNIT_SIMPLE = 16 };   // host-verified: rows are (0,1,1) with one user id, distinct feedback ids (repeated items: row_fresh)
 

@@ -66,6 +66,53 @@ def test_multi_level_feedback_every_path_matches_the_oracle(k, window):
         np.testing.assert_array_equal(r.view(name).view(np.uint32), o.view(name).view(np.uint32))
 
 
+def test_nesting_deeper_than_four_levels_takes_the_deep_kernel_build():
+    """spans nested up to 11 deep (the usual build of k_imfb holds 4 levels in registers; deeper data switches the engine to the
+    16-level build): parameters and predictions byte-identical to the oracle, per-block calls with a small staging window that cuts
+    units with open levels, and the same pass as a resident data set"""
+    nu, ni = 60, 40
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=12, num_ufeedback=ni, wd_ufeedback=0.004, ufeedback_init_sigma=0.01)
+    rng = np.random.default_rng(31)
+    e0 = np.zeros(0, np.uint32), np.zeros(0, np.float32)
+
+    def fb():
+        n = int(rng.integers(0, 5))
+        return np.sort(rng.choice(ni, size=n, replace=False)).astype(np.uint32), np.full(n, 1.0 / np.sqrt(max(n, 1)), np.float32)
+
+    def rows(uid):
+        rs = [(float(rng.integers(1, 6)), [], [(int(uid), 1.0)], [(int(rng.integers(0, ni)), 1.0)]) for _ in range(int(rng.integers(0, 4)))]
+        return sa.CSRData.from_rows(rs) if rs else sa.CSRData.empty()
+    blocks, peak = [], 0
+    for span in range(12):
+        uid, d = int(rng.integers(0, nu)), int(rng.integers(3, 12))
+        peak = max(peak, d + 1)
+        lists = [fb() for _ in range(d)]
+        for l in range(d):                                           # d nested STARTs ...
+            blocks.append(sa.PlusBlock(lists[l][0], lists[l][1], rows(uid), 1))
+            if rng.integers(0, 2):
+                blocks.append(sa.PlusBlock(e0[0], e0[1], rows(uid), 3))
+        f = fb()
+        blocks.append(sa.PlusBlock(f[0], f[1], rows(uid), 0))       # ... a DEFAULT block on top (push + pop at once) ...
+        for l in reversed(range(d)):                                 # ... and the ENDs, each scattering through its own list
+            blocks.append(sa.PlusBlock(lists[l][0], lists[l][1], rows(uid), 2))
+    assert peak == 12
+    t, r, o = _ready(hip, conf, 2), _ready(hip, conf, 2), _ready(port, conf, 2)
+    t.set_knob("stage_window", 7)
+    ds = r.dataset_from_blocks(blocks)
+    for _ in range(2):
+        for b in blocks:
+            t.update_block(b)
+            o.update_block(b)
+        t.finish_round()
+        r.train_dataset(ds)
+    for name in VIEWS:
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32))
+        np.testing.assert_array_equal(r.view(name).view(np.uint32), o.view(name).view(np.uint32))
+    po = np.concatenate([o.predict_block(b) for b in blocks])
+    pt = np.concatenate([t.predict_block(b) for b in blocks])
+    np.testing.assert_array_equal(po.view(np.uint32), pt.view(np.uint32))
+
+
 def test_multi_level_feedback_errors_and_limits():
     nu, ni = 30, 20
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=8, num_ufeedback=ni)
@@ -74,9 +121,9 @@ def test_multi_level_feedback_errors_and_limits():
     with pytest.raises(sa.SvdfError, match="start tag,end tag error in implicit feedback"):
         t.update_block(e)   # END without START (apex_multi_imfb.h:183)
     s = sa.PlusBlock(np.zeros(0, np.uint32), np.zeros(0, np.float32), sa.CSRData.empty(), 1)
-    for _ in range(4):
+    for _ in range(16):
         t.update_block(s)
-    with pytest.raises(sa.SvdfError, match="more than 4 nested"):
+    with pytest.raises(sa.SvdfError, match="more than 16 nested"):   # the reference's stack is an unbounded std::vector (apex_multi_imfb.h:41-58)
         t.update_block(s)
     with pytest.raises(sa.SvdfError, match="extend_type 30 is not supported"):
         sa.Trainer(0, 0, 30)
