@@ -9,7 +9,7 @@ timeout 900 python -m pytest tests/test_gpu_window.py -x -q > $OUT/test_window.l
 tail -3 $OUT/test_window.log
 timeout 1500 bash tools/shard_scale_probe.sh > $OUT/shard_scale_probe.txt 2>&1
 cat $OUT/shard_scale_probe.txt
-show='import sys,json; d=json.loads(sys.stdin.readline()); p=d.get("phase_ms") or {}; print(sys.argv[1], "ms/pass %.2f" % d["ms_per_step"], {k: round(v,3) for k,v in p.items() if k!="what"})'
+show='import sys,json; d=json.loads([l for l in sys.stdin if l.startswith(chr(123))][-1]); p=d.get("phase_ms") or {}; print(sys.argv[1], "ms/pass %.2f" % d["ms_per_step"], {k: round(v,3) for k,v in p.items() if k!="what"})'
 for kn in "window_groups=2" "window_slots=0"; do
   python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sequential-reference --force-exchange --exchange minibatch --windows 32 --ratings 12500000 --users 125000 --knob $kn 2>/dev/null | python -c "$show" "rank-of-8 $kn" | tee -a $OUT/knobs.txt
   python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-sequential-reference --force-exchange --exchange minibatch --windows 32 --ratings 50000000 --users 500000 --knob $kn 2>/dev/null | python -c "$show" "rank-of-2 $kn" | tee -a $OUT/knobs.txt
