@@ -358,6 +358,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
     # round-2 scheme (exact conflict-free levels per rank, item side stale across ranks only)
     exchanging = world > 1 or a.force_exchange
     minibatch = exchanging and name in ("basicmf", "pairwise") and a.exchange != "levels"
+    stratified = exchanging and name == "basicmf" and a.exchange == "stratified"
     auto_parts = 1 if world <= 2 else 2
     parts = (a.exchange_parts or auto_parts) if (name == "basicmf" and exchanging) else 1
     adaptor = HipShard(tr, torch, torch.device("cuda", local_rank), parts=parts, minibatch=minibatch)
@@ -388,7 +389,13 @@ def run_workload(name, a, env, steps, warmup, main_line):
         shards = [[per_part[q][w] for q in range(parts)] for w in range(nwin)]
     elif nwin > 1 and a.defer_tails > 0 and name in ("basicmf", "pairwise") and not minibatch:
         shards = defer_tails(shards, a.users, a.items, a.defer_tails)
-    if name == "neighbourhood":
+    if stratified:
+        from svdfeature_amd.multi_gpu import StratifiedTrainer, stratified_plan
+        plan = [[adaptor.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, rank, world, a.chunks, a.items, 32.0)]
+        wins = [w for chunk in plan for sub in chunk for w in sub]
+        nwin = len(wins)
+        parts = 1
+    elif name == "neighbourhood":
         wins = [tr.dataset_from_csr(d_all)]
     else:
         wins = adaptor.make_windows(shards)
@@ -398,7 +405,11 @@ def run_workload(name, a, env, steps, warmup, main_line):
     alg_bytes = sum(w.algorithmic_bytes for w in flat)
     my_n = sum(w.num_row for w in flat)
     log("%s: scheduled %d into %d conflict-free batches (largest %d) in %.1fs" % (name, my_n, n_batches, max(w.max_batch for w in flat), sched_s))
-    st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange, half_delta=(a.delta_dtype == "fp16"), parts=parts)
+    if stratified:
+        adaptor.set_wire_half(False)
+        st = StratifiedTrainer(adaptor, plan, world, rank, dist if world > 1 else None)
+    else:
+        st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange, half_delta=(a.delta_dtype == "fp16"), parts=parts)
 
     def sync_all():
         tr.synchronize()
@@ -446,6 +457,8 @@ def run_workload(name, a, env, steps, warmup, main_line):
         for phase, e in marks:
             phase_ms[phase] += ev.elapsed_ms(prev, e)
             prev = e
+        if stratified:
+            phase_ms["unpack"] = 0.0
         phase_ms["what"] = ("stream time of ONE extra pass (not in the timed region), HIP events on the trainer's stream after each phase was "
                             "enqueued; compute = %s, pack = %s, allreduce = the collective (incl. waiting for the slowest rank), unpack = %s" % (
                                 ("k_window_users (user walks)", "k_window_items (per-item sums into the wire buffer)", "k_delta_addto") if minibatch else
@@ -453,6 +466,10 @@ def run_workload(name, a, env, steps, warmup, main_line):
         steps_done = warmup + steps + 1
     else:
         steps_done = warmup + steps
+
+    if stratified and world > 1:
+        st.gather_blocks()   # between passes a rank holds one valid item block: complete the item side before scoring
+        sync_all()
 
     # ---- held-out quality after the run; with N ranks every rank scores the test rows of the users it owns
     def reduce_sum(vals):
@@ -549,14 +566,21 @@ def run_workload(name, a, env, steps, warmup, main_line):
                          "svdpp": "implicitFeedback (SVD++) %d users x %d ratings, feedback set = own items, k=%d fp32 (BASELINE configs[3])" % (a.svdpp_users, a.svdpp_per_user, factor),
                          "neighbourhood": "neighborhoodModel shape: %d ratings + 4 of %d global ids each, k=%d fp32 (BASELINE configs[3])" % (n, a.globals, factor)}[name],
             "order": "uniform random (file order preserved: result == sequential SGD)" if not exchanging else
+                     ("stratified: %d file-order chunks x %d sub-epochs per pass, rank r trains (user block r) x (item block (r + s) %% %d) with the "
+                      "window-minibatch step, the item block is handed to rank r - 1 afterwards (fp32, no all-reduce); %d window steps per rank and pass"
+                      % (a.chunks, world, world, nwin)) if stratified else
                      "user-sharded, %s, item-delta all-reduce (%s on the wire) every 1/%d pass%s" % (
                          "window-minibatch step (user side exact, item side applied at the window's end)" if minibatch else "exact conflict-free levels per rank",
                          a.delta_dtype, nwin, (", in %d item-range pieces overlapped with training" % parts) if parts > 1 else ""),
             "exchange": None if not exchanging else {
-                "path": ("torch.distributed %s all_reduce (RCCL over xGMI)" % dist.get_backend()) if (dist is not None and world > 1) else
+                "path": ("torch.distributed %s: ring hand-over of item blocks (batch_isend_irecv, rank r -> r - 1) after every sub-epoch, broadcasts of the "
+                         "blocks before scoring; no all-reduce" % dist.get_backend()) if (stratified and dist is not None and world > 1) else
+                        ("torch.distributed %s all_reduce (RCCL over xGMI)" % dist.get_backend()) if (dist is not None and world > 1) else
                         ("torch.distributed %s all_reduce with one rank (identity)" % dist.get_backend() if dist is not None else "none (one rank)"),
-                "step": "minibatch" if minibatch else "levels", "windows": nwin, "parts": parts,
-                "bytes_per_window": int(tr.item_delta_count() * (2 if a.delta_dtype == "fp16" else 4)),
+                "step": "stratified" if stratified else ("minibatch" if minibatch else "levels"), "windows": nwin, "parts": parts,
+                "handoffs_per_pass": a.chunks * world if (stratified and world > 1) else 0,
+                "bytes_per_window": int(tr.item_delta_count() * (2 if a.delta_dtype == "fp16" else 4)) if not stratified else
+                                    int(tr.item_delta_count() * 4 // max(world, 1)),
                 "updates_per_item_per_window": per_item / nwin},
             "phase_ms": phase_ms,
             "conflict_free_batches_per_pass": n_batches, "schedule_build_s": round(sched_s, 2),
@@ -715,10 +739,14 @@ def main():
                          "(1 = one synchronous all-reduce per window; 0 = auto: 1 at 2 ranks, 2 beyond -- a piece keeps the window's item-chain "
                          "depth, so pieces double a rank's launches: 12.9 -> 32.7 ms per pass at 2 ranks, 7.9 -> 10.6 at 4, 5.3 -> 7.7 at 8 "
                          "(tools/shard_parts_probe.sh), which only pays once the exchange it hides is the larger part)")
-    ap.add_argument("--exchange", choices=["auto", "minibatch", "levels"], default="auto",
+    ap.add_argument("--chunks", type=int, default=4,
+                    help="--exchange stratified: file-order chunks per pass (a chunk = N sub-epochs; more chunks keep the training order closer to "
+                         "the file order: tools/stratified_calibration.py)")
+    ap.add_argument("--exchange", choices=["auto", "minibatch", "levels", "stratified"], default="auto",
                     help="N>1 (or --force-exchange), ratings: how a window is trained.  minibatch (= auto): the window-minibatch step, user side "
                          "exact, item side one minibatch step per window, three launches per window (svdf_k_window.hip); levels: the round-2 scheme, "
-                         "exact conflict-free levels per rank with the item side stale across ranks only")
+                         "exact conflict-free levels per rank with the item side stale across ranks only; stratified: no all-reduce -- item blocks are "
+                         "owned exclusively and handed from rank to rank (DSGD-style strata, window-minibatch step inside a stratum; ratings only)")
     ap.add_argument("--no-sequential-reference", action="store_true",
                     help="N>1: skip the exact single-GPU run of the same passes on rank 0 that rmse_sequential_reference comes from")
     ap.add_argument("--delta-dtype", choices=["fp16", "fp32"], default="fp16",

@@ -201,6 +201,14 @@ svdf_dataset *svdf_dataset_window_from_triples(svdf_trainer *t, long n, const un
 svdf_dataset *svdf_dataset_window_from_pairs(svdf_trainer *t, long n, const unsigned *user, const unsigned *pos_item, const unsigned *neg_item);
 int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *device_dst, int half, int64_t *count);
 int svdf_window_delta_apply(svdf_trainer *t, const void *device_src, int half);
+/* STRATIFIED schedule: item block b = the partition chosen with svdf_item_delta_select(t, b, N).  While a rank
+ * trains a stratum (its users x one item block) it owns that block exclusively, so the window's per-item sums are added to the model in
+ * place (no wire buffer, no sum over ranks); afterwards the block -- its W_item rows and i_bias words (global biases travel with block 0),
+ * fp32, the packed layout of svdf_item_delta_pack -- is handed to the next rank: _get copies it out, _set copies a received block in.
+ * device_dst = NULL only returns *count (floats). */
+int svdf_window_delta_apply_local(svdf_trainer *t, svdf_dataset *ds);
+int svdf_item_block_get(svdf_trainer *t, float *device_dst, int64_t *count);
+int svdf_item_block_set(svdf_trainer *t, const float *device_src);
 
 /* test probe of the device rank sampler's sort (svdf_stdsort.h: libstdc++'s std::sort restated for host and device, because
  * PairwiseRankGenerator::sample_cmp, apex_svd_data.cpp:920-944, picks rows by POSITION after an unstable std::sort): ids 0..n-1

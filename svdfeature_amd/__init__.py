@@ -86,6 +86,9 @@ def load_library():
     lib.svdf_dataset_window_from_pairs.argtypes = [P, C.c_long, _u32p, _u32p, _u32p]
     lib.svdf_window_delta_pack.argtypes = [P, P, P, C.c_int, C.POINTER(C.c_int64)]
     lib.svdf_window_delta_apply.argtypes = [P, P, C.c_int]
+    lib.svdf_window_delta_apply_local.argtypes = [P, P]
+    lib.svdf_item_block_get.argtypes = [P, P, C.POINTER(C.c_int64)]
+    lib.svdf_item_block_set.argtypes = [P, P]
     lib.svdf_set_view.restype = C.c_int64
     lib.svdf_set_view.argtypes = [P, C.c_int, _f32p, C.c_int64]
     lib.svdf_dataset_from_buffer_file.restype = P
@@ -377,6 +380,23 @@ class Trainer:
     def window_delta_apply(self, device_ptr, half=False):
         """replicated ranges += the (all-reduced) wire buffer"""
         self._ok(self.lib.svdf_window_delta_apply(self.h, C.c_void_p(device_ptr), 1 if half else 0))
+
+    def window_delta_apply_local(self, ds):
+        """stratified schedule: the active item block (item_delta_select) += the trained window's per-item sums, in place"""
+        self._ok(self.lib.svdf_window_delta_apply_local(self.h, ds.h))
+
+    def item_block_count(self):
+        n = C.c_int64()
+        self._ok(self.lib.svdf_item_block_get(self.h, None, C.byref(n)))
+        return n.value
+
+    def item_block_get(self, device_ptr):
+        n = C.c_int64()
+        self._ok(self.lib.svdf_item_block_get(self.h, C.c_void_p(device_ptr), C.byref(n)))
+        return n.value
+
+    def item_block_set(self, device_ptr):
+        self._ok(self.lib.svdf_item_block_set(self.h, C.c_void_p(device_ptr)))
 
     def dataset_from_pairs(self, user, pos, neg):
         """Rank pairs (user, positive item, negative item), see svdf_dataset_from_pairs."""

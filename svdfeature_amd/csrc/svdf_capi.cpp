@@ -120,6 +120,9 @@ svdf_dataset *svdf_dataset_window_from_pairs(svdf_trainer *t, long n, const unsi
 int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *dst, int half, int64_t *count) {
     SVDF_GUARD(-1, { t->e->window_delta_pack(ds ? ds->d : nullptr, dst, half, count); return 0; })
 }
+int svdf_window_delta_apply_local(svdf_trainer *t, svdf_dataset *ds) { SVDF_GUARD(-1, { t->e->window_delta_apply_local(ds ? ds->d : nullptr); return 0; }) }
+int svdf_item_block_get(svdf_trainer *t, float *dst, int64_t *count) { SVDF_GUARD(-1, { t->e->item_block_copy(dst, 0, count); return 0; }) }
+int svdf_item_block_set(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->item_block_copy(const_cast<float *>(src), 1, nullptr); return 0; }) }
 int svdf_window_delta_apply(svdf_trainer *t, const void *src, int half) { SVDF_GUARD(-1, { t->e->window_delta_apply(src, half); return 0; }) }
 int svdf_debug_sort_labels(long n, const float *label, int *restated, int *library) {
     SVDF_GUARD(-1, {

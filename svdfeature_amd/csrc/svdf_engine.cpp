@@ -2064,6 +2064,30 @@ void Engine::window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t 
     HIPCHECK(hipGetLastError());
     n_launches_++;
 }
+// Stratified schedule: the rank owns the active item block (svdf_item_delta_select) exclusively while it trains
+// a stratum, so the window's per-item sums go straight into the model -- no wire buffer, no sum over ranks.
+void Engine::window_delta_apply_local(Dataset *ds) {
+    check(ds && ds->owner == this && ds->kind == 5, "window_delta_apply_local: not a window data set of this trainer");
+    check(!relaxed() && g_stride_ == 1 && user_off_ == 0, "window_delta_apply_local: random-order trainers without relaxed ids only");
+    need_device("window_delta");
+    check(window_trained_ == ds, "window_delta_apply_local: train this window data set first (svdf_train_dataset)");
+    const long ni = mp_.num_item;
+    const long lo = ni * delta_part_ / delta_nparts_, hi = ni * (delta_part_ + 1) / delta_nparts_;
+    launch_window_items_local(window_view(ds), pitch_, mp_.num_factor, lo, hi, dW_.p + (size_t)item_off_ * pitch_, dbias_.p + item_off_, stream_);
+    HIPCHECK(hipGetLastError());
+    n_launches_++;
+}
+void Engine::item_block_copy(float *device_buf, int set, int64_t *count) {
+    check(trainer_ready_, "item_block: init_trainer has not been called");
+    const DeltaRanges R = delta_ranges();
+    if (count) *count = R.off[R.n];
+    if (!device_buf) return;
+    need_device("item_block");
+    flush();
+    launch_ranges_copy(R, device_buf, set, stream_);
+    HIPCHECK(hipGetLastError());
+    n_launches_++;
+}
 void Engine::window_delta_apply(const void *device_src, int half) {
     need_device("window_delta");
     flush();

@@ -283,6 +283,8 @@ class Engine {
     Dataset *dataset_window_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg);
     void window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t *count);   // per-item sum of the window's contributions -> wire buffer
     void window_delta_apply(const void *device_src, int half);                           // replicated ranges += wire buffer
+    void window_delta_apply_local(Dataset *ds);                 // stratified schedule: the active item block += the window's per-item sums, in place
+    void item_block_copy(float *device_buf, int set, int64_t *count);   // the active partition of the replicated ranges <-> a packed fp32 buffer
     void train_dataset(Dataset *ds);
     void predict_dataset(Dataset *ds, float *out);
     void eval_dataset(Dataset *ds, float scale, double *sum_sq, int64_t *count);

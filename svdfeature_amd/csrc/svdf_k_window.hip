@@ -290,13 +290,23 @@ void launch_window_users(const DevParams &P, const WindowSchedule &S, int slots,
     else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_users<LPI, false, 1>), dim3((unsigned)waves), dim3(64), 0, st, P, S)); }
 }
 
+// position j of the packed layout -> the float it stands for
+__device__ __forceinline__ float *addto_slot(const DeltaRanges &R, long j) {
+    int r = 0;
+#pragma unroll
+    for (int q = 1; q < SVDF_MAX_DELTA_RANGES; q++) r += (q < R.n && j >= R.off[q]) ? 1 : 0;
+    return R.base[r] + (j - R.off[r]);
+}
+
 // ------------------------------------------------------------------------------------------------- kernel B
 // Item i's contributions sit in slots [iptr[i], iptr[i + 1]), in file order.  One lane group per item sums them in that order
 // (acc = 0 + c_1 + c_2 ..., four rows requested ahead) and writes the item's row and bias of the wire buffer:
 // dst = [ (hi - lo) rows of `pitch` | (hi - lo) item biases | nglobal zeros ] for the item range [lo, hi) of the active
 // exchange partition (svdf_item_delta_select) -- the packed layout of k_delta_pack.
-template <int LPI, bool HALF>
-__global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, int pitch, int k, long lo, long hi, long nglobal, void *dst) {
+// LOCAL (stratified schedule): the rank owns the item block exclusively, so there is no sum over ranks and the
+// per-item sum is added to the model in place: dst = W_item's first row (row i at dst + i * pitch), dbias = i_bias; fp32, no wire buffer.
+template <int LPI, bool HALF, bool LOCAL>
+__global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, int pitch, int k, long lo, long hi, long nglobal, void *dst, float *dbias) {
     constexpr int IPW = 64 / LPI;
     const int lane = threadIdx.x & 63;
     const int L = lane & (LPI - 1);
@@ -322,6 +332,17 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
 #pragma unroll
             for (int q = 0; q < 8; q++) { add_rows(acc, c[q]); accb = accb + cb[q]; }
         }
+        if (LOCAL) {
+            if (b == e) continue;   // nobody rated the item in this window
+            if (!(LPI * 4 > k && L * 4 >= k)) {
+                float4 *w = reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + (size_t)i * pitch + (size_t)L * 4);
+                float4 c = *w;
+                c.x = c.x + acc.x; c.y = c.y + acc.y; c.z = c.z + acc.z; c.w = c.w + acc.w;
+                *w = c;
+            }
+            if (L == 0) dbias[i] = dbias[i] + accb;
+            continue;
+        }
         if (!(LPI * 4 > k && L * 4 >= k)) {
             const size_t pos = (size_t)it * pitch + (size_t)L * 4;
             if (HALF) {
@@ -338,6 +359,7 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
             else reinterpret_cast<float *>(dst)[pos] = accb;
         }
     }
+    if (LOCAL) return;
     // the global biases' part of the wire buffer: a window data set carries no global entry
     const long g0 = nitem * (long)(pitch + 1);
     for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < nglobal; j += (long)gridDim.x * blockDim.x) {
@@ -352,18 +374,40 @@ void launch_window_items(const WindowSchedule &S, int pitch, int k, long lo, lon
     long waves = (std::max<long>(hi - lo, 1) + ipw - 1) / ipw;
     long grid = (waves + 3) / 4;
     if (grid > 16384) grid = 16384;
-    if (half) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, true>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst)); }
-    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst)); }
+    if (half) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, true, false>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst, (float *)nullptr)); }
+    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, false>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst, (float *)nullptr)); }
+}
+// the same sums added in place to the rows / biases of items [lo, hi): W_item + i * pitch, i_bias + i
+void launch_window_items_local(const WindowSchedule &S, int pitch, int k, long lo, long hi, float *w_item, float *i_bias, hipStream_t st) {
+    if (hi <= lo) return;
+    const int lpi = lanes_per_instance(k);
+    const long ipw = 64 / lpi;
+    long waves = (hi - lo + ipw - 1) / ipw;
+    long grid = (waves + 3) / 4;
+    if (grid > 16384) grid = 16384;
+    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, true>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, 0L, (void *)w_item, i_bias));
+}
+// the replicated ranges of the active partition as one packed fp32 buffer and back (the item block a rank hands to the next one)
+template <bool SET>
+__global__ __launch_bounds__(256) void k_ranges_copy(const DeltaRanges R, float *buf, long total) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < total; j += stride) {
+        float *cur = addto_slot(R, j);
+        if (SET) *cur = buf[j];
+        else buf[j] = *cur;
+    }
+}
+void launch_ranges_copy(const DeltaRanges &R, float *buf, int set, hipStream_t st) {
+    const long total = R.off[R.n];
+    if (total <= 0) return;
+    long grid = (total + 255) / 256;
+    if (grid > 8192) grid = 8192;
+    if (set) hipLaunchKernelGGL(k_ranges_copy<true>, dim3((int)grid), dim3(256), 0, st, R, buf, total);
+    else hipLaunchKernelGGL(k_ranges_copy<false>, dim3((int)grid), dim3(256), 0, st, R, buf, total);
 }
 
 // ------------------------------------------------------------------------------------------------- kernel C
 // replicated ranges += the all-reduced window delta (packed layout of k_delta_pack)
-__device__ __forceinline__ float *addto_slot(const DeltaRanges &R, long j) {
-    int r = 0;
-#pragma unroll
-    for (int q = 1; q < SVDF_MAX_DELTA_RANGES; q++) r += (q < R.n && j >= R.off[q]) ? 1 : 0;
-    return R.base[r] + (j - R.off[r]);
-}
 // The first range (item rows: a multiple of four floats, 16-byte aligned in the model and in the wire buffer) goes four floats per
 // lane; what follows (item biases, global biases) one float per lane.
 template <bool HALF>

@@ -68,19 +68,57 @@ class OracleShard:
     def _shared(self):
         return np.concatenate([v.ravel() for _, v in self._views()])
 
+    # ---- stratified schedule (multi_gpu.StratifiedTrainer)
+    def _write(self, new):
+        off = 0
+        for name, v in self._views():
+            self.t.set_view(name, new[off:off + v.size])
+            off += v.size
+
+    def apply_local(self, d, block, nblocks):
+        dW, db, dg = self.mb_delta
+        delta = np.concatenate([dW.ravel(), db, dg])
+        pos = self._piece(block, nblocks)
+        cur = self._shared()
+        cur[pos] = cur[pos] + delta[pos]
+        self._write(cur)
+
+    def block_get(self, block, nblocks):
+        v = np.ascontiguousarray(self._shared()[self._piece(block, nblocks)])
+        return self.torch.from_numpy(v) if self.torch is not None else v
+
+    def block_like(self, block, nblocks):
+        v = np.zeros(len(self._piece(block, nblocks)), np.float32)
+        return self.torch.from_numpy(v) if self.torch is not None else v
+
+    def block_set(self, block, nblocks, tensor):
+        v = tensor.numpy() if hasattr(tensor, "numpy") else tensor
+        cur = self._shared()
+        cur[self._piece(block, nblocks)] = v
+        self._write(cur)
+
+    def handoff(self, dist, out, dst, inc, src):
+        reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, out, dst), dist.P2POp(dist.irecv, inc, src)])
+        for q in reqs:
+            q.wait()
+
+    def broadcast(self, dist, buf, src):
+        dist.broadcast(buf, src)
+
     def delta_begin(self):
         if self.minibatch:
             return   # the replicated side does not move inside a window: it is its own snapshot
         self.snap = self._shared()
 
-    def _piece(self, part):
+    def _piece(self, part, parts=None):
         """flat positions of item-range piece `part` in the packed layout (svdf_item_delta_select): the item rows of W_item
         and i_bias in [num_item*part/parts, num_item*(part+1)/parts); everything else travels with piece 0"""
+        parts = parts or self.parts
         pos, off = [], 0
         for name, v in self._views():
             if name in ("W_item", "i_bias"):
                 ni = v.shape[0]
-                lo, hi = ni * part // self.parts, ni * (part + 1) // self.parts
+                lo, hi = ni * part // parts, ni * (part + 1) // parts
                 width = v.size // ni
                 pos.append(np.arange(off + lo * width, off + hi * width))
             elif part == 0:
@@ -191,3 +229,29 @@ def merged_predict(ranks, world, tu, ti, tr):
         if m.any():
             out[m] = a.t.predict_batch(CSRData.from_triples(tu[m], ti[m], tr[m]))
     return out
+
+
+def simulate_stratified(conf, u, i, r, world, chunks, passes, num_item, per_item=32.0, seed=10):
+    """multi_gpu.StratifiedTrainer with all ranks in one process: block hand-overs are array copies.  Returns the rank adaptors, the
+    item side completed everywhere (gather_blocks)."""
+    from svdfeature_amd.multi_gpu import stratified_plan
+    ranks = [OracleShard(make_oracle(conf, seed), minibatch=True) for _ in range(world)]
+    plans = [[[a.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, rk, world, chunks, num_item, per_item)] for rk, a in enumerate(ranks)]
+    for _ in range(passes):
+        for c in range(chunks):
+            for s in range(world):
+                for rk, a in enumerate(ranks):
+                    b = (rk + s) % world
+                    for w in plans[rk][c][s]:
+                        a.train(w)
+                        a.apply_local(w, b, world)
+                if world > 1:
+                    outs = [a.block_get((rk + s) % world, world).copy() for rk, a in enumerate(ranks)]
+                    for rk, a in enumerate(ranks):     # rank rk receives from rank rk + 1 the block that rank just trained
+                        a.block_set((rk + s + 1) % world, world, outs[(rk + 1) % world])
+    for b in range(world):
+        blk = ranks[b].block_get(b, world).copy()
+        for rk, a in enumerate(ranks):
+            if rk != b:
+                a.block_set(b, world, blk)
+    return ranks

@@ -180,3 +180,57 @@ def test_rank_pairs_on_simulated_ranks_equal_the_oracle_simulation(k, world):
             assert np.array_equal(ad.t.view(name).view(np.uint32), s.t.view(name).view(np.uint32)), name
     with pytest.raises(sa.SvdfError, match="must differ"):
         ranks[0][0].t.dataset_window_from_pairs(u[:3], p[:3], p[:3])
+
+
+@pytest.mark.parametrize("k,world,chunks", [(64, 3, 2), (16, 2, 1), (128, 4, 2)])
+def test_stratified_schedule_on_simulated_ranks_equals_the_simulation(k, world, chunks):
+    """multi_gpu.StratifiedTrainer's schedule with N trainers on one GPU (block hand-overs = device copies): in-place per-item sums into
+    the owned item block (svdf_window_delta_apply_local), svdf_item_block_get / _set -- == the oracle simulation bit for bit"""
+    import torch
+    from multi_rank_utils import simulate_stratified
+    from svdfeature_amd.multi_gpu import StratifiedTrainer, stratified_plan
+    nu, ni, n, passes, per_item = 1500, 701, 60000, 2, 9.0
+    u, i, r = cases.planted_triples(n, nu, ni, seed=k + world)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k)
+    dev = torch.device("cuda", 0)
+    ranks = []
+    for rk in range(world):
+        ad = HipShard(_trainer(conf), torch, dev, minibatch=True)
+        ad.set_wire_half(False)
+        plan = [[ad.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, rk, world, chunks, ni, per_item)]
+        ranks.append((ad, plan))
+    for _ in range(passes):
+        for c in range(chunks):
+            for s in range(world):
+                for rk, (ad, plan) in enumerate(ranks):
+                    for w in plan[c][s]:
+                        ad.train(w)
+                        ad.apply_local(w, (rk + s) % world, world)
+                outs = []
+                for rk, (ad, _) in enumerate(ranks):
+                    outs.append(ad.block_get((rk + s) % world, world).clone())
+                    ad.stream.synchronize()
+                torch.cuda.synchronize()
+                for rk, (ad, _) in enumerate(ranks):
+                    ad.block_set((rk + s + 1) % world, world, outs[(rk + 1) % world])
+    for b in range(world):
+        blk = ranks[b][0].block_get(b, world).clone()
+        ranks[b][0].stream.synchronize()
+        for rk, (ad, _) in enumerate(ranks):
+            if rk != b:
+                ad.block_set(b, world, blk)
+    sim = simulate_stratified(conf, u, i, r, world, chunks, passes, ni, per_item)
+    for (ad, _), s_ in zip(ranks, sim):
+        ad.t.synchronize()
+        for name in NAMES:
+            assert np.array_equal(ad.t.view(name).view(np.uint32), s_.t.view(name).view(np.uint32)), name
+    # one rank through the trainer class itself (no process group)
+    ad = HipShard(_trainer(conf), torch, dev, minibatch=True)
+    plan = [[ad.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, 0, 1, chunks, ni, per_item)]
+    st = StratifiedTrainer(ad, plan, 1, 0, None)
+    for _ in range(passes):
+        st.train_pass()
+    ad.t.synchronize()
+    one = simulate_stratified(conf, u, i, r, 1, chunks, passes, ni, per_item)
+    for name in NAMES:
+        assert np.array_equal(ad.t.view(name).view(np.uint32), one[0].t.view(name).view(np.uint32)), name
