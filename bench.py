@@ -358,7 +358,8 @@ def run_workload(name, a, env, steps, warmup, main_line):
     # round-2 scheme (exact conflict-free levels per rank, item side stale across ranks only)
     exchanging = world > 1 or a.force_exchange
     minibatch = exchanging and name in ("basicmf", "pairwise") and a.exchange != "levels"
-    stratified = exchanging and name == "basicmf" and a.exchange == "stratified"
+    # ratings on N > 1 ranks: the stratified schedule unless another one is asked for (no all-reduce: DESIGN.md section 6f)
+    stratified = exchanging and name == "basicmf" and (a.exchange == "stratified" or (a.exchange == "auto" and world > 1))
     auto_parts = 1 if world <= 2 else 2
     parts = (a.exchange_parts or auto_parts) if (name == "basicmf" and exchanging) else 1
     adaptor = HipShard(tr, torch, torch.device("cuda", local_rank), parts=parts, minibatch=minibatch)
@@ -391,7 +392,8 @@ def run_workload(name, a, env, steps, warmup, main_line):
         shards = defer_tails(shards, a.users, a.items, a.defer_tails)
     if stratified:
         from svdfeature_amd.multi_gpu import StratifiedTrainer, stratified_plan
-        plan = [[adaptor.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, rank, world, a.chunks, a.items, 32.0)]
+        bpr = max(1, a.blocks_per_rank) if world > 1 else 1
+        plan = [[adaptor.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, rank, world, a.chunks, a.items, 32.0, bpr)]
         wins = [w for chunk in plan for sub in chunk for w in sub]
         nwin = len(wins)
         parts = 1
@@ -407,7 +409,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
     log("%s: scheduled %d into %d conflict-free batches (largest %d) in %.1fs" % (name, my_n, n_batches, max(w.max_batch for w in flat), sched_s))
     if stratified:
         adaptor.set_wire_half(False)
-        st = StratifiedTrainer(adaptor, plan, world, rank, dist if world > 1 else None)
+        st = StratifiedTrainer(adaptor, plan, world, rank, dist if world > 1 else None, blocks_per_rank=bpr)
     else:
         st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange, half_delta=(a.delta_dtype == "fp16"), parts=parts)
 
@@ -566,9 +568,9 @@ def run_workload(name, a, env, steps, warmup, main_line):
                          "svdpp": "implicitFeedback (SVD++) %d users x %d ratings, feedback set = own items, k=%d fp32 (BASELINE configs[3])" % (a.svdpp_users, a.svdpp_per_user, factor),
                          "neighbourhood": "neighborhoodModel shape: %d ratings + 4 of %d global ids each, k=%d fp32 (BASELINE configs[3])" % (n, a.globals, factor)}[name],
             "order": "uniform random (file order preserved: result == sequential SGD)" if not exchanging else
-                     ("stratified: %d file-order chunks x %d sub-epochs per pass, rank r trains (user block r) x (item block (r + s) %% %d) with the "
+                     ("stratified: %d file-order chunks x %d steps per pass, in step t rank r trains (user block r) x (item block (%d r + t) %% %d) with the "
                       "window-minibatch step, the item block is handed to rank r - 1 afterwards (fp32, no all-reduce); %d window steps per rank and pass"
-                      % (a.chunks, world, world, nwin)) if stratified else
+                      % (a.chunks, world * bpr, bpr, world * bpr, nwin)) if stratified else
                      "user-sharded, %s, item-delta all-reduce (%s on the wire) every 1/%d pass%s" % (
                          "window-minibatch step (user side exact, item side applied at the window's end)" if minibatch else "exact conflict-free levels per rank",
                          a.delta_dtype, nwin, (", in %d item-range pieces overlapped with training" % parts) if parts > 1 else ""),
@@ -578,9 +580,9 @@ def run_workload(name, a, env, steps, warmup, main_line):
                         ("torch.distributed %s all_reduce (RCCL over xGMI)" % dist.get_backend()) if (dist is not None and world > 1) else
                         ("torch.distributed %s all_reduce with one rank (identity)" % dist.get_backend() if dist is not None else "none (one rank)"),
                 "step": "stratified" if stratified else ("minibatch" if minibatch else "levels"), "windows": nwin, "parts": parts,
-                "handoffs_per_pass": a.chunks * world if (stratified and world > 1) else 0,
+                "handoffs_per_pass": a.chunks * world * bpr if (stratified and world > 1) else 0,
                 "bytes_per_window": int(tr.item_delta_count() * (2 if a.delta_dtype == "fp16" else 4)) if not stratified else
-                                    int(tr.item_delta_count() * 4 // max(world, 1)),
+                                    int(tr.item_delta_count() * 4 // max(world * bpr, 1)),
                 "updates_per_item_per_window": per_item / nwin},
             "phase_ms": phase_ms,
             "conflict_free_batches_per_pass": n_batches, "schedule_build_s": round(sched_s, 2),
@@ -742,9 +744,13 @@ def main():
     ap.add_argument("--chunks", type=int, default=4,
                     help="--exchange stratified: file-order chunks per pass (a chunk = N sub-epochs; more chunks keep the training order closer to "
                          "the file order: tools/stratified_calibration.py)")
+    ap.add_argument("--blocks-per-rank", type=int, default=2,
+                    help="--exchange stratified: item blocks per rank (1: a block is handed over between two steps; 2: the hand-over of a block "
+                         "runs beside the training of the rank's next block)")
     ap.add_argument("--exchange", choices=["auto", "minibatch", "levels", "stratified"], default="auto",
-                    help="N>1 (or --force-exchange), ratings: how a window is trained.  minibatch (= auto): the window-minibatch step, user side "
-                         "exact, item side one minibatch step per window, three launches per window (svdf_k_window.hip); levels: the round-2 scheme, "
+                    help="N>1 (or --force-exchange): how the ranks train and exchange.  auto = stratified for ratings on N > 1 ranks, minibatch "
+                         "otherwise.  minibatch: the window-minibatch step, user side "
+                         "exact, item side one minibatch step per window, three launches per window (svdf_k_window.hip), all-reduce per window; levels: the round-2 scheme, "
                          "exact conflict-free levels per rank with the item side stale across ranks only; stratified: no all-reduce -- item blocks are "
                          "owned exclusively and handed from rank to rank (DSGD-style strata, window-minibatch step inside a stratum; ratings only)")
     ap.add_argument("--no-sequential-reference", action="store_true",

@@ -111,13 +111,14 @@ def item_block_bounds(num_item, world):
     return [(int(num_item) * b) // world for b in range(world + 1)]
 
 
-def stratum_windows(user, item, label, rank, world, sub_epoch, num_item, per_item=32.0):
-    """STRATIFIED schedule (DSGD-style): the instances of stratum (user block `rank`, item block (rank + sub_epoch) % world) of one
-    pass, in file order, cut into windows of at most `per_item` updates per item of the block.  Strata of one sub-epoch share neither
-    users nor items, so every rank trains its stratum against an item block it owns exclusively: no sum over ranks, the block is
-    handed on afterwards.  Returns a list of (u, i, r) windows (possibly empty arrays, never an empty list)."""
-    b = (rank + sub_epoch) % world
-    bounds = item_block_bounds(num_item, world)
+def stratum_windows(user, item, label, rank, world, step, num_item, per_item=32.0, blocks_per_rank=1):
+    """STRATIFIED schedule (DSGD-style): the instances of stratum (user block `rank`, item block (rank * P + step) % (world * P)) of one
+    chunk, in file order, cut into windows of at most `per_item` updates per item of the block (P = blocks_per_rank).  Strata of one step
+    share neither users nor items, so every rank trains its stratum against an item block it owns exclusively: no sum over ranks, the
+    block is handed on afterwards.  Returns a list of (u, i, r) windows (possibly empty arrays, never an empty list)."""
+    nblocks = world * blocks_per_rank
+    b = (rank * blocks_per_rank + step) % nblocks
+    bounds = item_block_bounds(num_item, nblocks)
     it = np.asarray(item)
     m = (it >= bounds[b]) & (it < bounds[b + 1])
     if world > 1:
@@ -289,64 +290,82 @@ class ShardedTrainer:
             mark("unpack")
 
 
-def stratified_plan(user, item, label, rank, world, chunks, num_item, per_item=32.0):
-    """plan[c][s] = the windows (u, i, r) this rank trains in sub-epoch s of file-order chunk c: the chunk's instances whose user is in
-    user block `rank` and whose item is in item block (rank + s) % world, file order, at most `per_item` updates per item per window."""
+def stratified_plan(user, item, label, rank, world, chunks, num_item, per_item=32.0, blocks_per_rank=1):
+    """plan[c][t] = the windows (u, i, r) this rank trains in step t (0 .. world * P - 1) of file-order chunk c: the chunk's instances whose
+    user is in user block `rank` and whose item is in item block (rank * P + t) % (world * P), file order, at most `per_item` updates per
+    item per window."""
     n = len(label)
     plan = []
     for c in range(chunks):
         lo, hi = (n * c) // chunks, (n * (c + 1)) // chunks
-        plan.append([stratum_windows(user[lo:hi], item[lo:hi], label[lo:hi], rank, world, s, num_item, per_item) for s in range(world)])
+        plan.append([stratum_windows(user[lo:hi], item[lo:hi], label[lo:hi], rank, world, t, num_item, per_item, blocks_per_rank)
+                     for t in range(world * blocks_per_rank)])
     return plan
 
 
 class StratifiedTrainer:
     """STRATIFIED window-minibatch schedule (DSGD-style): no all-reduce.
 
-    User block r = users with id % N == r (private to rank r, as everywhere in this module); item block b = items
-    [NI b / N, NI (b + 1) / N).  A pass is cut into `chunks` file-order chunks; a chunk is N sub-epochs; in sub-epoch s rank r trains
-    stratum (r, (r + s) % N) of the chunk with the window-minibatch step.  Strata of one sub-epoch share neither users nor items, so
-    the rank owns its item block exclusively: the per-item sums of a window are added to the model in place (adaptor.apply_local) and
-    after the sub-epoch the block -- NI / N rows -- is handed to rank r - 1 while block (r + s + 1) % N arrives from rank r + 1
-    (one point-to-point transfer per rank and sub-epoch: 3.25 MB at configs[2] on 8 ranks, against a 13 MB all-reduce per window).
-    Between passes every rank holds block `rank`; gather_blocks() completes the item side everywhere before predictions / a save.
+    User block r = users with id % N == r (private to rank r, as everywhere in this module); the items are cut into B = N * P blocks by id
+    range (P = blocks_per_rank).  A pass is cut into `chunks` file-order chunks; a chunk is B steps; in step t rank r trains stratum
+    (r, (r P + t) % B) of the chunk with the window-minibatch step.  Strata of one step share neither users nor items, so the rank owns
+    its item block exclusively: the per-item sums of a window are added to the model in place (adaptor.apply_local).  After the step the
+    block goes to rank r - 1, which trains it P steps later, while block (r P + t + P) % B arrives from rank r + 1 for this rank's step
+    t + P: with P = 1 the hand-over sits between two steps, with P = 2 it has a whole step of training to hide behind (the transfer is
+    started right after the step and only waited for right before the block is trained).  One point-to-point transfer per rank and step
+    (NI / B rows: 3.25 MB at configs[2] on 8 ranks with P = 1) against a 13 MB all-reduce per window.  Between passes every rank holds
+    its P home blocks r P .. r P + P - 1; gather_blocks() completes the item side everywhere before predictions / a save.
 
     adaptor protocol: train(window), apply_local(window, block, nblocks), block_get(block, nblocks) -> tensor,
     block_set(block, nblocks, tensor), block_like(block, nblocks) -> empty tensor of that block's size,
-    handoff(dist, out_tensor, dst_rank, in_tensor, src_rank)."""
+    handoff_start(dist, out_tensor, dst_rank, in_tensor, src_rank) -> handle, handoff_wait(handle), broadcast(dist, tensor, src)."""
 
     minibatch = True
 
-    def __init__(self, adaptor, plan_handles, world, rank, dist=None):
+    def __init__(self, adaptor, plan_handles, world, rank, dist=None, blocks_per_rank=1):
         self.a, self.plan, self.world, self.rank, self.dist = adaptor, plan_handles, world, rank, dist
+        self.P = int(blocks_per_rank)
+        self.pending = {}   # block id -> (handle, incoming tensor): a block on its way to this rank
+
+    def _arrive(self, b):
+        if b in self.pending:
+            handle, inc = self.pending.pop(b)
+            self.a.handoff_wait(handle)
+            self.a.block_set(b, self.world * self.P, inc)
 
     def train_pass(self, mark=None):
         mark = mark or (lambda phase: None)
-        a, N = self.a, self.world
+        a, N, P = self.a, self.world, self.P
+        B = N * P
         for chunk in self.plan:
-            for s in range(N):
-                b = (self.rank + s) % N
-                for w in chunk[s]:
+            for t in range(B):
+                b = (self.rank * P + t) % B
+                self._arrive(b)
+                mark("allreduce")
+                for w in chunk[t]:
                     a.train(w)
                     mark("compute")
-                    a.apply_local(w, b, N)
+                    a.apply_local(w, b, B)
                     mark("pack")
                 if N > 1:
-                    nxt = (b + 1) % N
-                    out = a.block_get(b, N)
-                    inc = a.block_like(nxt, N)
-                    a.handoff(self.dist, out, (self.rank - 1) % N, inc, (self.rank + 1) % N)
-                    a.block_set(nxt, N, inc)
-                    mark("allreduce")
+                    nxt = (b + P) % B
+                    out = a.block_get(b, B)
+                    inc = a.block_like(nxt, B)
+                    self.pending[nxt] = (a.handoff_start(self.dist, out, (self.rank - 1) % N, inc, (self.rank + 1) % N), inc)
+                    mark("pack")
+        for b in list(self.pending):   # the home blocks come back at the end of a chunk: have them in place between passes
+            self._arrive(b)
+        mark("allreduce")
 
     def gather_blocks(self):
-        """every rank broadcasts the block it holds between passes (block `rank`): the item side is complete everywhere afterwards"""
-        a, N = self.a, self.world
-        for b in range(N):
-            buf = a.block_get(b, N) if b == self.rank else a.block_like(b, N)
-            a.broadcast(self.dist, buf, b)
-            if b != self.rank:
-                a.block_set(b, N, buf)
+        """every rank broadcasts the blocks it holds between passes (its P home blocks): the item side is complete everywhere afterwards"""
+        a, N, P = self.a, self.world, self.P
+        for b in range(N * P):
+            owner = b // P
+            buf = a.block_get(b, N * P) if owner == self.rank else a.block_like(b, N * P)
+            a.broadcast(self.dist, buf, owner)
+            if owner != self.rank:
+                a.block_set(b, N * P, buf)
 
 
 class HipShard:
@@ -447,11 +466,14 @@ class HipShard:
         self.t.item_block_set(tensor.data_ptr())
         self.t.item_delta_select(0, 1)
 
-    def handoff(self, dist, out, dst, inc, src):
-        """send `out` to rank dst and receive `inc` from rank src, ordered on the trainer's stream (the copy-out kernel before, the
-        copy-in kernel after)"""
+    def handoff_start(self, dist, out, dst, inc, src):
+        """start sending `out` to rank dst and receiving `inc` from rank src: ordered after the copy-out kernel on the trainer's stream,
+        running beside whatever the trainer enqueues next"""
         with self.torch.cuda.stream(self.stream):
-            reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, out, dst), dist.P2POp(dist.irecv, inc, src)])
+            return dist.batch_isend_irecv([dist.P2POp(dist.isend, out, dst), dist.P2POp(dist.irecv, inc, src)])
+
+    def handoff_wait(self, reqs):
+        with self.torch.cuda.stream(self.stream):   # the trainer's stream waits for the transfer; the host does not
             for q in reqs:
                 q.wait()
 

@@ -97,8 +97,10 @@ class OracleShard:
         cur[self._piece(block, nblocks)] = v
         self._write(cur)
 
-    def handoff(self, dist, out, dst, inc, src):
-        reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, out, dst), dist.P2POp(dist.irecv, inc, src)])
+    def handoff_start(self, dist, out, dst, inc, src):
+        return dist.batch_isend_irecv([dist.P2POp(dist.isend, out, dst), dist.P2POp(dist.irecv, inc, src)])
+
+    def handoff_wait(self, reqs):
         for q in reqs:
             q.wait()
 
@@ -231,27 +233,29 @@ def merged_predict(ranks, world, tu, ti, tr):
     return out
 
 
-def simulate_stratified(conf, u, i, r, world, chunks, passes, num_item, per_item=32.0, seed=10):
-    """multi_gpu.StratifiedTrainer with all ranks in one process: block hand-overs are array copies.  Returns the rank adaptors, the
-    item side completed everywhere (gather_blocks)."""
+def simulate_stratified(conf, u, i, r, world, chunks, passes, num_item, per_item=32.0, seed=10, blocks_per_rank=1):
+    """multi_gpu.StratifiedTrainer with all ranks in one process: block hand-overs are array copies (a block trained by rank r + 1 in
+    step t reaches rank r before its step t + P).  Returns the rank adaptors, the item side completed everywhere (gather_blocks)."""
     from svdfeature_amd.multi_gpu import stratified_plan
+    P = blocks_per_rank
+    B = world * P
     ranks = [OracleShard(make_oracle(conf, seed), minibatch=True) for _ in range(world)]
-    plans = [[[a.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, rk, world, chunks, num_item, per_item)] for rk, a in enumerate(ranks)]
+    plans = [[[a.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, rk, world, chunks, num_item, per_item, P)] for rk, a in enumerate(ranks)]
     for _ in range(passes):
         for c in range(chunks):
-            for s in range(world):
+            for t in range(B):
                 for rk, a in enumerate(ranks):
-                    b = (rk + s) % world
-                    for w in plans[rk][c][s]:
+                    b = (rk * P + t) % B
+                    for w in plans[rk][c][t]:
                         a.train(w)
-                        a.apply_local(w, b, world)
-                if world > 1:
-                    outs = [a.block_get((rk + s) % world, world).copy() for rk, a in enumerate(ranks)]
-                    for rk, a in enumerate(ranks):     # rank rk receives from rank rk + 1 the block that rank just trained
-                        a.block_set((rk + s + 1) % world, world, outs[(rk + 1) % world])
-    for b in range(world):
-        blk = ranks[b].block_get(b, world).copy()
+                        a.apply_local(w, b, B)
+                if world > 1:   # copies may land at once: the receiver does not touch the block before step t + P
+                    outs = [a.block_get((rk * P + t) % B, B).copy() for rk, a in enumerate(ranks)]
+                    for rk, a in enumerate(ranks):
+                        a.block_set(((rk + 1) * P + t) % B, B, outs[(rk + 1) % world])
+    for b in range(B):
+        blk = ranks[b // P].block_get(b, B).copy()
         for rk, a in enumerate(ranks):
-            if rk != b:
-                a.block_set(b, world, blk)
+            if rk != b // P:
+                a.block_set(b, B, blk)
     return ranks

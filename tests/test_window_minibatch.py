@@ -187,7 +187,7 @@ def test_pairs_two_ranks_equal_one_rank_and_keep_the_pairwise_contract():
 
 
 # ---- STRATIFIED schedule (multi_gpu.StratifiedTrainer): item blocks owned exclusively and handed around, no all-reduce
-def _worker_strat(rank, world, port, chunks, passes, per_item, outdir):
+def _worker_strat(rank, world, port, chunks, passes, per_item, outdir, bpr=1):
     import torch
     import torch.distributed as dist
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -197,8 +197,8 @@ def _worker_strat(rank, world, port, chunks, passes, per_item, outdir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     u, i, r = cases.planted_triples(40000, NU, NI, seed=9)
     a = OracleShard(make_oracle(CONF), torch, minibatch=True)
-    plan = [[a.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, rank, world, chunks, NI, per_item)]
-    st = StratifiedTrainer(a, plan, world, rank, dist)
+    plan = [[a.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, rank, world, chunks, NI, per_item, bpr)]
+    st = StratifiedTrainer(a, plan, world, rank, dist, blocks_per_rank=bpr)
     for _ in range(passes):
         st.train_pass()
     st.gather_blocks()
@@ -208,16 +208,16 @@ def _worker_strat(rank, world, port, chunks, passes, per_item, outdir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_stratified_gloo_ranks_match_the_simulation_bit_for_bit(world, tmp_path):
+@pytest.mark.parametrize("world,bpr", [(2, 1), (3, 1), (2, 2), (3, 2)])
+def test_stratified_gloo_ranks_match_the_simulation_bit_for_bit(world, bpr, tmp_path):
     """StratifiedTrainer across gloo processes (point-to-point block hand-overs, broadcasts at the end) == the one-process simulation
     whose hand-overs are array copies; the item side is identical on every rank after gather_blocks"""
     import torch.multiprocessing as mp
     from multi_rank_utils import simulate_stratified
     chunks, passes, per_item = 2, 2, 12.0
-    mp.spawn(_worker_strat, args=(world, _free_port(), chunks, passes, per_item, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_strat, args=(world, _free_port(), chunks, passes, per_item, str(tmp_path), bpr), nprocs=world, join=True)
     u, i, r = cases.planted_triples(40000, NU, NI, seed=9)
-    sim = simulate_stratified(CONF, u, i, r, world, chunks, passes, NI, per_item)
+    sim = simulate_stratified(CONF, u, i, r, world, chunks, passes, NI, per_item, blocks_per_rank=bpr)
     for rk in range(world):
         z = np.load(str(tmp_path / ("rank%d.npz" % rk)))
         for name in ("W_item", "i_bias", "W_user", "u_bias"):
@@ -238,7 +238,8 @@ def test_stratified_schedule_uses_every_instance_once_and_one_rank_is_the_plain_
             assert len(chunk) == world
             for s, sub in enumerate(chunk):
                 for (wu, wi, wr) in sub:
-                    assert np.all(wu % world == rk) and np.all((wi.astype(np.int64) * world) // NI == (rk + s) % world)
+                    lo, hi = NI * ((rk + s) % world) // world, NI * ((rk + s) % world + 1) // world
+                    assert np.all(wu % world == rk) and np.all((wi >= lo) & (wi < hi))
                     seen.append(wu.astype(np.int64) * NI + wi)
     np.testing.assert_array_equal(np.sort(np.concatenate(seen)), np.sort(u.astype(np.int64) * NI + i))
     # one rank, one chunk, windows of W instances: the window-minibatch step with the sums added in place
@@ -262,3 +263,6 @@ def test_rmse_contract_of_the_stratified_schedule(world):
     ref = cases.rmse(merged_predict(simulate(conf, u, i, r, 1, 1, 5), 1, tu, ti, tr), tr)
     got = cases.rmse(merged_predict(simulate_stratified(conf, u, i, r, world, 4, 5, ni, 32.0), world, tu, ti, tr), tr)
     assert abs(got - ref) <= 1e-4
+    if world == 8:   # two item blocks per rank (the hand-over hides behind a step of training): same contract
+        got2 = cases.rmse(merged_predict(simulate_stratified(conf, u, i, r, world, 4, 5, ni, 32.0, blocks_per_rank=2), world, tu, ti, tr), tr)
+        assert abs(got2 - ref) <= 1e-4
