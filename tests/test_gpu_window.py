@@ -208,14 +208,16 @@ def test_stratified_schedule_on_simulated_ranks_equals_the_simulation(k, world, 
                         ad.apply_local(w, (rk + s) % world, world)
                 outs = []
                 for rk, (ad, _) in enumerate(ranks):
-                    outs.append(ad.block_get((rk + s) % world, world).clone())
-                    ad.stream.synchronize()
+                    blk = ad.block_get((rk + s) % world, world)
+                    ad.stream.synchronize()          # the copy-out kernel runs on the adaptor's stream, clone() on torch's
+                    outs.append(blk.clone())
                 torch.cuda.synchronize()
                 for rk, (ad, _) in enumerate(ranks):
                     ad.block_set((rk + s + 1) % world, world, outs[(rk + 1) % world])
     for b in range(world):
-        blk = ranks[b][0].block_get(b, world).clone()
+        blk = ranks[b][0].block_get(b, world)
         ranks[b][0].stream.synchronize()
+        blk = blk.clone()
         for rk, (ad, _) in enumerate(ranks):
             if rk != b:
                 ad.block_set(b, world, blk)
