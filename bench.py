@@ -629,7 +629,8 @@ def run_f3_secondary(a, env):
     i = rng.integers(0, a.items, n, dtype=np.uint32)
     r = rng.integers(1, 6, n).astype(np.float32)
     conf = [(kk, v) for kk, v in conf_for(a) if kk != "num_factor"] + [("num_factor", str(k)), ("ui_init_sigma", "0.1")]
-    t, o = sa.Trainer(0, 0), oracle.OracleTrainer("port", 0, 0)
+    f3_kind = "reference" if oracle.have_reference() else "port"   # the reference's own classes where oracle/_ref is present
+    t, o = sa.Trainer(0, 0), oracle.OracleTrainer(f3_kind, 0, 0)
     for x in (t, o):
         x.seed(10)
         for kk, v in conf:
@@ -655,7 +656,7 @@ def run_f3_secondary(a, env):
         "roofline": {"bound": "hbm", "achieved": n * byts / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": n * byts / dt / 1e9 / HBM_PEAK_GBS,
                      "kernel": "k_predict_basic", "algorithmic_bytes_per_instance": byts,
                      "timing": "host clock around svdf_eval_dataset (one launch + the partial-sum reduction + sync)", "traffic": None},
-        "cpu_baseline": {"value": S / dt_cpu, "unit": "instances/s", "cores": 1, "kind": "port", "sample": "predict of the first %d instances" % S},
+        "cpu_baseline": {"value": S / dt_cpu, "unit": "instances/s", "cores": 1, "kind": f3_kind, "sample": "predict of the first %d instances" % S},
         "parity": {"predictions_bit_exact_on_sample": bool(np.array_equal(gpu_pred.view(np.uint32), cpu_pred.view(np.uint32)))}}
     log("f3 evaluate: %.2f G inst/s (%.1f%% of peak), cpu %.2f M inst/s" % (n / dt / 1e9, 100 * out["evaluate_k64"]["roofline"]["frac"], S / dt_cpu / 1e6))
     path = os.path.join(tempfile.mkdtemp(), "rank.model")
@@ -681,7 +682,7 @@ def run_f3_secondary(a, env):
     byts = cand * (k * 4 + 4 + 4 + 1)
     for top_k in (0, 10):
         g = sa.Ranker(0, 0)
-        c = oracle.OracleRanker("port", 0, 0)
+        c = oracle.OracleRanker(f3_kind, 0, 0)
         for x in (g, c):
             x.set_param("top_k", str(top_k))
             x.load_model(path)
@@ -698,11 +699,13 @@ def run_f3_secondary(a, env):
             "workload": "ISVDRanker: %d candidates, k=128, %d user sections in one svdf_ranker_process_rows call, %s" % (
                 cand, nsec, "top_k=%d" % top_k if top_k else "rank positions of 5 positives"),
             "value": 1.0 / dt, "unit": "user sections/s", "ms_per_step": dt * 1e3, "sections_finished_by_host_sort": g.counter(1),
+            "tiles_of_up_to_8_sections": g.counter(3),
             "roofline": {"bound": "hbm", "achieved": byts / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / dt / 1e9 / HBM_PEAK_GBS,
-                         "kernel": "k_rank_score", "algorithmic_bytes_per_section": byts,
+                         "kernel": "k_rank_score_tile<8> (positions: up to 8 sections per pass over the candidate matrix)" if not top_k else "k_rank_score<8,2>",
+                         "algorithmic_bytes_per_section": byts,
                          "timing": "host clock over the whole call / sections: upload, k_rank_user, k_rank_score, selection, readback of every "
                                    "section (the scoring kernel alone: profiles/r02_ranker_*_kernel_stats.csv)", "traffic": None},
-            "cpu_baseline": {"value": 1.0 / dt_cpu, "unit": "user sections/s", "cores": 1, "kind": "port", "sample": "the first %d sections" % ncpu},
+            "cpu_baseline": {"value": 1.0 / dt_cpu, "unit": "user sections/s", "cores": 1, "kind": f3_kind, "sample": "the first %d sections" % ncpu},
             "parity": {"results_identical_on_sample": bool(np.array_equal(got[:len(ref)], ref))}}
         log("f3 ranker top_k=%d: %.1f us/section, cpu %.2f ms/section" % (top_k, dt * 1e6, dt_cpu * 1e3))
         g.close()

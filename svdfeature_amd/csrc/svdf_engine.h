@@ -534,7 +534,7 @@ class Ranker {
     long process_block(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label, const int *row_ptr,
                        const unsigned *feat_index, const float *feat_value, int *out, long cap);
     int64_t counter(int what) const {
-        return what == 0 ? n_sections_ : (what == 1 ? n_host_sorts_ : (what == 2 ? (int64_t)pos_item_.size() : -1));
+        return what == 0 ? n_sections_ : (what == 1 ? n_host_sorts_ : (what == 2 ? (int64_t)pos_item_.size() : (what == 3 ? n_tiles_ : -1)));
     }
   private:
     std::unique_ptr<Engine> eng_;   // owns the model in HBM, the side tables and the kernel parameter block
@@ -556,7 +556,18 @@ class Ranker {
         DevBuf<float> d_ps, d_score;
         hipEvent_t ev = nullptr;
     };
-    struct RankPending { int slot = 0, npos = 0, take = 0; long n = 0; std::vector<int> pos_item, banned; };
+    struct RankPending { int slot = 0, npos = 0, take = 0; long n = 0; std::vector<int> pos_item, banned;
+                         // a tile of sections sharing one scoring pass (svdf_k_rank.hip: k_rank_score_tile): per section its positives / bans
+                         int nsec = 0; std::vector<std::vector<int>> tile_pos, tile_ban; };
+    struct TileSec { std::vector<unsigned> user_idx; std::vector<float> user_val; std::vector<int> pos_item, banned; };
+    std::vector<TileSec> tile_;      // sections staged for the next tile (process_rows, positions mode, no special samples)
+    long tile_n_ = 0;                // the candidate count they were staged against
+    std::vector<int> tile_prev_ban_; // candidates whose ban bits the previous tile set (cleared by the next tile's opening kernel)
+    DevBuf<unsigned> d_banmask_;
+    DevBuf<float> d_tu_tile_;
+    void flush_tile();
+    bool tile_enabled_ = true;
+    int64_t n_tiles_ = 0;
     RankSlot slots_[RANK_SLOTS];
     struct RankChunk { std::vector<int> vals; std::future<std::vector<int>> fut; bool pending = false; };   // one section's results
     std::deque<RankPending> pending_;

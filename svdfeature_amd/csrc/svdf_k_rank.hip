@@ -443,6 +443,151 @@ void launch_rank_items(const DevParams &P, const DevCSR &D, long first, long n, 
 void launch_rank_feedback(const DevParams &P, const unsigned *fidx, const float *fval, int nfb, float *fb_out, hipStream_t st) {
     SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_rank_feedback<LPI, R>), dim3(1), dim3(64), 0, st, P, fidx, fval, nfb, fb_out));
 }
+// =====================================================================================================================================
+// A TILE of user sections per pass over the candidate matrix (svdf_ranker_process_rows, positions mode without special samples).  The
+// reference scores every candidate against ONE user per PROCESS line (apex_svd_base.h:754-765) and so did the pass above: 52 MB of
+// prepared candidates streamed per section.  Sections that follow each other without new candidates score the SAME matrix, so up to
+// RANK_TILE of them share one pass: a lane keeps its candidate's chunk in registers and walks the tile's user factors from LDS --
+// per user the four serial chains of the reference's dot product, unchanged.  What is per user stays per user: the ban bits (bit u of
+// banmask[i]: candidate i is BAN_SAMPLE in section u), the positives with their scores, the greater / tie counters.
+// stage words of section u at stage + T.off[u]: uidx[nu] uval[nu] pos[npos] ban[nban]; cnt / pos_score entries at T.pos0[u].
+// =====================================================================================================================================
+template <int LPI, typename R>
+__global__ __launch_bounds__(64 * RANK_TILE) void k_rank_tile_open(const DevParams P, const unsigned *stage, const RankTile T, const float *fb_in, float *tu_out,
+                                                                   unsigned *banmask, const unsigned *prev_ban, int nprev, int *cnt, unsigned *flag, long cap,
+                                                                   const float4 *ifT, const float *ibias, float *pos_score) {
+    extern __shared__ float tus[];   // [RANK_TILE][pitch + 4]
+    const int lane = threadIdx.x & 63, u = threadIdx.x >> 6;
+    for (int j = threadIdx.x; j < nprev; j += blockDim.x) banmask[prev_ban[j]] = 0u;   // the previous tile's bans
+    __syncthreads();
+    const bool live = u < T.nsec;
+    const unsigned *st = stage + (live ? T.off[u] : 0);
+    const int nu = live ? T.nu[u] : 0, npos = live ? T.npos[u] : 0, nban = live ? T.nban[u] : 0;
+    const unsigned *ban = st + 2 * nu + npos;
+    for (int j = lane; j < nban; j += 64) atomicOr(&banmask[ban[j]], 1u << u);
+    int *mycnt = cnt + 2 * (live ? T.pos0[u] : 0);
+    for (int j = lane; j < 2 * npos; j += 64) mycnt[j] = 0;
+    if (live && lane == 0) flag[u] = 0u;
+    using io = row_io<LPI, R>;
+    float *mytu = tus + (size_t)u * (P.pitch + 4);
+    if (live && lane < LPI) {
+        const unsigned *uidx = st;
+        const float *uval = reinterpret_cast<const float *>(st + nu);
+        R tu = fb_in ? io::load(fb_in, 0, P.pitch, lane, P.k) : row_traits<R>::zero();
+        for (int j = 0; j < nu; j++) {
+            const unsigned uid = uidx[j];
+            axpy4(tu, io::load(P.W, P.user_off + uid, P.pitch, lane, P.k), uval[j]);
+            if (uid < P.feat_user.num_row)
+                for (unsigned c = P.feat_user.row_ptr[uid]; c < P.feat_user.row_ptr[uid + 1]; c++)
+                    axpy4(tu, io::load(P.W, P.user_off + P.feat_user.index[c], P.pitch, lane, P.k), P.feat_user.value[c]);
+        }
+        io::store(tu_out, (size_t)u, P.pitch, lane, P.k, tu);
+        io::store(mytu, 0, P.pitch, lane, P.k, tu);
+    }
+    __syncthreads();
+    if (!live) return;
+    const int *pos = reinterpret_cast<const int *>(st + 2 * nu);
+    for (int j = lane; j < npos; j += 64)
+        pos_score[T.pos0[u] + j] = 0.0f + rank_lane_score<8>(P.k, cap, reinterpret_cast<const float4 *>(mytu), ifT + pos[j], ibias[pos[j]]);
+}
+
+template <int NSEC>
+__global__ __launch_bounds__(256) void k_rank_score_tile(int k, int pitch, long n, long cap, const float *__restrict__ tu, const float4 *__restrict__ ifT,
+                                                         const float *__restrict__ ibias, const unsigned *__restrict__ banmask, float *score,
+                                                         const unsigned *stage, const RankTile T, const float *pos_score, int *cnt) {
+    extern __shared__ float sh[];   // [NSEC][pitch] user factors, then 2 * total positives counters
+    float *ltu = sh;
+    int *lcnt = reinterpret_cast<int *>(sh + (size_t)NSEC * pitch);
+    const int totpos = T.pos0[T.nsec - 1] + T.npos[T.nsec - 1];
+    for (int j = threadIdx.x; j < NSEC * pitch; j += blockDim.x) ltu[j] = (j / pitch) < T.nsec ? tu[j] : 0.0f;
+    for (int j = threadIdx.x; j < 2 * totpos; j += blockDim.x) lcnt[j] = 0;
+    __syncthreads();
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in = i < n;
+    const long ic = in ? i : 0;
+    const int nfull = k >> 2, ntail = k & 3;
+    float a[NSEC][4];
+#pragma unroll
+    for (int u = 0; u < NSEC; u++) { a[u][0] = 0.0f; a[u][1] = 0.0f; a[u][2] = 0.0f; a[u][3] = 0.0f; }
+    const float4 *q = ifT + ic;
+    int j = 0;
+    for (; j + 4 <= nfull; j += 4) {
+        float4 v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[c] = q[(size_t)(j + c) * cap];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+#pragma unroll
+            for (int u = 0; u < NSEC; u++) {
+                const float4 p = *reinterpret_cast<const float4 *>(ltu + (size_t)u * pitch + 4 * (j + c));
+                a[u][0] = a[u][0] + p.x * v[c].x; a[u][1] = a[u][1] + p.y * v[c].y; a[u][2] = a[u][2] + p.z * v[c].z; a[u][3] = a[u][3] + p.w * v[c].w;
+            }
+        }
+    }
+    for (; j < nfull; j++) {
+        const float4 v = q[(size_t)j * cap];
+#pragma unroll
+        for (int u = 0; u < NSEC; u++) {
+            const float4 p = *reinterpret_cast<const float4 *>(ltu + (size_t)u * pitch + 4 * j);
+            a[u][0] = a[u][0] + p.x * v.x; a[u][1] = a[u][1] + p.y * v.y; a[u][2] = a[u][2] + p.z * v.z; a[u][3] = a[u][3] + p.w * v.w;
+        }
+    }
+    float4 vt = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (ntail) vt = q[(size_t)nfull * cap];
+    const float bias = ibias[ic];
+    const unsigned bm = banmask[ic];
+#pragma unroll
+    for (int u = 0; u < NSEC; u++) {
+        if (u >= T.nsec) break;
+        float sum = (a[u][0] + a[u][2]) + (a[u][1] + a[u][3]);
+        if (ntail) {
+            const float4 p = *reinterpret_cast<const float4 *>(ltu + (size_t)u * pitch + 4 * nfull);
+            sum = sum + p.x * vt.x;
+            if (ntail > 1) sum = sum + p.y * vt.y;
+            if (ntail > 2) sum = sum + p.z * vt.z;
+        }
+        const bool on = in && !((bm >> u) & 1u);
+        const float s = 0.0f + (bias + sum);    // item_score is the 0 of proc_user (:726) plus bias + dot (:762-764)
+        if (on) score[(size_t)u * cap + i] = s;
+        const int *pos = reinterpret_cast<const int *>(stage + T.off[u] + 2 * T.nu[u]);
+        for (int jj = 0; jj < T.npos[u]; jj++) {
+            const float ps = pos_score[T.pos0[u] + jj];
+            const bool gt = on && s > ps;
+            const bool tie = on && !gt && ((s == ps && pos[jj] != (int)i) || !(s <= ps));
+            const int ngt = __popcll(__ballot(gt)), ntie = __popcll(__ballot(tie));
+            if ((threadIdx.x & 63) == 0) {
+                if (ngt) atomicAdd(&lcnt[2 * T.pos0[u] + jj], ngt);
+                if (ntie) atomicAdd(&lcnt[2 * T.pos0[u] + T.npos[u] + jj], ntie);
+            }
+        }
+    }
+    __syncthreads();
+    for (int jj = threadIdx.x; jj < 2 * totpos; jj += blockDim.x)
+        if (lcnt[jj]) atomicAdd(&cnt[jj], lcnt[jj]);
+}
+
+void launch_rank_tile_open(const DevParams &P, const unsigned *stage, const RankTile &T, const float *fb_in, float *tu_out, unsigned *banmask,
+                           const unsigned *prev_ban, int nprev, int *cnt, unsigned *flag, long cap, const float *ifT, const float *ibias, float *pos_score,
+                           hipStream_t st) {
+    const size_t lds = (size_t)RANK_TILE * ((size_t)P.pitch + 4) * sizeof(float);
+    SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_rank_tile_open<LPI, R>), dim3(1), dim3(64 * RANK_TILE), lds, st, P, stage, T, fb_in, tu_out, banmask, prev_ban,
+                                              nprev, cnt, flag, cap, reinterpret_cast<const float4 *>(ifT), ibias, pos_score));
+}
+void launch_rank_score_tile(const DevParams &P, long n, long cap, const float *tu, const float *ifT, const float *ibias, const unsigned *banmask, float *score,
+                            const unsigned *stage, const RankTile &T, const float *pos_score, int *cnt, hipStream_t st) {
+    if (n <= 0 || T.nsec <= 0) return;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    const int totpos = T.pos0[T.nsec - 1] + T.npos[T.nsec - 1];
+    const float4 *q = reinterpret_cast<const float4 *>(ifT);
+    if (T.nsec <= 4) {
+        const size_t lds = (size_t)4 * P.pitch * sizeof(float) + (size_t)2 * totpos * sizeof(int);
+        hipLaunchKernelGGL((k_rank_score_tile<4>), dim3(grid), dim3(256), lds, st, P.k, P.pitch, n, cap, tu, q, ibias, banmask, score, stage, T, pos_score, cnt);
+    } else {
+        const size_t lds = (size_t)RANK_TILE * P.pitch * sizeof(float) + (size_t)2 * totpos * sizeof(int);
+        hipLaunchKernelGGL((k_rank_score_tile<RANK_TILE>), dim3(grid), dim3(256), lds, st, P.k, P.pitch, n, cap, tu, q, ibias, banmask, score, stage, T, pos_score, cnt);
+    }
+}
+
 void launch_rank_user(const DevParams &P, const unsigned *stage, const RankSection &S, const float *fb_in, float *tu_out, signed char *tag, int *cnt,
                       unsigned *flag, long cap, const float *ifT, const float *ibias, float *pos_score, unsigned *zero_words, int nzero, hipStream_t st) {
     const size_t lds = pos_score ? ((size_t)P.pitch + 4) * sizeof(float) : 0;

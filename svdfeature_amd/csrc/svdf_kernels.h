@@ -73,6 +73,15 @@ void launch_rank_transpose(const DevParams &P, long first, long n, long cap, con
 struct RankFused { int mode; const int *pos_item; const float *pos_score; int npos; int *greater, *ties; unsigned *keys, *vals, *flag, *hist1; };
 void launch_rank_score(const DevParams &P, long n, long cap, const float *tu, const float *ifT, const float *ibias, const signed char *tag,
                        float *item_score, int fresh, const RankFused &F, hipStream_t st);
+// a tile of user sections sharing one pass over the candidate matrix (positions mode, no special samples): per section u the staged
+// words at off[u] are uidx[nu] uval[nu] pos[npos] ban[nban]; its counters / positive scores start at entry pos0[u]
+#define RANK_TILE 8
+struct RankTile { int nsec; int off[RANK_TILE], nu[RANK_TILE], npos[RANK_TILE], nban[RANK_TILE], pos0[RANK_TILE]; };
+void launch_rank_tile_open(const DevParams &P, const unsigned *stage, const RankTile &T, const float *fb_in, float *tu_out, unsigned *banmask,
+                           const unsigned *prev_ban, int nprev, int *cnt, unsigned *flag, long cap, const float *ifT, const float *ibias, float *pos_score,
+                           hipStream_t st);
+void launch_rank_score_tile(const DevParams &P, long n, long cap, const float *tu, const float *ifT, const float *ibias, const unsigned *banmask, float *score,
+                            const unsigned *stage, const RankTile &T, const float *pos_score, int *cnt, hipStream_t st);
 void launch_rank_positions(long n, const float *score, const signed char *tag, const int *pos_item, int npos, int *greater, int *ties, hipStream_t st);
 // radix selection of the K1 smallest (key, value) pairs, ascending (svdf_k_rank.hip): work = rank_select_work_words() words
 // (zeroed by k_rank_user, first histogram filled by the scoring pass: RankFused::hist1 = work), ck / cv = rank_select_cap()

@@ -38,6 +38,7 @@ Ranker::~Ranker() {
 }
 
 void Ranker::set_param(const char *name, const char *val) {   // :656-660
+    if (!strcmp(name, "amd:rank_tile")) tile_enabled_ = atoi(val) != 0;   // extension key: 0 = one scoring pass per section
     if (!strcmp(name, "feature_user") || !strcmp(name, "feature_item")) eng_->set_param(name, val);
     if (!strcmp(name, "top_k")) top_k_ = atoi(val);
 }
@@ -64,6 +65,11 @@ void Ranker::init_ranker(int num_item_set) {                   // :666-685
                               eng_->stream_));
     }
     RCHECK(hipMemsetAsync(d_tag_.p, 0, (size_t)std::max(num_item_set, 1), eng_->stream_));
+    d_banmask_.reserve((size_t)std::max(num_item_set, 1));
+    RCHECK(hipMemsetAsync(d_banmask_.p, 0, (size_t)std::max(num_item_set, 1) * sizeof(unsigned), eng_->stream_));
+    d_tu_tile_.reserve((size_t)RANK_TILE * (pitch + 4));
+    tile_.clear();
+    tile_prev_ban_.clear();
     tag_.assign((size_t)num_item_set, 0);
     tagged_.clear();
     dev_tagged_.clear();
@@ -186,11 +192,91 @@ void Ranker::slot_reserve_back(RankSlot &S, size_t words) {
     RCHECK(hipHostMalloc(reinterpret_cast<void **>(&S.back), S.back_words * sizeof(unsigned), hipHostMallocDefault));
 }
 
+// the staged tile -> ONE pinned upload, the opening kernel (user factors, positives' scores, ban bits, counters), ONE pass over the
+// candidate matrix for all of its sections, ONE readback of the counters; resolved section by section, in order
+void Ranker::flush_tile() {
+    if (tile_.empty()) return;
+    const DevParams &P = eng_->params();
+    hipStream_t st = eng_->stream_;
+    const long n = tile_n_, cap_items = (long)std::max(num_item_set_, 1);
+    if (pending_.size() == RANK_SLOTS) resolve();
+    const int slot = next_slot_;
+    next_slot_ = (next_slot_ + 1) % RANK_SLOTS;
+    RankSlot &L = slots_[slot];
+    if (!L.ev) RCHECK(hipEventCreateWithFlags(&L.ev, hipEventDisableTiming));
+    RankTile T;
+    memset(&T, 0, sizeof(T));
+    T.nsec = (int)tile_.size();
+    size_t words = 0;
+    int totpos = 0;
+    for (int u = 0; u < T.nsec; u++) {
+        const TileSec &S = tile_[(size_t)u];
+        T.off[u] = (int)words; T.nu[u] = (int)S.user_idx.size(); T.npos[u] = (int)S.pos_item.size(); T.nban[u] = (int)S.banned.size(); T.pos0[u] = totpos;
+        words += 2 * S.user_idx.size() + S.pos_item.size() + S.banned.size();
+        totpos += T.npos[u];
+    }
+    const size_t prev_off = words;
+    words += tile_prev_ban_.size();
+    slot_reserve_pin(L, words);
+    {
+        unsigned *w = L.pin;
+        for (const TileSec &S : tile_) {
+            memcpy(w, S.user_idx.data(), S.user_idx.size() * 4); w += S.user_idx.size();
+            memcpy(w, S.user_val.data(), S.user_val.size() * 4); w += S.user_val.size();
+            memcpy(w, S.pos_item.data(), S.pos_item.size() * 4); w += S.pos_item.size();
+            memcpy(w, S.banned.data(), S.banned.size() * 4); w += S.banned.size();
+        }
+        memcpy(w, tile_prev_ban_.data(), tile_prev_ban_.size() * 4);
+    }
+    if (words) RCHECK(hipMemcpyAsync(L.d_stage.p, L.pin, words * sizeof(unsigned), hipMemcpyHostToDevice, st));
+    L.d_cnt.reserve((size_t)2 * std::max(totpos, 1));
+    L.d_flag.reserve(RANK_TILE);
+    L.d_ps.reserve((size_t)std::max(totpos, 1));
+    L.d_score.reserve((size_t)RANK_TILE * (size_t)cap_items);
+    launch_rank_tile_open(P, L.d_stage.p, T, eng_->user_group() ? d_fb_.p : nullptr, d_tu_tile_.p, d_banmask_.p, L.d_stage.p + prev_off, (int)tile_prev_ban_.size(),
+                          L.d_cnt.p, L.d_flag.p, cap_items, d_ift_.p, d_ibias_.p, L.d_ps.p, st);
+    launch_rank_score_tile(P, n, cap_items, d_tu_tile_.p, d_ift_.p, d_ibias_.p, d_banmask_.p, L.d_score.p, L.d_stage.p, T, L.d_ps.p, L.d_cnt.p, st);
+    RCHECK(hipGetLastError());
+    slot_reserve_back(L, (size_t)2 * totpos);
+    RCHECK(hipMemcpyAsync(L.back, L.d_cnt.p, (size_t)2 * totpos * sizeof(int), hipMemcpyDeviceToHost, st));
+    RCHECK(hipEventRecord(L.ev, st));
+    RankPending Q;
+    Q.slot = slot; Q.n = n; Q.nsec = T.nsec;
+    tile_prev_ban_.clear();
+    for (TileSec &S : tile_) {
+        for (int idx : S.banned) tile_prev_ban_.push_back(idx);
+        Q.tile_pos.push_back(std::move(S.pos_item));
+        Q.tile_ban.push_back(std::move(S.banned));
+    }
+    std::sort(tile_prev_ban_.begin(), tile_prev_ban_.end());
+    tile_prev_ban_.erase(std::unique(tile_prev_ban_.begin(), tile_prev_ban_.end()), tile_prev_ban_.end());
+    n_sections_ += T.nsec;
+    n_tiles_++;
+    tile_.clear();
+    pending_.push_back(std::move(Q));
+}
+
 void Ranker::enqueue() {
     rcheck(user_open_, "ranker: PROCESS_TAG without a USER_TAG section");
     const DevParams &P = eng_->params();
     hipStream_t st = eng_->stream_;
     const long n = num_item_processed_;
+    // process_rows, positions mode, no special sample, positives given, nothing new among the candidates: the section joins the tile
+    {
+        bool no_spec = true;
+        for (int v : spec_idx_) no_spec = no_spec && v < 0;
+        const bool tileable = deferred_ && tile_enabled_ && top_k_ <= 0 && no_spec && !pos_item_.empty() && n > 0 && items_on_device_ == n;
+        if (!tile_.empty() && (!tileable || tile_n_ != n)) flush_tile();
+        if (tileable) {
+            TileSec S;
+            S.user_idx = user_idx_; S.user_val = user_val_; S.pos_item = pos_item_;
+            for (int idx : tagged_) if (tag_[(size_t)idx] == -1) S.banned.push_back(idx);
+            tile_n_ = n;
+            tile_.push_back(std::move(S));
+            if ((int)tile_.size() == RANK_TILE) flush_tile();
+            return;
+        }
+    }
     // candidates that arrived since the last section
     if (items_on_device_ < n) {
         w_label_.upload(items_.row_label.data(), items_.row_label.size(), st);
@@ -353,6 +439,34 @@ void Ranker::resolve() {
         C.pending = true;
         C.fut = std::async(std::launch::async, host_sort_section, std::move(score), Q.banned, Q.pos_item, top_k_);
     };
+    if (Q.nsec > 0) {   // a tile: its sections in order, each with its own counters; a tie sends that one section to the host's sort
+        const int *cnt = reinterpret_cast<const int *>(L.back);
+        const long cap_items = (long)std::max(num_item_set_, 1);
+        int p0 = 0;
+        for (int u = 0; u < Q.nsec; u++) {
+            const int npos = (int)Q.tile_pos[(size_t)u].size();
+            RankChunk Cu;
+            bool ties = false;
+            for (int j = 0; j < npos; j++) ties = ties || cnt[(size_t)2 * p0 + npos + j] != 0;
+            if (ties) {
+                std::vector<float> score((size_t)n);
+                RCHECK(hipMemcpyAsync(score.data(), L.d_score.p + (size_t)u * cap_items, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
+                RCHECK(hipStreamSynchronize(st));
+                n_host_sorts_++;
+                size_t running = 0;
+                for (RankChunk &c : chunks_) running += c.pending ? 1 : 0;
+                if (running >= 8)
+                    for (RankChunk &c : chunks_) if (c.pending) { c.vals = c.fut.get(); c.pending = false; break; }
+                Cu.pending = true;
+                Cu.fut = std::async(std::launch::async, host_sort_section, std::move(score), Q.tile_ban[(size_t)u], Q.tile_pos[(size_t)u], top_k_);
+            } else {
+                for (int j = 0; j < npos; j++) Cu.vals.push_back(cnt[(size_t)2 * p0 + j]);
+            }
+            chunks_.push_back(std::move(Cu));
+            p0 += npos;
+        }
+        return;
+    }
     if (Q.take > 0) {
         const size_t take = (size_t)Q.take;
         const unsigned *hk = L.back, *hv = L.back + take;
@@ -382,6 +496,7 @@ void Ranker::flush_chunks() {
 }
 
 void Ranker::drain_quietly() {   // after an error: nothing of the sections in flight is reported
+    tile_.clear();
     (void)hipStreamSynchronize(eng_->stream_);
     pending_.clear();
     for (RankChunk &c : chunks_) if (c.pending) { try { (void)c.fut.get(); } catch (...) {} }
@@ -406,6 +521,7 @@ long Ranker::process_rows(int num_row, const float *row_label, const int *row_pt
             const int p0 = row_ptr[3 * r], p1 = row_ptr[3 * r + 1], p2 = row_ptr[3 * r + 2], p3 = row_ptr[3 * r + 3];
             process(row_label[r], p1 - p0, p2 - p1, p3 - p2, feat_index + p0, feat_value + p0, nullptr, 0);
         }
+        flush_tile();
         while (!pending_.empty()) resolve();
         flush_chunks();
     } catch (...) {

@@ -79,9 +79,21 @@ def main():
     t0 = time.time()
     got = r.process_rows(bulk)
     dt = (time.time() - t0) / max(1, a.sections - 1)
-    out["gpu_bulk"] = {"ms_per_section": dt * 1e3, "sections_per_s": 1.0 / dt, "host_sorts": r.counter(1),
+    out["gpu_bulk"] = {"ms_per_section": dt * 1e3, "sections_per_s": 1.0 / dt, "host_sorts": r.counter(1), "tiles": r.counter(3),
                        "GBps": out["gpu"]["bytes_per_section"] / dt / 1e9, "frac_of_8TBps": out["gpu"]["bytes_per_section"] / dt / 8e12,
                        "identical_to_per_section_calls": bool(np.array_equal(got, res["gpu"]))}
+    # the same call with one scoring pass per section (amd:rank_tile = 0: the round-2 pipeline)
+    r = sa.Ranker(0, 0)
+    r.set_param("amd:rank_tile", "0")
+    r.set_param("top_k", str(a.top_k))
+    r.load_model(path)
+    r.init_ranker(a.cand)
+    r.process_rows(items)
+    r.process_rows(secs[0])
+    t0 = time.time()
+    got1 = r.process_rows(bulk)
+    dt1 = (time.time() - t0) / max(1, a.sections - 1)
+    out["gpu_bulk_untiled"] = {"ms_per_section": dt1 * 1e3, "sections_per_s": 1.0 / dt1, "identical_to_tiled": bool(np.array_equal(got, got1))}
     n = len(res["cpu_port"])
     if a.cpu_sections > 1:
         out["identical_results"] = bool(np.array_equal(res["gpu"][:n], res["cpu_port"]))

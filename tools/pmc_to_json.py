@@ -8,7 +8,10 @@ import re
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-names = {"basicmf": "k_basicmf", "pairwise": "k_fewrow", "svdpp": "k_svdpp_wave", "neighbourhood": "k_fused"}
+names = {"basicmf": "k_basicmf", "pairwise": "k_fewrow", "svdpp": "k_svdpp_wave", "neighbourhood": "k_fused"}   # prefixes the summaries are matched by
+full = {"basicmf": "svdf::k_basicmf_slots<8, 2, G> (G = 1 ... 4 row sets per wave, chosen per launch size; all instantiations pooled)",
+        "pairwise": "svdf::k_fewrow_slots<16, 2, 1, 2>", "svdpp": "svdf::k_svdpp_wave<2, true, true, true, false, 8>",
+        "neighbourhood": "svdf::k_fused<32, 1, 1, 1, true, false>"}   # the names in profiles/r0N_kernel_stats.csv
 out = {}
 for w, kern in names.items():
     cand = glob.glob(os.path.join(src, "*pmc_%s.txt" % w))
@@ -29,7 +32,7 @@ for w, kern in names.items():
         continue
     # MI355X_MICROARCH.md section HBM: FETCH_SIZE/WRITE_SIZE are in KB; on gfx950 FETCH_SIZE reports half the bytes
     # of wide (16 B/lane) coalesced reads -> doubled.  WRITE_SIZE is used as reported.
-    out[w] = {"kernel": kern, "dispatches": nf, "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": wr,
+    out[w] = {"kernel": full[w], "dispatches": nf, "fetch_size_kb_per_launch": f, "write_size_kb_per_launch": wr,
               "hbm_bytes_per_launch": (2 * f + wr) * 1024,
               "tcc_ea_rdreq_per_launch": mean("TCC_EA0_RDREQ_sum")[0], "tcc_ea_wrreq_per_launch": mean("TCC_EA0_WRREQ_sum")[0],
               "tcc_hit_per_launch": mean("TCC_HIT_sum")[0], "tcc_miss_per_launch": mean("TCC_MISS_sum")[0],
