@@ -76,6 +76,7 @@ def main():
     r.process_rows(items)
     r.process_rows(secs[0])
     bulk = sa.CSRData.concat(secs[1:a.sections])
+    r.process_rows(bulk)      # first call: every slot's staging / score buffers are allocated
     t0 = time.time()
     got = r.process_rows(bulk)
     dt = (time.time() - t0) / max(1, a.sections - 1)
@@ -90,6 +91,7 @@ def main():
     r.init_ranker(a.cand)
     r.process_rows(items)
     r.process_rows(secs[0])
+    r.process_rows(bulk)
     t0 = time.time()
     got1 = r.process_rows(bulk)
     dt1 = (time.time() - t0) / max(1, a.sections - 1)
