@@ -622,6 +622,14 @@ def run_f3_secondary(a, env):
     oracle.build()
     log = env["log"]
     out = {}
+    try:   # HBM traffic of the f3 kernels from the builder's PMC passes (tools/r03_pmc_f3.sh), per launch
+        f3_traffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    except Exception:
+        f3_traffic = {}
+
+    def traffic_of(key):
+        v = f3_traffic.get(key)
+        return (v or {}).get("hbm_bytes_per_launch") if isinstance(v, dict) else None
     # ---- evaluator: basicMF shape of the main line, 20 M held-out-style ratings
     n, k = 20_000_000, 64
     rng = np.random.default_rng(31)
@@ -655,7 +663,8 @@ def run_f3_secondary(a, env):
         "value": n / dt, "unit": "instances/s", "ms_per_step": dt * 1e3, "rmse": float(np.sqrt(sse / cnt)),
         "roofline": {"bound": "hbm", "achieved": n * byts / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": n * byts / dt / 1e9 / HBM_PEAK_GBS,
                      "kernel": "k_predict_basic", "algorithmic_bytes_per_instance": byts,
-                     "timing": "host clock around svdf_eval_dataset (one launch + the partial-sum reduction + sync)", "traffic": None},
+                     "timing": "host clock around svdf_eval_dataset (one launch + the partial-sum reduction + sync)",
+                     "traffic": traffic_of("evaluate_k64"), "traffic_source": "profiles/hbm_traffic.json: k_predict_basic over the same 20 M instances, (2*FETCH+WRITE)*1024 per launch"},
         "cpu_baseline": {"value": S / dt_cpu, "unit": "instances/s", "cores": 1, "kind": f3_kind, "sample": "predict of the first %d instances" % S},
         "parity": {"predictions_bit_exact_on_sample": bool(np.array_equal(gpu_pred.view(np.uint32), cpu_pred.view(np.uint32)))}}
     log("f3 evaluate: %.2f G inst/s (%.1f%% of peak), cpu %.2f M inst/s" % (n / dt / 1e9, 100 * out["evaluate_k64"]["roofline"]["frac"], S / dt_cpu / 1e6))
@@ -704,7 +713,9 @@ def run_f3_secondary(a, env):
                          "kernel": "k_rank_score_tile<8> (positions: up to 8 sections per pass over the candidate matrix)" if not top_k else "k_rank_score<8,2>",
                          "algorithmic_bytes_per_section": byts,
                          "timing": "host clock over the whole call / sections: upload, k_rank_user, k_rank_score, selection, readback of every "
-                                   "section (the scoring kernel alone: profiles/r02_ranker_*_kernel_stats.csv)", "traffic": None},
+                                   "section (the scoring kernel alone: profiles/r03_ranker_*)",
+                         "traffic": traffic_of("ranker_k128_positions_tile") if not top_k else None,
+                         "traffic_source": "profiles/hbm_traffic.json: k_rank_score_tile, bytes per launch = per TILE of up to 8 sections" if not top_k else None},
             "cpu_baseline": {"value": 1.0 / dt_cpu, "unit": "user sections/s", "cores": 1, "kind": f3_kind, "sample": "the first %d sections" % ncpu},
             "parity": {"results_identical_on_sample": bool(np.array_equal(got[:len(ref)], ref))}}
         log("f3 ranker top_k=%d: %.1f us/section, cpu %.2f ms/section" % (top_k, dt * 1e6, dt_cpu * 1e3))
