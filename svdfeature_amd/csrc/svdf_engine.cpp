@@ -8,6 +8,7 @@
 #include <cstring>
 #include <memory>
 #include <mutex>
+#include <atomic>
 #include <thread>
 
 #include "svdf_kernels.h"
@@ -970,6 +971,21 @@ static void sort_batches(Schedule &sched, const unsigned *key) {
     for (auto &x : th) x.join();
 }
 
+// fn(a, b) over [0, n) in contiguous chunks on up to 16 host threads (fn must not throw)
+template <typename F>
+static void parallel_rows(long n, F fn) {
+    const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (n < (1 << 18) || hw == 1) { fn(0L, n); return; }
+    std::vector<std::thread> th;
+    const long chunk = (n + hw - 1) / hw;
+    for (unsigned t = 0; t < hw; t++) {
+        const long lo = t * chunk, hi = std::min(n, lo + chunk);
+        if (lo >= hi) break;
+        th.emplace_back([=]() { fn(lo, hi); });
+    }
+    for (auto &x : th) x.join();
+}
+
 template <typename T>
 static void parallel_gather(T *dst, const T *src, const int *order, long n, long stride, long offset) {
     // dst[s] = src[order[s]*stride + offset]
@@ -1813,6 +1829,100 @@ Dataset *Engine::dataset_from_pairs(long n, const unsigned *user, const unsigned
     return ds.release();
 }
 
+// Few-row instances with global features (<= 2 user ids, <= 2 item ids, <= 4 distinct global ids each: the neighbourhood
+// / time-bias shape) scheduled on the device like the triples: the host only spreads the rows into columns (one linear
+// pass), the level assignment (svdf_k_sched.hip, one resource slot per id) and the gathers into level order run in HBM.
+// Returns nullptr when the rows do not fit the shape (the host scheduler takes them).
+Dataset *Engine::dataset_fewrow_on_device(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) {
+    std::atomic<int> amu(0), ami(0), amg(0), fits(1), has_item(1), has_user(1);
+    std::atomic<long> a_nnz(0), a_rows(0), a_bias(0), a_g(0);
+    parallel_rows(n, [&](long lo, long hi) {
+        int mu = 0, mi = 0, mg = 0;
+        bool ok = true, ki = true, ku = true;
+        long nnz = 0, rows = 0, nbias = 0, ngt = 0;
+        for (long r = lo; r < hi && ok; r++) {
+            const int64_t *p = row_ptr + 3 * r;
+            const int ng = (int)(p[1] - p[0]), nu = (int)(p[2] - p[1]), ni = (int)(p[3] - p[2]);
+            if (nu > 2 || ni > 2 || ng > 4) { ok = false; break; }
+            if (nu == 2 && feat_index[p[1]] == feat_index[p[1] + 1]) ok = false;
+            if (ni == 2 && feat_index[p[2]] == feat_index[p[2] + 1]) ok = false;
+            for (int x = 0; x < ng; x++)
+                for (int y = x + 1; y < ng; y++) if (feat_index[p[0] + x] == feat_index[p[0] + y]) ok = false;
+            mu = std::max(mu, nu); mi = std::max(mi, ni); mg = std::max(mg, ng);
+            ki = ki && ni > 0; ku = ku && nu > 0;
+            nnz += ng + nu + ni; ngt += ng; rows += nu + ni; nbias += (mp_.no_user_bias ? 0 : nu) + ni;
+        }
+        if (!ok) fits = 0;
+        if (!ki) has_item = 0;
+        if (!ku) has_user = 0;
+        int v;
+        v = amu.load(); while (mu > v && !amu.compare_exchange_weak(v, mu)) {}
+        v = ami.load(); while (mi > v && !ami.compare_exchange_weak(v, mi)) {}
+        v = amg.load(); while (mg > v && !amg.compare_exchange_weak(v, mg)) {}
+        a_nnz += nnz; a_rows += rows; a_bias += nbias; a_g += ngt;
+    });
+    int mu = amu.load(), mi = ami.load();
+    const int mg = amg.load();
+    if (!fits.load() || mg == 0 || mu + mi + mg > SVDF_SCHED_MAX_SLOTS) return nullptr;
+    if ((sort_batches_ == 1 && !has_item.load()) || (sort_batches_ == 2 && !has_user.load())) return nullptr;
+    mu = std::max(mu, 1); mi = std::max(mi, 1);
+    const long nnz = a_nnz.load(), nrows_touched = a_rows.load(), nbias = a_bias.load(), ng_total = a_g.load();
+    std::vector<unsigned> cu[2], ci[2], cg[4];
+    std::vector<float> vu[2], vi[2], vg[4];
+    for (int a = 0; a < mu; a++) { cu[a].resize((size_t)n); vu[a].resize((size_t)n); }
+    for (int a = 0; a < mi; a++) { ci[a].resize((size_t)n); vi[a].resize((size_t)n); }
+    for (int j = 0; j < 4; j++) { cg[j].resize((size_t)n); vg[j].resize((size_t)n); }
+    parallel_rows(n, [&](long lo, long hi) {
+        for (long r = lo; r < hi; r++) {
+            const int64_t *p = row_ptr + 3 * r;
+            const int ng = (int)(p[1] - p[0]), nu = (int)(p[2] - p[1]), ni = (int)(p[3] - p[2]);
+            for (int j = 0; j < 4; j++) {
+                cg[j][(size_t)r] = j < ng ? feat_index[p[0] + j] : (unsigned)SLOT_ABSENT; vg[j][(size_t)r] = j < ng ? feat_value[p[0] + j] : 0.0f;
+            }
+            for (int j = 0; j < mu; j++) {
+                cu[j][(size_t)r] = j < nu ? feat_index[p[1] + j] : (unsigned)SLOT_ABSENT; vu[j][(size_t)r] = j < nu ? feat_value[p[1] + j] : 0.0f;
+            }
+            for (int j = 0; j < mi; j++) {
+                ci[j][(size_t)r] = j < ni ? feat_index[p[2] + j] : (unsigned)SLOT_ABSENT; vi[j][(size_t)r] = j < ni ? feat_value[p[2] + j] : 0.0f;
+            }
+        }
+    });
+    std::unique_ptr<Dataset> ds(new Dataset());
+    adopt(ds.get()); ds->num_row = n; ds->kind = 2;
+    FusedDev &f = ds->fused;
+    f.max_nu = mu; f.max_ni = mi; f.has_g = true; f.inline_g = true;
+    const int zero = 0;
+    f.gptr.upload(&zero, 1, stream_);   // non-null marks "has global features"; the ids themselves sit in the inline slots
+    std::vector<UCol> uc;
+    std::vector<FCol> fc;
+    int res_col[SVDF_SCHED_MAX_SLOTS];
+    unsigned off[SVDF_SCHED_MAX_SLOTS], limit[SVDF_SCHED_MAX_SLOTS];
+    const char *msg[SVDF_SCHED_MAX_SLOTS];
+    int K = 0, sort_col = -1;
+    for (int a = 0; a < mu; a++) {
+        if (a == 0 && sort_batches_ == 2) sort_col = (int)uc.size();
+        res_col[K] = (int)uc.size(); off[K] = 0u; limit[K] = (unsigned)mp_.num_user; msg[K] = "user feature index exceed bound"; K++;
+        uc.push_back(UCol{cu[a].data(), &f.uidx[a]}); fc.push_back(FCol{vu[a].data(), &f.uval[a]});
+    }
+    for (int a = 0; a < mi; a++) {
+        if (a == 0 && sort_batches_ == 1) sort_col = (int)uc.size();
+        res_col[K] = (int)uc.size(); off[K] = (unsigned)mp_.num_user; limit[K] = (unsigned)mp_.num_item; msg[K] = "item feature index exceed bound"; K++;
+        uc.push_back(UCol{ci[a].data(), &f.iidx[a]}); fc.push_back(FCol{vi[a].data(), &f.ival[a]});
+    }
+    for (int j = 0; j < 4; j++) {
+        if (j < mg) {
+            res_col[K] = (int)uc.size(); off[K] = (unsigned)(mp_.num_user + mp_.num_item); limit[K] = (unsigned)mp_.num_global;
+            msg[K] = "global feature index exceed bound"; K++;
+        }
+        uc.push_back(UCol{cg[j].data(), &f.gsi[j]}); fc.push_back(FCol{vg[j].data(), &f.gsv[j]});
+    }
+    fc.push_back(FCol{row_label, &f.label});
+    schedule_columns_on_device(ds.get(), n, K, res_col, off, limit, msg, sort_col,
+                               sort_col < 0 ? 0u : (sort_batches_ == 1 ? (unsigned)mp_.num_item : (unsigned)mp_.num_user), uc, fc);
+    ds->algorithmic_bytes = 8L * mp_.num_factor * nrows_touched + 8 * nbias + 8 * ng_total + 16 * n + 8 * nnz;
+    return ds.release();
+}
+
 Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
@@ -1823,11 +1933,33 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
     check(row_ptr[3 * n] - p00 < (int64_t)2147483647, "dataset: more than 2^31-1 feature entries");
     bool basic = basic_fast_path_allowed();
     bool unit = true;
-    for (long r = 0; r < n; r++) {
-        const int64_t *p = row_ptr + 3 * r;
-        check(p[0] <= p[1] && p[1] <= p[2] && p[2] <= p[3], "CSR row_ptr must be non-decreasing");
-        check_row((int)(p[1] - p[0]), (int)(p[2] - p[1]), (int)(p[3] - p[2]), feat_index + p[0]);
-        if (basic) basic = (p[1] == p[0]) && (p[2] == p[1] + 1) && (p[3] == p[2] + 1);
+    {   // row checks on several host threads; a failing row is reported by a serial pass (first error in file order)
+        std::atomic<int> bad(0), not_basic(0);
+        auto check_rows = [&](long lo, long hi, bool &is_basic) {
+            for (long r = lo; r < hi; r++) {
+                const int64_t *p = row_ptr + 3 * r;
+                check(p[0] <= p[1] && p[1] <= p[2] && p[2] <= p[3], "CSR row_ptr must be non-decreasing");
+                check_row((int)(p[1] - p[0]), (int)(p[2] - p[1]), (int)(p[3] - p[2]), feat_index + p[0]);
+                if (is_basic) is_basic = (p[1] == p[0]) && (p[2] == p[1] + 1) && (p[3] == p[2] + 1);
+            }
+        };
+        const unsigned lim_g = (unsigned)mp_.num_global, lim_u = (unsigned)mp_.num_user, lim_i = (unsigned)mp_.num_item;
+        parallel_rows(n, [&](long lo, long hi) {   // the same conditions as a predicate (no message, no exit from a thread)
+            bool b = true, ok = true;
+            for (long r = lo; r < hi; r++) {
+                const int64_t *p = row_ptr + 3 * r;
+                ok = ok && p[0] <= p[1] && p[1] <= p[2] && p[2] <= p[3];
+                if (!ok) break;
+                for (int64_t j = p[0]; j < p[1]; j++) ok = ok && feat_index[j] < lim_g;
+                for (int64_t j = p[1]; j < p[2]; j++) ok = ok && feat_index[j] < lim_u;
+                for (int64_t j = p[2]; j < p[3]; j++) ok = ok && feat_index[j] < lim_i;
+                b = b && (p[1] == p[0]) && (p[2] == p[1] + 1) && (p[3] == p[2] + 1);
+            }
+            if (!ok) bad = 1;
+            if (!b) not_basic = 1;
+        });
+        if (bad.load()) { bool b = true; check_rows(0, n, b); }
+        if (not_basic.load()) basic = false;
     }
     if (basic) {
         for (long r = 0; r < n && unit; r++) unit = feat_value[row_ptr[3 * r]] == 1.0f && feat_value[row_ptr[3 * r] + 1] == 1.0f;
@@ -1837,6 +1969,8 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
             return dataset_from_triples(n, u.data(), it.data(), row_label);
         }
     }
+    if (!basic && device_sched_ && n > 0 && fused_allowed() && !user_group() && !relaxed())
+        if (Dataset *d = dataset_fewrow_on_device(n, row_label, row_ptr, feat_index, feat_value)) return d;
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = n;
     std::vector<int> levels((size_t)n);

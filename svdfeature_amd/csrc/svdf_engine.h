@@ -416,6 +416,7 @@ class Engine {
     bool device_rank_ = true;                       // knob "device_rank"
     bool fewrow_fast_ = true;                       // knob "fewrow_fast": specialised few-row kernel (svdf_k_fewrow.hip)
     // columns that are already in HBM (file order) -> level schedule + level-sorted copies
+    Dataset *dataset_fewrow_on_device(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
     struct DUCol { const unsigned *src; DevBuf<unsigned> *dst; };
     struct DFCol { const float *src; DevBuf<float> *dst; };
     void schedule_device_columns(Dataset *ds, long n, int K, const unsigned *const *res_col, const unsigned *off, const unsigned *limit,

@@ -254,7 +254,13 @@ __global__ __launch_bounds__(256) void k_predict_fused(const DevParams P, const 
     const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
     for (long s = gidx; s < n; s += stride) {
         double bs = 0.0;
-        if (S.gptr) for (int j = S.gptr[s]; j < S.gptr[s + 1]; j++) bs += (double)(S.gval[j] * P.g_bias[gpos(P, S.gidx[j])]);
+        if (S.gsi[0]) {   // inline slots hold the instance's global ids in file order
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const unsigned gi = S.gsi[j][s];
+                if (gi != SLOT_ABSENT) bs += (double)(S.gsv[j][s] * P.g_bias[gpos(P, gi)]);
+            }
+        } else if (S.gptr) for (int j = S.gptr[s]; j < S.gptr[s + 1]; j++) bs += (double)(S.gval[j] * P.g_bias[gpos(P, S.gidx[j])]);
         float4 tu = f4zero(), ti = f4zero();
 #pragma unroll
         for (int a = 0; a < NU; a++) {

@@ -146,3 +146,70 @@ def test_staged_windows_scheduled_on_the_device_match_the_oracle(unit_values):
     assert t.counter(3) >= 3   # several windows were flushed
     for name in ("W_user", "W_item", "u_bias", "i_bias"):
         assert np.array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32)), name
+
+
+def _fewrow_global_rows(n, nu, ni, ng, seed, absent=True):
+    """<= 2 user ids, <= 2 item ids, 0..4 distinct global ids per instance, real-valued weights (neighbourhood / time-bias shape)"""
+    rng = np.random.default_rng(seed)
+    rows = []
+    for r in range(n):
+        g = [(int(x), float(np.float32(rng.uniform(-1, 1)))) for x in rng.choice(ng, int(rng.integers(0, 5)), replace=False)]
+        u = [(int(x), float(np.float32(rng.choice([1.0, 0.5, 0.25])))) for x in rng.choice(nu, int(rng.integers(1, 3)), replace=False)]
+        i = [(int(x), float(np.float32(rng.choice([1.0, -1.0, 0.5])))) for x in rng.choice(ni, int(rng.integers(1, 3)), replace=False)]
+        if absent and r % 31 == 7:
+            u = u[:1]
+        rows.append((float(rng.integers(1, 6)), g, u, i))
+    return sa.CSRData.from_rows(rows)
+
+
+@pytest.mark.parametrize("sort_batches", [0, 1, 2])
+@pytest.mark.parametrize("n,nu,ni,ng", [(60_000, 3000, 500, 64), (4000, 30, 20, 6), (2, 5, 5, 5)])
+def test_device_schedule_few_row_instances_with_global_features(n, nu, ni, ng, sort_batches):
+    """Rows with global features (the neighbourhood shape) scheduled on the device (dataset_fewrow_on_device) against the
+    host scheduler: same batches, byte-identical parameters and predictions, both identical to the oracle."""
+    d = _fewrow_global_rows(n, nu, ni, ng, seed=n % 89)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=16, wd_global=0.004)
+    dev, host = _ready(0, 0, conf, 1, sort_batches), _ready(0, 0, conf, 0, sort_batches)
+    dd, dh = dev.dataset_from_csr(d), host.dataset_from_csr(d)
+    assert dd.kind == 2 and dh.kind == 2
+    assert dd.num_batches == dh.num_batches and dd.max_batch == dh.max_batch and dd.num_row == dh.num_row == n
+    o = oracle.OracleTrainer("port", 0, 0)
+    o.seed(10)
+    for k, v in conf:
+        o.set_param(k, v)
+    o.init_model()
+    o.init_trainer()
+    for _ in range(2):
+        dev.train_dataset(dd)
+        host.train_dataset(dh)
+        o.update_batch(d)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "g_bias"):
+        assert np.array_equal(dev.view(name).view(np.uint32), host.view(name).view(np.uint32)), name
+        assert np.array_equal(dev.view(name).view(np.uint32), o.view(name).view(np.uint32)), name
+    assert np.array_equal(dev.predict_dataset(dd).view(np.uint32), o.predict_batch(d).view(np.uint32))
+    assert np.array_equal(host.predict_dataset(dh).view(np.uint32), o.predict_batch(d).view(np.uint32))
+
+
+def test_device_schedule_few_row_shape_limits_fall_back_to_the_host_scheduler():
+    """Five global ids on a row, or a repeated global id, do not fit the inline slots: the host scheduler takes the data set
+    and the result is the oracle's either way."""
+    nu, ni, ng = 200, 80, 12
+    base = _fewrow_global_rows(3000, nu, ni, ng, seed=3)
+    five = sa.CSRData.from_rows([(3.0, [(0, .5), (1, .5), (2, .5), (3, .5), (4, .5)], [(1, 1.0)], [(2, 1.0)])])
+    twice = sa.CSRData.from_rows([(2.0, [(7, .5), (7, .25)], [(3, 1.0)], [(4, 1.0)])])
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=16, wd_global=0.004)
+    for extra in (five, twice):
+        d = sa.CSRData.concat([base, extra])
+        t = _ready(0, 0, conf, 1, 1)
+        ds = t.dataset_from_csr(d)
+        o = oracle.OracleTrainer("port", 0, 0)
+        o.seed(10)
+        for k, v in conf:
+            o.set_param(k, v)
+        o.init_model()
+        o.init_trainer()
+        t.train_dataset(ds)
+        o.update_batch(d)
+        for name in ("W_user", "W_item", "u_bias", "i_bias", "g_bias"):
+            assert np.array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32)), name
+        assert np.array_equal(t.predict_dataset(ds).view(np.uint32), o.predict_batch(d).view(np.uint32))
