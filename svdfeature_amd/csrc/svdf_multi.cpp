@@ -421,6 +421,10 @@ Dataset *Engine::multi_dataset_from_triples(long n, const unsigned *user, const 
 
 Dataset *Engine::multi_dataset_from_csr(long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) {
     const int N = gpus_;
+    for (long r = 0; r < num_row; r++) {   // the sharding below walks the rows before any rank validates them
+        const int64_t *p = &row_ptr[(size_t)3 * r];
+        check(p[0] <= p[1] && p[1] <= p[2] && p[2] <= p[3], "CSR row_ptr must be non-decreasing");
+    }
     // plain (user, item, rating) rows take the three-column path (and with it the window-minibatch step)
     bool triples = multi_minibatch_allowed();
     for (long r = 0; r < num_row && triples; r++) {
