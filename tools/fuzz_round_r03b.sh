@@ -1,0 +1,21 @@
+#!/bin/bash
+# randomised differential run of round 3 (device scheduling of global-feature rows, threaded row checks, ranker tiles): training paths (fresh seeds) + ranker streams;
+# summary -> gpurun_out/fuzz_r03b.txt
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+out=gpurun_out/fuzz_r03b.txt
+: > $out
+for s in $(seq 3111 3130); do python tests/fuzz_parity.py --iters 1250 --seed $s 2>&1 | tail -1 | sed "s/^/seed $s: /" >> $out; done
+for s in 3151 3152; do python tests/fuzz_parity.py --iters 400 --seed $s --big 2>&1 | tail -1 | sed "s/^/seed $s --big: /" >> $out; done
+for s in 3161; do python tests/fuzz_parity.py --iters 400 --seed $s --wide 2>&1 | tail -1 | sed "s/^/seed $s --wide: /" >> $out; done
+for s in $(seq 3171 3173); do python tests/fuzz_ranker.py --iters 1000 --seed $s 2>&1 | tail -3 | sed "s/^/ranker seed $s: /" >> $out; done
+python - <<PY >> $out
+import json, re
+tot = dict(iters=0, exact=0, tolerance=0, skipped=0, failed=0)
+for line in open("$out"):
+    m = re.search(r"(\{.*\})", line)
+    if m and "MISMATCH" not in line:
+        d = json.loads(m.group(1))
+        for k in tot: tot[k] += d.get(k, 0)
+print("TOTAL", json.dumps(tot))
+PY
+tail -4 $out
