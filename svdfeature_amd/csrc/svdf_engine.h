@@ -559,8 +559,8 @@ class Ranker {
     };
     struct RankPending { int slot = 0, npos = 0, take = 0; long n = 0; std::vector<int> pos_item, banned;
                          // a tile of sections sharing one scoring pass (svdf_k_rank.hip: k_rank_score_tile): per section its positives / bans
-                         int nsec = 0; std::vector<std::vector<int>> tile_pos, tile_ban; };
-    struct TileSec { std::vector<unsigned> user_idx; std::vector<float> user_val; std::vector<int> pos_item, banned; };
+                         int nsec = 0; std::vector<std::vector<int>> tile_pos, tile_ban; std::vector<int> tile_take; long out_stride = 0; };
+    struct TileSec { std::vector<unsigned> user_idx; std::vector<float> user_val; std::vector<int> pos_item, banned; int take = 0; };
     std::vector<TileSec> tile_;      // sections staged for the next tile (process_rows, positions mode, no special samples)
     long tile_n_ = 0;                // the candidate count they were staged against
     std::vector<int> tile_prev_ban_; // candidates whose ban bits the previous tile set (cleared by the next tile's opening kernel)

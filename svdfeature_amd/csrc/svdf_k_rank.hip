@@ -290,10 +290,14 @@ __global__ __launch_bounds__(256) void k_rank_score(int k, long n, long cap, con
     }
 }
 
+// (blockIdx.y = section of a tile: keys / work areas of consecutive sections lie key_stride / work_stride words apart; one section: y = 0)
 template <int PASS>
-__global__ __launch_bounds__(256) void k_rsel_hist(long n, const unsigned *keys, unsigned *work, unsigned K1) {
+__global__ __launch_bounds__(256) void k_rsel_hist(long n, const unsigned *keys, unsigned *work, const RselSecs Ks, long key_stride, long work_stride) {
     __shared__ unsigned lh[RSEL_BINS];
     __shared__ unsigned sh[16];
+    keys += (size_t)blockIdx.y * key_stride;
+    work += (size_t)blockIdx.y * work_stride;
+    const unsigned K1 = Ks.K1[blockIdx.y];
     unsigned *hist = work + (PASS - 1) * RSEL_BINS, *state = work + 3 * RSEL_BINS;
     unsigned prefix = 0;
     int shift = 32;   // keys match when key >> shift == prefix
@@ -322,8 +326,13 @@ __global__ __launch_bounds__(256) void k_rsel_hist(long n, const unsigned *keys,
     for (int j = threadIdx.x; j < RSEL_BINS; j += blockDim.x)
         if (lh[j]) atomicAdd(&hist[j], lh[j]);
 }
-__global__ __launch_bounds__(256) void k_rsel_compact(long n, const unsigned *keys, const unsigned *vals, unsigned *work, unsigned *ck, unsigned *cv) {
+__global__ __launch_bounds__(256) void k_rsel_compact(long n, const unsigned *keys, const unsigned *vals, unsigned *work, unsigned *ck, unsigned *cv,
+                                                      long key_stride, long work_stride) {
     __shared__ unsigned sh[16];
+    keys += (size_t)blockIdx.y * key_stride;
+    work += (size_t)blockIdx.y * work_stride;
+    ck += (size_t)blockIdx.y * RSEL_CAP;
+    cv += (size_t)blockIdx.y * RSEL_CAP;
     unsigned *state = work + 3 * RSEL_BINS;
     unsigned b3, K4;
     rsel_find(work + 2 * RSEL_BINS, state[3], sh, b3, K4);
@@ -341,16 +350,22 @@ __global__ __launch_bounds__(256) void k_rsel_compact(long n, const unsigned *ke
             if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&state[4], (unsigned)__popcll(m));
             base = (unsigned)__builtin_amdgcn_readlane((int)base, __ffsll((long long)m) - 1);
             const unsigned pos = base + (unsigned)__popcll(m & ((1ull << lane) - 1ull));
-            if (on && pos < (unsigned)RSEL_CAP) { ck[pos] = key; cv[pos] = vals[i]; }
+            if (on && pos < (unsigned)RSEL_CAP) { ck[pos] = key; cv[pos] = vals ? vals[i] : (unsigned)i; }   // a tile's values are the candidate indices
         }
     }
 }
 // one workgroup: bitonic sort of the appended (key, candidate) pairs, the first K1 written out; more than RSEL_CAP keys <= T
 // (thousands of candidates tied at the threshold) raises flag bit 1: the host's sort takes the section
 // out: K1 keys, K1 candidates, then the section's flag word (1 = a NaN score, 2 = overflow here): ONE readback
-__global__ __launch_bounds__(1024) void k_rsel_sort(const unsigned *work, const unsigned *ck, const unsigned *cv, unsigned K1, unsigned *out,
-                                                    const unsigned *flag) {
+__global__ __launch_bounds__(1024) void k_rsel_sort(const unsigned *work, const unsigned *ck, const unsigned *cv, const RselSecs Ks, unsigned *out,
+                                                    const unsigned *flag, long work_stride, long out_stride) {
     __shared__ unsigned sk[RSEL_CAP], sv[RSEL_CAP];
+    work += (size_t)blockIdx.x * work_stride;   // one workgroup per section
+    ck += (size_t)blockIdx.x * RSEL_CAP;
+    cv += (size_t)blockIdx.x * RSEL_CAP;
+    out += (size_t)blockIdx.x * out_stride;
+    flag += blockIdx.x;
+    const unsigned K1 = Ks.K1[blockIdx.x];
     unsigned *out_keys = out, *out_vals = out + K1;
     const unsigned appended = work[3 * RSEL_BINS + 4];
     if (threadIdx.x == 0) out[2 * K1] = *flag | (appended > (unsigned)RSEL_CAP ? 2u : 0u);
@@ -378,6 +393,26 @@ __global__ __launch_bounds__(1024) void k_rsel_sort(const unsigned *work, const 
         out_keys[i] = i < P ? sk[i] : 0xFFFFFFFFu;
         out_vals[i] = i < P ? sv[i] : 0xFFFFFFFFu;
     }
+}
+
+// top_k on a tile: the sort keys of section blockIdx.y from its score slice and ban bit, and the first histogram of its selection
+__global__ __launch_bounds__(256) void k_rank_tile_keys(long n, long cap, const float *score, const unsigned *banmask, unsigned *keys, unsigned *work,
+                                                        long work_stride, unsigned *flag) {
+    __shared__ unsigned lh[RSEL_BINS];
+    const int u = blockIdx.y;
+    for (int j = threadIdx.x; j < RSEL_BINS; j += blockDim.x) lh[j] = 0;
+    __syncthreads();
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const bool banned = (banmask[i] >> u) & 1u;
+        const unsigned key = rank_sort_key(banned ? 0.0f : score[(size_t)u * cap + i], banned, flag + u);
+        keys[(size_t)u * cap + i] = key;
+        atomicAdd(&lh[key >> 21], 1u);
+    }
+    __syncthreads();
+    unsigned *hist1 = work + (size_t)u * work_stride;
+    for (int j = threadIdx.x; j < RSEL_BINS; j += blockDim.x)
+        if (lh[j]) atomicAdd(&hist1[j], lh[j]);
 }
 
 // rank positions of the positive samples (:777-784): position = number of ranked candidates with a strictly higher score;
@@ -635,10 +670,28 @@ void launch_rank_select(long n, const unsigned *keys, const unsigned *vals, unsi
                         const unsigned *flag, hipStream_t st) {
     long grid = (n + 255) / 256;
     if (grid > 256) grid = 256;
-    hipLaunchKernelGGL((k_rsel_hist<2>), dim3((int)grid), dim3(256), 0, st, n, keys, work, K1);
-    hipLaunchKernelGGL((k_rsel_hist<3>), dim3((int)grid), dim3(256), 0, st, n, keys, work, K1);
-    hipLaunchKernelGGL(k_rsel_compact, dim3((int)grid), dim3(256), 0, st, n, keys, vals, work, ck, cv);
-    hipLaunchKernelGGL(k_rsel_sort, dim3(1), dim3(1024), 0, st, work, ck, cv, K1, out, flag);
+    RselSecs Ks = {};
+    Ks.K1[0] = K1;
+    hipLaunchKernelGGL((k_rsel_hist<2>), dim3((int)grid), dim3(256), 0, st, n, keys, work, Ks, 0L, 0L);
+    hipLaunchKernelGGL((k_rsel_hist<3>), dim3((int)grid), dim3(256), 0, st, n, keys, work, Ks, 0L, 0L);
+    hipLaunchKernelGGL(k_rsel_compact, dim3((int)grid), dim3(256), 0, st, n, keys, vals, work, ck, cv, 0L, 0L);
+    hipLaunchKernelGGL(k_rsel_sort, dim3(1), dim3(1024), 0, st, work, ck, cv, Ks, out, flag, 0L, 0L);
+}
+// The same selection for the nsec sections of a tile at once (grid y = section): keys from the tile's score slices (score[u * cap + i],
+// bit u of banmask[i] = banned), the Ks.K1[u] smallest (key, candidate) pairs of section u ascending, then its flag word, at
+// out + u * out_stride.  keys: nsec * cap words; work: nsec * rank_select_work_words() words, ZEROED by the caller; ck / cv: nsec *
+// rank_select_cap() words each; flag: one word per section (zeroed by k_rank_tile_open).
+void launch_rank_select_tile(long n, long cap, int nsec, const float *score, const unsigned *banmask, const RselSecs &Ks, unsigned *keys, unsigned *work,
+                             unsigned *ck, unsigned *cv, unsigned *out, long out_stride, unsigned *flag, hipStream_t st) {
+    if (n <= 0 || nsec <= 0) return;
+    const long ww = rank_select_work_words();
+    hipLaunchKernelGGL(k_rank_tile_keys, dim3((unsigned)((n + 255) / 256), (unsigned)nsec), dim3(256), 0, st, n, cap, score, banmask, keys, work, ww, flag);
+    long grid = (n + 255) / 256;
+    if (grid > 128) grid = 128;
+    hipLaunchKernelGGL((k_rsel_hist<2>), dim3((int)grid, (unsigned)nsec), dim3(256), 0, st, n, keys, work, Ks, cap, ww);
+    hipLaunchKernelGGL((k_rsel_hist<3>), dim3((int)grid, (unsigned)nsec), dim3(256), 0, st, n, keys, work, Ks, cap, ww);
+    hipLaunchKernelGGL(k_rsel_compact, dim3((int)grid, (unsigned)nsec), dim3(256), 0, st, n, keys, (const unsigned *)nullptr, work, ck, cv, cap, ww);
+    hipLaunchKernelGGL(k_rsel_sort, dim3((unsigned)nsec), dim3(1024), 0, st, work, ck, cv, Ks, out, flag, ww, out_stride);
 }
 int sqerr_partials_grid(long n) {
     long grid = (n + 255) / 256;

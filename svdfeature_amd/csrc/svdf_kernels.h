@@ -82,6 +82,9 @@ void launch_rank_tile_open(const DevParams &P, const unsigned *stage, const Rank
                            hipStream_t st);
 void launch_rank_score_tile(const DevParams &P, long n, long cap, const float *tu, const float *ifT, const float *ibias, const unsigned *banmask, float *score,
                             const unsigned *stage, const RankTile &T, const float *pos_score, int *cnt, hipStream_t st);
+struct RselSecs { unsigned K1[RANK_TILE]; };
+void launch_rank_select_tile(long n, long cap, int nsec, const float *score, const unsigned *banmask, const RselSecs &Ks, unsigned *keys, unsigned *work,
+                             unsigned *ck, unsigned *cv, unsigned *out, long out_stride, unsigned *flag, hipStream_t st);
 void launch_rank_positions(long n, const float *score, const signed char *tag, const int *pos_item, int npos, int *greater, int *ties, hipStream_t st);
 // radix selection of the K1 smallest (key, value) pairs, ascending (svdf_k_rank.hip): work = rank_select_work_words() words
 // (zeroed by k_rank_user, first histogram filled by the scoring pass: RankFused::hist1 = work), ck / cv = rank_select_cap()

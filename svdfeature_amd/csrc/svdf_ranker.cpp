@@ -237,11 +237,30 @@ void Ranker::flush_tile() {
                           L.d_cnt.p, L.d_flag.p, cap_items, d_ift_.p, d_ibias_.p, L.d_ps.p, st);
     launch_rank_score_tile(P, n, cap_items, d_tu_tile_.p, d_ift_.p, d_ibias_.p, d_banmask_.p, L.d_score.p, L.d_stage.p, T, L.d_ps.p, L.d_cnt.p, st);
     RCHECK(hipGetLastError());
-    slot_reserve_back(L, (size_t)2 * totpos);
-    RCHECK(hipMemcpyAsync(L.back, L.d_cnt.p, (size_t)2 * totpos * sizeof(int), hipMemcpyDeviceToHost, st));
-    RCHECK(hipEventRecord(L.ev, st));
     RankPending Q;
     Q.slot = slot; Q.n = n; Q.nsec = T.nsec;
+    if (top_k_ > 0) {
+        // top_k: the radix selection of every section of the tile in one set of launches (grid y = section), ONE readback
+        RselSecs Ks;
+        memset(&Ks, 0, sizeof(Ks));
+        for (int u = 0; u < T.nsec; u++) Ks.K1[u] = (unsigned)tile_[(size_t)u].take;
+        const size_t ww = (size_t)rank_select_work_words(), rc = (size_t)rank_select_cap();
+        const size_t out_stride = (size_t)2 * ((size_t)top_k_ + 1) + 1;
+        d_keys_.reserve((size_t)RANK_TILE * (size_t)cap_items);
+        d_sel_.reserve((size_t)RANK_TILE * (ww + 2 * rc + out_stride));
+        unsigned *work = d_sel_.p, *ck = work + RANK_TILE * ww, *cv = ck + RANK_TILE * rc, *res = cv + RANK_TILE * rc;
+        RCHECK(hipMemsetAsync(work, 0, (size_t)T.nsec * ww * sizeof(unsigned), st));
+        launch_rank_select_tile(n, cap_items, T.nsec, L.d_score.p, d_banmask_.p, Ks, d_keys_.p, work, ck, cv, res, (long)out_stride, L.d_flag.p, st);
+        RCHECK(hipGetLastError());
+        slot_reserve_back(L, (size_t)T.nsec * out_stride);
+        RCHECK(hipMemcpyAsync(L.back, res, (size_t)T.nsec * out_stride * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        Q.out_stride = (long)out_stride;
+        for (int u = 0; u < T.nsec; u++) Q.tile_take.push_back(tile_[(size_t)u].take);
+    } else {
+        slot_reserve_back(L, (size_t)2 * totpos);
+        RCHECK(hipMemcpyAsync(L.back, L.d_cnt.p, (size_t)2 * totpos * sizeof(int), hipMemcpyDeviceToHost, st));
+    }
+    RCHECK(hipEventRecord(L.ev, st));
     tile_prev_ban_.clear();
     for (TileSec &S : tile_) {
         for (int idx : S.banned) tile_prev_ban_.push_back(idx);
@@ -265,11 +284,18 @@ void Ranker::enqueue() {
     {
         bool no_spec = true;
         for (int v : spec_idx_) no_spec = no_spec && v < 0;
-        const bool tileable = deferred_ && tile_enabled_ && top_k_ <= 0 && no_spec && !pos_item_.empty() && n > 0 && items_on_device_ == n;
+        // ... or top_k mode with a prefix short enough for the radix selection (the positives play no part in a top_k answer, :768-775)
+        const long nranked_t = n - n_banned_;
+        const long take_t = top_k_ > 0 ? std::min<long>(nranked_t, (long)top_k_ + 1) : 0;
+        const bool tile_pos = top_k_ <= 0 && !pos_item_.empty();
+        const bool tile_top = top_k_ > 0 && nranked_t >= (long)top_k_ && take_t <= rank_select_cap() / 2;
+        const bool tileable = deferred_ && tile_enabled_ && (tile_pos || tile_top) && no_spec && n > 0 && items_on_device_ == n;
         if (!tile_.empty() && (!tileable || tile_n_ != n)) flush_tile();
         if (tileable) {
             TileSec S;
-            S.user_idx = user_idx_; S.user_val = user_val_; S.pos_item = pos_item_;
+            S.user_idx = user_idx_; S.user_val = user_val_;
+            if (tile_pos) S.pos_item = pos_item_;
+            S.take = (int)take_t;
             for (int idx : tagged_) if (tag_[(size_t)idx] == -1) S.banned.push_back(idx);
             tile_n_ = n;
             tile_.push_back(std::move(S));
@@ -447,6 +473,13 @@ void Ranker::resolve() {
             const int npos = (int)Q.tile_pos[(size_t)u].size();
             RankChunk Cu;
             bool ties = false;
+            if (!Q.tile_take.empty()) {   // top_k: the selected prefix decides unless scores tie inside it, a score is NaN, or the selection overflowed
+                const size_t take = (size_t)Q.tile_take[(size_t)u];
+                const unsigned *hk = L.back + (size_t)u * (size_t)Q.out_stride, *hv = hk + take;
+                ties = hk[2 * take] != 0;
+                for (size_t j = 0; j + 1 < take; j++) ties = ties || hk[j] == hk[j + 1];
+                if (!ties) for (int k = 0; k < top_k_; k++) Cu.vals.push_back((int)hv[(size_t)k]);
+            }
             for (int j = 0; j < npos; j++) ties = ties || cnt[(size_t)2 * p0 + npos + j] != 0;
             if (ties) {
                 std::vector<float> score((size_t)n);

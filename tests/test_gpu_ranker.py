@@ -140,8 +140,8 @@ def test_ranker_bulk_rows_pipelined_equals_line_by_line(top_k, spec, tmp_path):
         if name != "oracle":
             assert r.counter(0) == 100
             hosted[name] = r.counter(1)
-            # positions mode without special samples: the bulk call scores a TILE of sections per pass over the candidate matrix
-            assert (r.counter(3) >= 12) == (name == "bulk" and top_k == 0 and not spec), r.counter(3)
+            # without special samples the bulk call scores a TILE of sections per pass over the candidate matrix (positions and top_k alike)
+            assert (r.counter(3) >= 12) == (name == "bulk" and not spec), r.counter(3)
     np.testing.assert_array_equal(outs["lines"], outs["oracle"])
     np.testing.assert_array_equal(outs["bulk"], outs["oracle"])
     assert hosted["bulk"] == hosted["lines"]   # the same sections needed the reference's sort either way
@@ -149,8 +149,9 @@ def test_ranker_bulk_rows_pipelined_equals_line_by_line(top_k, spec, tmp_path):
 
 def test_ranker_tiles_equal_one_pass_per_section(tmp_path):
     """k_rank_score_tile (up to 8 user sections per pass over the candidate matrix) against one pass per section (amd:rank_tile = 0) and the
-    C oracle: 300 sections with 0 ... 6 positives and bans each, k = 5, 64, 300 (ragged tail / full rows / wide rows), odd tile remainders"""
-    for k, nsec in ((5, 37), (64, 300), (300, 21)):
+    C oracle: 300 sections with 0 ... 6 positives and bans each, k = 5, 64, 300 (ragged tail / full rows / wide rows), odd tile remainders;
+    positions mode and top_k mode (the radix selection of all sections of a tile in one set of launches)"""
+    for k, nsec, top_k in ((5, 37, 0), (64, 300, 0), (300, 21, 0), (64, 300, 10), (5, 37, 1), (128, 45, 40)):
         nu, ni, ng = 150, 900, 3
         conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=k, ui_init_sigma=0.1)
         t = oracle.OracleTrainer("port", 0, 0)
@@ -168,7 +169,7 @@ def test_ranker_tiles_equal_one_pass_per_section(tmp_path):
             r = oracle.OracleRanker("port", 0, 0) if name == "oracle" else sa.Ranker(0, 0)
             if tile is not None:
                 r.set_param("amd:rank_tile", str(tile))
-            r.set_param("top_k", "0")
+            r.set_param("top_k", str(top_k))
             r.load_model(path)
             r.init_ranker(items.num_row)
             outs[name] = r.process_rows(stream) if name != "oracle" else np.concatenate([r.process(*stream.row(i)) for i in range(stream.num_row)])
