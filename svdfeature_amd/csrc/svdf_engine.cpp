@@ -251,6 +251,10 @@ Engine::~Engine() {
             worker_.join();
         }
         (void)hipStreamSynchronize(stream_);
+        for (int b = 0; b < 2; b++) {
+            if (save_pin_[b]) (void)hipHostFree(save_pin_[b]);
+            if (save_ev_[b]) (void)hipEventDestroy(save_ev_[b]);
+        }
         if (owns_stream_) (void)hipStreamDestroy(stream_);
     }
 }
@@ -440,6 +444,62 @@ void Engine::write_model(FILE *fo) {
         save_2d(fo, hW_.data(), mp_.num_ufeedback, k, pitch_);
     }
 }
+// The same file straight from the device model (no 282 MB host mirror for a 1 M x 64 user table): the tables travel in chunks through two
+// pinned buffers, chunk c+1 is copied out while chunk c goes to the file.  Rows are compacted by the copy itself (2-D copy: k floats
+// of every pitch_-float row), so the file bytes are write_model's.
+void Engine::dev_to_file(FILE *fo, const float *dsrc, long rows, long cols, long pitch) {
+    if (rows <= 0 || cols <= 0) return;
+    const size_t cap = (size_t)8 << 20;   // floats per buffer (32 MB)
+    if (!save_pin_[0]) {
+        for (int b = 0; b < 2; b++) {
+            HIPCHECK(hipHostMalloc(reinterpret_cast<void **>(&save_pin_[b]), cap * sizeof(float), hipHostMallocDefault));
+            HIPCHECK(hipEventCreateWithFlags(&save_ev_[b], hipEventDisableTiming));
+        }
+    }
+    check((size_t)cols <= cap, "save_model: a row wider than the staging buffer");
+    const long per = std::max<long>(1, (long)(cap / (size_t)cols));
+    long prev_rows = 0;
+    int c = 0;
+    for (long r0 = 0; r0 < rows || prev_rows > 0; r0 += per, c++) {
+        const long nr = r0 < rows ? std::min(per, rows - r0) : 0;
+        if (nr > 0) {
+            float *dst = save_pin_[c & 1];
+            if (cols == pitch) HIPCHECK(hipMemcpyAsync(dst, dsrc + (size_t)r0 * pitch, (size_t)nr * cols * sizeof(float), hipMemcpyDeviceToHost, stream_));
+            else HIPCHECK(hipMemcpy2DAsync(dst, (size_t)cols * sizeof(float), dsrc + (size_t)r0 * pitch, (size_t)pitch * sizeof(float), (size_t)cols * sizeof(float),
+                                           (size_t)nr, hipMemcpyDeviceToHost, stream_));
+            HIPCHECK(hipEventRecord(save_ev_[c & 1], stream_));
+        }
+        if (prev_rows > 0) {
+            HIPCHECK(hipEventSynchronize(save_ev_[(c - 1) & 1]));
+            fwrite(save_pin_[(c - 1) & 1], sizeof(float), (size_t)prev_rows * cols, fo);
+        }
+        prev_rows = nr;
+    }
+}
+void Engine::write_model_from_device(FILE *fo) {
+    const int k = mp_.num_factor;
+    auto d1 = [&](const float *d, int n) { fwrite(&n, sizeof(int), 1, fo); dev_to_file(fo, d, n, 1, 1); };
+    auto d2 = [&](const float *d, int rows) { int hdr[2] = {k, rows}; fwrite(hdr, sizeof(int), 2, fo); dev_to_file(fo, d, rows, k, pitch_); };
+    fwrite(&mp_, sizeof(ModelParam), 1, fo);
+    if (mp_.common_latent_space == 0) {
+        d1(dbias_.p + user_off_, mp_.num_user);
+        d2(dW_.p + (size_t)user_off_ * pitch_, mp_.num_user);
+        d1(dbias_.p + item_off_, mp_.num_item);
+        d2(dW_.p + (size_t)item_off_ * pitch_, mp_.num_item);
+    } else {
+        d1(dbias_.p, (int)n_uiset_);
+        d2(dW_.p, (int)n_uiset_);
+    }
+    {   // globals: a few words (strided on the device in the relaxed mode): through the host vector
+        hg_.resize((size_t)mp_.num_global);
+        if (!hg_.empty()) { download_globals(hg_.data()); HIPCHECK(hipStreamSynchronize(stream_)); }
+        save_1d(fo, hg_.data(), mp_.num_global);
+    }
+    if (user_group() && mp_.common_feedback_space == 0) {
+        d1(dbias_.p, mp_.num_ufeedback);
+        d2(dW_.p, mp_.num_ufeedback);
+    }
+}
 void Engine::read_model(FILE *fi) {
     if (fread(&mp_, sizeof(ModelParam), 1, fi) == 0) fail("error loading CF SVD model");
     alloc_host_model();
@@ -479,9 +539,15 @@ void Engine::load_model(FILE *fi) {  // apex_svd_base.h:138-140
 void Engine::save_model(FILE *fo) {  // apex_svd_base.h:142-144
     ScopedNs timer(ns_model_);
     check(space_allocated_, "save_model: model is not initialised");
-    if (device_model_) { flush(); if (multi_) multi_gather_user_rows(); download_model(); }
-    check(host_model_valid_, "save_model: no model");
-    write_model(fo);
+    if (device_model_) {
+        flush();
+        if (multi_) multi_gather_user_rows();
+        need_device("saving the model");
+        write_model_from_device(fo);
+    } else {
+        check(host_model_valid_, "save_model: no model");
+        write_model(fo);
+    }
     if (bilinear()) {   // BModel::save_to_file (apex_svd_bilinear.h:60-63, :198-201).  W_bi is inert: SVDPPFeature::update binds its OWN
         // non-virtual prepare_ufeedback (apex_svd_base.h:523,571), so the derived one that would fill up_index never runs and
         // get_bias_plugin / update_bias_plugin (:133-162) loop over nothing -- training is SVDPPFeature's, W_bi rides along

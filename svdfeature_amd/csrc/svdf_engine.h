@@ -512,6 +512,10 @@ class Engine {
     void predict_csr_batch_local(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value, float *out);
     // ---- counters
     int64_t n_instances_ = 0, n_launches_ = 0, n_batches_ = 0, n_flushes_ = 0;
+    float *save_pin_[2] = {nullptr, nullptr};   // save_model: pinned double buffer of the device -> file pipeline
+    hipEvent_t save_ev_[2] = {nullptr, nullptr};
+    void dev_to_file(FILE *fo, const float *dsrc, long rows, long cols, long pitch);
+    void write_model_from_device(FILE *fo);
     int64_t ns_flush_ = 0, ns_model_ = 0;   // host-side time accounting (SVDF_PROFILE=1 prints it)
     int64_t n_device_rank_passes_ = 0;
     int64_t n_kind_[3] = {0, 0, 0};   // launches of k_basicmf / k_general / k_fused
