@@ -188,6 +188,54 @@ def workload_conf(name, a, factor):
     raise ValueError(name)
 
 
+PMC_KERNEL = {"basicmf": "k_basicmf", "pairwise": "k_fewrow", "svdpp": "k_svdpp_wave", "neighbourhood": "k_fused"}
+
+
+def measure_traffic(name, a, log):
+    """--pmc: HBM bytes per launch of the workload's dominant kernel, measured NOW: two rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE,
+    then WRITE_SIZE: the TCC block cannot hold both, MI355X_MICROARCH.md) over one pass of the same workload in a child process of this
+    script; (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch -- the correction the guide prescribes for gfx950, checked on known byte
+    counts in this engine's access patterns by tools/pmc_calib (profiles/r03_pmc_calibration.txt).  None when rocprofv3 is missing or fails."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, None
+    per = {}
+    size_args = {"basicmf": ["--ratings", str(a.ratings)], "pairwise": ["--pairs", str(a.pairs)],
+                 "svdpp": ["--svdpp-users", str(a.svdpp_users), "--svdpp-per-user", str(a.svdpp_per_user)],
+                 "neighbourhood": ["--neighbour-rows", str(a.neighbour_rows), "--globals", str(a.globals)]}[name]
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="svdf_pmc_", dir="/tmp")
+        cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
+               "--workload", name, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--secondary", "", "--users", str(a.users), "--items", str(a.items)] + size_args
+        if a.factor and name == a.workload:   # secondary workloads run at their own configured width (128), like in this process
+            cmd += ["--factor", str(a.factor)]
+        env = dict(os.environ, TMPDIR="/tmp")
+        try:
+            p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                p.wait(timeout=600)
+            except subprocess.TimeoutExpired:
+                os.killpg(p.pid, signal.SIGKILL)   # exactly the group this call started
+                p.wait()
+                return None, None
+            tot, cnt = 0.0, 0
+            for f in glob.glob(out + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if PMC_KERNEL[name] in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                        tot += float(r["Counter_Value"]); cnt += 1
+            if cnt == 0:
+                return None, None
+            per[counter] = (tot / cnt, cnt)
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+    traffic = (2.0 * per["FETCH_SIZE"][0] + per["WRITE_SIZE"][0]) * 1024.0
+    log("%s: PMC passes: FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB per launch over %d launches -> %.3f MB per launch" % (
+        name, per["FETCH_SIZE"][0], per["WRITE_SIZE"][0], per["FETCH_SIZE"][1], traffic / 1e6))
+    return traffic, ("measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over one pass of this workload "
+                     "in a child process, kernels matching '%s', %d launches; (2*FETCH_SIZE + WRITE_SIZE)*1024 per launch" % (PMC_KERNEL[name], per["FETCH_SIZE"][1]))
+
+
 class HipEvents:
     """HIP events recorded on the engine's own stream (torch.cuda.Event only sees torch's stream)."""
 
@@ -561,6 +609,8 @@ def run_workload(name, a, env, steps, warmup, main_line):
                 traffic_src = "profiles/hbm_traffic.json (builder's rocprofv3 PMC run of this command, not measured in this run)"
             except Exception:
                 traffic = None
+        if world == 1 and not exchanging and getattr(a, "pmc_results", {}).get(name, (None, None))[0] is not None:
+            traffic, traffic_src = a.pmc_results[name]
         res = {
             "value": value, "unit": unit, "ms_per_step": elapsed * 1e3 / steps,
             "workload": {"basicmf": "basicMF synthetic %dx%d, %d ratings, k=%d fp32 (BASELINE configs[%d])" % (a.users, a.items, n, factor, 1 if world == 1 else 2),
@@ -775,6 +825,8 @@ def main():
     ap.add_argument("--groups-per-wave", type=int, default=0)
     ap.add_argument("--knob", action="append", default=[], help="extra tuning knob name=value (svdf_set_knob), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pmc", action="store_true",
+                    help="measure roofline.traffic in this run (two extra rocprofv3 --pmc passes per workload, ~1 min each) instead of quoting profiles/hbm_traffic.json")
     ap.add_argument("--secondary", default="auto", help="comma list of secondary workloads for the N=1 line (auto = all three with the default main line, none otherwise)")
     ap.add_argument("--secondary-steps", type=int, default=2)
     ap.add_argument("--defer-tails", type=float, default=0.05,
@@ -805,6 +857,15 @@ def main():
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
+    a.pmc_results = {}
+    if a.pmc and world == 1 and not a.force_exchange:
+        # before this process opens the device, so that the counted child is alone on the GPU (the same commands as tools/profile_round3.sh)
+        sec0 = a.secondary
+        if sec0 == "auto":
+            sec0 = "pairwise,svdpp,neighbourhood" if (a.workload == "basicmf" and a.ratings == 100_000_000) else ""
+        for nm in [a.workload] + [x for x in sec0.split(",") if x and x != a.workload]:
+            if nm in PMC_KERNEL:
+                a.pmc_results[nm] = measure_traffic(nm, a, log)
     import torch
     import svdfeature_amd as sa   # noqa: F401  (fails loudly when the HIP library is missing: there is no CPU fallback)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
