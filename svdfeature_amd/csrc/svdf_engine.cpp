@@ -1810,7 +1810,7 @@ Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsign
 Dataset *Engine::dataset_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg) {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
-    check(!multi_, "svdfeature_amd: rank pairs on an amd:gpus > 1 handle: hand them over as rows (svdf_dataset_from_csr) or shard them through svdfeature_amd.multi_gpu");
+    if (multi_ && !in_multi_scope()) return multi_dataset_from_pairs(n, user, pos, neg);
     if (device_sched_ && n > 0 && fused_allowed() && !user_group() && !relaxed()) {
         // everything on the device: the three columns go up as they are, the schedule columns (lower / higher item id, signs)
         // are formed there, ids are checked by the scheduling pass, pos == neg by the preparation kernel

@@ -493,6 +493,7 @@ class Engine {
     void multi_window(const std::function<void(int, Engine *)> &train, bool minibatch, Dataset *const *mb);
     bool multi_minibatch_allowed() const;
     Dataset *multi_dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
+    Dataset *multi_dataset_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg);
     Dataset *multi_dataset_from_csr(long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
     Dataset *multi_dataset_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
                                        const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,

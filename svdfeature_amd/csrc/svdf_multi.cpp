@@ -419,6 +419,45 @@ Dataset *Engine::multi_dataset_from_triples(long n, const unsigned *user, const 
     return ds.release();
 }
 
+// Rank pairs (user, positive, negative) on the handle (BASELINE configs[4]): sharded by user, cut into windows at global positions, every
+// (rank, window) piece a window data set with two signed item entries per pair (svdf_k_window.hip) -- the window-minibatch step only.
+Dataset *Engine::multi_dataset_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg) {
+    const int N = gpus_;
+    check(multi_minibatch_allowed(), "svdfeature_amd: rank pairs on an amd:gpus > 1 handle train with the window-minibatch step (amd:step = minibatch, "
+                                     "random-order trainer without side tables or relaxed ids); hand them over as rows (svdf_dataset_from_csr) otherwise");
+    for (long r = 0; r < n; r++) {
+        if (user[r] >= (unsigned)mp_.num_user) fail("user feature index exceed bound");
+        if (pos[r] >= (unsigned)mp_.num_item || neg[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound");
+        if (pos[r] == neg[r]) fail("dataset_from_pairs: positive and negative item of a pair must differ");
+    }
+    flush();
+    MultiScope local;
+    std::unique_ptr<Dataset> ds(new Dataset());
+    adopt(ds.get()); ds->num_row = n; ds->kind = 6;
+    ds->m_minibatch = true;
+    std::vector<long> cnt((size_t)mp_.num_item, 0);
+    for (long r = 0; r < n; r++) { cnt[pos[r]]++; cnt[neg[r]]++; }
+    const long W = multi_windows_for(n, cnt);
+    ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
+    for (long w = 0; w < W; w++) {
+        const long b0 = n * w / W, b1 = n * (w + 1) / W;
+        std::vector<std::vector<unsigned>> cu((size_t)N), cp((size_t)N), cq((size_t)N);
+        for (long r = b0; r < b1; r++) {
+            const size_t d = (size_t)(user[r] % (unsigned)N);
+            cu[d].push_back(user[r]); cp[d].push_back(pos[r]); cq[d].push_back(neg[r]);
+        }
+        multi_->pool->run([&](int d) {
+            ds->mchild[(size_t)d][(size_t)w] = rank_engine(d)->dataset_window_from_pairs((long)cu[(size_t)d].size(), cu[(size_t)d].data(), cp[(size_t)d].data(), cq[(size_t)d].data());
+        });
+    }
+    MCHECK(hipSetDevice(device_));
+    ds->sched.level_ptr = {0, n};
+    ds->sched.max_level_size = n;
+    const long nb = (mp_.no_user_bias ? 0 : 1) + 2;
+    ds->algorithmic_bytes = n * (8L * mp_.num_factor * 3 + 8 * nb + 16 + 8 * 3);
+    return ds.release();
+}
+
 Dataset *Engine::multi_dataset_from_csr(long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) {
     const int N = gpus_;
     for (long r = 0; r < num_row; r++) {   // the sharding below walks the rows before any rank validates them

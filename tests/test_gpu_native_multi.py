@@ -271,3 +271,45 @@ def test_virtual_ranks_with_global_features_and_ragged_rows():
     for rk in range(world):
         own = (np.arange(nu) % world) == rk
         np.testing.assert_array_equal(wu[own].view(np.uint32), ranks[rk].view("W_user")[own].view(np.uint32))
+
+
+@pytest.mark.parametrize("world,windows,k", [(2, 4, 16), (3, 5, 128), (8, 2, 64)])
+def test_rank_pairs_as_a_resident_data_set_of_the_handle(world, windows, k):
+    """BASELINE configs[4] on an amd:gpus handle: svdf_dataset_from_pairs shards the pairs by user and cuts them into exchange windows;
+    every (rank, window) piece trains with the window-minibatch step (two signed item entries per pair) -- bit for bit the oracle-backed
+    simulation, predictions routed to the owners"""
+    from svdfeature_amd.multi_gpu import Pairs
+    nu, ni, n, passes = 1200, 300, 40000, 2
+    u, p, q = cases.planted_pairs(n, nu, ni, seed=k)
+    conf = cases.conf_with(cases.PAIR_CONF, num_user=nu, num_item=ni, num_factor=k, learning_rate=0.05, ui_init_sigma=0.1)
+    t = sa.Trainer(0, 3)
+    t.seed(10)
+    for kk, v in list(conf) + [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows)]:
+        t.set_param(kk, str(v))
+    t.init_model()
+    t.init_trainer()
+    ds = t.dataset_from_pairs(u, p, q)
+    assert ds.kind == 6 and ds.num_row == n
+    for _ in range(passes):
+        t.train_dataset(ds)
+        t.finish_round()
+    assert t.counter(8) == passes * windows and t.counter(11) == passes * windows
+    sim = simulate(conf, Pairs(u, p, q), None, None, world, windows, passes, active=3, minibatch=True)
+    for name in ("W_item", "i_bias"):
+        np.testing.assert_array_equal(t.view(name).view(np.uint32), sim[0].t.view(name).view(np.uint32))
+    wu = t.view("W_user")
+    for rk in range(world):
+        own = (np.arange(nu) % world) == rk
+        np.testing.assert_array_equal(wu[own].view(np.uint32), sim[rk].t.view("W_user")[own].view(np.uint32))
+    with pytest.raises(sa.SvdfError, match="must differ"):
+        t.dataset_from_pairs(u[:4], p[:4], p[:4])
+    ds.close()
+    # the exact level scheme has no pair entry point on the handle: the refusal says where to go
+    t2 = sa.Trainer(0, 3)
+    t2.seed(10)
+    for kk, v in list(conf) + [("amd:gpus", 2), ("amd:step", "levels")]:
+        t2.set_param(kk, str(v))
+    t2.init_model()
+    t2.init_trainer()
+    with pytest.raises(sa.SvdfError, match="window-minibatch step"):
+        t2.dataset_from_pairs(u, p, q)
