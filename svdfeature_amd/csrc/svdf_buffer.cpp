@@ -275,7 +275,8 @@ Dataset *Engine::dataset_from_buffer_file(const char *path, int user_group_forma
 Dataset *Engine::dataset_from_rank_buffer_file(const char *path) {
     check(path != nullptr, "dataset_from_rank_buffer_file: null path");
     check(user_group(), "rank-pair input needs the user-group format (format_type = 1), svd_feature.cpp:129-133");
-    if (device_rank_ && device_sched_ && !rank_prefetch_ && !host_only_) {
+    // (an amd:gpus handle shards the pass: the blocks below go through multi_dataset_from_blocks; the all-in-HBM form is one engine's)
+    if (device_rank_ && device_sched_ && !rank_prefetch_ && !host_only_ && (!multi_ || in_multi_scope())) {
         Dataset *ds = rank_pass_device(path);
         if (ds) return ds;
     }

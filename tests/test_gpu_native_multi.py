@@ -313,3 +313,46 @@ def test_rank_pairs_as_a_resident_data_set_of_the_handle(world, windows, k):
     t2.init_trainer()
     with pytest.raises(sa.SvdfError, match="window-minibatch step"):
         t2.dataset_from_pairs(u, p, q)
+
+
+def test_rank_pass_from_a_candidate_file_is_sharded_on_the_handle(tmp_path):
+    """input_type = 2 on an amd:gpus handle: svdf_dataset_from_rank_buffer_file draws the round's pairs (device or host sampler, same libc
+    stream) and shards the blocks over the ranks -- it must not build one engine's all-in-HBM pass and train rank 0 alone"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from perf_rank_input import write_candidates
+    src = str(tmp_path / "cand.buffer")
+    users, rows, items, k = 400, 9, 150, 16
+    write_candidates(src, users, rows, items, seed=5)
+    conf = [("num_user", users), ("num_item", items), ("num_global", 0), ("num_factor", k), ("num_ufeedback", 0), ("learning_rate", "0.01"),
+            ("wd_user", "0.004"), ("wd_item", "0.004"), ("no_user_bias", 1), ("ui_init_sigma", "0.05")]
+    out = {}
+    for device_rank in (1, 0):
+        t = sa.Trainer(1, 3)
+        t.seed(10)
+        for kk, v in conf + [("amd:gpus", 2), ("amd:delta_half", 0), ("amd:window", 300)]:
+            t.set_param(kk, str(v))
+        t.init_model()
+        t.init_trainer()
+        t.set_knob("device_rank", device_rank)
+        for r in range(2):
+            t.set_round(r)
+            ds = t.dataset_from_rank_buffer_file(src)
+            assert ds.kind == 6 and ds.num_row > 0
+            t.train_dataset(ds)
+            t.finish_round()
+            ds.close()
+        assert t.counter(8) > 0
+        out[device_rank] = {n: t.view(n).copy() for n in ("W_user", "W_item", "i_bias")}
+        t.close()
+    for n in out[0]:
+        np.testing.assert_array_equal(out[0][n].view(np.uint32), out[1][n].view(np.uint32))
+    # both ranks' users moved (rank 1 owns the odd ids)
+    s = sa.Trainer(1, 3)
+    s.seed(10)
+    for kk, v in conf:
+        s.set_param(kk, str(v))
+    s.init_model()
+    w0 = s.view("W_user").copy()
+    moved = np.any(out[1]["W_user"] != w0, axis=1)
+    assert moved[0::2].sum() > 50 and moved[1::2].sum() > 50
