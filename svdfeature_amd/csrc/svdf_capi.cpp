@@ -118,12 +118,12 @@ svdf_dataset *svdf_dataset_window_from_pairs(svdf_trainer *t, long n, const unsi
     })
 }
 int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *dst, int half, int64_t *count) {
-    SVDF_GUARD(-1, { t->e->window_delta_pack(ds ? ds->d : nullptr, dst, half, count); return 0; })
+    SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->window_delta_pack(ds ? ds->d : nullptr, dst, half, count); return 0; })
 }
-int svdf_window_delta_apply_local(svdf_trainer *t, svdf_dataset *ds) { SVDF_GUARD(-1, { t->e->window_delta_apply_local(ds ? ds->d : nullptr); return 0; }) }
-int svdf_item_block_get(svdf_trainer *t, float *dst, int64_t *count) { SVDF_GUARD(-1, { t->e->item_block_copy(dst, 0, count); return 0; }) }
-int svdf_item_block_set(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->item_block_copy(const_cast<float *>(src), 1, nullptr); return 0; }) }
-int svdf_window_delta_apply(svdf_trainer *t, const void *src, int half) { SVDF_GUARD(-1, { t->e->window_delta_apply(src, half); return 0; }) }
+int svdf_window_delta_apply_local(svdf_trainer *t, svdf_dataset *ds) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->window_delta_apply_local(ds ? ds->d : nullptr); return 0; }) }
+int svdf_item_block_get(svdf_trainer *t, float *dst, int64_t *count) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_block_copy(dst, 0, count); return 0; }) }
+int svdf_item_block_set(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_block_copy(const_cast<float *>(src), 1, nullptr); return 0; }) }
+int svdf_window_delta_apply(svdf_trainer *t, const void *src, int half) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->window_delta_apply(src, half); return 0; }) }
 int svdf_debug_sort_labels(long n, const float *label, int *restated, int *library) {
     SVDF_GUARD(-1, {
         svdf::host_sort_by_label(label, n, restated);
@@ -196,19 +196,19 @@ int64_t svdf_dataset_info(const svdf_dataset *ds, int what) {
     }
 }
 
-int svdf_item_delta_begin(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->item_delta_begin(); return 0; }) }
-void *svdf_item_delta_buffer(svdf_trainer *t, int64_t *count) { SVDF_GUARD(nullptr, { return t->e->item_delta_buffer(count); }) }
-int svdf_item_delta_apply(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->item_delta_apply(); return 0; }) }
-int svdf_item_delta_export(svdf_trainer *t, float *dst) { SVDF_GUARD(-1, { t->e->item_delta_copy(dst, nullptr); return 0; }) }
-int svdf_item_delta_import(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->item_delta_copy(nullptr, src); return 0; }) }
+int svdf_item_delta_begin(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_delta_begin(); return 0; }) }
+void *svdf_item_delta_buffer(svdf_trainer *t, int64_t *count) { SVDF_GUARD(nullptr, { t->e->per_rank_api(); return t->e->item_delta_buffer(count); }) }
+int svdf_item_delta_apply(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_delta_apply(); return 0; }) }
+int svdf_item_delta_export(svdf_trainer *t, float *dst) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_delta_copy(dst, nullptr); return 0; }) }
+int svdf_item_delta_import(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_delta_copy(nullptr, src); return 0; }) }
 
-int svdf_item_delta_into(svdf_trainer *t, float *dst, int64_t *count) { SVDF_GUARD(-1, { t->e->item_delta_into(dst, count); return 0; }) }
-int svdf_item_delta_pack(svdf_trainer *t, void *dst, int half, int64_t *count) { SVDF_GUARD(-1, { t->e->item_delta_pack(dst, half, count); return 0; }) }
+int svdf_item_delta_into(svdf_trainer *t, float *dst, int64_t *count) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_delta_into(dst, count); return 0; }) }
+int svdf_item_delta_pack(svdf_trainer *t, void *dst, int half, int64_t *count) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_delta_pack(dst, half, count); return 0; }) }
 int svdf_item_delta_unpack(svdf_trainer *t, const void *src, int half, int refresh_snapshot) {
-    SVDF_GUARD(-1, { t->e->item_delta_unpack(src, half, refresh_snapshot); return 0; })
+    SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_delta_unpack(src, half, refresh_snapshot); return 0; })
 }
-int svdf_item_delta_select(svdf_trainer *t, int part, int nparts) { SVDF_GUARD(-1, { t->e->item_delta_select(part, nparts); return 0; }) }
-int svdf_item_delta_apply_from(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->item_delta_apply_from(src); return 0; }) }
+int svdf_item_delta_select(svdf_trainer *t, int part, int nparts) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_delta_select(part, nparts); return 0; }) }
+int svdf_item_delta_apply_from(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_delta_apply_from(src); return 0; }) }
 int svdf_set_stream(svdf_trainer *t, void *hip_stream) { SVDF_GUARD(-1, { t->e->set_stream((hipStream_t)hip_stream); return 0; }) }
 
 int64_t svdf_get_view(svdf_trainer *t, int which, float *out, int64_t capacity) { SVDF_GUARD(-1, { return t->e->get_view(which, out, capacity); }) }

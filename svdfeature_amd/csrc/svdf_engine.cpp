@@ -2707,6 +2707,9 @@ int64_t Engine::counter(int what) const {
 }
 int Engine::set_knob(const char *name, long value) {
     launch_version_++;   // any knob may change what a captured pass would launch
+    // tuning knobs reach every rank of an amd:gpus handle (they never change a result; the exchange window is the handle's own)
+    if (multi_ && !is_peer_ && strcmp(name, "stage_window") != 0 && strcmp(name, "async_flush") != 0)
+        for (int d = 1; d < gpus_; d++) (void)rank_engine(d)->set_knob(name, value);
     if (!strcmp(name, "use_graph")) { use_graph_ = value != 0; return 0; }
     if (!strcmp(name, "graph_min_levels")) { check(value >= 1, "graph_min_levels must be >= 1"); graph_min_levels_ = (int)value; return 0; }
     if (!strcmp(name, "stage_window")) { check(value >= 1, "stage_window must be >= 1"); stage_window_ = value; window_set_ = true; return 0; }

@@ -290,6 +290,12 @@ class Engine {
     void eval_dataset(Dataset *ds, float scale, double *sum_sq, int64_t *count);
 
     // multi-GPU item-side delta
+    // the per-rank exchange entry points (one process per GPU) make no sense on a handle that exchanges by itself
+    void per_rank_api() const {
+        if (multi_ && !in_multi_scope())
+            fail("svdfeature_amd: svdf_item_delta_* / svdf_window_delta_* / svdf_item_block_* are the per-rank entry points of the one-process-per-GPU "
+                 "scheme; an amd:gpus > 1 handle exchanges by itself (train through svdf_update* / svdf_train_dataset)");
+    }
     void item_delta_begin();
     void *item_delta_buffer(int64_t *count);
     void item_delta_apply();

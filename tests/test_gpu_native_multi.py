@@ -160,6 +160,11 @@ def test_refusals_of_an_amd_gpus_handle():
     with pytest.raises(sa.SvdfError, match="needs one device per rank"):
         t.update_batch(sa.CSRData.from_triples(u, i, r))
         t.finish_round()
+    t = _ready(conf, [("amd:gpus", 2)])
+    with pytest.raises(sa.SvdfError, match="exchanges by itself"):   # the per-rank exchange API belongs to the one-process-per-GPU scheme
+        t.item_delta_begin()
+    with pytest.raises(sa.SvdfError, match="exchanges by itself"):
+        t.item_block_count()
     with pytest.raises(sa.SvdfError, match="at most 16 ranks"):
         _ready(conf, [("amd:gpus", 17)])
     with pytest.raises(sa.SvdfError, match="amd:exchange must be p2p or rccl"):
