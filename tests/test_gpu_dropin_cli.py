@@ -177,3 +177,37 @@ def test_bulk_round_loop_on_two_ranks_from_the_config_file(shape, tmp_path):
     # ratings: the 1e-4 contract.  user-group data: the automatic window is a heuristic (svdf_multi.cpp), checked here to keep the two
     # ranks close to the sequential result (the CPU simulation of this data set: +1.6e-5 at 64 windows per pass, +1.1e-3 at 32)
     assert abs(rm["ref"] - rm["bulk2"]) <= (1e-4 if fmt == 0 else 5e-4), rm
+
+
+REF_INFER = os.path.join(REFDIR, "svd_feature_infer")
+AMD_INFER = os.path.join(REFDIR, "svd_feature_infer_amd")
+need_infer = pytest.mark.skipif(not (os.path.exists(REF_INFER) and os.path.exists(AMD_INFER) and os.path.exists(AMD_CLI)),
+                                reason="oracle/_ref CLIs are built in the build container only")
+
+
+@need_infer
+def test_infer_cli_links_and_initialises_against_the_engine(tmp_path):
+    """The reference's inference CLI (svd_feature_infer.cpp) linked against the engine: this fork's SVDInferTask::run_task ends after
+    configure() + init() (its task_pred / task_eval dispatch is commented out, svd_feature_infer.cpp:393-403), so what the binary exercises
+    is the boundary's inference-side protocol -- create_svd_trainer, load_model of a trained model file, every config pair through
+    set_param, init_trainer, the test iterator's init -- and, like the unmodified binary, it writes no prediction file.  Evaluation at GPU
+    rates goes through svdf_predict_dataset / svdf_eval_dataset (tests/test_gpu_ranker.py, tests/perf_eval.py)."""
+    base, test = cases.ml100k()
+    d = tmp_path
+    D.write_csr_buffer(str(d / "train.buffer"), base)
+    D.write_csr_buffer(str(d / "test.buffer"), test)
+    conf = cases.BASICMF_CONF + [("buffer_feature", "train.buffer"), ("model_out_folder", "./")]
+    _write_conf(str(d / "run.conf"), conf)
+    with open(str(d / "run.conf"), "a") as f:
+        f.write('test:buffer_feature = "test.buffer"\n')
+    p = subprocess.run([AMD_CLI, "run.conf", "num_round=2", "silent=1"], cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert p.returncode == 0, p.stdout.decode()
+    for name, cli in (("ref", REF_INFER), ("amd", AMD_INFER)):
+        q = subprocess.run([cli, "run.conf", "pred=2", "name_pred=pred_%s.txt" % name, "silent=1"], cwd=str(d), stdout=subprocess.PIPE,
+                           stderr=subprocess.STDOUT, timeout=600)
+        assert q.returncode == 0, q.stdout.decode()
+        assert not os.path.exists(str(d / ("pred_%s.txt" % name)))
+    # a model file that does not exist fails in both the same way (fopen_check)
+    for cli in (REF_INFER, AMD_INFER):
+        q = subprocess.run([cli, "run.conf", "pred=7", "start=7", "silent=1"], cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert q.returncode != 0

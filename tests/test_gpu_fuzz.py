@@ -6,7 +6,7 @@ import sys
 import pytest
 
 import fuzz_parity
-import fuzz_ranker
+import fuzz_ranker  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -20,3 +20,9 @@ def test_random_configurations_match_the_oracle(seed):
 def test_random_ranker_streams_match_the_cpu_ranker(monkeypatch):
     monkeypatch.setattr(sys, "argv", ["fuzz_ranker.py", "--iters", "60", "--seed", "5"])
     assert fuzz_ranker.main() == 0
+
+
+def test_random_amd_gpus_handles_match_the_oracle_simulation(monkeypatch):
+    import fuzz_multi
+    monkeypatch.setattr(sys, "argv", ["fuzz_multi.py", "--iters", "80", "--seed", "7"])
+    assert fuzz_multi.main() == 0
