@@ -251,6 +251,7 @@ Engine::~Engine() {
             worker_.join();
         }
         (void)hipStreamSynchronize(stream_);
+        if (pred_pin_) (void)hipHostFree(pred_pin_);
         for (int b = 0; b < 2; b++) {
             if (save_pin_[b]) (void)hipHostFree(save_pin_[b]);
             if (save_ev_[b]) (void)hipEventDestroy(save_ev_[b]);
@@ -1599,6 +1600,34 @@ void Engine::predict_csr_batch_local(int num_row, const float *row_label, const 
     if (num_row <= 0) return;
     flush();
     const DevParams &P = params();
+    {   // a few rows (the per-instance predict(Elem) of ISVDTrainer): no copies at all -- the rows are written into ONE pinned, device-mapped
+        // buffer, the kernel reads them and writes the predictions through it; a call is one launch + one stream synchronisation
+        const long nv = (long)row_ptr[3 * num_row] - (long)row_ptr[0];
+        const size_t words = (size_t)num_row * 2 + (size_t)3 * num_row + 1 + (size_t)2 * std::max<long>(nv, 0);
+        if (num_row <= 256 && nv >= 0 && words <= PRED_PIN_WORDS) {
+            for (int r = 0; r < num_row; r++) {
+                const int *p = row_ptr + 3 * r;
+                check(p[0] <= p[1] && p[1] <= p[2] && p[2] <= p[3], "CSR row_ptr must be non-decreasing");
+                check_row(p[1] - p[0], p[2] - p[1], p[3] - p[2], feat_index + p[0]);
+            }
+            if (!pred_pin_) HIPCHECK(hipHostMalloc(reinterpret_cast<void **>(&pred_pin_), PRED_PIN_WORDS * sizeof(unsigned), hipHostMallocMapped));
+            float *l = reinterpret_cast<float *>(pred_pin_), *o = l + num_row;
+            int *ptr = reinterpret_cast<int *>(o + num_row);
+            unsigned *idx = reinterpret_cast<unsigned *>(ptr + 3 * num_row + 1);
+            float *val = reinterpret_cast<float *>(idx + nv);
+            memcpy(l, row_label, (size_t)num_row * sizeof(float));
+            const int p0 = row_ptr[0];
+            for (int j = 0; j <= 3 * num_row; j++) ptr[j] = row_ptr[j] - p0;
+            if (nv > 0) { memcpy(idx, feat_index + p0, (size_t)nv * sizeof(unsigned)); memcpy(val, feat_value + p0, (size_t)nv * sizeof(float)); }
+            DevCSR D{l, ptr, idx, val};
+            launch_predict(P, D, num_row, o, stream_);
+            n_launches_++;
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipStreamSynchronize(stream_));
+            memcpy(out, o, (size_t)num_row * sizeof(float));
+            return;
+        }
+    }
     HostCSR tmp;   // prediction rows never enter the training stage
     tmp.row_label.reserve((size_t)num_row);
     stage_rows_into(tmp, num_row, row_label, row_ptr, feat_index, feat_value);

@@ -519,6 +519,8 @@ class Engine {
     void predict_csr_batch_local(int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value, float *out);
     // ---- counters
     int64_t n_instances_ = 0, n_launches_ = 0, n_batches_ = 0, n_flushes_ = 0;
+    static constexpr size_t PRED_PIN_WORDS = 1 << 16;   // predict of a few rows: pinned, device-mapped staging (rows in, predictions out)
+    unsigned *pred_pin_ = nullptr;
     float *save_pin_[2] = {nullptr, nullptr};   // save_model: pinned double buffer of the device -> file pipeline
     hipEvent_t save_ev_[2] = {nullptr, nullptr};
     void dev_to_file(FILE *fo, const float *dsrc, long rows, long cols, long pitch);
