@@ -1695,10 +1695,45 @@ void Engine::predict_block(int nfb, int tag, const unsigned *ifb, const float *v
         imfb_depth_ = after;
         return;
     }
-    HostCSR tmp;   // prediction rows never enter the training stage
-    stage_rows_into(tmp, num_row, row_label, row_ptr, feat_index, feat_value);
     const bool starts = (tag == TAG_DEFAULT || tag == TAG_START);
     DevUnit u{0, starts ? nfb : 0, 0, num_row, (starts ? UNIT_START : UNIT_LOAD) | UNIT_SAVE};
+    {   // the usual block (a user's rows and feedback list: a few hundred entries): no copies -- everything the kernel reads, and the
+        // predictions it writes, live in ONE pinned, device-mapped buffer (see predict_csr_batch_local)
+        const long nv = num_row > 0 ? (long)row_ptr[3 * num_row] - (long)row_ptr[0] : 0;
+        const long nf = starts ? nfb : 0;
+        const size_t uw = (sizeof(DevUnit) + 3) / 4;
+        const size_t words = (size_t)2 * num_row + (size_t)3 * num_row + 1 + (size_t)2 * nv + (size_t)2 * nf + uw + 8;
+        if (nv >= 0 && words <= PRED_PIN_WORDS) {
+            for (int r = 0; r < num_row; r++) {
+                const int *p = row_ptr + 3 * r;
+                check(p[0] <= p[1] && p[1] <= p[2] && p[2] <= p[3], "CSR row_ptr must be non-decreasing");
+                check_row(p[1] - p[0], p[2] - p[1], p[3] - p[2], feat_index + p[0]);
+            }
+            if (!pred_pin_) HIPCHECK(hipHostMalloc(reinterpret_cast<void **>(&pred_pin_), PRED_PIN_WORDS * sizeof(unsigned), hipHostMallocMapped));
+            DevUnit *du = reinterpret_cast<DevUnit *>(pred_pin_);
+            float *l = reinterpret_cast<float *>(pred_pin_ + uw), *o = l + num_row;
+            int *ptr = reinterpret_cast<int *>(o + num_row);
+            unsigned *idx = reinterpret_cast<unsigned *>(ptr + 3 * num_row + 1);
+            float *val = reinterpret_cast<float *>(idx + nv);
+            unsigned *fi = reinterpret_cast<unsigned *>(val + nv);
+            float *fv = reinterpret_cast<float *>(fi + nf);
+            *du = u;
+            if (num_row > 0) memcpy(l, row_label, (size_t)num_row * sizeof(float));
+            const int p0 = num_row > 0 ? row_ptr[0] : 0;
+            for (int j = 0; j <= 3 * num_row; j++) ptr[j] = num_row > 0 ? row_ptr[j] - p0 : 0;
+            if (nv > 0) { memcpy(idx, feat_index + p0, (size_t)nv * sizeof(unsigned)); memcpy(val, feat_value + p0, (size_t)nv * sizeof(float)); }
+            if (nf > 0) { memcpy(fi, ifb, (size_t)nf * sizeof(unsigned)); memcpy(fv, vfb, (size_t)nf * sizeof(float)); }
+            DevCSR D{l, ptr, idx, val};
+            launch_svdpp_predict(P, D, du, fi, fv, 1, o, stream_);
+            n_launches_++;
+            HIPCHECK(hipGetLastError());
+            HIPCHECK(hipStreamSynchronize(stream_));
+            if (num_row > 0) memcpy(out, o, (size_t)num_row * sizeof(float));
+            return;
+        }
+    }
+    HostCSR tmp;   // prediction rows never enter the training stage
+    stage_rows_into(tmp, num_row, row_label, row_ptr, feat_index, feat_value);
     w_label_.upload(tmp.row_label.data(), tmp.row_label.size(), stream_);
     w_ptr_.upload(tmp.row_ptr.data(), tmp.row_ptr.size(), stream_);
     w_index_.upload(tmp.feat_index.data(), tmp.feat_index.size(), stream_);
