@@ -191,6 +191,25 @@ def workload_conf(name, a, factor):
 PMC_KERNEL = {"basicmf": "k_basicmf", "pairwise": "k_fewrow", "svdpp": "k_svdpp_wave", "neighbourhood": "k_fused"}
 
 
+def ranker_roofline(matrix_bytes, cand, dt, nsec, tiles, top_k, tile_traffic):
+    """One pass over the prepared candidate matrix serves a TILE of up to 8 user sections (k_rank_score_tile), so the launch's algorithmic
+    bytes are the matrix ONCE plus a score slice written per section -- not the reference's matrix-per-user stream: with 8 sections per
+    pass the kernel is bound by its 8 dot products per candidate (LDS-fed VALU), not by HBM, and the fraction says so."""
+    per_tile = nsec / max(tiles, 1) if tiles else 1.0
+    launch_bytes = matrix_bytes + per_tile * cand * 4
+    achieved = launch_bytes / (dt * per_tile) / 1e9
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "kernel": "k_rank_score_tile<8> (up to 8 user sections per pass over the candidate matrix)" + (" + k_rank_tile_keys / k_rsel_* (radix selection of every section of the tile)" if top_k else ""),
+            "algorithmic_bytes_per_launch": launch_bytes, "sections_per_launch": per_tile,
+            "reference_bytes_per_section": matrix_bytes,
+            "reference_stream_equivalent_GBps": matrix_bytes / dt / 1e9,
+            "timing": "host clock over the whole svdf_ranker_process_rows call / tiles: uploads, opening kernel, scoring pass, selection or counting, readback "
+                      "(the scoring kernel alone: profiles/r03_ranker_*_kernel_stats.csv); reference_stream_equivalent = what streaming the matrix once per "
+                      "section, as the reference does, would have to sustain for the same sections/s",
+            "traffic": tile_traffic,
+            "traffic_source": "profiles/hbm_traffic.json: k_rank_score_tile, (2*FETCH+WRITE)*1024 per launch = per TILE of up to 8 sections"}
+
+
 def measure_traffic(name, a, log):
     """--pmc: HBM bytes per launch of the workload's dominant kernel, measured NOW: two rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE,
     then WRITE_SIZE: the TCC block cannot hold both, MI355X_MICROARCH.md) over one pass of the same workload in a child process of this
@@ -759,13 +778,7 @@ def run_f3_secondary(a, env):
                 cand, nsec, "top_k=%d" % top_k if top_k else "rank positions of 5 positives"),
             "value": 1.0 / dt, "unit": "user sections/s", "ms_per_step": dt * 1e3, "sections_finished_by_host_sort": g.counter(1),
             "tiles_of_up_to_8_sections": g.counter(3),
-            "roofline": {"bound": "hbm", "achieved": byts / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / dt / 1e9 / HBM_PEAK_GBS,
-                         "kernel": "k_rank_score_tile<8> (positions: up to 8 sections per pass over the candidate matrix)" if not top_k else "k_rank_score<8,2>",
-                         "algorithmic_bytes_per_section": byts,
-                         "timing": "host clock over the whole call / sections: upload, k_rank_user, k_rank_score, selection, readback of every "
-                                   "section (the scoring kernel alone: profiles/r03_ranker_*)",
-                         "traffic": traffic_of("ranker_k128_positions_tile") if not top_k else None,
-                         "traffic_source": "profiles/hbm_traffic.json: k_rank_score_tile, bytes per launch = per TILE of up to 8 sections" if not top_k else None},
+            "roofline": ranker_roofline(byts, cand, dt, nsec, g.counter(3), top_k, traffic_of("ranker_k128_positions_tile")),
             "cpu_baseline": {"value": 1.0 / dt_cpu, "unit": "user sections/s", "cores": 1, "kind": f3_kind, "sample": "the first %d sections" % ncpu},
             "parity": {"results_identical_on_sample": bool(np.array_equal(got[:len(ref)], ref))}}
         log("f3 ranker top_k=%d: %.1f us/section, cpu %.2f ms/section" % (top_k, dt * 1e6, dt_cpu * 1e3))
