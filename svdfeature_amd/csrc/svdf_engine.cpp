@@ -2431,7 +2431,7 @@ void Engine::train_dataset(Dataset *ds) {
 
 void Engine::predict_dataset(Dataset *ds, float *out) {
     check(ds && ds->owner == this, "predict_dataset: dataset belongs to another trainer");
-    check(ds->kind != 5 && ds->kind != 6, "predict_dataset: window / multi-GPU data sets are training sets; score rows with svdf_predict_csr_batch (routed to the owner of each user)");
+    check(ds->kind != 5 && ds->kind != 6, "predict_dataset: window / multi-GPU data sets are training sets (their rows are regrouped: there is no file order to report predictions in); svdf_eval_dataset gives their squared error, svdf_predict_csr_batch scores rows (routed to the owner of each user)");
     check(ds->sched_signature == schedule_signature(),
           "predict_dataset: the dataset was scheduled under another configuration; build it again");
     flush();
@@ -2479,7 +2479,26 @@ void Engine::predict_dataset(Dataset *ds, float *out) {
 // rounding only (relative 1e-13 at 1e8 instances), stated in the test.
 void Engine::eval_dataset(Dataset *ds, float scale, double *sum_sq, int64_t *count) {
     check(ds && ds->owner == this, "eval_dataset: dataset belongs to another trainer");
-    check(ds->kind != 5 && ds->kind != 6, "eval_dataset: window / multi-GPU data sets are training sets; score rows with svdf_predict_csr_batch (routed to the owner of each user)");
+    if (ds->kind == 6 && multi_ && !in_multi_scope()) {   // an amd:gpus handle: every (rank, window) piece is scored where it lives
+        flush();
+        MultiScope local;
+        long double acc = 0.0L;
+        int64_t cnt = 0;
+        for (int d = 0; d < gpus_; d++) {
+            Engine *e = rank_engine(d);
+            HIPCHECK(hipSetDevice(e->device_));
+            for (Dataset *c : ds->mchild[(size_t)d]) {
+                double s = 0.0; int64_t m = 0;
+                e->eval_dataset(c, scale, &s, &m);
+                acc += (long double)s; cnt += m;
+            }
+        }
+        HIPCHECK(hipSetDevice(device_));
+        *sum_sq = (double)acc; *count = cnt;
+        return;
+    }
+    check(ds->kind != 6, "eval_dataset: not a data set of this handle");
+    check(ds->kind != 5 || ds->fused.max_ni == 1, "eval_dataset: rank-pair window data sets have no label to compare a score with");
     check(ds->sched_signature == schedule_signature(), "eval_dataset: the dataset was scheduled under another configuration; build it again");
     flush();
     const DevParams &P = params();
@@ -2496,6 +2515,13 @@ void Engine::eval_dataset(Dataset *ds, float scale, double *sum_sq, int64_t *cou
         const UnitDev &d = ds->unitdev;
         launch_svdpp_predict(P, d.csr(), d.units.p, d.fbidx.p, d.fbval.p, ds->num_units, w_out_.p, stream_);
         labels = d.label.p;
+    } else if (ds->kind == 5) {   // a window data set: instances grouped by user; the user column is written out for the scoring kernel
+        w_pred_.reserve((size_t)n);
+        unsigned *ucol = reinterpret_cast<unsigned *>(w_pred_.p);
+        launch_window_user_column(ds->win_urec.p, (int)ds->num_units, ucol, stream_);
+        BasicSchedule S{ucol, ds->item.p, ds->label.p, nullptr, nullptr};
+        launch_predict_basic(P, S, n, w_out_.p, stream_);
+        labels = ds->label.p;
     } else if (ds->kind == 0) {
         BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
         launch_predict_basic(P, S, n, w_out_.p, stream_);

@@ -397,6 +397,19 @@ __global__ __launch_bounds__(256) void k_ranges_copy(const DeltaRanges R, float 
         else buf[j] = *cur;
     }
 }
+// the user id of every instance of a window data set (its instances are grouped by user: urec = user, begin, count), for scoring it
+__global__ __launch_bounds__(256) void k_window_user_column(const WinUser *urec, int nusers, unsigned *user_out) {
+    const int lane = threadIdx.x & 63;
+    const long w = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (w >= nusers) return;
+    const WinUser u = urec[w];
+    for (int j = lane; j < u.count; j += 64) user_out[u.begin + j] = u.user;
+}
+void launch_window_user_column(const WinUser *urec, int nusers, unsigned *user_out, hipStream_t st) {
+    if (nusers <= 0) return;
+    const long blocks = ((long)nusers * 64 + 255) / 256;
+    hipLaunchKernelGGL(k_window_user_column, dim3((unsigned)blocks), dim3(256), 0, st, urec, nusers, user_out);
+}
 void launch_ranges_copy(const DeltaRanges &R, float *buf, int set, hipStream_t st) {
     const long total = R.off[R.n];
     if (total <= 0) return;

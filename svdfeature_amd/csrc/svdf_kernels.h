@@ -52,6 +52,7 @@ void launch_window_items(const WindowSchedule &S, int pitch, int k, long lo, lon
 void launch_delta_addto(const DeltaRanges &R, const void *src, int half, hipStream_t st);
 void launch_window_items_local(const WindowSchedule &S, int pitch, int k, long lo, long hi, float *w_item, float *i_bias, hipStream_t st);
 void launch_ranges_copy(const DeltaRanges &R, float *buf, int set, hipStream_t st);
+void launch_window_user_column(const WinUser *urec, int nusers, unsigned *user_out, hipStream_t st);
 void launch_pairs_prepare(long n, const unsigned *pos, const unsigned *neg, unsigned *lo, unsigned *hi, float *vlo, float *vhi, float *ones,
                           unsigned *flag, hipStream_t st);
 void launch_delta_sum(const void *const *srcs, int n, void *dst, long total, int half, hipStream_t st);   // up to 16 buffers

@@ -361,3 +361,32 @@ def test_rank_pass_from_a_candidate_file_is_sharded_on_the_handle(tmp_path):
     w0 = s.view("W_user").copy()
     moved = np.any(out[1]["W_user"] != w0, axis=1)
     assert moved[0::2].sum() > 50 and moved[1::2].sum() > 50
+
+
+@pytest.mark.parametrize("step", ["minibatch", "levels"])
+def test_eval_dataset_on_the_handle(step, tmp_path):
+    """svdf_eval_dataset on an amd:gpus handle: a resident data set (sharded, windowed) is scored piece by piece on the rank that holds
+    it -- window data sets included -- and the squared error equals the one of the saved model on ONE GPU over the same rows"""
+    nu, ni, n, world = 2000, 300, 30000, 3
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=32)
+    u, i, r = cases.planted_triples(n, nu, ni, seed=3)
+    tu, ti, tr = cases.planted_triples(9000, nu, ni, seed=4)
+    t = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", 5000), ("amd:step", step)])
+    ds = t.dataset_from_triples(u, i, r)
+    test = t.dataset_from_triples(tu, ti, tr)
+    for _ in range(2):
+        t.train_dataset(ds)
+        t.finish_round()
+    ss, cnt = t.eval_dataset(test)
+    assert cnt == len(tr)
+    p = str(tmp_path / "m.model")
+    t.save_model(p)
+    s = sa.Trainer(0, 0)
+    s.load_model(p)
+    s.init_trainer()
+    ss1, cnt1 = s.eval_dataset(s.dataset_from_triples(tu, ti, tr))
+    assert cnt1 == cnt and abs(ss - ss1) <= 1e-9 * ss1
+    pred = t.predict_batch(sa.CSRData.from_triples(tu, ti, tr))
+    assert abs(ss - float(np.sum((pred.astype(np.float64) - tr) ** 2))) <= 1e-6 * ss
+    with pytest.raises(sa.SvdfError, match="no file order"):
+        t.predict_dataset(test)
