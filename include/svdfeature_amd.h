@@ -253,7 +253,9 @@ int svdf_set_knob(svdf_trainer *t, const char *name, long value);
 /* ---- evaluation: RMSEEvaluator of svd_feature_infer.cpp:38-56,243-277 over a resident data set.  Predictions
  * stay in HBM; *sum_sq_err = sum over instances of ((pred - label) * scale_score)^2 (difference and scaling in fp32, square and
  * sum in fp64 like add_eval), *count = instances; RMSE = sqrt(sum / count) (print_stat).  The sum is a fixed fp64 tree on the
- * device + long double over the partial sums, the reference's is a sequential long double sum: equal to ~1e-13 relative. */
+ * device + long double over the partial sums, the reference's is a sequential long double sum: equal to ~1e-13 relative.
+ * Works on the data sets of an "amd:gpus" handle and on window data sets too (every piece is scored on the rank that holds it);
+ * svdf_predict_dataset does not: their rows are regrouped, there is no file order to report predictions in. */
 int svdf_eval_dataset(svdf_trainer *t, svdf_dataset *ds, float scale_score, double *sum_sq_err, int64_t *count);
 
 /* ---- ranking: class apex_svd::ISVDRanker (apex_svd.h:160-197) as implemented by SVDFeatureRanker
