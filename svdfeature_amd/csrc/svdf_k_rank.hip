@@ -526,6 +526,9 @@ __global__ __launch_bounds__(1024) void k_rank_tile_open(const DevParams P, cons
         pos_score[T.pos0[u] + j] = 0.0f + rank_lane_score<8>(P.k, cap, reinterpret_cast<const float4 *>(mytu), ifT + pos[j], ibias[pos[j]]);
 }
 
+#ifndef RANK_TILE_LOADS
+#define RANK_TILE_LOADS 4
+#endif
 template <int NSEC>
 __global__ __launch_bounds__(256) void k_rank_score_tile(int k, int pitch, long n, long cap, const float *__restrict__ tu, const float4 *__restrict__ ifT,
                                                          const float *__restrict__ ibias, const unsigned *__restrict__ banmask, float *score,
@@ -546,12 +549,13 @@ __global__ __launch_bounds__(256) void k_rank_score_tile(int k, int pitch, long 
     for (int u = 0; u < NSEC; u++) { a[u][0] = 0.0f; a[u][1] = 0.0f; a[u][2] = 0.0f; a[u][3] = 0.0f; }
     const float4 *q = ifT + ic;
     int j = 0;
-    for (; j + 4 <= nfull; j += 4) {   // four 16-byte loads in flight per lane and 32 accumulators: 152 VGPRs at 8 sections (eight loads in flight
-        float4 v[4];                   // or 16 sections per tile spill: 104 us per tile of 16 against 29 us per tile of 8)
+    constexpr int LD = RANK_TILE_LOADS;
+    for (; j + LD <= nfull; j += LD) {   // LD 16-byte loads in flight per lane and 32 accumulators: 152 VGPRs at 8 sections with LD = 4 (eight loads in flight
+        float4 v[LD];                  // or 16 sections per tile spill: 104 us per tile of 16 against 29 us per tile of 8)
 #pragma unroll
-        for (int c = 0; c < 4; c++) v[c] = q[(size_t)(j + c) * cap];
+        for (int c = 0; c < LD; c++) v[c] = q[(size_t)(j + c) * cap];
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
+        for (int c = 0; c < LD; c++) {
 #pragma unroll
             for (int u = 0; u < NSEC; u++) {
                 const float4 p = *reinterpret_cast<const float4 *>(ltu + (size_t)u * pitch + 4 * (j + c));
