@@ -10,6 +10,7 @@
 // the reference's entry vector, so those rare sections are finished by running exactly that sort on the host.
 #include <algorithm>
 #include <future>
+#include <thread>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -424,6 +425,12 @@ void Ranker::enqueue() {
 // The reference's own ordering step (:767) for a section whose scores tie: std::sort over the entry vector (ranked candidates
 // in index order).  100 K entries take ~8 ms on one core, two hundred sections' worth of device time: it runs on a helper
 // thread over a private copy of the section's scores while the pipeline goes on; results are still reported in section order.
+// helper threads for the reference's tie-breaking sort: a quarter of the host's hardware threads, at least 8, at most 32 (each sorts
+// a private 100 K-entry copy for ~8 ms; the sections they belong to are reported in order when they finish)
+static size_t host_sort_threads() {
+    static const size_t n = std::min<size_t>(32, std::max<size_t>(8, std::thread::hardware_concurrency() / 4));
+    return n;
+}
 static std::vector<int> host_sort_section(std::vector<float> score, std::vector<int> banned_idx, std::vector<int> pos_item, int top_k) {
     const long n = (long)score.size();
     std::vector<char> banned((size_t)n, 0);
@@ -460,7 +467,7 @@ void Ranker::resolve() {
         n_host_sorts_++;
         size_t running = 0;
         for (RankChunk &c : chunks_) running += c.pending ? 1 : 0;
-        if (running >= 8)   // bound the helper threads: wait for the oldest unfinished sort
+        if (running >= host_sort_threads())   // bound the helper threads: wait for the oldest unfinished sort
             for (RankChunk &c : chunks_) if (c.pending) { c.vals = c.fut.get(); c.pending = false; break; }
         C.pending = true;
         C.fut = std::async(std::launch::async, host_sort_section, std::move(score), Q.banned, Q.pos_item, top_k_);
@@ -488,7 +495,7 @@ void Ranker::resolve() {
                 n_host_sorts_++;
                 size_t running = 0;
                 for (RankChunk &c : chunks_) running += c.pending ? 1 : 0;
-                if (running >= 8)
+                if (running >= host_sort_threads())
                     for (RankChunk &c : chunks_) if (c.pending) { c.vals = c.fut.get(); c.pending = false; break; }
                 Cu.pending = true;
                 Cu.fut = std::async(std::launch::async, host_sort_section, std::move(score), Q.tile_ban[(size_t)u], Q.tile_pos[(size_t)u], top_k_);
