@@ -490,9 +490,10 @@ void launch_rank_feedback(const DevParams &P, const unsigned *fidx, const float 
 template <int LPI, typename R>
 __global__ __launch_bounds__(1024) void k_rank_tile_open(const DevParams P, const unsigned *stage, const RankTile T, const float *fb_in, float *tu_out,
                                                                    unsigned *banmask, const unsigned *prev_ban, int nprev, int *cnt, unsigned *flag, long cap,
-                                                                   const float4 *ifT, const float *ibias, float *pos_score) {
+                                                                   const float4 *ifT, const float *ibias, float *pos_score, unsigned *zero_words, long nzero) {
     extern __shared__ float tus[];   // [RANK_TILE][pitch + 4]
     const int lane = threadIdx.x & 63, u = threadIdx.x >> 6;
+    for (long j = threadIdx.x; j < nzero; j += blockDim.x) zero_words[j] = 0u;           // top_k: the selection work areas of the tile's sections
     for (int j = threadIdx.x; j < nprev; j += blockDim.x) banmask[prev_ban[j]] = 0u;   // the previous tile's bans
     __syncthreads();
     const bool live = u < T.nsec;
@@ -607,10 +608,10 @@ __global__ __launch_bounds__(256) void k_rank_score_tile(int k, int pitch, long 
 
 void launch_rank_tile_open(const DevParams &P, const unsigned *stage, const RankTile &T, const float *fb_in, float *tu_out, unsigned *banmask,
                            const unsigned *prev_ban, int nprev, int *cnt, unsigned *flag, long cap, const float *ifT, const float *ibias, float *pos_score,
-                           hipStream_t st) {
+                           unsigned *zero_words, long nzero, hipStream_t st) {
     const size_t lds = (size_t)RANK_TILE * ((size_t)P.pitch + 4) * sizeof(float);
     SVDF_DISPATCH_ROW(P.k, hipLaunchKernelGGL((k_rank_tile_open<LPI, R>), dim3(1), dim3(64 * RANK_TILE), lds, st, P, stage, T, fb_in, tu_out, banmask, prev_ban,
-                                              nprev, cnt, flag, cap, reinterpret_cast<const float4 *>(ifT), ibias, pos_score));
+                                              nprev, cnt, flag, cap, reinterpret_cast<const float4 *>(ifT), ibias, pos_score, zero_words, nzero));
 }
 void launch_rank_score_tile(const DevParams &P, long n, long cap, const float *tu, const float *ifT, const float *ibias, const unsigned *banmask, float *score,
                             const unsigned *stage, const RankTile &T, const float *pos_score, int *cnt, hipStream_t st) {

@@ -80,7 +80,7 @@ void launch_rank_score(const DevParams &P, long n, long cap, const float *tu, co
 struct RankTile { int nsec; int off[RANK_TILE], nu[RANK_TILE], npos[RANK_TILE], nban[RANK_TILE], pos0[RANK_TILE]; };
 void launch_rank_tile_open(const DevParams &P, const unsigned *stage, const RankTile &T, const float *fb_in, float *tu_out, unsigned *banmask,
                            const unsigned *prev_ban, int nprev, int *cnt, unsigned *flag, long cap, const float *ifT, const float *ibias, float *pos_score,
-                           hipStream_t st);
+                           unsigned *zero_words, long nzero, hipStream_t st);
 void launch_rank_score_tile(const DevParams &P, long n, long cap, const float *tu, const float *ifT, const float *ibias, const unsigned *banmask, float *score,
                             const unsigned *stage, const RankTile &T, const float *pos_score, int *cnt, hipStream_t st);
 struct RselSecs { unsigned K1[RANK_TILE]; };

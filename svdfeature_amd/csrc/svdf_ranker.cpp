@@ -234,8 +234,16 @@ void Ranker::flush_tile() {
     L.d_flag.reserve(RANK_TILE);
     L.d_ps.reserve((size_t)std::max(totpos, 1));
     L.d_score.reserve((size_t)RANK_TILE * (size_t)cap_items);
+    // top_k: the selection's work areas (histograms + state of every section) are cleared by the opening kernel
+    const size_t sel_ww = (size_t)rank_select_work_words(), sel_rc = (size_t)rank_select_cap();
+    const size_t sel_out_stride = (size_t)2 * ((size_t)std::max(top_k_, 0) + 1) + 1;
+    if (top_k_ > 0) {
+        d_keys_.reserve((size_t)RANK_TILE * (size_t)cap_items);
+        d_sel_.reserve((size_t)RANK_TILE * (sel_ww + 2 * sel_rc + sel_out_stride));
+    }
     launch_rank_tile_open(P, L.d_stage.p, T, eng_->user_group() ? d_fb_.p : nullptr, d_tu_tile_.p, d_banmask_.p, L.d_stage.p + prev_off, (int)tile_prev_ban_.size(),
-                          L.d_cnt.p, L.d_flag.p, cap_items, d_ift_.p, d_ibias_.p, L.d_ps.p, st);
+                          L.d_cnt.p, L.d_flag.p, cap_items, d_ift_.p, d_ibias_.p, L.d_ps.p, top_k_ > 0 ? d_sel_.p : nullptr,
+                          top_k_ > 0 ? (long)((size_t)T.nsec * sel_ww) : 0L, st);
     launch_rank_score_tile(P, n, cap_items, d_tu_tile_.p, d_ift_.p, d_ibias_.p, d_banmask_.p, L.d_score.p, L.d_stage.p, T, L.d_ps.p, L.d_cnt.p, st);
     RCHECK(hipGetLastError());
     RankPending Q;
@@ -245,12 +253,8 @@ void Ranker::flush_tile() {
         RselSecs Ks;
         memset(&Ks, 0, sizeof(Ks));
         for (int u = 0; u < T.nsec; u++) Ks.K1[u] = (unsigned)tile_[(size_t)u].take;
-        const size_t ww = (size_t)rank_select_work_words(), rc = (size_t)rank_select_cap();
-        const size_t out_stride = (size_t)2 * ((size_t)top_k_ + 1) + 1;
-        d_keys_.reserve((size_t)RANK_TILE * (size_t)cap_items);
-        d_sel_.reserve((size_t)RANK_TILE * (ww + 2 * rc + out_stride));
+        const size_t ww = sel_ww, rc = sel_rc, out_stride = sel_out_stride;
         unsigned *work = d_sel_.p, *ck = work + RANK_TILE * ww, *cv = ck + RANK_TILE * rc, *res = cv + RANK_TILE * rc;
-        RCHECK(hipMemsetAsync(work, 0, (size_t)T.nsec * ww * sizeof(unsigned), st));
         launch_rank_select_tile(n, cap_items, T.nsec, L.d_score.p, d_banmask_.p, Ks, d_keys_.p, work, ck, cv, res, (long)out_stride, L.d_flag.p, st);
         RCHECK(hipGetLastError());
         slot_reserve_back(L, (size_t)T.nsec * out_stride);
