@@ -236,3 +236,29 @@ def test_stratified_schedule_on_simulated_ranks_equals_the_simulation(k, world, 
     one = simulate_stratified(conf, u, i, r, 1, chunks, passes, ni, per_item)
     for name in NAMES:
         assert np.array_equal(ad.t.view(name).view(np.uint32), one[0].t.view(name).view(np.uint32)), name
+
+
+@pytest.mark.parametrize("shape", ["one_user", "one_item", "one_instance", "few_heavy_users", "every_user_once"])
+@pytest.mark.parametrize("k", [10, 64])
+def test_degenerate_window_shapes(shape, k):
+    """shapes at the edges of the window layout: ONE user holding every instance of the window (one lane group walks thousands of
+    instances), ONE item receiving every contribution (one per-item sum over thousands of slots), a single instance, three users with
+    most of the mass next to hundreds with one instance, every user exactly once -- 2 simulated ranks == the oracle simulation"""
+    rng = np.random.default_rng(5)
+    nu, ni, n = 600, 90, 6000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=21)
+    if shape == "one_user":
+        u[:] = 7
+    elif shape == "one_item":
+        i[:] = 11
+    elif shape == "one_instance":
+        u, i, r = u[:1], i[:1], r[:1]
+    elif shape == "few_heavy_users":
+        heavy = rng.random(n) < 0.9
+        u[heavy] = rng.choice(np.array([3, 4, 500], np.uint32), int(heavy.sum()))
+    else:
+        u, i, r = np.arange(nu, dtype=np.uint32), i[:nu], r[:nu]
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k)
+    windows = 1 if len(r) < 10 else 3
+    ranks = _run_ranks(conf, u, i, r, 2, windows, 2)
+    _check(ranks, simulate(conf, u, i, r, 2, windows, 2, minibatch=True))
