@@ -182,14 +182,14 @@ def test_rank_pairs_on_simulated_ranks_equal_the_oracle_simulation(k, world):
         ranks[0][0].t.dataset_window_from_pairs(u[:3], p[:3], p[:3])
 
 
-@pytest.mark.parametrize("k,world,chunks", [(64, 3, 2), (16, 2, 1), (128, 4, 2)])
-def test_stratified_schedule_on_simulated_ranks_equals_the_simulation(k, world, chunks):
+@pytest.mark.parametrize("k,world,chunks,ni", [(64, 3, 2, 701), (16, 2, 1, 701), (128, 4, 2, 701), (16, 4, 1, 3)])   # last: fewer items than blocks
+def test_stratified_schedule_on_simulated_ranks_equals_the_simulation(k, world, chunks, ni):
     """multi_gpu.StratifiedTrainer's schedule with N trainers on one GPU (block hand-overs = device copies): in-place per-item sums into
     the owned item block (svdf_window_delta_apply_local), svdf_item_block_get / _set -- == the oracle simulation bit for bit"""
     import torch
     from multi_rank_utils import simulate_stratified
     from svdfeature_amd.multi_gpu import StratifiedTrainer, stratified_plan
-    nu, ni, n, passes, per_item = 1500, 701, 60000, 2, 9.0
+    nu, n, passes, per_item = 1500, 60000 if ni > 100 else 3000, 2, 9.0
     u, i, r = cases.planted_triples(n, nu, ni, seed=k + world)
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k)
     dev = torch.device("cuda", 0)
