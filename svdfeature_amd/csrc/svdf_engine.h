@@ -385,7 +385,7 @@ class Engine {
     int reg_bi_feedback_ = 0;
     bool unit_open_ = false;          // a START block was staged and its END has not arrived
     bool unit_open_on_device_ = false;  // ... and its first part was already flushed (state saved on device)
-    long stage_window_ = 1 << 22;
+    long stage_window_ = 1 << 21;   // rows per staged window: 1-4 M measure alike in tools/update_call_cost (125-153 M inst/s), smaller windows end a round sooner
     bool use_graph_ = false;   // measured: no gain, dependent short kernels are bound on the GPU side
     int graph_min_levels_ = 2;
     uint64_t launch_version_ = 1;
