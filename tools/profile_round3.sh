@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run on the GPU box through gpurun:  tools/profile_round2.sh r03
+# Run on the GPU box through gpurun:  tools/profile_round3.sh r03
 # Produces gpurun_out/<tag>/ : the bench line, rocprofv3 kernel stats of the same command (main line + secondary workloads),
 # and per-workload PMC summaries (FETCH/WRITE sizes, TCC EA requests, SQ instruction counts) of its dominant kernel.
 # Counters are collected in their own passes (--kernel-trace + --pmc only, never with sys/hip/hsa tracing).
