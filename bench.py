@@ -68,9 +68,24 @@ class Planted:
         return r
 
 
+_DATA_CACHE = {}   # the synthetic streams of this process: the N > 1 secondaries train the SAME data as the main line
+
+
+def cached(fn, *args):
+    key = (fn.__name__,) + args
+    if key not in _DATA_CACHE:
+        _DATA_CACHE[key] = fn(*args)
+    return _DATA_CACHE[key]
+
+
 def synth_triples(n, num_user, num_item, seed=12345, rank=4, noise=0.35, chunk=10_000_000):
     """(user, item, rating): u, i uniform; rating in 1..5 from a planted low-rank model + noise so that
     RMSE is meaningful."""
+    cache = os.environ.get("SVDF_BENCH_DATA_CACHE")   # the --pmc children read the parent's stream instead of drawing it again
+    path = os.path.join(cache, "triples_%d_%d_%d_%d.npz" % (n, num_user, num_item, seed)) if cache else None
+    if path and os.path.exists(path):
+        z = np.load(path)
+        return z["u"], z["i"], z["r"]
     rng = np.random.default_rng(seed)
     u = rng.integers(0, num_user, n, dtype=np.uint32)
     i = rng.integers(0, num_item, n, dtype=np.uint32)
@@ -80,6 +95,8 @@ def synth_triples(n, num_user, num_item, seed=12345, rank=4, noise=0.35, chunk=1
         e = min(n, s + chunk)
         score = pl.score(u[s:e], i[s:e]) + noise * rng.standard_normal(e - s).astype(np.float32)
         r[s:e] = np.clip(np.rint(score), 1, 5)
+    if path and os.environ.get("SVDF_BENCH_DATA_CACHE_WRITE") == "1":
+        np.savez(path, u=u, i=i, r=r)
     return u, i, r
 
 
@@ -210,7 +227,7 @@ def ranker_roofline(matrix_bytes, cand, dt, nsec, tiles, top_k, tile_traffic):
             "traffic_source": "profiles/hbm_traffic.json: k_rank_score_tile, (2*FETCH+WRITE)*1024 per launch = per TILE of up to 8 sections"}
 
 
-def measure_traffic(name, a, log):
+def measure_traffic(name, a, log, deadline=None):
     """--pmc: HBM bytes per launch of the workload's dominant kernel, measured NOW: two rocprofv3 passes (--kernel-trace --pmc FETCH_SIZE,
     then WRITE_SIZE: the TCC block cannot hold both, MI355X_MICROARCH.md) over one pass of the same workload in a child process of this
     script; (2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch -- the correction the guide prescribes for gfx950, checked on known byte
@@ -226,14 +243,20 @@ def measure_traffic(name, a, log):
     for counter in ("FETCH_SIZE", "WRITE_SIZE"):
         out = tempfile.mkdtemp(prefix="svdf_pmc_", dir="/tmp")
         cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "-o", "p", "--", sys.executable, os.path.abspath(__file__),
-               "--workload", name, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--secondary", "", "--users", str(a.users), "--items", str(a.items)] + size_args
+               "--workload", name, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--pmc", "off", "--secondary", "", "--users", str(a.users), "--items", str(a.items)] + size_args
         if a.factor and name == a.workload:   # secondary workloads run at their own configured width (128), like in this process
             cmd += ["--factor", str(a.factor)]
         env = dict(os.environ, TMPDIR="/tmp")
+        env.pop("SVDF_BENCH_DATA_CACHE_WRITE", None)
+        left = 600 if deadline is None else deadline - time.time()
+        if left < 20:
+            log("%s: PMC pass %s skipped: the time cap of the in-run counter passes is used up" % (name, counter))
+            shutil.rmtree(out, ignore_errors=True)
+            return None, None
         try:
             p = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
-                p.wait(timeout=600)
+                p.wait(timeout=left)
             except subprocess.TimeoutExpired:
                 os.killpg(p.pid, signal.SIGKILL)   # exactly the group this call started
                 p.wait()
@@ -363,14 +386,14 @@ def run_workload(name, a, env, steps, warmup, main_line):
     # ---- data (every rank generates the same stream from the same seed, then keeps its shard)
     if name == "basicmf":
         n = a.ratings
-        u, i, r = synth_triples(n + 1_000_000, a.users, a.items)
+        u, i, r = cached(synth_triples, n + 1_000_000, a.users, a.items)
         test = (u[n:n + 200000], i[n:n + 200000], r[n:n + 200000])
         u, i, r = u[:n], i[:n], r[:n]
         per_item = n / max(a.items, 1)
         sample = ("triples", u[:a.cpu_sample], i[:a.cpu_sample], r[:a.cpu_sample])
     elif name == "pairwise":
         n = a.pairs
-        u, p, q = synth_pairs(n + 200_000, a.users, a.items)
+        u, p, q = cached(synth_pairs, n + 200_000, a.users, a.items)
         test = (u[n:], p[n:], q[n:])
         u, p, q = u[:n], p[:n], q[:n]
         per_item = 2.0 * n / max(a.items, 1)
@@ -457,6 +480,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
         shards = [[per_part[q][w] for q in range(parts)] for w in range(nwin)]
     elif nwin > 1 and a.defer_tails > 0 and name in ("basicmf", "pairwise") and not minibatch:
         shards = defer_tails(shards, a.users, a.items, a.defer_tails)
+    bpr = 1
     if stratified:
         from svdfeature_amd.multi_gpu import StratifiedTrainer, stratified_plan
         bpr = max(1, a.blocks_per_rank) if world > 1 else 1
@@ -502,10 +526,15 @@ def run_workload(name, a, env, steps, warmup, main_line):
     elapsed = time.perf_counter() - t0
     ev_ms = ev.elapsed_ms(e0, e1)
     launches = tr.counter(1) - launches0
+    per_rank = None
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        # every rank's own clock, stream time, algorithmic bytes and instance count of the timed region: the line reports the MAX clock
+        # (contract) plus the spread over the ranks and the aggregate roofline
+        mine_ = torch.tensor([elapsed, ev_ms, float(alg_bytes), float(my_n), float(launches)], dtype=torch.float64, device="cuda")
+        allr = [torch.zeros_like(mine_) for _ in range(world)]
+        dist.all_gather(allr, mine_)
+        per_rank = [[float(x) for x in t_.tolist()] for t_ in allr]
+        elapsed = max(pr[0] for pr in per_rank)
 
     # ---- one more pass with a HIP event after every phase (outside the timed region): stream time per phase of the exchange
     phase_ms = None
@@ -654,6 +683,21 @@ def run_workload(name, a, env, steps, warmup, main_line):
                                     int(tr.item_delta_count() * 4 // max(world * bpr, 1)),
                 "updates_per_item_per_window": per_item / nwin},
             "phase_ms": phase_ms,
+            # N > 1: the spread of the ranks' own clocks over the timed region, the aggregate roofline (sum of the ranks' algorithmic bytes
+            # over the contract's max-over-ranks time against N x 8 TB/s) and what DESIGN.md's model expects for this line
+            "per_rank_ms": None if (per_rank is None or world == 1) else {
+                "min": min(pr[0] for pr in per_rank) * 1e3 / steps, "max": max(pr[0] for pr in per_rank) * 1e3 / steps,
+                "stream_min": min(pr[1] for pr in per_rank) / steps, "stream_max": max(pr[1] for pr in per_rank) / steps,
+                "instances_min": min(pr[3] for pr in per_rank), "instances_max": max(pr[3] for pr in per_rank),
+                "what": "per pass; min / max over the ranks of the host clock between the two barriers (the line's ms_per_step is the max) and of the HIP-event time on each rank's stream"},
+            "roofline_aggregate": None if (per_rank is None or world == 1) else {
+                "bound": "hbm", "achieved": sum(pr[2] for pr in per_rank) * steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
+                "frac": sum(pr[2] for pr in per_rank) * steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),
+                "what": "sum over the ranks of the algorithmic bytes of their passes (SURVEY 8d4 per instance + the window step's contribution slots) / the max-over-ranks elapsed time, against N x 8 TB/s"},
+            "model_ms": None if not exchanging else model_ms(
+                name, world, "stratified" if stratified else ("minibatch" if minibatch else "levels"), n, a.items, factor, nwin,
+                world * bpr if stratified else 1, a.chunks * world * bpr if (stratified and world > 1) else 0,
+                (23.5 * n / 1e8 * factor / 64.0) if name == "basicmf" else (177.3 * n / 2e8 * factor / 128.0 if name == "pairwise" else None)),
             "conflict_free_batches_per_pass": n_batches, "schedule_build_s": round(sched_s, 2),
             "parallelism": "1 GPU" if world == 1 else "dp%d user shards + RCCL all-reduce" % world,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -786,6 +830,219 @@ def run_f3_secondary(a, env):
     return out
 
 
+# =============================================================================== N > 1: watchdog, rendezvous ladder, preflight, model
+ATTEMPT_ENV, FALLBACK_ENV = "SVDF_BENCH_ATTEMPT", "SVDF_BENCH_FALLBACK_LOG"
+# the ladder of one driver command: every rung is a fresh process image of THIS rank (os.execv keeps the pid, so the
+# torch.distributed.run agent sees nothing) that meets the others again under a new key prefix of the same TCP store
+LADDER = ["as requested", "exchange = minibatch (RCCL all-reduce only, no point-to-point ring)", "backend = gloo (host-staged exchange), exchange = minibatch"]
+
+
+class Watchdog:
+    """One deadline at a time, watched by a daemon thread: when the armed phase does not finish in time the thread dumps every Python
+    stack (faulthandler) and runs the phase's action -- which never returns (os.execv to the next ladder rung, or the JSON line + os._exit).
+    A hung RCCL call blocks the main thread inside C; this thread does not need it."""
+
+    def __init__(self, log):
+        import threading
+        self.log, self.deadline, self.what, self.action = log, None, None, None
+        self.cv = threading.Condition()
+        th = threading.Thread(target=self._run, daemon=True)
+        th.start()
+
+    def arm(self, seconds, what, action):
+        with self.cv:
+            self.deadline, self.what, self.action = time.time() + seconds, what, action
+            self.cv.notify()
+
+    def disarm(self):
+        with self.cv:
+            self.deadline = None
+            self.cv.notify()
+
+    def _run(self):
+        import faulthandler
+        while True:
+            with self.cv:
+                if self.deadline is None:
+                    self.cv.wait()
+                    continue
+                left = self.deadline - time.time()
+                if left > 0:
+                    self.cv.wait(left)
+                    continue
+                what, action = self.what, self.action
+                self.deadline = None
+            print("[bench] WATCHDOG: '%s' did not finish in time; stacks follow" % what, file=sys.stderr, flush=True)
+            try:
+                faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
+            except Exception:
+                pass
+            action("watchdog: '%s' timed out" % what)
+
+
+def fallback_log():
+    try:
+        return json.loads(os.environ.get(FALLBACK_ENV, "[]"))
+    except Exception:
+        return []
+
+
+def escalate(reason, rank, world, attempt, metric="training instances/sec (SGD updates/s), basicMF k=64"):
+    """This rank gives up the current ladder rung: re-execute bench.py one rung lower (the other ranks follow through their own
+    watchdogs / store timeouts), or, below the last rung, print the contract line with value 0 and the reasons -- a record is never lost."""
+    reasons = fallback_log() + [{"attempt": attempt, "rung": LADDER[min(attempt, len(LADDER) - 1)], "rank": rank, "reason": str(reason)[:400]}]
+    print("[bench] rank %d attempt %d failed: %s" % (rank, attempt, reason), file=sys.stderr, flush=True)
+    if attempt + 1 < len(LADDER):
+        os.environ[ATTEMPT_ENV] = str(attempt + 1)
+        os.environ[FALLBACK_ENV] = json.dumps(reasons)
+        sys.stdout.flush(); sys.stderr.flush()
+        os.execv(sys.executable, [sys.executable] + sys.argv)
+    if rank == 0:
+        print(json.dumps({"metric": metric, "value": 0.0, "unit": "instances/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None,
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "FAILED: no exchange path worked on this node"}, "exchange": {"fallback": reasons}}), flush=True)
+    os._exit(3)
+
+
+def rendezvous(torch, rank, world, local_rank, attempt, share_gpu):
+    """(dist, key-value store, backend): the process group of this ladder rung.  Under torch.distributed.run the agent hosts the TCP store
+    (workers are clients), so a re-executed rank can meet the others again: every rung uses its own key prefix."""
+    import datetime
+    import torch.distributed as dist
+    host, port = os.environ.setdefault("MASTER_ADDR", "127.0.0.1"), int(os.environ.setdefault("MASTER_PORT", "29533"))
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE") == "True"
+    if not agent:
+        port += attempt   # rank 0 hosts the store itself: a fresh port per rung
+    tcp = dist.TCPStore(host, port, world, is_master=(not agent and rank == 0), timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+    store = dist.PrefixStore("svdf_bench_try%d" % attempt, tcp)
+    backend = "gloo" if (share_gpu or attempt >= 2) else "nccl"
+    kw = {} if backend == "gloo" else {"device_id": torch.device("cuda", local_rank)}
+    dist.init_process_group(backend, store=dist.PrefixStore("pg", store), rank=rank, world_size=world, timeout=datetime.timedelta(seconds=600), **kw)
+    return dist, store, backend
+
+
+def store_agree(store, rank, world, key, ok, seconds=120):
+    """every rank publishes ok / not ok under `key` and reads everybody's: host-side only (no collective), so it also works when the
+    collective under test is what is broken.  Raises when a rank said no or did not answer."""
+    import datetime
+    store.set("%s/%d" % (key, rank), "1" if ok else "0")
+    store.wait(["%s/%d" % (key, r) for r in range(world)], datetime.timedelta(seconds=seconds))
+    bad = [r for r in range(world) if store.get("%s/%d" % (key, r)) != b"1"]
+    if bad:
+        raise RuntimeError("%s failed on ranks %s" % (key, bad))
+
+
+def preflight(torch, dist, rank, world, device, ring, log):
+    """Before any training: the collectives the run will use, on small and on run-sized buffers, results CHECKED.
+    (1) all_reduce of 1 K floats and of a window's wire buffer (13 MB fp16 at configs[2]);
+    (2) when the stratified ring is the plan: batch_isend_irecv rank r -> r - 1 exactly as HipShard.handoff_start / handoff_wait issue it
+        (inside a side stream's context, wait() = stream wait), 1 K floats and one item block (1.6 MB).
+    Returns the measured times (they sit next to the model numbers in the JSON line)."""
+    out = {}
+    stream = torch.cuda.Stream(device=device)
+
+    def timed(fn, reps):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e6
+    with torch.cuda.stream(stream):
+        small = torch.full((1024,), float(rank + 1), device=device)
+        dist.all_reduce(small)
+        stream.synchronize()
+        want = world * (world + 1) / 2.0
+        if not bool((small == want).all().item()):
+            raise RuntimeError("preflight all_reduce: wrong sum %r (want %r)" % (float(small[0].item()), want))
+        big = torch.zeros(13 * 1024 * 1024 // 2, device=device, dtype=torch.float16)
+        out["allreduce_13MB_fp16_us"] = timed(lambda: dist.all_reduce(big), 10)
+        out["allreduce_4KB_us"] = timed(lambda: dist.all_reduce(small), 20)
+    if ring:
+        dst, src = (rank - 1) % world, (rank + 1) % world
+        for nfl, key, reps in ((1024, "handoff_4KB_us", 20), (400 * 1024, "handoff_1.6MB_us", 10)):
+            snd = torch.full((nfl,), float(rank), device=device)
+            rcv = torch.full((nfl,), -1.0, device=device)
+
+            def once():
+                with torch.cuda.stream(stream):
+                    reqs = dist.batch_isend_irecv([dist.P2POp(dist.isend, snd, dst), dist.P2POp(dist.irecv, rcv, src)])
+                    for q in reqs:
+                        q.wait()
+            once()
+            stream.synchronize()
+            if not bool((rcv == float(src)).all().item()):
+                raise RuntimeError("preflight ring hand-over: rank %d received %r from rank %d" % (rank, float(rcv[0].item()), src))
+            out[key] = timed(once, reps)
+    log("preflight ok: %s" % json.dumps({k: round(v, 1) for k, v in out.items()}))
+    return out
+
+
+def model_ms(name, world, exchange_step, n, items, factor, nwin, blocks, handoffs, t1_ms):
+    """What DESIGN.md sections 6c / 6d / 6f expect for this line, so that a hardware curve can be checked against the model from the line
+    itself.  compute share = the one-GPU share table of 6c / 6f where the workload is the contract one (100 M ratings, k = 64), else T1 / N;
+    all-reduce schemes: per-link-bound ring, 2 (N-1)/N x bytes / 153 GB/s + 30 us per window, not overlapped;
+    stratified: `handoffs` point-to-point transfers per rank and pass of one item block (NI / blocks rows, fp32) over one xGMI link,
+    bytes / 64 GB/s + 25 us each -- hidden behind the next step's training at 2 blocks per rank (lower figure), serial at 1 (upper)."""
+    contract = name == "basicmf" and n == 100_000_000 and items == 100_000 and factor == 64
+    table = {"minibatch": {2: 10.76, 4: 5.50, 8: 2.98}, "stratified": {2: 9.63, 4: 4.95, 8: 2.66}}
+    share = table.get(exchange_step, {}).get(world) if contract else None
+    src = "compute share: one rank's share measured on one GPU (DESIGN.md 6c / 6f)"
+    if share is None:
+        share, src = (t1_ms / world if t1_ms else None), "compute share: T1 / N with T1 = 23.5 ms per 100 M ratings (k = 64) scaled by size and width"
+    if share is None:
+        return None
+    if exchange_step == "stratified":
+        per = items * (factor + 1) * 4.0 / max(blocks, 1) / 64e9 * 1e3 + 0.025
+        lo, hi = share, share + handoffs * per
+        return {"compute_share_ms": share, "handoff_ms_each": per, "handoffs_per_rank": handoffs, "total_ms": [lo, hi],
+                "speedup_over_one_gpu": [t1_ms / hi, t1_ms / lo] if t1_ms else None, "source": src + "; hand-overs: DESIGN.md 6f"}
+    t_ar = 2.0 * (world - 1) / world * items * (factor + 1) * 2.0 / 153e9 * 1e3 + 0.030
+    total = share + nwin * t_ar
+    return {"compute_share_ms": share, "allreduce_ms_per_window": t_ar, "exchange_ms": nwin * t_ar, "total_ms": total,
+            "speedup_over_one_gpu": (t1_ms / total) if t1_ms else None, "source": src + "; ring all-reduce: DESIGN.md 6d"}
+
+
+def run_single_process_handle(sa, a, world, xch, device, log):
+    """secondary.single_process_handle: ONE svdf_trainer with amd:gpus = N (svdf_multi.cpp: N engines on N devices, one host thread per rank,
+    HIP events between the ranks' streams) trains the main line's ratings from a resident data set -- the window-minibatch step with the
+    handle's own exchange: amd:exchange = p2p (hipDeviceEnablePeerAccess + k_delta_reduce_gather through peer pointers over all xGMI links)
+    or rccl (ncclCommInitAll + grouped ncclAllReduce).  Host clock around svdf_train_dataset + synchronize, 1 warm-up + 3 timed passes."""
+    n = a.ratings
+    u, i, r = cached(synth_triples, n + 1_000_000, a.users, a.items)
+    test = (u[n:n + 200000], i[n:n + 200000], r[n:n + 200000])
+    u, i, r = u[:n], i[:n], r[:n]
+    nwin = max(1, int(np.ceil(n / max(a.items, 1) / 32.0)))
+    t0 = time.time()
+    t = sa.Trainer(0, 0, device=device)
+    t.seed(10)
+    for k, v in conf_for(a) + [("amd:gpus", str(world)), ("amd:exchange", xch), ("amd:step", "minibatch"), ("amd:window", str(-(-n // nwin)))]:
+        t.set_param(k, v)
+    t.init_model()
+    t.init_trainer()
+    ds = t.dataset_from_triples(u, i, r)
+    build_s = time.time() - t0
+    t.train_dataset(ds)
+    t.synchronize()
+    steps = 3
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        t.train_dataset(ds)
+    t.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    pred = t.predict_batch(sa.CSRData.from_triples(*test))
+    res = {"value": n / dt, "unit": "instances/s", "ms_per_step": dt * 1e3, "steps": steps, "warmup": 1, "windows": nwin,
+           "exchanges": t.counter(8), "exchange_path": "rccl" if t.counter(12) == 1 else "p2p", "devices_distinct": bool(t.counter(10)),
+           "window_minibatch_windows": t.counter(11), "rmse_test_after_run": rmse(pred, test[2]), "passes_before_rmse": steps + 1,
+           "build_s": round(build_s, 1),
+           "what": "one process, one C-ABI handle, amd:gpus = %d, amd:exchange = %s, fp16 wire format, resident data set sharded by user inside the handle" % (world, xch)}
+    log("single-process handle (%s): %.2f ms per pass = %.2f G inst/s, rmse %.6f" % (xch, dt * 1e3, n / dt / 1e9, res["rmse_test_after_run"]))
+    ds.close()
+    t.close()
+    return res
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -838,8 +1095,18 @@ def main():
     ap.add_argument("--groups-per-wave", type=int, default=0)
     ap.add_argument("--knob", action="append", default=[], help="extra tuning knob name=value (svdf_set_knob), repeatable")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pmc", action="store_true",
-                    help="measure roofline.traffic in this run (two extra rocprofv3 --pmc passes per workload, ~1 min each) instead of quoting profiles/hbm_traffic.json")
+    ap.add_argument("--pmc", choices=["auto", "all", "off"], default="auto", nargs="?", const="all",
+                    help="N = 1: measure roofline.traffic in this run with two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over one pass of the workload in "
+                         "a child process.  auto (default): the MAIN workload, capped at --pmc-cap seconds (a pass that does not fit quotes the committed "
+                         "profiles/hbm_traffic.json and says so); all: the secondary workloads too, no cap; off: quote the committed file")
+    ap.add_argument("--pmc-cap", type=float, default=150.0, help="--pmc auto: seconds the in-run counter passes may take in total")
+    ap.add_argument("--no-preflight", action="store_true", help="N>1: skip the checked all_reduce / ring hand-over before the run")
+    ap.add_argument("--preflight-timeout", type=float, default=150.0, help="N>1: watchdog of rendezvous + preflight (seconds); on expiry the rank re-executes one ladder rung lower")
+    ap.add_argument("--run-timeout", type=float, default=900.0, help="N>1: watchdog of the main workload (seconds)")
+    ap.add_argument("--secondary-timeout", type=float, default=420.0, help="N>1: watchdog of each secondary (seconds); on expiry the contract line is printed without it")
+    ap.add_argument("--no-multi-secondary", action="store_true",
+                    help="N>1, ratings: skip secondary.allreduce_minibatch (the RCCL all-reduce step on the same data) and secondary.single_process_handle (rank 0 alone "
+                         "drives all N devices through one amd:gpus handle, amd:exchange = p2p and rccl)")
     ap.add_argument("--secondary", default="auto", help="comma list of secondary workloads for the N=1 line (auto = all three with the default main line, none otherwise)")
     ap.add_argument("--secondary-steps", type=int, default=2)
     ap.add_argument("--defer-tails", type=float, default=0.05,
@@ -861,6 +1128,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    attempt = int(os.environ.get(ATTEMPT_ENV, "0"))
     if world != a.gpus:
         print("[bench] WORLD_SIZE=%d overrides --gpus %d" % (world, a.gpus), file=sys.stderr)
         a.gpus = world
@@ -869,16 +1137,35 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
+    metric = {"basicmf": "training instances/sec (SGD updates/s), basicMF k=%d" % (a.factor or 64),
+              "pairwise": "training pairs/sec (SGD updates/s), pairwiseRank k=%d" % (a.factor or 128),
+              "svdpp": "training instances/sec (SGD updates/s), SVD++ implicit feedback k=%d" % (a.factor or 128),
+              "neighbourhood": "training instances/sec (SGD updates/s), neighbourhood model k=%d" % (a.factor or 128)}[a.workload]
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     a.pmc_results = {}
-    if a.pmc and world == 1 and not a.force_exchange:
-        # before this process opens the device, so that the counted child is alone on the GPU (the same commands as tools/profile_round3.sh)
+    if a.pmc != "off" and world == 1 and not a.force_exchange:
+        # before this process opens the device, so that the counted child is alone on the GPU (the same commands as tools/profile_round3.sh).
+        # auto: the main workload only, under a 150 s cap (a pass that does not fit falls back to the committed profiles/hbm_traffic.json);
+        # the children read this process's synthetic stream from /dev/shm instead of drawing it again
+        import shutil, tempfile
         sec0 = a.secondary
         if sec0 == "auto":
             sec0 = "pairwise,svdpp,neighbourhood" if (a.workload == "basicmf" and a.ratings == 100_000_000) else ""
-        for nm in [a.workload] + [x for x in sec0.split(",") if x and x != a.workload]:
-            if nm in PMC_KERNEL:
-                a.pmc_results[nm] = measure_traffic(nm, a, log)
+        names = [a.workload] + ([x for x in sec0.split(",") if x and x != a.workload] if a.pmc == "all" else [])
+        cache = tempfile.mkdtemp(prefix="svdf_bench_data_", dir="/dev/shm" if os.path.isdir("/dev/shm") else "/tmp")
+        try:
+            os.environ["SVDF_BENCH_DATA_CACHE"] = cache
+            if a.workload == "basicmf":
+                os.environ["SVDF_BENCH_DATA_CACHE_WRITE"] = "1"
+                cached(synth_triples, a.ratings + 1_000_000, a.users, a.items)
+                os.environ.pop("SVDF_BENCH_DATA_CACHE_WRITE", None)
+            deadline = None if a.pmc == "all" else time.time() + a.pmc_cap
+            for nm in names:
+                if nm in PMC_KERNEL:
+                    a.pmc_results[nm] = measure_traffic(nm, a, log, deadline)
+        finally:
+            os.environ.pop("SVDF_BENCH_DATA_CACHE", None)
+            shutil.rmtree(cache, ignore_errors=True)
     import torch
     import svdfeature_amd as sa   # noqa: F401  (fails loudly when the HIP library is missing: there is no CPU fallback)
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs (no CPU fallback)"
@@ -888,8 +1175,40 @@ def main():
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1 or a.force_exchange:
+    dist, store, backend, pf, wd = None, None, None, None, None
+
+    def esc(reason):
+        escalate(reason, rank, world, attempt, metric)
+    if world > 1:
+        # ---- the N > 1 ladder: rendezvous + preflight under a watchdog; a rung that fails or hangs is left through
+        # os.execv, so ONE driver command always ends in a JSON line
+        wd = Watchdog(log)
+        requested = a.exchange
+        if attempt >= 1 and a.exchange in ("auto", "stratified"):
+            a.exchange = "minibatch"
+        if attempt >= 1:
+            log("ladder rung %d: %s (after: %s)" % (attempt, LADDER[attempt], json.dumps(fallback_log())))
+        wd.arm(a.preflight_timeout, "rendezvous + preflight", esc)
+        try:
+            dist, store, backend = rendezvous(torch, rank, world, local_rank, attempt, share_gpu)
+            ring = a.workload == "basicmf" and a.exchange in ("auto", "stratified")
+            ok, err = True, None
+            try:
+                if not a.no_preflight:
+                    if os.environ.get("SVDF_BENCH_TEST_FAIL_PREFLIGHT") == str(attempt) and rank == world - 1:
+                        raise RuntimeError("injected preflight failure (test hook)")
+                    if os.environ.get("SVDF_BENCH_TEST_HANG_PREFLIGHT") == str(attempt) and rank == world - 1:
+                        time.sleep(10 ** 6)
+                    pf = preflight(torch, dist, rank, world, torch.device("cuda", local_rank), ring, log)
+            except Exception as e:
+                ok, err = False, repr(e)
+            store_agree(store, rank, world, "preflight", ok, seconds=a.preflight_timeout)
+            if not ok:
+                raise RuntimeError(err)
+        except Exception as e:
+            esc("rendezvous / preflight: %r" % (e,))
+        wd.arm(a.run_timeout, "main workload", esc)
+    elif a.force_exchange:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
@@ -899,11 +1218,58 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     env = {"torch": torch, "dist": dist, "rank": rank, "world": world, "local_rank": local_rank, "log": log}
 
-    main_res = run_workload(a.workload, a, env, a.steps, a.warmup, True)
+    try:
+        main_res = run_workload(a.workload, a, env, a.steps, a.warmup, True)
+    except Exception as e:
+        if world > 1:
+            import traceback
+            traceback.print_exc()
+            esc("main workload: %r" % (e,))
+        raise
+    out = None
+    if rank == 0:
+        m = main_res
+        out = {
+            "metric": metric, "value": m["value"], "unit": m["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": m["ms_per_step"], "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": m["workload"], "order": m["order"],
+                       "conflict_free_batches_per_pass": m["conflict_free_batches_per_pass"], "schedule_build_s": m["schedule_build_s"],
+                       "parallelism": m["parallelism"]},
+            "roofline": m["roofline"], "cpu_baseline": m["cpu_baseline"], "parity": m["parity"],
+            "end_to_end": m["end_to_end"],
+        }
+        for k in ("rmse_test_after_run", "passes_before_rmse", "rmse_sequential_reference", "rmse_minus_sequential", "exchange", "phase_ms",
+                  "per_rank_ms", "roofline_aggregate", "model_ms",
+                  "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound", "launch_model"):
+            if m.get(k) is not None:
+                out[k] = m[k]
+        if world > 1:
+            out["exchange"] = dict(out.get("exchange") or {}, backend=backend, ladder_rung=attempt, ladder=LADDER[attempt],
+                                   fallback=fallback_log() or None, preflight_us=pf)
+
+    def emit(extra=None):
+        if rank == 0:
+            if extra:
+                out.update(extra)
+            sys.stdout.flush()
+            C.CDLL(None).fflush(None)   # RCCL prints its version banner through C stdio: push it out BEFORE the JSON line, which stays the last line
+            print(json.dumps(out), flush=True)
+
+    def finish_now(reason):
+        """watchdog action of the secondaries: the contract line goes out with what is there, every rank leaves without another collective"""
+        emit({"secondary_error": reason})
+        sys.stderr.flush()
+        os._exit(0)
+
     secondary = {}
+    if out is not None:
+        out["secondary"] = secondary
     sec = a.secondary
     if sec == "auto":
         sec = "pairwise,svdpp,neighbourhood" if (a.workload == "basicmf" and world == 1 and a.ratings == 100_000_000) else ""
+    if wd is not None:
+        wd.arm(a.secondary_timeout, "secondary workloads", finish_now)
     for name in [s for s in sec.split(",") if s]:
         if name == a.workload or (world > 1 and name == "neighbourhood"):
             continue
@@ -917,34 +1283,59 @@ def main():
             secondary.update(run_f3_secondary(a, env))
         except Exception as e:   # the f3 rows are extras: never lose the contract line over them
             secondary["f3_error"] = repr(e)
-    if rank == 0:
-        m = main_res
-        metric = {"basicmf": "training instances/sec (SGD updates/s), basicMF k=%d" % (a.factor or 64),
-                  "pairwise": "training pairs/sec (SGD updates/s), pairwiseRank k=%d" % (a.factor or 128),
-                  "svdpp": "training instances/sec (SGD updates/s), SVD++ implicit feedback k=%d" % (a.factor or 128),
-                  "neighbourhood": "training instances/sec (SGD updates/s), neighbourhood model k=%d" % (a.factor or 128)}[a.workload]
-        out = {
-            "metric": metric, "value": m["value"], "unit": m["unit"], "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": m["ms_per_step"], "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": m["workload"], "order": m["order"],
-                       "conflict_free_batches_per_pass": m["conflict_free_batches_per_pass"], "schedule_build_s": m["schedule_build_s"],
-                       "parallelism": m["parallelism"]},
-            "roofline": m["roofline"], "cpu_baseline": m["cpu_baseline"], "parity": m["parity"],
-            "end_to_end": m["end_to_end"],
-        }
-        for k in ("rmse_test_after_run", "passes_before_rmse", "rmse_sequential_reference", "rmse_minus_sequential", "exchange", "phase_ms",
-                  "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound", "launch_model"):
-            if m.get(k) is not None:
-                out[k] = m[k]
-        if secondary:
-            out["secondary"] = secondary
-        sys.stdout.flush()
-        C.CDLL(None).fflush(None)   # RCCL prints its version banner through C stdio: push it out BEFORE the JSON line, which stays the last line
-        print(json.dumps(out), flush=True)
+
+    # ---- N > 1, ratings: the other exchange designs on the SAME data in the SAME driver command
+    if world > 1 and a.workload == "basicmf" and not a.no_multi_secondary:
+        import argparse as _ap
+        main_step = (main_res or {}).get("exchange", {}).get("step") if rank == 0 else None
+        # (1) north_star's step: RCCL all-reduce of the per-item sums every window (window-minibatch step), when the main line was the ring
+        if a.exchange in ("auto", "stratified"):
+            wd.arm(a.secondary_timeout, "secondary: all-reduce window-minibatch step", finish_now)
+            a2 = _ap.Namespace(**vars(a))
+            a2.exchange, a2.no_cpu_baseline = "minibatch", True
+            t0 = time.time()
+            try:
+                r = run_workload("basicmf", a2, env, 3, 1, False)
+            except Exception as e:
+                import traceback
+                traceback.print_exc()
+                finish_now("allreduce_minibatch on rank %d: %r" % (rank, e))
+            if r is not None:
+                keep = ("value", "unit", "ms_per_step", "order", "exchange", "phase_ms", "per_rank_ms", "roofline", "roofline_aggregate", "model_ms",
+                        "rmse_test_after_run", "passes_before_rmse", "rmse_sequential_reference", "rmse_minus_sequential")
+                secondary["allreduce_minibatch"] = dict({k: r[k] for k in keep if r.get(k) is not None}, wall_s=round(time.time() - t0, 1), steps=3, warmup=1)
+        # (2) the same algorithm behind ONE C-ABI handle: rank 0 alone drives all N devices from C++ (svdf_multi.cpp), direct peer exchange
+        # and RCCL from the engine; the other ranks idle on the host (their GPUs hold no running kernel) until rank 0 says so through the store
+        wd.arm(a.secondary_timeout, "secondary: single-process amd:gpus handle", finish_now)
+        if rank == 0:
+            sp = {}
+            for xch in ("p2p", "rccl"):
+                try:
+                    sp[xch] = run_single_process_handle(sa, a, world, xch, 0 if share_gpu else local_rank, log)
+                except Exception as e:
+                    sp[xch] = {"error": repr(e)[:600]}
+                    log("single-process handle, amd:exchange = %s: %r" % (xch, e))
+            secondary["single_process_handle"] = sp
+            store.set("single_process_done", "1")
+        else:
+            import datetime
+            try:
+                store.wait(["single_process_done"], datetime.timedelta(seconds=a.secondary_timeout + 30))
+            except Exception:
+                pass
+    if wd is not None:
+        wd.disarm()
+    if out is not None and not secondary:
+        out.pop("secondary", None)
+    emit()
     if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        if wd is not None:
+            wd.arm(60, "shutdown", lambda reason: os._exit(0))
+        try:
+            dist.barrier()
+            dist.destroy_process_group()
+        except Exception:
+            pass
 
 
 if __name__ == "__main__":

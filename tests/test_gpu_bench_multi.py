@@ -1,0 +1,67 @@
+"""bench.py --gpus N end to end on the ONE-GPU test box (SVDF_BENCH_SHARE_GPU=1: every rank on GPU 0, exchange through gloo): the whole
+N > 1 flow of one driver command -- rendezvous + checked preflight under the watchdog, the stratified ring as the main line, the all-reduce
+window-minibatch step and the single-process amd:gpus handle as secondaries on the same data -- ends in ONE JSON line with the fields the
+scaling record is read from, inside the accuracy contract |dRMSE| <= 1e-4.  Replaces svd_feature.cpp:220-248,
+272-283 (the reference's round loop) on N ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(args, extra_env=None, timeout=1500):
+    env = dict(os.environ, SVDF_BENCH_SHARE_GPU="1")
+    for k in ("SVDF_BENCH_ATTEMPT", "SVDF_BENCH_FALLBACK_LOG", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    env.update(extra_env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-4000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line expected:\n" + p.stdout[-2000:]
+    return json.loads(lines[0]), p.stderr
+
+
+def test_two_ranks_one_command_yields_every_multi_gpu_number():
+    # a replica of configs[2] at its density (100 ratings per user, 1000 per item): at 5 M ratings over the full 1 M x 100 K id space
+    # (5 per user) the RMSE moves by 2e-4 under ANY reordering of the file, which says nothing about the exchange
+    line, err = _bench(["--gpus", "2", "--users", "50000", "--items", "5000", "--ratings", "5000000", "--steps", "2"])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "exchange", "phase_ms", "per_rank_ms", "roofline_aggregate", "model_ms",
+                "rmse_test_after_run", "rmse_sequential_reference", "rmse_minus_sequential", "secondary"):
+        assert key in line, key
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["value"] > 0 and line["unit"] == "instances/s"
+    x = line["exchange"]
+    assert x["step"] == "stratified" and x["ladder_rung"] == 0 and x["fallback"] is None and x["backend"] == "gloo"
+    assert set(("allreduce_4KB_us", "allreduce_13MB_fp16_us", "handoff_4KB_us", "handoff_1.6MB_us")) <= set(x["preflight_us"])
+    assert abs(line["rmse_minus_sequential"]) <= 1e-4
+    pr = line["per_rank_ms"]
+    assert 0 < pr["min"] <= pr["max"] and abs(pr["max"] - line["ms_per_step"]) < 1e-6
+    assert pr["instances_min"] + pr["instances_max"] == 5000000
+    ra = line["roofline_aggregate"]
+    assert ra["peak"] == 16000.0 and 0 < ra["frac"] < 1
+    assert line["model_ms"]["compute_share_ms"] > 0
+    # north_star's step on the same data, same command
+    ar = line["secondary"]["allreduce_minibatch"]
+    assert ar["exchange"]["step"] == "minibatch" and ar["value"] > 0 and abs(ar["rmse_minus_sequential"]) <= 1e-4
+    assert set(("compute", "pack", "allreduce", "unpack")) <= set(ar["phase_ms"])
+    # one C-ABI handle over both (here: virtual) ranks: the peer-pointer exchange runs; RCCL refuses ranks that share a device, and says so
+    sp = line["secondary"]["single_process_handle"]
+    assert sp["p2p"]["value"] > 0 and sp["p2p"]["exchange_path"] == "p2p" and sp["p2p"]["exchanges"] > 0
+    assert abs(sp["p2p"]["rmse_test_after_run"] - ar["rmse_sequential_reference"]) < 5e-3   # 4 passes against the secondary's 5: same ball park
+    assert "error" in sp["rccl"] or sp["rccl"]["value"] > 0
+
+
+@pytest.mark.parametrize("hook", ["SVDF_BENCH_TEST_FAIL_PREFLIGHT", "SVDF_BENCH_TEST_HANG_PREFLIGHT"])
+def test_a_broken_ring_preflight_falls_back_to_the_all_reduce_step_and_says_so(hook):
+    line, err = _bench(["--gpus", "2", "--users", "100000", "--items", "10000", "--ratings", "1000000", "--steps", "1", "--no-multi-secondary",
+                        "--no-cpu-baseline", "--preflight-timeout", "45"], {hook: "0"})
+    x = line["exchange"]
+    assert x["ladder_rung"] == 1 and x["step"] == "minibatch"
+    assert x["fallback"] and x["fallback"][0]["attempt"] == 0
+    assert line["value"] > 0 and abs(line["rmse_minus_sequential"]) <= 1e-4
