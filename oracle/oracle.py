@@ -66,6 +66,8 @@ def _load(kind):
     lib.svdo_predict_csr_batch.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p]
     lib.svdo_update_csr_batch_stale.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p, _f32p, _f32p]
     lib.svdo_update_csr_batch_stale.restype = C.c_int
+    lib.svdo_update_block_stale.argtypes = [P, C.c_int, C.c_int, _u32p, _f32p, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
+    lib.svdo_update_block_stale.restype = C.c_int
     lib.svdo_update_block.argtypes = [P, C.c_int, C.c_int, _u32p, _f32p, C.c_int, _f32p, _i32p, _u32p, _f32p]
     lib.svdo_predict_block.argtypes = lib.svdo_update_block.argtypes + [_f32p]
     lib.svdo_get_view.argtypes = [P, C.c_int, _f32p, C.c_long]
@@ -184,6 +186,32 @@ class OracleTrainer:
                                                   dW.reshape(-1) if dW.size else np.zeros(1, np.float32), db if db.size else np.zeros(1, np.float32),
                                                   dg if dg.size else np.zeros(1, np.float32))
         assert rc == 0, "window-minibatch step: configuration not supported by this checker"
+        return delta
+
+    def stale_delta_zero(self):
+        """zeroed delta arrays of the window-minibatch checker step for a user-group trainer:
+        (dW_item, di_bias, dg_bias, dW_ufeedback, dufeedback_bias), unpadded"""
+        shp = {}
+        for name in ("W_item", "i_bias", "g_bias", "W_ufeedback", "ufeedback_bias"):
+            rows, cols = C.c_int(), C.c_int()
+            self.lib.svdo_view_shape(self.h, VIEW[name], C.byref(rows), C.byref(cols))
+            shp[name] = (max(rows.value, 0), max(cols.value, 1))
+        return (np.zeros(shp["W_item"], np.float32), np.zeros(shp["i_bias"][0], np.float32), np.zeros(shp["g_bias"][0], np.float32),
+                np.zeros(shp["W_ufeedback"], np.float32), np.zeros(shp["ufeedback_bias"][0], np.float32))
+
+    def update_block_stale(self, b, delta=None):
+        """The window-minibatch checker step for one user-group block (svdf_oracle.h: svdo_update_block_stale): the reference's
+        update(block) on (the user's private state, the window-start replicated side); the replicated side stays as it is and its change
+        is accumulated in file order into `delta` (stale_delta_zero()), which is returned."""
+        if delta is None:
+            delta = self.stale_delta_zero()
+        d = b.data
+        z = np.zeros(1, np.float32)
+        arrs = [x.reshape(-1) if x.size else z for x in delta]
+        rc = self.lib.svdo_update_block_stale(self.h, b.num_ufeedback, b.extend_tag, _pad(b.index_ufeedback, np.uint32), _pad(b.value_ufeedback, np.float32),
+                                              d.num_row, _pad(d.row_label, np.float32), _pad(d.row_ptr, np.int32), _pad(d.feat_index, np.uint32),
+                                              _pad(d.feat_value, np.float32), *arrs)
+        assert rc == 0, "window-minibatch block step: configuration not supported by this checker"
         return delta
 
     def predict_batch(self, d):

@@ -223,37 +223,81 @@ static void load_from_bytes(svdo_trainer *t, std::vector<char> &buf) {
     }
     fclose(fi);
 }
+/* one row: ISVDTrainer::update(elem) -- or, for a user-group trainer, update(MIDDLE block holding that one row) = update_each of the
+ * row (apex_svd_base.h:560-565, 568-582) -- then the replicated rows it touched are diffed against the bytes of before and put back */
+static int stale_row_ref(svdo_trainer *t, const SVDFeatureCSR::Elem &e, const SVDPlusBlock *as_block, float *dW_item, float *di_bias, float *dg_bias) {
+    std::vector<char> before, after;
+    view_pos vw, vb, vg;
+    if (!dump_model(t, before)) return -1;
+    if (!locate(t, before, 3, vw) || !locate(t, before, 2, vb) || !locate(t, before, 4, vg)) return -1;
+    if (as_block) t->tr->update(*as_block);
+    else t->tr->update(e);
+    if (!dump_model(t, after)) return -1;
+    const int k = vw.cols;
+    for (int i = 0; i < e.num_ifactor; i++) {
+        const unsigned iid = e.index_ifactor[i];
+        float *a = reinterpret_cast<float *>(after.data() + vw.off) + (size_t)iid * k;
+        const float *b = reinterpret_cast<const float *>(before.data() + vw.off) + (size_t)iid * k;
+        for (int j = 0; j < k; j++) { float c = a[j] - b[j]; dW_item[(size_t)iid * k + j] = dW_item[(size_t)iid * k + j] + c; a[j] = b[j]; }
+        float *ab = reinterpret_cast<float *>(after.data() + vb.off) + iid;
+        const float *bb = reinterpret_cast<const float *>(before.data() + vb.off) + iid;
+        float cb = *ab - *bb;
+        di_bias[iid] = di_bias[iid] + cb;
+        *ab = *bb;
+    }
+    for (int i = 0; i < e.num_global; i++) {
+        const unsigned gid = e.index_global[i];
+        float *ag = reinterpret_cast<float *>(after.data() + vg.off) + gid;
+        const float *bg = reinterpret_cast<const float *>(before.data() + vg.off) + gid;
+        float c = *ag - *bg;
+        dg_bias[gid] = dg_bias[gid] + c;
+        *ag = *bg;
+    }
+    load_from_bytes(t, after);
+    return 0;
+}
 int svdo_update_csr_batch_stale(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
                                 const unsigned *feat_index, const float *feat_value, float *dW_item, float *di_bias, float *dg_bias) {
     if (t->mtype.format_type != 0 || t->mtype.extend_type != 0) return -1;
     SVDFeatureCSR m = make_csr(num_row, row_label, row_ptr, feat_index, feat_value);
-    std::vector<char> before, after;
-    view_pos vw, vb, vg;
+    for (int r = 0; r < num_row; r++)
+        if (stale_row_ref(t, m[r], NULL, dW_item, di_bias, dg_bias) != 0) return -1;
+    return 0;
+}
+/* The block step of svdf_oracle.h on the reference's own SVDPPFeature.  update(block) with tag T is, by the reference's own code
+ * (:568-582), the sequence  [T opens: prepare_ufeedback + backup]  update_each(rows)  [T closes: update_ufeedback]; the same sequence is
+ * issued here as update(START block without rows), update(MIDDLE block with ONE row) per row, update(END block without rows), so that the
+ * replicated side can be diffed and put back (save_model / load_model, which leave the trainer's tmp_ufeedback state alone) in between. */
+int svdo_update_block_stale(svdo_trainer *t, int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb,
+                            int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value,
+                            float *dW_item, float *di_bias, float *dg_bias, float *dW_fb, float *dfb_bias) {
+    if (t->mtype.format_type != 1 || t->mtype.extend_type != 0) return -1;
+    const int none[1] = {0};
+    if (extend_tag == svdpp_tag::DEFAULT || extend_tag == svdpp_tag::START_TAG)
+        t->tr->update(make_block(nfb, svdpp_tag::START_TAG, idx_fb, val_fb, 0, row_label, none, feat_index, feat_value));
+    SVDFeatureCSR m = make_csr(num_row, row_label, row_ptr, feat_index, feat_value);
     for (int r = 0; r < num_row; r++) {
-        if (!dump_model(t, before)) return -1;
-        if (!locate(t, before, 3, vw) || !locate(t, before, 2, vb) || !locate(t, before, 4, vg)) return -1;
-        SVDFeatureCSR::Elem e = m[r];
-        t->tr->update(e);
+        int one_ptr[4] = {row_ptr[3 * r] - row_ptr[3 * r], row_ptr[3 * r + 1] - row_ptr[3 * r], row_ptr[3 * r + 2] - row_ptr[3 * r], row_ptr[3 * r + 3] - row_ptr[3 * r]};
+        SVDPlusBlock b = make_block(nfb, svdpp_tag::MIDDLE_TAG, idx_fb, val_fb, 1, row_label + r, one_ptr, feat_index + row_ptr[3 * r], feat_value + row_ptr[3 * r]);
+        if (stale_row_ref(t, m[r], &b, dW_item, di_bias, dg_bias) != 0) return -1;
+    }
+    if (extend_tag == svdpp_tag::DEFAULT || extend_tag == svdpp_tag::END_TAG) {
+        std::vector<char> before, after;
+        view_pos vw, vb;
+        if (!dump_model(t, before) || !locate(t, before, 6, vw) || !locate(t, before, 5, vb)) return -1;
+        t->tr->update(make_block(nfb, svdpp_tag::END_TAG, idx_fb, val_fb, 0, row_label, none, feat_index, feat_value));
         if (!dump_model(t, after)) return -1;
         const int k = vw.cols;
-        for (int i = 0; i < e.num_ifactor; i++) {
-            const unsigned iid = e.index_ifactor[i];
-            float *a = reinterpret_cast<float *>(after.data() + vw.off) + (size_t)iid * k;
-            const float *b = reinterpret_cast<const float *>(before.data() + vw.off) + (size_t)iid * k;
-            for (int j = 0; j < k; j++) { float c = a[j] - b[j]; dW_item[(size_t)iid * k + j] = dW_item[(size_t)iid * k + j] + c; a[j] = b[j]; }
-            float *ab = reinterpret_cast<float *>(after.data() + vb.off) + iid;
-            const float *bb = reinterpret_cast<const float *>(before.data() + vb.off) + iid;
+        for (int i = 0; i < nfb; i++) {
+            const unsigned fid = idx_fb[i];
+            float *a = reinterpret_cast<float *>(after.data() + vw.off) + (size_t)fid * k;
+            const float *b = reinterpret_cast<const float *>(before.data() + vw.off) + (size_t)fid * k;
+            for (int j = 0; j < k; j++) { float c = a[j] - b[j]; dW_fb[(size_t)fid * k + j] = dW_fb[(size_t)fid * k + j] + c; a[j] = b[j]; }
+            float *ab = reinterpret_cast<float *>(after.data() + vb.off) + fid;
+            const float *bb = reinterpret_cast<const float *>(before.data() + vb.off) + fid;
             float cb = *ab - *bb;
-            di_bias[iid] = di_bias[iid] + cb;
+            dfb_bias[fid] = dfb_bias[fid] + cb;
             *ab = *bb;
-        }
-        for (int i = 0; i < e.num_global; i++) {
-            const unsigned gid = e.index_global[i];
-            float *ag = reinterpret_cast<float *>(after.data() + vg.off) + gid;
-            const float *bg = reinterpret_cast<const float *>(before.data() + vg.off) + gid;
-            float c = *ag - *bg;
-            dg_bias[gid] = dg_bias[gid] + c;
-            *ag = *bg;
         }
         load_from_bytes(t, after);
     }

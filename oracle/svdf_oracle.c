@@ -871,43 +871,52 @@ void svdo_update_csr_batch(svdo_trainer *t, int num_row, const float *row_label,
  * sequential SGD, the replicated side one minibatch step per window: replicated += sum of the deltas of all ranks.
  * Returns 0, or -1 for configurations whose per-instance step has side effects outside those rows (lazy decay, side tables on
  * the item side, user-group trainers). */
+/* one row of the checker step: update_inner on (current private side, window-start replicated side); the change of the row's item
+ * rows / biases and global biases goes to the delta arrays, the rows themselves are put back */
+typedef struct { float *buf; size_t cap; } stale_save;
+static void stale_row(svdo_trainer *t, const elem *e, stale_save *sv, float *dW_item, float *di_bias, float *dg_bias) {
+    const int k = t->mp.num_factor;
+    const size_t need = (size_t)e->ni + (size_t)e->ng;
+    if (need > sv->cap || sv->buf == NULL) { sv->cap = need * 2 + 64; sv->buf = (float *)realloc(sv->buf, sizeof(float) * (size_t)(k + 1) * sv->cap); }
+    float *save = sv->buf;
+    for (int i = 0; i < e->ni; i++) {
+        assert_true(e->ii[i] < (unsigned)t->mp.num_item, "item feature index exceed bound");
+        memcpy(save + (size_t)i * (k + 1), t->W_item + (size_t)e->ii[i] * t->pitch, sizeof(float) * (size_t)k);
+        save[(size_t)i * (k + 1) + k] = t->i_bias[e->ii[i]];
+    }
+    float *gsave = save + (size_t)e->ni * (k + 1);
+    for (int i = 0; i < e->ng; i++) {
+        assert_true(e->ig[i] < (unsigned)t->mp.num_global, "global feature index exceed setting");
+        gsave[i] = t->g_bias[e->ig[i]];
+    }
+    update_inner(t, e);
+    for (int i = 0; i < e->ni; i++) {   /* an id listed twice: the first entry carries the whole change, the second sees none */
+        float *w = t->W_item + (size_t)e->ii[i] * t->pitch, *d = dW_item + (size_t)e->ii[i] * k;
+        const float *s = save + (size_t)i * (k + 1);
+        for (int j = 0; j < k; j++) { float c = w[j] - s[j]; d[j] = d[j] + c; w[j] = s[j]; }
+        float cb = t->i_bias[e->ii[i]] - s[k];
+        di_bias[e->ii[i]] = di_bias[e->ii[i]] + cb;
+        t->i_bias[e->ii[i]] = s[k];
+    }
+    for (int i = 0; i < e->ng; i++) {
+        float c = t->g_bias[e->ig[i]] - gsave[i];
+        dg_bias[e->ig[i]] = dg_bias[e->ig[i]] + c;
+        t->g_bias[e->ig[i]] = gsave[i];
+    }
+}
+static int stale_supported(const svdo_trainer *t) {
+    return !(t->tp.reg_method >= 4 || t->tp.reg_global >= 4 || t->feat_item.num_row > 0 || t->feat_user.num_row > 0 || t->mtype[2] != 0 ||
+             t->mp.common_latent_space != 0);
+}
 int svdo_update_csr_batch_stale(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
                                 const unsigned *feat_index, const float *feat_value, float *dW_item, float *di_bias, float *dg_bias) {
-    const int k = t->mp.num_factor;
-    if (t->tp.reg_method >= 4 || t->tp.reg_global >= 4 || t->feat_item.num_row > 0 || t->feat_user.num_row > 0 || is_user_group(t) || t->mtype[2] != 0 ||
-        t->mp.common_latent_space != 0) return -1;
-    float *save = (float *)malloc(sizeof(float) * (size_t)(k + 1) * 64);
-    size_t cap = 64;
+    if (!stale_supported(t) || is_user_group(t)) return -1;
+    stale_save sv = {NULL, 0};
     for (int r = 0; r < num_row; r++) {
         elem e = csr_row(r, row_label, row_ptr, feat_index, feat_value);
-        const size_t need = (size_t)e.ni + (size_t)e.ng;
-        if (need > cap) { cap = need * 2; save = (float *)realloc(save, sizeof(float) * (size_t)(k + 1) * cap); }
-        for (int i = 0; i < e.ni; i++) {
-            assert_true(e.ii[i] < (unsigned)t->mp.num_item, "item feature index exceed bound");
-            memcpy(save + (size_t)i * (k + 1), t->W_item + (size_t)e.ii[i] * t->pitch, sizeof(float) * (size_t)k);
-            save[(size_t)i * (k + 1) + k] = t->i_bias[e.ii[i]];
-        }
-        float *gsave = save + (size_t)e.ni * (k + 1);
-        for (int i = 0; i < e.ng; i++) {
-            assert_true(e.ig[i] < (unsigned)t->mp.num_global, "global feature index exceed setting");
-            gsave[i] = t->g_bias[e.ig[i]];
-        }
-        update_inner(t, &e);
-        for (int i = 0; i < e.ni; i++) {   /* an id listed twice: the first entry carries the whole change, the second sees none */
-            float *w = t->W_item + (size_t)e.ii[i] * t->pitch, *d = dW_item + (size_t)e.ii[i] * k;
-            const float *s = save + (size_t)i * (k + 1);
-            for (int j = 0; j < k; j++) { float c = w[j] - s[j]; d[j] = d[j] + c; w[j] = s[j]; }
-            float cb = t->i_bias[e.ii[i]] - s[k];
-            di_bias[e.ii[i]] = di_bias[e.ii[i]] + cb;
-            t->i_bias[e.ii[i]] = s[k];
-        }
-        for (int i = 0; i < e.ng; i++) {
-            float c = t->g_bias[e.ig[i]] - gsave[i];
-            dg_bias[e.ig[i]] = dg_bias[e.ig[i]] + c;
-            t->g_bias[e.ig[i]] = gsave[i];
-        }
+        stale_row(t, &e, &sv, dW_item, di_bias, dg_bias);
     }
-    free(save);
+    free(sv.buf);
     return 0;
 }
 void svdo_predict_csr_batch(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
@@ -1009,6 +1018,49 @@ void svdo_update_block(svdo_trainer *t, int nfb, int extend_tag, const unsigned 
     }
     svdo_update_csr_batch(t, num_row, row_label, row_ptr, feat_index, feat_value); /* update_each :560-565 */
     if (extend_tag == 0 || extend_tag == 2) update_ufeedback(t, nfb, idx_fb, val_fb); /* DEFAULT or END_TAG */
+}
+/* NOT a reference function -- the window-minibatch step for USER-GROUP blocks, the checker of
+ * svdf_k_wunit.hip.  A block is the reference's SVDPPFeature::update (apex_svd_base.h:568-582) on (the user's private state --
+ * its W_user row and bias, tmp_ufeedback / old_ufeedback -- , the WINDOW-START replicated side): prepare_ufeedback (:523-538) reads the
+ * window-start W_ufeedback / ufeedback_bias; every row is update_inner with its item rows / biases and global biases put back afterwards
+ * and their change added to dW_item / di_bias / dg_bias (stale_row above); update_ufeedback (:539-554) runs on the window-start
+ * feedback rows, which are put back too, their change (w + d * val) - w added to dW_fb / dfb_bias in list order.  Returns 0, or -1 for
+ * configurations outside the step (lazy decay, side tables, variant solvers, shared latent / feedback spaces). */
+int svdo_update_block_stale(svdo_trainer *t, int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb,
+                            int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value,
+                            float *dW_item, float *di_bias, float *dg_bias, float *dW_fb, float *dfb_bias) {
+    if (!stale_supported(t) || !is_user_group(t) || t->mp.common_feedback_space != 0) return -1;
+    const int k = t->mp.num_factor;
+    if (extend_tag == 0 || extend_tag == 1) { /* DEFAULT or START_TAG */
+        prepare_ufeedback(t, nfb, idx_fb, val_fb);
+        t->old_fb_bias = t->tmp_fb_bias;
+        memcpy(t->old_fb, t->tmp_fb, sizeof(float) * (size_t)k);
+    }
+    stale_save sv = {NULL, 0};
+    for (int r = 0; r < num_row; r++) { /* update_each :560-565 */
+        elem e = csr_row(r, row_label, row_ptr, feat_index, feat_value);
+        stale_row(t, &e, &sv, dW_item, di_bias, dg_bias);
+    }
+    free(sv.buf);
+    if (extend_tag == 0 || extend_tag == 2) { /* DEFAULT or END_TAG */
+        float *save = (float *)malloc(sizeof(float) * (size_t)(k + 1) * (size_t)(nfb > 0 ? nfb : 1));
+        for (int i = 0; i < nfb; i++) {
+            assert_true(idx_fb[i] < (unsigned)t->mp.num_ufeedback, "ufeedback id exceed bound");
+            memcpy(save + (size_t)i * (k + 1), t->W_ufb + (size_t)idx_fb[i] * t->pitch, sizeof(float) * (size_t)k);
+            save[(size_t)i * (k + 1) + k] = t->ufb_bias[idx_fb[i]];
+        }
+        update_ufeedback(t, nfb, idx_fb, val_fb);
+        for (int i = 0; i < nfb; i++) {
+            float *w = t->W_ufb + (size_t)idx_fb[i] * t->pitch, *d = dW_fb + (size_t)idx_fb[i] * k;
+            const float *s_ = save + (size_t)i * (k + 1);
+            for (int j = 0; j < k; j++) { float c = w[j] - s_[j]; d[j] = d[j] + c; w[j] = s_[j]; }
+            float cb = t->ufb_bias[idx_fb[i]] - s_[k];
+            dfb_bias[idx_fb[i]] = dfb_bias[idx_fb[i]] + cb;
+            t->ufb_bias[idx_fb[i]] = s_[k];
+        }
+        free(save);
+    }
+    return 0;
 }
 void svdo_predict_block(svdo_trainer *t, int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb,
                         int num_row, const float *row_label, const int *row_ptr,
