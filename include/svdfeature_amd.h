@@ -199,6 +199,21 @@ int svdf_item_delta_unpack(svdf_trainer *t, const void *device_src, int half, in
 svdf_dataset *svdf_dataset_window_from_triples(svdf_trainer *t, long n, const unsigned *user, const unsigned *item, const float *label);
 /* the same for rank pairs (user, positive item, negative item), the instances of svdf_dataset_from_pairs (BASELINE configs[4]) */
 svdf_dataset *svdf_dataset_window_from_pairs(svdf_trainer *t, long n, const unsigned *user, const unsigned *pos_item, const unsigned *neg_item);
+/* The same step for USER UNITS (svdf_k_wunit.hip): rows with global features and / or several item entries
+ * (random-order trainers: _from_csr, the arrays of svdf_dataset_from_csr) and user-group (SVD++) blocks (_from_blocks, the arrays of
+ * svdf_dataset_from_blocks; every START closed by its END inside the window).  A user's unit is exact on its private state -- its W_user
+ * row and bias and SVDPPFeature's tmp_ufeedback / old_ufeedback (solvers/base-solver/apex_svd_base.h:486-488, 506-520) --; the shared rows
+ * -- W_item / i_bias, W_ufeedback / ufeedback_bias (prepare_ufeedback / update_ufeedback :523-554), g_bias (:188-210, :313-353) -- are
+ * read as of the window start and their change is summed per row in file order: svdf_window_delta_pack writes the sums in the packed
+ * layout [W_ufeedback | W_item | ufeedback_bias | i_bias | g_bias] (one piece: svdf_item_delta_select(t, 0, 1)),
+ * svdf_window_delta_apply_local adds them to the model in place.  Every row needs exactly one user entry; ids are distinct inside a
+ * row / a feedback list.  Equals oracle/svdf_oracle.c: svdo_update_csr_batch_stale / svdo_update_block_stale bit for bit. */
+svdf_dataset *svdf_dataset_window_from_csr(svdf_trainer *t, long num_row, const float *row_label, const int64_t *row_ptr,
+                                           const unsigned *feat_index, const float *feat_value);
+svdf_dataset *svdf_dataset_window_from_blocks(svdf_trainer *t, long num_block, const int *extend_tag, const int64_t *fb_ptr,
+                                              const unsigned *fb_index, const float *fb_value, const int64_t *block_row_ptr,
+                                              const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
+                                              const float *feat_value);
 int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *device_dst, int half, int64_t *count);
 int svdf_window_delta_apply(svdf_trainer *t, const void *device_src, int half);
 /* STRATIFIED schedule: item block b = the partition chosen with svdf_item_delta_select(t, b, N).  While a rank

@@ -84,6 +84,10 @@ def load_library():
     lib.svdf_dataset_window_from_triples.argtypes = [P, C.c_long, _u32p, _u32p, _f32p]
     lib.svdf_dataset_window_from_pairs.restype = P
     lib.svdf_dataset_window_from_pairs.argtypes = [P, C.c_long, _u32p, _u32p, _u32p]
+    lib.svdf_dataset_window_from_csr.restype = P
+    lib.svdf_dataset_window_from_csr.argtypes = [P, C.c_long, _f32p, _i64p, _u32p, _f32p]
+    lib.svdf_dataset_window_from_blocks.restype = P
+    lib.svdf_dataset_window_from_blocks.argtypes = [P, C.c_long, _i32p, _i64p, _u32p, _f32p, _i64p, _f32p, _i64p, _u32p, _f32p]
     lib.svdf_window_delta_pack.argtypes = [P, P, P, C.c_int, C.POINTER(C.c_int64)]
     lib.svdf_window_delta_apply.argtypes = [P, P, C.c_int]
     lib.svdf_window_delta_apply_local.argtypes = [P, P]
@@ -367,6 +371,24 @@ class Trainer:
     def dataset_window_from_pairs(self, user, pos, neg):
         """One exchange window of a rank's rank pairs for the window-minibatch step (svdf_dataset_window_from_pairs)."""
         h = self.lib.svdf_dataset_window_from_pairs(self.h, len(user), _pad(user, np.uint32), _pad(pos, np.uint32), _pad(neg, np.uint32))
+        if not h:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return Dataset(self, h)
+
+    def dataset_window_from_csr(self, d):
+        """One exchange window of rows with global features / several item entries (svdf_dataset_window_from_csr)."""
+        h = self.lib.svdf_dataset_window_from_csr(self.h, d.num_row, _pad(d.row_label, np.float32), _pad(d.row_ptr, np.int64),
+                                                  _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32))
+        if not h:
+            raise SvdfError(self.lib.svdf_last_error().decode())
+        return Dataset(self, h)
+
+    def dataset_window_from_blocks(self, ba):
+        """One exchange window of user-group (SVD++) blocks, a data.BlockArrays (svdf_dataset_window_from_blocks)."""
+        h = self.lib.svdf_dataset_window_from_blocks(self.h, ba.num_block, _pad(ba.extend_tag, np.int32), _pad(ba.fb_ptr, np.int64),
+                                                     _pad(ba.fb_index, np.uint32), _pad(ba.fb_value, np.float32), _pad(ba.block_row_ptr, np.int64),
+                                                     _pad(ba.row_label, np.float32), _pad(ba.row_ptr, np.int64), _pad(ba.feat_index, np.uint32),
+                                                     _pad(ba.feat_value, np.float32))
         if not h:
             raise SvdfError(self.lib.svdf_last_error().decode())
         return Dataset(self, h)

@@ -117,6 +117,25 @@ svdf_dataset *svdf_dataset_window_from_pairs(svdf_trainer *t, long n, const unsi
         return h;
     })
 }
+svdf_dataset *svdf_dataset_window_from_csr(svdf_trainer *t, long num_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
+                                           const float *feat_value) {
+    SVDF_GUARD(nullptr, {
+        svdf::Dataset *d = t->e->dataset_window_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);
+        svdf_dataset *h = new svdf_dataset();
+        h->d = d;
+        return h;
+    })
+}
+svdf_dataset *svdf_dataset_window_from_blocks(svdf_trainer *t, long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index,
+                                              const float *fb_value, const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr,
+                                              const unsigned *feat_index, const float *feat_value) {
+    SVDF_GUARD(nullptr, {
+        svdf::Dataset *d = t->e->dataset_window_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
+        svdf_dataset *h = new svdf_dataset();
+        h->d = d;
+        return h;
+    })
+}
 int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *dst, int half, int64_t *count) {
     SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->window_delta_pack(ds ? ds->d : nullptr, dst, half, count); return 0; })
 }
@@ -186,7 +205,7 @@ int64_t svdf_dataset_info(const svdf_dataset *ds, int what) {
     if (!ds || !ds->d) return -1;
     switch (what) {
     case 0: return ds->d->num_row;
-    case 1: return (int64_t)ds->d->sched.num_levels();
+    case 1: return ds->d->kind == 8 ? (int64_t)ds->d->wchild.size() : (int64_t)ds->d->sched.num_levels();   // kind 8: windows per pass
     case 2: return ds->d->sched.max_level_size;
     case 3: return ds->d->kind;
     case 4: return ds->d->algorithmic_bytes;

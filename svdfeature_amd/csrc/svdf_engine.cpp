@@ -75,6 +75,8 @@ template struct DevBuf<double>;
 template struct DevBuf<long>;
 template struct DevBuf<char>;
 template struct DevBuf<WinUser>;
+template struct DevBuf<WinUnit>;
+template struct DevBuf<WinSeg>;
 
 // =============================================================================== scheduler
 void build_schedule(const std::vector<int> &levels, int base, Schedule &out) {
@@ -280,6 +282,7 @@ void Engine::set_param(const char *name, const char *val) {  // apex_svd_base.h:
         check(!strcmp(val, "minibatch") || !strcmp(val, "levels"), "amd:step must be minibatch or levels");
         check(!multi_, "amd:step must be set before the model is created");
         multi_step_levels_ = !strcmp(val, "levels");
+        step_minibatch_set_ = !strcmp(val, "minibatch");   // one GPU: opt-in window-minibatch SGD (svdf_wunit.cpp: resident data sets become window sequences)
     }
     if (!strcmp(name, "amd:window")) { stage_window_ = std::max<long>(1, atol(val)); window_set_ = true; }
     if (multi_) for (int d = 1; d < gpus_; d++) rank_engine(d)->set_param(name, val);
@@ -1495,6 +1498,7 @@ Dataset *Engine::dataset_from_blocks(long num_block, const int *extend_tag, cons
     }
     flush();
     check(!unit_open_, "dataset_from_blocks: a START block is pending in the trainer");
+    if (single_minibatch()) return wseq_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
     if (imfb()) {   // multi-level units: every span of the pass must be closed inside it
         check(imfb_depth_ == 0, "dataset_from_blocks: a START block is pending in the trainer");
         const long saved_window = stage_window_;
@@ -1808,6 +1812,7 @@ Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsign
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
     if (multi_ && !in_multi_scope()) return multi_dataset_from_triples(n, user, item, label);
+    if (single_minibatch() && !user_group() && basic_fast_path_allowed()) return wseq_from_triples(n, user, item, label);
     if (!basic_fast_path_allowed()) {
         // fall back to the general representation (side tables / shared latent space / user-group trainer)
         std::vector<int64_t> ptr((size_t)3 * n + 1);
@@ -2058,6 +2063,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
     need_device("dataset");
     check(!user_group() || rows_as_instances_, "svdfeature_amd: resident datasets are for random-order (format_type 0) trainers");
     if (multi_ && !in_multi_scope()) return multi_dataset_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);
+    if (single_minibatch() && !user_group()) return wseq_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);
     const long n = num_row;
     const int64_t p00 = row_ptr[0];
     check(row_ptr[3 * n] - p00 < (int64_t)2147483647, "dataset: more than 2^31-1 feature entries");
@@ -2178,6 +2184,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
 
 Dataset::~Dataset() {
     for (auto &per_rank : mchild) for (Dataset *c : per_rank) delete c;
+    for (Dataset *c : wchild) delete c;
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     if (owner) owner->disown(this);
 }
@@ -2313,7 +2320,21 @@ void Engine::window_build(Dataset *ds, long n, const unsigned *user, const unsig
 }
 void Engine::window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t *count) {
     check(trainer_ready_, "window_delta: init_trainer has not been called");
-    check(ds && ds->owner == this && ds->kind == 5, "window_delta_pack: not a window data set of this trainer");
+    check(ds && ds->owner == this && (ds->kind == 5 || ds->kind == 7), "window_delta_pack: not a window data set of this trainer");
+    if (ds->kind == 7) {   // user units: the whole replicated side in one piece, [feedback rows | item rows | their biases | global biases]
+        check(delta_nparts_ == 1, "window_delta_pack: user-unit window data sets exchange the replicated side in one piece");
+        const DeltaRanges R7 = delta_ranges();
+        const long T = (user_group() ? (long)num_fb_rows() : 0) + (long)mp_.num_item;
+        check(R7.off[R7.n] == T * (pitch_ + 1) + (long)mp_.num_global, "window_delta_pack: unexpected layout of the replicated ranges");
+        if (count) *count = R7.off[R7.n];
+        if (!device_dst) return;
+        need_device("window_delta");
+        check(window_trained_ == ds, "window_delta_pack: train this window data set first (svdf_train_dataset)");
+        wunit_sum(ds, device_dst, half);
+        HIPCHECK(hipGetLastError());
+        n_launches_++;
+        return;
+    }
     check(!relaxed() && g_stride_ == 1 && user_off_ == 0, "window_delta_pack: random-order trainers without relaxed ids only");
     const long ni = mp_.num_item;
     const long lo = ni * delta_part_ / delta_nparts_, hi = ni * (delta_part_ + 1) / delta_nparts_;
@@ -2331,10 +2352,18 @@ void Engine::window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t 
 // Stratified schedule: the rank owns the active item block (svdf_item_delta_select) exclusively while it trains
 // a stratum, so the window's per-item sums go straight into the model -- no wire buffer, no sum over ranks.
 void Engine::window_delta_apply_local(Dataset *ds) {
-    check(ds && ds->owner == this && ds->kind == 5, "window_delta_apply_local: not a window data set of this trainer");
-    check(!relaxed() && g_stride_ == 1 && user_off_ == 0, "window_delta_apply_local: random-order trainers without relaxed ids only");
+    check(ds && ds->owner == this && (ds->kind == 5 || ds->kind == 7), "window_delta_apply_local: not a window data set of this trainer");
     need_device("window_delta");
     check(window_trained_ == ds, "window_delta_apply_local: train this window data set first (svdf_train_dataset)");
+    if (ds->kind == 7) {   // user units: every per-target sum of the window, added in place (one rank holds the whole replicated side)
+        check(delta_nparts_ == 1, "window_delta_apply_local: user-unit window data sets apply the replicated side in one piece");
+        wunit_sum(ds, nullptr, 0);
+        HIPCHECK(hipGetLastError());
+        n_launches_++;
+        window_trained_ = nullptr;   // the sums are in the model: applying them twice would be a silent error
+        return;
+    }
+    check(!relaxed() && g_stride_ == 1 && user_off_ == 0, "window_delta_apply_local: random-order trainers without relaxed ids only");
     const long ni = mp_.num_item;
     const long lo = ni * delta_part_ / delta_nparts_, hi = ni * (delta_part_ + 1) / delta_nparts_;
     launch_window_items_local(window_view(ds), pitch_, mp_.num_factor, lo, hi, dW_.p + (size_t)item_off_ * pitch_, dbias_.p + item_off_, stream_);
@@ -2366,6 +2395,19 @@ void Engine::train_dataset(Dataset *ds) {
     check(ds->sched_signature == schedule_signature(),
           "train_dataset: the dataset was scheduled under another configuration (relaxed-id keys, side tables, lazy decay or kernel-routing knobs changed since it was built); build it again");
     flush();
+    if (ds->kind == 8) {   // one GPU, amd:step = minibatch: the pass as a sequence of windows, each trained and applied in place (svdf_wunit.cpp)
+        wseq_train(ds);
+        HIPCHECK(hipGetLastError());
+        n_batches_ += (int64_t)ds->wchild.size();
+        n_instances_ += ds->num_row;
+        sample_counter_ += (unsigned)ds->num_row;
+        return;
+    }
+    if (ds->kind == 5) {   // the trainer-owned contribution scratch is sized BEFORE anything is issued (and never inside a stream capture)
+        d_contrib_.reserve((size_t)ds->win_slots * (size_t)pitch_);
+        d_cbias_.reserve((size_t)ds->win_slots);
+        window_trained_ = ds;
+    }
     const DevParams &P = params();
     const Schedule &sc = ds->sched;
     check(!lazy_decay() || ds->kind == 1 || ds->kind == 4 || (ds->kind == 3 && ds->num_simple_units == 0),
@@ -2377,10 +2419,9 @@ void Engine::train_dataset(Dataset *ds) {
         } else if (ds->kind == 5) {
             // window-minibatch step, first half: the users' exact walks; the item side is only read, its would-be change goes to the
             // contribution slots that window_delta_pack sums (svdf_k_window.hip)
-            d_contrib_.reserve((size_t)ds->win_slots * (size_t)pitch_);
-            d_cbias_.reserve((size_t)ds->win_slots);
             launch_window_users(P, window_view(ds), window_slots_, window_groups_, stream_);
-            window_trained_ = ds;
+        } else if (ds->kind == 7) {   // the same step for user units (svdf_k_wunit.hip)
+            wunit_train(ds);
         } else if (ds->kind == 3) {
             const UnitDev &d = ds->unitdev;
             const DevCSR D = d.csr();
@@ -2405,7 +2446,7 @@ void Engine::train_dataset(Dataset *ds) {
     // A pass over a resident dataset is the same launch sequence every time: capture it once into a hipGraph and
     // replay it (short batches are launch-bound on the host otherwise).  Re-captured when kernel parameters, launch
     // knobs or the stream change; the lazy decay modes pass a per-pass counter and stay on plain launches.
-    if (use_graph_ && !lazy_decay() && sc.num_levels() >= (size_t)graph_min_levels_) {
+    if (use_graph_ && !lazy_decay() && ds->kind != 5 && ds->kind != 7 && sc.num_levels() >= (size_t)graph_min_levels_) {   // window data sets use trainer-owned scratch that may be re-sized between passes: plain launches
         if (!ds->graph_exec || ds->graph_version != launch_version_ || ds->graph_stream != stream_) {
             if (ds->graph_exec) { (void)hipGraphExecDestroy(ds->graph_exec); ds->graph_exec = nullptr; }
             hipGraph_t g = nullptr;
@@ -2431,6 +2472,7 @@ void Engine::train_dataset(Dataset *ds) {
 
 void Engine::predict_dataset(Dataset *ds, float *out) {
     check(ds && ds->owner == this, "predict_dataset: dataset belongs to another trainer");
+    check(ds->kind != 7 && ds->kind != 8, "predict_dataset: window data sets are training sets (their rows are regrouped by user); score rows with svdf_predict_csr_batch / svdf_predict_block or a level-scheduled data set of the same rows");
     check(ds->kind != 5 && ds->kind != 6, "predict_dataset: window / multi-GPU data sets are training sets (their rows are regrouped: there is no file order to report predictions in); svdf_eval_dataset gives their squared error, svdf_predict_csr_batch scores rows (routed to the owner of each user)");
     check(ds->sched_signature == schedule_signature(),
           "predict_dataset: the dataset was scheduled under another configuration; build it again");
@@ -2498,6 +2540,7 @@ void Engine::eval_dataset(Dataset *ds, float scale, double *sum_sq, int64_t *cou
         return;
     }
     check(ds->kind != 6, "eval_dataset: not a data set of this handle");
+    check(ds->kind != 7 && ds->kind != 8, "eval_dataset: user-unit window data sets are training sets; evaluate a level-scheduled data set of the same rows");
     check(ds->kind != 5 || ds->fused.max_ni == 1, "eval_dataset: rank-pair window data sets have no label to compare a score with");
     check(ds->sched_signature == schedule_signature(), "eval_dataset: the dataset was scheduled under another configuration; build it again");
     flush();
@@ -2826,6 +2869,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "device_schedule_min")) { check(value >= 1, "device_schedule_min must be >= 1"); device_sched_min_ = value; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "rows_without_feedback")) { rows_without_feedback_ = value != 0; return 0; }
+    if (!strcmp(name, "window_per_target")) { check(value >= 1, "window_per_target must be positive"); wseq_per_target_ = (int)value; return 0; }
     if (!strcmp(name, "window_slots")) { window_slots_ = value != 0; return 0; }
     if (!strcmp(name, "window_groups")) { check(value >= 0 && value <= 2, "window_groups must be 0 (auto), 1 or 2"); window_groups_ = (int)value; return 0; }
     if (!strcmp(name, "block_threads")) {

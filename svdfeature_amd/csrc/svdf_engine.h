@@ -211,7 +211,18 @@ struct Dataset {
     DevBuf<int> win_slot, win_iptr, win_slot1;
     DevBuf<unsigned> win_item1;   // rank pairs: the second (higher-id) item entry, its slot and sign; entry 0 uses item / win_slot / ival
     DevBuf<float> win_ival1;
-    long win_slots = 0;           // contribution slots of the window = item entries
+    long win_slots = 0;           // contribution slots of the window = item entries (kind 7: + feedback entries)
+    // kind 7: window-minibatch data set of user units (svdf_k_wunit.hip): user-group blocks / rows with global features
+    DevBuf<WinUnit> wu_units;
+    DevBuf<WinSeg> wu_segs;
+    DevBuf<int> wu_rptr, wu_eslot, wu_fbslot, wu_tptr, wu_gptr;
+    DevBuf<unsigned> wu_eidx, wu_fbidx;
+    DevBuf<float> wu_eval, wu_fbval;
+    long wu_gslots = 0;           // contribution words of the global biases = global entries
+    int wu_estride = 0;           // > 0: every row has wu_estride - 1 global entries and one item entry (no row pointer array)
+    bool wu_feedback = false;     // the units carry implicit-feedback lists (user-group trainer)
+    // kind 8: one GPU, `amd:step = minibatch`: the pass as a sequence of windows (kind 5 or kind 7 children), each trained and applied in place
+    std::vector<Dataset *> wchild;
     // kind 6: a data set of an amd:gpus = N handle (svdf_multi.cpp): mchild[rank][window] lives in that rank's HBM
     std::vector<std::vector<Dataset *>> mchild;
     bool m_minibatch = false;     // the children are window-minibatch data sets (kind 5), else level-scheduled ones
@@ -284,6 +295,11 @@ class Engine {
     void window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t *count);   // per-item sum of the window's contributions -> wire buffer
     void window_delta_apply(const void *device_src, int half);                           // replicated ranges += wire buffer
     void window_delta_apply_local(Dataset *ds);                 // stratified schedule: the active item block += the window's per-item sums, in place
+    // the same step for user units (svdf_k_wunit.hip): rows with global features / several item entries, user-group (SVD++) blocks
+    Dataset *dataset_window_from_csr(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
+    Dataset *dataset_window_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
+                                        const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
+                                        const float *feat_value);
     void item_block_copy(float *device_buf, int set, int64_t *count);   // the active partition of the replicated ranges <-> a packed fp32 buffer
     void train_dataset(Dataset *ds);
     void predict_dataset(Dataset *ds, float *out);
@@ -479,6 +495,28 @@ class Engine {
     // ---- item delta
     DevBuf<float> d_snap_, d_delta_;
     DevBuf<float> d_contrib_, d_cbias_;   // window-minibatch scratch: one contribution row + bias word per instance of the largest window
+    DevBuf<float> d_gcontrib_;            // ... and one word per global entry (user-unit windows)
+    // user-unit windows (svdf_wunit.cpp)
+    WUnitSchedule wunit_view(const Dataset *ds) const;
+    void wunit_check_config(const char *what) const;
+    void wunit_build(Dataset *ds, const void *segs, size_t nseg, const std::vector<int64_t> &seg_rows, bool by_row_order, long num_src_row,
+                     const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value,
+                     const unsigned *fb_index, const float *fb_value);
+    void wunit_fill_from_csr(Dataset *ds, long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
+    void wunit_fill_from_blocks(Dataset *ds, long b0, long b1, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
+                                const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
+    void wunit_train(Dataset *ds);
+    void wunit_sum(Dataset *ds, void *dst, int half);
+    // one GPU, `amd:step = minibatch` (opt-in; not the reference's semantics): resident data sets become window sequences (kind 8)
+    bool step_minibatch_set_ = false;
+    int wseq_per_target_ = 24;            // knob "window_per_target": updates a shared row meets per window when amd:window is not given
+    bool single_minibatch() const { return step_minibatch_set_ && gpus_ == 1 && !multi_ && !is_peer_; }
+    long wseq_windows(long n, const std::vector<double> &updates_per_target) const;
+    Dataset *wseq_from_csr(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
+    Dataset *wseq_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
+                              const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
+    Dataset *wseq_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
+    void wseq_train(Dataset *ds);
     WindowSchedule window_view(const Dataset *ds) const;
     Dataset *window_trained_ = nullptr;   // the window data set whose contributions the scratch holds
     int window_slots_ = 1, window_groups_ = 0;   // knobs "window_slots", "window_groups"

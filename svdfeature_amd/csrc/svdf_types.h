@@ -194,6 +194,37 @@ struct WindowSchedule {
     const float *ival1;
 };
 
+// Window-minibatch data set of USER UNITS (svdf_k_wunit.hip): user-group (SVD++) blocks and rows with global
+// features.  A unit = one user's part of the window: `seg_count` segments walked in file order by one lane group, a segment = one
+// DEFAULT block or START..END span (its feedback list + its rows) of a user-group pass, or all the user's rows of a random-order window
+// (no feedback list).  Rows are regrouped unit by unit; row r's entries are e[rptr[2r] .. rptr[2r+1]) = global entries and
+// e[rptr[2r+1] .. rptr[2r+2]) = item entries (rptr == nullptr: the fixed layout `estride` entries per row, the last one the item entry).
+// eslot: where the entry's contribution goes -- item entries: a row of contrib / a word of cbias; global entries: a word of gcontrib;
+// fbslot: the same for the feedback rows a segment scatters into at its end.  Row slots are laid out target by target (tptr over the
+// replicated rows: feedback rows first, then item rows -- the order of W_uiset and of the wire buffer), inside a target in file order;
+// global slots global id by global id (gptr).
+struct WinUnit { unsigned user; int seg_begin; int seg_count; int rows; };
+struct WinSeg { int fb_begin, fb_count, row_begin, row_count; };
+struct WUnitSchedule {
+    const WinUnit *units;
+    long nunits;
+    const WinSeg *segs;
+    const float *label;
+    const float *uval;          // nullptr: every user value is 1.0f
+    const int *rptr;            // [2 nrows + 1], or nullptr with estride
+    int estride;
+    const unsigned *eidx;
+    const float *eval;
+    const int *eslot;
+    const unsigned *fbidx;
+    const float *fbval;
+    const int *fbslot;
+    float *contrib, *cbias, *gcontrib;
+    const int *tptr;            // [nfb_rows + nitem_rows + 1]
+    const int *gptr;            // [num_global + 1]
+    long nfb_rows, nitem_rows, nglobal;
+};
+
 }  // namespace svdf
 // replicated (item-side) parameter ranges of the multi-GPU exchange, packed back to back: range r covers packed
 // positions [off[r], off[r+1])

@@ -85,6 +85,26 @@ class CSRData:
         p = self.row_ptr[3 * start:3 * stop + 1]
         return CSRData(self.row_label[start:stop], p - p[0], self.feat_index[p[0]:p[-1]], self.feat_value[p[0]:p[-1]])
 
+    def select_rows(self, keep):
+        """the rows with keep[r] set, order kept, rebased to offset 0 (vectorised: millions of rows)"""
+        rows = np.nonzero(np.asarray(keep, bool))[0]
+        p = self.row_ptr.astype(np.int64)
+        start = p[0:-1:3][rows]
+        lens = p[3::3][rows] - start
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        src = np.repeat(start - off[:-1], lens) + np.arange(off[-1], dtype=np.int64)
+        rp = np.empty(3 * len(rows) + 1, np.int64)
+        for j in range(3):
+            rp[j:3 * len(rows):3] = p[3 * rows + j] - start + off[:-1]
+        rp[-1] = off[-1]
+        return CSRData(self.row_label[rows], rp, self.feat_index[src], self.feat_value[src])
+
+    def row_user(self):
+        """the user id of every row (rows with exactly one user entry)"""
+        p = self.row_ptr.astype(np.int64)
+        assert np.all(p[2::3] - p[1::3][:len(p[2::3])] == 1), "rows with exactly one user entry"
+        return self.feat_index[p[1:-1:3]]
+
     @staticmethod
     def concat(parts):
         parts = [p for p in parts if p.num_row]

@@ -78,6 +78,15 @@ def shard_pair_windows(user, pos, neg, rank, world, windows):
     return out
 
 
+def shard_csr_windows(d, rank, world, windows):
+    """General rows (data.CSRData with one user entry per row: global features, several item entries) sharded like triples: this rank's
+    rows (user % world == rank) of every global window, order kept."""
+    b = window_bounds(d.num_row, windows)
+    owner = d.row_user() % np.uint32(world)
+    idx = np.arange(d.num_row)
+    return [d.select_rows((owner == rank) & (idx >= b[w]) & (idx < b[w + 1])) for w in range(windows)]
+
+
 def block_window_bounds(ba, windows):
     """Window cuts of a user-group pass (data.BlockArrays) at BLOCK positions, the same on every rank: the even cut
     points are moved forward to the next position where no START..END span is open."""
@@ -397,7 +406,7 @@ class HipShard:
 
     def make_windows(self, shards):
         """shards: per window (user, item, label) triples, Pairs(user, pos, neg) or a data.BlockArrays (user-group data)."""
-        from .data import BlockArrays
+        from .data import BlockArrays, CSRData
         out = []
         for sh in shards:
             if isinstance(sh, list):    # item-range pieces of one window
@@ -405,11 +414,17 @@ class HipShard:
                 out.append([mk(*piece) for piece in sh])
                 continue
             if self.minibatch:
-                assert not isinstance(sh, BlockArrays), "window-minibatch mode: (user, item, rating) triples and rank pairs"
-                out.append(self.t.dataset_window_from_pairs(sh.user, sh.pos, sh.neg) if isinstance(sh, Pairs) else self.t.dataset_window_from_triples(*sh))
+                if isinstance(sh, BlockArrays):      # user-group (SVD++) blocks: user units with feedback lists (svdf_k_wunit.hip)
+                    out.append(self.t.dataset_window_from_blocks(sh))
+                elif isinstance(sh, CSRData):        # rows with global features / several item entries
+                    out.append(self.t.dataset_window_from_csr(sh))
+                else:
+                    out.append(self.t.dataset_window_from_pairs(sh.user, sh.pos, sh.neg) if isinstance(sh, Pairs) else self.t.dataset_window_from_triples(*sh))
                 continue
             if isinstance(sh, BlockArrays):
                 out.append(self.t.dataset_from_blocks(sh))
+            elif isinstance(sh, CSRData):
+                out.append(self.t.dataset_from_csr(sh))
             elif isinstance(sh, Pairs):
                 out.append(self.t.dataset_from_pairs(sh.user, sh.pos, sh.neg))
             else:

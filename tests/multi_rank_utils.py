@@ -5,7 +5,7 @@ import numpy as np
 import cases
 from oracle import oracle
 from svdfeature_amd import BlockArrays, CSRData, pairs_as_csr
-from svdfeature_amd.multi_gpu import Pairs, defer_tails, shard_block_windows, shard_pair_windows, shard_windows
+from svdfeature_amd.multi_gpu import Pairs, defer_tails, shard_block_windows, shard_csr_windows, shard_pair_windows, shard_windows
 
 
 def make_oracle(conf, seed=10, fmt=0, active=0):
@@ -39,16 +39,27 @@ class OracleShard:
                 continue
             if isinstance(sh, BlockArrays):
                 out.append(sh.to_blocks())
+            elif isinstance(sh, CSRData):
+                out.append(sh)
             elif isinstance(sh, Pairs):
                 out.append(pairs_as_csr(sh.user, sh.pos, sh.neg))
             else:
                 out.append(CSRData.from_triples(*sh))
         return out
 
+    def _mb_flat(self):
+        """the window's deltas in the packed order of the replicated ranges (SHARED)"""
+        return np.concatenate([self.mb_delta[name].ravel() for name, _ in self._views()])
+
     def train(self, d):
         if self.minibatch:
-            assert not isinstance(d, list), "window-minibatch mode: random-order data only"
-            self.mb_delta = self.t.update_batch_stale(d)
+            if isinstance(d, list):   # user-group blocks: svdo_update_block_stale, block after block
+                delta = self.t.stale_delta_zero()
+                for b in d:
+                    delta = self.t.update_block_stale(b, delta)
+                self.mb_delta = dict(zip(("W_item", "i_bias", "g_bias", "W_ufeedback", "ufeedback_bias"), delta))
+            else:
+                self.mb_delta = dict(zip(("W_item", "i_bias", "g_bias"), self.t.update_batch_stale(d)))
         elif isinstance(d, list):
             for b in d:
                 self.t.update_block(b)
@@ -76,8 +87,7 @@ class OracleShard:
             off += v.size
 
     def apply_local(self, d, block, nblocks):
-        dW, db, dg = self.mb_delta
-        delta = np.concatenate([dW.ravel(), db, dg])
+        delta = self._mb_flat()
         pos = self._piece(block, nblocks)
         cur = self._shared()
         cur[pos] = cur[pos] + delta[pos]
@@ -130,8 +140,7 @@ class OracleShard:
 
     def delta_get(self, part=None):
         if self.minibatch:
-            dW, db, dg = self.mb_delta
-            d = np.concatenate([dW.ravel(), db, dg])   # the SHARED order of a random-order trainer: W_item, i_bias, g_bias
+            d = self._mb_flat()   # the SHARED order: [W_ufeedback] W_item [ufeedback_bias] i_bias [g_bias]
             if part is not None:
                 d = np.ascontiguousarray(d[self._piece(part)])
             return self.torch.from_numpy(d) if self.torch is not None else d
@@ -198,6 +207,8 @@ def simulate(conf, u, i, r, world, windows, passes, seed=10, defer=0.0, fmt=0, a
     ranks = [OracleShard(make_oracle(conf, seed, fmt, active), minibatch=minibatch) for _ in range(world)]
     if isinstance(u, BlockArrays):
         shards = [shard_block_windows(u, rk, world, windows) for rk in range(world)]
+    elif isinstance(u, CSRData):
+        shards = [shard_csr_windows(u, rk, world, windows) for rk in range(world)]
     elif isinstance(u, Pairs):
         shards = [shard_pair_windows(u.user, u.pos, u.neg, rk, world, windows) for rk in range(world)]
     else:

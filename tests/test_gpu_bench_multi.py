@@ -59,7 +59,7 @@ def test_two_ranks_one_command_yields_every_multi_gpu_number():
 
 @pytest.mark.parametrize("hook", ["SVDF_BENCH_TEST_FAIL_PREFLIGHT", "SVDF_BENCH_TEST_HANG_PREFLIGHT"])
 def test_a_broken_ring_preflight_falls_back_to_the_all_reduce_step_and_says_so(hook):
-    line, err = _bench(["--gpus", "2", "--users", "100000", "--items", "10000", "--ratings", "1000000", "--steps", "1", "--no-multi-secondary",
+    line, err = _bench(["--gpus", "2", "--users", "10000", "--items", "1000", "--ratings", "1000000", "--steps", "1", "--no-multi-secondary",
                         "--no-cpu-baseline", "--preflight-timeout", "45"], {hook: "0"})
     x = line["exchange"]
     assert x["ladder_rung"] == 1 and x["step"] == "minibatch"

@@ -1,0 +1,192 @@
+"""Window-minibatch step for USER UNITS on one MI355X (svdf_k_wunit.hip): user-group (SVD++) blocks and rows with
+global features.  N trainers play the N ranks (HipShard(minibatch=True) windows, explicit sum in rank order instead of the collective) and
+must equal the oracle-backed simulation of tests/multi_rank_utils.py -- every block the reference's SVDPPFeature::update
+(/root/reference/solvers/base-solver/apex_svd_base.h:568-582) / every row its update_inner (:456-462) on (the user's private state, the
+window-start shared rows), shared-row changes summed per row in file order (oracle/svdf_oracle.c: svdo_update_block_stale, pinned to the
+compiled reference in tests/test_window_blocks.py) -- bit for bit.  Plus the one-GPU opt-in `amd:step = minibatch` (window sequences)."""
+import numpy as np
+import pytest
+
+import cases
+import svdfeature_amd as sa
+from multi_rank_utils import simulate
+from svdfeature_amd import BlockArrays, CSRData
+from svdfeature_amd.multi_gpu import HipShard, shard_block_windows, shard_csr_windows
+from test_window_blocks import SVDPP_EXTRA, _blocks_with_globals
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(conf, fmt=0, active=0, extra=()):
+    t = sa.Trainer(fmt, active)
+    t.seed(10)
+    for k, v in list(conf) + list(extra):
+        t.set_param(k, str(v))
+    t.init_model()
+    t.init_trainer()
+    return t
+
+
+def _run_ranks(conf, data, world, windows, passes, fmt, active=0, half=False):
+    import torch
+    dev = torch.device("cuda", 0)
+    ranks = []
+    for rk in range(world):
+        ad = HipShard(_trainer(conf, fmt, active), torch, dev, minibatch=True)
+        ad.set_wire_half(half)
+        sh = shard_block_windows(data, rk, world, windows) if isinstance(data, BlockArrays) else shard_csr_windows(data, rk, world, windows)
+        ranks.append((ad, ad.make_windows(sh)))
+    for _ in range(passes):
+        for w in range(windows):
+            ds_ = []
+            for ad, wins in ranks:
+                ad.train(wins[w])
+                d = ad.delta_get()
+                ad.stream.synchronize()
+                ds_.append(d.clone())
+            total = ds_[0]
+            for d in ds_[1:]:
+                total = total + d
+            torch.cuda.synchronize()
+            for ad, _ in ranks:
+                ad.delta_set(total)
+    for ad, _ in ranks:
+        ad.t.synchronize()
+    return [ad for ad, _ in ranks], ranks[0][1]
+
+
+def _check(ranks, sim, names):
+    for ad, s in zip(ranks, sim):
+        for name in names:
+            a, b = ad.t.view(name), s.t.view(name)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), name
+
+
+SVDPP_NAMES = ("W_item", "i_bias", "W_ufeedback", "ufeedback_bias", "W_user", "u_bias")
+
+
+@pytest.mark.parametrize("k,world,windows", [(16, 1, 3), (16, 2, 3), (64, 3, 2), (128, 2, 2), (100, 2, 3), (7, 4, 2), (256, 2, 2)])
+def test_user_group_blocks_on_simulated_ranks_equal_the_oracle_simulation(k, world, windows):
+    """SVD++ blocks: DEFAULT blocks and START / MIDDLE / END spans, users without feedback, users with several blocks in one window"""
+    nu, ni = 260, 90
+    blocks = cases.user_blocks(300, nu, ni, ni, seed=k + world, max_rows=9, max_fb=6, split_every=4)
+    blocks += cases.user_blocks(120, nu, ni, ni, seed=k + world + 50, max_rows=4, max_fb=3)   # the same users again: several segments per unit
+    ba = BlockArrays.from_blocks(blocks)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni) + SVDPP_EXTRA
+    ranks, wins = _run_ranks(conf, ba, world, windows, 2, fmt=1)
+    assert wins[0].kind == 7
+    _check(ranks, simulate(conf, ba, None, None, world, windows, 2, fmt=1, minibatch=True), SVDPP_NAMES)
+
+
+@pytest.mark.parametrize("active,extra", [(2, (("base_score", "0.5"),)), (0, (("reg_method", "1"), ("reg_global", "1"))),
+                                          (0, (("reg_method", "2"), ("wd_user", "0.5"), ("wd_item", "0.5"))), (0, (("no_user_bias", "1"),)),
+                                          (0, (("user_nonnegative", "1"),)), (0, (("scale_lr_ufeedback", "0.5"), ("wd_ufeedback_bias", "0.01"))),
+                                          (0, (("num_regfree_global", "2"), ("gp:wd", "0.1"), ("gp:bound", "3"), ("gp:wd", "0.002"), ("gp:bound", "100")))])
+def test_blocks_with_global_entries_two_item_entries_links_and_regularisers(active, extra):
+    nu, ni, ng = 120, 60, 7
+    blocks = _blocks_with_globals(200, nu, ni, ng, seed=11 + active)
+    if active == 2:
+        for b in blocks:
+            b.data.row_label[:] = (b.data.row_label > 3).astype(np.float32)
+    ba = BlockArrays.from_blocks(blocks)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=20, num_global=ng, num_ufeedback=ni, wd_global="0.002") + SVDPP_EXTRA + list(extra)
+    ranks, _ = _run_ranks(conf, ba, 2, 3, 2, fmt=1, active=active)
+    _check(ranks, simulate(conf, ba, None, None, 2, 3, 2, fmt=1, active=active, minibatch=True), SVDPP_NAMES + ("g_bias",))
+
+
+def _rows_with_globals(n, nu, ni, ng, per_row, seed, fixed=True):
+    rng = np.random.default_rng(seed)
+    rows = []
+    for _ in range(n):
+        m = per_row if fixed else int(rng.integers(0, per_row + 1))
+        gl = [(int(g), float(rng.uniform(0.1, 1.0))) for g in sorted(rng.choice(ng, size=m, replace=False))]
+        items = [(int(rng.integers(0, ni)), 1.0)]
+        if not fixed and rng.random() < 0.3:
+            x = int(rng.integers(0, ni))
+            if x != items[0][0]:
+                items = sorted(items + [(x, -1.0)])
+        rows.append((float(rng.integers(1, 6)), gl, [(int(rng.integers(0, nu)), 1.0 if fixed else float(rng.choice([1.0, 0.5])))], items))
+    return CSRData.from_rows(rows)
+
+
+@pytest.mark.parametrize("k,world,fixed", [(16, 1, True), (128, 2, True), (64, 3, False), (10, 2, False)])
+def test_rows_with_global_features_on_simulated_ranks_equal_the_oracle_simulation(k, world, fixed):
+    """the neighbourhood shape (4 global entries + user + item, fixed layout) and ragged rows (0..4 global entries, sometimes two item entries,
+    user values != 1) on a random-order trainer"""
+    nu, ni, ng, n = 500, 120, 40, 9000
+    d = _rows_with_globals(n, nu, ni, ng, 4, seed=k + world, fixed=fixed)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_global=ng, wd_global="0.001")
+    ranks, wins = _run_ranks(conf, d, world, 4, 2, fmt=0)
+    assert wins[0].kind == 7
+    _check(ranks, simulate(conf, d, None, None, world, 4, 2, minibatch=True), ("W_item", "i_bias", "g_bias", "W_user", "u_bias"))
+
+
+def test_fp16_wire_stays_within_the_rounding_of_the_wire_format():
+    nu, ni = 200, 80
+    ba = BlockArrays.from_blocks(cases.user_blocks(250, nu, ni, ni, seed=21, max_rows=8, max_fb=5))
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=32, num_ufeedback=ni) + SVDPP_EXTRA
+    ranks, _ = _run_ranks(conf, ba, 2, 3, 2, fmt=1, half=True)
+    sim = simulate(conf, ba, None, None, 2, 3, 2, fmt=1, minibatch=True)
+    for name in ("W_item", "W_ufeedback", "i_bias"):
+        np.testing.assert_allclose(ranks[0].t.view(name), sim[0].t.view(name), rtol=0, atol=2e-4)
+
+
+@pytest.mark.parametrize("shape", ["blocks", "rows", "triples"])
+def test_one_gpu_opt_in_minibatch_step_is_the_one_rank_simulation(shape):
+    """`amd:step = minibatch` on a single-GPU handle (opt-in, NOT the reference's semantics): resident data sets become window sequences
+    (kind 8), one pass = per window the users' exact walks + the per-row sums added in place; equals the one-rank oracle simulation with
+    the same window cuts bit for bit.  Without the key the same calls build the exact level-scheduled data sets."""
+    if shape == "blocks":
+        nu, ni, windows = 200, 70, 4
+        ba = BlockArrays.from_blocks(cases.user_blocks(320, nu, ni, ni, seed=4, max_rows=6, max_fb=5, split_every=5))
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=24, num_ufeedback=ni) + SVDPP_EXTRA
+        t = _trainer(conf, 1, 0, [("amd:step", "minibatch"), ("amd:window", -(-ba.num_row // windows))])
+        ds = t.dataset_from_blocks(ba)
+        from svdfeature_amd.multi_gpu import block_window_bounds
+        sim = simulate(conf, ba, None, None, 1, ds.num_batches, 2, fmt=1, minibatch=True)
+        names = SVDPP_NAMES
+        exact = _trainer(conf, 1, 0).dataset_from_blocks(ba)
+    elif shape == "rows":
+        nu, ni, ng, n, windows = 400, 100, 30, 8000, 5
+        d = _rows_with_globals(n, nu, ni, ng, 4, seed=6)
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=32, num_global=ng, wd_global="0.001")
+        t = _trainer(conf, 0, 0, [("amd:step", "minibatch"), ("amd:window", n // windows)])
+        ds = t.dataset_from_csr(d)
+        sim = simulate(conf, d, None, None, 1, windows, 2, minibatch=True)
+        names = ("W_item", "i_bias", "g_bias", "W_user", "u_bias")
+        exact = _trainer(conf, 0, 0).dataset_from_csr(d)
+    else:
+        nu, ni, n, windows = 900, 200, 30000, 6
+        u, i, r = cases.planted_triples(n, nu, ni, seed=12)
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
+        t = _trainer(conf, 0, 0, [("amd:step", "minibatch"), ("amd:window", n // windows)])
+        ds = t.dataset_from_triples(u, i, r)
+        sim = simulate(conf, u, i, r, 1, windows, 2, minibatch=True)
+        names = ("W_item", "i_bias", "W_user", "u_bias")
+        exact = _trainer(conf, 0, 0).dataset_from_triples(u, i, r)
+    assert ds.kind == 8 and exact.kind != 8
+    for _ in range(2):
+        t.train_dataset(ds)
+    t.synchronize()
+    for name in names:
+        assert np.array_equal(t.view(name).view(np.uint32), sim[0].t.view(name).view(np.uint32)), name
+
+
+def test_malformed_windows_are_refused_with_messages():
+    nu, ni = 50, 20
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=8, num_ufeedback=ni) + SVDPP_EXTRA
+    t = _trainer(conf, 1, 0)
+    from svdfeature_amd.data import PlusBlock, TAG_DEFAULT, TAG_START
+    rows2 = CSRData.from_rows([(3.0, [], [(1, 1.0)], [(2, 1.0)]), (4.0, [], [(5, 1.0)], [(3, 1.0)])])
+    with pytest.raises(sa.SvdfError, match="one user"):
+        t.dataset_window_from_blocks(BlockArrays.from_blocks([PlusBlock(np.array([1], np.uint32), np.array([1.0], np.float32), rows2, TAG_DEFAULT)]))
+    one = CSRData.from_rows([(3.0, [], [(1, 1.0)], [(2, 1.0)])])
+    with pytest.raises(sa.SvdfError, match="START..END"):
+        t.dataset_window_from_blocks(BlockArrays.from_blocks([PlusBlock(np.array([1], np.uint32), np.array([1.0], np.float32), one, TAG_START)]))
+    with pytest.raises(sa.SvdfError, match="listed twice"):
+        t.dataset_window_from_blocks(BlockArrays.from_blocks([PlusBlock(np.array([1, 1], np.uint32), np.array([0.5, 0.5], np.float32), one, TAG_DEFAULT)]))
+    r = _trainer(cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=8, num_global=4), 0, 0)
+    with pytest.raises(sa.SvdfError, match="exactly one user"):
+        r.dataset_window_from_csr(CSRData.from_rows([(3.0, [], [(1, 1.0), (2, 1.0)], [(2, 1.0)])]))
+    with pytest.raises(sa.SvdfError, match="listed twice"):
+        r.dataset_window_from_csr(CSRData.from_rows([(3.0, [(1, 0.5), (1, 0.5)], [(1, 1.0)], [(2, 1.0)])]))
