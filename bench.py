@@ -308,7 +308,7 @@ def rmse(pred, label):
     return float(np.sqrt(np.mean(d * d)))
 
 
-def make_trainer(sa, name, a, factor, device, oracle_kind=None):
+def make_trainer(sa, name, a, factor, device, oracle_kind=None, extra=()):
     fmt, act = WORKLOADS[name][0], WORKLOADS[name][1]
     if oracle_kind:
         from oracle import oracle   # checker only: never on the measured GPU path
@@ -316,7 +316,7 @@ def make_trainer(sa, name, a, factor, device, oracle_kind=None):
     else:
         t = sa.Trainer(fmt, act, device=device)
     t.seed(10)   # svd_feature.cpp:293
-    for k, v in workload_conf(name, a, factor):
+    for k, v in list(workload_conf(name, a, factor)) + list(extra):
         t.set_param(k, v)
     t.init_model()
     t.init_trainer()
@@ -386,14 +386,14 @@ def run_workload(name, a, env, steps, warmup, main_line):
     # ---- data (every rank generates the same stream from the same seed, then keeps its shard)
     if name == "basicmf":
         n = a.ratings
-        u, i, r = cached(synth_triples, n + 1_000_000, a.users, a.items)
+        u, i, r = cached(synth_triples, n + 1_000_000, a.users, a.items, 12345 + a.data_seed)
         test = (u[n:n + 200000], i[n:n + 200000], r[n:n + 200000])
         u, i, r = u[:n], i[:n], r[:n]
         per_item = n / max(a.items, 1)
         sample = ("triples", u[:a.cpu_sample], i[:a.cpu_sample], r[:a.cpu_sample])
     elif name == "pairwise":
         n = a.pairs
-        u, p, q = cached(synth_pairs, n + 200_000, a.users, a.items)
+        u, p, q = cached(synth_pairs, n + 200_000, a.users, a.items, 777 + a.data_seed)
         test = (u[n:], p[n:], q[n:])
         u, p, q = u[:n], p[:n], q[:n]
         per_item = 2.0 * n / max(a.items, 1)
@@ -401,13 +401,13 @@ def run_workload(name, a, env, steps, warmup, main_line):
         sample = ("pairs", u[:S], p[:S], q[:S])
     elif name == "svdpp":
         nblk = a.svdpp_users
-        train, test = synth_user_blocks(nblk, a.svdpp_per_user, a.users, a.items)
+        train, test = cached(synth_user_blocks, nblk, a.svdpp_per_user, a.users, a.items, 4242 + a.data_seed)
         n = train.num_row
         per_item = n / max(a.items, 1)
         sample = ("blocks", train.slice(0, min(nblk, max(1, (a.cpu_sample // 8) // a.svdpp_per_user))))
     else:
         n = a.neighbour_rows
-        d_all = synth_neighbourhood(n + 100_000, a.users, a.items, a.globals, 4)
+        d_all = cached(synth_neighbourhood, n + 100_000, a.users, a.items, a.globals, 4, 99 + a.data_seed)
         test = d_all.slice_rows(n, n + 100_000)
         d_all = d_all.slice_rows(0, n)
         per_item = n / max(a.items, 1)
@@ -1004,13 +1004,94 @@ def model_ms(name, world, exchange_step, n, items, factor, nwin, blocks, handoff
             "speedup_over_one_gpu": (t1_ms / total) if t1_ms else None, "source": src + "; ring all-reduce: DESIGN.md 6d"}
 
 
+def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
+    """secondary.<workload>_window_step: BASELINE configs[3] through the OPT-IN window-minibatch step on ONE GPU (`amd:step = minibatch`;
+    svdf_k_wunit.hip) -- next to, never instead of, the exact line.  A user's unit is exact on its private state,
+    the shared rows (W_item / i_bias, W_ufeedback / ufeedback_bias, g_bias) move once per window; the result is NOT the reference's bit for
+    bit, the contract is |dRMSE| <= 1e-4 against the exact pass of the same epochs, measured here (rmse_minus_sequential)."""
+    factor = WORKLOADS[name][2]
+    if name == "svdpp":
+        train, test = cached(synth_user_blocks, a.svdpp_users, a.svdpp_per_user, a.users, a.items, 4242 + a.data_seed)
+        n = train.num_row
+    else:
+        n = a.neighbour_rows
+        d_all = cached(synth_neighbourhood, n + 100_000, a.users, a.items, a.globals, 4, 99 + a.data_seed)
+        test = d_all.slice_rows(n, n + 100_000)
+        d_all = d_all.slice_rows(0, n)
+    extra = [("amd:step", "minibatch")]
+    if a.step_window > 0:
+        extra.append(("amd:window", str(a.step_window)))
+    t0 = time.time()
+    tr = make_trainer(sa, name, a, factor, device, extra=extra)
+    if a.step_per_target > 0:
+        tr.set_knob("window_per_target", a.step_per_target)
+    ds = tr.dataset_from_blocks(train) if name == "svdpp" else tr.dataset_from_csr(d_all)
+    build_s = time.time() - t0
+    assert ds.kind == 8
+    ev = HipEvents()
+    e0, e1 = ev.new(), ev.new()
+    for _ in range(warmup):
+        tr.train_dataset(ds)
+    tr.synchronize()
+    launches0 = tr.counter(1)
+    t0 = time.perf_counter()
+    ev.record(e0, tr.stream())
+    for _ in range(steps):
+        tr.train_dataset(ds)
+    ev.record(e1, tr.stream())
+    tr.synchronize()
+    elapsed = time.perf_counter() - t0
+    ev_ms = ev.elapsed_ms(e0, e1)
+    launches = tr.counter(1) - launches0
+
+    def score(t):
+        if name == "svdpp":
+            dt_ = t.dataset_from_blocks(test)
+            p = t.predict_dataset(dt_)
+            dt_.close()
+            return rmse(p, test.row_label)
+        return rmse(t.predict_batch(test), test.row_label)
+    # the same epochs as exact sequential SGD (the reference's result) on this GPU; the minibatch model is scored through an exact-mode twin
+    # that loads its model file (a minibatch handle builds window sequences, which are training sets)
+    import tempfile
+    sq = make_trainer(sa, name, a, factor, device)
+    dsq = sq.dataset_from_blocks(train) if name == "svdpp" else sq.dataset_from_csr(d_all)
+    for _ in range(warmup + steps):
+        sq.train_dataset(dsq)
+    rm_seq = score(sq)
+    path = os.path.join(tempfile.mkdtemp(), "wstep.model")
+    tr.save_model(path)
+    tw = sa.Trainer(WORKLOADS[name][0], WORKLOADS[name][1], device=device)
+    tw.load_model(path)
+    tw.init_trainer()
+    rm_run = score(tw)
+    os.remove(path)
+    alg = ds.algorithmic_bytes
+    res = {"value": steps * n / elapsed, "unit": "instances/s", "ms_per_step": elapsed * 1e3 / steps, "steps": steps, "warmup": warmup,
+           "windows_per_pass": ds.num_batches, "launches_per_pass": launches / steps, "build_s": round(build_s, 2),
+           "semantics": "OPT-IN amd:step = minibatch: window-minibatch SGD (user units exact, shared rows applied at the window's end, deterministic), NOT the reference's "
+                        "sequential result; contract |dRMSE| <= 1e-4 against the exact pass of the same epochs",
+           "rmse_test_after_run": rm_run, "rmse_sequential_reference": rm_seq, "rmse_minus_sequential": rm_run - rm_seq, "passes_before_rmse": warmup + steps,
+           "roofline": {"bound": "hbm", "achieved": alg * steps / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": alg * steps / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "k_wunit_walk<32,%s> + k_wunit_sum<32,false,true> (two launches per window)" % ("true" if name == "svdpp" else "false"),
+                        "launches": launches, "avg_launch_us": ev_ms * 1e3 / max(launches, 1), "algorithmic_bytes_per_launch": alg * steps / max(launches, 1),
+                        "algorithmic_bytes_per_instance": alg / max(n, 1), "traffic": None}}
+    log("%s window step: %.2f ms per pass = %.1f M inst/s (%.1f%% of peak), %d windows, rmse %.6f vs sequential %.6f (%+.2e)" % (
+        name, res["ms_per_step"], res["value"] / 1e6, 100 * res["roofline"]["frac"], ds.num_batches, rm_run, rm_seq, rm_run - rm_seq))
+    for x in (ds, dsq):
+        x.close()
+    for t in (tr, sq, tw):
+        t.close()
+    return res
+
+
 def run_single_process_handle(sa, a, world, xch, device, log):
     """secondary.single_process_handle: ONE svdf_trainer with amd:gpus = N (svdf_multi.cpp: N engines on N devices, one host thread per rank,
     HIP events between the ranks' streams) trains the main line's ratings from a resident data set -- the window-minibatch step with the
     handle's own exchange: amd:exchange = p2p (hipDeviceEnablePeerAccess + k_delta_reduce_gather through peer pointers over all xGMI links)
     or rccl (ncclCommInitAll + grouped ncclAllReduce).  Host clock around svdf_train_dataset + synchronize, 1 warm-up + 3 timed passes."""
     n = a.ratings
-    u, i, r = cached(synth_triples, n + 1_000_000, a.users, a.items)
+    u, i, r = cached(synth_triples, n + 1_000_000, a.users, a.items, 12345 + a.data_seed)
     test = (u[n:n + 200000], i[n:n + 200000], r[n:n + 200000])
     u, i, r = u[:n], i[:n], r[:n]
     nwin = max(1, int(np.ceil(n / max(a.items, 1) / 32.0)))
@@ -1104,6 +1185,10 @@ def main():
     ap.add_argument("--preflight-timeout", type=float, default=150.0, help="N>1: watchdog of rendezvous + preflight (seconds); on expiry the rank re-executes one ladder rung lower")
     ap.add_argument("--run-timeout", type=float, default=900.0, help="N>1: watchdog of the main workload (seconds)")
     ap.add_argument("--secondary-timeout", type=float, default=420.0, help="N>1: watchdog of each secondary (seconds); on expiry the contract line is printed without it")
+    ap.add_argument("--data-seed", type=int, default=0, help="added to the generator seed of every synthetic stream (0 = the streams of SURVEY 8d2 / earlier rounds)")
+    ap.add_argument("--no-window-step", action="store_true", help="N=1: skip the opt-in window-minibatch lines of the SVD++ / neighbourhood secondaries")
+    ap.add_argument("--step-window", type=int, default=0, help="window-step secondaries: rows per window (amd:window); 0 = the engine's choice from the data")
+    ap.add_argument("--step-per-target", type=int, default=0, help="window-step secondaries: updates a shared row meets per window (knob window_per_target); 0 = default")
     ap.add_argument("--no-multi-secondary", action="store_true",
                     help="N>1, ratings: skip secondary.allreduce_minibatch (the RCCL all-reduce step on the same data) and secondary.single_process_handle (rank 0 alone "
                          "drives all N devices through one amd:gpus handle, amd:exchange = p2p and rccl)")
@@ -1278,6 +1363,12 @@ def main():
         if r is not None:
             r["wall_s"] = round(time.time() - t0, 1)
             secondary["%s_k%d" % (name, WORKLOADS[name][2])] = r
+    if rank == 0 and world == 1 and not a.no_window_step:
+        for name in [s for s in sec.split(",") if s in ("svdpp", "neighbourhood")]:
+            try:   # extras: never lose the contract line over them
+                secondary["%s_k%d_window_step" % (name, WORKLOADS[name][2])] = run_window_step(sa, name, a, local_rank, log)
+            except Exception as e:
+                secondary["%s_window_step_error" % name] = repr(e)
     if rank == 0 and world == 1 and a.secondary == "auto" and secondary:
         try:
             secondary.update(run_f3_secondary(a, env))

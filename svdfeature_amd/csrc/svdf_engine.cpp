@@ -77,6 +77,7 @@ template struct DevBuf<char>;
 template struct DevBuf<WinUser>;
 template struct DevBuf<WinUnit>;
 template struct DevBuf<WinSeg>;
+template struct DevBuf<WinEnt>;
 
 // =============================================================================== scheduler
 void build_schedule(const std::vector<int> &levels, int base, Schedule &out) {
@@ -2869,6 +2870,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "device_schedule_min")) { check(value >= 1, "device_schedule_min must be >= 1"); device_sched_min_ = value; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "rows_without_feedback")) { rows_without_feedback_ = value != 0; return 0; }
+    if (!strcmp(name, "wunit_fast")) { wunit_fast_ = value != 0; return 0; }
     if (!strcmp(name, "window_per_target")) { check(value >= 1, "window_per_target must be positive"); wseq_per_target_ = (int)value; return 0; }
     if (!strcmp(name, "window_slots")) { window_slots_ = value != 0; return 0; }
     if (!strcmp(name, "window_groups")) { check(value >= 0 && value <= 2, "window_groups must be 0 (auto), 1 or 2"); window_groups_ = (int)value; return 0; }

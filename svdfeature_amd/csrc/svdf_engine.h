@@ -215,9 +215,8 @@ struct Dataset {
     // kind 7: window-minibatch data set of user units (svdf_k_wunit.hip): user-group blocks / rows with global features
     DevBuf<WinUnit> wu_units;
     DevBuf<WinSeg> wu_segs;
-    DevBuf<int> wu_rptr, wu_eslot, wu_fbslot, wu_tptr, wu_gptr;
-    DevBuf<unsigned> wu_eidx, wu_fbidx;
-    DevBuf<float> wu_eval, wu_fbval;
+    DevBuf<int> wu_rptr, wu_tptr, wu_gptr;
+    DevBuf<WinEnt> wu_ent, wu_fbent;
     long wu_gslots = 0;           // contribution words of the global biases = global entries
     int wu_estride = 0;           // > 0: every row has wu_estride - 1 global entries and one item entry (no row pointer array)
     bool wu_feedback = false;     // the units carry implicit-feedback lists (user-group trainer)
@@ -509,6 +508,7 @@ class Engine {
     void wunit_sum(Dataset *ds, void *dst, int half);
     // one GPU, `amd:step = minibatch` (opt-in; not the reference's semantics): resident data sets become window sequences (kind 8)
     bool step_minibatch_set_ = false;
+    int wunit_fast_ = 1;                  // knob "wunit_fast": 0 = the general lane-group kernel for every shape (A/B and tests)
     int wseq_per_target_ = 24;            // knob "window_per_target": updates a shared row meets per window when amd:window is not given
     bool single_minibatch() const { return step_minibatch_set_ && gpus_ == 1 && !multi_ && !is_peer_; }
     long wseq_windows(long n, const std::vector<double> &updates_per_target) const;

@@ -53,7 +53,7 @@ void launch_delta_addto(const DeltaRanges &R, const void *src, int half, hipStre
 void launch_window_items_local(const WindowSchedule &S, int pitch, int k, long lo, long hi, float *w_item, float *i_bias, hipStream_t st);
 void launch_ranges_copy(const DeltaRanges &R, float *buf, int set, hipStream_t st);
 // the same step for user units: user-group (SVD++) blocks, rows with global features (svdf_k_wunit.hip)
-void launch_wunit_walk(const DevParams &P, const WUnitSchedule &S, bool feedback, hipStream_t st);
+void launch_wunit_walk(const DevParams &P, const WUnitSchedule &S, bool feedback, int fast, hipStream_t st);
 void launch_wunit_sum(const DevParams &P, const WUnitSchedule &S, void *dst, int half, hipStream_t st);   // dst == nullptr: add to the model in place
 void launch_window_user_column(const WinUser *urec, int nusers, unsigned *user_out, hipStream_t st);
 void launch_pairs_prepare(long n, const unsigned *pos, const unsigned *neg, unsigned *lo, unsigned *hi, float *vlo, float *vhi, float *ones,

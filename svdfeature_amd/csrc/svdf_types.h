@@ -197,14 +197,16 @@ struct WindowSchedule {
 // Window-minibatch data set of USER UNITS (svdf_k_wunit.hip): user-group (SVD++) blocks and rows with global
 // features.  A unit = one user's part of the window: `seg_count` segments walked in file order by one lane group, a segment = one
 // DEFAULT block or START..END span (its feedback list + its rows) of a user-group pass, or all the user's rows of a random-order window
-// (no feedback list).  Rows are regrouped unit by unit; row r's entries are e[rptr[2r] .. rptr[2r+1]) = global entries and
-// e[rptr[2r+1] .. rptr[2r+2]) = item entries (rptr == nullptr: the fixed layout `estride` entries per row, the last one the item entry).
-// eslot: where the entry's contribution goes -- item entries: a row of contrib / a word of cbias; global entries: a word of gcontrib;
-// fbslot: the same for the feedback rows a segment scatters into at its end.  Row slots are laid out target by target (tptr over the
-// replicated rows: feedback rows first, then item rows -- the order of W_uiset and of the wire buffer), inside a target in file order;
-// global slots global id by global id (gptr).
-struct WinUnit { unsigned user; int seg_begin; int seg_count; int rows; };
+// (no feedback list).  The unit record carries its FIRST segment inline (most units have one), segs[seg_begin + s] the others.
+// Rows are regrouped unit by unit; row r's entries are ent[rptr[2r] .. rptr[2r+1]) = global entries and ent[rptr[2r+1] .. rptr[2r+2]) =
+// item entries (rptr == nullptr: the fixed layout, `estride` entries per row, the last one the item entry).
+// An entry = (id, value, slot): slot is where the entry's contribution goes -- item entries: a row of contrib / a word of cbias; global
+// entries: a word of gcontrib; feedback entries (fbent): the row a segment scatters into at its end.  Row slots are laid out target by
+// target (tptr over the replicated rows: feedback rows first, then item rows -- the order of W_uiset and of the wire buffer), inside a
+// target in file order; global slots global id by global id (gptr).
 struct WinSeg { int fb_begin, fb_count, row_begin, row_count; };
+struct WinUnit { unsigned user; int seg_begin; int seg_count; int rows; WinSeg first; };
+struct WinEnt { unsigned idx; float val; int slot; int pad; };
 struct WUnitSchedule {
     const WinUnit *units;
     long nunits;
@@ -213,12 +215,8 @@ struct WUnitSchedule {
     const float *uval;          // nullptr: every user value is 1.0f
     const int *rptr;            // [2 nrows + 1], or nullptr with estride
     int estride;
-    const unsigned *eidx;
-    const float *eval;
-    const int *eslot;
-    const unsigned *fbidx;
-    const float *fbval;
-    const int *fbslot;
+    const WinEnt *ent;
+    const WinEnt *fbent;
     float *contrib, *cbias, *gcontrib;
     const int *tptr;            // [nfb_rows + nitem_rows + 1]
     const int *gptr;            // [num_global + 1]

@@ -37,8 +37,7 @@ WUnitSchedule Engine::wunit_view(const Dataset *ds) const {
     S.units = ds->wu_units.p; S.nunits = ds->num_units; S.segs = ds->wu_segs.p;
     S.label = ds->label.p; S.uval = ds->unit_values ? nullptr : ds->uval.p;
     S.rptr = ds->wu_estride > 0 ? nullptr : ds->wu_rptr.p; S.estride = ds->wu_estride;
-    S.eidx = ds->wu_eidx.p; S.eval = ds->wu_eval.p; S.eslot = ds->wu_eslot.p;
-    S.fbidx = ds->wu_fbidx.p; S.fbval = ds->wu_fbval.p; S.fbslot = ds->wu_fbslot.p;
+    S.ent = ds->wu_ent.p; S.fbent = ds->wu_fbent.p;
     S.contrib = d_contrib_.p; S.cbias = d_cbias_.p; S.gcontrib = d_gcontrib_.p;
     S.tptr = ds->wu_tptr.p; S.gptr = ds->wu_gptr.p;
     S.nfb_rows = user_group() ? (long)num_fb_rows() : 0; S.nitem_rows = mp_.num_item; S.nglobal = mp_.num_global;
@@ -93,7 +92,7 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
         long acc = 0;
         for (size_t j = 0; j < nunit; j++) {
             const int un = launch[j];
-            units[j] = WinUnit{unit_user[(size_t)un], (int)acc, 0, 0};
+            units[j] = WinUnit{unit_user[(size_t)un], (int)acc, 0, 0, WinSeg{0, 0, 0, 0}};
             acc += unit_nseg[(size_t)un];
         }
     }
@@ -147,9 +146,7 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
         if (feat_value[p1] != 1.0f) unit_uval = false;
     }
     rptr[(size_t)2 * nrow] = (int)nent;
-    std::vector<unsigned> eidx((size_t)nent);
-    std::vector<float> evalv((size_t)nent);
-    std::vector<int> eslot((size_t)nent, 0);
+    std::vector<WinEnt> ent((size_t)nent, WinEnt{0u, 0.0f, 0, 0});
     // ---- slots: counts per target, then file-order assignment
     std::vector<int> tptr((size_t)(NF + NI) + 1, 0), gptr((size_t)NG + 1, 0);
     std::vector<unsigned> seen;   // duplicate check inside a row / a list
@@ -160,7 +157,7 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
         seen.clear();
         for (int64_t j = p0; j < p1; j++, e++) {
             if (feat_index[j] >= (unsigned)NG) fail("global feature index exceed setting");
-            eidx[(size_t)e] = feat_index[j]; evalv[(size_t)e] = feat_value[j];
+            ent[(size_t)e].idx = feat_index[j]; ent[(size_t)e].val = feat_value[j];
             for (unsigned x : seen) if (x == feat_index[j]) fail("window data sets: a global id listed twice in one row");
             seen.push_back(feat_index[j]);
             gptr[(size_t)feat_index[j] + 1]++;
@@ -168,15 +165,13 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
         seen.clear();
         for (int64_t j = p2; j < p3; j++, e++) {
             if (feat_index[j] >= (unsigned)NI) fail("item feature index exceed bound");
-            eidx[(size_t)e] = feat_index[j]; evalv[(size_t)e] = feat_value[j];
+            ent[(size_t)e].idx = feat_index[j]; ent[(size_t)e].val = feat_value[j];
             for (unsigned x : seen) if (x == feat_index[j]) fail("window data sets: an item id listed twice in one row");
             seen.push_back(feat_index[j]);
             tptr[(size_t)(NF + feat_index[j]) + 1]++;
         }
     }
-    std::vector<unsigned> fbidx((size_t)nfbe);
-    std::vector<float> fbval((size_t)nfbe);
-    std::vector<int> fbslot((size_t)nfbe, 0);
+    std::vector<WinEnt> fbent((size_t)nfbe, WinEnt{0u, 0.0f, 0, 0});
     for (size_t q = 0; q < nseg_used; q++) {
         const HostSeg &h = segs[seg_by_new[q]];
         std::vector<unsigned> ids(fb_index + h.fb_begin, fb_index + h.fb_begin + h.fb_count);
@@ -185,7 +180,7 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
         for (int64_t j = 0; j < h.fb_count; j++) {
             const unsigned f = fb_index[h.fb_begin + j];
             if (f >= (unsigned)NF) fail("ufeedback id exceed bound");
-            fbidx[(size_t)wsegs[q].fb_begin + (size_t)j] = f; fbval[(size_t)wsegs[q].fb_begin + (size_t)j] = fb_value[h.fb_begin + j];
+            fbent[(size_t)wsegs[q].fb_begin + (size_t)j].idx = f; fbent[(size_t)wsegs[q].fb_begin + (size_t)j].val = fb_value[h.fb_begin + j];
             tptr[(size_t)f + 1]++;
         }
     }
@@ -196,8 +191,8 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
         const long r = src_of_new[(size_t)nr];
         const int ng = (int)(row_ptr[3 * r + 1] - row_ptr[3 * r]);
         const int e0 = rptr[(size_t)2 * nr], e1 = e0 + ng, e2 = rptr[(size_t)2 * nr + 2];
-        for (int e = e0; e < e1; e++) eslot[(size_t)e] = gcur[eidx[(size_t)e]]++;
-        for (int e = e1; e < e2; e++) eslot[(size_t)e] = tcur[(size_t)NF + eidx[(size_t)e]]++;
+        for (int e = e0; e < e1; e++) ent[(size_t)e].slot = gcur[ent[(size_t)e].idx]++;
+        for (int e = e1; e < e2; e++) ent[(size_t)e].slot = tcur[(size_t)NF + ent[(size_t)e].idx]++;
     };
     if (by_row_order) {
         for (long r = 0; r < num_src_row; r++) if (newrow_of_src[(size_t)r] >= 0) row_slots(newrow_of_src[(size_t)r]);
@@ -206,7 +201,7 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
             if (seg_new[s] < 0) continue;
             const WinSeg &w = wsegs[(size_t)seg_new[s]];
             for (int j = 0; j < w.row_count; j++) row_slots((long)w.row_begin + j);
-            for (int j = 0; j < w.fb_count; j++) fbslot[(size_t)w.fb_begin + (size_t)j] = tcur[fbidx[(size_t)w.fb_begin + (size_t)j]]++;
+            for (int j = 0; j < w.fb_count; j++) fbent[(size_t)w.fb_begin + (size_t)j].slot = tcur[fbent[(size_t)w.fb_begin + (size_t)j].idx]++;
         }
     }
     // rptr as the kernel reads it: rptr[2r], rptr[2r + 1], rptr[2r + 2] -- the odd entries are the global / item boundary of row r
@@ -216,17 +211,14 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
     ds->wu_gslots = gptr.back();
     ds->wu_estride = fixed_ng >= 0 ? fixed_ng + 1 : 0;
     ds->unit_values = unit_uval;
+    for (size_t j = 0; j < nunit; j++) units[j].first = wsegs[(size_t)units[j].seg_begin];   // the first segment travels with the unit record
     ds->wu_units.upload(units.data(), nunit, stream_);
     ds->wu_segs.upload(wsegs.data(), nseg_used, stream_);
     ds->label.upload(w_label.data(), (size_t)nrow, stream_);
     if (!unit_uval) ds->uval.upload(w_uval.data(), (size_t)nrow, stream_);
     if (ds->wu_estride == 0) ds->wu_rptr.upload(rptr.data(), (size_t)2 * nrow + 1, stream_);
-    ds->wu_eidx.upload(eidx.data(), (size_t)nent, stream_);
-    ds->wu_eval.upload(evalv.data(), (size_t)nent, stream_);
-    ds->wu_eslot.upload(eslot.data(), (size_t)nent, stream_);
-    ds->wu_fbidx.upload(fbidx.data(), (size_t)nfbe, stream_);
-    ds->wu_fbval.upload(fbval.data(), (size_t)nfbe, stream_);
-    ds->wu_fbslot.upload(fbslot.data(), (size_t)nfbe, stream_);
+    ds->wu_ent.upload(ent.data(), (size_t)nent, stream_);
+    ds->wu_fbent.upload(fbent.data(), (size_t)nfbe, stream_);
     ds->wu_tptr.upload(tptr.data(), tptr.size(), stream_);
     ds->wu_gptr.upload(gptr.data(), gptr.size(), stream_);
     HIPCHECK(hipStreamSynchronize(stream_));   // the host columns go out of scope
@@ -341,7 +333,7 @@ void Engine::wunit_train(Dataset *ds) {
     d_contrib_.reserve((size_t)std::max<long>(ds->win_slots, 1) * (size_t)pitch_);
     d_cbias_.reserve((size_t)std::max<long>(ds->win_slots, 1));
     d_gcontrib_.reserve((size_t)std::max<long>(ds->wu_gslots, 1));
-    launch_wunit_walk(params(), wunit_view(ds), ds->wu_feedback, stream_);
+    launch_wunit_walk(params(), wunit_view(ds), ds->wu_feedback, wunit_fast_, stream_);
     window_trained_ = ds;
 }
 // second half: dst == nullptr adds the per-target sums to the model in place, else they go to the wire buffer

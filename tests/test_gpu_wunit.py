@@ -17,22 +17,24 @@ from test_window_blocks import SVDPP_EXTRA, _blocks_with_globals
 pytestmark = pytest.mark.gpu
 
 
-def _trainer(conf, fmt=0, active=0, extra=()):
+def _trainer(conf, fmt=0, active=0, extra=(), knobs=()):
     t = sa.Trainer(fmt, active)
     t.seed(10)
     for k, v in list(conf) + list(extra):
         t.set_param(k, str(v))
     t.init_model()
     t.init_trainer()
+    for k, v in knobs:
+        t.set_knob(k, v)
     return t
 
 
-def _run_ranks(conf, data, world, windows, passes, fmt, active=0, half=False):
+def _run_ranks(conf, data, world, windows, passes, fmt, active=0, half=False, knobs=()):
     import torch
     dev = torch.device("cuda", 0)
     ranks = []
     for rk in range(world):
-        ad = HipShard(_trainer(conf, fmt, active), torch, dev, minibatch=True)
+        ad = HipShard(_trainer(conf, fmt, active, knobs=knobs), torch, dev, minibatch=True)
         ad.set_wire_half(half)
         sh = shard_block_windows(data, rk, world, windows) if isinstance(data, BlockArrays) else shard_csr_windows(data, rk, world, windows)
         ranks.append((ad, ad.make_windows(sh)))
@@ -65,17 +67,44 @@ def _check(ranks, sim, names):
 SVDPP_NAMES = ("W_item", "i_bias", "W_ufeedback", "ufeedback_bias", "W_user", "u_bias")
 
 
-@pytest.mark.parametrize("k,world,windows", [(16, 1, 3), (16, 2, 3), (64, 3, 2), (128, 2, 2), (100, 2, 3), (7, 4, 2), (256, 2, 2)])
-def test_user_group_blocks_on_simulated_ranks_equal_the_oracle_simulation(k, world, windows):
-    """SVD++ blocks: DEFAULT blocks and START / MIDDLE / END spans, users without feedback, users with several blocks in one window"""
+@pytest.mark.parametrize("k,world,windows,knobs", [(16, 1, 3, ()), (16, 2, 3, ()), (64, 3, 2, ()), (128, 2, 2, ()), (100, 2, 3, ()), (7, 4, 2, ()), (256, 2, 2, ()),
+                                                   (64, 2, 2, (("wunit_fast", 0),)), (128, 1, 2, (("wunit_fast", 0),))])
+def test_user_group_blocks_on_simulated_ranks_equal_the_oracle_simulation(k, world, windows, knobs):
+    """SVD++ blocks: DEFAULT blocks and START / MIDDLE / END spans, users without feedback, users with several blocks in one window; the
+    lane-group kernel at every width and the slot kernel with its row ring at k = 64 / 128 (k_wunit_fast)"""
     nu, ni = 260, 90
     blocks = cases.user_blocks(300, nu, ni, ni, seed=k + world, max_rows=9, max_fb=6, split_every=4)
     blocks += cases.user_blocks(120, nu, ni, ni, seed=k + world + 50, max_rows=4, max_fb=3)   # the same users again: several segments per unit
     ba = BlockArrays.from_blocks(blocks)
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni) + SVDPP_EXTRA
-    ranks, wins = _run_ranks(conf, ba, world, windows, 2, fmt=1)
+    ranks, wins = _run_ranks(conf, ba, world, windows, 2, fmt=1, knobs=knobs)
     assert wins[0].kind == 7
     _check(ranks, simulate(conf, ba, None, None, world, windows, 2, fmt=1, minibatch=True), SVDPP_NAMES)
+
+
+@pytest.mark.parametrize("k,active,extra", [(64, 2, (("base_score", "0.5"),)), (128, 0, (("reg_method", "1"),)), (64, 0, (("reg_method", "3"),)), (128, 0, (("no_user_bias", "1"),)),
+                                            (64, 0, (("user_nonnegative", "1"),)), (128, 0, (("scale_lr_ufeedback", "0.5"), ("wd_ufeedback_bias", "0.01"))),
+                                            (64, 0, (("ip:wd", "0.1"), ("ip:bound", "30"), ("ip:wd", "0.002"), ("ip:bound", "100000")))])
+def test_slot_kernel_links_and_regularisers(k, active, extra):
+    """the configurations k_wunit_fast covers beyond the usual one (long units: up to 40 rows and 30 feedback ids per user)"""
+    nu, ni = 150, 120
+    ba = BlockArrays.from_blocks(cases.user_blocks(140, nu, ni, ni, seed=k + active, max_rows=40, max_fb=30, split_every=6, binary_label=(active == 2)))
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni) + SVDPP_EXTRA + list(extra)
+    ranks, _ = _run_ranks(conf, ba, 2, 2, 2, fmt=1, active=active)
+    _check(ranks, simulate(conf, ba, None, None, 2, 2, 2, fmt=1, active=active, minibatch=True), SVDPP_NAMES)
+
+
+@pytest.mark.parametrize("k", [64, 128])
+def test_plain_rows_through_the_unit_kernels(k):
+    """(user, item, rating) rows as a CSR window of a random-order trainer: the slot kernel without feedback and without global entries"""
+    nu, ni, n = 700, 150, 20000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=k)
+    u[:2000] = u[:2000] % 5   # a few long units
+    d = CSRData.from_triples(u, i, r)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k)
+    ranks, wins = _run_ranks(conf, d, 2, 3, 2, fmt=0)
+    assert wins[0].kind == 7
+    _check(ranks, simulate(conf, u, i, r, 2, 3, 2, minibatch=True), ("W_item", "i_bias", "W_user", "u_bias"))
 
 
 @pytest.mark.parametrize("active,extra", [(2, (("base_score", "0.5"),)), (0, (("reg_method", "1"), ("reg_global", "1"))),
@@ -109,14 +138,14 @@ def _rows_with_globals(n, nu, ni, ng, per_row, seed, fixed=True):
     return CSRData.from_rows(rows)
 
 
-@pytest.mark.parametrize("k,world,fixed", [(16, 1, True), (128, 2, True), (64, 3, False), (10, 2, False)])
-def test_rows_with_global_features_on_simulated_ranks_equal_the_oracle_simulation(k, world, fixed):
+@pytest.mark.parametrize("k,world,fixed,knobs", [(16, 1, True, ()), (128, 2, True, ()), (64, 2, True, ()), (128, 2, True, (("wunit_fast", 0),)), (64, 3, False, ()), (10, 2, False, ())])
+def test_rows_with_global_features_on_simulated_ranks_equal_the_oracle_simulation(k, world, fixed, knobs):
     """the neighbourhood shape (4 global entries + user + item, fixed layout) and ragged rows (0..4 global entries, sometimes two item entries,
     user values != 1) on a random-order trainer"""
     nu, ni, ng, n = 500, 120, 40, 9000
     d = _rows_with_globals(n, nu, ni, ng, 4, seed=k + world, fixed=fixed)
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_global=ng, wd_global="0.001")
-    ranks, wins = _run_ranks(conf, d, world, 4, 2, fmt=0)
+    ranks, wins = _run_ranks(conf, d, world, 4, 2, fmt=0, knobs=knobs)
     assert wins[0].kind == 7
     _check(ranks, simulate(conf, d, None, None, world, 4, 2, minibatch=True), ("W_item", "i_bias", "g_bias", "W_user", "u_bias"))
 
