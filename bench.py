@@ -447,7 +447,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
     # (svdf_k_window.hip: user side exact, item side one minibatch step per window; three launches per window), "levels" = the
     # round-2 scheme (exact conflict-free levels per rank, item side stale across ranks only)
     exchanging = world > 1 or a.force_exchange
-    minibatch = exchanging and name in ("basicmf", "pairwise") and a.exchange != "levels"
+    minibatch = exchanging and name in ("basicmf", "pairwise", "svdpp") and a.exchange != "levels"
     # ratings on N > 1 ranks: the stratified schedule unless another one is asked for (no all-reduce: DESIGN.md section 6f)
     stratified = exchanging and name == "basicmf" and (a.exchange == "stratified" or (a.exchange == "auto" and world > 1))
     auto_parts = 1 if world <= 2 else 2
@@ -461,6 +461,12 @@ def run_workload(name, a, env, steps, warmup, main_line):
         # beyond for ratings (tools/rmse_contract_fullsize.py); 50 for rank pairs (tests/test_multi_rank.py)
         tgt = 32.0 if minibatch else (50.0 if name == "pairwise" else (64.0 if world <= 2 else (42.0 if world <= 4 else 32.0)))
         nwin = max(1, int(np.ceil(per_item / tgt)))
+        if minibatch and name == "svdpp":
+            # user-group blocks: the feedback rows bind -- a block of n rows pushes n |value| instance-sized updates into every row of its
+            # list at once; sum m_f^2 / sum m_f of that mass is kept at 16 per window (profiles/r04_wstep_calibration.txt; svdf_wunit.cpp)
+            rows_of_block = np.diff(train.block_row_ptr).astype(np.float64)
+            mass = np.bincount(train.fb_index, weights=np.repeat(rows_of_block, np.diff(train.fb_ptr)) * np.abs(train.fb_value), minlength=a.items)
+            nwin = max(nwin, int(np.ceil(float((mass * mass).sum() / max(mass.sum(), 1e-30)) / 16.0)))
     if world == 1 and not a.force_exchange:
         nwin = 1
     if name == "basicmf":
@@ -538,7 +544,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
 
     # ---- one more pass with a HIP event after every phase (outside the timed region): stream time per phase of the exchange
     phase_ms = None
-    if exchanging and name in ("basicmf", "pairwise"):
+    if exchanging and (name in ("basicmf", "pairwise") or minibatch):
         marks = []
 
         def mark(phase):
@@ -609,7 +615,18 @@ def run_workload(name, a, env, steps, warmup, main_line):
         pred = tr.predict_dataset(dt_)
         dt_.close()
         sse, cnt = reduce_sum([float(np.sum((pred.astype(np.float64) - mine.row_label.astype(np.float64)) ** 2)), float(mine.num_row)])
-        quality = {"rmse_test_after_run": float(np.sqrt(sse / max(cnt, 1.0)))}
+        quality = {"rmse_test_after_run": float(np.sqrt(sse / max(cnt, 1.0))), "passes_before_rmse": steps_done}
+        if exchanging and rank == 0 and not a.no_sequential_reference:   # the contract of the exchange: the same passes as exact sequential SGD on this GPU
+            sq = make_trainer(sa, name, a, factor, local_rank)
+            dsq = sq.dataset_from_blocks(train)
+            for _ in range(steps_done):
+                sq.train_dataset(dsq)
+            dte = sq.dataset_from_blocks(test)
+            quality["rmse_sequential_reference"] = rmse(sq.predict_dataset(dte), test.row_label)
+            quality["rmse_minus_sequential"] = quality["rmse_test_after_run"] - quality["rmse_sequential_reference"]
+            for x in (dsq, dte):
+                x.close()
+            sq.close()
     else:
         quality = {"rmse_test_after_run": rmse(tr.predict_batch(test), test.row_label)}
 
@@ -704,7 +721,9 @@ def run_workload(name, a, env, steps, warmup, main_line):
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": (("k_window_users_slots<8,2,G,1,0,true> + k_window_items<16,HALF> + k_delta_addto<HALF>" if name == "basicmf" else
                                      "k_window_users_slots<16,2,1,2,3,false> + k_window_items<32,HALF> + k_delta_addto<HALF>") +
-                                    " (window-minibatch step, 3 launches per window)" if minibatch else WORKLOADS[name][3]), "launches": launches, "avg_launch_us": per_launch_us,
+                                    " (window-minibatch step, 3 launches per window)" if (minibatch and name != "svdpp") else
+                                    ("k_wunit_fast<16,2,true,0,4> + k_wunit_sum<32,HALF,false> + k_delta_addto<HALF> (window-minibatch step for user units, 3 launches per window)"
+                                     if minibatch else WORKLOADS[name][3])), "launches": launches, "avg_launch_us": per_launch_us,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "algorithmic_bytes_per_instance": alg_bytes / max(my_n, 1)},
             # what bounds one launch of this kernel: its measured HBM traffic at the achievable streaming rate + one dependent
@@ -1025,6 +1044,7 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
     tr = make_trainer(sa, name, a, factor, device, extra=extra)
     if a.step_per_target > 0:
         tr.set_knob("window_per_target", a.step_per_target)
+        tr.set_knob("window_per_target_fb", a.step_per_target)
     ds = tr.dataset_from_blocks(train) if name == "svdpp" else tr.dataset_from_csr(d_all)
     build_s = time.time() - t0
     assert ds.kind == 8

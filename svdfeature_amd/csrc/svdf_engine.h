@@ -498,6 +498,7 @@ class Engine {
     // user-unit windows (svdf_wunit.cpp)
     WUnitSchedule wunit_view(const Dataset *ds) const;
     void wunit_check_config(const char *what) const;
+    bool wunit_config_ok() const;       // the same conditions as a predicate (svdf_multi.cpp picks the step per data set)
     void wunit_build(Dataset *ds, const void *segs, size_t nseg, const std::vector<int64_t> &seg_rows, bool by_row_order, long num_src_row,
                      const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value,
                      const unsigned *fb_index, const float *fb_value);
@@ -509,6 +510,7 @@ class Engine {
     // one GPU, `amd:step = minibatch` (opt-in; not the reference's semantics): resident data sets become window sequences (kind 8)
     bool step_minibatch_set_ = false;
     int wunit_fast_ = 1;                  // knob "wunit_fast": 0 = the general lane-group kernel for every shape (A/B and tests)
+    int wseq_per_target_fb_ = 16;         // knob "window_per_target_fb": the same for feedback rows (instance-sized updates pushed by whole blocks)
     int wseq_per_target_ = 24;            // knob "window_per_target": updates a shared row meets per window when amd:window is not given
     bool single_minibatch() const { return step_minibatch_set_ && gpus_ == 1 && !multi_ && !is_peer_; }
     long wseq_windows(long n, const std::vector<double> &updates_per_target) const;
@@ -543,7 +545,7 @@ class Engine {
                                        const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
                                        const float *feat_value);
     void multi_train_dataset(Dataset *ds);
-    long multi_windows_for(long n, const std::vector<long> &item_count) const;
+    long multi_windows_for(long n, const std::vector<long> &item_count, bool minibatch) const;
     void multi_synchronize();
     int multi_predict_rank_ = 0;         // owner of the user-group block scored last (predict_block on an amd:gpus handle)
     int multi_exchange_mode_ = 0;        // "amd:exchange": 0 p2p (peer loads / stores between the ranks of this process), 1 rccl

@@ -368,12 +368,12 @@ void Engine::multi_flush(HostCSR &src) {
 // The automatic window assumes every item is updated equally often (per_item x num_item instances per window).  A resident data
 // set knows better: an instance meets  sum_i c_i^2 / n  updates of its own items per pass (c_i = rows that carry item i), which is
 // n / num_item for a uniform catalogue and larger for a skewed one -- THAT is kept at `per_item` per window.
-long Engine::multi_windows_for(long n, const std::vector<long> &item_count) const {
+long Engine::multi_windows_for(long n, const std::vector<long> &item_count, bool minibatch) const {
     long W = std::max<long>(1, (n + stage_window_ - 1) / stage_window_);
     if (window_set_ || n <= 0) return W;
     double s2 = 0.0;
     for (long c : item_count) s2 += (double)c * (double)c;
-    const double per_item = multi_step_levels_ || user_group() ? (gpus_ <= 2 ? 64.0 : (gpus_ <= 4 ? 42.0 : 32.0)) : 24.0;
+    const double per_item = !minibatch ? (gpus_ <= 2 ? 64.0 : (gpus_ <= 4 ? 42.0 : 32.0)) : 24.0;
     return std::max<long>(W, (long)std::ceil(s2 / (double)n / per_item));
 }
 
@@ -394,7 +394,7 @@ Dataset *Engine::multi_dataset_from_triples(long n, const unsigned *user, const 
     ds->m_minibatch = mbatch;
     std::vector<long> cnt((size_t)mp_.num_item, 0);
     for (long r = 0; r < n; r++) cnt[item[r]]++;
-    const long W = multi_windows_for(n, cnt);
+    const long W = multi_windows_for(n, cnt, mbatch);
     ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
     for (long w = 0; w < W; w++) {
         const long b0 = n * w / W, b1 = n * (w + 1) / W;
@@ -437,7 +437,7 @@ Dataset *Engine::multi_dataset_from_pairs(long n, const unsigned *user, const un
     ds->m_minibatch = true;
     std::vector<long> cnt((size_t)mp_.num_item, 0);
     for (long r = 0; r < n; r++) { cnt[pos[r]]++; cnt[neg[r]]++; }
-    const long W = multi_windows_for(n, cnt);
+    const long W = multi_windows_for(n, cnt, true);
     ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
     for (long w = 0; w < W; w++) {
         const long b0 = n * w / W, b1 = n * (w + 1) / W;
@@ -479,11 +479,27 @@ Dataset *Engine::multi_dataset_from_csr(long num_row, const float *row_label, co
     MultiScope local;
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = num_row; ds->kind = 6;
-    ds->m_minibatch = false;
-    std::vector<long> cnt((size_t)mp_.num_item, 0);
-    for (long r = 0; r < num_row; r++)
+    // rows with global features / several item entries: the window-minibatch step for user units (svdf_k_wunit.hip) when every row has
+    // exactly one user entry and no id twice; anything else keeps exact conflict-free levels per rank
+    bool units = !multi_step_levels_ && wunit_config_ok();
+    for (long r = 0; r < num_row && units; r++) {
+        const int64_t *p = &row_ptr[(size_t)3 * r];
+        units = p[2] == p[1] + 1;
+        for (int64_t a = p[0]; a < p[1] && units; a++) for (int64_t b = a + 1; b < p[1]; b++) if (feat_index[(size_t)a] == feat_index[(size_t)b]) units = false;
+        for (int64_t a = p[2]; a < p[3] && units; a++) for (int64_t b = a + 1; b < p[3]; b++) if (feat_index[(size_t)a] == feat_index[(size_t)b]) units = false;
+    }
+    ds->m_minibatch = units;
+    std::vector<long> cnt((size_t)mp_.num_item, 0), gcnt((size_t)mp_.num_global, 0);
+    for (long r = 0; r < num_row; r++) {
         for (int64_t j = row_ptr[(size_t)3 * r + 2]; j < row_ptr[(size_t)3 * r + 3]; j++) if (feat_index[(size_t)j] < (unsigned)mp_.num_item) cnt[feat_index[(size_t)j]]++;
-    const long W = multi_windows_for(num_row, cnt);
+        for (int64_t j = row_ptr[(size_t)3 * r]; j < row_ptr[(size_t)3 * r + 1]; j++) if (feat_index[(size_t)j] < (unsigned)mp_.num_global) gcnt[feat_index[(size_t)j]]++;
+    }
+    long W = multi_windows_for(num_row, cnt, units);
+    if (units && !window_set_) {   // a global bias meets sum c_g^2 / sum c_g updates of its own per pass: kept at the same per-window count
+        double s1 = 0.0, s2 = 0.0;
+        for (long c : gcnt) { s1 += (double)c; s2 += (double)c * (double)c; }
+        if (s1 > 0.0) W = std::max<long>(W, (long)std::ceil(s2 / s1 / 24.0));
+    }
     ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
     struct Part { std::vector<float> label, value; std::vector<int64_t> ptr{0}; std::vector<unsigned> index; };
     long alg = 0;
@@ -502,7 +518,9 @@ Dataset *Engine::multi_dataset_from_csr(long num_row, const float *row_label, co
         multi_->pool->run([&](int d) {
             Part &o = part[(size_t)d];
             if (o.index.empty()) { o.index.push_back(0); o.value.push_back(0.0f); }
-            ds->mchild[(size_t)d][(size_t)w] = rank_engine(d)->dataset_from_csr((long)o.label.size(), o.label.data(), o.ptr.data(), o.index.data(), o.value.data());
+            Engine *e = rank_engine(d);
+            ds->mchild[(size_t)d][(size_t)w] = units ? e->dataset_window_from_csr((long)o.label.size(), o.label.data(), o.ptr.data(), o.index.data(), o.value.data())
+                                                     : e->dataset_from_csr((long)o.label.size(), o.label.data(), o.ptr.data(), o.index.data(), o.value.data());
         });
         for (int d = 0; d < N; d++) alg += ds->mchild[(size_t)d][(size_t)w]->algorithmic_bytes;
     }
@@ -545,7 +563,9 @@ Dataset *Engine::multi_dataset_from_blocks(long num_block, const int *extend_tag
     std::vector<long> cnt((size_t)mp_.num_item, 0);
     for (int64_t r = block_row_ptr[0]; r < block_row_ptr[num_block]; r++)
         for (int64_t j = row_ptr[(size_t)3 * r + 2]; j < row_ptr[(size_t)3 * r + 3]; j++) if (feat_index[(size_t)j] < (unsigned)mp_.num_item) cnt[feat_index[(size_t)j]]++;
-    long W0 = multi_windows_for(std::max<long>(num_row, 1), cnt);
+    // the window-minibatch step for user units (svdf_k_wunit.hip) unless amd:step = levels or the configuration is outside it
+    const bool wstep = !multi_step_levels_ && wunit_config_ok();
+    long W0 = multi_windows_for(std::max<long>(num_row, 1), cnt, wstep);
     if (!window_set_ && num_row > 0) {
         // the implicit-feedback rows move by whole-block steps: a block of n rows pushes about n |value| instance-sized updates into
         // every row of its feedback list at once (update_ufeedback, apex_svd_base.h:539-554), and stale sums of those overshoot much
@@ -559,7 +579,7 @@ Dataset *Engine::multi_dataset_from_blocks(long num_block, const int *extend_tag
         }
         double s1 = 0.0, s2 = 0.0;
         for (double m : mass) { s1 += m; s2 += m * m; }
-        if (s1 > 0.0) W0 = std::max<long>(W0, std::min<long>(num_block, (long)std::ceil(s2 / s1 / 24.0)));
+        if (s1 > 0.0) W0 = std::max<long>(W0, std::min<long>(num_block, (long)std::ceil(s2 / s1 / (wstep ? (double)wseq_per_target_fb_ : 24.0))));   // window-minibatch step: calibrated at 16 (svdf_wunit.cpp)
     }
     std::vector<long> cut{0};
     for (long w = 1; w < W0; w++) {
@@ -573,7 +593,7 @@ Dataset *Engine::multi_dataset_from_blocks(long num_block, const int *extend_tag
     MultiScope local;
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = num_row; ds->kind = 6;
-    ds->m_minibatch = false;
+    ds->m_minibatch = wstep;
     ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
     struct Part {
         std::vector<int> tag; std::vector<int64_t> fbp{0}, brp{0}, ptr{0};
@@ -604,8 +624,10 @@ Dataset *Engine::multi_dataset_from_blocks(long num_block, const int *extend_tag
             if (o.fbi.empty()) { o.fbi.push_back(0); o.fbv.push_back(0.0f); }
             if (o.index.empty()) { o.index.push_back(0); o.value.push_back(0.0f); }
             if (o.label.empty()) o.label.push_back(0.0f);
-            ds->mchild[(size_t)d][(size_t)w] = rank_engine(d)->dataset_from_blocks((long)o.brp.size() - 1, o.tag.data(), o.fbp.data(), o.fbi.data(), o.fbv.data(),
-                                                                                     o.brp.data(), o.label.data(), o.ptr.data(), o.index.data(), o.value.data());
+            Engine *e = rank_engine(d);
+            const long nb = (long)o.brp.size() - 1;
+            ds->mchild[(size_t)d][(size_t)w] = wstep ? e->dataset_window_from_blocks(nb, o.tag.data(), o.fbp.data(), o.fbi.data(), o.fbv.data(), o.brp.data(), o.label.data(), o.ptr.data(), o.index.data(), o.value.data())
+                                                     : e->dataset_from_blocks(nb, o.tag.data(), o.fbp.data(), o.fbi.data(), o.fbv.data(), o.brp.data(), o.label.data(), o.ptr.data(), o.index.data(), o.value.data());
         });
         for (int d = 0; d < N; d++) { alg += ds->mchild[(size_t)d][(size_t)w]->algorithmic_bytes; units += ds->mchild[(size_t)d][(size_t)w]->num_units; }
     }

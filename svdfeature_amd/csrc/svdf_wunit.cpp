@@ -44,6 +44,10 @@ WUnitSchedule Engine::wunit_view(const Dataset *ds) const {
     return S;
 }
 
+bool Engine::wunit_config_ok() const {
+    return trainer_ready_ && mtype_.extend_type == 0 && !relaxed() && !lazy_decay() && mp_.common_latent_space == 0 && feat_user_.num_row() == 0 &&
+           feat_item_.num_row() == 0 && g_stride_ == 1 && mp_.num_factor <= 256 && (!user_group() || mp_.common_feedback_space == 0);
+}
 void Engine::wunit_check_config(const char *what) const {
     check(trainer_ready_, "dataset: init_trainer has not been called");
     check(mtype_.extend_type == 0, "window data sets: the base solvers only (extend_type 0)");
@@ -345,12 +349,16 @@ void Engine::wunit_sum(Dataset *ds, void *dst, int half) {
 // OPT-IN and NOT the reference's semantics: the pass is cut into windows; inside a window the shared rows are read as of its start and
 // move once, at its end (the N-rank step run by one rank -- the result does not depend on the number of ranks).
 // Accuracy contract |dRMSE| <= 1e-4 against the sequential pass, like every N > 1 line; the exact level-scheduled pass stays the default.
+// updates_per_target: {item rows, global biases[, feedback rows (instance-sized mass)]}.  Calibrated at the full BASELINE configs[3] sizes
+// on three data seeds, 4 and 10 passes (profiles/r04_wstep_calibration.txt): item rows / global biases at 24 per window, feedback rows at 16
+// keep |dRMSE| <= 6.2e-5 (SVD++: 24 -> 9.2e-5, 48 -> 1.6e-4; neighbourhood: 64 -> 2.1e-5, 256 -> 1.8e-4 after 10 passes).
 long Engine::wseq_windows(long n, const std::vector<double> &updates_per_target) const {
     if (n <= 0) return 1;
     if (window_set_) return std::max<long>(1, (n + stage_window_ - 1) / stage_window_);
     double worst = 0.0;
-    for (double x : updates_per_target) worst = std::max(worst, x);
-    return std::max<long>(1, (long)std::ceil(worst / (double)wseq_per_target_));
+    for (size_t j = 0; j < updates_per_target.size(); j++)
+        worst = std::max(worst, updates_per_target[j] / (double)(j == 2 ? wseq_per_target_fb_ : wseq_per_target_));
+    return std::max<long>(1, (long)std::ceil(worst));
 }
 
 

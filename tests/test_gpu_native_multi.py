@@ -81,25 +81,40 @@ def test_virtual_ranks_match_the_oracle_simulation(world, windows, k, step, tmp_
     ds.close()
 
 
-def test_resident_rows_with_globals_and_user_group_blocks_on_virtual_ranks(tmp_path):
-    """(i) rows with global features as a resident data set of the handle (level scheme, g_bias travels with the item side) == the
-    same rows staged through update(); (ii) a user-group (SVD++) pass as a resident data set on 2 / 4 virtual ranks == the
-    multi_gpu.py simulation (blocks follow their user, windows cut where no START..END span is open), bit for bit; the same pass
-    from a user-group buffer file."""
+@pytest.mark.parametrize("step", ["levels", "minibatch"])
+def test_resident_rows_with_globals_and_user_group_blocks_on_virtual_ranks(step, tmp_path):
+    """(i) rows with global features as a resident data set of the handle: amd:step = levels (exact conflict-free levels per rank, g_bias
+    travels with the item side) == the same rows staged through update(); amd:step = minibatch (default: the window-minibatch step for user
+    units, svdf_k_wunit.hip) == the oracle-backed simulation of that step; (ii) a user-group (SVD++) pass as a resident data set on 2 / 4
+    virtual ranks == the multi_gpu.py simulation of the same step (blocks follow their user, windows cut where no START..END span is open),
+    bit for bit; the same pass from a user-group buffer file."""
+    mb = step == "minibatch"
     from multi_rank_utils import simulate as sim_blocks
     nu, ni, ng, n, world, windows = 300, 120, 6, 6000, 3, 3
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=20, wd_global=0.002)
     d = _rows_with_one_rank_per_row(n, nu, ni, ng, world, seed=4)
-    a = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows)])
-    b = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows)])
+    if mb:   # the window-minibatch step for user units wants exactly one user entry per row (other rows keep the level scheme)
+        from test_gpu_wunit import _rows_with_globals
+        d = _rows_with_globals(n, nu, ni, ng, 3, seed=4, fixed=False)
+    a = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows), ("amd:step", step)])
+    b = _ready(conf, [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", n // windows), ("amd:step", step)])
     a.update_batch(d)
     a.finish_round()
     ds = b.dataset_from_csr(d)
     assert ds.kind == 6
     b.train_dataset(ds)
-    assert b.counter(8) == windows and b.counter(11) == 0
-    for name in ("W_item", "i_bias", "g_bias", "W_user", "u_bias"):
-        np.testing.assert_array_equal(a.view(name).view(np.uint32), b.view(name).view(np.uint32))
+    assert b.counter(8) == windows and b.counter(11) == (windows if mb else 0)
+    if not mb:
+        for name in ("W_item", "i_bias", "g_bias", "W_user", "u_bias"):
+            np.testing.assert_array_equal(a.view(name).view(np.uint32), b.view(name).view(np.uint32))
+    else:   # (staged rows with global entries keep the level scheme; the resident data set takes the window-minibatch step)
+        sim = sim_blocks(conf, d, None, None, world, windows, 1, minibatch=True)
+        for name in ("W_item", "i_bias", "g_bias"):
+            np.testing.assert_array_equal(b.view(name).view(np.uint32), sim[0].t.view(name).view(np.uint32))
+        wu = b.view("W_user")
+        for rk in range(world):
+            own = (np.arange(nu) % world) == rk
+            np.testing.assert_array_equal(wu[own].view(np.uint32), sim[rk].t.view("W_user")[own].view(np.uint32))
     # (ii) SVD++ blocks
     for world, windows in ((2, 3), (4, 2)):
         nu, ni = 240, 90
@@ -109,7 +124,7 @@ def test_resident_rows_with_globals_and_user_group_blocks_on_virtual_ranks(tmp_p
         pconf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=16, num_ufeedback=ni, wd_ufeedback=0.004, ufeedback_init_sigma=0.01)
         t = sa.Trainer(1, 0)
         t.seed(10)
-        for k, v in pconf + [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", -(-ba.num_row // windows))]:
+        for k, v in pconf + [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", -(-ba.num_row // windows)), ("amd:step", step)]:
             t.set_param(k, str(v))
         t.init_model()
         t.init_trainer()
@@ -117,8 +132,8 @@ def test_resident_rows_with_globals_and_user_group_blocks_on_virtual_ranks(tmp_p
         assert ds.kind == 6
         for _ in range(2):
             t.train_dataset(ds)
-        assert t.counter(8) == 2 * windows
-        sim = sim_blocks(pconf, ba, None, None, world, windows, 2, fmt=1)
+        assert t.counter(8) == 2 * windows and t.counter(11) == (2 * windows if mb else 0)
+        sim = sim_blocks(pconf, ba, None, None, world, windows, 2, fmt=1, minibatch=mb)
         for name in ("W_item", "i_bias", "W_ufeedback", "ufeedback_bias"):
             np.testing.assert_array_equal(t.view(name).view(np.uint32), sim[0].t.view(name).view(np.uint32))
         wu = t.view("W_user")
@@ -133,7 +148,7 @@ def test_resident_rows_with_globals_and_user_group_blocks_on_virtual_ranks(tmp_p
         D.write_ugroup_buffer(path, blocks)
         t3 = sa.Trainer(1, 0)
         t3.seed(10)
-        for k, v in pconf + [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", -(-ba.num_row // windows))]:
+        for k, v in pconf + [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", -(-ba.num_row // windows)), ("amd:step", step)]:
             t3.set_param(k, str(v))
         t3.init_model()
         t3.init_trainer()

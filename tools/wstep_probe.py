@@ -22,7 +22,7 @@ def main():
     log = lambda m: print("[probe] " + m, file=sys.stderr, flush=True)
     for seed in seeds:
         for pt in targets:
-            a.data_seed, a.step_per_target = seed, pt
+            a.data_seed, a.step_per_target = seed, pt   # (sets both knobs: window_per_target and window_per_target_fb)
             r = bench.run_window_step(sa, name, a, 0, log, steps=steps)
             print(json.dumps({"workload": name, "seed": seed, "per_target": pt, "windows": r["windows_per_pass"], "ms_per_pass": r["ms_per_step"],
                               "M_inst_s": r["value"] / 1e6, "frac": r["roofline"]["frac"], "rmse": r["rmse_test_after_run"],
