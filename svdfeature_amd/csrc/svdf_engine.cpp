@@ -1657,6 +1657,10 @@ void Engine::predict_block(int nfb, int tag, const unsigned *ifb, const float *v
     if (multi_ && !in_multi_scope()) {
         // the block is scored by the owner of its user (the first user entry of its first row; a block without one -- the MIDDLE / END
         // pieces of a span carry their rows' user too -- goes where the previous block went)
+        for (int r = 0; r < num_row; r++) {   // the owner is read from the rows before any rank validates them
+            const int *q = row_ptr + 3 * r;
+            check(q[0] >= 0 && q[0] <= q[1] && q[1] <= q[2] && q[2] <= q[3], "CSR row_ptr must be non-decreasing");
+        }
         if (num_row > 0 && row_ptr[2] > row_ptr[1]) multi_predict_rank_ = (int)(feat_index[row_ptr[1]] % (unsigned)gpus_);
         Engine *e = rank_engine(multi_predict_rank_);
         if (e != this) {
@@ -2312,6 +2316,9 @@ void Engine::window_build(Dataset *ds, long n, const unsigned *user, const unsig
         ds->win_ival1.upload(w_v1.data(), (size_t)n, stream_);
     }
     HIPCHECK(hipStreamSynchronize(stream_));   // the host columns go out of scope
+    ds->sched_signature = schedule_signature();   // a data set refilled in place (the staged path of an amd:gpus handle) is valid under the CURRENT configuration
+    ds->win_item_lo = NI; ds->win_item_hi = -1;    // the item ids the window touches: window_delta_apply_local checks them against the active block
+    for (long i = 0; i < NI; i++) if (iptr[(size_t)i + 1] > iptr[(size_t)i]) { if (ds->win_item_lo == NI) ds->win_item_lo = i; ds->win_item_hi = i; }
     ds->unit_values = true;
     ds->num_units = nact;
     ds->sched.level_ptr = {0, n};
@@ -2367,6 +2374,8 @@ void Engine::window_delta_apply_local(Dataset *ds) {
     check(!relaxed() && g_stride_ == 1 && user_off_ == 0, "window_delta_apply_local: random-order trainers without relaxed ids only");
     const long ni = mp_.num_item;
     const long lo = ni * delta_part_ / delta_nparts_, hi = ni * (delta_part_ + 1) / delta_nparts_;
+    check(ds->win_item_hi < 0 || (ds->win_item_lo >= lo && ds->win_item_hi < hi),
+          "window_delta_apply_local: the window holds instances of items outside the active item block (svdf_item_delta_select): their updates would be lost");
     launch_window_items_local(window_view(ds), pitch_, mp_.num_factor, lo, hi, dW_.p + (size_t)item_off_ * pitch_, dbias_.p + item_off_, stream_);
     HIPCHECK(hipGetLastError());
     n_launches_++;

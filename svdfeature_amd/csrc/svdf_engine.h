@@ -211,6 +211,7 @@ struct Dataset {
     DevBuf<int> win_slot, win_iptr, win_slot1;
     DevBuf<unsigned> win_item1;   // rank pairs: the second (higher-id) item entry, its slot and sign; entry 0 uses item / win_slot / ival
     DevBuf<float> win_ival1;
+    long win_item_lo = 0, win_item_hi = -1;   // kind 5: lowest / highest item id with an instance in the window (-1: none)
     long win_slots = 0;           // contribution slots of the window = item entries (kind 7: + feedback entries)
     // kind 7: window-minibatch data set of user units (svdf_k_wunit.hip): user-group blocks / rows with global features
     DevBuf<WinUnit> wu_units;

@@ -324,8 +324,12 @@ void Engine::multi_flush(HostCSR &src) {
     const long n = src.num_row();
     if (n == 0) return;
     const int N = gpus_;
+    // A rank may throw inside a window (a HIP / RCCL error reported through RankPool::run).  The windows before it are trained and
+    // exchanged: whatever happens, the staged rows are dropped here, so that a later flush() (or the destructor's) cannot train them twice.
+    struct DropStaged { HostCSR &s; long total; long done = 0; ~DropStaged() { if (done < total) fprintf(stderr, "svdfeature_amd: an exchange window failed: %ld staged rows were trained, %ld dropped\n", done, total - done); s.clear(); } } drop{src, n};
     for (long w0 = 0; w0 < n; w0 += stage_window_) {
         const long w1 = std::min(n, w0 + stage_window_);
+        drop.done = w0;
         if (multi_minibatch_allowed() && rows_are_triples(src, w0, w1)) {
             std::vector<std::vector<unsigned>> cu((size_t)N), ci((size_t)N);
             std::vector<std::vector<float>> cl((size_t)N);
@@ -361,8 +365,8 @@ void Engine::multi_flush(HostCSR &src) {
         }
         multi_window([&](int d, Engine *e) { e->flush_csr(part[(size_t)d]); }, false, nullptr);
     }
+    drop.done = n;
     MCHECK(hipSetDevice(device_));
-    src.clear();
 }
 
 // The automatic window assumes every item is updated equally often (per_item x num_item instances per window).  A resident data
@@ -540,6 +544,11 @@ Dataset *Engine::multi_dataset_from_blocks(long num_block, const int *extend_tag
                                            const float *feat_value) {
     const int N = gpus_;
     const long num_row = block_row_ptr[num_block] - block_row_ptr[0];
+    for (long b = 0; b < num_block; b++) check(block_row_ptr[b] <= block_row_ptr[b + 1] && fb_ptr[b] <= fb_ptr[b + 1], "dataset_from_blocks: block_row_ptr / fb_ptr must be non-decreasing");
+    for (int64_t r = block_row_ptr[0]; r < block_row_ptr[num_block]; r++) {   // the owners are read from the rows before any rank validates them
+        const int64_t *p = &row_ptr[(size_t)3 * r];
+        check(p[0] >= 0 && p[0] <= p[1] && p[1] <= p[2] && p[2] <= p[3], "CSR row_ptr must be non-decreasing");
+    }
     std::vector<int> owner((size_t)num_block, 0);
     int cur = 0;
     for (long b = 0; b < num_block; b++) {

@@ -69,6 +69,7 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
     const bool feedback = user_group();
     if (window_trained_ == ds) window_trained_ = nullptr;
     ds->kind = 7;
+    ds->sched_signature = schedule_signature();
     ds->wu_feedback = feedback;
     // ---- units: the segments of one user, in file order; launch order by cost (rows + feedback entries), descending
     std::vector<int> unit_of_user((size_t)NU, -1);

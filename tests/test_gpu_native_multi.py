@@ -405,3 +405,22 @@ def test_eval_dataset_on_the_handle(step, tmp_path):
     assert abs(ss - float(np.sum((pred.astype(np.float64) - tr) ** 2))) <= 1e-6 * ss
     with pytest.raises(sa.SvdfError, match="no file order"):
         t.predict_dataset(test)
+
+
+def test_malformed_rows_are_reported_before_the_handle_reads_an_owner_from_them():
+    """predict(block) and resident block data sets on an amd:gpus handle pick the owner rank from the rows: a decreasing row_ptr must
+    raise the usual message instead of being read out of bounds"""
+    nu, ni = 60, 20
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=8, num_ufeedback=ni)
+    t = sa.Trainer(1, 0)
+    t.seed(10)
+    for k, v in conf + [("amd:gpus", 2)]:
+        t.set_param(k, str(v))
+    t.init_model()
+    t.init_trainer()
+    blk = cases.user_blocks(1, nu, ni, ni, seed=2, max_rows=3, max_fb=2)[0]
+    bad = blk.data.row_ptr.copy()
+    bad[1] = bad[2] + 5
+    blk.data.row_ptr = bad
+    with pytest.raises(sa.SvdfError, match="non-decreasing"):
+        t.predict_block(blk)

@@ -262,3 +262,18 @@ def test_degenerate_window_shapes(shape, k):
     windows = 1 if len(r) < 10 else 3
     ranks = _run_ranks(conf, u, i, r, 2, windows, 2)
     _check(ranks, simulate(conf, u, i, r, 2, windows, 2, minibatch=True))
+
+
+def test_apply_local_refuses_a_window_with_items_outside_the_active_block():
+    """stratified schedule: a window whose instances touch items outside the selected item block would silently lose those updates"""
+    nu, ni = 100, 40
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=16)
+    t = _trainer(conf)
+    u, i, r = cases.planted_triples(500, nu, ni, seed=1)
+    ds = t.dataset_window_from_triples(u, i, r)          # items of every block
+    t.train_dataset(ds)
+    t.item_delta_select(1, 4)
+    with pytest.raises(sa.SvdfError, match="outside the active item block"):
+        t.window_delta_apply_local(ds)
+    t.item_delta_select(0, 1)
+    t.window_delta_apply_local(ds)                        # the whole range: fine
