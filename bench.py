@@ -415,7 +415,8 @@ def run_workload(name, a, env, steps, warmup, main_line):
     log("%s: synthetic data (%d %s per pass) in %.1fs" % (name, n, unit.split("/")[0], time.time() - t0))
 
     t0 = time.time()
-    tr = make_trainer(sa, name, a, factor, local_rank)
+    contrib = [("amd:contrib", a.contrib)] if a.contrib != "fp32" else []
+    tr = make_trainer(sa, name, a, factor, local_rank, extra=contrib)
     if name == "basicmf" and a.groups_per_wave:
         tr.set_knob("groups_per_wave", a.groups_per_wave)
     tr.set_knob("use_graph", a.use_graph)
@@ -431,7 +432,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
             parity = None   # the N-rank result is window-synchronous SGD: accuracy contract, not bit parity
         # fresh model for the measured run: the parity prefix trained this one
         tr.close()
-        tr = make_trainer(sa, name, a, factor, local_rank)
+        tr = make_trainer(sa, name, a, factor, local_rank, extra=contrib)
         tr.set_knob("use_graph", a.use_graph)
         if name == "basicmf" and a.groups_per_wave:
             tr.set_knob("groups_per_wave", a.groups_per_wave)
@@ -490,7 +491,13 @@ def run_workload(name, a, env, steps, warmup, main_line):
     if stratified:
         from svdfeature_amd.multi_gpu import StratifiedTrainer, stratified_plan
         bpr = max(1, a.blocks_per_rank) if world > 1 else 1
-        plan = [[adaptor.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, rank, world, a.chunks, a.items, 32.0, bpr)]
+        # accuracy defaults from the 3-seed contract at the full configs[2] size (profiles/r04_contract_seeds.txt): below 8 ranks a stratum holds
+        # many updates per item and its order is far from the file's -- 8 chunks per pass and <= 16 updates per item per window keep every cell
+        # <= 6.0e-5 (4 chunks / 32: up to 1.10e-4 at 2 and 4 ranks); at 8 ranks 4 chunks / 32 measure <= 6.3e-5 and the steps are already short
+        if a.chunks <= 0:
+            a.chunks = 8 if world < 8 else 4
+        strat_per_item = a.stratified_per_item if a.stratified_per_item > 0 else (16.0 if world < 8 else 32.0)
+        plan = [[adaptor.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, rank, world, a.chunks, a.items, strat_per_item, bpr)]
         wins = [w for chunk in plan for sub in chunk for w in sub]
         nwin = len(wins)
         parts = 1
@@ -1037,7 +1044,7 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
         d_all = cached(synth_neighbourhood, n + 100_000, a.users, a.items, a.globals, 4, 99 + a.data_seed)
         test = d_all.slice_rows(n, n + 100_000)
         d_all = d_all.slice_rows(0, n)
-    extra = [("amd:step", "minibatch")]
+    extra = [("amd:step", "minibatch")] + ([("amd:contrib", a.contrib)] if getattr(a, "contrib", "fp32") != "fp32" else [])
     if a.step_window > 0:
         extra.append(("amd:window", str(a.step_window)))
     t0 = time.time()
@@ -1176,9 +1183,12 @@ def main():
                          "(1 = one synchronous all-reduce per window; 0 = auto: 1 at 2 ranks, 2 beyond -- a piece keeps the window's item-chain "
                          "depth, so pieces double a rank's launches: 12.9 -> 32.7 ms per pass at 2 ranks, 7.9 -> 10.6 at 4, 5.3 -> 7.7 at 8 "
                          "(tools/shard_parts_probe.sh), which only pays once the exchange it hides is the larger part)")
-    ap.add_argument("--chunks", type=int, default=4,
+    ap.add_argument("--stratified-per-item", type=float, default=0.0, help="--exchange stratified: updates per item per window inside a stratum (0 = 16 below 8 ranks, 32 from 8 ranks)")
+    ap.add_argument("--contrib", choices=["fp32", "bf16"], default="fp32",
+                    help="window-minibatch step: storage format of the contribution rows (amd:contrib; bf16 halves their bytes, sums stay fp32; opt-in)")
+    ap.add_argument("--chunks", type=int, default=0,
                     help="--exchange stratified: file-order chunks per pass (a chunk = N sub-epochs; more chunks keep the training order closer to "
-                         "the file order: tools/stratified_calibration.py)")
+                         "the file order: tools/stratified_calibration.py, tools/contract_seeds.py); 0 = 8 below 8 ranks, 4 from 8 ranks")
     ap.add_argument("--blocks-per-rank", type=int, default=2,
                     help="--exchange stratified: item blocks per rank (1: a block is handed over between two steps; 2: the hand-over of a block "
                          "runs beside the training of the rank's next block)")

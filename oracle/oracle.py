@@ -68,6 +68,8 @@ def _load(kind):
     lib.svdo_update_csr_batch_stale.restype = C.c_int
     lib.svdo_update_block_stale.argtypes = [P, C.c_int, C.c_int, _u32p, _f32p, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
     lib.svdo_update_block_stale.restype = C.c_int
+    lib.svdo_set_stale_rounding.argtypes = [P, C.c_int]
+    lib.svdo_set_stale_rounding.restype = None
     lib.svdo_update_block.argtypes = [P, C.c_int, C.c_int, _u32p, _f32p, C.c_int, _f32p, _i32p, _u32p, _f32p]
     lib.svdo_predict_block.argtypes = lib.svdo_update_block.argtypes + [_f32p]
     lib.svdo_get_view.argtypes = [P, C.c_int, _f32p, C.c_long]
@@ -187,6 +189,10 @@ class OracleTrainer:
                                                   dg if dg.size else np.zeros(1, np.float32))
         assert rc == 0, "window-minibatch step: configuration not supported by this checker"
         return delta
+
+    def set_stale_rounding(self, bf16):
+        """checker steps: round row contributions to bfloat16 before summing (the HIP engine's amd:contrib = bf16)"""
+        self.lib.svdo_set_stale_rounding(self.h, 1 if bf16 else 0)
 
     def stale_delta_zero(self):
         """zeroed delta arrays of the window-minibatch checker step for a user-group trainer:

@@ -29,6 +29,7 @@ using namespace apex_svd;
 struct svdo_trainer {
     SVDTypeParam mtype;
     ISVDTrainer *tr;
+    int stale_bf16 = 0;
 };
 
 extern "C" {
@@ -225,6 +226,13 @@ static void load_from_bytes(svdo_trainer *t, std::vector<char> &buf) {
 }
 /* one row: ISVDTrainer::update(elem) -- or, for a user-group trainer, update(MIDDLE block holding that one row) = update_each of the
  * row (apex_svd_base.h:560-565, 568-582) -- then the replicated rows it touched are diffed against the bytes of before and put back */
+static float bf16_round(float x) {
+    union { float f; unsigned u; } v;
+    v.f = x;
+    v.u = ((v.u + 0x7FFFu + ((v.u >> 16) & 1u)) >> 16) << 16;
+    return v.f;
+}
+void svdo_set_stale_rounding(svdo_trainer *t, int bf16) { t->stale_bf16 = bf16 != 0; }
 static int stale_row_ref(svdo_trainer *t, const SVDFeatureCSR::Elem &e, const SVDPlusBlock *as_block, float *dW_item, float *di_bias, float *dg_bias) {
     std::vector<char> before, after;
     view_pos vw, vb, vg;
@@ -238,7 +246,7 @@ static int stale_row_ref(svdo_trainer *t, const SVDFeatureCSR::Elem &e, const SV
         const unsigned iid = e.index_ifactor[i];
         float *a = reinterpret_cast<float *>(after.data() + vw.off) + (size_t)iid * k;
         const float *b = reinterpret_cast<const float *>(before.data() + vw.off) + (size_t)iid * k;
-        for (int j = 0; j < k; j++) { float c = a[j] - b[j]; dW_item[(size_t)iid * k + j] = dW_item[(size_t)iid * k + j] + c; a[j] = b[j]; }
+        for (int j = 0; j < k; j++) { float c = a[j] - b[j]; if (t->stale_bf16) c = bf16_round(c); dW_item[(size_t)iid * k + j] = dW_item[(size_t)iid * k + j] + c; a[j] = b[j]; }
         float *ab = reinterpret_cast<float *>(after.data() + vb.off) + iid;
         const float *bb = reinterpret_cast<const float *>(before.data() + vb.off) + iid;
         float cb = *ab - *bb;
@@ -292,7 +300,7 @@ int svdo_update_block_stale(svdo_trainer *t, int nfb, int extend_tag, const unsi
             const unsigned fid = idx_fb[i];
             float *a = reinterpret_cast<float *>(after.data() + vw.off) + (size_t)fid * k;
             const float *b = reinterpret_cast<const float *>(before.data() + vw.off) + (size_t)fid * k;
-            for (int j = 0; j < k; j++) { float c = a[j] - b[j]; dW_fb[(size_t)fid * k + j] = dW_fb[(size_t)fid * k + j] + c; a[j] = b[j]; }
+            for (int j = 0; j < k; j++) { float c = a[j] - b[j]; if (t->stale_bf16) c = bf16_round(c); dW_fb[(size_t)fid * k + j] = dW_fb[(size_t)fid * k + j] + c; a[j] = b[j]; }
             float *ab = reinterpret_cast<float *>(after.data() + vb.off) + fid;
             const float *bb = reinterpret_cast<const float *>(before.data() + vb.off) + fid;
             float cb = *ab - *bb;

@@ -76,6 +76,7 @@ struct svdo_trainer {
     /* scratch (apex_svd_base.h:85, 486-488) */
     float *tmp_u, *tmp_i, *tmp_fb, *old_fb;
     float norm_fb, tmp_fb_bias, old_fb_bias;
+    int stale_bf16;     /* checker steps only: row contributions rounded to bfloat16 before they are summed (svdo_set_stale_rounding) */
     sparse_feat feat_user, feat_item;
     char name_feat_user[256], name_feat_item[256];
     unsigned sample_counter;
@@ -871,6 +872,14 @@ void svdo_update_csr_batch(svdo_trainer *t, int num_row, const float *row_label,
  * sequential SGD, the replicated side one minibatch step per window: replicated += sum of the deltas of all ranks.
  * Returns 0, or -1 for configurations whose per-instance step has side effects outside those rows (lazy decay, side tables on
  * the item side, user-group trainers). */
+/* `amd:contrib = bf16` of the HIP engine: a row contribution is stored as bfloat16 (round to nearest even) and summed in fp32 */
+static float bf16_round(float x) {
+    union { float f; unsigned u; } v;
+    v.f = x;
+    v.u = ((v.u + 0x7FFFu + ((v.u >> 16) & 1u)) >> 16) << 16;
+    return v.f;
+}
+void svdo_set_stale_rounding(svdo_trainer *t, int bf16) { t->stale_bf16 = bf16 != 0; }
 /* one row of the checker step: update_inner on (current private side, window-start replicated side); the change of the row's item
  * rows / biases and global biases goes to the delta arrays, the rows themselves are put back */
 typedef struct { float *buf; size_t cap; } stale_save;
@@ -893,7 +902,7 @@ static void stale_row(svdo_trainer *t, const elem *e, stale_save *sv, float *dW_
     for (int i = 0; i < e->ni; i++) {   /* an id listed twice: the first entry carries the whole change, the second sees none */
         float *w = t->W_item + (size_t)e->ii[i] * t->pitch, *d = dW_item + (size_t)e->ii[i] * k;
         const float *s = save + (size_t)i * (k + 1);
-        for (int j = 0; j < k; j++) { float c = w[j] - s[j]; d[j] = d[j] + c; w[j] = s[j]; }
+        for (int j = 0; j < k; j++) { float c = w[j] - s[j]; if (t->stale_bf16) c = bf16_round(c); d[j] = d[j] + c; w[j] = s[j]; }
         float cb = t->i_bias[e->ii[i]] - s[k];
         di_bias[e->ii[i]] = di_bias[e->ii[i]] + cb;
         t->i_bias[e->ii[i]] = s[k];
@@ -1053,7 +1062,7 @@ int svdo_update_block_stale(svdo_trainer *t, int nfb, int extend_tag, const unsi
         for (int i = 0; i < nfb; i++) {
             float *w = t->W_ufb + (size_t)idx_fb[i] * t->pitch, *d = dW_fb + (size_t)idx_fb[i] * k;
             const float *s_ = save + (size_t)i * (k + 1);
-            for (int j = 0; j < k; j++) { float c = w[j] - s_[j]; d[j] = d[j] + c; w[j] = s_[j]; }
+            for (int j = 0; j < k; j++) { float c = w[j] - s_[j]; if (t->stale_bf16) c = bf16_round(c); d[j] = d[j] + c; w[j] = s_[j]; }
             float cb = t->ufb_bias[idx_fb[i]] - s_[k];
             dfb_bias[idx_fb[i]] = dfb_bias[idx_fb[i]] + cb;
             t->ufb_bias[idx_fb[i]] = s_[k];

@@ -60,6 +60,8 @@ void svdo_predict_csr_batch(svdo_trainer *t, int num_row, const float *row_label
  * Returns 0, -1 where the configuration is not supported. */
 int svdo_update_csr_batch_stale(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
                                 const unsigned *feat_index, const float *feat_value, float *dW_item, float *di_bias, float *dg_bias);
+/* checker steps: round every ROW contribution to bfloat16 before it is summed (the HIP engine's `amd:contrib = bf16`); bias words stay fp32 */
+void svdo_set_stale_rounding(svdo_trainer *t, int bf16);
 /* the same step for one user-group block (SVDPPFeature::update on the window-start replicated side; svdf_oracle.c) */
 int svdo_update_block_stale(svdo_trainer *t, int nfb, int extend_tag, const unsigned *idx_fb, const float *val_fb,
                             int num_row, const float *row_label, const int *row_ptr, const unsigned *feat_index, const float *feat_value,

@@ -453,6 +453,35 @@ __device__ __forceinline__ void store_row_policy(float *W, size_t row, int pitch
     }
 }
 
+// ---- contribution rows of the window-minibatch step (svdf_k_window.hip, svdf_k_wunit.hip): fp32, or -- opt-in, `amd:contrib = bf16` --
+// bfloat16 (round to nearest even of the fp32 contribution; sums are taken in fp32): a contribution is written once and read once, so
+// half the bytes is half the traffic of both.  The checker applies the same rounding (oracle/svdf_oracle.c: svdo_set_stale_rounding).
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+}
+template <int LPI>
+__device__ __forceinline__ void store_contrib(float *base, int bf16, size_t slot, int pitch, int L, int k, const float4 v) {
+    if (LPI * 4 > k && L * 4 >= k) return;
+    if (bf16) {
+        uint2 pk;
+        pk.x = bf16_rne(v.x) | (bf16_rne(v.y) << 16);
+        pk.y = bf16_rne(v.z) | (bf16_rne(v.w) << 16);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<unsigned short *>(base) + slot * (size_t)pitch + (size_t)L * 4) = pk;
+    } else {
+        *reinterpret_cast<float4 *>(base + slot * (size_t)pitch + (size_t)L * 4) = v;
+    }
+}
+template <int LPI>
+__device__ __forceinline__ float4 load_contrib(const float *base, int bf16, size_t slot, int pitch, int L, int k) {
+    if (LPI * 4 > k && L * 4 >= k) return f4zero();
+    if (bf16) {
+        const uint2 pk = *reinterpret_cast<const uint2 *>(reinterpret_cast<const unsigned short *>(base) + slot * (size_t)pitch + (size_t)L * 4);
+        return make_float4(__uint_as_float(pk.x << 16), __uint_as_float(pk.x & 0xFFFF0000u), __uint_as_float(pk.y << 16), __uint_as_float(pk.y & 0xFFFF0000u));
+    }
+    return *reinterpret_cast<const float4 *>(base + slot * (size_t)pitch + (size_t)L * 4);
+}
+
 // row load / store by row type (float4: one lane group per row; WideRow: the whole wave, VPL slots)
 template <int LPI, typename R> struct row_io;
 template <int LPI> struct row_io<LPI, float4> {

@@ -285,6 +285,10 @@ void Engine::set_param(const char *name, const char *val) {  // apex_svd_base.h:
         multi_step_levels_ = !strcmp(val, "levels");
         step_minibatch_set_ = !strcmp(val, "minibatch");   // one GPU: opt-in window-minibatch SGD (svdf_wunit.cpp: resident data sets become window sequences)
     }
+    if (!strcmp(name, "amd:contrib")) {   // window-minibatch step: storage format of the contribution rows (sums are fp32 either way)
+        check(!strcmp(val, "fp32") || !strcmp(val, "bf16"), "amd:contrib must be fp32 or bf16");
+        contrib_bf16_ = !strcmp(val, "bf16");
+    }
     if (!strcmp(name, "amd:window")) { stage_window_ = std::max<long>(1, atol(val)); window_set_ = true; }
     if (multi_) for (int d = 1; d < gpus_; d++) rank_engine(d)->set_param(name, val);
     if (!strcmp(name, "feature_user")) name_feat_user_ = val;
@@ -2222,7 +2226,7 @@ WindowSchedule Engine::window_view(const Dataset *ds) const {
     const bool pairs = ds->win_item1.p != nullptr && ds->fused.max_ni == 2;
     return WindowSchedule{ds->win_urec.p, ds->num_units, ds->item.p, pairs ? nullptr : ds->label.p, ds->win_slot.p, ds->unit_values ? nullptr : ds->uval.p,
                           (ds->unit_values && !pairs) ? nullptr : ds->ival.p, ds->win_iptr.p, d_contrib_.p, d_cbias_.p,
-                          pairs ? ds->win_item1.p : nullptr, pairs ? ds->win_slot1.p : nullptr, pairs ? ds->win_ival1.p : nullptr};
+                          pairs ? ds->win_item1.p : nullptr, pairs ? ds->win_slot1.p : nullptr, pairs ? ds->win_ival1.p : nullptr, contrib_bf16_ ? 1 : 0};
 }
 Dataset *Engine::dataset_window_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     check(trainer_ready_, "dataset: init_trainer has not been called");

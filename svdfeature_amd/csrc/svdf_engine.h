@@ -510,6 +510,7 @@ class Engine {
     void wunit_sum(Dataset *ds, void *dst, int half);
     // one GPU, `amd:step = minibatch` (opt-in; not the reference's semantics): resident data sets become window sequences (kind 8)
     bool step_minibatch_set_ = false;
+    bool contrib_bf16_ = false;           // "amd:contrib = bf16": contribution rows of the window-minibatch step in bfloat16 (opt-in)
     int wunit_fast_ = 1;                  // knob "wunit_fast": 0 = the general lane-group kernel for every shape (A/B and tests)
     int wseq_per_target_fb_ = 16;         // knob "window_per_target_fb": the same for feedback rows (instance-sized updates pushed by whole blocks)
     int wseq_per_target_ = 24;            // knob "window_per_target": updates a shared row meets per window when amd:window is not given

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_window_users(const DevParams P, const W
             if (act) {   // what the reference would have changed on the item side
                 sub4(wi, q[e]);
                 const long slot = e == 0 ? S.slot[s] : S.slot1[s];
-                store_row<LPI>(S.contrib, (size_t)slot, pitch, L, k, wi);
+                store_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)slot, pitch, L, k, wi);
                 if (L == 0) S.cbias[slot] = nbi - bi[e];
             }
         }
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_window_users_slots(const DevParams P, c
                 }
                 if (act) {
 #pragma unroll
-                    for (int v = 0; v < V; v++) store_row<K / 4>(S.contrib, (size_t)slot[g][e], pitch, m + v * LANES, K, c[v]);
+                    for (int v = 0; v < V; v++) store_contrib<K / 4>(S.contrib, S.contrib_bf16, (size_t)slot[g][e], pitch, m + v * LANES, K, c[v]);
                     S.cbias[slot[g][e]] = nbi - bi[g][e];
                 }
             }
@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const bool in = t + q < e;
-                c[q] = in ? load_row<LPI>(S.contrib, (size_t)(t + q), pitch, L, k) : f4zero();
+                c[q] = in ? load_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)(t + q), pitch, L, k) : f4zero();
                 cb[q] = in ? S.cbias[t + q] : 0.0f;
             }
 #pragma unroll

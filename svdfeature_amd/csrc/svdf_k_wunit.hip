@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256) void k_wunit_walk(const DevParams P, const WUn
                 reg_row<LPI>(P, wi, get_wd(P.i_rng, e.idx, P.wd_item), true, L);
                 nbi = nbi * (1.0f - lr * P.wd_item_bias);
                 sub4(wi, q);
-                store_row<LPI>(S.contrib, (size_t)e.slot, pitch, L, k, wi);
+                store_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)e.slot, pitch, L, k, wi);
                 if (L == 0) S.cbias[e.slot] = nbi - bi;
             }
             if (FB) pp.update(P, err, ti, ub);
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void k_wunit_walk(const DevParams P, const WUn
                 float4 w2 = w;
                 axpy4(w2, d, f.val);
                 sub4(w2, w);
-                store_row<LPI>(S.contrib, (size_t)f.slot, pitch, L, k, w2);
+                store_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)f.slot, pitch, L, k, w2);
                 if (L == 0) {
                     float cb = 0.0f;
                     if (ub) { const float b = P.bias[row]; const float b2 = b + db * f.val; cb = b2 - b; }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void k_wunit_fast(const DevParams P, const WUn
                 axpy4(wi, tu[v], si);
                 reg_chunk(P, wi, wd_i, true);
                 sub4(wi, q[v]);
-                store_row<K / 4>(S.contrib, (size_t)ie.slot, pitch, m + v * LANES, K, wi);
+                store_contrib<K / 4>(S.contrib, S.contrib_bf16, (size_t)ie.slot, pitch, m + v * LANES, K, wi);
             }
             if (m == 0) S.cbias[ie.slot] = nbi - bi;
             if (FB) {   // update_svdpp (:512-520)
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(256) void k_wunit_fast(const DevParams P, const WUn
                             float4 w2 = w[q][v];
                             axpy4(w2, d[v], f[q].val);
                             sub4(w2, w[q][v]);
-                            store_row<K / 4>(S.contrib, (size_t)f[q].slot, pitch, m + v * LANES, K, w2);
+                            store_contrib<K / 4>(S.contrib, S.contrib_bf16, (size_t)f[q].slot, pitch, m + v * LANES, K, w2);
                         }
                         if (m == 0) {
                             float cb = 0.0f;
@@ -405,7 +405,7 @@ __global__ __launch_bounds__(256) void k_wunit_sum(const WUnitSchedule S, float 
 #pragma unroll
             for (int q = 0; q < 8; q++) {
                 const bool in = s + q < e;
-                c[q] = in ? load_row<LPI>(S.contrib, (size_t)(s + q), pitch, L, k) : f4zero();
+                c[q] = in ? load_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)(s + q), pitch, L, k) : f4zero();
                 cb[q] = in ? S.cbias[s + q] : 0.0f;
             }
 #pragma unroll

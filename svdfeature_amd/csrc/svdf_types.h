@@ -192,6 +192,7 @@ struct WindowSchedule {
     const unsigned *item1;
     const int *slot1;
     const float *ival1;
+    int contrib_bf16;           // 1: contribution rows are bfloat16 (amd:contrib = bf16), sums stay fp32
 };
 
 // Window-minibatch data set of USER UNITS (svdf_k_wunit.hip): user-group (SVD++) blocks and rows with global
@@ -221,6 +222,7 @@ struct WUnitSchedule {
     const int *tptr;            // [nfb_rows + nitem_rows + 1]
     const int *gptr;            // [num_global + 1]
     long nfb_rows, nitem_rows, nglobal;
+    int contrib_bf16;           // 1: contribution rows are bfloat16 (amd:contrib = bf16); bias / global-bias contributions stay fp32
 };
 
 }  // namespace svdf

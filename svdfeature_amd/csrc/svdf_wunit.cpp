@@ -41,6 +41,7 @@ WUnitSchedule Engine::wunit_view(const Dataset *ds) const {
     S.contrib = d_contrib_.p; S.cbias = d_cbias_.p; S.gcontrib = d_gcontrib_.p;
     S.tptr = ds->wu_tptr.p; S.gptr = ds->wu_gptr.p;
     S.nfb_rows = user_group() ? (long)num_fb_rows() : 0; S.nitem_rows = mp_.num_item; S.nglobal = mp_.num_global;
+    S.contrib_bf16 = contrib_bf16_ ? 1 : 0;
     return S;
 }
 

@@ -312,6 +312,38 @@ def stratified_plan(user, item, label, rank, world, chunks, num_item, per_item=3
     return plan
 
 
+def stratified_plan_all_ranks(user, item, label, world, chunks, num_item, per_item=32.0, blocks_per_rank=1):
+    """stratified_plan for EVERY rank at once (plans[rank][c][t] = windows): one stable sort of a chunk by (rank, step) instead of
+    world x steps boolean passes over it -- the single-process simulation of N ranks at full size (tools/contract_seeds.py)."""
+    n, P = len(label), int(blocks_per_rank)
+    B = world * P
+    bounds = np.asarray(item_block_bounds(num_item, B), np.int64)
+    plans = [[] for _ in range(world)]
+    for c in range(chunks):
+        lo, hi = (n * c) // chunks, (n * (c + 1)) // chunks
+        u, i, r = user[lo:hi], item[lo:hi], label[lo:hi]
+        rk = (np.asarray(u) % world).astype(np.int64) if world > 1 else np.zeros(hi - lo, np.int64)
+        ib = np.searchsorted(bounds, np.asarray(i, np.int64), side="right") - 1     # item block of every instance
+        step = (ib - rk * P) % B
+        key = rk * B + step
+        order = np.argsort(key, kind="stable")
+        cnt = np.bincount(key, minlength=world * B)
+        off = np.concatenate([[0], np.cumsum(cnt)])
+        su, si, sr = u[order], i[order], r[order]
+        for rank in range(world):
+            steps = []
+            for t in range(B):
+                a, b_ = off[rank * B + t], off[rank * B + t + 1]
+                blk = (rank * P + t) % B
+                nblk = max(int(bounds[blk + 1] - bounds[blk]), 1)
+                m = int(b_ - a)
+                nwin = max(1, int(np.ceil(m / nblk / float(per_item))))
+                cuts = [a + (m * w) // nwin for w in range(nwin + 1)]
+                steps.append([(su[cuts[w]:cuts[w + 1]], si[cuts[w]:cuts[w + 1]], sr[cuts[w]:cuts[w + 1]]) for w in range(nwin)])
+            plans[rank].append(steps)
+    return plans
+
+
 class StratifiedTrainer:
     """STRATIFIED window-minibatch schedule (DSGD-style): no all-reduce.
 

@@ -8,8 +8,13 @@ from svdfeature_amd import BlockArrays, CSRData, pairs_as_csr
 from svdfeature_amd.multi_gpu import Pairs, defer_tails, shard_block_windows, shard_csr_windows, shard_pair_windows, shard_windows
 
 
+CONTRIB_BF16 = False   # tests of `amd:contrib = bf16` set this around simulate*(): the oracles round row contributions to bfloat16
+
+
 def make_oracle(conf, seed=10, fmt=0, active=0):
     t = oracle.OracleTrainer("port", fmt, active)
+    if CONTRIB_BF16:
+        t.set_stale_rounding(True)
     t.seed(seed)
     for k, v in conf:
         t.set_param(k, v)

@@ -219,3 +219,60 @@ def test_malformed_windows_are_refused_with_messages():
         r.dataset_window_from_csr(CSRData.from_rows([(3.0, [], [(1, 1.0), (2, 1.0)], [(2, 1.0)])]))
     with pytest.raises(sa.SvdfError, match="listed twice"):
         r.dataset_window_from_csr(CSRData.from_rows([(3.0, [(1, 0.5), (1, 0.5)], [(1, 1.0)], [(2, 1.0)])]))
+
+
+@pytest.mark.parametrize("shape,k", [("blocks", 128), ("blocks", 24), ("rows", 64), ("triples", 64), ("triples", 40)])
+def test_bf16_contribution_rows_equal_the_oracle_simulation_with_the_same_rounding(shape, k):
+    """`amd:contrib = bf16` (opt-in): contribution rows stored as bfloat16, sums in fp32 -- every kernel that writes or sums contributions
+    (k_window_users / _slots, k_window_items, k_wunit_walk / _fast, k_wunit_sum) against the oracle simulation that rounds the same way"""
+    import multi_rank_utils
+    from svdfeature_amd.multi_gpu import shard_windows
+    import torch
+    dev = torch.device("cuda", 0)
+    world, windows = 2, 3
+    if shape == "blocks":
+        nu, ni = 200, 80
+        data = BlockArrays.from_blocks(cases.user_blocks(260, nu, ni, ni, seed=k, max_rows=12, max_fb=8, split_every=5))
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni) + SVDPP_EXTRA
+        fmt, names = 1, SVDPP_NAMES
+    elif shape == "rows":
+        nu, ni, ng = 400, 100, 30
+        data = _rows_with_globals(8000, nu, ni, ng, 4, seed=k)
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_global=ng, wd_global="0.001")
+        fmt, names = 0, ("W_item", "i_bias", "g_bias", "W_user", "u_bias")
+    else:
+        nu, ni = 900, 200
+        tri = cases.planted_triples(30000, nu, ni, seed=k)
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k)
+        fmt, names = 0, ("W_item", "i_bias", "W_user", "u_bias")
+    ranks = []
+    for rk in range(world):
+        ad = HipShard(_trainer(conf, fmt, 0, [("amd:contrib", "bf16")]), torch, dev, minibatch=True)
+        ad.set_wire_half(False)
+        if shape == "blocks":
+            sh = shard_block_windows(data, rk, world, windows)
+        elif shape == "rows":
+            sh = shard_csr_windows(data, rk, world, windows)
+        else:
+            sh = shard_windows(tri[0], tri[1], tri[2], rk, world, windows)
+        ranks.append((ad, ad.make_windows(sh)))
+    for _ in range(2):
+        for w in range(windows):
+            ds_ = []
+            for ad, wins in ranks:
+                ad.train(wins[w])
+                d = ad.delta_get()
+                ad.stream.synchronize()
+                ds_.append(d.clone())
+            total = ds_[0] + ds_[1]
+            torch.cuda.synchronize()
+            for ad, _ in ranks:
+                ad.delta_set(total)
+    for ad, _ in ranks:
+        ad.t.synchronize()
+    multi_rank_utils.CONTRIB_BF16 = True
+    try:
+        sim = simulate(conf, data, None, None, world, windows, 2, fmt=fmt, minibatch=True) if shape != "triples" else simulate(conf, tri[0], tri[1], tri[2], world, windows, 2, minibatch=True)
+    finally:
+        multi_rank_utils.CONTRIB_BF16 = False
+    _check([ad for ad, _ in ranks], sim, names)

@@ -101,3 +101,30 @@ def test_one_block_per_window_is_the_sequential_reference_on_disjoint_rows():
         np.testing.assert_array_equal(a.view("W_user"), b.view("W_user"))
         for n in before:
             a.set_view(n, b.view(n))
+
+
+@pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference (oracle/_ref) not present")
+def test_bf16_contribution_rounding_of_the_checker_equals_the_same_rounding_over_the_reference():
+    """`amd:contrib = bf16`: row contributions are rounded to bfloat16 (nearest even) before they are summed; the C port and the step
+    driven through the reference's classes apply the same rounding and agree bit for bit; the result differs from the fp32 step and every
+    summed delta of ONE contribution is a bfloat16 number."""
+    nu, ni, ng = 30, 12, 5
+    blocks = _blocks_with_globals(24, nu, ni, ng, seed=9)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=6, num_global=ng, num_ufeedback=ni, wd_global="0.002") + SVDPP_EXTRA
+    got = {}
+    for kind in ("port", "reference", "fp32"):
+        t = _make("port" if kind == "fp32" else kind, conf, 1, 0)
+        if kind != "fp32":
+            t.set_stale_rounding(True)
+        delta = None
+        for b in blocks:
+            delta = t.update_block_stale(b, delta)
+        got[kind] = delta + (t.view("W_user"),)
+    for a, b in zip(got["port"], got["reference"]):
+        np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert not np.array_equal(got["port"][0], got["fp32"][0])
+    np.testing.assert_allclose(got["port"][0], got["fp32"][0], rtol=0, atol=1e-4)
+    one = _make("port", conf, 1, 0)
+    one.set_stale_rounding(True)
+    d1 = one.update_block_stale(blocks[0])
+    assert np.all((d1[3].view(np.uint32) & 0xFFFF) == 0) and np.abs(d1[3]).max() > 0   # feedback rows: one contribution each

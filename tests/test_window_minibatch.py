@@ -266,3 +266,20 @@ def test_rmse_contract_of_the_stratified_schedule(world):
     if world == 8:   # two item blocks per rank (the hand-over hides behind a step of training): same contract
         got2 = cases.rmse(merged_predict(simulate_stratified(conf, u, i, r, world, 4, 5, ni, 32.0, blocks_per_rank=2), world, tu, ti, tr), tr)
         assert abs(got2 - ref) <= 1e-4
+
+
+def test_all_rank_stratified_plan_equals_the_per_rank_plans():
+    from svdfeature_amd.multi_gpu import stratified_plan, stratified_plan_all_ranks
+    u, i, r = cases.planted_triples(20000, 700, 90, seed=5)
+    for world, chunks, P in ((1, 2, 1), (3, 2, 1), (4, 3, 2)):
+        allp = stratified_plan_all_ranks(u, i, r, world, chunks, 90, 7.0, P)
+        for rk in range(world):
+            one = stratified_plan(u, i, r, rk, world, chunks, 90, 7.0, P)
+            assert len(one) == len(allp[rk])
+            for ca, cb in zip(one, allp[rk]):
+                assert len(ca) == len(cb)
+                for sa_, sb in zip(ca, cb):
+                    assert len(sa_) == len(sb)
+                    for wa, wb in zip(sa_, sb):
+                        for x, y in zip(wa, wb):
+                            np.testing.assert_array_equal(x, y)
