@@ -460,7 +460,10 @@ def run_workload(name, a, env, steps, warmup, main_line):
         # updates per item per window that keep the accuracy contract: window-minibatch step 32 at any number of ranks
         # (tools/minibatch_calibration.py: the result does not depend on the rank count); level scheme 64 at 2 ranks, 42 at 3-4, 32
         # beyond for ratings (tools/rmse_contract_fullsize.py); 50 for rank pairs (tests/test_multi_rank.py)
-        tgt = 32.0 if minibatch else (50.0 if name == "pairwise" else (64.0 if world <= 2 else (42.0 if world <= 4 else 32.0)))
+        # rank pairs through the window step: calibrated at the demo learning rate on the full configs[4] stream (profiles/r04_pairs_windows_demo_rate.txt:
+        # 12 windows per pass = 333 updates per item per window cost 3.9e-4 of held-out pair accuracy and 0.02 % of mean margin against the exact pass --
+        # the contract is 3e-3 / 2 % -- and even 3 windows stay inside it); round 3's 32 per window (125 windows) came from a run at ten times that rate
+        tgt = (320.0 if name == "pairwise" else 32.0) if minibatch else (50.0 if name == "pairwise" else (64.0 if world <= 2 else (42.0 if world <= 4 else 32.0)))
         nwin = max(1, int(np.ceil(per_item / tgt)))
         if minibatch and name == "svdpp":
             # user-group blocks: the feedback rows bind -- a block of n rows pushes n |value| instance-sized updates into every row of its

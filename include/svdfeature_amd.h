@@ -224,6 +224,25 @@ int svdf_window_delta_apply(svdf_trainer *t, const void *device_src, int half);
 int svdf_window_delta_apply_local(svdf_trainer *t, svdf_dataset *ds);
 int svdf_item_block_get(svdf_trainer *t, float *device_dst, int64_t *count);
 int svdf_item_block_set(svdf_trainer *t, const float *device_src);
+/* ---- cross-PROCESS direct exchange (svdf_ipc.cpp): one process per GPU, but the exchange of a window runs through
+ * IPC-mapped device buffers -- every rank's wire buffer and flag page mapped into every process (over xGMI on distinct devices) -- with the
+ * peer-pointer reduce-scatter + all-gather kernel of the amd:gpus handle, ordered across processes by sequence flags in device memory
+ * (no collective library, no host rendezvous inside a pass).  The reference has no counterpart (single process).
+ *   svdf_ipc_setup(t, rank, world, wire_bytes, block_floats, handles)   allocate + export; handles = 128 bytes to all-gather
+ *   svdf_ipc_connect(t, all_handles)                                    world x 128 bytes in rank order
+ *   per window: svdf_train_dataset(ds); svdf_ipc_window_pack(t, ds, half); svdf_ipc_window_reduce(t, half); svdf_ipc_window_apply(t, half)
+ *   stratified hand-over: svdf_ipc_block_send(t, dst, slot) stores the active item block (svdf_item_delta_select) into rank dst's inbox;
+ *   svdf_ipc_block_recv(t, src, slot, seq) waits for the seq-th block of rank src, puts it in place and acknowledges the slot.
+ * A wait that hits its spin limit raises an error word instead of hanging the queue: svdf_ipc_status(t) != 0, later calls fail. */
+int svdf_ipc_setup(svdf_trainer *t, int rank, int world, int64_t wire_bytes, int64_t block_floats, unsigned char *handles_out);
+int svdf_ipc_connect(svdf_trainer *t, const unsigned char *all_handles);
+int svdf_ipc_window_pack(svdf_trainer *t, svdf_dataset *ds, int half);
+int svdf_ipc_window_reduce(svdf_trainer *t, int half);
+int svdf_ipc_window_apply(svdf_trainer *t, int half);
+int svdf_ipc_block_send(svdf_trainer *t, int dst_rank, int slot);
+int svdf_ipc_block_recv(svdf_trainer *t, int src_rank, int slot, unsigned seq);
+int svdf_ipc_status(svdf_trainer *t);
+int svdf_ipc_close(svdf_trainer *t);
 
 /* test probe of the device rank sampler's sort (svdf_stdsort.h: libstdc++'s std::sort restated for host and device, because
  * PairwiseRankGenerator::sample_cmp, apex_svd_data.cpp:920-944, picks rows by POSITION after an unstable std::sort): ids 0..n-1

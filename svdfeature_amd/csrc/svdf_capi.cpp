@@ -136,6 +136,15 @@ svdf_dataset *svdf_dataset_window_from_blocks(svdf_trainer *t, long num_block, c
         return h;
     })
 }
+int svdf_ipc_setup(svdf_trainer *t, int rank, int world, int64_t wire_bytes, int64_t block_floats, unsigned char *handles_out) { SVDF_GUARD(-1, { t->e->ipc_setup(rank, world, wire_bytes, block_floats, handles_out); return 0; }) }
+int svdf_ipc_connect(svdf_trainer *t, const unsigned char *all_handles) { SVDF_GUARD(-1, { t->e->ipc_connect(all_handles); return 0; }) }
+int svdf_ipc_window_pack(svdf_trainer *t, svdf_dataset *ds, int half) { SVDF_GUARD(-1, { t->e->ipc_window_pack(ds ? ds->d : nullptr, half); return 0; }) }
+int svdf_ipc_window_reduce(svdf_trainer *t, int half) { SVDF_GUARD(-1, { t->e->ipc_window_reduce(half); return 0; }) }
+int svdf_ipc_window_apply(svdf_trainer *t, int half) { SVDF_GUARD(-1, { t->e->ipc_window_apply(half); return 0; }) }
+int svdf_ipc_block_send(svdf_trainer *t, int dst_rank, int slot) { SVDF_GUARD(-1, { t->e->ipc_block_send(dst_rank, slot); return 0; }) }
+int svdf_ipc_block_recv(svdf_trainer *t, int src_rank, int slot, unsigned seq) { SVDF_GUARD(-1, { t->e->ipc_block_recv(src_rank, slot, seq); return 0; }) }
+int svdf_ipc_status(svdf_trainer *t) { SVDF_GUARD(-1, { return t->e->ipc_status(); }) }
+int svdf_ipc_close(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->ipc_close(); return 0; }) }
 int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *dst, int half, int64_t *count) {
     SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->window_delta_pack(ds ? ds->d : nullptr, dst, half, count); return 0; })
 }

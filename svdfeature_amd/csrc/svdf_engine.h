@@ -173,6 +173,8 @@ struct RankPrefetch;
 struct UserGroupArrays;
 struct MultiState;                                   // svdf_multi.cpp: the other ranks of an "amd:gpus = N" handle
 struct MultiDeleter { void operator()(MultiState *m) const; };
+struct IpcState;                                     // svdf_ipc.cpp: IPC-mapped wire buffers / flag pages of the one-process-per-GPU ranks
+struct IpcDeleter { void operator()(IpcState *s) const; };
 // a user-group buffer file kept in HBM for the device sampler (svdf_k_sample.hip); built once per file, reused every pass
 struct RankSource {
     std::string path;
@@ -295,6 +297,16 @@ class Engine {
     void window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t *count);   // per-item sum of the window's contributions -> wire buffer
     void window_delta_apply(const void *device_src, int half);                           // replicated ranges += wire buffer
     void window_delta_apply_local(Dataset *ds);                 // stratified schedule: the active item block += the window's per-item sums, in place
+    // cross-process direct exchange through IPC-mapped buffers (svdf_ipc.cpp)
+    void ipc_setup(int rank, int world, int64_t wire_bytes, int64_t block_floats, unsigned char *handles_out);
+    void ipc_connect(const unsigned char *all_handles);
+    void ipc_window_pack(Dataset *ds, int half);
+    void ipc_window_reduce(int half);
+    void ipc_window_apply(int half);
+    void ipc_block_send(int dst, int slot);
+    void ipc_block_recv(int src, int slot, unsigned seq);
+    int ipc_status() const;
+    void ipc_close();
     // the same step for user units (svdf_k_wunit.hip): rows with global features / several item entries, user-group (SVD++) blocks
     Dataset *dataset_window_from_csr(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
     Dataset *dataset_window_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
@@ -495,6 +507,8 @@ class Engine {
     // ---- item delta
     DevBuf<float> d_snap_, d_delta_;
     DevBuf<float> d_contrib_, d_cbias_;   // window-minibatch scratch: one contribution row + bias word per instance of the largest window
+    std::unique_ptr<IpcState, IpcDeleter> ipc_;
+    void ipc_check(const char *what);
     DevBuf<float> d_gcontrib_;            // ... and one word per global entry (user-unit windows)
     // user-unit windows (svdf_wunit.cpp)
     WUnitSchedule wunit_view(const Dataset *ds) const;

@@ -177,6 +177,55 @@ void launch_delta_reduce_gather(void *const *bufs, int n, long begin, long end, 
     else hipLaunchKernelGGL(k_delta_reduce_gather<false>, dim3((int)grid), dim3(256), 0, st, B, begin, end);
 }
 
+// ---- cross-PROCESS direct exchange (svdf_ipc.cpp): the ranks' wire buffers and flag pages are IPC-mapped into
+// every process, so the peer-pointer reduce-scatter + all-gather of k_delta_reduce_gather serves one-process-per-GPU runs too.  Events do
+// not order work across processes without a host rendezvous per window (waiting on an event that has not been recorded yet is a no-op), so
+// the ranks meet through SEQUENCE FLAGS in device memory: rank `me` stores `seq` into word (phase, me) of every rank's flag page once its
+// own phase is done (kernel boundary + system-scope fence before the store); a one-wave kernel on the waiting rank polls its own page
+// (system-scope loads, s_sleep between polls, a spin limit that raises *err instead of hanging the queue).
+struct IpcFlags { unsigned *page[16]; int n; };
+__global__ void k_ipc_signal(const IpcFlags F, int phase, int me, unsigned seq) {
+    const int r = threadIdx.x;
+    if (r >= F.n) return;
+    __threadfence_system();
+    __hip_atomic_store(F.page[r] + (phase * 16 + me) * 32, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__global__ void k_ipc_wait(unsigned *page, int phase, int n, unsigned seq, unsigned *err, unsigned long long spin_limit) {
+    const int r = threadIdx.x;
+    if (r < n) {
+        unsigned *f = page + (phase * 16 + r) * 32;
+        unsigned long long spins = 0;
+        while ((int)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - seq) < 0) {
+            if (++spins > spin_limit || __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) {
+                __hip_atomic_store(err, 1u + (unsigned)r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+    __threadfence_system();
+}
+void launch_ipc_signal(unsigned *const *pages, int n, int phase, int me, unsigned seq, hipStream_t st) {
+    IpcFlags F;
+    F.n = n;
+    for (int r = 0; r < 16; r++) F.page[r] = r < n ? pages[r] : nullptr;
+    hipLaunchKernelGGL(k_ipc_signal, dim3(1), dim3(64), 0, st, F, phase, me, seq);
+}
+void launch_ipc_wait(unsigned *page, int phase, int n, unsigned seq, unsigned *err, unsigned long long spin_limit, hipStream_t st) {
+    hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(64), 0, st, page, phase, n, seq, err, spin_limit);
+}
+// a packed block (svdf_item_block_get layout) stored straight into a peer's mapped buffer: the stratified hand-over without a collective
+__global__ __launch_bounds__(256) void k_ipc_copy(float *dst, const float *src, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) dst[j] = src[j];
+}
+void launch_ipc_copy(float *dst, const float *src, long n, hipStream_t st) {
+    if (n <= 0) return;
+    long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(k_ipc_copy, dim3((int)grid), dim3(256), 0, st, dst, src, n);
+}
+
 // row r of dst (rows dst_first + r * dst_stride) <- row r of src (rows src_first + r * src_stride), `width` floats per row: packs the
 // user rows a rank owns (ids = rank mod N) for the hand-over to rank 0 and unpacks them there (svdf_multi.cpp, save_model / get_view)
 __global__ __launch_bounds__(256) void k_rows_strided_copy(float *dst, long dst_first, long dst_stride, const float *src, long src_first, long src_stride,

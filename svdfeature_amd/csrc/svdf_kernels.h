@@ -55,6 +55,10 @@ void launch_ranges_copy(const DeltaRanges &R, float *buf, int set, hipStream_t s
 // the same step for user units: user-group (SVD++) blocks, rows with global features (svdf_k_wunit.hip)
 void launch_wunit_walk(const DevParams &P, const WUnitSchedule &S, bool feedback, int fast, hipStream_t st);
 void launch_wunit_sum(const DevParams &P, const WUnitSchedule &S, void *dst, int half, hipStream_t st);   // dst == nullptr: add to the model in place
+// cross-process direct exchange (svdf_ipc.cpp): sequence flags in IPC-mapped device memory
+void launch_ipc_signal(unsigned *const *pages, int n, int phase, int me, unsigned seq, hipStream_t st);
+void launch_ipc_wait(unsigned *page, int phase, int n, unsigned seq, unsigned *err, unsigned long long spin_limit, hipStream_t st);
+void launch_ipc_copy(float *dst, const float *src, long n, hipStream_t st);
 void launch_window_user_column(const WinUser *urec, int nusers, unsigned *user_out, hipStream_t st);
 void launch_pairs_prepare(long n, const unsigned *pos, const unsigned *neg, unsigned *lo, unsigned *hi, float *vlo, float *vhi, float *ones,
                           unsigned *flag, hipStream_t st);
