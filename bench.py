@@ -415,7 +415,8 @@ def run_workload(name, a, env, steps, warmup, main_line):
     log("%s: synthetic data (%d %s per pass) in %.1fs" % (name, n, unit.split("/")[0], time.time() - t0))
 
     t0 = time.time()
-    contrib = [("amd:contrib", a.contrib)] if a.contrib != "fp32" else []
+    contrib_fmt = a.contrib if a.contrib != "auto" else ("bf16" if world > 1 else "fp32")
+    contrib = [("amd:contrib", contrib_fmt)] if contrib_fmt != "fp32" else []
     tr = make_trainer(sa, name, a, factor, local_rank, extra=contrib)
     if name == "basicmf" and a.groups_per_wave:
         tr.set_knob("groups_per_wave", a.groups_per_wave)
@@ -453,6 +454,8 @@ def run_workload(name, a, env, steps, warmup, main_line):
     stratified = exchanging and name == "basicmf" and (a.exchange == "stratified" or (a.exchange == "auto" and world > 1))
     auto_parts = 1 if world <= 2 else 2
     parts = (a.exchange_parts or auto_parts) if (name == "basicmf" and exchanging) else 1
+    if a.exchange_transport == "ipc":
+        parts = 1   # the IPC exchange is synchronous per window (its reduce runs over all links at once; nothing to hide behind pieces)
     adaptor = HipShard(tr, torch, torch.device("cuda", local_rank), parts=parts, minibatch=minibatch)
     if a.windows > 0:
         nwin = a.windows
@@ -514,11 +517,16 @@ def run_workload(name, a, env, steps, warmup, main_line):
     alg_bytes = sum(w.algorithmic_bytes for w in flat)
     my_n = sum(w.num_row for w in flat)
     log("%s: scheduled %d into %d conflict-free batches (largest %d) in %.1fs" % (name, my_n, n_batches, max(w.max_batch for w in flat), sched_s))
+    use_ipc = a.exchange_transport == "ipc" and world > 1 and minibatch and parts == 1
     if stratified:
         adaptor.set_wire_half(False)
+        if use_ipc:
+            adaptor.ipc_open(dist, rank, world, blocks=world * bpr)
         st = StratifiedTrainer(adaptor, plan, world, rank, dist if world > 1 else None, blocks_per_rank=bpr)
     else:
         st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange, half_delta=(a.delta_dtype == "fp16"), parts=parts)
+        if use_ipc:
+            adaptor.ipc_open(dist, rank, world)
 
     def sync_all():
         tr.synchronize()
@@ -704,6 +712,9 @@ def run_workload(name, a, env, steps, warmup, main_line):
                          "blocks before scoring; no all-reduce" % dist.get_backend()) if (stratified and dist is not None and world > 1) else
                         ("torch.distributed %s all_reduce (RCCL over xGMI)" % dist.get_backend()) if (dist is not None and world > 1) else
                         ("torch.distributed %s all_reduce with one rank (identity)" % dist.get_backend() if dist is not None else "none (one rank)"),
+                "transport": ("ipc: IPC-mapped wire buffers / inboxes, k_delta_reduce_gather + sequence flags (svdf_ipc.cpp); torch.distributed only carries the handles, "
+                              "the final block broadcasts and the timing reductions") if use_ipc else "torch.distributed",
+                "contributions": contrib_fmt if minibatch else None,
                 "step": "stratified" if stratified else ("minibatch" if minibatch else "levels"), "windows": nwin, "parts": parts,
                 "handoffs_per_pass": a.chunks * world * bpr if (stratified and world > 1) else 0,
                 "bytes_per_window": int(tr.item_delta_count() * (2 if a.delta_dtype == "fp16" else 4)) if not stratified else
@@ -748,6 +759,10 @@ def run_workload(name, a, env, steps, warmup, main_line):
                            "what": "40 passes (demo/basicMF num_round) + the one-off schedule build + upload of this run"},
         }
         res.update(quality)
+    if use_ipc:
+        if dist is not None:
+            dist.barrier()   # nobody unmaps while a peer may still read
+        tr.ipc_close()
     for w in flat:
         w.close()
     tr.close()
@@ -1047,7 +1062,7 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
         d_all = cached(synth_neighbourhood, n + 100_000, a.users, a.items, a.globals, 4, 99 + a.data_seed)
         test = d_all.slice_rows(n, n + 100_000)
         d_all = d_all.slice_rows(0, n)
-    extra = [("amd:step", "minibatch")] + ([("amd:contrib", a.contrib)] if getattr(a, "contrib", "fp32") != "fp32" else [])
+    extra = [("amd:step", "minibatch")] + ([("amd:contrib", a.contrib)] if getattr(a, "contrib", "fp32") == "bf16" else [])
     if a.step_window > 0:
         extra.append(("amd:window", str(a.step_window)))
     t0 = time.time()
@@ -1187,8 +1202,9 @@ def main():
                          "depth, so pieces double a rank's launches: 12.9 -> 32.7 ms per pass at 2 ranks, 7.9 -> 10.6 at 4, 5.3 -> 7.7 at 8 "
                          "(tools/shard_parts_probe.sh), which only pays once the exchange it hides is the larger part)")
     ap.add_argument("--stratified-per-item", type=float, default=0.0, help="--exchange stratified: updates per item per window inside a stratum (0 = 16 below 8 ranks, 32 from 8 ranks)")
-    ap.add_argument("--contrib", choices=["fp32", "bf16"], default="fp32",
-                    help="window-minibatch step: storage format of the contribution rows (amd:contrib; bf16 halves their bytes, sums stay fp32; opt-in)")
+    ap.add_argument("--contrib", choices=["auto", "fp32", "bf16"], default="auto",
+                    help="window-minibatch step: storage format of the contribution rows (amd:contrib; sums stay fp32).  auto = bf16 on N > 1 ranks (a contribution is "
+                         "written once and read once: half the bytes; the 3-seed contract is unchanged to 1e-9, profiles/r04_contract_seeds.txt), fp32 otherwise")
     ap.add_argument("--chunks", type=int, default=0,
                     help="--exchange stratified: file-order chunks per pass (a chunk = N sub-epochs; more chunks keep the training order closer to "
                          "the file order: tools/stratified_calibration.py, tools/contract_seeds.py); 0 = 8 below 8 ranks, 4 from 8 ranks")
@@ -1201,6 +1217,10 @@ def main():
                          "exact, item side one minibatch step per window, three launches per window (svdf_k_window.hip), all-reduce per window; levels: the round-2 scheme, "
                          "exact conflict-free levels per rank with the item side stale across ranks only; stratified: no all-reduce -- item blocks are "
                          "owned exclusively and handed from rank to rank (DSGD-style strata, window-minibatch step inside a stratum; ratings only)")
+    ap.add_argument("--exchange-transport", choices=["rccl", "ipc"], default="rccl",
+                    help="N>1: what carries the exchange between the processes.  rccl: torch.distributed collectives / point-to-point (default until a hardware "
+                         "run says otherwise); ipc: every rank's wire buffer and flag page IPC-mapped into every process, peer-pointer reduce-scatter + "
+                         "all-gather kernel and inbox stores ordered by sequence flags in device memory (svdf_ipc.cpp, DESIGN.md section 6i)")
     ap.add_argument("--no-sequential-reference", action="store_true",
                     help="N>1: skip the exact single-GPU run of the same passes on rank 0 that rmse_sequential_reference comes from")
     ap.add_argument("--delta-dtype", choices=["fp16", "fp32"], default="fp16",
@@ -1428,6 +1448,22 @@ def main():
                 keep = ("value", "unit", "ms_per_step", "order", "exchange", "phase_ms", "per_rank_ms", "roofline", "roofline_aggregate", "model_ms",
                         "rmse_test_after_run", "passes_before_rmse", "rmse_sequential_reference", "rmse_minus_sequential")
                 secondary["allreduce_minibatch"] = dict({k: r[k] for k in keep if r.get(k) is not None}, wall_s=round(time.time() - t0, 1), steps=3, warmup=1)
+        # (1b) both steps again with the DIRECT exchange between the processes (IPC-mapped buffers, no collective library on the data path)
+        for key, exch in (("allreduce_minibatch_ipc", "minibatch"), ("stratified_ipc", "stratified")):
+            wd.arm(a.secondary_timeout, "secondary: %s" % key, finish_now)
+            a3 = _ap.Namespace(**vars(a))
+            a3.exchange, a3.no_cpu_baseline, a3.exchange_transport = exch, True, "ipc"
+            t0 = time.time()
+            try:
+                r = run_workload("basicmf", a3, env, 3, 1, False)
+            except Exception as e:
+                import traceback
+                traceback.print_exc()
+                finish_now("%s on rank %d: %r" % (key, rank, e))
+            if r is not None:
+                keep = ("value", "unit", "ms_per_step", "order", "exchange", "phase_ms", "per_rank_ms", "roofline_aggregate", "model_ms",
+                        "rmse_test_after_run", "passes_before_rmse", "rmse_sequential_reference", "rmse_minus_sequential")
+                secondary[key] = dict({k: r[k] for k in keep if r.get(k) is not None}, wall_s=round(time.time() - t0, 1), steps=3, warmup=1)
         # (2) the same algorithm behind ONE C-ABI handle: rank 0 alone drives all N devices from C++ (svdf_multi.cpp), direct peer exchange
         # and RCCL from the engine; the other ranks idle on the host (their GPUs hold no running kernel) until rank 0 says so through the store
         wd.arm(a.secondary_timeout, "secondary: single-process amd:gpus handle", finish_now)

@@ -88,6 +88,15 @@ def load_library():
     lib.svdf_dataset_window_from_csr.argtypes = [P, C.c_long, _f32p, _i64p, _u32p, _f32p]
     lib.svdf_dataset_window_from_blocks.restype = P
     lib.svdf_dataset_window_from_blocks.argtypes = [P, C.c_long, _i32p, _i64p, _u32p, _f32p, _i64p, _f32p, _i64p, _u32p, _f32p]
+    lib.svdf_ipc_setup.argtypes = [P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_char_p]
+    lib.svdf_ipc_connect.argtypes = [P, C.c_char_p]
+    lib.svdf_ipc_window_pack.argtypes = [P, P, C.c_int]
+    lib.svdf_ipc_window_reduce.argtypes = [P, C.c_int]
+    lib.svdf_ipc_window_apply.argtypes = [P, C.c_int]
+    lib.svdf_ipc_block_send.argtypes = [P, C.c_int, C.c_int]
+    lib.svdf_ipc_block_recv.argtypes = [P, C.c_int, C.c_int, C.c_uint]
+    lib.svdf_ipc_status.argtypes = [P]
+    lib.svdf_ipc_close.argtypes = [P]
     lib.svdf_window_delta_pack.argtypes = [P, P, P, C.c_int, C.POINTER(C.c_int64)]
     lib.svdf_window_delta_apply.argtypes = [P, P, C.c_int]
     lib.svdf_window_delta_apply_local.argtypes = [P, P]
@@ -392,6 +401,37 @@ class Trainer:
         if not h:
             raise SvdfError(self.lib.svdf_last_error().decode())
         return Dataset(self, h)
+
+    # -- cross-process direct exchange through IPC-mapped buffers (svdf_ipc.cpp)
+    def ipc_setup(self, rank, world, wire_bytes, block_floats=0):
+        """allocates + exports this rank's wire buffer / flag page; returns the 128 handle bytes to all-gather"""
+        buf = C.create_string_buffer(128)
+        self._ok(self.lib.svdf_ipc_setup(self.h, rank, world, int(wire_bytes), int(block_floats), buf))
+        return buf.raw
+
+    def ipc_connect(self, all_handles):
+        self._ok(self.lib.svdf_ipc_connect(self.h, bytes(all_handles)))
+
+    def ipc_window_pack(self, ds, half=False):
+        self._ok(self.lib.svdf_ipc_window_pack(self.h, ds.h, 1 if half else 0))
+
+    def ipc_window_reduce(self, half=False):
+        self._ok(self.lib.svdf_ipc_window_reduce(self.h, 1 if half else 0))
+
+    def ipc_window_apply(self, half=False):
+        self._ok(self.lib.svdf_ipc_window_apply(self.h, 1 if half else 0))
+
+    def ipc_block_send(self, dst, slot):
+        self._ok(self.lib.svdf_ipc_block_send(self.h, dst, slot))
+
+    def ipc_block_recv(self, src, slot, seq):
+        self._ok(self.lib.svdf_ipc_block_recv(self.h, src, slot, seq))
+
+    def ipc_status(self):
+        return int(self.lib.svdf_ipc_status(self.h))
+
+    def ipc_close(self):
+        self._ok(self.lib.svdf_ipc_close(self.h))
 
     def window_delta_pack(self, ds, device_ptr, half=False):
         """Sum of the trained window's item-side contributions into the wire buffer at device_ptr; returns its element count."""

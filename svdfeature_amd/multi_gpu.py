@@ -291,6 +291,14 @@ class ShardedTrainer:
                 mark("pack")
             self.a.train(w)
             mark("compute")
+            if getattr(self.a, "ipc_ready", False):   # direct exchange through IPC-mapped buffers: no collective library (svdf_ipc.cpp)
+                self.a.ipc_pack()
+                mark("pack")
+                self.a.ipc_reduce()
+                mark("allreduce")
+                self.a.ipc_apply()
+                mark("unpack")
+                continue
             d = self.a.delta_get()
             mark("pack")
             self._reduce(d)   # SUM over ranks, in place
@@ -372,7 +380,7 @@ class StratifiedTrainer:
         if b in self.pending:
             handle, inc = self.pending.pop(b)
             self.a.handoff_wait(handle)
-            self.a.block_set(b, self.world * self.P, inc)
+            self.a.block_set(b, self.world * self.P, handle if (isinstance(handle, tuple) and handle[0] == "ipc-recv") else inc)
 
     def train_pass(self, mark=None):
         mark = mark or (lambda phase: None)
@@ -390,8 +398,9 @@ class StratifiedTrainer:
                     mark("pack")
                 if N > 1:
                     nxt = (b + P) % B
-                    out = a.block_get(b, B)
-                    inc = a.block_like(nxt, B)
+                    ipc = getattr(a, "ipc_ready", False)
+                    out = a.block_get(b, B, True) if ipc else a.block_get(b, B)
+                    inc = a.block_like(nxt, B, True) if ipc else a.block_like(nxt, B)
                     self.pending[nxt] = (a.handoff_start(self.dist, out, (self.rank - 1) % N, inc, (self.rank + 1) % N), inc)
                     mark("pack")
         for b in list(self.pending):   # the home blocks come back at the end of a chunk: have them in place between passes
@@ -487,7 +496,9 @@ class HipShard:
         self.t.window_delta_apply_local(ds)
         self.t.item_delta_select(0, 1)
 
-    def block_like(self, block, nblocks):
+    def block_like(self, block, nblocks, for_handoff=False):
+        if self.ipc_ready and for_handoff:
+            return ("ipc-in", block, nblocks)
         self.t.item_delta_select(block, nblocks)
         n = self.t.item_block_count()
         self.t.item_delta_select(0, 1)
@@ -497,7 +508,9 @@ class HipShard:
                 self.bufs[key] = self.torch.empty(n, device=self.device, dtype=self.torch.float32)
         return self.bufs[key]
 
-    def block_get(self, block, nblocks):
+    def block_get(self, block, nblocks, for_handoff=False):
+        if self.ipc_ready and for_handoff:
+            return ("ipc-out", block, nblocks)   # the block is stored straight into the neighbour's inbox by handoff_start
         self.t.item_delta_select(block, nblocks)
         n = self.t.item_block_count()
         key = ("out", block, nblocks)
@@ -510,16 +523,30 @@ class HipShard:
 
     def block_set(self, block, nblocks, tensor):
         self.t.item_delta_select(block, nblocks)
-        self.t.item_block_set(tensor.data_ptr())
+        if isinstance(tensor, tuple) and tensor[0] == "ipc-recv":   # wait for the neighbour's store, put the block in place, acknowledge the slot
+            _, src, slot, seq = tensor
+            self.t.ipc_block_recv(src, slot, seq)
+        else:
+            self.t.item_block_set(tensor.data_ptr())
         self.t.item_delta_select(0, 1)
 
     def handoff_start(self, dist, out, dst, inc, src):
         """start sending `out` to rank dst and receiving `inc` from rank src: ordered after the copy-out kernel on the trainer's stream,
         running beside whatever the trainer enqueues next"""
+        if self.ipc_ready:
+            _, block, nblocks = out
+            self.t.item_delta_select(block, nblocks)
+            self.t.ipc_block_send(dst, self.ipc_sent % 2)
+            self.t.item_delta_select(0, 1)
+            self.ipc_sent += 1
+            self.ipc_received += 1
+            return ("ipc-recv", src, (self.ipc_received - 1) % 2, self.ipc_received)
         with self.torch.cuda.stream(self.stream):
             return dist.batch_isend_irecv([dist.P2POp(dist.isend, out, dst), dist.P2POp(dist.irecv, inc, src)])
 
     def handoff_wait(self, reqs):
+        if self.ipc_ready:
+            return   # block_set does the waiting, on the stream
         with self.torch.cuda.stream(self.stream):   # the trainer's stream waits for the transfer; the host does not
             for q in reqs:
                 q.wait()
@@ -527,6 +554,37 @@ class HipShard:
     def broadcast(self, dist, buf, src):
         with self.torch.cuda.stream(self.stream):
             dist.broadcast(buf, src)
+
+    # ---- cross-process direct exchange (svdf_ipc.cpp): wire buffers / flag pages IPC-mapped into every rank's process
+    ipc_ready = False
+
+    def ipc_open(self, dist, rank, world, blocks=0):
+        """every rank exports its wire buffer + flag page, the handles travel through the process group (all_gather_object), every rank
+        maps the others'.  blocks > 0: also an inbox for the stratified schedule's item blocks (num_item / blocks rows each)."""
+        assert self.minibatch, "the IPC exchange serves the window-minibatch step"
+        n = self.t.item_delta_count()
+        block_floats = 0
+        if blocks > 0:
+            for b in range(blocks):
+                self.t.item_delta_select(b, blocks)
+                block_floats = max(block_floats, self.t.item_block_count())
+            self.t.item_delta_select(0, 1)
+        mine = self.t.ipc_setup(rank, world, n * 4, block_floats)
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        self.t.ipc_connect(b"".join(gathered))
+        dist.barrier()   # nobody signals into a page that is not mapped yet
+        self.ipc_ready, self.ipc_rank, self.ipc_world = True, rank, world
+        self.ipc_sent, self.ipc_received = 0, 0
+
+    def ipc_pack(self):
+        self.t.ipc_window_pack(self.last, self.half)
+
+    def ipc_reduce(self):
+        self.t.ipc_window_reduce(self.half)
+
+    def ipc_apply(self):
+        self.t.ipc_window_apply(self.half)
 
     def delta_begin(self):
         if not self.minibatch:

@@ -50,6 +50,12 @@ def test_two_ranks_one_command_yields_every_multi_gpu_number():
     ar = line["secondary"]["allreduce_minibatch"]
     assert ar["exchange"]["step"] == "minibatch" and ar["value"] > 0 and abs(ar["rmse_minus_sequential"]) <= 1e-4
     assert set(("compute", "pack", "allreduce", "unpack")) <= set(ar["phase_ms"])
+    # the same two steps with the direct exchange between the processes (IPC-mapped buffers; on this box the ranks share the device)
+    for key, step in (("allreduce_minibatch_ipc", "minibatch"), ("stratified_ipc", "stratified")):
+        ip = line["secondary"][key]
+        assert ip["exchange"]["step"] == step and ip["exchange"]["transport"].startswith("ipc") and ip["value"] > 0
+        assert abs(ip["rmse_minus_sequential"]) <= 1e-4
+    assert x["contributions"] == "bf16"
     # one C-ABI handle over both (here: virtual) ranks: the peer-pointer exchange runs; RCCL refuses ranks that share a device, and says so
     sp = line["secondary"]["single_process_handle"]
     assert sp["p2p"]["value"] > 0 and sp["p2p"]["exchange_path"] == "p2p" and sp["p2p"]["exchanges"] > 0
