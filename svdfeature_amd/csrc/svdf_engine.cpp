@@ -2035,6 +2035,7 @@ Dataset *Engine::dataset_fewrow_on_device(long n, const float *row_label, const 
     adopt(ds.get()); ds->num_row = n; ds->kind = 2;
     FusedDev &f = ds->fused;
     f.max_nu = mu; f.max_ni = mi; f.has_g = true; f.inline_g = true;
+    f.dense_slots = mu == 1 && mi == 1 && has_item.load() && has_user.load();
     const int zero = 0;
     f.gptr.upload(&zero, 1, stream_);   // non-null marks "has global features"; the ids themselves sit in the inline slots
     std::vector<UCol> uc;
@@ -2450,8 +2451,12 @@ void Engine::train_dataset(Dataset *ds) {
                 launch_imfb(P, D, d.units.p, d.blks.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_ptr[l], sc.level_ptr[l + 1], sample_counter_, nullptr, stream_);
         } else if (ds->kind == 2) {
             const FusedSchedule S = ds->fused.view();
-            for (size_t l = 0; l < sc.num_levels(); l++)
-                launch_fused(P, S, ds->fused.max_nu, ds->fused.max_ni, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
+            if (fewrow_gslots_ && fewrow_fast_ && fewrow_gslots_applies(P, S, ds->fused.max_nu, ds->fused.max_ni, ds->fused.dense_slots)) {
+                for (size_t l = 0; l < sc.num_levels(); l++) launch_fewrow_gslots(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], stream_);
+            } else {
+                for (size_t l = 0; l < sc.num_levels(); l++)
+                    launch_fused(P, S, ds->fused.max_nu, ds->fused.max_ni, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
+            }
         } else {
             DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
             for (size_t l = 0; l < sc.num_levels(); l++) launch_general(P, D, ds->order.p, sc.level_ptr[l], sc.level_ptr[l + 1], sample_counter_, stream_);
@@ -2883,6 +2888,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "device_schedule_min")) { check(value >= 1, "device_schedule_min must be >= 1"); device_sched_min_ = value; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "rows_without_feedback")) { rows_without_feedback_ = value != 0; return 0; }
+    if (!strcmp(name, "fewrow_gslots")) { fewrow_gslots_ = value != 0; launch_version_++; return 0; }
     if (!strcmp(name, "wunit_fast")) { wunit_fast_ = value != 0; return 0; }
     if (!strcmp(name, "window_per_target_fb")) { check(value >= 1, "window_per_target_fb must be positive"); wseq_per_target_fb_ = (int)value; return 0; }
     if (!strcmp(name, "window_per_target")) { check(value >= 1, "window_per_target must be positive"); wseq_per_target_ = (int)value; return 0; }

@@ -109,6 +109,7 @@ struct FusedDev {
     DevBuf<int> gptr;
     int max_nu = 1, max_ni = 1;
     bool has_g = false, inline_g = false;
+    bool dense_slots = false;   // every instance has exactly one user id and one item id (k_fewrow_gslots reads slot 0 without an absent test)
     void upload(const FusedHost &h, hipStream_t st);
     FusedSchedule view() const;
 };
@@ -525,6 +526,7 @@ class Engine {
     // one GPU, `amd:step = minibatch` (opt-in; not the reference's semantics): resident data sets become window sequences (kind 8)
     bool step_minibatch_set_ = false;
     bool contrib_bf16_ = false;           // "amd:contrib = bf16": contribution rows of the window-minibatch step in bfloat16 (opt-in)
+    int fewrow_gslots_ = 1;               // knob "fewrow_gslots": 0 = k_fused for few-row data sets with inline global slots (A/B)
     int wunit_fast_ = 1;                  // knob "wunit_fast": 0 = the general lane-group kernel for every shape (A/B and tests)
     int wseq_per_target_fb_ = 16;         // knob "window_per_target_fb": the same for feedback rows (instance-sized updates pushed by whole blocks)
     int wseq_per_target_ = 24;            // knob "window_per_target": updates a shared row meets per window when amd:window is not given

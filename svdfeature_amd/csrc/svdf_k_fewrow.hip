@@ -204,6 +204,93 @@ __global__ __launch_bounds__(256) void k_fewrow_slots(const DevParams P, const F
     }
 }
 
+// ---- one user id, one item id, up to four INLINE global slots (the neighbourhood shape of BASELINE configs[3]: FusedSchedule::gsi / gsv),
+// the usual configuration of fewrow_fast_applies plus reg_global 0 / 1 through reg_gbias.  A level of this shape is ~280 instances: the
+// launch is pure latency, and k_fused's generality (two row slots each side, CSR and inline global paths, relaxed ids, range lookups, per-row
+// regulariser switch: ~12 KB of ISA, 754 instruction-cache misses per launch on ~140 CUs, profiles/r03_pmc_neighbourhood_detail.txt) is
+// paid on every one of 14 211 levels.  Same arithmetic, same order, same bits: 16 lanes x 2 chunks per row at k = 128 (8 x 2 at k = 64),
+// the global biases' update + decay id by id (distinct ids: apex_svd_base.h:384-387, 288-292).
+template <int LANES, int V>
+__global__ __launch_bounds__(256) void k_fewrow_gslots(const DevParams P, const FusedSchedule S, long begin, long end) {
+    constexpr int T = 16 / LANES, IPW = 64 / LANES, K = 4 * LANES * V, GR = 4;
+    const int lane = threadIdx.x & 63;
+    const int m = (lane & 15) / T;
+    const int gslot = (lane >> 4) * T + (lane & (T - 1));
+    const long wave = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long s = begin + wave * (long)IPW + gslot;
+    if (begin + wave * (long)IPW >= end) return;
+    const bool valid = s < end;
+    const long sc = valid ? s : begin;
+    const int pitch = P.pitch;
+    const bool use_ubias = P.no_user_bias == 0;
+    const float label = S.label[sc];
+    const unsigned ur = P.user_off + S.uidx[0][sc], ir = P.item_off + S.iidx[0][sc];
+    const float ua = S.uval[0][sc], ia = S.ival[0][sc];
+    unsigned gid[GR];
+    float gv[GR], gb[GR];
+    bool gon[GR];
+#pragma unroll
+    for (int j = 0; j < GR; j++) { gid[j] = S.gsi[j][sc]; gv[j] = S.gsv[j][sc]; gon[j] = gid[j] != SLOT_ABSENT; }
+    float4 p[V], q[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) { p[v] = load_row_nt<K / 4>(P.W, ur, pitch, m + v * LANES, K); q[v] = load_row_nt<K / 4>(P.W, ir, pitch, m + v * LANES, K); }
+    const float bu = use_ubias ? P.bias[ur] : 0.0f, bi = P.bias[ir];
+#pragma unroll
+    for (int j = 0; j < GR; j++) gb[j] = gon[j] ? P.g_bias[gid[j]] : 0.0f;
+    const float dec_u = snap_to_one(1.0f - P.lr * P.wd_user), dec_i = snap_to_one(1.0f - P.lr * P.wd_item);
+    const float dec_ub = 1.0f - P.lr * P.wd_user_bias, dec_ib = 1.0f - P.lr * P.wd_item_bias;
+    double bs = 0.0;
+#pragma unroll
+    for (int j = 0; j < GR; j++) if (gon[j]) bs += (double)(gv[j] * gb[j]);
+    if (use_ubias) bs += (double)(ua * bu);
+    bs += (double)(ia * bi);
+    double sum = (double)P.base_score + bs;
+    float4 tu[V], ti[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) { tu[v] = f4zero(); ti[v] = f4zero(); axpy4(tu[v], p[v], ua); axpy4(ti[v], q[v], ia); }
+    sum += (double)dot_slots<LANES, V>(tu, ti, m, lane);
+    const float pred = map_active((float)sum, P.active_type);
+    const float err = cal_grad(label, pred, P.active_type) * 1.0f;
+    const float lr = P.lr;
+    if (!valid) return;
+#pragma unroll
+    for (int j = 0; j < GR; j++) if (gon[j] && m == 0) P.g_bias[gid[j]] = reg_gbias(P, gid[j], gb[j] + lr * err * gv[j]);
+    const float su = lr * err * ua, si = lr * err * ia;
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        float4 w = p[v];
+        axpy4(w, ti[v], su);
+        w.x = w.x * dec_u; w.y = w.y * dec_u; w.z = w.z * dec_u; w.w = w.w * dec_u;
+        store_row<K / 4>(P.W, ur, pitch, m + v * LANES, K, w);
+        float4 x = q[v];
+        axpy4(x, tu[v], si);
+        x.x = x.x * dec_i; x.y = x.y * dec_i; x.z = x.z * dec_i; x.w = x.w * dec_i;
+        store_row<K / 4>(P.W, ir, pitch, m + v * LANES, K, x);
+    }
+    if (m == 0) {
+        if (use_ubias) P.bias[ur] = (bu + su) * dec_ub;
+        P.bias[ir] = (bi + si) * dec_ib;
+    }
+}
+// data sets this kernel is specialised for: inline global slots, one user id and one item id in EVERY instance (no absent slot), the
+// configuration of fewrow_fast_applies on the factor side, no lazy / ranged decay of the global biases, full rows of 64 / 128 factors
+bool fewrow_gslots_applies(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, bool dense_slots) {
+    return S.gsi[0] != nullptr && dense_slots && max_nu == 1 && max_ni == 1 && !P.relax_global && P.relax_user_from == 0xFFFFFFFFu &&
+           P.relax_item_from == 0xFFFFFFFFu && P.reg_method == 0 && P.reg_global < 4 && P.u_rng.n == 0 && P.i_rng.n == 0 && P.user_nonnegative == 0 &&
+           P.g_stride == 1 && (P.k == 64 || P.k == 128);
+}
+void launch_fewrow_gslots(const DevParams &P, const FusedSchedule &S, long begin, long end, hipStream_t st) {
+    if (end <= begin) return;
+    const long n = end - begin;
+    if (P.k == 128) {
+        const int grid = (int)((n + 3) / 4);
+        hipLaunchKernelGGL((k_fewrow_gslots<16, 2>), dim3(grid), dim3(64), 0, st, P, S, begin, end);
+    } else {
+        const int grid = (int)((n + 7) / 8);
+        hipLaunchKernelGGL((k_fewrow_gslots<8, 2>), dim3(grid), dim3(64), 0, st, P, S, begin, end);
+    }
+}
+
 template <int LANES, int V, int NU, int NI>
 static void launch_fewrow_slots_shape(const DevParams &P, const FusedSchedule &S, long begin, long end, int block_threads, hipStream_t st) {
     const long n = end - begin;

@@ -23,6 +23,8 @@ void launch_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int ma
                   int block_threads, hipStream_t st);
 // the same step specialised for data sets without global features under L2 decay without ranges / relaxed ids (svdf_k_fewrow.hip)
 bool fewrow_fast_applies(const DevParams &P, const FusedSchedule &S);
+bool fewrow_gslots_applies(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, bool dense_slots);
+void launch_fewrow_gslots(const DevParams &P, const FusedSchedule &S, long begin, long end, hipStream_t st);
 void launch_fewrow_fast(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int block_threads, hipStream_t st);
 void launch_predict_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long n, float *out, hipStream_t st);
 // counter_base: the reference's sample_counter at the first instance of D (row r runs with counter_base + r); only the

@@ -213,3 +213,36 @@ def test_device_schedule_few_row_shape_limits_fall_back_to_the_host_scheduler():
         for name in ("W_user", "W_item", "u_bias", "i_bias", "g_bias"):
             assert np.array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32)), name
         assert np.array_equal(t.predict_dataset(ds).view(np.uint32), o.predict_batch(d).view(np.uint32))
+
+
+@pytest.mark.parametrize("k,active,extra", [(128, 0, ()), (64, 0, ()), (128, 2, (("base_score", "0.5"),)), (64, 0, (("reg_global", "1"), ("num_regfree_global", "3"))),
+                                            (128, 0, (("no_user_bias", "1"),))])
+def test_specialised_kernel_for_inline_global_slots_equals_k_fused_and_the_oracle(k, active, extra):
+    """k_fewrow_gslots (one user id, one item id, up to four inline global ids; k = 64 / 128) against k_fused (knob fewrow_gslots = 0) and
+    the oracle: identical bytes.  Rows with 0..4 global entries, so absent inline slots are exercised too."""
+    rng = np.random.default_rng(k + active)
+    nu, ni, ng, n = 900, 150, 40, 20000
+    rows = []
+    for _ in range(n):
+        g = sorted(int(x) for x in rng.choice(ng, size=int(rng.integers(0, 5)), replace=False))
+        rows.append((float(rng.integers(0, 2)) if active == 2 else float(rng.integers(1, 6)), [(x, float(rng.uniform(0.1, 1.0))) for x in g],
+                     [(int(rng.integers(0, nu)), float(rng.choice([1.0, 0.5])))], [(int(rng.integers(0, ni)), 1.0)]))
+    d = sa.CSRData.from_rows(rows)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=k, wd_global=0.004) + [(a, b) for a, b in extra]
+    fast, slow = _ready(0, active, conf, 1, 1), _ready(0, active, conf, 1, 1)
+    slow.set_knob("fewrow_gslots", 0)
+    df, dsl = fast.dataset_from_csr(d), slow.dataset_from_csr(d)
+    assert df.kind == 2 and dsl.kind == 2
+    o = oracle.OracleTrainer("port", 0, active)
+    o.seed(10)
+    for kk, v in conf:
+        o.set_param(kk, v)
+    o.init_model()
+    o.init_trainer()
+    for _ in range(2):
+        fast.train_dataset(df)
+        slow.train_dataset(dsl)
+        o.update_batch(d)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "g_bias"):
+        assert np.array_equal(fast.view(name).view(np.uint32), slow.view(name).view(np.uint32)), name
+        assert np.array_equal(fast.view(name).view(np.uint32), o.view(name).view(np.uint32)), name
