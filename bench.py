@@ -187,7 +187,7 @@ WORKLOADS = {
     "basicmf": (0, 0, 64, "k_basicmf_slots<8,2,4> at k=64 (8 lanes per row x 2 chunks, 4 row sets = 32 instances per wave), k_basicmf<k/4,G,...> at other widths", "instances/s"),
     "pairwise": (0, 3, 128, "k_fewrow_slots<16,2,1,2> (few-row kernel, 3 rows per pair, 16 lanes x 2 chunks per row)", "pairs/s"),
     "svdpp": (1, 0, 128, "k_svdpp_wave<2,true,true,true,false,8> (one wave per user for the row recurrence + 7 helper waves for the feedback phases)", "instances/s"),
-    "neighbourhood": (0, 0, 128, "k_fused<32,1,1,1,true,false> (few-row fused kernel, inline global slots)", "instances/s"),
+    "neighbourhood": (0, 0, 128, "k_fewrow_gslots<16,2> (few-row kernel stripped for one user id + one item id + up to 4 inline global slots; k_fused<32,1,1,1,...> with knob fewrow_gslots=0)", "instances/s"),
 }
 
 
@@ -205,7 +205,7 @@ def workload_conf(name, a, factor):
     raise ValueError(name)
 
 
-PMC_KERNEL = {"basicmf": "k_basicmf", "pairwise": "k_fewrow", "svdpp": "k_svdpp_wave", "neighbourhood": "k_fused"}
+PMC_KERNEL = {"basicmf": "k_basicmf", "pairwise": "k_fewrow_slots", "svdpp": "k_svdpp_wave", "neighbourhood": "k_fewrow_gslots"}
 
 
 def ranker_roofline(matrix_bytes, cand, dt, nsec, tiles, top_k, tile_traffic):
