@@ -1112,6 +1112,10 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
     rm_run = score(tw)
     os.remove(path)
     alg = ds.algorithmic_bytes
+    try:
+        wtraffic = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json"))).get(name + "_window_step", {}).get("hbm_bytes_per_launch")
+    except Exception:
+        wtraffic = None
     res = {"value": steps * n / elapsed, "unit": "instances/s", "ms_per_step": elapsed * 1e3 / steps, "steps": steps, "warmup": warmup,
            "windows_per_pass": ds.num_batches, "launches_per_pass": launches / steps, "build_s": round(build_s, 2),
            "semantics": "OPT-IN amd:step = minibatch: window-minibatch SGD (user units exact, shared rows applied at the window's end, deterministic), NOT the reference's "
@@ -1120,7 +1124,8 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
            "roofline": {"bound": "hbm", "achieved": alg * steps / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": alg * steps / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "k_wunit_walk<32,%s> + k_wunit_sum<32,false,true> (two launches per window)" % ("true" if name == "svdpp" else "false"),
                         "launches": launches, "avg_launch_us": ev_ms * 1e3 / max(launches, 1), "algorithmic_bytes_per_launch": alg * steps / max(launches, 1),
-                        "algorithmic_bytes_per_instance": alg / max(n, 1), "traffic": None}}
+                        "algorithmic_bytes_per_instance": alg / max(n, 1), "traffic": wtraffic,
+                        "traffic_source": "profiles/hbm_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 of k_wunit_fast + k_wunit_sum per window / 2 launches (builder's rocprofv3 PMC passes, tools/profile_round4.sh)"}}
     log("%s window step: %.2f ms per pass = %.1f M inst/s (%.1f%% of peak), %d windows, rmse %.6f vs sequential %.6f (%+.2e)" % (
         name, res["ms_per_step"], res["value"] / 1e6, 100 * res["roofline"]["frac"], ds.num_batches, rm_run, rm_seq, rm_run - rm_seq))
     for x in (ds, dsq):
