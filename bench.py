@@ -415,7 +415,11 @@ def run_workload(name, a, env, steps, warmup, main_line):
     log("%s: synthetic data (%d %s per pass) in %.1fs" % (name, n, unit.split("/")[0], time.time() - t0))
 
     t0 = time.time()
-    contrib_fmt = a.contrib if a.contrib != "auto" else ("bf16" if world > 1 else "fp32")
+    # auto: bf16 where it pays -- the all-reduce step at any N (one rank's share 2.98 -> 2.66 ms at N = 8, 22.1 -> 16.0 ms at full size) and the stratified
+    # schedule's large windows at 2 ranks (11.4 -> 9.8 ms); its small windows at 4 / 8 ranks are launch-latency bound and run 0 ... 18 % SLOWER with
+    # 8-byte row pieces (profiles/r04_shard_scale_probe.txt), so they stay fp32.  The 3-seed contract is the same either way (to 1e-9).
+    strat_default = name == "basicmf" and a.exchange in ("auto", "stratified") and world > 1
+    contrib_fmt = a.contrib if a.contrib != "auto" else ("fp32" if world == 1 or (strat_default and world > 2) else "bf16")
     contrib = [("amd:contrib", contrib_fmt)] if contrib_fmt != "fp32" else []
     tr = make_trainer(sa, name, a, factor, local_rank, extra=contrib)
     if name == "basicmf" and a.groups_per_wave:
@@ -1030,7 +1034,7 @@ def model_ms(name, world, exchange_step, n, items, factor, nwin, blocks, handoff
     stratified: `handoffs` point-to-point transfers per rank and pass of one item block (NI / blocks rows, fp32) over one xGMI link,
     bytes / 64 GB/s + 25 us each -- hidden behind the next step's training at 2 blocks per rank (lower figure), serial at 1 (upper)."""
     contract = name == "basicmf" and n == 100_000_000 and items == 100_000 and factor == 64
-    table = {"minibatch": {2: 10.76, 4: 5.50, 8: 2.98}, "stratified": {2: 9.63, 4: 4.95, 8: 2.66}}
+    table = {"minibatch": {2: 8.26, 4: 4.26, 8: 2.66}, "stratified": {2: 9.78, 4: 5.92, 8: 2.71}}   # round-4 defaults, profiles/r04_shard_scale_probe.txt
     share = table.get(exchange_step, {}).get(world) if contract else None
     src = "compute share: one rank's share measured on one GPU (DESIGN.md 6c / 6f)"
     if share is None:

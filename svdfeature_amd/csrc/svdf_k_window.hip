@@ -318,20 +318,8 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
         const int b = S.iptr[i], e = S.iptr[i + 1];
         float4 acc = f4zero();
         float accb = 0.0f;
-        // eight rows requested at a time; slots past the segment's end feed +0.0f, which leaves the running sum unchanged bit for bit
-        // (the sum starts at +0.0f and x + y is -0 only when both are, so acc is never -0)
-        for (int t = b; t < e; t += 8) {
-            float4 c[8];
-            float cb[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const bool in = t + q < e;
-                c[q] = in ? load_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)(t + q), pitch, L, k) : f4zero();
-                cb[q] = in ? S.cbias[t + q] : 0.0f;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; q++) { add_rows(acc, c[q]); accb = accb + cb[q]; }
-        }
+        if (S.contrib_bf16) sum_contrib_slots<LPI, true>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
+        else sum_contrib_slots<LPI, false>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
         if (LOCAL) {
             if (b == e) continue;   // nobody rated the item in this window
             if (!(LPI * 4 > k && L * 4 >= k)) {

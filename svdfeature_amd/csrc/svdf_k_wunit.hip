@@ -399,18 +399,8 @@ __global__ __launch_bounds__(256) void k_wunit_sum(const WUnitSchedule S, float 
         if (LOCAL && b == e) continue;
         float4 acc = f4zero();
         float accb = 0.0f;
-        for (int s = b; s < e; s += 8) {
-            float4 c[8];
-            float cb[8];
-#pragma unroll
-            for (int q = 0; q < 8; q++) {
-                const bool in = s + q < e;
-                c[q] = in ? load_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)(s + q), pitch, L, k) : f4zero();
-                cb[q] = in ? S.cbias[s + q] : 0.0f;
-            }
-#pragma unroll
-            for (int q = 0; q < 8; q++) { add_rows(acc, c[q]); accb = accb + cb[q]; }
-        }
+        if (S.contrib_bf16) sum_contrib_slots<LPI, true>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
+        else sum_contrib_slots<LPI, false>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
         const bool owns = !(LPI * 4 > k && L * 4 >= k);
         if (LOCAL) {
             const size_t row = t < S.nfb_rows ? (size_t)fb_off + (size_t)t : (size_t)item_off + (size_t)(t - S.nfb_rows);

@@ -70,10 +70,10 @@ def test_watchdog_fires_only_when_armed_and_late():
 def test_model_figures_of_the_line():
     # ring all-reduce of 13 MB at 8 ranks ~ 0.18 ms per window, 32 windows; 6c share 2.98 ms
     m = bench.model_ms("basicmf", 8, "minibatch", 100_000_000, 100_000, 64, 32, 1, 0, 23.5)
-    assert m["compute_share_ms"] == 2.98 and 0.17 < m["allreduce_ms_per_window"] < 0.19 and 8.5 < m["total_ms"] < 9.0
+    assert m["compute_share_ms"] == 2.66 and 0.17 < m["allreduce_ms_per_window"] < 0.19 and 8.2 < m["total_ms"] < 8.7
     # 6f: 64 hand-overs of 1.6 MB, hidden .. serial
     s = bench.model_ms("basicmf", 8, "stratified", 100_000_000, 100_000, 64, 64, 16, 64, 23.5)
-    assert s["compute_share_ms"] == 2.66 and s["total_ms"][0] == 2.66 and 5.5 < s["total_ms"][1] < 6.5
+    assert s["compute_share_ms"] == 2.71 and s["total_ms"][0] == 2.71 and 5.5 < s["total_ms"][1] < 6.5
     # another size: T1 / N
     o = bench.model_ms("basicmf", 2, "minibatch", 5_000_000, 100_000, 64, 2, 1, 0, 23.5 * 0.05)
     assert abs(o["compute_share_ms"] - 23.5 * 0.05 / 2) < 1e-9
