@@ -1058,7 +1058,13 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
     the shared rows (W_item / i_bias, W_ufeedback / ufeedback_bias, g_bias) move once per window; the result is NOT the reference's bit for
     bit, the contract is |dRMSE| <= 1e-4 against the exact pass of the same epochs, measured here (rmse_minus_sequential)."""
     factor = WORKLOADS[name][2]
-    if name == "svdpp":
+    tri = None
+    if name == "basicmf":   # the contract workload through the same opt-in step (k_window_users_slots + k_window_items in place), bf16 contribution rows
+        n = a.ratings
+        u, i, r = cached(synth_triples, n + 1_000_000, a.users, a.items, 12345 + a.data_seed)
+        test = sa.CSRData.from_triples(u[n:n + 200000], i[n:n + 200000], r[n:n + 200000])
+        tri = (u[:n], i[:n], r[:n])
+    elif name == "svdpp":
         train, test = cached(synth_user_blocks, a.svdpp_users, a.svdpp_per_user, a.users, a.items, 4242 + a.data_seed)
         n = train.num_row
     else:
@@ -1066,7 +1072,7 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
         d_all = cached(synth_neighbourhood, n + 100_000, a.users, a.items, a.globals, 4, 99 + a.data_seed)
         test = d_all.slice_rows(n, n + 100_000)
         d_all = d_all.slice_rows(0, n)
-    extra = [("amd:step", "minibatch")] + ([("amd:contrib", a.contrib)] if getattr(a, "contrib", "fp32") == "bf16" else [])
+    extra = [("amd:step", "minibatch")] + ([("amd:contrib", "bf16")] if (getattr(a, "contrib", "fp32") == "bf16" or (name == "basicmf" and getattr(a, "contrib", "auto") == "auto")) else [])
     if a.step_window > 0:
         extra.append(("amd:window", str(a.step_window)))
     t0 = time.time()
@@ -1074,7 +1080,7 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
     if a.step_per_target > 0:
         tr.set_knob("window_per_target", a.step_per_target)
         tr.set_knob("window_per_target_fb", a.step_per_target)
-    ds = tr.dataset_from_blocks(train) if name == "svdpp" else tr.dataset_from_csr(d_all)
+    ds = tr.dataset_from_triples(*tri) if tri else (tr.dataset_from_blocks(train) if name == "svdpp" else tr.dataset_from_csr(d_all))
     build_s = time.time() - t0
     assert ds.kind == 8
     ev = HipEvents()
@@ -1104,7 +1110,7 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
     # that loads its model file (a minibatch handle builds window sequences, which are training sets)
     import tempfile
     sq = make_trainer(sa, name, a, factor, device)
-    dsq = sq.dataset_from_blocks(train) if name == "svdpp" else sq.dataset_from_csr(d_all)
+    dsq = sq.dataset_from_triples(*tri) if tri else (sq.dataset_from_blocks(train) if name == "svdpp" else sq.dataset_from_csr(d_all))
     for _ in range(warmup + steps):
         sq.train_dataset(dsq)
     rm_seq = score(sq)
@@ -1426,7 +1432,7 @@ def main():
             r["wall_s"] = round(time.time() - t0, 1)
             secondary["%s_k%d" % (name, WORKLOADS[name][2])] = r
     if rank == 0 and world == 1 and not a.no_window_step:
-        for name in [s for s in sec.split(",") if s in ("svdpp", "neighbourhood")]:
+        for name in (["basicmf"] if (a.workload == "basicmf" and sec) else []) + [s for s in sec.split(",") if s in ("svdpp", "neighbourhood")]:
             try:   # extras: never lose the contract line over them
                 secondary["%s_k%d_window_step" % (name, WORKLOADS[name][2])] = run_window_step(sa, name, a, local_rank, log)
             except Exception as e:

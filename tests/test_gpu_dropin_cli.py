@@ -183,6 +183,56 @@ def test_bulk_round_loop_on_two_ranks_from_the_config_file(shape, tmp_path):
     assert abs(rm["ref"] - rm["bulk2"]) <= (1e-4 if fmt == 0 else 5e-4), rm
 
 
+@need_cli
+@pytest.mark.parametrize("shape", ["basicmf", "implicit"])
+def test_bulk_round_loop_opts_into_the_window_step_from_the_config_file(shape, tmp_path):
+    """`amd:step = minibatch` in the config file of the plain-C round loop, ONE GPU: the resident buffer file becomes a window sequence (DESIGN.md
+    6h) -- not the reference's sequential result, but within the accuracy contract of the unmodified reference CLI after equal rounds; the
+    model files are ordinary model files (loaded by a plain trainer for scoring)."""
+    import svdfeature_amd as sa
+    exe = _build_bulk(tmp_path)
+    base, test = cases.ml100k()
+    if shape == "basicmf":
+        conf, make, rounds, fmt = cases.conf_with(cases.BASICMF_CONF, num_factor=16), (lambda p: D.write_csr_buffer(p, base)), 5, 0
+        step = [("amd:step", "minibatch")]                       # the data-driven default: <= 24 updates per item per window
+    else:
+        order = np.argsort(base.feat_index[0::2], kind="stable")
+        users, items, labels = base.feat_index[0::2][order], base.feat_index[1::2][order], base.row_label[order]
+        blocks = []
+        for uid in np.unique(users):
+            m = users == uid
+            it = np.unique(items[m]).astype(np.uint32)
+            rows = [(float(l), [], [(int(uid), 1.0)], [(int(x), 1.0)]) for l, x in zip(labels[m], items[m])]
+            blocks.append(D.PlusBlock(it, np.full(len(it), 1.0 / np.sqrt(len(it)), np.float32), sa.CSRData.from_rows(rows), 0))
+        conf = cases.conf_with(cases.BASICMF_CONF, format_type=1, num_ufeedback=1682, wd_ufeedback=0.004, num_factor=16)
+        make, rounds, fmt = (lambda p: D.write_ugroup_buffer(p, blocks)), 3, 1
+        step = [("amd:step", "minibatch"), ("amd:window", "200")]   # a 943-user file: see profiles/r04_wstep_demo_shape_calibration.txt
+    models = {}
+    for name, cli, extra in (("ref", REF_CLI, []), ("wstep", exe, step)):
+        d = tmp_path / name
+        d.mkdir()
+        make(str(d / "train.buffer"))
+        _write_conf(str(d / "run.conf"), conf + extra + [("buffer_feature", "train.buffer"), ("model_out_folder", "./")])
+        p = subprocess.run([cli, "run.conf", "num_round=%d" % rounds, "silent=1"], cwd=str(d), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+        assert p.returncode == 0, p.stdout.decode()
+        models[name] = str(d / ("%04d.model" % rounds))
+    assert open(models["ref"], "rb").read() != open(models["wstep"], "rb").read()   # it IS another algorithm ...
+    rm = {}
+    for name, path in models.items():
+        t = sa.Trainer(fmt, 0)
+        t.load_model(path)
+        t.init_trainer()
+        if fmt == 0:
+            rm[name] = cases.rmse(t.predict_batch(test), test.row_label)
+        else:
+            fb = {int(b.data.feat_index[0]): b for b in blocks}
+            tu = test.feat_index[0::2]
+            pred = np.concatenate([t.predict_block(D.PlusBlock(fb[int(tu[r])].index_ufeedback, fb[int(tu[r])].value_ufeedback, test.slice_rows(r, r + 1), 0))
+                                   for r in range(0, test.num_row, 11)])
+            rm[name] = cases.rmse(pred, test.row_label[0::11])
+    assert abs(rm["ref"] - rm["wstep"]) <= (3e-4 if fmt == 0 else 5e-4), rm   # ... inside the contract's neighbourhood on a 943-user file
+
+
 REF_INFER = os.path.join(REFDIR, "svd_feature_infer")
 AMD_INFER = os.path.join(REFDIR, "svd_feature_infer_amd")
 need_infer = pytest.mark.skipif(not (os.path.exists(REF_INFER) and os.path.exists(AMD_INFER) and os.path.exists(AMD_CLI)),
