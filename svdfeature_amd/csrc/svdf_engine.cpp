@@ -1889,6 +1889,7 @@ Dataset *Engine::dataset_from_pairs(long n, const unsigned *user, const unsigned
     check(trainer_ready_, "dataset: init_trainer has not been called");
     need_device("dataset");
     if (multi_ && !in_multi_scope()) return multi_dataset_from_pairs(n, user, pos, neg);
+    if (single_minibatch() && !user_group() && basic_fast_path_allowed()) return wseq_from_pairs(n, user, pos, neg);
     if (device_sched_ && n > 0 && fused_allowed() && !user_group() && !relaxed()) {
         // everything on the device: the three columns go up as they are, the schedule columns (lower / higher item id, signs)
         // are formed there, ids are checked by the scheduling pass, pos == neg by the preparation kernel

@@ -536,6 +536,7 @@ class Engine {
     Dataset *wseq_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
                               const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
     Dataset *wseq_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
+    Dataset *wseq_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg);
     void wseq_train(Dataset *ds);
     WindowSchedule window_view(const Dataset *ds) const;
     Dataset *window_trained_ = nullptr;   // the window data set whose contributions the scratch holds

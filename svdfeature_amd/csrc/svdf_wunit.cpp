@@ -465,6 +465,31 @@ Dataset *Engine::wseq_from_triples(long n, const unsigned *user, const unsigned 
     return ds.release();
 }
 
+// rank pairs (BASELINE configs[4]): two signed item entries per instance, two contribution slots per pair.  The window rule counts both
+// entries; amd:window (pairs per window) overrides -- the demo-rate calibration allows ~320 updates per item per window
+// (profiles/r04_pairs_windows_demo_rate.txt), an order of magnitude more than the rating default kept here.
+Dataset *Engine::wseq_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg) {
+    std::vector<long> ci((size_t)mp_.num_item, 0);
+    for (long r = 0; r < n; r++) {
+        if (pos[r] >= (unsigned)mp_.num_item || neg[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound");
+        ci[pos[r]]++; ci[neg[r]]++;
+    }
+    const long W = wseq_windows(n, {mean_updates_met(ci)});
+    std::unique_ptr<Dataset> ds(new Dataset());
+    adopt(ds.get()); ds->kind = 8; ds->num_row = n;
+    for (long w = 0; w < W; w++) {
+        const long b0 = n * w / W, b1 = n * (w + 1) / W;
+        std::unique_ptr<Dataset> c(new Dataset());
+        adopt(c.get());
+        window_build(c.get(), b1 - b0, user + b0, pos + b0, nullptr, neg + b0);
+        ds->algorithmic_bytes += c->algorithmic_bytes; ds->num_units += c->num_units;
+        ds->wchild.push_back(c.release());
+    }
+    ds->sched.level_ptr = {0, n};
+    ds->sched.max_level_size = W > 0 ? (n + W - 1) / W : n;
+    return ds.release();
+}
+
 // one pass over a window sequence: per window the users' walks, then the per-target sums added in place (two launches per window)
 void Engine::wseq_train(Dataset *ds) {
     const DevParams &P = params();

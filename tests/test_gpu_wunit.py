@@ -160,7 +160,7 @@ def test_fp16_wire_stays_within_the_rounding_of_the_wire_format():
         np.testing.assert_allclose(ranks[0].t.view(name), sim[0].t.view(name), rtol=0, atol=2e-4)
 
 
-@pytest.mark.parametrize("shape", ["blocks", "rows", "triples"])
+@pytest.mark.parametrize("shape", ["blocks", "rows", "triples", "pairs"])
 def test_one_gpu_opt_in_minibatch_step_is_the_one_rank_simulation(shape):
     """`amd:step = minibatch` on a single-GPU handle (opt-in, NOT the reference's semantics): resident data sets become window sequences
     (kind 8), one pass = per window the users' exact walks + the per-row sums added in place; equals the one-rank oracle simulation with
@@ -184,6 +184,16 @@ def test_one_gpu_opt_in_minibatch_step_is_the_one_rank_simulation(shape):
         sim = simulate(conf, d, None, None, 1, windows, 2, minibatch=True)
         names = ("W_item", "i_bias", "g_bias", "W_user", "u_bias")
         exact = _trainer(conf, 0, 0).dataset_from_csr(d)
+    elif shape == "pairs":
+        from svdfeature_amd.multi_gpu import Pairs
+        nu, ni, n, windows = 600, 150, 24000, 4
+        pu, pp, pq = cases.planted_pairs(n, nu, ni, seed=3)
+        conf = cases.conf_with(cases.PAIR_CONF, num_user=nu, num_item=ni, num_factor=128, learning_rate=0.05, ui_init_sigma=0.1)
+        t = _trainer(conf, 0, 3, [("amd:step", "minibatch"), ("amd:window", n // windows)])
+        ds = t.dataset_from_pairs(pu, pp, pq)
+        sim = simulate(conf, Pairs(pu, pp, pq), None, None, 1, windows, 2, active=3, minibatch=True)
+        names = ("W_item", "i_bias", "W_user")
+        exact = _trainer(conf, 0, 3).dataset_from_pairs(pu, pp, pq)
     else:
         nu, ni, n, windows = 900, 200, 30000, 6
         u, i, r = cases.planted_triples(n, nu, ni, seed=12)
