@@ -74,7 +74,15 @@ void Engine::ipc_setup(int rank, int world, int64_t wire_bytes, int64_t block_fl
     S.wire_bytes = ((size_t)wire_bytes + 255) & ~(size_t)255;
     S.block_floats = (size_t)block_floats;
     HIPCHECK(hipMalloc(&S.wire, S.wire_bytes + 2 * S.block_floats * sizeof(float) + 256));
-    HIPCHECK(hipMalloc((void **)&S.page, PAGE_WORDS * sizeof(unsigned)));
+    // the flag page is polled by this device while PEERS store into it: allocated uncached (no L2 line of it can go stale under a remote
+    // store), fine-grained as the second choice, plain device memory last (the ranks of the one-GPU tests share a device: any of them works)
+    if (hipExtMallocWithFlags((void **)&S.page, PAGE_WORDS * sizeof(unsigned), hipDeviceMallocUncached) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipExtMallocWithFlags((void **)&S.page, PAGE_WORDS * sizeof(unsigned), hipDeviceMallocFinegrained) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHECK(hipMalloc((void **)&S.page, PAGE_WORDS * sizeof(unsigned)));
+        }
+    }
     HIPCHECK(hipMemset(S.page, 0, PAGE_WORDS * sizeof(unsigned)));
     S.inbox = reinterpret_cast<float *>(reinterpret_cast<char *>(S.wire) + S.wire_bytes);
     HIPCHECK(hipHostMalloc((void **)&S.err_host, sizeof(unsigned), hipHostMallocMapped));

@@ -692,4 +692,260 @@ void launch_svdpp_wave(const DevParams &P, const DevCSR &D, const DevUnit *units
 #undef SVDF_WAVE_CASE
 }
 
+// ------------------------------------------------------------------------------------------------- window-minibatch step, one WAVE per user unit
+// The window step for user units (svdf_k_wunit.hip) is bound by the LATENCY of its longest unit: a window of the
+// BASELINE configs[3] SVD++ data holds ~1 500 users (about one per SIMD), every one a strict recurrence of 100 rows between a gather and a
+// scatter of 100 feedback rows.  k_wunit_fast gives a unit 16 lanes (float4 x 2 per lane: ~400 instructions per row step on a wave that
+// issues one every >= 4 cycles); this kernel gives it the whole wave in the chain layout of k_svdpp_wave above -- one element per lane and
+// register, each SSE accumulation chain in its own DPP row: ~140 instructions per row -- with the window step's semantics: the shared rows
+// are only READ (window-start values, so nothing fetched ahead can go stale), what the reference would have changed on them goes to the
+// unit's contribution slots.  With every unit of the window in flight at once the memory system is loaded (~3 TB/s) and its latency is a
+// multiple of the idle one, so more is kept in flight than in the exact kernel: item rows PFW = 16 ahead, feedback rows in linear layout two
+// batches of 16 (one being accumulated / scattered, one requested), the 64-record blocks one block ahead.  Same statements in the same order
+// as k_wunit_walk ==> the same bits (tests/test_gpu_wunit.py, tests/fuzz_wunit.py).  Fixed row layout without global entries (estride 1),
+// unit user values, full rows (k = 64 NR); contribution rows fp32 or bfloat16.
+template <int NR, bool BF16> __device__ __forceinline__ void contrib_chain_store(float *base, size_t slot, int pitch, int lane, const ChainRow<NR> &x) {
+    if constexpr (!BF16) chain_store<NR>(base, slot, pitch, lane, -1, x);
+    else {
+        unsigned short *row = reinterpret_cast<unsigned short *>(base) + slot * (size_t)pitch;
+        const int e0 = 4 * NR * (lane & 15) + (lane >> 4);
+#pragma unroll
+        for (int q = 0; q < NR; q++) row[e0 + 4 * q] = (unsigned short)bf16_rne(x.r[q]);
+    }
+}
+template <int NR, bool BF16> __device__ __forceinline__ void contrib_lin_store(float *base, size_t slot, int pitch, int lane, const ChainRow<NR> &x) {
+    if constexpr (!BF16) lin_store<NR>(base, slot, pitch, lane, -1, x);
+    else {
+        unsigned short *row = reinterpret_cast<unsigned short *>(base) + slot * (size_t)pitch + NR * lane;
+        if constexpr (NR == 2) *reinterpret_cast<unsigned *>(row) = bf16_rne(x.r[0]) | (bf16_rne(x.r[1]) << 16);
+        else if constexpr (NR == 4) *reinterpret_cast<uint2 *>(row) = make_uint2(bf16_rne(x.r[0]) | (bf16_rne(x.r[1]) << 16), bf16_rne(x.r[2]) | (bf16_rne(x.r[3]) << 16));
+        else {
+#pragma unroll
+            for (int c = 0; c < NR; c++) row[c] = (unsigned short)bf16_rne(x.r[c]);
+        }
+    }
+}
+// a 64-entry block of a feedback list, one entry per lane (entries past the list repeat its last one), with the entry's feedback-bias word
+struct WaveFbBlock { WinEnt e; float b; };
+__device__ __forceinline__ WaveFbBlock wave_fb_block(const DevParams &P, const WUnitSchedule &S, int fb_begin, int first, int fb_last, int lane, bool ub) {
+    WaveFbBlock x;
+    x.e = S.fbent[fb_begin + min(first + lane, fb_last)];
+    x.b = ub ? P.bias[P.fb_off + x.e.idx] : 0.0f;
+    return x;
+}
+template <int NR, int FBW> struct WaveFbBatch { ChainRow<NR> w[FBW]; };
+template <int NR, int FBW>   // request the feedback rows of entries off .. off+FBW-1 of a block
+__device__ __forceinline__ void wave_fb_issue(const DevParams &P, const WinEnt &fe, int off, int lane, WaveFbBatch<NR, FBW> &o) {
+#pragma unroll
+    for (int c = 0; c < FBW; c++) o.w[c] = lin_load<NR>(P.W, P.fb_off + pick(fe.idx, off + c), P.pitch, lane, -1);
+}
+// a 64-record block of a segment's rows, one row per lane: the record (item id, value, contribution slot), the label and the item's bias word
+struct WaveRowBlock { WinEnt e; float label, bi; };
+__device__ __forceinline__ WaveRowBlock wave_row_block(const DevParams &P, const WUnitSchedule &S, int row_begin, int first, int row_last, int lane) {
+    WaveRowBlock x;
+    const int j = row_begin + min(first + lane, row_last);
+    x.e = S.ent[j];
+    x.label = S.label[j];
+    x.bi = P.bias[P.item_off + x.e.idx];
+    return x;
+}
+// FAST: the configuration of every BASELINE run (k_svdpp_wave's predicate: linear link, L2 decay, user bias on, no per-range decay, no clamp)
+// compiled without the per-row switches.  Vector-memory instructions are the scarce resource of a wave here (at most 64 in flight, and all
+// ~1 500 waves of a window run their phases at the same time): bias words come with the 64-entry blocks (one load per block instead of
+// one per row), bias contributions leave as one store per group, and what is fetched ahead are row requests only.
+template <int NR, int PFW, bool BF16, bool FAST>
+__global__ __launch_bounds__(64, (NR <= 2 ? 2 : 1)) void k_wunit_wave(   // two waves per SIMD (<= 256 registers) at k <= 128: a window has ~1.5 units per SIMD
+    const DevParams P, const WUnitSchedule S) {
+    constexpr int FBW = 16;
+    static_assert(64 % PFW == 0 && 64 % (2 * FBW) == 0, "a group must not straddle two 64-record blocks");
+    const int lane = threadIdx.x & 63;
+    const long uidx = blockIdx.x;
+    if (uidx >= S.nunits) return;
+    const int pitch = P.pitch, k = 64 * NR, kio = -1;
+    const bool ub = FAST ? true : P.no_user_bias == 0;
+    const float lr = P.lr, lr2 = P.lr * P.scale_lr_ufeedback;
+    const int4 u0 = *reinterpret_cast<const int4 *>(&S.units[uidx]);            // user, seg_begin, seg_count, rows
+    const int4 u1 = *(reinterpret_cast<const int4 *>(&S.units[uidx]) + 1);      // the first segment
+    const unsigned user = (unsigned)__builtin_amdgcn_readfirstlane(u0.x);
+    const int seg_begin = __builtin_amdgcn_readfirstlane(u0.y), seg_count = __builtin_amdgcn_readfirstlane(u0.z);
+    const unsigned urow = P.user_off + user;
+    ChainRow<NR> p = chain_load<NR>(P.W, urow, pitch, lane, kio);
+    float bu = ub ? P.bias[urow] : 0.0f;
+    const float wd_u = FAST ? P.wd_user : get_wd(P.u_rng, user, P.wd_user);
+    const float dec_ub = 1.0f - lr * P.wd_user_bias, dec_ib = 1.0f - lr * P.wd_item_bias;
+    const float dec_u = 1.0f - lr * wd_u, dec_i = 1.0f - lr * P.wd_item;       // FAST: chain_reg's L2 form with the constant rates
+    for (int sg = 0; sg < seg_count; sg++) {
+        int4 sv = u1;
+        if (sg > 0) sv = *reinterpret_cast<const int4 *>(&S.segs[seg_begin + sg]);
+        const int fb_begin = __builtin_amdgcn_readfirstlane(sv.x), nfb = __builtin_amdgcn_readfirstlane(sv.y);
+        const int row_begin = __builtin_amdgcn_readfirstlane(sv.z), nrow = __builtin_amdgcn_readfirstlane(sv.w);
+        const int fb_last = max(nfb - 1, 0), row_last = max(nrow - 1, 0);
+        // ---- prepare_ufeedback (:523-538) in LINEAR layout: batches of 16 rows, accumulated in list order, the next batch requested
+        ChainRow<NR> tl = chain_zero<NR>();
+        float norm = 0.0f, tmp_bias = 0.0f;
+        auto gather = [&](const WaveFbBatch<NR, FBW> &x, const WaveFbBlock &fb, int j) {   // entries j .. j+FBW-1
+#pragma unroll
+            for (int c = 0; c < FBW; c++) {
+                if (j + c < nfb) {
+                    const float v = pick(fb.e.val, (j & 63) + c);
+                    chain_axpy(tl, x.w[c], v);
+                    norm = norm + v * v;
+                    if (ub) tmp_bias = tmp_bias + pick(fb.b, (j & 63) + c) * v;
+                }
+            }
+        };
+        if (nfb > 0) {
+            WaveFbBlock fb = wave_fb_block(P, S, fb_begin, 0, fb_last, lane, ub), fb_next = wave_fb_block(P, S, fb_begin, 64, fb_last, lane, ub);
+            WaveFbBatch<NR, FBW> A, B;
+            wave_fb_issue<NR, FBW>(P, fb.e, 0, lane, A);
+            for (int j = 0; j < nfb; j += 2 * FBW) {   // A holds batch j; batch j + FBW lies in the same block
+                if (j + FBW < nfb) wave_fb_issue<NR, FBW>(P, fb.e, (j + FBW) & 63, lane, B);
+                gather(A, fb, j);
+                WaveFbBlock fn = fb;
+                if (((j + 2 * FBW) & 63) == 0) { fn = fb_next; fb_next = wave_fb_block(P, S, fb_begin, j + 2 * FBW + 64, fb_last, lane, ub); }
+                if (j + 2 * FBW < nfb) wave_fb_issue<NR, FBW>(P, fn.e, (j + 2 * FBW) & 63, lane, A);
+                if (j + FBW < nfb) gather(B, fb, j + FBW);
+                fb = fn;
+            }
+        }
+        ChainRow<NR> tmp_fb = lin_to_chain<NR>(tl, lane);
+        const ChainRow<NR> old_fb = tmp_fb;
+        const float old_bias = tmp_bias;
+        // ---- the rows: records 64 at a time (one per lane, the next block requested a block ahead), item rows PFW ahead
+        WaveRowBlock rb = wave_row_block(P, S, row_begin, 0, row_last, lane), rb_next = wave_row_block(P, S, row_begin, 64, row_last, lane);
+        ChainRow<NR> cur[PFW], nxt[PFW];
+#pragma unroll
+        for (int c = 0; c < PFW; c++) cur[c] = chain_load<NR>(P.W, P.item_off + pick(rb.e.idx, c), pitch, lane, kio);
+        for (int j0 = 0; j0 < nrow; j0 += PFW) {
+            const int off_cur = j0 & 63, off_pre = (j0 + PFW) & 63;
+            WaveRowBlock rb_pre = rb;
+            if (off_pre == 0) { rb_pre = rb_next; rb_next = wave_row_block(P, S, row_begin, j0 + PFW + 64, row_last, lane); }   // the next group starts a new block
+            if (j0 + PFW < nrow) {
+#pragma unroll
+                for (int c = 0; c < PFW; c++) nxt[c] = chain_load<NR>(P.W, P.item_off + pick(rb_pre.e.idx, off_pre + c), pitch, lane, kio);
+            }
+            float cbv = 0.0f;   // lane off_cur + c: the bias contribution of row j0 + c
+#pragma unroll
+            for (int c = 0; c < PFW; c++) {
+                if (j0 + c < nrow) {
+                    const ChainRow<NR> &xq = cur[c];
+                    const float label = pick(rb.label, off_cur + c), iv = pick(rb.e.val, off_cur + c), bi = pick(rb.bi, off_cur + c);
+                    const int slot = pick(rb.e.slot, off_cur + c);
+                    double bs = 0.0;
+                    if (ub) { bs += (double)(1.0f * bu); bs += (double)tmp_bias; }
+                    bs += 0.0;
+                    bs += (double)(iv * bi);
+                    double sum = (double)P.base_score + bs;
+                    ChainRow<NR> tu = tmp_fb, ti = chain_zero<NR>();
+                    chain_axpy(tu, p, 1.0f);
+                    chain_axpy(ti, xq, iv);
+                    sum += (double)chain_dot(tu, ti, lane, k);
+                    const float pred = FAST ? (float)sum : map_active((float)sum, P.active_type);
+                    const float err = (FAST ? label - pred : cal_grad(label, pred, P.active_type)) * 1.0f;
+                    const float su = lr * err * 1.0f, si = lr * err * iv;
+                    ChainRow<NR> wu = p;
+                    chain_axpy(wu, ti, su);
+                    float nbu = bu + su;
+                    ChainRow<NR> w = xq;
+                    chain_axpy(w, tu, si);
+                    float nbi = bi + si;
+                    if (FAST) chain_scale(w, dec_i);
+                    else chain_reg(P, w, get_wd(P.i_rng, pick(rb.e.idx, off_cur + c), P.wd_item), true, lane, k);
+                    nbi = nbi * dec_ib;
+#pragma unroll
+                    for (int q = 0; q < NR; q++) w.r[q] = w.r[q] - xq.r[q];
+                    contrib_chain_store<NR, BF16>(S.contrib, (size_t)slot, pitch, lane, w);
+                    cbv = (lane == off_cur + c) ? nbi - bi : cbv;
+                    chain_axpy(tmp_fb, ti, lr2 * err * norm);          // update_svdpp (:512-520)
+                    chain_scale(tmp_fb, 1.0f - lr2 * P.wd_ufeedback);
+                    if (ub) {
+                        tmp_bias = tmp_bias + lr2 * err * norm;
+                        tmp_bias = tmp_bias * (1.0f - lr2 * P.wd_ufeedback_bias);
+                    }
+                    if (FAST) chain_scale(wu, dec_u);
+                    else chain_reg(P, wu, wd_u, false, lane, k);
+                    nbu = nbu * dec_ub;
+                    p = wu;
+                    if (ub) bu = nbu;
+                }
+            }
+            if (lane >= off_cur && lane < off_cur + PFW && j0 + (lane - off_cur) < nrow) S.cbias[rb.e.slot] = cbv;   // one store for the group
+#pragma unroll
+            for (int c = 0; c < PFW; c++) cur[c] = nxt[c];
+            rb = rb_pre;
+        }
+        // ---- update_ufeedback (:539-554) against the window-start rows: contributions (w + d val) - w, linear layout, same pipeline
+        if (nfb > 0) {
+            ChainRow<NR> d = tmp_fb;
+#pragma unroll
+            for (int q = 0; q < NR; q++) d.r[q] = d.r[q] - old_fb.r[q];
+            float db = tmp_bias - old_bias;
+            const float inv = 1.0f / norm;
+            chain_scale(d, inv);
+            db = db * inv;
+            const ChainRow<NR> dl = chain_to_lin<NR>(d, lane);
+            auto scatter = [&](const WaveFbBatch<NR, FBW> &x, const WaveFbBlock &fb, int j) {
+#pragma unroll
+                for (int c = 0; c < FBW; c++) {
+                    if (j + c < nfb) {
+                        const float v = pick(fb.e.val, (j & 63) + c);
+                        const int slot = pick(fb.e.slot, (j & 63) + c);
+                        ChainRow<NR> w2 = x.w[c];
+                        chain_axpy(w2, dl, v);
+#pragma unroll
+                        for (int q = 0; q < NR; q++) w2.r[q] = w2.r[q] - x.w[c].r[q];
+                        contrib_lin_store<NR, BF16>(S.contrib, (size_t)slot, pitch, lane, w2);
+                    }
+                }
+            };
+            auto scatter_bias = [&](const WaveFbBlock &fb, int first) {   // the block's bias contributions, one entry per lane: one store per block
+                float cb = 0.0f;
+                if (ub) { const float b2 = fb.b + db * fb.e.val; cb = b2 - fb.b; }
+                if (first + lane < nfb) S.cbias[fb.e.slot] = cb;
+            };
+            WaveFbBlock fb = wave_fb_block(P, S, fb_begin, 0, fb_last, lane, ub), fb_next = wave_fb_block(P, S, fb_begin, 64, fb_last, lane, ub);
+            WaveFbBatch<NR, FBW> A, B;
+            wave_fb_issue<NR, FBW>(P, fb.e, 0, lane, A);
+            scatter_bias(fb, 0);
+            for (int j = 0; j < nfb; j += 2 * FBW) {
+                if (j + FBW < nfb) wave_fb_issue<NR, FBW>(P, fb.e, (j + FBW) & 63, lane, B);
+                scatter(A, fb, j);
+                WaveFbBlock fn = fb;
+                if (((j + 2 * FBW) & 63) == 0) {
+                    fn = fb_next; fb_next = wave_fb_block(P, S, fb_begin, j + 2 * FBW + 64, fb_last, lane, ub);
+                    if (j + 2 * FBW < nfb) scatter_bias(fn, j + 2 * FBW);
+                }
+                if (j + 2 * FBW < nfb) wave_fb_issue<NR, FBW>(P, fn.e, (j + 2 * FBW) & 63, lane, A);
+                if (j + FBW < nfb) scatter(B, fb, j + FBW);
+                fb = fn;
+            }
+        }
+    }
+    chain_store<NR>(P.W, urow, pitch, lane, kio, p);
+    if (ub && lane == 0) P.bias[urow] = bu;
+}
+bool wunit_wave_applies(const DevParams &P, const WUnitSchedule &S, bool feedback) {
+    return feedback && S.rptr == nullptr && S.estride == 1 && S.uval == nullptr && P.k % 64 == 0 && P.k <= 256;
+}
+template <int NR, int PFW> static void launch_wunit_wave_nr(const DevParams &P, const WUnitSchedule &S, hipStream_t st) {
+    const bool fast = P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 && P.user_nonnegative == 0 && P.u_rng.n == 0 && P.i_rng.n == 0;
+    const dim3 grid((unsigned)S.nunits), block(64);
+    if (S.contrib_bf16) {
+        if (fast) hipLaunchKernelGGL((k_wunit_wave<NR, PFW, true, true>), grid, block, 0, st, P, S);
+        else hipLaunchKernelGGL((k_wunit_wave<NR, PFW, true, false>), grid, block, 0, st, P, S);
+    } else {
+        if (fast) hipLaunchKernelGGL((k_wunit_wave<NR, PFW, false, true>), grid, block, 0, st, P, S);
+        else hipLaunchKernelGGL((k_wunit_wave<NR, PFW, false, false>), grid, block, 0, st, P, S);
+    }
+}
+void launch_wunit_wave(const DevParams &P, const WUnitSchedule &S, hipStream_t st) {
+    if (S.nunits <= 0) return;
+    switch (P.k / 64) {
+    case 1: launch_wunit_wave_nr<1, 8>(P, S, st); break;
+    case 2: launch_wunit_wave_nr<2, 8>(P, S, st); break;
+    case 3: launch_wunit_wave_nr<3, 8>(P, S, st); break;
+    default: launch_wunit_wave_nr<4, 8>(P, S, st); break;
+    }
+}
+
 }  // namespace svdf

@@ -447,6 +447,9 @@ bool wunit_fast_applies(const DevParams &P, const WUnitSchedule &S, bool feedbac
 }
 void launch_wunit_walk(const DevParams &P, const WUnitSchedule &S, bool feedback, int fast, hipStream_t st) {
     if (S.nunits <= 0) return;
+    // fast: 0 = the general lane-group kernel, 1 = the slot kernel where it applies, 2 (default) = in addition one WAVE per unit for user-group
+    // windows whose launch does not fill the chip anyway (its time is the longest unit's latency: svdf_k_wave.hip, k_wunit_wave)
+    if (fast >= 2 && wunit_wave_applies(P, S, feedback) && S.nunits <= 16384) { launch_wunit_wave(P, S, st); return; }
     if (fast && wunit_fast_applies(P, S, feedback)) {
         auto go = [&](auto lanes) {
             constexpr int LANES = decltype(lanes)::value;

@@ -56,6 +56,8 @@ void launch_window_items_local(const WindowSchedule &S, int pitch, int k, long l
 void launch_ranges_copy(const DeltaRanges &R, float *buf, int set, hipStream_t st);
 // the same step for user units: user-group (SVD++) blocks, rows with global features (svdf_k_wunit.hip)
 void launch_wunit_walk(const DevParams &P, const WUnitSchedule &S, bool feedback, int fast, hipStream_t st);
+bool wunit_wave_applies(const DevParams &P, const WUnitSchedule &S, bool feedback);   // svdf_k_wave.hip: one wave per user unit (SVD++ shape)
+void launch_wunit_wave(const DevParams &P, const WUnitSchedule &S, hipStream_t st);
 void launch_wunit_sum(const DevParams &P, const WUnitSchedule &S, void *dst, int half, hipStream_t st);   // dst == nullptr: add to the model in place
 // cross-process direct exchange (svdf_ipc.cpp): sequence flags in IPC-mapped device memory
 void launch_ipc_signal(unsigned *const *pages, int n, int phase, int me, unsigned seq, hipStream_t st);

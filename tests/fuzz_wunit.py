@@ -49,7 +49,7 @@ def one(rng, torch):
     elif r == 5: extra.update(reg_method=3)
     if active == 2: extra.update(base_score=0.5)
     bf16 = bool(rng.integers(0, 3) == 0)
-    knobs = [("wunit_fast", 0)] if rng.integers(0, 4) == 0 else []
+    knobs = [("wunit_fast", int(rng.integers(0, 2)))] if rng.integers(0, 3) == 0 else []   # default 2: one wave per unit where it applies
     if blocks_mode:
         nb = int(rng.integers(windows, 260))
         blocks = []

@@ -68,10 +68,12 @@ SVDPP_NAMES = ("W_item", "i_bias", "W_ufeedback", "ufeedback_bias", "W_user", "u
 
 
 @pytest.mark.parametrize("k,world,windows,knobs", [(16, 1, 3, ()), (16, 2, 3, ()), (64, 3, 2, ()), (128, 2, 2, ()), (100, 2, 3, ()), (7, 4, 2, ()), (256, 2, 2, ()),
-                                                   (64, 2, 2, (("wunit_fast", 0),)), (128, 1, 2, (("wunit_fast", 0),))])
+                                                   (64, 2, 2, (("wunit_fast", 0),)), (128, 1, 2, (("wunit_fast", 0),)), (64, 2, 2, (("wunit_fast", 1),)), (128, 2, 2, (("wunit_fast", 1),)),
+                                                   (192, 2, 2, ())])
 def test_user_group_blocks_on_simulated_ranks_equal_the_oracle_simulation(k, world, windows, knobs):
     """SVD++ blocks: DEFAULT blocks and START / MIDDLE / END spans, users without feedback, users with several blocks in one window; the
-    lane-group kernel at every width and the slot kernel with its row ring at k = 64 / 128 (k_wunit_fast)"""
+    lane-group kernel at every width, the slot kernel with its row ring at k = 64 / 128 (k_wunit_fast, knob wunit_fast = 1) and one wave per
+    unit at k = 64 / 128 / 192 / 256 (k_wunit_wave, the default where it applies)"""
     nu, ni = 260, 90
     blocks = cases.user_blocks(300, nu, ni, ni, seed=k + world, max_rows=9, max_fb=6, split_every=4)
     blocks += cases.user_blocks(120, nu, ni, ni, seed=k + world + 50, max_rows=4, max_fb=3)   # the same users again: several segments per unit
@@ -85,13 +87,26 @@ def test_user_group_blocks_on_simulated_ranks_equal_the_oracle_simulation(k, wor
 @pytest.mark.parametrize("k,active,extra", [(64, 2, (("base_score", "0.5"),)), (128, 0, (("reg_method", "1"),)), (64, 0, (("reg_method", "3"),)), (128, 0, (("no_user_bias", "1"),)),
                                             (64, 0, (("user_nonnegative", "1"),)), (128, 0, (("scale_lr_ufeedback", "0.5"), ("wd_ufeedback_bias", "0.01"))),
                                             (64, 0, (("ip:wd", "0.1"), ("ip:bound", "30"), ("ip:wd", "0.002"), ("ip:bound", "100000")))])
-def test_slot_kernel_links_and_regularisers(k, active, extra):
-    """the configurations k_wunit_fast covers beyond the usual one (long units: up to 40 rows and 30 feedback ids per user)"""
+@pytest.mark.parametrize("fast", [1, 2])
+def test_slot_kernel_links_and_regularisers(k, active, extra, fast):
+    """the configurations k_wunit_fast (fast = 1) and k_wunit_wave (fast = 2) cover beyond the usual one (long units: up to 40 rows and 30
+    feedback ids per user)"""
     nu, ni = 150, 120
     ba = BlockArrays.from_blocks(cases.user_blocks(140, nu, ni, ni, seed=k + active, max_rows=40, max_fb=30, split_every=6, binary_label=(active == 2)))
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni) + SVDPP_EXTRA + list(extra)
-    ranks, _ = _run_ranks(conf, ba, 2, 2, 2, fmt=1, active=active)
+    ranks, _ = _run_ranks(conf, ba, 2, 2, 2, fmt=1, active=active, knobs=(("wunit_fast", fast),))
     _check(ranks, simulate(conf, ba, None, None, 2, 2, 2, fmt=1, active=active, minibatch=True), SVDPP_NAMES)
+
+
+@pytest.mark.parametrize("k,fast", [(64, 2), (128, 2), (256, 2), (128, 1)])
+def test_units_longer_than_one_record_block(k, fast):
+    """units of up to 200 rows and 170 feedback ids: the wave kernel reads records and feedback entries 64 at a time and fetches item rows eight
+    ahead -- the block boundaries, the partial last block and the partial last group"""
+    nu, ni = 40, 300
+    ba = BlockArrays.from_blocks(cases.user_blocks(60, nu, ni, ni, seed=k + 7, max_rows=200, max_fb=170, split_every=5))
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni) + SVDPP_EXTRA
+    ranks, _ = _run_ranks(conf, ba, 2, 2, 2, fmt=1, knobs=(("wunit_fast", fast),))
+    _check(ranks, simulate(conf, ba, None, None, 2, 2, 2, fmt=1, minibatch=True), SVDPP_NAMES)
 
 
 @pytest.mark.parametrize("k", [64, 128])
