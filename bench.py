@@ -747,7 +747,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
                          "kernel": (("k_window_users_slots<8,2,G,1,0,true> + k_window_items<16,HALF> + k_delta_addto<HALF>" if name == "basicmf" else
                                      "k_window_users_slots<16,2,1,2,3,false> + k_window_items<32,HALF> + k_delta_addto<HALF>") +
                                     " (window-minibatch step, 3 launches per window)" if (minibatch and name != "svdpp") else
-                                    ("k_wunit_fast<16,2,true,0,4> + k_wunit_sum<32,HALF,false> + k_delta_addto<HALF> (window-minibatch step for user units, 3 launches per window)"
+                                    ("k_wunit_wave<2,8,BF16,true> + k_wunit_sum<32,HALF,false> + k_delta_addto<HALF> (window-minibatch step for user units, one wave per unit, 3 launches per window)"
                                      if minibatch else WORKLOADS[name][3])), "launches": launches, "avg_launch_us": per_launch_us,
                          "algorithmic_bytes_per_launch": per_launch_bytes,
                          "algorithmic_bytes_per_instance": alg_bytes / max(my_n, 1)},
@@ -1149,10 +1149,10 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
               if name == "pairwise" else
               {"rmse_test_after_run": rm_run, "rmse_sequential_reference": rm_seq, "rmse_minus_sequential": rm_run - rm_seq}), "passes_before_rmse": warmup + steps,
            "roofline": {"bound": "hbm", "achieved": alg * steps / (ev_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": alg * steps / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": "k_wunit_walk<32,%s> + k_wunit_sum<32,false,true> (two launches per window)" % ("true" if name == "svdpp" else "false"),
+                        "frac": alg * steps / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": ("k_wunit_wave<2,8,BF16,true> (one wave per user unit)" if name == "svdpp" else "k_wunit_fast<16,2,false,4,1>" if name == "neighbourhood" else "k_wunit_fast<LANES,2,false,0,4>") + " + k_wunit_sum<32,false,true> (two launches per window)",
                         "launches": launches, "avg_launch_us": ev_ms * 1e3 / max(launches, 1), "algorithmic_bytes_per_launch": alg * steps / max(launches, 1),
                         "algorithmic_bytes_per_instance": alg / max(n, 1), "traffic": wtraffic,
-                        "traffic_source": "profiles/hbm_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 of k_wunit_fast + k_wunit_sum per window / 2 launches (builder's rocprofv3 PMC passes, tools/profile_round4.sh)"}}
+                        "traffic_source": "profiles/hbm_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 of the unit kernel (k_wunit_wave / k_wunit_fast) + k_wunit_sum per window / 2 launches (builder's rocprofv3 PMC passes, tools/profile_round4.sh)"}}
     log("%s window step: %.2f ms per pass = %.1f M inst/s (%.1f%% of peak), %d windows, quality %s vs sequential %s" % (
         name, res["ms_per_step"], res["value"] / 1e6, 100 * res["roofline"]["frac"], ds.num_batches, rm_run, rm_seq))
     for x in (ds, dsq):
