@@ -31,13 +31,15 @@ def rows_of(rng, n, users, ni, ng, max_g, two_items, uvals):
     return rows
 
 
-def one(rng, torch):
+def one(rng, torch, wave=False):
+    """wave: the shapes k_wunit_wave takes (feedback blocks, fixed row layout without global entries, k = 64 NR) with long units -- up to 150
+    rows and 140 feedback ids: several 64-record blocks, partial groups, partial batches"""
     world, windows, passes = int(rng.integers(1, 5)), int(rng.integers(1, 6)), int(rng.integers(1, 3))
-    k = int(rng.choice([4, 10, 16, 33, 64, 64, 100, 128, 128, 200]))
+    k = int(rng.choice([64, 128, 128, 192, 256])) if wave else int(rng.choice([4, 10, 16, 33, 64, 64, 100, 128, 128, 200]))
     nu, ni = int(rng.integers(world * 4, 500)), int(rng.integers(8, 200))
-    ng = int(rng.choice([0, 0, 6, 30]))
-    blocks_mode = bool(rng.integers(0, 2))
-    fixed = bool(rng.integers(0, 2))          # fixed row layout (slot kernel at k = 64 / 128) or ragged rows
+    ng = 0 if wave else int(rng.choice([0, 0, 6, 30]))
+    blocks_mode = True if wave else bool(rng.integers(0, 2))
+    fixed = True if wave else bool(rng.integers(0, 2))          # fixed row layout (slot kernel at k = 64 / 128) or ragged rows
     active = int(rng.choice([0, 0, 0, 2]))
     extra = {}
     r = int(rng.integers(0, 8))
@@ -49,15 +51,18 @@ def one(rng, torch):
     elif r == 5: extra.update(reg_method=3)
     if active == 2: extra.update(base_score=0.5)
     bf16 = bool(rng.integers(0, 3) == 0)
-    knobs = [("wunit_fast", int(rng.integers(0, 2)))] if rng.integers(0, 3) == 0 else []   # default 2: one wave per unit where it applies
+    knobs = [("wunit_fast", int(rng.integers(0, 2)))] if (rng.integers(0, 3) == 0 and not wave) else []   # default 2: one wave per unit where it applies
     if blocks_mode:
-        nb = int(rng.integers(windows, 260))
+        nb = int(rng.integers(windows, 60 if wave else 260))
+        long_units = wave and rng.random() < 0.6
+        if wave:
+            ni = max(ni, 160)
         blocks = []
         users = rng.integers(0, nu, nb)
         for b in range(nb):
             uid = int(users[b])
-            nrow = int(rng.integers(1, 14))
-            nfb = 0 if rng.random() < 0.15 else int(rng.integers(1, min(ni, 12) + 1))
+            nrow = int(rng.integers(1, 150 if long_units else 14))
+            nfb = 0 if rng.random() < 0.15 else int(rng.integers(1, min(ni, 140 if long_units else 12) + 1))
             fb_idx = np.sort(rng.choice(ni, size=nfb, replace=False)).astype(np.uint32)
             fb_val = np.full(nfb, 1.0 / np.sqrt(max(nfb, 1)), np.float32) if rng.random() < 0.7 else rng.uniform(0.1, 1.0, nfb).astype(np.float32)
             rows = rows_of(rng, nrow, [uid], ni, 0 if fixed else ng, 3, not fixed, not fixed)
@@ -152,11 +157,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--wave", action="store_true", help="only the shapes the one-wave-per-unit kernel takes, long units")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     tot = dict(iters=0, exact=0, failed=0)
     for it in range(a.iters):
-        ok, desc = one(rng, torch)
+        ok, desc = one(rng, torch, a.wave)
         tot["iters"] += 1
         if ok:
             tot["exact"] += 1
