@@ -1077,7 +1077,7 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
         d_all = cached(synth_neighbourhood, n + 100_000, a.users, a.items, a.globals, 4, 99 + a.data_seed)
         test = d_all.slice_rows(n, n + 100_000)
         d_all = d_all.slice_rows(0, n)
-    extra = [("amd:step", "minibatch")] + ([("amd:contrib", "bf16")] if (getattr(a, "contrib", "fp32") == "bf16" or (name in ("basicmf", "pairwise") and getattr(a, "contrib", "auto") == "auto")) else [])
+    extra = [("amd:step", "minibatch")] + ([("amd:contrib", "bf16")] if (getattr(a, "contrib", "fp32") == "bf16" or (name in ("basicmf", "pairwise", "svdpp") and getattr(a, "contrib", "auto") == "auto")) else [])
     if a.step_window > 0:
         extra.append(("amd:window", str(a.step_window)))
     elif name == "pairwise":
