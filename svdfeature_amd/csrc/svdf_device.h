@@ -482,6 +482,18 @@ __device__ __forceinline__ float4 load_contrib(const float *base, int bf16, size
     return *reinterpret_cast<const float4 *>(base + slot * (size_t)pitch + (size_t)L * 4);
 }
 
+// A shared row's ONLY contribution of a window (slot < 0 in its entry; one-GPU window sequences, svdf_wunit.cpp): nobody else reads or
+// writes the row inside the window, so the unit applies it where it is computed -- with the sum kernel's own operations, acc = +0 + c on the
+// contribution as the slot would have stored it, then row + acc -- instead of writing a slot that k_wunit_sum reads back: the same bits,
+// a row write instead of a slot write + a slot read + a row read + a row write.
+__device__ __forceinline__ float contrib_as_stored(float x, bool bf16) { return bf16 ? __uint_as_float(bf16_rne(x) << 16) : x; }
+__device__ __forceinline__ float apply_single(float w, float c, bool bf16) {
+    const float acc = 0.0f + contrib_as_stored(c, bf16);
+    return w + acc;
+}
+__device__ __forceinline__ float4 apply_single(const float4 w, const float4 c, bool bf16) {
+    return make_float4(apply_single(w.x, c.x, bf16), apply_single(w.y, c.y, bf16), apply_single(w.z, c.z, bf16), apply_single(w.w, c.w, bf16));
+}
 // sum of contribution slots [b, e) in slot order: eight rows requested at a time; slots past the segment's end feed +0.0f, which leaves the running
 // sum unchanged bit for bit (the sum starts at +0.0f and x + y is -0 only when both are, so acc is never -0).  The storage format is a TEMPLATE
 // parameter here: with the format test inside the unrolled block the compiler kept a branch between the eight loads and they were issued one

@@ -2890,6 +2890,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "rows_without_feedback")) { rows_without_feedback_ = value != 0; return 0; }
     if (!strcmp(name, "fewrow_gslots")) { fewrow_gslots_ = value != 0; launch_version_++; return 0; }
+    if (!strcmp(name, "wunit_inplace")) { wunit_inplace_ = value != 0; return 0; }
     if (!strcmp(name, "wunit_fast")) { check(value >= 0 && value <= 2, "wunit_fast must be 0, 1 or 2"); wunit_fast_ = (int)value; return 0; }
     if (!strcmp(name, "window_per_target_fb")) { check(value >= 1, "window_per_target_fb must be positive"); wseq_per_target_fb_ = (int)value; return 0; }
     if (!strcmp(name, "window_per_target")) { check(value >= 1, "window_per_target must be positive"); wseq_per_target_ = (int)value; return 0; }

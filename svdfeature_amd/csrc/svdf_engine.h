@@ -527,6 +527,8 @@ class Engine {
     bool step_minibatch_set_ = false;
     bool contrib_bf16_ = false;           // "amd:contrib = bf16": contribution rows of the window-minibatch step in bfloat16 (opt-in)
     int fewrow_gslots_ = 1;               // knob "fewrow_gslots": 0 = k_fused for few-row data sets with inline global slots (A/B)
+    int wunit_inplace_ = 1;               // knob "wunit_inplace": one-GPU window sequences apply a row's only contribution of a window in place (no slot); 0 = every contribution through a slot (A/B)
+    bool wunit_inplace_build_ = false;    // set while wseq_from_csr / _from_blocks build their windows
     int wunit_fast_ = 2;                  // knob "wunit_fast": 0 = the general lane-group kernel for every shape, 1 = + the slot kernel, 2 = + one wave per unit (A/B and tests)
     int wseq_per_target_fb_ = 16;         // knob "window_per_target_fb": the same for feedback rows (instance-sized updates pushed by whole blocks)
     int wseq_per_target_ = 24;            // knob "window_per_target": updates a shared row meets per window when amd:window is not given

@@ -727,10 +727,10 @@ template <int NR, bool BF16> __device__ __forceinline__ void contrib_lin_store(f
 }
 // a 64-entry block of a feedback list, one entry per lane (entries past the list repeat its last one), with the entry's feedback-bias word
 struct WaveFbBlock { WinEnt e; float b; };
-__device__ __forceinline__ WaveFbBlock wave_fb_block(const DevParams &P, const WUnitSchedule &S, int fb_begin, int first, int fb_last, int lane, bool ub) {
+__device__ __forceinline__ WaveFbBlock wave_fb_block(const DevParams &P, const WUnitSchedule &S, int fb_begin, int first, int fb_last, int lane, bool) {
     WaveFbBlock x;
     x.e = S.fbent[fb_begin + min(first + lane, fb_last)];
-    x.b = ub ? P.bias[P.fb_off + x.e.idx] : 0.0f;
+    x.b = P.bias[P.fb_off + x.e.idx];   // (also without user bias: a single contribution applied in place adds its +0 to the word like the sum kernel)
     return x;
 }
 template <int NR, int FBW> struct WaveFbBatch { ChainRow<NR> w[FBW]; };
@@ -854,7 +854,14 @@ __global__ __launch_bounds__(64, (NR <= 2 ? 2 : 1)) void k_wunit_wave(   // two 
                     nbi = nbi * dec_ib;
 #pragma unroll
                     for (int q = 0; q < NR; q++) w.r[q] = w.r[q] - xq.r[q];
-                    contrib_chain_store<NR, BF16>(S.contrib, (size_t)slot, pitch, lane, w);
+                    if (slot < 0) {   // the row's only contribution of this window: applied here (apply_single, svdf_device.h)
+                        ChainRow<NR> a;
+#pragma unroll
+                        for (int q = 0; q < NR; q++) a.r[q] = apply_single(xq.r[q], w.r[q], BF16);
+                        chain_store<NR>(P.W, P.item_off + pick(rb.e.idx, off_cur + c), pitch, lane, kio, a);
+                    } else {
+                        contrib_chain_store<NR, BF16>(S.contrib, (size_t)slot, pitch, lane, w);
+                    }
                     cbv = (lane == off_cur + c) ? nbi - bi : cbv;
                     chain_axpy(tmp_fb, ti, lr2 * err * norm);          // update_svdpp (:512-520)
                     chain_scale(tmp_fb, 1.0f - lr2 * P.wd_ufeedback);
@@ -869,7 +876,10 @@ __global__ __launch_bounds__(64, (NR <= 2 ? 2 : 1)) void k_wunit_wave(   // two 
                     if (ub) bu = nbu;
                 }
             }
-            if (lane >= off_cur && lane < off_cur + PFW && j0 + (lane - off_cur) < nrow) S.cbias[rb.e.slot] = cbv;   // one store for the group
+            if (lane >= off_cur && lane < off_cur + PFW && j0 + (lane - off_cur) < nrow) {   // one store for the group
+                if (rb.e.slot < 0) P.bias[P.item_off + rb.e.idx] = apply_single(rb.bi, cbv, false);
+                else S.cbias[rb.e.slot] = cbv;
+            }
 #pragma unroll
             for (int c = 0; c < PFW; c++) cur[c] = nxt[c];
             rb = rb_pre;
@@ -894,14 +904,24 @@ __global__ __launch_bounds__(64, (NR <= 2 ? 2 : 1)) void k_wunit_wave(   // two 
                         chain_axpy(w2, dl, v);
 #pragma unroll
                         for (int q = 0; q < NR; q++) w2.r[q] = w2.r[q] - x.w[c].r[q];
-                        contrib_lin_store<NR, BF16>(S.contrib, (size_t)slot, pitch, lane, w2);
+                        if (slot < 0) {
+                            ChainRow<NR> a;
+#pragma unroll
+                            for (int q = 0; q < NR; q++) a.r[q] = apply_single(x.w[c].r[q], w2.r[q], BF16);
+                            lin_store<NR>(P.W, P.fb_off + pick(fb.e.idx, (j & 63) + c), pitch, lane, -1, a);
+                        } else {
+                            contrib_lin_store<NR, BF16>(S.contrib, (size_t)slot, pitch, lane, w2);
+                        }
                     }
                 }
             };
             auto scatter_bias = [&](const WaveFbBlock &fb, int first) {   // the block's bias contributions, one entry per lane: one store per block
                 float cb = 0.0f;
                 if (ub) { const float b2 = fb.b + db * fb.e.val; cb = b2 - fb.b; }
-                if (first + lane < nfb) S.cbias[fb.e.slot] = cb;
+                if (first + lane < nfb) {
+                    if (fb.e.slot < 0) P.bias[P.fb_off + fb.e.idx] = apply_single(fb.b, cb, false);
+                    else S.cbias[fb.e.slot] = cb;
+                }
             };
             WaveFbBlock fb = wave_fb_block(P, S, fb_begin, 0, fb_last, lane, ub), fb_next = wave_fb_block(P, S, fb_begin, 64, fb_last, lane, ub);
             WaveFbBatch<NR, FBW> A, B;

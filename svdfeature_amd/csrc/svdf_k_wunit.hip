@@ -98,8 +98,13 @@ __global__ __launch_bounds__(256) void k_wunit_walk(const DevParams P, const WUn
                 reg_row<LPI>(P, wi, get_wd(P.i_rng, e.idx, P.wd_item), true, L);
                 nbi = nbi * (1.0f - lr * P.wd_item_bias);
                 sub4(wi, q);
-                store_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)e.slot, pitch, L, k, wi);
-                if (L == 0) S.cbias[e.slot] = nbi - bi;
+                if (e.slot < 0) {   // the row's only contribution of this window: applied here (apply_single, svdf_device.h)
+                    store_row<LPI>(P.W, P.item_off + e.idx, pitch, L, k, apply_single(q, wi, S.contrib_bf16 != 0));
+                    if (L == 0) P.bias[P.item_off + e.idx] = apply_single(bi, nbi - bi, false);
+                } else {
+                    store_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)e.slot, pitch, L, k, wi);
+                    if (L == 0) S.cbias[e.slot] = nbi - bi;
+                }
             }
             if (FB) pp.update(P, err, ti, ub);
             reg_row<LPI>(P, wu, wd_u, false, L);
@@ -121,11 +126,14 @@ __global__ __launch_bounds__(256) void k_wunit_walk(const DevParams P, const WUn
                 float4 w2 = w;
                 axpy4(w2, d, f.val);
                 sub4(w2, w);
-                store_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)f.slot, pitch, L, k, w2);
+                if (f.slot < 0) store_row<LPI>(P.W, row, pitch, L, k, apply_single(w, w2, S.contrib_bf16 != 0));
+                else store_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)f.slot, pitch, L, k, w2);
                 if (L == 0) {
+                    const float b = (ub || f.slot < 0) ? P.bias[row] : 0.0f;
                     float cb = 0.0f;
-                    if (ub) { const float b = P.bias[row]; const float b2 = b + db * f.val; cb = b2 - b; }
-                    S.cbias[f.slot] = cb;
+                    if (ub) { const float b2 = b + db * f.val; cb = b2 - b; }
+                    if (f.slot < 0) P.bias[row] = apply_single(b, cb, false);
+                    else S.cbias[f.slot] = cb;
                 }
             }
         }
@@ -247,9 +255,13 @@ __global__ __launch_bounds__(256) void k_wunit_fast(const DevParams P, const WUn
                 axpy4(wi, tu[v], si);
                 reg_chunk(P, wi, wd_i, true);
                 sub4(wi, q[v]);
-                store_contrib<K / 4>(S.contrib, S.contrib_bf16, (size_t)ie.slot, pitch, m + v * LANES, K, wi);
+                if (ie.slot < 0) store_row<K / 4>(P.W, P.item_off + ie.idx, pitch, m + v * LANES, K, apply_single(q[v], wi, S.contrib_bf16 != 0));   // the row's only contribution of the window
+                else store_contrib<K / 4>(S.contrib, S.contrib_bf16, (size_t)ie.slot, pitch, m + v * LANES, K, wi);
             }
-            if (m == 0) S.cbias[ie.slot] = nbi - bi;
+            if (m == 0) {
+                if (ie.slot < 0) P.bias[P.item_off + ie.idx] = apply_single(bi, nbi - bi, false);
+                else S.cbias[ie.slot] = nbi - bi;
+            }
             if (FB) {   // update_svdpp (:512-520)
                 const float lr2 = lr * P.scale_lr_ufeedback;
 #pragma unroll
@@ -361,12 +373,14 @@ __global__ __launch_bounds__(256) void k_wunit_fast(const DevParams P, const WUn
                             float4 w2 = w[q][v];
                             axpy4(w2, d[v], f[q].val);
                             sub4(w2, w[q][v]);
-                            store_contrib<K / 4>(S.contrib, S.contrib_bf16, (size_t)f[q].slot, pitch, m + v * LANES, K, w2);
+                            if (f[q].slot < 0) store_row<K / 4>(P.W, P.fb_off + f[q].idx, pitch, m + v * LANES, K, apply_single(w[q][v], w2, S.contrib_bf16 != 0));
+                            else store_contrib<K / 4>(S.contrib, S.contrib_bf16, (size_t)f[q].slot, pitch, m + v * LANES, K, w2);
                         }
                         if (m == 0) {
                             float cb = 0.0f;
                             if (ub) { const float b2 = b[q] + db * f[q].val; cb = b2 - b[q]; }
-                            S.cbias[f[q].slot] = cb;
+                            if (f[q].slot < 0) { const float b0 = ub ? b[q] : P.bias[P.fb_off + f[q].idx]; P.bias[P.fb_off + f[q].idx] = apply_single(b0, cb, false); }
+                            else S.cbias[f[q].slot] = cb;
                         }
                     }
                 }

@@ -190,6 +190,14 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
             tptr[(size_t)f + 1]++;
         }
     }
+    // one-GPU window sequences: a row that meets exactly ONE contribution in this window gets no slot (slot -1): the unit applies it in place
+    // with the sum kernel's operations (apply_single, svdf_device.h) -- nobody else reads or writes that row inside the window
+    std::vector<unsigned char> single;
+    if (wunit_inplace_build_) {
+        single.assign((size_t)(NF + NI), 0);
+        for (size_t t = 0; t < (size_t)(NF + NI); t++) if (tptr[t + 1] == 1) { single[t] = 1; tptr[t + 1] = 0; }
+    }
+    auto take_slot = [&](std::vector<int> &cur, size_t t) { return (!single.empty() && single[t]) ? -1 : cur[t]++; };
     for (size_t t = 0; t < (size_t)(NF + NI); t++) tptr[t + 1] += tptr[t];
     for (size_t g = 0; g < (size_t)NG; g++) gptr[g + 1] += gptr[g];
     std::vector<int> tcur(tptr.begin(), tptr.end() - 1), gcur(gptr.begin(), gptr.end() - 1);
@@ -198,7 +206,7 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
         const int ng = (int)(row_ptr[3 * r + 1] - row_ptr[3 * r]);
         const int e0 = rptr[(size_t)2 * nr], e1 = e0 + ng, e2 = rptr[(size_t)2 * nr + 2];
         for (int e = e0; e < e1; e++) ent[(size_t)e].slot = gcur[ent[(size_t)e].idx]++;
-        for (int e = e1; e < e2; e++) ent[(size_t)e].slot = tcur[(size_t)NF + ent[(size_t)e].idx]++;
+        for (int e = e1; e < e2; e++) ent[(size_t)e].slot = take_slot(tcur, (size_t)NF + ent[(size_t)e].idx);
     };
     if (by_row_order) {
         for (long r = 0; r < num_src_row; r++) if (newrow_of_src[(size_t)r] >= 0) row_slots(newrow_of_src[(size_t)r]);
@@ -207,7 +215,7 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
             if (seg_new[s] < 0) continue;
             const WinSeg &w = wsegs[(size_t)seg_new[s]];
             for (int j = 0; j < w.row_count; j++) row_slots((long)w.row_begin + j);
-            for (int j = 0; j < w.fb_count; j++) fbent[(size_t)w.fb_begin + (size_t)j].slot = tcur[fbent[(size_t)w.fb_begin + (size_t)j].idx]++;
+            for (int j = 0; j < w.fb_count; j++) fbent[(size_t)w.fb_begin + (size_t)j].slot = take_slot(tcur, (size_t)fbent[(size_t)w.fb_begin + (size_t)j].idx);
         }
     }
     // rptr as the kernel reads it: rptr[2r], rptr[2r + 1], rptr[2r + 2] -- the odd entries are the global / item boundary of row r
@@ -384,6 +392,8 @@ Dataset *Engine::wseq_from_csr(long n, const float *row_label, const int64_t *ro
         const long b0 = n * w / W, b1 = n * (w + 1) / W;
         std::unique_ptr<Dataset> c(new Dataset());
         adopt(c.get());
+        wunit_inplace_build_ = wunit_inplace_ != 0;   // the window is summed in place right after its walk (wseq_train): single contributions need no slot
+        struct Off { bool &f; ~Off() { f = false; } } off{wunit_inplace_build_};
         wunit_fill_from_csr(c.get(), b1 - b0, row_label + b0, row_ptr + 3 * b0, feat_index, feat_value);
         ds->algorithmic_bytes += c->algorithmic_bytes; ds->num_units += c->num_units;
         ds->wchild.push_back(c.release());
@@ -437,6 +447,8 @@ Dataset *Engine::wseq_from_blocks(long num_block, const int *extend_tag, const i
     for (size_t w = 0; w + 1 < cut.size(); w++) {
         std::unique_ptr<Dataset> c(new Dataset());
         adopt(c.get());
+        wunit_inplace_build_ = wunit_inplace_ != 0;
+        struct Off { bool &f; ~Off() { f = false; } } off{wunit_inplace_build_};
         wunit_fill_from_blocks(c.get(), cut[w], cut[w + 1], extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
         ds->algorithmic_bytes += c->algorithmic_bytes; ds->num_units += c->num_units;
         ds->wchild.push_back(c.release());

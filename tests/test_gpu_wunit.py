@@ -226,6 +226,47 @@ def test_one_gpu_opt_in_minibatch_step_is_the_one_rank_simulation(shape):
         assert np.array_equal(t.view(name).view(np.uint32), sim[0].t.view(name).view(np.uint32)), name
 
 
+@pytest.mark.parametrize("shape,k,fast,contrib,extra", [
+    ("blocks", 128, 2, "fp32", ()), ("blocks", 64, 2, "bf16", ()), ("blocks", 128, 2, "fp32", (("no_user_bias", "1"),)), ("blocks", 128, 1, "bf16", ()),
+    ("blocks", 64, 1, "fp32", (("no_user_bias", "1"),)), ("blocks", 24, 2, "fp32", ()), ("blocks", 40, 0, "bf16", (("reg_method", "1"),)), ("blocks", 256, 2, "fp32", ()),
+    ("rows", 128, 2, "fp32", ()), ("rows", 64, 1, "bf16", ()), ("rows", 32, 2, "fp32", ()), ("rows", 128, 0, "fp32", ()), ("rows_ragged", 48, 2, "bf16", ())])
+def test_single_contributions_of_a_window_are_applied_in_place_with_the_same_bits(shape, k, fast, contrib, extra):
+    """one-GPU window sequences: a shared row that meets exactly one contribution in a window gets no slot -- the unit applies it where it
+    computes it, with the sum kernel's operations (apply_single).  Many more items than rows per window, so most contributions are single:
+    every unit kernel (lane groups, slots, one wave per unit), fp32 and bf16 contribution rows, with and without user bias == the one-rank
+    oracle simulation bit for bit == the same pass with every contribution through a slot (knob wunit_inplace = 0)"""
+    import multi_rank_utils
+    windows = 5
+    if shape == "blocks":
+        nu, ni = 300, 4000
+        data = BlockArrays.from_blocks(cases.user_blocks(280, nu, ni, ni, seed=k + fast, max_rows=30, max_fb=24, split_every=6))
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni) + SVDPP_EXTRA + list(extra)
+        fmt, names, window = 1, SVDPP_NAMES, -(-data.num_row // windows)
+    else:
+        nu, ni, ng, n = 900, 6000, 30, 6000
+        data = _rows_with_globals(n, nu, ni, ng, 4, seed=k + fast, fixed=(shape == "rows"))
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_global=ng, wd_global="0.001") + list(extra)
+        fmt, names, window = 0, ("W_item", "i_bias", "g_bias", "W_user", "u_bias"), n // windows
+    got = []
+    for inplace in (1, 0):
+        t = _trainer(conf, fmt, 0, [("amd:step", "minibatch"), ("amd:window", window), ("amd:contrib", contrib)], knobs=(("wunit_fast", fast), ("wunit_inplace", inplace)))
+        ds = t.dataset_from_blocks(data) if fmt == 1 else t.dataset_from_csr(data)
+        assert ds.kind == 8
+        for _ in range(2):
+            t.train_dataset(ds)
+        t.synchronize()
+        got.append({name: t.view(name).copy() for name in names})
+        nwin = ds.num_batches
+    multi_rank_utils.CONTRIB_BF16 = contrib == "bf16"
+    try:
+        sim = simulate(conf, data, None, None, 1, nwin, 2, fmt=fmt, minibatch=True)
+    finally:
+        multi_rank_utils.CONTRIB_BF16 = False
+    for name in names:
+        assert np.array_equal(got[0][name].view(np.uint32), got[1][name].view(np.uint32)), name
+        assert np.array_equal(got[0][name].view(np.uint32), sim[0].t.view(name).view(np.uint32)), name
+
+
 def test_malformed_windows_are_refused_with_messages():
     nu, ni = 50, 20
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=8, num_ufeedback=ni) + SVDPP_EXTRA
