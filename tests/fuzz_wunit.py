@@ -31,12 +31,16 @@ def rows_of(rng, n, users, ni, ng, max_g, two_items, uvals):
     return rows
 
 
-def one(rng, torch, wave=False):
+def one(rng, torch, wave=False, onegpu=False):
     """wave: the shapes k_wunit_wave takes (feedback blocks, fixed row layout without global entries, k = 64 NR) with long units -- up to 150
     rows and 140 feedback ids: several 64-record blocks, partial groups, partial batches"""
     world, windows, passes = int(rng.integers(1, 5)), int(rng.integers(1, 6)), int(rng.integers(1, 3))
+    if onegpu:
+        world = 1
     k = int(rng.choice([64, 128, 128, 192, 256])) if wave else int(rng.choice([4, 10, 16, 33, 64, 64, 100, 128, 128, 200]))
     nu, ni = int(rng.integers(world * 4, 500)), int(rng.integers(8, 200))
+    if onegpu and rng.random() < 0.6:
+        ni = int(rng.integers(500, 5000))   # many more items than rows per window: most contributions are the only one of their row (applied in place)
     ng = 0 if wave else int(rng.choice([0, 0, 6, 30]))
     blocks_mode = True if wave else bool(rng.integers(0, 2))
     fixed = True if wave else bool(rng.integers(0, 2))          # fixed row layout (slot kernel at k = 64 / 128) or ragged rows
@@ -97,6 +101,39 @@ def one(rng, torch, wave=False):
         fmt = 0
         conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_global=ng, wd_global=0.002, **extra)
         names = ("W_item", "i_bias", "W_user", "u_bias") + (("g_bias",) if ng else ())
+    if onegpu:   # `amd:step = minibatch` on one handle: a window sequence (kind 8) against the one-rank simulation with the same cuts
+        nrows = data.num_row
+        t = sa.Trainer(fmt, active)
+        t.seed(10)
+        for kk, v in conf + [("amd:step", "minibatch"), ("amd:window", max(1, -(-nrows // windows)))] + ([("amd:contrib", "bf16")] if bf16 else []):
+            t.set_param(kk, str(v))
+        t.init_model()
+        t.init_trainer()
+        inplace = int(rng.integers(0, 4) != 0)
+        for kk, v in knobs + [("wunit_inplace", inplace)]:
+            t.set_knob(kk, v)
+        ds = t.dataset_from_blocks(data) if blocks_mode else t.dataset_from_csr(data)
+        for _ in range(passes):
+            t.train_dataset(ds)
+        t.synchronize()
+        multi_rank_utils.CONTRIB_BF16 = bf16
+        try:
+            sim = simulate(conf, data, None, None, 1, ds.num_batches, passes, fmt=fmt, active=active, minibatch=True)
+        finally:
+            multi_rank_utils.CONTRIB_BF16 = False
+        ok = True
+        for name in names:
+            a, b = t.view(name), sim[0].t.view(name)
+            both_nan = np.isnan(a) & np.isnan(b)
+            if not np.array_equal(np.where(both_nan, 0, a.view(np.uint32)), np.where(both_nan, 0, b.view(np.uint32))):
+                ok = False
+                if os.environ.get("FUZZ_WUNIT_DEBUG"):
+                    bad = np.argwhere(a.view(np.uint32) != b.view(np.uint32))
+                    print("  differs:", name, "elements", len(bad), "of", a.size, "first", bad[:6].tolist(), flush=True)
+        desc = dict(onegpu=True, windows=ds.num_batches, passes=passes, k=k, nu=nu, ni=ni, ng=ng, blocks=blocks_mode, fixed=fixed, active=active, extra=extra, bf16=bf16, knobs=knobs, inplace=inplace)
+        ds.close()
+        t.close()
+        return ok, desc
     dev = torch.device("cuda", 0)
     ranks = []
     for rk in range(world):
@@ -158,11 +195,12 @@ def main():
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--wave", action="store_true", help="only the shapes the one-wave-per-unit kernel takes, long units")
+    ap.add_argument("--one-gpu", action="store_true", help="amd:step = minibatch window sequences on one handle (single contributions applied in place)")
     a = ap.parse_args()
     rng = np.random.default_rng(a.seed)
     tot = dict(iters=0, exact=0, failed=0)
     for it in range(a.iters):
-        ok, desc = one(rng, torch, a.wave)
+        ok, desc = one(rng, torch, a.wave, a.one_gpu)
         tot["iters"] += 1
         if ok:
             tot["exact"] += 1
