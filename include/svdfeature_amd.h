@@ -279,7 +279,11 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  * "device_rank" (0 = draw rank pairs with the host sampler; same pairs), "load_mode" (row gathers: 0 plain, 1 nontemporal hint,
  * 2 = by row size), "basic_i8" / "fewrow_i16" (0 = the lane-group layout instead of several chunks per lane in the specialised
  * basicMF / few-row kernels), "svdpp_helpers" (waves per user in the SVD++ kernel: 1, 4, 8, 16), "svdpp_xunits" (0 = no launch
- * records), "small_blocks" (0 = 256-thread workgroups also for small levels).  Returns 0 if the knob exists.
+ * records), "small_blocks" (0 = 256-thread workgroups also for small levels), "fewrow_gslots" (0 = the general few-row kernel for rows with
+ * inline global slots); the window-minibatch step for user units: "wunit_fast" (0 = lane groups for every shape, 1 = + the slot kernel,
+ * 2 = + one wave per user unit: default), "wunit_inplace" (one-GPU window sequences: 0 = every contribution through a slot, default 1 = a
+ * row's only contribution of a window applied in place; same bits), "window_per_target" / "window_per_target_fb" (updates a shared row
+ * meets per window when `amd:window` is not set: these two DO change the opt-in step's windows, hence its result).  Returns 0 if the knob exists.
  * The relaxed mode itself is switched by CONFIG keys through svdf_set_param ("amd:relax_global",
  * "amd:relax_user_from", "amd:relax_item_from", "amd:relax_feedback"), not by knobs: it changes results. */
 int svdf_set_knob(svdf_trainer *t, const char *name, long value);
