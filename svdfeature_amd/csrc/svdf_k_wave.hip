@@ -725,6 +725,8 @@ template <int NR, bool BF16> __device__ __forceinline__ void contrib_lin_store(f
         }
     }
 }
+static_assert(sizeof(WinUnit) == 32 && sizeof(WinSeg) == 16 && sizeof(WinEnt) == 16 && offsetof(WinUnit, first) == 16,
+              "k_wunit_wave reads unit and segment records as 16-byte words");
 // a 64-entry block of a feedback list, one entry per lane (entries past the list repeat its last one), with the entry's feedback-bias word
 struct WaveFbBlock { WinEnt e; float b; };
 __device__ __forceinline__ WaveFbBlock wave_fb_block(const DevParams &P, const WUnitSchedule &S, int fb_begin, int first, int fb_last, int lane, bool) {
