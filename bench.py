@@ -318,8 +318,12 @@ def make_trainer(sa, name, a, factor, device, oracle_kind=None, extra=()):
     t.seed(10)   # svd_feature.cpp:293
     for k, v in list(workload_conf(name, a, factor)) + list(extra):
         t.set_param(k, v)
+    t0 = time.perf_counter()
     t.init_model()
+    t1 = time.perf_counter()
     t.init_trainer()
+    # SVDModel::rand_init: on the device since round 4 (svdf_k_init.hip); the oracle trainers run the reference's own loop
+    t.init_model_s, t.init_trainer_s = t1 - t0, time.perf_counter() - t1
     return t
 
 
@@ -761,6 +765,10 @@ def run_workload(name, a, env, steps, warmup, main_line):
             # end to end: what a training run of `rounds` passes sees when the one-off schedule build is counted in
             "end_to_end": {"rounds": 40, "value": 40 * n / (sched_s + 40 * elapsed / steps), "unit": unit,
                            "what": "40 passes (demo/basicMF num_round) + the one-off schedule build + upload of this run"},
+            # SVDModel::rand_init of this run's model: on the device (svdf_k_init.hip), the reference's draws and values bit for bit
+            # (the in-run parity above starts the reference's classes from their own rand_init: equal results = equal start)
+            "init_model": {"seconds": getattr(tr, "init_model_s", None), "rand_draws": tr.counter(14), "values_decided_by_host_libm": tr.counter(13),
+                           "where": "device" if tr.counter(14) > 0 else "host loop"},
         }
         res.update(quality)
     if use_ipc:
@@ -1414,7 +1422,7 @@ def main():
         }
         for k in ("rmse_test_after_run", "passes_before_rmse", "rmse_sequential_reference", "rmse_minus_sequential", "exchange", "phase_ms",
                   "per_rank_ms", "roofline_aggregate", "model_ms",
-                  "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound", "launch_model"):
+                  "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound", "launch_model", "init_model"):
             if m.get(k) is not None:
                 out[k] = m[k]
         if world > 1:

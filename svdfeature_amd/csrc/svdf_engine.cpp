@@ -390,9 +390,142 @@ void Engine::rand_init() {  // SVDModel::rand_init apex_svd_model.h:665-705
         sample_gaussian(hW_.data() + (size_t)fb_off_ * pitch_, num_fb_rows(), k, pitch_, mp_.ufeedback_init_sigma);
 }
 
+// SVDModel::rand_init on the device (svdf_k_init.hip): the same draws, the same accepted attempts, the same float products; the few
+// values whose double sits within `margin` of a float rounding boundary are recomputed here with the host libm (the one function the
+// device cannot restate) and patched.  Leaves the model in HBM (no host copy) and libc's generator where the reference's calls would
+// have left it.  Returns false -- nothing touched -- when the path does not apply: libc's generator not in its 31-word mode, or a
+// feedback space that aliases the user rows (W_ufeedback is then written over W_user in sequence).
+bool Engine::rand_init_device() {
+    if (host_only_ || !device_init_) return false;
+    compute_geometry();
+    if (user_group() && mp_.common_feedback_space != 0) return false;
+    LibcRand s0;
+    if (!libc_rand_capture(s0)) return false;
+    const int k = mp_.num_factor;
+    InitPlan plan;
+    memset(&plan, 0, sizeof(plan));
+    plan.pitch = pitch_;
+    plan.margin = std::ldexp(1.0, -device_init_margin_log2_);
+    long total = 0;
+    auto add = [&](long rows, unsigned row0, float sigma, bool absf) {
+        InitSeg &g = plan.seg[plan.nseg++];
+        g.begin = total; g.count = rows * (long)k; g.row0 = (long)row0; g.k = std::max(k, 1); g.sigma = sigma; g.absf = absf ? 1 : 0;
+        total += g.count;
+    };
+    add(mp_.num_randinit_ufactor != 0 ? mp_.num_randinit_ufactor : mp_.num_user, user_off_, mp_.u_init_sigma, mp_.user_nonnegative != 0);
+    if (mp_.common_latent_space == 0)
+        add(mp_.num_randinit_ifactor != 0 ? mp_.num_randinit_ifactor : mp_.num_item, item_off_, mp_.i_init_sigma, mp_.item_nonnegative != 0);
+    if (user_group()) add(num_fb_rows(), fb_off_, mp_.ufeedback_init_sigma, false);
+    for (int g = plan.nseg; g < 3; g++) plan.seg[g].begin = total;
+    plan.total = total;
+    for (int g = 0; g < plan.nseg; g++)
+        check(plan.seg[g].count >= 0 && plan.seg[g].row0 * (long)pitch_ + (plan.seg[g].count / std::max(k, 1)) * (long)pitch_ <= (long)n_uiset_ * pitch_,
+              "init_model: num_randinit_ufactor / num_randinit_ifactor exceed the matrix");
+    need_device("init_model");
+    mp_.base_score = calc_base_score(mp_.base_score, mtype_.active_type);
+    dW_.reserve(std::max<size_t>((size_t)n_uiset_ * pitch_, 1));
+    HIPCHECK(hipMemsetAsync(dW_.p, 0, (size_t)n_uiset_ * pitch_ * sizeof(float), stream_));
+    n_init_reports_ = 0;
+    if (total > 0) {
+        const long TILE = 1L << 25, C = 16384;   // attempts per tile (256 MB of raw draws), draws per jump-ahead chunk
+        const int report_cap = 1 << 20;
+        DevBuf<unsigned> raw, flag, off, tables;
+        DevBuf<char> tmp;
+        DevBuf<unsigned long long> state;
+        DevBuf<InitReport> reports;
+        state.reserve(4); reports.reserve((size_t)report_cap);
+        HIPCHECK(hipMemsetAsync(state.p, 0, 4 * sizeof(unsigned long long), stream_));
+        long accepted = 0, draws_total = 0;
+        LibcRand cur = s0, after = s0;
+        std::vector<uint32_t> htab;
+        for (bool done = false; !done;) {
+            const long need = total - accepted;
+            const long A = std::min<long>(TILE, (long)((double)need / 0.78539816339744831) + 8 * (long)std::sqrt((double)need) + 4096);
+            const long D = 2 * A, nchunks = (D + C - 1) / C;
+            libc_rand_chunk_states(cur, nchunks, C, htab);
+            tables.upload(htab.data(), htab.size(), stream_);
+            raw.reserve((size_t)D); flag.reserve((size_t)A); off.reserve((size_t)A);
+            const size_t tb = init_scan_tmp_bytes(A);
+            tmp.reserve(std::max<size_t>(tb, 1));
+            launch_init_expand(tables.p, nchunks, C, D, raw.p, stream_);
+            HIPCHECK(hipMemsetAsync(state.p, 0, 2 * sizeof(unsigned long long), stream_));
+            launch_init_tile(raw.p, A, accepted, plan, dW_.p, flag.p, off.p, tmp.p, tb, state.p, reports.p, report_cap, stream_);
+            unsigned long long hs[4];
+            HIPCHECK(hipMemcpyAsync(hs, state.p, sizeof(hs), hipMemcpyDeviceToHost, stream_));
+            HIPCHECK(hipStreamSynchronize(stream_));
+            long used = D;   // draws of this tile that the reference's loop would have taken
+            if (hs[1] != 0) { used = 2 * (long)hs[1]; done = true; }
+            else { accepted += (long)hs[0]; check((long)hs[0] > 0, "init_model: the device sampler made no progress"); }
+            LibcRand nxt = cur;
+            if (used >= 31) {
+                HIPCHECK(hipMemcpyAsync(nxt.x, raw.p + (used - 31), 31 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+                HIPCHECK(hipStreamSynchronize(stream_));
+            } else {
+                uint32_t head[31];
+                HIPCHECK(hipMemcpyAsync(head, raw.p, (size_t)used * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+                HIPCHECK(hipStreamSynchronize(stream_));
+                for (long j = 0; j < 31 - used; j++) nxt.x[j] = cur.x[used + j];
+                for (long j = 0; j < used; j++) nxt.x[31 - used + j] = head[j];
+            }
+            cur = nxt; after = nxt;
+            draws_total += used;
+            n_init_reports_ = (int64_t)hs[2];
+        }
+        // values near a float rounding boundary: the host libm decides (apex_random.h:67-77 as written)
+        check(n_init_reports_ <= report_cap, "init_model: too many values near a rounding boundary were reported (device_init_margin_log2 too small)");
+        if (n_init_reports_ > 0) {
+            std::vector<InitReport> rep((size_t)n_init_reports_);
+            HIPCHECK(hipMemcpyAsync(rep.data(), reports.p, rep.size() * sizeof(InitReport), hipMemcpyDeviceToHost, stream_));
+            HIPCHECK(hipStreamSynchronize(stream_));
+            std::vector<long> pidx(rep.size());
+            std::vector<float> pval(rep.size());
+            for (size_t q = 0; q < rep.size(); q++) {
+                const double x = 2 * (((double)(int)(rep[q].r1 >> 1) + 1.0) / ((double)RAND_MAX + 2.0)) - 1.0;
+                const double y = 2 * (((double)(int)(rep[q].r2 >> 1) + 1.0) / ((double)RAND_MAX + 2.0)) - 1.0;
+                const double sq = x * x + y * y;
+                const double v = x * sqrt(-2.0 * log(sq) / sq);
+                int g = 0;
+                while (g + 1 < plan.nseg && rep[q].j >= plan.seg[g + 1].begin) g++;
+                const InitSeg &sg = plan.seg[g];
+                const long jj = rep[q].j - sg.begin, row = jj / sg.k, col = jj - row * sg.k;
+                float w = (float)v * sg.sigma;
+                if (sg.absf) w = fabsf(w);
+                pidx[q] = (sg.row0 + row) * (long)pitch_ + col;
+                pval[q] = w;
+            }
+            DevBuf<long> didx;
+            DevBuf<float> dval;
+            didx.upload(pidx.data(), pidx.size(), stream_);
+            dval.upload(pval.data(), pval.size(), stream_);
+            launch_init_patch((long)pidx.size(), didx.p, dval.p, dW_.p, stream_);
+            HIPCHECK(hipStreamSynchronize(stream_));
+        }
+        libc_rand_restore(after);   // libc's generator moves on by exactly the draws of the reference's loop
+        n_init_draws_ = draws_total;
+    }
+    // the rest of a fresh model: biases and global biases 0 (apex_svd_model.h:666-667), the kernels' state words 0
+    dbias_.reserve(std::max<size_t>((size_t)n_uiset_, 1));
+    HIPCHECK(hipMemsetAsync(dbias_.p, 0, std::max<size_t>((size_t)n_uiset_, 1) * sizeof(float), stream_));
+    g_stride_ = wanted_g_stride();
+    dg_.reserve(std::max<size_t>((size_t)mp_.num_global * (size_t)g_stride_, 1));
+    HIPCHECK(hipMemsetAsync(dg_.p, 0, std::max<size_t>((size_t)mp_.num_global * (size_t)g_stride_, 1) * sizeof(float), stream_));
+    std::vector<float> zero(imfb() ? (size_t)4 + IMFB_DEPTH_MAX * ((size_t)2 * pitch_ + 4) : (size_t)2 * pitch_ + 4, 0.0f);
+    dstate_.upload(zero.data(), zero.size(), stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    device_model_ = true;
+    params_dirty_ = true;
+    hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hbias_.shrink_to_fit(); hg_.clear();
+    host_model_valid_ = false;
+    return true;
+}
+
 void Engine::init_model() {  // apex_svd_base.h:146-149
-    alloc_host_model();
-    rand_init();
+    if (rand_init_device()) {
+        if (gpus_ > 1) download_model();   // the other ranks of an amd:gpus handle start from a host copy of rank 0's model
+    } else {
+        alloc_host_model();
+        rand_init();
+    }
     if (bilinear()) {   // BModel::alloc_space (apex_svd_bilinear.h:49-54, :202-205): W_bi[num_item][num_bi_feedback] = 0
         check(bi_param_.num_bi_feedback >= 0, "num_bi_feedback must not be negative");
         hbi_.assign((size_t)mp_.num_item * (size_t)bi_param_.num_bi_feedback, 0.0f);
@@ -400,7 +533,7 @@ void Engine::init_model() {  // apex_svd_base.h:146-149
     }
     multi_setup();
     multi_copy_model_to_peers();
-    if (device_model_) {
+    if (device_model_ && host_model_valid_) {   // a host-built model (or the host copy an amd:gpus handle starts its ranks from) replaces what the device held
         if (multi_) for (int d = 1; d < gpus_; d++) { Engine *e = rank_engine(d); if (e->device_model_) { HIPCHECK(hipSetDevice(e->device_)); e->upload_model(); } }
         HIPCHECK(hipSetDevice(device_));
         upload_model();
@@ -2855,6 +2988,8 @@ int64_t Engine::counter(int what) const {
     case 10: return multi_counter(2);   // 1 when every rank has a device of its own
     case 11: return multi_counter(3);   // exchange windows trained with the window-minibatch step
     case 12: return multi_counter(4);   // exchange path: 0 p2p, 1 rccl
+    case 13: return n_init_reports_;    // init_model on the device: values the host libm decided (near a float rounding boundary)
+    case 14: return n_init_draws_;      // init_model on the device: rand() draws consumed
     default: return -1;
     }
 }
@@ -2885,6 +3020,8 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "use_fused")) { use_fused_ = value != 0; return 0; }
     if (!strcmp(name, "device_schedule")) { device_sched_ = value != 0; return 0; }
     if (!strcmp(name, "device_rank")) { device_rank_ = value != 0; return 0; }
+    if (!strcmp(name, "device_init")) { device_init_ = value != 0; return 0; }
+    if (!strcmp(name, "device_init_margin_log2")) { check(value >= 8 && value <= 52, "device_init_margin_log2 must be in 8 .. 52"); device_init_margin_log2_ = (int)value; return 0; }
     if (!strcmp(name, "fewrow_fast")) { fewrow_fast_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "device_schedule_min")) { check(value >= 1, "device_schedule_min must be >= 1"); device_sched_min_ = value; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }

@@ -368,6 +368,7 @@ class Engine {
     bool host_model_valid_ = false;
     void alloc_host_model();
     void rand_init();
+    bool rand_init_device();
     void upload_model();
     void download_model();
     void read_model(FILE *fi);
@@ -449,6 +450,9 @@ class Engine {
     bool rank_pass_device_general(const char *path, UserGroupArrays &g);   // any row shape / method: the pass drawn in HBM, blocks back in g
     std::unique_ptr<RankSource> rank_source_;
     bool device_rank_ = true;                       // knob "device_rank"
+    bool device_init_ = true;                       // knob "device_init": rand_init on the device (svdf_k_init.hip)
+    int device_init_margin_log2_ = 46;              // knob "device_init_margin_log2": values closer than 2^-this (relative) to a float rounding boundary go to the host libm
+    int64_t n_init_reports_ = 0, n_init_draws_ = 0;
     bool fewrow_fast_ = true;                       // knob "fewrow_fast": specialised few-row kernel (svdf_k_fewrow.hip)
     // columns that are already in HBM (file order) -> level schedule + level-sorted copies
     Dataset *dataset_fewrow_on_device(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);

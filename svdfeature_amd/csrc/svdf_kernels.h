@@ -137,6 +137,15 @@ void launch_gpair_write(const RankRowsDev &S, const GSamplerParams &sp, long npa
 void device_exclusive_scan_i32(const int *in, int *out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st);
 void host_sort_by_label(const float *label, long n, int *ids);   // the restated std::sort (svdf_stdsort.h) on the host, for tests
 void launch_rand_expand(const unsigned *tables, long nchunks, long C, long D, unsigned *raw, hipStream_t st);
+// ---- SVDModel::rand_init on the device (svdf_k_init.hip): the j-th matrix element is the j-th accepted attempt of the polar loop
+struct InitSeg { long begin, count; long row0; int k; float sigma; int absf; };   // elements [begin, begin + count) -> rows row0.. of W, k per row
+struct InitPlan { InitSeg seg[3]; int nseg; long total; int pitch; double margin; };
+struct InitReport { long j; unsigned r1, r2; };   // an element whose double lies within `margin` of a float rounding boundary, with its two raw draws
+void launch_init_expand(const unsigned *tables, long nchunks, long C, long D, unsigned *raw, hipStream_t st);
+size_t init_scan_tmp_bytes(long A);
+void launch_init_patch(long n, const long *idx, const float *val, float *W, hipStream_t st);
+void launch_init_tile(const unsigned *raw, long A, long base, const InitPlan &plan, float *W, unsigned *flag, unsigned *off, void *tmp, size_t tmp_bytes,
+                      unsigned long long *state, InitReport *reports, int report_cap, hipStream_t st);
 void launch_sample_counts(const RankSourceDev &S, const SamplerParams &sp, long *draws, long *pairs, hipStream_t st);
 void launch_sample_posneg(const RankSourceDev &S, const SamplerParams &sp, const long *draw_off, const long *pair_off, const unsigned *raw,
                           int *pos_list, int *neg_list, const PairColumns &out, hipStream_t st);
