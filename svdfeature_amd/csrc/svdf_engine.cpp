@@ -2396,6 +2396,7 @@ void Engine::window_build(Dataset *ds, long n, const unsigned *user, const unsig
     ds->num_row = n; ds->kind = 5;
     ds->win_slots = pairs ? 2 * n : n;
     ds->fused.max_ni = pairs ? 2 : 1;
+    if (window_build_device(ds, n, user, item, label, neg)) return;
     std::vector<int> ucnt((size_t)NU, 0), iptr((size_t)NI + 1, 0);
     for (long r = 0; r < n; r++) {
         if (user[r] >= (unsigned)NU) fail("user feature index exceed bound");
@@ -2464,6 +2465,48 @@ void Engine::window_build(Dataset *ds, long n, const unsigned *user, const unsig
     ds->sched.max_level_size = n;
     const long nrow_touched = pairs ? 3 : 2, nb = (mp_.no_user_bias ? 0 : 1) + (pairs ? 2 : 1);
     ds->algorithmic_bytes = n * (8L * mp_.num_factor * nrow_touched + 8 * nb + 16 + 8 * nrow_touched);   // SURVEY 8(d4), what the reference's step moves per instance
+}
+// The same arrays from the device (svdf_k_wbuild.hip): the window's columns go up as they are, three stable sorts and two scans regroup them
+// in HBM.  false = not taken (host-only handle, knob device_window = 0, an empty window): the host builder above runs.
+bool Engine::window_build_device(Dataset *ds, long n, const unsigned *user, const unsigned *item, const float *label, const unsigned *neg) {
+    if (host_only_ || !device_window_ || n <= 0) return false;
+    need_device("dataset");
+    const long NU = mp_.num_user, NI = mp_.num_item;
+    const bool pairs = neg != nullptr;
+    const long E = pairs ? 2 * n : n;
+    wb_user_.upload(user, (size_t)n, stream_);
+    wb_item_.upload(item, (size_t)n, stream_);
+    if (pairs) wb_neg_.upload(neg, (size_t)n, stream_); else wb_label_.upload(label, (size_t)n, stream_);
+    wb_k0_.reserve((size_t)E); wb_k1_.reserve((size_t)E); wb_v0_.reserve((size_t)E); wb_v1_.reserve((size_t)E);
+    wb_inst_.reserve((size_t)n); wb_slot_e_.reserve((size_t)E); wb_head_.reserve((size_t)n); wb_mark_.reserve((size_t)n);
+    wb_run_user_.reserve((size_t)n); wb_run_start_.reserve((size_t)n); wb_run_begin_.reserve((size_t)n);
+    wb_state_.reserve(8);
+    const size_t tb = wbuild_tmp_bytes(E);
+    wb_tmp_.reserve(std::max<size_t>(tb, 1));
+    ds->win_urec.reserve((size_t)std::min<long>(n, std::max<long>(NU, 1)));
+    ds->item.reserve((size_t)n); ds->win_slot.reserve((size_t)n); ds->win_iptr.reserve((size_t)NI + 1);
+    if (!pairs) { ds->label.reserve((size_t)n); ds->win_item1.release(); }
+    else { ds->win_item1.reserve((size_t)n); ds->win_slot1.reserve((size_t)n); ds->ival.reserve((size_t)n); ds->win_ival1.reserve((size_t)n); }
+    WBuildIn in{n, pairs ? 1 : 0, wb_user_.p, wb_item_.p, pairs ? wb_neg_.p : nullptr, pairs ? nullptr : wb_label_.p, NU, NI};
+    WBuildBuffers B{wb_k0_.p, wb_k1_.p, wb_v0_.p, wb_v1_.p, wb_inst_.p, wb_slot_e_.p, wb_head_.p, wb_mark_.p, wb_run_user_.p, wb_run_start_.p, wb_run_begin_.p,
+                    wb_tmp_.p, tb, wb_state_.p};
+    WBuildOut out{ds->win_urec.p, ds->item.p, pairs ? ds->win_item1.p : nullptr, pairs ? nullptr : ds->label.p, pairs ? ds->ival.p : nullptr,
+                  pairs ? ds->win_ival1.p : nullptr, ds->win_slot.p, pairs ? ds->win_slot1.p : nullptr, ds->win_iptr.p};
+    long nact = 0, lo = 0, hi = -1;
+    try {
+        device_window_build(in, B, out, &nact, &lo, &hi, stream_);
+    } catch (const std::runtime_error &e) {
+        fail(e.what());
+    }
+    ds->sched_signature = schedule_signature();
+    ds->win_item_lo = lo; ds->win_item_hi = hi;
+    ds->unit_values = true;
+    ds->num_units = nact;
+    ds->sched.level_ptr = {0, n};
+    ds->sched.max_level_size = n;
+    const long nrow_touched = pairs ? 3 : 2, nb = (mp_.no_user_bias ? 0 : 1) + (pairs ? 2 : 1);
+    ds->algorithmic_bytes = n * (8L * mp_.num_factor * nrow_touched + 8 * nb + 16 + 8 * nrow_touched);   // SURVEY 8(d4), as in the host builder
+    return true;
 }
 void Engine::window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t *count) {
     check(trainer_ready_, "window_delta: init_trainer has not been called");
@@ -3021,6 +3064,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "device_schedule")) { device_sched_ = value != 0; return 0; }
     if (!strcmp(name, "device_rank")) { device_rank_ = value != 0; return 0; }
     if (!strcmp(name, "device_init")) { device_init_ = value != 0; return 0; }
+    if (!strcmp(name, "device_window")) { device_window_ = value != 0; return 0; }
     if (!strcmp(name, "device_init_margin_log2")) { check(value >= 8 && value <= 52, "device_init_margin_log2 must be in 8 .. 52"); device_init_margin_log2_ = (int)value; return 0; }
     if (!strcmp(name, "fewrow_fast")) { fewrow_fast_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "device_schedule_min")) { check(value >= 1, "device_schedule_min must be >= 1"); device_sched_min_ = value; return 0; }

@@ -450,6 +450,7 @@ class Engine {
     bool rank_pass_device_general(const char *path, UserGroupArrays &g);   // any row shape / method: the pass drawn in HBM, blocks back in g
     std::unique_ptr<RankSource> rank_source_;
     bool device_rank_ = true;                       // knob "device_rank"
+    bool device_window_ = true;                     // knob "device_window": kind-5 window data sets regrouped on the device (svdf_k_wbuild.hip)
     bool device_init_ = true;                       // knob "device_init": rand_init on the device (svdf_k_init.hip)
     int device_init_margin_log2_ = 46;              // knob "device_init_margin_log2": values closer than 2^-this (relative) to a float rounding boundary go to the host libm
     int64_t n_init_reports_ = 0, n_init_draws_ = 0;
@@ -511,6 +512,12 @@ class Engine {
     UnitDev w_unitdev_;
     // ---- item delta
     DevBuf<float> d_snap_, d_delta_;
+    // scratch of the device window builder (svdf_k_wbuild.hip), grow-only: the window's columns as handed over + sort / scan buffers
+    DevBuf<unsigned> wb_user_, wb_item_, wb_neg_, wb_k0_, wb_k1_, wb_v0_, wb_v1_, wb_inst_, wb_state_;
+    DevBuf<float> wb_label_;
+    DevBuf<int> wb_slot_e_, wb_head_, wb_mark_, wb_run_user_, wb_run_start_, wb_run_begin_;
+    DevBuf<char> wb_tmp_;
+    bool window_build_device(Dataset *ds, long n, const unsigned *user, const unsigned *item, const float *label, const unsigned *neg);
     DevBuf<float> d_contrib_, d_cbias_;   // window-minibatch scratch: one contribution row + bias word per instance of the largest window
     std::unique_ptr<IpcState, IpcDeleter> ipc_;
     void ipc_check(const char *what);

@@ -137,6 +137,21 @@ void launch_gpair_write(const RankRowsDev &S, const GSamplerParams &sp, long npa
 void device_exclusive_scan_i32(const int *in, int *out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st);
 void host_sort_by_label(const float *label, long n, int *ids);   // the restated std::sort (svdf_stdsort.h) on the host, for tests
 void launch_rand_expand(const unsigned *tables, long nchunks, long C, long D, unsigned *raw, hipStream_t st);
+// ---- window data sets of plain ratings / rank pairs (kind 5) regrouped on the device (svdf_k_wbuild.hip): the arrays of Engine::window_build.
+// All pointers are device pointers; E = n (ratings) or 2 n (pairs) item entries.
+struct WBuildIn { long n; int pairs; const unsigned *user, *item, *neg; const float *label; long num_user, num_item; };
+struct WBuildBuffers {
+    unsigned *k0, *k1, *v0, *v1;   // [E] sort ping-pong
+    unsigned *inst;                // [n] instances in (user, file order)
+    int *slot_e;                   // [E] slot of every item entry
+    int *head, *mark;              // [n]
+    int *run_user, *run_start, *run_begin;   // [n]
+    void *tmp; size_t tmp_bytes;   // wbuild_tmp_bytes(E)
+    unsigned *state;               // [8]
+};
+struct WBuildOut { WinUser *urec; unsigned *item, *item1; float *label, *v0, *v1; int *slot, *slot1, *iptr; };
+size_t wbuild_tmp_bytes(long m);
+void device_window_build(const WBuildIn &in, const WBuildBuffers &B, const WBuildOut &out, long *nact, long *item_lo, long *item_hi, hipStream_t st);
 // ---- SVDModel::rand_init on the device (svdf_k_init.hip): the j-th matrix element is the j-th accepted attempt of the polar loop
 struct InitSeg { long begin, count; long row0; int k; float sigma; int absf; };   // elements [begin, begin + count) -> rows row0.. of W, k per row
 struct InitPlan { InitSeg seg[3]; int nseg; long total; int pitch; double margin; };
