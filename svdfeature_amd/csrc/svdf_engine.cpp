@@ -3065,6 +3065,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "device_rank")) { device_rank_ = value != 0; return 0; }
     if (!strcmp(name, "device_init")) { device_init_ = value != 0; return 0; }
     if (!strcmp(name, "device_window")) { device_window_ = value != 0; return 0; }
+    if (!strcmp(name, "wseq_build_threads")) { check(value >= 1 && value <= 256, "wseq_build_threads must be in 1 .. 256"); wseq_build_threads_ = (int)value; return 0; }
     if (!strcmp(name, "device_init_margin_log2")) { check(value >= 8 && value <= 52, "device_init_margin_log2 must be in 8 .. 52"); device_init_margin_log2_ = (int)value; return 0; }
     if (!strcmp(name, "fewrow_fast")) { fewrow_fast_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "device_schedule_min")) { check(value >= 1, "device_schedule_min must be >= 1"); device_sched_min_ = value; return 0; }

@@ -137,6 +137,7 @@ struct RankRow {
 };
 
 // libc rand() as a random-access stream (svdf_randstream.cpp): the generator's last 31 values, oldest first
+struct WUnitHost;   // one window's host-built arrays of the user-unit step (svdf_wunit.cpp)
 struct LibcRand { uint32_t x[31]; char *handle = nullptr; };
 bool libc_rand_capture(LibcRand &s);
 void libc_rand_restore(const LibcRand &s);
@@ -529,6 +530,14 @@ class Engine {
     void wunit_build(Dataset *ds, const void *segs, size_t nseg, const std::vector<int64_t> &seg_rows, bool by_row_order, long num_src_row,
                      const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value,
                      const unsigned *fb_index, const float *fb_value);
+    void wunit_build_host(WUnitHost &H, bool inplace, const void *segs, size_t nseg, const std::vector<int64_t> &seg_rows, bool by_row_order, long num_src_row,
+                          const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value,
+                          const unsigned *fb_index, const float *fb_value) const;
+    void wunit_adopt(Dataset *ds, const WUnitHost &H);
+    void wunit_host_from_csr(WUnitHost &H, bool inplace, long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) const;
+    void wunit_host_from_blocks(WUnitHost &H, bool inplace, long b0, long b1, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
+                                const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) const;
+    int wseq_build_threads_ = 32;         // knob "wseq_build_threads": host threads building the windows of a one-GPU window sequence (user units)
     void wunit_fill_from_csr(Dataset *ds, long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
     void wunit_fill_from_blocks(Dataset *ds, long b0, long b1, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
                                 const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <numeric>
 #include <string>
+#include <thread>
 
 #include "svdf_engine.h"
 #include "svdf_kernels.h"
@@ -31,6 +32,19 @@ struct HostSeg {
     bool has_user = false;
 };
 }  // namespace
+
+// what one window's host build produces (wunit_build_host) and wunit_adopt uploads: plain arrays, so that the windows of a sequence can be
+// built by several host threads at once (they share nothing but the caller's read-only columns)
+struct WUnitHost {
+    std::vector<WinUnit> units;
+    std::vector<WinSeg> wsegs;
+    std::vector<float> w_label, w_uval;
+    std::vector<int> rptr, tptr, gptr;
+    std::vector<WinEnt> ent, fbent;
+    long nrow = 0, nent = 0, nfbe = 0, item_entries = 0, global_entries = 0;
+    int fixed_ng = -2;
+    bool unit_uval = true, feedback = false;
+};
 
 WUnitSchedule Engine::wunit_view(const Dataset *ds) const {
     WUnitSchedule S;
@@ -65,13 +79,17 @@ void Engine::wunit_check_config(const char *what) const {
 void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std::vector<int64_t> &seg_rows, bool by_row_order, long num_src_row,
                          const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value,
                          const unsigned *fb_index, const float *fb_value) {
+    WUnitHost H;
+    wunit_build_host(H, wunit_inplace_build_, segs_v, nseg, seg_rows, by_row_order, num_src_row, row_label, row_ptr, feat_index, feat_value, fb_index, fb_value);
+    wunit_adopt(ds, H);
+}
+void Engine::wunit_build_host(WUnitHost &H, bool inplace, const void *segs_v, size_t nseg, const std::vector<int64_t> &seg_rows, bool by_row_order,
+                              long num_src_row, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value,
+                              const unsigned *fb_index, const float *fb_value) const {
     const HostSeg *segs = static_cast<const HostSeg *>(segs_v);
     const long NU = mp_.num_user, NI = mp_.num_item, NG = mp_.num_global, NF = user_group() ? (long)num_fb_rows() : 0;
     const bool feedback = user_group();
-    if (window_trained_ == ds) window_trained_ = nullptr;
-    ds->kind = 7;
-    ds->sched_signature = schedule_signature();
-    ds->wu_feedback = feedback;
+    H.feedback = feedback;
     // ---- units: the segments of one user, in file order; launch order by cost (rows + feedback entries), descending
     std::vector<int> unit_of_user((size_t)NU, -1);
     std::vector<unsigned> unit_user;
@@ -93,7 +111,8 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
     std::stable_sort(launch.begin(), launch.end(), [&](int a, int b) { return unit_cost[(size_t)a] > unit_cost[(size_t)b]; });
     std::vector<int> pos_of_unit(nunit);
     for (size_t j = 0; j < nunit; j++) pos_of_unit[(size_t)launch[j]] = (int)j;
-    std::vector<WinUnit> units(nunit);
+    std::vector<WinUnit> &units = H.units;
+    units.assign(nunit, WinUnit{});
     {
         long acc = 0;
         for (size_t j = 0; j < nunit; j++) {
@@ -105,7 +124,8 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
     // segments in launch order of their unit, file order inside a unit; rows regrouped accordingly
     size_t nseg_used = 0;
     for (size_t s = 0; s < nseg; s++) nseg_used += seg_unit[s] >= 0;
-    std::vector<WinSeg> wsegs(nseg_used);
+    std::vector<WinSeg> &wsegs = H.wsegs;
+    wsegs.assign(nseg_used, WinSeg{});
     std::vector<int> seg_new(nseg, -1);
     for (size_t s = 0; s < nseg; s++) {
         if (seg_unit[s] < 0) continue;
@@ -131,8 +151,10 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
         }
     }
     // ---- regrouped rows: label, user value, entries = [global entries | item entries]
-    std::vector<float> w_label((size_t)nrow), w_uval((size_t)nrow);
-    std::vector<int> rptr((size_t)2 * nrow + 1, 0);
+    std::vector<float> &w_label = H.w_label, &w_uval = H.w_uval;
+    w_label.assign((size_t)nrow, 0.0f); w_uval.assign((size_t)nrow, 0.0f);
+    std::vector<int> &rptr = H.rptr;
+    rptr.assign((size_t)2 * nrow + 1, 0);
     bool unit_uval = true;
     long nent = 0;
     int fixed_ng = -2;   // -2 unknown, -1 not fixed
@@ -152,9 +174,11 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
         if (feat_value[p1] != 1.0f) unit_uval = false;
     }
     rptr[(size_t)2 * nrow] = (int)nent;
-    std::vector<WinEnt> ent((size_t)nent, WinEnt{0u, 0.0f, 0, 0});
+    std::vector<WinEnt> &ent = H.ent;
+    ent.assign((size_t)nent, WinEnt{0u, 0.0f, 0, 0});
     // ---- slots: counts per target, then file-order assignment
-    std::vector<int> tptr((size_t)(NF + NI) + 1, 0), gptr((size_t)NG + 1, 0);
+    std::vector<int> &tptr = H.tptr, &gptr = H.gptr;
+    tptr.assign((size_t)(NF + NI) + 1, 0); gptr.assign((size_t)NG + 1, 0);
     std::vector<unsigned> seen;   // duplicate check inside a row / a list
     for (long nr = 0; nr < nrow; nr++) {
         const long r = src_of_new[(size_t)nr];
@@ -177,7 +201,8 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
             tptr[(size_t)(NF + feat_index[j]) + 1]++;
         }
     }
-    std::vector<WinEnt> fbent((size_t)nfbe, WinEnt{0u, 0.0f, 0, 0});
+    std::vector<WinEnt> &fbent = H.fbent;
+    fbent.assign((size_t)nfbe, WinEnt{0u, 0.0f, 0, 0});
     for (size_t q = 0; q < nseg_used; q++) {
         const HostSeg &h = segs[seg_by_new[q]];
         std::vector<unsigned> ids(fb_index + h.fb_begin, fb_index + h.fb_begin + h.fb_count);
@@ -193,7 +218,7 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
     // one-GPU window sequences: a row that meets exactly ONE contribution in this window gets no slot (slot -1): the unit applies it in place
     // with the sum kernel's operations (apply_single, svdf_device.h) -- nobody else reads or writes that row inside the window
     std::vector<unsigned char> single;
-    if (wunit_inplace_build_) {
+    if (inplace) {
         single.assign((size_t)(NF + NI), 0);
         for (size_t t = 0; t < (size_t)(NF + NI); t++) if (tptr[t + 1] == 1) { single[t] = 1; tptr[t + 1] = 0; }
     }
@@ -218,6 +243,26 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
             for (int j = 0; j < w.fb_count; j++) fbent[(size_t)w.fb_begin + (size_t)j].slot = take_slot(tcur, (size_t)fbent[(size_t)w.fb_begin + (size_t)j].idx);
         }
     }
+    for (size_t j = 0; j < nunit; j++) units[j].first = wsegs[(size_t)units[j].seg_begin];   // the first segment travels with the unit record
+    H.nrow = nrow; H.nent = nent; H.nfbe = nfbe; H.fixed_ng = fixed_ng; H.unit_uval = unit_uval;
+    for (long nr = 0; nr < nrow; nr++) { const int g = rptr[(size_t)2 * nr + 1] - rptr[(size_t)2 * nr]; H.global_entries += g; H.item_entries += rptr[(size_t)2 * nr + 2] - rptr[(size_t)2 * nr] - g; }
+    (void)NU;
+}
+// the uploads and the data set's fields: the calling thread, in window order
+void Engine::wunit_adopt(Dataset *ds, const WUnitHost &H) {
+    const std::vector<WinUnit> &units = H.units;
+    const std::vector<WinSeg> &wsegs = H.wsegs;
+    const std::vector<float> &w_label = H.w_label, &w_uval = H.w_uval;
+    const std::vector<int> &rptr = H.rptr, &tptr = H.tptr, &gptr = H.gptr;
+    const std::vector<WinEnt> &ent = H.ent, &fbent = H.fbent;
+    const long nrow = H.nrow, nent = H.nent, nfbe = H.nfbe;
+    const size_t nunit = units.size(), nseg_used = wsegs.size();
+    const int fixed_ng = H.fixed_ng;
+    const bool unit_uval = H.unit_uval;
+    if (window_trained_ == ds) window_trained_ = nullptr;
+    ds->kind = 7;
+    ds->sched_signature = schedule_signature();
+    ds->wu_feedback = H.feedback;
     // rptr as the kernel reads it: rptr[2r], rptr[2r + 1], rptr[2r + 2] -- the odd entries are the global / item boundary of row r
     ds->num_row = nrow;
     ds->num_units = (long)nunit;
@@ -225,7 +270,6 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
     ds->wu_gslots = gptr.back();
     ds->wu_estride = fixed_ng >= 0 ? fixed_ng + 1 : 0;
     ds->unit_values = unit_uval;
-    for (size_t j = 0; j < nunit; j++) units[j].first = wsegs[(size_t)units[j].seg_begin];   // the first segment travels with the unit record
     ds->wu_units.upload(units.data(), nunit, stream_);
     ds->wu_segs.upload(wsegs.data(), nseg_used, stream_);
     ds->label.upload(w_label.data(), (size_t)nrow, stream_);
@@ -240,13 +284,18 @@ void Engine::wunit_build(Dataset *ds, const void *segs_v, size_t nseg, const std
     ds->sched.max_level_size = nrow;
     // what the reference's step moves -- per row 8k (nu + ni) + 8 (nu_b + ni) + 8 ng + 16 + 8 (ng + nu + ni), per feedback entry 12k + 20
     const long k = mp_.num_factor, nub = mp_.no_user_bias ? 0 : 1;
-    long item_entries = 0, global_entries = 0;
-    for (long nr = 0; nr < nrow; nr++) { const int g = rptr[(size_t)2 * nr + 1] - rptr[(size_t)2 * nr]; global_entries += g; item_entries += rptr[(size_t)2 * nr + 2] - rptr[(size_t)2 * nr] - g; }
+    const long item_entries = H.item_entries, global_entries = H.global_entries;
     ds->algorithmic_bytes = nrow * (8 * k + 8 * nub + 16 + 8) + item_entries * (8 * k + 8 + 8) + global_entries * 16 + nfbe * (12 * k + 20);
 }
 
 // ---- one exchange window of rows of a random-order trainer: any number of global and item entries, exactly one user entry
 void Engine::wunit_fill_from_csr(Dataset *ds, long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) {
+    WUnitHost H;
+    wunit_host_from_csr(H, wunit_inplace_build_, n, row_label, row_ptr, feat_index, feat_value);
+    wunit_adopt(ds, H);
+}
+void Engine::wunit_host_from_csr(WUnitHost &H, bool inplace, long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
+                                 const float *feat_value) const {
     const long NU = mp_.num_user;
     std::vector<int> cnt((size_t)NU, 0);
     for (long r = 0; r < n; r++) {
@@ -268,13 +317,20 @@ void Engine::wunit_fill_from_csr(Dataset *ds, long n, const float *row_label, co
         HostSeg &h = segs[(size_t)seg_of_user[feat_index[row_ptr[3 * r + 1]]]];
         seg_rows[h.row_first + h.row_count++] = r;
     }
-    wunit_build(ds, segs.data(), segs.size(), seg_rows, true, n, row_label, row_ptr, feat_index, feat_value, nullptr, nullptr);
+    wunit_build_host(H, inplace, segs.data(), segs.size(), seg_rows, true, n, row_label, row_ptr, feat_index, feat_value, nullptr, nullptr);
 }
 
 // ---- one exchange window of a user-group pass: blocks [b0, b1), every START closed by its END inside the window
 void Engine::wunit_fill_from_blocks(Dataset *ds, long b0, long b1, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
                                     const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
                                     const float *feat_value) {
+    WUnitHost H;
+    wunit_host_from_blocks(H, wunit_inplace_build_, b0, b1, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
+    wunit_adopt(ds, H);
+}
+void Engine::wunit_host_from_blocks(WUnitHost &H, bool inplace, long b0, long b1, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index,
+                                    const float *fb_value, const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr,
+                                    const unsigned *feat_index, const float *feat_value) const {
     const long NU = mp_.num_user;
     std::vector<HostSeg> segs;
     std::vector<int64_t> seg_rows;
@@ -315,7 +371,7 @@ void Engine::wunit_fill_from_blocks(Dataset *ds, long b0, long b1, const int *ex
     for (auto &r : seg_rows) r -= r_lo;
     std::vector<int64_t> ptr((size_t)3 * (r_hi - r_lo) + 1);
     for (size_t j = 0; j < ptr.size(); j++) ptr[j] = row_ptr[3 * r_lo + (long)j];
-    wunit_build(ds, segs.data(), segs.size(), seg_rows, false, r_hi - r_lo, row_label + r_lo, ptr.data(), feat_index, feat_value, fb_index, fb_value);
+    wunit_build_host(H, inplace, segs.data(), segs.size(), seg_rows, false, r_hi - r_lo, row_label + r_lo, ptr.data(), feat_index, feat_value, fb_index, fb_value);
 }
 
 Dataset *Engine::dataset_window_from_csr(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) {
@@ -378,6 +434,34 @@ static double mean_updates_met(const std::vector<long> &cnt) {   // sum c^2 / su
     return s1 > 0.0 ? s2 / s1 : 0.0;
 }
 
+// The windows of a sequence share nothing but the caller's read-only columns: their host builds run on several threads (a quarter of the
+// host's hardware threads, at most 32 and at most `wseq_build_threads`), a batch of windows at a time; uploads stay with the calling thread,
+// in window order.  A failure inside a worker is reported by the calling thread (the error text is thread-local).
+template <typename BuildFn, typename AdoptFn>
+static void wseq_build_windows(long W, int max_threads, BuildFn build, AdoptFn adopt_window) {
+    const long hw = (long)std::thread::hardware_concurrency();
+    const long T = std::max<long>(1, std::min<long>(std::min<long>(W, max_threads), std::max<long>(1, std::min<long>(32, hw / 4))));
+    for (long w0 = 0; w0 < W; w0 += T) {
+        const long nb = std::min<long>(T, W - w0);
+        std::vector<WUnitHost> H((size_t)nb);
+        std::vector<std::string> err((size_t)nb);
+        std::vector<char> failed((size_t)nb, 0);
+        auto work = [&](long j) {
+            try { build(w0 + j, H[(size_t)j]); }
+            catch (const std::exception &e) { failed[(size_t)j] = 1; err[(size_t)j] = e.what(); }
+        };
+        if (nb == 1) work(0);
+        else {
+            std::vector<std::thread> th;
+            for (long j = 1; j < nb; j++) th.emplace_back(work, j);
+            work(0);
+            for (auto &t : th) t.join();
+        }
+        for (long j = 0; j < nb; j++) if (failed[(size_t)j]) fail(err[(size_t)j]);
+        for (long j = 0; j < nb; j++) { adopt_window(w0 + j, H[(size_t)j]); H[(size_t)j] = WUnitHost(); }
+    }
+}
+
 Dataset *Engine::wseq_from_csr(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) {
     wunit_check_config("dataset_from_csr");
     std::vector<long> ci((size_t)mp_.num_item, 0), cg((size_t)mp_.num_global, 0);
@@ -388,16 +472,19 @@ Dataset *Engine::wseq_from_csr(long n, const float *row_label, const int64_t *ro
     const long W = wseq_windows(n, {mean_updates_met(ci), mean_updates_met(cg)});
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->kind = 8; ds->num_row = n;
-    for (long w = 0; w < W; w++) {
-        const long b0 = n * w / W, b1 = n * (w + 1) / W;
-        std::unique_ptr<Dataset> c(new Dataset());
-        adopt(c.get());
-        wunit_inplace_build_ = wunit_inplace_ != 0;   // the window is summed in place right after its walk (wseq_train): single contributions need no slot
-        struct Off { bool &f; ~Off() { f = false; } } off{wunit_inplace_build_};
-        wunit_fill_from_csr(c.get(), b1 - b0, row_label + b0, row_ptr + 3 * b0, feat_index, feat_value);
-        ds->algorithmic_bytes += c->algorithmic_bytes; ds->num_units += c->num_units;
-        ds->wchild.push_back(c.release());
-    }
+    const bool inplace = wunit_inplace_ != 0;   // a window is summed in place right after its walk (wseq_train): single contributions need no slot
+    wseq_build_windows(W, wseq_build_threads_,
+        [&](long w, WUnitHost &H) {
+            const long b0 = n * w / W, b1 = n * (w + 1) / W;
+            wunit_host_from_csr(H, inplace, b1 - b0, row_label + b0, row_ptr + 3 * b0, feat_index, feat_value);
+        },
+        [&](long, const WUnitHost &H) {
+            std::unique_ptr<Dataset> c(new Dataset());
+            adopt(c.get());
+            wunit_adopt(c.get(), H);
+            ds->algorithmic_bytes += c->algorithmic_bytes; ds->num_units += c->num_units;
+            ds->wchild.push_back(c.release());
+        });
     ds->sched.level_ptr = {0, n};
     ds->sched.max_level_size = W > 0 ? (n + W - 1) / W : n;
     return ds.release();
@@ -444,15 +531,19 @@ Dataset *Engine::wseq_from_blocks(long num_block, const int *extend_tag, const i
     if (num_block > 0 && (extend_tag[num_block - 1] == TAG_START || extend_tag[num_block - 1] == TAG_MIDDLE)) fail("dataset_from_blocks: the last user's END block is missing");
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->kind = 8; ds->num_row = n;
-    for (size_t w = 0; w + 1 < cut.size(); w++) {
-        std::unique_ptr<Dataset> c(new Dataset());
-        adopt(c.get());
-        wunit_inplace_build_ = wunit_inplace_ != 0;
-        struct Off { bool &f; ~Off() { f = false; } } off{wunit_inplace_build_};
-        wunit_fill_from_blocks(c.get(), cut[w], cut[w + 1], extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
-        ds->algorithmic_bytes += c->algorithmic_bytes; ds->num_units += c->num_units;
-        ds->wchild.push_back(c.release());
-    }
+    const bool inplace = wunit_inplace_ != 0;
+    wseq_build_windows((long)cut.size() - 1, wseq_build_threads_,
+        [&](long w, WUnitHost &H) {
+            wunit_host_from_blocks(H, inplace, cut[(size_t)w], cut[(size_t)w + 1], extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr,
+                                   feat_index, feat_value);
+        },
+        [&](long, const WUnitHost &H) {
+            std::unique_ptr<Dataset> c(new Dataset());
+            adopt(c.get());
+            wunit_adopt(c.get(), H);
+            ds->algorithmic_bytes += c->algorithmic_bytes; ds->num_units += c->num_units;
+            ds->wchild.push_back(c.release());
+        });
     ds->sched.level_ptr = {0, n};
     ds->sched.max_level_size = n;
     return ds.release();
