@@ -56,8 +56,9 @@ void svdf_destroy(svdf_trainer *t);
 int svdf_set_param(svdf_trainer *t, const char *name, const char *val);
 /* apex_random::seed (apex-tensor/apex_random.h:42-44) -> srand; process-global like the reference. */
 void svdf_seed(unsigned seed);
-/* ISVDTrainer::init_model (apex_svd.h:58; apex_svd_base.h:146-149): alloc + rand_init with libc
- * rand(), bit-identical starting point, then upload to HBM. */
+/* ISVDTrainer::init_model (apex_svd.h:58; apex_svd_base.h:146-149): alloc + SVDModel::rand_init (apex_svd_model.h:665-705) over the
+ * libc rand() stream -- the reference's draws and values bit for bit, libc's generator left where the reference's calls would have left
+ * it.  On a device handle the matrices are sampled IN HBM (svdf_k_init.hip): 70 M normals in 4.5 ms instead of 1.9 s. */
 int svdf_init_model(svdf_trainer *t);
 /* ISVDTrainer::load_model / save_model (apex_svd.h:47,52): byte-compatible with
  * SVDModel::load_from_file / save_to_file (apex_svd_model.h:570-660).  The caller owns the FILE*
@@ -265,7 +266,9 @@ void *svdf_stream(svdf_trainer *t);
 int svdf_set_stream(svdf_trainer *t, void *hip_stream);
 int svdf_synchronize(svdf_trainer *t);
 /* counters: 0 instances trained, 1 kernels launched, 2 conflict-free batches executed,
- * 3 staged-window flushes, 4/5/6 launches of the basicMF / general / few-row fused kernel */
+ * 3 staged-window flushes, 4/5/6 launches of the basicMF / general / few-row fused kernel, 7 rank passes sampled on the device,
+ * 8..12 amd:gpus handles (exchanges, RCCL, distinct devices, window steps, exchange path), 13 / 14 the last svdf_init_model on the
+ * device: values the host libm decided (next to a float rounding boundary) / rand() draws consumed (0 = the host loop ran) */
 int64_t svdf_counter(svdf_trainer *t, int what);
 /* tuning knobs (not part of the reference surface; none changes a result bit): "stage_window" (instances staged
  * before an automatic flush), "async_flush" (background scheduling of full windows), "groups_per_wave",
@@ -283,7 +286,11 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  * inline global slots); the window-minibatch step for user units: "wunit_fast" (0 = lane groups for every shape, 1 = + the slot kernel,
  * 2 = + one wave per user unit: default), "wunit_inplace" (one-GPU window sequences: 0 = every contribution through a slot, default 1 = a
  * row's only contribution of a window applied in place; same bits), "window_per_target" / "window_per_target_fb" (updates a shared row
- * meets per window when `amd:window` is not set: these two DO change the opt-in step's windows, hence its result).  Returns 0 if the knob exists.
+ * meets per window when `amd:window` is not set: these two DO change the opt-in step's windows, hence its result); the one-off builders:
+ * "device_init" (0 = SVDModel::rand_init as the reference's host loop instead of svdf_k_init.hip; same model, same rand() position),
+ * "device_init_margin_log2" (values closer than 2^-this to a float rounding boundary are recomputed with the host libm; default 46),
+ * "device_window" (0 = window data sets of ratings / pairs regrouped on the host; same arrays), "wseq_build_threads" (host threads building the
+ * user-unit windows of a one-GPU window sequence; default 32, capped by a quarter of the host's hardware threads).  Returns 0 if the knob exists.
  * The relaxed mode itself is switched by CONFIG keys through svdf_set_param ("amd:relax_global",
  * "amd:relax_user_from", "amd:relax_item_from", "amd:relax_feedback"), not by knobs: it changes results. */
 int svdf_set_knob(svdf_trainer *t, const char *name, long value);
