@@ -422,7 +422,7 @@ bool Engine::rand_init_device() {
         check(plan.seg[g].count >= 0 && plan.seg[g].row0 * (long)pitch_ + (plan.seg[g].count / std::max(k, 1)) * (long)pitch_ <= (long)n_uiset_ * pitch_,
               "init_model: num_randinit_ufactor / num_randinit_ifactor exceed the matrix");
     need_device("init_model");
-    mp_.base_score = calc_base_score(mp_.base_score, mtype_.active_type);
+    const float base_score = calc_base_score(mp_.base_score, mtype_.active_type);
     dW_.reserve(std::max<size_t>((size_t)n_uiset_ * pitch_, 1));
     HIPCHECK(hipMemsetAsync(dW_.p, 0, (size_t)n_uiset_ * pitch_ * sizeof(float), stream_));
     n_init_reports_ = 0;
@@ -472,7 +472,10 @@ bool Engine::rand_init_device() {
             n_init_reports_ = (int64_t)hs[2];
         }
         // values near a float rounding boundary: the host libm decides (apex_random.h:67-77 as written)
-        check(n_init_reports_ <= report_cap, "init_model: too many values near a rounding boundary were reported (device_init_margin_log2 too small)");
+        if (n_init_reports_ > report_cap) {   // a margin wider than the float spacing reports everything: the host loop does the whole job
+            n_init_reports_ = 0; n_init_draws_ = 0;   // (libc's generator and the parameters have not been touched)
+            return false;
+        }
         if (n_init_reports_ > 0) {
             std::vector<InitReport> rep((size_t)n_init_reports_);
             HIPCHECK(hipMemcpyAsync(rep.data(), reports.p, rep.size() * sizeof(InitReport), hipMemcpyDeviceToHost, stream_));
@@ -503,6 +506,7 @@ bool Engine::rand_init_device() {
         libc_rand_restore(after);   // libc's generator moves on by exactly the draws of the reference's loop
         n_init_draws_ = draws_total;
     }
+    mp_.base_score = base_score;
     // the rest of a fresh model: biases and global biases 0 (apex_svd_model.h:666-667), the kernels' state words 0
     dbias_.reserve(std::max<size_t>((size_t)n_uiset_, 1));
     HIPCHECK(hipMemsetAsync(dbias_.p, 0, std::max<size_t>((size_t)n_uiset_, 1) * sizeof(float), stream_));
@@ -2386,16 +2390,22 @@ Dataset *Engine::dataset_window_from_pairs(long n, const unsigned *user, const u
 }
 // (re)fills ds in place: the staged path of an amd:gpus handle rebuilds one window data set per rank every window.
 // neg != nullptr: rank pairs, `item` holds the positive items and the labels are 1.
+void Engine::window_build_header(Dataset *ds, long n, bool pairs) {
+    check(!user_group() && mtype_.extend_type == 0, "window data sets: random-order trainers only");
+    check(basic_fast_path_allowed(), "window data sets: no side tables, relaxed ids, lazy decay or shared latent space; num_factor <= 256");
+    check(n >= 0 && n < (1L << 30), "window data sets: at most 2^30-1 instances per window");
+    if (window_trained_ == ds) window_trained_ = nullptr;
+    ds->num_row = n; ds->kind = 5;
+    ds->win_slots = pairs ? 2 * n : n;
+    ds->fused.max_ni = pairs ? 2 : 1;
+}
 void Engine::window_build(Dataset *ds, long n, const unsigned *user, const unsigned *item, const float *label, const unsigned *neg) {
     check(!user_group() && mtype_.extend_type == 0, "window data sets: random-order trainers only");
     check(basic_fast_path_allowed(), "window data sets: no side tables, relaxed ids, lazy decay or shared latent space; num_factor <= 256");
     check(n >= 0 && n < (1L << 30), "window data sets: at most 2^30-1 instances per window");
     const long NU = mp_.num_user, NI = mp_.num_item;
     const bool pairs = neg != nullptr;
-    if (window_trained_ == ds) window_trained_ = nullptr;
-    ds->num_row = n; ds->kind = 5;
-    ds->win_slots = pairs ? 2 * n : n;
-    ds->fused.max_ni = pairs ? 2 : 1;
+    window_build_header(ds, n, pairs);
     if (window_build_device(ds, n, user, item, label, neg)) return;
     std::vector<int> ucnt((size_t)NU, 0), iptr((size_t)NI + 1, 0);
     for (long r = 0; r < n; r++) {
@@ -2471,12 +2481,19 @@ void Engine::window_build(Dataset *ds, long n, const unsigned *user, const unsig
 bool Engine::window_build_device(Dataset *ds, long n, const unsigned *user, const unsigned *item, const float *label, const unsigned *neg) {
     if (host_only_ || !device_window_ || n <= 0) return false;
     need_device("dataset");
-    const long NU = mp_.num_user, NI = mp_.num_item;
     const bool pairs = neg != nullptr;
-    const long E = pairs ? 2 * n : n;
     wb_user_.upload(user, (size_t)n, stream_);
     wb_item_.upload(item, (size_t)n, stream_);
     if (pairs) wb_neg_.upload(neg, (size_t)n, stream_); else wb_label_.upload(label, (size_t)n, stream_);
+    window_build_resident(ds, n, wb_user_.p, wb_item_.p, pairs ? nullptr : wb_label_.p, pairs ? wb_neg_.p : nullptr);
+    return true;
+}
+// the columns already in HBM (a whole data set handed over in one copy, its windows built from slices: wseq_from_triples / _pairs).
+// pairs: d_label == nullptr, d_neg != nullptr.  The caller has set the window's header fields (window_build).
+void Engine::window_build_resident(Dataset *ds, long n, const unsigned *d_user, const unsigned *d_item, const float *d_label, const unsigned *d_neg) {
+    const long NU = mp_.num_user, NI = mp_.num_item;
+    const bool pairs = d_neg != nullptr;
+    const long E = pairs ? 2 * n : n;
     wb_k0_.reserve((size_t)E); wb_k1_.reserve((size_t)E); wb_v0_.reserve((size_t)E); wb_v1_.reserve((size_t)E);
     wb_inst_.reserve((size_t)n); wb_slot_e_.reserve((size_t)E); wb_head_.reserve((size_t)n); wb_mark_.reserve((size_t)n);
     wb_run_user_.reserve((size_t)n); wb_run_start_.reserve((size_t)n); wb_run_begin_.reserve((size_t)n);
@@ -2487,7 +2504,7 @@ bool Engine::window_build_device(Dataset *ds, long n, const unsigned *user, cons
     ds->item.reserve((size_t)n); ds->win_slot.reserve((size_t)n); ds->win_iptr.reserve((size_t)NI + 1);
     if (!pairs) { ds->label.reserve((size_t)n); ds->win_item1.release(); }
     else { ds->win_item1.reserve((size_t)n); ds->win_slot1.reserve((size_t)n); ds->ival.reserve((size_t)n); ds->win_ival1.reserve((size_t)n); }
-    WBuildIn in{n, pairs ? 1 : 0, wb_user_.p, wb_item_.p, pairs ? wb_neg_.p : nullptr, pairs ? nullptr : wb_label_.p, NU, NI};
+    WBuildIn in{n, pairs ? 1 : 0, d_user, d_item, d_neg, d_label, NU, NI};
     WBuildBuffers B{wb_k0_.p, wb_k1_.p, wb_v0_.p, wb_v1_.p, wb_inst_.p, wb_slot_e_.p, wb_head_.p, wb_mark_.p, wb_run_user_.p, wb_run_start_.p, wb_run_begin_.p,
                     wb_tmp_.p, tb, wb_state_.p};
     WBuildOut out{ds->win_urec.p, ds->item.p, pairs ? ds->win_item1.p : nullptr, pairs ? nullptr : ds->label.p, pairs ? ds->ival.p : nullptr,
@@ -2506,7 +2523,6 @@ bool Engine::window_build_device(Dataset *ds, long n, const unsigned *user, cons
     ds->sched.max_level_size = n;
     const long nrow_touched = pairs ? 3 : 2, nb = (mp_.no_user_bias ? 0 : 1) + (pairs ? 2 : 1);
     ds->algorithmic_bytes = n * (8L * mp_.num_factor * nrow_touched + 8 * nb + 16 + 8 * nrow_touched);   // SURVEY 8(d4), as in the host builder
-    return true;
 }
 void Engine::window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t *count) {
     check(trainer_ready_, "window_delta: init_trainer has not been called");

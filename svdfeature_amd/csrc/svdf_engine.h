@@ -519,6 +519,9 @@ class Engine {
     DevBuf<int> wb_slot_e_, wb_head_, wb_mark_, wb_run_user_, wb_run_start_, wb_run_begin_;
     DevBuf<char> wb_tmp_;
     bool window_build_device(Dataset *ds, long n, const unsigned *user, const unsigned *item, const float *label, const unsigned *neg);
+    void window_build_resident(Dataset *ds, long n, const unsigned *d_user, const unsigned *d_item, const float *d_label, const unsigned *d_neg);
+    void window_build_header(Dataset *ds, long n, bool pairs);
+    bool device_window_ready() const { return !host_only_ && device_window_; }
     DevBuf<float> d_contrib_, d_cbias_;   // window-minibatch scratch: one contribution row + bias word per instance of the largest window
     std::unique_ptr<IpcState, IpcDeleter> ipc_;
     void ipc_check(const char *what);

@@ -555,11 +555,18 @@ Dataset *Engine::wseq_from_triples(long n, const unsigned *user, const unsigned 
     const long W = wseq_windows(n, {mean_updates_met(ci)});
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->kind = 8; ds->num_row = n;
+    // the columns go to HBM in ONE copy each (large pageable copies run at the PCIe rate, 56 GB/s; window-sized ones at a fifth of it), the
+    // windows are regrouped from slices of them (svdf_k_wbuild.hip)
+    DevBuf<unsigned> d_user, d_item;
+    DevBuf<float> d_label;
+    const bool resident = device_window_ready() && n > 0;
+    if (resident) { need_device("dataset"); d_user.upload(user, (size_t)n, stream_); d_item.upload(item, (size_t)n, stream_); d_label.upload(label, (size_t)n, stream_); }
     for (long w = 0; w < W; w++) {
         const long b0 = n * w / W, b1 = n * (w + 1) / W;
         std::unique_ptr<Dataset> c(new Dataset());
         adopt(c.get());
-        window_build(c.get(), b1 - b0, user + b0, item + b0, label + b0);
+        if (resident && b1 > b0) { window_build_header(c.get(), b1 - b0, false); window_build_resident(c.get(), b1 - b0, d_user.p + b0, d_item.p + b0, d_label.p + b0, nullptr); }
+        else window_build(c.get(), b1 - b0, user + b0, item + b0, label + b0);
         ds->algorithmic_bytes += c->algorithmic_bytes; ds->num_units += c->num_units;
         ds->wchild.push_back(c.release());
     }
@@ -580,11 +587,15 @@ Dataset *Engine::wseq_from_pairs(long n, const unsigned *user, const unsigned *p
     const long W = wseq_windows(n, {mean_updates_met(ci)});
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->kind = 8; ds->num_row = n;
+    DevBuf<unsigned> d_user, d_pos, d_neg;
+    const bool resident = device_window_ready() && n > 0;
+    if (resident) { need_device("dataset"); d_user.upload(user, (size_t)n, stream_); d_pos.upload(pos, (size_t)n, stream_); d_neg.upload(neg, (size_t)n, stream_); }
     for (long w = 0; w < W; w++) {
         const long b0 = n * w / W, b1 = n * (w + 1) / W;
         std::unique_ptr<Dataset> c(new Dataset());
         adopt(c.get());
-        window_build(c.get(), b1 - b0, user + b0, pos + b0, nullptr, neg + b0);
+        if (resident && b1 > b0) { window_build_header(c.get(), b1 - b0, true); window_build_resident(c.get(), b1 - b0, d_user.p + b0, d_pos.p + b0, nullptr, d_neg.p + b0); }
+        else window_build(c.get(), b1 - b0, user + b0, pos + b0, nullptr, neg + b0);
         ds->algorithmic_bytes += c->algorithmic_bytes; ds->num_units += c->num_units;
         ds->wchild.push_back(c.release());
     }
