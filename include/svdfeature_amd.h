@@ -289,6 +289,7 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  * meets per window when `amd:window` is not set: these two DO change the opt-in step's windows, hence its result); the one-off builders:
  * "device_init" (0 = SVDModel::rand_init as the reference's host loop instead of svdf_k_init.hip; same model, same rand() position),
  * "device_init_margin_log2" (values closer than 2^-this to a float rounding boundary are recomputed with the host libm; default 46),
+ * "device_load" (0 = svdf_load_model through a host copy of the model instead of file -> pinned chunks -> HBM; same model),
  * "device_window" (0 = window data sets of ratings / pairs regrouped on the host; same arrays), "wseq_build_threads" (host threads building the
  * user-unit windows of a one-GPU window sequence; default 32, capped by a quarter of the host's hardware threads).  Returns 0 if the knob exists.
  * The relaxed mode itself is switched by CONFIG keys through svdf_set_param ("amd:relax_global",

@@ -418,9 +418,8 @@ bool Engine::rand_init_device() {
     if (user_group()) add(num_fb_rows(), fb_off_, mp_.ufeedback_init_sigma, false);
     for (int g = plan.nseg; g < 3; g++) plan.seg[g].begin = total;
     plan.total = total;
-    for (int g = 0; g < plan.nseg; g++)
-        check(plan.seg[g].count >= 0 && plan.seg[g].row0 * (long)pitch_ + (plan.seg[g].count / std::max(k, 1)) * (long)pitch_ <= (long)n_uiset_ * pitch_,
-              "init_model: num_randinit_ufactor / num_randinit_ifactor exceed the matrix");
+    for (int g = 0; g < plan.nseg; g++)   // a view that does not fit its matrix (inconsistent shape keys): leave it to the host loop, as before
+        if (plan.seg[g].count < 0 || plan.seg[g].row0 + plan.seg[g].count / std::max(k, 1) > (long)n_uiset_) return false;
     need_device("init_model");
     const float base_score = calc_base_score(mp_.base_score, mtype_.active_type);
     dW_.reserve(std::max<size_t>((size_t)n_uiset_ * pitch_, 1));
@@ -646,6 +645,75 @@ void Engine::write_model_from_device(FILE *fo) {
         d2(dW_.p, mp_.num_ufeedback);
     }
 }
+// the mirror of dev_to_file: a tensor's rows from the file into HBM through the two pinned buffers, fread of chunk c + 1 beside the copy of chunk c
+void Engine::file_to_dev(FILE *fi, float *ddst, long rows, long cols, long pitch) {
+    if (rows <= 0 || cols <= 0) return;
+    const size_t cap = (size_t)8 << 20;   // floats per buffer (32 MB)
+    if (!save_pin_[0]) {
+        for (int b = 0; b < 2; b++) {
+            HIPCHECK(hipHostMalloc(reinterpret_cast<void **>(&save_pin_[b]), cap * sizeof(float), hipHostMallocDefault));
+            HIPCHECK(hipEventCreateWithFlags(&save_ev_[b], hipEventDisableTiming));
+        }
+    }
+    check((size_t)cols <= cap, "load_model: a row wider than the staging buffer");
+    const long per = std::max<long>(1, (long)(cap / (size_t)cols));
+    int c = 0;
+    for (long r0 = 0; r0 < rows; r0 += per, c++) {
+        const long nr = std::min(per, rows - r0);
+        float *buf = save_pin_[c & 1];
+        if (c >= 2) HIPCHECK(hipEventSynchronize(save_ev_[c & 1]));   // the copy that read this buffer two chunks ago
+        check(fread(buf, sizeof(float), (size_t)nr * cols, fi) == (size_t)nr * cols, "tensor::load_from_file");
+        if (cols == pitch) HIPCHECK(hipMemcpyAsync(ddst + (size_t)r0 * pitch, buf, (size_t)nr * cols * sizeof(float), hipMemcpyHostToDevice, stream_));
+        else HIPCHECK(hipMemcpy2DAsync(ddst + (size_t)r0 * pitch, (size_t)pitch * sizeof(float), buf, (size_t)cols * sizeof(float), (size_t)cols * sizeof(float),
+                                       (size_t)nr, hipMemcpyHostToDevice, stream_));
+        HIPCHECK(hipEventRecord(save_ev_[c & 1], stream_));
+    }
+    HIPCHECK(hipStreamSynchronize(stream_));   // the buffers are free for the next tensor
+}
+// SVDModel::load_from_file (apex_svd_model.h:570-585) straight into HBM: same order, same shape checks as read_model, no host copy of the matrices
+void Engine::read_model_to_device(FILE *fi) {
+    if (fread(&mp_, sizeof(ModelParam), 1, fi) == 0) fail("error loading CF SVD model");
+    compute_geometry();
+    need_device("loading the model");
+    const int k = mp_.num_factor;
+    dW_.reserve(std::max<size_t>((size_t)n_uiset_ * pitch_, 1));
+    dbias_.reserve(std::max<size_t>((size_t)n_uiset_, 1));
+    if (pitch_ != k) HIPCHECK(hipMemsetAsync(dW_.p, 0, (size_t)n_uiset_ * pitch_ * sizeof(float), stream_));   // the pad floats of every row stay 0
+    auto d1 = [&](float *d, int n) {
+        int x;
+        check(fread(&x, sizeof(int), 1, fi) > 0, "tensor::load_from_file");
+        check(x == n, "tensor::load_from_file: shape does not match the model header");
+        file_to_dev(fi, d, n, 1, 1);
+    };
+    auto d2 = [&](float *d, int rows) {
+        int hdr[2];
+        check(fread(hdr, sizeof(int), 2, fi) > 0, "tensor::load_from_file");
+        check(hdr[0] == k && hdr[1] == rows, "tensor::load_from_file: shape does not match the model header");
+        file_to_dev(fi, d, rows, k, pitch_);
+    };
+    if (mp_.common_latent_space == 0) {
+        d1(dbias_.p + user_off_, mp_.num_user);
+        d2(dW_.p + (size_t)user_off_ * pitch_, mp_.num_user);
+        d1(dbias_.p + item_off_, mp_.num_item);
+        d2(dW_.p + (size_t)item_off_ * pitch_, mp_.num_item);
+    } else {
+        d1(dbias_.p, (int)n_uiset_);
+        d2(dW_.p, (int)n_uiset_);
+    }
+    hg_.assign((size_t)mp_.num_global, 0.0f);
+    load_1d(fi, hg_.data(), mp_.num_global);
+    upload_globals(wanted_g_stride());
+    if (user_group() && mp_.common_feedback_space == 0) {
+        d1(dbias_.p, mp_.num_ufeedback);
+        d2(dW_.p, mp_.num_ufeedback);
+    }
+    std::vector<float> zero(imfb() ? (size_t)4 + IMFB_DEPTH_MAX * ((size_t)2 * pitch_ + 4) : (size_t)2 * pitch_ + 4, 0.0f);
+    dstate_.upload(zero.data(), zero.size(), stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    device_model_ = true;
+    hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hbias_.shrink_to_fit(); hg_.clear();
+    host_model_valid_ = false;
+}
 void Engine::read_model(FILE *fi) {
     if (fread(&mp_, sizeof(ModelParam), 1, fi) == 0) fail("error loading CF SVD model");
     alloc_host_model();
@@ -667,7 +735,8 @@ void Engine::read_model(FILE *fi) {
 }
 void Engine::load_model(FILE *fi) {  // apex_svd_base.h:138-140
     if (trainer_ready_ && !host_only_) flush();
-    read_model(fi);
+    if (!host_only_ && gpus_ <= 1 && device_load_) read_model_to_device(fi);   // the matrices stream file -> pinned chunks -> HBM
+    else read_model(fi);
     if (bilinear()) {   // BModel::load_from_file (apex_svd_bilinear.h:64-68, :194-197)
         check(fread(&bi_param_, sizeof(BiParam), 1, fi) > 0, "load from file");
         check(bi_param_.num_bi_feedback >= 0, "num_bi_feedback must not be negative");
@@ -680,7 +749,7 @@ void Engine::load_model(FILE *fi) {  // apex_svd_base.h:138-140
     multi_copy_model_to_peers();
     if (multi_) for (int d = 1; d < gpus_; d++) { Engine *e = rank_engine(d); e->params_dirty_ = true; if (e->device_model_) { HIPCHECK(hipSetDevice(e->device_)); e->upload_model(); } }
     if (multi_ && !host_only_) HIPCHECK(hipSetDevice(device_));
-    if (device_model_) upload_model();
+    if (device_model_ && host_model_valid_) upload_model();
 }
 void Engine::save_model(FILE *fo) {  // apex_svd_base.h:142-144
     ScopedNs timer(ns_model_);
@@ -3081,6 +3150,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "device_rank")) { device_rank_ = value != 0; return 0; }
     if (!strcmp(name, "device_init")) { device_init_ = value != 0; return 0; }
     if (!strcmp(name, "device_window")) { device_window_ = value != 0; return 0; }
+    if (!strcmp(name, "device_load")) { device_load_ = value != 0; return 0; }
     if (!strcmp(name, "wseq_build_threads")) { check(value >= 1 && value <= 256, "wseq_build_threads must be in 1 .. 256"); wseq_build_threads_ = (int)value; return 0; }
     if (!strcmp(name, "device_init_margin_log2")) { check(value >= 8 && value <= 52, "device_init_margin_log2 must be in 8 .. 52"); device_init_margin_log2_ = (int)value; return 0; }
     if (!strcmp(name, "fewrow_fast")) { fewrow_fast_ = value != 0; params_dirty_ = true; return 0; }

@@ -373,6 +373,8 @@ class Engine {
     void upload_model();
     void download_model();
     void read_model(FILE *fi);
+    void read_model_to_device(FILE *fi);
+    void file_to_dev(FILE *fi, float *ddst, long rows, long cols, long pitch);
     void write_model(FILE *fo);
     // ---- device
     int device_ = -1;
@@ -451,6 +453,7 @@ class Engine {
     bool rank_pass_device_general(const char *path, UserGroupArrays &g);   // any row shape / method: the pass drawn in HBM, blocks back in g
     std::unique_ptr<RankSource> rank_source_;
     bool device_rank_ = true;                       // knob "device_rank"
+    bool device_load_ = true;                       // knob "device_load": load_model streams the matrices file -> pinned chunks -> HBM (0 = through a host copy of the model)
     bool device_window_ = true;                     // knob "device_window": kind-5 window data sets regrouped on the device (svdf_k_wbuild.hip)
     bool device_init_ = true;                       // knob "device_init": rand_init on the device (svdf_k_init.hip)
     int device_init_margin_log2_ = 46;              // knob "device_init_margin_log2": values closer than 2^-this (relative) to a float rounding boundary go to the host libm

@@ -118,3 +118,60 @@ def test_unusual_libc_state_takes_the_host_loop():
         assert w.shape == (20, 8) and np.all(np.isfinite(w)) and np.any(w != 0)
     finally:
         libc.setstate(old)
+
+
+# ---- load_model straight into HBM (file -> pinned chunks -> device; knob device_load = 0: through a host copy of the model)
+@pytest.mark.parametrize("fmt,kw", [(0, dict(num_user=700, num_item=333, num_global=4, num_factor=64)),
+                                    (0, dict(num_user=90, num_item=50, num_global=0, num_factor=7)),          # pitch != k: pad floats stay 0
+                                    (1, dict(num_user=300, num_item=200, num_global=2, num_factor=33, num_ufeedback=150, ufeedback_init_sigma="0.01")),
+                                    (0, dict(num_user=120, num_item=120, num_global=0, num_factor=16, common_latent_space=1, common_feedback_space=1))])
+def test_load_model_streams_into_hbm(tmp_path, fmt, kw):
+    a = sa.Trainer(fmt, 0)
+    a.seed(3)
+    for k, v in kw.items():
+        a.set_param(k, str(v))
+    a.init_model()
+    a.init_trainer()
+    names = [n for n in ("W_user", "W_item", "W_ufeedback", "u_bias", "i_bias", "g_bias", "ufeedback_bias") if a.view(n) is not None]
+    rng = np.random.default_rng(1)
+    for n in ("u_bias", "i_bias", "g_bias"):   # biases are 0 after init: give them values
+        if a.view(n) is not None and a.view(n).size:
+            a.set_view(n, rng.normal(size=a.view(n).shape).astype(np.float32))
+    f0 = str(tmp_path / "m0.model")
+    a.save_model(f0)
+    want = {n: a.view(n).copy() for n in names}
+    out = []
+    for dev in (0, 1):
+        b = sa.Trainer(fmt, 0)
+        b.set_knob("device_load", dev)
+        b.load_model(f0)
+        for k, v in kw.items():
+            b.set_param(k, str(v))
+        got_before = {n: b.view(n).copy() for n in names}
+        b.init_trainer()
+        for n in names:
+            assert np.array_equal(want[n].view(np.uint32), got_before[n].view(np.uint32)), (dev, n)
+            assert np.array_equal(want[n].view(np.uint32), b.view(n).view(np.uint32)), (dev, n)
+        f1 = str(tmp_path / ("m1_%d.model" % dev))
+        b.save_model(f1)
+        out.append(open(f1, "rb").read())
+    assert out[0] == out[1] == open(f0, "rb").read()
+    # a second model over an existing device model, then training goes on from it
+    b.load_model(f0)
+    for n in names:
+        assert np.array_equal(want[n].view(np.uint32), b.view(n).view(np.uint32)), n
+
+
+def test_load_model_shape_checks_survive(tmp_path):
+    a = sa.Trainer(0, 0)
+    for k, v in dict(num_user=30, num_item=20, num_global=0, num_factor=8).items():
+        a.set_param(k, str(v))
+    a.init_model()
+    f0 = str(tmp_path / "m.model")
+    a.save_model(f0)
+    data = bytearray(open(f0, "rb").read())
+    bad = str(tmp_path / "short.model")
+    open(bad, "wb").write(bytes(data[:len(data) // 2]))
+    b = sa.Trainer(0, 0)
+    with pytest.raises(sa.SvdfError, match="load_from_file"):
+        b.load_model(bad)
