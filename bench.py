@@ -553,6 +553,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
     ev.record(e0, tr.stream())
     for _ in range(steps):
         st.train_pass()
+    enqueue_s = time.perf_counter() - t0   # the host's share: every launch / collective of the timed passes has been ENQUEUED (nothing waited for)
     ev.record(e1, tr.stream())
     sync_all()
     elapsed = time.perf_counter() - t0
@@ -562,7 +563,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
     if dist is not None:
         # every rank's own clock, stream time, algorithmic bytes and instance count of the timed region: the line reports the MAX clock
         # (contract) plus the spread over the ranks and the aggregate roofline
-        mine_ = torch.tensor([elapsed, ev_ms, float(alg_bytes), float(my_n), float(launches)], dtype=torch.float64, device="cuda")
+        mine_ = torch.tensor([elapsed, ev_ms, float(alg_bytes), float(my_n), float(launches), enqueue_s], dtype=torch.float64, device="cuda")
         allr = [torch.zeros_like(mine_) for _ in range(world)]
         dist.all_gather(allr, mine_)
         per_rank = [[float(x) for x in t_.tolist()] for t_ in allr]
@@ -729,13 +730,16 @@ def run_workload(name, a, env, steps, warmup, main_line):
                                     int(tr.item_delta_count() * 4 // max(world * bpr, 1)),
                 "updates_per_item_per_window": per_item / nwin},
             "phase_ms": phase_ms,
+            "enqueue_ms_per_pass": enqueue_s * 1e3 / steps,   # host time until a pass is enqueued (launches are asynchronous): small against ms_per_step = not host-bound
             # N > 1: the spread of the ranks' own clocks over the timed region, the aggregate roofline (sum of the ranks' algorithmic bytes
             # over the contract's max-over-ranks time against N x 8 TB/s) and what DESIGN.md's model expects for this line
             "per_rank_ms": None if (per_rank is None or world == 1) else {
                 "min": min(pr[0] for pr in per_rank) * 1e3 / steps, "max": max(pr[0] for pr in per_rank) * 1e3 / steps,
                 "stream_min": min(pr[1] for pr in per_rank) / steps, "stream_max": max(pr[1] for pr in per_rank) / steps,
                 "instances_min": min(pr[3] for pr in per_rank), "instances_max": max(pr[3] for pr in per_rank),
-                "what": "per pass; min / max over the ranks of the host clock between the two barriers (the line's ms_per_step is the max) and of the HIP-event time on each rank's stream"},
+                "enqueue_min": min(pr[5] for pr in per_rank) * 1e3 / steps, "enqueue_max": max(pr[5] for pr in per_rank) * 1e3 / steps,
+                "what": "per pass; min / max over the ranks of the host clock between the two barriers (the line's ms_per_step is the max), of the HIP-event time on each rank's "
+                        "stream, and of the host time until every launch / collective of the pass was ENQUEUED (enqueue close to the clock = the rank is bound by its host thread, not by the GPU or the links)"},
             "roofline_aggregate": None if (per_rank is None or world == 1) else {
                 "bound": "hbm", "achieved": sum(pr[2] for pr in per_rank) * steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                 "frac": sum(pr[2] for pr in per_rank) * steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),
@@ -1422,7 +1426,7 @@ def main():
         }
         for k in ("rmse_test_after_run", "passes_before_rmse", "rmse_sequential_reference", "rmse_minus_sequential", "exchange", "phase_ms",
                   "per_rank_ms", "roofline_aggregate", "model_ms",
-                  "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound", "launch_model", "init_model"):
+                  "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound", "launch_model", "init_model", "enqueue_ms_per_pass"):
             if m.get(k) is not None:
                 out[k] = m[k]
         if world > 1:
