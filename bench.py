@@ -462,7 +462,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
     stratified = exchanging and name == "basicmf" and (a.exchange == "stratified" or (a.exchange == "auto" and world > 1))
     auto_parts = 1 if world <= 2 else 2
     parts = (a.exchange_parts or auto_parts) if (name == "basicmf" and exchanging) else 1
-    if a.exchange_transport == "ipc":
+    if a.exchange_transport in ("ipc", "native"):
         parts = 1   # the IPC exchange is synchronous per window (its reduce runs over all links at once; nothing to hide behind pieces)
     adaptor = HipShard(tr, torch, torch.device("cuda", local_rank), parts=parts, minibatch=minibatch)
     if a.windows > 0:
@@ -526,15 +526,21 @@ def run_workload(name, a, env, steps, warmup, main_line):
     my_n = sum(w.num_row for w in flat)
     log("%s: scheduled %d into %d conflict-free batches (largest %d) in %.1fs" % (name, my_n, n_batches, max(w.max_batch for w in flat), sched_s))
     use_ipc = a.exchange_transport == "ipc" and world > 1 and minibatch and parts == 1
+    # the rank's own RCCL communicator driven from C++ (svdf_rccl.cpp): no torch.distributed call on the data path
+    use_native = a.exchange_transport == "native" and world > 1 and minibatch and parts == 1
     if stratified:
         adaptor.set_wire_half(False)
         if use_ipc:
             adaptor.ipc_open(dist, rank, world, blocks=world * bpr)
+        if use_native:
+            adaptor.rccl_open(dist, rank, world)
         st = StratifiedTrainer(adaptor, plan, world, rank, dist if world > 1 else None, blocks_per_rank=bpr)
     else:
         st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange, half_delta=(a.delta_dtype == "fp16"), parts=parts)
         if use_ipc:
             adaptor.ipc_open(dist, rank, world)
+        if use_native:
+            adaptor.rccl_open(dist, rank, world)
 
     def sync_all():
         tr.synchronize()
@@ -722,7 +728,10 @@ def run_workload(name, a, env, steps, warmup, main_line):
                         ("torch.distributed %s all_reduce (RCCL over xGMI)" % dist.get_backend()) if (dist is not None and world > 1) else
                         ("torch.distributed %s all_reduce with one rank (identity)" % dist.get_backend() if dist is not None else "none (one rank)"),
                 "transport": ("ipc: IPC-mapped wire buffers / inboxes, k_delta_reduce_gather + sequence flags (svdf_ipc.cpp); torch.distributed only carries the handles, "
-                              "the final block broadcasts and the timing reductions") if use_ipc else "torch.distributed",
+                              "the final block broadcasts and the timing reductions") if use_ipc else
+                             ("native: the rank's own RCCL communicator driven from C++ (svdf_rccl.cpp: ncclAllReduce / ncclSend + ncclRecv on a side stream, ordered by "
+                              "HIP events, one C call per hand-over); torch.distributed only carries the unique id, the final block broadcasts and the timing reductions")
+                             if use_native else "torch.distributed",
                 "contributions": contrib_fmt if minibatch else None,
                 "step": "stratified" if stratified else ("minibatch" if minibatch else "levels"), "windows": nwin, "parts": parts,
                 "handoffs_per_pass": a.chunks * world * bpr if (stratified and world > 1) else 0,
@@ -779,6 +788,10 @@ def run_workload(name, a, env, steps, warmup, main_line):
         if dist is not None:
             dist.barrier()   # nobody unmaps while a peer may still read
         tr.ipc_close()
+    if use_native:
+        if dist is not None:
+            dist.barrier()
+        adaptor.rccl_close()
     for w in flat:
         w.close()
     tr.close()
@@ -1264,7 +1277,7 @@ def main():
                          "exact, item side one minibatch step per window, three launches per window (svdf_k_window.hip), all-reduce per window; levels: the round-2 scheme, "
                          "exact conflict-free levels per rank with the item side stale across ranks only; stratified: no all-reduce -- item blocks are "
                          "owned exclusively and handed from rank to rank (DSGD-style strata, window-minibatch step inside a stratum; ratings only)")
-    ap.add_argument("--exchange-transport", choices=["rccl", "ipc"], default="rccl",
+    ap.add_argument("--exchange-transport", choices=["rccl", "ipc", "native"], default="rccl",
                     help="N>1: what carries the exchange between the processes.  rccl: torch.distributed collectives / point-to-point (default until a hardware "
                          "run says otherwise); ipc: every rank's wire buffer and flag page IPC-mapped into every process, peer-pointer reduce-scatter + "
                          "all-gather kernel and inbox stores ordered by sequence flags in device memory (svdf_ipc.cpp, DESIGN.md section 6i)")
@@ -1495,11 +1508,16 @@ def main():
                 keep = ("value", "unit", "ms_per_step", "order", "exchange", "phase_ms", "per_rank_ms", "roofline", "roofline_aggregate", "model_ms",
                         "rmse_test_after_run", "passes_before_rmse", "rmse_sequential_reference", "rmse_minus_sequential")
                 secondary["allreduce_minibatch"] = dict({k: r[k] for k in keep if r.get(k) is not None}, wall_s=round(time.time() - t0, 1), steps=3, warmup=1)
-        # (1b) both steps again with the DIRECT exchange between the processes (IPC-mapped buffers, no collective library on the data path)
-        for key, exch in (("allreduce_minibatch_ipc", "minibatch"), ("stratified_ipc", "stratified")):
+        # (1a) both steps with the rank's OWN RCCL communicator driven from C++ (svdf_rccl.cpp): the same RCCL, no Python / c10d call per collective --
+        # what the host thread costs a pass shows in per_rank_ms.enqueue_* of this entry against the main line's; (1b) both steps again with the
+        # DIRECT exchange between the processes (IPC-mapped buffers, no collective library on the data path)
+        variants = [("allreduce_minibatch_ipc", "minibatch", "ipc"), ("stratified_ipc", "stratified", "ipc")]
+        if backend == "nccl":   # RCCL refuses two ranks on one device: only with a device per rank
+            variants = [("stratified_native", "stratified", "native"), ("allreduce_minibatch_native", "minibatch", "native")] + variants
+        for key, exch, transport in variants:
             wd.arm(a.secondary_timeout, "secondary: %s" % key, finish_now)
             a3 = _ap.Namespace(**vars(a))
-            a3.exchange, a3.no_cpu_baseline, a3.exchange_transport = exch, True, "ipc"
+            a3.exchange, a3.no_cpu_baseline, a3.exchange_transport = exch, True, transport
             t0 = time.time()
             try:
                 r = run_workload("basicmf", a3, env, 3, 1, False)

@@ -245,6 +245,25 @@ int svdf_ipc_block_recv(svdf_trainer *t, int src_rank, int slot, unsigned seq);
 int svdf_ipc_status(svdf_trainer *t);
 int svdf_ipc_close(svdf_trainer *t);
 
+/* ---- the same exchanges issued from C++ straight into RCCL (svdf_rccl.cpp): one process per GPU, the rank's own communicator
+ * (ncclCommInitRank on the trainer's device; librccl.so resolved at run time -- inside a torch process the library torch loaded), so that a
+ * pass needs no Python call and no torch.distributed work object per collective.  Replaces, like the rest of section 6, the round loop of ONE
+ * process (svd_feature.cpp:220-248) on N ranks.
+ *   svdf_rccl_unique_id(out[128])                      rank 0; the bytes reach the other ranks through the caller's process group / store
+ *   svdf_rccl_init(t, id, rank, world)
+ *   all-reduce step, per window: svdf_train_dataset(ds); svdf_rccl_window_allreduce(t, ds, half)   (per-item sums -> ncclAllReduce in place -> add)
+ *   stratified hand-over: svdf_rccl_block_handoff(t, dst, src, slot, in_block, nblocks) sends the ACTIVE item block (svdf_item_delta_select) to rank
+ *   dst while block in_block of nblocks arrives from rank src into inbox slot `slot` (0 / 1), on a side stream ordered by events;
+ *   svdf_rccl_block_arrive(t, slot) makes the trainer's stream wait for that transfer and puts the block in place (active partition = its block).
+ *   svdf_rccl_counter: 0 hand-overs issued, 1 all-reduces issued. */
+int svdf_rccl_unique_id(unsigned char *out128);
+int svdf_rccl_init(svdf_trainer *t, const unsigned char *id128, int rank, int world);
+int svdf_rccl_window_allreduce(svdf_trainer *t, svdf_dataset *ds, int half);
+int svdf_rccl_block_handoff(svdf_trainer *t, int dst_rank, int src_rank, int slot, int in_block, int nblocks);
+int svdf_rccl_block_arrive(svdf_trainer *t, int slot);
+int64_t svdf_rccl_counter(svdf_trainer *t, int what);
+int svdf_rccl_close(svdf_trainer *t);
+
 /* test probe of the device rank sampler's sort (svdf_stdsort.h: libstdc++'s std::sort restated for host and device, because
  * PairwiseRankGenerator::sample_cmp, apex_svd_data.cpp:920-944, picks rows by POSITION after an unstable std::sort): ids 0..n-1
  * sorted by label with the restated code (restated[]) and with the C++ library's own std::sort (library[]). */

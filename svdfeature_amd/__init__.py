@@ -97,6 +97,14 @@ def load_library():
     lib.svdf_ipc_block_recv.argtypes = [P, C.c_int, C.c_int, C.c_uint]
     lib.svdf_ipc_status.argtypes = [P]
     lib.svdf_ipc_close.argtypes = [P]
+    lib.svdf_rccl_unique_id.argtypes = [C.c_char_p]
+    lib.svdf_rccl_init.argtypes = [P, C.c_char_p, C.c_int, C.c_int]
+    lib.svdf_rccl_window_allreduce.argtypes = [P, P, C.c_int]
+    lib.svdf_rccl_block_handoff.argtypes = [P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.svdf_rccl_block_arrive.argtypes = [P, C.c_int]
+    lib.svdf_rccl_counter.restype = C.c_int64
+    lib.svdf_rccl_counter.argtypes = [P, C.c_int]
+    lib.svdf_rccl_close.argtypes = [P]
     lib.svdf_window_delta_pack.argtypes = [P, P, P, C.c_int, C.POINTER(C.c_int64)]
     lib.svdf_window_delta_apply.argtypes = [P, P, C.c_int]
     lib.svdf_window_delta_apply_local.argtypes = [P, P]
@@ -164,6 +172,14 @@ def load_library():
 
 def device_count():
     return load_library().svdf_device_count()
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId (rank 0): 128 bytes for svdf_rccl_init on every rank"""
+    buf = C.create_string_buffer(128)
+    if load_library().svdf_rccl_unique_id(buf) != 0:
+        raise SvdfError(load_library().svdf_last_error().decode())
+    return buf.raw
 
 
 def rand_peek(n):
@@ -432,6 +448,25 @@ class Trainer:
 
     def ipc_close(self):
         self._ok(self.lib.svdf_ipc_close(self.h))
+
+    # -- the exchanges issued from C++ straight into RCCL (svdf_rccl.cpp): the rank's own communicator
+    def rccl_init(self, unique_id, rank, world):
+        self._ok(self.lib.svdf_rccl_init(self.h, bytes(unique_id), rank, world))
+
+    def rccl_window_allreduce(self, ds, half=False):
+        self._ok(self.lib.svdf_rccl_window_allreduce(self.h, ds.h, 1 if half else 0))
+
+    def rccl_block_handoff(self, dst, src, slot, in_block, nblocks):
+        self._ok(self.lib.svdf_rccl_block_handoff(self.h, dst, src, slot, in_block, nblocks))
+
+    def rccl_block_arrive(self, slot):
+        self._ok(self.lib.svdf_rccl_block_arrive(self.h, slot))
+
+    def rccl_counter(self, what):
+        return int(self.lib.svdf_rccl_counter(self.h, what))
+
+    def rccl_close(self):
+        self._ok(self.lib.svdf_rccl_close(self.h))
 
     def window_delta_pack(self, ds, device_ptr, half=False):
         """Sum of the trained window's item-side contributions into the wire buffer at device_ptr; returns its element count."""

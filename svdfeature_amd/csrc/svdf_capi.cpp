@@ -145,6 +145,13 @@ int svdf_ipc_block_send(svdf_trainer *t, int dst_rank, int slot) { SVDF_GUARD(-1
 int svdf_ipc_block_recv(svdf_trainer *t, int src_rank, int slot, unsigned seq) { SVDF_GUARD(-1, { t->e->ipc_block_recv(src_rank, slot, seq); return 0; }) }
 int svdf_ipc_status(svdf_trainer *t) { SVDF_GUARD(-1, { return t->e->ipc_status(); }) }
 int svdf_ipc_close(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->ipc_close(); return 0; }) }
+int svdf_rccl_unique_id(unsigned char *out128) { SVDF_GUARD(-1, { svdf::rccl_unique_id(out128); return 0; }) }
+int svdf_rccl_init(svdf_trainer *t, const unsigned char *id128, int rank, int world) { SVDF_GUARD(-1, { t->e->rccl_init(id128, rank, world); return 0; }) }
+int svdf_rccl_window_allreduce(svdf_trainer *t, svdf_dataset *ds, int half) { SVDF_GUARD(-1, { t->e->rccl_window_allreduce(ds ? ds->d : nullptr, half); return 0; }) }
+int svdf_rccl_block_handoff(svdf_trainer *t, int dst_rank, int src_rank, int slot, int in_block, int nblocks) { SVDF_GUARD(-1, { t->e->rccl_block_handoff(dst_rank, src_rank, slot, in_block, nblocks); return 0; }) }
+int svdf_rccl_block_arrive(svdf_trainer *t, int slot) { SVDF_GUARD(-1, { t->e->rccl_block_arrive(slot); return 0; }) }
+int64_t svdf_rccl_counter(svdf_trainer *t, int what) { SVDF_GUARD(-1, { return t->e->rccl_counter(what); }) }
+int svdf_rccl_close(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->rccl_close(); return 0; }) }
 int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *dst, int half, int64_t *count) {
     SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->window_delta_pack(ds ? ds->d : nullptr, dst, half, count); return 0; })
 }

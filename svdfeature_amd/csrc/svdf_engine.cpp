@@ -735,8 +735,14 @@ void Engine::read_model(FILE *fi) {
 }
 void Engine::load_model(FILE *fi) {  // apex_svd_base.h:138-140
     if (trainer_ready_ && !host_only_) flush();
-    if (!host_only_ && gpus_ <= 1 && device_load_) read_model_to_device(fi);   // the matrices stream file -> pinned chunks -> HBM
-    else read_model(fi);
+    if (!host_only_ && gpus_ <= 1 && device_load_) {   // the matrices stream file -> pinned chunks -> HBM
+        try { read_model_to_device(fi); }
+        catch (...) {   // a truncated / mismatching file leaves no half-loaded model behind: the handle has no model until the next init / load
+            (void)hipStreamSynchronize(stream_);
+            device_model_ = false; host_model_valid_ = false; space_allocated_ = false; trainer_ready_ = false;
+            throw;
+        }
+    } else read_model(fi);
     if (bilinear()) {   // BModel::load_from_file (apex_svd_bilinear.h:64-68, :194-197)
         check(fread(&bi_param_, sizeof(BiParam), 1, fi) > 0, "load from file");
         check(bi_param_.num_bi_feedback >= 0, "num_bi_feedback must not be negative");

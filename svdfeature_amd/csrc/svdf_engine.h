@@ -177,6 +177,9 @@ struct MultiState;                                   // svdf_multi.cpp: the othe
 struct MultiDeleter { void operator()(MultiState *m) const; };
 struct IpcState;                                     // svdf_ipc.cpp: IPC-mapped wire buffers / flag pages of the one-process-per-GPU ranks
 struct IpcDeleter { void operator()(IpcState *s) const; };
+struct RcclState;                                    // svdf_rccl.cpp: the rank's own RCCL communicator, side stream and hand-over buffers
+struct RcclDeleter { void operator()(RcclState *s) const; };
+void rccl_unique_id(unsigned char *out128);
 // a user-group buffer file kept in HBM for the device sampler (svdf_k_sample.hip); built once per file, reused every pass
 struct RankSource {
     std::string path;
@@ -309,6 +312,13 @@ class Engine {
     void ipc_block_recv(int src, int slot, unsigned seq);
     int ipc_status() const;
     void ipc_close();
+    // the same exchanges issued from C++ straight into RCCL (svdf_rccl.cpp)
+    void rccl_init(const unsigned char *id128, int rank, int world);
+    void rccl_window_allreduce(Dataset *ds, int half);
+    void rccl_block_handoff(int dst, int src, int slot, int in_block, int nblocks);
+    void rccl_block_arrive(int slot);
+    int64_t rccl_counter(int what) const;
+    void rccl_close();
     // the same step for user units (svdf_k_wunit.hip): rows with global features / several item entries, user-group (SVD++) blocks
     Dataset *dataset_window_from_csr(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
     Dataset *dataset_window_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,
@@ -527,6 +537,8 @@ class Engine {
     bool device_window_ready() const { return !host_only_ && device_window_; }
     DevBuf<float> d_contrib_, d_cbias_;   // window-minibatch scratch: one contribution row + bias word per instance of the largest window
     std::unique_ptr<IpcState, IpcDeleter> ipc_;
+    std::unique_ptr<RcclState, RcclDeleter> rccl_;
+    void rccl_check(const char *what);
     void ipc_check(const char *what);
     DevBuf<float> d_gcontrib_;            // ... and one word per global entry (user-unit windows)
     // user-unit windows (svdf_wunit.cpp)

@@ -291,6 +291,10 @@ class ShardedTrainer:
                 mark("pack")
             self.a.train(w)
             mark("compute")
+            if getattr(self.a, "rccl_ready", False):   # the rank's own RCCL communicator, issued from C++ (svdf_rccl.cpp): pack -> ncclAllReduce -> add
+                self.a.rccl_allreduce()
+                mark("allreduce")
+                continue
             if getattr(self.a, "ipc_ready", False):   # direct exchange through IPC-mapped buffers: no collective library (svdf_ipc.cpp)
                 self.a.ipc_pack()
                 mark("pack")
@@ -379,6 +383,9 @@ class StratifiedTrainer:
     def _arrive(self, b):
         if b in self.pending:
             handle, inc = self.pending.pop(b)
+            if isinstance(handle, tuple) and handle[0] == "rccl-recv":
+                self.a.rccl_arrive(b, self.world * self.P, handle[1])
+                return
             self.a.handoff_wait(handle)
             self.a.block_set(b, self.world * self.P, handle if (isinstance(handle, tuple) and handle[0] == "ipc-recv") else inc)
 
@@ -396,7 +403,12 @@ class StratifiedTrainer:
                     mark("compute")
                     a.apply_local(w, b, B)
                     mark("pack")
-                if N > 1:
+                if getattr(a, "rccl_ready", False) and (N > 1 or getattr(a, "rccl_self_ring", False)):   # one C call per hand-over (svdf_rccl.cpp);
+                    # rccl_self_ring: the one-rank ring of the tests -- the block goes to this rank itself and comes back P steps later
+                    nxt = (b + P) % B
+                    self.pending[nxt] = (a.rccl_handoff(b, nxt, B, (self.rank - 1) % N, (self.rank + 1) % N), None)
+                    mark("pack")
+                elif N > 1:
                     nxt = (b + P) % B
                     ipc = getattr(a, "ipc_ready", False)
                     out = a.block_get(b, B, True) if ipc else a.block_get(b, B)
@@ -554,6 +566,42 @@ class HipShard:
     def broadcast(self, dist, buf, src):
         with self.torch.cuda.stream(self.stream):
             dist.broadcast(buf, src)
+
+    # ---- the exchanges issued from C++ straight into RCCL (svdf_rccl.cpp): the rank's own communicator; torch.distributed only carries the id
+    rccl_ready = False
+    rccl_self_ring = False
+
+    def rccl_open(self, dist, rank, world):
+        import svdfeature_amd as sa
+        assert self.minibatch, "the native RCCL exchange serves the window-minibatch step"
+        box = [sa.rccl_unique_id() if rank == 0 else None]
+        if dist is not None and world > 1:
+            dist.broadcast_object_list(box, src=0)
+        self.t.rccl_init(box[0], rank, world)
+        if dist is not None and world > 1:
+            dist.barrier()
+        self.rccl_ready, self.rccl_sent = True, 0
+
+    def rccl_close(self):
+        if self.rccl_ready:
+            self.t.rccl_close()
+        self.rccl_ready = False
+
+    def rccl_allreduce(self):
+        self.t.rccl_window_allreduce(self.last, self.half)
+
+    def rccl_handoff(self, block, in_block, nblocks, dst, src):
+        slot = self.rccl_sent % 2
+        self.t.item_delta_select(block, nblocks)
+        self.t.rccl_block_handoff(dst, src, slot, in_block, nblocks)
+        self.t.item_delta_select(0, 1)
+        self.rccl_sent += 1
+        return ("rccl-recv", slot)
+
+    def rccl_arrive(self, block, nblocks, slot):
+        self.t.item_delta_select(block, nblocks)
+        self.t.rccl_block_arrive(slot)
+        self.t.item_delta_select(0, 1)
 
     # ---- cross-process direct exchange (svdf_ipc.cpp): wire buffers / flag pages IPC-mapped into every rank's process
     ipc_ready = False

@@ -175,3 +175,8 @@ def test_load_model_shape_checks_survive(tmp_path):
     b = sa.Trainer(0, 0)
     with pytest.raises(sa.SvdfError, match="load_from_file"):
         b.load_model(bad)
+    with pytest.raises(sa.SvdfError):   # no half-loaded model is left behind
+        b.save_model(str(tmp_path / "after_failure.model"))
+    b.load_model(f0)                    # and the handle takes a good file afterwards
+    b.init_trainer()
+    assert np.array_equal(a.view("W_user").view(np.uint32), b.view("W_user").view(np.uint32))
