@@ -119,7 +119,11 @@ void Engine::rccl_init(const unsigned char *id128, int rank, int world) {
     // ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank): the id travels by value
     auto init = reinterpret_cast<int (*)(void **, int, UniqueId, int)>(api().init_rank_sym);
     api().ok(init(&S.comm, world, id, rank), "ncclCommInitRank");
-    HIPCHECK(hipStreamCreateWithFlags(&S.xfer, hipStreamNonBlocking));
+    {   // the transfers ride a HIGH-priority stream: their few workgroups must not queue behind the training kernels that fill the chip
+        int lo = 0, hi = 0;
+        HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHECK(hipStreamCreateWithPriority(&S.xfer, hipStreamNonBlocking, hi));
+    }
     for (int j = 0; j < 2; j++) {
         HIPCHECK(hipEventCreateWithFlags(&S.out_ready[j], hipEventDisableTiming));
         HIPCHECK(hipEventCreateWithFlags(&S.moved[j], hipEventDisableTiming));
