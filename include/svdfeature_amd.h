@@ -225,6 +225,11 @@ int svdf_window_delta_apply(svdf_trainer *t, const void *device_src, int half);
 int svdf_window_delta_apply_local(svdf_trainer *t, svdf_dataset *ds);
 int svdf_item_block_get(svdf_trainer *t, float *device_dst, int64_t *count);
 int svdf_item_block_set(svdf_trainer *t, const float *device_src);
+/* one stratum step in one call: every window data set trained (svdf_train_dataset) and summed in place into item block `block` of `nblocks`
+ * (svdf_window_delta_apply_local), then -- device_out != NULL -- the block copied out for its hand-over; svdf_item_block_set_at puts an arrived
+ * block in place.  The same launches as the calls they fuse (the host thread of a rank has ~40 us per step at 8 ranks). */
+int svdf_stratum_step(svdf_trainer *t, svdf_dataset *const *windows, int num_windows, int block, int nblocks, float *device_out);
+int svdf_item_block_set_at(svdf_trainer *t, int block, int nblocks, const float *device_src);
 /* ---- cross-PROCESS direct exchange (svdf_ipc.cpp): one process per GPU, but the exchange of a window runs through
  * IPC-mapped device buffers -- every rank's wire buffer and flag page mapped into every process (over xGMI on distinct devices) -- with the
  * peer-pointer reduce-scatter + all-gather kernel of the amd:gpus handle, ordered across processes by sequence flags in device memory

@@ -97,6 +97,8 @@ def load_library():
     lib.svdf_ipc_block_recv.argtypes = [P, C.c_int, C.c_int, C.c_uint]
     lib.svdf_ipc_status.argtypes = [P]
     lib.svdf_ipc_close.argtypes = [P]
+    lib.svdf_stratum_step.argtypes = [P, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, P]
+    lib.svdf_item_block_set_at.argtypes = [P, C.c_int, C.c_int, P]
     lib.svdf_rccl_unique_id.argtypes = [C.c_char_p]
     lib.svdf_rccl_init.argtypes = [P, C.c_char_p, C.c_int, C.c_int]
     lib.svdf_rccl_window_allreduce.argtypes = [P, P, C.c_int]
@@ -494,6 +496,13 @@ class Trainer:
 
     def item_block_set(self, device_ptr):
         self._ok(self.lib.svdf_item_block_set(self.h, C.c_void_p(device_ptr)))
+
+    def stratum_step(self, handles, n, block, nblocks, out_ptr):
+        """handles: a ctypes array of the window data sets' handles (svdf_stratum_step)"""
+        self._ok(self.lib.svdf_stratum_step(self.h, handles, n, block, nblocks, C.c_void_p(out_ptr) if out_ptr else None))
+
+    def item_block_set_at(self, block, nblocks, device_ptr):
+        self._ok(self.lib.svdf_item_block_set_at(self.h, block, nblocks, C.c_void_p(device_ptr)))
 
     def dataset_from_pairs(self, user, pos, neg):
         """Rank pairs (user, positive item, negative item), see svdf_dataset_from_pairs."""

@@ -157,6 +157,16 @@ int svdf_window_delta_pack(svdf_trainer *t, svdf_dataset *ds, void *dst, int hal
 }
 int svdf_window_delta_apply_local(svdf_trainer *t, svdf_dataset *ds) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->window_delta_apply_local(ds ? ds->d : nullptr); return 0; }) }
 int svdf_item_block_get(svdf_trainer *t, float *dst, int64_t *count) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_block_copy(dst, 0, count); return 0; }) }
+int svdf_stratum_step(svdf_trainer *t, svdf_dataset *const *windows, int num_windows, int block, int nblocks, float *device_out) {
+    SVDF_GUARD(-1, {
+        t->e->per_rank_api();
+        std::vector<svdf::Dataset *> d((size_t)(num_windows > 0 ? num_windows : 0));
+        for (int w = 0; w < num_windows; w++) d[(size_t)w] = windows[w] ? windows[w]->d : nullptr;
+        t->e->stratum_step(d.data(), num_windows, block, nblocks, device_out);
+        return 0;
+    })
+}
+int svdf_item_block_set_at(svdf_trainer *t, int block, int nblocks, const float *src) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_block_set_at(block, nblocks, src); return 0; }) }
 int svdf_item_block_set(svdf_trainer *t, const float *src) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->item_block_copy(const_cast<float *>(src), 1, nullptr); return 0; }) }
 int svdf_window_delta_apply(svdf_trainer *t, const void *src, int half) { SVDF_GUARD(-1, { t->e->per_rank_api(); t->e->window_delta_apply(src, half); return 0; }) }
 int svdf_debug_sort_labels(long n, const float *label, int *restated, int *library) {

@@ -313,6 +313,8 @@ class Engine {
     int ipc_status() const;
     void ipc_close();
     // the same exchanges issued from C++ straight into RCCL (svdf_rccl.cpp)
+    void stratum_step(Dataset *const *ds, int n, int block, int nblocks, float *device_out);
+    void item_block_set_at(int block, int nblocks, const float *device_src);
     void rccl_init(const unsigned char *id128, int rank, int world);
     void rccl_window_allreduce(Dataset *ds, int half);
     void rccl_block_handoff(int dst, int src, int slot, int in_block, int nblocks);

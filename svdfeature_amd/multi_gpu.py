@@ -390,6 +390,7 @@ class StratifiedTrainer:
             self.a.block_set(b, self.world * self.P, handle if (isinstance(handle, tuple) and handle[0] == "ipc-recv") else inc)
 
     def train_pass(self, mark=None):
+        fused = mark is None and hasattr(self.a, "stratum_step")   # the timed passes: one engine call per stratum step (phase marks need the separate calls)
         mark = mark or (lambda phase: None)
         a, N, P = self.a, self.world, self.P
         B = N * P
@@ -398,6 +399,19 @@ class StratifiedTrainer:
                 b = (self.rank * P + t) % B
                 self._arrive(b)
                 mark("allreduce")
+                if fused:
+                    native = getattr(a, "rccl_ready", False) and (N > 1 or getattr(a, "rccl_self_ring", False))
+                    torch_ring = N > 1 and not native and not getattr(a, "ipc_ready", False)
+                    out = a.stratum_step(chunk[t], b, B, torch_ring)
+                    nxt = (b + P) % B
+                    if native:
+                        self.pending[nxt] = (a.rccl_handoff(b, nxt, B, (self.rank - 1) % N, (self.rank + 1) % N), None)
+                    elif torch_ring:
+                        inc = a.block_like(nxt, B)
+                        self.pending[nxt] = (a.handoff_start(self.dist, out, (self.rank - 1) % N, inc, (self.rank + 1) % N), inc)
+                    elif N > 1:   # IPC: the block goes straight into the neighbour's inbox
+                        self.pending[nxt] = (a.handoff_start(self.dist, a.block_get(b, B, True), (self.rank - 1) % N, a.block_like(nxt, B, True), (self.rank + 1) % N), None)
+                    continue
                 for w in chunk[t]:
                     a.train(w)
                     mark("compute")
@@ -445,6 +459,7 @@ class HipShard:
         # delta_set = replicated ranges += all-reduced buffer.  No snapshot, no pack.
         self.minibatch = bool(minibatch)
         self.last = None
+        self._step_arrays = {}
         self.stream = torch.cuda.Stream(device=device)
         trainer.set_stream(self.stream.cuda_stream)
         self.buf = None
@@ -508,13 +523,39 @@ class HipShard:
         self.t.window_delta_apply_local(ds)
         self.t.item_delta_select(0, 1)
 
+    def stratum_step(self, windows, block, nblocks, want_out):
+        """the whole stratum step in ONE engine call (svdf_stratum_step): train + sum in place for every window, then the block copied out for its
+        hand-over (want_out); returns the out tensor or None.  Same launches as train / apply_local / block_get."""
+        import ctypes as C
+        key = id(windows)
+        arr = self._step_arrays.get(key)
+        if arr is None or arr[1] is not windows:
+            arr = ((C.c_void_p * max(len(windows), 1))(*[w.h for w in windows]), windows)
+            self._step_arrays[key] = arr
+        out = None
+        if want_out:
+            k = ("out", block, nblocks)
+            out = self.bufs.get(k)
+            if out is None:
+                self.t.item_delta_select(block, nblocks)
+                n = self.t.item_block_count()
+                self.t.item_delta_select(0, 1)
+                with self.torch.cuda.stream(self.stream):
+                    out = self.bufs[k] = self.torch.empty(n, device=self.device, dtype=self.torch.float32)
+        self.t.stratum_step(arr[0], len(windows), block, nblocks, out.data_ptr() if out is not None else 0)
+        if windows:
+            self.last = windows[-1]
+        return out
+
     def block_like(self, block, nblocks, for_handoff=False):
         if self.ipc_ready and for_handoff:
             return ("ipc-in", block, nblocks)
+        key = ("in", block, nblocks)
+        if key in self.bufs:
+            return self.bufs[key]
         self.t.item_delta_select(block, nblocks)
         n = self.t.item_block_count()
         self.t.item_delta_select(0, 1)
-        key = ("in", block, nblocks)
         if key not in self.bufs:
             with self.torch.cuda.stream(self.stream):
                 self.bufs[key] = self.torch.empty(n, device=self.device, dtype=self.torch.float32)
@@ -534,6 +575,9 @@ class HipShard:
         return self.bufs[key]
 
     def block_set(self, block, nblocks, tensor):
+        if not isinstance(tensor, tuple):
+            self.t.item_block_set_at(block, nblocks, tensor.data_ptr())
+            return
         self.t.item_delta_select(block, nblocks)
         if isinstance(tensor, tuple) and tensor[0] == "ipc-recv":   # wait for the neighbour's store, put the block in place, acknowledge the slot
             _, src, slot, seq = tensor
