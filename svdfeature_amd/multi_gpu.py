@@ -409,7 +409,7 @@ class StratifiedTrainer:
                     elif torch_ring:
                         inc = a.block_like(nxt, B)
                         self.pending[nxt] = (a.handoff_start(self.dist, out, (self.rank - 1) % N, inc, (self.rank + 1) % N), inc)
-                    elif N > 1:   # IPC: the block goes straight into the neighbour's inbox
+                    elif N > 1 or (getattr(a, "ipc_ready", False) and getattr(a, "ipc_self_ring", False)):   # IPC: the block goes straight into the neighbour's inbox
                         self.pending[nxt] = (a.handoff_start(self.dist, a.block_get(b, B, True), (self.rank - 1) % N, a.block_like(nxt, B, True), (self.rank + 1) % N), None)
                     continue
                 for w in chunk[t]:
@@ -663,9 +663,13 @@ class HipShard:
             self.t.item_delta_select(0, 1)
         mine = self.t.ipc_setup(rank, world, n * 4, block_floats)
         gathered = [None] * world
-        dist.all_gather_object(gathered, mine)
+        if dist is None:   # the one-rank ring of the probes / tests
+            gathered = [mine]
+        else:
+            dist.all_gather_object(gathered, mine)
         self.t.ipc_connect(b"".join(gathered))
-        dist.barrier()   # nobody signals into a page that is not mapped yet
+        if dist is not None:
+            dist.barrier()   # nobody signals into a page that is not mapped yet
         self.ipc_ready, self.ipc_rank, self.ipc_world = True, rank, world
         self.ipc_sent, self.ipc_received = 0, 0
 

@@ -22,7 +22,7 @@ i = rng.integers(0, ni, n).astype(np.uint32)
 r = rng.integers(1, 6, n).astype(np.float32)
 conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k)
 res = {}
-for native in (False, True):
+for native in (False, True, "ipc"):
     t = sa.Trainer(0, 0)
     t.seed(10)
     for kk, v in conf:
@@ -32,7 +32,10 @@ for native in (False, True):
     ad = HipShard(t, torch, torch.device("cuda", 0), minibatch=True)
     ad.set_wire_half(False)
     plan = [[ad.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, 0, 1, chunks, ni, 32.0, blocks_per_rank=P)]
-    if native:
+    if native == "ipc":
+        ad.ipc_open(None, 0, 1, blocks=P)
+        ad.ipc_self_ring = True
+    elif native:
         ad.rccl_open(None, 0, 1)
         ad.rccl_self_ring = True
     st = StratifiedTrainer(ad, plan, 1, 0, None, blocks_per_rank=P)
@@ -46,9 +49,11 @@ for native in (False, True):
     t.synchronize()
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    key = "with native hand-overs" if native else "no hand-overs"
+    key = "with IPC hand-overs" if native == "ipc" else "with native hand-overs" if native else "no hand-overs"
     res[key] = {"enqueue_ms_per_pass": round(enq * 1e3 / steps, 3), "ms_per_pass": round(wall * 1e3 / steps, 3),
-                "window_steps_per_pass": sum(len(s) for c in plan for s in c), "handoffs_per_pass": t.rccl_counter(0) // (steps + 1) if native else 0}
-    if native:
+                "window_steps_per_pass": sum(len(s) for c in plan for s in c), "handoffs_per_pass": (64 if native == "ipc" else t.rccl_counter(0) // (steps + 1)) if native else 0}
+    if native == "ipc":
+        t.ipc_close()
+    elif native:
         ad.rccl_close()
 print(json.dumps(res))
