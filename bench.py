@@ -739,7 +739,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
                                     int(tr.item_delta_count() * 4 // max(world * bpr, 1)),
                 "updates_per_item_per_window": per_item / nwin},
             "phase_ms": phase_ms,
-            "enqueue_ms_per_pass": enqueue_s * 1e3 / steps,   # host time until a pass is enqueued (launches are asynchronous): small against ms_per_step = not host-bound
+            "enqueue_ms_per_pass": enqueue_s * 1e3 / steps,   # host time until a pass is enqueued (launches are asynchronous): small against ms_per_step = not host-bound; close to it = host-bound OR the device queue pushed back (thousands of launches in flight)
             # N > 1: the spread of the ranks' own clocks over the timed region, the aggregate roofline (sum of the ranks' algorithmic bytes
             # over the contract's max-over-ranks time against N x 8 TB/s) and what DESIGN.md's model expects for this line
             "per_rank_ms": None if (per_rank is None or world == 1) else {
@@ -748,7 +748,8 @@ def run_workload(name, a, env, steps, warmup, main_line):
                 "instances_min": min(pr[3] for pr in per_rank), "instances_max": max(pr[3] for pr in per_rank),
                 "enqueue_min": min(pr[5] for pr in per_rank) * 1e3 / steps, "enqueue_max": max(pr[5] for pr in per_rank) * 1e3 / steps,
                 "what": "per pass; min / max over the ranks of the host clock between the two barriers (the line's ms_per_step is the max), of the HIP-event time on each rank's "
-                        "stream, and of the host time until every launch / collective of the pass was ENQUEUED (enqueue close to the clock = the rank is bound by its host thread, not by the GPU or the links)"},
+                        "stream, and of the host time until every launch / collective of the pass was ENQUEUED (enqueue well below the clock = the host thread was NOT the limit; "
+                        "close to the clock = either host-bound or the device queue filled up and pushed back, as it does over the ~1 900 launches of an exact one-GPU pass)"},
             "roofline_aggregate": None if (per_rank is None or world == 1) else {
                 "bound": "hbm", "achieved": sum(pr[2] for pr in per_rank) * steps / elapsed / 1e9, "peak": HBM_PEAK_GBS * world, "unit": "GB/s",
                 "frac": sum(pr[2] for pr in per_rank) * steps / elapsed / 1e9 / (HBM_PEAK_GBS * world),

@@ -174,9 +174,12 @@ void Engine::rccl_block_handoff(int dst, int src, int slot, int in_block, int nb
     HIPCHECK(hipStreamWaitEvent(S.xfer, S.out_ready[slot], 0));
     if (S.consumed_set[slot]) HIPCHECK(hipStreamWaitEvent(S.xfer, S.consumed[slot], 0));
     api().ok(api().GroupStart(), "ncclGroupStart");
-    api().ok(api().Send(S.out[slot].p, (size_t)n_out, 7, dst, S.comm, S.xfer), "ncclSend");
-    api().ok(api().Recv(S.in[slot].p, (size_t)n_in, 7, src, S.comm, S.xfer), "ncclRecv");
-    api().ok(api().GroupEnd(), "ncclGroupEnd");
+    const int rs = api().Send(S.out[slot].p, (size_t)n_out, 7, dst, S.comm, S.xfer);
+    const int rr = rs == 0 ? api().Recv(S.in[slot].p, (size_t)n_in, 7, src, S.comm, S.xfer) : 0;
+    const int re = api().GroupEnd();   // the group is closed whatever happened inside it
+    api().ok(rs, "ncclSend");
+    api().ok(rr, "ncclRecv");
+    api().ok(re, "ncclGroupEnd");
     HIPCHECK(hipEventRecord(S.moved[slot], S.xfer));
     S.moved_set[slot] = true;
     S.in_flight[slot] = true;
