@@ -1053,6 +1053,30 @@ def preflight(torch, dist, rank, world, device, ring, log):
     return out
 
 
+def choose_schedule(pf, world, a):
+    """--exchange auto on real devices (backend nccl): the stratified ring or the all-reduce step as the MAIN line, from what the preflight just measured
+    on this node.  Both keep the accuracy contract; which one is faster depends on what a hand-over of one item block costs the rank that
+    issues it (host + link, not hidden behind a ~40 us step at 8 ranks: DESIGN.md 6j) against what an all-reduce of a window's sums costs.
+    est(stratified) = max(compute share, hand-overs x measured hand-over); est(all-reduce step) = compute share + windows x measured all-reduce.
+    The other schedule is still measured in the same command as a secondary."""
+    n, items, factor = a.ratings, a.items, (a.factor or 64)
+    t1 = 23.5 * n / 1e8 * factor / 64.0
+    contract = n == 100_000_000 and items == 100_000 and factor == 64
+    share_s = ({2: 9.78, 4: 5.92, 8: 2.71}.get(world) if contract else None) or t1 / world
+    share_a = ({2: 8.26, 4: 4.26, 8: 2.66}.get(world) if contract else None) or t1 / world
+    bpr = max(1, a.blocks_per_rank)
+    chunks = a.chunks if a.chunks > 0 else (8 if world < 8 else 4)
+    handoffs = chunks * world * bpr
+    nwin = a.windows if a.windows > 0 else max(1, int(np.ceil(n / max(items, 1) / 32.0)))
+    block_bytes = items * (factor + 1) * 4.0 / (world * bpr)
+    ho_ms = pf["handoff_1.6MB_us"] * 1e-3 * max(block_bytes / (400 * 1024 * 4.0), 0.25)    # measured on a 1.6 MB block; small blocks keep the fixed part
+    ar_ms = pf["allreduce_13MB_fp16_us"] * 1e-3 * max(items * (factor + 1) * 2.0 / (13 * 1024 * 1024.0), 0.25)
+    est_s, est_a = max(share_s, handoffs * ho_ms), share_a + nwin * ar_ms
+    return {"pick": "stratified" if est_s <= est_a else "minibatch", "est_stratified_ms": est_s, "est_allreduce_step_ms": est_a,
+            "handoffs_per_pass": handoffs, "handoff_ms": ho_ms, "windows": nwin, "allreduce_ms": ar_ms,
+            "what": "decided by rank 0 from the preflight's timings of this node; the other schedule is measured as a secondary of the same command"}
+
+
 def model_ms(name, world, exchange_step, n, items, factor, nwin, blocks, handoffs, t1_ms):
     """What DESIGN.md sections 6c / 6d / 6f expect for this line, so that a hardware curve can be checked against the model from the line
     itself.  compute share = the one-GPU share table of 6c / 6f where the workload is the contract one (100 M ratings, k = 64), else T1 / N;
@@ -1295,6 +1319,7 @@ def main():
                          "a child process.  auto (default): the MAIN workload, capped at --pmc-cap seconds (a pass that does not fit quotes the committed "
                          "profiles/hbm_traffic.json and says so); all: the secondary workloads too, no cap; off: quote the committed file")
     ap.add_argument("--pmc-cap", type=float, default=150.0, help="--pmc auto: seconds the in-run counter passes may take in total")
+    ap.add_argument("--no-auto-schedule", action="store_true", help="N>1, --exchange auto: keep the stratified ring as the main line whatever the preflight measured")
     ap.add_argument("--no-preflight", action="store_true", help="N>1: skip the checked all_reduce / ring hand-over before the run")
     ap.add_argument("--preflight-timeout", type=float, default=150.0, help="N>1: watchdog of rendezvous + preflight (seconds); on expiry the rank re-executes one ladder rung lower")
     ap.add_argument("--run-timeout", type=float, default=900.0, help="N>1: watchdog of the main workload (seconds)")
@@ -1375,6 +1400,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist, store, backend, pf, wd = None, None, None, None, None
+    schedule_choice = None
 
     def esc(reason):
         escalate(reason, rank, world, attempt, metric)
@@ -1404,6 +1430,15 @@ def main():
             store_agree(store, rank, world, "preflight", ok, seconds=a.preflight_timeout)
             if not ok:
                 raise RuntimeError(err)
+            # (gloo stages through the host -- its timings say nothing about xGMI; SVDF_BENCH_TEST_AUTO_SCHEDULE lets the one-GPU tests walk the path)
+            if ring and pf and a.exchange == "auto" and (backend == "nccl" or os.environ.get("SVDF_BENCH_TEST_AUTO_SCHEDULE")) and not a.no_auto_schedule \
+                    and "handoff_1.6MB_us" in pf:
+                if rank == 0:
+                    store.set("schedule_choice", json.dumps(choose_schedule(pf, world, a)))
+                schedule_choice = json.loads(store.get("schedule_choice").decode())   # blocks until rank 0 has decided
+                log("schedule: %s" % json.dumps(schedule_choice))
+                if schedule_choice["pick"] == "minibatch":
+                    a.exchange = "minibatch"
         except Exception as e:
             esc("rendezvous / preflight: %r" % (e,))
         wd.arm(a.run_timeout, "main workload", esc)
@@ -1445,7 +1480,7 @@ def main():
                 out[k] = m[k]
         if world > 1:
             out["exchange"] = dict(out.get("exchange") or {}, backend=backend, ladder_rung=attempt, ladder=LADDER[attempt],
-                                   fallback=fallback_log() or None, preflight_us=pf)
+                                   fallback=fallback_log() or None, preflight_us=pf, schedule_choice=schedule_choice)
 
     def emit(extra=None):
         if rank == 0:
@@ -1494,21 +1529,24 @@ def main():
         import argparse as _ap
         main_step = (main_res or {}).get("exchange", {}).get("step") if rank == 0 else None
         # (1) north_star's step: RCCL all-reduce of the per-item sums every window (window-minibatch step), when the main line was the ring
-        if a.exchange in ("auto", "stratified"):
-            wd.arm(a.secondary_timeout, "secondary: all-reduce window-minibatch step", finish_now)
+        # (when the preflight's timings made the all-reduce step the main line, the ring over torch.distributed is measured here instead)
+        other = ("allreduce_minibatch", "minibatch") if a.exchange in ("auto", "stratified") else \
+                (("stratified_ring", "stratified") if (schedule_choice or {}).get("pick") == "minibatch" else None)
+        if other is not None:
+            wd.arm(a.secondary_timeout, "secondary: %s" % other[0], finish_now)
             a2 = _ap.Namespace(**vars(a))
-            a2.exchange, a2.no_cpu_baseline = "minibatch", True
+            a2.exchange, a2.no_cpu_baseline = other[1], True
             t0 = time.time()
             try:
                 r = run_workload("basicmf", a2, env, 3, 1, False)
             except Exception as e:
                 import traceback
                 traceback.print_exc()
-                finish_now("allreduce_minibatch on rank %d: %r" % (rank, e))
+                finish_now("%s on rank %d: %r" % (other[0], rank, e))
             if r is not None:
                 keep = ("value", "unit", "ms_per_step", "order", "exchange", "phase_ms", "per_rank_ms", "roofline", "roofline_aggregate", "model_ms",
                         "rmse_test_after_run", "passes_before_rmse", "rmse_sequential_reference", "rmse_minus_sequential")
-                secondary["allreduce_minibatch"] = dict({k: r[k] for k in keep if r.get(k) is not None}, wall_s=round(time.time() - t0, 1), steps=3, warmup=1)
+                secondary[other[0]] = dict({k: r[k] for k in keep if r.get(k) is not None}, wall_s=round(time.time() - t0, 1), steps=3, warmup=1)
         # (1a) both steps with the rank's OWN RCCL communicator driven from C++ (svdf_rccl.cpp): the same RCCL, no Python / c10d call per collective --
         # what the host thread costs a pass shows in per_rank_ms.enqueue_* of this entry against the main line's; (1b) both steps again with the
         # DIRECT exchange between the processes (IPC-mapped buffers, no collective library on the data path)

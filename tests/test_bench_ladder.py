@@ -77,3 +77,15 @@ def test_model_figures_of_the_line():
     # another size: T1 / N
     o = bench.model_ms("basicmf", 2, "minibatch", 5_000_000, 100_000, 64, 2, 1, 0, 23.5 * 0.05)
     assert abs(o["compute_share_ms"] - 23.5 * 0.05 / 2) < 1e-9
+
+
+def test_schedule_choice_follows_the_preflight_timings():
+    import argparse
+    a = argparse.Namespace(ratings=100_000_000, items=100_000, factor=0, blocks_per_rank=2, chunks=0, windows=0)
+    fast_ring = bench.choose_schedule({"handoff_1.6MB_us": 50.0, "allreduce_13MB_fp16_us": 180.0}, 8, a)
+    assert fast_ring["pick"] == "stratified" and fast_ring["handoffs_per_pass"] == 64 and 3.0 < fast_ring["est_stratified_ms"] < 3.4
+    assert 7.5 < fast_ring["est_allreduce_step_ms"] < 8.7
+    slow_ring = bench.choose_schedule({"handoff_1.6MB_us": 200.0, "allreduce_13MB_fp16_us": 180.0}, 8, a)
+    assert slow_ring["pick"] == "minibatch" and slow_ring["est_stratified_ms"] > slow_ring["est_allreduce_step_ms"]
+    # a hidden hand-over never makes the estimate smaller than the compute share
+    assert bench.choose_schedule({"handoff_1.6MB_us": 1.0, "allreduce_13MB_fp16_us": 180.0}, 8, a)["est_stratified_ms"] == 2.71

@@ -71,3 +71,17 @@ def test_a_broken_ring_preflight_falls_back_to_the_all_reduce_step_and_says_so(h
     assert x["ladder_rung"] == 1 and x["step"] == "minibatch"
     assert x["fallback"] and x["fallback"][0]["attempt"] == 0
     assert line["value"] > 0 and abs(line["rmse_minus_sequential"]) <= 1e-4
+
+
+def test_the_preflight_timings_pick_the_main_schedule_and_the_other_one_becomes_a_secondary():
+    """--exchange auto on real devices decides ring vs all-reduce step from the preflight (bench.choose_schedule); gloo's host-staged hand-over is so slow
+    that the test hook makes the all-reduce step the main line here -- the ring is then measured as secondary.stratified_ring"""
+    line, err = _bench(["--gpus", "2", "--users", "10000", "--items", "1000", "--ratings", "1000000", "--steps", "1", "--no-cpu-baseline"],
+                       {"SVDF_BENCH_TEST_AUTO_SCHEDULE": "1"})
+    x = line["exchange"]
+    assert x["ladder_rung"] == 0 and x["fallback"] is None
+    c = x["schedule_choice"]
+    assert c["pick"] == x["step"] and c["est_stratified_ms"] > 0 and c["est_allreduce_step_ms"] > 0
+    other = "stratified_ring" if c["pick"] == "minibatch" else "allreduce_minibatch"
+    assert line["secondary"][other]["value"] > 0 and abs(line["secondary"][other]["rmse_minus_sequential"]) <= 1e-4
+    assert abs(line["rmse_minus_sequential"]) <= 1e-4
