@@ -12,7 +12,6 @@
 // Everything is enqueued on the trainer's stream; the host never waits inside a pass.  A wire buffer is not written again before every
 // rank has finished reading it: the next pack comes after this window's apply, which waited for every rank's phase-1 word.
 // Replaces, like the rest of section 6, what ONE process does in /root/reference/svd_feature.cpp:220-248 (the round loop) on N ranks.
-#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,12 +44,6 @@ struct IpcState {
     unsigned *err_host = nullptr;     // pinned, device-visible: raised by a wait kernel that hit its spin limit
     unsigned *err_dev = nullptr;
     unsigned long long spin_limit = 200000000ull;   // ~ several seconds of s_sleep(32) polls
-    // the hand-over's outgoing half rides a HIGH-priority side stream (wait for the slot's acknowledgement, store into the neighbour's inbox,
-    // signal): the trainer's stream only copies the block out and goes on with the next stratum step
-    hipStream_t xfer = nullptr;
-    hipEvent_t out_ready[2] = {nullptr, nullptr}, sent[2] = {nullptr, nullptr};
-    bool sent_set[2] = {false, false};
-    DevBuf<float> out[2];
 };
 void IpcDeleter::operator()(IpcState *s) const {
     if (!s) return;
@@ -59,12 +52,6 @@ void IpcDeleter::operator()(IpcState *s) const {
         (void)hipIpcCloseMemHandle(s->peer_wire[(size_t)r]);
         (void)hipIpcCloseMemHandle(s->peer_page[(size_t)r]);
     }
-    if (s->xfer) (void)hipStreamSynchronize(s->xfer);
-    for (int j = 0; j < 2; j++) {
-        if (s->out_ready[j]) (void)hipEventDestroy(s->out_ready[j]);
-        if (s->sent[j]) (void)hipEventDestroy(s->sent[j]);
-    }
-    if (s->xfer) (void)hipStreamDestroy(s->xfer);
     if (s->wire) (void)hipFree(s->wire);
     if (s->page) (void)hipFree(s->page);
     if (s->err_host) (void)hipHostFree(s->err_host);
@@ -112,15 +99,6 @@ void Engine::ipc_setup(int rank, int world, int64_t wire_bytes, int64_t block_fl
     S.opened.assign((size_t)world, false);
     S.peer_wire[(size_t)rank] = S.wire;
     S.peer_page[(size_t)rank] = S.page;
-    {
-        int lo = 0, hi = 0;
-        HIPCHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-        HIPCHECK(hipStreamCreateWithPriority(&S.xfer, hipStreamNonBlocking, hi));
-        for (int j = 0; j < 2; j++) {
-            HIPCHECK(hipEventCreateWithFlags(&S.out_ready[j], hipEventDisableTiming));
-            HIPCHECK(hipEventCreateWithFlags(&S.sent[j], hipEventDisableTiming));
-        }
-    }
     HIPCHECK(hipDeviceSynchronize());
 }
 // all_handles: world x (2 x 64) bytes in rank order, as gathered by the caller
@@ -189,23 +167,16 @@ void Engine::ipc_block_send(int dst, int slot) {
     int64_t n = 0;
     item_block_copy(nullptr, 0, &n);
     check((size_t)n <= S.block_floats, "svdf_ipc_block_send: the inbox of svdf_ipc_setup is too small for this block");
-    // the trainer's stream: the block copied out into this slot's send buffer (free once the side stream's previous store from it is over)
-    S.out[slot].reserve((size_t)std::max<int64_t>(n, 1));
-    if (S.sent_set[slot]) HIPCHECK(hipStreamWaitEvent(stream_, S.sent[slot], 0));
-    item_block_copy(S.out[slot].p, 0, nullptr);
-    HIPCHECK(hipEventRecord(S.out_ready[slot], stream_));
-    // the side stream: the slot is free once the destination acknowledged my previous block in it (ranks of a ring can drift apart by more than
-    // two steps); then the store into the neighbour's inbox and the flag
-    HIPCHECK(hipStreamWaitEvent(S.xfer, S.out_ready[slot], 0));
-    if (S.slot_seq[slot] != 0u) launch_ipc_wait(S.page + (size_t)dst * 32, 4 + slot, 1, S.slot_seq[slot], S.err_dev, S.spin_limit, S.xfer);
+    w_out_.reserve((size_t)n);
+    item_block_copy(w_out_.p, 0, nullptr);
+    // the slot is free once the destination acknowledged my previous block in it (ranks of a ring can drift apart by more than two steps)
+    if (S.slot_seq[slot] != 0u) launch_ipc_wait(S.page + (size_t)dst * 32, 4 + slot, 1, S.slot_seq[slot], S.err_dev, S.spin_limit, stream_);
     float *peer_inbox = reinterpret_cast<float *>(reinterpret_cast<char *>(S.peer_wire[(size_t)dst]) + S.wire_bytes) + (size_t)slot * S.block_floats;
-    launch_ipc_copy(peer_inbox, S.out[slot].p, n, S.xfer);
+    launch_ipc_copy(peer_inbox, w_out_.p, n, stream_);
     S.seq_block++;
     S.slot_seq[slot] = S.seq_block;
     unsigned *page[1] = {S.peer_page[(size_t)dst]};
-    launch_ipc_signal(page, 1, 2 + slot, S.rank, S.seq_block, S.xfer);
-    HIPCHECK(hipEventRecord(S.sent[slot], S.xfer));
-    S.sent_set[slot] = true;
+    launch_ipc_signal(page, 1, 2 + slot, S.rank, S.seq_block, stream_);
     HIPCHECK(hipGetLastError());
     n_launches_ += 2;
 }
@@ -228,7 +199,6 @@ int Engine::ipc_status() const { return ipc_ ? (int)*ipc_->err_host : 0; }
 void Engine::ipc_close() {
     if (!ipc_) return;
     HIPCHECK(hipStreamSynchronize(stream_));
-    if (ipc_->xfer) HIPCHECK(hipStreamSynchronize(ipc_->xfer));
     ipc_.reset();
 }
 
