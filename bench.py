@@ -533,14 +533,14 @@ def run_workload(name, a, env, steps, warmup, main_line):
         if use_ipc:
             adaptor.ipc_open(dist, rank, world, blocks=world * bpr)
         if use_native:
-            adaptor.rccl_open(dist, rank, world)
+            open_transport_agreed(env, "native", lambda: adaptor.rccl_open(dist, rank, world))
         st = StratifiedTrainer(adaptor, plan, world, rank, dist if world > 1 else None, blocks_per_rank=bpr)
     else:
         st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange, half_delta=(a.delta_dtype == "fp16"), parts=parts)
         if use_ipc:
             adaptor.ipc_open(dist, rank, world)
         if use_native:
-            adaptor.rccl_open(dist, rank, world)
+            open_transport_agreed(env, "native", lambda: adaptor.rccl_open(dist, rank, world))
 
     def sync_all():
         tr.synchronize()
@@ -1053,6 +1053,33 @@ def preflight(torch, dist, rank, world, device, ring, log):
     return out
 
 
+class TransportUnavailable(RuntimeError):
+    """a secondary's transport could not be opened on some rank; EVERY rank knows (agreed through the store), so the secondary is skipped, not fatal"""
+
+
+_open_counter = [0]
+
+
+def open_transport_agreed(env, what, open_fn):
+    """opens an optional exchange transport (native RCCL communicator, IPC mapping) on every rank and makes the ranks agree on the outcome through the
+    store before anyone trains through it: a rank that could not open it takes the others out of the secondary together.  (A rank that HANGS inside
+    the open is the watchdog's business.)"""
+    ok, err = True, None
+    try:
+        open_fn()
+    except Exception as e:   # noqa: BLE001
+        ok, err = False, repr(e)
+    store = env.get("store")
+    if store is not None and env["world"] > 1:
+        _open_counter[0] += 1
+        try:
+            store_agree(store, env["rank"], env["world"], "open_%s_%d" % (what, _open_counter[0]), ok, seconds=120)
+        except Exception as e:
+            raise TransportUnavailable("%s: %s" % (what, err or e))
+    elif not ok:
+        raise TransportUnavailable("%s: %s" % (what, err))
+
+
 def choose_schedule(pf, world, a):
     """--exchange auto on real devices (backend nccl): the stratified ring or the all-reduce step as the MAIN line, from what the preflight just measured
     on this node.  Both keep the accuracy contract; which one is faster depends on what a hand-over of one item block costs the rank that
@@ -1450,7 +1477,7 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    env = {"torch": torch, "dist": dist, "rank": rank, "world": world, "local_rank": local_rank, "log": log}
+    env = {"torch": torch, "dist": dist, "rank": rank, "world": world, "local_rank": local_rank, "log": log, "store": store}
 
     try:
         main_res = run_workload(a.workload, a, env, a.steps, a.warmup, True)
@@ -1551,7 +1578,7 @@ def main():
         # what the host thread costs a pass shows in per_rank_ms.enqueue_* of this entry against the main line's; (1b) both steps again with the
         # DIRECT exchange between the processes (IPC-mapped buffers, no collective library on the data path)
         variants = [("allreduce_minibatch_ipc", "minibatch", "ipc"), ("stratified_ipc", "stratified", "ipc")]
-        if backend == "nccl":   # RCCL refuses two ranks on one device: only with a device per rank
+        if backend == "nccl" or os.environ.get("SVDF_BENCH_TEST_NATIVE_ON_GLOO"):   # RCCL refuses two ranks on one device: only with a device per rank (the hook: tests of the skip path)
             variants = [("stratified_native", "stratified", "native"), ("allreduce_minibatch_native", "minibatch", "native")] + variants
         for key, exch, transport in variants:
             wd.arm(a.secondary_timeout, "secondary: %s" % key, finish_now)
@@ -1560,6 +1587,10 @@ def main():
             t0 = time.time()
             try:
                 r = run_workload("basicmf", a3, env, 3, 1, False)
+            except TransportUnavailable as e:   # every rank is here: the next secondary can run
+                log("secondary %s skipped: %s" % (key, e))
+                secondary[key] = {"error": str(e)[:300]}
+                continue
             except Exception as e:
                 import traceback
                 traceback.print_exc()

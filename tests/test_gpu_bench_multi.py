@@ -85,3 +85,16 @@ def test_the_preflight_timings_pick_the_main_schedule_and_the_other_one_becomes_
     other = "stratified_ring" if c["pick"] == "minibatch" else "allreduce_minibatch"
     assert line["secondary"][other]["value"] > 0 and abs(line["secondary"][other]["rmse_minus_sequential"]) <= 1e-4
     assert abs(line["rmse_minus_sequential"]) <= 1e-4
+
+
+def test_a_transport_that_cannot_be_opened_skips_its_secondary_only():
+    """two ranks on ONE device: ncclCommInitRank refuses the duplicate GPU on every rank -- the ranks agree through the store, the native secondaries
+    carry the error, the IPC secondaries and the line itself are unaffected"""
+    line, err = _bench(["--gpus", "2", "--users", "10000", "--items", "1000", "--ratings", "1000000", "--steps", "1", "--no-cpu-baseline",
+                        "--secondary-timeout", "150"], {"SVDF_BENCH_TEST_NATIVE_ON_GLOO": "1"})
+    sec = line["secondary"]
+    for key in ("stratified_native", "allreduce_minibatch_native"):
+        assert "error" in sec[key] and "native" in sec[key]["error"], sec[key]
+    for key in ("allreduce_minibatch_ipc", "stratified_ipc"):
+        assert sec[key]["value"] > 0 and abs(sec[key]["rmse_minus_sequential"]) <= 1e-4
+    assert line["value"] > 0 and "secondary_error" not in line
