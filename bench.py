@@ -531,14 +531,16 @@ def run_workload(name, a, env, steps, warmup, main_line):
     if stratified:
         adaptor.set_wire_half(False)
         if use_ipc:
-            adaptor.ipc_open(dist, rank, world, blocks=world * bpr)
+            open_transport_agreed(env, "ipc", lambda: adaptor.ipc_open(dist, rank, world, blocks=world * bpr, barrier=False))
+            dist.barrier()   # nobody signals into a page that is not mapped yet
         if use_native:
             open_transport_agreed(env, "native", lambda: adaptor.rccl_open(dist, rank, world))
         st = StratifiedTrainer(adaptor, plan, world, rank, dist if world > 1 else None, blocks_per_rank=bpr)
     else:
         st = ShardedTrainer(adaptor, wins, world, dist, force_exchange=a.force_exchange, half_delta=(a.delta_dtype == "fp16"), parts=parts)
         if use_ipc:
-            adaptor.ipc_open(dist, rank, world)
+            open_transport_agreed(env, "ipc", lambda: adaptor.ipc_open(dist, rank, world, barrier=False))
+            dist.barrier()
         if use_native:
             open_transport_agreed(env, "native", lambda: adaptor.rccl_open(dist, rank, world))
 

@@ -650,7 +650,7 @@ class HipShard:
     # ---- cross-process direct exchange (svdf_ipc.cpp): wire buffers / flag pages IPC-mapped into every rank's process
     ipc_ready = False
 
-    def ipc_open(self, dist, rank, world, blocks=0):
+    def ipc_open(self, dist, rank, world, blocks=0, barrier=True):
         """every rank exports its wire buffer + flag page, the handles travel through the process group (all_gather_object), every rank
         maps the others'.  blocks > 0: also an inbox for the stratified schedule's item blocks (num_item / blocks rows each)."""
         assert self.minibatch, "the IPC exchange serves the window-minibatch step"
@@ -668,7 +668,7 @@ class HipShard:
         else:
             dist.all_gather_object(gathered, mine)
         self.t.ipc_connect(b"".join(gathered))
-        if dist is not None:
+        if dist is not None and barrier:   # (barrier=False: the caller agrees on the outcome first, then meets the others itself)
             dist.barrier()   # nobody signals into a page that is not mapped yet
         self.ipc_ready, self.ipc_rank, self.ipc_world = True, rank, world
         self.ipc_sent, self.ipc_received = 0, 0
