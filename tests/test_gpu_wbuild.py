@@ -89,3 +89,32 @@ def test_bound_errors_come_from_the_device_builder_too():
         t2.dataset_window_from_pairs(i, i, i)
     with pytest.raises(sa.SvdfError, match="item feature index exceed bound"):
         t2.dataset_window_from_pairs(i, i, np.array([5, 12, 3], np.uint32))
+
+
+@pytest.mark.parametrize("shape", ["one_user", "one_item", "one_instance", "every_user_once", "two_items_pairs", "sorted_by_item"])
+def test_degenerate_windows_device_equals_host(shape):
+    rng = np.random.default_rng(11)
+    nu, ni, n, k = 200, 60, 3000, 64
+    pairs = shape == "two_items_pairs"
+    if shape == "one_user":
+        u = np.full(n, 7, np.uint32); i = rng.integers(0, ni, n).astype(np.uint32)
+    elif shape == "one_item":
+        u = rng.integers(0, nu, n).astype(np.uint32); i = np.full(n, 3, np.uint32)
+    elif shape == "one_instance":
+        n = 1; u = np.array([5], np.uint32); i = np.array([9], np.uint32)
+    elif shape == "every_user_once":
+        n = nu; u = rng.permutation(nu).astype(np.uint32); i = rng.integers(0, ni, n).astype(np.uint32)
+    elif shape == "two_items_pairs":
+        ni = 2; u = rng.integers(0, nu, n).astype(np.uint32); i = rng.integers(0, 2, n).astype(np.uint32)
+    else:   # file order already item-major, users descending: both regroupings have to move everything
+        i = np.sort(rng.integers(0, ni, n)).astype(np.uint32); u = (nu - 1 - (np.arange(n) % nu)).astype(np.uint32)
+    if pairs:
+        cols = (u, i, (1 - i).astype(np.uint32))
+    else:
+        cols = (u, i, rng.integers(1, 6, n).astype(np.float32))
+    conf = _conf(nu, ni, 128 if pairs else k, pairs)
+    for window in (max(n // 3, 1), n):
+        host, wh = _train(conf, cols, pairs, 0, window)
+        dev, wd = _train(conf, cols, pairs, 1, window)
+        assert wh == wd
+        _same(host, dev)
