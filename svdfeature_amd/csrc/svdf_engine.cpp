@@ -2717,6 +2717,11 @@ void Engine::train_dataset(Dataset *ds) {
     const Schedule &sc = ds->sched;
     check(!lazy_decay() || ds->kind == 1 || ds->kind == 4 || (ds->kind == 3 && ds->num_simple_units == 0),
           "train_dataset: the dataset was scheduled before lazy decay (reg_method/reg_global >= 4) was selected");
+    if (ds->kind == 2 && chain_width_ > 0 && !ds->d_level_ptr_ok && sc.num_levels() >= 4) {   // the level boundaries for chained launches: once, outside any capture
+        ds->d_level_ptr.upload(sc.level_ptr.data(), sc.level_ptr.size(), stream_);
+        HIPCHECK(hipStreamSynchronize(stream_));
+        ds->d_level_ptr_ok = true;
+    }
     auto issue = [&]() {
         if (ds->kind == 0) {
             BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
@@ -2744,8 +2749,24 @@ void Engine::train_dataset(Dataset *ds) {
             if (fewrow_gslots_ && fewrow_fast_ && fewrow_gslots_applies(P, S, ds->fused.max_nu, ds->fused.max_ni, ds->fused.dense_slots)) {
                 for (size_t l = 0; l < sc.num_levels(); l++) launch_fewrow_gslots(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], stream_);
             } else {
-                for (size_t l = 0; l < sc.num_levels(); l++)
-                    launch_fused(P, S, ds->fused.max_nu, ds->fused.max_ni, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
+                // runs of NARROW levels (a rank pass in file order: tens of thousands of levels of a few dozen pairs) go through one launch per
+                // run -- one workgroup walks the levels with a barrier in between (k_fewrow_slots_chain) --, everything else level by level
+                const size_t L = sc.num_levels();
+                const long cw = chain_width_;
+                const bool can_chain = cw > 0 && ds->d_level_ptr_ok && launch_fewrow_chain(P, S, ds->fused.max_nu, ds->fused.max_ni, nullptr, 0, 0, stream_);
+                for (size_t l = 0; l < L;) {
+                    size_t e = l;
+                    if (can_chain) while (e < L && sc.level_ptr[e + 1] - sc.level_ptr[e] <= cw) e++;
+                    if (e >= l + 4) {
+                        (void)launch_fewrow_chain(P, S, ds->fused.max_nu, ds->fused.max_ni, ds->d_level_ptr.p, (long)l, (long)e, stream_);
+                        n_chained_levels_ += (int64_t)(e - l);
+                        l = e;
+                        continue;
+                    }
+                    const size_t stop = std::max(e, l + 1);
+                    for (; l < stop; l++)
+                        launch_fused(P, S, ds->fused.max_nu, ds->fused.max_ni, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
+                }
             }
         } else {
             DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
@@ -3146,6 +3167,7 @@ int64_t Engine::counter(int what) const {
     case 12: return multi_counter(4);   // exchange path: 0 p2p, 1 rccl
     case 13: return n_init_reports_;    // init_model on the device: values the host libm decided (near a float rounding boundary)
     case 14: return n_init_draws_;      // init_model on the device: rand() draws consumed
+    case 15: return n_chained_levels_;  // conflict-free levels executed inside chained launches (k_fewrow_slots_chain)
     default: return -1;
     }
 }
@@ -3179,6 +3201,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "device_init")) { device_init_ = value != 0; return 0; }
     if (!strcmp(name, "device_window")) { device_window_ = value != 0; return 0; }
     if (!strcmp(name, "device_load")) { device_load_ = value != 0; return 0; }
+    if (!strcmp(name, "chain_width")) { check(value >= 0, "chain_width must not be negative"); chain_width_ = value; return 0; }
     if (!strcmp(name, "wseq_build_threads")) { check(value >= 1 && value <= 256, "wseq_build_threads must be in 1 .. 256"); wseq_build_threads_ = (int)value; return 0; }
     if (!strcmp(name, "device_init_margin_log2")) { check(value >= 8 && value <= 52, "device_init_margin_log2 must be in 8 .. 52"); device_init_margin_log2_ = (int)value; return 0; }
     if (!strcmp(name, "fewrow_fast")) { fewrow_fast_ = value != 0; params_dirty_ = true; return 0; }

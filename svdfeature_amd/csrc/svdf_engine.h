@@ -219,6 +219,8 @@ struct Dataset {
     DevBuf<unsigned> win_item1;   // rank pairs: the second (higher-id) item entry, its slot and sign; entry 0 uses item / win_slot / ival
     DevBuf<float> win_ival1;
     long win_item_lo = 0, win_item_hi = -1;   // kind 5: lowest / highest item id with an instance in the window (-1: none)
+    DevBuf<long> d_level_ptr;     // kind 2: the level boundaries in HBM, uploaded when a run of narrow levels is first chained (k_fewrow_slots_chain)
+    bool d_level_ptr_ok = false;
     long win_slots = 0;           // contribution slots of the window = item entries (kind 7: + feedback entries)
     // kind 7: window-minibatch data set of user units (svdf_k_wunit.hip): user-group blocks / rows with global features
     DevBuf<WinUnit> wu_units;
@@ -469,7 +471,8 @@ class Engine {
     bool device_window_ = true;                     // knob "device_window": kind-5 window data sets regrouped on the device (svdf_k_wbuild.hip)
     bool device_init_ = true;                       // knob "device_init": rand_init on the device (svdf_k_init.hip)
     int device_init_margin_log2_ = 46;              // knob "device_init_margin_log2": values closer than 2^-this (relative) to a float rounding boundary go to the host libm
-    int64_t n_init_reports_ = 0, n_init_draws_ = 0;
+    int64_t n_init_reports_ = 0, n_init_draws_ = 0, n_chained_levels_ = 0;
+    long chain_width_ = 96;                         // knob "chain_width": levels of at most this many instances are walked in runs inside ONE launch by one workgroup (0 = off)
     bool fewrow_fast_ = true;                       // knob "fewrow_fast": specialised few-row kernel (svdf_k_fewrow.hip)
     // columns that are already in HBM (file order) -> level schedule + level-sorted copies
     Dataset *dataset_fewrow_on_device(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);

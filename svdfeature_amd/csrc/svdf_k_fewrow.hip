@@ -100,32 +100,43 @@ __global__ __launch_bounds__(256) void k_fewrow_fast(const DevParams P, const Fu
 // the chunks of slot 0 in lane order (LANES - 1 row_shr:T steps), the finished sums rotate from the row's last lanes to its first
 // (row_ror:T) and are folded into the addend of the next slot's first chunk -- the carry trick of group_dot<32> --, and so on
 // through the slots (dot_slots, svdf_device.h).  Same additions in the same order.  k = 128: LANES = 16, V = 2 (one instance per DPP row).
+// the schedule record of one instance (the level-sorted columns of FusedSchedule): what a chained launch requests one level ahead
+template <int NU, int NI>
+struct FewrowRec { float label; unsigned ur[NU], ir[NI]; float ua[NU], ia[NI]; };
+template <int LANES, int NU, int NI>
+__device__ __forceinline__ FewrowRec<NU, NI> fewrow_slots_rec(const FusedSchedule &S, long begin, long end, long wave) {
+    constexpr int T = 16 / LANES, IPW = 64 / LANES;
+    const int lane = threadIdx.x & 63;
+    const int gslot = (lane >> 4) * T + (lane & (T - 1));
+    const long s = begin + wave * (long)IPW + gslot;
+    const bool valid = s < end;
+    const long sc = valid ? s : begin;
+    FewrowRec<NU, NI> R;
+    R.label = S.label[sc];
+#pragma unroll
+    for (int a = 0; a < NU; a++) { R.ur[a] = valid ? S.uidx[a][sc] : (unsigned)SLOT_ABSENT; R.ua[a] = S.uval[a][sc]; }
+#pragma unroll
+    for (int b = 0; b < NI; b++) { R.ir[b] = valid ? S.iidx[b][sc] : (unsigned)SLOT_ABSENT; R.ia[b] = S.ival[b][sc]; }
+    return R;
+}
+// the instances [begin + wave IPW, begin + (wave + 1) IPW) of a level, by one wave, their records in R
 template <int LANES, int V, int NU, int NI>
-__global__ __launch_bounds__(256) void k_fewrow_slots(const DevParams P, const FusedSchedule S, long begin, long end) {
+__device__ __forceinline__ void fewrow_slots_apply(const DevParams &P, const FewrowRec<NU, NI> &R) {
     constexpr int T = 16 / LANES;          // instances interleaved in one DPP row
-    constexpr int IPW = 64 / LANES;        // instances per wave
     constexpr int K = 4 * LANES * V;
     const int lane = threadIdx.x & 63;
     const int m = (lane & 15) / T;
-    const int gslot = (lane >> 4) * T + (lane & (T - 1));
-    long tile = blockIdx.x;
-    if (P.xcd_remap) tile = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const long wave = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long s = begin + wave * (long)IPW + gslot;
-    if (begin + wave * (long)IPW >= end) return;
-    const bool valid = s < end;
-    const long sc = valid ? s : begin;
     const int pitch = P.pitch;
     const bool use_ubias = P.no_user_bias == 0;
 
     unsigned ur[NU], ir[NI];
     float ua[NU], ia[NI], bu[NU], bi[NI];
     float4 p[NU][V], q[NI][V];
-    const float label = S.label[sc];
+    const float label = R.label;
 #pragma unroll
-    for (int a = 0; a < NU; a++) { ur[a] = valid ? S.uidx[a][sc] : (unsigned)SLOT_ABSENT; ua[a] = S.uval[a][sc]; }
+    for (int a = 0; a < NU; a++) { ur[a] = R.ur[a]; ua[a] = R.ua[a]; }
 #pragma unroll
-    for (int b = 0; b < NI; b++) { ir[b] = valid ? S.iidx[b][sc] : (unsigned)SLOT_ABSENT; ia[b] = S.ival[b][sc]; }
+    for (int b = 0; b < NI; b++) { ir[b] = R.ir[b]; ia[b] = R.ia[b]; }
 #pragma unroll
     for (int a = 0; a < NU; a++) {
 #pragma unroll
@@ -203,6 +214,33 @@ __global__ __launch_bounds__(256) void k_fewrow_slots(const DevParams P, const F
         P.bias[P.item_off + ir[b]] = (bi[b] + si) * dec_ib;
     }
 }
+template <int LANES, int V, int NU, int NI>
+__global__ __launch_bounds__(256) void k_fewrow_slots(const DevParams P, const FusedSchedule S, long begin, long end) {
+    long tile = blockIdx.x;
+    if (P.xcd_remap) tile = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long wave = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (begin + wave * (long)(64 / LANES) >= end) return;
+    fewrow_slots_apply<LANES, V, NU, NI>(P, fewrow_slots_rec<LANES, NU, NI>(S, begin, end, wave));
+}
+// DEEP, NARROW dependency graphs (a rank pass in the reference's own file order, apex_svd_data.cpp:946-965: user-grouped pairs, 58 693 levels of
+// ~54 pairs): a launch per level costs its boundary and a cold start (~5.4 us) for 14 waves of work.  ONE workgroup of 16 waves walks a RUN of
+// narrow levels inside one launch instead: level l's instances, a workgroup barrier, level l + 1 -- the waves share the CU's vector L1, so what
+// one of them stored before the barrier is what the others load after it (workgroup scope needs no cache action).  Same instances in the same
+// level order, same arithmetic: the same bits as one launch per level (tests/test_gpu_sched.py).
+template <int LANES, int V, int NU, int NI>
+__global__ __launch_bounds__(1024) void k_fewrow_slots_chain(const DevParams P, const FusedSchedule S, const long *level_ptr, long l0, long l1) {
+    constexpr int IPW = 64 / LANES;
+    const long w0 = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (long l = l0; l < l1; l++) {
+        const long begin = level_ptr[l], end = level_ptr[l + 1];
+        for (long wave = w0; begin + wave * (long)IPW < end; wave += nw)
+            fewrow_slots_apply<LANES, V, NU, NI>(P, fewrow_slots_rec<LANES, NU, NI>(S, begin, end, wave));
+        __syncthreads();
+    }
+}
+// (requesting the next level's records before the barrier was built and measured: no gain on the 54-pair levels of a real rank pass -- a level there
+// is its rows' latency chain, ~4.5 us, not its launch -- and slower on one-pair levels; the chain pays on streams that are nearly totally ordered,
+// 3.4 -> 1.5 us per level, and is neutral otherwise: profiles/r04_chain_probe.txt)
 
 // ---- one user id, one item id, up to four INLINE global slots (the neighbourhood shape of BASELINE configs[3]: FusedSchedule::gsi / gsv),
 // the usual configuration of fewrow_fast_applies plus reg_global 0 / 1 through reg_gbias.  A level of this shape is ~280 instances: the
@@ -322,6 +360,16 @@ static void launch_fewrow_lpi(const DevParams &P, const FusedSchedule &S, int nu
     else if (nu <= 1) launch_fewrow_shape<LPI, 1, 2>(P, S, begin, end, bt, st);
     else if (ni <= 1) launch_fewrow_shape<LPI, 2, 1>(P, S, begin, end, bt, st);
     else launch_fewrow_shape<LPI, 2, 2>(P, S, begin, end, bt, st);
+}
+// a run of narrow levels [l0, l1) in one launch (k_fewrow_slots_chain); false when the shape has no chain form (the caller launches level by level)
+bool launch_fewrow_chain(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, const long *d_level_ptr, long l0, long l1, hipStream_t st) {
+    if (!(P.fewrow_fast && fewrow_fast_applies(P, S) && P.k == 128 && P.fewrow_i16 == 1)) return false;
+    if (l1 <= l0) return true;
+    if (max_nu <= 1 && max_ni <= 1) hipLaunchKernelGGL((k_fewrow_slots_chain<16, 2, 1, 1>), dim3(1), dim3(1024), 0, st, P, S, d_level_ptr, l0, l1);
+    else if (max_nu <= 1) hipLaunchKernelGGL((k_fewrow_slots_chain<16, 2, 1, 2>), dim3(1), dim3(1024), 0, st, P, S, d_level_ptr, l0, l1);
+    else if (max_ni <= 1) hipLaunchKernelGGL((k_fewrow_slots_chain<16, 2, 2, 1>), dim3(1), dim3(1024), 0, st, P, S, d_level_ptr, l0, l1);
+    else hipLaunchKernelGGL((k_fewrow_slots_chain<16, 2, 2, 2>), dim3(1), dim3(1024), 0, st, P, S, d_level_ptr, l0, l1);
+    return true;
 }
 // true when the configuration / data set is the one this kernel is specialised for
 bool fewrow_fast_applies(const DevParams &P, const FusedSchedule &S) {

@@ -23,6 +23,7 @@ void launch_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int ma
                   int block_threads, hipStream_t st);
 // the same step specialised for data sets without global features under L2 decay without ranges / relaxed ids (svdf_k_fewrow.hip)
 bool fewrow_fast_applies(const DevParams &P, const FusedSchedule &S);
+bool launch_fewrow_chain(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, const long *d_level_ptr, long l0, long l1, hipStream_t st);
 bool fewrow_gslots_applies(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, bool dense_slots);
 void launch_fewrow_gslots(const DevParams &P, const FusedSchedule &S, long begin, long end, hipStream_t st);
 void launch_fewrow_fast(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int block_threads, hipStream_t st);
