@@ -1234,7 +1234,7 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
                         "frac": alg * steps / (ev_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": ("k_wunit_wave<2,8,BF16,true> (one wave per user unit)" if name == "svdpp" else "k_wunit_fast<16,2,false,4,1>" if name == "neighbourhood" else "k_wunit_fast<LANES,2,false,0,4>") + " + k_wunit_sum<32,false,true> (two launches per window)",
                         "launches": launches, "avg_launch_us": ev_ms * 1e3 / max(launches, 1), "algorithmic_bytes_per_launch": alg * steps / max(launches, 1),
                         "algorithmic_bytes_per_instance": alg / max(n, 1), "traffic": wtraffic,
-                        "traffic_source": "profiles/hbm_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 of the unit kernel (k_wunit_wave / k_wunit_fast) + k_wunit_sum per window / 2 launches (builder's rocprofv3 PMC passes, tools/profile_round4.sh)"}}
+                        "traffic_source": "profiles/hbm_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024 of the unit kernel (k_wunit_wave / k_wunit_fast) + k_wunit_sum per window / 2 launches (builder's rocprofv3 PMC passes, tools/profile_round.sh)"}}
     log("%s window step: %.2f ms per pass = %.1f M inst/s (%.1f%% of peak), %d windows, quality %s vs sequential %s" % (
         name, res["ms_per_step"], res["value"] / 1e6, 100 * res["roofline"]["frac"], ds.num_batches, rm_run, rm_seq))
     for x in (ds, dsq):
@@ -1397,7 +1397,7 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL across processes needs it on this driver
     a.pmc_results = {}
     if a.pmc != "off" and world == 1 and not a.force_exchange:
-        # before this process opens the device, so that the counted child is alone on the GPU (the same commands as tools/profile_round3.sh).
+        # before this process opens the device, so that the counted child is alone on the GPU (the same commands as tools/profile_round.sh).
         # auto: the main workload only, under a 150 s cap (a pass that does not fit falls back to the committed profiles/hbm_traffic.json);
         # the children read this process's synthetic stream from /dev/shm instead of drawing it again
         import shutil, tempfile
