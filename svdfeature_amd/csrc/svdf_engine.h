@@ -44,9 +44,25 @@ struct DevBuf {
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
-    void release();
-    void reserve(size_t n);            // grow-only, contents not preserved
-    void upload(const T *src, size_t n, hipStream_t st);
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    void reserve(size_t n) {           // grow-only, contents not preserved
+        if (n <= cap && p) return;
+        release();
+        const size_t want = n ? n : 1;
+        hipError_t e = hipMalloc((void **)&p, want * sizeof(T));
+        if (e != hipSuccess) fail(std::string("HIP error: ") + hipGetErrorString(e) + " at hipMalloc (DevBuf::reserve)");
+        cap = want;
+    }
+    void upload(const T *src, size_t n, hipStream_t st) {
+        reserve(n);
+        if (!n) return;
+        hipError_t e = hipMemcpyAsync(p, src, n * sizeof(T), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) fail(std::string("HIP error: ") + hipGetErrorString(e) + " at hipMemcpyAsync (DevBuf::upload)");
+    }
 };
 
 // --------------------------------------------------------------------------- scheduler (pure host)

@@ -1,0 +1,604 @@
+// svdf_model.cpp -- part of the host engine (class Engine, svdf_engine.h): model geometry, rand_init, model file I/O, host <-> HBM copies, parameter views
+// Reference citations are relative to /root/reference.
+#include "svdf_engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <atomic>
+#include <thread>
+
+#include "svdf_kernels.h"
+#include "svdf_internal.h"
+
+namespace svdf {
+
+void Engine::compute_geometry() {  // SVDModel::alloc_space apex_svd_model.h:511-556
+    const int ustart = (mp_.common_feedback_space == 0 && user_group()) ? mp_.num_ufeedback : 0;
+    if (mp_.common_latent_space == 0) {
+        n_uiset_ = (long)ustart + mp_.num_user + mp_.num_item;
+        user_off_ = (unsigned)ustart;
+        item_off_ = (unsigned)(ustart + mp_.num_user);
+    } else {
+        check(mp_.num_user == mp_.num_item, "num_user and num_item must be the same to use common latent space");
+        check(mp_.common_feedback_space != 0, "common latent space must enforce common feedback space");
+        n_uiset_ = mp_.num_item;
+        user_off_ = item_off_ = (unsigned)ustart;
+    }
+    fb_off_ = mp_.common_feedback_space == 0 ? 0u : user_off_;
+    pitch_ = ((mp_.num_factor + 3) / 4) * 4;   // ceil(4k/16)*16 bytes (apex_tensor_sse.h:26-27)
+    space_allocated_ = true;
+}
+void Engine::alloc_host_model() {
+    compute_geometry();
+    hW_.assign((size_t)n_uiset_ * pitch_, 0.0f);
+    hbias_.assign((size_t)n_uiset_, 0.0f);
+    hg_.assign((size_t)mp_.num_global, 0.0f);
+    host_model_valid_ = true;
+}
+
+// ---- PRNG: apex-tensor/apex_random.h:42-77 over libc rand(), so the starting point is bit-identical
+static inline double next_double2() { return ((double)rand() + 1.0) / ((double)RAND_MAX + 2.0); }
+static inline double sample_normal() {
+    double x, y, s;
+    do {
+        x = 2 * next_double2() - 1.0;
+        y = 2 * next_double2() - 1.0;
+        s = x * x + y * y;
+    } while (s >= 1.0 || s == 0.0);
+    return x * sqrt(-2.0 * log(s) / s);
+}
+static void sample_gaussian(float *w, long rows, int cols, int pitch, float sd) {  // apex_tensor_cpu_inline_common.h:249-253
+    for (long y = 0; y < rows; y++)
+        for (int x = 0; x < cols; x++) w[(size_t)y * pitch + x] = (float)sample_normal() * sd;
+}
+static float calc_base_score(float base_score, int type) {  // apex_svd_model.h:220-237
+    switch (type) {
+    case ACT_LINEAR: case ACT_HINGE_L2: case ACT_HINGE_SMOOTH: return base_score;
+    case ACT_SIGMOID_L2: case ACT_SIGMOID_LIKELIHOOD: case ACT_SIGMOID_RANK: case ACT_SIGMOID_QSGRAD:
+        check(base_score > 0.0f && base_score < 1.0f, "sigmoid range constrain");
+        return -logf(1.0f / base_score - 1.0f);
+    default: fail("unkown active type");
+    }
+}
+void Engine::rand_init() {  // SVDModel::rand_init apex_svd_model.h:665-705
+    mp_.base_score = calc_base_score(mp_.base_score, mtype_.active_type);
+    const int k = mp_.num_factor;
+    float *Wu = hW_.data() + (size_t)user_off_ * pitch_;
+    float *Wi = hW_.data() + (size_t)item_off_ * pitch_;
+    {
+        long rows = mp_.num_randinit_ufactor != 0 ? mp_.num_randinit_ufactor : mp_.num_user;
+        sample_gaussian(Wu, rows, k, pitch_, mp_.u_init_sigma);
+        if (mp_.user_nonnegative)
+            for (long y = 0; y < mp_.num_user; y++)
+                for (int x = 0; x < k; x++) Wu[(size_t)y * pitch_ + x] = fabsf(Wu[(size_t)y * pitch_ + x]);
+    }
+    if (mp_.common_latent_space == 0) {
+        long rows = mp_.num_randinit_ifactor != 0 ? mp_.num_randinit_ifactor : mp_.num_item;
+        sample_gaussian(Wi, rows, k, pitch_, mp_.i_init_sigma);
+        if (mp_.item_nonnegative)
+            for (long y = 0; y < rows; y++)
+                for (int x = 0; x < k; x++) Wi[(size_t)y * pitch_ + x] = fabsf(Wi[(size_t)y * pitch_ + x]);
+    }
+    if (user_group())  // draws are consumed even when sigma == 0 (apex_svd_model.h:702-704)
+        sample_gaussian(hW_.data() + (size_t)fb_off_ * pitch_, num_fb_rows(), k, pitch_, mp_.ufeedback_init_sigma);
+}
+
+// SVDModel::rand_init on the device (svdf_k_init.hip): the same draws, the same accepted attempts, the same float products; the few
+// values whose double sits within `margin` of a float rounding boundary are recomputed here with the host libm (the one function the
+// device cannot restate) and patched.  Leaves the model in HBM (no host copy) and libc's generator where the reference's calls would
+// have left it.  Returns false -- nothing touched -- when the path does not apply: libc's generator not in its 31-word mode, or a
+// feedback space that aliases the user rows (W_ufeedback is then written over W_user in sequence).
+bool Engine::rand_init_device() {
+    if (host_only_ || !device_init_) return false;
+    compute_geometry();
+    if (user_group() && mp_.common_feedback_space != 0) return false;
+    LibcRand s0;
+    if (!libc_rand_capture(s0)) return false;
+    const int k = mp_.num_factor;
+    InitPlan plan;
+    memset(&plan, 0, sizeof(plan));
+    plan.pitch = pitch_;
+    plan.margin = std::ldexp(1.0, -device_init_margin_log2_);
+    long total = 0;
+    auto add = [&](long rows, unsigned row0, float sigma, bool absf) {
+        InitSeg &g = plan.seg[plan.nseg++];
+        g.begin = total; g.count = rows * (long)k; g.row0 = (long)row0; g.k = std::max(k, 1); g.sigma = sigma; g.absf = absf ? 1 : 0;
+        total += g.count;
+    };
+    add(mp_.num_randinit_ufactor != 0 ? mp_.num_randinit_ufactor : mp_.num_user, user_off_, mp_.u_init_sigma, mp_.user_nonnegative != 0);
+    if (mp_.common_latent_space == 0)
+        add(mp_.num_randinit_ifactor != 0 ? mp_.num_randinit_ifactor : mp_.num_item, item_off_, mp_.i_init_sigma, mp_.item_nonnegative != 0);
+    if (user_group()) add(num_fb_rows(), fb_off_, mp_.ufeedback_init_sigma, false);
+    for (int g = plan.nseg; g < 3; g++) plan.seg[g].begin = total;
+    plan.total = total;
+    for (int g = 0; g < plan.nseg; g++)   // a view that does not fit its matrix (inconsistent shape keys): leave it to the host loop, as before
+        if (plan.seg[g].count < 0 || plan.seg[g].row0 + plan.seg[g].count / std::max(k, 1) > (long)n_uiset_) return false;
+    need_device("init_model");
+    const float base_score = calc_base_score(mp_.base_score, mtype_.active_type);
+    dW_.reserve(std::max<size_t>((size_t)n_uiset_ * pitch_, 1));
+    HIPCHECK(hipMemsetAsync(dW_.p, 0, (size_t)n_uiset_ * pitch_ * sizeof(float), stream_));
+    n_init_reports_ = 0;
+    if (total > 0) {
+        const long TILE = 1L << 25, C = 16384;   // attempts per tile (256 MB of raw draws), draws per jump-ahead chunk
+        const int report_cap = 1 << 20;
+        DevBuf<unsigned> raw, flag, off, tables;
+        DevBuf<char> tmp;
+        DevBuf<unsigned long long> state;
+        DevBuf<InitReport> reports;
+        state.reserve(4); reports.reserve((size_t)report_cap);
+        HIPCHECK(hipMemsetAsync(state.p, 0, 4 * sizeof(unsigned long long), stream_));
+        long accepted = 0, draws_total = 0;
+        LibcRand cur = s0, after = s0;
+        std::vector<uint32_t> htab;
+        for (bool done = false; !done;) {
+            const long need = total - accepted;
+            const long A = std::min<long>(TILE, (long)((double)need / 0.78539816339744831) + 8 * (long)std::sqrt((double)need) + 4096);
+            const long D = 2 * A, nchunks = (D + C - 1) / C;
+            libc_rand_chunk_states(cur, nchunks, C, htab);
+            tables.upload(htab.data(), htab.size(), stream_);
+            raw.reserve((size_t)D); flag.reserve((size_t)A); off.reserve((size_t)A);
+            const size_t tb = init_scan_tmp_bytes(A);
+            tmp.reserve(std::max<size_t>(tb, 1));
+            launch_init_expand(tables.p, nchunks, C, D, raw.p, stream_);
+            HIPCHECK(hipMemsetAsync(state.p, 0, 2 * sizeof(unsigned long long), stream_));
+            launch_init_tile(raw.p, A, accepted, plan, dW_.p, flag.p, off.p, tmp.p, tb, state.p, reports.p, report_cap, stream_);
+            unsigned long long hs[4];
+            HIPCHECK(hipMemcpyAsync(hs, state.p, sizeof(hs), hipMemcpyDeviceToHost, stream_));
+            HIPCHECK(hipStreamSynchronize(stream_));
+            long used = D;   // draws of this tile that the reference's loop would have taken
+            if (hs[1] != 0) { used = 2 * (long)hs[1]; done = true; }
+            else { accepted += (long)hs[0]; check((long)hs[0] > 0, "init_model: the device sampler made no progress"); }
+            LibcRand nxt = cur;
+            if (used >= 31) {
+                HIPCHECK(hipMemcpyAsync(nxt.x, raw.p + (used - 31), 31 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+                HIPCHECK(hipStreamSynchronize(stream_));
+            } else {
+                uint32_t head[31];
+                HIPCHECK(hipMemcpyAsync(head, raw.p, (size_t)used * sizeof(uint32_t), hipMemcpyDeviceToHost, stream_));
+                HIPCHECK(hipStreamSynchronize(stream_));
+                for (long j = 0; j < 31 - used; j++) nxt.x[j] = cur.x[used + j];
+                for (long j = 0; j < used; j++) nxt.x[31 - used + j] = head[j];
+            }
+            cur = nxt; after = nxt;
+            draws_total += used;
+            n_init_reports_ = (int64_t)hs[2];
+        }
+        // values near a float rounding boundary: the host libm decides (apex_random.h:67-77 as written)
+        if (n_init_reports_ > report_cap) {   // a margin wider than the float spacing reports everything: the host loop does the whole job
+            n_init_reports_ = 0; n_init_draws_ = 0;   // (libc's generator and the parameters have not been touched)
+            return false;
+        }
+        if (n_init_reports_ > 0) {
+            std::vector<InitReport> rep((size_t)n_init_reports_);
+            HIPCHECK(hipMemcpyAsync(rep.data(), reports.p, rep.size() * sizeof(InitReport), hipMemcpyDeviceToHost, stream_));
+            HIPCHECK(hipStreamSynchronize(stream_));
+            std::vector<long> pidx(rep.size());
+            std::vector<float> pval(rep.size());
+            for (size_t q = 0; q < rep.size(); q++) {
+                const double x = 2 * (((double)(int)(rep[q].r1 >> 1) + 1.0) / ((double)RAND_MAX + 2.0)) - 1.0;
+                const double y = 2 * (((double)(int)(rep[q].r2 >> 1) + 1.0) / ((double)RAND_MAX + 2.0)) - 1.0;
+                const double sq = x * x + y * y;
+                const double v = x * sqrt(-2.0 * log(sq) / sq);
+                int g = 0;
+                while (g + 1 < plan.nseg && rep[q].j >= plan.seg[g + 1].begin) g++;
+                const InitSeg &sg = plan.seg[g];
+                const long jj = rep[q].j - sg.begin, row = jj / sg.k, col = jj - row * sg.k;
+                float w = (float)v * sg.sigma;
+                if (sg.absf) w = fabsf(w);
+                pidx[q] = (sg.row0 + row) * (long)pitch_ + col;
+                pval[q] = w;
+            }
+            DevBuf<long> didx;
+            DevBuf<float> dval;
+            didx.upload(pidx.data(), pidx.size(), stream_);
+            dval.upload(pval.data(), pval.size(), stream_);
+            launch_init_patch((long)pidx.size(), didx.p, dval.p, dW_.p, stream_);
+            HIPCHECK(hipStreamSynchronize(stream_));
+        }
+        libc_rand_restore(after);   // libc's generator moves on by exactly the draws of the reference's loop
+        n_init_draws_ = draws_total;
+    }
+    mp_.base_score = base_score;
+    // the rest of a fresh model: biases and global biases 0 (apex_svd_model.h:666-667), the kernels' state words 0
+    dbias_.reserve(std::max<size_t>((size_t)n_uiset_, 1));
+    HIPCHECK(hipMemsetAsync(dbias_.p, 0, std::max<size_t>((size_t)n_uiset_, 1) * sizeof(float), stream_));
+    g_stride_ = wanted_g_stride();
+    dg_.reserve(std::max<size_t>((size_t)mp_.num_global * (size_t)g_stride_, 1));
+    HIPCHECK(hipMemsetAsync(dg_.p, 0, std::max<size_t>((size_t)mp_.num_global * (size_t)g_stride_, 1) * sizeof(float), stream_));
+    std::vector<float> zero(imfb() ? (size_t)4 + IMFB_DEPTH_MAX * ((size_t)2 * pitch_ + 4) : (size_t)2 * pitch_ + 4, 0.0f);
+    dstate_.upload(zero.data(), zero.size(), stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    device_model_ = true;
+    params_dirty_ = true;
+    hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hbias_.shrink_to_fit(); hg_.clear();
+    host_model_valid_ = false;
+    return true;
+}
+
+void Engine::init_model() {  // apex_svd_base.h:146-149
+    if (rand_init_device()) {
+        if (gpus_ > 1) download_model();   // the other ranks of an amd:gpus handle start from a host copy of rank 0's model
+    } else {
+        alloc_host_model();
+        rand_init();
+    }
+    if (bilinear()) {   // BModel::alloc_space (apex_svd_bilinear.h:49-54, :202-205): W_bi[num_item][num_bi_feedback] = 0
+        check(bi_param_.num_bi_feedback >= 0, "num_bi_feedback must not be negative");
+        hbi_.assign((size_t)mp_.num_item * (size_t)bi_param_.num_bi_feedback, 0.0f);
+        bi_allocated_ = true;
+    }
+    multi_setup();
+    multi_copy_model_to_peers();
+    if (device_model_ && host_model_valid_) {   // a host-built model (or the host copy an amd:gpus handle starts its ranks from) replaces what the device held
+        if (multi_) for (int d = 1; d < gpus_; d++) { Engine *e = rank_engine(d); if (e->device_model_) { HIPCHECK(hipSetDevice(e->device_)); e->upload_model(); } }
+        HIPCHECK(hipSetDevice(device_));
+        upload_model();
+    }
+}
+
+// ---- model file: apex_svd_model.h:570-660; tensors: int header x_max[,y_max] + unpadded rows
+static void save_1d(FILE *fo, const float *v, int n) {
+    fwrite(&n, sizeof(int), 1, fo);
+    fwrite(v, sizeof(float), (size_t)n, fo);
+}
+static void save_2d(FILE *fo, const float *w, int rows, int cols, int pitch) {
+    int hdr[2] = {cols, rows};
+    fwrite(hdr, sizeof(int), 2, fo);
+    if (cols == pitch) { fwrite(w, sizeof(float), (size_t)rows * cols, fo); return; }   // k % 4 == 0: rows are contiguous
+    for (int y = 0; y < rows; y++) fwrite(w + (size_t)y * pitch, sizeof(float), (size_t)cols, fo);
+}
+static void load_1d(FILE *fi, float *v, int n) {
+    int x;
+    check(fread(&x, sizeof(int), 1, fi) > 0, "tensor::load_from_file");
+    check(x == n, "tensor::load_from_file: shape does not match the model header");
+    if (n > 0) check(fread(v, sizeof(float), (size_t)n, fi) > 0, "tensor::load_from_file");
+}
+static void load_2d(FILE *fi, float *w, int rows, int cols, int pitch) {
+    int hdr[2];
+    check(fread(hdr, sizeof(int), 2, fi) > 0, "tensor::load_from_file");
+    check(hdr[0] == cols && hdr[1] == rows, "tensor::load_from_file: shape does not match the model header");
+    if (cols == pitch && rows > 0 && cols > 0) {
+        check(fread(w, sizeof(float), (size_t)rows * cols, fi) == (size_t)rows * cols, "tensor::load_from_file");
+        return;
+    }
+    for (int y = 0; y < rows; y++)
+        if (cols > 0) check(fread(w + (size_t)y * pitch, sizeof(float), (size_t)cols, fi) > 0, "tensor::load_from_file");
+}
+void Engine::write_model(FILE *fo) {
+    const int k = mp_.num_factor;
+    fwrite(&mp_, sizeof(ModelParam), 1, fo);
+    if (mp_.common_latent_space == 0) {
+        save_1d(fo, hbias_.data() + user_off_, mp_.num_user);
+        save_2d(fo, hW_.data() + (size_t)user_off_ * pitch_, mp_.num_user, k, pitch_);
+        save_1d(fo, hbias_.data() + item_off_, mp_.num_item);
+        save_2d(fo, hW_.data() + (size_t)item_off_ * pitch_, mp_.num_item, k, pitch_);
+    } else {
+        save_1d(fo, hbias_.data(), (int)n_uiset_);
+        save_2d(fo, hW_.data(), (int)n_uiset_, k, pitch_);
+    }
+    save_1d(fo, hg_.data(), mp_.num_global);
+    if (user_group() && mp_.common_feedback_space == 0) {
+        save_1d(fo, hbias_.data(), mp_.num_ufeedback);
+        save_2d(fo, hW_.data(), mp_.num_ufeedback, k, pitch_);
+    }
+}
+// The same file straight from the device model (no 282 MB host mirror for a 1 M x 64 user table): the tables travel in chunks through two
+// pinned buffers, chunk c+1 is copied out while chunk c goes to the file.  Rows are compacted by the copy itself (2-D copy: k floats
+// of every pitch_-float row), so the file bytes are write_model's.
+void Engine::dev_to_file(FILE *fo, const float *dsrc, long rows, long cols, long pitch) {
+    if (rows <= 0 || cols <= 0) return;
+    const size_t cap = (size_t)8 << 20;   // floats per buffer (32 MB)
+    if (!save_pin_[0]) {
+        for (int b = 0; b < 2; b++) {
+            HIPCHECK(hipHostMalloc(reinterpret_cast<void **>(&save_pin_[b]), cap * sizeof(float), hipHostMallocDefault));
+            HIPCHECK(hipEventCreateWithFlags(&save_ev_[b], hipEventDisableTiming));
+        }
+    }
+    check((size_t)cols <= cap, "save_model: a row wider than the staging buffer");
+    const long per = std::max<long>(1, (long)(cap / (size_t)cols));
+    long prev_rows = 0;
+    int c = 0;
+    for (long r0 = 0; r0 < rows || prev_rows > 0; r0 += per, c++) {
+        const long nr = r0 < rows ? std::min(per, rows - r0) : 0;
+        if (nr > 0) {
+            float *dst = save_pin_[c & 1];
+            if (cols == pitch) HIPCHECK(hipMemcpyAsync(dst, dsrc + (size_t)r0 * pitch, (size_t)nr * cols * sizeof(float), hipMemcpyDeviceToHost, stream_));
+            else HIPCHECK(hipMemcpy2DAsync(dst, (size_t)cols * sizeof(float), dsrc + (size_t)r0 * pitch, (size_t)pitch * sizeof(float), (size_t)cols * sizeof(float),
+                                           (size_t)nr, hipMemcpyDeviceToHost, stream_));
+            HIPCHECK(hipEventRecord(save_ev_[c & 1], stream_));
+        }
+        if (prev_rows > 0) {
+            HIPCHECK(hipEventSynchronize(save_ev_[(c - 1) & 1]));
+            fwrite(save_pin_[(c - 1) & 1], sizeof(float), (size_t)prev_rows * cols, fo);
+        }
+        prev_rows = nr;
+    }
+}
+void Engine::write_model_from_device(FILE *fo) {
+    const int k = mp_.num_factor;
+    auto d1 = [&](const float *d, int n) { fwrite(&n, sizeof(int), 1, fo); dev_to_file(fo, d, n, 1, 1); };
+    auto d2 = [&](const float *d, int rows) { int hdr[2] = {k, rows}; fwrite(hdr, sizeof(int), 2, fo); dev_to_file(fo, d, rows, k, pitch_); };
+    fwrite(&mp_, sizeof(ModelParam), 1, fo);
+    if (mp_.common_latent_space == 0) {
+        d1(dbias_.p + user_off_, mp_.num_user);
+        d2(dW_.p + (size_t)user_off_ * pitch_, mp_.num_user);
+        d1(dbias_.p + item_off_, mp_.num_item);
+        d2(dW_.p + (size_t)item_off_ * pitch_, mp_.num_item);
+    } else {
+        d1(dbias_.p, (int)n_uiset_);
+        d2(dW_.p, (int)n_uiset_);
+    }
+    {   // globals: a few words (strided on the device in the relaxed mode): through the host vector
+        hg_.resize((size_t)mp_.num_global);
+        if (!hg_.empty()) { download_globals(hg_.data()); HIPCHECK(hipStreamSynchronize(stream_)); }
+        save_1d(fo, hg_.data(), mp_.num_global);
+    }
+    if (user_group() && mp_.common_feedback_space == 0) {
+        d1(dbias_.p, mp_.num_ufeedback);
+        d2(dW_.p, mp_.num_ufeedback);
+    }
+}
+// the mirror of dev_to_file: a tensor's rows from the file into HBM through the two pinned buffers, fread of chunk c + 1 beside the copy of chunk c
+void Engine::file_to_dev(FILE *fi, float *ddst, long rows, long cols, long pitch) {
+    if (rows <= 0 || cols <= 0) return;
+    const size_t cap = (size_t)8 << 20;   // floats per buffer (32 MB)
+    if (!save_pin_[0]) {
+        for (int b = 0; b < 2; b++) {
+            HIPCHECK(hipHostMalloc(reinterpret_cast<void **>(&save_pin_[b]), cap * sizeof(float), hipHostMallocDefault));
+            HIPCHECK(hipEventCreateWithFlags(&save_ev_[b], hipEventDisableTiming));
+        }
+    }
+    check((size_t)cols <= cap, "load_model: a row wider than the staging buffer");
+    const long per = std::max<long>(1, (long)(cap / (size_t)cols));
+    int c = 0;
+    for (long r0 = 0; r0 < rows; r0 += per, c++) {
+        const long nr = std::min(per, rows - r0);
+        float *buf = save_pin_[c & 1];
+        if (c >= 2) HIPCHECK(hipEventSynchronize(save_ev_[c & 1]));   // the copy that read this buffer two chunks ago
+        check(fread(buf, sizeof(float), (size_t)nr * cols, fi) == (size_t)nr * cols, "tensor::load_from_file");
+        if (cols == pitch) HIPCHECK(hipMemcpyAsync(ddst + (size_t)r0 * pitch, buf, (size_t)nr * cols * sizeof(float), hipMemcpyHostToDevice, stream_));
+        else HIPCHECK(hipMemcpy2DAsync(ddst + (size_t)r0 * pitch, (size_t)pitch * sizeof(float), buf, (size_t)cols * sizeof(float), (size_t)cols * sizeof(float),
+                                       (size_t)nr, hipMemcpyHostToDevice, stream_));
+        HIPCHECK(hipEventRecord(save_ev_[c & 1], stream_));
+    }
+    HIPCHECK(hipStreamSynchronize(stream_));   // the buffers are free for the next tensor
+}
+// SVDModel::load_from_file (apex_svd_model.h:570-585) straight into HBM: same order, same shape checks as read_model, no host copy of the matrices
+void Engine::read_model_to_device(FILE *fi) {
+    if (fread(&mp_, sizeof(ModelParam), 1, fi) == 0) fail("error loading CF SVD model");
+    compute_geometry();
+    need_device("loading the model");
+    const int k = mp_.num_factor;
+    dW_.reserve(std::max<size_t>((size_t)n_uiset_ * pitch_, 1));
+    dbias_.reserve(std::max<size_t>((size_t)n_uiset_, 1));
+    if (pitch_ != k) HIPCHECK(hipMemsetAsync(dW_.p, 0, (size_t)n_uiset_ * pitch_ * sizeof(float), stream_));   // the pad floats of every row stay 0
+    auto d1 = [&](float *d, int n) {
+        int x;
+        check(fread(&x, sizeof(int), 1, fi) > 0, "tensor::load_from_file");
+        check(x == n, "tensor::load_from_file: shape does not match the model header");
+        file_to_dev(fi, d, n, 1, 1);
+    };
+    auto d2 = [&](float *d, int rows) {
+        int hdr[2];
+        check(fread(hdr, sizeof(int), 2, fi) > 0, "tensor::load_from_file");
+        check(hdr[0] == k && hdr[1] == rows, "tensor::load_from_file: shape does not match the model header");
+        file_to_dev(fi, d, rows, k, pitch_);
+    };
+    if (mp_.common_latent_space == 0) {
+        d1(dbias_.p + user_off_, mp_.num_user);
+        d2(dW_.p + (size_t)user_off_ * pitch_, mp_.num_user);
+        d1(dbias_.p + item_off_, mp_.num_item);
+        d2(dW_.p + (size_t)item_off_ * pitch_, mp_.num_item);
+    } else {
+        d1(dbias_.p, (int)n_uiset_);
+        d2(dW_.p, (int)n_uiset_);
+    }
+    hg_.assign((size_t)mp_.num_global, 0.0f);
+    load_1d(fi, hg_.data(), mp_.num_global);
+    upload_globals(wanted_g_stride());
+    if (user_group() && mp_.common_feedback_space == 0) {
+        d1(dbias_.p, mp_.num_ufeedback);
+        d2(dW_.p, mp_.num_ufeedback);
+    }
+    std::vector<float> zero(imfb() ? (size_t)4 + IMFB_DEPTH_MAX * ((size_t)2 * pitch_ + 4) : (size_t)2 * pitch_ + 4, 0.0f);
+    dstate_.upload(zero.data(), zero.size(), stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    device_model_ = true;
+    hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hbias_.shrink_to_fit(); hg_.clear();
+    host_model_valid_ = false;
+}
+void Engine::read_model(FILE *fi) {
+    if (fread(&mp_, sizeof(ModelParam), 1, fi) == 0) fail("error loading CF SVD model");
+    alloc_host_model();
+    const int k = mp_.num_factor;
+    if (mp_.common_latent_space == 0) {
+        load_1d(fi, hbias_.data() + user_off_, mp_.num_user);
+        load_2d(fi, hW_.data() + (size_t)user_off_ * pitch_, mp_.num_user, k, pitch_);
+        load_1d(fi, hbias_.data() + item_off_, mp_.num_item);
+        load_2d(fi, hW_.data() + (size_t)item_off_ * pitch_, mp_.num_item, k, pitch_);
+    } else {
+        load_1d(fi, hbias_.data(), (int)n_uiset_);
+        load_2d(fi, hW_.data(), (int)n_uiset_, k, pitch_);
+    }
+    load_1d(fi, hg_.data(), mp_.num_global);
+    if (user_group() && mp_.common_feedback_space == 0) {
+        load_1d(fi, hbias_.data(), mp_.num_ufeedback);
+        load_2d(fi, hW_.data(), mp_.num_ufeedback, k, pitch_);
+    }
+}
+void Engine::load_model(FILE *fi) {  // apex_svd_base.h:138-140
+    if (trainer_ready_ && !host_only_) flush();
+    if (!host_only_ && gpus_ <= 1 && device_load_) {   // the matrices stream file -> pinned chunks -> HBM
+        try { read_model_to_device(fi); }
+        catch (...) {   // a truncated / mismatching file leaves no half-loaded model behind: the handle has no model until the next init / load
+            (void)hipStreamSynchronize(stream_);
+            device_model_ = false; host_model_valid_ = false; space_allocated_ = false; trainer_ready_ = false;
+            throw;
+        }
+    } else read_model(fi);
+    if (bilinear()) {   // BModel::load_from_file (apex_svd_bilinear.h:64-68, :194-197)
+        check(fread(&bi_param_, sizeof(BiParam), 1, fi) > 0, "load from file");
+        check(bi_param_.num_bi_feedback >= 0, "num_bi_feedback must not be negative");
+        hbi_.assign((size_t)mp_.num_item * (size_t)bi_param_.num_bi_feedback, 0.0f);
+        bi_allocated_ = true;
+        load_2d(fi, hbi_.data(), mp_.num_item, bi_param_.num_bi_feedback, bi_param_.num_bi_feedback);
+    }
+    params_dirty_ = true;
+    multi_setup();
+    multi_copy_model_to_peers();
+    if (multi_) for (int d = 1; d < gpus_; d++) { Engine *e = rank_engine(d); e->params_dirty_ = true; if (e->device_model_) { HIPCHECK(hipSetDevice(e->device_)); e->upload_model(); } }
+    if (multi_ && !host_only_) HIPCHECK(hipSetDevice(device_));
+    if (device_model_ && host_model_valid_) upload_model();
+}
+void Engine::save_model(FILE *fo) {  // apex_svd_base.h:142-144
+    ScopedNs timer(ns_model_);
+    check(space_allocated_, "save_model: model is not initialised");
+    if (device_model_) {
+        flush();
+        if (multi_) multi_gather_user_rows();
+        need_device("saving the model");
+        write_model_from_device(fo);
+    } else {
+        check(host_model_valid_, "save_model: no model");
+        write_model(fo);
+    }
+    if (bilinear()) {   // BModel::save_to_file (apex_svd_bilinear.h:60-63, :198-201).  W_bi is inert: SVDPPFeature::update binds its OWN
+        // non-virtual prepare_ufeedback (apex_svd_base.h:523,571), so the derived one that would fill up_index never runs and
+        // get_bias_plugin / update_bias_plugin (:133-162) loop over nothing -- training is SVDPPFeature's, W_bi rides along
+        check(bi_allocated_, "save_model: bilinear model is not initialised");
+        fwrite(&bi_param_, sizeof(BiParam), 1, fo);
+        save_2d(fo, hbi_.data(), mp_.num_item, bi_param_.num_bi_feedback, bi_param_.num_bi_feedback);
+    }
+    if (device_model_) { hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hg_.clear(); host_model_valid_ = false; }
+}
+
+// g_bias on the device: hg_ scattered with `stride` floats between entries (padding zero)
+void Engine::upload_globals(int stride) {
+    g_stride_ = stride;
+    const size_t n = hg_.size();
+    dg_.reserve(std::max<size_t>(n * (size_t)stride, 1));
+    if (n == 0) return;
+    if (stride == 1) { dg_.upload(hg_.data(), n, stream_); return; }
+    HIPCHECK(hipMemsetAsync(dg_.p, 0, n * (size_t)stride * sizeof(float), stream_));
+    HIPCHECK(hipMemcpy2DAsync(dg_.p, (size_t)stride * sizeof(float), hg_.data(), sizeof(float), sizeof(float), n, hipMemcpyHostToDevice, stream_));
+}
+void Engine::download_globals(float *dst) {
+    const size_t n = (size_t)mp_.num_global;
+    if (n == 0) return;
+    if (g_stride_ == 1) HIPCHECK(hipMemcpyAsync(dst, dg_.p, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    else HIPCHECK(hipMemcpy2DAsync(dst, sizeof(float), dg_.p, (size_t)g_stride_ * sizeof(float), sizeof(float), n, hipMemcpyDeviceToHost, stream_));
+}
+
+void Engine::upload_model() {
+    need_device("uploading the model");
+    check(host_model_valid_, "upload_model: no host model");
+    dW_.upload(hW_.data(), hW_.size(), stream_);
+    dbias_.upload(hbias_.data(), hbias_.size(), stream_);
+    upload_globals(wanted_g_stride());
+    std::vector<float> zero(imfb() ? (size_t)4 + IMFB_DEPTH_MAX * ((size_t)2 * pitch_ + 4) : (size_t)2 * pitch_ + 4, 0.0f);
+    dstate_.upload(zero.data(), zero.size(), stream_);
+    HIPCHECK(hipStreamSynchronize(stream_));
+    device_model_ = true;
+    params_dirty_ = true;
+    hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hbias_.shrink_to_fit(); hg_.clear();
+    host_model_valid_ = false;
+}
+void Engine::download_model() {
+    need_device("downloading the model");
+    hW_.resize((size_t)n_uiset_ * pitch_);
+    hbias_.resize((size_t)n_uiset_);
+    hg_.resize((size_t)mp_.num_global);
+    if (!hW_.empty()) HIPCHECK(hipMemcpyAsync(hW_.data(), dW_.p, hW_.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (!hbias_.empty()) HIPCHECK(hipMemcpyAsync(hbias_.data(), dbias_.p, hbias_.size() * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (!hg_.empty()) download_globals(hg_.data());
+    HIPCHECK(hipStreamSynchronize(stream_));
+    host_model_valid_ = true;
+}
+// =============================================================================== introspection
+void Engine::view_shape(int which, int *rows, int *cols) {
+    *rows = -1; *cols = 0;
+    if (!space_allocated_) return;
+    switch (which) {
+    case 0: *rows = mp_.num_user; *cols = 1; break;
+    case 1: *rows = mp_.num_user; *cols = mp_.num_factor; break;
+    case 2: *rows = mp_.num_item; *cols = 1; break;
+    case 3: *rows = mp_.num_item; *cols = mp_.num_factor; break;
+    case 4: *rows = mp_.num_global; *cols = 1; break;
+    case 5: if (user_group()) { *rows = num_fb_rows(); *cols = 1; } break;
+    case 6: if (user_group()) { *rows = num_fb_rows(); *cols = mp_.num_factor; } break;
+    default: break;
+    }
+}
+int64_t Engine::get_view(int which, float *out, int64_t capacity) {
+    int rows, cols;
+    view_shape(which, &rows, &cols);
+    if (rows < 0) return -1;
+    const int64_t n = (int64_t)rows * cols;
+    if (n > capacity) return -1;
+    if (n == 0) return 0;
+    const bool matrix = (which == 1 || which == 3 || which == 6);
+    const unsigned off = (which <= 1) ? user_off_ : (which <= 3) ? item_off_ : fb_off_;
+    if (device_model_ && multi_ && which <= 1) {   // user rows live on their owners
+        flush();
+        multi_gather_user_rows();
+        download_model();
+        if (!matrix) memcpy(out, hbias_.data() + off, (size_t)n * sizeof(float));
+        else for (int y = 0; y < rows; y++) memcpy(out + (size_t)y * cols, hW_.data() + ((size_t)off + y) * pitch_, (size_t)cols * sizeof(float));
+        hW_.clear(); hW_.shrink_to_fit(); hbias_.clear(); hg_.clear(); host_model_valid_ = false;
+        return n;
+    }
+    if (device_model_) {
+        flush();
+        if (which == 4) download_globals(out);
+        else if (!matrix) HIPCHECK(hipMemcpyAsync(out, dbias_.p + off, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        else HIPCHECK(hipMemcpy2DAsync(out, (size_t)cols * sizeof(float), dW_.p + (size_t)off * pitch_, (size_t)pitch_ * sizeof(float),
+                                       (size_t)cols * sizeof(float), (size_t)rows, hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
+    } else {
+        check(host_model_valid_, "get_view: no model");
+        if (which == 4) memcpy(out, hg_.data(), (size_t)n * sizeof(float));
+        else if (!matrix) memcpy(out, hbias_.data() + off, (size_t)n * sizeof(float));
+        else for (int y = 0; y < rows; y++) memcpy(out + (size_t)y * cols, hW_.data() + ((size_t)off + y) * pitch_, (size_t)cols * sizeof(float));
+    }
+    return n;
+}
+// overwrite a parameter view from rows*cols unpadded floats (multi-GPU: gathering the owners' user rows before a save)
+int64_t Engine::set_view(int which, const float *in, int64_t count) {
+    int rows, cols;
+    view_shape(which, &rows, &cols);
+    if (rows < 0) return -1;
+    const int64_t n = (int64_t)rows * cols;
+    if (n != count) return -1;
+    if (n == 0) return 0;
+    check(!multi_, "set_view: not available with amd:gpus > 1");
+    const bool matrix = (which == 1 || which == 3 || which == 6);
+    const unsigned off = (which <= 1) ? user_off_ : (which <= 3) ? item_off_ : fb_off_;
+    if (device_model_) {
+        flush();
+        if (which == 4) {
+            std::vector<float> keep;
+            keep.assign(in, in + n);
+            std::swap(keep, hg_);
+            upload_globals(g_stride_);
+            HIPCHECK(hipStreamSynchronize(stream_));
+            std::swap(keep, hg_);
+            return n;
+        }
+        if (!matrix) HIPCHECK(hipMemcpyAsync(dbias_.p + off, in, (size_t)n * sizeof(float), hipMemcpyHostToDevice, stream_));
+        else HIPCHECK(hipMemcpy2DAsync(dW_.p + (size_t)off * pitch_, (size_t)pitch_ * sizeof(float), in, (size_t)cols * sizeof(float),
+                                       (size_t)cols * sizeof(float), (size_t)rows, hipMemcpyHostToDevice, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
+    } else {
+        check(host_model_valid_, "set_view: no model");
+        if (which == 4) memcpy(hg_.data(), in, (size_t)n * sizeof(float));
+        else if (!matrix) memcpy(hbias_.data() + off, in, (size_t)n * sizeof(float));
+        else for (int y = 0; y < rows; y++) memcpy(hW_.data() + ((size_t)off + y) * pitch_, in + (size_t)y * cols, (size_t)cols * sizeof(float));
+    }
+    return n;
+}
+}  // namespace svdf
