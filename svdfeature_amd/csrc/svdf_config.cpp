@@ -209,6 +209,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "device_init")) { device_init_ = value != 0; return 0; }
     if (!strcmp(name, "device_window")) { device_window_ = value != 0; return 0; }
     if (!strcmp(name, "device_load")) { device_load_ = value != 0; return 0; }
+    if (!strcmp(name, "ipc_spin_limit")) { ipc_set_spin_limit(value); return 0; }
     if (!strcmp(name, "chain_width")) { check(value >= 0, "chain_width must not be negative"); chain_width_ = value; return 0; }
     if (!strcmp(name, "wseq_build_threads")) { check(value >= 1 && value <= 256, "wseq_build_threads must be in 1 .. 256"); wseq_build_threads_ = (int)value; return 0; }
     if (!strcmp(name, "device_init_margin_log2")) { check(value >= 8 && value <= 52, "device_init_margin_log2 must be in 8 .. 52"); device_init_margin_log2_ = (int)value; return 0; }

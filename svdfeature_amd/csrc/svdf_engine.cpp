@@ -780,6 +780,7 @@ void Engine::train_dataset(Dataset *ds) {
                 launch_imfb(P, D, d.units.p, d.blks.p, d.fbidx.p, d.fbval.p, d.order.p, sc.level_ptr[l], sc.level_ptr[l + 1], sample_counter_, nullptr, stream_);
         } else if (ds->kind == 2) {
             const FusedSchedule S = ds->fused.view();
+            ds->chained_levels = 0;
             if (fewrow_gslots_ && fewrow_fast_ && fewrow_gslots_applies(P, S, ds->fused.max_nu, ds->fused.max_ni, ds->fused.dense_slots)) {
                 for (size_t l = 0; l < sc.num_levels(); l++) launch_fewrow_gslots(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], stream_);
             } else {
@@ -787,13 +788,14 @@ void Engine::train_dataset(Dataset *ds) {
                 // run -- one workgroup walks the levels with a barrier in between (k_fewrow_slots_chain) --, everything else level by level
                 const size_t L = sc.num_levels();
                 const long cw = chain_width_;
+                int64_t chained = 0;
                 const bool can_chain = cw > 0 && ds->d_level_ptr_ok && launch_fewrow_chain(P, S, ds->fused.max_nu, ds->fused.max_ni, nullptr, 0, 0, stream_);
                 for (size_t l = 0; l < L;) {
                     size_t e = l;
                     if (can_chain) while (e < L && sc.level_ptr[e + 1] - sc.level_ptr[e] <= cw) e++;
                     if (e >= l + 4) {
                         (void)launch_fewrow_chain(P, S, ds->fused.max_nu, ds->fused.max_ni, ds->d_level_ptr.p, (long)l, (long)e, stream_);
-                        n_chained_levels_ += (int64_t)(e - l);
+                        chained += (int64_t)(e - l);
                         l = e;
                         continue;
                     }
@@ -801,6 +803,7 @@ void Engine::train_dataset(Dataset *ds) {
                     for (; l < stop; l++)
                         launch_fused(P, S, ds->fused.max_nu, ds->fused.max_ni, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
                 }
+                ds->chained_levels = chained;   // what this launch sequence chains: counted per PASS below (issue() runs once per graph capture)
             }
         } else {
             DevCSR D{ds->row_label.p, ds->row_ptr.p, ds->feat_index.p, ds->feat_value.p};
@@ -827,6 +830,7 @@ void Engine::train_dataset(Dataset *ds) {
         issue();
     }
     HIPCHECK(hipGetLastError());
+    n_chained_levels_ += ds->chained_levels;
     n_launches_ += (int64_t)sc.num_levels();
     if (ds->kind < 3) n_kind_[ds->kind] += (int64_t)sc.num_levels();
     n_batches_ += (int64_t)sc.num_levels();
@@ -846,5 +850,6 @@ void Engine::synchronize() {
     if (host_only_) return;
     if (multi_) { multi_synchronize(); return; }
     HIPCHECK(hipStreamSynchronize(stream_));
+    ipc_fail_if_dead("svdf_synchronize");
 }
 }  // namespace svdf

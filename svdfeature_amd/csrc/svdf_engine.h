@@ -237,6 +237,7 @@ struct Dataset {
     long win_item_lo = 0, win_item_hi = -1;   // kind 5: lowest / highest item id with an instance in the window (-1: none)
     DevBuf<long> d_level_ptr;     // kind 2: the level boundaries in HBM, uploaded when a run of narrow levels is first chained (k_fewrow_slots_chain)
     bool d_level_ptr_ok = false;
+    int64_t chained_levels = 0;   // levels the current launch sequence of this data set walks inside chained launches
     long win_slots = 0;           // contribution slots of the window = item entries (kind 7: + feedback entries)
     // kind 7: window-minibatch data set of user units (svdf_k_wunit.hip): user-group blocks / rows with global features
     DevBuf<WinUnit> wu_units;
@@ -329,6 +330,9 @@ class Engine {
     void ipc_block_send(int dst, int slot);
     void ipc_block_recv(int src, int slot, unsigned seq);
     int ipc_status() const;
+    void ipc_set_spin_limit(long polls);       // knob "ipc_spin_limit": polls before a flag wait gives up (tests; default ~ several seconds)
+    long ipc_spin_limit_ = 0;
+    void ipc_fail_if_dead(const char *where);   // raised by svdf_synchronize: a timeout in the last window must not pass silently
     void ipc_close();
     // the same exchanges issued from C++ straight into RCCL (svdf_rccl.cpp)
     void stratum_step(Dataset *const *ds, int n, int block, int nblocks, float *device_out);

@@ -39,6 +39,16 @@ struct ScopedNs {   // host-side time accounting (SVDF_PROFILE=1)
 void config_set_train_param(TrainParam &p, const char *name, const char *val);
 void config_set_model_param(ModelParam &p, const char *name, const char *val);
 
+// Pointer arrays handed over by a caller are checked before anything indexes through them (the messages of dataset_from_csr /
+// dataset_from_blocks): counts not negative, pointers starting at >= 0 and non-decreasing, fewer than 2^31 entries.
+void validate_csr_pointers(long num_row, const int64_t *row_ptr);
+void validate_block_pointers(long num_block, const int64_t *fb_ptr, const int64_t *block_row_ptr);
+// the shapes the user-unit window step takes (svdf_wunit.cpp's builders fail on anything else): one user entry per row, one user per
+// block / START..END span, no id twice in a row's global or item entries, no feedback id twice in a block.  Pointers must be valid.
+bool wunit_rows_ok(long r0, long r1, const int64_t *row_ptr, const unsigned *feat_index);
+bool wunit_blocks_ok(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const int64_t *block_row_ptr,
+                     const int64_t *row_ptr, const unsigned *feat_index);
+
 // Instances of one batch commute: sorting a batch by a key changes no bit of the result (svdf_sched.cpp)
 void sort_batches(Schedule &sched, const unsigned *key);
 

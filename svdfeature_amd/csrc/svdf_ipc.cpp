@@ -71,6 +71,7 @@ void Engine::ipc_setup(int rank, int world, int64_t wire_bytes, int64_t block_fl
     ipc_.reset(new IpcState());
     IpcState &S = *ipc_;
     S.rank = rank; S.world = world;
+    if (ipc_spin_limit_ > 0) S.spin_limit = (unsigned long long)ipc_spin_limit_;
     S.wire_bytes = ((size_t)wire_bytes + 255) & ~(size_t)255;
     S.block_floats = (size_t)block_floats;
     HIPCHECK(hipMalloc(&S.wire, S.wire_bytes + 2 * S.block_floats * sizeof(float) + 256));
@@ -134,7 +135,7 @@ void Engine::ipc_window_pack(Dataset *ds, int half) {
     check((size_t)count * (half ? 2 : 4) <= S.wire_bytes, "svdf_ipc_window_pack: the wire buffer of svdf_ipc_setup is too small for this exchange");
     window_delta_pack(ds, S.wire, half, nullptr);
     S.seq++;
-    launch_ipc_signal(S.peer_page.data(), S.world, 0, S.rank, S.seq, stream_);
+    launch_ipc_signal(S.peer_page.data(), S.world, 0, S.rank, S.seq, S.err_dev, stream_);
     HIPCHECK(hipGetLastError());
     n_launches_++;
 }
@@ -144,8 +145,8 @@ void Engine::ipc_window_reduce(int half) {
     IpcState &S = *ipc_;
     const int64_t count = delta_ranges().off[delta_ranges().n];
     launch_ipc_wait(S.page, 0, S.world, S.seq, S.err_dev, S.spin_limit, stream_);
-    launch_delta_reduce_gather(S.peer_wire.data(), S.world, count * S.rank / S.world, count * (S.rank + 1) / S.world, half, stream_);
-    launch_ipc_signal(S.peer_page.data(), S.world, 1, S.rank, S.seq, stream_);
+    launch_delta_reduce_gather(S.peer_wire.data(), S.world, count * S.rank / S.world, count * (S.rank + 1) / S.world, half, stream_, S.err_dev);
+    launch_ipc_signal(S.peer_page.data(), S.world, 1, S.rank, S.seq, S.err_dev, stream_);
     HIPCHECK(hipGetLastError());
     n_launches_ += 3;
 }
@@ -172,11 +173,11 @@ void Engine::ipc_block_send(int dst, int slot) {
     // the slot is free once the destination acknowledged my previous block in it (ranks of a ring can drift apart by more than two steps)
     if (S.slot_seq[slot] != 0u) launch_ipc_wait(S.page + (size_t)dst * 32, 4 + slot, 1, S.slot_seq[slot], S.err_dev, S.spin_limit, stream_);
     float *peer_inbox = reinterpret_cast<float *>(reinterpret_cast<char *>(S.peer_wire[(size_t)dst]) + S.wire_bytes) + (size_t)slot * S.block_floats;
-    launch_ipc_copy(peer_inbox, w_out_.p, n, stream_);
+    launch_ipc_copy(peer_inbox, w_out_.p, n, S.err_dev, stream_);
     S.seq_block++;
     S.slot_seq[slot] = S.seq_block;
     unsigned *page[1] = {S.peer_page[(size_t)dst]};
-    launch_ipc_signal(page, 1, 2 + slot, S.rank, S.seq_block, stream_);
+    launch_ipc_signal(page, 1, 2 + slot, S.rank, S.seq_block, S.err_dev, stream_);
     HIPCHECK(hipGetLastError());
     n_launches_ += 2;
 }
@@ -191,15 +192,25 @@ void Engine::ipc_block_recv(int src, int slot, unsigned seq) {
     launch_ipc_wait(S.page + (size_t)src * 32, 2 + slot, 1, seq, S.err_dev, S.spin_limit, stream_);
     item_block_copy(S.inbox + (size_t)slot * S.block_floats, 1, nullptr);
     unsigned *page[1] = {S.peer_page[(size_t)src]};
-    launch_ipc_signal(page, 1, 4 + slot, S.rank, seq, stream_);
+    launch_ipc_signal(page, 1, 4 + slot, S.rank, seq, S.err_dev, stream_);
     HIPCHECK(hipGetLastError());
     n_launches_ += 2;
 }
+void Engine::ipc_set_spin_limit(long polls) { check(polls >= 1, "ipc_spin_limit must be positive"); ipc_spin_limit_ = polls; if (ipc_) ipc_->spin_limit = (unsigned long long)polls; }
 int Engine::ipc_status() const { return ipc_ ? (int)*ipc_->err_host : 0; }
 void Engine::ipc_close() {
     if (!ipc_) return;
     HIPCHECK(hipStreamSynchronize(stream_));
+    const unsigned err = *ipc_->err_host;   // a wait that timed out in the LAST window has no later svdf_ipc_* call to report it
     ipc_.reset();
+    if (err != 0u)
+        fail("svdf_ipc_close: a wait on rank " + std::to_string((int)err - 1) + "'s flag hit its spin limit during the pass (that rank died or never reached the exchange); "
+             "this rank's model holds an incomplete exchange");
+}
+void Engine::ipc_fail_if_dead(const char *where) {
+    if (ipc_ && *ipc_->err_host != 0u)
+        fail(std::string(where) + ": the IPC exchange is dead -- a wait on rank " + std::to_string((int)*ipc_->err_host - 1) +
+             "'s flag hit its spin limit (svdf_ipc_status); this rank's model holds an incomplete exchange");
 }
 
 }  // namespace svdf

@@ -117,7 +117,9 @@ void launch_delta_sum(const void *const *srcs, int n, void *dst, long total, int
 // picks it up.  16-byte accesses over the aligned body of the slice, scalar head / tail.
 struct PeerBufs { void *p[16]; int n; };
 template <bool HALF>
-__global__ __launch_bounds__(256) void k_delta_reduce_gather(const PeerBufs B, long begin, long end) {
+__global__ __launch_bounds__(256) void k_delta_reduce_gather(const PeerBufs B, long begin, long end, const unsigned *err) {
+    // a wait of this exchange timed out (svdf_ipc.cpp): the peers' buffers are incomplete -- nothing is summed and nothing is stored anywhere
+    if (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
     const long stride = (long)gridDim.x * blockDim.x;
     const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
     constexpr int PER = HALF ? 8 : 4;                       // elements per 16-byte access
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void k_delta_reduce_gather(const PeerBufs B, l
         }
     }
 }
-void launch_delta_reduce_gather(void *const *bufs, int n, long begin, long end, int half, hipStream_t st) {
+void launch_delta_reduce_gather(void *const *bufs, int n, long begin, long end, int half, hipStream_t st, const unsigned *err) {
     if (end <= begin || n <= 0) return;
     PeerBufs B;
     B.n = n > 16 ? 16 : n;
@@ -173,8 +175,8 @@ void launch_delta_reduce_gather(void *const *bufs, int n, long begin, long end, 
     long grid = ((end - begin) / per + 255) / 256;
     if (grid < 1) grid = 1;
     if (grid > 4096) grid = 4096;
-    if (half) hipLaunchKernelGGL(k_delta_reduce_gather<true>, dim3((int)grid), dim3(256), 0, st, B, begin, end);
-    else hipLaunchKernelGGL(k_delta_reduce_gather<false>, dim3((int)grid), dim3(256), 0, st, B, begin, end);
+    if (half) hipLaunchKernelGGL(k_delta_reduce_gather<true>, dim3((int)grid), dim3(256), 0, st, B, begin, end, err);
+    else hipLaunchKernelGGL(k_delta_reduce_gather<false>, dim3((int)grid), dim3(256), 0, st, B, begin, end, err);
 }
 
 // ---- cross-PROCESS direct exchange (svdf_ipc.cpp): the ranks' wire buffers and flag pages are IPC-mapped into
@@ -184,9 +186,13 @@ void launch_delta_reduce_gather(void *const *bufs, int n, long begin, long end, 
 // own phase is done (kernel boundary + system-scope fence before the store); a one-wave kernel on the waiting rank polls its own page
 // (system-scope loads, s_sleep between polls, a spin limit that raises *err instead of hanging the queue).
 struct IpcFlags { unsigned *page[16]; int n; };
-__global__ void k_ipc_signal(const IpcFlags F, int phase, int me, unsigned seq) {
+// Once a wait has raised *err the exchange is dead: signals stop (the peers' waits then time out too instead of consuming a sum over
+// incomplete buffers), the reduce and the block copies become no-ops, and the host fails at its next svdf_ipc_* call, at
+// svdf_synchronize or at svdf_ipc_close, whichever comes first.
+__global__ void k_ipc_signal(const IpcFlags F, int phase, int me, unsigned seq, const unsigned *err) {
     const int r = threadIdx.x;
     if (r >= F.n) return;
+    if (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
     __threadfence_system();
     __hip_atomic_store(F.page[r] + (phase * 16 + me) * 32, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
@@ -205,25 +211,26 @@ __global__ void k_ipc_wait(unsigned *page, int phase, int n, unsigned seq, unsig
     }
     __threadfence_system();
 }
-void launch_ipc_signal(unsigned *const *pages, int n, int phase, int me, unsigned seq, hipStream_t st) {
+void launch_ipc_signal(unsigned *const *pages, int n, int phase, int me, unsigned seq, const unsigned *err, hipStream_t st) {
     IpcFlags F;
     F.n = n;
     for (int r = 0; r < 16; r++) F.page[r] = r < n ? pages[r] : nullptr;
-    hipLaunchKernelGGL(k_ipc_signal, dim3(1), dim3(64), 0, st, F, phase, me, seq);
+    hipLaunchKernelGGL(k_ipc_signal, dim3(1), dim3(64), 0, st, F, phase, me, seq, err);
 }
 void launch_ipc_wait(unsigned *page, int phase, int n, unsigned seq, unsigned *err, unsigned long long spin_limit, hipStream_t st) {
     hipLaunchKernelGGL(k_ipc_wait, dim3(1), dim3(64), 0, st, page, phase, n, seq, err, spin_limit);
 }
 // a packed block (svdf_item_block_get layout) stored straight into a peer's mapped buffer: the stratified hand-over without a collective
-__global__ __launch_bounds__(256) void k_ipc_copy(float *dst, const float *src, long n) {
+__global__ __launch_bounds__(256) void k_ipc_copy(float *dst, const float *src, long n, const unsigned *err) {
+    if (err && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
     const long stride = (long)gridDim.x * blockDim.x;
     for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) dst[j] = src[j];
 }
-void launch_ipc_copy(float *dst, const float *src, long n, hipStream_t st) {
+void launch_ipc_copy(float *dst, const float *src, long n, const unsigned *err, hipStream_t st) {
     if (n <= 0) return;
     long grid = (n + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(k_ipc_copy, dim3((int)grid), dim3(256), 0, st, dst, src, n);
+    hipLaunchKernelGGL(k_ipc_copy, dim3((int)grid), dim3(256), 0, st, dst, src, n, err);
 }
 
 // row r of dst (rows dst_first + r * dst_stride) <- row r of src (rows src_first + r * src_stride), `width` floats per row: packs the

@@ -61,15 +61,15 @@ bool wunit_wave_applies(const DevParams &P, const WUnitSchedule &S, bool feedbac
 void launch_wunit_wave(const DevParams &P, const WUnitSchedule &S, hipStream_t st);
 void launch_wunit_sum(const DevParams &P, const WUnitSchedule &S, void *dst, int half, hipStream_t st);   // dst == nullptr: add to the model in place
 // cross-process direct exchange (svdf_ipc.cpp): sequence flags in IPC-mapped device memory
-void launch_ipc_signal(unsigned *const *pages, int n, int phase, int me, unsigned seq, hipStream_t st);
+void launch_ipc_signal(unsigned *const *pages, int n, int phase, int me, unsigned seq, const unsigned *err, hipStream_t st);
 void launch_ipc_wait(unsigned *page, int phase, int n, unsigned seq, unsigned *err, unsigned long long spin_limit, hipStream_t st);
-void launch_ipc_copy(float *dst, const float *src, long n, hipStream_t st);
+void launch_ipc_copy(float *dst, const float *src, long n, const unsigned *err, hipStream_t st);
 void launch_window_user_column(const WinUser *urec, int nusers, unsigned *user_out, hipStream_t st);
 void launch_pairs_prepare(long n, const unsigned *pos, const unsigned *neg, unsigned *lo, unsigned *hi, float *vlo, float *vhi, float *ones,
                           unsigned *flag, hipStream_t st);
 void launch_delta_sum(const void *const *srcs, int n, void *dst, long total, int half, hipStream_t st);   // up to 16 buffers
 // rank d's share of the direct exchange: elements [begin, end) of every buffer <- their sum over the n buffers (rank order, fp32)
-void launch_delta_reduce_gather(void *const *bufs, int n, long begin, long end, int half, hipStream_t st);
+void launch_delta_reduce_gather(void *const *bufs, int n, long begin, long end, int half, hipStream_t st, const unsigned *err = nullptr);
 void launch_rows_strided_copy(float *dst, long dst_first, long dst_stride, const float *src, long src_first, long src_stride, long nrows, int width,
                               hipStream_t st);
 void launch_delta_sub(const float *cur, const float *snap, float *delta, long n, hipStream_t st);

@@ -33,6 +33,7 @@
 
 #include "svdf_engine.h"
 #include "svdf_kernels.h"
+#include "svdf_internal.h"
 
 namespace svdf {
 
@@ -42,7 +43,6 @@ namespace svdf {
         if (e_ != hipSuccess) fail(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #call); \
     } while (0)
 
-static inline void check(bool ok, const char *msg) { if (!ok) fail(msg); }
 
 // ---- RCCL, resolved at run time (rccl.h: ncclCommInitAll, ncclAllReduce; ncclHalf = 6, ncclFloat = 7, ncclSum = 0)
 struct Rccl {
@@ -573,7 +573,10 @@ Dataset *Engine::multi_dataset_from_blocks(long num_block, const int *extend_tag
     for (int64_t r = block_row_ptr[0]; r < block_row_ptr[num_block]; r++)
         for (int64_t j = row_ptr[(size_t)3 * r + 2]; j < row_ptr[(size_t)3 * r + 3]; j++) if (feat_index[(size_t)j] < (unsigned)mp_.num_item) cnt[feat_index[(size_t)j]]++;
     // the window-minibatch step for user units (svdf_k_wunit.hip) unless amd:step = levels or the configuration is outside it
-    const bool wstep = !multi_step_levels_ && wunit_config_ok();
+    // ... or the data holds a shape its builders refuse (a feedback id twice in a block, several users in a block, an id twice in a row,
+    // a row without exactly one user entry): those keep exact conflict-free units per rank, as before the step existed
+    const bool wstep = !multi_step_levels_ && wunit_config_ok() &&
+                       wunit_blocks_ok(num_block, extend_tag, fb_ptr, fb_index, block_row_ptr, row_ptr, feat_index);
     long W0 = multi_windows_for(std::max<long>(num_row, 1), cnt, wstep);
     if (!window_set_ && num_row > 0) {
         // the implicit-feedback rows move by whole-block steps: a block of n rows pushes about n |value| instance-sized updates into

@@ -14,15 +14,10 @@
 
 #include "svdf_engine.h"
 #include "svdf_kernels.h"
+#include "svdf_internal.h"
 
 namespace svdf {
 
-#define HIPCHECK(call)                                                                           \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess) fail(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #call); \
-    } while (0)
-static inline void check(bool ok, const char *msg) { if (!ok) fail(msg); }
 
 namespace {
 struct HostSeg {
@@ -379,7 +374,7 @@ Dataset *Engine::dataset_window_from_csr(long n, const float *row_label, const i
     need_device("dataset");
     check(!user_group(), "svdf_dataset_window_from_csr: random-order (format_type 0) trainers; user-group data goes through svdf_dataset_window_from_blocks");
     check(!multi_ || in_multi_scope(), "window data sets are per rank; an amd:gpus handle builds them itself from svdf_dataset_from_csr");
-    check(n >= 0, "dataset: negative row count");
+    validate_csr_pointers(n, row_ptr);
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get());
     wunit_fill_from_csr(ds.get(), n, row_label, row_ptr, feat_index, feat_value);
@@ -392,6 +387,8 @@ Dataset *Engine::dataset_window_from_blocks(long num_block, const int *extend_ta
     need_device("dataset");
     check(user_group(), "svdf_dataset_window_from_blocks: user-group (format_type 1) trainers");
     check(!multi_ || in_multi_scope(), "window data sets are per rank; an amd:gpus handle builds them itself from svdf_dataset_from_blocks");
+    validate_block_pointers(num_block, fb_ptr, block_row_ptr);
+    validate_csr_pointers((long)(block_row_ptr[num_block] - block_row_ptr[0]), row_ptr + 3 * block_row_ptr[0]);
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get());
     wunit_fill_from_blocks(ds.get(), 0, num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
@@ -462,8 +459,65 @@ static void wseq_build_windows(long W, int max_threads, BuildFn build, AdoptFn a
     }
 }
 
+void validate_csr_pointers(long num_row, const int64_t *row_ptr) {
+    check(num_row >= 0, "dataset: negative row count");
+    if (num_row == 0) return;
+    check(row_ptr[0] >= 0, "CSR row_ptr must not be negative");
+    for (long r = 0; r < num_row; r++) {
+        const int64_t *p = &row_ptr[(size_t)3 * r];
+        check(p[0] <= p[1] && p[1] <= p[2] && p[2] <= p[3], "CSR row_ptr must be non-decreasing");
+    }
+    check(row_ptr[(size_t)3 * num_row] - row_ptr[0] < (int64_t)2147483647, "dataset: more than 2^31-1 feature entries");
+}
+void validate_block_pointers(long num_block, const int64_t *fb_ptr, const int64_t *block_row_ptr) {
+    check(num_block >= 0, "dataset_from_blocks: negative block count");
+    check(fb_ptr[0] >= 0 && block_row_ptr[0] >= 0, "dataset_from_blocks: block_row_ptr / fb_ptr must not be negative");
+    for (long b = 0; b < num_block; b++)
+        check(block_row_ptr[b] <= block_row_ptr[b + 1] && fb_ptr[b] <= fb_ptr[b + 1], "dataset_from_blocks: block_row_ptr / fb_ptr must be non-decreasing");
+    check(fb_ptr[num_block] - fb_ptr[0] < (int64_t)2147483647 && block_row_ptr[num_block] - block_row_ptr[0] < (int64_t)2147483647,
+          "dataset_from_blocks: more than 2^31-1 rows / feedback entries");
+}
+static bool no_id_twice(const unsigned *a, int64_t n, std::vector<unsigned> &tmp) {
+    if (n < 2) return true;
+    if (n <= 8) { for (int64_t i = 0; i < n; i++) for (int64_t j = i + 1; j < n; j++) if (a[i] == a[j]) return false; return true; }
+    tmp.assign(a, a + n);
+    std::sort(tmp.begin(), tmp.end());
+    return std::adjacent_find(tmp.begin(), tmp.end()) == tmp.end();
+}
+bool wunit_rows_ok(long r0, long r1, const int64_t *row_ptr, const unsigned *feat_index) {
+    std::vector<unsigned> tmp;
+    for (long r = r0; r < r1; r++) {
+        const int64_t *p = &row_ptr[(size_t)3 * r];
+        if (p[2] != p[1] + 1) return false;
+        if (!no_id_twice(feat_index + p[0], p[1] - p[0], tmp) || !no_id_twice(feat_index + p[2], p[3] - p[2], tmp)) return false;
+    }
+    return true;
+}
+bool wunit_blocks_ok(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const int64_t *block_row_ptr,
+                     const int64_t *row_ptr, const unsigned *feat_index) {
+    std::vector<unsigned> tmp;
+    bool open = false, have_user = false;
+    unsigned user = 0;
+    for (long b = 0; b < num_block; b++) {
+        const int tag = extend_tag[b];
+        if (tag == TAG_DEFAULT || tag == TAG_START) { if (open) return false; have_user = false; }
+        else if (tag == TAG_MIDDLE || tag == TAG_END) { if (!open) return false; }
+        else return false;
+        if (!no_id_twice(fb_index + fb_ptr[b], fb_ptr[b + 1] - fb_ptr[b], tmp)) return false;
+        if (!wunit_rows_ok((long)block_row_ptr[b], (long)block_row_ptr[b + 1], row_ptr, feat_index)) return false;
+        for (int64_t r = block_row_ptr[b]; r < block_row_ptr[b + 1]; r++) {
+            const unsigned u = feat_index[(size_t)row_ptr[(size_t)3 * r + 1]];
+            if (have_user && u != user) return false;
+            user = u; have_user = true;
+        }
+        open = (tag == TAG_START || tag == TAG_MIDDLE);
+    }
+    return !open;
+}
+
 Dataset *Engine::wseq_from_csr(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value) {
     wunit_check_config("dataset_from_csr");
+    validate_csr_pointers(n, row_ptr);
     std::vector<long> ci((size_t)mp_.num_item, 0), cg((size_t)mp_.num_global, 0);
     for (long r = 0; r < n; r++) {
         for (int64_t j = row_ptr[3 * r]; j < row_ptr[3 * r + 1]; j++) { if (feat_index[j] >= (unsigned)mp_.num_global) fail("global feature index exceed setting"); cg[feat_index[j]]++; }
@@ -494,6 +548,8 @@ Dataset *Engine::wseq_from_blocks(long num_block, const int *extend_tag, const i
                                   const int64_t *block_row_ptr, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index,
                                   const float *feat_value) {
     wunit_check_config("dataset_from_blocks");
+    validate_block_pointers(num_block, fb_ptr, block_row_ptr);
+    validate_csr_pointers((long)(block_row_ptr[num_block] - block_row_ptr[0]), row_ptr + 3 * block_row_ptr[0]);
     const long n = (long)(block_row_ptr[num_block] - block_row_ptr[0]);
     std::vector<long> ci((size_t)mp_.num_item, 0), cg((size_t)mp_.num_global, 0);
     for (long r = block_row_ptr[0]; r < block_row_ptr[num_block]; r++) {

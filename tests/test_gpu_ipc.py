@@ -82,3 +82,58 @@ def test_ipc_stratified_hand_over_equals_the_simulation(world, tmp_path):
         z = np.load(str(tmp_path / ("rank%d.npz" % rk)))
         for name in ("W_item", "i_bias", "W_user", "u_bias"):
             np.testing.assert_array_equal(z[name].view(np.uint32), sim[rk].t.view(name).view(np.uint32))
+
+
+def _dead_peer_worker(rank, world, port, out_dir):
+    import torch
+    import torch.distributed as dist
+    import svdfeature_amd as sa
+    from svdfeature_amd.multi_gpu import HipShard, ShardedTrainer, shard_windows
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    t = sa.Trainer(0, 0)
+    t.seed(10)
+    for k, v in CONF:
+        t.set_param(k, v)
+    t.init_model()
+    t.init_trainer()
+    t.set_knob("ipc_spin_limit", 20000)
+    before = t.view("W_item").copy()
+    u, i, r = cases.planted_triples(8000, NU, NI, seed=9)
+    ad = HipShard(t, torch, torch.device("cuda", 0), minibatch=True)
+    ad.set_wire_half(False)
+    ad.ipc_open(dist, rank, world)
+    st = ShardedTrainer(ad, ad.make_windows(shard_windows(u, i, r, rank, world, 1)), world, dist)
+    msgs = []
+    if rank == 0:   # rank 1 never reaches the exchange: rank 0's wait must time out, say so, and leave rank 1's buffers alone
+        st.train_pass()
+        for call in (t.synchronize, t.ipc_close):
+            try:
+                call()
+                msgs.append("no error")
+            except Exception as e:   # noqa: BLE001
+                msgs.append(str(e))
+        assert t.ipc_status() == 0   # closed
+    dist.barrier()
+    if rank == 1:
+        t.synchronize()
+        assert t.ipc_status() == 0
+        assert np.array_equal(before.view(np.uint32), t.view("W_item").view(np.uint32))
+        t.ipc_close()
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("\n".join(msgs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ipc_wait_timeout_is_reported_at_synchronize_and_close(tmp_path):
+    """a flag wait that hits its spin limit in the LAST window used to pass silently (no later svdf_ipc_* call) and the
+    stream went on to sum incomplete buffers into every peer.  Now the signal / reduce / copy kernels are no-ops once the error word is
+    raised and svdf_synchronize / svdf_ipc_close fail."""
+    import torch.multiprocessing as mp
+    mp.spawn(_dead_peer_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    msgs = open(str(tmp_path / "rank0.txt")).read().split("\n")
+    assert len(msgs) == 2 and "spin limit" in msgs[0] and "svdf_synchronize" in msgs[0], msgs
+    assert "spin limit" in msgs[1] and "svdf_ipc_close" in msgs[1], msgs

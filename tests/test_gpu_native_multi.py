@@ -424,3 +424,30 @@ def test_malformed_rows_are_reported_before_the_handle_reads_an_owner_from_them(
     blk.data.row_ptr = bad
     with pytest.raises(sa.SvdfError, match="non-decreasing"):
         t.predict_block(blk)
+
+
+def test_block_shapes_outside_the_window_step_keep_exact_levels_on_the_handle():
+    """amd:gpus data sets from blocks default to the user-unit window step, whose builders refuse a feedback id listed twice
+    in a block (the reference accepts it: prepare_ufeedback just adds the row twice, apex_svd_base.h:523-538).  Such data must keep the exact
+    level scheme per rank -- as multi_dataset_from_csr's pre-scan already did for rows -- instead of failing inside the rank pool."""
+    nu, ni, world = 120, 40, 2
+    blocks = cases.user_blocks(60, nu, ni, ni, seed=3, max_rows=5, max_fb=4)
+    ba = sa.BlockArrays.from_blocks(blocks)
+    b = next(j for j in range(ba.num_block) if ba.fb_ptr[j + 1] - ba.fb_ptr[j] >= 2)
+    ba.fb_index = ba.fb_index.copy()
+    ba.fb_index[ba.fb_ptr[b] + 1] = ba.fb_index[ba.fb_ptr[b]]   # the same feedback id twice in one block
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=16, num_ufeedback=ni, wd_ufeedback=0.004, ufeedback_init_sigma=0.01)
+    models = {}
+    for step in (None, "levels"):
+        t = sa.Trainer(1, 0)
+        t.seed(10)
+        for k, v in conf + [("amd:gpus", world), ("amd:delta_half", 0), ("amd:window", 100)] + ([("amd:step", step)] if step else []):
+            t.set_param(k, str(v))
+        t.init_model()
+        t.init_trainer()
+        ds = t.dataset_from_blocks(ba)
+        t.train_dataset(ds)
+        assert t.counter(11) == 0   # no window of the pass took the minibatch step
+        models[step] = {n: t.view(n) for n in ("W_user", "W_item", "W_ufeedback", "i_bias")}
+    for n, a in models[None].items():
+        np.testing.assert_array_equal(a.view(np.uint32), models["levels"][n].view(np.uint32))

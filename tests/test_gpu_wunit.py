@@ -342,3 +342,37 @@ def test_bf16_contribution_rows_equal_the_oracle_simulation_with_the_same_roundi
     finally:
         multi_rank_utils.CONTRIB_BF16 = False
     _check([ad for ad, _ in ranks], sim, names)
+
+
+def test_window_sequences_validate_the_callers_pointer_arrays():
+    """amd:step = minibatch returned into the window builders before any of the pointer checks of the level path ran; a
+    decreasing row_ptr / fb_ptr / block_row_ptr or a negative start must raise the usual messages instead of indexing out of bounds."""
+    nu, ni, ng = 50, 30, 4
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=8)
+    t = sa.Trainer(0, 0)
+    t.seed(10)
+    for k, v in conf + [("amd:step", "minibatch")]:
+        t.set_param(k, str(v))
+    t.init_model()
+    t.init_trainer()
+    d = _rows_with_globals(200, nu, ni, ng, 2, seed=1, fixed=True)
+    for edit, msg in ((lambda p: p.__setitem__(4, p[5] + 3), "non-decreasing"), (lambda p: p.__isub__(p[-1] + 7), "negative")):
+        bad = sa.CSRData(d.row_label, d.row_ptr.copy(), d.feat_index, d.feat_value)
+        edit(bad.row_ptr)
+        with pytest.raises(sa.SvdfError, match=msg):
+            t.dataset_from_csr(bad)
+    pconf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=8, num_ufeedback=ni)
+    t = sa.Trainer(1, 0)
+    t.seed(10)
+    for k, v in pconf + [("amd:step", "minibatch")]:
+        t.set_param(k, str(v))
+    t.init_model()
+    t.init_trainer()
+    blocks = cases.user_blocks(20, nu, ni, ni, seed=2, max_rows=4, max_fb=3)
+    for field in ("fb_ptr", "block_row_ptr", "row_ptr"):
+        ba = sa.BlockArrays.from_blocks(blocks)
+        arr = getattr(ba, field).copy()
+        arr[3] = arr[4] + 2
+        setattr(ba, field, arr)
+        with pytest.raises(sa.SvdfError, match="non-decreasing"):
+            t.dataset_from_blocks(ba)
