@@ -120,10 +120,11 @@ void Engine::set_param(const char *name, const char *val) {  // apex_svd_base.h:
         multi_exchange_mode_ = !strcmp(val, "rccl") ? 1 : 0;
     }
     if (!strcmp(name, "amd:step")) {
-        check(!strcmp(val, "minibatch") || !strcmp(val, "levels"), "amd:step must be minibatch or levels");
+        check(!strcmp(val, "minibatch") || !strcmp(val, "levels") || !strcmp(val, "auto"), "amd:step must be minibatch, levels or auto");
         check(!multi_, "amd:step must be set before the model is created");
         multi_step_levels_ = !strcmp(val, "levels");
         step_minibatch_set_ = !strcmp(val, "minibatch");   // one GPU: opt-in window-minibatch SGD (svdf_wunit.cpp: resident data sets become window sequences)
+        step_auto_set_ = !strcmp(val, "auto");             // one GPU: opt-in, decided per resident data set from its level schedule (svdf_dataset.cpp: auto_step)
     }
     if (!strcmp(name, "amd:contrib")) {   // window-minibatch step: storage format of the contribution rows (sums are fp32 either way)
         check(!strcmp(val, "fp32") || !strcmp(val, "bf16"), "amd:contrib must be fp32 or bf16");
@@ -176,6 +177,12 @@ int64_t Engine::counter(int what) const {
     case 13: return n_init_reports_;    // init_model on the device: values the host libm decided (near a float rounding boundary)
     case 14: return n_init_draws_;      // init_model on the device: rand() draws consumed
     case 15: return n_chained_levels_;  // conflict-free levels executed inside chained launches (k_fewrow_slots_chain)
+    // amd:step = auto, the decision taken for the data set built last (svdf_dataset.cpp: auto_step)
+    case 16: return auto_last_.decided;                           // 0 none yet, 1 exact levels kept, 2 window step chosen, 3 exact kept because the window step does not cover the configuration / the data
+    case 17: return auto_last_.levels;
+    case 18: return (int64_t)(auto_last_.dag_ms * 1000.0);        // levels x unit latency, microseconds
+    case 19: return (int64_t)(auto_last_.stream_ms * 1000.0);     // algorithmic bytes at the measured random-row rate, microseconds
+    case 20: return auto_last_.windows;
     default: return -1;
     }
 }

@@ -30,6 +30,13 @@ Dataset *Engine::dataset_from_blocks(long num_block, const int *extend_tag, cons
     flush();
     check(!unit_open_, "dataset_from_blocks: a START block is pending in the trainer");
     if (single_minibatch()) return wseq_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
+    if (auto_step_active()) {
+        auto_building_ = true;
+        struct Done { bool &f; ~Done() { f = false; } } done{auto_building_};
+        Dataset *exact = dataset_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
+        const bool ok = wunit_config_ok() && wunit_blocks_ok(num_block, extend_tag, fb_ptr, fb_index, block_row_ptr, row_ptr, feat_index);
+        return auto_step(exact, ok, [&]() { return wseq_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value); });
+    }
     if (imfb()) {   // multi-level units: every span of the pass must be closed inside it
         check(imfb_depth_ == 0, "dataset_from_blocks: a START block is pending in the trainer");
         const long saved_window = stage_window_;
@@ -114,6 +121,12 @@ Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsign
     need_device("dataset");
     if (multi_ && !in_multi_scope()) return multi_dataset_from_triples(n, user, item, label);
     if (single_minibatch() && !user_group() && basic_fast_path_allowed()) return wseq_from_triples(n, user, item, label);
+    if (auto_step_active()) {
+        auto_building_ = true;
+        struct Done { bool &f; ~Done() { f = false; } } done{auto_building_};
+        Dataset *exact = dataset_from_triples(n, user, item, label);
+        return auto_step(exact, wunit_config_ok() && !user_group() && basic_fast_path_allowed(), [&]() { return wseq_from_triples(n, user, item, label); });
+    }
     if (!basic_fast_path_allowed()) {
         // fall back to the general representation (side tables / shared latent space / user-group trainer)
         std::vector<int64_t> ptr((size_t)3 * n + 1);
@@ -182,6 +195,12 @@ Dataset *Engine::dataset_from_pairs(long n, const unsigned *user, const unsigned
     need_device("dataset");
     if (multi_ && !in_multi_scope()) return multi_dataset_from_pairs(n, user, pos, neg);
     if (single_minibatch() && !user_group() && basic_fast_path_allowed()) return wseq_from_pairs(n, user, pos, neg);
+    if (auto_step_active()) {
+        auto_building_ = true;
+        struct Done { bool &f; ~Done() { f = false; } } done{auto_building_};
+        Dataset *exact = dataset_from_pairs(n, user, pos, neg);
+        return auto_step(exact, wunit_config_ok() && !user_group() && basic_fast_path_allowed(), [&]() { return wseq_from_pairs(n, user, pos, neg); });
+    }
     if (device_sched_ && n > 0 && fused_allowed() && !user_group() && !relaxed()) {
         // everything on the device: the three columns go up as they are, the schedule columns (lower / higher item id, signs)
         // are formed there, ids are checked by the scheduling pass, pos == neg by the preparation kernel
@@ -367,6 +386,13 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
     check(!user_group() || rows_as_instances_, "svdfeature_amd: resident datasets are for random-order (format_type 0) trainers");
     if (multi_ && !in_multi_scope()) return multi_dataset_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);
     if (single_minibatch() && !user_group()) return wseq_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);
+    if (auto_step_active() && !user_group()) {
+        auto_building_ = true;
+        struct Done { bool &f; ~Done() { f = false; } } done{auto_building_};
+        Dataset *exact = dataset_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);   // validates the pointers
+        const bool ok = wunit_config_ok() && wunit_rows_ok(0, num_row, row_ptr, feat_index);
+        return auto_step(exact, ok, [&]() { return wseq_from_csr(num_row, row_label, row_ptr, feat_index, feat_value); });
+    }
     const long n = num_row;
     const int64_t p00 = row_ptr[0];
     check(row_ptr[3 * n] - p00 < (int64_t)2147483647, "dataset: more than 2^31-1 feature entries");
@@ -483,6 +509,45 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
     ds->order.upload(ds->sched.order.data(), (size_t)n, stream_);
     HIPCHECK(hipStreamSynchronize(stream_));
     return ds.release();
+}
+
+// `amd:step = auto`: keep the exact level schedule or rebuild the data set as a window sequence.  What is compared (both from the
+// schedule the engine has just built, nothing is run):
+//   dag_ms    = levels x the latency of ONE unit launched alone -- a pass of exact sequential semantics cannot be faster (bench.py's
+//               dag_bound measures the same figure): 4.5 us for an instance (kernel boundary + record -> rows -> dot chain -> stores,
+//               DESIGN.md section 5), 5 us + 0.42 us per row for a user unit of the SVD++ kernels (46.6 us at 100 rows);
+//   stream_ms = the pass's algorithmic bytes at the rate random 256 / 512-byte row read-modify-writes reach on this
+//               chip (0.57 x 8 TB/s, the contract line).
+// dag_ms <= 2 x stream_ms: the levels are wide enough to stream, the exact pass stays (bit parity with the reference).  Otherwise the
+// data's dependency depth binds and the window step (user side exact, shared rows once per window; |dRMSE| <= 1e-4) is taken.  The
+// decision is printed once per data set and kept in counters 16 .. 20.
+Dataset *Engine::auto_step(Dataset *exact, bool window_ok, const std::function<Dataset *()> &build_window) {
+    std::unique_ptr<Dataset> ex(exact);
+    AutoDecision D;
+    D.levels = (long)ex->sched.num_levels();
+    const long units = ex->kind == 3 || ex->kind == 4 ? std::max<long>(ex->num_units, 1) : std::max<long>(ex->num_row, 1);
+    const double unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : 4.5;
+    D.dag_ms = (double)D.levels * unit_us * 1e-3;
+    D.stream_ms = (double)ex->algorithmic_bytes / (0.57 * 8.0e12) * 1e3;
+    const bool deep = D.dag_ms > 2.0 * D.stream_ms;
+    const char *why;
+    if (!deep) { D.decided = 1; why = "exact levels kept (wide enough to stream)"; }
+    else if (!window_ok) { D.decided = 3; why = "exact levels kept: the dependency depth binds, but the window step does not cover this configuration / these rows"; }
+    else { D.decided = 2; why = "window step chosen: the dependency depth of exact sequential semantics binds"; }
+    Dataset *out = ex.get();
+    if (D.decided == 2) {
+        ex.reset();   // its HBM goes back before the windows are built
+        out = build_window();
+        D.windows = (long)out->wchild.size();
+    } else {
+        ex.release();
+    }
+    auto_last_ = D;
+    if (!getenv("SVDF_QUIET"))
+        fprintf(stderr, "[svdfeature_amd] amd:step = auto: %ld rows, %ld conflict-free levels: dag bound %.2f ms (%.1f us per unit), stream model %.2f ms -> %s%s\n",
+                (long)out->num_row, D.levels, D.dag_ms, unit_us, D.stream_ms, why,
+                D.decided == 2 ? (" (" + std::to_string(D.windows) + " windows)").c_str() : "");
+    return out;
 }
 
 Dataset::~Dataset() {

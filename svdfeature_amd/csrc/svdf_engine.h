@@ -596,6 +596,13 @@ class Engine {
     int wseq_per_target_fb_ = 16;         // knob "window_per_target_fb": the same for feedback rows (instance-sized updates pushed by whole blocks)
     int wseq_per_target_ = 24;            // knob "window_per_target": updates a shared row meets per window when amd:window is not given
     bool single_minibatch() const { return step_minibatch_set_ && gpus_ == 1 && !multi_ && !is_peer_; }
+    // one GPU, `amd:step = auto` (opt-in): every resident data set is level-scheduled first (that is cheap on the device); when the
+    // dependency depth of exact sequential semantics -- levels x the latency of one unit -- exceeds twice what the pass would take at the
+    // streaming rate, the data set is rebuilt as a window sequence (the contract of `amd:step = minibatch`), else the exact levels stay.
+    bool step_auto_set_ = false, auto_building_ = false;
+    struct AutoDecision { int decided = 0; long levels = 0, windows = 0; double dag_ms = 0.0, stream_ms = 0.0; } auto_last_;
+    bool auto_step_active() const { return step_auto_set_ && !auto_building_ && gpus_ == 1 && !multi_ && !is_peer_ && !host_only_; }
+    Dataset *auto_step(Dataset *exact, bool window_ok, const std::function<Dataset *()> &build_window);
     long wseq_windows(long n, const std::vector<double> &updates_per_target) const;
     Dataset *wseq_from_csr(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
     Dataset *wseq_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,

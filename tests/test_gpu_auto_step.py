@@ -1,0 +1,143 @@
+"""`amd:step = auto` (svdf_dataset.cpp: Engine::auto_step): opt-in, decided per resident data set from the level schedule the
+engine builds anyway -- exact conflict-free levels when they are wide enough to stream, the window-minibatch step when the data's dependency depth
+binds (levels x unit latency > 2 x bytes at the streaming rate).  Default (key absent) stays exact.
+
+The guard: on the reference's own FILE order of a rank pass (user-grouped pairs, apex_svd_data.cpp:946-965; the stream of
+tools/chain_probe.py, 99 % of whose pairs form one dependency chain) the exact pass is slower than the CPU reference path; the path `auto` picks must
+not be."""
+import time
+
+import numpy as np
+import pytest
+
+import cases
+import svdfeature_amd as sa
+
+pytestmark = pytest.mark.gpu
+
+
+def _trainer(conf, active=0, fmt=0, extra=()):
+    t = sa.Trainer(fmt, active)
+    t.seed(10)
+    for k, v in list(conf) + list(extra):
+        t.set_param(k, str(v))
+    t.init_model()
+    t.init_trainer()
+    return t
+
+
+def _grouped_pairs(nu, ni, per_user, seed):
+    rng = np.random.default_rng(seed)
+    u = np.repeat(np.arange(nu, dtype=np.uint32), per_user)
+    p = rng.integers(0, ni, len(u)).astype(np.uint32)
+    q = ((p + 1 + rng.integers(0, ni - 1, len(u))) % ni).astype(np.uint32)
+    return u, p, q
+
+
+def test_wide_levels_stay_exact_and_equal_the_oracle():
+    from oracle import oracle
+    oracle.build()
+    nu, ni, n = 200000, 40000, 3000000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=3)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
+    t = _trainer(conf, extra=[("amd:step", "auto")])
+    ds = t.dataset_from_triples(u, i, r)
+    assert t.counter(16) == 1 and ds.kind == 0 and t.counter(17) == ds.num_batches   # exact levels kept
+    assert t.counter(18) <= 2 * t.counter(19)
+    t.train_dataset(ds)
+    o = oracle.OracleTrainer("port", 0, 0)
+    o.seed(10)
+    for k, v in conf:
+        o.set_param(k, v)
+    o.init_model()
+    o.init_trainer()
+    o.update_batch(sa.CSRData.from_triples(u, i, r))
+    for name in ("W_user", "W_item", "u_bias", "i_bias"):
+        assert np.array_equal(t.view(name).view(np.uint32), o.view(name).view(np.uint32)), name
+
+
+def test_default_is_exact_whatever_the_depth():
+    nu, ni = 60, 200
+    cols = _grouped_pairs(nu, ni, 300, 5)
+    t = _trainer(cases.conf_with(cases.PAIR_CONF, num_user=nu, num_item=ni, num_factor=128), active=3)
+    ds = t.dataset_from_pairs(*cols)
+    assert ds.kind == 2 and t.counter(16) == 0
+
+
+def test_deep_data_takes_the_window_step_and_equals_amd_step_minibatch():
+    nu, ni = 120, 400
+    cols = _grouped_pairs(nu, ni, 500, 7)
+    conf = cases.conf_with(cases.PAIR_CONF, num_user=nu, num_item=ni, num_factor=128)
+    models = []
+    for step in ("auto", "minibatch"):
+        t = _trainer(conf, active=3, extra=[("amd:step", step)])
+        ds = t.dataset_from_pairs(*cols)
+        assert ds.kind == 8
+        if step == "auto":
+            assert t.counter(16) == 2 and t.counter(18) > 2 * t.counter(19) and t.counter(20) >= 1
+        for _ in range(2):
+            t.train_dataset(ds)
+        models.append({n: t.view(n).copy() for n in ("W_user", "W_item", "i_bias")})
+    for n in models[0]:
+        assert np.array_equal(models[0][n].view(np.uint32), models[1][n].view(np.uint32)), n
+
+
+def test_shapes_outside_the_window_step_keep_exact_levels_and_say_so():
+    """lazy decay (reg_method 4) is outside the window step: the deep data set keeps its exact levels, decision 3"""
+    nu, ni = 80, 60
+    u, i, r = cases.planted_triples(30000, nu, ni, seed=2)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=32, reg_method=4)
+    t = _trainer(conf, extra=[("amd:step", "auto")])
+    ds = t.dataset_from_triples(u, i, r)
+    assert t.counter(16) == 3 and ds.kind != 8
+    t.train_dataset(ds)
+    # rows with global features and user-group blocks decide the same way
+    from test_gpu_wunit import _rows_with_globals
+    d = _rows_with_globals(20000, 300, 200, 8, 3, seed=1, fixed=True)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=300, num_item=200, num_global=8, num_factor=32, wd_global=0.001)
+    t = _trainer(conf, extra=[("amd:step", "auto")])
+    ds = t.dataset_from_csr(d)
+    assert t.counter(16) == 2 and ds.kind == 8
+    blocks = cases.user_blocks(400, 500, 150, 150, seed=6, max_rows=20, max_fb=12)
+    pconf = cases.conf_with(cases.BASICMF_CONF, num_user=500, num_item=150, num_factor=32, num_ufeedback=150, wd_ufeedback=0.004)
+    t = _trainer(pconf, fmt=1, extra=[("amd:step", "auto")])
+    ds = t.dataset_from_blocks(sa.BlockArrays.from_blocks(blocks))
+    assert t.counter(16) == 2 and ds.kind == 8
+    t.train_dataset(ds)
+
+
+def test_guard_the_path_auto_picks_is_not_slower_than_the_cpu_reference():
+    """tools/chain_probe.py's stream at a size the CPU path finishes in seconds: 943 users x 1 682 items (the demo's shape), 600 pairs per user in
+    the generator's file order, k = 128.  CPU = the compiled reference (oracle/_ref) when it travelled, else the pinned C port; one thread."""
+    from oracle import oracle
+    oracle.build()
+    nu, ni, per_user, k = 943, 1682, 600, 128
+    cols = _grouped_pairs(nu, ni, per_user, 1)
+    n = len(cols[0])
+    conf = cases.conf_with(cases.PAIR_CONF, num_user=nu, num_item=ni, num_factor=k)
+    kind = "reference" if oracle.have_reference() else "port"
+    o = oracle.OracleTrainer(kind, 0, 3)
+    o.seed(10)
+    for kk, v in conf:
+        o.set_param(kk, v)
+    o.init_model()
+    o.init_trainer()
+    csr = sa.pairs_as_csr(*cols)
+    t0 = time.perf_counter()
+    o.update_batch(csr)
+    cpu_rate = n / (time.perf_counter() - t0)
+    rates = {}
+    for step in (None, "auto"):
+        t = _trainer(conf, active=3, extra=[("amd:step", step)] if step else [])
+        ds = t.dataset_from_pairs(*cols)
+        t.train_dataset(ds)
+        t.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            t.train_dataset(ds)
+        t.synchronize()
+        rates[step] = 3 * n / (time.perf_counter() - t0)
+        if step == "auto":
+            assert t.counter(16) == 2, "auto must leave the exact levels on a 99 % sequential stream"
+    print("pairs/s: CPU (%s, 1 thread) %.3g, exact levels %.3g, auto (window step) %.3g" % (kind, cpu_rate, rates[None], rates["auto"]))
+    assert rates["auto"] >= cpu_rate, (rates, cpu_rate)
