@@ -183,6 +183,7 @@ int64_t Engine::counter(int what) const {
     case 18: return (int64_t)(auto_last_.dag_ms * 1000.0);        // levels x unit latency, microseconds
     case 19: return (int64_t)(auto_last_.stream_ms * 1000.0);     // algorithmic bytes at the measured random-row rate, microseconds
     case 20: return auto_last_.windows;
+    case 21: return n_stream_passes_;   // passes issued as ONE launch by the in-launch DAG executor (knob stream_exec)
     default: return -1;
     }
 }
@@ -216,6 +217,10 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "device_init")) { device_init_ = value != 0; return 0; }
     if (!strcmp(name, "device_window")) { device_window_ = value != 0; return 0; }
     if (!strcmp(name, "device_load")) { device_load_ = value != 0; return 0; }
+    if (!strcmp(name, "stream_exec")) { check(value == 0 || value == 1, "stream_exec must be 0 or 1"); stream_exec_ = (int)value; return 0; }
+    if (!strcmp(name, "stream_debug_mode")) { stream_debug_mode_ = (int)value; return 0; }
+    if (!strcmp(name, "stream_waves")) { check(value >= 0 && value <= 65536, "stream_waves must be in 0 .. 65536"); stream_waves_ = (int)value; return 0; }
+    if (!strcmp(name, "stream_spin_limit")) { check(value >= 1 && value <= 0x7fffffffL, "stream_spin_limit must be positive"); stream_spin_limit_ = value; return 0; }
     if (!strcmp(name, "ipc_spin_limit")) { ipc_set_spin_limit(value); return 0; }
     if (!strcmp(name, "chain_width")) { check(value >= 0, "chain_width must not be negative"); chain_width_ = value; return 0; }
     if (!strcmp(name, "wseq_build_threads")) { check(value >= 1 && value <= 256, "wseq_build_threads must be in 1 .. 256"); wseq_build_threads_ = (int)value; return 0; }

@@ -103,6 +103,7 @@ Engine::~Engine() {
         }
         (void)hipStreamSynchronize(stream_);
         if (pred_pin_) (void)hipHostFree(pred_pin_);
+        if (stream_err_) (void)hipHostFree(stream_err_);
         for (int b = 0; b < 2; b++) {
             if (save_pin_[b]) (void)hipHostFree(save_pin_[b]);
             if (save_ev_[b]) (void)hipEventDestroy(save_ev_[b]);
@@ -756,8 +757,11 @@ void Engine::train_dataset(Dataset *ds) {
         HIPCHECK(hipStreamSynchronize(stream_));
         ds->d_level_ptr_ok = true;
     }
+    const bool as_stream = stream_applies(ds);   // builds the tile plan on first use (outside any capture)
     auto issue = [&]() {
-        if (ds->kind == 0) {
+        if (as_stream) {
+            stream_train(ds);
+        } else if (ds->kind == 0) {
             BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
             for (size_t l = 0; l < sc.num_levels(); l++) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
         } else if (ds->kind == 5) {
@@ -851,5 +855,6 @@ void Engine::synchronize() {
     if (multi_) { multi_synchronize(); return; }
     HIPCHECK(hipStreamSynchronize(stream_));
     ipc_fail_if_dead("svdf_synchronize");
+    stream_fail_if_dead("svdf_synchronize");
 }
 }  // namespace svdf

@@ -237,6 +237,12 @@ struct Dataset {
     long win_item_lo = 0, win_item_hi = -1;   // kind 5: lowest / highest item id with an instance in the window (-1: none)
     DevBuf<long> d_level_ptr;     // kind 2: the level boundaries in HBM, uploaded when a run of narrow levels is first chained (k_fewrow_slots_chain)
     bool d_level_ptr_ok = false;
+    // the tile plan of the in-launch DAG executor (svdf_stream.cpp), built on first use when the knob stream_exec is on
+    DevBuf<uint2> st_tile_hdr;
+    DevBuf<unsigned> st_pred[3], st_done;
+    unsigned st_ntiles = 0, st_pass = 0;
+    int st_nslots = 0;
+    bool st_built = false;
     int64_t chained_levels = 0;   // levels the current launch sequence of this data set walks inside chained launches
     long win_slots = 0;           // contribution slots of the window = item entries (kind 7: + feedback entries)
     // kind 7: window-minibatch data set of user units (svdf_k_wunit.hip): user-group blocks / rows with global features
@@ -596,6 +602,19 @@ class Engine {
     int wseq_per_target_fb_ = 16;         // knob "window_per_target_fb": the same for feedback rows (instance-sized updates pushed by whole blocks)
     int wseq_per_target_ = 24;            // knob "window_per_target": updates a shared row meets per window when amd:window is not given
     bool single_minibatch() const { return step_minibatch_set_ && gpus_ == 1 && !multi_ && !is_peer_; }
+    // the conflict DAG inside one launch per pass (svdf_stream.cpp / svdf_k_stream.hip)
+    int stream_exec_ = 0;                 // knob "stream_exec"
+    int stream_num_cu_ = 0;
+    int stream_debug_mode_ = 0;           // knob "stream_debug_mode" (experiments; non-zero = not coherent across XCDs)
+    int stream_waves_ = 0;                // knob "stream_waves": persistent waves of the launch (0 = 8 per CU)
+    long stream_spin_limit_ = 1 << 22;    // knob "stream_spin_limit": polls before a wait gives up
+    unsigned *stream_err_ = nullptr, *stream_err_dev_ = nullptr;
+    int64_t n_stream_passes_ = 0;
+    void stream_build(Dataset *ds, int TS, const unsigned *const *cols, int nslots, const int *space_of_slot);
+    StreamPlan stream_view(const Dataset *ds);
+    bool stream_applies(Dataset *ds);
+    void stream_train(Dataset *ds);
+    void stream_fail_if_dead(const char *where);
     // one GPU, `amd:step = auto` (opt-in): every resident data set is level-scheduled first (that is cheap on the device); when the
     // dependency depth of exact sequential semantics -- levels x the latency of one unit -- exceeds twice what the pass would take at the
     // streaming rate, the data set is rebuilt as a window sequence (the contract of `amd:step = minibatch`), else the exact levels stay.

@@ -107,6 +107,17 @@ long rank_select_cap();
 void launch_rank_select(long n, const unsigned *keys, const unsigned *vals, unsigned K1, unsigned *work, unsigned *ck, unsigned *cv, unsigned *out,
                         const unsigned *flag, hipStream_t st);
 // ascending radix sort of (key, value) pairs (svdf_k_sched.hip, rocPRIM); tmp is grown as needed
+// in-launch DAG executor (svdf_k_stream.hip)
+void launch_stream_tiles(const unsigned *tile_base, const unsigned *level_ptr, long nlevels, int TS, unsigned ntiles, uint2 *tile_hdr,
+                         unsigned *tile_of_pos, hipStream_t st);
+void launch_stream_iota(unsigned *v, long n, hipStream_t st);
+void launch_stream_interleave(const unsigned *const *cols, int members, long n, unsigned *keys, unsigned *entries, hipStream_t st);
+void launch_stream_preds(const unsigned *keys, const unsigned *entries, long m, unsigned absent, const unsigned *tile_of_pos, unsigned *pred, int members,
+                         int member, hipStream_t st);
+int stream_basic_tile_size(const DevParams &P);
+int stream_basic_max_waves(int num_cu);
+bool stream_basic_applies(const DevParams &P, const BasicSchedule &S);
+void launch_basicmf_stream(const DevParams &P, const BasicSchedule &S, const StreamPlan &T, unsigned pass, int waves, hipStream_t st);
 void device_sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, unsigned *vals_out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st);
 int sqerr_partials_grid(long n);
 void launch_sqerr_partials(const float *pred, const float *label, long n, float scale, double *partials, hipStream_t st);
