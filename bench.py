@@ -131,11 +131,14 @@ def synth_user_blocks(num_blocks, per_user, num_user, num_item, seed=4242):
     i = rng.integers(0, num_item, n, dtype=np.uint32)
     pl = Planted(num_user, num_item, rng)
     r = pl.rate(u, i, rng)
-    # feedback set of a block = its distinct items, sorted (np.unique per block, vectorised through a sort of (block, item))
-    blk = np.repeat(np.arange(num_blocks, dtype=np.int64), per_user)
-    key = np.unique(blk * num_item + i)
-    fb_blk, fb_idx = key // num_item, (key % num_item).astype(np.uint32)
-    fb_cnt = np.bincount(fb_blk, minlength=num_blocks)
+    # feedback set of a block = its distinct items, sorted: a row-wise sort of the (block, per_user) item matrix, duplicates masked out (the same
+    # arrays np.unique(block * num_item + item) gives, without a 100 M-key sort at the configs[3] size of round 5: 1 M users)
+    srt = np.sort(i.reshape(num_blocks, per_user), axis=1)
+    keep = np.ones(srt.shape, dtype=bool)
+    keep[:, 1:] = srt[:, 1:] != srt[:, :-1]
+    fb_idx = srt[keep].astype(np.uint32)
+    fb_cnt = keep.sum(axis=1).astype(np.int64)
+    del srt, keep
     fb_ptr = np.concatenate([[0], np.cumsum(fb_cnt)]).astype(np.int64)
     fb_val = (1.0 / np.sqrt(np.repeat(fb_cnt, fb_cnt))).astype(np.float32)
 
@@ -1131,7 +1134,7 @@ def model_ms(name, world, exchange_step, n, items, factor, nwin, blocks, handoff
             "speedup_over_one_gpu": (t1_ms / total) if t1_ms else None, "source": src + "; ring all-reduce: DESIGN.md 6d"}
 
 
-def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
+def run_window_step(sa, name, a, device, log, steps=3, warmup=1, seq_quality=None):
     """secondary.<workload>_window_step: BASELINE configs[3] through the OPT-IN window-minibatch step on ONE GPU (`amd:step = minibatch`;
     svdf_k_wunit.hip) -- next to, never instead of, the exact line.  A user's unit is exact on its private state,
     the shared rows (W_item / i_bias, W_ufeedback / ufeedback_bias, g_bias) move once per window; the result is NOT the reference's bit for
@@ -1204,11 +1207,15 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
     # the same epochs as exact sequential SGD (the reference's result) on this GPU; the minibatch model is scored through an exact-mode twin
     # that loads its model file (a minibatch handle builds window sequences, which are training sets)
     import tempfile
-    sq = make_trainer(sa, name, a, factor, device)
-    dsq = (sq.dataset_from_pairs(*tri) if name == "pairwise" else sq.dataset_from_triples(*tri)) if tri else (sq.dataset_from_blocks(train) if name == "svdpp" else sq.dataset_from_csr(d_all))
-    for _ in range(warmup + steps):
-        sq.train_dataset(dsq)
-    rm_seq = score(sq)
+    sq = dsq = None
+    if seq_quality is not None and seq_quality[0] == warmup + steps:
+        rm_seq = seq_quality[1]   # the exact secondary of this run trained the same passes over the same stream (7 s per pass at 1 M SVD++ users: not twice)
+    else:
+        sq = make_trainer(sa, name, a, factor, device)
+        dsq = (sq.dataset_from_pairs(*tri) if name == "pairwise" else sq.dataset_from_triples(*tri)) if tri else (sq.dataset_from_blocks(train) if name == "svdpp" else sq.dataset_from_csr(d_all))
+        for _ in range(warmup + steps):
+            sq.train_dataset(dsq)
+        rm_seq = score(sq)
     path = os.path.join(tempfile.mkdtemp(), "wstep.model")
     tr.save_model(path)
     tw = sa.Trainer(WORKLOADS[name][0], WORKLOADS[name][1], device=device)
@@ -1238,9 +1245,11 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1):
     log("%s window step: %.2f ms per pass = %.1f M inst/s (%.1f%% of peak), %d windows, quality %s vs sequential %s" % (
         name, res["ms_per_step"], res["value"] / 1e6, 100 * res["roofline"]["frac"], ds.num_batches, rm_run, rm_seq))
     for x in (ds, dsq):
-        x.close()
+        if x is not None:
+            x.close()
     for t in (tr, sq, tw):
-        t.close()
+        if t is not None:
+            t.close()
     return res
 
 
@@ -1299,7 +1308,7 @@ def main():
     ap.add_argument("--workload", choices=list(WORKLOADS), default="basicmf", help="which BASELINE config is the main JSON line")
     ap.add_argument("--ratings", type=int, default=100_000_000)
     ap.add_argument("--pairs", type=int, default=200_000_000, help="pairwise workload: rank pairs per pass (BASELINE configs[4])")
-    ap.add_argument("--svdpp-users", type=int, default=40_000)
+    ap.add_argument("--svdpp-users", type=int, default=1_000_000, help="SVD++ workload: user blocks per pass (round 5: 1 M x 100 = 100 M instances; rounds 1-4 ran 40 K)")
     ap.add_argument("--svdpp-per-user", type=int, default=100)
     ap.add_argument("--neighbour-rows", type=int, default=4_000_000)
     ap.add_argument("--globals", type=int, default=10_000)
@@ -1354,6 +1363,7 @@ def main():
     ap.add_argument("--run-timeout", type=float, default=900.0, help="N>1: watchdog of the main workload (seconds)")
     ap.add_argument("--secondary-timeout", type=float, default=420.0, help="N>1: watchdog of each secondary (seconds); on expiry the contract line is printed without it")
     ap.add_argument("--data-seed", type=int, default=0, help="added to the generator seed of every synthetic stream (0 = the streams of SURVEY 8d2 / earlier rounds)")
+    ap.add_argument("--no-orders", action="store_true", help="N=1: skip secondary.orders (Zipf items, generator-order pairs; benchlib/orders.py)")
     ap.add_argument("--no-window-step", action="store_true", help="N=1: skip the opt-in window-minibatch lines of the SVD++ / neighbourhood secondaries")
     ap.add_argument("--step-window", type=int, default=0, help="window-step secondaries: rows per window (amd:window); 0 = the engine's choice from the data")
     ap.add_argument("--step-per-target", type=int, default=0, help="window-step secondaries: updates a shared row meets per window (knob window_per_target); 0 = default")
@@ -1537,14 +1547,18 @@ def main():
         if name == a.workload or (world > 1 and name == "neighbourhood"):
             continue
         t0 = time.time()
-        r = run_workload(name, a, env, a.secondary_steps, 1, False)
+        # SVD++ at 1 M users: an exact pass is 159 K levels x 46 us = 7.4 s whatever the kernel does (dag_bound): one timed pass after one warm-up
+        r = run_workload(name, a, env, 1 if (name == "svdpp" and a.svdpp_users >= 200_000) else a.secondary_steps, 1, False)
         if r is not None:
             r["wall_s"] = round(time.time() - t0, 1)
             secondary["%s_k%d" % (name, WORKLOADS[name][2])] = r
     if rank == 0 and world == 1 and not a.no_window_step:
         for name in (["basicmf"] if (a.workload == "basicmf" and sec) else []) + [s for s in sec.split(",") if s in ("pairwise", "svdpp", "neighbourhood")]:
             try:   # extras: never lose the contract line over them
-                secondary["%s_k%d_window_step" % (name, WORKLOADS[name][2])] = run_window_step(sa, name, a, local_rank, log)
+                exact = secondary.get("%s_k%d" % (name, WORKLOADS[name][2])) or {}
+                big = name == "svdpp" and a.svdpp_users >= 200_000
+                seq = (exact["passes_before_rmse"], exact["rmse_test_after_run"]) if (big and "passes_before_rmse" in exact) else None
+                secondary["%s_k%d_window_step" % (name, WORKLOADS[name][2])] = run_window_step(sa, name, a, local_rank, log, steps=1 if big else 3, seq_quality=seq)
             except Exception as e:
                 secondary["%s_window_step_error" % name] = repr(e)
     if rank == 0 and world == 1 and a.secondary == "auto" and secondary:
@@ -1552,6 +1566,15 @@ def main():
             secondary.update(run_f3_secondary(a, env))
         except Exception as e:   # the f3 rows are extras: never lose the contract line over them
             secondary["f3_error"] = repr(e)
+    if rank == 0 and world == 1 and a.secondary == "auto" and secondary and not a.no_orders:
+        try:   # the BASELINE workloads on the reference's own data orders, exact / window / auto (benchlib/orders.py)
+            import types
+            from benchlib import orders
+            ctx = types.SimpleNamespace(Planted=Planted, HipEvents=HipEvents, rmse=rmse, make_trainer=make_trainer, WORKLOADS=WORKLOADS,
+                                        HBM_PEAK_GBS=HBM_PEAK_GBS, cpu_baseline_and_parity=cpu_baseline_and_parity, log=log)
+            secondary["orders"] = orders.run_orders(ctx, sa, a, local_rank)
+        except Exception as e:
+            secondary["orders_error"] = repr(e)
 
     # ---- N > 1, ratings: the other exchange designs on the SAME data in the SAME driver command
     if world > 1 and a.workload == "basicmf" and not a.no_multi_secondary:

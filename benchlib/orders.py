@@ -1,0 +1,237 @@
+"""secondary.orders of the default `python bench.py` line: the BASELINE workloads on the data ORDERS the reference itself
+produces or its one real data set has, instead of the uniform-random streams of the contract line:
+
+  * zipf_c2       -- configs[1] (basicMF k = 64, 1 M x 100 K, 100 M ratings) with Zipf-distributed items, exponent 0.7: the slope of the upper half
+                     of demo/basicMF/ua.base's item popularity (0.66 - 0.73; its top item holds 0.55 % of the ratings, here 0.97 %).  The hottest
+                     item's ratings form ONE dependency chain (every update reads the row the previous one wrote), so exact sequential semantics has
+                     as many conflict-free levels as that item has ratings.
+  * generator_c5  -- configs[4] (pairwiseRank k = 128, 200 M pairs) in the order PairwiseRankGenerator emits them (apex_svd_data.cpp:946-965: all pairs
+                     of one user block, then the next block): users in random order, 200 consecutive pairs each.
+  * (configs[3] SVD++ is user-grouped by construction -- tools/svdpp_randorder.cpp order -- and runs at 1 M users in secondary.svdpp_k128.)
+
+Each stream runs in three ways on one GPU: `exact` (default: conflict-free levels, the reference's result bit for bit -- checked on a prefix against the
+compiled reference, which is also the CPU baseline, timed on the SAME order), `window` (`amd:step = minibatch`, contract |dRMSE| <= 1e-4 / pair accuracy
+within 3e-3 of the exact run of the same passes, measured here) and `auto` (`amd:step = auto`: the engine's choice between the two from the level
+schedule, svdf_dataset.cpp).  Every entry carries value, roofline (algorithmic bytes of SURVEY 8d4 over the HIP-event time of the pass) and, for
+the exact pass, dag_bound = levels x the latency of one instance launched alone."""
+import os
+import tempfile
+import time
+
+import numpy as np
+
+ZIPF_EXPONENT = 0.7
+
+
+def synth_zipf_triples(ctx, n, num_user, num_item, seed):
+    """users uniform, items ~ Zipf(ZIPF_EXPONENT) over a random permutation of the ids (popularity is not a function of the id), ratings 1..5 from
+    the planted model of the contract stream"""
+    rng = np.random.default_rng(seed)
+    u = rng.integers(0, num_user, n, dtype=np.uint32)
+    w = 1.0 / np.arange(1, num_item + 1, dtype=np.float64) ** ZIPF_EXPONENT
+    cdf = np.cumsum(w / w.sum())
+    perm = rng.permutation(num_item).astype(np.uint32)
+    i = np.empty(n, np.uint32)
+    for s in range(0, n, 10_000_000):
+        e = min(n, s + 10_000_000)
+        i[s:e] = perm[np.minimum(np.searchsorted(cdf, rng.random(e - s)), num_item - 1)]
+    pl = ctx.Planted(num_user, num_item, rng)
+    return u, i, pl.rate(u, i, rng)
+
+
+def synth_generator_pairs(ctx, n, num_user, num_item, per_user, seed):
+    """the generator's file order: user blocks in random order, `per_user` consecutive pairs each; the positive item is the one the planted model
+    (+ noise) scores higher for that user"""
+    rng = np.random.default_rng(seed)
+    nblk = -(-n // per_user)
+    users = rng.integers(0, num_user, nblk, dtype=np.uint32) if nblk > num_user else rng.permutation(num_user)[:nblk].astype(np.uint32)
+    u = np.repeat(users, per_user)[:n]
+    a = rng.integers(0, num_item, n, dtype=np.uint32)
+    b = rng.integers(0, num_item - 1, n, dtype=np.uint32)
+    b = ((a.astype(np.int64) + 1 + b) % num_item).astype(np.uint32)
+    pl = ctx.Planted(num_user, num_item, rng)
+    pos, neg = np.empty(n, np.uint32), np.empty(n, np.uint32)
+    for s in range(0, n, 10_000_000):
+        e = min(n, s + 10_000_000)
+        first = pl.score(u[s:e], a[s:e]) + 0.35 * rng.standard_normal(e - s).astype(np.float32) > pl.score(u[s:e], b[s:e])
+        pos[s:e] = np.where(first, a[s:e], b[s:e])
+        neg[s:e] = np.where(first, b[s:e], a[s:e])
+    return u, pos, neg
+
+
+def _unit_latency_us(ctx, tr, one):
+    ev = ctx.HipEvents()
+    e0, e1 = ev.new(), ev.new()
+    for _ in range(20):
+        tr.train_dataset(one)
+    tr.synchronize()
+    ev.record(e0, tr.stream())
+    for _ in range(200):
+        tr.train_dataset(one)
+    ev.record(e1, tr.stream())
+    return ev.elapsed_ms(e0, e1) * 1e3 / 200
+
+
+EXACT_BUDGET_S = 4.0     # an exact pass longer than this is measured on a prefix of the stream (its rate does not improve with size: levels grow with n)
+PROBE_ROWS = 2_000_000
+
+
+def _timed_passes(ctx, tr, ds, passes):
+    ev = ctx.HipEvents()
+    e0, e1 = ev.new(), ev.new()
+    tr.synchronize()
+    times = []
+    for _ in range(passes):
+        ev.record(e0, tr.stream())
+        t0 = time.perf_counter()
+        tr.train_dataset(ds)
+        ev.record(e1, tr.stream())
+        tr.synchronize()
+        times.append((time.perf_counter() - t0, ev.elapsed_ms(e0, e1)))
+    return min(times[1:] or times)   # the first pass warms up unless it is the only one
+
+
+def run_case(ctx, sa, name, a, device, cols, test, passes=2, window_extra=()):
+    """cols: (u, i, r) ratings or (u, pos, neg) pairs of workload `name` ("basicmf" / "pairwise"); test: held-out columns of the same kind."""
+    pairs = name == "pairwise"
+    factor = ctx.WORKLOADS[name][2]
+    n = len(cols[0])
+    unit = ctx.WORKLOADS[name][4]
+
+    def build(t, m):
+        c = tuple(x[:m] for x in cols)
+        return t.dataset_from_pairs(*c) if pairs else t.dataset_from_triples(*c)
+    test_csr = sa.pairs_as_csr(*test) if pairs else sa.CSRData.from_triples(*test)
+
+    def score(t):
+        p = t.predict_batch(test_csr)
+        if pairs:
+            return {"pair_accuracy": float(np.mean(p > 0)), "mean_margin": float(np.mean(p, dtype=np.float64))}
+        return {"rmse": ctx.rmse(p, test[2])}
+
+    def score_window_handle(tr):   # a window handle's model is scored through an exact-mode twin (window data sets are training sets)
+        path = os.path.join(tempfile.mkdtemp(), "orders.model")
+        tr.save_model(path)
+        tw = sa.Trainer(ctx.WORKLOADS[name][0], ctx.WORKLOADS[name][1], device=device)
+        tw.load_model(path)
+        tw.init_trainer()
+        q = score(tw)
+        tw.close()
+        os.remove(path)
+        return q
+
+    def roof(alg, ev_ms, m, mode):
+        return {"bound": "hbm", "achieved": alg / (ev_ms * 1e-3) / 1e9, "peak": ctx.HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (ev_ms * 1e-3) / 1e9 / ctx.HBM_PEAK_GBS,
+                "traffic": None, "algorithmic_bytes_per_instance": alg / max(m, 1),
+                "what": "algorithmic bytes of the pass (SURVEY 8d4%s) / HIP-event time of the pass on the engine's stream" % ("" if mode == "exact" else " + the window step's contribution slots")}
+    out = {"instances_per_pass": n, "passes": passes}
+    wextra = [("amd:step", "minibatch")] + list(window_extra)
+    # ---- exact: how long would a full pass take?  one pass over the first PROBE_ROWS rows, extrapolated linearly
+    tr = ctx.make_trainer(sa, name, a, factor, device)
+    m_exact = n
+    if n > 2 * PROBE_ROWS:
+        ds = build(tr, PROBE_ROWS)
+        wall, _ = _timed_passes(ctx, tr, ds, 1)
+        est = wall * n / PROBE_ROWS
+        ds.close()
+        tr.close()
+        tr = ctx.make_trainer(sa, name, a, factor, device)
+        if est > EXACT_BUDGET_S:
+            m_exact = max(PROBE_ROWS, int(n * EXACT_BUDGET_S / est))
+    t0 = time.time()
+    ds = build(tr, m_exact)
+    build_s = time.time() - t0
+    wall, ev_ms = _timed_passes(ctx, tr, ds, passes)
+    one = build(tr, 1)
+    lat = _unit_latency_us(ctx, tr, one)
+    one.close()
+    q_exact = score(tr)
+    out["exact"] = {"value": m_exact / wall, "unit": unit, "ms_per_step": wall * 1e3, "build_s": round(build_s, 2), "conflict_free_levels": ds.num_batches,
+                    "measured_on": "the whole stream" if m_exact == n else
+                                   "the first %d of the %d (a full pass would take ~%.0f s: conflict-free levels grow linearly with the stream, the rate does not)" % (m_exact, n, wall * n / m_exact),
+                    "roofline": roof(ds.algorithmic_bytes, ev_ms, m_exact, "exact"),
+                    "dag_bound": {"levels_per_pass": ds.num_batches, "unit_latency_us": lat, "bound_ms_per_pass": ds.num_batches * lat * 1e-3,
+                                  "measured_over_bound": wall * 1e3 / max(ds.num_batches * lat * 1e-3, 1e-9)},
+                    "quality_after_%d_passes" % passes: q_exact}
+    ctx.log("orders %s exact: %d rows %.1f ms per pass = %.1f M %s (%.2f%% of peak), %d levels" % (
+        name, m_exact, wall * 1e3, m_exact / wall / 1e6, unit, 100 * out["exact"]["roofline"]["frac"], ds.num_batches))
+    ds.close()
+    tr.close()
+    # ---- window step on the whole stream (throughput), and on the exact run's rows for the contract when that was a prefix
+    t0 = time.time()
+    tr = ctx.make_trainer(sa, name, a, factor, device, extra=wextra)
+    ds = build(tr, n)
+    build_s = time.time() - t0
+    wall, ev_ms = _timed_passes(ctx, tr, ds, passes)
+    out["window"] = {"value": n / wall, "unit": unit, "ms_per_step": wall * 1e3, "build_s": round(build_s, 2), "windows": ds.num_batches,
+                     "roofline": roof(ds.algorithmic_bytes, ev_ms, n, "window")}
+    q_win = score_window_handle(tr)
+    ctx.log("orders %s window: %.1f ms per pass = %.1f M %s (%.1f%% of peak), %d windows" % (
+        name, wall * 1e3, n / wall / 1e6, unit, 100 * out["window"]["roofline"]["frac"], ds.num_batches))
+    ds.close()
+    tr.close()
+    if m_exact != n:
+        tr = ctx.make_trainer(sa, name, a, factor, device, extra=wextra)
+        ds = build(tr, m_exact)
+        for _ in range(passes):
+            tr.train_dataset(ds)
+        q_win = score_window_handle(tr)
+        ds.close()
+        tr.close()
+    out["window"]["quality_after_%d_passes" % passes] = q_win
+    out["window"]["contract_delta_vs_exact"] = {k: q_win[k] - q_exact[k] for k in q_exact}
+    out["window"]["contract_rows"] = m_exact
+    out["window"]["contract"] = ("pair accuracy within 3e-3, mean margin within 2 % of the exact run of the same passes over the same rows" if pairs else
+                                 "|dRMSE| <= 1e-4 against the exact run of the same passes over the same rows")
+    # ---- amd:step = auto: the decision the engine takes from the level schedule (nothing is trained: the data set IS one of the two above)
+    t0 = time.time()
+    tr = ctx.make_trainer(sa, name, a, factor, device, extra=[("amd:step", "auto")] + list(window_extra))
+    ds = build(tr, n)
+    dec = tr.counter(16)
+    out["auto"] = {"decision": {1: "exact", 2: "window", 3: "exact (window step not applicable)"}.get(dec, "none"), "levels": tr.counter(17),
+                   "dag_bound_ms": tr.counter(18) / 1e3, "stream_model_ms": tr.counter(19) / 1e3, "windows": tr.counter(20), "build_s": round(time.time() - t0, 2),
+                   "value": out["window" if dec == 2 else "exact"]["value"],
+                   "rule": "window step when levels x unit latency > 2 x algorithmic bytes at 0.57 x 8 TB/s (svdf_dataset.cpp: Engine::auto_step; streams of "
+                           "more than 8 M rows are judged on their first 2 M when those are deep by 16 x)"}
+    ds.close()
+    tr.close()
+    return out
+
+
+def ds_num(ent):
+    return ent.get("conflict_free_levels", ent.get("windows", 0))
+
+
+def run_orders(ctx, sa, a, device):
+    res = {"what": __doc__.split("\n\n")[0]}
+    t0 = time.time()
+    # ---- zipf_c2
+    n = a.ratings
+    u, i, r = synth_zipf_triples(ctx, n + 200_000, a.users, a.items, 4321 + a.data_seed)
+    cnt = np.bincount(i[:n], minlength=a.items)
+    ctx.log("orders: zipf stream in %.1fs (top item %d ratings = %.2f %%)" % (time.time() - t0, cnt.max(), 100.0 * cnt.max() / n))
+    case = run_case(ctx, sa, "basicmf", a, device, (u[:n], i[:n], r[:n]), (u[n:], i[n:], r[n:]))   # fp32 contributions: the hot items make windows small
+    case["stream"] = "1 M users uniform x 100 K items Zipf(%.2f) in random file order; top item %.2f %% of the ratings (demo/basicMF/ua.base: 0.55 %%)" % (
+        ZIPF_EXPONENT, 100.0 * cnt.max() / n)
+    if not a.no_cpu_baseline:
+        S = min(n, a.cpu_sample)
+        tr = ctx.make_trainer(sa, "basicmf", a, 64, device)
+        case["cpu_baseline"], case["parity"] = ctx.cpu_baseline_and_parity(sa, "basicmf", a, 64, tr, ("triples", u[:S], i[:S], r[:S]), n, ctx.log)
+        tr.close()
+    res["zipf_c2"] = case
+    del u, i, r
+    # ---- generator_c5
+    t0 = time.time()
+    n = a.pairs
+    per_user = max(1, n // max(a.users, 1))
+    u, p, q = synth_generator_pairs(ctx, n + 200_000, a.users, a.items, per_user, 8765 + a.data_seed)
+    ctx.log("orders: generator-order pairs in %.1fs (%d consecutive pairs per user block)" % (time.time() - t0, per_user))
+    case = run_case(ctx, sa, "pairwise", a, device, (u[:n], p[:n], q[:n]), (u[n:], p[n:], q[n:]), window_extra=[("amd:contrib", "bf16")])
+    case["stream"] = "user blocks in random order, %d consecutive pairs each (PairwiseRankGenerator's file order, apex_svd_data.cpp:946-965), items uniform" % per_user
+    if not a.no_cpu_baseline:
+        S = min(n, a.cpu_sample // 4)
+        tr = ctx.make_trainer(sa, "pairwise", a, 128, device)
+        case["cpu_baseline"], case["parity"] = ctx.cpu_baseline_and_parity(sa, "pairwise", a, 128, tr, ("pairs", u[:S], p[:S], q[:S]), n, ctx.log)
+        tr.close()
+    res["generator_c5"] = case
+    return res

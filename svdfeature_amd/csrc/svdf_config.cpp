@@ -233,6 +233,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "wunit_inplace")) { wunit_inplace_ = value != 0; return 0; }
     if (!strcmp(name, "wunit_fast")) { check(value >= 0 && value <= 2, "wunit_fast must be 0, 1 or 2"); wunit_fast_ = (int)value; return 0; }
     if (!strcmp(name, "window_per_target_fb")) { check(value >= 1, "window_per_target_fb must be positive"); wseq_per_target_fb_ = (int)value; return 0; }
+    if (!strcmp(name, "window_per_target_max")) { check(value >= 1, "window_per_target_max must be positive"); wseq_per_target_max_ = (int)value; return 0; }
     if (!strcmp(name, "window_per_target")) { check(value >= 1, "window_per_target must be positive"); wseq_per_target_ = (int)value; return 0; }
     if (!strcmp(name, "window_slots")) { window_slots_ = value != 0; return 0; }
     if (!strcmp(name, "window_groups")) { check(value >= 0 && value <= 2, "window_groups must be 0 (auto), 1 or 2"); window_groups_ = (int)value; return 0; }

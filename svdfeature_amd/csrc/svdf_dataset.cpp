@@ -124,8 +124,11 @@ Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsign
     if (auto_step_active()) {
         auto_building_ = true;
         struct Done { bool &f; ~Done() { f = false; } } done{auto_building_};
+        const bool wok = wunit_config_ok() && !user_group() && basic_fast_path_allowed();
+        if (wok && n > AUTO_PROBE_MIN && auto_probe_deep(dataset_from_triples(AUTO_PROBE_ROWS, user, item, label), n))
+            return auto_step(nullptr, true, [&]() { return wseq_from_triples(n, user, item, label); });
         Dataset *exact = dataset_from_triples(n, user, item, label);
-        return auto_step(exact, wunit_config_ok() && !user_group() && basic_fast_path_allowed(), [&]() { return wseq_from_triples(n, user, item, label); });
+        return auto_step(exact, wok, [&]() { return wseq_from_triples(n, user, item, label); });
     }
     if (!basic_fast_path_allowed()) {
         // fall back to the general representation (side tables / shared latent space / user-group trainer)
@@ -198,8 +201,11 @@ Dataset *Engine::dataset_from_pairs(long n, const unsigned *user, const unsigned
     if (auto_step_active()) {
         auto_building_ = true;
         struct Done { bool &f; ~Done() { f = false; } } done{auto_building_};
+        const bool wok = wunit_config_ok() && !user_group() && basic_fast_path_allowed();
+        if (wok && n > AUTO_PROBE_MIN && auto_probe_deep(dataset_from_pairs(AUTO_PROBE_ROWS, user, pos, neg), n))
+            return auto_step(nullptr, true, [&]() { return wseq_from_pairs(n, user, pos, neg); });
         Dataset *exact = dataset_from_pairs(n, user, pos, neg);
-        return auto_step(exact, wunit_config_ok() && !user_group() && basic_fast_path_allowed(), [&]() { return wseq_from_pairs(n, user, pos, neg); });
+        return auto_step(exact, wok, [&]() { return wseq_from_pairs(n, user, pos, neg); });
     }
     if (device_sched_ && n > 0 && fused_allowed() && !user_group() && !relaxed()) {
         // everything on the device: the three columns go up as they are, the schedule columns (lower / higher item id, signs)
@@ -389,6 +395,12 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
     if (auto_step_active() && !user_group()) {
         auto_building_ = true;
         struct Done { bool &f; ~Done() { f = false; } } done{auto_building_};
+        if (num_row > AUTO_PROBE_MIN) {
+            validate_csr_pointers(num_row, row_ptr);
+            if (wunit_config_ok() && wunit_rows_ok(0, num_row, row_ptr, feat_index) &&
+                auto_probe_deep(dataset_from_csr(AUTO_PROBE_ROWS, row_label, row_ptr, feat_index, feat_value), num_row))
+                return auto_step(nullptr, true, [&]() { return wseq_from_csr(num_row, row_label, row_ptr, feat_index, feat_value); });
+        }
         Dataset *exact = dataset_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);   // validates the pointers
         const bool ok = wunit_config_ok() && wunit_rows_ok(0, num_row, row_ptr, feat_index);
         return auto_step(exact, ok, [&]() { return wseq_from_csr(num_row, row_label, row_ptr, feat_index, feat_value); });
@@ -521,14 +533,36 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
 // dag_ms <= 2 x stream_ms: the levels are wide enough to stream, the exact pass stays (bit parity with the reference).  Otherwise the
 // data's dependency depth binds and the window step (user side exact, shared rows once per window; |dRMSE| <= 1e-4) is taken.  The
 // decision is printed once per data set and kept in counters 16 .. 20.
+static void auto_measures(const Dataset *ex, long &levels, double &unit_us, double &dag_ms, double &stream_ms) {
+    levels = (long)ex->sched.num_levels();
+    const long units = ex->kind == 3 || ex->kind == 4 ? std::max<long>(ex->num_units, 1) : std::max<long>(ex->num_row, 1);
+    unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : 4.5;
+    dag_ms = (double)levels * unit_us * 1e-3;
+    stream_ms = (double)ex->algorithmic_bytes / (0.57 * 8.0e12) * 1e3;
+}
+// Deep streams are expensive to level-schedule in full (a user-grouped rank pass of 200 M pairs has 56 M levels: 85 s on the device
+// scheduler): the first AUTO_PROBE_ROWS rows are scheduled first, and when THEY are deep by a wide margin (dag bound > 16 x the stream
+// model; both grow linearly with the row count on such streams) the window step is chosen without ever building the full schedule.
+bool Engine::auto_probe_deep(Dataset *probe, long n_full) {
+    std::unique_ptr<Dataset> p(probe);
+    long levels; double unit_us, dag_ms, stream_ms;
+    auto_measures(p.get(), levels, unit_us, dag_ms, stream_ms);
+    if (dag_ms <= 16.0 * stream_ms) return false;
+    const double scale = (double)n_full / (double)std::max<long>(p->num_row, 1);
+    auto_probe_ = AutoDecision();
+    auto_probe_.levels = (long)((double)levels * scale);
+    auto_probe_.dag_ms = dag_ms * scale;
+    auto_probe_.stream_ms = stream_ms * scale;
+    auto_probe_.decided = -1;   // "from a prefix"
+    return true;
+}
 Dataset *Engine::auto_step(Dataset *exact, bool window_ok, const std::function<Dataset *()> &build_window) {
     std::unique_ptr<Dataset> ex(exact);
     AutoDecision D;
-    D.levels = (long)ex->sched.num_levels();
-    const long units = ex->kind == 3 || ex->kind == 4 ? std::max<long>(ex->num_units, 1) : std::max<long>(ex->num_row, 1);
-    const double unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : 4.5;
-    D.dag_ms = (double)D.levels * unit_us * 1e-3;
-    D.stream_ms = (double)ex->algorithmic_bytes / (0.57 * 8.0e12) * 1e3;
+    double unit_us = 4.5;
+    const bool from_probe = !ex;
+    if (from_probe) { D = auto_probe_; D.decided = 0; }
+    else auto_measures(ex.get(), D.levels, unit_us, D.dag_ms, D.stream_ms);
     const bool deep = D.dag_ms > 2.0 * D.stream_ms;
     const char *why;
     if (!deep) { D.decided = 1; why = "exact levels kept (wide enough to stream)"; }
@@ -544,8 +578,8 @@ Dataset *Engine::auto_step(Dataset *exact, bool window_ok, const std::function<D
     }
     auto_last_ = D;
     if (!getenv("SVDF_QUIET"))
-        fprintf(stderr, "[svdfeature_amd] amd:step = auto: %ld rows, %ld conflict-free levels: dag bound %.2f ms (%.1f us per unit), stream model %.2f ms -> %s%s\n",
-                (long)out->num_row, D.levels, D.dag_ms, unit_us, D.stream_ms, why,
+        fprintf(stderr, "[svdfeature_amd] amd:step = auto: %ld rows, %s%ld conflict-free levels: dag bound %.2f ms, stream model %.2f ms -> %s%s\n",
+                (long)out->num_row, from_probe ? "extrapolated from the first 2 M rows: ~" : "", D.levels, D.dag_ms, D.stream_ms, why,
                 D.decided == 2 ? (" (" + std::to_string(D.windows) + " windows)").c_str() : "");
     return out;
 }

@@ -600,6 +600,8 @@ class Engine {
     bool wunit_inplace_build_ = false;    // set while wseq_from_csr / _from_blocks build their windows
     int wunit_fast_ = 2;                  // knob "wunit_fast": 0 = the general lane-group kernel for every shape, 1 = + the slot kernel, 2 = + one wave per unit (A/B and tests)
     int wseq_per_target_fb_ = 16;         // knob "window_per_target_fb": the same for feedback rows (instance-sized updates pushed by whole blocks)
+    int wseq_per_target_max_ = 128;       // knob "window_per_target_max": the MOST updates any shared row may meet per window (binds on skewed data only)
+    double wseq_max_ratio() const { return (double)wseq_per_target_ / (double)wseq_per_target_max_; }
     int wseq_per_target_ = 24;            // knob "window_per_target": updates a shared row meets per window when amd:window is not given
     bool single_minibatch() const { return step_minibatch_set_ && gpus_ == 1 && !multi_ && !is_peer_; }
     // the conflict DAG inside one launch per pass (svdf_stream.cpp / svdf_k_stream.hip)
@@ -622,6 +624,9 @@ class Engine {
     struct AutoDecision { int decided = 0; long levels = 0, windows = 0; double dag_ms = 0.0, stream_ms = 0.0; } auto_last_;
     bool auto_step_active() const { return step_auto_set_ && !auto_building_ && gpus_ == 1 && !multi_ && !is_peer_ && !host_only_; }
     Dataset *auto_step(Dataset *exact, bool window_ok, const std::function<Dataset *()> &build_window);
+    static constexpr long AUTO_PROBE_ROWS = 2000000, AUTO_PROBE_MIN = 8000000;
+    AutoDecision auto_probe_;
+    bool auto_probe_deep(Dataset *probe, long n_full);
     long wseq_windows(long n, const std::vector<double> &updates_per_target) const;
     Dataset *wseq_from_csr(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
     Dataset *wseq_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,

@@ -376,9 +376,12 @@ long Engine::multi_windows_for(long n, const std::vector<long> &item_count, bool
     long W = std::max<long>(1, (n + stage_window_ - 1) / stage_window_);
     if (window_set_ || n <= 0) return W;
     double s2 = 0.0;
-    for (long c : item_count) s2 += (double)c * (double)c;
+    long mx = 0;
+    for (long c : item_count) { s2 += (double)c * (double)c; mx = std::max(mx, c); }
     const double per_item = !minibatch ? (gpus_ <= 2 ? 64.0 : (gpus_ <= 4 ? 42.0 : 32.0)) : 24.0;
-    return std::max<long>(W, (long)std::ceil(s2 / (double)n / per_item));
+    // ... and no row more than window_per_target_max updates per window (skewed data: svdf_wunit.cpp, mean_updates_met)
+    const double need = std::max(s2 / (double)n / per_item, (double)mx / (double)wseq_per_target_max_);
+    return std::max<long>(W, (long)std::ceil(need));
 }
 
 // ---- resident data sets on the handle: sharded by user, cut into windows at global positions, one child per (rank, window)

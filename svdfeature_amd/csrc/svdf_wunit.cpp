@@ -425,10 +425,15 @@ long Engine::wseq_windows(long n, const std::vector<double> &updates_per_target)
 }
 
 
-static double mean_updates_met(const std::vector<long> &cnt) {   // sum c^2 / sum c: how many updates of its own target an entry meets per pass
+// How many updates of its own target an entry meets per pass: sum c^2 / sum c (the MEAN over entries, what the calibrations at the uniform
+// BASELINE sizes bound at 24 per window) -- and, for skewed data, the MAX: a row that collects far more updates in one window than the
+// mean (a Zipf-popular item: 800 where the mean is 24) has all of them computed against its window-start value and overshoots; the pass
+// diverges (NaN on Zipf(0.7) items, round 5).  max c is therefore bounded at `per_max` per window, expressed here on the mean's scale.
+static double mean_updates_met(const std::vector<long> &cnt, double per_mean_over_per_max) {
     double s1 = 0.0, s2 = 0.0;
-    for (long c : cnt) { s1 += (double)c; s2 += (double)c * (double)c; }
-    return s1 > 0.0 ? s2 / s1 : 0.0;
+    long mx = 0;
+    for (long c : cnt) { s1 += (double)c; s2 += (double)c * (double)c; mx = std::max(mx, c); }
+    return std::max(s1 > 0.0 ? s2 / s1 : 0.0, (double)mx * per_mean_over_per_max);
 }
 
 // The windows of a sequence share nothing but the caller's read-only columns: their host builds run on several threads (a quarter of the
@@ -523,7 +528,7 @@ Dataset *Engine::wseq_from_csr(long n, const float *row_label, const int64_t *ro
         for (int64_t j = row_ptr[3 * r]; j < row_ptr[3 * r + 1]; j++) { if (feat_index[j] >= (unsigned)mp_.num_global) fail("global feature index exceed setting"); cg[feat_index[j]]++; }
         for (int64_t j = row_ptr[3 * r + 2]; j < row_ptr[3 * r + 3]; j++) { if (feat_index[j] >= (unsigned)mp_.num_item) fail("item feature index exceed bound"); ci[feat_index[j]]++; }
     }
-    const long W = wseq_windows(n, {mean_updates_met(ci), mean_updates_met(cg)});
+    const long W = wseq_windows(n, {mean_updates_met(ci, wseq_max_ratio()), mean_updates_met(cg, wseq_max_ratio())});
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->kind = 8; ds->num_row = n;
     const bool inplace = wunit_inplace_ != 0;   // a window is summed in place right after its walk (wseq_train): single contributions need no slot
@@ -574,7 +579,7 @@ Dataset *Engine::wseq_from_blocks(long num_block, const int *extend_tag, const i
     }
     double m1 = 0.0, m2 = 0.0;
     for (double m : mass) { m1 += m; m2 += m * m; }
-    const long W0 = std::min<long>(std::max<long>(num_block, 1), wseq_windows(n, {mean_updates_met(ci), mean_updates_met(cg), m1 > 0.0 ? m2 / m1 : 0.0}));
+    const long W0 = std::min<long>(std::max<long>(num_block, 1), wseq_windows(n, {mean_updates_met(ci, wseq_max_ratio()), mean_updates_met(cg, wseq_max_ratio()), m1 > 0.0 ? m2 / m1 : 0.0}));
     // cuts in blocks (the rule of multi_gpu.block_window_bounds and svdf_multi.cpp): even block positions moved forward to the next
     // position where no START..END span is open
     std::vector<long> cut{0};
@@ -608,7 +613,7 @@ Dataset *Engine::wseq_from_blocks(long num_block, const int *extend_tag, const i
 Dataset *Engine::wseq_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     std::vector<long> ci((size_t)mp_.num_item, 0);
     for (long r = 0; r < n; r++) { if (item[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound"); ci[item[r]]++; }
-    const long W = wseq_windows(n, {mean_updates_met(ci)});
+    const long W = wseq_windows(n, {mean_updates_met(ci, wseq_max_ratio())});
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->kind = 8; ds->num_row = n;
     // the columns go to HBM in ONE copy each (large pageable copies run at the PCIe rate, 56 GB/s; window-sized ones at a fifth of it), the
@@ -640,7 +645,7 @@ Dataset *Engine::wseq_from_pairs(long n, const unsigned *user, const unsigned *p
         if (pos[r] >= (unsigned)mp_.num_item || neg[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound");
         ci[pos[r]]++; ci[neg[r]]++;
     }
-    const long W = wseq_windows(n, {mean_updates_met(ci)});
+    const long W = wseq_windows(n, {mean_updates_met(ci, wseq_max_ratio())});
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->kind = 8; ds->num_row = n;
     DevBuf<unsigned> d_user, d_pos, d_neg;
