@@ -580,6 +580,38 @@ def run_workload(name, a, env, steps, warmup, main_line):
         per_rank = [[float(x) for x in t_.tolist()] for t_ in allr]
         elapsed = max(pr[0] for pr in per_rank)
 
+    # ---- host cost of a launch with the device queue DRAINED: enqueue_ms_per_pass cannot tell a host-bound pass from a GPU-bound one once thousands
+    # of launches are in flight (the launch call blocks when the queue is full, so both read ~ms_per_step).  Here a short prefix of the pass
+    # (at most 256 launches: nothing can push back) is enqueued onto an idle stream and only the host side is timed.
+    host_enq = None
+    if world == 1 and not exchanging and name in ("basicmf", "pairwise"):
+        m = min(n, 4_000_000)
+        tr_main, tr = tr, make_trainer(sa, name, a, factor, local_rank, extra=contrib)   # a trainer of its own: the measured model is not trained further
+        tr.set_knob("use_graph", a.use_graph)
+        for kv in a.knob:
+            tr.set_knob(kv.split("=")[0], int(kv.split("=")[1]))
+        small = tr.dataset_from_triples(u[:m], i[:m], r[:m]) if name == "basicmf" else tr.dataset_from_pairs(u[:m], p[:m], q[:m])
+        nl = small.num_batches
+        if 0 < nl <= 4096:
+            best = None
+            for _ in range(3):
+                tr.synchronize()
+                l0 = tr.counter(1)
+                t0_ = time.perf_counter()
+                tr.train_dataset(small)
+                dt_ = time.perf_counter() - t0_
+                tr.synchronize()
+                per = dt_ / max(tr.counter(1) - l0, 1)
+                best = per if best is None else min(best, per)
+            lpp = launches / max(steps, 1)
+            host_enq = {"us_per_launch": best * 1e6, "launches_measured": nl, "launches_per_pass": lpp, "ms_per_pass_estimate": best * lpp * 1e3,
+                        "host_bound": bool(best * lpp > 0.8 * elapsed / steps),
+                        "what": "host time to enqueue one launch onto an IDLE stream (a %d-launch prefix of the pass, best of 3); x launches per pass = what the host "
+                                "needs for a pass when nothing pushes back -- well below ms_per_step = the pass is GPU-bound" % nl}
+        small.close()
+        tr.close()
+        tr = tr_main
+
     # ---- one more pass with a HIP event after every phase (outside the timed region): stream time per phase of the exchange
     phase_ms = None
     if exchanging and (name in ("basicmf", "pairwise") or minibatch):
@@ -737,6 +769,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
                              ("native: the rank's own RCCL communicator driven from C++ (svdf_rccl.cpp: ncclAllReduce / ncclSend + ncclRecv on a side stream, ordered by "
                               "HIP events, one C call per hand-over); torch.distributed only carries the unique id, the final block broadcasts and the timing reductions")
                              if use_native else "torch.distributed",
+                "world_size_reported": (dist.get_world_size() if dist is not None else 1),   # what the process group (RCCL with backend nccl) says, not what --gpus asked for
                 "contributions": contrib_fmt if minibatch else None,
                 "step": "stratified" if stratified else ("minibatch" if minibatch else "levels"), "windows": nwin, "parts": parts,
                 "handoffs_per_pass": a.chunks * world * bpr if (stratified and world > 1) else 0,
@@ -744,7 +777,8 @@ def run_workload(name, a, env, steps, warmup, main_line):
                                     int(tr.item_delta_count() * 4 // max(world * bpr, 1)),
                 "updates_per_item_per_window": per_item / nwin},
             "phase_ms": phase_ms,
-            "enqueue_ms_per_pass": enqueue_s * 1e3 / steps,   # host time until a pass is enqueued (launches are asynchronous): small against ms_per_step = not host-bound; close to it = host-bound OR the device queue pushed back (thousands of launches in flight)
+            "enqueue_ms_per_pass": enqueue_s * 1e3 / steps,   # host time until a pass is enqueued; under queue back-pressure (thousands of launches in flight) this reads ~ms_per_step whoever is the limit: host_enqueue is the field that tells
+            "host_enqueue": host_enq,
             # N > 1: the spread of the ranks' own clocks over the timed region, the aggregate roofline (sum of the ranks' algorithmic bytes
             # over the contract's max-over-ranks time against N x 8 TB/s) and what DESIGN.md's model expects for this line
             "per_rank_ms": None if (per_rank is None or world == 1) else {
@@ -1514,7 +1548,7 @@ def main():
         }
         for k in ("rmse_test_after_run", "passes_before_rmse", "rmse_sequential_reference", "rmse_minus_sequential", "exchange", "phase_ms",
                   "per_rank_ms", "roofline_aggregate", "model_ms",
-                  "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound", "launch_model", "init_model", "enqueue_ms_per_pass"):
+                  "pair_accuracy_test_after_run", "mean_margin_test_after_run", "dag_bound", "launch_model", "init_model", "enqueue_ms_per_pass", "host_enqueue"):
             if m.get(k) is not None:
                 out[k] = m[k]
         if world > 1:
@@ -1643,6 +1677,24 @@ def main():
                 store.wait(["single_process_done"], datetime.timedelta(seconds=a.secondary_timeout + 30))
             except Exception:
                 pass
+    if out is not None and world > 1 and a.workload == "basicmf":
+        # north_star's step -- user shards + an RCCL all-reduce of the item-side sums every window -- at the TOP level of every N > 1 line, whichever
+        # schedule the preflight made the main line (the first hardware run decides between them from these two entries)
+        keep = ("value", "unit", "ms_per_step", "per_rank_ms", "roofline_aggregate", "phase_ms", "model_ms", "rmse_test_after_run", "rmse_sequential_reference",
+                "rmse_minus_sequential", "passes_before_rmse")
+        if (out.get("exchange") or {}).get("step") == "minibatch":
+            src, where = out, "the main line of this run"
+        else:
+            src, where = secondary.get("allreduce_minibatch") or {}, "secondary.allreduce_minibatch of this run (3 passes after 1 warm-up, same data, same ranks)"
+        ns = {k: src[k] for k in keep if src.get(k) is not None}
+        if ns:
+            xs = src.get("exchange") or {}
+            ns.update({"step": "window-minibatch step + all-reduce (SUM) of the per-item sums every window", "measured_as": where, "n_gpus": world,
+                       "world_size_reported": xs.get("world_size_reported"), "backend": xs.get("backend", backend), "windows": xs.get("windows"),
+                       "bytes_per_window": xs.get("bytes_per_window"), "transport": xs.get("transport")})
+            out["allreduce_step"] = ns
+        else:
+            out["allreduce_step"] = {"error": "not measured in this run (secondary skipped or failed: see secondary / secondary_error)"}
     if wd is not None:
         wd.disarm()
     if out is not None and not secondary:

@@ -141,3 +141,45 @@ def test_guard_the_path_auto_picks_is_not_slower_than_the_cpu_reference():
             assert t.counter(16) == 2, "auto must leave the exact levels on a 99 % sequential stream"
     print("pairs/s: CPU (%s, 1 thread) %.3g, exact levels %.3g, auto (window step) %.3g" % (kind, cpu_rate, rates[None], rates["auto"]))
     assert rates["auto"] >= cpu_rate, (rates, cpu_rate)
+
+
+def test_a_hot_row_bounds_the_window_and_the_step_stays_finite():
+    """round 5: the window rule bounded the MEAN number of updates a shared row meets per window (sum c^2 / sum c at 24); on Zipf-popular items the hot
+    row then met hundreds, all computed against its window-start value, and the pass diverged to NaN at the configs[1] size.  Now no row meets more
+    than window_per_target_max (128) updates per window."""
+    nu, ni, n = 50000, 2000, 2000000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=11, zipf=True)
+    top = int(np.bincount(i, minlength=ni).max())
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
+    t = _trainer(conf, extra=[("amd:step", "minibatch")])
+    ds = t.dataset_from_triples(u, i, r)
+    assert ds.kind == 8 and ds.num_batches >= -(-top // 128), (ds.num_batches, top)
+    for _ in range(3):
+        t.train_dataset(ds)
+    e = _trainer(conf)
+    de = e.dataset_from_triples(u, i, r)
+    for _ in range(3):
+        e.train_dataset(de)
+    for name in ("W_item", "W_user", "i_bias"):
+        a, b = t.view(name), e.view(name)
+        assert np.isfinite(a).all(), name
+        assert np.abs(a - b).max() < 0.05, (name, float(np.abs(a - b).max()))
+    # the knob moves the bound
+    t2 = _trainer(conf, extra=[("amd:step", "minibatch")])
+    t2.set_knob("window_per_target_max", 32)
+    assert t2.dataset_from_triples(u, i, r).num_batches >= -(-top // 32)
+
+
+def test_streams_beyond_the_probe_size_are_judged_on_their_first_rows():
+    """a deep stream of more than 8 M rows: auto schedules the first 2 M only (a full level schedule of a user-grouped rank pass of 200 M pairs has
+    56 M levels and takes 85 s to build), extrapolates, and builds the window sequence straight away"""
+    nu, ni = 943, 1682
+    cols = _grouped_pairs(nu, ni, 9000, 3)
+    conf = cases.conf_with(cases.PAIR_CONF, num_user=nu, num_item=ni, num_factor=128)
+    t = _trainer(conf, active=3, extra=[("amd:step", "auto")])
+    ds = t.dataset_from_pairs(*cols)
+    n = len(cols[0])
+    assert n > 8_000_000 and ds.kind == 8 and t.counter(16) == 2
+    assert 0.5 * n < t.counter(17) < 1.2 * n   # extrapolated level count of a ~99 % sequential stream
+    t.train_dataset(ds)
+    t.synchronize()

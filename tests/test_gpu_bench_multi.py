@@ -50,6 +50,10 @@ def test_two_ranks_one_command_yields_every_multi_gpu_number():
     ar = line["secondary"]["allreduce_minibatch"]
     assert ar["exchange"]["step"] == "minibatch" and ar["value"] > 0 and abs(ar["rmse_minus_sequential"]) <= 1e-4
     assert set(("compute", "pack", "allreduce", "unpack")) <= set(ar["phase_ms"])
+    # north_star's step sits at the TOP level of every N > 1 line, with the ranks' own clocks and the world size the group reports
+    ns = line["allreduce_step"]
+    assert ns["value"] == ar["value"] and ns["n_gpus"] == 2 and ns["world_size_reported"] == 2 and ns["measured_as"].startswith("secondary.allreduce_minibatch")
+    assert ns["per_rank_ms"]["max"] > 0 and abs(ns["rmse_minus_sequential"]) <= 1e-4 and x["world_size_reported"] == 2
     # the same two steps with the direct exchange between the processes (IPC-mapped buffers; on this box the ranks share the device)
     for key, step in (("allreduce_minibatch_ipc", "minibatch"), ("stratified_ipc", "stratified")):
         ip = line["secondary"][key]
@@ -69,6 +73,7 @@ def test_a_broken_ring_preflight_falls_back_to_the_all_reduce_step_and_says_so(h
                         "--no-cpu-baseline", "--preflight-timeout", "45"], {hook: "0"})
     x = line["exchange"]
     assert x["ladder_rung"] == 1 and x["step"] == "minibatch"
+    assert line["allreduce_step"]["measured_as"] == "the main line of this run" and line["allreduce_step"]["value"] == line["value"]
     assert x["fallback"] and x["fallback"][0]["attempt"] == 0
     assert line["value"] > 0 and abs(line["rmse_minus_sequential"]) <= 1e-4
 
