@@ -131,6 +131,9 @@ void Engine::set_param(const char *name, const char *val) {  // apex_svd_base.h:
         contrib_bf16_ = !strcmp(val, "bf16");
     }
     if (!strcmp(name, "amd:window")) { stage_window_ = std::max<long>(1, atol(val)); window_set_ = true; }
+    // the data-driven window rule of the window / N-rank steps (svdf_wunit.cpp, svdf_multi.cpp): updates a shared row may meet per window, mean and most
+    if (!strcmp(name, "amd:window_per_target")) { check(atoi(val) >= 1, "amd:window_per_target must be positive"); wseq_per_target_ = atoi(val); }
+    if (!strcmp(name, "amd:window_per_target_max")) { check(atoi(val) >= 1, "amd:window_per_target_max must be positive"); wseq_per_target_max_ = atoi(val); }
     if (multi_) for (int d = 1; d < gpus_; d++) rank_engine(d)->set_param(name, val);
     if (!strcmp(name, "feature_user")) name_feat_user_ = val;
     if (!strcmp(name, "feature_item")) name_feat_item_ = val;

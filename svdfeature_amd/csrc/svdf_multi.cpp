@@ -327,8 +327,43 @@ void Engine::multi_flush(HostCSR &src) {
     // A rank may throw inside a window (a HIP / RCCL error reported through RankPool::run).  The windows before it are trained and
     // exchanged: whatever happens, the staged rows are dropped here, so that a later flush() (or the destructor's) cannot train them twice.
     struct DropStaged { HostCSR &s; long total; long done = 0; ~DropStaged() { if (done < total) fprintf(stderr, "svdfeature_amd: an exchange window failed: %ld staged rows were trained, %ld dropped\n", done, total - done); s.clear(); } } drop{src, n};
-    for (long w0 = 0; w0 < n; w0 += stage_window_) {
-        const long w1 = std::min(n, w0 + stage_window_);
+    // Without amd:window the cut is made from the DATA, on line (the reference's CLI hands instances over one at a time, nothing about the
+    // pass is known in advance): a window closes when an item row has met window_per_target_max updates of its own, or the mean over
+    // the window's entries (sum c^2 / sum c) passes the calibrated per-window figure of the step, or after stage_window rows.  The same
+    // rule as the resident data sets' (multi_windows_for), which see the whole pass; on ML-100K (943 x 1682, top item 495 of 90 570
+    // ratings) it cuts a round into ~13 windows where the fixed default was ONE and needed a hand-set amd:window to keep the contract.
+    std::vector<int> wcnt;
+    std::vector<unsigned> wtouched;
+    if (!window_set_) wcnt.assign((size_t)mp_.num_item, 0);
+    // (the level scheme's round-2 figures -- 64 / 42 / 32 by rank count -- were calibrated on uniform synthetic data; on ML-100K they leave
+    // +2.2e-4 after 40 rounds at 4 and 8 ranks, so the staged path bounds both steps by the same figure)
+    // HALF the resident data sets' figure: on ML-100K through the reference's CLI (tools/contract_ml100k.py, 2 / 4 / 8 ranks, both steps, 5 and 40
+    // rounds) 24 leaves up to +1.0e-4, 12 at most +5.3e-5 (profiles/r05_contract_ml100k.txt)
+    const double per_item = std::max(1.0, 0.5 * (double)wseq_per_target_);
+    auto next_cut = [&](long w0) {
+        const long hard = std::min(n, w0 + stage_window_);
+        if (window_set_) return hard;
+        double s1 = 0.0, s2 = 0.0;
+        long w1 = w0;
+        for (; w1 < hard; w1++) {
+            const int *p = &src.row_ptr[(size_t)3 * w1];
+            bool full = false;
+            for (int j = p[2]; j < p[3]; j++) {
+                const unsigned it = src.feat_index[(size_t)j];
+                if (it >= (unsigned)mp_.num_item) continue;   // reported by the rank that trains the row
+                int &c = wcnt[it];
+                if (c == 0) wtouched.push_back(it);
+                s2 += 2.0 * c + 1.0; s1 += 1.0; c++;
+                if (c >= wseq_per_target_max_) full = true;
+            }
+            if (full || (s1 > 0.0 && s2 / s1 > per_item)) { w1++; break; }
+        }
+        for (unsigned it : wtouched) wcnt[it] = 0;
+        wtouched.clear();
+        return std::max(w1, w0 + 1);
+    };
+    for (long w0 = 0, w1 = 0; w0 < n; w0 = w1) {
+        w1 = next_cut(w0);
         drop.done = w0;
         if (multi_minibatch_allowed() && rows_are_triples(src, w0, w1)) {
             std::vector<std::vector<unsigned>> cu((size_t)N), ci((size_t)N);
