@@ -120,6 +120,21 @@ def item_block_bounds(num_item, world):
     return [(int(num_item) * b) // world for b in range(world + 1)]
 
 
+PER_ITEM_MAX = 128.0   # the most updates ANY item row may meet per window (svdf_wunit.cpp: window_per_target_max; calibrated on Zipf(0.7) items: 512 diverges)
+
+
+def stratum_num_windows(items, lo, nblk, per_item):
+    """windows of one stratum: `per_item` updates per item of the block on average -- over the block's ids for uniform catalogues (the
+    round-3 rule), over the stratum's ENTRIES (sum c^2 / sum c) when popular items dominate -- and never more than PER_ITEM_MAX for any single
+    item (round 5: with the id-average alone the schedule diverged to NaN on Zipf(0.7) items at the configs[2] size)."""
+    m = len(items)
+    if m == 0:
+        return 1
+    c = np.bincount(np.asarray(items, dtype=np.int64) - int(lo), minlength=int(nblk)).astype(np.float64)
+    need = max(m / float(nblk) / float(per_item), float((c * c).sum()) / float(m) / (2.0 * float(per_item)), float(c.max()) / PER_ITEM_MAX)
+    return max(1, int(np.ceil(need)))
+
+
 def stratum_windows(user, item, label, rank, world, step, num_item, per_item=32.0, blocks_per_rank=1):
     """STRATIFIED schedule (DSGD-style): the instances of stratum (user block `rank`, item block (rank * P + step) % (world * P)) of one
     chunk, in file order, cut into windows of at most `per_item` updates per item of the block (P = blocks_per_rank).  Strata of one step
@@ -134,7 +149,7 @@ def stratum_windows(user, item, label, rank, world, step, num_item, per_item=32.
         m &= (np.asarray(user) % world) == rank
     su, si, sr = user[m], item[m], label[m]
     nblk = max(bounds[b + 1] - bounds[b], 1)
-    nwin = max(1, int(np.ceil(len(sr) / nblk / float(per_item))))
+    nwin = stratum_num_windows(si, bounds[b], nblk, per_item)
     cuts = [(len(sr) * w) // nwin for w in range(nwin + 1)]
     return [(su[cuts[w]:cuts[w + 1]], si[cuts[w]:cuts[w + 1]], sr[cuts[w]:cuts[w + 1]]) for w in range(nwin)]
 
@@ -349,7 +364,7 @@ def stratified_plan_all_ranks(user, item, label, world, chunks, num_item, per_it
                 blk = (rank * P + t) % B
                 nblk = max(int(bounds[blk + 1] - bounds[blk]), 1)
                 m = int(b_ - a)
-                nwin = max(1, int(np.ceil(m / nblk / float(per_item))))
+                nwin = stratum_num_windows(si[a:b_], bounds[blk], nblk, per_item)
                 cuts = [a + (m * w) // nwin for w in range(nwin + 1)]
                 steps.append([(su[cuts[w]:cuts[w + 1]], si[cuts[w]:cuts[w + 1]], sr[cuts[w]:cuts[w + 1]]) for w in range(nwin)])
             plans[rank].append(steps)

@@ -1,5 +1,4 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/r05f
-
-
-timeout 1500 python -m pytest tests/test_gpu_native_multi.py tests/test_gpu_dropin_cli.py tests/test_gpu_window.py tests/test_gpu_bench_multi.py -x -q 2>&1 | grep -v amdgpu.ids | tail -5
+SVDF_QUIET=1 timeout 2400 python tools/contract_seeds.py 0 2,8 --zipf 0.7 --per-item 24 --checks 3,10 2> gpurun_out/r05f/contract_zipf.err | tee gpurun_out/r05f/contract_zipf.txt
+tail -3 gpurun_out/r05f/contract_zipf.err

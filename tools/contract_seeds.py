@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--per-item", type=float, default=32.0)
     ap.add_argument("--checks", default="3,10", help="passes after which the held-out RMSE is taken")
     ap.add_argument("--skip-allreduce", action="store_true")
+    ap.add_argument("--zipf", type=float, default=0.0, help="> 0: items Zipf-distributed with this exponent (benchlib/orders.py: the skew of demo/basicMF/ua.base is ~0.7) instead of uniform")
+    ap.add_argument("--per-item-max", type=float, default=128.0, help="all-reduce step: the most updates ANY item may meet per window (svdf_wunit.cpp: window_per_target_max)")
     ap.add_argument("--contrib", choices=["fp32", "bf16"], default="fp32", help="amd:contrib of the window-minibatch trainers")
     a = ap.parse_args()
     import torch
@@ -53,7 +55,13 @@ def main():
         print(json.dumps(kw), flush=True)
     for seed in [int(x) for x in a.seeds.split(",")]:
         t0 = time.time()
-        u, i, r = bench.synth_triples(n + 1_000_000, a.users, a.items, 12345 + seed)
+        if a.zipf > 0:
+            import types
+            from benchlib import orders
+            orders.ZIPF_EXPONENT = a.zipf
+            u, i, r = orders.synth_zipf_triples(types.SimpleNamespace(Planted=bench.Planted), n + 1_000_000, a.users, a.items, 4321 + seed)
+        else:
+            u, i, r = bench.synth_triples(n + 1_000_000, a.users, a.items, 12345 + seed)
         tu, ti, tl = u[n:n + 200000], i[n:n + 200000], r[n:n + 200000]
         u, i, r = u[:n], i[:n], r[:n]
         test = sa.CSRData.from_triples(tu, ti, tl)
@@ -70,7 +78,8 @@ def main():
         out(seed=seed, scheme="sequential", rmse={str(k): v for k, v in seq.items()})
         # ---- all-reduce window-minibatch step: one rank plays all of them
         if not a.skip_allreduce:
-            nwin = max(1, int(np.ceil(n / a.items / a.per_item)))
+            cnt_i = np.bincount(i, minlength=a.items).astype(np.float64)
+            nwin = max(1, int(np.ceil(max(float((cnt_i * cnt_i).sum() / max(cnt_i.sum(), 1.0)) / a.per_item, float(cnt_i.max()) / a.per_item_max))))
             t = trainer()
             ad = HipShard(t, torch, dev, minibatch=True)
             ad.set_wire_half(True)
