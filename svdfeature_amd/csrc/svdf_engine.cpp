@@ -752,7 +752,7 @@ void Engine::train_dataset(Dataset *ds) {
     const Schedule &sc = ds->sched;
     check(!lazy_decay() || ds->kind == 1 || ds->kind == 4 || (ds->kind == 3 && ds->num_simple_units == 0),
           "train_dataset: the dataset was scheduled before lazy decay (reg_method/reg_global >= 4) was selected");
-    if (ds->kind == 2 && chain_width_ > 0 && !ds->d_level_ptr_ok && sc.num_levels() >= 4) {   // the level boundaries for chained launches: once, outside any capture
+    if ((ds->kind == 2 || ds->kind == 0) && chain_width_ > 0 && !ds->d_level_ptr_ok && sc.num_levels() >= 4) {   // the level boundaries for chained launches: once, outside any capture
         ds->d_level_ptr.upload(sc.level_ptr.data(), sc.level_ptr.size(), stream_);
         HIPCHECK(hipStreamSynchronize(stream_));
         ds->d_level_ptr_ok = true;
@@ -763,7 +763,24 @@ void Engine::train_dataset(Dataset *ds) {
             stream_train(ds);
         } else if (ds->kind == 0) {
             BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
-            for (size_t l = 0; l < sc.num_levels(); l++) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
+            // runs of NARROW levels (the tail of a pass over Zipf-popular items) through one launch per run, everything else level by level
+            const size_t L = sc.num_levels();
+            const long cw = std::min<long>(chain_width_, 128);   // one round of the chained workgroup: 16 waves x 8 instances
+            int64_t chained = 0;
+            const bool can_chain = cw > 0 && ds->d_level_ptr_ok && launch_basicmf_chain(P, S, nullptr, 0, 0, stream_);
+            for (size_t l = 0; l < L;) {
+                size_t e = l;
+                if (can_chain) while (e < L && sc.level_ptr[e + 1] - sc.level_ptr[e] <= cw) e++;
+                if (e >= l + 4) {
+                    (void)launch_basicmf_chain(P, S, ds->d_level_ptr.p, (long)l, (long)e, stream_);
+                    chained += (int64_t)(e - l);
+                    l = e;
+                    continue;
+                }
+                const size_t stop = std::max(e, l + 1);
+                for (; l < stop; l++) launch_basicmf(P, S, sc.level_ptr[l], sc.level_ptr[l + 1], groups_per_wave_, block_threads_, stream_);
+            }
+            ds->chained_levels = chained;
         } else if (ds->kind == 5) {
             // window-minibatch step, first half: the users' exact walks; the item side is only read, its would-be change goes to the
             // contribution slots that window_delta_pack sums (svdf_k_window.hip)

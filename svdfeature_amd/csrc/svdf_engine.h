@@ -498,7 +498,7 @@ class Engine {
     bool device_init_ = true;                       // knob "device_init": rand_init on the device (svdf_k_init.hip)
     int device_init_margin_log2_ = 46;              // knob "device_init_margin_log2": values closer than 2^-this (relative) to a float rounding boundary go to the host libm
     int64_t n_init_reports_ = 0, n_init_draws_ = 0, n_chained_levels_ = 0;
-    long chain_width_ = 96;                         // knob "chain_width": levels of at most this many instances are walked in runs inside ONE launch by one workgroup (0 = off)
+    long chain_width_ = 128;                        // knob "chain_width": levels of at most this many instances are walked in runs inside ONE launch by one workgroup (0 = off)
     bool fewrow_fast_ = true;                       // knob "fewrow_fast": specialised few-row kernel (svdf_k_fewrow.hip)
     // columns that are already in HBM (file order) -> level schedule + level-sorted copies
     Dataset *dataset_fewrow_on_device(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);

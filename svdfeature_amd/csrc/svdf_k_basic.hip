@@ -136,34 +136,37 @@ __global__ __launch_bounds__(256) void k_basicmf(const DevParams P, const BasicS
 // lane by lane, so that the dot product's hand-over is ONE row_shr:T add per step for all of them (dot_slots, svdf_device.h) and
 // every wave instruction serves V times the instances.  Same additions in the same order as the lane-group scan; at k = 64
 // (LANES = 8, V = 2, G = 4: 32 instances per wave) the per-instance instruction count drops by 40 %.
-template <int LANES, int V, int G>
-__global__ __launch_bounds__(256) void k_basicmf_slots(const DevParams P, const BasicSchedule S, long begin, long end) {
-    constexpr int T = 16 / LANES;      // instances interleaved in one DPP row
-    constexpr int IPS = 64 / LANES;    // instances per row set
-    constexpr int K = 4 * LANES * V;
+// the schedule records of one wave's G x 64 / LANES instances starting at position w0 of the level [begin, end)
+template <int G> struct BasicRecs { bool valid[G]; unsigned ur[G], ir[G]; float label[G]; };
+template <int LANES, int G>
+__device__ __forceinline__ BasicRecs<G> basicmf_slots_recs(const DevParams &P, const BasicSchedule &S, long begin, long end, long w0) {
+    constexpr int T = 16 / LANES, IPS = 64 / LANES;
     const int lane = threadIdx.x & 63;
-    long tile = blockIdx.x;
-    if (P.xcd_remap) tile = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    const long wave = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const long w0 = begin + wave * (long)(G * IPS);
-    if (w0 >= end) return;
-    const int m = (lane & 15) / T;
     const int gslot = (lane >> 4) * T + (lane & (T - 1));
-    const int pitch = P.pitch;
-
-    bool valid[G];
-    unsigned ur[G], ir[G];
-    float label[G], bu[G], bi[G];
-    float4 p[G][V], q[G][V];
+    BasicRecs<G> R;
 #pragma unroll
     for (int g = 0; g < G; g++) {
         const long s = w0 + (long)g * IPS + gslot;
-        valid[g] = s < end;
-        const long sc = valid[g] ? s : begin;
-        ur[g] = P.user_off + S.user[sc];
-        ir[g] = P.item_off + S.item[sc];
-        label[g] = S.label[sc];
+        R.valid[g] = s < end;
+        const long sc = R.valid[g] ? s : begin;
+        R.ur[g] = P.user_off + S.user[sc];
+        R.ir[g] = P.item_off + S.item[sc];
+        R.label[g] = S.label[sc];
     }
+    return R;
+}
+template <int LANES, int V, int G>
+__device__ __forceinline__ void basicmf_slots_apply(const DevParams &P, const BasicRecs<G> &R) {
+    constexpr int T = 16 / LANES;      // instances interleaved in one DPP row
+    constexpr int K = 4 * LANES * V;
+    const int lane = threadIdx.x & 63;
+    const int m = (lane & 15) / T;
+    const int pitch = P.pitch;
+    const bool (&valid)[G] = R.valid;
+    const unsigned (&ur)[G] = R.ur, (&ir)[G] = R.ir;
+    const float (&label)[G] = R.label;
+    float bu[G], bi[G];
+    float4 p[G][V], q[G][V];
 #pragma unroll
     for (int g = 0; g < G; g++) {
 #pragma unroll
@@ -216,6 +219,43 @@ __global__ __launch_bounds__(256) void k_basicmf_slots(const DevParams P, const 
             P.bias[ir[g]] = nbi;
         }
     }
+}
+template <int LANES, int V, int G>
+__global__ __launch_bounds__(256) void k_basicmf_slots(const DevParams P, const BasicSchedule S, long begin, long end) {
+    long tile = blockIdx.x;
+    if (P.xcd_remap) tile = (long)(blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const long wave = tile * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const long w0 = begin + wave * (long)(G * (64 / LANES));
+    if (w0 >= end) return;
+    basicmf_slots_apply<LANES, V, G>(P, basicmf_slots_recs<LANES, G>(P, S, begin, end, w0));
+}
+// DEEP, NARROW dependency graphs (round 5: ratings with Zipf-popular items -- the hottest item's ratings are ONE chain, 973 K levels at the
+// configs[1] size, 97 % of them narrower than 128 instances): ONE workgroup of 16 waves walks a RUN of narrow levels inside one launch,
+// level l's instances, a workgroup barrier, level l + 1 -- the form of k_fewrow_slots_chain (svdf_k_fewrow.hip) for the contract kernel.  The
+// waves share the CU's vector L1, so what one of them stored before the barrier is what the others load after it.  Same instances in the
+// same level order, same arithmetic: the same bits as one launch per level (tests/test_gpu_chain.py).
+template <int LANES, int V>
+__global__ __launch_bounds__(1024) void k_basicmf_slots_chain(const DevParams P, const BasicSchedule S, const long *level_ptr, long l0, long l1) {
+    // every level of the run fits ONE round of the workgroup (the caller chains levels of at most 16 x 64 / LANES instances; more row sets per
+    // wave lengthen the level in proportion: 2.9 / 3.3 / 4.7 us per level at 1 / 2 / 4 sets).  Requesting level l + 1's records ahead of level
+    // l's rows was built and measured: slower (3.5 against 2.8 s per pass on Zipf(0.7) items at the configs[1] size, profiles/r05_zipf_chain.txt).
+    constexpr int IPW = 64 / LANES;
+    const long w = threadIdx.x >> 6;
+    for (long l = l0; l < l1; l++) {
+        const long begin = level_ptr[l], end = level_ptr[l + 1];
+        const long w0 = begin + w * IPW;
+        if (w0 < end) basicmf_slots_apply<LANES, V, 1>(P, basicmf_slots_recs<LANES, 1>(P, S, begin, end, w0));
+        __syncthreads();
+    }
+}
+// a run of narrow levels [l0, l1) in one launch; false when the configuration has no chained form (the caller launches level by level)
+bool launch_basicmf_chain(const DevParams &P, const BasicSchedule &S, const long *d_level_ptr, long l0, long l1, hipStream_t st) {
+    const bool slots_cfg = P.basic_i8 && S.uval == nullptr && P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 &&
+                           P.user_nonnegative == 0 && P.u_rng.n == 0 && P.i_rng.n == 0 && P.store_mode == 0 && P.k == 64;
+    if (!slots_cfg) return false;
+    if (d_level_ptr == nullptr) return true;   // query
+    hipLaunchKernelGGL((k_basicmf_slots_chain<8, 2>), dim3(1), dim3(1024), 0, st, P, S, d_level_ptr, l0, l1);
+    return true;
 }
 
 template <int LPI, bool UNITVAL>

@@ -18,6 +18,7 @@ int max_fast_path_factor();   // widest row of the register-tiled kernels (k_bas
 
 // every launch below processes ONE conflict-free batch [begin,end) on stream st
 void launch_basicmf(const DevParams &P, const BasicSchedule &S, long begin, long end, int groups_per_wave, int block_threads, hipStream_t st);
+bool launch_basicmf_chain(const DevParams &P, const BasicSchedule &S, const long *d_level_ptr, long l0, long l1, hipStream_t st);
 // few-row fused kernel: instances with <= max_nu (1|2) user ids and <= max_ni (1|2) item ids
 void launch_fused(const DevParams &P, const FusedSchedule &S, int max_nu, int max_ni, long begin, long end, int groups_per_wave,
                   int block_threads, hipStream_t st);

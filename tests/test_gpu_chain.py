@@ -69,3 +69,33 @@ def test_chained_pass_equals_the_oracle():
     o.update_batch(sa.pairs_as_csr(*cols))
     for n in ("W_user", "W_item", "i_bias"):
         assert np.array_equal(got[n].view(np.uint32), o.view(n).view(np.uint32)), n
+
+
+@pytest.mark.parametrize("nu,ni,n,width", [(3000, 40, 60000, 96), (500, 8, 20000, 1 << 20), (20000, 300, 200000, 16)])
+def test_chained_levels_of_plain_ratings_equal_the_level_by_level_pass(nu, ni, n, width):
+    """round 5: the contract kernel's chained form (k_basicmf_slots_chain): ratings over few / Zipf-popular items have a long tail of narrow levels"""
+    u, i, r = cases.planted_triples(n, nu, ni, seed=nu + ni, zipf=True)
+    cols = (u.astype(np.uint32), i.astype(np.uint32), r)
+    a, levels, chained0 = _run(cols, nu, ni, 64, 0, triples=True)
+    b, levels_b, chained = _run(cols, nu, ni, 64, width, triples=True)
+    assert levels == levels_b and chained0 == 0 and chained > 0
+    for n_ in a:
+        assert np.array_equal(a[n_].view(np.uint32), b[n_].view(np.uint32)), n_
+
+
+def test_chained_ratings_pass_equals_the_oracle():
+    from oracle import oracle
+    oracle.build()
+    nu, ni, n = 800, 12, 15000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=4, zipf=True)
+    got, _, chained = _run((u.astype(np.uint32), i.astype(np.uint32), r), nu, ni, 64, 96, passes=1, triples=True)
+    assert chained > 0
+    o = oracle.OracleTrainer("port", 0, 0)
+    o.seed(10)
+    for kk, v in cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64):
+        o.set_param(kk, v)
+    o.init_model()
+    o.init_trainer()
+    o.update_batch(sa.CSRData.from_triples(u, i, r))
+    for n_ in ("W_user", "W_item", "u_bias", "i_bias"):
+        assert np.array_equal(got[n_].view(np.uint32), o.view(n_).view(np.uint32)), n_
