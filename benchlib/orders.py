@@ -72,7 +72,7 @@ def _unit_latency_us(ctx, tr, one):
     return ev.elapsed_ms(e0, e1) * 1e3 / 200
 
 
-EXACT_BUDGET_S = 4.0     # an exact pass longer than this is measured on a prefix of the stream (its rate does not improve with size: levels grow with n)
+EXACT_BUDGET_S = 2.5     # an exact pass longer than this is measured on a prefix of the stream (its rate does not improve with size: levels grow with n)
 PROBE_ROWS = 2_000_000
 
 
@@ -214,7 +214,7 @@ def run_orders(ctx, sa, a, device):
     case["stream"] = "1 M users uniform x 100 K items Zipf(%.2f) in random file order; top item %.2f %% of the ratings (demo/basicMF/ua.base: 0.55 %%)" % (
         ZIPF_EXPONENT, 100.0 * cnt.max() / n)
     if not a.no_cpu_baseline:
-        S = min(n, a.cpu_sample)
+        S = min(n, a.cpu_sample // 2)
         tr = ctx.make_trainer(sa, "basicmf", a, 64, device)
         case["cpu_baseline"], case["parity"] = ctx.cpu_baseline_and_parity(sa, "basicmf", a, 64, tr, ("triples", u[:S], i[:S], r[:S]), n, ctx.log)
         tr.close()
