@@ -293,7 +293,9 @@ int svdf_synchronize(svdf_trainer *t);
  * 3 staged-window flushes, 4/5/6 launches of the basicMF / general / few-row fused kernel, 7 rank passes sampled on the device,
  * 8..12 amd:gpus handles (exchanges, RCCL, distinct devices, window steps, exchange path), 13 / 14 the last svdf_init_model on the
  * device: values the host libm decided (next to a float rounding boundary) / rand() draws consumed (0 = the host loop ran), 15 conflict-free
- * levels executed inside chained launches */
+ * levels executed inside chained launches, 16 .. 20 the decision of `amd:step = auto` for the data set built last (16: 0 none, 1 exact levels
+ * kept, 2 window step chosen, 3 exact kept because the window step does not cover the configuration / the rows; 17 conflict-free levels;
+ * 18 / 19 dag bound and stream model in microseconds; 20 windows), 21 passes issued as one launch by the in-launch DAG executor */
 int64_t svdf_counter(svdf_trainer *t, int what);
 /* tuning knobs (not part of the reference surface; none changes a result bit): "stage_window" (instances staged
  * before an automatic flush), "async_flush" (background scheduling of full windows), "groups_per_wave",
@@ -314,8 +316,12 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  * meets per window when `amd:window` is not set: these two DO change the opt-in step's windows, hence its result); the one-off builders:
  * "device_init" (0 = SVDModel::rand_init as the reference's host loop instead of svdf_k_init.hip; same model, same rand() position),
  * "device_init_margin_log2" (values closer than 2^-this to a float rounding boundary are recomputed with the host libm; default 46),
- * "chain_width" (levels of at most this many instances are walked in runs inside ONE launch by one workgroup, k = 128 few-row data sets; default 96,
- * 0 = one launch per level; same bits),
+ * "chain_width" (levels of at most this many instances are walked in runs inside ONE launch by one workgroup: k = 128 few-row data sets and, round 5,
+ * the k = 64 contract kernel (at most 128 there); default 128, 0 = one launch per level; same bits),
+ * "stream_exec" (1 = a resident basicMF k = 64 pass as ONE persistent launch over tiles with exact predecessor waits, svdf_k_stream.hip; same bits,
+ * measured slower than the level loop: off), "stream_waves" / "stream_spin_limit" (its persistent waves / polls before a wait gives up),
+ * "window_per_target_max" (the MOST updates any shared row may meet per window of the opt-in / N-rank step; default 128; changes that step's windows),
+ * "ipc_spin_limit" (polls before a flag wait of the IPC exchange gives up),
  * "device_load" (0 = svdf_load_model through a host copy of the model instead of file -> pinned chunks -> HBM; same model),
  * "device_window" (0 = window data sets of ratings / pairs regrouped on the host; same arrays), "wseq_build_threads" (host threads building the
  * user-unit windows of a one-GPU window sequence; default 32, capped by a quarter of the host's hardware threads).  Returns 0 if the knob exists.
