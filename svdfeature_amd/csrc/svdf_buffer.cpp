@@ -14,12 +14,8 @@
 // apex_svd_data.cpp:403,426,516).
 #include "svdf_engine.h"
 #include "svdf_kernels.h"
+#include "svdf_internal.h"
 #include <sys/stat.h>
-#define HIPCHECK(call)                                                                           \
-    do {                                                                                         \
-        hipError_t e_ = (call);                                                                  \
-        if (e_ != hipSuccess) fail(std::string("HIP error: ") + hipGetErrorString(e_) + " at " #call); \
-    } while (0)
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -34,7 +30,6 @@
 namespace svdf {
 namespace {
 
-inline void check(bool ok, const char *msg) { if (!ok) fail(msg); }
 
 struct MappedFile {
     const char *p = nullptr;
@@ -276,15 +271,28 @@ Dataset *Engine::dataset_from_rank_buffer_file(const char *path) {
     check(path != nullptr, "dataset_from_rank_buffer_file: null path");
     check(user_group(), "rank-pair input needs the user-group format (format_type = 1), svd_feature.cpp:129-133");
     // (an amd:gpus handle shards the pass: the blocks below go through multi_dataset_from_blocks; the all-in-HBM form is one engine's)
-    if (device_rank_ && device_sched_ && !rank_prefetch_ && !host_only_ && (!multi_ || in_multi_scope())) {
+    // `amd:step = auto`: the pass is re-drawn every round, the DEPTH of its dependency graph is a property of the file (user-grouped pairs): the
+    // first pass goes through dataset_from_blocks' auto hook (level schedule, decision), the decision is kept for the later passes of this file --
+    // exact: the all-in-HBM form below; window: the drawn blocks straight into the window builder.
+    const bool auto_on = auto_step_active();
+    const bool auto_known = auto_on && auto_rank_path_ == path && auto_rank_decision_ != 0;
+    if (device_rank_ && device_sched_ && !rank_prefetch_ && !host_only_ && (!multi_ || in_multi_scope()) && (!auto_on || (auto_known && auto_rank_decision_ != 2))) {
         Dataset *ds = rank_pass_device(path);
         if (ds) return ds;
     }
     UserGroupArrays g;
     if (!(device_rank_ && !rank_prefetch_ && !host_only_ && rank_pass_device_general(path, g))) rank_pass(path, g);
-    return dataset_from_blocks((long)g.tag.size(), g.tag.data(), g.fb_ptr.data(), g.fb_index.data(), g.fb_value.data(),
-                               g.block_row_ptr.data(), g.rows.label.data(), g.rows.row_ptr.data(), g.rows.index.data(),
-                               g.rows.value.data());
+    if (auto_known && auto_rank_decision_ == 2 && wunit_config_ok() &&
+        wunit_blocks_ok((long)g.tag.size(), g.tag.data(), g.fb_ptr.data(), g.fb_index.data(), g.block_row_ptr.data(), g.rows.row_ptr.data(), g.rows.index.data())) {
+        flush();
+        return wseq_from_blocks((long)g.tag.size(), g.tag.data(), g.fb_ptr.data(), g.fb_index.data(), g.fb_value.data(), g.block_row_ptr.data(),
+                                g.rows.label.data(), g.rows.row_ptr.data(), g.rows.index.data(), g.rows.value.data());
+    }
+    Dataset *ds = dataset_from_blocks((long)g.tag.size(), g.tag.data(), g.fb_ptr.data(), g.fb_index.data(), g.fb_value.data(),
+                                      g.block_row_ptr.data(), g.rows.label.data(), g.rows.row_ptr.data(), g.rows.index.data(),
+                                      g.rows.value.data());
+    if (auto_on && !auto_known) { auto_rank_path_ = path; auto_rank_decision_ = auto_last_.decided; }
+    return ds;
 }
 
 // The device form of the same pass: the file's rows live in HBM (uploaded once per file), every pass draws

@@ -626,6 +626,8 @@ class Engine {
     Dataset *auto_step(Dataset *exact, bool window_ok, const std::function<Dataset *()> &build_window);
     static constexpr long AUTO_PROBE_ROWS = 2000000, AUTO_PROBE_MIN = 8000000;
     AutoDecision auto_probe_;
+    std::string auto_rank_path_;          // rank-pair input: the candidate file whose passes the decision below was taken for
+    int auto_rank_decision_ = 0;
     bool auto_probe_deep(Dataset *probe, long n_full);
     long wseq_windows(long n, const std::vector<double> &updates_per_target) const;
     Dataset *wseq_from_csr(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);

@@ -183,3 +183,30 @@ def test_streams_beyond_the_probe_size_are_judged_on_their_first_rows():
     assert 0.5 * n < t.counter(17) < 1.2 * n   # extrapolated level count of a ~99 % sequential stream
     t.train_dataset(ds)
     t.synchronize()
+
+
+def test_rank_pair_passes_from_a_candidate_file_follow_the_decision_of_their_first_pass(tmp_path):
+    """input_type = 2 (the reference's own generator order, re-drawn every round): the first pass goes through the level schedule and decides, the later
+    passes of the same file go straight to the chosen builder; the pairs drawn are the same as without the key (same libc rand() stream)."""
+    from svdfeature_amd import data as D
+    src = str(tmp_path / "train.buffer")
+    D.write_ugroup_buffer(src, cases.rank_blocks(600, 60, 50, 0, 901, side_user=False, max_fb=0))
+    conf = [(k, v) for k, v in cases.RANK_E2E_CONF if k not in ("num_global", "wd_global")] + [("num_global", "0")]
+    out = {}
+    for step in (None, "auto"):
+        t = _trainer(conf + ([("amd:step", step)] if step else []), active=3, fmt=1)
+        kinds, rows = [], 0
+        for r in range(3):
+            t.set_round(r)
+            ds = t.dataset_from_rank_buffer_file(src)
+            kinds.append(ds.kind)
+            rows += ds.info(0)
+            t.train_dataset(ds)
+            t.finish_round()
+            ds.close()
+        out[step] = (kinds, rows, {n: t.view(n).copy() for n in ("W_user", "W_item", "i_bias")}, t.counter(16))
+    assert out["auto"][0] == [8, 8, 8] and out["auto"][3] == 2, out["auto"][0]
+    assert 8 not in out[None][0] and out[None][1] == out["auto"][1] and out[None][1] > 1000   # the same draws either way
+    for n in out[None][2]:
+        a, b = out[None][2][n], out["auto"][2][n]
+        assert np.isfinite(b).all() and np.abs(a - b).max() < 0.05, n
