@@ -65,6 +65,13 @@ int svdf_init_model(svdf_trainer *t);
  * and reads/writes the leading 4-byte SVDTypeParam itself (svd_feature.cpp:165-190). */
 int svdf_load_model(svdf_trainer *t, FILE *fi);
 int svdf_save_model(svdf_trainer *t, FILE *fo);
+/* EXTENSION for loops that own their files (integration/svdf_train_bulk.c): the model file written BESIDE the next pass.  _begin snapshots the model
+ * in HBM (ordered behind everything enqueued so far) and returns; a writer thread streams the snapshot into `fo` (the same bytes svdf_save_model
+ * would have written at that moment); training may go on.  _end joins the writer (the caller then closes the file).  One save in flight per
+ * handle; amd:gpus handles, host-only handles and the bilinear solver write synchronously inside _begin.  The reference's protocol
+ * (ISVDTrainer::save_model returns with the file complete, svd_feature.cpp:184-191) is svdf_save_model above. */
+int svdf_save_model_begin(svdf_trainer *t, FILE *fo);
+int svdf_save_model_end(svdf_trainer *t);
 /* ISVDTrainer::init_trainer (apex_svd.h:64; apex_svd_base.h:151-173, 499-503) */
 int svdf_init_trainer(svdf_trainer *t);
 /* ISVDTrainer::set_round / finish_round (apex_svd.h:72,77).  finish_round flushes staged work. */

@@ -58,15 +58,30 @@ static const char *get(const char *name, const char *dflt) {
     for (int i = 0; i < np_; i++) if (!strcmp(names[i], name)) r = vals[i];   /* later pairs win (command line after the file) */
     return r;
 }
-static int save(svdf_trainer *t, const char *folder, int round, const unsigned char mtype[4]) {   /* svd_feature.cpp:184-191 */
+/* svd_feature.cpp:184-191, with the write BESIDE the next pass: svdf_save_model_begin snapshots the model in HBM and returns, a writer thread streams the
+ * snapshot into the file; the file of round r is completed (svdf_save_model_end, fclose) before round r + 1's is opened.  The same NNNN.model bytes. */
+static FILE *pending_fo = NULL;
+static int save_end(svdf_trainer *t) {
+    if (!pending_fo) return 0;
+    int rc = svdf_save_model_end(t);
+    if (fclose(pending_fo) != 0) rc = -1;
+    pending_fo = NULL;
+    return rc;
+}
+static int save(svdf_trainer *t, const char *folder, int round, const unsigned char mtype[4]) {
     char path[1024];
+    if (save_end(t) != 0) return -1;
     snprintf(path, sizeof(path), "%s/%04d.model", folder, round);
     FILE *fo = fopen(path, "wb");
     if (!fo) return -1;
     fwrite(mtype, 1, 4, fo);
-    int rc = svdf_save_model(t, fo);
-    fclose(fo);
-    return rc;
+    if (getenv("SVDF_BULK_SYNC_SAVE")) {   /* A/B: the reference's protocol, the file complete before the next pass starts */
+        int rc = svdf_save_model(t, fo);
+        fclose(fo);
+        return rc;
+    }
+    pending_fo = fo;
+    return svdf_save_model_begin(t, fo);
 }
 
 int main(int argc, char **argv) {
@@ -106,9 +121,10 @@ int main(int argc, char **argv) {
         if (input_type == 2) { svdf_dataset_destroy(ds); ds = NULL; }
         save(t, folder, r, mtype);
     }
+    if (save_end(t) != 0) { fprintf(stderr, "cannot complete the last model file\n"); return 3; }
     if (ds) svdf_dataset_destroy(ds);
     printf("svdf_train_bulk: %d rounds, %ld instances, %s\n", num_round, trained, svdf_version());
-    if (num_round >= 2) printf("svdf_train_bulk: seconds per round (rounds 2..%d, model save included): %.6f\n", num_round, (now_s() - t_second) / (num_round - 1));
+    if (num_round >= 2) printf("svdf_train_bulk: seconds per round (rounds 2..%d, model files written beside the next pass): %.6f\n", num_round, (now_s() - t_second) / (num_round - 1));
     svdf_destroy(t);
     return 0;
 }

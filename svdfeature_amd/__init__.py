@@ -67,6 +67,8 @@ def load_library():
     lib.svdf_set_round.argtypes = [P, C.c_int]
     lib.svdf_load_model.argtypes = [P, C.c_void_p]
     lib.svdf_save_model.argtypes = [P, C.c_void_p]
+    lib.svdf_save_model_begin.argtypes = [P, C.c_void_p]
+    lib.svdf_save_model_end.argtypes = [P]
     lib.svdf_update_csr.argtypes = [P, C.c_float, C.c_int, C.c_int, C.c_int, _u32p, _f32p]
     lib.svdf_predict_csr.argtypes = lib.svdf_update_csr.argtypes
     lib.svdf_predict_csr.restype = C.c_float
@@ -316,6 +318,33 @@ class Trainer:
 
     def finish_round(self):
         self._ok(self.lib.svdf_finish_round(self.h))
+
+    def save_model_begin(self, path, with_type_header=True):
+        """svdf_save_model_begin: the model as of NOW goes to `path` on a writer thread while training continues; save_model_end() joins it and closes the file."""
+        assert getattr(self, "_async_fo", None) is None, "one asynchronous save at a time"
+        fo = _libc.fopen(str(path).encode(), b"wb")
+        if not fo:
+            raise SvdfError("can not open file \"%s\"" % path)
+        if with_type_header:
+            hdr = (C.c_char * 4).from_buffer_copy(self.mtype)
+            _libc.fwrite(hdr, 1, 4, C.c_void_p(fo))
+        self._async_fo = fo
+        try:
+            self._ok(self.lib.svdf_save_model_begin(self.h, fo))
+        except Exception:
+            _libc.fclose(fo)
+            self._async_fo = None
+            raise
+
+    def save_model_end(self):
+        fo = getattr(self, "_async_fo", None)
+        if fo is None:
+            return
+        try:
+            self._ok(self.lib.svdf_save_model_end(self.h))
+        finally:
+            _libc.fclose(fo)
+            self._async_fo = None
 
     def save_model(self, path, with_type_header=True):
         """Caller-side protocol of svd_feature.cpp:184-191: fopen, 4-byte SVDTypeParam, save_model(fo)."""

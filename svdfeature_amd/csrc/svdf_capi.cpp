@@ -57,6 +57,8 @@ void svdf_seed(unsigned seed) { srand(seed); }
 int svdf_init_model(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->init_model(); return 0; }) }
 int svdf_load_model(svdf_trainer *t, FILE *fi) { SVDF_GUARD(-1, { t->e->load_model(fi); return 0; }) }
 int svdf_save_model(svdf_trainer *t, FILE *fo) { SVDF_GUARD(-1, { t->e->save_model(fo); return 0; }) }
+int svdf_save_model_begin(svdf_trainer *t, FILE *fo) { SVDF_GUARD(-1, { t->e->save_model_begin(fo); return 0; }) }
+int svdf_save_model_end(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->save_model_end(); return 0; }) }
 int svdf_init_trainer(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->init_trainer(); return 0; }) }
 int svdf_set_round(svdf_trainer *t, int nround) { SVDF_GUARD(-1, { t->e->set_round(nround); return 0; }) }
 int svdf_finish_round(svdf_trainer *t) { SVDF_GUARD(-1, { t->e->finish_round(); return 0; }) }

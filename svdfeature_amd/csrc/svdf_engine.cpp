@@ -84,7 +84,15 @@ Engine::Engine(TypeParam mtype, int device) : mtype_(mtype) {
 }
 
 
+void Engine::save_pipe_free(SavePipe &sp) {
+    for (int b = 0; b < 2; b++) {
+        if (sp.pin[b]) (void)hipHostFree(sp.pin[b]);
+        if (sp.ev[b]) (void)hipEventDestroy(sp.ev[b]);
+        sp.pin[b] = nullptr; sp.ev[b] = nullptr;
+    }
+}
 Engine::~Engine() {
+    if (save_async_.th.joinable()) save_async_.th.join();   // a writer still streaming the snapshot: let it finish, the caller owns the file
     if (multi_ && !host_only_ && stream_) { try { flush(); } catch (...) {} }
     multi_.reset();
     if (!host_only_ && device_ >= 0) (void)hipSetDevice(device_);
@@ -104,10 +112,10 @@ Engine::~Engine() {
         (void)hipStreamSynchronize(stream_);
         if (pred_pin_) (void)hipHostFree(pred_pin_);
         if (stream_err_) (void)hipHostFree(stream_err_);
-        for (int b = 0; b < 2; b++) {
-            if (save_pin_[b]) (void)hipHostFree(save_pin_[b]);
-            if (save_ev_[b]) (void)hipEventDestroy(save_ev_[b]);
-        }
+        save_pipe_free(save_pipe_);
+        save_pipe_free(save_async_.pipe);
+        if (save_async_.ready) (void)hipEventDestroy(save_async_.ready);
+        if (save_async_.st) (void)hipStreamDestroy(save_async_.st);
         if (owns_stream_) (void)hipStreamDestroy(stream_);
     }
 }

@@ -293,6 +293,8 @@ class Engine {
     void init_model();
     void load_model(FILE *fi);
     void save_model(FILE *fo);
+    void save_model_begin(FILE *fo);   // the file written beside the next pass (svdf_model.cpp)
+    void save_model_end();
     void init_trainer();
     void set_round(int nround);
     void finish_round();
@@ -678,9 +680,16 @@ class Engine {
     int64_t n_instances_ = 0, n_launches_ = 0, n_batches_ = 0, n_flushes_ = 0;
     static constexpr size_t PRED_PIN_WORDS = 1 << 16;   // predict of a few rows: pinned, device-mapped staging (rows in, predictions out)
     unsigned *pred_pin_ = nullptr;
-    float *save_pin_[2] = {nullptr, nullptr};   // save_model: pinned double buffer of the device -> file pipeline
-    hipEvent_t save_ev_[2] = {nullptr, nullptr};
-    void dev_to_file(FILE *fo, const float *dsrc, long rows, long cols, long pitch);
+    // save_model: pinned double buffer of the device -> file pipeline, one for the synchronous path and one for the writer thread of the asynchronous one
+    static constexpr size_t SAVE_PIN_FLOATS = (size_t)8 << 20;
+    struct SavePipe { float *pin[2] = {nullptr, nullptr}; hipEvent_t ev[2] = {nullptr, nullptr}; hipStream_t st = nullptr; };
+    SavePipe save_pipe_;
+    struct SaveAsync { DevBuf<float> W, bias; std::vector<float> g; hipEvent_t ready = nullptr; hipStream_t st = nullptr; SavePipe pipe; std::thread th;
+                       std::string error; bool active = false; } save_async_;
+    void save_pipe_init(SavePipe &sp, hipStream_t st);
+    static void save_pipe_free(SavePipe &sp);
+    void dev_to_file(SavePipe &sp, FILE *fo, const float *dsrc, long rows, long cols, long pitch);
+    void write_model_from_device(SavePipe &sp, FILE *fo, const float *W, const float *bias, const float *g);
     void write_model_from_device(FILE *fo);
     int64_t ns_flush_ = 0, ns_model_ = 0;   // host-side time accounting (SVDF_PROFILE=1 prints it)
     int64_t n_device_rank_passes_ = 0;

@@ -180,3 +180,34 @@ def test_load_model_shape_checks_survive(tmp_path):
     b.load_model(f0)                    # and the handle takes a good file afterwards
     b.init_trainer()
     assert np.array_equal(a.view("W_user").view(np.uint32), b.view("W_user").view(np.uint32))
+
+
+def test_the_model_file_written_beside_the_next_pass_equals_the_synchronous_one(tmp_path):
+    """svdf_save_model_begin / _end (round 5): the snapshot taken at _begin is what the file holds, whatever trains meanwhile"""
+    import cases
+    nu, ni, n = 30000, 3000, 600000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=8)
+    for fmt, conf in ((0, cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64, num_global=5)),):
+        t = sa.Trainer(fmt, 0)
+        t.seed(10)
+        for k, v in conf:
+            t.set_param(k, str(v))
+        t.init_model()
+        t.init_trainer()
+        ds = t.dataset_from_triples(u, i, r)
+        t.train_dataset(ds)
+        a, b, c = str(tmp_path / "sync.model"), str(tmp_path / "async.model"), str(tmp_path / "after.model")
+        t.save_model(a)
+        t.save_model_begin(b)
+        for _ in range(3):
+            t.train_dataset(ds)          # the model moves on while the writer streams the snapshot
+        t.save_model_end()
+        t.save_model(c)
+        assert open(a, "rb").read() == open(b, "rb").read()
+        assert open(a, "rb").read() != open(c, "rb").read()
+        t.save_model_begin(b)
+        fo = sa._libc.fopen(c.encode(), b"wb")
+        assert t.lib.svdf_save_model_begin(t.h, fo) != 0 and "has not been ended" in t.lib.svdf_last_error().decode()   # one save in flight per handle
+        sa._libc.fclose(fo)
+        t.save_model_end()
+        t.save_model_end()               # idempotent
