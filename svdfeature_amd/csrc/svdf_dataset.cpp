@@ -142,6 +142,7 @@ Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsign
         ptr[(size_t)3 * n] = 2 * n;
         return dataset_from_csr(n, label, ptr.data(), idx.data(), val.data());
     }
+    if (Dataset *pv = pivot_dataset_from_triples(n, user, item, label)) return pv;   // hot rows: runs of their ratings as walker units (svdf_pivot.cpp)
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = n; ds->kind = 0;
     const long nb_ = mp_.no_user_bias ? 1 : 2;
@@ -536,7 +537,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
 static void auto_measures(const Dataset *ex, long &levels, double &unit_us, double &dag_ms, double &stream_ms) {
     levels = (long)ex->sched.num_levels();
     const long units = ex->kind == 3 || ex->kind == 4 ? std::max<long>(ex->num_units, 1) : std::max<long>(ex->num_row, 1);
-    unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : 4.5;
+    unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : (ex->kind == 9 ? 30.0 : 4.5);   // kind 9: a level is a run of up to 64 ratings of a hot row
     dag_ms = (double)levels * unit_us * 1e-3;
     stream_ms = (double)ex->algorithmic_bytes / (0.57 * 8.0e12) * 1e3;
 }
@@ -616,6 +617,7 @@ void Engine::disown(Dataset *ds) {
 // into the wire buffer; after the all-reduce window_delta_apply adds the sum on every rank.  Replaces what one instance
 void Engine::predict_dataset(Dataset *ds, float *out) {
     check(ds && ds->owner == this, "predict_dataset: dataset belongs to another trainer");
+    check(ds->kind != 9, "predict_dataset: a data set with hot rows keeps no file order (its ratings are regrouped into units); score rows with svdf_predict_csr_batch");
     check(ds->kind != 7 && ds->kind != 8, "predict_dataset: window data sets are training sets (their rows are regrouped by user); score rows with svdf_predict_csr_batch / svdf_predict_block or a level-scheduled data set of the same rows");
     check(ds->kind != 5 && ds->kind != 6, "predict_dataset: window / multi-GPU data sets are training sets (their rows are regrouped: there is no file order to report predictions in); svdf_eval_dataset gives their squared error, svdf_predict_csr_batch scores rows (routed to the owner of each user)");
     check(ds->sched_signature == schedule_signature(),
@@ -709,7 +711,7 @@ void Engine::eval_dataset(Dataset *ds, float scale, double *sum_sq, int64_t *cou
         BasicSchedule S{ucol, ds->item.p, ds->label.p, nullptr, nullptr};
         launch_predict_basic(P, S, n, w_out_.p, stream_);
         labels = ds->label.p;
-    } else if (ds->kind == 0) {
+    } else if (ds->kind == 0 || ds->kind == 9) {   // (kind 9: the columns hold the cold ratings, then the units' rows: svdf_pivot.cpp)
         BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
         launch_predict_basic(P, S, n, w_out_.p, stream_);
         labels = ds->label.p;   // same (level) order as the predictions

@@ -751,6 +751,13 @@ void Engine::train_dataset(Dataset *ds) {
         sample_counter_ += (unsigned)ds->num_row;
         return;
     }
+    if (ds->kind == 9) {   // ratings with hot rows: cold ratings level by level, runs of a hot row's ratings as walker units (svdf_pivot.cpp)
+        check(pivot_config_ok(), "train_dataset: the data set was built for the symmetric basicMF configuration (svdf_pivot.cpp); the configuration changed since");
+        pivot_train(ds);
+        n_instances_ += ds->num_row;
+        sample_counter_ += (unsigned)ds->num_row;
+        return;
+    }
     if (ds->kind == 5) {   // the trainer-owned contribution scratch is sized BEFORE anything is issued (and never inside a stream capture)
         d_contrib_.reserve((size_t)ds->win_slots * (size_t)pitch_);
         d_cbias_.reserve((size_t)ds->win_slots);

@@ -227,7 +227,7 @@ class Ranker;
 struct Dataset {
     Engine *owner = nullptr;
     long num_row = 0;
-    int kind = 0;                 // 0 basicMF fused kernel, 1 general sparse kernel, 2 few-row fused kernel, 3 SVD++ units, 4 multi-level units,
+    int kind = 0;                 // 0 basicMF fused kernel, 1 general sparse kernel, 2 few-row fused kernel, 3 SVD++ units, 4 multi-level units, 9 ratings with hot rows (svdf_pivot.cpp),
                                   // 5 window-minibatch (user-grouped instances of one exchange window, svdf_k_window.hip)
     // kind 5: user records in launch order, user-grouped columns (item / label / uval / ival above), contribution slots, item segments
     DevBuf<WinUser> win_urec;
@@ -237,6 +237,11 @@ struct Dataset {
     long win_item_lo = 0, win_item_hi = -1;   // kind 5: lowest / highest item id with an instance in the window (-1: none)
     DevBuf<long> d_level_ptr;     // kind 2: the level boundaries in HBM, uploaded when a run of narrow levels is first chained (k_fewrow_slots_chain)
     bool d_level_ptr_ok = false;
+    // kind 9: hot rows walked as units (svdf_pivot.cpp): sched.level_ptr = the cold ratings' level boundaries (user / item / label above),
+    // pv_unit_ptr = the units' (unitdev.xunits in launch order, their rows in unitdev)
+    std::vector<long> pv_unit_ptr;
+    bool pv_item_pivot = false;
+    long pv_cold = 0, pv_hot_rows = 0;
     // the tile plan of the in-launch DAG executor (svdf_stream.cpp), built on first use when the knob stream_exec is on
     DevBuf<uint2> st_tile_hdr;
     DevBuf<unsigned> st_pred[3], st_done;
@@ -606,6 +611,14 @@ class Engine {
     double wseq_max_ratio() const { return (double)wseq_per_target_ / (double)wseq_per_target_max_; }
     int wseq_per_target_ = 24;            // knob "window_per_target": updates a shared row meets per window when amd:window is not given
     bool single_minibatch() const { return step_minibatch_set_ && gpus_ == 1 && !multi_ && !is_peer_; }
+    // exact passes over data with hot rows: runs of a hot row's ratings as walker units (svdf_pivot.cpp)
+    int pivot_exec_ = 1;                  // knob "pivot_exec"
+    int pivot_run_ = 64, pivot_run_long_ = 512;   // knobs "pivot_run" / "pivot_run_long": ratings per unit at most, among cold levels / beyond them
+    int pivot_min_ = 4096;                // knob "pivot_min": a row with at least this many ratings in the data set is hot
+    int64_t n_pivot_passes_ = 0;
+    bool pivot_config_ok() const;
+    Dataset *pivot_dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
+    void pivot_train(Dataset *ds);
     // the conflict DAG inside one launch per pass (svdf_stream.cpp / svdf_k_stream.hip)
     int stream_exec_ = 0;                 // knob "stream_exec"
     int stream_num_cu_ = 0;

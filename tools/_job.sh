@@ -1,19 +1,23 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
-mkdir -p gpurun_out/r05h /tmp/bulk
-gcc -std=gnu99 -O2 -Iinclude integration/svdf_train_bulk.c -o /tmp/bulk/svdf_train_bulk -Lsvdfeature_amd -lsvdfeature_amd -Wl,-rpath,$PWD/svdfeature_amd
-python - <<'PY'
-import sys, numpy as np
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
-import bench
-from svdfeature_amd import data as D
+mkdir -p gpurun_out/r05i
+timeout 900 python -m pytest tests/test_gpu_pivot.py -x -q 2>&1 | grep -v amdgpu.ids | grep -E "passed|failed|Error" | head
+cat > /tmp/z.py <<'PY'
+import sys, time, types
+import numpy as np
+sys.path.insert(0, "."); import bench
+from benchlib import orders
 import svdfeature_amd as sa
-u, i, r = bench.synth_triples(100_000_000, 1_000_000, 100_000, 12345)
-D.write_csr_buffer("/tmp/bulk/train.buffer", sa.CSRData.from_triples(u, i, r))
-open("/tmp/bulk/run.conf", "w").write("\n".join("%s = %s" % kv for kv in [("base_score", "3"), ("learning_rate", "0.005"), ("wd_item", "0.004"), ("wd_user", "0.004"), ("num_item", "100000"), ("num_user", "1000000"), ("num_global", "0"), ("num_factor", "64"), ("active_type", "0"), ("buffer_feature", '"train.buffer"'), ("model_out_folder", '"./"')]) + "\n")
+n = 100_000_000
+a = types.SimpleNamespace(users=1_000_000, items=100_000, factor=64, globals=0)
+u, i, r = orders.synth_zipf_triples(types.SimpleNamespace(Planted=bench.Planted), n, a.users, a.items, 4321)
+for run, long_, pmin in ((64, 64, 4096), (64, 512, 4096), (64, 2048, 4096), (32, 512, 4096), (128, 1024, 4096), (64, 512, 1024)):
+    t = bench.make_trainer(sa, "basicmf", a, 64, 0)
+    t.set_knob("pivot_run", run); t.set_knob("pivot_run_long", long_); t.set_knob("pivot_min", pmin)
+    t0 = time.time(); ds = t.dataset_from_triples(u, i, r); b = time.time() - t0
+    ms = []
+    for _ in range(2):
+        t.synchronize(); t0 = time.perf_counter(); t.train_dataset(ds); t.synchronize(); ms.append((time.perf_counter() - t0) * 1e3)
+    print("pivot_run %d / %d, pivot_min %d: build %.1f s, %.1f ms per pass = %.1f M inst/s, %d levels" % (run, long_, pmin, b, min(ms), n / min(ms) / 1e3, ds.num_batches), flush=True)
+    ds.close(); t.close()
 PY
-cd /tmp/bulk
-for mode in async sync async sync async sync; do
-  rm -f /tmp/bulk/0*.model; sync
-  if [ $mode = sync ]; then export SVDF_BULK_SYNC_SAVE=1; else unset SVDF_BULK_SYNC_SAVE; fi
-  echo "== $mode"; ./svdf_train_bulk run.conf num_round=8 2>&1 | grep "seconds per round"
-done | tee "${GRAFT_REPO_ROOT:-/root/repo}/gpurun_out/r05h/bulk_save_ab.txt"
+SVDF_QUIET=1 timeout 1200 python /tmp/z.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r05i/zipf_pivot_runs.txt
