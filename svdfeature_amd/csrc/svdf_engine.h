@@ -613,8 +613,8 @@ class Engine {
     bool single_minibatch() const { return step_minibatch_set_ && gpus_ == 1 && !multi_ && !is_peer_; }
     // exact passes over data with hot rows: runs of a hot row's ratings as walker units (svdf_pivot.cpp)
     int pivot_exec_ = 1;                  // knob "pivot_exec"
-    int pivot_run_ = 64, pivot_run_long_ = 512;   // knobs "pivot_run" / "pivot_run_long": ratings per unit at most, among cold levels / beyond them
-    int pivot_min_ = 4096;                // knob "pivot_min": a row with at least this many ratings in the data set is hot
+    int pivot_run_ = 256, pivot_run_long_ = 256;   // knobs "pivot_run" / "pivot_run_long": ratings per unit at most, among cold levels / beyond them (a longer tail cap measured slower)
+    int pivot_min_ = 2048;                // knob "pivot_min": a row with at least this many ratings in the data set is hot
     int64_t n_pivot_passes_ = 0;
     bool pivot_config_ok() const;
     Dataset *pivot_dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);

@@ -1,6 +1,6 @@
 // svdf_pivot.cpp -- exact passes over data with HOT rows (knob "pivot_exec"): ratings whose items (or users) are
 // Zipf-popular have as many conflict-free levels as the hottest row has ratings -- every update of that row reads what the previous one
-// wrote -- and a level costs a kernel boundary plus its rows' round trip however few instances it holds.  Here up to pivot_run (64; 512 in the tail) consecutive
+// wrote -- and a level costs a kernel boundary plus its rows' round trip however few instances it holds.  Here up to pivot_run (256) consecutive
 // ratings of a hot row become ONE unit: a wave keeps the hot ("pivot") row in registers and walks the unit's ratings in file order, the
 // partner rows through memory -- the user-unit walker the engine already has for SVD++ users (k_svdpp_wave, svdf_k_wave.hip), fed with
 // units that carry no feedback list.  When the hot side is the ITEMS the walker runs on TRANSPOSED parameters (user / item offsets, decays
@@ -48,9 +48,10 @@ Dataset *Engine::pivot_dataset_from_triples(long n, const unsigned *user, const 
     const unsigned *pcol = item_pivot ? item : user, *qcol = item_pivot ? user : item;
     const long NP = item_pivot ? NI : NU;
     // ---- one scan in file order: levels of the cold ratings, units of the hot ones
-    // ratings per unit at most: a unit is one level, and a level lasts as long as its longest unit -- short runs (pivot_run, 64) while cold ratings
-    // share the levels, long ones (pivot_run_long, 512) beyond the horizon no cold rating can reach: a cold row has fewer than pivot_min ratings,
-    // and levels through such rows stay below ~1.7 x their largest count (1 872 levels for at most 1 136 ratings per item on the uniform stream)
+    // ratings per unit at most: a unit is one level, and a level lasts as long as its longest unit.  pivot_run (256) while cold ratings share the
+    // levels, pivot_run_long beyond the horizon no cold rating can reach (a cold row has fewer than pivot_min ratings, and levels through such rows
+    // stay below ~1.7 x their largest count).  Measured on Zipf(0.7) items at the configs[1] size (profiles/r05_zipf_pivot.txt): 64 / 64 398 ms per
+    // pass, 128 / 128 348, 192 / 192 332, 256 / 256 327 (pivot_min 2048), 128 / 1024 422: a longer cap in the tail is SLOWER, both default to 256.
     const int cold_horizon = 2 * pivot_min_;
     struct Open { int level = 0, len = 0, unit = -1, cap = 0; };
     std::vector<int> hot_slot((size_t)NP, -1);
@@ -58,11 +59,13 @@ Dataset *Engine::pivot_dataset_from_triples(long n, const unsigned *user, const 
     for (long r = 0; r < NP; r++) if (cp[(size_t)r] >= pivot_min_) hot_slot[(size_t)r] = nhot++;
     std::vector<Open> open((size_t)nhot);
     std::vector<int> lastp((size_t)NP, 0), lastq((size_t)(item_pivot ? NU : NI), 0);
+    std::vector<int> plainp((size_t)NP, 0), plainq((size_t)(item_pivot ? NU : NI), 0);   // the plain level schedule of the same stream, for the comparison below
     std::vector<int> lvl((size_t)n), unit_of((size_t)n, -1);
     std::vector<int> unit_level, unit_len;
-    int max_level = 0;
+    int max_level = 0, plain_levels = 0;
     for (long t = 0; t < n; t++) {
         const unsigned pv = pcol[t], qv = qcol[t];
+        { const int pl = 1 + std::max(plainp[pv], plainq[qv]); plainp[pv] = pl; plainq[qv] = pl; plain_levels = std::max(plain_levels, pl); }
         const int hs = hot_slot[pv];
         if (hs < 0) {
             const int l = 1 + std::max(lastp[pv], lastq[qv]);
@@ -86,6 +89,17 @@ Dataset *Engine::pivot_dataset_from_triples(long n, const unsigned *user, const 
         max_level = std::max(max_level, l);
     }
     const long nunit = (long)unit_level.size();
+    {   // Units pay only where a hot row's chain is what makes the schedule deep.  A level of this data set lasts as long as its longest unit
+        // (~5 us + 0.3 us per rating), a plain level ~3 us: when hot and clustered rows interleave (ratings sorted by user over Zipf items: the
+        // partner rows are busy, units are cut after a few ratings) the unit form is SLOWER than plain levels -- measured 33 s against ~15 s per
+        // pass of 20 M such ratings -- and the plain schedule is built instead.
+        std::vector<int> longest((size_t)max_level + 1, 0);
+        for (long j = 0; j < nunit; j++) longest[(size_t)unit_level[(size_t)j]] = std::max(longest[(size_t)unit_level[(size_t)j]], unit_len[(size_t)j]);
+        double t_units = 0.0;
+        for (int l = 1; l <= max_level; l++) t_units += longest[(size_t)l] > 0 ? 5.0 + 0.3 * longest[(size_t)l] : 3.0;
+        const double t_plain = 3.0 * (double)plain_levels;
+        if (!(t_units < 0.6 * t_plain)) return nullptr;
+    }
     // ---- cold ratings level-sorted (stable), units level-sorted (stable), a unit's rows contiguous in file order
     const int L = max_level;
     std::vector<long> cptr((size_t)L + 2, 0), uptr((size_t)L + 2, 0);
