@@ -249,7 +249,7 @@ def measure_traffic(name, a, log, deadline=None):
                "--workload", name, "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--pmc", "off", "--secondary", "", "--users", str(a.users), "--items", str(a.items)] + size_args
         if a.factor and name == a.workload:   # secondary workloads run at their own configured width (128), like in this process
             cmd += ["--factor", str(a.factor)]
-        env = dict(os.environ, TMPDIR="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp", SVDF_BENCH_PMC_CHILD="1")
         env.pop("SVDF_BENCH_DATA_CACHE_WRITE", None)
         left = 600 if deadline is None else deadline - time.time()
         if left < 20:
@@ -584,7 +584,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
     # of launches are in flight (the launch call blocks when the queue is full, so both read ~ms_per_step).  Here a short prefix of the pass
     # (at most 256 launches: nothing can push back) is enqueued onto an idle stream and only the host side is timed.
     host_enq = None
-    if world == 1 and not exchanging and name in ("basicmf", "pairwise"):
+    if world == 1 and not exchanging and name in ("basicmf", "pairwise") and not os.environ.get("SVDF_BENCH_PMC_CHILD"):   # (not in the --pmc children: their launches are counted)
         m = min(n, 4_000_000)
         tr_main, tr = tr, make_trainer(sa, name, a, factor, local_rank, extra=contrib)   # a trainer of its own: the measured model is not trained further
         tr.set_knob("use_graph", a.use_graph)

@@ -534,10 +534,10 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
 // dag_ms <= 2 x stream_ms: the levels are wide enough to stream, the exact pass stays (bit parity with the reference).  Otherwise the
 // data's dependency depth binds and the window step (user side exact, shared rows once per window; |dRMSE| <= 1e-4) is taken.  The
 // decision is printed once per data set and kept in counters 16 .. 20.
-static void auto_measures(const Dataset *ex, long &levels, double &unit_us, double &dag_ms, double &stream_ms) {
+static void auto_measures(const Dataset *ex, long &levels, double &unit_us, double &dag_ms, double &stream_ms, int pivot_run = 256) {
     levels = (long)ex->sched.num_levels();
     const long units = ex->kind == 3 || ex->kind == 4 ? std::max<long>(ex->num_units, 1) : std::max<long>(ex->num_row, 1);
-    unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : (ex->kind == 9 ? 30.0 : 4.5);   // kind 9: a level is a run of up to 64 ratings of a hot row
+    unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : (ex->kind == 9 ? 5.0 + 0.3 * pivot_run : 4.5);   // kind 9: a level lasts as long as its longest run of a hot row's ratings
     dag_ms = (double)levels * unit_us * 1e-3;
     stream_ms = (double)ex->algorithmic_bytes / (0.57 * 8.0e12) * 1e3;
 }
@@ -563,7 +563,7 @@ Dataset *Engine::auto_step(Dataset *exact, bool window_ok, const std::function<D
     double unit_us = 4.5;
     const bool from_probe = !ex;
     if (from_probe) { D = auto_probe_; D.decided = 0; }
-    else auto_measures(ex.get(), D.levels, unit_us, D.dag_ms, D.stream_ms);
+    else auto_measures(ex.get(), D.levels, unit_us, D.dag_ms, D.stream_ms, pivot_run_);
     const bool deep = D.dag_ms > 2.0 * D.stream_ms;
     const char *why;
     if (!deep) { D.decided = 1; why = "exact levels kept (wide enough to stream)"; }
