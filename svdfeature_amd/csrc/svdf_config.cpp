@@ -186,6 +186,7 @@ int64_t Engine::counter(int what) const {
     case 18: return (int64_t)(auto_last_.dag_ms * 1000.0);        // levels x unit latency, microseconds
     case 19: return (int64_t)(auto_last_.stream_ms * 1000.0);     // algorithmic bytes at the measured random-row rate, microseconds
     case 20: return auto_last_.windows;
+    case 23: return n_runs_passes_;     // passes over data sets scheduled as runs of an item's consecutive ratings (svdf_runs.cpp)
     case 22: return n_pivot_passes_;    // passes over data sets with hot rows walked as units (svdf_pivot.cpp)
     case 21: return n_stream_passes_;   // passes issued as ONE launch by the in-launch DAG executor (knob stream_exec)
     default: return -1;
@@ -221,6 +222,11 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "device_init")) { device_init_ = value != 0; return 0; }
     if (!strcmp(name, "device_window")) { device_window_ = value != 0; return 0; }
     if (!strcmp(name, "device_load")) { device_load_ = value != 0; return 0; }
+    if (!strcmp(name, "runs_exec")) { check(value == 0 || value == 1, "runs_exec must be 0 or 1"); runs_exec_ = (int)value; return 0; }
+    if (!strcmp(name, "runs_len")) { check(value >= 2 && value <= 7, "runs_len must be in 2 .. 7"); runs_len_ = (int)value; return 0; }
+    if (!strcmp(name, "runs_sets")) { check(value >= 1 && value <= 2, "runs_sets must be 1 or 2"); runs_sets_ = (int)value; return 0; }
+    if (!strcmp(name, "runs_block")) { check(value == 64 || value == 128 || value == 256, "runs_block must be 64, 128 or 256"); runs_block_ = (int)value; return 0; }
+    if (!strcmp(name, "runs_min_rows")) { check(value >= 0, "runs_min_rows must not be negative"); runs_min_rows_ = value; return 0; }
     if (!strcmp(name, "pivot_exec")) { check(value == 0 || value == 1, "pivot_exec must be 0 or 1"); pivot_exec_ = (int)value; return 0; }
     if (!strcmp(name, "pivot_run")) { check(value >= 1 && value <= 65536, "pivot_run must be in 1 .. 65536"); pivot_run_ = (int)value; return 0; }
     if (!strcmp(name, "pivot_run_long")) { check(value >= 1 && value <= 65536, "pivot_run_long must be in 1 .. 65536"); pivot_run_long_ = (int)value; return 0; }

@@ -142,7 +142,8 @@ Dataset *Engine::dataset_from_triples(long n, const unsigned *user, const unsign
         ptr[(size_t)3 * n] = 2 * n;
         return dataset_from_csr(n, label, ptr.data(), idx.data(), val.data());
     }
-    if (Dataset *pv = pivot_dataset_from_triples(n, user, item, label)) return pv;   // hot rows: runs of their ratings as walker units (svdf_pivot.cpp)
+    if (Dataset *pv = pivot_dataset_from_triples(n, user, item, label)) return pv;
+    if (Dataset *rn = runs_dataset_from_triples(n, user, item, label)) return rn;   // the contract configuration: runs of an item's consecutive ratings (svdf_runs.cpp)   // hot rows: runs of their ratings as walker units (svdf_pivot.cpp)
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->num_row = n; ds->kind = 0;
     const long nb_ = mp_.no_user_bias ? 1 : 2;
@@ -537,7 +538,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
 static void auto_measures(const Dataset *ex, long &levels, double &unit_us, double &dag_ms, double &stream_ms, int pivot_run = 256) {
     levels = (long)ex->sched.num_levels();
     const long units = ex->kind == 3 || ex->kind == 4 ? std::max<long>(ex->num_units, 1) : std::max<long>(ex->num_row, 1);
-    unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : (ex->kind == 9 ? 5.0 + 0.3 * pivot_run : 4.5);   // kind 9: a level lasts as long as its longest run of a hot row's ratings
+    unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : (ex->kind == 9 ? 5.0 + 0.3 * pivot_run : (ex->kind == 10 ? 6.0 : 4.5));   // kind 9: a level lasts as long as its longest run of a hot row's ratings
     dag_ms = (double)levels * unit_us * 1e-3;
     stream_ms = (double)ex->algorithmic_bytes / (0.57 * 8.0e12) * 1e3;
 }
@@ -638,6 +639,11 @@ void Engine::predict_dataset(Dataset *ds, float *out) {
         launch_svdpp_predict(P, D, d.units.p, d.fbidx.p, d.fbval.p, ds->num_units, w_out_.p, stream_);
         HIPCHECK(hipMemcpyAsync(out, w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
         HIPCHECK(hipStreamSynchronize(stream_));
+    } else if (ds->kind == 10) {   // the columns of a runs data set are in file order: no permutation to undo
+        BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, nullptr, nullptr};
+        launch_predict_basic(P, S, n, w_out_.p, stream_);
+        HIPCHECK(hipMemcpyAsync(out, w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
     } else if (ds->kind == 0 || ds->kind == 2) {
         if (ds->kind == 0) {
             BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
@@ -711,7 +717,7 @@ void Engine::eval_dataset(Dataset *ds, float scale, double *sum_sq, int64_t *cou
         BasicSchedule S{ucol, ds->item.p, ds->label.p, nullptr, nullptr};
         launch_predict_basic(P, S, n, w_out_.p, stream_);
         labels = ds->label.p;
-    } else if (ds->kind == 0 || ds->kind == 9) {   // (kind 9: the columns hold the cold ratings, then the units' rows: svdf_pivot.cpp)
+    } else if (ds->kind == 0 || ds->kind == 9 || ds->kind == 10) {   // (kind 9: the columns hold the cold ratings, then the units' rows: svdf_pivot.cpp; kind 10: file order)
         BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
         launch_predict_basic(P, S, n, w_out_.p, stream_);
         labels = ds->label.p;   // same (level) order as the predictions

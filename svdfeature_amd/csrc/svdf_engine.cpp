@@ -751,6 +751,13 @@ void Engine::train_dataset(Dataset *ds) {
         sample_counter_ += (unsigned)ds->num_row;
         return;
     }
+    if (ds->kind == 10) {   // runs of an item's consecutive ratings (svdf_runs.cpp)
+        check(runs_config_ok(), "train_dataset: the data set was built for the contract configuration's runs kernel (svdf_runs.cpp); the configuration changed since");
+        runs_train(ds);
+        n_instances_ += ds->num_row;
+        sample_counter_ += (unsigned)ds->num_row;
+        return;
+    }
     if (ds->kind == 9) {   // ratings with hot rows: cold ratings level by level, runs of a hot row's ratings as walker units (svdf_pivot.cpp)
         check(pivot_config_ok(), "train_dataset: the data set was built for the symmetric basicMF configuration (svdf_pivot.cpp); the configuration changed since");
         pivot_train(ds);

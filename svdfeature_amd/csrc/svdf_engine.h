@@ -237,6 +237,10 @@ struct Dataset {
     long win_item_lo = 0, win_item_hi = -1;   // kind 5: lowest / highest item id with an instance in the window (-1: none)
     DevBuf<long> d_level_ptr;     // kind 2: the level boundaries in HBM, uploaded when a run of narrow levels is first chained (k_fewrow_slots_chain)
     bool d_level_ptr_ok = false;
+    // kind 10: runs of an item's consecutive ratings (svdf_runs.cpp): level-sorted columns of the runs; user / item / label above stay in FILE order
+    DevBuf<unsigned> rn_item, rn_user[8];
+    DevBuf<float> rn_label[8];
+    int rn_len = 0;
     // kind 9: hot rows walked as units (svdf_pivot.cpp): sched.level_ptr = the cold ratings' level boundaries (user / item / label above),
     // pv_unit_ptr = the units' (unitdev.xunits in launch order, their rows in unitdev)
     std::vector<long> pv_unit_ptr;
@@ -611,6 +615,15 @@ class Engine {
     double wseq_max_ratio() const { return (double)wseq_per_target_ / (double)wseq_per_target_max_; }
     int wseq_per_target_ = 24;            // knob "window_per_target": updates a shared row meets per window when amd:window is not given
     bool single_minibatch() const { return step_minibatch_set_ && gpus_ == 1 && !multi_ && !is_peer_; }
+    // runs of an item's consecutive ratings as the units of the contract workload's schedule (svdf_runs.cpp / svdf_k_runs.hip)
+    int runs_exec_ = 1;                   // knob "runs_exec"
+    int runs_len_ = 4;                    // knob "runs_len": ratings per run at most (2 .. 7)
+    int runs_sets_ = 1, runs_block_ = 64; // knobs "runs_sets" / "runs_block": row sets per wave, threads per workgroup of k_basicmf_runs_soa
+    long runs_min_rows_ = 1 << 20;        // knob "runs_min_rows": smaller data sets keep the plain schedule (levels too narrow for runs to matter)
+    int64_t n_runs_passes_ = 0;
+    bool runs_config_ok() const;
+    Dataset *runs_dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
+    void runs_train(Dataset *ds);
     // exact passes over data with hot rows: runs of a hot row's ratings as walker units (svdf_pivot.cpp)
     int pivot_exec_ = 1;                  // knob "pivot_exec"
     int pivot_run_ = 256, pivot_run_long_ = 256;   // knobs "pivot_run" / "pivot_run_long": ratings per unit at most, among cold levels / beyond them (a longer tail cap measured slower)

@@ -301,6 +301,25 @@ void device_sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals
     SCHK(rocprim::radix_sort_pairs(*tmp, need, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0u, 32u, st));
 }
 
+// exclusive prefix sum of n flags (0 / 1 words); returns the total.  *tmp grows as needed (the caller frees it).
+long device_exclusive_scan_u32(const unsigned *in, unsigned *out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st) {
+    if (n <= 0) return 0;
+    size_t need = 0;
+    SCHK(rocprim::exclusive_scan(nullptr, need, in, out, 0u, (size_t)n, rocprim::plus<unsigned>(), st));
+    if (need > *tmp_bytes) {
+        if (*tmp) (void)hipFree(*tmp);
+        *tmp = nullptr;
+        SCHK(hipMalloc(tmp, need));
+        *tmp_bytes = need;
+    }
+    SCHK(rocprim::exclusive_scan(*tmp, need, in, out, 0u, (size_t)n, rocprim::plus<unsigned>(), st));
+    unsigned last_in = 0, last_out = 0;
+    SCHK(hipMemcpyAsync(&last_in, in + (n - 1), sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    SCHK(hipMemcpyAsync(&last_out, out + (n - 1), sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    SCHK(hipStreamSynchronize(st));
+    return (long)last_in + (long)last_out;
+}
+
 // See svdf_kernels.h.  Returns the number of levels; throws std::runtime_error with the reference's bound messages.
 long device_schedule(const SchedColumns &in, int *order_out, std::vector<long> &level_ptr, long *max_level_size, hipStream_t st) {
     const long n = in.n;

@@ -119,6 +119,17 @@ int stream_basic_tile_size(const DevParams &P);
 int stream_basic_max_waves(int num_cu);
 bool stream_basic_applies(const DevParams &P, const BasicSchedule &S);
 void launch_basicmf_stream(const DevParams &P, const BasicSchedule &S, const StreamPlan &T, unsigned pass, int waves, hipStream_t st);
+long device_exclusive_scan_u32(const unsigned *in, unsigned *out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st);
+// runs of an item's consecutive ratings as schedule units (svdf_k_runs.hip)
+void launch_runs_check(const unsigned *user, const unsigned *item, long n, unsigned nu, unsigned ni, unsigned *flag, hipStream_t st);
+void launch_runs_prev(const unsigned *keys, const unsigned *pos, long n, unsigned *prev, hipStream_t st);
+void launch_runs_form(const unsigned *ikeys, const unsigned *ipos, long n, unsigned num_item, const unsigned *prev, int R, unsigned *head, unsigned *head_of,
+                      unsigned char *idx, hipStream_t st);
+void launch_runs_fill(const unsigned *user, const unsigned *item, const float *label, long n, const unsigned *unit_at, const unsigned *head_of,
+                      const unsigned char *idx, long nunit, unsigned *c_item, unsigned *c_user, float *c_label, hipStream_t st);
+void launch_runs_fill_u32(unsigned *v, long n, unsigned x, hipStream_t st);
+bool basicmf_runs_soa_applies(const DevParams &P);
+void launch_basicmf_runs_soa(const DevParams &P, const RunSchedule &S, long begin, long end, int R, int G, int block_threads, hipStream_t st);
 void device_sort_pairs_u32(unsigned *keys_in, unsigned *keys_out, unsigned *vals_in, unsigned *vals_out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st);
 int sqerr_partials_grid(long n);
 void launch_sqerr_partials(const float *pred, const float *label, long n, float scale, double *partials, hipStream_t st);

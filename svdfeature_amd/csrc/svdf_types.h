@@ -115,6 +115,13 @@ struct BasicSchedule {
     const float *ival;
 };
 
+// One conflict-free level of RUNS (svdf_k_runs.hip): run s = item[s] with up to 8 ratings (user[j][s], label[j][s]); user[j][s] == SLOT_ABSENT ends it
+struct RunSchedule {
+    const unsigned *item;
+    const unsigned *user[8];
+    const float *label[8];
+};
+
 // The tile plan of the in-launch DAG executor (svdf_k_stream.hip): tile t = tile_hdr[t].y consecutive positions of the level-sorted arrays
 // starting at tile_hdr[t].x (never across a level boundary); pred[s][position] = the tile that holds the previous toucher of the row in
 // slot s of that instance (0xFFFFFFFF: none in this pass); done[t] = stamp of the pass that finished tile t.

@@ -42,7 +42,7 @@ def test_wide_levels_stay_exact_and_equal_the_oracle():
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
     t = _trainer(conf, extra=[("amd:step", "auto")])
     ds = t.dataset_from_triples(u, i, r)
-    assert t.counter(16) == 1 and ds.kind == 0 and t.counter(17) == ds.num_batches   # exact levels kept
+    assert t.counter(16) == 1 and ds.kind in (0, 10) and t.counter(17) == ds.num_batches   # exact levels kept (as runs of an item's ratings at this size)
     assert t.counter(18) <= 2 * t.counter(19)
     t.train_dataset(ds)
     o = oracle.OracleTrainer("port", 0, 0)

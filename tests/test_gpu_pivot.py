@@ -20,6 +20,7 @@ def _run(u, i, r, nu, ni, pivot, k=64, passes=2, pivot_min=256, extra=()):
     t.init_model()
     t.init_trainer()
     t.set_knob("pivot_exec", pivot)
+    t.set_knob("runs_exec", 0)   # (the plain schedule, not runs of an item's ratings, is what the unit form is compared with)
     t.set_knob("pivot_min", pivot_min)
     ds = t.dataset_from_triples(u, i, r)
     for _ in range(passes):

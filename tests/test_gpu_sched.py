@@ -75,6 +75,8 @@ def test_device_schedule_pairs_and_a_deep_chain():
     cr = np.ones(m, np.float32)
     conf0 = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=8)
     c1, c0 = _ready(0, 0, conf0, 1), _ready(0, 0, conf0, 0)
+    for c in (c1, c0):
+        c.set_knob("pivot_exec", 0)   # (a row this hot would otherwise be walked as units, svdf_pivot.cpp: here the plain schedulers are compared)
     e1, e0 = c1.dataset_from_triples(cu, ci, cr), c0.dataset_from_triples(cu, ci, cr)
     assert e1.num_batches == e0.num_batches == m and e1.max_batch == 1
     c1.train_dataset(e1)
@@ -101,6 +103,7 @@ def test_device_schedule_build_time_at_the_contract_size():
     u, i, r = bench.synth_triples(n, nu, ni)
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
     t = _ready(0, 0, conf)
+    t.set_knob("runs_exec", 0)   # the plain schedule first (one instance per unit); the default -- runs of an item's ratings -- below
     t.dataset_from_triples(u[:1000], i[:1000], r[:1000]).close()   # warm-up of the code path
     t0 = time.time()
     ds = t.dataset_from_triples(u, i, r)
@@ -108,7 +111,17 @@ def test_device_schedule_build_time_at_the_contract_size():
     print("device schedule of 100M ratings: %.3f s, %d batches, largest %d" % (dt, ds.num_batches, ds.max_batch))
     assert 1800 <= ds.num_batches <= 1950 and ds.num_row == n and ds.max_batch <= ni
     assert dt < 0.5
+    # round 5: the default schedule of this configuration, runs of up to 4 consecutive ratings of an item (svdf_k_runs.hip): two more radix
+    # sorts, the run formation and the level schedule over ~30 M runs with 5 row slots each -- inside the same budget
+    t.set_knob("runs_exec", 1)
+    t0 = time.time()
+    dr = t.dataset_from_triples(u, i, r)
+    dtr = time.time() - t0
+    print("runs schedule of the same: %.3f s, %d levels, kind %d" % (dtr, dr.num_batches, dr.kind))
+    assert dr.kind == 10 and dr.num_batches < 1000 and dtr < 0.6
+    dr.close()
     h = _ready(0, 0, conf, 0)
+    h.set_knob("runs_exec", 0)
     t0 = time.time()
     dh = h.dataset_from_triples(u, i, r)
     print("host schedule of the same: %.3f s" % (time.time() - t0))

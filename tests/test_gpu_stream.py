@@ -20,6 +20,7 @@ def _run(u, i, r, nu, ni, stream, waves=0, passes=2, k=64):
     t.init_trainer()
     t.set_knob("stream_exec", stream)
     t.set_knob("pivot_exec", 0)   # (hot rows would otherwise be walked as units: svdf_pivot.cpp, another kind of data set)
+    t.set_knob("runs_exec", 0)    # (... and large data sets of this configuration scheduled as runs: svdf_runs.cpp)
     t.set_knob("stream_spin_limit", 400000)
     if waves:
         t.set_knob("stream_waves", waves)
