@@ -187,7 +187,8 @@ def conf_for(a):
 
 WORKLOADS = {
     # name: (format_type, active_type, default factor, dominant kernel, unit name)
-    "basicmf": (0, 0, 64, "k_basicmf_slots<8,2,4> at k=64 (8 lanes per row x 2 chunks, 4 row sets = 32 instances per wave), k_basicmf<k/4,G,...> at other widths", "instances/s"),
+    "basicmf": (0, 0, 64, "k_basicmf_runs_soa<8,2,4,1> at k=64 (round 5: a lane group of 8 lanes x 2 chunks walks a RUN of up to 4 consecutive ratings of one item with the item's row in registers; "
+                          "one launch per conflict-free level of runs; knob runs_exec=0: k_basicmf_slots<8,2,4>, one instance per lane group), k_basicmf<k/4,G,...> at other widths", "instances/s"),
     "pairwise": (0, 3, 128, "k_fewrow_slots<16,2,1,2> (few-row kernel, 3 rows per pair, 16 lanes x 2 chunks per row)", "pairs/s"),
     "svdpp": (1, 0, 128, "k_svdpp_wave<2,true,true,true,false,8> (one wave per user for the row recurrence + 7 helper waves for the feedback phases)", "instances/s"),
     "neighbourhood": (0, 0, 128, "k_fewrow_gslots<16,2> (few-row kernel stripped for one user id + one item id + up to 4 inline global slots; k_fused<32,1,1,1,...> with knob fewrow_gslots=0)", "instances/s"),

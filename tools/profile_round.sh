@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box through gpurun:  tools/profile_round.sh r05
 # gpurun_out/<tag>/: the default bench line (N = 1: main + secondaries + the opt-in window-step lines, traffic measured in the run), rocprofv3 kernel
-# stats of the same command, and PMC traffic (FETCH_SIZE / WRITE_SIZE, separate passes, --kernel-trace only) of the user-unit window kernels.
+# stats of the same command (SVD++ at 40 K users and without secondary.orders: their deep exact passes are millions of launches), and PMC traffic (FETCH_SIZE / WRITE_SIZE, separate passes, --kernel-trace only) of the user-unit window kernels.
 set -u
 TAG=${1:-r05}
 cd /tmp && export TMPDIR=/tmp
@@ -10,7 +10,7 @@ OUT=gpurun_out/$TAG
 mkdir -p $OUT
 python bench.py > $OUT/bench.json 2> $OUT/bench.stderr.log
 tail -1 $OUT/bench.json | cut -c1-300
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python bench.py --no-cpu-baseline --pmc off > $OUT/kt_bench.json 2> $OUT/kt.stderr.log
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -o kt -- python bench.py --no-cpu-baseline --pmc off --no-orders --svdpp-users 40000 > $OUT/kt_bench.json 2> $OUT/kt.stderr.log
 find $OUT/kt -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats.csv \;
 rm -rf $OUT/kt
 head -16 $OUT/kernel_stats.csv | cut -c1-200
@@ -24,3 +24,15 @@ for W in svdpp neighbourhood; do
   done
   echo "== window step, $W"; cat $OUT/pmc_wstep_$W.txt
 done
+# the in-launch DAG executor (knob stream_exec): traffic and instruction counters of its one kernel against the level loop's
+: > $OUT/pmc_stream_exec.txt
+for K in "stream_exec=1" "stream_exec=0"; do
+  for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY"; do
+    n=$(echo $c | tr " " "_")
+    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_se_$n -o p -- python bench.py --no-cpu-baseline --pmc off --secondary '' --steps 1 --warmup 0 --knob runs_exec=0 --knob $K > /dev/null 2> $OUT/pmc_se.stderr.log
+    echo "== $K, $c" >> $OUT/pmc_stream_exec.txt
+    python tools/pmc_summary.py $OUT/pmc_se_$n | grep -E "k_basicmf|counter_collection" >> $OUT/pmc_stream_exec.txt
+    rm -rf $OUT/pmc_se_$n
+  done
+done
+cat $OUT/pmc_stream_exec.txt
