@@ -797,7 +797,7 @@ def run_workload(name, a, env, steps, warmup, main_line):
             "model_ms": None if not exchanging else model_ms(
                 name, world, "stratified" if stratified else ("minibatch" if minibatch else "levels"), n, a.items, factor, nwin,
                 world * bpr if stratified else 1, a.chunks * world * bpr if (stratified and world > 1) else 0,
-                (23.5 * n / 1e8 * factor / 64.0) if name == "basicmf" else (177.3 * n / 2e8 * factor / 128.0 if name == "pairwise" else None)),
+                (17.1 * n / 1e8 * factor / 64.0) if name == "basicmf" else (177.3 * n / 2e8 * factor / 128.0 if name == "pairwise" else None)),
             "conflict_free_batches_per_pass": n_batches, "schedule_build_s": round(sched_s, 2),
             "parallelism": "1 GPU" if world == 1 else "dp%d user shards + RCCL all-reduce" % world,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -1127,7 +1127,7 @@ def choose_schedule(pf, world, a):
     est(stratified) = max(compute share, hand-overs x measured hand-over); est(all-reduce step) = compute share + windows x measured all-reduce.
     The other schedule is still measured in the same command as a secondary."""
     n, items, factor = a.ratings, a.items, (a.factor or 64)
-    t1 = 23.5 * n / 1e8 * factor / 64.0
+    t1 = 17.1 * n / 1e8 * factor / 64.0   # the exact one-GPU pass (round 5: runs; 23.5 ms in rounds 2-4)
     contract = n == 100_000_000 and items == 100_000 and factor == 64
     share_s = ({2: 9.78, 4: 5.92, 8: 2.71}.get(world) if contract else None) or t1 / world
     share_a = ({2: 8.26, 4: 4.26, 8: 2.66}.get(world) if contract else None) or t1 / world
@@ -1155,7 +1155,7 @@ def model_ms(name, world, exchange_step, n, items, factor, nwin, blocks, handoff
     share = table.get(exchange_step, {}).get(world) if contract else None
     src = "compute share: one rank's share measured on one GPU (DESIGN.md 6c / 6f)"
     if share is None:
-        share, src = (t1_ms / world if t1_ms else None), "compute share: T1 / N with T1 = 23.5 ms per 100 M ratings (k = 64) scaled by size and width"
+        share, src = (t1_ms / world if t1_ms else None), "compute share: T1 / N with T1 = 17.1 ms per 100 M ratings (k = 64; the exact one-GPU pass of round 5) scaled by size and width"
     if share is None:
         return None
     if exchange_step == "stratified":

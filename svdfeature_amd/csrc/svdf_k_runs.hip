@@ -195,19 +195,24 @@ __global__ __launch_bounds__(256) void k_basicmf_runs_soa(const DevParams P, con
 }
 bool basicmf_runs_soa_applies(const DevParams &P) {
     return P.basic_i8 && P.active_type == ACT_LINEAR && P.reg_method == 0 && P.no_user_bias == 0 && P.user_nonnegative == 0 && P.u_rng.n == 0 && P.i_rng.n == 0 &&
-           P.store_mode == 0 && P.k == 64;
+           P.store_mode == 0 && (P.k == 64 || P.k == 128);
 }
+// k = 64: 8 lanes x 2 chunks per row, 8 runs per wave and row set; k = 128: 16 lanes x 2 chunks, 4 runs
 void launch_basicmf_runs_soa(const DevParams &P, const RunSchedule &S, long begin, long end, int R, int G, int block_threads, hipStream_t st) {
     if (end <= begin) return;
     if (G < 1) G = 1;
     if (block_threads != 64 && block_threads != 128 && block_threads != 256) block_threads = 64;
-    const long per_block = (long)(block_threads / 64) * G * 8;
+    const int per_wave = P.k == 128 ? 4 : 8;
+    const long per_block = (long)(block_threads / 64) * G * per_wave;
     int grid = (int)((end - begin + per_block - 1) / per_block);
     if (P.xcd_remap) grid = (grid + 7) & ~7;
-#define RUNS_LAUNCH(R_, G_) hipLaunchKernelGGL((k_basicmf_runs_soa<8, 2, R_, G_>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end)
-    if (R == 2) { if (G >= 2) RUNS_LAUNCH(2, 2); else RUNS_LAUNCH(2, 1); }      // R = the number of user / label columns the schedule holds: 2, 4 or 7
-    else if (R == 4) { if (G >= 2) RUNS_LAUNCH(4, 2); else RUNS_LAUNCH(4, 1); }
-    else { if (G >= 2) RUNS_LAUNCH(7, 2); else RUNS_LAUNCH(7, 1); }
+#define RUNS_LAUNCH(L_, R_, G_) hipLaunchKernelGGL((k_basicmf_runs_soa<L_, 2, R_, G_>), dim3(grid), dim3(block_threads), 0, st, P, S, begin, end)
+#define RUNS_BY_R(L_)                                                                                                          \
+    if (R == 2) { if (G >= 2) RUNS_LAUNCH(L_, 2, 2); else RUNS_LAUNCH(L_, 2, 1); }      /* R = user / label columns of the schedule: 2, 4 or 7 */ \
+    else if (R == 4) { if (G >= 2) RUNS_LAUNCH(L_, 4, 2); else RUNS_LAUNCH(L_, 4, 1); }                                       \
+    else { if (G >= 2) RUNS_LAUNCH(L_, 7, 2); else RUNS_LAUNCH(L_, 7, 1); }
+    if (P.k == 128) { RUNS_BY_R(16) } else { RUNS_BY_R(8) }
+#undef RUNS_BY_R
 #undef RUNS_LAUNCH
 }
 

@@ -14,7 +14,7 @@ namespace svdf {
 
 bool Engine::runs_config_ok() const {
     return runs_exec_ != 0 && !host_only_ && device_sched_ && !user_group() && basic_fast_path_allowed() && mtype_.extend_type == 0 && mtype_.active_type == ACT_LINEAR &&
-           tp_.reg_method == 0 && mp_.user_nonnegative == 0 && mp_.no_user_bias == 0 && u_param_.bound.empty() && i_param_.bound.empty() && mp_.num_factor == 64 &&
+           tp_.reg_method == 0 && mp_.user_nonnegative == 0 && mp_.no_user_bias == 0 && u_param_.bound.empty() && i_param_.bound.empty() && (mp_.num_factor == 64 || mp_.num_factor == 128) &&
            basic_i8_ != 0 && store_mode_ == 0;
 }
 

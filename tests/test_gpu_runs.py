@@ -12,10 +12,10 @@ pytestmark = pytest.mark.gpu
 NAMES = ("W_user", "W_item", "u_bias", "i_bias")
 
 
-def _trainer(nu, ni, knobs):
+def _trainer(nu, ni, knobs, k=64):
     t = sa.Trainer(0, 0)
     t.seed(10)
-    for kk, v in cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64):
+    for kk, v in cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k):
         t.set_param(kk, str(v))
     t.init_model()
     t.init_trainer()
@@ -26,8 +26,8 @@ def _trainer(nu, ni, knobs):
     return t
 
 
-def _run(u, i, r, nu, ni, knobs, passes=2):
-    t = _trainer(nu, ni, knobs)
+def _run(u, i, r, nu, ni, knobs, passes=2, k=64):
+    t = _trainer(nu, ni, knobs, k)
     ds = t.dataset_from_triples(u, i, r)
     for _ in range(passes):
         t.train_dataset(ds)
@@ -55,6 +55,18 @@ def test_runs_equal_the_level_by_level_pass(nu, ni, n, zipf, knobs):
     sb_, cb = tb.eval_dataset(dsb)
     assert ca == cb == n and abs(sa_ - sb_) <= 1e-9 * abs(sa_)
     assert np.array_equal(ta.predict_dataset(dsa).view(np.uint32), tb.predict_dataset(dsb).view(np.uint32))
+
+
+@pytest.mark.parametrize("knobs", [[("runs_len", 4)], [("runs_len", 7), ("runs_sets", 2)], [("runs_len", 2), ("runs_block", 256)]])
+def test_runs_at_k_128(knobs):
+    """k = 128: 16 lanes x 2 chunks per row, 4 runs per wave"""
+    nu, ni, n = 30000, 2500, 600000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=33)
+    a, dsa, _ = _run(u, i, r, nu, ni, [("runs_exec", 0)], k=128)
+    b, dsb, _ = _run(u, i, r, nu, ni, [("runs_exec", 1)] + knobs, k=128)
+    assert dsa.kind == 0 and dsb.kind == 10
+    for name in NAMES:
+        assert np.array_equal(a[name].view(np.uint32), b[name].view(np.uint32)), name
 
 
 def test_a_user_rating_the_same_item_twice_in_a_row_and_other_repeats():
