@@ -106,6 +106,22 @@ def draw(rng, tmp, wide=False, big=False):
         plan["knobs"]["device_schedule"] = 0
     elif rng.integers(0, 2) == 0:
         plan["knobs"]["device_schedule_min"] = 1
+    # round 5: runs of an item's consecutive ratings (svdf_k_runs.hip) and hot rows walked as units (svdf_pivot.cpp) at fuzz sizes -- both are
+    # schedule forms of the same pass: they apply to the configurations they are built for and must not change a bit
+    if rng.integers(0, 2) == 0:
+        plan["knobs"]["runs_min_rows"] = 0
+        plan["knobs"]["runs_len"] = int(rng.integers(2, 8))
+        if rng.integers(0, 2) == 0:
+            plan["knobs"]["runs_sets"] = 2
+    elif rng.integers(0, 3) == 0:
+        plan["knobs"]["runs_exec"] = 0
+    if rng.integers(0, 2) == 0:
+        plan["knobs"]["pivot_min"] = int(rng.choice([2, 16, 200]))
+        plan["knobs"]["pivot_run"] = int(rng.choice([2, 8, 256]))
+    elif rng.integers(0, 3) == 0:
+        plan["knobs"]["pivot_exec"] = 0
+    if rng.integers(0, 3) == 0:
+        plan["knobs"]["chain_width"] = int(rng.choice([0, 4, 128]))
     # the multi-level implicit-feedback solver (extend_type 2) on nested spans, the bilinear solver (15) on plain blocks
     plan["extend"] = 0
     if fmt == 1 and not shared:
