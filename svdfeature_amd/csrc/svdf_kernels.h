@@ -87,18 +87,26 @@ void launch_rank_transpose(const DevParams &P, long first, long n, long cap, con
 struct RankFused { int mode; const int *pos_item; const float *pos_score; int npos; int *greater, *ties; unsigned *keys, *vals, *flag, *hist1; };
 void launch_rank_score(const DevParams &P, long n, long cap, const float *tu, const float *ifT, const float *ibias, const signed char *tag,
                        float *item_score, int fresh, const RankFused &F, hipStream_t st);
-// a tile of user sections sharing one pass over the candidate matrix (positions mode, no special samples): per section u the staged
-// words at off[u] are uidx[nu] uval[nu] pos[npos] ban[nban]; its counters / positive scores start at entry pos0[u]
-#define RANK_TILE 8
+// a tile of user sections sharing one pass over the candidate matrix (no special samples): per section u the staged words at off[u] are
+// uidx[nu] uval[nu] pos[npos] ban[nban]; its counters / positive scores start at entry pos0[u].  32 = the bits of a ban word.
+#define RANK_TILE 32
 struct RankTile { int nsec; int off[RANK_TILE], nu[RANK_TILE], npos[RANK_TILE], nban[RANK_TILE], pos0[RANK_TILE]; };
-void launch_rank_tile_open(const DevParams &P, const unsigned *stage, const RankTile &T, const float *fb_in, float *tu_out, unsigned *banmask,
+// tuT: the tile's user factors chunk-major, RANK_TILE * pitch floats (written here, read as scalars by the scoring pass)
+void launch_rank_tile_open(const DevParams &P, const unsigned *stage, const RankTile &T, const float *fb_in, float *tuT, unsigned *banmask,
                            const unsigned *prev_ban, int nprev, int *cnt, unsigned *flag, long cap, const float *ifT, const float *ibias, float *pos_score,
                            unsigned *zero_words, long nzero, hipStream_t st);
-void launch_rank_score_tile(const DevParams &P, long n, long cap, const float *tu, const float *ifT, const float *ibias, const unsigned *banmask, float *score,
-                            const unsigned *stage, const RankTile &T, const float *pos_score, int *cnt, hipStream_t st);
+// mode 0: out[u * cap + i] = score bits of the ranked candidates + the positives' counters; mode 1: out = sort keys of every candidate,
+// wmin[u * rank_tile_minima(n) + wave] = per-wave minimum keys
+void launch_rank_score_tile(const DevParams &P, long n, long cap, const float *tuT, const float *ifT, const float *ibias, const unsigned *banmask, unsigned *out,
+                            const unsigned *stage, const RankTile &T, const float *pos_score, int *cnt, int mode, unsigned *wmin, unsigned *flag, hipStream_t st);
 struct RselSecs { unsigned K1[RANK_TILE]; };
-void launch_rank_select_tile(long n, long cap, int nsec, const float *score, const unsigned *banmask, const RselSecs &Ks, unsigned *keys, unsigned *work,
-                             unsigned *ck, unsigned *cv, unsigned *out, long out_stride, unsigned *flag, hipStream_t st);
+long rank_tile_minima(long n);
+bool rank_tile_select_applies(long n, long cap, long K1max);
+// top_k of every section of a tile from its keys and wave minima: out + u * out_stride = K1[u] keys, K1[u] candidates, flag word
+void launch_rank_tile_select(long n, long cap, int nsec, const unsigned *keys, const unsigned *wmin, const RselSecs &Ks, unsigned *out, long out_stride,
+                             const unsigned *flag, hipStream_t st);
+void launch_rank_select_tile(long n, long cap, int nsec, const unsigned *keys, const RselSecs &Ks, unsigned *work, unsigned *ck, unsigned *cv, unsigned *out,
+                             long out_stride, unsigned *flag, hipStream_t st);
 void launch_rank_positions(long n, const float *score, const signed char *tag, const int *pos_item, int npos, int *greater, int *ties, hipStream_t st);
 // radix selection of the K1 smallest (key, value) pairs, ascending (svdf_k_rank.hip): work = rank_select_work_words() words
 // (zeroed by k_rank_user, first histogram filled by the scoring pass: RankFused::hist1 = work), ck / cv = rank_select_cap()

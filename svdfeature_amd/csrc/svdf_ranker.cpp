@@ -68,7 +68,7 @@ void Ranker::init_ranker(int num_item_set) {                   // :666-685
     RCHECK(hipMemsetAsync(d_tag_.p, 0, (size_t)std::max(num_item_set, 1), eng_->stream_));
     d_banmask_.reserve((size_t)std::max(num_item_set, 1));
     RCHECK(hipMemsetAsync(d_banmask_.p, 0, (size_t)std::max(num_item_set, 1) * sizeof(unsigned), eng_->stream_));
-    d_tu_tile_.reserve((size_t)RANK_TILE * (pitch + 4));
+    d_tu_tile_.reserve((size_t)RANK_TILE * pitch + 256);   // chunk-major user factors of a tile (+ one group the scoring pass prefetches past the end)
     tile_.clear();
     tile_prev_ban_.clear();
     tag_.assign((size_t)num_item_set, 0);
@@ -233,33 +233,37 @@ void Ranker::flush_tile() {
     L.d_cnt.reserve((size_t)2 * std::max(totpos, 1));
     L.d_flag.reserve(RANK_TILE);
     L.d_ps.reserve((size_t)std::max(totpos, 1));
-    L.d_score.reserve((size_t)RANK_TILE * (size_t)cap_items);
-    // top_k: the selection's work areas (histograms + state of every section) are cleared by the opening kernel
+    L.d_score.reserve((size_t)RANK_TILE * (size_t)cap_items);   // scores (positions mode) or sort keys (top_k) of the tile's sections
+    unsigned *d_out = reinterpret_cast<unsigned *>(L.d_score.p);
+    // top_k: short prefixes are selected from the keys and per-wave minima of the scoring pass (k_rank_tile_select); long ones by the radix
+    // selection, whose work areas (histograms + state of every section) are cleared by the opening kernel
+    int take_max = 0;
+    for (const TileSec &S : tile_) take_max = std::max(take_max, S.take);
+    const bool top = top_k_ > 0;
+    const bool quick = top && rank_tile_select_applies(n, cap_items, take_max);
     const size_t sel_ww = (size_t)rank_select_work_words(), sel_rc = (size_t)rank_select_cap();
     const size_t sel_out_stride = (size_t)2 * ((size_t)std::max(top_k_, 0) + 1) + 1;
-    if (top_k_ > 0) {
-        d_keys_.reserve((size_t)RANK_TILE * (size_t)cap_items);
-        d_sel_.reserve((size_t)RANK_TILE * (sel_ww + 2 * sel_rc + sel_out_stride));
-    }
+    const size_t nmin = (size_t)rank_tile_minima(n);
+    if (top) d_sel_.reserve((size_t)RANK_TILE * (sel_ww + 2 * sel_rc + sel_out_stride + nmin));
+    unsigned *work = d_sel_.p, *ck = work + RANK_TILE * sel_ww, *cv = ck + RANK_TILE * sel_rc, *res = cv + RANK_TILE * sel_rc, *wmin = res + RANK_TILE * sel_out_stride;
     launch_rank_tile_open(P, L.d_stage.p, T, eng_->user_group() ? d_fb_.p : nullptr, d_tu_tile_.p, d_banmask_.p, L.d_stage.p + prev_off, (int)tile_prev_ban_.size(),
-                          L.d_cnt.p, L.d_flag.p, cap_items, d_ift_.p, d_ibias_.p, L.d_ps.p, top_k_ > 0 ? d_sel_.p : nullptr,
-                          top_k_ > 0 ? (long)((size_t)T.nsec * sel_ww) : 0L, st);
-    launch_rank_score_tile(P, n, cap_items, d_tu_tile_.p, d_ift_.p, d_ibias_.p, d_banmask_.p, L.d_score.p, L.d_stage.p, T, L.d_ps.p, L.d_cnt.p, st);
+                          L.d_cnt.p, L.d_flag.p, cap_items, d_ift_.p, d_ibias_.p, L.d_ps.p, (top && !quick) ? d_sel_.p : nullptr,
+                          (top && !quick) ? (long)((size_t)T.nsec * sel_ww) : 0L, st);
+    launch_rank_score_tile(P, n, cap_items, d_tu_tile_.p, d_ift_.p, d_ibias_.p, d_banmask_.p, d_out, L.d_stage.p, T, L.d_ps.p, L.d_cnt.p, top ? 1 : 0,
+                           top ? wmin : nullptr, L.d_flag.p, st);
     RCHECK(hipGetLastError());
     RankPending Q;
     Q.slot = slot; Q.n = n; Q.nsec = T.nsec;
-    if (top_k_ > 0) {
-        // top_k: the radix selection of every section of the tile in one set of launches (grid y = section), ONE readback
+    if (top) {
         RselSecs Ks;
         memset(&Ks, 0, sizeof(Ks));
         for (int u = 0; u < T.nsec; u++) Ks.K1[u] = (unsigned)tile_[(size_t)u].take;
-        const size_t ww = sel_ww, rc = sel_rc, out_stride = sel_out_stride;
-        unsigned *work = d_sel_.p, *ck = work + RANK_TILE * ww, *cv = ck + RANK_TILE * rc, *res = cv + RANK_TILE * rc;
-        launch_rank_select_tile(n, cap_items, T.nsec, L.d_score.p, d_banmask_.p, Ks, d_keys_.p, work, ck, cv, res, (long)out_stride, L.d_flag.p, st);
+        if (quick) launch_rank_tile_select(n, cap_items, T.nsec, d_out, wmin, Ks, res, (long)sel_out_stride, L.d_flag.p, st);
+        else launch_rank_select_tile(n, cap_items, T.nsec, d_out, Ks, work, ck, cv, res, (long)sel_out_stride, L.d_flag.p, st);
         RCHECK(hipGetLastError());
-        slot_reserve_back(L, (size_t)T.nsec * out_stride);
-        RCHECK(hipMemcpyAsync(L.back, res, (size_t)T.nsec * out_stride * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-        Q.out_stride = (long)out_stride;
+        slot_reserve_back(L, (size_t)T.nsec * sel_out_stride);
+        RCHECK(hipMemcpyAsync(L.back, res, (size_t)T.nsec * sel_out_stride * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        Q.out_stride = (long)sel_out_stride;
         for (int u = 0; u < T.nsec; u++) Q.tile_take.push_back(tile_[(size_t)u].take);
     } else {
         slot_reserve_back(L, (size_t)2 * totpos);
@@ -435,6 +439,18 @@ static size_t host_sort_threads() {
     static const size_t n = std::min<size_t>(32, std::max<size_t>(8, std::thread::hardware_concurrency() / 4));
     return n;
 }
+// k_rank_score_tile<., 1> keeps the sort KEY of a candidate where the positions pass keeps its score: the key back to a score the
+// reference's comparator cannot tell from the original (-0 comes back as +0, every NaN as one NaN; banned candidates carry no score)
+static void keys_to_scores(std::vector<float> &v) {
+    for (float &f : v) {
+        unsigned key;
+        memcpy(&key, &f, 4);
+        unsigned bits;
+        if (key >= 0xFFFFFFFEu) bits = 0x7FC00000u;
+        else { const unsigned up = ~key; bits = (up & 0x80000000u) ? (up & 0x7FFFFFFFu) : ~up; }
+        memcpy(&f, &bits, 4);
+    }
+}
 static std::vector<int> host_sort_section(std::vector<float> score, std::vector<int> banned_idx, std::vector<int> pos_item, int top_k) {
     const long n = (long)score.size();
     std::vector<char> banned((size_t)n, 0);
@@ -496,6 +512,7 @@ void Ranker::resolve() {
                 std::vector<float> score((size_t)n);
                 RCHECK(hipMemcpyAsync(score.data(), L.d_score.p + (size_t)u * cap_items, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
                 RCHECK(hipStreamSynchronize(st));
+                if (!Q.tile_take.empty()) keys_to_scores(score);   // top_k tiles hold sort keys
                 n_host_sorts_++;
                 size_t running = 0;
                 for (RankChunk &c : chunks_) running += c.pending ? 1 : 0;

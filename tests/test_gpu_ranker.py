@@ -141,18 +141,21 @@ def test_ranker_bulk_rows_pipelined_equals_line_by_line(top_k, spec, tmp_path):
             assert r.counter(0) == 100
             hosted[name] = r.counter(1)
             # without special samples the bulk call scores a TILE of sections per pass over the candidate matrix (positions and top_k alike)
-            assert (r.counter(3) >= 12) == (name == "bulk" and not spec), r.counter(3)
+            assert (r.counter(3) >= 3) == (name == "bulk" and not spec), r.counter(3)
     np.testing.assert_array_equal(outs["lines"], outs["oracle"])
     np.testing.assert_array_equal(outs["bulk"], outs["oracle"])
     assert hosted["bulk"] == hosted["lines"]   # the same sections needed the reference's sort either way
 
 
 def test_ranker_tiles_equal_one_pass_per_section(tmp_path):
-    """k_rank_score_tile (up to 8 user sections per pass over the candidate matrix) against one pass per section (amd:rank_tile = 0) and the
-    C oracle: 300 sections with 0 ... 6 positives and bans each, k = 5, 64, 300 (ragged tail / full rows / wide rows), odd tile remainders;
-    positions mode and top_k mode (the radix selection of all sections of a tile in one set of launches)"""
-    for k, nsec, top_k in ((5, 37, 0), (64, 300, 0), (300, 21, 0), (64, 300, 10), (5, 37, 1), (128, 45, 40)):
-        nu, ni, ng = 150, 900, 3
+    """k_rank_score_tile (up to 32 user sections per pass over the candidate matrix) against one pass per section (amd:rank_tile = 0) and the
+    C oracle: sections with 0 ... 6 positives and bans each, k = 5, 64, 300 (ragged tail / full rows / wide rows), odd tile remainders
+    (every kernel width: 4 / 8 / 16 / 32 sections); positions mode and top_k mode -- short prefixes through the wave minima
+    (k_rank_tile_select: fewer minima than the prefix at 300 candidates, 9 000 candidates), long ones (top_k = 40) through the radix
+    selection of all sections of a tile in one set of launches"""
+    for k, nsec, top_k, cand in ((5, 37, 0, 700), (64, 300, 0, 700), (300, 21, 0, 700), (64, 300, 10, 700), (5, 37, 1, 700), (128, 45, 40, 700),
+                                 (64, 43, 10, 300), (32, 75, 31, 9000), (128, 70, 0, 9000), (16, 99, 3, 2049)):
+        nu, ni, ng = 150, max(900, cand), 3
         conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_global=ng, num_factor=k, ui_init_sigma=0.1)
         t = oracle.OracleTrainer("port", 0, 0)
         t.seed(k)
@@ -162,7 +165,7 @@ def test_ranker_tiles_equal_one_pass_per_section(tmp_path):
         t.init_trainer()
         path = str(tmp_path / ("m%d.model" % k))
         t.save_model(path)
-        items, sections = cases.ranker_stream(700, nsec, nu, ni, ng, seed=k, spec=False)
+        items, sections = cases.ranker_stream(cand, nsec, nu, ni, ng, seed=k, spec=False)
         stream = sa.CSRData.concat([items] + sections)
         outs = {}
         for name, tile in (("oracle", None), ("tiles", 1), ("single", 0)):
@@ -174,7 +177,7 @@ def test_ranker_tiles_equal_one_pass_per_section(tmp_path):
             r.init_ranker(items.num_row)
             outs[name] = r.process_rows(stream) if name != "oracle" else np.concatenate([r.process(*stream.row(i)) for i in range(stream.num_row)])
             if name == "tiles":
-                assert r.counter(3) >= nsec // 8 - 2
+                assert r.counter(3) >= nsec // 32
             if name == "single":
                 assert r.counter(3) == 0
         np.testing.assert_array_equal(outs["tiles"], outs["oracle"])
