@@ -280,6 +280,10 @@ int svdf_rccl_close(svdf_trainer *t);
  * PairwiseRankGenerator::sample_cmp, apex_svd_data.cpp:920-944, picks rows by POSITION after an unstable std::sort): ids 0..n-1
  * sorted by label with the restated code (restated[]) and with the C++ library's own std::sort (library[]). */
 int svdf_debug_sort_labels(long n, const float *label, int *restated, int *library);
+/* test probe of the ranker's tie-breaking sort (SVDFeatureRanker sorts its entry vector with std::sort, apex_svd_base.h:767; sections whose
+ * scores tie are finished by exactly that sort, its partitions spread over `threads` host threads): ids 0..n-1 by descending score with
+ * the threaded restatement (parallel[]) and with the library's std::sort over the reference's Entry struct (library[]). */
+int svdf_debug_sort_scores(long n, const float *score, int threads, int *parallel, int *library);
 
 /* ---- introspection used by tests, bench.py and the harness ---- */
 /* raw copies of parameter views: 0 u_bias 1 W_user 2 i_bias 3 W_item 4 g_bias 5 ufeedback_bias

@@ -169,6 +169,7 @@ def load_library():
     lib.svdf_rand_skip.argtypes = [C.c_long]
     lib.svdf_device_expf.argtypes = [C.c_void_p, C.c_uint, C.c_uint, _f32p, C.c_long]
     lib.svdf_debug_sort_labels.argtypes = [C.c_long, _f32p, _i32p, _i32p]
+    lib.svdf_debug_sort_scores.argtypes = [C.c_long, _f32p, C.c_int, _i32p, _i32p]
     lib.svdf_set_error_mode(1)   # python callers get exceptions instead of exit(-1)
     _lib = lib
     return lib
@@ -207,6 +208,16 @@ def debug_sort_labels(label):
     if load_library().svdf_debug_sort_labels(len(label), _pad(label, np.float32), a, b) != 0:
         raise SvdfError(load_library().svdf_last_error().decode())
     return a[:len(label)], b[:len(label)]
+
+
+def debug_sort_scores(score, threads=8):
+    """(ids by descending score with the ranker's threaded restatement of std::sort, the same with the library's std::sort over the
+    reference's Entry struct)"""
+    score = np.ascontiguousarray(score, np.float32)
+    a, b = np.zeros(max(len(score), 1), np.int32), np.zeros(max(len(score), 1), np.int32)
+    if load_library().svdf_debug_sort_scores(len(score), _pad(score, np.float32), int(threads), a, b) != 0:
+        raise SvdfError(load_library().svdf_last_error().decode())
+    return a[:len(score)], b[:len(score)]
 
 
 def device_expf(x=None, first=0, step=1, n=None):

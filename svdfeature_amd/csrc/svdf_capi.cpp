@@ -181,6 +181,18 @@ int svdf_debug_sort_labels(long n, const float *label, int *restated, int *libra
         return 0;
     })
 }
+int svdf_debug_sort_scores(long n, const float *score, int threads, int *parallel, int *library) {
+    SVDF_GUARD(-1, {
+        for (long j = 0; j < n; j++) parallel[j] = (int)j;
+        svdf::host_parallel_sort_scores(score, parallel, n, threads);
+        struct Entry { int iid; float score; bool operator<(const Entry &p) const { return score > p.score; } };   // apex_svd_base.h:617-624
+        std::vector<Entry> e((size_t)std::max<long>(n, 0));
+        for (long j = 0; j < n; j++) e[(size_t)j] = Entry{(int)j, score[j]};
+        std::sort(e.begin(), e.end());
+        for (long j = 0; j < n; j++) library[j] = e[(size_t)j].iid;
+        return 0;
+    })
+}
 svdf_dataset *svdf_dataset_from_pairs(svdf_trainer *t, long n, const unsigned *user, const unsigned *pos_item, const unsigned *neg_item) {
     SVDF_GUARD(nullptr, {
         svdf::Dataset *d = t->e->dataset_from_pairs(n, user, pos_item, neg_item);

@@ -1,5 +1,8 @@
 // svdf_engine.cpp -- part of the host engine (class Engine, svdf_engine.h): errors, device buffers, lifecycle, staging of update() calls, flush, predict, train_dataset
 // Reference citations are relative to /root/reference.
+#include <malloc.h>
+#include <mutex>
+
 #include "svdf_engine.h"
 
 #include <algorithm>
@@ -44,7 +47,22 @@ MultiScope::~MultiScope() { tl_multi_depth--; }
 
 // =============================================================================== lifecycle
 
+// glibc raises its mmap threshold to the size of every mmapped block that is freed ("dynamic threshold"), after which blocks of that size
+// come from the arena heaps -- and helper threads that free them make their arenas shrink (madvise / remap of the heap tail).  Each of those
+// runs the GPU driver's MMU notifier for the process, and the device queues stall while it does: a ranker call of 38 tiles took 5 ms or
+// 25 - 40 ms from one process to the next depending on where malloc had put the blocks (profiles/r05_ranker_malloc.txt; any of
+// MALLOC_MMAP_THRESHOLD_ / MALLOC_TRIM_THRESHOLD_ / MALLOC_TOP_PAD_ in the environment: always 5 ms).  Setting the threshold to the value it
+// already has switches the adjustment off and changes nothing else.  SVDF_KEEP_MALLOC_DYNAMIC=1 leaves malloc alone.
+static void pin_malloc_threshold() {
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *e = getenv("SVDF_KEEP_MALLOC_DYNAMIC");
+        if (!(e && atoi(e) != 0)) (void)mallopt(M_MMAP_THRESHOLD, 128 * 1024);
+    });
+}
+
 Engine::Engine(TypeParam mtype, int device) : mtype_(mtype) {
+    pin_malloc_threshold();
     memset(&mp_, 0, sizeof(mp_));
     mp_.u_init_sigma = mp_.i_init_sigma = 0.01f;   // SVDModelParam() apex_svd_model.h:436-450
     mp_.base_score = 0.5f;

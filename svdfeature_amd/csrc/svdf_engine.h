@@ -740,7 +740,7 @@ class Ranker {
     long process_block(int nfb, int tag, const unsigned *ifb, const float *vfb, int num_row, const float *row_label, const int *row_ptr,
                        const unsigned *feat_index, const float *feat_value, int *out, long cap);
     int64_t counter(int what) const {
-        return what == 0 ? n_sections_ : (what == 1 ? n_host_sorts_ : (what == 2 ? (int64_t)pos_item_.size() : (what == 3 ? n_tiles_ : -1)));
+        return what == 0 ? n_sections_ : (what == 1 ? n_host_sorts_ : (what == 2 ? (int64_t)pos_item_.size() : (what == 3 ? n_tiles_ : (what == 4 ? tie_copy_ns_ : (what == 5 ? tie_wait_ns_ : (what == 6 ? event_wait_ns_ : (what == 7 ? flush_ns_ : -1)))))));
     }
   private:
     std::unique_ptr<Engine> eng_;   // owns the model in HBM, the side tables and the kernel parameter block
@@ -798,6 +798,12 @@ class Ranker {
     size_t sort_tmp_bytes_ = 0;
     DevBuf<signed char> d_tag_;
     int64_t n_sections_ = 0, n_host_sorts_ = 0;
+    std::unique_ptr<struct TieWork> tie_scores(const float *d_src, long n);
+    hipStream_t tie_stream_ = nullptr;
+    float *tie_pin_ = nullptr;
+    size_t tie_pin_floats_ = 0;
+    int64_t event_wait_ns_ = 0, flush_ns_ = 0;   // waiting for a slot's event; staging + enqueueing tiles (includes resolving the oldest slot)
+    int64_t tie_copy_ns_ = 0, tie_wait_ns_ = 0;   // tied sections: copying their scores out (a stream sync each); waiting for their sorts at the end
     void stage(HostCSR &dst, int ng, int nu, int ni, const unsigned *index, const float *value);
     void check_item_side(int ng, int nu, int ni, const unsigned *index);
     long rank(int *out, long cap);

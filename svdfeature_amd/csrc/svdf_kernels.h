@@ -167,7 +167,9 @@ void launch_gpair_sizes(const RankRowsDev &S, const GSamplerParams &sp, long npa
 void launch_gpair_write(const RankRowsDev &S, const GSamplerParams &sp, long npairs, const int *pair_p, const int *pair_n, const int *optr, float *olabel,
                         unsigned *oi, float *ov, hipStream_t st);
 void device_exclusive_scan_i32(const int *in, int *out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st);
-void host_sort_by_label(const float *label, long n, int *ids);   // the restated std::sort (svdf_stdsort.h) on the host, for tests
+void host_sort_by_label(const float *label, long n, int *ids);
+// std::sort of candidate ids by descending score as the reference's ranker does it (apex_svd_base.h:767), its partitions on nthreads threads
+void host_parallel_sort_scores(const float *score, int *ids, long n, int nthreads);   // the restated std::sort (svdf_stdsort.h) on the host, for tests
 void launch_rand_expand(const unsigned *tables, long nchunks, long C, long D, unsigned *raw, hipStream_t st);
 // ---- window data sets of plain ratings / rank pairs (kind 5) regrouped on the device (svdf_k_wbuild.hip): the arrays of Engine::window_build.
 // All pointers are device pointers; E = n (ratings) or 2 n (pairs) item entries.

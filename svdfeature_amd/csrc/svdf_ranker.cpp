@@ -9,7 +9,12 @@
 // ranked candidates tie with a requested position (or inside the top_k prefix) the order is whatever std::sort makes of
 // the reference's entry vector, so those rare sections are finished by running exactly that sort on the host.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <functional>
 #include <future>
+#include <mutex>
 #include <thread>
 #include <cmath>
 #include <cstring>
@@ -17,6 +22,7 @@
 
 #include "svdf_engine.h"
 #include "svdf_kernels.h"
+#include "svdf_stdsort.h"
 
 namespace svdf {
 
@@ -31,6 +37,8 @@ Ranker::Ranker(TypeParam mtype, int device) : eng_(new Engine(TypeParam{mtype.fo
 Ranker::~Ranker() {
     (void)hipStreamSynchronize(eng_->stream_);
     if (sort_tmp_) (void)hipFree(sort_tmp_);
+    if (tie_pin_) (void)hipHostFree(tie_pin_);
+    if (tie_stream_) (void)hipStreamDestroy(tie_stream_);
     for (RankSlot &S : slots_) {
         if (S.pin) (void)hipHostFree(S.pin);
         if (S.back) (void)hipHostFree(S.back);
@@ -197,6 +205,8 @@ void Ranker::slot_reserve_back(RankSlot &S, size_t words) {
 // candidate matrix for all of its sections, ONE readback of the counters; resolved section by section, in order
 void Ranker::flush_tile() {
     if (tile_.empty()) return;
+    struct Tm { int64_t &acc; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                ~Tm() { acc += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count(); } } tm_{flush_ns_};
     const DevParams &P = eng_->params();
     hipStream_t st = eng_->stream_;
     const long n = tile_n_, cap_items = (long)std::max(num_item_set_, 1);
@@ -451,24 +461,232 @@ static void keys_to_scores(std::vector<float> &v) {
         memcpy(&f, &bits, 4);
     }
 }
-static std::vector<int> host_sort_section(std::vector<float> score, std::vector<int> banned_idx, std::vector<int> pos_item, int top_k) {
+// std::sort over the reference's entry vector (:767; Entry::operator<: score > p.score) executed by several threads.  libstdc++'s
+// introsort (restated in svdf_stdsort.h, checked against the library's own std::sort) recurses into DISJOINT sub-ranges after every
+// partition, so the partitions may run in any order and concurrently: the ranges a partition splits off go to a shared queue when they are
+// large.  Its final insertion sort is stable and never moves an element across a partition cut, so it runs per region between the cuts
+// that were shared.  Same comparisons on the same ranges: the permutation of tied scores is the library's.  a[]: candidate ids.
+struct ByScoreDesc {
+    const float *score;
+    bool operator()(int a, int b) const { return score[a] > score[b]; }
+};
+// helper threads of the sorts, started once (starting a thread inside a process that holds a GPU context measured ~170 us here: a sort
+// that starts its own helpers is slower than the sequential one)
+class SortPool {
+  public:
+    static SortPool &get() { static SortPool p; return p; }
+    void submit(std::function<void()> f) {
+        { std::lock_guard<std::mutex> lk(mu_); q_.push_back(std::move(f)); }
+        cv_.notify_one();
+    }
+    int size() const { return (int)th_.size(); }
+  private:
+    SortPool() {
+        const unsigned hw = std::thread::hardware_concurrency();
+        const int n = (int)std::min<unsigned>(32u, std::max<unsigned>(4u, hw / 4u));
+        for (int t = 0; t < n; t++) th_.emplace_back([this] { run(); });
+    }
+    ~SortPool() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; }
+        cv_.notify_all();
+        for (std::thread &t : th_) t.join();
+    }
+    void run() {
+        for (;;) {
+            std::function<void()> f;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                f = std::move(q_.front());
+                q_.pop_front();
+            }
+            f();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::function<void()>> q_;
+    bool stop_ = false;
+};
+
+namespace {
+struct SortFrame { int *first, *last; int depth; };
+// what the threads of one sort share; helpers hold it by shared_ptr (one that is scheduled after the sort has finished finds nothing to do)
+struct SortJob {
+    ByScoreDesc comp;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<SortFrame> queue;
+    std::vector<int *> cuts;
+    long open_frames = 0;          // frames queued or being worked on
+    std::vector<int *> bounds;     // phase 2: regions of the final insertion sort
+    std::atomic<size_t> next{0}, done{0};
+    static constexpr long GRAIN = 2048;
+    void partitions() {            // phase 1: __introsort_loop over the queued frames
+        using namespace stdsort;
+        std::vector<SortFrame> local;
+        for (;;) {
+            SortFrame f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return !queue.empty() || open_frames == 0; });
+                if (queue.empty()) return;
+                f = queue.back();
+                queue.pop_back();
+            }
+            local.push_back(f);
+            while (!local.empty()) {
+                SortFrame g = local.back();
+                local.pop_back();
+                while (g.last - g.first > 16) {
+                    if (g.depth == 0) { heap_sort(g.first, g.last, comp); break; }
+                    --g.depth;
+                    int *mid = g.first + (g.last - g.first) / 2;
+                    move_median_to_first(g.first, g.first + 1, mid, g.last - 1, comp);
+                    int *cut = unguarded_partition(g.first + 1, g.last, g.first, comp);
+                    const SortFrame right{cut, g.last, g.depth};
+                    if (right.last - right.first >= GRAIN && cut - g.first >= GRAIN) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        queue.push_back(right);
+                        cuts.push_back(cut);
+                        open_frames++;
+                        cv.notify_one();
+                    } else if (right.last - right.first > 16) {
+                        local.push_back(right);
+                    }
+                    g.last = cut;
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--open_frames == 0) cv.notify_all();
+            }
+        }
+    }
+    void regions() {               // phase 2: __final_insertion_sort, region by region
+        for (;;) {
+            const size_t r = next.fetch_add(1);
+            if (r + 1 >= bounds.size()) return;
+            stdsort::insertion_sort(bounds[r], bounds[r + 1], comp);
+            if (done.fetch_add(1) + 2 == bounds.size()) { std::lock_guard<std::mutex> lk(mu); cv.notify_all(); }
+        }
+    }
+};
+}  // namespace
+
+void host_parallel_sort_scores(const float *score, int *a, long n, int nthreads) {
+    if (n <= 1) return;
+    auto job = std::make_shared<SortJob>();
+    job->comp = ByScoreDesc{score};
+    job->queue.push_back(SortFrame{a, a + n, stdsort::floor_log2(n) * 2});
+    job->open_frames = 1;
+    const int T = nthreads <= 1 ? 1 : (int)std::max<long>(1, std::min<long>(std::min<long>(nthreads, SortPool::get().size() + 1), n / SortJob::GRAIN));
+    for (int t = 1; t < T; t++) SortPool::get().submit([job] { job->partitions(); });
+    job->partitions();   // (returns when no frame is queued or being worked on: every partition is done)
+    {
+        std::unique_lock<std::mutex> lk(job->mu);
+        job->cv.wait(lk, [&] { return job->open_frames == 0; });
+    }
+    // every region start is a partition cut: nothing to its left sorts behind anything in it, and the insertion sort is stable
+    std::vector<int *> &cuts = job->cuts;
+    std::sort(cuts.begin(), cuts.end());
+    cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+    job->bounds.push_back(a);
+    for (int *c : cuts) if (c > a && c < a + n) job->bounds.push_back(c);
+    job->bounds.push_back(a + n);
+    const size_t nreg = job->bounds.size() - 1;
+    const int T2 = (int)std::max<size_t>(1, std::min<size_t>((size_t)T, nreg));
+    for (int t = 1; t < T2; t++) SortPool::get().submit([job] { job->regions(); });
+    job->regions();
+    std::unique_lock<std::mutex> lk(job->mu);
+    job->cv.wait(lk, [&] { return job->done.load() == nreg; });
+}
+
+static int rank_sort_threads() {
+    static const int v = [] { const char *e = getenv("SVDF_RANK_SORT_THREADS"); const int x = e ? atoi(e) : 0; return x > 0 ? x : 8; }();
+    return v;
+}
+// Work areas of a tied section's sort (100 K candidates: 1.3 MB), recycled.  Freed and re-allocated per section they are mmap / munmap
+// calls, and every munmap of a process that holds a GPU context runs the driver's MMU notifier, which stalls the device queues: a
+// process_rows call of 38 tiles with 7 tied sections took 5 ms or 40 ms depending on what malloc did with the blocks
+// (MALLOC_MMAP_THRESHOLD_ / MALLOC_TRIM_THRESHOLD_ = never: always 5 ms).
+struct TieWork {
+    std::vector<float> score;
+    std::vector<int> entry, where;
+    std::vector<char> banned;
+};
+static std::mutex g_tiework_mu;
+static std::vector<std::unique_ptr<TieWork>> g_tiework_free;
+static std::unique_ptr<TieWork> tiework_get() {
+    std::lock_guard<std::mutex> lk(g_tiework_mu);
+    if (g_tiework_free.empty()) return std::unique_ptr<TieWork>(new TieWork());
+    std::unique_ptr<TieWork> w = std::move(g_tiework_free.back());
+    g_tiework_free.pop_back();
+    return w;
+}
+static void tiework_put(std::unique_ptr<TieWork> w) {
+    std::lock_guard<std::mutex> lk(g_tiework_mu);
+    if (g_tiework_free.size() < 64) g_tiework_free.push_back(std::move(w));
+}
+
+static std::vector<int> host_sort_section(std::unique_ptr<TieWork> w, std::vector<int> banned_idx, std::vector<int> pos_item, int top_k) {
+    const std::vector<float> &score = w->score;
     const long n = (long)score.size();
-    std::vector<char> banned((size_t)n, 0);
+    std::vector<char> &banned = w->banned;
+    banned.assign((size_t)n, 0);
     for (int idx : banned_idx) banned[(size_t)idx] = 1;
-    std::vector<RankEntry> entry;
+    std::vector<int> &entry = w->entry;   // the ranked candidates in index order (the reference's entry vector, :749-766)
+    entry.clear();
     entry.reserve((size_t)n);
     for (long i = 0; i < n; i++)
-        if (!banned[(size_t)i]) entry.push_back(RankEntry{(int)i, score[(size_t)i]});
-    std::sort(entry.begin(), entry.end());
+        if (!banned[(size_t)i]) entry.push_back((int)i);
+    host_parallel_sort_scores(score.data(), entry.data(), (long)entry.size(), rank_sort_threads());
     std::vector<int> out;
     if (top_k > 0) {
-        for (int k = 0; k < top_k; k++) out.push_back(entry[(size_t)k].iid);
+        for (int k = 0; k < top_k; k++) out.push_back(entry[(size_t)k]);
     } else {
-        std::vector<int> where((size_t)n, 0);
-        for (size_t i = 0; i < entry.size(); i++) where[(size_t)entry[i].iid] = (int)i;
+        std::vector<int> &where = w->where;
+        where.assign((size_t)n, 0);
+        for (size_t i = 0; i < entry.size(); i++) where[(size_t)entry[i]] = (int)i;
         for (int p : pos_item) out.push_back(where[(size_t)p]);
     }
+    tiework_put(std::move(w));
     return out;
+}
+
+// a section's sort on a thread of the pool (it takes part in its own partitions, so it finishes even when every other helper is busy)
+static std::future<std::vector<int>> sort_section_async(std::unique_ptr<TieWork> w, std::vector<int> banned, std::vector<int> pos_item, int top_k) {
+    std::shared_ptr<TieWork> hold(w.release());   // (a copyable holder for the task; handed on as the unique owner when it runs)
+    auto task = std::make_shared<std::packaged_task<std::vector<int>()>>(
+        [hold, banned = std::move(banned), pos_item = std::move(pos_item), top_k]() mutable {
+            std::unique_ptr<TieWork> mine(new TieWork());
+            std::swap(*mine, *hold);
+            return host_sort_section(std::move(mine), std::move(banned), std::move(pos_item), top_k);
+        });
+    std::future<std::vector<int>> fut = task->get_future();
+    if (rank_sort_threads() <= 1) std::thread([task] { (*task)(); }).detach();   // (measurements: no pool at all)
+    else SortPool::get().submit([task] { (*task)(); });
+    return fut;
+}
+
+// scores of a tied section for the host's sort.  The slot's event has passed, so its scores are final: they are copied on a stream of their
+// own into a pinned buffer -- the pipeline's stream keeps running (a synchronise there drains every tile in flight), and a pageable
+// destination would have the runtime pin and unpin its pages around the copy
+std::unique_ptr<TieWork> Ranker::tie_scores(const float *d_src, long n) {
+    if (!tie_stream_) RCHECK(hipStreamCreateWithFlags(&tie_stream_, hipStreamNonBlocking));
+    if ((size_t)n > tie_pin_floats_) {
+        if (tie_pin_) (void)hipHostFree(tie_pin_);
+        tie_pin_ = nullptr;
+        tie_pin_floats_ = (size_t)n + 1024;
+        RCHECK(hipHostMalloc(reinterpret_cast<void **>(&tie_pin_), tie_pin_floats_ * sizeof(float), hipHostMallocDefault));
+    }
+    RCHECK(hipMemcpyAsync(tie_pin_, d_src, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, tie_stream_));
+    RCHECK(hipStreamSynchronize(tie_stream_));
+    std::unique_ptr<TieWork> w = tiework_get();
+    w->score.assign(tie_pin_, tie_pin_ + n);
+    return w;
 }
 
 // oldest section in flight -> its results (or the future of its host sort) appended to the result chunks
@@ -477,20 +695,29 @@ void Ranker::resolve() {
     pending_.pop_front();
     RankSlot &L = slots_[Q.slot];
     hipStream_t st = eng_->stream_;
-    RCHECK(hipEventSynchronize(L.ev));
+    {
+        const auto t0_ = std::chrono::steady_clock::now();
+        // poll: a blocking wait sleeps on an interrupt, and the wake-up measured up to ~0.4 ms per tile here (a process_rows call of 38 tiles
+        // took 5 ms or 40 ms depending on it); the pipeline is a few tiles deep, so the event is usually a few microseconds away
+        for (;;) {
+            const hipError_t e_ = hipEventQuery(L.ev);
+            if (e_ == hipSuccess) break;
+            if (e_ != hipErrorNotReady) RCHECK(e_);
+            __builtin_ia32_pause();
+        }
+        event_wait_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
+    }
     const long n = Q.n;
     RankChunk C;
     auto host_sort = [&]() {
-        std::vector<float> score((size_t)n);
-        RCHECK(hipMemcpyAsync(score.data(), L.d_score.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
-        RCHECK(hipStreamSynchronize(st));   // the slot's item_score is free again after this
+        std::unique_ptr<TieWork> score = tie_scores(L.d_score.p, n);   // the slot's item_score is free again after this
         n_host_sorts_++;
         size_t running = 0;
         for (RankChunk &c : chunks_) running += c.pending ? 1 : 0;
         if (running >= host_sort_threads())   // bound the helper threads: wait for the oldest unfinished sort
             for (RankChunk &c : chunks_) if (c.pending) { c.vals = c.fut.get(); c.pending = false; break; }
         C.pending = true;
-        C.fut = std::async(std::launch::async, host_sort_section, std::move(score), Q.banned, Q.pos_item, top_k_);
+        C.fut = sort_section_async(std::move(score), Q.banned, Q.pos_item, top_k_);
     };
     if (Q.nsec > 0) {   // a tile: its sections in order, each with its own counters; a tie sends that one section to the host's sort
         const int *cnt = reinterpret_cast<const int *>(L.back);
@@ -509,17 +736,17 @@ void Ranker::resolve() {
             }
             for (int j = 0; j < npos; j++) ties = ties || cnt[(size_t)2 * p0 + npos + j] != 0;
             if (ties) {
-                std::vector<float> score((size_t)n);
-                RCHECK(hipMemcpyAsync(score.data(), L.d_score.p + (size_t)u * cap_items, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, st));
-                RCHECK(hipStreamSynchronize(st));
-                if (!Q.tile_take.empty()) keys_to_scores(score);   // top_k tiles hold sort keys
+                const auto t0_ = std::chrono::steady_clock::now();
+                std::unique_ptr<TieWork> score = tie_scores(L.d_score.p + (size_t)u * cap_items, n);
+                tie_copy_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
+                if (!Q.tile_take.empty()) keys_to_scores(score->score);   // top_k tiles hold sort keys
                 n_host_sorts_++;
                 size_t running = 0;
                 for (RankChunk &c : chunks_) running += c.pending ? 1 : 0;
                 if (running >= host_sort_threads())
                     for (RankChunk &c : chunks_) if (c.pending) { c.vals = c.fut.get(); c.pending = false; break; }
                 Cu.pending = true;
-                Cu.fut = std::async(std::launch::async, host_sort_section, std::move(score), Q.tile_ban[(size_t)u], Q.tile_pos[(size_t)u], top_k_);
+                Cu.fut = sort_section_async(std::move(score), Q.tile_ban[(size_t)u], Q.tile_pos[(size_t)u], top_k_);
             } else {
                 for (int j = 0; j < npos; j++) Cu.vals.push_back(cnt[(size_t)2 * p0 + j]);
             }
@@ -550,7 +777,12 @@ void Ranker::resolve() {
 void Ranker::flush_chunks() {
     while (!chunks_.empty()) {
         RankChunk &c = chunks_.front();
-        if (c.pending) { c.vals = c.fut.get(); c.pending = false; }
+        if (c.pending) {
+            const auto t0_ = std::chrono::steady_clock::now();
+            c.vals = c.fut.get();
+            c.pending = false;
+            tie_wait_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();
+        }
         for (int v : c.vals) { if (out_n_ < out_cap_ && out_ptr_) out_ptr_[out_n_] = v; out_n_++; }
         chunks_.pop_front();
     }

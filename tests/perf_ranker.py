@@ -81,6 +81,7 @@ def main():
     got = r.process_rows(bulk)
     dt = (time.time() - t0) / max(1, a.sections - 1)
     out["gpu_bulk"] = {"ms_per_section": dt * 1e3, "sections_per_s": 1.0 / dt, "host_sorts": r.counter(1), "tiles": r.counter(3),
+                       "tie_copy_ms_total": r.counter(4) / 1e6, "tie_wait_ms_total": r.counter(5) / 1e6, "event_wait_ms_total": r.counter(6) / 1e6, "flush_ms_total": r.counter(7) / 1e6,
                        "GBps": out["gpu"]["bytes_per_section"] / dt / 1e9, "frac_of_8TBps": out["gpu"]["bytes_per_section"] / dt / 8e12,
                        "identical_to_per_section_calls": bool(np.array_equal(got, res["gpu"]))}
     # the same call with one scoring pass per section (amd:rank_tile = 0: the round-2 pipeline)

@@ -211,3 +211,35 @@ def test_restated_std_sort_equals_the_library_sort_position_for_position():
         mine, lib = sa.debug_sort_labels(lab)
         np.testing.assert_array_equal(mine, lib)
         assert np.all(np.diff(lab[mine]) >= 0) and sorted(mine.tolist()) == list(range(len(lab)))
+
+
+def test_threaded_ranker_sort_equals_std_sort_on_the_entry_struct():
+    """Sections whose scores tie are finished by the reference's own ordering step -- std::sort over the Entry vector
+    (apex_svd_base.h:617-624, :767) -- with its partitions spread over host threads (svdf_ranker.cpp: host_parallel_sort_scores).  The
+    permutation (tied scores included) must be the library's: few distinct values, all equal, sorted / reversed inputs, Musser's
+    median-of-3 killer (heap-sort branch), sizes around the sharing grain, 1 ... 16 threads."""
+    rng = np.random.default_rng(5)
+    cases_ = []
+    for n in (0, 1, 2, 15, 16, 17, 100, 2047, 2048, 4097, 30000, 100000):
+        cases_.append(rng.normal(size=n).astype(np.float32))
+        cases_.append(rng.integers(0, 3, size=n).astype(np.float32))
+        cases_.append(np.round(rng.normal(size=n), 1).astype(np.float32))
+        cases_.append(np.zeros(n, np.float32))
+        cases_.append(np.arange(n, dtype=np.float32))
+        cases_.append(np.arange(n, dtype=np.float32)[::-1].copy())
+
+    def killer(n):
+        k = n // 2
+        a = np.zeros(n, np.float32)
+        for i in range(1, k + 1):
+            if i % 2 == 1:
+                a[i - 1] = i
+                a[i] = k + i
+            a[k + i - 1] = 2 * i
+        return -a   # (descending comparator)
+    for n in (4096, 30000, 100000):
+        cases_.append(killer(n))
+    for j, sc in enumerate(cases_):
+        for threads in ((1, 8) if j % 3 else (2, 5, 16)):
+            mine, lib = sa.debug_sort_scores(sc, threads)
+            np.testing.assert_array_equal(mine, lib)
