@@ -158,7 +158,7 @@ int svdf_predict_dataset(svdf_trainer *t, svdf_dataset *ds, float *out); /* out[
 /* dataset facts: 0 num_row, 1 number of conflict-free batches, 2 largest batch, 3 kernel kind
  * (0 = basicMF fused kernel, 1 = general sparse kernel, 2 = few-row fused kernel, 3 = SVD++ user units),
  * 4 algorithmic bytes per pass, 5 number of user units, 6 units on the register-resident
- * fast path */
+ * fast path, 7 a digest of the host-resident schedule (level boundaries, fast-path split, unit order) */
 int64_t svdf_dataset_info(const svdf_dataset *ds, int what);
 
 /* ---- multi-GPU support: item-side parameters are replicated, each rank trains its
@@ -306,7 +306,8 @@ int svdf_synchronize(svdf_trainer *t);
  * device: values the host libm decided (next to a float rounding boundary) / rand() draws consumed (0 = the host loop ran), 15 conflict-free
  * levels executed inside chained launches, 16 .. 20 the decision of `amd:step = auto` for the data set built last (16: 0 none, 1 exact levels
  * kept, 2 window step chosen, 3 exact kept because the window step does not cover the configuration / the rows; 17 conflict-free levels;
- * 18 / 19 dag bound and stream model in microseconds; 20 windows), 21 passes issued as one launch by the in-launch DAG executor */
+ * 18 / 19 dag bound and stream model in microseconds; 20 windows), 21 passes issued as one launch by the in-launch DAG executor,
+ * 22 / 23 passes over hot-row units / runs, 24 microseconds the schedule of the last user-unit data set took, 25 whether the device built it */
 int64_t svdf_counter(svdf_trainer *t, int what);
 /* tuning knobs (not part of the reference surface; none changes a result bit): "stage_window" (instances staged
  * before an automatic flush), "async_flush" (background scheduling of full windows), "groups_per_wave",

@@ -251,6 +251,14 @@ int64_t svdf_dataset_info(const svdf_dataset *ds, int what) {
     case 4: return ds->d->algorithmic_bytes;
     case 5: return ds->d->num_units;
     case 6: return ds->d->num_simple_units;
+    case 7: {   // FNV-1a over the host-resident schedule (level_ptr, level_mid, order): equal schedules <=> equal digests (tests)
+        uint64_t h = 1469598103934665603ull;
+        auto mix = [&h](uint64_t v) { for (int b = 0; b < 8; b++) { h ^= (v >> (8 * b)) & 0xFFu; h *= 1099511628211ull; } };
+        for (long v : ds->d->sched.level_ptr) mix((uint64_t)v);
+        for (long v : ds->d->sched.level_mid) mix((uint64_t)v);
+        for (int v : ds->d->sched.order) mix((uint64_t)(unsigned)v);
+        return (int64_t)(h >> 1);
+    }
     default: return -1;
     }
 }

@@ -188,6 +188,8 @@ int64_t Engine::counter(int what) const {
     case 20: return auto_last_.windows;
     case 23: return n_runs_passes_;     // passes over data sets scheduled as runs of an item's consecutive ratings (svdf_runs.cpp)
     case 22: return n_pivot_passes_;    // passes over data sets with hot rows walked as units (svdf_pivot.cpp)
+    case 24: return unit_sched_us_;     // microseconds the last user-unit data set's schedule took (levels, order, fast-path flags)
+    case 25: return unit_sched_on_device_ ? 1 : 0;   // ... built by svdf_k_sched.hip's device_schedule_units (1) or the host scan (0)
     case 21: return n_stream_passes_;   // passes issued as ONE launch by the in-launch DAG executor (knob stream_exec)
     default: return -1;
     }

@@ -101,12 +101,18 @@ Dataset *Engine::dataset_from_blocks(long num_block, const int *extend_tag, cons
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->kind = 3; ds->num_row = staged_.num_row();
     if (!staged_units_.empty()) staged_units_.back().flags |= UNIT_SAVE;
-    LevelTracker saved;
-    std::swap(saved, tracker_);   // a dataset pass is preceded by a flush: schedule against an empty tracker
     std::vector<DevUnit> du;
-    schedule_units(0, ds->sched, du);
-    std::swap(saved, tracker_);
-    upload_units(ds->unitdev, ds->sched, du);
+    const auto sched_t0 = std::chrono::steady_clock::now();
+    const bool on_device = schedule_units_on_device(ds->unitdev, ds->sched, du);
+    if (!on_device) {
+        LevelTracker saved;
+        std::swap(saved, tracker_);   // a dataset pass is preceded by a flush: schedule against an empty tracker
+        schedule_units(0, ds->sched, du);
+        std::swap(saved, tracker_);
+    }
+    unit_sched_us_ = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - sched_t0).count();
+    unit_sched_on_device_ = on_device;
+    upload_units(ds->unitdev, ds->sched, du, on_device);
     long nfb = (long)staged_fb_index_.size();
     const long nb = mp_.no_user_bias ? 1 : 2;
     ds->algorithmic_bytes = ds->num_row * (8L * mp_.num_factor * 2 + 8 * nb + 16 + 16) + nfb * (12L * mp_.num_factor + 20);

@@ -557,7 +557,11 @@ class Engine {
     std::string worker_error_;
     // levels + DevUnit records for the staged units (marks UNIT_SIMPLE); returns the schedule
     void schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du);
-    void upload_units(UnitDev &dst, const Schedule &sched, const std::vector<DevUnit> &du);
+    void upload_unit_arrays(UnitDev &dst);
+    void upload_units(UnitDev &dst, const Schedule &sched, const std::vector<DevUnit> &du, bool scheduled_on_device = false);
+    bool schedule_units_on_device(UnitDev &dst, Schedule &sched, std::vector<DevUnit> &du);
+    int64_t unit_sched_us_ = 0;
+    bool unit_sched_on_device_ = false;   // resident user-group data sets (svdf_k_sched.hip)
     std::vector<int64_t> stamp_;   // scratch for per-unit distinctness checks: stamp_epoch_ + unit index of the last toucher
     int64_t stamp_epoch_ = 0;
     // reusable device staging buffers

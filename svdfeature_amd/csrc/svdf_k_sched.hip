@@ -443,4 +443,338 @@ long device_schedule(const SchedColumns &in, int *order_out, std::vector<long> &
     return nlevels;
 }
 
+// =============================================================================== user units (SVD++ blocks): lists of rows per unit
+// Engine::schedule_units' scan (svdf_sched.cpp; the reference walks a user's blocks in file order, apex_svd_base.h:568-582) as the same
+// frontier peel: a unit touches the rows of its instances (global biases, its user row, item rows), the rows of its feedback list and --
+// when it loads or saves the trainer's feedback registers -- one state resource.  Entries are a list per unit (eptr), not K columns:
+//   * a row met twice inside a unit is ONE dependency (the later entries are taken off the unit's count and get no successor); the same
+//     neighbour test yields what the host finds with its stamp array: an item rated twice inside a simple unit (row_fresh: the wave kernel
+//     reads that row at use) and a feedback id listed twice (the unit is not simple),
+//   * the user entry of every row but the first is not emitted when the rows have the simple shape (it would be the same row 100 times),
+//   * retiring a unit walks its list with one WAVE (lanes stride the entries); narrow frontiers are chained inside one launch as above.
+namespace {
+
+enum { UST_ANY_FRESH = 5, UST_NONUNIT = 6 };
+
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_us_count(const UnitSchedIn U, unsigned *cnt) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < U.n; u += stride) {
+        const DevUnit un = U.units[u];
+        cnt[u] = (unsigned)(U.row_ptr[3 * (long)un.row_end] - U.row_ptr[3 * (long)un.row_begin]) + (unsigned)(un.fb_end - un.fb_begin) +
+                 ((un.flags & (UNIT_LOAD | UNIT_SAVE)) ? 1u : 0u);
+    }
+}
+
+// one wave per unit: resource keys of its entries, the entry's owner, the unit's dependency count; the shape tests of the simple path
+__global__ __launch_bounds__(256) void k_us_fill(const UnitSchedIn U, const unsigned *eptr, unsigned absent_key, unsigned *keys, unsigned *vals,
+                                                 int *owner, int *remaining, int *first_fail, unsigned char *nonunit) {
+    const int lane = threadIdx.x & 63;
+    const long nwaves = (long)gridDim.x * (blockDim.x >> 6);
+    for (long u = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); u < U.n; u += nwaves) {
+        const DevUnit un = U.units[u];
+        const unsigned e0 = eptr[u];
+        const int pf = U.row_ptr[3 * (long)un.row_begin];
+        const int nrow_ent = U.row_ptr[3 * (long)un.row_end] - pf;
+        auto shape_of = [&](int r, unsigned uid0) {
+            const int *p = U.row_ptr + 3 * (long)r;
+            return p[1] == p[0] && p[2] == p[1] + 1 && p[3] == p[2] + 1 && U.index[p[1]] == uid0;
+        };
+        unsigned uid0 = 0;
+        bool shape0 = false;
+        if (un.row_end > un.row_begin) { uid0 = U.index[pf]; shape0 = shape_of(un.row_begin, uid0); }
+        int ff = 0x7FFFFFFF, fn = 0x7FFFFFFF, live = 0;
+        for (int r = un.row_begin + lane; r < un.row_end; r += 64) {
+            const int *p = U.row_ptr + 3 * (long)r;
+            const bool shape = shape_of(r, uid0);
+            if (!shape) ff = min(ff, r);
+            else if (U.value[p[1]] != 1.0f || U.value[p[2]] != 1.0f) fn = min(fn, r);
+            for (int j = p[0]; j < p[3]; j++) {
+                const unsigned id = U.index[j];
+                unsigned key;
+                if (j < p[1]) key = U.goff + id;
+                else if (j < p[2]) key = (shape0 && shape && r != un.row_begin) ? absent_key : U.user_off + id;
+                else key = U.item_off + id;
+                const unsigned e = e0 + (unsigned)(j - pf);
+                keys[e] = key; vals[e] = e; owner[e] = (int)u;
+                live += key != absent_key;
+            }
+        }
+        for (int j = un.fb_begin + lane; j < un.fb_end; j += 64) {
+            const unsigned e = e0 + (unsigned)nrow_ent + (unsigned)(j - un.fb_begin);
+            keys[e] = U.fb_off + U.fb_index[j]; vals[e] = e; owner[e] = (int)u;
+            live++;
+        }
+        if (lane == 0 && (un.flags & (UNIT_LOAD | UNIT_SAVE))) {
+            const unsigned e = e0 + (unsigned)nrow_ent + (unsigned)(un.fb_end - un.fb_begin);
+            keys[e] = U.state_res; vals[e] = e; owner[e] = (int)u;
+            live++;
+        }
+        ff = wave_min_i(ff); fn = wave_min_i(fn); live = wave_sum_i(live);
+        if (lane == 0) { first_fail[u] = ff; nonunit[u] = fn < ff ? 1 : 0; remaining[u] = live; }
+    }
+}
+
+// sorted (row, entry): successor unit of every entry, one credit for the unit that heads a row, repeated rows inside a unit
+__global__ __launch_bounds__(256) void k_us_links(const UnitSchedIn U, const unsigned *eptr, const unsigned *keys, const unsigned *vals, long m,
+                                                  unsigned absent_key, const int *owner, const int *first_fail, int *succ, int *remaining,
+                                                  unsigned char *fbdup, unsigned char *fresh, unsigned *state) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const unsigned key = keys[j];
+        if (key == absent_key) continue;
+        const unsigned e = vals[j];
+        const int u = owner[e];
+        const bool prev_same = j > 0 && keys[j - 1] == key;
+        if (prev_same && owner[vals[j - 1]] == u) {   // this row again inside the unit
+            atomicSub(&remaining[u], 1);
+            if (key >= U.item_off && key - U.item_off < U.num_item) {
+                const DevUnit un = U.units[u];
+                const int jc = U.row_ptr[3 * (long)un.row_begin] + (int)(e - eptr[u]);
+                int lo = un.row_begin, hi = un.row_end - 1;   // the row holding CSR entry jc
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (U.row_ptr[3 * (long)mid] <= jc) lo = mid; else hi = mid - 1;
+                }
+                if (lo < first_fail[u]) { fresh[lo] = 1; state[UST_ANY_FRESH] = 1u; }
+            } else if (key >= U.fb_off && key - U.fb_off < U.num_fb) {
+                fbdup[u] = 1;
+            }
+            continue;
+        }
+        if (!prev_same) atomicSub(&remaining[u], 1);
+        long jj = j + 1;
+        while (jj < m && keys[jj] == key && owner[vals[jj]] == u) jj++;
+        succ[e] = (jj < m && keys[jj] == key) ? owner[vals[jj]] : -1;
+    }
+}
+
+// the fast-path flag of every unit (Engine::schedule_units: simple && use_simple_units && ...) and the key of the in-level partition
+__global__ __launch_bounds__(256) void k_us_simple(const UnitSchedIn U, const int *first_fail, const unsigned char *fbdup, const unsigned char *nonunit,
+                                                   unsigned char *simple_out, unsigned *sort_key, unsigned *state) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long u = (long)blockIdx.x * blockDim.x + threadIdx.x; u < U.n; u += stride) {
+        const DevUnit un = U.units[u];
+        const bool rows = un.row_end > un.row_begin;
+        if (U.simple_ok && rows && nonunit[u]) state[UST_NONUNIT] = 1u;
+        const bool fast = U.simple_ok && rows && first_fail[u] == 0x7FFFFFFF && !fbdup[u] && U.fast_ok;
+        simple_out[u] = fast ? 1 : 0;
+        sort_key[u] = fast ? 0u : 1u;
+    }
+}
+
+__global__ __launch_bounds__(PEEL_THREADS) void k_us_seed(long n, const int *remaining, int *order, int *level, unsigned *state, unsigned *level_end) {
+    const int lane = threadIdx.x & 63;
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long rounds = (n + stride - 1) / stride;
+    for (long it = 0; it < rounds; it++) {
+        const long u = it * stride + (long)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool ready = u < n && remaining[u] == 0;
+        const unsigned long long mask = __ballot(ready);
+        if (mask) {
+            unsigned base = 0;
+            if (lane == 0) base = atomicAdd(&state[ST_CURSOR], (unsigned)__popcll(mask));
+            base = __shfl(base, 0);
+            if (ready) { level[u] = 1; order[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = (int)u; }
+        }
+    }
+    __shared__ Stage sh;
+    publish_level_end(sh, state, level_end, 0);
+}
+
+// level l+1 from level l: one wave per retiring unit, appends through one atomic per wave and 64 entries
+__global__ __launch_bounds__(PEEL_THREADS) void k_us_peel(int l, const unsigned *eptr, const int *succ, int *remaining, int *order, int *level,
+                                                          unsigned *state, unsigned *level_end) {
+    const int lane = threadIdx.x & 63;
+    const unsigned begin = level_end[l - 1], end = level_end[l];
+    const unsigned nwaves = gridDim.x * (blockDim.x >> 6);
+    for (unsigned i = begin + blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); i < end; i += nwaves) {
+        const int u = order[i];
+        const unsigned e0 = eptr[u], e1 = eptr[u + 1];
+        for (unsigned eb = e0; eb < e1; eb += 64) {
+            const unsigned e = eb + (unsigned)lane;
+            const int v = e < e1 ? succ[e] : -1;
+            const bool ready = v >= 0 && atomicSub(&remaining[v], 1) == 1;
+            const unsigned long long mask = __ballot(ready);
+            if (mask) {
+                unsigned base = 0;
+                if (lane == 0) base = atomicAdd(&state[ST_CURSOR], (unsigned)__popcll(mask));
+                base = __shfl(base, 0);
+                if (ready) { level[v] = l + 1; order[base + (unsigned)__popcll(mask & ((1ull << lane) - 1ull))] = v; }
+            }
+        }
+    }
+    __shared__ Stage sh;
+    publish_level_end(sh, state, level_end, l);
+}
+
+// narrow frontiers: ONE workgroup peels level after level, the frontier in LDS (k_sched_peel_chain for lists)
+__global__ __launch_bounds__(PEEL_THREADS) void k_us_peel_chain(int l, int max_levels, const unsigned *eptr, const int *succ, int *remaining, int *order,
+                                                                int *level, unsigned *state, unsigned *level_end) {
+    __shared__ int fr[2][CHAIN_CAP];
+    __shared__ int nnext;
+    __shared__ unsigned cursor;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
+    unsigned begin = level_end[l - 1], end = level_end[l];
+    int ncur = (int)(end - begin);
+    if (ncur > CHAIN_CAP || ncur == 0) {
+        if (threadIdx.x == 0) state[ST_NEXT_LEVEL] = (unsigned)l;
+        return;
+    }
+    for (int i = threadIdx.x; i < ncur; i += blockDim.x) fr[0][i] = order[begin + (unsigned)i];
+    if (threadIdx.x == 0) { nnext = 0; cursor = end; }
+    __syncthreads();
+    int cur = 0, done = 0;
+    while (done < max_levels && ncur > 0 && ncur <= CHAIN_CAP) {
+        const unsigned base = cursor;
+        for (int i = wv; i < ncur; i += nwv) {
+            const int u = fr[cur][i];
+            const unsigned e0 = eptr[u], e1 = eptr[u + 1];
+            for (unsigned eb = e0; eb < e1; eb += 64) {
+                const unsigned e = eb + (unsigned)lane;
+                const int v = e < e1 ? succ[e] : -1;
+                const bool ready = v >= 0 && atomicSub(&remaining[v], 1) == 1;
+                const unsigned long long mask = __ballot(ready);
+                if (mask) {
+                    int pos0 = 0;
+                    if (lane == 0) pos0 = atomicAdd(&nnext, __popcll(mask));
+                    pos0 = __shfl(pos0, 0);
+                    if (ready) {
+                        const int pos = pos0 + __popcll(mask & ((1ull << lane) - 1ull));
+                        level[v] = l + 1;
+                        order[base + (unsigned)pos] = v;
+                        if (pos < CHAIN_CAP) fr[cur ^ 1][pos] = v;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        const int made = nnext;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            cursor = base + (unsigned)made;
+            level_end[l + 1] = cursor;
+            nnext = 0;
+        }
+        __syncthreads();
+        l++; done++;
+        cur ^= 1;
+        ncur = made;
+    }
+    if (threadIdx.x == 0) {
+        state[ST_CURSOR] = cursor;
+        state[ST_NEXT_LEVEL] = (unsigned)l;
+        if (ncur > 0) state[ST_NLEVELS] = (unsigned)l; else state[ST_NLEVELS] = (unsigned)(l - 1);
+    }
+}
+
+}  // namespace
+
+long device_schedule_units(const UnitSchedIn &in, int *order_out, unsigned char *simple_out, unsigned char *fresh_out, UnitSchedOut &out, hipStream_t st) {
+    const long n = in.n;
+    out.level_ptr.assign(1, 0);
+    out.max_level_size = 0; out.any_fresh = false; out.unit_values = true;
+    if (n == 0) return 0;
+    if (n >= 0x7FFFFFFFL) throw std::runtime_error("device scheduler: too many units");
+    Scratch S;
+    unsigned *cnt = S.get<unsigned>((size_t)n), *eptr = S.get<unsigned>((size_t)n + 1);
+    hipLaunchKernelGGL(k_us_count, dim3(grid_for_n(n)), dim3(256), 0, st, in, cnt);
+    void *scan_tmp = nullptr;
+    size_t scan_bytes = 0;
+    long m = 0;
+    try { m = device_exclusive_scan_u32(cnt, eptr, n, &scan_tmp, &scan_bytes, st); }
+    catch (...) { if (scan_tmp) (void)hipFree(scan_tmp); throw; }
+    if (scan_tmp) (void)hipFree(scan_tmp);
+    if (m >= 0xFFFFFFF0L) throw std::runtime_error("device scheduler: more than 2^32 row entries in one data set");
+    {
+        const unsigned mm = (unsigned)m;
+        SCHK(hipMemcpyAsync(eptr + n, &mm, sizeof(unsigned), hipMemcpyHostToDevice, st));
+        SCHK(hipStreamSynchronize(st));
+    }
+    const unsigned absent_key = in.state_res + 1;
+    const int res_bits = bits_for(absent_key);
+    const size_t me = (size_t)(m > 0 ? m : 1);
+    unsigned *keys_a = S.get<unsigned>(std::max(me, (size_t)n)), *keys_b = S.get<unsigned>(std::max(me, (size_t)n));
+    unsigned *vals_a = S.get<unsigned>(std::max(me, (size_t)n)), *vals_b = S.get<unsigned>(me);
+    int *owner = S.get<int>(me), *succ = S.get<int>(me);
+    int *remaining = S.get<int>((size_t)n), *level = S.get<int>((size_t)n), *first_fail = S.get<int>((size_t)n), *frontier = S.get<int>((size_t)n);
+    unsigned char *nonunit = S.get<unsigned char>((size_t)n), *fbdup = S.get<unsigned char>((size_t)n);
+    unsigned *sort_key = S.get<unsigned>((size_t)n);
+    unsigned *state = S.get<unsigned>(ST_WORDS);
+    const long level_cap = n + 2;
+    unsigned *level_end = S.get<unsigned>((size_t)level_cap);
+    SCHK(hipMemsetAsync(state, 0, ST_WORDS * sizeof(unsigned), st));
+    SCHK(hipMemsetAsync(succ, 0xFF, me * sizeof(int), st));
+    SCHK(hipMemsetAsync(fbdup, 0, (size_t)n, st));
+    SCHK(hipMemsetAsync(level_end, 0, sizeof(unsigned), st));
+    if (in.nrow > 0) SCHK(hipMemsetAsync(fresh_out, 0, (size_t)in.nrow, st));
+    {
+        long g = (n + 3) / 4;
+        if (g > 8192) g = 8192;
+        hipLaunchKernelGGL(k_us_fill, dim3((unsigned)g), dim3(256), 0, st, in, eptr, absent_key, keys_a, vals_a, owner, remaining, first_fail, nonunit);
+    }
+    if (m > 0) {
+        size_t tmp_bytes = 0;
+        SCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0u, (unsigned)res_bits, st));
+        void *tmp = S.get<char>(tmp_bytes);
+        SCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_a, keys_b, vals_a, vals_b, (size_t)m, 0u, (unsigned)res_bits, st));
+        hipLaunchKernelGGL(k_us_links, dim3(grid_for_n(m)), dim3(256), 0, st, in, eptr, keys_b, vals_b, m, absent_key, owner, first_fail, succ, remaining,
+                           fbdup, fresh_out, state);
+    }
+    hipLaunchKernelGGL(k_us_simple, dim3(grid_for_n(n)), dim3(256), 0, st, in, first_fail, fbdup, nonunit, simple_out, sort_key, state);
+    const int peel_grid = 64;
+    hipLaunchKernelGGL(k_us_seed, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, n, remaining, frontier, level, state, level_end);
+    unsigned host_state[ST_WORDS];
+    long l = 1;
+    long placed_before = -1;
+    for (;;) {
+        hipLaunchKernelGGL(k_us_peel_chain, dim3(1), dim3(PEEL_THREADS), 0, st, (int)l, 1 << 20, eptr, succ, remaining, frontier, level, state, level_end);
+        SCHK(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
+        SCHK(hipStreamSynchronize(st));
+        l = (long)host_state[ST_NEXT_LEVEL];
+        if ((long)host_state[ST_CURSOR] >= n) break;
+        if ((long)host_state[ST_CURSOR] == placed_before) throw std::runtime_error("device scheduler: the dependency graph did not drain");
+        placed_before = (long)host_state[ST_CURSOR];
+        if (l + 1 >= level_cap) throw std::runtime_error("device scheduler: the dependency graph did not drain");
+        const long wide = 32;
+        for (long j = 0; j < wide && l + 1 < level_cap; j++, l++)
+            hipLaunchKernelGGL(k_us_peel, dim3(peel_grid), dim3(PEEL_THREADS), 0, st, (int)l, eptr, succ, remaining, frontier, level, state, level_end);
+    }
+    SCHK(hipMemcpyAsync(host_state, state, sizeof(host_state), hipMemcpyDeviceToHost, st));
+    SCHK(hipStreamSynchronize(st));
+    const long nlevels = (long)host_state[ST_NLEVELS];
+    out.any_fresh = host_state[UST_ANY_FRESH] != 0;
+    out.unit_values = host_state[UST_NONUNIT] == 0;
+    std::vector<unsigned> ends((size_t)nlevels + 1);
+    SCHK(hipMemcpyAsync(ends.data(), level_end, ((size_t)nlevels + 1) * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    // final order: by (level, fast-path units first, file position)
+    const int lvl_bits = bits_for((unsigned long long)nlevels);
+    if (lvl_bits + 1 > 32) throw std::runtime_error("device scheduler: too many levels");
+    hipLaunchKernelGGL(k_sched_final_keys<unsigned>, dim3(grid_for_n(n)), dim3(256), 0, st, n, level, sort_key, 1, keys_a, vals_a);
+    {
+        size_t tmp_bytes = 0;
+        SCHK(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys_a, keys_b, vals_a, (unsigned *)order_out, (size_t)n, 0u, (unsigned)(lvl_bits + 1), st));
+        void *tmp = S.get<char>(tmp_bytes);
+        SCHK(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys_a, keys_b, vals_a, (unsigned *)order_out, (size_t)n, 0u, (unsigned)(lvl_bits + 1), st));
+    }
+    SCHK(hipStreamSynchronize(st));
+    SCHK(hipGetLastError());
+    out.level_ptr.resize((size_t)nlevels + 1);
+    for (long j = 0; j <= nlevels; j++) {
+        out.level_ptr[(size_t)j] = (long)ends[(size_t)j];
+        if (j > 0) out.max_level_size = std::max(out.max_level_size, out.level_ptr[(size_t)j] - out.level_ptr[(size_t)j - 1]);
+    }
+    return nlevels;
+}
+
 }  // namespace svdf

@@ -215,6 +215,26 @@ struct SchedColumns {
     unsigned sort_key_max;
 };
 long device_schedule(const SchedColumns &in, int *order_out, std::vector<long> &level_ptr, long *max_level_size, hipStream_t st);
+// ---- the same for USER UNITS (SVD++ blocks; Engine::schedule_units, svdf_sched.cpp): unit u touches the rows of its instances
+// [row_begin, row_end) of the staged CSR (global ids at goff, user ids at user_off, item ids at item_off), its feedback list at fb_off and,
+// with UNIT_LOAD / UNIT_SAVE, the state resource.  Also decides the host scan's by-products: which units take the one-wave-per-user kernel
+// (simple_out, 0 / 1 per unit), which rows repeat an item inside such a unit (fresh_out, per row), whether every simple unit has unit values.
+struct UnitSchedIn {
+    long n, nrow;
+    const DevUnit *units;          // device, file order (flags without UNIT_SIMPLE)
+    const int *row_ptr;            // device, 3 * nrow + 1
+    const unsigned *index;
+    const float *value;
+    const unsigned *fb_index;
+    unsigned goff, user_off, item_off, fb_off, num_item, num_fb, state_res;   // resource ids; state_res = the last one
+    int simple_ok, fast_ok;
+};
+struct UnitSchedOut {
+    std::vector<long> level_ptr;
+    long max_level_size;
+    bool any_fresh, unit_values;
+};
+long device_schedule_units(const UnitSchedIn &in, int *order_out, unsigned char *simple_out, unsigned char *fresh_out, UnitSchedOut &out, hipStream_t st);
 void device_gather_u32(const unsigned *src, const int *order, unsigned *dst, long n, hipStream_t st);
 void device_gather_f32(const float *src, const int *order, float *dst, long n, hipStream_t st);
 void device_scatter_f32(const float *src, const int *order, float *dst, long n, hipStream_t st);   // dst[order[s]] = src[s]

@@ -388,15 +388,20 @@ void Engine::schedule_units(int base, Schedule &sched, std::vector<DevUnit> &du)
         sched.level_mid[l] = sched.level_ptr[l] + (long)(m - b);
     }
 }
-void Engine::upload_units(UnitDev &d, const Schedule &sched, const std::vector<DevUnit> &du) {
+void Engine::upload_unit_arrays(UnitDev &d) {
     d.label.upload(staged_.row_label.data(), staged_.row_label.size(), stream_);
     d.ptr.upload(staged_.row_ptr.data(), staged_.row_ptr.size(), stream_);
     d.index.upload(staged_.feat_index.data(), staged_.feat_index.size(), stream_);
     d.value.upload(staged_.feat_value.data(), staged_.feat_value.size(), stream_);
     d.fbidx.upload(staged_fb_index_.data(), staged_fb_index_.size(), stream_);
     d.fbval.upload(staged_fb_value_.data(), staged_fb_value_.size(), stream_);
+}
+void Engine::upload_units(UnitDev &d, const Schedule &sched, const std::vector<DevUnit> &du, bool scheduled_on_device) {
+    if (!scheduled_on_device) {
+        upload_unit_arrays(d);
+        d.order.upload(sched.order.data(), sched.order.size(), stream_);
+    }
     d.units.upload(du.data(), du.size(), stream_);
-    d.order.upload(sched.order.data(), sched.order.size(), stream_);
     {   // launch records of the wave-per-user kernel: schedule order, first row entry and user id inline
         std::vector<DevUnitX> xu(sched.order.size());
         for (size_t s = 0; s < sched.order.size(); s++) {
@@ -413,8 +418,57 @@ void Engine::upload_units(UnitDev &d, const Schedule &sched, const std::vector<D
     }
     d.unit_values = simple_unit_values_;
     d.has_fresh = any_fresh_;
-    if (any_fresh_) d.fresh.upload(staged_fresh_.data(), staged_fresh_.size(), stream_);
+    if (any_fresh_ && !scheduled_on_device) d.fresh.upload(staged_fresh_.data(), staged_fresh_.size(), stream_);
     HIPCHECK(hipStreamSynchronize(stream_));
+}
+
+// The same schedule built on the device (svdf_k_sched.hip: device_schedule_units) for resident user-group data sets: the staged arrays go
+// up first, levels / order / the fast-path flags / row_fresh are formed in HBM, the host gets back the order and one byte per unit.
+// 1 M users x 100 rows: 4.2 s of host scan -> see DESIGN.md 4e.  Falls back (returns false) for what the device form does not cover:
+// relaxed ids, side tables, shared latent spaces (their units touch child rows).
+bool Engine::schedule_units_on_device(UnitDev &d, Schedule &sched, std::vector<DevUnit> &du) {
+    const long nu = (long)staged_units_.size();
+    const bool plain = feat_user_.num_row() == 0 && feat_item_.num_row() == 0 && mp_.common_latent_space == 0 && mp_.common_feedback_space == 0;
+    if (!device_sched_ || !plain || relaxed() || nu == 0 || staged_.num_row() < device_sched_min_) return false;
+    if (staged_.feat_index.size() + staged_fb_index_.size() + (size_t)nu >= 0xFFFFFF00ull) return false;
+    static_assert(sizeof(HostUnit) == sizeof(DevUnit), "HostUnit and DevUnit share their layout");
+    upload_unit_arrays(d);
+    d.units.upload(reinterpret_cast<const DevUnit *>(staged_units_.data()), (size_t)nu, stream_);
+    d.order.reserve((size_t)nu);
+    d.fresh.reserve((size_t)std::max<long>(staged_.num_row(), 1));
+    DevBuf<unsigned char> simple;
+    simple.reserve((size_t)nu);
+    UnitSchedIn in{};
+    in.n = nu; in.nrow = staged_.num_row();
+    in.units = d.units.p; in.row_ptr = d.ptr.p; in.index = d.index.p; in.value = d.value.p; in.fb_index = d.fbidx.p;
+    in.goff = (unsigned)n_uiset_; in.user_off = user_off_; in.item_off = item_off_; in.fb_off = fb_off_;
+    in.num_item = (unsigned)mp_.num_item; in.num_fb = (unsigned)num_fb_rows(); in.state_res = (unsigned)num_resources();
+    in.simple_ok = 1;
+    in.fast_ok = (use_simple_units_ && !lazy_decay() && mp_.num_factor <= max_fast_path_factor()) ? 1 : 0;
+    UnitSchedOut out;
+    try { device_schedule_units(in, d.order.p, simple.p, d.fresh.p, out, stream_); }
+    catch (const std::exception &e) { fail(e.what()); }
+    sched.level_ptr = out.level_ptr;
+    sched.max_level_size = out.max_level_size;
+    sched.order.resize((size_t)nu);
+    std::vector<unsigned char> hs((size_t)nu);
+    HIPCHECK(hipMemcpyAsync(sched.order.data(), d.order.p, (size_t)nu * sizeof(int), hipMemcpyDeviceToHost, stream_));
+    HIPCHECK(hipMemcpyAsync(hs.data(), simple.p, (size_t)nu, hipMemcpyDeviceToHost, stream_));
+    HIPCHECK(hipStreamSynchronize(stream_));
+    du.resize((size_t)nu);
+    for (long t = 0; t < nu; t++) {
+        const HostUnit &u = staged_units_[(size_t)t];
+        du[(size_t)t] = DevUnit{u.fb_begin, u.fb_end, u.row_begin, u.row_end, u.flags | (hs[(size_t)t] ? UNIT_SIMPLE : 0)};
+    }
+    sched.level_mid.resize(sched.num_levels());
+    for (size_t l = 0; l < sched.num_levels(); l++) {   // the final sort put a level's fast-path units first
+        long m = sched.level_ptr[l];
+        while (m < sched.level_ptr[l + 1] && hs[(size_t)sched.order[(size_t)m]]) m++;
+        sched.level_mid[l] = m;
+    }
+    simple_unit_values_ = out.unit_values;
+    any_fresh_ = out.any_fresh;
+    return true;
 }
 
 void Engine::flush_units() {

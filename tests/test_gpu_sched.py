@@ -259,3 +259,122 @@ def test_specialised_kernel_for_inline_global_slots_equals_k_fused_and_the_oracl
     for name in ("W_user", "W_item", "u_bias", "i_bias", "g_bias"):
         assert np.array_equal(fast.view(name).view(np.uint32), slow.view(name).view(np.uint32)), name
         assert np.array_equal(fast.view(name).view(np.uint32), o.view(name).view(np.uint32)), name
+
+
+# ---- user units (SVD++ blocks): Engine::schedule_units against device_schedule_units ---------------------------------------------
+def _svdpp_conf(nu, ni, k, **kw):
+    return cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_ufeedback=ni, wd_ufeedback=0.004,
+                           wd_ufeedback_bias=0.002, scale_lr_ufeedback=0.7, ufeedback_init_sigma=0.01, learning_rate=0.01, **kw)
+
+
+def _unit_trainers(conf, knobs=()):
+    out = []
+    for dev in (1, 0):
+        t = sa.Trainer(1, 0)
+        t.seed(21)
+        for k, v in conf:
+            t.set_param(k, v)
+        t.init_model()
+        t.init_trainer()
+        t.set_knob("device_schedule", dev)
+        t.set_knob("device_schedule_min", 1)
+        for k, v in knobs:
+            t.set_knob(k, v)
+        out.append(t)
+    return out
+
+
+def _same_unit_schedule(blocks, conf, passes=2, knobs=()):
+    d, h = _unit_trainers(conf, knobs)
+    dd, dh = d.dataset_from_blocks(blocks), h.dataset_from_blocks(blocks)
+    assert dd.kind == dh.kind == 3
+    for what in (0, 1, 2, 5, 6, 7):   # rows, levels, widest level, units, fast-path units, digest of level_ptr / level_mid / order
+        assert dd.info(what) == dh.info(what), what
+    for _ in range(passes):
+        d.train_dataset(dd)
+        h.train_dataset(dh)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "W_ufeedback", "ufeedback_bias"):
+        assert np.array_equal(d.view(name).view(np.uint32), h.view(name).view(np.uint32)), name
+    assert np.array_equal(d.predict_dataset(dd).view(np.uint32), h.predict_dataset(dh).view(np.uint32))
+    return d, dd
+
+
+@pytest.mark.parametrize("k", [16, 128])
+def test_device_unit_schedule_equals_host_schedule(k):
+    """split users, users without feedback, an item rated twice inside a unit (row_fresh), a feedback id listed twice and rows with a
+    non-unit value (both: not on the fast path) -- same levels, same fast-path split, same order, same bits; and the oracle"""
+    nu, ni = 900, 350
+    blocks = cases.user_blocks(700, nu, ni, ni, seed=k, max_rows=30, max_fb=25, split_every=6)
+    for b in blocks[::9]:
+        if b.data.num_row >= 2 and b.extend_tag == 0:
+            b.data.feat_index[3] = b.data.feat_index[1]
+            if b.data.num_row >= 20:
+                b.data.feat_index[2 * 19 + 1] = b.data.feat_index[1]
+    for b in blocks[4::11]:
+        if b.num_ufeedback >= 2 and b.extend_tag == 0:
+            b.index_ufeedback[1] = b.index_ufeedback[0]
+    for b in blocks[5::13]:
+        if b.data.num_row >= 2:
+            b.data.feat_value[2] = 0.5
+    conf = _svdpp_conf(nu, ni, k)
+    d, dd = _same_unit_schedule(blocks, conf)
+    assert 0 < dd.num_simple_units < dd.num_units
+    o = oracle.OracleTrainer("port", 1, 0)
+    o.seed(21)
+    for kk, v in conf:
+        o.set_param(kk, v)
+    o.init_model()
+    o.init_trainer()
+    for _ in range(2):
+        for b in blocks:
+            o.update_block(b)
+    for name in ("W_user", "W_item", "u_bias", "i_bias", "W_ufeedback", "ufeedback_bias"):
+        assert np.array_equal(d.view(name).view(np.uint32), o.view(name).view(np.uint32)), name
+
+
+def test_device_unit_schedule_degenerate_shapes():
+    """one user; every user the same single item (one chain of units); no feedback at all but one block; the generic path only"""
+    nu, ni = 300, 40
+    one = cases.user_blocks(1, nu, ni, ni, seed=3, max_rows=12, max_fb=6)
+    _same_unit_schedule(one, _svdpp_conf(nu, ni, 32))
+    chain = cases.user_blocks(200, nu, ni, ni, seed=4, max_rows=3, max_fb=4)
+    for b in chain:
+        b.data.feat_index[1::2] = 7
+    d, dd = _same_unit_schedule(chain, _svdpp_conf(nu, ni, 32))
+    assert dd.num_batches == len(chain)
+    wide = cases.user_blocks(250, nu, 5000, 5000, seed=5, max_rows=4, max_fb=3)
+    _same_unit_schedule(wide, _svdpp_conf(nu, 5000, 64))
+    _same_unit_schedule(wide, _svdpp_conf(nu, 5000, 64), knobs=(("use_simple_units", 0),))
+
+
+def test_device_unit_schedule_at_scale_is_fast():
+    """40 K users x 100 rows (BASELINE configs[3]'s shape at the bench's old size): identical schedule, and the device build is reported"""
+    rng = np.random.default_rng(11)
+    nu, ni, per = 40_000, 100_000, 100
+    n = nu * per
+    item = rng.integers(0, ni, n, dtype=np.uint32)
+    user = np.repeat(np.arange(nu, dtype=np.uint32), per)
+    feat_index = np.empty(2 * n, np.uint32)
+    feat_index[0::2] = user
+    feat_index[1::2] = item
+    row_ptr = np.empty(3 * n + 1, np.int64)
+    row_ptr[0::3] = 2 * np.arange(n + 1)[: n + 1]
+    row_ptr[1::3] = 2 * np.arange(n)
+    row_ptr[2::3] = 2 * np.arange(n) + 1
+    fbn = 100
+    fb_index = np.concatenate([np.sort(rng.choice(ni, fbn, replace=False)) for _ in range(nu)]).astype(np.uint32)
+    blocks = sa.BlockArrays(np.zeros(nu, np.int32), np.arange(nu + 1, dtype=np.int64) * fbn, fb_index, np.full(nu * fbn, 0.1, np.float32),
+                            np.arange(nu + 1, dtype=np.int64) * per, rng.integers(1, 6, n).astype(np.float32), row_ptr, feat_index,
+                            np.ones(2 * n, np.float32))
+    conf = _svdpp_conf(nu, ni, 128)
+    d, h = _unit_trainers(conf)
+    t0 = time.perf_counter()
+    dd = d.dataset_from_blocks(blocks)
+    t1 = time.perf_counter()
+    dh = h.dataset_from_blocks(blocks)
+    t2 = time.perf_counter()
+    print("dataset_from_blocks, 40 K users x 100: %.3f / %.3f s with the schedule on the device / host; the schedule itself %.1f ms (uploads included) / %.1f ms, %d levels" % (t1 - t0, t2 - t1, d.counter(24) / 1e3, h.counter(24) / 1e3, dd.num_batches))
+    assert d.counter(25) == 1 and h.counter(25) == 0
+    for what in (0, 1, 2, 5, 6, 7):
+        assert dd.info(what) == dh.info(what), what
+    assert dd.num_simple_units == dd.num_units == nu
