@@ -87,6 +87,16 @@ Dataset *Engine::dataset_from_blocks(long num_block, const int *extend_tag, cons
     const long saved_window = stage_window_;
     stage_window_ = (long)1 << 60;
     std::vector<int> ptr32;
+    if (num_block > 0) {   // the staged copies grow once, not by doubling (100 M rows: 4 GB of host vectors)
+        const int64_t nr = block_row_ptr[num_block] - block_row_ptr[0], ne = row_ptr[3 * block_row_ptr[num_block]] - row_ptr[3 * block_row_ptr[0]];
+        const int64_t nf = fb_ptr[num_block] - fb_ptr[0];
+        if (nr > 0 && nr < 2147483647L && ne >= 0 && ne < 2147483647L && nf >= 0 && nf < 2147483647L) {
+            staged_.row_label.reserve((size_t)nr); staged_.row_ptr.reserve((size_t)(3 * nr + 1));
+            staged_.feat_index.reserve((size_t)ne); staged_.feat_value.reserve((size_t)ne);
+            staged_fb_index_.reserve((size_t)nf); staged_fb_value_.reserve((size_t)nf);
+            staged_units_.reserve((size_t)num_block);
+        }
+    }
     for (long b = 0; b < num_block; b++) {
         const int64_t r0 = block_row_ptr[b], r1 = block_row_ptr[b + 1];
         const int64_t e0 = row_ptr[3 * r0];

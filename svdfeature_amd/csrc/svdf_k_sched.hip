@@ -618,63 +618,105 @@ __global__ __launch_bounds__(PEEL_THREADS) void k_us_peel(int l, const unsigned 
     publish_level_end(sh, state, level_end, l);
 }
 
-// narrow frontiers: ONE workgroup peels level after level, the frontier in LDS (k_sched_peel_chain for lists)
+// narrow frontiers: ONE workgroup peels level after level, the frontier in LDS (k_sched_peel_chain for lists).  A level is a chain of
+// dependent memory operations -- a unit's successors, their counters, the released units' entry ranges -- and nothing else, so:
+//   * the frontier holds CHUNKS of up to 128 entries (two per lane, both successor loads and both counter atomics in flight together), spread
+//     over all sixteen waves: a unit of 200 entries is two work items, not four dependent rounds of one wave (4.7 -> ~2 us per level);
+//   * a released unit's range is fetched while the counter that may release it is still in flight and travels with it through LDS.
+#define UCHAIN_CAP 4096
+#define UCHAIN_SPAN 128
+__device__ __forceinline__ int wave_incl_scan_i(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(v, o); if (lane >= o) v += t; }
+    return v;
+}
+// A barrier that orders LDS traffic only: __syncthreads() also waits for the level's global stores (order[], level[], level_end[] -- read by
+// nobody before the launch ends) to be acknowledged, one more memory round trip on the critical path of every level.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 __global__ __launch_bounds__(PEEL_THREADS) void k_us_peel_chain(int l, int max_levels, const unsigned *eptr, const int *succ, int *remaining, int *order,
                                                                 int *level, unsigned *state, unsigned *level_end) {
-    __shared__ int fr[2][CHAIN_CAP];
-    __shared__ int nnext;
+    __shared__ unsigned fe0[2][UCHAIN_CAP], fe1[2][UCHAIN_CAP];
+    __shared__ int nchunk, nunit;
     __shared__ unsigned cursor;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nwv = blockDim.x >> 6;
     unsigned begin = level_end[l - 1], end = level_end[l];
-    int ncur = (int)(end - begin);
-    if (ncur > CHAIN_CAP || ncur == 0) {
+    int units_cur = (int)(end - begin);
+    if (units_cur > UCHAIN_CAP / 4 || units_cur == 0) {
         if (threadIdx.x == 0) state[ST_NEXT_LEVEL] = (unsigned)l;
         return;
     }
-    for (int i = threadIdx.x; i < ncur; i += blockDim.x) fr[0][i] = order[begin + (unsigned)i];
-    if (threadIdx.x == 0) { nnext = 0; cursor = end; }
+    if (threadIdx.x == 0) { nchunk = 0; nunit = 0; cursor = end; }
+    __syncthreads();
+    // chunks of the first frontier; a frontier that does not fit ends the chain (the wide kernel continues from the global order array)
+    for (int i = threadIdx.x; i < units_cur; i += blockDim.x) {
+        const int u = order[begin + (unsigned)i];
+        const unsigned e0 = eptr[u], e1 = eptr[u + 1];
+        const int nc = (int)((e1 - e0 + UCHAIN_SPAN - 1) / UCHAIN_SPAN);
+        const int pos = atomicAdd(&nchunk, nc);
+        for (int c = 0; c < nc; c++)
+            if (pos + c < UCHAIN_CAP) { fe0[0][pos + c] = e0 + (unsigned)c * UCHAIN_SPAN; fe1[0][pos + c] = min(e1, e0 + (unsigned)(c + 1) * UCHAIN_SPAN); }
+    }
+    __syncthreads();
+    int ncur = nchunk;
+    __syncthreads();
+    if (threadIdx.x == 0) nchunk = 0;
     __syncthreads();
     int cur = 0, done = 0;
-    while (done < max_levels && ncur > 0 && ncur <= CHAIN_CAP) {
+    bool fits = ncur <= UCHAIN_CAP;
+    while (done < max_levels && units_cur > 0 && fits) {
         const unsigned base = cursor;
-        for (int i = wv; i < ncur; i += nwv) {
-            const int u = fr[cur][i];
-            const unsigned e0 = eptr[u], e1 = eptr[u + 1];
-            for (unsigned eb = e0; eb < e1; eb += 64) {
-                const unsigned e = eb + (unsigned)lane;
-                const int v = e < e1 ? succ[e] : -1;
-                const bool ready = v >= 0 && atomicSub(&remaining[v], 1) == 1;
+        for (int w = wv; w < ncur; w += nwv) {
+            const unsigned e0 = fe0[cur][w], e1 = fe1[cur][w];
+            const unsigned ea = e0 + (unsigned)lane, eb = ea + 64u;
+            const int va = ea < e1 ? succ[ea] : -1, vb = eb < e1 ? succ[eb] : -1;
+            unsigned a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+            if (va >= 0) { a0 = eptr[va]; a1 = eptr[va + 1]; }
+            if (vb >= 0) { b0 = eptr[vb]; b1 = eptr[vb + 1]; }
+            const bool ra = va >= 0 && atomicSub(&remaining[va], 1) == 1;
+            const bool rb = vb >= 0 && atomicSub(&remaining[vb], 1) == 1;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const bool ready = h ? rb : ra;
                 const unsigned long long mask = __ballot(ready);
-                if (mask) {
-                    int pos0 = 0;
-                    if (lane == 0) pos0 = atomicAdd(&nnext, __popcll(mask));
-                    pos0 = __shfl(pos0, 0);
-                    if (ready) {
-                        const int pos = pos0 + __popcll(mask & ((1ull << lane) - 1ull));
-                        level[v] = l + 1;
-                        order[base + (unsigned)pos] = v;
-                        if (pos < CHAIN_CAP) fr[cur ^ 1][pos] = v;
-                    }
+                if (!mask) continue;
+                const int v = h ? vb : va;
+                const unsigned r0 = h ? b0 : a0, r1 = h ? b1 : a1;
+                const int nc = ready ? (int)((r1 - r0 + UCHAIN_SPAN - 1) / UCHAIN_SPAN) : 0;
+                const int incl = wave_incl_scan_i(nc, lane);
+                int cpos0 = 0, upos0 = 0;
+                if (lane == 63) { cpos0 = atomicAdd(&nchunk, incl); upos0 = atomicAdd(&nunit, __popcll(mask)); }
+                cpos0 = __shfl(cpos0, 63); upos0 = __shfl(upos0, 63);
+                if (ready) {
+                    level[v] = l + 1;
+                    order[base + (unsigned)(upos0 + __popcll(mask & ((1ull << lane) - 1ull)))] = v;
+                    const int cpos = cpos0 + incl - nc;
+                    for (int c = 0; c < nc; c++)
+                        if (cpos + c < UCHAIN_CAP) { fe0[cur ^ 1][cpos + c] = r0 + (unsigned)c * UCHAIN_SPAN; fe1[cur ^ 1][cpos + c] = min(r1, r0 + (unsigned)(c + 1) * UCHAIN_SPAN); }
                 }
             }
         }
-        __syncthreads();
-        const int made = nnext;
-        __syncthreads();
+        lds_barrier();
+        const int made_units = nunit, made_chunks = nchunk;
+        lds_barrier();
         if (threadIdx.x == 0) {
-            cursor = base + (unsigned)made;
+            cursor = base + (unsigned)made_units;
             level_end[l + 1] = cursor;
-            nnext = 0;
+            nunit = 0; nchunk = 0;
         }
-        __syncthreads();
+        lds_barrier();
         l++; done++;
         cur ^= 1;
-        ncur = made;
+        units_cur = made_units;
+        ncur = made_chunks;
+        fits = made_chunks <= UCHAIN_CAP;
     }
     if (threadIdx.x == 0) {
         state[ST_CURSOR] = cursor;
         state[ST_NEXT_LEVEL] = (unsigned)l;
-        if (ncur > 0) state[ST_NLEVELS] = (unsigned)l; else state[ST_NLEVELS] = (unsigned)(l - 1);
+        // level l's frontier is order[level_end[l-1], level_end[l]); levels up to l-1 have been retired, level l exists iff it holds units
+        if (units_cur > 0) state[ST_NLEVELS] = (unsigned)l; else state[ST_NLEVELS] = (unsigned)(l - 1);
     }
 }
 
