@@ -212,23 +212,29 @@ def workload_conf(name, a, factor):
 PMC_KERNEL = {"basicmf": "k_basicmf", "pairwise": "k_fewrow_slots", "svdpp": "k_svdpp_wave", "neighbourhood": "k_fewrow_gslots"}
 
 
-def ranker_roofline(matrix_bytes, cand, dt, nsec, tiles, top_k, tile_traffic):
-    """One pass over the prepared candidate matrix serves a TILE of up to 8 user sections (k_rank_score_tile), so the launch's algorithmic
-    bytes are the matrix ONCE plus a score slice written per section -- not the reference's matrix-per-user stream: with 8 sections per
-    pass the kernel is bound by its 8 dot products per candidate (LDS-fed VALU), not by HBM, and the fraction says so."""
+def ranker_roofline(matrix_bytes, cand, dt, nsec, tiles, top_k, tile_traffic, k=128):
+    """One launch over the prepared candidate matrix serves a TILE of up to 32 user sections (k_rank_score_tile<NS, MODE>, round 5), so the launch's
+    algorithmic bytes are the matrix ONCE plus a score / key slice per section -- not the reference's matrix-per-user stream.  With 32 dots per
+    candidate the pass is fp32 VALU work (unfused multiplies and adds in the reference's four-chain order: half the FMA peak), not HBM; both
+    fractions are in the line."""
     per_tile = nsec / max(tiles, 1) if tiles else 1.0
     launch_bytes = matrix_bytes + per_tile * cand * 4
     achieved = launch_bytes / (dt * per_tile) / 1e9
+    flops = 2.0 * k * cand   # per section: one multiply and one add per element, not fused (the reference's SSE order)
     return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "kernel": "k_rank_score_tile<8> (up to 8 user sections per pass over the candidate matrix)" + (" + k_rank_tile_keys / k_rsel_* (radix selection of every section of the tile)" if top_k else ""),
+            "kernel": ("k_rank_score_tile<16, 1, ...> (a tile of up to 32 user sections per launch, 16 dots per lane and candidate, two section groups) + "
+                       "k_rank_tile_select (top_k of every section of the tile from per-wave minimum keys)" if top_k else
+                       "k_rank_score_tile<8, 0, ...> (a tile of up to 32 user sections per launch, 8 dots per lane and candidate, four section groups; positions counted in the pass)"),
             "algorithmic_bytes_per_launch": launch_bytes, "sections_per_launch": per_tile,
+            "valu_fp32": {"achieved_tflops": flops / dt / 1e12, "peak_tflops_unfused": 157.3 / 2, "frac": flops / dt / 1e12 / (157.3 / 2),
+                          "note": "the scoring pass as arithmetic: 2 k flop per candidate and section over the whole call's time per section"},
             "reference_bytes_per_section": matrix_bytes,
             "reference_stream_equivalent_GBps": matrix_bytes / dt / 1e9,
-            "timing": "host clock over the whole svdf_ranker_process_rows call / tiles: uploads, opening kernel, scoring pass, selection or counting, readback "
-                      "(the scoring kernel alone: profiles/r03_ranker_*_kernel_stats.csv); reference_stream_equivalent = what streaming the matrix once per "
-                      "section, as the reference does, would have to sustain for the same sections/s",
+            "timing": "host clock over the whole svdf_ranker_process_rows call / sections: uploads, opening kernel, scoring pass, selection or counting, readback, "
+                      "tied sections on the host's sort pool; reference_stream_equivalent = what streaming the matrix once per section, as the reference does, "
+                      "would have to sustain for the same sections/s",
             "traffic": tile_traffic,
-            "traffic_source": "profiles/hbm_traffic.json: k_rank_score_tile, (2*FETCH+WRITE)*1024 per launch = per TILE of up to 8 sections"}
+            "traffic_source": "profiles/hbm_traffic.json: k_rank_score_tile, (2*FETCH+WRITE)*1024 per launch = per TILE of sections (null until measured for the 32-section tile)"}
 
 
 def measure_traffic(name, a, log, deadline=None):
@@ -935,7 +941,7 @@ def run_f3_secondary(a, env):
             "workload": "ISVDRanker: %d candidates, k=128, %d user sections in one svdf_ranker_process_rows call, %s" % (
                 cand, nsec, "top_k=%d" % top_k if top_k else "rank positions of 5 positives"),
             "value": 1.0 / dt, "unit": "user sections/s", "ms_per_step": dt * 1e3, "sections_finished_by_host_sort": g.counter(1),
-            "tiles_of_up_to_8_sections": g.counter(3),
+            "tiles_of_up_to_32_sections": g.counter(3),
             "roofline": ranker_roofline(byts, cand, dt, nsec, g.counter(3), top_k, traffic_of("ranker_k128_positions_tile")),
             "cpu_baseline": {"value": 1.0 / dt_cpu, "unit": "user sections/s", "cores": 1, "kind": f3_kind, "sample": "the first %d sections" % ncpu},
             "parity": {"results_identical_on_sample": bool(np.array_equal(got[:len(ref)], ref))}}

@@ -118,18 +118,20 @@ void PairSampler::sample_block(const std::vector<RankRow> &rows, std::vector<flo
         neg_ = rows;
         shuffle(neg_);
         std::sort(pos_.begin(), pos_.end(), by_label);
-        for (size_t i = 0; i < neg_.size(); i++) {
-            RankRow el = neg_[i];
-            el.label -= gap_;
-            const size_t left = (size_t)(std::lower_bound(pos_.begin(), pos_.end(), el, by_label) - pos_.begin());
-            el.label += gap_ * 2;
-            const size_t right = (size_t)(std::lower_bound(pos_.begin(), pos_.end(), el, by_label) - pos_.begin());
-            const uint32_t rng = (uint32_t)(left + pos_.size() - right);
-            if (rng > 0) {
-                const size_t idx = next_uint32(rng);
-                if (idx < left) genpair(neg_[i], pos_[idx]);
-                else genpair(pos_[right + idx - left], neg_[i]);
-            }
+        // sorted copy: how many rows have a label below `bound` (the reference asks std::lower_bound with a row whose label it shifts)
+        auto below = [&](const RankRow &like, float bound) {
+            RankRow probe = like;
+            probe.label = bound;
+            return (size_t)(std::lower_bound(pos_.begin(), pos_.end(), probe, by_label) - pos_.begin());
+        };
+        for (const RankRow &anchor : neg_) {
+            const float under = anchor.label - gap_, over = under + gap_ * 2;   // the same two float steps: label - gap, then + 2 gap
+            const size_t n_under = below(anchor, under), n_to_over = below(anchor, over);
+            const uint32_t partners = (uint32_t)(n_under + pos_.size() - n_to_over);   // rows more than a gap below, then rows a gap or more above
+            if (partners == 0) continue;
+            const size_t pick = next_uint32(partners);
+            if (pick < n_under) genpair(anchor, pos_[pick]);
+            else genpair(pos_[n_to_over + pick - n_under], anchor);
         }
         return;
     }

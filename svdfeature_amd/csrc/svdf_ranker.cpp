@@ -694,15 +694,14 @@ void Ranker::resolve() {
     RankPending Q = std::move(pending_.front());
     pending_.pop_front();
     RankSlot &L = slots_[Q.slot];
-    hipStream_t st = eng_->stream_;
     {
         const auto t0_ = std::chrono::steady_clock::now();
         // poll: a blocking wait sleeps on an interrupt, and the wake-up measured up to ~0.4 ms per tile here (a process_rows call of 38 tiles
         // took 5 ms or 40 ms depending on it); the pipeline is a few tiles deep, so the event is usually a few microseconds away
         for (;;) {
-            const hipError_t e_ = hipEventQuery(L.ev);
-            if (e_ == hipSuccess) break;
-            if (e_ != hipErrorNotReady) RCHECK(e_);
+            const hipError_t query = hipEventQuery(L.ev);
+            if (query == hipSuccess) break;
+            if (query != hipErrorNotReady) RCHECK(query);   // (RCHECK declares an e_ of its own)
             __builtin_ia32_pause();
         }
         event_wait_ns_ += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0_).count();

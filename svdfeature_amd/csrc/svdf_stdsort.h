@@ -9,6 +9,8 @@
 // of row ids compared through their labels.  The sub-ranges introsort recurses into are disjoint, so the explicit stack below may
 // visit them in any order.  tests/test_rank_sampler.py compares this with std::sort itself on the host (svdf_debug_sort_labels);
 // the device sampler (svdf_k_sample.hip) runs the same code per user block.
+// Provenance: this file follows the ALGORITHM of GNU libstdc++'s <bits/stl_algo.h> (GPLv3 with the GCC Runtime Library Exception 3.1); no text of
+// it is copied, the code below is written against the description above.
 #ifndef SVDF_STDSORT_H_
 #define SVDF_STDSORT_H_
 
