@@ -317,7 +317,8 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  * lane-group kernel), "rows_without_feedback" (0 keeps whole users as sequential units even when no block of a block
  * dataset carries a feedback id; default 1 schedules such rows one by one), "use_graph" / "graph_min_levels" (hipGraph replay of a resident dataset's pass), "hot_reduce"
  * (relaxed mode: workgroup pre-reduction of a shared user row), "device_schedule" (0 = build the conflict-free levels on the host
- * instead of the GPU; same schedule), "device_schedule_min" (staged windows with fewer instances stay on the host scheduler),
+ * instead of the GPU; same schedule -- rating / pair columns, runs, and since round 5 the user units of resident SVD++ data sets),
+ * "device_schedule_min" (staged windows / user-group data sets with fewer instances stay on the host scheduler),
  * "device_rank" (0 = draw rank pairs with the host sampler; same pairs), "load_mode" (row gathers: 0 plain, 1 nontemporal hint,
  * 2 = by row size), "basic_i8" / "fewrow_i16" (0 = the lane-group layout instead of several chunks per lane in the specialised
  * basicMF / few-row kernels), "svdpp_helpers" (waves per user in the SVD++ kernel: 1, 4, 8, 16), "svdpp_xunits" (0 = no launch
