@@ -33,9 +33,21 @@ Dataset *Engine::dataset_from_blocks(long num_block, const int *extend_tag, cons
     if (auto_step_active()) {
         auto_building_ = true;
         struct Done { bool &f; ~Done() { f = false; } } done{auto_building_};
-        Dataset *exact = dataset_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
         const bool ok = wunit_config_ok() && wunit_blocks_ok(num_block, extend_tag, fb_ptr, fb_index, block_row_ptr, row_ptr, feat_index);
-        return auto_step(exact, ok, [&]() { return wseq_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value); });
+        auto windows = [&]() { return wseq_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value); };
+        // a large pass is judged on a prefix of whole users (like the rating / pair streams above): SVD++ blocks keep ~6 users per level whatever
+        // their number, so the first 2 M rows tell -- and 100 M rows are not staged and level-scheduled (2.5 s) only to be dropped for the windows
+        const int64_t nrows = num_block > 0 ? block_row_ptr[num_block] - block_row_ptr[0] : 0;
+        if (ok && nrows > AUTO_PROBE_MIN) {
+            long bp = 0;
+            while (bp < num_block && (block_row_ptr[bp] - block_row_ptr[0] < AUTO_PROBE_ROWS || bp == 0 ||
+                                      !(extend_tag[bp - 1] == TAG_DEFAULT || extend_tag[bp - 1] == TAG_END))) bp++;
+            if (bp > 0 && bp < num_block &&
+                auto_probe_deep(dataset_from_blocks(bp, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value), (long)nrows))
+                return auto_step(nullptr, true, windows);
+        }
+        Dataset *exact = dataset_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr, feat_index, feat_value);
+        return auto_step(exact, ok, windows);
     }
     if (imfb()) {   // multi-level units: every span of the pass must be closed inside it
         check(imfb_depth_ == 0, "dataset_from_blocks: a START block is pending in the trainer");

@@ -210,3 +210,48 @@ def test_rank_pair_passes_from_a_candidate_file_follow_the_decision_of_their_fir
     for n in out[None][2]:
         a, b = out[None][2][n], out["auto"][2][n]
         assert np.isfinite(b).all() and np.abs(a - b).max() < 0.05, n
+
+
+def test_user_group_passes_beyond_the_probe_size_are_judged_on_a_prefix_of_whole_users():
+    """SVD++ blocks, 9 M rows: auto stages and level-schedules only the first users (>= 2 M rows, ending at a unit boundary -- one user here is split
+    into START / MIDDLE / END right where the prefix would end), extrapolates the level count, and builds the window sequence without the full
+    exact data set; same windows as amd:step = minibatch builds."""
+    rng = np.random.default_rng(5)
+    nu, ni, per = 90_000, 20_000, 100
+    n = nu * per
+    feat_index = np.empty(2 * n, np.uint32)
+    feat_index[0::2] = np.repeat(np.arange(nu, dtype=np.uint32), per)
+    feat_index[1::2] = rng.integers(0, ni, n, dtype=np.uint32)
+    row_ptr = np.empty(3 * n + 1, np.int64)
+    row_ptr[0::3] = 2 * np.arange(n + 1)
+    row_ptr[1::3] = 2 * np.arange(n)
+    row_ptr[2::3] = 2 * np.arange(n) + 1
+    fbn = 20
+    fb_index = (rng.integers(0, ni // fbn, (nu, fbn)) + np.arange(fbn) * (ni // fbn)).astype(np.uint32).ravel()   # distinct ids inside a list
+    # user 20 000 (rows 2 000 000 .. 2 000 099: where a 2 M-row prefix would end) comes as three blocks
+    cut = 20_000
+    tags = np.zeros(nu + 2, np.int32)
+    tags[cut], tags[cut + 1], tags[cut + 2] = 1, 3, 2   # START, MIDDLE, END (svdpp_tag: 0 default, 1 start, 2 end, 3 middle)
+    brp = np.concatenate([np.arange(cut + 1) * per, [cut * per + 30, cut * per + 70], np.arange(cut + 1, nu + 1) * per]).astype(np.int64)
+    fbp = np.concatenate([np.arange(cut + 1) * fbn, [(cut + 1) * fbn, (cut + 1) * fbn], np.arange(cut + 2, nu + 2) * fbn]).astype(np.int64)
+    # (START carries the list, MIDDLE none, END the same list again)
+    fb_full = np.concatenate([fb_index[:(cut + 1) * fbn], fb_index[cut * fbn:(cut + 1) * fbn], fb_index[(cut + 1) * fbn:]])
+    blocks = sa.BlockArrays(tags, fbp, fb_full, np.full(fb_full.size, fbn ** -0.5, np.float32), brp, rng.integers(1, 6, n).astype(np.float32), row_ptr,
+                            feat_index, np.ones(2 * n, np.float32))
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64, num_ufeedback=ni, wd_ufeedback=0.004)
+    t = _trainer(conf, fmt=1, extra=[("amd:step", "auto")])
+    t0 = time.perf_counter()
+    ds = t.dataset_from_blocks(blocks)
+    dt = time.perf_counter() - t0
+    assert ds.kind == 8 and t.counter(16) == 2 and ds.num_row == n
+    assert 0.5 * (nu / 8) < t.counter(17) < 2.0 * nu   # extrapolated levels: a handful of users per level
+    m = _trainer(conf, fmt=1, extra=[("amd:step", "minibatch")])
+    t0 = time.perf_counter()
+    dm = m.dataset_from_blocks(blocks)
+    dt_m = time.perf_counter() - t0
+    assert dm.kind == 8 and dm.num_batches == ds.num_batches
+    print("9 M rows of user blocks: auto %.2f s (prefix probe + windows), minibatch %.2f s (windows only), %d windows" % (dt, dt_m, ds.num_batches))
+    t.train_dataset(ds)
+    m.train_dataset(dm)
+    for name in ("W_user", "W_item", "W_ufeedback"):
+        assert np.array_equal(t.view(name).view(np.uint32), m.view(name).view(np.uint32)), name
