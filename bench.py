@@ -864,7 +864,7 @@ def run_window_step(sa, name, a, device, log, steps=3, warmup=1, seq_quality=Non
         tr.set_knob("window_per_target_fb", a.step_per_target)
     if os.environ.get("SVDF_WUNIT_FAST"):   # A/B of the user-unit kernels (tools/wstep_probe.py): 0 lane groups, 1 slot kernel, 2 one wave per unit
         tr.set_knob("wunit_fast", int(os.environ["SVDF_WUNIT_FAST"]))
-    for env, knob in (("SVDF_WUNIT_INPLACE", "wunit_inplace"),):
+    for env, knob in (("SVDF_WUNIT_INPLACE", "wunit_inplace"), ("SVDF_WUNIT_DEFER_FB", "wunit_defer_fb")):
         if os.environ.get(env):
             tr.set_knob(knob, int(os.environ[env]))
     ds = (tr.dataset_from_pairs(*tri) if name == "pairwise" else tr.dataset_from_triples(*tri)) if tri else (tr.dataset_from_blocks(train) if name == "svdpp" else tr.dataset_from_csr(d_all))

@@ -247,6 +247,7 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "rows_without_feedback")) { rows_without_feedback_ = value != 0; return 0; }
     if (!strcmp(name, "fewrow_gslots")) { fewrow_gslots_ = value != 0; launch_version_++; return 0; }
     if (!strcmp(name, "wunit_inplace")) { wunit_inplace_ = value != 0; return 0; }
+    if (!strcmp(name, "wunit_defer_fb")) { wunit_defer_fb_ = value != 0; return 0; }
     if (!strcmp(name, "wunit_fast")) { check(value >= 0 && value <= 2, "wunit_fast must be 0, 1 or 2"); wunit_fast_ = (int)value; return 0; }
     if (!strcmp(name, "window_per_target_fb")) { check(value >= 1, "window_per_target_fb must be positive"); wseq_per_target_fb_ = (int)value; return 0; }
     if (!strcmp(name, "window_per_target_max")) { check(value >= 1, "window_per_target_max must be positive"); wseq_per_target_max_ = (int)value; return 0; }

@@ -498,19 +498,19 @@ __device__ __forceinline__ float4 apply_single(const float4 w, const float4 c, b
 // sum unchanged bit for bit (the sum starts at +0.0f and x + y is -0 only when both are, so acc is never -0).  The storage format is a TEMPLATE
 // parameter here: with the format test inside the unrolled block the compiler kept a branch between the eight loads and they were issued one
 // by one (the stratified step's small windows: 11.6 -> 26 us per launch).
-template <int LPI, bool BF16>
+template <int LPI, bool BF16, int NB = 8>   // NB rows requested at a time (8; 4 where lists are short and registers buy resident waves: the in-place sums of one-GPU windows)
 __device__ __forceinline__ void sum_contrib_slots(const float *contrib, const float *cbias, int b, int e, int pitch, int L, int k, float4 &acc, float &accb) {
-    for (int t = b; t < e; t += 8) {
-        float4 c[8];
-        float cb[8];
+    for (int t = b; t < e; t += NB) {
+        float4 c[NB];
+        float cb[NB];
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < NB; q++) {
             const bool in = t + q < e;
             c[q] = in ? load_contrib<LPI>(contrib, BF16 ? 1 : 0, (size_t)(t + q), pitch, L, k) : f4zero();
             cb[q] = in ? cbias[t + q] : 0.0f;
         }
 #pragma unroll
-        for (int q = 0; q < 8; q++) { add_rows(acc, c[q]); accb = accb + cb[q]; }
+        for (int q = 0; q < NB; q++) { add_rows(acc, c[q]); accb = accb + cb[q]; }
     }
 }
 

@@ -259,6 +259,9 @@ struct Dataset {
     DevBuf<WinSeg> wu_segs;
     DevBuf<int> wu_rptr, wu_tptr, wu_gptr;
     DevBuf<WinEnt> wu_ent, wu_fbent;
+    DevBuf<WinFbRec> wu_fbrec;    // deferred feedback scatter: slot-ordered (segment, value) records; empty = the walk writes contribution rows
+    long wu_nseg = 0;
+    bool wu_defer_fb = false;
     long wu_gslots = 0;           // contribution words of the global biases = global entries
     int wu_estride = 0;           // > 0: every row has wu_estride - 1 global entries and one item entry (no row pointer array)
     bool wu_feedback = false;     // the units carry implicit-feedback lists (user-group trainer)
@@ -581,6 +584,7 @@ class Engine {
     void window_build_resident(Dataset *ds, long n, const unsigned *d_user, const unsigned *d_item, const float *d_label, const unsigned *d_neg);
     void window_build_header(Dataset *ds, long n, bool pairs);
     bool device_window_ready() const { return !host_only_ && device_window_; }
+    DevBuf<float> d_dvec_, d_dbias_;      // deferred feedback scatter: one scaled delta row + bias delta per segment of the largest window
     DevBuf<float> d_contrib_, d_cbias_;   // window-minibatch scratch: one contribution row + bias word per instance of the largest window
     std::unique_ptr<IpcState, IpcDeleter> ipc_;
     std::unique_ptr<RcclState, RcclDeleter> rccl_;
@@ -611,6 +615,7 @@ class Engine {
     bool step_minibatch_set_ = false;
     bool contrib_bf16_ = false;           // "amd:contrib = bf16": contribution rows of the window-minibatch step in bfloat16 (opt-in)
     int fewrow_gslots_ = 1;               // knob "fewrow_gslots": 0 = k_fused for few-row data sets with inline global slots (A/B)
+    int wunit_defer_fb_ = 1;              // knob "wunit_defer_fb": feedback-row contributions are formed by k_wunit_sum from the segments' deltas (1) or written as rows by the walk (0: A/B; same bits)
     int wunit_inplace_ = 1;               // knob "wunit_inplace": one-GPU window sequences apply a row's only contribution of a window in place (no slot); 0 = every contribution through a slot (A/B)
     bool wunit_inplace_build_ = false;    // set while wseq_from_csr / _from_blocks build their windows
     int wunit_fast_ = 2;                  // knob "wunit_fast": 0 = the general lane-group kernel for every shape, 1 = + the slot kernel, 2 = + one wave per unit (A/B and tests)

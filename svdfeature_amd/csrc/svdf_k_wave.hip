@@ -896,6 +896,11 @@ __global__ __launch_bounds__(64, (NR <= 2 ? 2 : 1)) void k_wunit_wave(   // two 
             chain_scale(d, inv);
             db = db * inv;
             const ChainRow<NR> dl = chain_to_lin<NR>(d, lane);
+            if (S.fbrec) {   // deferred scatter (round 5): the segment's delta goes out once; k_wunit_sum forms (w + d val) - w against the rows it updates
+                lin_store<NR>(S.dvec, (size_t)(seg_begin + sg), pitch, lane, -1, dl);
+                if (lane == 0) S.dbias[seg_begin + sg] = db;
+                continue;
+            }
             auto scatter = [&](const WaveFbBatch<NR, FBW> &x, const WaveFbBlock &fb, int j) {
 #pragma unroll
                 for (int c = 0; c < FBW; c++) {

@@ -119,6 +119,10 @@ __global__ __launch_bounds__(256) void k_wunit_walk(const DevParams P, const WUn
             const float inv = 1.0f / pp.norm;
             scale4(d, inv);
             db = db * inv;
+            if (S.fbrec) {   // deferred scatter: the segment's delta; k_wunit_sum forms (w + d val) - w against the rows it updates
+                if (!(LPI * 4 > k && L * 4 >= k)) *reinterpret_cast<float4 *>(S.dvec + (size_t)(un.seg_begin + sg) * pitch + (size_t)L * 4) = d;
+                if (L == 0) S.dbias[un.seg_begin + sg] = db;
+            } else
             for (int j = seg.fb_begin; j < seg.fb_begin + seg.fb_count; j++) {
                 const WinEnt f = S.fbent[j];
                 const unsigned row = P.fb_off + f.idx;
@@ -352,6 +356,11 @@ __global__ __launch_bounds__(256) void k_wunit_fast(const DevParams P, const WUn
 #pragma unroll
             for (int v = 0; v < V; v++) scale4(d[v], inv);
             db = db * inv;
+            if (S.fbrec) {   // deferred scatter (see k_wunit_walk)
+#pragma unroll
+                for (int v = 0; v < V; v++) *reinterpret_cast<float4 *>(S.dvec + (size_t)(un.seg_begin + sg) * pitch + (size_t)(m + v * LANES) * 4) = d[v];
+                if (m == 0) S.dbias[un.seg_begin + sg] = db;
+            } else
             for (int j0 = 0; j0 < seg.fb_count; j0 += 8) {
                 WinEnt f[8];
                 float4 w[8][V];
@@ -408,14 +417,51 @@ __global__ __launch_bounds__(256) void k_wunit_sum(const WUnitSchedule S, float 
     const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
     const long first = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * IPW + lane / LPI;
     const long T = S.nfb_rows + S.nitem_rows;
+    // a target is a chain of dependent loads (its slot range, the records or rows of its slots, for deferred feedback rows the segments' deltas) and the
+    // kernel is bound by how many such chains the resident waves hold, not by bytes: the next target's slot range is requested one iteration ahead
+    int pb = 0, pe = 0;
+    if (first < T) { pb = S.tptr[first]; pe = S.tptr[first + 1]; }
     for (long t = first; t < T; t += stride) {
-        const int b = S.tptr[t], e = S.tptr[t + 1];
+        const int b = pb, e = pe;
+        if (t + stride < T) { pb = S.tptr[t + stride]; pe = S.tptr[t + stride + 1]; }
         if (LOCAL && b == e) continue;
         float4 acc = f4zero();
         float accb = 0.0f;
-        if (S.contrib_bf16) sum_contrib_slots<LPI, true>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
-        else sum_contrib_slots<LPI, false>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
         const bool owns = !(LPI * 4 > k && L * 4 >= k);
+        if (S.fbrec && t < S.nfb_rows) {
+            // deferred feedback scatter: slot s names a segment and the entry's value; the contribution is what the unit's walk would have stored --
+            // (w + d val) - w against the window-start row, rounded like a stored contribution row -- and the sum runs in slot (= file) order
+            const size_t row = (size_t)fb_off + (size_t)t;
+            const float4 w = owns ? *reinterpret_cast<const float4 *>(W + row * pitch + (size_t)L * 4) : f4zero();
+            const float bw = S.user_bias ? bias[row] : 0.0f;
+            const bool bf = S.contrib_bf16 != 0;
+            constexpr int DB = 4;   // records / deltas requested together (a feedback row of the configs[3] windows meets 1.5 contributions on average)
+            for (int s0 = b; s0 < e; s0 += DB) {
+                WinFbRec r[DB];
+                float4 d[DB];
+                float dbv[DB];
+#pragma unroll
+                for (int q = 0; q < DB; q++) r[q] = S.fbrec[min(s0 + q, e - 1)];
+#pragma unroll
+                for (int q = 0; q < DB; q++) {
+                    d[q] = owns ? *reinterpret_cast<const float4 *>(S.dvec + (size_t)r[q].seg * pitch + (size_t)L * 4) : f4zero();
+                    dbv[q] = S.dbias[r[q].seg];
+                }
+#pragma unroll
+                for (int q = 0; q < DB; q++) {
+                    if (s0 + q < e) {
+                        float4 w2 = w;
+                        axpy4(w2, d[q], r[q].val);
+                        sub4(w2, w);
+                        add_rows(acc, make_float4(contrib_as_stored(w2.x, bf), contrib_as_stored(w2.y, bf), contrib_as_stored(w2.z, bf), contrib_as_stored(w2.w, bf)));
+                        float cb = 0.0f;
+                        if (S.user_bias) { const float b2 = bw + dbv[q] * r[q].val; cb = b2 - bw; }
+                        accb = accb + cb;
+                    }
+                }
+            }
+        } else if (S.contrib_bf16) sum_contrib_slots<LPI, true, (LOCAL ? 4 : 8)>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
+        else sum_contrib_slots<LPI, false, (LOCAL ? 4 : 8)>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
         if (LOCAL) {
             const size_t row = t < S.nfb_rows ? (size_t)fb_off + (size_t)t : (size_t)item_off + (size_t)(t - S.nfb_rows);
             if (owns) {

@@ -227,6 +227,9 @@ struct WindowSchedule {
 struct WinSeg { int fb_begin, fb_count, row_begin, row_count; };
 struct WinUnit { unsigned user; int seg_begin; int seg_count; int rows; WinSeg first; };
 struct WinEnt { unsigned idx; float val; int slot; int pad; };
+// deferred feedback scatter (round 5): slot s of a feedback row holds WHO contributes -- the segment whose scaled delta d the sum kernel reads
+// from dvec[seg] -- and the entry's value; the contribution (w + d val) - w is formed by k_wunit_sum against the row it is about to update
+struct WinFbRec { int seg; float val; };
 struct WUnitSchedule {
     const WinUnit *units;
     long nunits;
@@ -242,6 +245,9 @@ struct WUnitSchedule {
     const int *gptr;            // [num_global + 1]
     long nfb_rows, nitem_rows, nglobal;
     int contrib_bf16;           // 1: contribution rows are bfloat16 (amd:contrib = bf16); bias / global-bias contributions stay fp32
+    const WinFbRec *fbrec;      // nullptr: feedback contributions are rows in `contrib` (written by the walk); else deferred: [tptr[nfb_rows]] records
+    float *dvec, *dbias;        // deferred: the scaled delta of every segment (row pitch = the model's), its bias delta
+    int user_bias;              // 1 unless no_user_bias
 };
 
 }  // namespace svdf

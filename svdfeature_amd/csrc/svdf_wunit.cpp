@@ -36,6 +36,7 @@ struct WUnitHost {
     std::vector<float> w_label, w_uval;
     std::vector<int> rptr, tptr, gptr;
     std::vector<WinEnt> ent, fbent;
+    std::vector<WinFbRec> fbrec;   // deferred feedback scatter (empty: contribution rows)
     long nrow = 0, nent = 0, nfbe = 0, item_entries = 0, global_entries = 0;
     int fixed_ng = -2;
     bool unit_uval = true, feedback = false;
@@ -51,6 +52,8 @@ WUnitSchedule Engine::wunit_view(const Dataset *ds) const {
     S.tptr = ds->wu_tptr.p; S.gptr = ds->wu_gptr.p;
     S.nfb_rows = user_group() ? (long)num_fb_rows() : 0; S.nitem_rows = mp_.num_item; S.nglobal = mp_.num_global;
     S.contrib_bf16 = contrib_bf16_ ? 1 : 0;
+    S.fbrec = ds->wu_defer_fb ? ds->wu_fbrec.p : nullptr; S.dvec = d_dvec_.p; S.dbias = d_dbias_.p;
+    S.user_bias = mp_.no_user_bias ? 0 : 1;
     return S;
 }
 
@@ -212,15 +215,18 @@ void Engine::wunit_build_host(WUnitHost &H, bool inplace, const void *segs_v, si
     }
     // one-GPU window sequences: a row that meets exactly ONE contribution in this window gets no slot (slot -1): the unit applies it in place
     // with the sum kernel's operations (apply_single, svdf_device.h) -- nobody else reads or writes that row inside the window
+    // deferred feedback scatter: every feedback contribution keeps a slot (a record, not a row) -- the sum kernel forms (w + d val) - w itself
+    const bool defer_fb = feedback && wunit_defer_fb_ != 0;
     std::vector<unsigned char> single;
     if (inplace) {
         single.assign((size_t)(NF + NI), 0);
-        for (size_t t = 0; t < (size_t)(NF + NI); t++) if (tptr[t + 1] == 1) { single[t] = 1; tptr[t + 1] = 0; }
+        for (size_t t = defer_fb ? (size_t)NF : 0; t < (size_t)(NF + NI); t++) if (tptr[t + 1] == 1) { single[t] = 1; tptr[t + 1] = 0; }
     }
     auto take_slot = [&](std::vector<int> &cur, size_t t) { return (!single.empty() && single[t]) ? -1 : cur[t]++; };
     for (size_t t = 0; t < (size_t)(NF + NI); t++) tptr[t + 1] += tptr[t];
     for (size_t g = 0; g < (size_t)NG; g++) gptr[g + 1] += gptr[g];
     std::vector<int> tcur(tptr.begin(), tptr.end() - 1), gcur(gptr.begin(), gptr.end() - 1);
+    if (defer_fb) H.fbrec.assign((size_t)tptr[(size_t)NF], WinFbRec{0, 0.0f});
     auto row_slots = [&](long nr) {
         const long r = src_of_new[(size_t)nr];
         const int ng = (int)(row_ptr[3 * r + 1] - row_ptr[3 * r]);
@@ -235,7 +241,11 @@ void Engine::wunit_build_host(WUnitHost &H, bool inplace, const void *segs_v, si
             if (seg_new[s] < 0) continue;
             const WinSeg &w = wsegs[(size_t)seg_new[s]];
             for (int j = 0; j < w.row_count; j++) row_slots((long)w.row_begin + j);
-            for (int j = 0; j < w.fb_count; j++) fbent[(size_t)w.fb_begin + (size_t)j].slot = take_slot(tcur, (size_t)fbent[(size_t)w.fb_begin + (size_t)j].idx);
+            for (int j = 0; j < w.fb_count; j++) {
+                WinEnt &f = fbent[(size_t)w.fb_begin + (size_t)j];
+                f.slot = take_slot(tcur, (size_t)f.idx);
+                if (defer_fb) H.fbrec[(size_t)f.slot] = WinFbRec{seg_new[s], f.val};
+            }
         }
     }
     for (size_t j = 0; j < nunit; j++) units[j].first = wsegs[(size_t)units[j].seg_begin];   // the first segment travels with the unit record
@@ -272,6 +282,9 @@ void Engine::wunit_adopt(Dataset *ds, const WUnitHost &H) {
     if (ds->wu_estride == 0) ds->wu_rptr.upload(rptr.data(), (size_t)2 * nrow + 1, stream_);
     ds->wu_ent.upload(ent.data(), (size_t)nent, stream_);
     ds->wu_fbent.upload(fbent.data(), (size_t)nfbe, stream_);
+    ds->wu_fbrec.upload(H.fbrec.data(), H.fbrec.size(), stream_);
+    ds->wu_nseg = (long)nseg_used;
+    ds->wu_defer_fb = !H.fbrec.empty();
     ds->wu_tptr.upload(tptr.data(), tptr.size(), stream_);
     ds->wu_gptr.upload(gptr.data(), gptr.size(), stream_);
     HIPCHECK(hipStreamSynchronize(stream_));   // the host columns go out of scope
@@ -400,6 +413,7 @@ void Engine::wunit_train(Dataset *ds) {
     d_contrib_.reserve((size_t)std::max<long>(ds->win_slots, 1) * (size_t)pitch_);
     d_cbias_.reserve((size_t)std::max<long>(ds->win_slots, 1));
     d_gcontrib_.reserve((size_t)std::max<long>(ds->wu_gslots, 1));
+    if (ds->wu_defer_fb) { d_dvec_.reserve((size_t)std::max<long>(ds->wu_nseg, 1) * (size_t)pitch_); d_dbias_.reserve((size_t)std::max<long>(ds->wu_nseg, 1)); }
     launch_wunit_walk(params(), wunit_view(ds), ds->wu_feedback, wunit_fast_, stream_);
     window_trained_ = ds;
 }

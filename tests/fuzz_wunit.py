@@ -110,7 +110,7 @@ def one(rng, torch, wave=False, onegpu=False):
         t.init_model()
         t.init_trainer()
         inplace = int(rng.integers(0, 4) != 0)
-        for kk, v in knobs + [("wunit_inplace", inplace)]:
+        for kk, v in knobs + [("wunit_inplace", inplace), ("wunit_defer_fb", int(rng.integers(0, 3) != 0))]:
             t.set_knob(kk, v)
         ds = t.dataset_from_blocks(data) if blocks_mode else t.dataset_from_csr(data)
         for _ in range(passes):
@@ -135,6 +135,7 @@ def one(rng, torch, wave=False, onegpu=False):
         t.close()
         return ok, desc
     dev = torch.device("cuda", 0)
+    defer_ranks = int(rng.integers(0, 3) != 0)   # feedback contributions formed by the sum kernel (default) or written as rows by the walk
     ranks = []
     for rk in range(world):
         t = sa.Trainer(fmt, active)
@@ -143,7 +144,7 @@ def one(rng, torch, wave=False, onegpu=False):
             t.set_param(kk, str(v))
         t.init_model()
         t.init_trainer()
-        for kk, v in knobs:
+        for kk, v in knobs + [("wunit_defer_fb", defer_ranks)]:
             t.set_knob(kk, v)
         ad = HipShard(t, torch, dev, minibatch=True)
         ad.set_wire_half(False)

@@ -234,7 +234,9 @@ def test_single_contributions_of_a_window_are_applied_in_place_with_the_same_bit
     """one-GPU window sequences: a shared row that meets exactly one contribution in a window gets no slot -- the unit applies it where it
     computes it, with the sum kernel's operations (apply_single).  Many more items than rows per window, so most contributions are single:
     every unit kernel (lane groups, slots, one wave per unit), fp32 and bf16 contribution rows, with and without user bias == the one-rank
-    oracle simulation bit for bit == the same pass with every contribution through a slot (knob wunit_inplace = 0)"""
+    oracle simulation bit for bit == the same pass with every contribution through a slot (knob wunit_inplace = 0) == the same passes with
+    the feedback rows' contributions written as rows by the walk (knob wunit_defer_fb = 0; default: k_wunit_sum forms them from the segments'
+    deltas against the rows it updates)"""
     import multi_rank_utils
     windows = 5
     if shape == "blocks":
@@ -248,8 +250,10 @@ def test_single_contributions_of_a_window_are_applied_in_place_with_the_same_bit
         conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, num_global=ng, wd_global="0.001") + list(extra)
         fmt, names, window = 0, ("W_item", "i_bias", "g_bias", "W_user", "u_bias"), n // windows
     got = []
-    for inplace in (1, 0):
-        t = _trainer(conf, fmt, 0, [("amd:step", "minibatch"), ("amd:window", window), ("amd:contrib", contrib)], knobs=(("wunit_fast", fast), ("wunit_inplace", inplace)))
+    # (in place, deferred feedback scatter): the default, every contribution through a slot, feedback contributions as rows written by the walk
+    for inplace, defer in ((1, 1), (0, 1), (1, 0), (0, 0)):
+        t = _trainer(conf, fmt, 0, [("amd:step", "minibatch"), ("amd:window", window), ("amd:contrib", contrib)],
+                     knobs=(("wunit_fast", fast), ("wunit_inplace", inplace), ("wunit_defer_fb", defer)))
         ds = t.dataset_from_blocks(data) if fmt == 1 else t.dataset_from_csr(data)
         assert ds.kind == 8
         for _ in range(2):
@@ -263,7 +267,8 @@ def test_single_contributions_of_a_window_are_applied_in_place_with_the_same_bit
     finally:
         multi_rank_utils.CONTRIB_BF16 = False
     for name in names:
-        assert np.array_equal(got[0][name].view(np.uint32), got[1][name].view(np.uint32)), name
+        for other in got[1:]:
+            assert np.array_equal(got[0][name].view(np.uint32), other[name].view(np.uint32)), name
         assert np.array_equal(got[0][name].view(np.uint32), sim[0].t.view(name).view(np.uint32)), name
 
 

@@ -17,7 +17,7 @@ def main():
     seeds = [int(x) for x in sys.argv[2].split(",")]
     targets = [int(x) for x in sys.argv[3].split(",")]
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else 3
-    a = argparse.Namespace(users=1_000_000, items=100_000, globals=10_000, svdpp_users=40_000, svdpp_per_user=100, neighbour_rows=4_000_000,
+    a = argparse.Namespace(users=1_000_000, items=100_000, globals=10_000, svdpp_users=int(os.environ.get("WSTEP_USERS", "40000")), svdpp_per_user=100, neighbour_rows=4_000_000,
                            step_window=0, step_per_target=0, data_seed=0, contrib=os.environ.get("WSTEP_CONTRIB", "fp32"))
     log = lambda m: print("[probe] " + m, file=sys.stderr, flush=True)
     for seed in seeds:
