@@ -325,7 +325,8 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  * records), "small_blocks" (0 = 256-thread workgroups also for small levels), "fewrow_gslots" (0 = the general few-row kernel for rows with
  * inline global slots); the window-minibatch step for user units: "wunit_fast" (0 = lane groups for every shape, 1 = + the slot kernel,
  * 2 = + one wave per user unit: default), "wunit_inplace" (one-GPU window sequences: 0 = every contribution through a slot, default 1 = a
- * row's only contribution of a window applied in place; same bits), "window_per_target" / "window_per_target_fb" (updates a shared row
+ * row's only contribution of a window applied in place; same bits), "wunit_defer_fb" (default 1 = a feedback row's contributions are formed by the sum
+ * kernel from the segments' deltas; 0 = written as contribution rows by the walk; same bits), "window_per_target" / "window_per_target_fb" (updates a shared row
  * meets per window when `amd:window` is not set: these two DO change the opt-in step's windows, hence its result); the one-off builders:
  * "device_init" (0 = SVDModel::rand_init as the reference's host loop instead of svdf_k_init.hip; same model, same rand() position),
  * "device_init_margin_log2" (values closer than 2^-this to a float rounding boundary are recomputed with the host libm; default 46),
