@@ -259,6 +259,8 @@ struct Dataset {
     DevBuf<WinSeg> wu_segs;
     DevBuf<int> wu_rptr, wu_tptr, wu_gptr;
     DevBuf<WinEnt> wu_ent, wu_fbent;
+    DevBuf<WinTouched> wu_touched; // one-GPU window sequences: targets with slots (in-place sums)
+    long wu_ntouched = -1;         // -1: no list
     DevBuf<WinFbRec> wu_fbrec;    // deferred feedback scatter: slot-ordered (segment, value) records; empty = the walk writes contribution rows
     long wu_nseg = 0;
     bool wu_defer_fb = false;

@@ -230,6 +230,8 @@ struct WinEnt { unsigned idx; float val; int slot; int pad; };
 // deferred feedback scatter (round 5): slot s of a feedback row holds WHO contributes -- the segment whose scaled delta d the sum kernel reads
 // from dvec[seg] -- and the entry's value; the contribution (w + d val) - w is formed by k_wunit_sum against the row it is about to update
 struct WinFbRec { int seg; float val; };
+// one-GPU windows: the targets that have slots at all (target, first slot, one past its last): the in-place sums walk this list instead of every row
+struct WinTouched { int t, b, e; };
 struct WUnitSchedule {
     const WinUnit *units;
     long nunits;
@@ -248,6 +250,8 @@ struct WUnitSchedule {
     const WinFbRec *fbrec;      // nullptr: feedback contributions are rows in `contrib` (written by the walk); else deferred: [tptr[nfb_rows]] records
     float *dvec, *dbias;        // deferred: the scaled delta of every segment (row pitch = the model's), its bias delta
     int user_bias;              // 1 unless no_user_bias
+    const WinTouched *touched;  // nullptr: every target is visited (wire buffers need the untouched rows' zeros); else [ntouched]
+    long ntouched;
 };
 
 }  // namespace svdf

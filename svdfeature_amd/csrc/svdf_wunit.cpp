@@ -37,6 +37,8 @@ struct WUnitHost {
     std::vector<int> rptr, tptr, gptr;
     std::vector<WinEnt> ent, fbent;
     std::vector<WinFbRec> fbrec;   // deferred feedback scatter (empty: contribution rows)
+    std::vector<WinTouched> touched;   // one-GPU windows (inplace builds): the targets that keep slots
+    bool has_touched = false;
     long nrow = 0, nent = 0, nfbe = 0, item_entries = 0, global_entries = 0;
     int fixed_ng = -2;
     bool unit_uval = true, feedback = false;
@@ -54,6 +56,7 @@ WUnitSchedule Engine::wunit_view(const Dataset *ds) const {
     S.contrib_bf16 = contrib_bf16_ ? 1 : 0;
     S.fbrec = ds->wu_defer_fb ? ds->wu_fbrec.p : nullptr; S.dvec = d_dvec_.p; S.dbias = d_dbias_.p;
     S.user_bias = mp_.no_user_bias ? 0 : 1;
+    S.touched = ds->wu_ntouched >= 0 ? ds->wu_touched.p : nullptr; S.ntouched = std::max<long>(ds->wu_ntouched, 0);
     return S;
 }
 
@@ -248,6 +251,10 @@ void Engine::wunit_build_host(WUnitHost &H, bool inplace, const void *segs_v, si
             }
         }
     }
+    if (inplace) {   // the in-place sums visit only the targets that have slots (a window touches a fraction of the rows; singles keep none)
+        H.has_touched = true;
+        for (size_t t = 0; t < (size_t)(NF + NI); t++) if (tptr[t + 1] > tptr[t]) H.touched.push_back(WinTouched{(int)t, tptr[t], tptr[t + 1]});
+    }
     for (size_t j = 0; j < nunit; j++) units[j].first = wsegs[(size_t)units[j].seg_begin];   // the first segment travels with the unit record
     H.nrow = nrow; H.nent = nent; H.nfbe = nfbe; H.fixed_ng = fixed_ng; H.unit_uval = unit_uval;
     for (long nr = 0; nr < nrow; nr++) { const int g = rptr[(size_t)2 * nr + 1] - rptr[(size_t)2 * nr]; H.global_entries += g; H.item_entries += rptr[(size_t)2 * nr + 2] - rptr[(size_t)2 * nr] - g; }
@@ -283,6 +290,8 @@ void Engine::wunit_adopt(Dataset *ds, const WUnitHost &H) {
     ds->wu_ent.upload(ent.data(), (size_t)nent, stream_);
     ds->wu_fbent.upload(fbent.data(), (size_t)nfbe, stream_);
     ds->wu_fbrec.upload(H.fbrec.data(), H.fbrec.size(), stream_);
+    ds->wu_ntouched = H.has_touched ? (long)H.touched.size() : -1;
+    if (H.has_touched) ds->wu_touched.upload(H.touched.data(), H.touched.size(), stream_);
     ds->wu_nseg = (long)nseg_used;
     ds->wu_defer_fb = !H.fbrec.empty();
     ds->wu_tptr.upload(tptr.data(), tptr.size(), stream_);
