@@ -305,33 +305,44 @@ __device__ __forceinline__ float *addto_slot(const DeltaRanges &R, long j) {
 // exchange partition (svdf_item_delta_select) -- the packed layout of k_delta_pack.
 // LOCAL (stratified schedule): the rank owns the item block exclusively, so there is no sum over ranks and the
 // per-item sum is added to the model in place: dst = W_item's first row (row i at dst + i * pitch), dbias = i_bias; fp32, no wire buffer.
+// LONG lists (round 5).  The window rule lets a row meet up to 128 updates per window, and on skewed data (Zipf-popular items) the hottest rows do: one
+// lane group adding 128 slots eight at a time is sixteen dependent round trips -- 42 us per window of 13 K ratings, when the users' walk takes 6.  A lane
+// group that meets a list longer than HOT_MIN therefore queues it (LDS), and after the scan the WHOLE workgroup loads such a list's slots side by side into
+// LDS (one round trip per 16 - 64 slots) and its first lane group adds them in slot order: the same additions in the same order, hence the same bits.
+#define SVDF_WIN_HOT_MIN 16
+#define SVDF_WIN_HOT_QUEUE 32
 template <int LPI, bool HALF, bool LOCAL>
 __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, int pitch, int k, long lo, long hi, long nglobal, void *dst, float *dbias) {
-    constexpr int IPW = 64 / LPI;
+    constexpr int IPW = 64 / LPI, G = 256 / LPI;
+    constexpr int CHUNK = LPI >= 64 ? 16 : (LPI >= 32 ? 32 : 64);   // slots staged at a time: at most 16 KB of LDS whatever the width
+    __shared__ int hq_it[SVDF_WIN_HOT_QUEUE], hq_b[SVDF_WIN_HOT_QUEUE], hq_e[SVDF_WIN_HOT_QUEUE];
+    __shared__ int hq_n;
+    __shared__ float4 stage[CHUNK * LPI];
+    __shared__ float stage_b[CHUNK];
     const int lane = threadIdx.x & 63;
     const int L = lane & (LPI - 1);
+    const int grp = threadIdx.x / LPI;
     const long stride = (long)gridDim.x * (blockDim.x >> 6) * IPW;
     const long first = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * IPW + lane / LPI;
     const long nitem = hi - lo;
-    for (long it = first; it < nitem; it += stride) {
+    const bool owns = !(LPI * 4 > k && L * 4 >= k);
+    if (threadIdx.x == 0) hq_n = 0;
+    __syncthreads();
+    // what becomes of a finished sum: added to the model in place (LOCAL) or written to the wire buffer
+    auto finish = [&](long it, int b, int e, const float4 &acc, float accb) {
         const long i = lo + it;
-        const int b = S.iptr[i], e = S.iptr[i + 1];
-        float4 acc = f4zero();
-        float accb = 0.0f;
-        if (S.contrib_bf16) sum_contrib_slots<LPI, true>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
-        else sum_contrib_slots<LPI, false>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
         if (LOCAL) {
-            if (b == e) continue;   // nobody rated the item in this window
-            if (!(LPI * 4 > k && L * 4 >= k)) {
+            if (b == e) return;   // nobody rated the item in this window
+            if (owns) {
                 float4 *w = reinterpret_cast<float4 *>(reinterpret_cast<float *>(dst) + (size_t)i * pitch + (size_t)L * 4);
                 float4 c = *w;
                 c.x = c.x + acc.x; c.y = c.y + acc.y; c.z = c.z + acc.z; c.w = c.w + acc.w;
                 *w = c;
             }
             if (L == 0) dbias[i] = dbias[i] + accb;
-            continue;
+            return;
         }
-        if (!(LPI * 4 > k && L * 4 >= k)) {
+        if (owns) {
             const size_t pos = (size_t)it * pitch + (size_t)L * 4;
             if (HALF) {
                 __half2 *h = reinterpret_cast<__half2 *>(reinterpret_cast<__half *>(dst) + pos);
@@ -346,6 +357,56 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
             if (HALF) reinterpret_cast<__half *>(dst)[pos] = __float2half_rn(accb);
             else reinterpret_cast<float *>(dst)[pos] = accb;
         }
+    };
+    for (long it = first; it < nitem; it += stride) {
+        const long i = lo + it;
+        const int b = S.iptr[i], e = S.iptr[i + 1];
+        if (e - b > SVDF_WIN_HOT_MIN) {   // a long list: left to the whole workgroup (below) while the queue has room
+            int pos = SVDF_WIN_HOT_QUEUE;
+            if (L == 0) pos = atomicAdd(&hq_n, 1);
+            pos = __shfl(pos, (lane / LPI) * LPI);
+            if (pos < SVDF_WIN_HOT_QUEUE) {
+                if (L == 0) { hq_it[pos] = (int)it; hq_b[pos] = b; hq_e[pos] = e; }
+                continue;
+            }
+        }
+        float4 acc = f4zero();
+        float accb = 0.0f;
+        if (S.contrib_bf16) sum_contrib_slots<LPI, true>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
+        else sum_contrib_slots<LPI, false>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
+        finish(it, b, e, acc, accb);
+    }
+    __syncthreads();
+    const int nq = min(hq_n, SVDF_WIN_HOT_QUEUE);
+    for (int qi = 0; qi < nq; qi++) {
+        const int b = hq_b[qi], e = hq_e[qi];
+        float4 acc = f4zero();
+        float accb = 0.0f;
+        for (int c0 = b; c0 < e; c0 += CHUNK) {
+            const int cn = min(CHUNK, e - c0);
+            // every lane group requests its share of the chunk's slots at once (CHUNK / G per group), then parks them in LDS
+            constexpr int PER = (CHUNK + G - 1) / G;
+            float4 v[PER];
+            float vb[PER];
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const int sl = grp + r * G;
+                const bool in = sl < cn;
+                v[r] = in ? load_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)(c0 + sl), pitch, L, k) : f4zero();
+                vb[r] = (in && L == 0) ? S.cbias[c0 + sl] : 0.0f;
+            }
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const int sl = grp + r * G;
+                if (sl < cn) { stage[sl * LPI + L] = v[r]; if (L == 0) stage_b[sl] = vb[r]; }
+            }
+            __syncthreads();
+            if (grp == 0) {   // slot order, acc = ((0 + c_1) + c_2) + ... as sum_contrib_slots does
+                for (int sl = 0; sl < cn; sl++) { add_rows(acc, stage[sl * LPI + L]); accb = accb + stage_b[sl]; }
+            }
+            __syncthreads();
+        }
+        if (grp == 0) finish((long)hq_it[qi], b, e, acc, accb);
     }
     if (LOCAL) return;
     // the global biases' part of the wire buffer: a window data set carries no global entry
