@@ -416,6 +416,92 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
         else reinterpret_cast<float *>(dst)[g0 + j] = 0.0f;
     }
 }
+// SPARSE windows (round 5): the windows the max-updates rule cuts on skewed data hold far fewer instances than there are items (13 K ratings over
+// 100 K items), and a lane group per ITEM is then 25 K waves that find nothing.  Here a THREAD looks at one item, the workgroup's items that have slots
+// go to an LDS queue, the lane groups share the queue (long lists: the cooperative form above).  In place only; same additions in the same order.
+template <int LPI>
+__global__ __launch_bounds__(256) void k_window_items_sparse(const WindowSchedule S, int pitch, int k, long lo, long hi, float *w_item, float *dbias) {
+    constexpr int G = 256 / LPI;
+    constexpr int CHUNK = LPI >= 64 ? 16 : (LPI >= 32 ? 32 : 64);
+    __shared__ int q_it[256], q_b[256], q_e[256];
+    __shared__ int hq_idx[SVDF_WIN_HOT_QUEUE];
+    __shared__ int q_n, hq_n;
+    __shared__ float4 stage[CHUNK * LPI];
+    __shared__ float stage_b[CHUNK];
+    const int lane = threadIdx.x & 63;
+    const int L = lane & (LPI - 1);
+    const int grp = threadIdx.x / LPI;
+    const long nitem = hi - lo;
+    const bool owns = !(LPI * 4 > k && L * 4 >= k);
+    auto finish = [&](long it, const float4 &acc, float accb) {
+        const long i = lo + it;
+        if (owns) {
+            float4 *w = reinterpret_cast<float4 *>(w_item + (size_t)i * pitch + (size_t)L * 4);
+            float4 c = *w;
+            c.x = c.x + acc.x; c.y = c.y + acc.y; c.z = c.z + acc.z; c.w = c.w + acc.w;
+            *w = c;
+        }
+        if (L == 0) dbias[i] = dbias[i] + accb;
+    };
+    for (long base = (long)blockIdx.x * 256; base < nitem; base += (long)gridDim.x * 256) {
+        if (threadIdx.x == 0) { q_n = 0; hq_n = 0; }
+        __syncthreads();
+        const long it = base + threadIdx.x;
+        if (it < nitem) {
+            const int b = S.iptr[lo + it], e = S.iptr[lo + it + 1];
+            if (e > b) { const int pos = atomicAdd(&q_n, 1); q_it[pos] = (int)it; q_b[pos] = b; q_e[pos] = e; }
+        }
+        __syncthreads();
+        const int n = q_n;
+        for (int idx = grp; idx < n; idx += G) {
+            const int b = q_b[idx], e = q_e[idx];
+            if (e - b > SVDF_WIN_HOT_MIN) {
+                int pos = SVDF_WIN_HOT_QUEUE;
+                if (L == 0) pos = atomicAdd(&hq_n, 1);
+                pos = __shfl(pos, (lane / LPI) * LPI);
+                if (pos < SVDF_WIN_HOT_QUEUE) { if (L == 0) hq_idx[pos] = idx; continue; }
+            }
+            float4 acc = f4zero();
+            float accb = 0.0f;
+            if (S.contrib_bf16) sum_contrib_slots<LPI, true, 4>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
+            else sum_contrib_slots<LPI, false, 4>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
+            finish((long)q_it[idx], acc, accb);
+        }
+        __syncthreads();
+        const int nq = min(hq_n, SVDF_WIN_HOT_QUEUE);
+        for (int qi = 0; qi < nq; qi++) {
+            const int idx = hq_idx[qi];
+            const int b = q_b[idx], e = q_e[idx];
+            float4 acc = f4zero();
+            float accb = 0.0f;
+            for (int c0 = b; c0 < e; c0 += CHUNK) {
+                const int cn = min(CHUNK, e - c0);
+                constexpr int PER = (CHUNK + G - 1) / G;
+                float4 v[PER];
+                float vb[PER];
+#pragma unroll
+                for (int r = 0; r < PER; r++) {
+                    const int sl = grp + r * G;
+                    const bool in = sl < cn;
+                    v[r] = in ? load_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)(c0 + sl), pitch, L, k) : f4zero();
+                    vb[r] = (in && L == 0) ? S.cbias[c0 + sl] : 0.0f;
+                }
+#pragma unroll
+                for (int r = 0; r < PER; r++) {
+                    const int sl = grp + r * G;
+                    if (sl < cn) { stage[sl * LPI + L] = v[r]; if (L == 0) stage_b[sl] = vb[r]; }
+                }
+                __syncthreads();
+                if (grp == 0) {
+                    for (int sl = 0; sl < cn; sl++) { add_rows(acc, stage[sl * LPI + L]); accb = accb + stage_b[sl]; }
+                }
+                __syncthreads();
+            }
+            if (grp == 0) finish((long)q_it[idx], acc, accb);
+        }
+        __syncthreads();
+    }
+}
 void launch_window_items(const WindowSchedule &S, int pitch, int k, long lo, long hi, long nglobal, void *dst, int half, hipStream_t st) {
     if (hi <= lo && nglobal <= 0) return;
     const int lpi = lanes_per_instance(k);
@@ -427,9 +513,14 @@ void launch_window_items(const WindowSchedule &S, int pitch, int k, long lo, lon
     else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, false>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst, (float *)nullptr)); }
 }
 // the same sums added in place to the rows / biases of items [lo, hi): W_item + i * pitch, i_bias + i
-void launch_window_items_local(const WindowSchedule &S, int pitch, int k, long lo, long hi, float *w_item, float *i_bias, hipStream_t st) {
+void launch_window_items_local(const WindowSchedule &S, int pitch, int k, long lo, long hi, float *w_item, float *i_bias, hipStream_t st, long nslots) {
     if (hi <= lo) return;
     const int lpi = lanes_per_instance(k);
+    if (nslots >= 0 && nslots * 2 < hi - lo) {   // far fewer contributions than items: most items have none (k_window_items_sparse)
+        const long grid = std::min<long>((hi - lo + 255) / 256, 16384);
+        SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items_sparse<LPI>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, w_item, i_bias));
+        return;
+    }
     const long ipw = 64 / lpi;
     long waves = (hi - lo + ipw - 1) / ipw;
     long grid = (waves + 3) / 4;

@@ -231,7 +231,7 @@ void Engine::window_delta_apply_local(Dataset *ds) {
     const long lo = ni * delta_part_ / delta_nparts_, hi = ni * (delta_part_ + 1) / delta_nparts_;
     check(ds->win_item_hi < 0 || (ds->win_item_lo >= lo && ds->win_item_hi < hi),
           "window_delta_apply_local: the window holds instances of items outside the active item block (svdf_item_delta_select): their updates would be lost");
-    launch_window_items_local(window_view(ds), pitch_, mp_.num_factor, lo, hi, dW_.p + (size_t)item_off_ * pitch_, dbias_.p + item_off_, stream_);
+    launch_window_items_local(window_view(ds), pitch_, mp_.num_factor, lo, hi, dW_.p + (size_t)item_off_ * pitch_, dbias_.p + item_off_, stream_, ds->win_slots);
     HIPCHECK(hipGetLastError());
     n_launches_++;
 }

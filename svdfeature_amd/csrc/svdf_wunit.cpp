@@ -696,7 +696,7 @@ void Engine::wseq_train(Dataset *ds) {
             d_contrib_.reserve((size_t)std::max<long>(c->win_slots, 1) * (size_t)pitch_);
             d_cbias_.reserve((size_t)std::max<long>(c->win_slots, 1));
             launch_window_users(P, window_view(c), window_slots_, window_groups_, stream_);
-            launch_window_items_local(window_view(c), pitch_, mp_.num_factor, 0, mp_.num_item, dW_.p + (size_t)item_off_ * pitch_, dbias_.p + item_off_, stream_);
+            launch_window_items_local(window_view(c), pitch_, mp_.num_factor, 0, mp_.num_item, dW_.p + (size_t)item_off_ * pitch_, dbias_.p + item_off_, stream_, c->win_slots);
         } else {
             wunit_train(c);
             wunit_sum(c, nullptr, 0);
