@@ -401,8 +401,15 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
                 if (sl < cn) { stage[sl * LPI + L] = v[r]; if (L == 0) stage_b[sl] = vb[r]; }
             }
             __syncthreads();
-            if (grp == 0) {   // slot order, acc = ((0 + c_1) + c_2) + ... as sum_contrib_slots does
-                for (int sl = 0; sl < cn; sl++) { add_rows(acc, stage[sl * LPI + L]); accb = accb + stage_b[sl]; }
+            if (grp == 0) {   // slot order, acc = ((0 + c_1) + c_2) + ... as sum_contrib_slots does; eight LDS reads requested ahead of their (ordered) additions
+                for (int sl = 0; sl < cn; sl += 8) {
+                    float4 t[8];
+                    float tb[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) { const int x = min(sl + q, cn - 1); t[q] = stage[x * LPI + L]; tb[q] = stage_b[x]; }
+#pragma unroll
+                    for (int q = 0; q < 8; q++) if (sl + q < cn) { add_rows(acc, t[q]); accb = accb + tb[q]; }
+                }
             }
             __syncthreads();
         }
@@ -493,7 +500,14 @@ __global__ __launch_bounds__(256) void k_window_items_sparse(const WindowSchedul
                 }
                 __syncthreads();
                 if (grp == 0) {
-                    for (int sl = 0; sl < cn; sl++) { add_rows(acc, stage[sl * LPI + L]); accb = accb + stage_b[sl]; }
+                    for (int sl = 0; sl < cn; sl += 8) {
+                        float4 t[8];
+                        float tb[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) { const int x = min(sl + q, cn - 1); t[q] = stage[x * LPI + L]; tb[q] = stage_b[x]; }
+#pragma unroll
+                        for (int q = 0; q < 8; q++) if (sl + q < cn) { add_rows(acc, t[q]); accb = accb + tb[q]; }
+                    }
                 }
                 __syncthreads();
             }
