@@ -311,14 +311,14 @@ __device__ __forceinline__ float *addto_slot(const DeltaRanges &R, long j) {
 // LDS (one round trip per 16 - 64 slots) and its first lane group adds them in slot order: the same additions in the same order, hence the same bits.
 #define SVDF_WIN_HOT_MIN 16
 #define SVDF_WIN_HOT_QUEUE 32
-template <int LPI, bool HALF, bool LOCAL>
-__global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, int pitch, int k, long lo, long hi, long nglobal, void *dst, float *dbias) {
+template <int LPI, bool HALF, bool LOCAL, bool HOT>   // HOT: the window may hold lists that are long relative to its mean (the launcher decides: dense windows keep the plain form)
+__global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, int pitch, int k, long lo, long hi, long nglobal, void *dst, float *dbias, int hot_min) {
     constexpr int IPW = 64 / LPI, G = 256 / LPI;
     constexpr int CHUNK = LPI >= 64 ? 16 : (LPI >= 32 ? 32 : 64);   // slots staged at a time: at most 16 KB of LDS whatever the width
-    __shared__ int hq_it[SVDF_WIN_HOT_QUEUE], hq_b[SVDF_WIN_HOT_QUEUE], hq_e[SVDF_WIN_HOT_QUEUE];
+    __shared__ int hq_it[HOT ? SVDF_WIN_HOT_QUEUE : 1], hq_b[HOT ? SVDF_WIN_HOT_QUEUE : 1], hq_e[HOT ? SVDF_WIN_HOT_QUEUE : 1];
     __shared__ int hq_n;
-    __shared__ float4 stage[CHUNK * LPI];
-    __shared__ float stage_b[CHUNK];
+    __shared__ float4 stage[HOT ? CHUNK * LPI : 1];
+    __shared__ float stage_b[HOT ? CHUNK : 1];
     const int lane = threadIdx.x & 63;
     const int L = lane & (LPI - 1);
     const int grp = threadIdx.x / LPI;
@@ -326,8 +326,10 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
     const long first = ((long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * IPW + lane / LPI;
     const long nitem = hi - lo;
     const bool owns = !(LPI * 4 > k && L * 4 >= k);
-    if (threadIdx.x == 0) hq_n = 0;
-    __syncthreads();
+    if constexpr (HOT) {
+        if (threadIdx.x == 0) hq_n = 0;
+        __syncthreads();
+    }
     // what becomes of a finished sum: added to the model in place (LOCAL) or written to the wire buffer
     auto finish = [&](long it, int b, int e, const float4 &acc, float accb) {
         const long i = lo + it;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
     for (long it = first; it < nitem; it += stride) {
         const long i = lo + it;
         const int b = S.iptr[i], e = S.iptr[i + 1];
-        if (e - b > SVDF_WIN_HOT_MIN) {   // a long list: left to the whole workgroup (below) while the queue has room
+        if (HOT && e - b > hot_min) {   // a long list: left to the whole workgroup (below) while the queue has room
             int pos = SVDF_WIN_HOT_QUEUE;
             if (L == 0) pos = atomicAdd(&hq_n, 1);
             pos = __shfl(pos, (lane / LPI) * LPI);
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
         else sum_contrib_slots<LPI, false>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
         finish(it, b, e, acc, accb);
     }
+    if constexpr (HOT) {
     __syncthreads();
     const int nq = min(hq_n, SVDF_WIN_HOT_QUEUE);
     for (int qi = 0; qi < nq; qi++) {
@@ -415,6 +418,7 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
         }
         if (grp == 0) finish((long)hq_it[qi], b, e, acc, accb);
     }
+    }
     if (LOCAL) return;
     // the global biases' part of the wire buffer: a window data set carries no global entry
     const long g0 = nitem * (long)(pitch + 1);
@@ -427,7 +431,7 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
 // 100 K items), and a lane group per ITEM is then 25 K waves that find nothing.  Here a THREAD looks at one item, the workgroup's items that have slots
 // go to an LDS queue, the lane groups share the queue (long lists: the cooperative form above).  In place only; same additions in the same order.
 template <int LPI>
-__global__ __launch_bounds__(256) void k_window_items_sparse(const WindowSchedule S, int pitch, int k, long lo, long hi, float *w_item, float *dbias) {
+__global__ __launch_bounds__(256) void k_window_items_sparse(const WindowSchedule S, int pitch, int k, long lo, long hi, float *w_item, float *dbias, int hot_min) {
     constexpr int G = 256 / LPI;
     constexpr int CHUNK = LPI >= 64 ? 16 : (LPI >= 32 ? 32 : 64);
     __shared__ int q_it[256], q_b[256], q_e[256];
@@ -462,7 +466,7 @@ __global__ __launch_bounds__(256) void k_window_items_sparse(const WindowSchedul
         const int n = q_n;
         for (int idx = grp; idx < n; idx += G) {
             const int b = q_b[idx], e = q_e[idx];
-            if (e - b > SVDF_WIN_HOT_MIN) {
+            if (e - b > hot_min) {
                 int pos = SVDF_WIN_HOT_QUEUE;
                 if (L == 0) pos = atomicAdd(&hq_n, 1);
                 pos = __shfl(pos, (lane / LPI) * LPI);
@@ -516,15 +520,29 @@ __global__ __launch_bounds__(256) void k_window_items_sparse(const WindowSchedul
         __syncthreads();
     }
 }
-void launch_window_items(const WindowSchedule &S, int pitch, int k, long lo, long hi, long nglobal, void *dst, int half, hipStream_t st) {
+// A list is LONG relative to its window: the cooperative form serialises a workgroup's long lists, which pays when they are the exception (the hot rows of a
+// skewed window) and costs when every list is long (a dense window of uniform data: 24 slots per item at configs[1], 300 at configs[4] -- there the lane
+// groups' own loops, all busy at once, are the parallel form).  Long = more than 16 slots AND more than four times the window's mean list.
+static int window_hot_min(long nslots, long nitems) {
+    if (nslots < 0 || nitems <= 0) return 0x7FFFFFFF;   // unknown: never
+    const long mean4 = 4 * ((nslots + nitems - 1) / nitems);
+    return (int)std::min<long>(std::max<long>(SVDF_WIN_HOT_MIN, mean4), 0x7FFFFFFF);
+}
+// dense windows (8 or more slots per item on average: uniform data) run the plain form of the kernel: no queue, no LDS, no barrier
+static bool window_may_hold_long_lists(long nslots, long nitems) { return nslots >= 0 && nitems > 0 && nslots < 8 * nitems; }
+void launch_window_items(const WindowSchedule &S, int pitch, int k, long lo, long hi, long nglobal, void *dst, int half, hipStream_t st, long nslots) {
     if (hi <= lo && nglobal <= 0) return;
     const int lpi = lanes_per_instance(k);
     const long ipw = 64 / lpi;
     long waves = (std::max<long>(hi - lo, 1) + ipw - 1) / ipw;
     long grid = (waves + 3) / 4;
     if (grid > 16384) grid = 16384;
-    if (half) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, true, false>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst, (float *)nullptr)); }
-    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, false>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst, (float *)nullptr)); }
+    const int hot_min = window_hot_min(nslots, hi - lo);
+    const bool hot = window_may_hold_long_lists(nslots, hi - lo);
+    if (half && hot) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, true, false, true>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst, (float *)nullptr, hot_min)); }
+    else if (half) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, true, false, false>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst, (float *)nullptr, hot_min)); }
+    else if (hot) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, false, true>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst, (float *)nullptr, hot_min)); }
+    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, false, false>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, nglobal, dst, (float *)nullptr, hot_min)); }
 }
 // the same sums added in place to the rows / biases of items [lo, hi): W_item + i * pitch, i_bias + i
 void launch_window_items_local(const WindowSchedule &S, int pitch, int k, long lo, long hi, float *w_item, float *i_bias, hipStream_t st, long nslots) {
@@ -532,14 +550,15 @@ void launch_window_items_local(const WindowSchedule &S, int pitch, int k, long l
     const int lpi = lanes_per_instance(k);
     if (nslots >= 0 && nslots * 2 < hi - lo) {   // far fewer contributions than items: most items have none (k_window_items_sparse)
         const long grid = std::min<long>((hi - lo + 255) / 256, 16384);
-        SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items_sparse<LPI>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, w_item, i_bias));
+        SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items_sparse<LPI>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, w_item, i_bias, window_hot_min(nslots, hi - lo)));
         return;
     }
     const long ipw = 64 / lpi;
     long waves = (hi - lo + ipw - 1) / ipw;
     long grid = (waves + 3) / 4;
     if (grid > 16384) grid = 16384;
-    SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, true>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, 0L, (void *)w_item, i_bias));
+    if (window_may_hold_long_lists(nslots, hi - lo)) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, true, true>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, 0L, (void *)w_item, i_bias, window_hot_min(nslots, hi - lo))); }
+    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, true, false>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, 0L, (void *)w_item, i_bias, 0x7FFFFFFF)); }
 }
 // the replicated ranges of the active partition as one packed fp32 buffer and back (the item block a rank hands to the next one)
 template <bool SET>

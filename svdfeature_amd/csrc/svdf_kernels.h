@@ -52,7 +52,7 @@ void launch_delta_unpack(const DeltaRanges &R, float *snap, const void *src, int
 // buffer (item range [lo, hi) + nglobal zeros), and replicated ranges += all-reduced wire buffer
 bool window_slots_applies(const DevParams &P, const WindowSchedule &S);
 void launch_window_users(const DevParams &P, const WindowSchedule &S, int slots, int groups_per_wave, hipStream_t st);
-void launch_window_items(const WindowSchedule &S, int pitch, int k, long lo, long hi, long nglobal, void *dst, int half, hipStream_t st);
+void launch_window_items(const WindowSchedule &S, int pitch, int k, long lo, long hi, long nglobal, void *dst, int half, hipStream_t st, long nslots = -1);
 void launch_delta_addto(const DeltaRanges &R, const void *src, int half, hipStream_t st);
 void launch_window_items_local(const WindowSchedule &S, int pitch, int k, long lo, long hi, float *w_item, float *i_bias, hipStream_t st, long nslots = -1);   // nslots: contributions in the window (sparse windows take k_window_items_sparse)
 void launch_ranges_copy(const DeltaRanges &R, float *buf, int set, hipStream_t st);

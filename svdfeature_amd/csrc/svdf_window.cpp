@@ -208,7 +208,7 @@ void Engine::window_delta_pack(Dataset *ds, void *device_dst, int half, int64_t 
     if (!device_dst) return;
     need_device("window_delta");
     check(window_trained_ == ds, "window_delta_pack: train this window data set first (svdf_train_dataset)");
-    launch_window_items(window_view(ds), pitch_, mp_.num_factor, lo, hi, nglobal, device_dst, half, stream_);
+    launch_window_items(window_view(ds), pitch_, mp_.num_factor, lo, hi, nglobal, device_dst, half, stream_, ds->win_slots);
     HIPCHECK(hipGetLastError());
     n_launches_++;
 }

@@ -280,7 +280,8 @@ def test_apply_local_refuses_a_window_with_items_outside_the_active_block():
 
 
 @pytest.mark.parametrize("k,ni,contrib", [(16, 9, "fp32"), (64, 9, "bf16"), (128, 9, "fp32"), (200, 9, "fp32"), (256, 5, "bf16"), (16, 300, "fp32"), (8, 500, "fp32"),
-                                          (64, 30000, "fp32"), (128, 30000, "bf16"), (16, 30000, "fp32"), (256, 30000, "fp32")])
+                                          (64, 30000, "fp32"), (128, 30000, "bf16"), (16, 30000, "fp32"), (256, 30000, "fp32"),
+                                          (64, 2000, "fp32"), (128, 2000, "bf16"), (16, 2000, "fp32"), (200, 2000, "fp32"), (8, 1000, "fp32")])
 def test_long_contribution_lists_are_summed_by_the_whole_workgroup_in_slot_order(k, ni, contrib):
     """items that meet far more than 16 contributions per window (a Zipf-popular catalogue): k_window_items queues such lists and the whole workgroup
     loads their slots into LDS, one lane group adds them in slot order -- lists of ~600 slots (several LDS chunks) at every width, and more long lists
@@ -290,7 +291,10 @@ def test_long_contribution_lists_are_summed_by_the_whole_workgroup_in_slot_order
     import multi_rank_utils
     nu, n, windows = 2000, 24000, 4
     u, i, r = cases.planted_triples(n, nu, ni, seed=k + ni)
-    if ni >= 30000:   # a SPARSE window (6 000 ratings over 30 000 items: the in-place sums take k_window_items_sparse) with two hot items (2 000 / 850 slots per window)
+    if ni == 1000:    # a hundred neighbouring items with ~40 slots each among 6 per item on average: more long lists than one workgroup's queue holds
+        i[: 2 * n // 3] = i[: 2 * n // 3] % 100
+    if ni >= 2000:    # lists are LONG relative to their window's mean (more than 16 slots and more than 4 x the mean: dense windows of uniform data keep the lane-group loops);
+                      # ni = 2 000: the scan kernel's cooperative form (3 slots per item on average, two hot items); ni = 30 000: a SPARSE window (6 000 ratings over 30 000 items: the in-place sums take k_window_items_sparse) with two hot items (2 000 / 850 slots per window)
         i[::3] = 7
         i[1::7] = 11
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, learning_rate=0.0005)
