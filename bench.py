@@ -1217,9 +1217,25 @@ def main():
         if rank == 0:
             if extra:
                 out.update(extra)
+            # the full object (any size) -> bench_secondary.json + a short table on stderr; stdout gets the contract head with one compact
+            # tuple per secondary, asserted <= 6 000 bytes (benchlib/contract.py: the driver keeps the last 8 000 bytes of stdout)
+            from benchlib.contract import compact_line, stderr_table
+            side = os.environ.get("SVDF_BENCH_SIDE_FILE", os.path.join(ROOT, "bench_secondary.json"))
+            try:
+                with open(side, "w") as f:
+                    json.dump(out, f, indent=1)
+                out["details"] = os.path.basename(side)
+            except OSError as e:
+                out["details"] = "not written: %r" % (e,)
+            table = stderr_table(out)
+            if table:
+                print("[bench] secondaries (full objects: %s)\n%s" % (out["details"], table), file=sys.stderr, flush=True)
+            line, shed = compact_line(out)
+            if shed:
+                print("[bench] contract line: shed to fit: %s" % shed, file=sys.stderr, flush=True)
             sys.stdout.flush()
             C.CDLL(None).fflush(None)   # RCCL prints its version banner through C stdio: push it out BEFORE the JSON line, which stays the last line
-            print(json.dumps(out), flush=True)
+            print(line, flush=True)
 
     def finish_now(reason):
         """watchdog action of the secondaries: the contract line goes out with what is there, every rank leaves without another collective"""

@@ -75,9 +75,12 @@ def escalate(reason, rank, world, attempt, metric="training instances/sec (SGD u
         sys.stdout.flush(); sys.stderr.flush()
         os.execv(sys.executable, [sys.executable] + sys.argv)
     if rank == 0:
-        print(json.dumps({"metric": metric, "value": 0.0, "unit": "instances/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None,
-                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "FAILED: no exchange path worked on this node"}, "exchange": {"fallback": reasons}}), flush=True)
+        from benchlib.contract import compact_line
+        line, _ = compact_line({"metric": metric, "value": 0.0, "unit": "instances/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None,
+                                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                                "config": {"workload": "FAILED: no exchange path worked on this node"}, "roofline": None, "cpu_baseline": None,
+                                "parity": None, "exchange": {"fallback": reasons}})
+        print(line, flush=True)
     os._exit(3)
 
 

@@ -15,7 +15,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _bench(args, extra_env=None, timeout=1500):
-    env = dict(os.environ, SVDF_BENCH_SHARE_GPU="1")
+    """-> (the FULL object bench.py wrote to its side file, stderr); the stdout line itself is checked here: one line, <= 6 000 bytes, the
+    contract head present, value / ms_per_step equal to the full object's (benchlib/contract.py)"""
+    import tempfile
+    side = os.path.join(tempfile.mkdtemp(prefix="svdf_bench_side_"), "bench_secondary.json")
+    env = dict(os.environ, SVDF_BENCH_SHARE_GPU="1", SVDF_BENCH_SIDE_FILE=side)
     for k in ("SVDF_BENCH_ATTEMPT", "SVDF_BENCH_FALLBACK_LOG", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     env.update(extra_env or {})
@@ -24,7 +28,24 @@ def _bench(args, extra_env=None, timeout=1500):
     assert p.returncode == 0, p.stderr[-4000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, "exactly one JSON line expected:\n" + p.stdout[-2000:]
-    return json.loads(lines[0]), p.stderr
+    assert p.stdout.rstrip("\n").splitlines()[-1] == lines[0], "the contract line is the LAST line of stdout"
+    assert len(lines[0]) + 1 <= 6000, len(lines[0])
+    short = json.loads(p.stdout.encode()[-8000:].decode().strip().splitlines()[-1])    # the driver's view: the last 8 000 bytes
+    with open(side) as f:
+        full = json.load(f)
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+                "config", "roofline", "cpu_baseline", "parity"):
+        assert key in short, key
+    assert short["value"] == full["value"] and short["ms_per_step"] == full["ms_per_step"] and short["n_gpus"] == full["n_gpus"]
+    if "exchange" in full:
+        assert short["exchange"]["step"] == full["exchange"]["step"] and short["exchange"]["ladder_rung"] == full["exchange"]["ladder_rung"]
+        assert abs(short["rmse_minus_sequential"] - full["rmse_minus_sequential"]) < 1e-9
+    if isinstance(full.get("allreduce_step"), dict) and "value" in full["allreduce_step"]:
+        assert abs(short["allreduce_step"]["value"] / full["allreduce_step"]["value"] - 1) < 1e-5
+    for name, r in (full.get("secondary") or {}).items():
+        if isinstance(r, dict) and "value" in r:
+            assert abs(short["secondary"][name]["value"] / r["value"] - 1) < 1e-5, name
+    return full, p.stderr
 
 
 def test_two_ranks_one_command_yields_every_multi_gpu_number():
