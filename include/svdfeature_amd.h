@@ -332,8 +332,6 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  * "device_init_margin_log2" (values closer than 2^-this to a float rounding boundary are recomputed with the host libm; default 46),
  * "chain_width" (levels of at most this many instances are walked in runs inside ONE launch by one workgroup: k = 128 few-row data sets and, round 5,
  * the k = 64 contract kernel (at most 128 there); default 128, 0 = one launch per level; same bits),
- * "stream_exec" (1 = a resident basicMF k = 64 pass as ONE persistent launch over tiles with exact predecessor waits, svdf_k_stream.hip; same bits,
- * measured slower than the level loop: off), "stream_waves" / "stream_spin_limit" (its persistent waves / polls before a wait gives up),
  * "window_per_target_max" (the MOST updates any shared row may meet per window of the opt-in / N-rank step; default 128; changes that step's windows),
  * "ipc_spin_limit" (polls before a flag wait of the IPC exchange gives up),
  * "device_load" (0 = svdf_load_model through a host copy of the model instead of file -> pinned chunks -> HBM; same model),

@@ -90,6 +90,7 @@ svdf_dataset *svdf_dataset_from_csr(svdf_trainer *t, long num_row, const float *
                                     const unsigned *feat_index, const float *feat_value) {
     SVDF_GUARD(nullptr, {
         svdf::Dataset *d = t->e->dataset_from_csr(num_row, row_label, row_ptr, feat_index, feat_value);
+        t->e->note_dataset(d);
         svdf_dataset *h = new svdf_dataset();
         h->d = d;
         return h;
@@ -98,6 +99,7 @@ svdf_dataset *svdf_dataset_from_csr(svdf_trainer *t, long num_row, const float *
 svdf_dataset *svdf_dataset_from_triples(svdf_trainer *t, long n, const unsigned *user, const unsigned *item, const float *label) {
     SVDF_GUARD(nullptr, {
         svdf::Dataset *d = t->e->dataset_from_triples(n, user, item, label);
+        t->e->note_dataset(d);
         svdf_dataset *h = new svdf_dataset();
         h->d = d;
         return h;
@@ -196,6 +198,7 @@ int svdf_debug_sort_scores(long n, const float *score, int threads, int *paralle
 svdf_dataset *svdf_dataset_from_pairs(svdf_trainer *t, long n, const unsigned *user, const unsigned *pos_item, const unsigned *neg_item) {
     SVDF_GUARD(nullptr, {
         svdf::Dataset *d = t->e->dataset_from_pairs(n, user, pos_item, neg_item);
+        t->e->note_dataset(d);
         svdf_dataset *h = new svdf_dataset();
         h->d = d;
         return h;
@@ -208,6 +211,7 @@ svdf_dataset *svdf_dataset_from_blocks(svdf_trainer *t, long num_block, const in
     SVDF_GUARD(nullptr, {
         svdf::Dataset *d = t->e->dataset_from_blocks(num_block, extend_tag, fb_ptr, fb_index, fb_value, block_row_ptr, row_label, row_ptr,
                                                      feat_index, feat_value);
+        t->e->note_dataset(d);
         svdf_dataset *h = new svdf_dataset();
         h->d = d;
         return h;
@@ -216,6 +220,7 @@ svdf_dataset *svdf_dataset_from_blocks(svdf_trainer *t, long num_block, const in
 svdf_dataset *svdf_dataset_from_buffer_file(svdf_trainer *t, const char *path, int user_group_format) {
     SVDF_GUARD(nullptr, {
         svdf::Dataset *d = t->e->dataset_from_buffer_file(path, user_group_format);
+        t->e->note_dataset(d);
         svdf_dataset *h = new svdf_dataset();
         h->d = d;
         return h;
@@ -224,6 +229,7 @@ svdf_dataset *svdf_dataset_from_buffer_file(svdf_trainer *t, const char *path, i
 svdf_dataset *svdf_dataset_from_rank_buffer_file(svdf_trainer *t, const char *path) {
     SVDF_GUARD(nullptr, {
         svdf::Dataset *d = t->e->dataset_from_rank_buffer_file(path);
+        t->e->note_dataset(d);
         svdf_dataset *h = new svdf_dataset();
         h->d = d;
         return h;

@@ -190,7 +190,10 @@ int64_t Engine::counter(int what) const {
     case 22: return n_pivot_passes_;    // passes over data sets with hot rows walked as units (svdf_pivot.cpp)
     case 24: return unit_sched_us_;     // microseconds the last user-unit data set's schedule took (levels, order, fast-path flags)
     case 25: return unit_sched_on_device_ ? 1 : 0;   // ... built by svdf_k_sched.hip's device_schedule_units (1) or the host scan (0)
-    case 21: return n_stream_passes_;   // passes issued as ONE launch by the in-launch DAG executor (knob stream_exec)
+    case 26: return n_guard_warnings_;                            // data sets whose DEFAULT (exact) step was predicted > 10 x slower than the streaming model (note_dataset)
+    case 27: return (int64_t)(guard_last_.dag_ms * 1000.0);       // ... the last noted data set's dag bound / stream model, microseconds
+    case 28: return (int64_t)(guard_last_.stream_ms * 1000.0);
+    case 21: return 0;   // (was: passes of the in-launch DAG executor, removed in round 6 -- DESIGN_APPENDIX.md section K)
     default: return -1;
     }
 }
@@ -233,10 +236,6 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "pivot_run")) { check(value >= 1 && value <= 65536, "pivot_run must be in 1 .. 65536"); pivot_run_ = (int)value; return 0; }
     if (!strcmp(name, "pivot_run_long")) { check(value >= 1 && value <= 65536, "pivot_run_long must be in 1 .. 65536"); pivot_run_long_ = (int)value; return 0; }
     if (!strcmp(name, "pivot_min")) { check(value >= 2, "pivot_min must be at least 2"); pivot_min_ = (int)value; return 0; }
-    if (!strcmp(name, "stream_exec")) { check(value == 0 || value == 1, "stream_exec must be 0 or 1"); stream_exec_ = (int)value; return 0; }
-    if (!strcmp(name, "stream_debug_mode")) { stream_debug_mode_ = (int)value; return 0; }
-    if (!strcmp(name, "stream_waves")) { check(value >= 0 && value <= 65536, "stream_waves must be in 0 .. 65536"); stream_waves_ = (int)value; return 0; }
-    if (!strcmp(name, "stream_spin_limit")) { check(value >= 1 && value <= 0x7fffffffL, "stream_spin_limit must be positive"); stream_spin_limit_ = value; return 0; }
     if (!strcmp(name, "ipc_spin_limit")) { ipc_set_spin_limit(value); return 0; }
     if (!strcmp(name, "chain_width")) { check(value >= 0, "chain_width must not be negative"); chain_width_ = value; return 0; }
     if (!strcmp(name, "wseq_build_threads")) { check(value >= 1 && value <= 256, "wseq_build_threads must be in 1 .. 256"); wseq_build_threads_ = (int)value; return 0; }

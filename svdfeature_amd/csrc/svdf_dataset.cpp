@@ -614,6 +614,61 @@ Dataset *Engine::auto_step(Dataset *exact, bool window_ok, const std::function<D
     return out;
 }
 
+// The path a resident data set takes through the engine, in one place: the schedule form (from ds->kind) and the kernel family the
+// launchers will pick for it under the current configuration (the same predicates the launch sites consult).
+std::string Engine::path_for(const Dataset *ds) const {
+    const DevParams &P = const_cast<Engine *>(this)->params();
+    const long L = (long)ds->sched.num_levels();
+    char buf[512];
+    auto levels = [&](const char *what) { snprintf(buf, sizeof(buf), "exact, %ld conflict-free levels: %s", L, what); return std::string(buf); };
+    switch (ds->kind) {
+    case 0: return levels(chain_width_ > 0 ? "contract kernel k_basicmf / k_basicmf_slots, one (user, item) instance per lane group; narrow levels chained (k_basicmf_slots_chain)"
+                                           : "contract kernel k_basicmf / k_basicmf_slots, one (user, item) instance per lane group");
+    case 1: return levels("general sparse kernel k_general (any number of ids per row, side tables, lazy decay)");
+    case 2: {
+        const FusedSchedule S = ds->fused.view();
+        if (fewrow_gslots_ && fewrow_fast_ && fewrow_gslots_applies(P, S, ds->fused.max_nu, ds->fused.max_ni, ds->fused.dense_slots))
+            return levels("few-row kernel with global ids k_fewrow_gslots (neighbourhood shape)");
+        return levels(fewrow_fast_ && fewrow_fast_applies(P, S) ? "few-row kernel k_fewrow_slots (<= 2 user + 2 item rows per instance: rank pairs, side ids); narrow levels chained"
+                                                                 : "fused few-row kernel k_fused");
+    }
+    case 3: snprintf(buf, sizeof(buf), "exact, %ld conflict-free levels of user units: k_svdpp_wave (one wave per user, %ld of %ld units) + k_svdpp (general units)",
+                     L, ds->num_simple_units, ds->num_units); return buf;
+    case 4: return levels("multi-level implicit feedback units k_imfb");
+    case 5: return "window data set (one window of the window-minibatch step, user side exact): k_window_users / k_window_items";
+    case 6: return "amd:gpus handle: per-rank windows (svdf_multi.cpp)";
+    case 7: return "window data set of user units: k_wunit_* (svdf_k_wunit.hip)";
+    case 8: snprintf(buf, sizeof(buf), "window sequence (amd:step = minibatch / auto): %zu windows, each trained and applied in place; NOT the reference's sequential semantics (|dRMSE| <= 1e-4 contract)",
+                     ds->wchild.size()); return buf;
+    case 9: snprintf(buf, sizeof(buf), "exact, %ld levels: hot rows walked as units (k_svdpp_wave on %s parameters, %ld units) + cold ratings through the contract kernel",
+                     L, ds->pv_item_pivot ? "transposed" : "plain", ds->num_units); return buf;
+    case 10: snprintf(buf, sizeof(buf), "exact, %ld levels of runs: k_basicmf_runs_soa (up to %d consecutive ratings of one item per lane group, the item's row in registers)", L, ds->rn_len); return buf;
+    default: return "unknown";
+    }
+}
+void Engine::note_dataset(Dataset *ds) {
+    if (!ds || host_only_ || is_peer_) return;
+    const bool verbose = getenv("SVDF_VERBOSE") != nullptr, quiet = getenv("SVDF_QUIET") != nullptr;
+    if (verbose && !quiet) fprintf(stderr, "[svdfeature_amd] data set of %ld rows -> %s\n", (long)ds->num_row, path_for(ds).c_str());
+    // the guard of the DEFAULT step: only level-scheduled (exact) data sets of a one-GPU handle; `amd:step` set = the caller has chosen
+    if (step_auto_set_ || step_minibatch_set_ || multi_ || gpus_ != 1) return;
+    if (!(ds->kind == 0 || ds->kind == 1 || ds->kind == 2 || ds->kind == 3 || ds->kind == 4 || ds->kind == 9 || ds->kind == 10) || ds->num_row <= 0) return;
+    AutoDecision D;
+    double unit_us = 4.5;
+    auto_measures(ds, D.levels, unit_us, D.dag_ms, D.stream_ms, pivot_run_);
+    guard_last_ = D;
+    if (D.dag_ms <= 10.0 * D.stream_ms || D.dag_ms < 50.0) return;   // (passes below 50 ms are not worth a line)
+    n_guard_warnings_++;
+    if (quiet) return;
+    const bool window_ok = wunit_config_ok() && (ds->kind == 3 || ds->kind == 4 || basic_fast_path_allowed());
+    fprintf(stderr, "[svdfeature_amd] default (exact) step: %ld rows in %ld conflict-free levels -- the data's dependency depth binds: about %.0f ms per pass "
+                    "(%.2f M rows/s; levels x %.1f us) against %.1f ms if the rows streamed.  The exact pass keeps the reference's sequential result bit for bit; "
+                    "%s\n",
+            (long)ds->num_row, D.levels, D.dag_ms, (double)ds->num_row / D.dag_ms * 1e-3, unit_us, D.stream_ms,
+            window_ok ? "`amd:step = auto` would train this data set with the window step (user side exact, shared rows once per window; |dRMSE| <= 1e-4 contract) near the streaming rate"
+                      : "the window step of `amd:step = auto` does not cover this configuration");
+}
+
 Dataset::~Dataset() {
     for (auto &per_rank : mchild) for (Dataset *c : per_rank) delete c;
     for (Dataset *c : wchild) delete c;
@@ -646,7 +701,6 @@ void Engine::disown(Dataset *ds) {
 // into the wire buffer; after the all-reduce window_delta_apply adds the sum on every rank.  Replaces what one instance
 void Engine::predict_dataset(Dataset *ds, float *out) {
     check(ds && ds->owner == this, "predict_dataset: dataset belongs to another trainer");
-    check(ds->kind != 9, "predict_dataset: a data set with hot rows keeps no file order (its ratings are regrouped into units); score rows with svdf_predict_csr_batch");
     check(ds->kind != 7 && ds->kind != 8, "predict_dataset: window data sets are training sets (their rows are regrouped by user); score rows with svdf_predict_csr_batch / svdf_predict_block or a level-scheduled data set of the same rows");
     check(ds->kind != 5 && ds->kind != 6, "predict_dataset: window / multi-GPU data sets are training sets (their rows are regrouped: there is no file order to report predictions in); svdf_eval_dataset gives their squared error, svdf_predict_csr_batch scores rows (routed to the owner of each user)");
     check(ds->sched_signature == schedule_signature(),
@@ -672,8 +726,8 @@ void Engine::predict_dataset(Dataset *ds, float *out) {
         launch_predict_basic(P, S, n, w_out_.p, stream_);
         HIPCHECK(hipMemcpyAsync(out, w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
         HIPCHECK(hipStreamSynchronize(stream_));
-    } else if (ds->kind == 0 || ds->kind == 2) {
-        if (ds->kind == 0) {
+    } else if (ds->kind == 0 || ds->kind == 2 || ds->kind == 9) {   // (kind 9: cold ratings level-sorted, then the units' rows; order_dev = file positions, svdf_pivot.cpp)
+        if (ds->kind != 2) {
             BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
             launch_predict_basic(P, S, n, w_out_.p, stream_);
         } else {
@@ -681,7 +735,7 @@ void Engine::predict_dataset(Dataset *ds, float *out) {
         }
         // back into the caller's instance order on the device (a host scatter of 1e8 predictions costs more than the scoring),
         // then one copy out; a host-built schedule's order goes to HBM once
-        if (!ds->order_dev.p) ds->order_dev.upload(ds->sched.order.data(), (size_t)n, stream_);
+        if (!ds->order_dev.p) { check(ds->sched.order.size() == (size_t)n, "predict_dataset: the data set keeps no file order"); ds->order_dev.upload(ds->sched.order.data(), (size_t)n, stream_); }
         w_pred_.reserve((size_t)n);
         device_scatter_f32(w_out_.p, ds->order_dev.p, w_pred_.p, n, stream_);
         HIPCHECK(hipMemcpyAsync(out, w_pred_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));

@@ -129,7 +129,6 @@ Engine::~Engine() {
         }
         (void)hipStreamSynchronize(stream_);
         if (pred_pin_) (void)hipHostFree(pred_pin_);
-        if (stream_err_) (void)hipHostFree(stream_err_);
         save_pipe_free(save_pipe_);
         save_pipe_free(save_async_.pipe);
         if (save_async_.ready) (void)hipEventDestroy(save_async_.ready);
@@ -797,11 +796,8 @@ void Engine::train_dataset(Dataset *ds) {
         HIPCHECK(hipStreamSynchronize(stream_));
         ds->d_level_ptr_ok = true;
     }
-    const bool as_stream = stream_applies(ds);   // builds the tile plan on first use (outside any capture)
     auto issue = [&]() {
-        if (as_stream) {
-            stream_train(ds);
-        } else if (ds->kind == 0) {
+        if (ds->kind == 0) {
             BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
             // runs of NARROW levels (the tail of a pass over Zipf-popular items) through one launch per run, everything else level by level
             const size_t L = sc.num_levels();
@@ -912,6 +908,5 @@ void Engine::synchronize() {
     if (multi_) { multi_synchronize(); return; }
     HIPCHECK(hipStreamSynchronize(stream_));
     ipc_fail_if_dead("svdf_synchronize");
-    stream_fail_if_dead("svdf_synchronize");
 }
 }  // namespace svdf

@@ -246,12 +246,6 @@ struct Dataset {
     std::vector<long> pv_unit_ptr;
     bool pv_item_pivot = false;
     long pv_cold = 0, pv_hot_rows = 0;
-    // the tile plan of the in-launch DAG executor (svdf_stream.cpp), built on first use when the knob stream_exec is on
-    DevBuf<uint2> st_tile_hdr;
-    DevBuf<unsigned> st_pred[3], st_done;
-    unsigned st_ntiles = 0, st_pass = 0;
-    int st_nslots = 0;
-    bool st_built = false;
     int64_t chained_levels = 0;   // levels the current launch sequence of this data set walks inside chained launches
     long win_slots = 0;           // contribution slots of the window = item entries (kind 7: + feedback entries)
     // kind 7: window-minibatch data set of user units (svdf_k_wunit.hip): user-group blocks / rows with global features
@@ -398,6 +392,8 @@ class Engine {
     int64_t set_view(int which, const float *in, int64_t count);
     void view_shape(int which, int *rows, int *cols);
     hipStream_t stream() const { return stream_; }
+    std::string path_for(const Dataset *ds) const;   // the schedule form + kernel family a resident data set takes (svdf_dataset.cpp)
+    void note_dataset(Dataset *ds);                  // once per data set from the C entry points: the default-step guard (counters 26 .. 28)
     void synchronize();
     int64_t counter(int what) const;
     int set_knob(const char *name, long value);
@@ -643,19 +639,6 @@ class Engine {
     bool pivot_config_ok() const;
     Dataset *pivot_dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
     void pivot_train(Dataset *ds);
-    // the conflict DAG inside one launch per pass (svdf_stream.cpp / svdf_k_stream.hip)
-    int stream_exec_ = 0;                 // knob "stream_exec"
-    int stream_num_cu_ = 0;
-    int stream_debug_mode_ = 0;           // knob "stream_debug_mode" (experiments; non-zero = not coherent across XCDs)
-    int stream_waves_ = 0;                // knob "stream_waves": persistent waves of the launch (0 = 8 per CU)
-    long stream_spin_limit_ = 1 << 22;    // knob "stream_spin_limit": polls before a wait gives up
-    unsigned *stream_err_ = nullptr, *stream_err_dev_ = nullptr;
-    int64_t n_stream_passes_ = 0;
-    void stream_build(Dataset *ds, int TS, const unsigned *const *cols, int nslots, const int *space_of_slot);
-    StreamPlan stream_view(const Dataset *ds);
-    bool stream_applies(Dataset *ds);
-    void stream_train(Dataset *ds);
-    void stream_fail_if_dead(const char *where);
     // one GPU, `amd:step = auto` (opt-in): every resident data set is level-scheduled first (that is cheap on the device); when the
     // dependency depth of exact sequential semantics -- levels x the latency of one unit -- exceeds twice what the pass would take at the
     // streaming rate, the data set is rebuilt as a window sequence (the contract of `amd:step = minibatch`), else the exact levels stay.
@@ -668,6 +651,11 @@ class Engine {
     std::string auto_rank_path_;          // rank-pair input: the candidate file whose passes the decision below was taken for
     int auto_rank_decision_ = 0;
     bool auto_probe_deep(Dataset *probe, long n_full);
+    // ONE place that names the path a resident data set takes (kernel family, schedule form) and, in the DEFAULT (exact) step, runs the
+    // estimator of `amd:step = auto` on it: when the data's dependency depth is predicted to cost more than 10 x the streaming model, one
+    // stderr line says so and names `amd:step = auto` (svdf_dataset.cpp; counters 26 .. 28).  Called once per data set by the C entry points.
+    int64_t n_guard_warnings_ = 0;
+    AutoDecision guard_last_;
     long wseq_windows(long n, const std::vector<double> &updates_per_target) const;
     Dataset *wseq_from_csr(long n, const float *row_label, const int64_t *row_ptr, const unsigned *feat_index, const float *feat_value);
     Dataset *wseq_from_blocks(long num_block, const int *extend_tag, const int64_t *fb_ptr, const unsigned *fb_index, const float *fb_value,

@@ -92,6 +92,16 @@ void launch_runs_fill(const unsigned *user, const unsigned *item, const float *l
                       const unsigned char *idx, long nunit, unsigned *c_item, unsigned *c_user, float *c_label, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_runs_fill, dim3(runs_grid(n)), dim3(256), 0, st, user, item, label, n, unit_at, head_of, idx, nunit, c_item, c_user, c_label);
 }
+__global__ __launch_bounds__(256) void k_runs_iota(unsigned *v, long n) {
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += stride) v[j] = (unsigned)j;
+}
+void launch_runs_iota(unsigned *v, long n, hipStream_t st) {
+    if (n <= 0) return;
+    long grid = (n + 255) / 256;
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(k_runs_iota, dim3((int)grid), dim3(256), 0, st, v, n);
+}
 void launch_runs_fill_u32(unsigned *v, long n, unsigned x, hipStream_t st) {
     if (n > 0) hipLaunchKernelGGL(k_runs_fill_u32, dim3(runs_grid(n)), dim3(256), 0, st, v, n, x);
 }

@@ -116,17 +116,6 @@ long rank_select_cap();
 void launch_rank_select(long n, const unsigned *keys, const unsigned *vals, unsigned K1, unsigned *work, unsigned *ck, unsigned *cv, unsigned *out,
                         const unsigned *flag, hipStream_t st);
 // ascending radix sort of (key, value) pairs (svdf_k_sched.hip, rocPRIM); tmp is grown as needed
-// in-launch DAG executor (svdf_k_stream.hip)
-void launch_stream_tiles(const unsigned *tile_base, const unsigned *level_ptr, long nlevels, int TS, unsigned ntiles, uint2 *tile_hdr,
-                         unsigned *tile_of_pos, hipStream_t st);
-void launch_stream_iota(unsigned *v, long n, hipStream_t st);
-void launch_stream_interleave(const unsigned *const *cols, int members, long n, unsigned *keys, unsigned *entries, hipStream_t st);
-void launch_stream_preds(const unsigned *keys, const unsigned *entries, long m, unsigned absent, const unsigned *tile_of_pos, unsigned *pred, int members,
-                         int member, hipStream_t st);
-int stream_basic_tile_size(const DevParams &P);
-int stream_basic_max_waves(int num_cu);
-bool stream_basic_applies(const DevParams &P, const BasicSchedule &S);
-void launch_basicmf_stream(const DevParams &P, const BasicSchedule &S, const StreamPlan &T, unsigned pass, int waves, hipStream_t st);
 long device_exclusive_scan_u32(const unsigned *in, unsigned *out, long n, void **tmp, size_t *tmp_bytes, hipStream_t st);
 // runs of an item's consecutive ratings as schedule units (svdf_k_runs.hip)
 void launch_runs_check(const unsigned *user, const unsigned *item, long n, unsigned nu, unsigned ni, unsigned *flag, hipStream_t st);
@@ -135,6 +124,7 @@ void launch_runs_form(const unsigned *ikeys, const unsigned *ipos, long n, unsig
                       unsigned char *idx, hipStream_t st);
 void launch_runs_fill(const unsigned *user, const unsigned *item, const float *label, long n, const unsigned *unit_at, const unsigned *head_of,
                       const unsigned char *idx, long nunit, unsigned *c_item, unsigned *c_user, float *c_label, hipStream_t st);
+void launch_runs_iota(unsigned *v, long n, hipStream_t st);
 void launch_runs_fill_u32(unsigned *v, long n, unsigned x, hipStream_t st);
 bool basicmf_runs_soa_applies(const DevParams &P);
 void launch_basicmf_runs_soa(const DevParams &P, const RunSchedule &S, long begin, long end, int R, int G, int block_threads, hipStream_t st);

@@ -146,11 +146,12 @@ Dataset *Engine::pivot_dataset_from_triples(long n, const unsigned *user, const 
     // evaluator scores the data set like a plain one; the kernels of a pass read the front part and the units' own CSR)
     std::vector<unsigned> c_user((size_t)n), c_item((size_t)n);
     std::vector<float> c_label((size_t)n);
+    std::vector<int> c_pos((size_t)n);   // file position of every column slot: predict_dataset reports in file order (scatter, as kinds 0 / 2 do)
     {
         std::vector<long> cur(cptr.begin(), cptr.end());
         for (long t = 0; t < n; t++) if (unit_of[(size_t)t] < 0) {
             const long s = cur[(size_t)lvl[(size_t)t]]++;
-            c_user[(size_t)s] = user[t]; c_item[(size_t)s] = item[t]; c_label[(size_t)s] = label[t];
+            c_user[(size_t)s] = user[t]; c_item[(size_t)s] = item[t]; c_label[(size_t)s] = label[t]; c_pos[(size_t)s] = (int)t;
         }
     }
     std::vector<long> unit_pos((size_t)std::max<long>(nunit, 1));   // launch position of unit j
@@ -174,7 +175,7 @@ Dataset *Engine::pivot_dataset_from_triples(long n, const unsigned *user, const 
             const long s = unit_pos[(size_t)j];
             const long r = row_begin[(size_t)s] + fill[(size_t)j]++;
             h_label[(size_t)r] = label[t];
-            c_user[(size_t)(ncold + r)] = user[t]; c_item[(size_t)(ncold + r)] = item[t]; c_label[(size_t)(ncold + r)] = label[t];
+            c_user[(size_t)(ncold + r)] = user[t]; c_item[(size_t)(ncold + r)] = item[t]; c_label[(size_t)(ncold + r)] = label[t]; c_pos[(size_t)(ncold + r)] = (int)t;
             h_index[(size_t)2 * r] = pcol[t];       // the walker's "user" entry: the pivot row
             h_index[(size_t)2 * r + 1] = qcol[t];   // its "item" entry: the partner row
             xu[(size_t)s].user = pcol[t];
@@ -193,6 +194,7 @@ Dataset *Engine::pivot_dataset_from_triples(long n, const unsigned *user, const 
     ds->user.upload(c_user.data(), c_user.size(), stream_);
     ds->item.upload(c_item.data(), c_item.size(), stream_);
     ds->label.upload(c_label.data(), c_label.size(), stream_);
+    ds->order_dev.upload(c_pos.data(), c_pos.size(), stream_);
     ds->unit_values = true;
     UnitDev &d = ds->unitdev;
     d.label.upload(h_label.data(), h_label.size(), stream_);

@@ -50,12 +50,12 @@ Dataset *Engine::runs_dataset_from_triples(long n, const unsigned *user, const u
     struct FreeTmp { void *&p; ~FreeTmp() { if (p) (void)hipFree(p); } } free_tmp{tmp};
     // 1. the previous rating of every rating's user
     HIPCHECK(hipMemcpyAsync(ka.p, ds->user.p, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, stream_));
-    launch_stream_iota(va.p, n, stream_);
+    launch_runs_iota(va.p, n, stream_);
     device_sort_pairs_u32(ka.p, kb.p, va.p, vb.p, n, &tmp, &tmp_bytes, stream_);
     launch_runs_prev(kb.p, vb.p, n, prev.p, stream_);
     // 2. the item-major list, 3. runs
     HIPCHECK(hipMemcpyAsync(ka.p, ds->item.p, (size_t)n * sizeof(unsigned), hipMemcpyDeviceToDevice, stream_));
-    launch_stream_iota(va.p, n, stream_);
+    launch_runs_iota(va.p, n, stream_);
     device_sort_pairs_u32(ka.p, kb.p, va.p, vb.p, n, &tmp, &tmp_bytes, stream_);
     launch_runs_form(kb.p, vb.p, n, NI, prev.p, RF, head.p, head_of.p, idx.p, stream_);
     // 4. runs numbered by the file position of their head

@@ -122,18 +122,6 @@ struct RunSchedule {
     const float *label[8];
 };
 
-// The tile plan of the in-launch DAG executor (svdf_k_stream.hip): tile t = tile_hdr[t].y consecutive positions of the level-sorted arrays
-// starting at tile_hdr[t].x (never across a level boundary); pred[s][position] = the tile that holds the previous toucher of the row in
-// slot s of that instance (0xFFFFFFFF: none in this pass); done[t] = stamp of the pass that finished tile t.
-struct StreamPlan {
-    const uint2 *tile_hdr;   // {first position, number of instances}
-    const unsigned *pred[3];
-    unsigned *done;
-    unsigned *err;        // host-mapped: raised by a wait that hit its spin limit
-    unsigned ntiles, spin_limit, w_bytes;
-    int debug_mode;       // experiments only (knob stream_debug_mode): plain instead of write-through accesses
-};
-
 // One conflict-free batch of "few-row" instances for the fused kernel: at most 2 user ids and 2 item ids
 // per instance (slot value 0xFFFFFFFF = absent), any number of global features (CSR over the batch order),
 // no id repeated inside an instance.  Covers pairwise-rank pairs (nu=1, ni=2), neighbourhood rows

@@ -255,3 +255,31 @@ def test_user_group_passes_beyond_the_probe_size_are_judged_on_a_prefix_of_whole
     m.train_dataset(dm)
     for name in ("W_user", "W_item", "W_ufeedback"):
         assert np.array_equal(t.view(name).view(np.uint32), m.view(name).view(np.uint32)), name
+
+
+def test_the_default_step_warns_when_the_dependency_depth_binds(capfd):
+    """the DEFAULT step stays exact whatever the data order, but it no longer does so silently -- on the reference's own
+    pair order (user-grouped pairs: one dependency chain) the engine runs the `amd:step = auto` estimator on the schedule it has built anyway and says
+    on stderr what the pass will cost and which key trades bit parity for the streaming rate.  Wide data sets get no line."""
+    nu, ni = 400, 2000
+    cols = _grouped_pairs(nu, ni, 400, 9)                      # 160 K pairs, ~99 % of them one chain
+    conf = cases.conf_with(cases.PAIR_CONF, num_user=nu, num_item=ni, num_factor=128)
+    t = _trainer(conf, active=3)
+    capfd.readouterr()
+    ds = t.dataset_from_pairs(*cols)
+    err = capfd.readouterr().err
+    assert ds.kind == 2 and t.counter(16) == 0                  # exact levels, no auto decision taken
+    assert t.counter(26) == 1 and t.counter(27) > 10 * t.counter(28)
+    assert "default (exact) step" in err and "amd:step = auto" in err and "conflict-free levels" in err
+    # the same stream under amd:step = auto: no guard line (the caller has chosen), the decision line instead
+    t2 = _trainer(conf, active=3, extra=[("amd:step", "auto")])
+    capfd.readouterr()
+    ds2 = t2.dataset_from_pairs(*cols)
+    err2 = capfd.readouterr().err
+    assert ds2.kind == 8 and t2.counter(26) == 0 and "default (exact) step" not in err2 and "amd:step = auto" in err2
+    # wide levels: silent
+    u, i, r = cases.planted_triples(3000000, 200000, 40000, seed=3)
+    t3 = _trainer(cases.conf_with(cases.BASICMF_CONF, num_user=200000, num_item=40000, num_factor=64))
+    capfd.readouterr()
+    t3.dataset_from_triples(u, i, r)
+    assert t3.counter(26) == 0 and "default (exact) step" not in capfd.readouterr().err

@@ -75,3 +75,20 @@ def test_configurations_outside_the_symmetric_form_keep_plain_levels():
     u, i, r = cases.planted_triples(n, nu, 4000, seed=2)
     _, kind, _, _, _, _ = _run(u, i, r, nu, 4000, 1, passes=1)
     assert kind == 0
+
+
+def test_predict_dataset_of_a_hot_row_data_set_reports_in_file_order():
+    """dataset_from_triples may pick the unit form by itself (pivot_exec defaults to 1); the documented inference call
+    `predict_dataset` (out[num_row], file order) must work on it and equal the plain data set's predictions bit for bit"""
+    nu, ni, n = 20000, 300, 200000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=11, zipf=True)
+    a, kind_a, _, _, ta, dsa = _run(u, i, r, nu, ni, 0)
+    b, kind_b, _, _, tb, dsb = _run(u, i, r, nu, ni, 1)
+    assert kind_a == 0 and kind_b == 9
+    pa, pb = ta.predict_dataset(dsa), tb.predict_dataset(dsb)
+    assert pa.shape == pb.shape == (n,)
+    assert np.array_equal(pa.view(np.uint32), pb.view(np.uint32))
+    # and against the per-row scorer on a sample of file positions
+    sel = np.arange(0, n, 997)
+    ref = tb.predict_batch(sa.CSRData.from_triples(u[sel], i[sel], r[sel]))
+    assert np.array_equal(np.asarray(ref, np.float32).view(np.uint32), pb[sel].view(np.uint32))

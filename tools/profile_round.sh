@@ -24,15 +24,3 @@ for W in svdpp neighbourhood; do
   done
   echo "== window step, $W"; cat $OUT/pmc_wstep_$W.txt
 done
-# the in-launch DAG executor (knob stream_exec): traffic and instruction counters of its one kernel against the level loop's
-: > $OUT/pmc_stream_exec.txt
-for K in "stream_exec=1" "stream_exec=0"; do
-  for c in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAIT_INST_ANY"; do
-    n=$(echo $c | tr " " "_")
-    rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/pmc_se_$n -o p -- python bench.py --no-cpu-baseline --pmc off --secondary '' --steps 1 --warmup 0 --knob runs_exec=0 --knob $K > /dev/null 2> $OUT/pmc_se.stderr.log
-    echo "== $K, $c" >> $OUT/pmc_stream_exec.txt
-    python tools/pmc_summary.py $OUT/pmc_se_$n | grep -E "k_basicmf|counter_collection" >> $OUT/pmc_stream_exec.txt
-    rm -rf $OUT/pmc_se_$n
-  done
-done
-cat $OUT/pmc_stream_exec.txt
