@@ -85,6 +85,11 @@ def _tuple(r):
     for k in ("rmse_minus_sequential", "rmse_test_after_run", "pair_accuracy_test_after_run"):
         if r.get(k) is not None:
             t[k] = _num(r[k])
+    db = r.get("dag_bound")
+    if isinstance(db, dict):
+        ob = db.get("measured_over_chain_bound", db.get("measured_over_bound"))
+        if ob is not None:
+            t["over_dag_bound"] = _num(ob, 3)
     cd = r.get("contract_delta_vs_exact")
     if isinstance(cd, dict):
         t["delta_vs_exact"] = _slim(cd)
@@ -194,7 +199,7 @@ def compact_line(full, limit=LIMIT):
     if size() > limit and sec:
         for t in sec.values():
             if isinstance(t, dict):
-                for k in ("delta_vs_exact", "traffic_ratio", "ms_per_step", "rmse_test_after_run", "pair_accuracy_test_after_run", "unit"):
+                for k in ("delta_vs_exact", "over_dag_bound", "traffic_ratio", "ms_per_step", "rmse_test_after_run", "pair_accuracy_test_after_run", "unit"):
                     t.pop(k, None)
         dropped.append("secondary:optional-members")
     # 3: whole secondaries, largest first

@@ -153,6 +153,16 @@ def run_case(ctx, sa, name, a, device, cols, test, passes=2, window_extra=()):
                     "dag_bound": {"levels_per_pass": ds.num_batches, "unit_latency_us": lat, "bound_ms_per_pass": ds.num_batches * lat * 1e-3,
                                   "measured_over_bound": wall * 1e3 / max(ds.num_batches * lat * 1e-3, 1e-9)},
                     "quality_after_%d_passes" % passes: q_exact}
+    if ds.kind == 9 and not pairs:
+        # hot rows walked as units (svdf_pivot.cpp): a level lasts as long as its longest unit, so "levels x one instance's latency" is not the bound of this
+        # schedule.  What bounds ANY exact pass over this stream is the hottest row's own chain: its ratings are strictly sequential (each reads the row
+        # the previous one wrote), ~0.3 us per in-register step of the walker (tools/dag_probe: 0.43 us per step with random partner rows)
+        hot = int(max(np.bincount(cols[0][:m_exact]).max(), np.bincount(cols[1][:m_exact]).max()))
+        out["exact"]["dag_bound"].update({
+            "hottest_row_ratings": hot, "walker_step_us": 0.3, "chain_bound_ms_per_pass": hot * 0.3e-3,
+            "measured_over_chain_bound": wall * 1e3 / max(hot * 0.3e-3, 1e-9),
+            "what": "kind 9 (hot rows walked as units): the pass cannot be shorter than the hottest row's sequential chain = its ratings x the walker's "
+                    "per-rating step; measured_over_bound (levels x one instance's latency) does not apply to unit levels"})
     ctx.log("orders %s exact: %d rows %.1f ms per pass = %.1f M %s (%.2f%% of peak), %d levels" % (
         name, m_exact, wall * 1e3, m_exact / wall / 1e6, unit, 100 * out["exact"]["roofline"]["frac"], ds.num_batches))
     ds.close()

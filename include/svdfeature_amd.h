@@ -306,38 +306,40 @@ int svdf_synchronize(svdf_trainer *t);
  * device: values the host libm decided (next to a float rounding boundary) / rand() draws consumed (0 = the host loop ran), 15 conflict-free
  * levels executed inside chained launches, 16 .. 20 the decision of `amd:step = auto` for the data set built last (16: 0 none, 1 exact levels
  * kept, 2 window step chosen, 3 exact kept because the window step does not cover the configuration / the rows; 17 conflict-free levels;
- * 18 / 19 dag bound and stream model in microseconds; 20 windows), 21 passes issued as one launch by the in-launch DAG executor,
- * 22 / 23 passes over hot-row units / runs, 24 microseconds the schedule of the last user-unit data set took, 25 whether the device built it */
+ * 18 / 19 dag bound and stream model in microseconds; 20 windows), 21 unused,
+ * 22 / 23 passes over hot-row units / runs, 24 microseconds the schedule of the last user-unit data set took, 25 whether the device built it,
+ * 26 data sets whose DEFAULT (exact) step drew the depth warning (a stderr line naming `amd:step = auto`: the level schedule predicts the pass
+ * more than 10 x slower than the streaming model), 27 / 28 the last noted data set's dag bound / stream model in microseconds */
 int64_t svdf_counter(svdf_trainer *t, int what);
-/* tuning knobs (not part of the reference surface; none changes a result bit): "stage_window" (instances staged
- * before an automatic flush), "async_flush" (background scheduling of full windows), "groups_per_wave",
- * "block_threads" (0 = tuned per factor width), "sort_batches" (0 file order, 1 by item, 2 by user inside a
- * conflict-free batch), "xcd_remap", "store_mode" (0 plain, 1 nontemporal, 2 write-through row stores), "use_fused"
- * (0 routes few-row instances through the general kernel), "use_simple_units" (0 routes user units through the
- * lane-group kernel), "rows_without_feedback" (0 keeps whole users as sequential units even when no block of a block
- * dataset carries a feedback id; default 1 schedules such rows one by one), "use_graph" / "graph_min_levels" (hipGraph replay of a resident dataset's pass), "hot_reduce"
- * (relaxed mode: workgroup pre-reduction of a shared user row), "device_schedule" (0 = build the conflict-free levels on the host
- * instead of the GPU; same schedule -- rating / pair columns, runs, and since round 5 the user units of resident SVD++ data sets),
- * "device_schedule_min" (staged windows / user-group data sets with fewer instances stay on the host scheduler),
- * "device_rank" (0 = draw rank pairs with the host sampler; same pairs), "load_mode" (row gathers: 0 plain, 1 nontemporal hint,
- * 2 = by row size), "basic_i8" / "fewrow_i16" (0 = the lane-group layout instead of several chunks per lane in the specialised
- * basicMF / few-row kernels), "svdpp_helpers" (waves per user in the SVD++ kernel: 1, 4, 8, 16), "svdpp_xunits" (0 = no launch
- * records), "small_blocks" (0 = 256-thread workgroups also for small levels), "fewrow_gslots" (0 = the general few-row kernel for rows with
- * inline global slots); the window-minibatch step for user units: "wunit_fast" (0 = lane groups for every shape, 1 = + the slot kernel,
- * 2 = + one wave per user unit: default), "wunit_inplace" (one-GPU window sequences: 0 = every contribution through a slot, default 1 = a
- * row's only contribution of a window applied in place; same bits), "wunit_defer_fb" (default 1 = a feedback row's contributions are formed by the sum
- * kernel from the segments' deltas; 0 = written as contribution rows by the walk; same bits), "window_per_target" / "window_per_target_fb" (updates a shared row
- * meets per window when `amd:window` is not set: these two DO change the opt-in step's windows, hence its result); the one-off builders:
- * "device_init" (0 = SVDModel::rand_init as the reference's host loop instead of svdf_k_init.hip; same model, same rand() position),
- * "device_init_margin_log2" (values closer than 2^-this to a float rounding boundary are recomputed with the host libm; default 46),
- * "chain_width" (levels of at most this many instances are walked in runs inside ONE launch by one workgroup: k = 128 few-row data sets and, round 5,
- * the k = 64 contract kernel (at most 128 there); default 128, 0 = one launch per level; same bits),
- * "window_per_target_max" (the MOST updates any shared row may meet per window of the opt-in / N-rank step; default 128; changes that step's windows),
- * "ipc_spin_limit" (polls before a flag wait of the IPC exchange gives up),
- * "device_load" (0 = svdf_load_model through a host copy of the model instead of file -> pinned chunks -> HBM; same model),
- * "device_window" (0 = window data sets of ratings / pairs regrouped on the host; same arrays), "wseq_build_threads" (host threads building the
- * user-unit windows of a one-GPU window sequence; default 32, capped by a quarter of the host's hardware threads).  Returns 0 if the knob exists.
- * The relaxed mode itself is switched by CONFIG keys through svdf_set_param ("amd:relax_global",
+/* Tuning knobs (not part of the reference surface).  None changes a result bit except the three marked (*), which move the windows of the
+ * OPT-IN window step only.  Every knob, its default, what other values select (round 6: knobs no test or tool sets were deleted).
+ *   staging / launches
+ *     stage_window        2^21   instances staged by svdf_update_* before an automatic flush (also set by the config key amd:window)
+ *     async_flush         1      full staged windows are scheduled on a background thread
+ *     use_graph           0      1 = a resident data set's pass is replayed as a captured hipGraph
+ *     groups_per_wave     0      lane-group sets per wave of the contract / few-row kernels (0 = tuned per width; 1..6, 8)
+ *     block_threads       0      workgroup size (0 = tuned per width; 64, 128, 256)
+ *     xcd_remap           1      blockIdx -> tile mapping that keeps neighbouring tiles on one XCD's L2 (0 = plain)
+ *     load_mode           2      row gathers: 0 plain, 1 nontemporal, 2 = by row size
+ *     store_mode          0      row stores: 0 plain, 1 nontemporal, 2 write-through
+ *     sort_batches        1      order inside a conflict-free level: 0 file order, 1 by item, 2 by user
+ *     chain_width         128    levels of at most this many instances are walked inside ONE launch by one workgroup (0 = a launch per level)
+ *   kernel routing (0 = the more general kernel; same bits)
+ *     use_fused 1, fewrow_i16 1, fewrow_gslots 1, basic_i8 1, use_simple_units 1, svdpp_helpers 8 (waves per SVD++ user: 1, 4, 8, 16),
+ *     rows_without_feedback 1 (0 = whole users stay sequential units even when no block carries a feedback id)
+ *   schedule forms of plain ratings
+ *     runs_exec           1      runs of an item's consecutive ratings as units (svdf_k_runs.hip); runs_len 4 (2..7), runs_sets 1, runs_block 64,
+ *                                runs_min_rows 2^20 (smaller data sets keep one instance per lane group)
+ *     pivot_exec          1      hot rows walked as units (svdf_pivot.cpp); pivot_min 2048 (ratings that make a row hot), pivot_run 256 (per unit)
+ *   one-off builders on the device (0 = the host builder; same arrays / model)
+ *     device_schedule 1 (device_schedule_min 2^16: smaller staged windows stay on the host), device_rank 1, device_init 1
+ *     (device_init_margin_log2 46), device_window 1, device_load 1
+ *   the opt-in window step (amd:step = minibatch / auto; N-rank handles)
+ *     wunit_fast 2, wunit_inplace 1, wunit_defer_fb 1, window_slots 1, window_groups 0      kernel forms, same bits
+ *     window_per_target (*) 24, window_per_target_fb (*) 16     updates a shared row / feedback row meets per window on average
+ *     window_per_target_max (*) 128                             ... and at most
+ *     ipc_spin_limit             polls before a flag wait of the IPC exchange gives up
+ * Returns 0 if the knob exists, -1 otherwise.  The relaxed mode is switched by CONFIG keys through svdf_set_param ("amd:relax_global",
  * "amd:relax_user_from", "amd:relax_item_from", "amd:relax_feedback"), not by knobs: it changes results. */
 int svdf_set_knob(svdf_trainer *t, const char *name, long value);
 

@@ -302,6 +302,11 @@ class Trainer:
 
     def close(self):
         if getattr(self, "h", None):
+            if getattr(self, "_async_fo", None) is not None:   # an asynchronous save still open: join the writer and close its file (buffered bytes!)
+                try:
+                    self.save_model_end()
+                except Exception:
+                    pass
             self.lib.svdf_destroy(self.h)
             self.h = None
 

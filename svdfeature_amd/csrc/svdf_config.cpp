@@ -109,6 +109,7 @@ void config_set_train_param(TrainParam &p, const char *name, const char *val) { 
 void config_set_model_param(ModelParam &p, const char *name, const char *val) { apply_key(kModelKeys, sizeof(kModelKeys) / sizeof(kModelKeys[0]), p, name, val); }
 
 void Engine::set_param(const char *name, const char *val) {  // apex_svd_base.h:126-136
+    if (save_async_.active) save_model_end();   // (the asynchronous writer reads mp_ live)
     if (trainer_ready_ && !host_only_) flush();   // staged instances were issued under the old parameters
     // N GPUs behind one handle (svdf_multi.cpp): extension keys, ignored by the reference like any unknown key
     if (!strcmp(name, "amd:gpus")) { check(!multi_ && !space_allocated_, "amd:gpus must be set before the model is created"); gpus_ = std::max(1, atoi(val)); }
@@ -203,7 +204,6 @@ int Engine::set_knob(const char *name, long value) {
     if (multi_ && !is_peer_ && strcmp(name, "stage_window") != 0 && strcmp(name, "async_flush") != 0)
         for (int d = 1; d < gpus_; d++) (void)rank_engine(d)->set_knob(name, value);
     if (!strcmp(name, "use_graph")) { use_graph_ = value != 0; return 0; }
-    if (!strcmp(name, "graph_min_levels")) { check(value >= 1, "graph_min_levels must be >= 1"); graph_min_levels_ = (int)value; return 0; }
     if (!strcmp(name, "stage_window")) { check(value >= 1, "stage_window must be >= 1"); stage_window_ = value; window_set_ = true; return 0; }
     if (!strcmp(name, "groups_per_wave")) {
         check(value >= 0 && value <= 8 && value != 7, "groups_per_wave must be 0 (auto), 1 ... 6 or 8");
@@ -211,10 +211,7 @@ int Engine::set_knob(const char *name, long value) {
         return 0;
     }
     if (!strcmp(name, "xcd_remap")) { xcd_remap_ = value != 0; params_dirty_ = true; return 0; }
-    if (!strcmp(name, "hot_reduce")) { hot_reduce_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "fewrow_i16")) { check(value >= 0 && value <= 1, "fewrow_i16 must be 0 or 1"); fewrow_i16_ = (int)value; params_dirty_ = true; return 0; }
-    if (!strcmp(name, "small_blocks")) { check(value == 0 || value == 1, "small_blocks must be 0 or 1"); small_blocks_ = (int)value; params_dirty_ = true; return 0; }
-    if (!strcmp(name, "svdpp_xunits")) { check(value == 0 || value == 1, "svdpp_xunits must be 0 or 1"); svdpp_xunits_ = (int)value; return 0; }
     if (!strcmp(name, "svdpp_helpers")) { check(value == 1 || value == 4 || value == 8 || value == 16, "svdpp_helpers must be 1, 4, 8 or 16"); svdpp_helpers_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "basic_i8")) { check(value >= 0 && value <= 1, "basic_i8 must be 0 or 1"); basic_i8_ = (int)value; params_dirty_ = true; return 0; }
     if (!strcmp(name, "load_mode")) { check(value >= 0 && value <= 2, "load_mode must be 0, 1 or 2 (auto)"); load_mode_ = (int)value; params_dirty_ = true; return 0; }
@@ -234,13 +231,10 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "runs_min_rows")) { check(value >= 0, "runs_min_rows must not be negative"); runs_min_rows_ = value; return 0; }
     if (!strcmp(name, "pivot_exec")) { check(value == 0 || value == 1, "pivot_exec must be 0 or 1"); pivot_exec_ = (int)value; return 0; }
     if (!strcmp(name, "pivot_run")) { check(value >= 1 && value <= 65536, "pivot_run must be in 1 .. 65536"); pivot_run_ = (int)value; return 0; }
-    if (!strcmp(name, "pivot_run_long")) { check(value >= 1 && value <= 65536, "pivot_run_long must be in 1 .. 65536"); pivot_run_long_ = (int)value; return 0; }
     if (!strcmp(name, "pivot_min")) { check(value >= 2, "pivot_min must be at least 2"); pivot_min_ = (int)value; return 0; }
     if (!strcmp(name, "ipc_spin_limit")) { ipc_set_spin_limit(value); return 0; }
     if (!strcmp(name, "chain_width")) { check(value >= 0, "chain_width must not be negative"); chain_width_ = value; return 0; }
-    if (!strcmp(name, "wseq_build_threads")) { check(value >= 1 && value <= 256, "wseq_build_threads must be in 1 .. 256"); wseq_build_threads_ = (int)value; return 0; }
     if (!strcmp(name, "device_init_margin_log2")) { check(value >= 8 && value <= 52, "device_init_margin_log2 must be in 8 .. 52"); device_init_margin_log2_ = (int)value; return 0; }
-    if (!strcmp(name, "fewrow_fast")) { fewrow_fast_ = value != 0; params_dirty_ = true; return 0; }
     if (!strcmp(name, "device_schedule_min")) { check(value >= 1, "device_schedule_min must be >= 1"); device_sched_min_ = value; return 0; }
     if (!strcmp(name, "use_simple_units")) { use_simple_units_ = value != 0; return 0; }
     if (!strcmp(name, "rows_without_feedback")) { rows_without_feedback_ = value != 0; return 0; }

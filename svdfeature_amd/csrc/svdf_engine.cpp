@@ -53,16 +53,20 @@ MultiScope::~MultiScope() { tl_multi_depth--; }
 // 25 - 40 ms from one process to the next depending on where malloc had put the blocks (profiles/r05_ranker_malloc.txt; any of
 // MALLOC_MMAP_THRESHOLD_ / MALLOC_TRIM_THRESHOLD_ / MALLOC_TOP_PAD_ in the environment: always 5 ms).  Setting the threshold to the value it
 // already has switches the adjustment off and changes nothing else.  SVDF_KEEP_MALLOC_DYNAMIC=1 leaves malloc alone.
-static void pin_malloc_threshold() {
+// Applied by the RANKER only (the component it was measured on; svdf_ranker_create), never by a trainer handle, and not at all when the host
+// application has set any MALLOC_* tunable itself: a library does not override the allocator policy of the process it is loaded into.
+void pin_malloc_threshold() {
     static std::once_flag once;
     std::call_once(once, [] {
         const char *e = getenv("SVDF_KEEP_MALLOC_DYNAMIC");
-        if (!(e && atoi(e) != 0)) (void)mallopt(M_MMAP_THRESHOLD, 128 * 1024);
+        if (e && atoi(e) != 0) return;
+        for (const char *name : {"MALLOC_MMAP_THRESHOLD_", "MALLOC_TRIM_THRESHOLD_", "MALLOC_TOP_PAD_", "MALLOC_MMAP_MAX_", "MALLOC_ARENA_MAX", "GLIBC_TUNABLES"})
+            if (getenv(name)) return;
+        (void)mallopt(M_MMAP_THRESHOLD, 128 * 1024);
     });
 }
 
 Engine::Engine(TypeParam mtype, int device) : mtype_(mtype) {
-    pin_malloc_threshold();
     memset(&mp_, 0, sizeof(mp_));
     mp_.u_init_sigma = mp_.i_init_sigma = 0.01f;   // SVDModelParam() apex_svd_model.h:436-450
     mp_.base_score = 0.5f;

@@ -33,6 +33,7 @@ struct Error : std::runtime_error {
 [[noreturn]] void fail(const std::string &msg);
 // true while the calling thread runs the multi-GPU code of an amd:gpus handle (svdf_engine.cpp)
 bool in_multi_scope();
+void pin_malloc_threshold();   // svdf_engine.cpp: glibc's dynamic mmap threshold off, once per process, from the ranker only (see there)
 struct MultiScope { MultiScope(); ~MultiScope(); MultiScope(const MultiScope &) = delete; MultiScope &operator=(const MultiScope &) = delete; };
 
 // --------------------------------------------------------------------------- device memory

@@ -221,6 +221,7 @@ bool Engine::rand_init_device() {
 }
 
 void Engine::init_model() {  // apex_svd_base.h:146-149
+    save_model_end();   // a writer thread of svdf_save_model_begin reads the geometry (mp_, offsets) it is about to change: join it first
     if (rand_init_device()) {
         if (gpus_ > 1) download_model();   // the other ranks of an amd:gpus handle start from a host copy of rank 0's model
     } else {
@@ -386,6 +387,7 @@ void Engine::save_model_begin(FILE *fo) {
             HIPCHECK(hipEventSynchronize(B.ready));
             write_model_from_device(B.pipe, fo, B.W.p, B.bias.p, B.g.data());
             HIPCHECK(hipStreamSynchronize(B.st));
+            if (fflush(fo) != 0 || ferror(fo)) B.error = "the model file could not be written completely (disk full?): the file is truncated";
         } catch (const std::exception &e) {
             B.error = e.what();
         }
@@ -484,6 +486,7 @@ void Engine::read_model(FILE *fi) {
     }
 }
 void Engine::load_model(FILE *fi) {  // apex_svd_base.h:138-140
+    save_model_end();   // a writer thread of svdf_save_model_begin reads the geometry (mp_, offsets) it is about to change: join it first
     if (trainer_ready_ && !host_only_) flush();
     if (!host_only_ && gpus_ <= 1 && device_load_) {   // the matrices stream file -> pinned chunks -> HBM
         try { read_model_to_device(fi); }

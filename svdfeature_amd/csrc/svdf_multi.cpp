@@ -419,6 +419,32 @@ long Engine::multi_windows_for(long n, const std::vector<long> &item_count, bool
     return std::max<long>(W, (long)std::ceil(need));
 }
 
+// multi_windows_for bounds a row's updates per window on AVERAGE (mx / cap windows), but the windows are cut at equal row positions n w / W:
+// a hot item whose rows are clustered in the file (sorted or bursty input) would still meet far more than the cap inside one window -- the
+// condition under which stale sums diverge (the staged path's next_cut enforces the bound exactly).  Count per window after cutting and
+// take more windows until the bound holds.  cols: the item columns of the rows (one for ratings, two for rank pairs).
+static long multi_windows_capped(long W, long n, long num_item, long cap, bool fixed, std::initializer_list<const unsigned *> cols) {
+    if (fixed || n <= 0 || cap <= 0) return W;
+    std::vector<int> stamp((size_t)num_item), count((size_t)num_item);
+    for (int round = 0; round < 12; round++) {
+        std::fill(stamp.begin(), stamp.end(), -1);
+        long worst = 0;
+        for (long w = 0; w < W; w++) {
+            const long b0 = n * w / W, b1 = n * (w + 1) / W;
+            for (const unsigned *c : cols)
+                for (long r = b0; r < b1; r++) {
+                    const unsigned it = c[r];
+                    if (stamp[it] != (int)w) { stamp[it] = (int)w; count[it] = 0; }
+                    worst = std::max<long>(worst, ++count[it]);
+                }
+        }
+        if (worst <= cap) return W;
+        W = std::max<long>(W + 1, (long)std::ceil((double)W * (double)worst / (double)cap));
+        if (W >= n) return n;
+    }
+    return W;
+}
+
 // ---- resident data sets on the handle: sharded by user, cut into windows at global positions, one child per (rank, window)
 static long multi_num_windows(long n, long window) { return std::max<long>(1, (n + window - 1) / window); }
 
@@ -436,7 +462,7 @@ Dataset *Engine::multi_dataset_from_triples(long n, const unsigned *user, const 
     ds->m_minibatch = mbatch;
     std::vector<long> cnt((size_t)mp_.num_item, 0);
     for (long r = 0; r < n; r++) cnt[item[r]]++;
-    const long W = multi_windows_for(n, cnt, mbatch);
+    const long W = multi_windows_capped(multi_windows_for(n, cnt, mbatch), n, mp_.num_item, mbatch ? wseq_per_target_max_ : 0, window_set_, {item});
     ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
     for (long w = 0; w < W; w++) {
         const long b0 = n * w / W, b1 = n * (w + 1) / W;
@@ -479,7 +505,7 @@ Dataset *Engine::multi_dataset_from_pairs(long n, const unsigned *user, const un
     ds->m_minibatch = true;
     std::vector<long> cnt((size_t)mp_.num_item, 0);
     for (long r = 0; r < n; r++) { cnt[pos[r]]++; cnt[neg[r]]++; }
-    const long W = multi_windows_for(n, cnt, true);
+    const long W = multi_windows_capped(multi_windows_for(n, cnt, true), n, mp_.num_item, wseq_per_target_max_, window_set_, {pos, neg});
     ds->mchild.assign((size_t)N, std::vector<Dataset *>((size_t)W, nullptr));
     for (long w = 0; w < W; w++) {
         const long b0 = n * w / W, b1 = n * (w + 1) / W;

@@ -33,7 +33,7 @@ namespace svdf {
     } while (0)
 static inline void rcheck(bool ok, const char *msg) { if (!ok) fail(msg); }
 
-Ranker::Ranker(TypeParam mtype, int device) : eng_(new Engine(TypeParam{mtype.format_type, mtype.active_type, 0, 0}, device)) {}
+Ranker::Ranker(TypeParam mtype, int device) : eng_(new Engine(TypeParam{mtype.format_type, mtype.active_type, 0, 0}, device)) { pin_malloc_threshold(); }
 Ranker::~Ranker() {
     (void)hipStreamSynchronize(eng_->stream_);
     if (sort_tmp_) (void)hipFree(sort_tmp_);
