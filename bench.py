@@ -382,13 +382,15 @@ def run_workload(name, a, env, steps, warmup, main_line):
         shards = defer_tails(shards, a.users, a.items, a.defer_tails)
     bpr = 1
     if stratified:
-        from svdfeature_amd.multi_gpu import StratifiedTrainer, stratified_plan
+        from svdfeature_amd.multi_gpu import StratifiedTrainer, default_chunks, stratified_plan
         bpr = max(1, a.blocks_per_rank) if world > 1 else 1
         # accuracy defaults from the 3-seed contract at the full configs[2] size (profiles/r04_contract_seeds.txt): below 8 ranks a stratum holds
         # many updates per item and its order is far from the file's -- 8 chunks per pass and <= 16 updates per item per window keep every cell
         # <= 6.0e-5 (4 chunks / 32: up to 1.10e-4 at 2 and 4 ranks); at 8 ranks 4 chunks / 32 measure <= 6.3e-5 and the steps are already short
+        # skewed catalogues (hottest item >= 16 x a mean item): 12 chunks at every rank count (3 seeds of Zipf(0.7) at the configs[2] size on 8 ranks:
+        # 4 chunks 9.0e-5, 12 chunks 4.4e-5; profiles/r06_contract_zipf_c2.txt)
         if a.chunks <= 0:
-            a.chunks = 8 if world < 8 else 4
+            a.chunks = default_chunks(i, a.items, world)
         strat_per_item = a.stratified_per_item if a.stratified_per_item > 0 else (16.0 if world < 8 else 32.0)
         plan = [[adaptor.make_windows(sub) for sub in chunk] for chunk in stratified_plan(u, i, r, rank, world, a.chunks, a.items, strat_per_item, bpr)]
         wins = [w for chunk in plan for sub in chunk for w in sub]

@@ -66,6 +66,8 @@ def _load(kind):
     lib.svdo_predict_csr_batch.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p]
     lib.svdo_update_csr_batch_stale.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p, _f32p, _f32p]
     lib.svdo_update_csr_batch_stale.restype = C.c_int
+    lib.svdo_update_window_substeps.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, C.c_int]
+    lib.svdo_update_window_substeps.restype = C.c_int
     lib.svdo_update_block_stale.argtypes = [P, C.c_int, C.c_int, _u32p, _f32p, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
     lib.svdo_update_block_stale.restype = C.c_int
     lib.svdo_set_stale_rounding.argtypes = [P, C.c_int]
@@ -189,6 +191,13 @@ class OracleTrainer:
                                                   dg if dg.size else np.zeros(1, np.float32))
         assert rc == 0, "window-minibatch step: configuration not supported by this checker"
         return delta
+
+    def update_window_substeps(self, d, sub=128):
+        """One window of the one-GPU window step with ordered sub-steps on the item side (svdf_oracle.c: svdo_update_window_substeps): the model
+        moves in place -- users exactly, against the window-start item rows; every item in sub-steps of at most `sub` of its rows, in file order."""
+        rc = self.lib.svdo_update_window_substeps(self.h, d.num_row, _pad(d.row_label, np.float32), _pad(d.row_ptr, np.int32),
+                                                  _pad(d.feat_index, np.uint32), _pad(d.feat_value, np.float32), int(sub))
+        assert rc == 0, "window step with sub-steps: configuration / rows not supported by this checker"
 
     def set_stale_rounding(self, bf16):
         """checker steps: round row contributions to bfloat16 before summing (the HIP engine's amd:contrib = bf16)"""

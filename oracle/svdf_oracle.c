@@ -928,6 +928,82 @@ int svdo_update_csr_batch_stale(svdo_trainer *t, int num_row, const float *row_l
     free(sv.buf);
     return 0;
 }
+/* ---- one window of the one-GPU window step with ORDERED SUB-STEPS on the item side (HIP engine round 6: svdf_k_window.hip, k_window_hot;
+ * `amd:step = minibatch / auto` on one GPU).  Not the reference's semantics either -- the same checker role as svdo_update_csr_batch_stale:
+ *   * user side: exactly as the stale step -- every row is update_inner (apex_svd_base.h:456-462) on (the user's current row, the item row as
+ *     it was at the WINDOW START); the item row is put back after every row;
+ *   * item side: item i's rows of the window, in file order, are applied in sub-steps of at most `sub` rows.  Inside a sub-step every row's
+ *     item-side change is what update_inner gives on (the user's row and bias as they were just BEFORE that row's own update in the user
+ *     walk, the item's row as the PREVIOUS sub-step left it); the changes are added up in file order (acc = 0 + c_1 + c_2 ...) and the sum is
+ *     added to the item's row.  An item with at most `sub` rows in the window moves exactly as in svdo_update_csr_batch_stale followed by
+ *     `W_item += delta`; a hot item no longer collects thousands of changes computed against one stale value (which diverges), it takes
+ *     count / sub minibatch steps in order.
+ * Rows must be (no global entry, one user entry, one item entry).  Returns 0, -1 for unsupported configurations / rows. */
+int svdo_update_window_substeps(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
+                                const unsigned *feat_index, const float *feat_value, int sub) {
+    if (!stale_supported(t) || is_user_group(t) || sub < 1) return -1;
+    const int k = t->mp.num_factor;
+    for (int r = 0; r < num_row; r++) {
+        elem e = csr_row(r, row_label, row_ptr, feat_index, feat_value);
+        if (e.ng != 0 || e.nu != 1 || e.ni != 1) return -1;
+    }
+    float *pre = (float *)malloc(sizeof(float) * (size_t)(k + 1) * (size_t)(num_row > 0 ? num_row : 1));   /* the user's row + bias before row r's update */
+    float *save = (float *)malloc(sizeof(float) * (size_t)(k + 1) * 2);
+    /* user walks against the window-start item side */
+    for (int r = 0; r < num_row; r++) {
+        elem e = csr_row(r, row_label, row_ptr, feat_index, feat_value);
+        assert_true(e.ii[0] < (unsigned)t->mp.num_item, "item feature index exceed bound");
+        assert_true(e.iu[0] < (unsigned)t->mp.num_user, "user feature index exceed bound");
+        float *wi = t->W_item + (size_t)e.ii[0] * t->pitch, *wu = t->W_user + (size_t)e.iu[0] * t->pitch;
+        memcpy(pre + (size_t)r * (k + 1), wu, sizeof(float) * (size_t)k);
+        pre[(size_t)r * (k + 1) + k] = t->u_bias[e.iu[0]];
+        memcpy(save, wi, sizeof(float) * (size_t)k);
+        save[k] = t->i_bias[e.ii[0]];
+        update_inner(t, &e);
+        memcpy(wi, save, sizeof(float) * (size_t)k);
+        t->i_bias[e.ii[0]] = save[k];
+    }
+    /* rows grouped by item, file order inside an item (counting sort) */
+    int *iptr = (int *)calloc((size_t)t->mp.num_item + 1, sizeof(int));
+    int *rows = (int *)malloc(sizeof(int) * (size_t)(num_row > 0 ? num_row : 1));
+    for (int r = 0; r < num_row; r++) iptr[feat_index[row_ptr[3 * r + 2]] + 1]++;
+    for (int i = 0; i < t->mp.num_item; i++) iptr[i + 1] += iptr[i];
+    {
+        int *cur = (int *)malloc(sizeof(int) * (size_t)(t->mp.num_item + 1));
+        memcpy(cur, iptr, sizeof(int) * (size_t)(t->mp.num_item + 1));
+        for (int r = 0; r < num_row; r++) rows[cur[feat_index[row_ptr[3 * r + 2]]]++] = r;
+        free(cur);
+    }
+    float *acc = (float *)malloc(sizeof(float) * (size_t)(k + 1));
+    float *usave = save + (k + 1);
+    for (int i = 0; i < t->mp.num_item; i++) {
+        float *wi = t->W_item + (size_t)i * t->pitch;
+        for (int c0 = iptr[i]; c0 < iptr[i + 1]; c0 += sub) {
+            const int c1 = c0 + sub < iptr[i + 1] ? c0 + sub : iptr[i + 1];
+            for (int j = 0; j <= k; j++) acc[j] = 0.0f;
+            for (int s = c0; s < c1; s++) {
+                const int r = rows[s];
+                elem e = csr_row(r, row_label, row_ptr, feat_index, feat_value);
+                float *wu = t->W_user + (size_t)e.iu[0] * t->pitch;
+                memcpy(usave, wu, sizeof(float) * (size_t)k);                 /* the user's true row: put back below */
+                usave[k] = t->u_bias[e.iu[0]];
+                memcpy(wu, pre + (size_t)r * (k + 1), sizeof(float) * (size_t)k);
+                t->u_bias[e.iu[0]] = pre[(size_t)r * (k + 1) + k];
+                memcpy(save, wi, sizeof(float) * (size_t)k);
+                save[k] = t->i_bias[i];
+                update_inner(t, &e);
+                for (int j = 0; j < k; j++) { float c = wi[j] - save[j]; acc[j] = acc[j] + c; wi[j] = save[j]; }
+                { float cb = t->i_bias[i] - save[k]; acc[k] = acc[k] + cb; t->i_bias[i] = save[k]; }
+                memcpy(wu, usave, sizeof(float) * (size_t)k);
+                t->u_bias[e.iu[0]] = usave[k];
+            }
+            for (int j = 0; j < k; j++) wi[j] = wi[j] + acc[j];
+            t->i_bias[i] = t->i_bias[i] + acc[k];
+        }
+    }
+    free(acc); free(rows); free(iptr); free(save); free(pre);
+    return 0;
+}
 void svdo_predict_csr_batch(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
                             const unsigned *feat_index, const float *feat_value, float *out) {
     for (int r = 0; r < num_row; r++) {

@@ -326,6 +326,19 @@ class ShardedTrainer:
             mark("unpack")
 
 
+def default_chunks(item, num_item, world):
+    """File-order chunks per pass of the stratified schedule when the caller names none.  What the accuracy contract (|dRMSE| <= 1e-4 against the
+    sequential pass) is sensitive to is how far the training order strays from the file order, and skewed catalogues are more sensitive than uniform
+    ones: Zipf(0.7) items at the full configs[2] size on 8 ranks, 3 data seeds (profiles/r06_contract_zipf_c2.txt): 4 chunks max |d| 9.0e-5, 8: 7.0e-5,
+    12: 4.4e-5, 16: 4.3e-5.  Skewed = the hottest item holds >= 16 x the ratings of a mean touched item (the test svdf_pivot.cpp uses): 12 chunks at
+    every rank count; uniform streams keep 8 below 8 ranks and 4 from 8 ranks (profiles/r04_contract_seeds.txt: <= 6.3e-5).  Every rank computes
+    this from the same item column, so the ranks agree without a message."""
+    cnt = np.bincount(np.asarray(item), minlength=int(num_item))
+    touched = int((cnt > 0).sum())
+    skew = touched > 0 and float(cnt.max()) >= 16.0 * len(item) / touched
+    return 12 if skew else (8 if world < 8 else 4)
+
+
 def stratified_plan(user, item, label, rank, world, chunks, num_item, per_item=32.0, blocks_per_rank=1):
     """plan[c][t] = the windows (u, i, r) this rank trains in step t (0 .. world * P - 1) of file-order chunk c: the chunk's instances whose
     user is in user block `rank` and whose item is in item block (rank * P + t) % (world * P), file order, at most `per_item` updates per

@@ -393,3 +393,16 @@ def test_piecewise_exchange_keeps_the_rmse_contract():
     ref = cases.rmse(merged_predict(simulate(conf, u, i, r, 1, 1, 5), 1, tu, ti, tr), tr)
     got = cases.rmse(merged_predict(simulate_parts(conf, u, i, r, 8, 16, 5, 2, ni), 8, tu, ti, tr), tr)
     assert abs(got - ref) <= 1e-4
+
+
+def test_default_chunks_follow_the_skew_of_the_catalogue():
+    """multi_gpu.default_chunks (round 6; profiles/r06_contract_zipf_c2.txt): uniform items keep 8 / 4 chunks per pass, a skewed catalogue trains
+    with 12 at every rank count; the rule reads only the item column, so every rank computes the same number"""
+    from svdfeature_amd.multi_gpu import default_chunks
+    rng = np.random.default_rng(0)
+    uni = rng.integers(0, 5000, 400000).astype(np.uint32)
+    assert default_chunks(uni, 5000, 2) == 8 and default_chunks(uni, 5000, 8) == 4
+    w = 1.0 / np.arange(1, 5001) ** 0.7
+    zipf = rng.choice(5000, 400000, p=w / w.sum()).astype(np.uint32)
+    assert default_chunks(zipf, 5000, 2) == 12 and default_chunks(zipf, 5000, 8) == 12
+    assert default_chunks(np.zeros(0, np.uint32), 10, 8) == 4
