@@ -66,8 +66,9 @@ def _load(kind):
     lib.svdo_predict_csr_batch.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p]
     lib.svdo_update_csr_batch_stale.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p, _f32p, _f32p]
     lib.svdo_update_csr_batch_stale.restype = C.c_int
-    lib.svdo_update_window_substeps.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, C.c_int]
-    lib.svdo_update_window_substeps.restype = C.c_int
+    if hasattr(lib, "svdo_update_window_substeps"):   # (the port only: the compiled reference's shim has no window steps beyond the stale one)
+        lib.svdo_update_window_substeps.argtypes = [P, C.c_int, _f32p, _i32p, _u32p, _f32p, C.c_int]
+        lib.svdo_update_window_substeps.restype = C.c_int
     lib.svdo_update_block_stale.argtypes = [P, C.c_int, C.c_int, _u32p, _f32p, C.c_int, _f32p, _i32p, _u32p, _f32p, _f32p, _f32p, _f32p, _f32p, _f32p]
     lib.svdo_update_block_stale.restype = C.c_int
     lib.svdo_set_stale_rounding.argtypes = [P, C.c_int]

@@ -243,6 +243,8 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "wunit_defer_fb")) { wunit_defer_fb_ = value != 0; return 0; }
     if (!strcmp(name, "wunit_fast")) { check(value >= 0 && value <= 2, "wunit_fast must be 0, 1 or 2"); wunit_fast_ = (int)value; return 0; }
     if (!strcmp(name, "window_per_target_fb")) { check(value >= 1, "window_per_target_fb must be positive"); wseq_per_target_fb_ = (int)value; return 0; }
+    if (!strcmp(name, "window_hot_sub")) { check(value >= 0 && value <= 4096, "window_hot_sub must be in 0 .. 4096"); wseq_hot_sub_ = (int)value; return 0; }
+    if (!strcmp(name, "window_hot_max")) { check(value >= 1, "window_hot_max must be positive"); wseq_hot_max_ = (int)value; return 0; }
     if (!strcmp(name, "window_per_target_max")) { check(value >= 1, "window_per_target_max must be positive"); wseq_per_target_max_ = (int)value; return 0; }
     if (!strcmp(name, "window_per_target")) { check(value >= 1, "window_per_target must be positive"); wseq_per_target_ = (int)value; return 0; }
     if (!strcmp(name, "window_slots")) { window_slots_ = value != 0; return 0; }

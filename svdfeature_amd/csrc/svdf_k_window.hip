@@ -86,8 +86,14 @@ __global__ __launch_bounds__(256) void k_window_users(const DevParams P, const W
             if (act) {   // what the reference would have changed on the item side
                 sub4(wi, q[e]);
                 const long slot = e == 0 ? S.slot[s] : S.slot1[s];
-                store_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)slot, pitch, L, k, wi);
-                if (L == 0) S.cbias[slot] = nbi - bi[e];
+                if (NI == 1 && S.hot_sub > 0 && S.iptr[item[0] + 1] - S.iptr[item[0]] > S.hot_sub) {
+                    // a hot item of this window: what the change is computed FROM goes to the slot; k_window_hot forms it against the row of its sub-step
+                    store_contrib<LPI>(S.contrib, 0, (size_t)slot, pitch, L, k, tu);
+                    if (L == 0) { S.cbias[slot] = use_ubias ? bu : 0.0f; S.clabel[slot] = label; }
+                } else {
+                    store_contrib<LPI>(S.contrib, S.contrib_bf16, (size_t)slot, pitch, L, k, wi);
+                    if (L == 0) S.cbias[slot] = nbi - bi[e];
+                }
             }
         }
         if (act) {
@@ -146,7 +152,10 @@ __global__ __launch_bounds__(256) void k_window_users_slots(const DevParams P, c
     unsigned nir[G][NI];
     float nlabel[G], nbi_[G][NI], nia[G][NI];
     int nslot[G][NI];
+    bool nhot[G];
     float4 nq[G][NI][V];
+#pragma unroll
+    for (int g = 0; g < G; g++) nhot[g] = false;
     auto fetch = [&](int j) {
 #pragma unroll
         for (int g = 0; g < G; g++) {
@@ -156,6 +165,7 @@ __global__ __launch_bounds__(256) void k_window_users_slots(const DevParams P, c
             nia[g][0] = NI == 2 ? S.ival[s] : 1.0f;
             if (NI == 2) { nir[g][NI - 1] = P.item_off + S.item1[s]; nslot[g][NI - 1] = S.slot1[s]; nia[g][NI - 1] = S.ival1[s]; }
             nlabel[g] = NI == 2 ? 1.0f : S.label[s];
+            if (NI == 1) nhot[g] = S.hot_sub > 0 && S.iptr[S.item[s] + 1] - S.iptr[S.item[s]] > S.hot_sub;
         }
 #pragma unroll
         for (int g = 0; g < G; g++) {
@@ -171,10 +181,11 @@ __global__ __launch_bounds__(256) void k_window_users_slots(const DevParams P, c
     for (int j = 0; j < maxc; j++) {
         float label[G], bi[G][NI], ia[G][NI];
         int slot[G][NI];
+        bool hot[G];
         float4 q[G][NI][V];
 #pragma unroll
         for (int g = 0; g < G; g++) {
-            label[g] = nlabel[g];
+            label[g] = nlabel[g]; hot[g] = nhot[g];
 #pragma unroll
             for (int e = 0; e < NI; e++) {
                 bi[g][e] = nbi_[g][e]; slot[g][e] = nslot[g][e]; ia[g][e] = nia[g][e];
@@ -214,6 +225,7 @@ __global__ __launch_bounds__(256) void k_window_users_slots(const DevParams P, c
                 wu.x = wu.x * dec_u1; wu.y = wu.y * dec_u1; wu.z = wu.z * dec_u1; wu.w = wu.w * dec_u1;
                 if (act) p[g][v] = wu;
             }
+            const float bu_before = bu[g];   // (the hot-item slot below takes the bias the row's pred was formed with)
             if (act && UB) bu[g] = nbu;
 #pragma unroll
             for (int e = 0; e < NI; e++) {
@@ -229,7 +241,12 @@ __global__ __launch_bounds__(256) void k_window_users_slots(const DevParams P, c
                     sub4(wi, q[g][e][v]);
                     c[v] = wi;
                 }
-                if (act) {
+                if (act && NI == 1 && hot[g]) {   // a hot item of this window (WindowSchedule::hot_sub): the slot takes what the change is computed FROM
+#pragma unroll
+                    for (int v = 0; v < V; v++) store_contrib<K / 4>(S.contrib, 0, (size_t)slot[g][e], pitch, m + v * LANES, K, tu[v]);
+                    S.cbias[slot[g][e]] = UB ? bu_before : 0.0f;
+                    S.clabel[slot[g][e]] = label[g];
+                } else if (act) {
 #pragma unroll
                     for (int v = 0; v < V; v++) store_contrib<K / 4>(S.contrib, S.contrib_bf16, (size_t)slot[g][e], pitch, m + v * LANES, K, c[v]);
                     S.cbias[slot[g][e]] = nbi - bi[g][e];
@@ -363,6 +380,10 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
     for (long it = first; it < nitem; it += stride) {
         const long i = lo + it;
         const int b = S.iptr[i], e = S.iptr[i + 1];
+        if (LOCAL && S.hot_sub > 0 && e - b > S.hot_sub) {   // ordered sub-steps: k_window_hot takes the item (its slots hold vectors, not changes)
+            if (L == 0) { const int h = atomicAdd(S.hot_count, 1); S.hot_list[3 * h] = (int)i; S.hot_list[3 * h + 1] = b; S.hot_list[3 * h + 2] = e; }
+            continue;
+        }
         if (HOT && e - b > hot_min) {   // a long list: left to the whole workgroup (below) while the queue has room
             int pos = SVDF_WIN_HOT_QUEUE;
             if (L == 0) pos = atomicAdd(&hq_n, 1);
@@ -466,6 +487,10 @@ __global__ __launch_bounds__(256) void k_window_items_sparse(const WindowSchedul
         const int n = q_n;
         for (int idx = grp; idx < n; idx += G) {
             const int b = q_b[idx], e = q_e[idx];
+            if (S.hot_sub > 0 && e - b > S.hot_sub) {   // ordered sub-steps: left to k_window_hot
+                if (L == 0) { const int h = atomicAdd(S.hot_count, 1); S.hot_list[3 * h] = (int)(lo + q_it[idx]); S.hot_list[3 * h + 1] = b; S.hot_list[3 * h + 2] = e; }
+                continue;
+            }
             if (e - b > hot_min) {
                 int pos = SVDF_WIN_HOT_QUEUE;
                 if (L == 0) pos = atomicAdd(&hq_n, 1);
@@ -559,6 +584,178 @@ void launch_window_items_local(const WindowSchedule &S, int pitch, int k, long l
     if (grid > 16384) grid = 16384;
     if (window_may_hold_long_lists(nslots, hi - lo)) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, true, true>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, 0L, (void *)w_item, i_bias, window_hot_min(nslots, hi - lo))); }
     else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, true, false>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, 0L, (void *)w_item, i_bias, 0x7FFFFFFF)); }
+}
+// ------------------------------------------------------------------------------------------------- kernel B', hot items (round 6)
+// ORDERED SUB-STEPS.  The window rule of round 5 let no row meet more than 128 updates per window, because thousands of changes computed against
+// ONE stale value of a row overshoot (NaN on Zipf-popular items) -- so the single hottest item set the number of windows (7 605 at the configs[1]
+// size for a top item of 0.97 %), each a few launches over 13 K ratings.  Here a window is cut by what the COLD rows tolerate, and an item with more
+// than hot_sub slots in it is applied by ONE workgroup in file order, hot_sub slots at a time: the slots hold what the users' walk computed the
+// change FROM (tmp_u, the user's bias, the label); a sub-step forms every slot's change against the row as the previous sub-step left it --
+// update_inner's item side (apex_svd_base.h:456-462 with :383-427): pred from (bias sum in double, dot in the reference's order), err, the axpy,
+// the decay -- parks the changes in LDS, its first lane group adds them in slot order (acc = 0 + c_1 + c_2 ...) and the row moves by the sum.
+// Equals oracle/svdf_oracle.c: svdo_update_window_substeps bit for bit (tests/test_gpu_window_hot.py).  The workgroup's lane groups hold a copy of
+// the row each; the next round's slots are requested before the current round's barrier.
+// NT = 1024 threads: a sub-step is 128 dots in the reference's summation order (15 dependent DPP additions per chain: ~1 us of issue per 8 slots of a
+// wave) -- sixteen waves share them two slots per lane group (four waves, eight slots each: 8.6 us per sub-step, 138 us per window of 2 048 slots).
+// PLAIN: linear link, L2 decay (reg_method 0): the switch over links and regularisers is compiled out of the dependent chain.
+template <int LPI, int NT, bool PLAIN>
+__global__ __launch_bounds__(NT) void k_window_hot(const DevParams P, const WindowSchedule S) {
+    constexpr int G = NT / LPI;
+    constexpr int K4 = 4 * LPI;                                       // floats of a (padded) row
+    constexpr int CHUNK0 = 2048 / LPI > 128 ? 128 : 2048 / LPI;       // slots per round: at most 32 KB of LDS whatever the width ...
+    constexpr int CHUNK = CHUNK0 < G ? G : CHUNK0;                    // ... and at least one per lane group
+    constexpr int PER = CHUNK / G;
+    constexpr int EPL = (K4 + 63) / 64;                               // row elements per lane of the summing wave
+    __shared__ float4 stage[CHUNK * LPI];
+    __shared__ float stage_b[CHUNK];
+    __shared__ float4 rowq[LPI];
+    __shared__ float rowb;
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int L = lane & (LPI - 1);
+    const int grp = threadIdx.x / LPI;
+    const int pitch = P.pitch, k = P.k;
+    const bool use_ubias = P.no_user_bias == 0;
+    const int nhot = *S.hot_count;
+    const float *stage_f = reinterpret_cast<const float *>(stage);
+    float *rowf = reinterpret_cast<float *>(rowq);
+    for (int h = blockIdx.x; h < nhot; h += gridDim.x) {
+        const unsigned item = (unsigned)S.hot_list[3 * h];
+        const int b = S.hot_list[3 * h + 1], e = S.hot_list[3 * h + 2];
+        const unsigned ir = P.item_off + item;
+        const float wd_i = get_wd(P.i_rng, item, P.wd_item);
+        float4 q = load_row<LPI>(P.W, ir, pitch, L, k);
+        float bi = P.bias[ir];
+        if (grp == 0) { rowq[L] = q; if (L == 0) rowb = bi; }
+        {   // the item's slots were written by other CUs a kernel ago (they sit in HBM / the Infinity Cache): one request per 128-byte line, all in flight at
+            // once, brings them into this XCD's L2 -- the sub-steps below are a dependent chain and would otherwise pay that latency once per sub-step
+            float warm = 0.0f;
+            const size_t w0 = (size_t)b * (size_t)pitch, w1 = (size_t)e * (size_t)pitch;
+            for (size_t off = w0 + (size_t)threadIdx.x * 32; off < w1; off += (size_t)NT * 32) warm += S.contrib[off];
+            for (int sl = b + (int)threadIdx.x * 32; sl < e; sl += NT * 32) warm += S.cbias[sl] + S.clabel[sl];
+            if (warm == 1.2345e-38f) rowb = warm;   // (never true for data that matters: keeps the loads alive)
+        }
+        // the slots of a round do not depend on the row: the NEXT round's are requested before this round's changes are formed
+        float4 ntu[PER];
+        float nbu[PER], nlabel[PER];
+        auto fetch = [&](int first, int cn) {
+#pragma unroll
+            for (int r = 0; r < PER; r++) {
+                const int sl = grp + r * G;
+                const size_t slot = (size_t)(first + (sl < cn ? sl : 0));
+                ntu[r] = load_contrib<LPI>(S.contrib, 0, slot, pitch, L, k);
+                nbu[r] = S.cbias[slot];
+                nlabel[r] = S.clabel[slot];
+            }
+        };
+        fetch(b, min(min(CHUNK, S.hot_sub), e - b));
+        for (int s0 = b; s0 < e; s0 += S.hot_sub) {
+            const int sn = min(S.hot_sub, e - s0);
+            float acc[EPL];
+#pragma unroll
+            for (int x = 0; x < EPL; x++) acc[x] = 0.0f;
+            float accb = 0.0f;
+            for (int c0 = 0; c0 < sn; c0 += CHUNK) {
+                const int cn = min(CHUNK, sn - c0);
+                float4 tu[PER];
+                float bu[PER], label[PER];
+#pragma unroll
+                for (int r = 0; r < PER; r++) { tu[r] = ntu[r]; bu[r] = nbu[r]; label[r] = nlabel[r]; }
+                {   // the round after this one: the rest of the sub-step, else the head of the next sub-step
+                    int nf = s0 + c0 + CHUNK, nn = sn - c0 - CHUNK;
+                    if (nn <= 0) { nf = s0 + S.hot_sub; nn = min(S.hot_sub, e - nf); }
+                    if (nn > 0) fetch(nf, min(CHUNK, nn));
+                }
+#pragma unroll
+                for (int r = 0; r < PER; r++) {
+                    const int sl = grp + r * G;
+                    // calc_bias (:313-353) in double; "+ 0.0" terms are the svdpp / plugin hooks returning 0.0f -- the sums of k_window_users
+                    double bs = 0.0;
+                    if (use_ubias) { bs += (double)(1.0f * bu[r]); bs += 0.0; }
+                    bs += 0.0;
+                    bs += (double)(1.0f * bi);
+                    double sum = (double)P.base_score + bs;
+                    float4 ti = f4zero();
+                    axpy4(ti, q, 1.0f);
+                    sum += (double)group_dot<LPI>(tu[r], ti, L, k);
+                    const float pred = PLAIN ? (float)sum : map_active((float)sum, P.active_type);
+                    const float err = (PLAIN ? label[r] - pred : cal_grad(label[r], pred, P.active_type)) * 1.0f;
+                    const float si = P.lr * err * 1.0f;
+                    float4 wi = q;
+                    axpy4(wi, tu[r], si);
+                    float nbi = bi + si;
+                    if (PLAIN) scale4(wi, 1.0f - P.lr * wd_i);   // (reg_row's method 0)
+                    else reg_row<LPI>(P, wi, wd_i, true, L);
+                    nbi = nbi * (1.0f - P.lr * P.wd_item_bias);
+                    sub4(wi, q);
+                    if (sl < cn) { stage[sl * LPI + L] = wi; if (L == 0) stage_b[sl] = nbi - bi; }
+                }
+                __syncthreads();
+                // slot order (acc = ((0 + c_1) + c_2) + ..., the sums of k_window_items), one ROW ELEMENT per lane of the first wave: 128 dependent
+                // additions of one float instead of 128 x 4 in a lane group's float4; the bias word by one lane of the second wave beside it
+                if (wv == 0) {
+                    // whole batches first: AH reads at constant offsets, AH additions, no per-slot bounds test (the clamped form costs ~45 cycles of scalar
+                    // bookkeeping per slot: 2.5 us per sub-step of 128), then the tail one slot at a time
+                    constexpr int AH = EPL == 1 ? 32 : (EPL == 2 ? 16 : 8);
+                    bool on[EPL];
+#pragma unroll
+                    for (int z = 0; z < EPL; z++) on[z] = lane + 64 * z < K4;
+                    int sl = 0;
+                    for (; sl + AH <= cn; sl += AH) {
+                        const float *src = stage_f + (size_t)sl * K4 + lane;
+                        float t[AH][EPL];
+#pragma unroll
+                        for (int x = 0; x < AH; x++) {
+#pragma unroll
+                            for (int z = 0; z < EPL; z++) t[x][z] = on[z] ? src[x * K4 + 64 * z] : 0.0f;
+                        }
+#pragma unroll
+                        for (int x = 0; x < AH; x++) {
+#pragma unroll
+                            for (int z = 0; z < EPL; z++) acc[z] = acc[z] + t[x][z];
+                        }
+                    }
+                    for (; sl < cn; sl++) {
+#pragma unroll
+                        for (int z = 0; z < EPL; z++) acc[z] = acc[z] + (on[z] ? stage_f[(size_t)sl * K4 + lane + 64 * z] : 0.0f);
+                    }
+                } else if (wv == 1) {   // (every lane of the second wave, redundantly: 32 broadcast reads in flight, then their ordered additions -- a
+                                        // one-lane loop pays an LDS round trip per slot: 7 us per sub-step of 128)
+                    int sl = 0;
+                    for (; sl + 32 <= cn; sl += 32) {
+                        float t[32];
+#pragma unroll
+                        for (int x = 0; x < 32; x++) t[x] = stage_b[sl + x];
+#pragma unroll
+                        for (int x = 0; x < 32; x++) accb = accb + t[x];
+                    }
+                    for (; sl < cn; sl++) accb = accb + stage_b[sl];
+                }
+                if (c0 + CHUNK < sn) __syncthreads();   // (more rounds of this sub-step: the staging area is written again)
+            }
+            // the row moves by the sub-step's sum (c = c + acc, as the in-place sums do); every lane group takes the new row
+            if (wv == 0) {
+#pragma unroll
+                for (int z = 0; z < EPL; z++) { const int el = lane + 64 * z; if (el < K4) rowf[el] = rowf[el] + acc[z]; }
+            } else if (wv == 1 && lane == 0) {
+                rowb = rowb + accb;
+            }
+            __syncthreads();
+            q = rowq[L];
+            bi = rowb;
+        }
+        __syncthreads();   // (the next item of this workgroup writes rowq / rowb)
+        if (grp == 0) {
+            store_row<LPI>(P.W, ir, pitch, L, k, q);
+            if (L == 0) P.bias[ir] = bi;
+        }
+    }
+}
+void launch_window_hot(const DevParams &P, const WindowSchedule &S, hipStream_t st) {
+    if (S.hot_sub <= 0) return;
+    const int lpi = lanes_per_instance(P.k);
+    if (P.active_type == ACT_LINEAR && P.reg_method == 0) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_hot<LPI, 1024, true>), dim3(256), dim3(1024), 0, st, P, S)); }
+    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_hot<LPI, 1024, false>), dim3(256), dim3(1024), 0, st, P, S)); }
 }
 // the replicated ranges of the active partition as one packed fp32 buffer and back (the item block a rank hands to the next one)
 template <bool SET>

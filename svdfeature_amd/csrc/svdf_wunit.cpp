@@ -633,10 +633,53 @@ Dataset *Engine::wseq_from_blocks(long num_block, const int *extend_tag, const i
     return ds.release();
 }
 
+// Ordered sub-steps (svdf_k_window.hip: k_window_hot): plain ratings of the configurations the window kernels walk with unit values and fp32
+// contribution rows, on the one-GPU sequence (in-place sums).
+bool Engine::wseq_hot_ok() const {
+    return wseq_hot_sub_ > 0 && !contrib_bf16_ && !user_group() && basic_fast_path_allowed() && gpus_ == 1 && !multi_ && !is_peer_;
+}
+// The window count with the hot lane.  What the round-5 rule bounded through ONE number per row -- updates met per window -- are two different things:
+//   * how many changes of a row are computed against one value of it (overshoot: diverges on Zipf items): with sub-steps at most hot_sub for every row,
+//     so the MEAN over entries  sum_i min(c_i / W, hot_sub) c_i / n  is kept at window_per_target (24, the calibration of the uniform sizes);
+//   * how stale the USERS' view of a hot row gets (they read it as of the window start): at most window_hot_max updates (2 048; CPU simulation on a
+//     10 M-rating Zipf(0.7) stream, tools/substep_sim.py: 500 per window +1.5e-5, 1 000 +2.8e-5, 2 000 +6.0e-5, 4 000 +9.1e-5 against the 1e-4 contract;
+//     on the MI355X at the configs[1] size, 3 data seeds: 1 024 -> max 4.2e-5, 2 048 -> 6.6e-5, 3 072 -> 7.2e-5, profiles/r06_hot_lane_calibration.txt).
+long Engine::wseq_windows_hot(long n, const std::vector<long> &item_count) const {
+    if (n <= 0) return 1;
+    if (window_set_) return std::max<long>(1, (n + stage_window_ - 1) / stage_window_);
+    long mx = 0;
+    for (long c : item_count) mx = std::max(mx, c);
+    auto met = [&](long W) {
+        double s = 0.0;
+        for (long c : item_count) s += std::min((double)c / (double)W, (double)wseq_hot_sub_) * (double)c;
+        return s / (double)n;
+    };
+    long lo = std::max<long>(1, (mx + wseq_hot_max_ - 1) / wseq_hot_max_);
+    if (met(lo) <= (double)wseq_per_target_) return lo;
+    long hi = lo;
+    while (met(hi) > (double)wseq_per_target_ && hi < n) hi *= 2;
+    while (lo + 1 < hi) { const long mid = (lo + hi) / 2; if (met(mid) <= (double)wseq_per_target_) hi = mid; else lo = mid; }
+    return hi;
+}
+
 Dataset *Engine::wseq_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     std::vector<long> ci((size_t)mp_.num_item, 0);
     for (long r = 0; r < n; r++) { if (item[r] >= (unsigned)mp_.num_item) fail("item feature index exceed bound"); ci[item[r]]++; }
-    const long W = wseq_windows(n, {mean_updates_met(ci, wseq_max_ratio())});
+    const bool hot_lane = wseq_hot_ok();
+    const long W = hot_lane ? wseq_windows_hot(n, ci) : wseq_windows(n, {mean_updates_met(ci, wseq_max_ratio())});
+    // which windows hold a hot item (more than window_hot_sub slots of one item): one scan with per-item stamps
+    std::vector<char> whot((size_t)W, 0);
+    if (hot_lane) {
+        std::vector<int> stamp((size_t)mp_.num_item, -1), cnt((size_t)mp_.num_item, 0);
+        for (long w = 0; w < W; w++) {
+            const long b0 = n * w / W, b1 = n * (w + 1) / W;
+            for (long r = b0; r < b1; r++) {
+                const unsigned it = item[r];
+                if (stamp[it] != (int)w) { stamp[it] = (int)w; cnt[it] = 0; }
+                if (++cnt[it] > wseq_hot_sub_) { whot[(size_t)w] = 1; break; }
+            }
+        }
+    }
     std::unique_ptr<Dataset> ds(new Dataset());
     adopt(ds.get()); ds->kind = 8; ds->num_row = n;
     // the columns go to HBM in ONE copy each (large pageable copies run at the PCIe rate, 56 GB/s; window-sized ones at a fifth of it), the
@@ -651,6 +694,7 @@ Dataset *Engine::wseq_from_triples(long n, const unsigned *user, const unsigned 
         adopt(c.get());
         if (resident && b1 > b0) { window_build_header(c.get(), b1 - b0, false); window_build_resident(c.get(), b1 - b0, d_user.p + b0, d_item.p + b0, d_label.p + b0, nullptr); }
         else window_build(c.get(), b1 - b0, user + b0, item + b0, label + b0);
+        c->win_hot = whot[(size_t)w] != 0;
         ds->algorithmic_bytes += c->algorithmic_bytes; ds->num_units += c->num_units;
         ds->wchild.push_back(c.release());
     }
@@ -691,12 +735,28 @@ Dataset *Engine::wseq_from_pairs(long n, const unsigned *user, const unsigned *p
 // one pass over a window sequence: per window the users' walks, then the per-target sums added in place (two launches per window)
 void Engine::wseq_train(Dataset *ds) {
     const DevParams &P = params();
+    bool any_hot = false;
+    long max_slots = 1;
+    for (Dataset *c : ds->wchild) if (c->kind == 5 && c->win_hot) { any_hot = true; max_slots = std::max(max_slots, c->win_slots); }
+    const bool hot_lane = any_hot && wseq_hot_ok();
+    if (any_hot) check(hot_lane, "train_dataset: the window sequence was built with ordered sub-steps for hot items (window_hot_sub); the configuration changed since");
+    if (hot_lane) {   // one counter word per window, zeroed once per pass; the list holds at most slots / hot_sub items
+        d_clabel_.reserve((size_t)max_slots);
+        d_hot_list_.reserve((size_t)3 * (size_t)(max_slots / std::max(wseq_hot_sub_, 1) + 1));
+        d_hot_count_.reserve(ds->wchild.size());
+        HIPCHECK(hipMemsetAsync(d_hot_count_.p, 0, ds->wchild.size() * sizeof(int), stream_));
+    }
+    size_t widx = 0;
     for (Dataset *c : ds->wchild) {
         if (c->kind == 5) {
             d_contrib_.reserve((size_t)std::max<long>(c->win_slots, 1) * (size_t)pitch_);
             d_cbias_.reserve((size_t)std::max<long>(c->win_slots, 1));
-            launch_window_users(P, window_view(c), window_slots_, window_groups_, stream_);
-            launch_window_items_local(window_view(c), pitch_, mp_.num_factor, 0, mp_.num_item, dW_.p + (size_t)item_off_ * pitch_, dbias_.p + item_off_, stream_, c->win_slots);
+            WindowSchedule S = window_view(c);
+            if (hot_lane && c->win_hot) { S.hot_sub = wseq_hot_sub_; S.clabel = d_clabel_.p; S.hot_list = d_hot_list_.p; S.hot_count = d_hot_count_.p + widx; }
+            launch_window_users(P, S, window_slots_, window_groups_, stream_);
+            launch_window_items_local(S, pitch_, mp_.num_factor, 0, mp_.num_item, dW_.p + (size_t)item_off_ * pitch_, dbias_.p + item_off_, stream_, c->win_slots);
+            if (S.hot_sub > 0) { launch_window_hot(P, S, stream_); n_launches_++; }
+            widx++;
         } else {
             wunit_train(c);
             wunit_sum(c, nullptr, 0);

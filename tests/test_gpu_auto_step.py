@@ -145,29 +145,36 @@ def test_guard_the_path_auto_picks_is_not_slower_than_the_cpu_reference():
 
 def test_a_hot_row_bounds_the_window_and_the_step_stays_finite():
     """round 5: the window rule bounded the MEAN number of updates a shared row meets per window (sum c^2 / sum c at 24); on Zipf-popular items the hot
-    row then met hundreds, all computed against its window-start value, and the pass diverged to NaN at the configs[1] size.  Now no row meets more
-    than window_per_target_max (128) updates per window."""
+    row then met hundreds, all computed against its window-start value, and the pass diverged to NaN at the configs[1] size.  Round 5 bounded every row
+    at window_per_target_max (128) per window; round 6 applies a hot row in ordered sub-steps of window_hot_sub (128) instead and bounds it at
+    window_hot_max (2 048) per window (tests/test_gpu_window_hot.py); window_hot_sub = 0 restores the round-5 rule."""
     nu, ni, n = 50000, 2000, 2000000
     u, i, r = cases.planted_triples(n, nu, ni, seed=11, zipf=True)
     top = int(np.bincount(i, minlength=ni).max())
     conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=64)
-    t = _trainer(conf, extra=[("amd:step", "minibatch")])
-    ds = t.dataset_from_triples(u, i, r)
-    assert ds.kind == 8 and ds.num_batches >= -(-top // 128), (ds.num_batches, top)
-    for _ in range(3):
-        t.train_dataset(ds)
     e = _trainer(conf)
     de = e.dataset_from_triples(u, i, r)
     for _ in range(3):
         e.train_dataset(de)
-    for name in ("W_item", "W_user", "i_bias"):
-        a, b = t.view(name), e.view(name)
-        assert np.isfinite(a).all(), name
-        assert np.abs(a - b).max() < 0.05, (name, float(np.abs(a - b).max()))
-    # the knob moves the bound
+    for sub in (128, 0):
+        t = _trainer(conf, extra=[("amd:step", "minibatch")])
+        t.set_knob("window_hot_sub", sub)
+        ds = t.dataset_from_triples(u, i, r)
+        assert ds.kind == 8 and ds.num_batches >= -(-top // (128 if sub == 0 else 2048)), (ds.num_batches, top)
+        for _ in range(3):
+            t.train_dataset(ds)
+        for name in ("W_item", "W_user", "i_bias"):
+            a, b = t.view(name), e.view(name)
+            assert np.isfinite(a).all(), name
+            assert np.abs(a - b).max() < 0.05, (name, float(np.abs(a - b).max()))
+    # the knobs move the bounds
     t2 = _trainer(conf, extra=[("amd:step", "minibatch")])
+    t2.set_knob("window_hot_sub", 0)
     t2.set_knob("window_per_target_max", 32)
     assert t2.dataset_from_triples(u, i, r).num_batches >= -(-top // 32)
+    t3 = _trainer(conf, extra=[("amd:step", "minibatch")])
+    t3.set_knob("window_hot_max", 256)
+    assert t3.dataset_from_triples(u, i, r).num_batches >= -(-top // 256)
 
 
 def test_streams_beyond_the_probe_size_are_judged_on_their_first_rows():

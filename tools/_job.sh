@@ -1,9 +1,3 @@
 #!/bin/bash
-mkdir -p gpurun_out/r06_contract
-for cfg in "24 16" "24 12"; do
-  set -- $cfg
-  timeout 1100 python tools/contract_seeds.py 0,1,2 8 --zipf 0.7 --skip-allreduce --checks 3 --per-item $1 --chunks $2 \
-      > gpurun_out/r06_contract/zipf_c2_per${1}_chunks${2}.txt 2> gpurun_out/r06_contract/zipf_c2_per${1}_chunks${2}.err
-  echo "cfg $cfg rc=$?"
-  cat gpurun_out/r06_contract/zipf_c2_per${1}_chunks${2}.txt
-done
+python -m pytest tests/test_gpu_window_hot.py tests/test_gpu_window.py tests/test_gpu_wunit.py tests/test_gpu_auto_step.py -x -q 2>&1 | tail -4
+python tools/hot_lane_calibration.py 100000000 0,1,2 1024,2048,3072 2>&1 | grep -v "^\[svdf\|amdgpu.ids" | tee gpurun_out/r06_hot_lane_calibration.txt
