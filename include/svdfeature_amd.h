@@ -311,7 +311,7 @@ int svdf_synchronize(svdf_trainer *t);
  * 26 data sets whose DEFAULT (exact) step drew the depth warning (a stderr line naming `amd:step = auto`: the level schedule predicts the pass
  * more than 10 x slower than the streaming model), 27 / 28 the last noted data set's dag bound / stream model in microseconds */
 int64_t svdf_counter(svdf_trainer *t, int what);
-/* Tuning knobs (not part of the reference surface).  None changes a result bit except the three marked (*), which move the windows of the
+/* Tuning knobs (not part of the reference surface).  None changes a result bit except the five marked (*), which move the windows of the
  * OPT-IN window step only.  Every knob, its default, what other values select (round 6: knobs no test or tool sets were deleted).
  *   staging / launches
  *     stage_window        2^21   instances staged by svdf_update_* before an automatic flush (also set by the config key amd:window)
@@ -337,7 +337,10 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  *   the opt-in window step (amd:step = minibatch / auto; N-rank handles)
  *     wunit_fast 2, wunit_inplace 1, wunit_defer_fb 1, window_slots 1, window_groups 0      kernel forms, same bits
  *     window_per_target (*) 24, window_per_target_fb (*) 16     updates a shared row / feedback row meets per window on average
- *     window_per_target_max (*) 128                             ... and at most
+ *     window_per_target_max (*) 128                             ... and at most (N-rank steps, rank pairs, user units; plain ratings on one GPU with window_hot_sub = 0)
+ *     window_hot_sub (*) 128, window_hot_max (*) 2048           one-GPU sequences of plain ratings (round 6): an item with more than window_hot_sub slots in a window
+ *                                                               moves in ordered sub-steps of that many (k_window_apply; 0 = off) and meets at most window_hot_max
+ *                                                               updates per window -- the hottest item no longer sets the number of windows
  *     ipc_spin_limit             polls before a flag wait of the IPC exchange gives up
  * Returns 0 if the knob exists, -1 otherwise.  The relaxed mode is switched by CONFIG keys through svdf_set_param ("amd:relax_global",
  * "amd:relax_user_from", "amd:relax_item_from", "amd:relax_feedback"), not by knobs: it changes results. */

@@ -928,7 +928,7 @@ int svdo_update_csr_batch_stale(svdo_trainer *t, int num_row, const float *row_l
     free(sv.buf);
     return 0;
 }
-/* ---- one window of the one-GPU window step with ORDERED SUB-STEPS on the item side (HIP engine round 6: svdf_k_window.hip, k_window_hot;
+/* ---- one window of the one-GPU window step with ORDERED SUB-STEPS on the item side (HIP engine round 6: svdf_k_window.hip, k_window_apply;
  * `amd:step = minibatch / auto` on one GPU).  Not the reference's semantics either -- the same checker role as svdo_update_csr_batch_stale:
  *   * user side: exactly as the stale step -- every row is update_inner (apex_svd_base.h:456-462) on (the user's current row, the item row as
  *     it was at the WINDOW START); the item row is put back after every row;

@@ -60,7 +60,7 @@ void svdo_predict_csr_batch(svdo_trainer *t, int num_row, const float *row_label
  * Returns 0, -1 where the configuration is not supported. */
 int svdo_update_csr_batch_stale(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
                                 const unsigned *feat_index, const float *feat_value, float *dW_item, float *di_bias, float *dg_bias);
-/* one window of the one-GPU window step with ordered sub-steps of at most `sub` rows per item (svdf_oracle.c; HIP: k_window_hot) */
+/* one window of the one-GPU window step with ordered sub-steps of at most `sub` rows per item (svdf_oracle.c; HIP: k_window_apply) */
 int svdo_update_window_substeps(svdo_trainer *t, int num_row, const float *row_label, const int *row_ptr,
                                 const unsigned *feat_index, const float *feat_value, int sub);
 /* checker steps: round every ROW contribution to bfloat16 before it is summed (the HIP engine's `amd:contrib = bf16`); bias words stay fp32 */

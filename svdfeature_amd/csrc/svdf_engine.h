@@ -248,7 +248,7 @@ struct Dataset {
     bool pv_item_pivot = false;
     long pv_cold = 0, pv_hot_rows = 0;
     int64_t chained_levels = 0;   // levels the current launch sequence of this data set walks inside chained launches
-    bool win_hot = false;         // kind 5 inside a one-GPU sequence: some item has more than window_hot_sub slots in this window (ordered sub-steps: k_window_hot)
+    bool win_hot = false;         // kind 5 inside a one-GPU sequence: some item has more than window_hot_sub slots in this window (ordered sub-steps: k_window_apply)
     long win_slots = 0;           // contribution slots of the window = item entries (kind 7: + feedback entries)
     // kind 7: window-minibatch data set of user units (svdf_k_wunit.hip): user-group blocks / rows with global features
     DevBuf<WinUnit> wu_units;
@@ -621,11 +621,10 @@ class Engine {
     int wunit_fast_ = 2;                  // knob "wunit_fast": 0 = the general lane-group kernel for every shape, 1 = + the slot kernel, 2 = + one wave per unit (A/B and tests)
     int wseq_per_target_fb_ = 16;         // knob "window_per_target_fb": the same for feedback rows (instance-sized updates pushed by whole blocks)
     int wseq_per_target_max_ = 128;       // knob "window_per_target_max": the MOST updates any shared row may meet per window (binds on skewed data only)
-    // ordered sub-steps for hot items of a one-GPU window sequence of plain ratings (svdf_k_window.hip: k_window_hot; round 6)
+    // ordered sub-steps for hot items of a one-GPU window sequence of plain ratings (svdf_k_window.hip: k_window_apply; round 6)
     int wseq_hot_sub_ = 128;              // knob "window_hot_sub": an item with more slots than this in a window is applied in sub-steps of this many (0 = off: the round-5 rule, no row more than window_per_target_max per window)
     int wseq_hot_max_ = 2048;             // knob "window_hot_max": the most updates a hot row may meet per window (how stale the USERS' view of it gets); 3 seeds of Zipf(0.7) at the configs[1] size: 1 024 max |dRMSE| 4.2e-5 / 66 ms per pass, 2 048 6.6e-5 / 55 ms, 3 072 7.2e-5 / 52 ms (profiles/r06_hot_lane_calibration.txt)
     DevBuf<float> d_clabel_;
-    DevBuf<int> d_hot_list_, d_hot_count_;
     bool wseq_hot_ok() const;             // the configuration has the hot lane (unit ratings, fp32 contribution rows, one GPU)
     long wseq_windows_hot(long n, const std::vector<long> &item_count) const;
     double wseq_max_ratio() const { return (double)wseq_per_target_ / (double)wseq_per_target_max_; }

@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_window_users(const DevParams P, const W
                 sub4(wi, q[e]);
                 const long slot = e == 0 ? S.slot[s] : S.slot1[s];
                 if (NI == 1 && S.hot_sub > 0 && S.iptr[item[0] + 1] - S.iptr[item[0]] > S.hot_sub) {
-                    // a hot item of this window: what the change is computed FROM goes to the slot; k_window_hot forms it against the row of its sub-step
+                    // a hot item of this window: what the change is computed FROM goes to the slot; k_window_apply forms it against the row of its sub-step
                     store_contrib<LPI>(S.contrib, 0, (size_t)slot, pitch, L, k, tu);
                     if (L == 0) { S.cbias[slot] = use_ubias ? bu : 0.0f; S.clabel[slot] = label; }
                 } else {
@@ -380,10 +380,6 @@ __global__ __launch_bounds__(256) void k_window_items(const WindowSchedule S, in
     for (long it = first; it < nitem; it += stride) {
         const long i = lo + it;
         const int b = S.iptr[i], e = S.iptr[i + 1];
-        if (LOCAL && S.hot_sub > 0 && e - b > S.hot_sub) {   // ordered sub-steps: k_window_hot takes the item (its slots hold vectors, not changes)
-            if (L == 0) { const int h = atomicAdd(S.hot_count, 1); S.hot_list[3 * h] = (int)i; S.hot_list[3 * h + 1] = b; S.hot_list[3 * h + 2] = e; }
-            continue;
-        }
         if (HOT && e - b > hot_min) {   // a long list: left to the whole workgroup (below) while the queue has room
             int pos = SVDF_WIN_HOT_QUEUE;
             if (L == 0) pos = atomicAdd(&hq_n, 1);
@@ -487,10 +483,6 @@ __global__ __launch_bounds__(256) void k_window_items_sparse(const WindowSchedul
         const int n = q_n;
         for (int idx = grp; idx < n; idx += G) {
             const int b = q_b[idx], e = q_e[idx];
-            if (S.hot_sub > 0 && e - b > S.hot_sub) {   // ordered sub-steps: left to k_window_hot
-                if (L == 0) { const int h = atomicAdd(S.hot_count, 1); S.hot_list[3 * h] = (int)(lo + q_it[idx]); S.hot_list[3 * h + 1] = b; S.hot_list[3 * h + 2] = e; }
-                continue;
-            }
             if (e - b > hot_min) {
                 int pos = SVDF_WIN_HOT_QUEUE;
                 if (L == 0) pos = atomicAdd(&hq_n, 1);
@@ -585,11 +577,11 @@ void launch_window_items_local(const WindowSchedule &S, int pitch, int k, long l
     if (window_may_hold_long_lists(nslots, hi - lo)) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, true, true>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, 0L, (void *)w_item, i_bias, window_hot_min(nslots, hi - lo))); }
     else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_items<LPI, false, true, false>), dim3((unsigned)grid), dim3(256), 0, st, S, pitch, k, lo, hi, 0L, (void *)w_item, i_bias, 0x7FFFFFFF)); }
 }
-// ------------------------------------------------------------------------------------------------- kernel B', hot items (round 6)
+// ------------------------------------------------------------------------------------------------- kernel B', windows with hot items (round 6)
 // ORDERED SUB-STEPS.  The window rule of round 5 let no row meet more than 128 updates per window, because thousands of changes computed against
 // ONE stale value of a row overshoot (NaN on Zipf-popular items) -- so the single hottest item set the number of windows (7 605 at the configs[1]
 // size for a top item of 0.97 %), each a few launches over 13 K ratings.  Here a window is cut by what the COLD rows tolerate, and an item with more
-// than hot_sub slots in it is applied by ONE workgroup in file order, hot_sub slots at a time: the slots hold what the users' walk computed the
+// than hot_sub slots in it is applied by ONE workgroup (of 1 024 threads) in file order, hot_sub slots at a time: the slots hold what the users' walk computed the
 // change FROM (tmp_u, the user's bias, the label); a sub-step forms every slot's change against the row as the previous sub-step left it --
 // update_inner's item side (apex_svd_base.h:456-462 with :383-427): pred from (bias sum in double, dot in the reference's order), err, the axpy,
 // the decay -- parks the changes in LDS, its first lane group adds them in slot order (acc = 0 + c_1 + c_2 ...) and the row moves by the sum.
@@ -598,8 +590,12 @@ void launch_window_items_local(const WindowSchedule &S, int pitch, int k, long l
 // NT = 1024 threads: a sub-step is 128 dots in the reference's summation order (15 dependent DPP additions per chain: ~1 us of issue per 8 slots of a
 // wave) -- sixteen waves share them two slots per lane group (four waves, eight slots each: 8.6 us per sub-step, 138 us per window of 2 048 slots).
 // PLAIN: linear link, L2 decay (reg_method 0): the switch over links and regularisers is compiled out of the dependent chain.
+// ONE launch applies the whole window (k_window_apply): the first `hot_blocks` workgroups are the hot lane -- workgroup g looks at items g, g + hot_blocks,
+// ... (neighbouring ids, which real catalogues often sort by popularity, go to different workgroups), queues the hot ones in LDS and walks them --, the
+// other workgroups add the cold items' slots in place, a lane group per item in slot order (sum_contrib_slots: the additions of k_window_items).  Hot and
+// cold items share no row, so the hot items' dependent chains run beside the streaming sums instead of after them.
 template <int LPI, int NT, bool PLAIN>
-__global__ __launch_bounds__(NT) void k_window_hot(const DevParams P, const WindowSchedule S) {
+__global__ __launch_bounds__(NT) void k_window_apply(const DevParams P, const WindowSchedule S, long num_item, float *w_item, float *i_bias, int hot_blocks) {
     constexpr int G = NT / LPI;
     constexpr int K4 = 4 * LPI;                                       // floats of a (padded) row
     constexpr int CHUNK0 = 2048 / LPI > 128 ? 128 : 2048 / LPI;       // slots per round: at most 32 KB of LDS whatever the width ...
@@ -616,12 +612,44 @@ __global__ __launch_bounds__(NT) void k_window_hot(const DevParams P, const Wind
     const int grp = threadIdx.x / LPI;
     const int pitch = P.pitch, k = P.k;
     const bool use_ubias = P.no_user_bias == 0;
-    const int nhot = *S.hot_count;
+    if ((int)blockIdx.x >= hot_blocks) {   // ---- cold items: the in-place sums of k_window_items<LPI, false, true, .> for every list of at most hot_sub slots
+        const bool owns = !(LPI * 4 > k && L * 4 >= k);
+        const long stride = (long)(gridDim.x - hot_blocks) * G;
+        for (long i = (long)(blockIdx.x - hot_blocks) * G + grp; i < num_item; i += stride) {
+            const int b = S.iptr[i], e = S.iptr[i + 1];
+            if (b == e || e - b > S.hot_sub) continue;
+            float4 acc = f4zero();
+            float accb = 0.0f;
+            sum_contrib_slots<LPI, false>(S.contrib, S.cbias, b, e, pitch, L, k, acc, accb);
+            if (owns) {
+                float4 *w = reinterpret_cast<float4 *>(w_item + (size_t)i * pitch + (size_t)L * 4);
+                float4 c = *w;
+                c.x = c.x + acc.x; c.y = c.y + acc.y; c.z = c.z + acc.z; c.w = c.w + acc.w;
+                *w = c;
+            }
+            if (L == 0) i_bias[i] = i_bias[i] + accb;
+        }
+        return;
+    }
+    __shared__ int hl_item[NT], hl_b[NT], hl_e[NT];
+    __shared__ int hl_n;
     const float *stage_f = reinterpret_cast<const float *>(stage);
     float *rowf = reinterpret_cast<float *>(rowq);
-    for (int h = blockIdx.x; h < nhot; h += gridDim.x) {
-        const unsigned item = (unsigned)S.hot_list[3 * h];
-        const int b = S.hot_list[3 * h + 1], e = S.hot_list[3 * h + 2];
+    for (long base = blockIdx.x; base < num_item; base += (long)hot_blocks * NT) {
+    if (threadIdx.x == 0) hl_n = 0;
+    __syncthreads();
+    {
+        const long i = base + (long)threadIdx.x * hot_blocks;
+        if (i < num_item) {
+            const int b = S.iptr[i], e = S.iptr[i + 1];
+            if (e - b > S.hot_sub) { const int pos = atomicAdd(&hl_n, 1); hl_item[pos] = (int)i; hl_b[pos] = b; hl_e[pos] = e; }
+        }
+    }
+    __syncthreads();
+    const int nhot = hl_n;
+    for (int h = 0; h < nhot; h++) {
+        const unsigned item = (unsigned)hl_item[h];
+        const int b = hl_b[h], e = hl_e[h];
         const unsigned ir = P.item_off + item;
         const float wd_i = get_wd(P.i_rng, item, P.wd_item);
         float4 q = load_row<LPI>(P.W, ir, pitch, L, k);
@@ -750,12 +778,18 @@ __global__ __launch_bounds__(NT) void k_window_hot(const DevParams P, const Wind
             if (L == 0) P.bias[ir] = bi;
         }
     }
+    __syncthreads();   // (the next scan resets the queue)
+    }
 }
-void launch_window_hot(const DevParams &P, const WindowSchedule &S, hipStream_t st) {
-    if (S.hot_sub <= 0) return;
+void launch_window_apply(const DevParams &P, const WindowSchedule &S, long num_item, float *w_item, float *i_bias, hipStream_t st) {
+    if (S.hot_sub <= 0 || num_item <= 0) return;
     const int lpi = lanes_per_instance(P.k);
-    if (P.active_type == ACT_LINEAR && P.reg_method == 0) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_hot<LPI, 1024, true>), dim3(256), dim3(1024), 0, st, P, S)); }
-    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_hot<LPI, 1024, false>), dim3(256), dim3(1024), 0, st, P, S)); }
+    const int hot_blocks = 256;
+    const long groups = 1024 / lpi;
+    const long cold = std::min<long>(std::max<long>((num_item + groups - 1) / groups, 1), 4096);
+    const unsigned grid = (unsigned)(hot_blocks + cold);
+    if (P.active_type == ACT_LINEAR && P.reg_method == 0) { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_apply<LPI, 1024, true>), dim3(grid), dim3(1024), 0, st, P, S, num_item, w_item, i_bias, hot_blocks)); }
+    else { SVDF_DISPATCH_LPI(lpi, hipLaunchKernelGGL((k_window_apply<LPI, 1024, false>), dim3(grid), dim3(1024), 0, st, P, S, num_item, w_item, i_bias, hot_blocks)); }
 }
 // the replicated ranges of the active partition as one packed fp32 buffer and back (the item block a rank hands to the next one)
 template <bool SET>

@@ -51,7 +51,7 @@ void launch_delta_unpack(const DeltaRanges &R, float *snap, const void *src, int
 // window-minibatch step (svdf_k_window.hip): user walk with the item side read-only, per-item sum of the contributions into the wire
 // buffer (item range [lo, hi) + nglobal zeros), and replicated ranges += all-reduced wire buffer
 bool window_slots_applies(const DevParams &P, const WindowSchedule &S);
-void launch_window_hot(const DevParams &P, const WindowSchedule &S, hipStream_t st);   // ordered sub-steps of the window's hot items (after the in-place sums)
+void launch_window_apply(const DevParams &P, const WindowSchedule &S, long num_item, float *w_item, float *i_bias, hipStream_t st);   // a window WITH hot items: ordered sub-steps of the hot ones beside the in-place sums of the others, one launch
 void launch_window_users(const DevParams &P, const WindowSchedule &S, int slots, int groups_per_wave, hipStream_t st);
 void launch_window_items(const WindowSchedule &S, int pitch, int k, long lo, long hi, long nglobal, void *dst, int half, hipStream_t st, long nslots = -1);
 void launch_delta_addto(const DeltaRanges &R, const void *src, int half, hipStream_t st);

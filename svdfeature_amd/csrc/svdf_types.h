@@ -202,13 +202,11 @@ struct WindowSchedule {
     int contrib_bf16;           // 1: contribution rows are bfloat16 (amd:contrib = bf16), sums stay fp32
     // ORDERED SUB-STEPS for hot items (round 6; one-GPU window sequences, in-place sums only; 0 = off).  An item with MORE than hot_sub slots in the
     // window is "hot" there: the users' walk stores, instead of the would-be change, what it was computed FROM -- the user's vector (tmp_u), bias
-    // and the label -- and k_window_hot applies the item's slots in file order in sub-steps of hot_sub: every sub-step's changes are computed
+    // and the label -- and k_window_apply's hot lane applies the item's slots in file order in sub-steps of hot_sub: every sub-step's changes are computed
     // against the row as the previous sub-step left it (oracle/svdf_oracle.c: svdo_update_window_substeps).  Needs unit values, one item entry,
     // fp32 contribution rows.
     int hot_sub;
     float *clabel;              // [slots] scratch: the label of a hot entry
-    int *hot_list;              // {item, first slot, one past the last} of the window's hot items, appended by the sum kernel
-    int *hot_count;             // ... how many (zeroed once per pass; one word per window)
 };
 
 // Window-minibatch data set of USER UNITS (svdf_k_wunit.hip): user-group (SVD++) blocks and rows with global

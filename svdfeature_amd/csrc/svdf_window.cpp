@@ -23,7 +23,7 @@ WindowSchedule Engine::window_view(const Dataset *ds) const {
     return WindowSchedule{ds->win_urec.p, ds->num_units, ds->item.p, pairs ? nullptr : ds->label.p, ds->win_slot.p, ds->unit_values ? nullptr : ds->uval.p,
                           (ds->unit_values && !pairs) ? nullptr : ds->ival.p, ds->win_iptr.p, d_contrib_.p, d_cbias_.p,
                           pairs ? ds->win_item1.p : nullptr, pairs ? ds->win_slot1.p : nullptr, pairs ? ds->win_ival1.p : nullptr, contrib_bf16_ ? 1 : 0,
-                          0, nullptr, nullptr, nullptr};   // (ordered sub-steps of hot items: set by wseq_train for the windows that have any)
+                          0, nullptr};   // (ordered sub-steps of hot items: set by wseq_train for the windows that have any)
 }
 Dataset *Engine::dataset_window_from_triples(long n, const unsigned *user, const unsigned *item, const float *label) {
     check(trainer_ready_, "dataset: init_trainer has not been called");

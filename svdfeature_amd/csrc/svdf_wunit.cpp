@@ -633,7 +633,7 @@ Dataset *Engine::wseq_from_blocks(long num_block, const int *extend_tag, const i
     return ds.release();
 }
 
-// Ordered sub-steps (svdf_k_window.hip: k_window_hot): plain ratings of the configurations the window kernels walk with unit values and fp32
+// Ordered sub-steps (svdf_k_window.hip: k_window_apply): plain ratings of the configurations the window kernels walk with unit values and fp32
 // contribution rows, on the one-GPU sequence (in-place sums).
 bool Engine::wseq_hot_ok() const {
     return wseq_hot_sub_ > 0 && !contrib_bf16_ && !user_group() && basic_fast_path_allowed() && gpus_ == 1 && !multi_ && !is_peer_;
@@ -740,23 +740,16 @@ void Engine::wseq_train(Dataset *ds) {
     for (Dataset *c : ds->wchild) if (c->kind == 5 && c->win_hot) { any_hot = true; max_slots = std::max(max_slots, c->win_slots); }
     const bool hot_lane = any_hot && wseq_hot_ok();
     if (any_hot) check(hot_lane, "train_dataset: the window sequence was built with ordered sub-steps for hot items (window_hot_sub); the configuration changed since");
-    if (hot_lane) {   // one counter word per window, zeroed once per pass; the list holds at most slots / hot_sub items
-        d_clabel_.reserve((size_t)max_slots);
-        d_hot_list_.reserve((size_t)3 * (size_t)(max_slots / std::max(wseq_hot_sub_, 1) + 1));
-        d_hot_count_.reserve(ds->wchild.size());
-        HIPCHECK(hipMemsetAsync(d_hot_count_.p, 0, ds->wchild.size() * sizeof(int), stream_));
-    }
-    size_t widx = 0;
+    if (hot_lane) d_clabel_.reserve((size_t)max_slots);
     for (Dataset *c : ds->wchild) {
         if (c->kind == 5) {
             d_contrib_.reserve((size_t)std::max<long>(c->win_slots, 1) * (size_t)pitch_);
             d_cbias_.reserve((size_t)std::max<long>(c->win_slots, 1));
             WindowSchedule S = window_view(c);
-            if (hot_lane && c->win_hot) { S.hot_sub = wseq_hot_sub_; S.clabel = d_clabel_.p; S.hot_list = d_hot_list_.p; S.hot_count = d_hot_count_.p + widx; }
+            if (hot_lane && c->win_hot) { S.hot_sub = wseq_hot_sub_; S.clabel = d_clabel_.p; }
             launch_window_users(P, S, window_slots_, window_groups_, stream_);
-            launch_window_items_local(S, pitch_, mp_.num_factor, 0, mp_.num_item, dW_.p + (size_t)item_off_ * pitch_, dbias_.p + item_off_, stream_, c->win_slots);
-            if (S.hot_sub > 0) { launch_window_hot(P, S, stream_); n_launches_++; }
-            widx++;
+            if (S.hot_sub > 0) launch_window_apply(P, S, mp_.num_item, dW_.p + (size_t)item_off_ * pitch_, dbias_.p + item_off_, stream_);
+            else launch_window_items_local(S, pitch_, mp_.num_factor, 0, mp_.num_item, dW_.p + (size_t)item_off_ * pitch_, dbias_.p + item_off_, stream_, c->win_slots);
         } else {
             wunit_train(c);
             wunit_sum(c, nullptr, 0);

@@ -1,4 +1,4 @@
-"""Ordered sub-steps for the hot items of a one-GPU window sequence (svdf_k_window.hip: k_window_hot; svdf_wunit.cpp: wseq_windows_hot; round 6,
+"""Ordered sub-steps for the hot items of a one-GPU window sequence (svdf_k_window.hip: k_window_apply; svdf_wunit.cpp: wseq_windows_hot; round 6,
 VERDICT round 5 item 4).  `amd:step = minibatch / auto` on plain ratings: a window is cut by what the cold rows tolerate; an item with more than
 `window_hot_sub` slots in a window is applied by one workgroup in file order, window_hot_sub slots at a time, every sub-step's changes computed against
 the row as the previous sub-step left it.  The checker is oracle/svdf_oracle.c: svdo_update_window_substeps (the reference's update_inner, apex_svd_base.h:

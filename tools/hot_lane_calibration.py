@@ -1,4 +1,4 @@
-"""Calibration of the ordered sub-steps for hot items (svdf_k_window.hip: k_window_hot; knobs window_hot_sub / window_hot_max): BASELINE configs[1] with
+"""Calibration of the ordered sub-steps for hot items (svdf_k_window.hip: k_window_apply; knobs window_hot_sub / window_hot_max): BASELINE configs[1] with
 Zipf(0.7) items (benchlib/orders.py), 3 passes through the exact pass and through the one-GPU window step -- the round-5 rule (window_hot_sub = 0: no row more
 than 128 updates per window) and the hot lane with window_hot_max = 512 ... 4096 --, held-out RMSE against the exact run's, ms per pass.
 python tools/hot_lane_calibration.py [ratings] [seeds] [hot_max list] [exponent]"""
