@@ -1061,6 +1061,11 @@ def main():
     ap.add_argument("--no-window-step", action="store_true", help="N=1: skip the opt-in window-minibatch lines of the SVD++ / neighbourhood secondaries")
     ap.add_argument("--step-window", type=int, default=0, help="window-step secondaries: rows per window (amd:window); 0 = the engine's choice from the data")
     ap.add_argument("--step-per-target", type=int, default=0, help="window-step secondaries: updates a shared row meets per window (knob window_per_target); 0 = default")
+    ap.add_argument("--multi-secondary", choices=["allreduce", "all", "none"], default="allreduce",
+                    help="N>1, ratings: what runs besides the main line in the same command.  allreduce (default since round 6): the OTHER schedule on the same data -- "
+                         "north_star's all-reduce window step when the ring is the main line, the ring otherwise -- so that allreduce_step is always measured; "
+                         "all: also the native-RCCL / IPC transports of both steps and the single-process amd:gpus handle (five more runs, each under "
+                         "--secondary-timeout: none of them has ever run on more than one device, and an 8-GPU driver run must not spend its wall clock on them); none = --no-multi-secondary")
     ap.add_argument("--no-multi-secondary", action="store_true",
                     help="N>1, ratings: skip secondary.allreduce_minibatch (the RCCL all-reduce step on the same data) and secondary.single_process_handle (rank 0 alone "
                          "drives all N devices through one amd:gpus handle, amd:exchange = p2p and rccl)")
@@ -1287,7 +1292,9 @@ def main():
             secondary["orders_error"] = repr(e)
 
     # ---- N > 1, ratings: the other exchange designs on the SAME data in the SAME driver command
-    if world > 1 and a.workload == "basicmf" and not a.no_multi_secondary:
+    if a.no_multi_secondary:
+        a.multi_secondary = "none"
+    if world > 1 and a.workload == "basicmf" and a.multi_secondary != "none":
         import argparse as _ap
         main_step = (main_res or {}).get("exchange", {}).get("step") if rank == 0 else None
         # (1) north_star's step: RCCL all-reduce of the per-item sums every window (window-minibatch step), when the main line was the ring
@@ -1315,6 +1322,8 @@ def main():
         variants = [("allreduce_minibatch_ipc", "minibatch", "ipc"), ("stratified_ipc", "stratified", "ipc")]
         if backend == "nccl" or os.environ.get("SVDF_BENCH_TEST_NATIVE_ON_GLOO"):   # RCCL refuses two ranks on one device: only with a device per rank (the hook: tests of the skip path)
             variants = [("stratified_native", "stratified", "native"), ("allreduce_minibatch_native", "minibatch", "native")] + variants
+        if a.multi_secondary != "all":
+            variants = []
         for key, exch, transport in variants:
             wd.arm(a.secondary_timeout, "secondary: %s" % key, finish_now)
             a3 = _ap.Namespace(**vars(a))
@@ -1337,7 +1346,9 @@ def main():
         # (2) the same algorithm behind ONE C-ABI handle: rank 0 alone drives all N devices from C++ (svdf_multi.cpp), direct peer exchange
         # and RCCL from the engine; the other ranks idle on the host (their GPUs hold no running kernel) until rank 0 says so through the store
         wd.arm(a.secondary_timeout, "secondary: single-process amd:gpus handle", finish_now)
-        if rank == 0:
+        if a.multi_secondary != "all":
+            pass
+        elif rank == 0:
             sp = {}
             for xch in ("p2p", "rccl"):
                 try:

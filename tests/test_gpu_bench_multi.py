@@ -51,7 +51,7 @@ def _bench(args, extra_env=None, timeout=1500):
 def test_two_ranks_one_command_yields_every_multi_gpu_number():
     # a replica of configs[2] at its density (100 ratings per user, 1000 per item): at 5 M ratings over the full 1 M x 100 K id space
     # (5 per user) the RMSE moves by 2e-4 under ANY reordering of the file, which says nothing about the exchange
-    line, err = _bench(["--gpus", "2", "--users", "50000", "--items", "5000", "--ratings", "5000000", "--steps", "2"])
+    line, err = _bench(["--gpus", "2", "--users", "50000", "--items", "5000", "--ratings", "5000000", "--steps", "2", "--multi-secondary", "all"])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "config", "roofline", "cpu_baseline", "exchange", "phase_ms", "per_rank_ms", "roofline_aggregate", "model_ms",
                 "rmse_test_after_run", "rmse_sequential_reference", "rmse_minus_sequential", "secondary"):
@@ -117,7 +117,7 @@ def test_a_transport_that_cannot_be_opened_skips_its_secondary_only():
     """two ranks on ONE device: ncclCommInitRank refuses the duplicate GPU on every rank -- the ranks agree through the store, the native secondaries
     carry the error, the IPC secondaries and the line itself are unaffected"""
     line, err = _bench(["--gpus", "2", "--users", "10000", "--items", "1000", "--ratings", "1000000", "--steps", "1", "--no-cpu-baseline",
-                        "--secondary-timeout", "150"], {"SVDF_BENCH_TEST_NATIVE_ON_GLOO": "1"})
+                        "--secondary-timeout", "150", "--multi-secondary", "all"], {"SVDF_BENCH_TEST_NATIVE_ON_GLOO": "1"})
     sec = line["secondary"]
     for key in ("stratified_native", "allreduce_minibatch_native"):
         assert "error" in sec[key] and "native" in sec[key]["error"], sec[key]
