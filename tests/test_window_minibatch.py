@@ -283,3 +283,39 @@ def test_all_rank_stratified_plan_equals_the_per_rank_plans():
                     for wa, wb in zip(sa_, sb):
                         for x, y in zip(wa, wb):
                             np.testing.assert_array_equal(x, y)
+
+
+def test_substep_checker_reduces_to_the_stale_step_when_no_item_is_hot():
+    """oracle/svdf_oracle.c: svdo_update_window_substeps (the checker of the one-GPU window step with ordered sub-steps, round 6) against the stale-step
+    checker it generalises: with `sub` at least the largest per-item count of the window every item takes ONE sub-step, computed against the window-start
+    row -- exactly svdo_update_csr_batch_stale followed by W_item += dW, i_bias += db; bit for bit.  With a small `sub` the hot items move differently
+    (and stay finite where thousands of stale changes summed at once do not)."""
+    import cases
+    from oracle import oracle
+    from svdfeature_amd.data import CSRData
+    oracle.build()
+    nu, ni, n = 400, 60, 6000
+    u, i, r = cases.planted_triples(n, nu, ni, seed=9, zipf=True)
+    conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=24)
+    d = CSRData.from_triples(u, i, r)
+    top = int(np.bincount(i, minlength=ni).max())
+
+    def make():
+        o = oracle.OracleTrainer("port", 0, 0)
+        o.seed(10)
+        for k, v in conf:
+            o.set_param(k, v)
+        o.init_model()
+        o.init_trainer()
+        return o
+    a, b, c = make(), make(), make()
+    a.update_window_substeps(d, top)
+    dW, db, dg = b.update_batch_stale(d)
+    b.set_view("W_item", b.view("W_item") + dW)
+    b.set_view("i_bias", b.view("i_bias") + db)
+    for name in ("W_item", "i_bias", "W_user", "u_bias"):
+        assert np.array_equal(a.view(name).view(np.uint32), b.view(name).view(np.uint32)), name
+    c.update_window_substeps(d, 16)
+    assert top > 64 and np.isfinite(c.view("W_item")).all()
+    assert np.array_equal(c.view("W_user").view(np.uint32), a.view("W_user").view(np.uint32))      # the user side does not depend on the sub-step size
+    assert not np.array_equal(c.view("W_item").view(np.uint32), a.view("W_item").view(np.uint32))
