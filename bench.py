@@ -56,7 +56,7 @@ def conf_for(a):
 
 WORKLOADS = {
     # name: (format_type, active_type, default factor, dominant kernel, unit name)
-    "basicmf": (0, 0, 64, "k_basicmf_runs_soa<8,2,4,1> at k=64 (round 5: a lane group of 8 lanes x 2 chunks walks a RUN of up to 4 consecutive ratings of one item with the item's row in registers; "
+    "basicmf": (0, 0, 64, "k_basicmf_runs_soa<8,2,4,1> at k=64 (a lane group of 8 lanes x 2 chunks walks a RUN of up to 4 consecutive ratings of one item with the item's row in registers; "
                           "one launch per conflict-free level of runs; knob runs_exec=0: k_basicmf_slots<8,2,4>, one instance per lane group), k_basicmf<k/4,G,...> at other widths", "instances/s"),
     "pairwise": (0, 3, 128, "k_fewrow_slots<16,2,1,2> (few-row kernel, 3 rows per pair, 16 lanes x 2 chunks per row)", "pairs/s"),
     "svdpp": (1, 0, 128, "k_svdpp_wave<2,true,true,true,false,8> (one wave per user for the row recurrence + 7 helper waves for the feedback phases)", "instances/s"),

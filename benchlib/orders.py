@@ -148,7 +148,7 @@ def run_case(ctx, sa, name, a, device, cols, test, passes=2, window_extra=()):
     q_exact = score(tr)
     out["exact"] = {"value": m_exact / wall, "unit": unit, "ms_per_step": wall * 1e3, "build_s": round(build_s, 2), "conflict_free_levels": ds.num_batches,
                     "measured_on": "the whole stream" if m_exact == n else
-                                   "the first %d of the %d (a full pass would take ~%.0f s: conflict-free levels grow linearly with the stream, the rate does not)" % (m_exact, n, wall * n / m_exact),
+                                   "the first %d of the %d (a full pass would take ~%.3g s: conflict-free levels grow linearly with the stream, the rate does not)" % (m_exact, n, wall * n / m_exact),
                     "roofline": roof(ds.algorithmic_bytes, ev_ms, m_exact, "exact"),
                     "dag_bound": {"levels_per_pass": ds.num_batches, "unit_latency_us": lat, "bound_ms_per_pass": ds.num_batches * lat * 1e-3,
                                   "measured_over_bound": wall * 1e3 / max(ds.num_batches * lat * 1e-3, 1e-9)},
