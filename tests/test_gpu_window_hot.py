@@ -113,3 +113,32 @@ def test_the_hot_lane_keeps_the_accuracy_contract_on_skewed_items():
         out.append((float(np.sqrt(np.mean((p.astype(np.float64) - tl) ** 2))), ds.num_batches, ds.kind))
     assert out[1][2] == 8
     assert abs(out[1][0] - out[0][0]) <= 1e-4, out
+
+
+def test_random_shapes_against_the_checker():
+    """twenty random (users, items, ratings, width, sub-step, cap, passes) draws over Zipf items -- incl. windows without any hot item, sub-steps that do not
+    divide the slot counts, widths that are not a multiple of 4, caps below the sub-step (every item of a window hot) -- each equal to the checker bit for bit"""
+    rng = np.random.default_rng(2026)
+    for case in range(20):
+        nu, ni = int(rng.integers(50, 3000)), int(rng.integers(5, 400))
+        n = int(rng.integers(2000, 40000))
+        k = int(rng.choice([3, 8, 16, 24, 32, 64, 64, 100, 128, 200]))
+        sub = int(rng.choice([1, 3, 8, 16, 33, 64, 128]))
+        cap = int(sub * rng.choice([0.5, 1, 2, 7, 20]) + 1)
+        passes = int(rng.integers(1, 3))
+        u, i, r = cases.planted_triples(n, nu, ni, seed=1000 + case, zipf=bool(rng.integers(0, 4)))
+        extra = [("no_user_bias", "1")] if rng.integers(0, 5) == 0 else []
+        conf = cases.conf_with(cases.BASICMF_CONF, num_user=nu, num_item=ni, num_factor=k, learning_rate=0.002) + extra
+        t = _trainer(conf, 0, [("amd:step", "minibatch")], [("window_hot_sub", sub), ("window_hot_max", cap), ("window_per_target", 100000)])
+        ds = t.dataset_from_triples(u, i, r)
+        W = ds.num_batches
+        for _ in range(passes):
+            t.train_dataset(ds)
+        t.synchronize()
+        o = _oracle(conf, 0, u, i, r, W, sub, passes)
+        for name in NAMES:
+            a, b = t.view(name), o.view(name)
+            if a is None and b is None:
+                continue
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32)), (case, name, nu, ni, n, k, sub, cap, W)
+        t.close()
