@@ -81,9 +81,7 @@ Dataset *Engine::runs_dataset_from_triples(long n, const unsigned *user, const u
         du.push_back(DUCol{c_user.p + (size_t)j * (size_t)nunit, &ds->rn_user[j]});
         df.push_back(DFCol{c_label.p + (size_t)j * (size_t)nunit, &ds->rn_label[j]});
     }
-    // order inside a level: by item (1, default: the item rows of a level ascend in memory), by the run's first user (2), or by head position (0)
-    schedule_device_columns(ds.get(), nunit, 1 + R, res, off, limit, msg, sort_batches_ == 1 ? c_item.p : (sort_batches_ == 2 ? c_user.p : nullptr),
-                            sort_batches_ == 2 ? NU : NI, du, df);
+    schedule_device_columns(ds.get(), nunit, 1 + R, res, off, limit, msg, sort_batches_ == 1 ? c_item.p : nullptr, NI, du, df);
     ds->num_units = nunit;
     ds->algorithmic_bytes = n * (8L * mp_.num_factor * 2 + 8 * 2 + 16 + 8 * 2);
     return ds.release();
