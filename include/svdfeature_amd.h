@@ -309,7 +309,8 @@ int svdf_synchronize(svdf_trainer *t);
  * 18 / 19 dag bound and stream model in microseconds; 20 windows), 21 unused,
  * 22 / 23 passes over hot-row units / runs, 24 microseconds the schedule of the last user-unit data set took, 25 whether the device built it,
  * 26 data sets whose DEFAULT (exact) step drew the depth warning (a stderr line naming `amd:step = auto`: the level schedule predicts the pass
- * more than 10 x slower than the streaming model), 27 / 28 the last noted data set's dag bound / stream model in microseconds */
+ * more than 10 x slower than the streaming model), 27 / 28 the last noted data set's dag bound / stream model in microseconds,
+ * 29 passes over rank pairs walked as user-run units */
 int64_t svdf_counter(svdf_trainer *t, int what);
 /* Tuning knobs (not part of the reference surface).  None changes a result bit except the five marked (*), which move the windows of the
  * OPT-IN window step only.  Every knob, its default, what other values select (round 6: knobs no test or tool sets were deleted).
@@ -331,6 +332,9 @@ int64_t svdf_counter(svdf_trainer *t, int what);
  *     runs_exec           1      runs of an item's consecutive ratings as units (svdf_k_runs.hip); runs_len 4 (2..7), runs_sets 1, runs_block 64,
  *                                runs_min_rows 2^20 (smaller data sets keep one instance per lane group)
  *     pivot_exec          1      hot rows walked as units (svdf_pivot.cpp); pivot_min 2048 (ratings that make a row hot), pivot_run 256 (per unit)
+ *   schedule forms of rank pairs
+ *     pair_units          1      user-grouped pair streams (the generator's own order: a user's pairs back to back) walked as user-run units
+ *                                (svdf_punit.cpp: k_pair_units, the user's row in registers); pair_unit_cap 16 (pairs per unit at most)
  *   one-off builders on the device (0 = the host builder; same arrays / model)
  *     device_schedule 1 (device_schedule_min 2^16: smaller staged windows stay on the host), device_rank 1, device_init 1
  *     (device_init_margin_log2 46), device_window 1, device_load 1

@@ -194,6 +194,7 @@ int64_t Engine::counter(int what) const {
     case 26: return n_guard_warnings_;                            // data sets whose DEFAULT (exact) step was predicted > 10 x slower than the streaming model (note_dataset)
     case 27: return (int64_t)(guard_last_.dag_ms * 1000.0);       // ... the last noted data set's dag bound / stream model, microseconds
     case 28: return (int64_t)(guard_last_.stream_ms * 1000.0);
+    case 29: return n_punit_passes_;   // passes over rank pairs walked as user-run units (svdf_punit.cpp)
     case 21: return 0;   // (was: passes of the in-launch DAG executor, removed in round 6 -- DESIGN_APPENDIX.md section K)
     default: return -1;
     }
@@ -229,6 +230,8 @@ int Engine::set_knob(const char *name, long value) {
     if (!strcmp(name, "runs_sets")) { check(value >= 1 && value <= 2, "runs_sets must be 1 or 2"); runs_sets_ = (int)value; return 0; }
     if (!strcmp(name, "runs_block")) { check(value == 64 || value == 128 || value == 256, "runs_block must be 64, 128 or 256"); runs_block_ = (int)value; return 0; }
     if (!strcmp(name, "runs_min_rows")) { check(value >= 0, "runs_min_rows must not be negative"); runs_min_rows_ = value; return 0; }
+    if (!strcmp(name, "pair_units")) { check(value == 0 || value == 1, "pair_units must be 0 or 1"); pair_units_ = (int)value; return 0; }
+    if (!strcmp(name, "pair_unit_cap")) { check(value >= 1 && value <= 4096, "pair_unit_cap must be in 1 .. 4096"); pair_unit_cap_ = (int)value; return 0; }
     if (!strcmp(name, "pivot_exec")) { check(value == 0 || value == 1, "pivot_exec must be 0 or 1"); pivot_exec_ = (int)value; return 0; }
     if (!strcmp(name, "pivot_run")) { check(value >= 1 && value <= 65536, "pivot_run must be in 1 .. 65536"); pivot_run_ = (int)value; return 0; }
     if (!strcmp(name, "pivot_min")) { check(value >= 2, "pivot_min must be at least 2"); pivot_min_ = (int)value; return 0; }

@@ -237,6 +237,7 @@ Dataset *Engine::dataset_from_pairs(long n, const unsigned *user, const unsigned
         Dataset *exact = dataset_from_pairs(n, user, pos, neg);
         return auto_step(exact, wok, [&]() { return wseq_from_pairs(n, user, pos, neg); });
     }
+    if (Dataset *pu = punit_dataset_from_pairs(n, user, pos, neg)) return pu;   // a user-grouped stream (the generator's own order): user-run units (svdf_punit.cpp)
     if (device_sched_ && n > 0 && fused_allowed() && !user_group() && !relaxed()) {
         // everything on the device: the three columns go up as they are, the schedule columns (lower / higher item id, signs)
         // are formed there, ids are checked by the scheduling pass, pos == neg by the preparation kernel
@@ -566,7 +567,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
 static void auto_measures(const Dataset *ex, long &levels, double &unit_us, double &dag_ms, double &stream_ms, int pivot_run = 256) {
     levels = (long)ex->sched.num_levels();
     const long units = ex->kind == 3 || ex->kind == 4 ? std::max<long>(ex->num_units, 1) : std::max<long>(ex->num_row, 1);
-    unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : (ex->kind == 9 ? 5.0 + 0.3 * pivot_run : (ex->kind == 10 ? 6.0 : 4.5));   // kind 9: a level lasts as long as its longest run of a hot row's ratings
+    unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : (ex->kind == 9 ? 5.0 + 0.3 * pivot_run : (ex->kind == 10 ? 6.0 : (ex->kind == 11 ? 3.0 + 0.45 * (double)ex->num_row / (double)std::max<long>(ex->num_units, 1) : 4.5)));   // kind 9: a level lasts as long as its longest run of a hot row's ratings
     dag_ms = (double)levels * unit_us * 1e-3;
     stream_ms = (double)ex->algorithmic_bytes / (0.57 * 8.0e12) * 1e3;
 }
@@ -643,6 +644,8 @@ std::string Engine::path_for(const Dataset *ds) const {
     case 9: snprintf(buf, sizeof(buf), "exact, %ld levels: hot rows walked as units (k_svdpp_wave on %s parameters, %ld units) + cold ratings through the contract kernel",
                      L, ds->pv_item_pivot ? "transposed" : "plain", ds->num_units); return buf;
     case 10: snprintf(buf, sizeof(buf), "exact, %ld levels of runs: k_basicmf_runs_soa (up to %d consecutive ratings of one item per lane group, the item's row in registers)", L, ds->rn_len); return buf;
+    case 11: snprintf(buf, sizeof(buf), "exact, %ld levels of user-run units: k_pair_units (%ld units of up to %d consecutive pairs of one user, the user's row in registers)",
+                      L, ds->num_units, pair_unit_cap_); return buf;
     default: return "unknown";
     }
 }
@@ -652,7 +655,7 @@ void Engine::note_dataset(Dataset *ds) {
     if (verbose && !quiet) fprintf(stderr, "[svdfeature_amd] data set of %ld rows -> %s\n", (long)ds->num_row, path_for(ds).c_str());
     // the guard of the DEFAULT step: only level-scheduled (exact) data sets of a one-GPU handle; `amd:step` set = the caller has chosen
     if (step_auto_set_ || step_minibatch_set_ || multi_ || gpus_ != 1) return;
-    if (!(ds->kind == 0 || ds->kind == 1 || ds->kind == 2 || ds->kind == 3 || ds->kind == 4 || ds->kind == 9 || ds->kind == 10) || ds->num_row <= 0) return;
+    if (!(ds->kind == 0 || ds->kind == 1 || ds->kind == 2 || ds->kind == 3 || ds->kind == 4 || ds->kind == 9 || ds->kind == 10 || ds->kind == 11) || ds->num_row <= 0) return;
     AutoDecision D;
     double unit_us = 4.5;
     auto_measures(ds, D.levels, unit_us, D.dag_ms, D.stream_ms, pivot_run_);
@@ -719,6 +722,10 @@ void Engine::predict_dataset(Dataset *ds, float *out) {
         const UnitDev &d = ds->unitdev;
         const DevCSR D = d.csr();
         launch_svdpp_predict(P, D, d.units.p, d.fbidx.p, d.fbval.p, ds->num_units, w_out_.p, stream_);
+        HIPCHECK(hipMemcpyAsync(out, w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+        HIPCHECK(hipStreamSynchronize(stream_));
+    } else if (ds->kind == 11) {   // user-run units of rank pairs: columns in file order
+        punit_predict(ds, w_out_.p);
         HIPCHECK(hipMemcpyAsync(out, w_out_.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, stream_));
         HIPCHECK(hipStreamSynchronize(stream_));
     } else if (ds->kind == 10) {   // the columns of a runs data set are in file order: no permutation to undo
@@ -803,6 +810,10 @@ void Engine::eval_dataset(Dataset *ds, float scale, double *sum_sq, int64_t *cou
         BasicSchedule S{ds->user.p, ds->item.p, ds->label.p, ds->unit_values ? nullptr : ds->uval.p, ds->unit_values ? nullptr : ds->ival.p};
         launch_predict_basic(P, S, n, w_out_.p, stream_);
         labels = ds->label.p;   // same (level) order as the predictions
+    } else if (ds->kind == 11) {   // user-run units of rank pairs: every label is 1 (apex_svd_data.cpp:905-911)
+        punit_predict(ds, w_out_.p);
+        if (!ds->pu_one.p) { ds->pu_one.reserve((size_t)n); launch_runs_fill_u32(reinterpret_cast<unsigned *>(ds->pu_one.p), n, 0x3f800000u, stream_); }
+        labels = ds->pu_one.p;
     } else if (ds->kind == 2) {
         launch_predict_fused(P, ds->fused.view(), ds->fused.max_nu, ds->fused.max_ni, n, w_out_.p, stream_);
         labels = ds->fused.label.p;

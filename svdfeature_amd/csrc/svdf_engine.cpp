@@ -772,6 +772,12 @@ void Engine::train_dataset(Dataset *ds) {
         sample_counter_ += (unsigned)ds->num_row;
         return;
     }
+    if (ds->kind == 11) {   // user-run units of rank pairs (svdf_punit.cpp)
+        punit_train(ds);
+        n_instances_ += ds->num_row;
+        sample_counter_ += (unsigned)ds->num_row;
+        return;
+    }
     if (ds->kind == 10) {   // runs of an item's consecutive ratings (svdf_runs.cpp)
         check(runs_config_ok(), "train_dataset: the data set was built for the contract configuration's runs kernel (svdf_runs.cpp); the configuration changed since");
         runs_train(ds);

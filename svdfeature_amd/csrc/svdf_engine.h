@@ -239,6 +239,10 @@ struct Dataset {
     DevBuf<long> d_level_ptr;     // kind 2: the level boundaries in HBM, uploaded when a run of narrow levels is first chained (k_fewrow_slots_chain)
     bool d_level_ptr_ok = false;
     // kind 10: runs of an item's consecutive ratings (svdf_runs.cpp): level-sorted columns of the runs; user / item / label above stay in FILE order
+    // kind 11: user-run units of rank pairs (svdf_punit.cpp): pu_units in launch order (sched.level_ptr over units), pair columns in file order
+    DevBuf<PairUnit> pu_units;
+    DevBuf<unsigned> pu_lo, pu_hi;
+    DevBuf<float> pu_vlo, pu_one;
     DevBuf<unsigned> rn_item, rn_user[8];
     DevBuf<float> rn_label[8];
     int rn_len = 0;
@@ -644,6 +648,14 @@ class Engine {
     int pivot_run_ = 256, pivot_run_long_ = 256;   // knobs "pivot_run" / "pivot_run_long": ratings per unit at most, among cold levels / beyond them (a longer tail cap measured slower)
     int pivot_min_ = 2048;                // knob "pivot_min": a row with at least this many ratings in the data set is hot
     int64_t n_pivot_passes_ = 0;
+    // user-run units of rank pairs (svdf_punit.cpp; knob "pair_units", default on; "pair_unit_cap": pairs per unit at most)
+    int pair_units_ = 1, pair_unit_cap_ = 16;
+    int64_t n_punit_passes_ = 0;
+    bool punit_config_ok() const;
+    Dataset *punit_dataset_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg);
+    PairUnitSchedule punit_view(const Dataset *ds) const;
+    void punit_train(Dataset *ds);
+    void punit_predict(Dataset *ds, float *d_out);
     bool pivot_config_ok() const;
     Dataset *pivot_dataset_from_triples(long n, const unsigned *user, const unsigned *item, const float *label);
     void pivot_train(Dataset *ds);

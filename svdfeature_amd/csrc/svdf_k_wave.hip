@@ -975,4 +975,123 @@ void launch_wunit_wave(const DevParams &P, const WUnitSchedule &S, hipStream_t s
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------- user-run units of rank pairs (round 6)
+// One wave per unit (PairUnit): the user's row (and bias) in registers, the unit's pairs walked in file order -- update_inner (apex_svd_base.h:456-462) on
+// (user:1, {lower item: vlo, higher item: -vlo}, label 1) pair after pair: the arithmetic of k_window_users<., ., 2> / k_fewrow_slots in the chain layout.
+// The two item rows of the pairs PUF ahead are in flight while a pair is computed: the unit's item ids are pairwise distinct (the builder cuts a unit where
+// an id repeats) and no other unit of the level touches them, so a row fetched ahead cannot go stale.  PRED: scores only (out[pair], nothing written).
+constexpr int PUF = 4;
+// PLAIN: the demo configuration (sigmoid rank loss, L2 decay, no per-range decay): the switches over links and regularisers are compiled out of the chain.
+template <int NR, bool FULL, bool PRED, bool PLAIN>
+__device__ __forceinline__ void pair_unit_walk(const DevParams &P, const PairUnitSchedule &S, long idx, int lane, float *out) {
+    PairUnit u;
+    u.user = uniform_load(&S.units[idx].user); u.begin = uniform_load(&S.units[idx].begin); u.count = uniform_load(&S.units[idx].count); u.pad = 0;
+    const int pitch = P.pitch;
+    const int k = FULL ? 64 * NR : P.k;
+    const int kio = FULL ? -1 : P.k;
+    const bool ub = P.no_user_bias == 0;
+    const unsigned urow = P.user_off + u.user;
+    ChainRow<NR> p = chain_load<NR>(P.W, urow, pitch, lane, kio);
+    float bu = ub ? P.bias[urow] : 0.0f;
+    const float wd_u = PLAIN ? P.wd_user : get_wd(P.u_rng, u.user, P.wd_user);
+    const float lr = P.lr;
+    const float dec_u = 1.0f - lr * wd_u, dec_i = 1.0f - lr * P.wd_item;   // (PLAIN: chain_reg's method 0 with the row-invariant scalars hoisted)
+    struct Ahead { ChainRow<NR> ql, qh; float bl, bh, vl; unsigned rl, rh; };
+    Ahead cur[PUF], nxt[PUF];
+    auto fetch = [&](int j0, Ahead *a) {
+#pragma unroll
+        for (int c = 0; c < PUF; c++) {
+            const long t = (long)u.begin + min(j0 + c, u.count - 1);   // (past the end: the last pair again, fetched, never used)
+            a[c].rl = P.item_off + uniform_load(S.lo + t);
+            a[c].rh = P.item_off + uniform_load(S.hi + t);
+            a[c].vl = uniform_load(S.vlo + t);
+        }
+#pragma unroll
+        for (int c = 0; c < PUF; c++) {
+            a[c].ql = chain_load<NR>(P.W, a[c].rl, pitch, lane, kio);
+            a[c].qh = chain_load<NR>(P.W, a[c].rh, pitch, lane, kio);
+            a[c].bl = P.bias[a[c].rl];
+            a[c].bh = P.bias[a[c].rh];
+        }
+    };
+    fetch(0, cur);
+    for (int j0 = 0; j0 < u.count; j0 += PUF) {
+        if (j0 + PUF < u.count) fetch(j0 + PUF, nxt);
+#pragma unroll
+        for (int c = 0; c < PUF; c++) {
+            if (j0 + c < u.count) {
+                const Ahead &x = cur[c];
+                const float vl = x.vl, vh = -x.vl;
+                double bs = 0.0;                                   // calc_bias (:313-353); "+ 0.0": the svdpp / plugin hooks
+                if (ub) { bs += (double)(1.0f * bu); bs += 0.0; }
+                bs += 0.0;
+                bs += (double)(vl * x.bl);
+                bs += (double)(vh * x.bh);
+                double sum = (double)P.base_score + bs;
+                ChainRow<NR> tu = chain_zero<NR>(), ti = chain_zero<NR>();   // prepare_tmp (:354-381)
+                chain_axpy(tu, p, 1.0f);
+                chain_axpy(ti, x.ql, vl);
+                chain_axpy(ti, x.qh, vh);
+                sum += (double)chain_dot(tu, ti, lane, k);
+                const float pred = PLAIN ? (float)sum : map_active((float)sum, P.active_type);
+                if (PRED) {
+                    if (lane == 0) out[(long)u.begin + j0 + c] = pred;
+                } else {
+                    const float err = (PLAIN ? 1.0f - 1.0f / (1.0f + glibc_expf(-pred)) : cal_grad(1.0f, pred, P.active_type)) * 1.0f;
+                    const float su = lr * err * 1.0f;              // update_no_decay (:383-427) + regularize (:286-311)
+                    ChainRow<NR> wu = p;
+                    chain_axpy(wu, ti, su);
+                    float nbu = bu + su;
+                    if (PLAIN) chain_scale(wu, dec_u); else chain_reg(P, wu, wd_u, false, lane, k);
+                    nbu = nbu * (1.0f - lr * P.wd_user_bias);
+                    const float sl = lr * err * vl, sh = lr * err * vh;
+                    ChainRow<NR> wl = x.ql, wh = x.qh;
+                    chain_axpy(wl, tu, sl);
+                    chain_axpy(wh, tu, sh);
+                    float nbl = x.bl + sl, nbh = x.bh + sh;
+                    if (PLAIN) { chain_scale(wl, dec_i); chain_scale(wh, dec_i); }
+                    else {
+                        chain_reg(P, wl, get_wd(P.i_rng, x.rl - P.item_off, P.wd_item), true, lane, k);
+                        chain_reg(P, wh, get_wd(P.i_rng, x.rh - P.item_off, P.wd_item), true, lane, k);
+                    }
+                    nbl = nbl * (1.0f - lr * P.wd_item_bias);
+                    nbh = nbh * (1.0f - lr * P.wd_item_bias);
+                    chain_store<NR>(P.W, x.rl, pitch, lane, kio, wl);
+                    chain_store<NR>(P.W, x.rh, pitch, lane, kio, wh);
+                    if (lane == 0) { P.bias[x.rl] = nbl; P.bias[x.rh] = nbh; }
+                    p = wu;
+                    if (ub) bu = nbu;
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < PUF; c++) cur[c] = nxt[c];
+    }
+    if (!PRED) {
+        chain_store<NR>(P.W, urow, pitch, lane, kio, p);
+        if (ub && lane == 0) P.bias[urow] = bu;
+    }
+}
+template <int NR, bool FULL, bool PRED, bool PLAIN>
+__global__ __launch_bounds__(64) void k_pair_units(const DevParams P, const PairUnitSchedule S, long begin, long end, float *out) {
+    const long idx = begin + blockIdx.x;
+    if (idx < end) pair_unit_walk<NR, FULL, PRED, PLAIN>(P, S, idx, (int)threadIdx.x, out);
+}
+bool pair_units_applies(const DevParams &P) { return P.k >= 1 && P.k <= 256 && P.reg_method <= 3; }
+void launch_pair_units(const DevParams &P, const PairUnitSchedule &S, long begin, long end, float *out, hipStream_t st) {
+    if (end <= begin) return;
+    const int nr = (P.k + 63) / 64;
+    const bool full = P.k == 64 * nr;
+    const dim3 grid((unsigned)(end - begin)), block(64);
+    const bool plain = P.active_type == ACT_SIGMOID_RANK && P.reg_method == 0 && P.u_rng.n == 0 && P.i_rng.n == 0 && P.user_nonnegative == 0;
+#define PU_LAUNCH(NR_, FULL_) { if (out) hipLaunchKernelGGL((k_pair_units<NR_, FULL_, true, false>), grid, block, 0, st, P, S, begin, end, out); \
+                                else if (plain) hipLaunchKernelGGL((k_pair_units<NR_, FULL_, false, true>), grid, block, 0, st, P, S, begin, end, out); \
+                                else hipLaunchKernelGGL((k_pair_units<NR_, FULL_, false, false>), grid, block, 0, st, P, S, begin, end, out); }
+#define PU_BY_FULL(NR_) { if (full) PU_LAUNCH(NR_, true) else PU_LAUNCH(NR_, false) }
+    if (nr == 1) PU_BY_FULL(1) else if (nr == 2) PU_BY_FULL(2) else if (nr == 3) PU_BY_FULL(3) else PU_BY_FULL(4)
+#undef PU_BY_FULL
+#undef PU_LAUNCH
+}
+
 }  // namespace svdf

@@ -125,6 +125,9 @@ void launch_runs_form(const unsigned *ikeys, const unsigned *ipos, long n, unsig
                       unsigned char *idx, hipStream_t st);
 void launch_runs_fill(const unsigned *user, const unsigned *item, const float *label, long n, const unsigned *unit_at, const unsigned *head_of,
                       const unsigned char *idx, long nunit, unsigned *c_item, unsigned *c_user, float *c_label, hipStream_t st);
+// user-run units of rank pairs (svdf_k_wave.hip: k_pair_units); out != nullptr: scores only
+bool pair_units_applies(const DevParams &P);
+void launch_pair_units(const DevParams &P, const PairUnitSchedule &S, long begin, long end, float *out, hipStream_t st);
 void launch_runs_iota(unsigned *v, long n, hipStream_t st);
 void launch_runs_fill_u32(unsigned *v, long n, unsigned x, hipStream_t st);
 bool basicmf_runs_soa_applies(const DevParams &P);

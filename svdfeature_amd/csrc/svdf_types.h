@@ -122,6 +122,17 @@ struct RunSchedule {
     const float *label[8];
 };
 
+// USER-RUN UNITS of rank pairs (svdf_k_wave.hip: k_pair_units; svdf_punit.cpp; round 6): the reference's own pair order (apex_svd_data.cpp:946-965) emits a
+// user's pairs back to back.  A unit = up to `cap` CONSECUTIVE pairs of one user whose item ids are pairwise distinct; a wave keeps the user's row in
+// registers and walks the unit's pairs in file order.  Pair columns stay in FILE order: lo / hi = the lower / higher item id of the pair (the entry order of the
+// reference's merged row, :828-860), vlo = the sign of the lower entry (+1: it is the positive item), the higher entry carries -vlo; labels are 1.
+struct PairUnit { unsigned user; int begin; int count; int pad; };
+struct PairUnitSchedule {
+    const PairUnit *units;   // launch order: level by level
+    const unsigned *lo, *hi;
+    const float *vlo;
+};
+
 // One conflict-free batch of "few-row" instances for the fused kernel: at most 2 user ids and 2 item ids
 // per instance (slot value 0xFFFFFFFF = absent), any number of global features (CSR over the batch order),
 // no id repeated inside an instance.  Covers pairwise-rank pairs (nu=1, ni=2), neighbourhood rows

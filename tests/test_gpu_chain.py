@@ -27,6 +27,7 @@ def _run(cols, nu, ni, k, chain_width, passes=2, triples=False):
     t.init_trainer()
     t.set_knob("chain_width", chain_width)
     t.set_knob("pivot_exec", 0)   # (ratings with hot rows would otherwise be walked as units: svdf_pivot.cpp)
+    t.set_knob("pair_units", 0)   # (user-grouped pairs would otherwise be walked as user-run units: svdf_punit.cpp, tests/test_gpu_punit.py)
     ds = t.dataset_from_triples(*cols) if triples else t.dataset_from_pairs(*cols)
     for _ in range(passes):
         t.train_dataset(ds)
