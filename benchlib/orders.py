@@ -163,6 +163,11 @@ def run_case(ctx, sa, name, a, device, cols, test, passes=2, window_extra=()):
             "measured_over_chain_bound": wall * 1e3 / max(hot * 0.3e-3, 1e-9),
             "what": "kind 9 (hot rows walked as units): the pass cannot be shorter than the hottest row's sequential chain = its ratings x the walker's "
                     "per-rating step; measured_over_bound (levels x one instance's latency) does not apply to unit levels"})
+    if ds.kind == 11:
+        out["exact"]["dag_bound"]["what"] = ("kind 11 (user-run units of up to 16 consecutive pairs of one user, svdf_punit.cpp): a level is the walk of its longest unit (~0.7 us "
+                                             "per pair) plus a boundary, so levels x one instance's latency is not this schedule's bound; the DATA's bound is the pair-level "
+                                             "critical path: 0.28 n dependent steps x 0.43 us = 8.3 M pairs/s for any exact executor (DESIGN.md 2e)")
+        out["exact"]["path"] = "user-run units (k_pair_units)"
     ctx.log("orders %s exact: %d rows %.1f ms per pass = %.1f M %s (%.2f%% of peak), %d levels" % (
         name, m_exact, wall * 1e3, m_exact / wall / 1e6, unit, 100 * out["exact"]["roofline"]["frac"], ds.num_batches))
     ds.close()
