@@ -167,6 +167,7 @@ def run_case(ctx, sa, name, a, device, cols, test, passes=2, window_extra=()):
         out["exact"]["dag_bound"]["what"] = ("kind 11 (user-run units of up to 16 consecutive pairs of one user, svdf_punit.cpp): a level is the walk of its longest unit (~0.7 us "
                                              "per pair) plus a boundary, so levels x one instance's latency is not this schedule's bound; the DATA's bound is the pair-level "
                                              "critical path: 0.28 n dependent steps x 0.43 us = 8.3 M pairs/s for any exact executor (DESIGN.md 2e)")
+        out["exact"]["dag_bound"].pop("measured_over_bound", None)   # (levels here are unit levels: the ratio to one INSTANCE's latency says nothing)
         out["exact"]["path"] = "user-run units (k_pair_units)"
     ctx.log("orders %s exact: %d rows %.1f ms per pass = %.1f M %s (%.2f%% of peak), %d levels" % (
         name, m_exact, wall * 1e3, m_exact / wall / 1e6, unit, 100 * out["exact"]["roofline"]["frac"], ds.num_batches))
