@@ -653,6 +653,9 @@ class Engine {
     int64_t n_punit_passes_ = 0;
     bool punit_config_ok() const;
     Dataset *punit_dataset_from_pairs(long n, const unsigned *user, const unsigned *pos, const unsigned *neg);
+    bool punit_build(long n, const unsigned *user, const unsigned *lo, const unsigned *hi, std::vector<PairUnit> &sorted, std::vector<long> &level_ptr) const;
+    bool punit_flush(HostCSR &src);        // a staged window of user-grouped rank pairs (the per-instance route of the reference CLI)
+    DevBuf<PairUnit> w_pu_units_;
     PairUnitSchedule punit_view(const Dataset *ds) const;
     void punit_train(Dataset *ds);
     void punit_predict(Dataset *ds, float *d_out);

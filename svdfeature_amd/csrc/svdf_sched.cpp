@@ -106,6 +106,7 @@ void sort_batches(Schedule &sched, const unsigned *key) {
 void Engine::flush_csr(HostCSR &src) {
     const long n = src.num_row();
     if (n == 0) return;
+    if (punit_flush(src)) return;   // a window of user-grouped rank pairs: user-run units (svdf_punit.cpp)
     need_device("update");
     const DevParams &P = params();
     tracker_.resize(num_resources() + 1);

@@ -113,3 +113,41 @@ def test_bad_ids_raise_the_reference_messages():
     same = q.copy(); same[11] = p[11]
     with pytest.raises(sa.SvdfError, match="must differ"):
         t.dataset_from_pairs(u, p, same)
+
+
+def test_staged_windows_of_grouped_pairs_take_the_unit_walker_too():
+    """the per-instance route (svdf_update_csr / _batch: what the reference's CLI drives, svd_feature.cpp:220-248 with input_type = 2): a staged window whose
+    rows are all user-grouped rank pairs in the generator's shape is walked as user-run units at the flush; same bits as with the knob off; windows of any
+    other shape (a label that is not 1, a non-unit value) keep the level-by-level flush"""
+    nu, ni = 150, 900
+    cols = _grouped_pairs(nu, ni, 70, 77)
+    csr = sa.pairs_as_csr(*cols)
+    out = []
+    for units in (0, 1):
+        t = sa.Trainer(0, 3)
+        t.seed(10)
+        for kk, v in cases.conf_with(cases.PAIR_CONF, num_user=nu, num_item=ni, num_factor=128):
+            t.set_param(kk, str(v))
+        t.init_model()
+        t.init_trainer()
+        t.set_knob("pair_units", units)
+        t.set_knob("stage_window", 4000)        # several flushes per pass
+        for _ in range(2):
+            t.update_batch(csr)
+            t.finish_round()
+        out.append(({n: t.view(n).copy() for n in ("W_user", "W_item", "i_bias")}, t.counter(29), t.counter(3)))
+    assert out[0][1] == 0 and out[1][1] >= 2 and out[1][2] == out[0][2]
+    for n in out[0][0]:
+        assert np.array_equal(out[0][0][n].view(np.uint32), out[1][0][n].view(np.uint32)), n
+    # another shape in the window: the plain flush
+    d = sa.pairs_as_csr(*cols)
+    d.row_label[5] = 0.0
+    t = sa.Trainer(0, 3)
+    t.seed(10)
+    for kk, v in cases.conf_with(cases.PAIR_CONF, num_user=nu, num_item=ni, num_factor=128):
+        t.set_param(kk, str(v))
+    t.init_model()
+    t.init_trainer()
+    t.update_batch(d)
+    t.finish_round()
+    assert t.counter(29) == 0
