@@ -567,7 +567,7 @@ Dataset *Engine::dataset_from_csr(long num_row, const float *row_label, const in
 static void auto_measures(const Dataset *ex, long &levels, double &unit_us, double &dag_ms, double &stream_ms, int pivot_run = 256) {
     levels = (long)ex->sched.num_levels();
     const long units = ex->kind == 3 || ex->kind == 4 ? std::max<long>(ex->num_units, 1) : std::max<long>(ex->num_row, 1);
-    unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : (ex->kind == 9 ? 5.0 + 0.3 * pivot_run : (ex->kind == 10 ? 6.0 : (ex->kind == 11 ? 3.0 + 0.45 * (double)ex->num_row / (double)std::max<long>(ex->num_units, 1) : 4.5)));   // kind 9: a level lasts as long as its longest run of a hot row's ratings
+    unit_us = (ex->kind == 3 || ex->kind == 4) ? 5.0 + 0.42 * (double)ex->num_row / (double)units : (ex->kind == 9 ? 5.0 + 0.3 * pivot_run : (ex->kind == 10 ? 6.0 : (ex->kind == 11 ? 3.0 + 0.7 * (double)ex->num_row / (double)std::max<long>(ex->num_units, 1) : 4.5)));   // kind 9: a level lasts as long as its longest run of a hot row's ratings
     dag_ms = (double)levels * unit_us * 1e-3;
     stream_ms = (double)ex->algorithmic_bytes / (0.57 * 8.0e12) * 1e3;
 }
